@@ -1,0 +1,339 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/lance_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of lance_oracle.c.  Importable from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never from
+lance_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblance_oracle.so")
+
+L2, COSINE, DOT = 0, 1, 2
+NONE = 0xFFFFFFFF
+_METRICS = {"l2": L2, "L2": L2, "cosine": COSINE, "dot": DOT, 0: 0, 1: 1, 2: 2}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "lance_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liblance_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_l2_f32.restype = C.c_float
+        _lib.orc_l2_f16.restype = C.c_float
+        _lib.orc_l2_u8.restype = C.c_float
+        _lib.orc_dot_f32.restype = C.c_float
+        _lib.orc_dot_f16.restype = C.c_float
+        _lib.orc_norm_l2_f32.restype = C.c_float
+        _lib.orc_cosine_f32.restype = C.c_float
+        _lib.orc_cosine_f32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_size_t]
+        _lib.orc_f16_to_f32.restype = C.c_float
+        _lib.orc_f32_to_f16.restype = C.c_uint16
+        _lib.orc_f32_to_f16.argtypes = [C.c_float]
+        _lib.orc_heap_topk.restype = C.c_size_t
+        _lib.orc_sort_fetch.restype = C.c_size_t
+        _lib.orc_partition_layout.restype = C.c_size_t
+        _lib.orc_kmeans_train_f32.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _m(metric):
+    return _METRICS[metric]
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+# ---- distances ---------------------------------------------------------------
+def l2(x, y):
+    x = np.ascontiguousarray(x); y = np.ascontiguousarray(y)
+    if x.dtype == np.float16:
+        return float(lib().orc_l2_f16(_p(x.view(np.uint16)), _p(y.view(np.uint16)), C.c_size_t(x.size)))
+    if x.dtype == np.uint8:
+        return float(lib().orc_l2_u8(_p(x), _p(y), C.c_size_t(x.size)))
+    x = _f32(x); y = _f32(y)
+    return float(lib().orc_l2_f32(_p(x), _p(y), C.c_size_t(x.size)))
+
+
+def dot(x, y):
+    x = np.ascontiguousarray(x); y = np.ascontiguousarray(y)
+    if x.dtype == np.float16:
+        return float(lib().orc_dot_f16(_p(x.view(np.uint16)), _p(y.view(np.uint16)), C.c_size_t(x.size)))
+    x = _f32(x); y = _f32(y)
+    return float(lib().orc_dot_f32(_p(x), _p(y), C.c_size_t(x.size)))
+
+
+def norm_l2(x):
+    x = _f32(x)
+    return float(lib().orc_norm_l2_f32(_p(x), C.c_size_t(x.size)))
+
+
+def cosine(x, y):
+    x = _f32(x); y = _f32(y)
+    return float(lib().orc_cosine_f32(_p(x), C.c_float(norm_l2(x)), _p(y), C.c_size_t(x.size)))
+
+
+def distance_batch(metric, q, x):
+    q = _f32(q); x = _f32(x)
+    n, d = x.shape
+    out = np.empty(n, np.float32)
+    lib().orc_distance_batch_f32(_m(metric), _p(q), _p(x), C.c_size_t(n), C.c_size_t(d), _p(out))
+    return out
+
+
+def normalize(x):
+    x = _f32(x)
+    x2 = x.reshape(-1, x.shape[-1])
+    out = np.empty_like(x2)
+    lib().orc_normalize_f32(_p(x2), C.c_size_t(x2.shape[0]), C.c_size_t(x2.shape[1]), _p(out))
+    return out.reshape(x.shape)
+
+
+def is_finite(x):
+    x = _f32(x)
+    out = np.empty(x.shape[0], np.uint8)
+    lib().orc_is_finite_f32(_p(x), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]), _p(out))
+    return out.astype(bool)
+
+
+# ---- assignment / k-means ------------------------------------------------------
+def assign(x, centroids, metric="l2", bias=None):
+    """-> (ids u32 [NONE = no partition], dists f32)"""
+    x = np.ascontiguousarray(x); centroids = np.ascontiguousarray(centroids)
+    n, d = x.shape
+    k = centroids.shape[0]
+    ids = np.empty(n, np.uint32); dists = np.empty(n, np.float32)
+    if x.dtype == np.float16:
+        assert bias is None
+        lib().orc_assign_f16(_m(metric), _p(x.view(np.uint16)), C.c_size_t(n), C.c_size_t(d),
+                             _p(centroids.astype(np.float16).view(np.uint16)), C.c_size_t(k), _p(ids), _p(dists))
+        return ids, dists
+    x = _f32(x); centroids = _f32(centroids)
+    b = None if bias is None else _f32(bias)
+    lib().orc_assign_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(centroids), C.c_size_t(k),
+                         _p(b), _p(ids), _p(dists))
+    return ids, dists
+
+
+def kmeans_init_indices(n, k, seed):
+    out = np.empty(k, np.uint64)
+    lib().orc_kmeans_init_indices(C.c_uint64(n), C.c_uint32(k), C.c_uint64(seed), _p(out))
+    return out
+
+
+def kmeans_train(x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2"):
+    """KMeans::train_kmeans on exactly the rows given (caller applies caps).
+    -> (centroids [k,d], loss, iters, cluster_sizes)"""
+    x = _f32(x)
+    n, d = x.shape
+    cent = np.empty((k, d), np.float32)
+    loss = C.c_double(0)
+    sizes = np.empty(k, np.uint64)
+    init_a = None if init is None else _f32(init)
+    it = lib().orc_kmeans_train_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(k),
+                                    C.c_uint32(max_iters), C.c_double(tol), C.c_float(balance_factor),
+                                    _p(init_a), C.c_uint64(seed), _p(cent), C.byref(loss), _p(sizes))
+    return cent, loss.value, int(it), sizes
+
+
+def residual(x, centroids, part_ids):
+    x = _f32(x); centroids = _f32(centroids)
+    part_ids = np.ascontiguousarray(part_ids, np.uint32)
+    out = np.empty_like(x)
+    lib().orc_residual_f32(_p(x), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]), _p(centroids), _p(part_ids), _p(out))
+    return out
+
+
+def divide_to_subvectors(x, m):
+    x = _f32(x)
+    n, d = x.shape
+    out = np.empty((m, n, d // m), np.float32)
+    lib().orc_divide_to_subvectors_f32(_p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(m), _p(out))
+    return out
+
+
+def pq_train(resid, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
+    resid = _f32(resid)
+    n, d = resid.shape
+    kc = 1 << nbits
+    cb = np.empty((m, kc, d // m), np.float32)
+    iters = np.zeros(m, np.int32)
+    lib().orc_pq_train_f32(_p(resid), C.c_size_t(n), C.c_size_t(d), C.c_size_t(m), C.c_uint32(nbits),
+                           C.c_uint32(max_iters), C.c_size_t(sample_rate), C.c_uint64(seed), _p(cb), _p(iters))
+    return cb, iters
+
+
+def pq_encode(x, codebook, metric="l2", nbits=8):
+    x = _f32(x); codebook = _f32(codebook)
+    n, d = x.shape
+    m = codebook.shape[0]
+    if nbits == 4:
+        codes = np.empty((n, m // 2), np.uint8)
+        lib().orc_pq_encode4_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(codebook), C.c_size_t(m), _p(codes))
+        return codes
+    codes = np.empty((n, m), np.uint8)
+    lib().orc_pq_encode_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(codebook), C.c_size_t(m),
+                            C.c_uint32(nbits), _p(codes))
+    return codes
+
+
+def transpose(codes):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, m = codes.shape
+    out = np.empty((m, n), np.uint8)
+    lib().orc_transpose_u8(_p(codes), C.c_size_t(n), C.c_size_t(m), _p(out))
+    return out
+
+
+def build_lut(q, codebook, metric="l2", nbits=8):
+    q = _f32(q); codebook = _f32(codebook)
+    m = codebook.shape[0]
+    lut = np.empty((m, 1 << nbits), np.float32)
+    lib().orc_build_lut_f32(_m(metric), _p(q), C.c_size_t(q.size), _p(codebook), C.c_size_t(m), C.c_uint32(nbits), _p(lut))
+    return lut
+
+
+def pq_scan(lut, codes_t, metric="l2"):
+    lut = _f32(lut); codes_t = np.ascontiguousarray(codes_t, np.uint8)
+    m, n_p = codes_t.shape
+    out = np.empty(n_p, np.float32)
+    lib().orc_pq_scan_f32(_m(metric), _p(lut), C.c_size_t(m), _p(codes_t), C.c_size_t(n_p), _p(out))
+    return out
+
+
+def pq_scan_rowmajor(lut, codes):
+    lut = _f32(lut); codes = np.ascontiguousarray(codes, np.uint8)
+    n_p, m = codes.shape
+    out = np.empty(n_p, np.float32)
+    lib().orc_pq_scan_rowmajor_f32(_p(lut), C.c_size_t(m), _p(codes), C.c_size_t(n_p), _p(out))
+    return out
+
+
+def heap_topk(dists, row_ids, k, lower=None, upper=None):
+    dists = _f32(dists); row_ids = np.ascontiguousarray(row_ids, np.uint64)
+    out_i = np.empty(max(k, 1), np.uint64); out_d = np.empty(max(k, 1), np.float32)
+    has = lower is not None or upper is not None
+    lo = np.float32(np.finfo(np.float32).min if lower is None else lower)
+    hi = np.float32(np.finfo(np.float32).max if upper is None else upper)
+    c = lib().orc_heap_topk(_p(dists), _p(row_ids), C.c_size_t(dists.size), C.c_size_t(k), C.c_int(int(has)),
+                            C.c_float(lo), C.c_float(hi), _p(out_i), _p(out_d))
+    return out_i[:c].copy(), out_d[:c].copy()
+
+
+def sort_fetch(ids, dists, k):
+    ids = np.array(ids, np.uint64); dists = np.array(dists, np.float32)
+    c = lib().orc_sort_fetch(_p(ids), _p(dists), C.c_size_t(ids.size), C.c_size_t(k))
+    return ids[:c].copy(), dists[:c].copy()
+
+
+def find_partitions(q, centroids, nprobes, metric="l2"):
+    q = _f32(q).reshape(-1, centroids.shape[1]); centroids = _f32(centroids)
+    nq, d = q.shape
+    nlist = centroids.shape[0]
+    nprobes = min(nprobes, nlist)
+    ids = np.empty((nq, nprobes), np.uint32); dists = np.empty((nq, nprobes), np.float32)
+    lib().orc_find_partitions_f32(_m(metric), _p(q), C.c_size_t(nq), C.c_size_t(d), _p(centroids), C.c_size_t(nlist),
+                                  C.c_size_t(nprobes), _p(ids), _p(dists))
+    return ids, dists
+
+
+def flat_knn(x, q, k, metric="l2", row_ids=None):
+    x = _f32(x); q = _f32(q).reshape(-1, x.shape[1])
+    n, d = x.shape
+    nq = q.shape[0]
+    rid = None if row_ids is None else np.ascontiguousarray(row_ids, np.uint64)
+    ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
+    lib().orc_flat_knn_f32(_m(metric), _p(x), _p(rid), C.c_size_t(n), C.c_size_t(d), _p(q), C.c_size_t(nq),
+                           C.c_size_t(k), _p(ids), _p(dists))
+    return ids, dists
+
+
+def partition_layout(part_ids, nlist):
+    part_ids = np.ascontiguousarray(part_ids, np.uint32)
+    n = part_ids.size
+    offs = np.empty(nlist + 1, np.uint32); perm = np.empty(n, np.uint32)
+    tot = lib().orc_partition_layout(_p(part_ids), C.c_size_t(n), C.c_size_t(nlist), _p(offs), _p(perm))
+    return offs, perm[:tot].copy()
+
+
+class IvfPqIndex:
+    """Canonical CPU index (reference layout: per-partition transposed codes)."""
+
+    def __init__(self, metric, centroids, codebook, part_offsets, codes_t, row_ids):
+        self.metric = _m(metric)
+        self.centroids = _f32(centroids)
+        self.codebook = _f32(codebook)
+        self.part_offsets = np.ascontiguousarray(part_offsets, np.uint32)
+        self.codes_t = np.ascontiguousarray(codes_t, np.uint8)
+        self.row_ids = np.ascontiguousarray(row_ids, np.uint64)
+
+    def search(self, queries, k, nprobes, refine=0, raw=None):
+        q = _f32(queries).reshape(-1, self.centroids.shape[1])
+        nq, d = q.shape
+        ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
+        r = None if raw is None else _f32(raw)
+        lib().orc_ivfpq_search_f32(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
+                                   _p(self.codebook), C.c_size_t(self.codebook.shape[0]), _p(self.part_offsets),
+                                   _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq), C.c_size_t(k),
+                                   C.c_size_t(nprobes), C.c_size_t(refine), _p(r), _p(ids), _p(dists))
+        return ids, dists
+
+
+def build_index(x, centroids, codebook, metric="l2", row_ids=None):
+    """Transform chain of lance-index ivf.rs:188-236 + per-partition storage
+    (builder.rs:685-846) in canonical stable row order:
+    [normalise if cosine] -> keep finite -> assign -> residual (L2/cosine) -> PQ encode
+    -> group by partition -> transpose each partition's codes."""
+    x = _f32(x)
+    m = _m(metric)
+    if row_ids is None:
+        row_ids = np.arange(x.shape[0], dtype=np.uint64)
+    row_ids = np.asarray(row_ids, np.uint64)
+    xs = normalize(x) if m == COSINE else x
+    keep = is_finite(xs)
+    xs = xs[keep]; rid = row_ids[keep]
+    sm = L2 if m == COSINE else m
+    part, _ = assign(xs, centroids, sm)
+    res = residual(xs, centroids, np.where(part == NONE, 0, part)) if sm == L2 else xs
+    codes = pq_encode(res, codebook, sm)
+    nlist = centroids.shape[0]
+    offs, perm = partition_layout(part, nlist)
+    codes_sorted = codes[perm]
+    mm = codes.shape[1]
+    codes_t = np.empty(codes_sorted.size, np.uint8)
+    for p in range(nlist):
+        a, b = int(offs[p]), int(offs[p + 1])
+        if b > a:
+            codes_t[a * mm:b * mm] = transpose(codes_sorted[a:b]).ravel()
+    idx = IvfPqIndex(m, centroids, codebook, offs, codes_t, rid[perm])
+    idx.part_ids = part
+    idx.codes_rowmajor = codes
+    idx.perm = perm
+    return idx

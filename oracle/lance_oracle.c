@@ -1,0 +1,900 @@
+/*
+ * lance_oracle.c -- CPU restatement of the reference's IVF-PQ hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the timed CPU baseline.  The product path
+ * (lance_amd/, liblance_hip.so) never links or calls it.
+ *
+ * Every function restates, operation for operation, the arithmetic of the cited
+ * reference source (paths relative to /root/reference).  Compile with
+ *   gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp
+ * (-ffp-contract=off matters: the reference is plain Rust, which never contracts
+ * a*b+c into an fma; gcc would with -march=native).
+ *
+ * Parity pins: tests/test_oracle_golden.py transcribes the reference's own
+ * known-answer tests (l2.rs:281-375,432-447; dot.rs; kernels.rs:278-300;
+ * kmeans.rs:1398-1486; pq.rs:580-665; pq/distance.rs:337-364; pq/utils.rs:84-99).
+ *
+ * Not pinned by any reference test (reference is OS-seeded, kmeans.rs:181,646):
+ * the RNG stream used for k-means initialisation and empty-cluster splitting.
+ * The oracle and the product share the RNG specified below (xoshiro256++ seeded
+ * by splitmix64); given the same seed both must produce bit-identical centroids.
+ *
+ * Third-party algorithms restated here (not vendored in /root/reference):
+ *   - Rust std 1.90.0 (rust-toolchain.toml) alloc::collections::BinaryHeap
+ *     push / pop (sift_up, sift_down_to_bottom) -- used by FlatIndex::search
+ *     (rust/lance-index/src/vector/flat/index.rs:94-126); determines which of
+ *     several equal-distance rows survive in a full heap.
+ *   - rand 0.9 IteratorRandom::choose_multiple (reservoir) shape for
+ *     kmeans_random_init (kmeans.rs:149-170); stream itself is unpinned.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_L2 0
+#define ORC_COSINE 1
+#define ORC_DOT 2
+#define ORC_NONE 0xFFFFFFFFu
+
+/* ------------------------------------------------------------------------- */
+/* f16 <-> f32 (IEEE binary16, the `half` crate's f16::to_f32 is exact).       */
+static inline float orc_h2f(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu;
+  uint32_t man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else { /* subnormal */
+      int e = -1;
+      do { man <<= 1; e++; } while ((man & 0x400u) == 0);
+      man &= 0x3ffu;
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7f800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+/* round-to-nearest-even f32 -> f16 (half crate f16::from_f32). */
+static inline uint16_t orc_f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t exp = (x >> 23) & 0xffu;
+  uint32_t man = x & 0x7fffffu;
+  if (exp == 255) return (uint16_t)(sign | 0x7c00u | (man ? (0x200u | (man >> 13)) : 0));
+  int32_t e = (int32_t)exp - 127 + 15;
+  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  if (e <= 0) {
+    if (e < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    uint32_t shift = (uint32_t)(14 - e);
+    uint32_t hm = man >> shift;
+    uint32_t rem = man & ((1u << shift) - 1);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hm & 1))) hm++;
+    return (uint16_t)(sign | hm);
+  }
+  uint32_t hm = man >> 13;
+  uint32_t rem = man & 0x1fffu;
+  uint16_t h = (uint16_t)(sign | ((uint32_t)e << 10) | hm);
+  if (rem > 0x1000u || (rem == 0x1000u && (hm & 1))) h++;
+  return h;
+}
+
+uint16_t orc_f32_to_f16(float f) { return orc_f2h(f); }
+float orc_f16_to_f32(uint16_t h) { return orc_h2f(h); }
+
+/* ------------------------------------------------------------------------- */
+/* a1: l2_scalar<T,f32,16>  rust/lance-linalg/src/distance/l2.rs:57-91,161-168
+ * remainder (len % 16) summed sequentially first; 16 lane accumulators over full
+ * chunks; result = s + (((0 + sums[0]) + sums[1]) + ... + sums[15]).           */
+float orc_l2_f32(const float *x, const float *y, size_t d) {
+  const size_t LANES = 16;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f; /* iter().sum::<f32>() */
+    for (size_t i = full; i < d; i++) {
+      float diff = x[i] - y[i];
+      acc = acc + diff * diff;
+    }
+    s = acc;
+  }
+  float sums[16];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) {
+      float diff = x[c + i] - y[c + i];
+      sums[i] += diff * diff;
+    }
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return s + tot;
+}
+
+/* f16 data: each element widened to f32 (`as_()`), l2_scalar<f16,f32,16>
+ * l2.rs:128-159 (the non-fp16kernels fallback arm).                           */
+float orc_l2_f16(const uint16_t *x, const uint16_t *y, size_t d) {
+  const size_t LANES = 16;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (size_t i = full; i < d; i++) {
+      float diff = orc_h2f(x[i]) - orc_h2f(y[i]);
+      acc = acc + diff * diff;
+    }
+    s = acc;
+  }
+  float sums[16];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) {
+      float diff = orc_h2f(x[c + i]) - orc_h2f(y[c + i]);
+      sums[i] += diff * diff;
+    }
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return s + tot;
+}
+
+/* l2_distance_uint_scalar  l2.rs:44-49 */
+float orc_l2_u8(const uint8_t *x, const uint8_t *y, size_t d) {
+  uint32_t acc = 0;
+  for (size_t i = 0; i < d; i++) {
+    uint32_t a = x[i] > y[i] ? (uint32_t)(x[i] - y[i]) : (uint32_t)(y[i] - x[i]);
+    acc += a * a;
+  }
+  return (float)acc;
+}
+
+/* a2: dot_scalar<f32,f32,16>  dot.rs:30-58; dot_distance = 1 - dot  dot.rs:68-70 */
+float orc_dot_f32(const float *x, const float *y, size_t d) {
+  const size_t LANES = 16;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (size_t i = full; i < d; i++) acc = acc + x[i] * y[i];
+    s = acc;
+  }
+  float sums[16];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) sums[i] += x[c + i] * y[c + i];
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return s + tot;
+}
+
+/* dot_scalar<f16,f32,32>  dot.rs:138-161 (32 lanes for f16) */
+float orc_dot_f16(const uint16_t *x, const uint16_t *y, size_t d) {
+  const size_t LANES = 32;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (size_t i = full; i < d; i++) acc = acc + orc_h2f(x[i]) * orc_h2f(y[i]);
+    s = acc;
+  }
+  float sums[32];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) sums[i] += orc_h2f(x[c + i]) * orc_h2f(y[c + i]);
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return s + tot;
+}
+
+float orc_dot_distance_f32(const float *x, const float *y, size_t d) {
+  return 1.0f - orc_dot_f32(x, y, d);
+}
+
+/* norm_l2_impl<f32,f32,16>  norm_l2.rs:106-129 */
+float orc_norm_l2_f32(const float *x, size_t d) {
+  const size_t LANES = 16;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (size_t i = full; i < d; i++) acc = acc + x[i] * x[i];
+    s = acc;
+  }
+  float sums[16];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) sums[i] += x[c + i] * x[c + i];
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return sqrtf(s + tot);
+}
+
+/* f32x8::reduce_sum, x86_64 AVX2 arm  simd/f32.rs:203-218:
+ * ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7))                                        */
+static inline float orc_reduce8(const float *a) {
+  float s0 = a[0] + a[4], s1 = a[1] + a[5], s2 = a[2] + a[6], s3 = a[3] + a[7];
+  return (s0 + s2) + (s1 + s3);
+}
+
+/* a3: Cosine for f32::cosine_fast  cosine.rs:143-175 on the default x86_64 build
+ * (target-cpu=haswell: f32x16 = 2 x __m256, multiply_add = vfmadd, reduce_sum
+ * simd/f32.rs:625-644; .cargo/config.toml:12-13).  x_norm = norm_l2(x).
+ * Used only by the flat cosine scan (un-indexed KNN / refine of a cosine index). */
+float orc_cosine_f32(const float *x, float x_norm, const float *y, size_t d) {
+  size_t unrolled = d / 16 * 16, aligned = d / 8 * 8;
+  float xy16[16], yn16[16], xy8[8], yn8[8];
+  for (int i = 0; i < 16; i++) { xy16[i] = 0.0f; yn16[i] = 0.0f; }
+  for (int i = 0; i < 8; i++) { xy8[i] = 0.0f; yn8[i] = 0.0f; }
+  for (size_t c = 0; c < unrolled; c += 16)
+    for (int i = 0; i < 16; i++) {
+      xy16[i] = fmaf(x[c + i], y[c + i], xy16[i]);
+      yn16[i] = fmaf(y[c + i], y[c + i], yn16[i]);
+    }
+  for (size_t c = unrolled; c < aligned; c += 8)
+    for (int i = 0; i < 8; i++) {
+      xy8[i] = fmaf(x[c + i], y[c + i], xy8[i]);
+      yn8[i] = fmaf(y[c + i], y[c + i], yn8[i]);
+    }
+  float t16[8], u16[8];
+  for (int i = 0; i < 8; i++) { t16[i] = xy16[i] + xy16[i + 8]; u16[i] = yn16[i] + yn16[i + 8]; }
+  float nrest = orc_norm_l2_f32(y + aligned, d - aligned);
+  float y_norm = orc_reduce8(u16) + orc_reduce8(yn8) + nrest * nrest;
+  float xy = orc_reduce8(t16) + orc_reduce8(xy8) + orc_dot_f32(x + aligned, y + aligned, d - aligned);
+  return 1.0f - xy / x_norm / sqrtf(y_norm);
+}
+
+/* a4: normalize  kernels.rs:141-146 -- l2_norm = sqrt(sequential sum of x^2 in T) */
+void orc_normalize_f32(const float *x, size_t n, size_t d, float *out) {
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++) {
+    const float *v = x + r * d;
+    float acc = 0.0f;
+    for (size_t i = 0; i < d; i++) acc = acc + v[i] * v[i];
+    float norm = sqrtf(acc);
+    for (size_t i = 0; i < d; i++) out[r * d + i] = v[i] / norm;
+  }
+}
+
+/* utils.rs:263-286 is_finite: 1 if every element finite */
+void orc_is_finite_f32(const float *x, size_t n, size_t d, uint8_t *out) {
+  for (size_t r = 0; r < n; r++) {
+    uint8_t ok = 1;
+    for (size_t i = 0; i < d; i++)
+      if (!isfinite(x[r * d + i])) { ok = 0; break; }
+    out[r] = ok;
+  }
+}
+
+static inline float orc_dist(int metric, const float *x, const float *y, size_t d) {
+  return metric == ORC_DOT ? orc_dot_distance_f32(x, y, d) : orc_l2_f32(x, y, d);
+}
+
+/* DistanceType::func / arrow_batch_func  distance.rs:56-75 for the flat scan */
+void orc_distance_batch_f32(int metric, const float *q, const float *x, size_t n, size_t d,
+                            float *out) {
+  float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q, d) : 0.0f;
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++)
+    out[r] = metric == ORC_COSINE ? orc_cosine_f32(q, qn, x + r * d, d) : orc_dist(metric, q, x + r * d, d);
+}
+
+/* ------------------------------------------------------------------------- */
+/* a5: argmin_value_float / argmin_value_float_with_bias  kernels.rs:79-111
+ * strict '<' against +inf start: NaN and +inf are never selected; all such -> None.
+ * Returns 1 if found.                                                          */
+static inline int orc_argmin_row(int metric, const float *v, const float *cent, size_t k,
+                                 size_t d, const float *bias, uint32_t *id, float *dist) {
+  int found = 0;
+  uint32_t min_idx = 0;
+  float min_value = INFINITY, min_orig = INFINITY;
+  if (bias == NULL) {
+    for (size_t c = 0; c < k; c++) {
+      float value = orc_dist(metric, v, cent + c * d, d);
+      if (value < min_value) { min_value = value; min_idx = (uint32_t)c; found = 1; }
+    }
+    min_orig = min_value;
+  } else {
+    for (size_t c = 0; c < k; c++) {
+      float value = orc_dist(metric, v, cent + c * d, d);
+      float vb = value + bias[c];
+      if (vb < min_value) { min_value = vb; min_orig = value; min_idx = (uint32_t)c; found = 1; }
+    }
+  }
+  *id = found ? min_idx : ORC_NONE;
+  *dist = min_orig;
+  return found;
+}
+
+/* a6/a9: compute_membership_and_dist  kmeans.rs:317-369 ; compute_partition :1350 */
+void orc_assign_f32(int metric, const float *x, size_t n, size_t d, const float *cent, size_t k,
+                    const float *bias, uint32_t *ids, float *dists) {
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++) {
+    uint32_t id; float dist;
+    orc_argmin_row(metric, x + r * d, cent, k, d, bias, &id, &dist);
+    ids[r] = id;
+    if (dists) dists[r] = dist;
+  }
+}
+
+/* f16 data + f16 centroids (KMeansAlgoFloat<Float16Type>) */
+void orc_assign_f16(int metric, const uint16_t *x, size_t n, size_t d, const uint16_t *cent,
+                    size_t k, uint32_t *ids, float *dists) {
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++) {
+    int found = 0; uint32_t mi = 0; float mv = INFINITY;
+    for (size_t c = 0; c < k; c++) {
+      float value = metric == ORC_DOT ? 1.0f - orc_dot_f16(x + r * d, cent + c * d, d)
+                                      : orc_l2_f16(x + r * d, cent + c * d, d);
+      if (value < mv) { mv = value; mi = (uint32_t)c; found = 1; }
+    }
+    ids[r] = found ? mi : ORC_NONE;
+    if (dists) dists[r] = mv;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* RNG shared by oracle and product: xoshiro256++ seeded with splitmix64.
+ * (The reference seeds SmallRng from the OS: kmeans.rs:181,646 -- unpinned.)   */
+typedef struct { uint64_t s[4]; } orc_rng;
+static inline uint64_t orc_splitmix(uint64_t *x) {
+  uint64_t z = (*x += 0x9e3779b97f4a7c15ULL);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+static inline void orc_rng_seed(orc_rng *r, uint64_t seed) {
+  for (int i = 0; i < 4; i++) r->s[i] = orc_splitmix(&seed);
+}
+static inline uint64_t orc_rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t orc_rng_next(orc_rng *r) {
+  uint64_t *s = r->s;
+  uint64_t result = orc_rotl(s[0] + s[3], 23) + s[0];
+  uint64_t t = s[1] << 17;
+  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+  s[2] ^= t; s[3] = orc_rotl(s[3], 45);
+  return result;
+}
+/* uniform f32 in [0,1): top 24 bits */
+static inline float orc_rng_f32(orc_rng *r) {
+  return (float)(orc_rng_next(r) >> 40) * (1.0f / 16777216.0f);
+}
+/* uniform integer in [0, n] inclusive (n < 2^63), by rejection on the top bits */
+static inline uint64_t orc_rng_upto(orc_rng *r, uint64_t n) {
+  uint64_t range = n + 1;
+  uint64_t mask = range - 1;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
+  mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+  for (;;) {
+    uint64_t v = orc_rng_next(r) & mask;
+    if (v < range) return v;
+  }
+}
+
+/* kmeans_random_init  kmeans.rs:149-170: (0..n).choose_multiple(rng, k) --
+ * reservoir: first k indices, then for i >= k draw j in [0,i], replace if j < k. */
+void orc_kmeans_init_indices(uint64_t n, uint32_t k, uint64_t seed, uint64_t *out) {
+  orc_rng r; orc_rng_seed(&r, seed);
+  for (uint64_t i = 0; i < k; i++) out[i] = i;
+  for (uint64_t i = k; i < n; i++) {
+    uint64_t j = orc_rng_upto(&r, i);
+    if (j < k) out[j] = i;
+  }
+}
+
+/* split_clusters  kmeans.rs:174-207 (f32) */
+static void orc_split_clusters(size_t n, uint64_t *cnts, size_t k, float *centroids, size_t dim,
+                               orc_rng *rng) {
+  const float eps = 1.0f / 1024.0f;
+  for (size_t i = 0; i < k; i++) {
+    if (cnts[i] == 0) {
+      size_t j = 0;
+      for (;;) {
+        float p = ((float)cnts[j] - 1.0f) / (float)(n - k);
+        if (orc_rng_f32(rng) < p) break;
+        j += 1;
+        j %= k;
+      }
+      cnts[i] = cnts[j] / 2;
+      cnts[j] -= cnts[i];
+      for (size_t t = 0; t < dim; t++) {
+        if (t % 2 == 0) {
+          centroids[i * dim + t] = centroids[j * dim + t] * (1.0f + eps);
+          centroids[j * dim + t] *= 1.0f - eps;
+        } else {
+          centroids[i * dim + t] = centroids[j * dim + t] * (1.0f - eps);
+          centroids[j * dim + t] *= 1.0f + eps;
+        }
+      }
+    }
+  }
+}
+
+/* a7/a8: KMeans::train_kmeans  kmeans.rs:610-719 with
+ *   compute_membership_and_loss :250-281, compute_cluster_sizes :210-232,
+ *   compute_balance_loss :234-237, to_kmeans :371-446, split_clusters :174-207.
+ * `balance_factor` is the already-scaled value (train_kmeans :1344 divides by n).
+ * The caller applies the k*512 / sample_rate*k row caps (:623-627, :1328-1340).
+ * init_centroids NULL -> random init from `seed`; split RNG = seed ^ 0x5bd1e995.
+ * Returns the number of iterations executed.                                   */
+int orc_kmeans_train_f32(int metric, const float *x, size_t n, size_t d, size_t k,
+                         uint32_t max_iters, double tol, float balance_factor,
+                         const float *init_centroids, uint64_t seed, float *centroids_out,
+                         double *loss_out, uint64_t *sizes_out) {
+  float *cent = centroids_out;
+  if (init_centroids) {
+    memcpy(cent, init_centroids, k * d * sizeof(float));
+  } else {
+    uint64_t *idx = (uint64_t *)malloc(k * sizeof(uint64_t));
+    orc_kmeans_init_indices(n, (uint32_t)k, seed, idx);
+    for (size_t c = 0; c < k; c++) memcpy(cent + c * d, x + idx[c] * d, d * sizeof(float));
+    free(idx);
+  }
+  orc_rng split_rng; orc_rng_seed(&split_rng, seed ^ 0x5bd1e995ULL);
+
+  uint32_t *membership = (uint32_t *)malloc(n * sizeof(uint32_t));
+  float *dists = (float *)malloc(n * sizeof(float));
+  uint64_t *cluster_sizes = (uint64_t *)calloc(k, sizeof(uint64_t));
+  float *bias = (float *)malloc(k * sizeof(float));
+  float *radius = (float *)malloc(k * sizeof(float));
+  double *losses = (double *)malloc(k * sizeof(double));
+  float *newc = (float *)malloc(k * d * sizeof(float));
+  float adjusted_balance_factor = FLT_MAX;
+  double loss = DBL_MAX, last_loss = DBL_MAX;
+  int iters = 0;
+
+  for (uint32_t it = 1; it <= max_iters; it++) {
+    iters = (int)it;
+    float bf = adjusted_balance_factor < balance_factor ? adjusted_balance_factor : balance_factor;
+    /* f32::min: if either is NaN returns the other; not reachable with finite inputs */
+    for (size_t c = 0; c < k; c++) bias[c] = bf * (float)cluster_sizes[c];
+    orc_assign_f32(metric, x, n, d, cent, k, bias, membership, dists);
+
+    for (size_t c = 0; c < k; c++) { radius[c] = 0.0f; losses[c] = 0.0; }
+    for (size_t r = 0; r < n; r++) {
+      if (membership[r] != ORC_NONE) {
+        size_t c = membership[r];
+        radius[c] = fmaxf(radius[c], dists[r]); /* f32::max */
+        losses[c] += (double)dists[r];
+      }
+    }
+    /* compute_cluster_sizes */
+    for (size_t c = 0; c < k; c++) cluster_sizes[c] = 0;
+    size_t max_cluster_id = 0; uint64_t max_cluster_size = 0;
+    for (size_t r = 0; r < n; r++) {
+      if (membership[r] != ORC_NONE) {
+        size_t c = membership[r];
+        cluster_sizes[c] += 1;
+        if (cluster_sizes[c] > max_cluster_size) { max_cluster_size = cluster_sizes[c]; max_cluster_id = c; }
+      }
+    }
+    adjusted_balance_factor =
+        (radius[max_cluster_id] - (float)losses[max_cluster_id] / (float)cluster_sizes[max_cluster_id]) /
+        (float)n;
+    /* compute_balance_loss: usize sums, then as f32 */
+    uint64_t size_loss_u = 0;
+    for (size_t c = 0; c < k; c++) size_loss_u += cluster_sizes[c] * cluster_sizes[c];
+    float size_loss = (float)size_loss_u;
+    float balance_loss = bf * (size_loss - (float)((uint64_t)n * (uint64_t)n) / (float)k);
+    double lsum = 0.0;
+    for (size_t c = 0; c < k; c++) lsum = lsum + losses[c];
+    last_loss = lsum + (double)balance_loss;
+
+    /* to_kmeans: per-centroid sequential sum in row order, in T; then *= 1/cnt */
+    memset(newc, 0, k * d * sizeof(float));
+    for (size_t r = 0; r < n; r++) {
+      if (membership[r] != ORC_NONE) {
+        float *c = newc + (size_t)membership[r] * d;
+        const float *v = x + r * d;
+        for (size_t t = 0; t < d; t++) c[t] += v[t];
+      }
+    }
+    for (size_t c = 0; c < k; c++) {
+      if (cluster_sizes[c] > 0) {
+        float norm = 1.0f / (float)cluster_sizes[c];
+        for (size_t t = 0; t < d; t++) newc[c * d + t] *= norm;
+      }
+    }
+    orc_split_clusters(n, cluster_sizes, k, newc, d, &split_rng);
+    memcpy(cent, newc, k * d * sizeof(float));
+
+    if (fabs(loss - last_loss) < tol * last_loss) break;
+    loss = last_loss;
+  }
+  if (loss_out) *loss_out = last_loss;
+  if (sizes_out) for (size_t c = 0; c < k; c++) sizes_out[c] = cluster_sizes[c];
+  free(membership); free(dists); free(cluster_sizes); free(bias); free(radius); free(losses); free(newc);
+  return iters;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a10: do_compute_residual  residual.rs:58-102 */
+void orc_residual_f32(const float *x, size_t n, size_t d, const float *cent,
+                      const uint32_t *part_ids, float *out) {
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++) {
+    const float *c = cent + (size_t)part_ids[r] * d;
+    for (size_t t = 0; t < d; t++) out[r * d + t] = x[r * d + t] - c[t];
+  }
+}
+
+/* divide_to_subvectors  pq/utils.rs:14-49: sub-matrix m = columns [m*sd,(m+1)*sd) */
+void orc_divide_to_subvectors_f32(const float *x, size_t n, size_t d, size_t m_count, float *out) {
+  size_t sd = d / m_count;
+  for (size_t m = 0; m < m_count; m++)
+    for (size_t r = 0; r < n; r++)
+      memcpy(out + (m * n + r) * sd, x + r * d + m * sd, sd * sizeof(float));
+}
+
+/* a11: PQBuildParams::build_from_fsl  pq/builder.rs:89-157: M sequential k-means
+ * (k=2^nbits, L2, balance 0) on sub-vector matrices; codebook laid out [M][k][sd].
+ * Sub-quantiser m uses seed + m.  Inner train_kmeans applies the sample_rate*k
+ * slice (kmeans.rs:1328-1340) and the k*512 cap (:623-627).                    */
+void orc_pq_train_f32(const float *resid, size_t n, size_t d, size_t m_count, uint32_t nbits,
+                      uint32_t max_iters, size_t sample_rate, uint64_t seed, float *codebook_out,
+                      int *iters_out) {
+  size_t sd = d / m_count, kc = (size_t)1 << nbits;
+  size_t rows = n;
+  if (rows > sample_rate * kc) rows = sample_rate * kc;
+  if (rows >= kc * 512) rows = kc * 512;
+  float *sub = (float *)malloc(rows * sd * sizeof(float));
+  for (size_t m = 0; m < m_count; m++) {
+    for (size_t r = 0; r < rows; r++) memcpy(sub + r * sd, resid + r * d + m * sd, sd * sizeof(float));
+    double loss;
+    int it = orc_kmeans_train_f32(ORC_L2, sub, rows, sd, kc, max_iters, 1e-4, 0.0f, NULL, seed + m,
+                                  codebook_out + m * kc * sd, &loss, NULL);
+    if (iters_out) iters_out[m] = it;
+  }
+  free(sub);
+}
+
+/* a12: ProductQuantizer::transform_impl<8>  pq.rs:116-191: per sub-vector argmin
+ * (compute_partition, no bias), unwrap_or(0).  codes row-major [n][M].        */
+void orc_pq_encode_f32(int metric, const float *x, size_t n, size_t d, const float *codebook,
+                       size_t m_count, uint32_t nbits, uint8_t *codes) {
+  size_t sd = d / m_count, kc = (size_t)1 << nbits;
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++) {
+    for (size_t m = 0; m < m_count; m++) {
+      uint32_t id; float dist;
+      int found = orc_argmin_row(metric, x + r * d + m * sd, codebook + m * kc * sd, kc, sd, NULL, &id, &dist);
+      codes[r * m_count + m] = found ? (uint8_t)id : 0;
+    }
+  }
+}
+
+/* 4-bit packing  pq.rs:168-172: (v[1] << 4) | v[0] */
+void orc_pq_encode4_f32(int metric, const float *x, size_t n, size_t d, const float *codebook,
+                        size_t m_count, uint8_t *codes) {
+  size_t sd = d / m_count, kc = 16;
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < n; r++) {
+    for (size_t m = 0; m < m_count; m += 2) {
+      uint32_t id0, id1; float dist;
+      int f0 = orc_argmin_row(metric, x + r * d + m * sd, codebook + m * kc * sd, kc, sd, NULL, &id0, &dist);
+      int f1 = orc_argmin_row(metric, x + r * d + (m + 1) * sd, codebook + (m + 1) * kc * sd, kc, sd, NULL, &id1, &dist);
+      uint8_t c0 = f0 ? (uint8_t)id0 : 0, c1 = f1 ? (uint8_t)id1 : 0;
+      codes[r * (m_count / 2) + m / 2] = (uint8_t)((c1 << 4) | c0);
+    }
+  }
+}
+
+/* a13: transpose  pq/storage.rs:430-449: [n][M] -> [M][n] */
+void orc_transpose_u8(const uint8_t *in, size_t n, size_t m_count, uint8_t *out) {
+  for (size_t r = 0; r < n; r++)
+    for (size_t m = 0; m < m_count; m++) out[m * n + r] = in[r * m_count + m];
+}
+
+/* a16: build_distance_table_l2 / _dot  pq/distance.rs:24-92 -> [M][2^nbits] f32 */
+void orc_build_lut_f32(int metric, const float *q, size_t d, const float *codebook, size_t m_count,
+                       uint32_t nbits, float *lut) {
+  size_t sd = d / m_count, kc = (size_t)1 << nbits;
+  for (size_t m = 0; m < m_count; m++)
+    for (size_t c = 0; c < kc; c++)
+      lut[m * kc + c] = orc_dist(metric, q + m * sd, codebook + (m * kc + c) * sd, sd);
+}
+
+/* a17: compute_pq_distance (8-bit)  pq/distance.rs:109-144 over TRANSPOSED codes;
+ * dist[j] = ((0 + LUT[0][c0j]) + LUT[1][c1j]) + ... ; dot post-bias -(M-1)
+ * pq/storage.rs:949-957.                                                        */
+void orc_pq_scan_f32(int metric, const float *lut, size_t m_count, const uint8_t *codes_t,
+                     size_t n_p, float *dists) {
+  for (size_t j = 0; j < n_p; j++) dists[j] = 0.0f;
+  for (size_t m = 0; m < m_count; m++) {
+    const float *t = lut + m * 256;
+    const uint8_t *c = codes_t + m * n_p;
+    for (size_t j = 0; j < n_p; j++) dists[j] += t[c[j]];
+  }
+  if (metric == ORC_DOT) {
+    float diff = (float)m_count - 1.0f;
+    for (size_t j = 0; j < n_p; j++) dists[j] = dists[j] - diff;
+  }
+}
+
+/* row-major variant used by pq/distance.rs:337-364 test (must equal transposed exactly) */
+void orc_pq_scan_rowmajor_f32(const float *lut, size_t m_count, const uint8_t *codes, size_t n_p,
+                              float *dists) {
+  for (size_t j = 0; j < n_p; j++) {
+    float s = 0.0f;
+    for (size_t m = 0; m < m_count; m++) s += lut[m * 256 + codes[j * m_count + m]];
+    dists[j] = s;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* f32::total_cmp key (graph.rs:66-82 OrderedFloat): monotone u32 */
+static inline uint32_t orc_key(float f) {
+  uint32_t b; memcpy(&b, &f, 4);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+/* Rust std 1.90 BinaryHeap<OrderedNode> (max-heap on dist only). */
+typedef struct { uint32_t key; float dist; uint64_t id; } orc_node;
+typedef struct { orc_node *data; size_t len; } orc_heap;
+
+static void orc_heap_sift_up(orc_heap *h, size_t start, size_t pos) {
+  orc_node elt = h->data[pos];
+  while (pos > start) {
+    size_t parent = (pos - 1) / 2;
+    if (elt.key <= h->data[parent].key) break;
+    h->data[pos] = h->data[parent];
+    pos = parent;
+  }
+  h->data[pos] = elt;
+}
+static void orc_heap_push(orc_heap *h, orc_node n) {
+  size_t old_len = h->len;
+  h->data[h->len++] = n;
+  orc_heap_sift_up(h, 0, old_len);
+}
+static void orc_heap_sift_down_to_bottom(orc_heap *h, size_t pos) {
+  size_t end = h->len, start = pos;
+  orc_node elt = h->data[pos];
+  size_t child = 2 * pos + 1;
+  size_t lim = end >= 2 ? end - 2 : 0; /* end.saturating_sub(2) */
+  while (child <= lim && end >= 2) {
+    if (h->data[child].key <= h->data[child + 1].key) child += 1;
+    h->data[pos] = h->data[child];
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  if (child == end - 1) {
+    h->data[pos] = h->data[child];
+    pos = child;
+  }
+  h->data[pos] = elt;
+  orc_heap_sift_up(h, start, pos);
+}
+static orc_node orc_heap_pop(orc_heap *h) {
+  orc_node item = h->data[--h->len];
+  if (h->len > 0) {
+    orc_node t = h->data[0]; h->data[0] = item; item = t;
+    orc_heap_sift_down_to_bottom(h, 0);
+  }
+  return item;
+}
+
+/* a19: FlatIndex::search  flat/index.rs:82-177 (no prefilter): push while < k,
+ * else replace the root only if root.dist > dist (total order).  Optional
+ * [lower, upper) range.  Output = heap vector order (unsorted).  Returns count. */
+size_t orc_heap_topk(const float *dists, const uint64_t *row_ids, size_t n, size_t k,
+                     int has_range, float lower, float upper, uint64_t *out_ids, float *out_dists) {
+  if (k == 0) return 0;
+  orc_heap h; h.data = (orc_node *)malloc((k + 1) * sizeof(orc_node)); h.len = 0;
+  uint32_t lo = orc_key(lower), hi = orc_key(upper);
+  for (size_t j = 0; j < n; j++) {
+    orc_node nd; nd.dist = dists[j]; nd.key = orc_key(dists[j]); nd.id = row_ids[j];
+    if (has_range && (nd.key < lo || nd.key >= hi)) continue;
+    if (h.len < k) {
+      orc_heap_push(&h, nd);
+    } else if (h.data[0].key > nd.key) {
+      orc_heap_pop(&h);
+      orc_heap_push(&h, nd);
+    }
+  }
+  size_t cnt = h.len;
+  for (size_t i = 0; i < cnt; i++) { out_ids[i] = h.data[i].id; out_dists[i] = h.data[i].dist; }
+  free(h.data);
+  return cnt;
+}
+
+/* a21: SortExec([_distance asc, _rowid asc]).fetch(k)  scanner.rs:3440-3468 */
+typedef struct { uint32_t key; float dist; uint64_t id; } orc_pair;
+static int orc_pair_cmp(const void *a, const void *b) {
+  const orc_pair *x = (const orc_pair *)a, *y = (const orc_pair *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  if (x->id != y->id) return x->id < y->id ? -1 : 1;
+  return 0;
+}
+size_t orc_sort_fetch(uint64_t *ids, float *dists, size_t n, size_t k) {
+  orc_pair *p = (orc_pair *)malloc((n ? n : 1) * sizeof(orc_pair));
+  for (size_t i = 0; i < n; i++) { p[i].key = orc_key(dists[i]); p[i].dist = dists[i]; p[i].id = ids[i]; }
+  qsort(p, n, sizeof(orc_pair), orc_pair_cmp);
+  size_t out = n < k ? n : k;
+  for (size_t i = 0; i < out; i++) { ids[i] = p[i].id; dists[i] = p[i].dist; }
+  free(p);
+  return out;
+}
+
+/* a14: kmeans_find_partitions  kmeans.rs:1134-1158: all distances, then
+ * sort_to_indices(limit=nprobes) ascending.  arrow's partial sort is unstable, so
+ * the order of EQUAL distances is unspecified in the reference; we fix (dist, id). */
+void orc_find_partitions_f32(int metric, const float *q, size_t nq, size_t d, const float *cent,
+                             size_t nlist, size_t nprobes, uint32_t *part_ids, float *dists) {
+  if (nprobes > nlist) nprobes = nlist;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < nq; i++) {
+    orc_pair *p = (orc_pair *)malloc(nlist * sizeof(orc_pair));
+    for (size_t c = 0; c < nlist; c++) {
+      float v = orc_dist(metric, q + i * d, cent + c * d, d);
+      p[c].key = orc_key(v); p[c].dist = v; p[c].id = c;
+    }
+    qsort(p, nlist, sizeof(orc_pair), orc_pair_cmp);
+    for (size_t j = 0; j < nprobes; j++) {
+      part_ids[i * nprobes + j] = (uint32_t)p[j].id;
+      if (dists) dists[i * nprobes + j] = p[j].dist;
+    }
+    free(p);
+  }
+}
+
+/* a20+a21: flat KNN  flat.rs:95-148 + scanner.rs:3386-3406: all distances, then
+ * sort by (dist, rowid) and fetch k.  Implemented as a bounded selection with the
+ * same total order (result identical to a full sort + fetch).                   */
+void orc_flat_knn_f32(int metric, const float *x, const uint64_t *row_ids, size_t n, size_t d,
+                      const float *q, size_t nq, size_t k, uint64_t *out_ids, float *out_dists) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t i = 0; i < nq; i++) {
+    /* keep the k best in a small sorted array (k is small) */
+    orc_pair *best = (orc_pair *)malloc((k + 1) * sizeof(orc_pair));
+    size_t cnt = 0;
+    float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q + i * d, d) : 0.0f;
+    for (size_t r = 0; r < n; r++) {
+      float v = metric == ORC_COSINE ? orc_cosine_f32(q + i * d, qn, x + r * d, d)
+                                     : orc_dist(metric, q + i * d, x + r * d, d);
+      orc_pair e; e.key = orc_key(v); e.dist = v; e.id = row_ids ? row_ids[r] : (uint64_t)r;
+      if (cnt == k && orc_pair_cmp(&e, &best[k - 1]) >= 0) continue;
+      size_t pos = cnt < k ? cnt : k - 1;
+      while (pos > 0 && orc_pair_cmp(&e, &best[pos - 1]) < 0) { best[pos] = best[pos - 1]; pos--; }
+      best[pos] = e;
+      if (cnt < k) cnt++;
+    }
+    for (size_t j = 0; j < k; j++) {
+      out_ids[i * k + j] = j < cnt ? best[j].id : UINT64_MAX;
+      out_dists[i * k + j] = j < cnt ? best[j].dist : INFINITY;
+    }
+    free(best);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Full IVF_PQ query (3.2 of SURVEY): per query
+ *   [cosine: normalise q  knn.rs:495-498]
+ *   find_partitions (a14) -> first nprobes partitions
+ *   per partition: residual q - centroid[p] (v2.rs:316-332, L2/cosine only),
+ *     LUT (a16), ADC scan over transposed codes (a17), heap top-(k*refine) (a19)
+ *   SortExec (dist,rowid) fetch k*refine (a21)
+ *   [refine: exact distance on raw vectors of the candidates, sort, fetch k
+ *            scanner.rs:2884-2904,3336-3412]
+ * Index layout: part_offsets[nlist+1]; codes_t = per-partition transposed [M][n_p]
+ * blocks concatenated (block p starts at part_offsets[p]*M); row_ids[N] in
+ * partition order.  raw/raw_pos: raw vectors [*][d] and, for slot i, raw row of
+ * row_ids[i] given through rowid_to_raw (NULL => rowid is the raw row index).   */
+void orc_ivfpq_search_f32(int metric, const float *centroids, size_t nlist, size_t d,
+                          const float *codebook, size_t m_count, const uint32_t *part_offsets,
+                          const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                          size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                          uint64_t *out_ids, float *out_dists) {
+  if (nprobes > nlist) nprobes = nlist;
+  int scan_metric = (metric == ORC_COSINE) ? ORC_L2 : metric;
+  size_t keff = k * (refine ? refine : 1);
+  size_t max_np = 0;
+  for (size_t p = 0; p < nlist; p++) {
+    size_t np_ = part_offsets[p + 1] - part_offsets[p];
+    if (np_ > max_np) max_np = np_;
+  }
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t i = 0; i < nq; i++) {
+    float *q = (float *)malloc(d * sizeof(float));
+    float *qr = (float *)malloc(d * sizeof(float));
+    float *lut = (float *)malloc(m_count * 256 * sizeof(float));
+    float *pd = (float *)malloc((max_np ? max_np : 1) * sizeof(float));
+    uint32_t *parts = (uint32_t *)malloc(nprobes * sizeof(uint32_t));
+    uint64_t *cand_ids = (uint64_t *)malloc((nprobes * keff + 1) * sizeof(uint64_t));
+    float *cand_d = (float *)malloc((nprobes * keff + 1) * sizeof(float));
+    size_t ncand = 0;
+    if (metric == ORC_COSINE) orc_normalize_f32(queries + i * d, 1, d, q);
+    else memcpy(q, queries + i * d, d * sizeof(float));
+    /* single-query find_partitions (serial inside the parallel region) */
+    {
+      orc_pair *p = (orc_pair *)malloc(nlist * sizeof(orc_pair));
+      for (size_t c = 0; c < nlist; c++) {
+        float v = orc_dist(scan_metric, q, centroids + c * d, d);
+        p[c].key = orc_key(v); p[c].dist = v; p[c].id = c;
+      }
+      qsort(p, nlist, sizeof(orc_pair), orc_pair_cmp);
+      for (size_t j = 0; j < nprobes; j++) parts[j] = (uint32_t)p[j].id;
+      free(p);
+    }
+    for (size_t j = 0; j < nprobes; j++) {
+      size_t p = parts[j];
+      size_t off = part_offsets[p], np_ = part_offsets[p + 1] - off;
+      if (np_ == 0) continue;
+      if (scan_metric == ORC_L2) {
+        for (size_t t = 0; t < d; t++) qr[t] = q[t] - centroids[p * d + t];
+      } else {
+        memcpy(qr, q, d * sizeof(float));
+      }
+      orc_build_lut_f32(scan_metric, qr, d, codebook, m_count, 8, lut);
+      orc_pq_scan_f32(scan_metric, lut, m_count, codes_t + off * m_count, np_, pd);
+      ncand += orc_heap_topk(pd, row_ids + off, np_, keff, 0, 0, 0, cand_ids + ncand, cand_d + ncand);
+    }
+    size_t got = orc_sort_fetch(cand_ids, cand_d, ncand, keff);
+    if (refine && raw) {
+      /* flat_knn on the taken rows with the index's metric and the ORIGINAL query
+       * (scanner.rs:2884-2904): KNNVectorDistanceExec + SortExec(dist,rowid).fetch(k) */
+      const float *qo = queries + i * d;
+      float qn = metric == ORC_COSINE ? orc_norm_l2_f32(qo, d) : 0.0f;
+      for (size_t c = 0; c < got; c++) {
+        const float *rv = raw + cand_ids[c] * d;
+        cand_d[c] = metric == ORC_COSINE ? orc_cosine_f32(qo, qn, rv, d) : orc_dist(metric, qo, rv, d);
+      }
+      got = orc_sort_fetch(cand_ids, cand_d, got, k);
+    } else if (got > k) {
+      got = k;
+    }
+    for (size_t j = 0; j < k; j++) {
+      out_ids[i * k + j] = j < got ? cand_ids[j] : UINT64_MAX;
+      out_dists[i * k + j] = j < got ? cand_d[j] : INFINITY;
+    }
+    free(q); free(qr); free(lut); free(pd); free(parts); free(cand_ids); free(cand_d);
+  }
+}
+
+/* Index build glue (builder.rs:555-846 in canonical, stable row order):
+ * counting sort of rows by partition id -> part_offsets, slot->row permutation.
+ * Rows with part id NONE (all-NaN, kmeans.rs:1447-1486) are dropped.           */
+size_t orc_partition_layout(const uint32_t *part_ids, size_t n, size_t nlist, uint32_t *part_offsets,
+                            uint32_t *perm) {
+  memset(part_offsets, 0, (nlist + 1) * sizeof(uint32_t));
+  for (size_t r = 0; r < n; r++)
+    if (part_ids[r] != ORC_NONE) part_offsets[part_ids[r] + 1]++;
+  for (size_t p = 0; p < nlist; p++) part_offsets[p + 1] += part_offsets[p];
+  uint32_t *cur = (uint32_t *)malloc((nlist + 1) * sizeof(uint32_t));
+  memcpy(cur, part_offsets, (nlist + 1) * sizeof(uint32_t));
+  for (size_t r = 0; r < n; r++)
+    if (part_ids[r] != ORC_NONE) perm[cur[part_ids[r]]++] = (uint32_t)r;
+  size_t total = part_offsets[nlist];
+  free(cur);
+  return total;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void orc_set_threads(int t) {
+#ifdef _OPENMP
+  omp_set_num_threads(t);
+#else
+  (void)t;
+#endif
+}

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP engine; GPU tests fail loudly (never skip silently) if it cannot load."""
+    import lance_amd
+    return lance_amd
