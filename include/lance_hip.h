@@ -1,0 +1,203 @@
+/*
+ * lance_hip.h -- C ABI of liblance_hip.so: the MI355X (gfx950) engine for Lance's
+ * IVF-PQ hot path (k-means training, PQ codebook learning/encoding, flat and IVF-PQ
+ * distance scans with top-k).
+ *
+ * This is the drop-in boundary: a Rust `extern "C"` block (or JNI / ctypes) binds
+ * exactly these symbols; INTEGRATION.md shows the reference-side call sites.
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * lancedb/lance tree).
+ *
+ * Conventions
+ *   - Plain C types only.  All data pointers are DEVICE pointers (HBM) unless the
+ *     parameter name ends in `_host`; buffers are caller-owned, row-major, and no
+ *     allocation crosses the ABI except opaque handles.  lance_hip_malloc/free/memcpy
+ *     are provided so a host without its own HIP binding can stage data.
+ *   - Return 0 on success, a negative LANCE_HIP_E* code on failure; the message is
+ *     available from lance_hip_last_error() (thread-local).  Never throws or aborts.
+ *   - Work is issued on the context's stream; calls return after the stream has been
+ *     synchronised unless stated otherwise.  A context may be used by one thread at a
+ *     time; create one per thread for concurrent callers (the reference calls these
+ *     paths from rayon / tokio worker threads).
+ *   - "No partition" (all-NaN row; kmeans.rs:1447-1486) is id 0xFFFFFFFF.
+ *   - Results are bit-identical to the reference CPU path for ids / codes / distances
+ *     (see DESIGN.md for the exact statement and the two documented tie rules).
+ */
+#ifndef LANCE_HIP_H
+#define LANCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LANCE_HIP_OK 0
+#define LANCE_HIP_EINVAL -1    /* bad argument */
+#define LANCE_HIP_ERUNTIME -2  /* HIP runtime error */
+#define LANCE_HIP_ENOTSUP -3   /* combination not implemented */
+#define LANCE_HIP_ENOMEM -4
+
+#define LANCE_HIP_NONE 0xFFFFFFFFu
+
+/* lance_linalg::distance::DistanceType (distance.rs:36).  Cosine is handled the way
+ * the reference index does: normalise, then L2 (lance-index ivf.rs:198-205).        */
+enum { LANCE_HIP_L2 = 0, LANCE_HIP_COSINE = 1, LANCE_HIP_DOT = 2 };
+/* element type of vectors / centroids / codebook */
+enum { LANCE_HIP_F32 = 0, LANCE_HIP_F16 = 1 };
+
+typedef struct lance_hip_ctx lance_hip_ctx;
+typedef struct lance_hip_index lance_hip_index;
+
+/* ---- context ------------------------------------------------------------------ */
+/* stream == NULL: the context creates and owns a stream; otherwise it borrows the
+ * caller's hipStream_t (e.g. torch's current stream).                               */
+int lance_hip_ctx_create(int device_id, void *stream, lance_hip_ctx **out);
+void lance_hip_ctx_destroy(lance_hip_ctx *ctx);
+const char *lance_hip_last_error(void);
+const char *lance_hip_version(void);
+int lance_hip_synchronize(lance_hip_ctx *ctx);
+
+int lance_hip_malloc(lance_hip_ctx *ctx, size_t bytes, void **out);
+int lance_hip_free(lance_hip_ctx *ctx, void *ptr);
+int lance_hip_memcpy_h2d(lance_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int lance_hip_memcpy_d2h(lance_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
+
+/* ---- a4: normalize_fsl (lance-linalg kernels.rs:141-146,172-211) ---------------- */
+int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, void *out);
+
+/* ---- a5/a6/a9: argmin over centroids ------------------------------------------- */
+/* KMeansAlgoFloat::compute_membership_and_dist (lance-index kmeans.rs:317-369),
+ * compute_partitions_arrow_array (:1187-1246), compute_partition (:1350-1369) with
+ * argmin_value_float[_with_bias] (lance-linalg kernels.rs:79-111).
+ * bias: k floats added before the comparison (un-biased distance returned) or NULL.
+ * ids: n (LANCE_HIP_NONE = None); dists: n or NULL.                                  */
+int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                     const void *centroids, uint32_t k, const float *bias, uint32_t *ids, float *dists);
+
+/* ---- a7/a8: KMeans::train_kmeans (kmeans.rs:610-719) ---------------------------- */
+/* Lloyd iterations on exactly the n rows given (the caller applies the sample_rate*k
+ * slice of kmeans.rs:1328-1340; the k*512 cap of :623-627 is applied here).
+ * balance_factor is the caller's value (1.0 for IVF, ivf.rs:1859); it is divided by n
+ * as train_kmeans does (:1344).  init_centroids: k*d or NULL (random rows from `seed`,
+ * kmeans_random_init :149-170).  Given the same inputs, init and seed the centroids,
+ * loss and iteration count are bit-identical to the reference algorithm (M-step sums
+ * are accumulated per centroid in row order, :371-446).  k <= 4096 in this version.   */
+int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                           uint32_t k, uint32_t max_iters, double tol, float balance_factor,
+                           const void *init_centroids, uint64_t seed, void *centroids_out,
+                           double *loss_out_host, uint32_t *iters_out_host);
+
+/* Building blocks of one Lloyd iteration, for a host that owns the loop (multi-GPU:
+ * one process per GPU, rows sharded, one all-reduce per iteration).
+ * estep_partial: assign the local rows and accumulate, per centroid and in local row
+ * order, sums[k][d] (f32), counts[k] (stored as f32 so that one all-reduce buffer
+ * holds everything), and loss (f64 stored in 2 floats is NOT used: loss is returned to
+ * the host).  buf layout: [k*d sums | k counts] floats.                              */
+int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n,
+                                   uint32_t d, const void *centroids, uint32_t k, const float *bias,
+                                   float *buf /* k*d + k */, double *loss_out_host);
+/* finalize: centroids = sums * (1/count) for count > 0 (kmeans.rs:410-418). */
+int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, uint32_t k, uint32_t d,
+                              void *centroids_out);
+
+/* ---- a11: PQBuildParams::build_from_fsl (pq/builder.rs:89-157) ------------------- */
+/* M independent k-means (k = 2^nbits, L2, no balance) over the sub-vector columns of
+ * `residuals`; sub-quantiser m uses seed + m.  codebook_out: [m][2^nbits][d/m].      */
+int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uint64_t n, uint32_t d,
+                       uint32_t m, uint32_t nbits, uint32_t max_iters, uint32_t sample_rate, uint64_t seed,
+                       void *codebook_out, uint32_t *iters_out_host /* m or NULL */);
+
+/* ---- a10: do_compute_residual (residual.rs:58-102) ------------------------------- */
+int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d,
+                       const void *centroids, const uint32_t *part_ids, void *out);
+
+/* ---- a12: ProductQuantizer::transform_impl (pq.rs:116-191) ----------------------- */
+/* codes: [n][m] (nbits = 8) */
+int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                        const void *codebook, uint32_t m, uint32_t nbits, uint8_t *codes);
+
+/* ---- a9+a10+a12: the IvfTransformer chain for one batch (lance-index ivf.rs:188-236;
+ * precedent: one_pass_assign_ivf_pq_on_accelerator, python/lance/vector.py:607-755) --- */
+/* [cosine: normalise] -> assign -> residual (L2/cosine) -> PQ encode.  Emits the
+ * shuffle-buffer columns (__ivf_part_id u32, __pq_code u8[m]).  Non-finite rows get
+ * part id LANCE_HIP_NONE (KeepFiniteVectors, utils.rs:263-286).                      */
+int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                           const void *centroids, uint32_t nlist, const void *codebook, uint32_t m,
+                           uint32_t nbits, uint32_t *part_ids, uint8_t *codes, double *loss_out_host);
+
+/* ---- a13 + builder.rs:685-846: per-partition storage ------------------------------ */
+/* Builds a device-resident index from the shuffle-buffer columns: rows are grouped by
+ * partition in ascending input order (stable), rows with part id NONE are dropped.
+ * row_ids: n u64 labels or NULL (row i gets id i).  The index keeps its own copies.   */
+int lance_hip_index_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids,
+                           uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
+                           const uint32_t *part_ids, const uint8_t *codes, const uint64_t *row_ids, uint64_t n,
+                           lance_hip_index **out);
+/* Same, from the reference's on-disk/storage layout (pq/storage.rs:183-290): rows
+ * already grouped by partition (part_offsets_host[nlist+1]) and each partition's codes
+ * transposed to [m][n_p] (transposed != 0) or row-major.                              */
+int lance_hip_index_from_storage(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids,
+                                 uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
+                                 const uint32_t *part_offsets_host, const uint8_t *codes, int transposed,
+                                 const uint64_t *row_ids, uint64_t n, lance_hip_index **out);
+void lance_hip_index_destroy(lance_hip_index *idx);
+/* Optional raw vectors for refine (scanner.rs:2884-2904 `take` + flat_knn): x[n_raw][d],
+ * indexed by row id (row id r -> x[r]); borrowed, must outlive the index.             */
+int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw);
+int lance_hip_index_info(const lance_hip_index *idx, uint64_t *n_rows, uint32_t *nlist, uint32_t *m, uint32_t *d);
+/* Copies out the storage layout (host pointers, any may be NULL): part_offsets[nlist+1],
+ * codes transposed per partition (the reference layout), row ids in partition order. */
+int lance_hip_index_export(lance_hip_ctx *ctx, const lance_hip_index *idx, uint32_t *part_offsets_host,
+                           uint8_t *codes_transposed_host, uint64_t *row_ids_host);
+
+/* ---- a14: IvfModel::find_partitions (ivf/storage.rs:107-119, kmeans.rs:1134-1158) -- */
+/* Batched.  Ascending by distance; equal distances ordered by partition id (the
+ * reference's partial sort is unstable, so any order of equals is a valid outcome).
+ * part_ids / dists: [nq][nprobes].  Cosine: q must already be normalised.            */
+int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const void *q, uint32_t nq, uint32_t d,
+                              const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids,
+                              float *dists);
+
+/* ---- a16+a17+a19: one partition (PQDistCalculator::new + distance_all, pq/storage.rs:
+ * 854-960; FlatIndex::search, flat/index.rs:82-177) --------------------------------- */
+/* q_residual: [d] already residualised (v2.rs:316-332).  codes_transposed: [m][n_p].
+ * has_range: keep only lower <= dist < upper.  out_*: capacity k; *out_n_host = count;
+ * output is sorted by (dist, row id).                                                 */
+int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *q_residual, uint32_t d,
+                           const void *codebook, uint32_t m, uint32_t nbits, const uint8_t *codes_transposed,
+                           const uint64_t *row_ids, uint64_t n_p, uint32_t k, int has_range, float lower,
+                           float upper, uint64_t *out_ids, float *out_dists, uint32_t *out_n_host);
+
+/* ---- a14..a21 batched: the ANN query (knn.rs:359-1075, v2.rs:455-505, scanner.rs:
+ * 3440-3468, refine :2884-2904) -------------------------------------------------------- */
+/* q: [nq][d] raw queries (cosine: normalised internally, knn.rs:495-498).  nprobes =
+ * minimum_nprobes = maximum_nprobes.  refine_factor 0 = None (no refine); rf >= 1 = Some(rf):
+ * k*rf candidates re-ranked with exact distances on the raw vectors.  ids/dists: [nq][k],
+ * missing results are id UINT64_MAX / dist +inf.                                      */
+int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq,
+                           uint32_t k, uint32_t nprobes, uint32_t refine_factor, uint64_t *ids, float *dists);
+/* Same, but only enqueues on the stream (no synchronisation, no host reads): for
+ * callers that time or pipeline batches.  Scratch is owned by the context.           */
+int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq,
+                                 uint32_t k, uint32_t nprobes, uint32_t refine_factor, uint64_t *ids,
+                                 float *dists);
+
+/* ---- a20+a21: flat KNN (flat.rs:95-148, l2.rs:245-266, scanner.rs:3386-3411) ------- */
+/* Exhaustive scan of x[n][d] for nq queries; result sorted by (dist, row id).
+ * row_ids NULL -> row index.                                                          */
+int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x, const uint64_t *row_ids,
+                        uint64_t n, uint32_t d, const void *q, uint32_t nq, uint32_t k, uint64_t *ids,
+                        float *dists);
+
+/* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx stream --- */
+/* When enabled, each internal launch of the named hot kernels is bracketed by events;
+ * query returns accumulated milliseconds and launch count, then resets.              */
+int lance_hip_timing_enable(lance_hip_ctx *ctx, int on);
+int lance_hip_timing_query(lance_hip_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCE_HIP_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of liblance_hip.so (the C ABI in include/lance_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is
+visible, loading / context creation raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblance_hip.so")
+
+OK, EINVAL, ERUNTIME, ENOTSUP, ENOMEM = 0, -1, -2, -3, -4
+L2, COSINE, DOT = 0, 1, 2
+F32, F16 = 0, 1
+NONE = 0xFFFFFFFF
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+
+METRICS = {"l2": L2, "L2": L2, "euclidean": L2, "cosine": COSINE, "dot": DOT, 0: L2, 1: COSINE, 2: DOT}
+
+# every symbol include/lance_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "lance_hip_ctx_create", "lance_hip_ctx_destroy", "lance_hip_last_error", "lance_hip_version",
+    "lance_hip_synchronize", "lance_hip_malloc", "lance_hip_free", "lance_hip_memcpy_h2d", "lance_hip_memcpy_d2h",
+    "lance_hip_normalize", "lance_hip_assign", "lance_hip_kmeans_train", "lance_hip_kmeans_estep_partial",
+    "lance_hip_kmeans_finalize", "lance_hip_pq_train", "lance_hip_residual", "lance_hip_pq_encode",
+    "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
+    "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
+    "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_flat_topk",
+    "lance_hip_timing_enable", "lance_hip_timing_query",
+]
+
+
+class LanceHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lance_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load liblance_hip.so.  torch is imported first so that both share one HIP runtime
+    (torch bundles libamdhip64.so.7 under the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C lance_amd/csrc`). lance_amd has no CPU fallback."
+        )
+    try:
+        import torch  # noqa: F401  (runtime sharing)
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32, f32, f64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_double
+    sig = {
+        "lance_hip_ctx_create": (i32, [i32, vp, C.POINTER(vp)]),
+        "lance_hip_ctx_destroy": (None, [vp]),
+        "lance_hip_last_error": (C.c_char_p, []),
+        "lance_hip_version": (C.c_char_p, []),
+        "lance_hip_synchronize": (i32, [vp]),
+        "lance_hip_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+        "lance_hip_free": (i32, [vp, vp]),
+        "lance_hip_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),
+        "lance_hip_memcpy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
+        "lance_hip_normalize": (i32, [vp, i32, vp, u64, u32, vp]),
+        "lance_hip_assign": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp]),
+        "lance_hip_kmeans_train": (i32, [vp, i32, i32, vp, u64, u32, u32, u32, f64, f32, vp, u64, vp,
+                                         C.POINTER(f64), C.POINTER(u32)]),
+        "lance_hip_kmeans_estep_partial": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, C.POINTER(f64)]),
+        "lance_hip_kmeans_finalize": (i32, [vp, i32, vp, u32, u32, vp]),
+        "lance_hip_pq_train": (i32, [vp, i32, vp, u64, u32, u32, u32, u32, u32, u64, vp, vp]),
+        "lance_hip_residual": (i32, [vp, i32, vp, u64, u32, vp, vp, vp]),
+        "lance_hip_pq_encode": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, u32, vp]),
+        "lance_hip_ivfpq_encode": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, u32, u32, vp, vp, C.POINTER(f64)]),
+        "lance_hip_index_create": (i32, [vp, i32, i32, u32, vp, u32, vp, u32, u32, vp, vp, vp, u64, C.POINTER(vp)]),
+        "lance_hip_index_from_storage": (i32, [vp, i32, i32, u32, vp, u32, vp, u32, u32, vp, vp, i32, vp, u64,
+                                               C.POINTER(vp)]),
+        "lance_hip_index_destroy": (None, [vp]),
+        "lance_hip_index_set_raw": (i32, [vp, vp, u64]),
+        "lance_hip_index_info": (i32, [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+        "lance_hip_index_export": (i32, [vp, vp, vp, vp, vp]),
+        "lance_hip_find_partitions": (i32, [vp, i32, i32, vp, u32, u32, vp, u32, u32, vp, vp]),
+        "lance_hip_pq_scan_topk": (i32, [vp, i32, i32, vp, u32, vp, u32, u32, vp, vp, u64, u32, i32, f32, f32, vp, vp,
+                                         C.POINTER(u32)]),
+        "lance_hip_ivfpq_search": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
+        "lance_hip_ivfpq_search_async": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
+        "lance_hip_flat_topk": (i32, [vp, i32, i32, vp, vp, u64, u32, vp, u32, u32, vp, vp]),
+        "lance_hip_timing_enable": (i32, [vp, i32]),
+        "lance_hip_timing_query": (i32, [vp, C.c_char_p, C.POINTER(f64), C.POINTER(u64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != OK:
+        raise LanceHipError(code, load().lance_hip_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,365 @@
+// build.hip -- the IvfTransformer chain and per-partition storage on the device.
+//
+//   NormalizeTransformer / normalize_fsl   lance-linalg kernels.rs:141-146,172-211
+//   KeepFiniteVectors / is_finite          lance-index utils.rs:263-286
+//   PartitionTransformer                   ivf/transform.rs:75-137  (assign kernel)
+//   ResidualTransform / do_compute_residual residual.rs:58-102
+//   PQTransformer / transform_impl         pq.rs:116-191            (batched assign kernel)
+//   shuffle + per-partition storage        v3/shuffler.rs:105-218, builder.rs:685-846,
+//                                          pq/storage.rs:183-290,430-449 (transpose)
+// HBM layout of an index (ours, chosen for the GPU scan): rows grouped by partition in
+// ascending input order; PQ codes ROW-major [n][m] so one lane fetches a row's m bytes with
+// 16-byte loads (the reference's per-partition [m][n_p] transpose serves CPU SIMD gathers;
+// import/export convert).
+#include <vector>
+
+#include "common.h"
+#include "exact.cuh"
+#include "index.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+// a4: l2_norm = sqrt(sequential sum of x^2 in f32); out = x / l2_norm.  One lane per row.
+__global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const float *v = x + r * d;
+  float acc = 0.0f;
+  for (int i = 0; i < d; ++i) acc = acc + v[i] * v[i];
+  const float norm = sqrtf(acc);
+  float *o = out + r * d;
+  for (int i = 0; i < d; ++i) o[i] = v[i] / norm;
+}
+
+// KeepFiniteVectors: rows with any non-finite element get part id NONE.
+__global__ __launch_bounds__(256) void finite_mask_kernel(const float *__restrict__ x, int64_t n, int d, uint32_t *__restrict__ part_ids) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const float *v = x + r * d;
+  bool ok = true;
+  for (int i = 0; i < d; ++i) ok &= isfinite(v[i]);
+  if (!ok) part_ids[r] = LANCE_HIP_NONE;
+}
+
+// a10: out[r] = x[r] - centroids[part_ids[r]] ; coalesced over the flattened [n*d] range.
+__global__ __launch_bounds__(256) void residual_kernel(const float *__restrict__ x, int64_t n, int d,
+                                                       const float *__restrict__ cent, const uint32_t *__restrict__ part_ids,
+                                                       float *__restrict__ out) {
+  const int64_t total = n * d;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int64_t r = g / d;
+    const int t = (int)(g - r * d);
+    const uint32_t p = part_ids[r];
+    out[g] = p == LANCE_HIP_NONE ? 0.0f : x[g] - cent[(int64_t)p * d + t];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_codes_kernel(const uint8_t *__restrict__ codes, const uint64_t *__restrict__ row_ids,
+                                                           const uint32_t *__restrict__ perm, int64_t n_out, int m,
+                                                           uint8_t *__restrict__ codes_out, uint64_t *__restrict__ row_ids_out) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_out) return;
+  const uint32_t r = perm[s];
+  row_ids_out[s] = row_ids ? row_ids[r] : (uint64_t)r;
+  const uint8_t *src = codes + (int64_t)r * m;
+  uint8_t *dst = codes_out + s * m;
+  if ((m & 15) == 0 && ((reinterpret_cast<uintptr_t>(codes) | reinterpret_cast<uintptr_t>(codes_out)) & 15) == 0) {
+    for (int i = 0; i < m; i += 16) *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+  } else {
+    for (int i = 0; i < m; ++i) dst[i] = src[i];
+  }
+}
+
+__device__ __forceinline__ uint32_t find_partition(const uint32_t *__restrict__ offs, int nlist, uint32_t slot) {
+  // largest p with offs[p] <= slot
+  int lo = 0, hi = nlist;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offs[mid] <= slot) lo = mid; else hi = mid;
+  }
+  return (uint32_t)lo;
+}
+
+// transposed per-partition blocks <-> row-major.  dir 0: transposed -> row-major, 1: reverse
+__global__ __launch_bounds__(256) void retile_codes_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int64_t n,
+                                                           int m, const uint32_t *__restrict__ offs, int nlist, int dir) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n * m) return;
+  const uint32_t slot = (uint32_t)(g / m);
+  const int mm = (int)(g % m);
+  const uint32_t p = find_partition(offs, nlist, slot);
+  const uint32_t off = offs[p], np = offs[p + 1] - off;
+  const int64_t t = (int64_t)off * m + (int64_t)mm * np + (slot - off);
+  if (dir == 0) out[g] = in[t]; else out[t] = in[g];
+}
+
+static int dev_dup(lance_hip_ctx *ctx, const void *src, size_t bytes, void **out) {
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return LANCE_HIP_ENOMEM;
+  }
+  if (src && bytes) {
+    e = hipMemcpyAsync(p, src, bytes, hipMemcpyDefault, ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      set_error("hipMemcpyAsync failed: %s", hipGetErrorString(e));
+      return LANCE_HIP_ERUNTIME;
+    }
+  }
+  *out = p;
+  return LANCE_HIP_OK;
+}
+
+static int check_pq_params(uint32_t d, uint32_t m, uint32_t nbits) {
+  LH_REQUIRE(m > 0 && d % m == 0, "num_sub_vectors must divide vector dimension %u, but got %u", d, m);
+  LH_REQUIRE(nbits == 8, "ProductQuantization: num_bits %u not supported in this version (8 only)", nbits);
+  return LANCE_HIP_OK;
+}
+
+int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out) {
+  if (n == 0) return LANCE_HIP_OK;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+int pq_encode_launch(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, const float *codebook, int m,
+                     uint8_t *codes) {
+  PairwiseArgs pa;
+  pa.x = x; pa.n = n; pa.ldx = d; pa.x_batch_off = d / m;
+  pa.cent = codebook; pa.k = 256; pa.cent_batch_stride = (int64_t)256 * (d / m);
+  pa.codes = codes; pa.codes_ld = m;
+  return launch_assign(ctx, pa, d / m, metric, m);
+}
+
+}  // namespace lh
+
+using namespace lh;
+
+lance_hip_index::~lance_hip_index() {
+  (void)hipSetDevice(device);
+  if (centroids) (void)hipFree(centroids);
+  if (codebook) (void)hipFree(codebook);
+  if (part_offsets) (void)hipFree(part_offsets);
+  if (codes) (void)hipFree(codes);
+  if (row_ids) (void)hipFree(row_ids);
+}
+
+extern "C" {
+
+int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, void *out) {
+  LH_REQUIRE(ctx && x && out, "normalize: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "normalize: only f32 is implemented in this version");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (n == 0) return LANCE_HIP_OK;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream,
+                     static_cast<const float *>(x), (int64_t)n, (int)d, static_cast<float *>(out));
+  LH_CHECK_HIP(hipGetLastError());
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, const void *centroids,
+                       const uint32_t *part_ids, void *out) {
+  LH_REQUIRE(ctx && x && centroids && part_ids && out, "residual: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "residual: only f32 is implemented in this version");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (n == 0) return LANCE_HIP_OK;
+  const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(n * d, 256), 65536);
+  hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const float *>(x), (int64_t)n,
+                     (int)d, static_cast<const float *>(centroids), part_ids, static_cast<float *>(out));
+  LH_CHECK_HIP(hipGetLastError());
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                        const void *codebook, uint32_t m, uint32_t nbits, uint8_t *codes) {
+  LH_REQUIRE(ctx && x && codebook && codes, "pq_encode: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "pq_encode: only f32 is implemented in this version");
+  LH_TRY(check_pq_params(d, m, nbits));
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, static_cast<const float *>(x),
+                          (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                           const void *centroids, uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
+                           uint32_t *part_ids, uint8_t *codes, double *loss_out_host) {
+  LH_REQUIRE(ctx && x && centroids && codebook && part_ids && codes, "ivfpq_encode: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "ivfpq_encode: only f32 is implemented in this version");
+  LH_TRY(check_pq_params(d, m, nbits));
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (n == 0) { if (loss_out_host) *loss_out_host = 0.0; return LANCE_HIP_OK; }
+  const float *xs = static_cast<const float *>(x);
+  const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
+  if (metric == LANCE_HIP_COSINE) {
+    float *xn = ctx->scratch_t<float>("encode.norm", (size_t)n * d);
+    if (!xn) return LANCE_HIP_ENOMEM;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d, xn);
+    xs = xn;
+  }
+  float *dists = ctx->scratch_t<float>("encode.dists", (size_t)n);
+  if (!dists) return LANCE_HIP_ENOMEM;
+  PairwiseArgs pa;
+  pa.x = xs; pa.n = (int64_t)n; pa.ldx = d;
+  pa.cent = static_cast<const float *>(centroids); pa.k = (int)nlist;
+  pa.ids = part_ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
+  LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
+  hipLaunchKernelGGL(finite_mask_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d, part_ids);
+  const float *enc_in = xs;
+  if (scan_metric == LANCE_HIP_L2) {
+    float *res = ctx->scratch_t<float>("encode.residual", (size_t)n * d);
+    if (!res) return LANCE_HIP_ENOMEM;
+    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(n * d, 256), 65536);
+    hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d,
+                       static_cast<const float *>(centroids), part_ids, res);
+    enc_in = res;
+  }
+  LH_TRY(pq_encode_launch(ctx, scan_metric, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes));
+  LH_CHECK_HIP(hipGetLastError());
+  if (loss_out_host) {
+    // sum of the assignment distances (compute_partitions, kmeans.rs:1276-1290): f64, host side
+    std::vector<float> dh(n);
+    std::vector<uint32_t> ph(n);
+    LH_CHECK_HIP(hipMemcpyAsync(dh.data(), dists, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipMemcpyAsync(ph.data(), part_ids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<double> losses(nlist, 0.0);
+    for (uint64_t r = 0; r < n; ++r)
+      if (ph[r] != LANCE_HIP_NONE) losses[ph[r]] += (double)dh[r];
+    double tot = 0.0;
+    for (uint32_t c = 0; c < nlist; ++c) tot = tot + losses[c];
+    *loss_out_host = tot;
+  }
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,
+                              const void *codebook, uint32_t m, uint32_t nbits, lance_hip_index **out) {
+  LH_REQUIRE(ctx && centroids && codebook && out, "index: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "index: only f32 is implemented in this version");
+  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_COSINE || metric == LANCE_HIP_DOT, "index: bad metric %d", metric);
+  LH_REQUIRE(nlist > 0 && nlist <= 8192, "index: nlist=%u not supported in this version (1..8192)", nlist);
+  LH_TRY(check_pq_params(d, m, nbits));
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  auto *ix = new lance_hip_index();
+  ix->device = ctx->device; ix->metric = metric; ix->d = d; ix->nlist = nlist; ix->m = m; ix->nbits = nbits;
+  int r = dev_dup(ctx, centroids, (size_t)nlist * d * 4, reinterpret_cast<void **>(&ix->centroids));
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, codebook, (size_t)m * 256 * (d / m) * 4, reinterpret_cast<void **>(&ix->codebook));
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)(nlist + 1) * 4, reinterpret_cast<void **>(&ix->part_offsets));
+  if (r != LANCE_HIP_OK) { delete ix; return r; }
+  *out = ix;
+  return LANCE_HIP_OK;
+}
+
+static int index_finish_offsets(lance_hip_ctx *ctx, lance_hip_index *ix) {
+  ix->part_offsets_h.resize(ix->nlist + 1);
+  LH_CHECK_HIP(hipMemcpyAsync(ix->part_offsets_h.data(), ix->part_offsets, (size_t)(ix->nlist + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  ix->max_part = 0;
+  for (uint32_t p = 0; p < ix->nlist; ++p)
+    ix->max_part = std::max(ix->max_part, ix->part_offsets_h[p + 1] - ix->part_offsets_h[p]);
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_index_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,
+                           const void *codebook, uint32_t m, uint32_t nbits, const uint32_t *part_ids,
+                           const uint8_t *codes, const uint64_t *row_ids, uint64_t n, lance_hip_index **out) {
+  LH_REQUIRE(part_ids && codes, "index_create: NULL argument");
+  LH_REQUIRE(n < (1ull << 32), "index_create: n too large for this version");
+  lance_hip_index *ix = nullptr;
+  LH_TRY(index_alloc_common(ctx, dtype, metric, d, centroids, nlist, codebook, m, nbits, &ix));
+  uint32_t *perm = ctx->scratch_t<uint32_t>("index.perm", (size_t)(n ? n : 1));
+  int r = perm ? LANCE_HIP_OK : LANCE_HIP_ENOMEM;
+  if (r == LANCE_HIP_OK) r = stable_group(ctx, part_ids, (int64_t)n, (int64_t)n, (int)nlist, 1, ix->part_offsets, perm, (int64_t)n, nullptr);
+  if (r == LANCE_HIP_OK) r = index_finish_offsets(ctx, ix);
+  if (r == LANCE_HIP_OK) {
+    ix->n = ix->part_offsets_h[nlist];
+    r = dev_dup(ctx, nullptr, (size_t)ix->n * m, reinterpret_cast<void **>(&ix->codes));
+    if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)ix->n * 8, reinterpret_cast<void **>(&ix->row_ids));
+  }
+  if (r == LANCE_HIP_OK && ix->n > 0) {
+    hipLaunchKernelGGL(gather_codes_kernel, dim3((unsigned)cdiv(ix->n, 256)), dim3(256), 0, ctx->stream, codes, row_ids, perm,
+                       (int64_t)ix->n, (int)m, ix->codes, ix->row_ids);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      set_error("index_create: gather kernel failed");
+      r = LANCE_HIP_ERUNTIME;
+    }
+  }
+  if (r != LANCE_HIP_OK) { delete ix; return r; }
+  *out = ix;
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_index_from_storage(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids,
+                                 uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
+                                 const uint32_t *part_offsets_host, const uint8_t *codes, int transposed,
+                                 const uint64_t *row_ids, uint64_t n, lance_hip_index **out) {
+  LH_REQUIRE(part_offsets_host && (n == 0 || (codes && row_ids)), "index_from_storage: NULL argument");
+  LH_REQUIRE(part_offsets_host[0] == 0 && part_offsets_host[nlist] == n, "index_from_storage: offsets do not cover n rows");
+  lance_hip_index *ix = nullptr;
+  LH_TRY(index_alloc_common(ctx, dtype, metric, d, centroids, nlist, codebook, m, nbits, &ix));
+  int r = LANCE_HIP_OK;
+  ix->n = n;
+  if (hipMemcpyAsync(ix->part_offsets, part_offsets_host, (size_t)(nlist + 1) * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) r = LANCE_HIP_ERUNTIME;
+  if (r == LANCE_HIP_OK) r = index_finish_offsets(ctx, ix);
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, transposed ? nullptr : codes, (size_t)n * m, reinterpret_cast<void **>(&ix->codes));
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, row_ids, (size_t)n * 8, reinterpret_cast<void **>(&ix->row_ids));
+  if (r == LANCE_HIP_OK && transposed && n > 0) {
+    hipLaunchKernelGGL(retile_codes_kernel, dim3((unsigned)cdiv(n * m, 256)), dim3(256), 0, ctx->stream, codes, ix->codes,
+                       (int64_t)n, (int)m, ix->part_offsets, (int)nlist, 0);
+    if (hipGetLastError() != hipSuccess) r = LANCE_HIP_ERUNTIME;
+  }
+  if (r == LANCE_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = LANCE_HIP_ERUNTIME;
+  if (r != LANCE_HIP_OK) { if (r == LANCE_HIP_ERUNTIME) set_error("index_from_storage: HIP failure"); delete ix; return r; }
+  *out = ix;
+  return LANCE_HIP_OK;
+}
+
+void lance_hip_index_destroy(lance_hip_index *idx) { delete idx; }
+
+int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw) {
+  LH_REQUIRE(idx, "index is NULL");
+  idx->raw = static_cast<const float *>(x);
+  idx->n_raw = n_raw;
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_index_info(const lance_hip_index *idx, uint64_t *n_rows, uint32_t *nlist, uint32_t *m, uint32_t *d) {
+  LH_REQUIRE(idx, "index is NULL");
+  if (n_rows) *n_rows = idx->n;
+  if (nlist) *nlist = idx->nlist;
+  if (m) *m = idx->m;
+  if (d) *d = idx->d;
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_index_export(lance_hip_ctx *ctx, const lance_hip_index *idx, uint32_t *part_offsets_host,
+                           uint8_t *codes_transposed_host, uint64_t *row_ids_host) {
+  LH_REQUIRE(ctx && idx, "index_export: NULL argument");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (part_offsets_host) memcpy(part_offsets_host, idx->part_offsets_h.data(), (size_t)(idx->nlist + 1) * 4);
+  if (codes_transposed_host && idx->n > 0) {
+    uint8_t *tmp = ctx->scratch_t<uint8_t>("index.export", (size_t)idx->n * idx->m);
+    if (!tmp) return LANCE_HIP_ENOMEM;
+    hipLaunchKernelGGL(retile_codes_kernel, dim3((unsigned)cdiv(idx->n * idx->m, 256)), dim3(256), 0, ctx->stream, idx->codes, tmp,
+                       (int64_t)idx->n, (int)idx->m, idx->part_offsets, (int)idx->nlist, 1);
+    LH_CHECK_HIP(hipGetLastError());
+    LH_CHECK_HIP(hipMemcpyAsync(codes_transposed_host, tmp, (size_t)idx->n * idx->m, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (row_ids_host && idx->n > 0)
+    LH_CHECK_HIP(hipMemcpyAsync(row_ids_host, idx->row_ids, (size_t)idx->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+}  // extern "C"

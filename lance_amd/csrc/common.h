@@ -1,0 +1,80 @@
+// common.h -- context, error channel, scratch arena, launch helpers (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lance_hip.h"
+
+namespace lh {
+
+void set_error(const char *fmt, ...);
+
+#define LH_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      lh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return LANCE_HIP_ERUNTIME;                                                        \
+    }                                                                                   \
+  } while (0)
+
+#define LH_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      lh::set_error(__VA_ARGS__);  \
+      return LANCE_HIP_EINVAL;     \
+    }                              \
+  } while (0)
+
+#define LH_TRY(expr)              \
+  do {                            \
+    int _r = (expr);              \
+    if (_r != LANCE_HIP_OK) return _r; \
+  } while (0)
+
+struct KernelTimer {
+  double ms = 0.0;
+  uint64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace lh
+
+// Grow-only device scratch: named slots so that steady-state calls never hipMalloc.
+struct lance_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  int num_cus = 256;
+  std::map<std::string, std::pair<void *, size_t>> slots;
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  bool timing = false;
+  std::map<std::string, lh::KernelTimer> timers;
+
+  // returns nullptr on failure (error set)
+  void *scratch(const char *name, size_t bytes);
+  void *host_staging(size_t bytes);
+  template <typename T>
+  T *scratch_t(const char *name, size_t count) {
+    return reinterpret_cast<T *>(scratch(name, count * sizeof(T)));
+  }
+  void time_begin(const char *kernel);
+  void time_end(const char *kernel);
+};
+
+namespace lh {
+struct ScopedTimer {
+  lance_hip_ctx *c; const char *k;
+  ScopedTimer(lance_hip_ctx *c_, const char *k_) : c(c_), k(k_) { if (c->timing) c->time_begin(k); }
+  ~ScopedTimer() { if (c->timing) c->time_end(k); }
+};
+inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+}  // namespace lh

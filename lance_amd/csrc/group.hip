@@ -1,0 +1,146 @@
+// group.hip -- stable group-by of row indices by a small integer key (cluster id).
+//
+// Used twice on the hot path:
+//   * k-means M-step (kmeans.rs:371-446): the reference sums each centroid's members
+//     SEQUENTIALLY IN ROW ORDER in the element type, so bit-exact centroids need each
+//     cluster's member list in ascending row order;
+//   * shuffle / per-partition storage (v3/shuffler.rs:105-218, builder.rs:685-846):
+//     rows grouped by IVF partition, canonical (stable) order inside a partition.
+// Three kernels: per-block histogram -> exclusive scan over [key][block] -> stable scatter
+// using wave ballots as a match-any (ranks inside a 64-row chunk are popcounts of the lanes
+// below with the same key, so the output order is deterministic and stable).
+#include "common.h"
+#include "kernels.h"
+
+namespace lh {
+
+constexpr int GROUP_ROWS_PER_BLOCK = 1024;  // one wave, 16 chunks of 64 rows
+
+__global__ __launch_bounds__(64) void group_hist_kernel(const uint32_t *__restrict__ ids, int64_t n, int64_t id_stride,
+                                                        int k, int nblocks, uint32_t *__restrict__ blockhist,
+                                                        const uint8_t *__restrict__ active) {
+  extern __shared__ uint32_t hist[];
+  const int b = blockIdx.y;
+  if (active && !active[b]) return;
+  const int blk = blockIdx.x;
+  for (int c = threadIdx.x; c < k; c += 64) hist[c] = 0;
+  __syncthreads();
+  const uint32_t *idb = ids + (int64_t)b * id_stride;
+  const int64_t r0 = (int64_t)blk * GROUP_ROWS_PER_BLOCK;
+  for (int ch = 0; ch < GROUP_ROWS_PER_BLOCK / 64; ++ch) {
+    const int64_t r = r0 + ch * 64 + threadIdx.x;
+    if (r < n) {
+      const uint32_t key = idb[r];
+      if (key < (uint32_t)k) atomicAdd(&hist[key], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t *out = blockhist + (int64_t)b * k * nblocks;
+  for (int c = threadIdx.x; c < k; c += 64) out[(int64_t)c * nblocks + blk] = hist[c];
+}
+
+// exclusive scan of k*nblocks entries (key-major), one workgroup per batch entry.
+__global__ __launch_bounds__(256) void group_scan_kernel(uint32_t *__restrict__ blockhist, int k, int nblocks,
+                                                         uint32_t *__restrict__ starts,
+                                                         const uint8_t *__restrict__ active) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
+  const int b = blockIdx.x;
+  if (active && !active[b]) return;
+  uint32_t *h = blockhist + (int64_t)b * k * nblocks;
+  uint32_t *st = starts + (int64_t)b * (k + 1);
+  const int64_t total = (int64_t)k * nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < total; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t v = i < total ? h[i] : 0;
+    // inclusive scan within the wave
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint32_t carry = carry_s;
+    const uint32_t excl = carry + woff + incl - v;
+    if (i < total) {
+      h[i] = excl;
+      if (i % nblocks == 0) st[i / nblocks] = excl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st[k] = carry_s;
+}
+
+__global__ __launch_bounds__(64) void group_scatter_kernel(const uint32_t *__restrict__ ids, int64_t n, int64_t id_stride,
+                                                           int k, int kbits, int nblocks,
+                                                           const uint32_t *__restrict__ blockoffs,
+                                                           uint32_t *__restrict__ sorted_rows, int64_t out_stride,
+                                                           const uint8_t *__restrict__ active) {
+  extern __shared__ uint32_t cursor[];
+  const int b = blockIdx.y;
+  if (active && !active[b]) return;
+  const int blk = blockIdx.x;
+  const uint32_t *offs = blockoffs + (int64_t)b * k * nblocks;
+  for (int c = threadIdx.x; c < k; c += 64) cursor[c] = offs[(int64_t)c * nblocks + blk];
+  __syncthreads();
+  const uint32_t *idb = ids + (int64_t)b * id_stride;
+  uint32_t *outb = sorted_rows + (int64_t)b * out_stride;
+  const int lane = threadIdx.x;
+  const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t r0 = (int64_t)blk * GROUP_ROWS_PER_BLOCK;
+  for (int ch = 0; ch < GROUP_ROWS_PER_BLOCK / 64; ++ch) {
+    const int64_t r = r0 + ch * 64 + lane;
+    uint32_t key = LANCE_HIP_NONE;
+    if (r < n) key = idb[r];
+    const bool valid = key < (uint32_t)k;
+    uint64_t mask = __ballot(valid);
+    for (int bit = 0; bit < kbits; ++bit) {
+      const bool one = (key >> bit) & 1u;
+      const uint64_t bal = __ballot(one);
+      mask &= one ? bal : ~bal;
+    }
+    uint32_t base = 0;
+    if (valid) base = cursor[key];
+    __syncthreads();
+    if (valid) {
+      const uint32_t rank = (uint32_t)__popcll(mask & below);
+      outb[base + rank] = (uint32_t)r;
+      if (rank == 0) cursor[key] = base + (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+  }
+}
+
+// ids: [batches][n] (stride id_stride) keys in [0,k) or NONE.  Outputs per batch:
+// starts[k+1] (exclusive offsets, starts[k] = number of grouped rows) and sorted_rows
+// (row indices grouped by key, ascending inside a group).
+int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_stride, int k, int batches,
+                 uint32_t *starts, uint32_t *sorted_rows, int64_t out_stride, const uint8_t *active) {
+  LH_REQUIRE(k > 0 && k <= 16384, "stable_group: k=%d not supported (1..16384)", k);
+  LH_REQUIRE(n < (1ll << 32), "stable_group: n too large");
+  if (batches == 0) return LANCE_HIP_OK;
+  const int nblocks = (int)cdiv(n > 0 ? n : 1, GROUP_ROWS_PER_BLOCK);
+  uint32_t *blockhist = ctx->scratch_t<uint32_t>("group.blockhist", (size_t)batches * k * nblocks);
+  if (!blockhist) return LANCE_HIP_ENOMEM;
+  int kbits = 0;
+  while ((1 << kbits) < k) ++kbits;
+  const size_t lds = (size_t)k * sizeof(uint32_t);
+  hipLaunchKernelGGL(group_hist_kernel, dim3(nblocks, batches), dim3(64), lds, ctx->stream, ids, n, id_stride, k,
+                     nblocks, blockhist, active);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(batches), dim3(256), 0, ctx->stream, blockhist, k, nblocks, starts, active);
+  hipLaunchKernelGGL(group_scatter_kernel, dim3(nblocks, batches), dim3(64), lds, ctx->stream, ids, n, id_stride, k,
+                     kbits, nblocks, blockhist, sorted_rows, out_stride, active);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh

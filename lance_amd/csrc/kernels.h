@@ -1,0 +1,46 @@
+// kernels.h -- internal launcher prototypes shared by the translation units.
+#pragma once
+#include <stdint.h>
+
+#include "common.h"
+
+namespace lh {
+
+// One operand per lane (rows of x), the other staged in LDS (centroids).
+// Batched views: batch b reads columns [b*x_batch_off, +d) of x (row stride ldx) against
+// centroid block cent + b*cent_batch_stride -- this is how the M PQ sub-quantisers run
+// in one launch (pq/builder.rs:109-138, pq.rs:146-166).
+struct PairwiseArgs {
+  const float *x = nullptr;
+  int64_t n = 0;
+  int64_t ldx = 0;
+  int x_batch_off = 0;
+  const float *cent = nullptr;
+  int k = 0;
+  int64_t cent_batch_stride = 0;
+  const float *bias = nullptr;
+  int64_t bias_batch_stride = 0;
+  uint32_t *ids = nullptr;
+  float *dists = nullptr;
+  int64_t out_batch_stride = 0;
+  uint8_t *codes = nullptr;  // codes[row*codes_ld + b] = id (0 if none), pq.rs:165
+  int codes_ld = 0;
+  float *matrix = nullptr;  // MODE 1: [b][n][k]
+  const uint8_t *active = nullptr;
+  bool x_aligned = false;
+  bool cent_aligned = false;
+};
+
+int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
+int launch_dist_matrix(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
+
+int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_stride, int k, int batches,
+                 uint32_t *starts, uint32_t *sorted_rows, int64_t out_stride, const uint8_t *active);
+
+int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int64_t ldx, int x_batch_off, int d,
+                         int k, int B, uint32_t max_iters, double tol, float balance_factor_scaled, bool have_init,
+                         const uint64_t *seeds, float *cent, double *loss_out, uint32_t *iters_out);
+
+int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
+
+}  // namespace lh

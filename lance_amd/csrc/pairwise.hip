@@ -1,0 +1,262 @@
+// pairwise.hip -- exact-order distance kernels with one operand per lane.
+//
+//   assign   : argmin over centroids           (kmeans.rs:317-369, :1350-1369; kernels.rs:79-111)
+//   matrix   : all distances row x centroid    (kmeans.rs:1134-1158 before the partial sort)
+//
+// Shape of every kernel here: each lane owns ONE row vector `a` held entirely in VGPRs
+// (compile-time D <= 128); the other operand (centroid / codebook tile) is staged in LDS
+// and read with wave-uniform addresses (broadcast ds_read_b128), so the inner loop is
+// pure packed-f32 VALU (v_pk_add_f32 / v_pk_mul_f32) fed by LDS broadcasts.  The work is
+// VALU-bound: 3 flops per element with no FMA allowed (bit parity with the reference's
+// un-fused l2_scalar); f32 MFMA runs at the same rate as the VALU on gfx950 and cannot
+// reproduce the (x-y)^2 lane order, so it is deliberately not used here.
+#include "common.h"
+#include "exact.cuh"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+template <int D>
+__device__ __forceinline__ void load_row(RegVec<D> &a, const float *__restrict__ src, bool aligned16) {
+  if constexpr (D % 4 == 0) {
+    if (aligned16) {
+#pragma unroll
+      for (int i = 0; i < D / 4; ++i) a.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RegVec<D>::Q * 4; ++i) a.q[i >> 2][i & 3] = i < D ? src[i] : 0.0f;
+}
+
+template <int D>
+__device__ __forceinline__ void zero_row(RegVec<D> &a) {
+#pragma unroll
+  for (int i = 0; i < RegVec<D>::Q; ++i) a.q[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// MODE 0: argmin  MODE 1: full distance matrix
+template <int D, int METRIC, int CT, int MODE>
+__global__ __launch_bounds__(256) void pairwise_kernel(PairwiseArgs p) {
+  __shared__ __attribute__((aligned(16))) float tile[CT * D];
+  const int b = blockIdx.y;
+  if (p.active && !p.active[b]) return;
+  const float *xb = p.x + (int64_t)b * p.x_batch_off;
+  const float *cb = p.cent + (int64_t)b * p.cent_batch_stride;
+  const float *biasb = p.bias ? p.bias + (int64_t)b * p.bias_batch_stride : nullptr;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = row < p.n;
+  RegVec<D> a;
+  if (valid) {
+    load_row<D>(a, xb + row * p.ldx, p.x_aligned);
+  } else {
+    zero_row<D>(a);
+  }
+  float minv = INFINITY, mino = INFINITY;
+  uint32_t mini = LANCE_HIP_NONE;
+  float *mrow = (MODE == 1 && valid) ? p.matrix + ((int64_t)b * p.n + row) * p.k : nullptr;
+
+  for (int c0 = 0; c0 < p.k; c0 += CT) {
+    const int ct = min(CT, p.k - c0);
+    __syncthreads();
+    // L2: stage -c so the inner loop is x + (-c) (see dist_exact BNEG)
+    constexpr bool NEG = METRIC != METRIC_DOT;
+    if (p.cent_aligned) {
+      for (int i = threadIdx.x * 4; i < ct * D; i += 256 * 4) {
+        const f4 v = *reinterpret_cast<const f4 *>(&cb[(int64_t)c0 * D + i]);
+        *reinterpret_cast<f4 *>(&tile[i]) = NEG ? -v : v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < ct * D; i += 256) tile[i] = NEG ? -cb[(int64_t)c0 * D + i] : cb[(int64_t)c0 * D + i];
+    }
+    __syncthreads();
+    if (valid) {
+      if constexpr (D <= 16) {
+#pragma unroll 4
+        for (int c = 0; c < ct; ++c) {
+          const float v = finish_metric<METRIC>(dist_exact<D, METRIC, METRIC != METRIC_DOT>(a, &tile[c * D]));
+          if constexpr (MODE == 1) {
+            mrow[c0 + c] = v;
+          } else {
+            const float vb = biasb ? v + biasb[c0 + c] : v;
+            if (vb < minv) { minv = vb; mino = v; mini = (uint32_t)(c0 + c); }
+          }
+        }
+      } else {
+        for (int c = 0; c < ct; ++c) {
+          const float v = finish_metric<METRIC>(dist_exact<D, METRIC, METRIC != METRIC_DOT>(a, &tile[c * D]));
+          if constexpr (MODE == 1) {
+            mrow[c0 + c] = v;
+          } else {
+            const float vb = biasb ? v + biasb[c0 + c] : v;
+            if (vb < minv) { minv = vb; mino = v; mini = (uint32_t)(c0 + c); }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    if (valid) {
+      if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = mini;
+      if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = mino;
+      if (p.codes) p.codes[row * p.codes_ld + b] = mini == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)mini;
+    }
+  }
+}
+
+// Generic dimension: `a` streamed from global in 16-chunks, 4 centroids per pass share
+// each chunk; centroid tile in dynamic LDS.  Same arithmetic order (16 lane sums).
+template <int METRIC, int MODE>
+__global__ __launch_bounds__(256) void pairwise_generic_kernel(PairwiseArgs p, int d, int ct_max) {
+  extern __shared__ __attribute__((aligned(16))) float gtile[];
+  const int b = blockIdx.y;
+  if (p.active && !p.active[b]) return;
+  const float *xb = p.x + (int64_t)b * p.x_batch_off;
+  const float *cb = p.cent + (int64_t)b * p.cent_batch_stride;
+  const float *biasb = p.bias ? p.bias + (int64_t)b * p.bias_batch_stride : nullptr;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = row < p.n;
+  const float *arow = xb + (valid ? row : 0) * p.ldx;
+  const int full = d / 16 * 16;
+  float minv = INFINITY, mino = INFINITY;
+  uint32_t mini = LANCE_HIP_NONE;
+  float *mrow = (MODE == 1 && valid) ? p.matrix + ((int64_t)b * p.n + row) * p.k : nullptr;
+
+  for (int c0 = 0; c0 < p.k; c0 += ct_max) {
+    const int ct = min(ct_max, p.k - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ct * d; i += 256) gtile[i] = cb[(int64_t)c0 * d + i];
+    __syncthreads();
+    if (!valid) continue;
+    for (int cc = 0; cc < ct; cc += 4) {
+      const int nc = min(4, ct - cc);
+      float sums[4][16];
+      float rem[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rem[q] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sums[q][i] = 0.0f;
+      }
+      for (int i = full; i < d; ++i) {
+        const float av = arow[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < nc) {
+            const float bv = gtile[(cc + q) * d + i];
+            if constexpr (METRIC == METRIC_DOT) {
+              rem[q] = rem[q] + av * bv;
+            } else {
+              const float diff = av - bv;
+              rem[q] = rem[q] + diff * diff;
+            }
+          }
+        }
+      }
+      for (int j = 0; j < full; j += 16) {
+        float av[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[i] = arow[j + i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < nc) {
+            const float *bp = &gtile[(cc + q) * d + j];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              if constexpr (METRIC == METRIC_DOT) {
+                sums[q][i] += av[i] * bp[i];
+              } else {
+                const float diff = av[i] - bp[i];
+                sums[q][i] += diff * diff;
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < nc) {
+          float tot = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tot = tot + sums[q][i];
+          const float v = finish_metric<METRIC>(rem[q] + tot);
+          const int c = c0 + cc + q;
+          if constexpr (MODE == 1) {
+            mrow[c] = v;
+          } else {
+            const float vb = biasb ? v + biasb[c] : v;
+            if (vb < minv) { minv = vb; mino = v; mini = (uint32_t)c; }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    if (valid) {
+      if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = mini;
+      if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = mino;
+      if (p.codes) p.codes[row * p.codes_ld + b] = mini == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)mini;
+    }
+  }
+}
+
+template <int D, int MODE>
+static void launch_fixed(lance_hip_ctx *ctx, const PairwiseArgs &p, int metric, int batches) {
+  constexpr int CT = (8192 / D) > 256 ? 256 : (8192 / D);
+  dim3 grid((unsigned)cdiv(p.n, 256), batches);
+  if (metric == METRIC_DOT)
+    hipLaunchKernelGGL((pairwise_kernel<D, METRIC_DOT, CT, MODE>), grid, dim3(256), 0, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((pairwise_kernel<D, METRIC_L2, CT, MODE>), grid, dim3(256), 0, ctx->stream, p);
+}
+
+template <int MODE>
+static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric, int batches) {
+  if (p.n == 0 || batches == 0) return LANCE_HIP_OK;
+  LH_REQUIRE(p.k > 0, "pairwise: k must be > 0");
+  LH_REQUIRE(metric == METRIC_L2 || metric == METRIC_DOT, "pairwise: metric must be L2 or Dot (cosine = normalise + L2)");
+  p.x_aligned = ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.ldx % 4 == 0) && (p.x_batch_off % 4 == 0);
+  p.cent_aligned = ((reinterpret_cast<uintptr_t>(p.cent) & 15) == 0) && (((int64_t)p.cent_batch_stride) % 4 == 0) && (d % 4 == 0);
+  const char *tname = MODE == 0 ? "assign" : "dist_matrix";
+  ScopedTimer t(ctx, tname);
+  const bool fixed_ok = p.cent_aligned;  // LDS tile float4 reads in dist_exact need 16B-aligned rows
+  if (fixed_ok) {
+    switch (d) {
+      case 4: launch_fixed<4, MODE>(ctx, p, metric, batches); goto done;
+      case 8: launch_fixed<8, MODE>(ctx, p, metric, batches); goto done;
+      case 16: launch_fixed<16, MODE>(ctx, p, metric, batches); goto done;
+      case 32: launch_fixed<32, MODE>(ctx, p, metric, batches); goto done;
+      case 64: launch_fixed<64, MODE>(ctx, p, metric, batches); goto done;
+      case 96: launch_fixed<96, MODE>(ctx, p, metric, batches); goto done;
+      case 128: launch_fixed<128, MODE>(ctx, p, metric, batches); goto done;
+      default: break;
+    }
+  }
+  {
+    int ct = 8192 / d;
+    if (ct < 4) ct = 4;
+    if (ct > 256) ct = 256;
+    ct = ct / 4 * 4;
+    size_t lds = (size_t)ct * d * sizeof(float);
+    LH_REQUIRE(lds <= 160 * 1024, "pairwise: dimension %d too large", d);
+    dim3 grid((unsigned)cdiv(p.n, 256), batches);
+    if (metric == METRIC_DOT)
+      hipLaunchKernelGGL((pairwise_generic_kernel<METRIC_DOT, MODE>), grid, dim3(256), lds, ctx->stream, p, d, ct);
+    else
+      hipLaunchKernelGGL((pairwise_generic_kernel<METRIC_L2, MODE>), grid, dim3(256), lds, ctx->stream, p, d, ct);
+  }
+done:
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches) {
+  return launch_pairwise<0>(ctx, p, d, metric, batches);
+}
+int launch_dist_matrix(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches) {
+  return launch_pairwise<1>(ctx, p, d, metric, batches);
+}
+
+}  // namespace lh

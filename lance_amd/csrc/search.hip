@@ -1,0 +1,626 @@
+// search.hip -- the batched ANN query on the device.
+//
+//   find_partitions         ivf/storage.rs:107-119 -> kmeans_find_partitions kmeans.rs:1134-1158
+//   preprocess_query        lance/src/index/vector/ivf/v2.rs:316-332   (q - centroid[p])
+//   build_distance_table    pq/distance.rs:24-92                         (LUT [m][256] f32)
+//   compute_pq_distance     pq/distance.rs:109-144, pq/storage.rs:921-960 (sequential-m ADC)
+//   FlatIndex::search       flat/index.rs:82-177                         (per-partition top-k)
+//   SortExec(dist,rowid)    lance/src/dataset/scanner.rs:3440-3468       (global merge)
+//   refine                  scanner.rs:2884-2904,3336-3412
+//
+// Scan kernel design (query-major): one workgroup per (query, probe-split).  For each
+// probed partition it builds the residual LUT in LDS (exact l2_scalar order per entry),
+// then every lane streams rows of the partition: one 16-byte load of a row's PQ codes
+// (row-major codes, coalesced), m LDS gathers summed in m order (bit-equal to the
+// reference's transposed ADC), and a compare against the query's running threshold T.
+// Rows with key <= T are appended to an LDS candidate buffer; when the buffer fills, T is
+// tightened to a k-th-smallest bound computed from per-lane minima (wave bitonic sort +
+// rank merge), which keeps every row with key <= T.  The scan is LDS-gather-bound, the
+// codes stream from L2/Infinity Cache (16 MB for SIFT-1M), HBM only sees them once.
+//
+// Exactness: the final candidate list holds EVERY scanned row with dist <= T_final, so
+// sorting it by (dist, row id) reproduces the reference's global SortExec.  The one case
+// that depends on the reference's heap internals -- a single partition holding more than
+// k rows tied at the boundary distance -- is detected and flagged.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "exact.cuh"
+#include "index.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+constexpr int SCAN_CAP = 2048;    // LDS candidate buffer entries
+constexpr int SCAN_ROUND = 1024;  // rows per round (4 per lane)
+constexpr int SCAN_LCAP = 256;    // entries handed to the merge kernel per (query, split)
+constexpr int SCAN_MAX_KEFF = 128;
+constexpr uint32_t FLAG_OVERFLOW = 1u, FLAG_AMBIGUOUS = 2u;
+
+// ------------------------------------------------------------------------------------
+// bitonic sort of P (power of two) 64-bit keys in LDS with 256 threads
+__device__ __forceinline__ void bitonic_sort_u64(uint64_t *a, int P) {
+  for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P / 2; i += 256) {
+        const int ix = 2 * j * (i / j) + (i % j);
+        const int px = ix + j;
+        const bool up = (ix & k2) == 0;
+        const uint64_t x = a[ix], y = a[px];
+        if ((x > y) == up) { a[ix] = y; a[px] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// a14: per query, sort (dist, id) and keep the first nprobes
+__global__ __launch_bounds__(256) void select_probes_kernel(const float *__restrict__ matrix, int nlist, int P, int nprobes,
+                                                            uint32_t *__restrict__ part_ids, float *__restrict__ dists) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
+  const int q = blockIdx.x;
+  const float *row = matrix + (int64_t)q * nlist;
+  for (int i = threadIdx.x; i < P; i += 256)
+    skeys[i] = i < nlist ? ((uint64_t)order_key(row[i]) << 32) | (uint32_t)i : ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(skeys, P);
+  for (int i = threadIdx.x; i < nprobes; i += 256) {
+    const uint64_t e = skeys[i];
+    part_ids[(int64_t)q * nprobes + i] = (uint32_t)e;
+    if (dists) dists[(int64_t)q * nprobes + i] = key_to_float((uint32_t)(e >> 32));
+  }
+}
+
+// ------------------------------------------------------------------------------------
+struct ScanArgs {
+  const float *q;  // [nq][d], normalised for cosine
+  const uint32_t *probes;  // [nq][nprobes]
+  const float *centroids;
+  const float *codebook;
+  const uint32_t *part_offsets;
+  const uint8_t *codes;
+  int d, m, sd, nprobes, nsplit, keff;
+  int residual;  // 1: q - centroid (L2 / cosine), 0: dot
+  int has_range;
+  uint32_t lo_key, hi_key;
+  uint32_t *out_keys;  // [nq*nsplit][SCAN_LCAP]
+  uint32_t *out_pos;
+  uint32_t *out_cnt;  // [nq*nsplit]
+  uint32_t *flags;    // [nq]
+};
+
+struct ScanShared {
+  float *r;
+  float *lut;
+  uint32_t *ckey;
+  uint32_t *cpos;
+  uint32_t *sorted;  // 256
+  uint32_t *misc;    // [0]=count [1]=T [2]=Tnew [3]=flags
+};
+
+// k-th smallest (0-based rank kk) of the 256 per-thread values `v`; result broadcast via misc[2]
+__device__ __forceinline__ void kth_smallest_256(uint32_t v, int kk, const ScanShared &s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave-level bitonic sort (ascending by lane)
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const uint32_t o = __shfl_xor(v, j, 64);
+      const bool up = (lane & k2) == 0;
+      const bool lower = (lane & j) == 0;
+      v = (lower == up) ? min(v, o) : max(v, o);
+    }
+  }
+  s.sorted[threadIdx.x] = v;
+  __syncthreads();
+  // global rank with ties ordered by (run, position)
+  int rank = lane;
+  for (int w = 0; w < 4; ++w) {
+    if (w == wave) continue;
+    const uint32_t *run = s.sorted + w * 64;
+    int lo = 0, hi = 64;  // first index with run[i] > v (w < wave) or run[i] >= v (w > wave)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const bool before = w < wave ? run[mid] <= v : run[mid] < v;
+      if (before) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  if (rank == kk) s.misc[2] = v;
+  __syncthreads();
+}
+
+// Tighten the running threshold: T <- upper bound of the keff-th smallest key in the buffer
+// (exact when the buffer holds <= 256 entries), then drop entries with key > T.
+__device__ __forceinline__ void tighten(const ScanShared &s, int keff) {
+  __syncthreads();
+  const int c = min((int)s.misc[0], SCAN_CAP);
+  if (c < keff) return;  // uniform
+  uint32_t ek[SCAN_CAP / 256], ep[SCAN_CAP / 256];
+  uint32_t mymin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < SCAN_CAP / 256; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    ek[j] = 0xFFFFFFFFu; ep[j] = 0;
+    if (i < c) { ek[j] = s.ckey[i]; ep[j] = s.cpos[i]; mymin = min(mymin, ek[j]); }
+  }
+  kth_smallest_256(mymin, keff - 1, s);
+  const uint32_t tnew = s.misc[2];
+  __syncthreads();
+  if (threadIdx.x == 0) { s.misc[0] = 0; s.misc[1] = tnew; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SCAN_CAP / 256; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i < c && ek[j] <= tnew) {
+      const uint32_t slot = atomicAdd(&s.misc[0], 1u);
+      s.ckey[slot] = ek[j]; s.cpos[slot] = ep[j];
+    }
+  }
+  __syncthreads();
+}
+
+template <int SD, int METRIC, int MU>
+__global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ScanShared s;
+  const int dpad = (p.d + 3) & ~3;
+  s.r = reinterpret_cast<float *>(smem);
+  s.lut = s.r + dpad;
+  s.ckey = reinterpret_cast<uint32_t *>(s.lut + p.m * 256);
+  s.cpos = s.ckey + SCAN_CAP;
+  s.sorted = s.cpos + SCAN_CAP;
+  s.misc = s.sorted + 256;
+
+  const int qi = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit;
+  const float *qv = p.q + (int64_t)qi * p.d;
+  if (threadIdx.x == 0) { s.misc[0] = 0; s.misc[1] = 0xFFFFFFFFu; s.misc[3] = 0; }
+  __syncthreads();
+  const int m = MU > 0 ? MU * 16 : p.m;
+  const int sd = SD > 0 ? SD : p.sd;
+
+  for (int pi = sp; pi < p.nprobes; pi += p.nsplit) {
+    const uint32_t part = p.probes[(int64_t)qi * p.nprobes + pi];
+    const uint32_t off = p.part_offsets[part];
+    const int np = (int)(p.part_offsets[part + 1] - off);
+    if (np == 0) continue;
+    __syncthreads();  // previous partition's LUT readers are done
+    // v2.rs:316-332 residual query
+    for (int t = threadIdx.x; t < p.d; t += 256)
+      s.r[t] = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+    __syncthreads();
+    // pq/distance.rs:24-92: LUT[mm][c] = dist(q_sub[mm], codebook[mm][c]) in l2_scalar / dot_scalar order
+    for (int idx = threadIdx.x; idx < m * 256; idx += 256) {
+      const int mm = idx >> 8;
+      float v;
+      if constexpr (SD > 0) {
+        RegVec<SD> a;
+#pragma unroll
+        for (int i = 0; i < RegVec<SD>::Q; ++i) a.q[i] = *reinterpret_cast<const f4 *>(&s.r[mm * SD + 4 * i]);
+        v = dist_exact<SD, METRIC>(a, p.codebook + (int64_t)idx * SD);
+      } else {
+        v = dist_exact_rt<METRIC>(&s.r[mm * sd], p.codebook + (int64_t)idx * sd, sd);
+      }
+      s.lut[idx] = finish_metric<METRIC>(v);
+    }
+    __syncthreads();
+
+    const uint8_t *pcodes = p.codes + (int64_t)off * m;
+    for (int base = 0; base < np; base += SCAN_ROUND) {
+      if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);  // uniform: misc[0] stable after the barrier
+      const uint32_t T = s.misc[1];
+#pragma unroll
+      for (int u = 0; u < SCAN_ROUND / 256; ++u) {
+        const int row = base + u * 256 + threadIdx.x;
+        if (row < np) {
+          float dist = 0.0f;  // pq/distance.rs:128-141: distances start at 0.0, += table[code] for m = 0..M-1
+          if constexpr (MU > 0) {
+#pragma unroll
+            for (int w = 0; w < MU; ++w) {
+              const uint4 cw = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * (MU * 16) + w * 16);
+              const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) dist += s.lut[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+            }
+          } else {
+            const uint8_t *rc = pcodes + (int64_t)row * m;
+            for (int mm = 0; mm < m; ++mm) dist += s.lut[mm * 256 + rc[mm]];
+          }
+          if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);  // pq/storage.rs:949-957
+          const uint32_t key = order_key(dist);
+          const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);  // flat/index.rs:98-105
+          if (in_range && key <= T) {
+            const uint32_t slot = atomicAdd(&s.misc[0], 1u);
+            if (slot < SCAN_CAP) { s.ckey[slot] = key; s.cpos[slot] = off + (uint32_t)row; }
+            else s.misc[3] = FLAG_OVERFLOW;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // final: shrink to <= LCAP entries (exact threshold once <= 256 entries remain)
+  __syncthreads();
+  for (int iter = 0; iter < 8 && (int)s.misc[0] > SCAN_LCAP; ++iter) tighten(s, p.keff);
+  __syncthreads();
+  int c = min((int)s.misc[0], SCAN_CAP);
+  uint32_t fl = s.misc[3];
+  if (c > SCAN_LCAP) { c = SCAN_LCAP; fl |= FLAG_OVERFLOW; }
+  const int64_t ob = (int64_t)blockIdx.x * SCAN_LCAP;
+  for (int i = threadIdx.x; i < c; i += 256) { p.out_keys[ob + i] = s.ckey[i]; p.out_pos[ob + i] = s.cpos[i]; }
+  if (threadIdx.x == 0) {
+    p.out_cnt[blockIdx.x] = (uint32_t)c;
+    if (fl) atomicOr(&p.flags[qi], fl);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+struct MergeArgs {
+  const uint32_t *keys, *pos, *cnt;  // per (query, split)
+  const uint64_t *row_ids;
+  const uint32_t *part_offsets;
+  int nlist, nsplit, keff, k, P;
+  int refine;             // 1: write candidates for the refine kernel
+  uint64_t *out_ids;      // [nq][k]     (refine == 0)
+  float *out_dists;
+  uint64_t *cand_rid;     // [nq][keff]  (refine == 1)
+  uint32_t *cand_cnt;     // [nq]
+  uint32_t *flags;
+};
+
+__device__ __forceinline__ uint32_t find_partition_dev(const uint32_t *__restrict__ offs, int nlist, uint32_t slot) {
+  int lo = 0, hi = nlist;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offs[mid] <= slot) lo = mid; else hi = mid;
+  }
+  return (uint32_t)lo;
+}
+
+// sort entries by (key, rowid) -- the SortExec order -- with pos as payload
+__device__ __forceinline__ void bitonic_sort_kr(uint32_t *key, uint64_t *rid, uint32_t *pos, int P) {
+  for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P / 2; i += 256) {
+        const int ix = 2 * j * (i / j) + (i % j);
+        const int px = ix + j;
+        const bool up = (ix & k2) == 0;
+        const uint32_t kx = key[ix], ky = key[px];
+        const uint64_t rx = rid[ix], ry = rid[px];
+        const bool gt = kx > ky || (kx == ky && rx > ry);
+        if (gt == up) {
+          key[ix] = ky; key[px] = kx; rid[ix] = ry; rid[px] = rx;
+          const uint32_t t = pos[ix]; pos[ix] = pos[px]; pos[px] = t;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ivfpq_merge_kernel(MergeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
+  uint32_t *key = reinterpret_cast<uint32_t *>(rid + p.P);
+  uint32_t *pos = key + p.P;
+  __shared__ int s_total, s_amb;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) { s_total = 0; s_amb = 0; }
+  for (int i = threadIdx.x; i < p.P; i += 256) { key[i] = 0xFFFFFFFFu; rid[i] = ~0ull; pos[i] = 0; }
+  __syncthreads();
+  for (int sp = 0; sp < p.nsplit; ++sp) {
+    const int blk = q * p.nsplit + sp;
+    const int c = (int)p.cnt[blk];
+    const int base = s_total;
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) {
+      const uint32_t ps = p.pos[(int64_t)blk * SCAN_LCAP + i];
+      key[base + i] = p.keys[(int64_t)blk * SCAN_LCAP + i];
+      pos[base + i] = ps;
+      rid[base + i] = p.row_ids[ps];
+    }
+    if (threadIdx.x == 0) s_total = base + c;
+    __syncthreads();
+  }
+  const int total = s_total;
+  bitonic_sort_kr(key, rid, pos, p.P);
+  const int got = min(total, p.keff);
+  // tie check: more rows at the boundary distance than fit?
+  if (total > p.keff && key[p.keff] == key[p.keff - 1]) {
+    const uint32_t tf = key[p.keff - 1];
+    // L = entries with key <= tf (sorted prefix)
+    int lo = p.keff, hi = total;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= tf) lo = mid + 1; else hi = mid; }
+    const int L = lo;
+    for (int i = threadIdx.x; i < L; i += 256) {
+      const uint32_t pi = find_partition_dev(p.part_offsets, p.nlist, pos[i]);
+      const uint32_t a = p.part_offsets[pi], b = p.part_offsets[pi + 1];
+      int same = 0;
+      for (int j = 0; j < L; ++j) same += (pos[j] >= a && pos[j] < b) ? 1 : 0;
+      if (same > p.keff) s_amb = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_amb) atomicOr(&p.flags[q], FLAG_AMBIGUOUS);
+  }
+  if (p.refine) {
+    for (int i = threadIdx.x; i < p.keff; i += 256) p.cand_rid[(int64_t)q * p.keff + i] = i < got ? rid[i] : ~0ull;
+    if (threadIdx.x == 0) p.cand_cnt[q] = (uint32_t)got;
+  } else {
+    for (int i = threadIdx.x; i < p.k; i += 256) {
+      p.out_ids[(int64_t)q * p.k + i] = i < got ? rid[i] : ~0ull;
+      p.out_dists[(int64_t)q * p.k + i] = i < got ? key_to_float(key[i]) : INFINITY;
+    }
+  }
+}
+
+// refine: exact distance of the original query to the raw vectors of the candidates, then
+// (dist, rowid) order, fetch k  (scanner.rs:2884-2904 take + flat_knn :3336-3412)
+template <int METRIC>
+__global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const float *__restrict__ raw,
+                                                     uint64_t n_raw, const uint64_t *__restrict__ cand_rid,
+                                                     const uint32_t *__restrict__ cand_cnt, int keff, int k, int P,
+                                                     uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
+  uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
+  uint32_t *pos = key + P;
+  const int qi = blockIdx.x;
+  const int c = (int)cand_cnt[qi];
+  const float *qv = q + (int64_t)qi * d;
+  for (int i = threadIdx.x; i < P; i += 256) {
+    uint32_t kk = 0xFFFFFFFFu;
+    uint64_t r = ~0ull;
+    if (i < c) {
+      r = cand_rid[(int64_t)qi * keff + i];
+      if (r < n_raw) kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, raw + r * d, d)));
+    }
+    key[i] = kk; rid[i] = r; pos[i] = 0;
+  }
+  __syncthreads();
+  bitonic_sort_kr(key, rid, pos, P);
+  const int got = min(c, k);
+  for (int i = threadIdx.x; i < k; i += 256) {
+    out_ids[(int64_t)qi * k + i] = i < got ? rid[i] : ~0ull;
+    out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(key[i]) : INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+template <int SD, int METRIC>
+static void launch_scan_mu(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t lds) {
+  const int mu = (a.m % 16 == 0) ? a.m / 16 : 0;
+  switch (mu) {
+    case 1: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 1>), dim3(grid), dim3(256), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 2>), dim3(grid), dim3(256), lds, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 4>), dim3(grid), dim3(256), lds, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 6>), dim3(grid), dim3(256), lds, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 0>), dim3(grid), dim3(256), lds, ctx->stream, a); break;
+  }
+}
+
+template <int METRIC>
+static void launch_scan(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t lds) {
+  const bool cb_aligned = (reinterpret_cast<uintptr_t>(a.codebook) & 15) == 0;
+  const bool codes_aligned = (reinterpret_cast<uintptr_t>(a.codes) & 15) == 0;
+  if (cb_aligned && codes_aligned) {
+    switch (a.sd) {
+      case 4: launch_scan_mu<4, METRIC>(ctx, a, grid, lds); return;
+      case 8: launch_scan_mu<8, METRIC>(ctx, a, grid, lds); return;
+      case 16: launch_scan_mu<16, METRIC>(ctx, a, grid, lds); return;
+      default: break;
+    }
+  }
+  ScanArgs b = a;
+  hipLaunchKernelGGL((ivfpq_scan_kernel<0, METRIC, 0>), dim3(grid), dim3(256), lds, ctx->stream, b);
+}
+
+// The whole query pipeline, enqueued on ctx->stream.  flags_out: device [nq] (zeroed here).
+int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
+                         uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
+                         uint64_t *ids, float *dists, uint32_t **flags_out) {
+  LH_REQUIRE(k > 0, "search: k must be > 0");
+  if (nprobes > ix->nlist) nprobes = ix->nlist;
+  LH_REQUIRE(nprobes > 0, "search: nprobes must be > 0");
+  const uint32_t rf = refine_factor == 0 ? 1 : refine_factor;
+  const uint32_t keff = k * rf;
+  LH_REQUIRE(keff <= (uint32_t)SCAN_MAX_KEFF, "search: k * refine_factor = %u > %d is not supported in this version", keff, SCAN_MAX_KEFF);
+  const bool do_refine = refine_factor >= 1;  // Some(rf): re-rank even when rf == 1 (scanner.rs:2884)
+  LH_REQUIRE(!do_refine || ix->raw != nullptr, "search: refine_factor needs raw vectors (lance_hip_index_set_raw)");
+  LH_REQUIRE(!(do_refine && ix->metric == LANCE_HIP_COSINE), "search: refine on a cosine index is not implemented in this version");
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
+  const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
+
+  uint32_t *flags = ctx->scratch_t<uint32_t>("search.flags", nq);
+  if (!flags) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)nq * 4, ctx->stream));
+  if (flags_out) *flags_out = flags;
+  if (nq == 0) return LANCE_HIP_OK;
+
+  const float *qs = q;
+  if (ix->metric == LANCE_HIP_COSINE) {  // knn.rs:495-498
+    float *qn = ctx->scratch_t<float>("search.qnorm", (size_t)nq * d);
+    if (!qn) return LANCE_HIP_ENOMEM;
+    LH_TRY(launch_normalize(ctx, q, (int64_t)nq, d, qn));
+    qs = qn;
+  }
+  // coarse quantiser: all distances, then per-query partial sort
+  float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
+  uint32_t *probes = ctx->scratch_t<uint32_t>("search.probes", (size_t)nq * nprobes);
+  if (!matrix || !probes) return LANCE_HIP_ENOMEM;
+  {
+    PairwiseArgs pa;
+    pa.x = qs; pa.n = nq; pa.ldx = d; pa.cent = ix->centroids; pa.k = nlist; pa.matrix = matrix;
+    LH_TRY(launch_dist_matrix(ctx, pa, d, scan_metric, 1));
+    ScopedTimer t(ctx, "select_probes");
+    const int P = next_pow2(nlist);
+    hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, nlist, P, (int)nprobes,
+                       probes, (float *)nullptr);
+  }
+  // scan
+  int nsplit = 1;
+  if (nq < (uint32_t)(2 * ctx->num_cus)) {
+    nsplit = (int)std::min<uint64_t>({8ull, (uint64_t)nprobes, cdiv(2ull * ctx->num_cus, nq)});
+    if (nsplit < 1) nsplit = 1;
+  }
+  const size_t nblk = (size_t)nq * nsplit;
+  uint32_t *ckeys = ctx->scratch_t<uint32_t>("search.ckeys", nblk * SCAN_LCAP);
+  uint32_t *cpos = ctx->scratch_t<uint32_t>("search.cpos", nblk * SCAN_LCAP);
+  uint32_t *ccnt = ctx->scratch_t<uint32_t>("search.ccnt", nblk);
+  if (!ckeys || !cpos || !ccnt) return LANCE_HIP_ENOMEM;
+  {
+    ScanArgs a;
+    a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook;
+    a.part_offsets = ix->part_offsets; a.codes = ix->codes;
+    a.d = d; a.m = m; a.sd = sd; a.nprobes = (int)nprobes; a.nsplit = nsplit; a.keff = (int)keff;
+    a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
+    a.has_range = has_range;
+    a.lo_key = 0; a.hi_key = 0xFFFFFFFFu;
+    if (has_range) {
+      uint32_t lb, ub;
+      memcpy(&lb, &lower, 4); memcpy(&ub, &upper, 4);
+      a.lo_key = (lb & 0x80000000u) ? ~lb : (lb | 0x80000000u);
+      a.hi_key = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
+    }
+    a.out_keys = ckeys; a.out_pos = cpos; a.out_cnt = ccnt; a.flags = flags;
+    const int dpad = (d + 3) & ~3;
+    const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
+    LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
+    ScopedTimer t(ctx, "ivfpq_scan");
+    if (scan_metric == LANCE_HIP_DOT) launch_scan<METRIC_DOT>(ctx, a, (int)nblk, lds);
+    else launch_scan<METRIC_L2>(ctx, a, (int)nblk, lds);
+  }
+  // merge (+ refine)
+  uint64_t *cand_rid = nullptr;
+  uint32_t *cand_cnt = nullptr;
+  if (do_refine) {
+    cand_rid = ctx->scratch_t<uint64_t>("search.cand_rid", (size_t)nq * keff);
+    cand_cnt = ctx->scratch_t<uint32_t>("search.cand_cnt", nq);
+    if (!cand_rid || !cand_cnt) return LANCE_HIP_ENOMEM;
+  }
+  {
+    MergeArgs ma;
+    ma.keys = ckeys; ma.pos = cpos; ma.cnt = ccnt; ma.row_ids = ix->row_ids; ma.part_offsets = ix->part_offsets;
+    ma.nlist = nlist; ma.nsplit = nsplit; ma.keff = (int)keff; ma.k = (int)k;
+    ma.P = next_pow2(std::max(nsplit * SCAN_LCAP, 64));
+    ma.refine = do_refine ? 1 : 0;
+    ma.out_ids = ids; ma.out_dists = dists; ma.cand_rid = cand_rid; ma.cand_cnt = cand_cnt; ma.flags = flags;
+    ScopedTimer t(ctx, "ivfpq_merge");
+    hipLaunchKernelGGL(ivfpq_merge_kernel, dim3(nq), dim3(256), (size_t)ma.P * 16, ctx->stream, ma);
+  }
+  if (do_refine) {
+    const int P = next_pow2(std::max((int)keff, 64));
+    ScopedTimer t(ctx, "refine");
+    if (ix->metric == LANCE_HIP_DOT)
+      hipLaunchKernelGGL((refine_kernel<METRIC_DOT>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+    else
+      hipLaunchKernelGGL((refine_kernel<METRIC_L2>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+static int check_flags(lance_hip_ctx *ctx, const uint32_t *flags, uint32_t nq) {
+  std::vector<uint32_t> fh(nq);
+  LH_CHECK_HIP(hipMemcpyAsync(fh.data(), flags, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  uint32_t n_over = 0, n_amb = 0;
+  for (uint32_t i = 0; i < nq; ++i) { n_over += (fh[i] & FLAG_OVERFLOW) ? 1 : 0; n_amb += (fh[i] & FLAG_AMBIGUOUS) ? 1 : 0; }
+  if (n_over || n_amb) {
+    set_error("search: %u queries overflowed the candidate buffer and %u have more than k rows of one partition tied at the "
+              "boundary distance (result depends on the reference's heap internals); the exact-heap fallback is not "
+              "implemented in this version",
+              n_over, n_amb);
+    return LANCE_HIP_ENOTSUP;
+  }
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh
+
+using namespace lh;
+
+extern "C" {
+
+int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const void *q, uint32_t nq, uint32_t d,
+                              const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids, float *dists) {
+  LH_REQUIRE(ctx && q && centroids && part_ids, "find_partitions: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "find_partitions: only f32 is implemented in this version");
+  LH_REQUIRE(nlist > 0 && nlist <= 8192, "find_partitions: nlist=%u not supported in this version (1..8192)", nlist);
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (nprobes > nlist) nprobes = nlist;
+  if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
+  float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
+  if (!matrix) return LANCE_HIP_ENOMEM;
+  PairwiseArgs pa;
+  pa.x = static_cast<const float *>(q); pa.n = nq; pa.ldx = d;
+  pa.cent = static_cast<const float *>(centroids); pa.k = (int)nlist; pa.matrix = matrix;
+  LH_TRY(launch_dist_matrix(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
+  const int P = next_pow2((int)nlist);
+  hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, (int)nlist, P, (int)nprobes,
+                     part_ids, dists);
+  LH_CHECK_HIP(hipGetLastError());
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                 uint32_t nprobes, uint32_t refine_factor, uint64_t *ids, float *dists) {
+  LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search: NULL argument");
+  LH_REQUIRE(ctx->device == idx->device, "search: context and index live on different devices");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  return ivfpq_search_enqueue(ctx, idx, static_cast<const float *>(q), nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, nullptr);
+}
+
+int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                           uint32_t nprobes, uint32_t refine_factor, uint64_t *ids, float *dists) {
+  LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search: NULL argument");
+  LH_REQUIRE(ctx->device == idx->device, "search: context and index live on different devices");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  uint32_t *flags = nullptr;
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, static_cast<const float *>(q), nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags));
+  return check_flags(ctx, flags, nq);
+}
+
+int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *q_residual, uint32_t d,
+                           const void *codebook, uint32_t m, uint32_t nbits, const uint8_t *codes_transposed,
+                           const uint64_t *row_ids, uint64_t n_p, uint32_t k, int has_range, float lower, float upper,
+                           uint64_t *out_ids, float *out_dists, uint32_t *out_n_host) {
+  LH_REQUIRE(ctx && q_residual && codebook && out_ids && out_dists, "pq_scan_topk: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "pq_scan_topk: only f32 is implemented in this version");
+  LH_REQUIRE(n_p == 0 || (codes_transposed && row_ids), "pq_scan_topk: NULL codes");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  // a single-partition index whose centroid is 0: q_residual - 0 == q_residual exactly
+  std::vector<float> zero(d, 0.0f);
+  float *zc = ctx->scratch_t<float>("scan1.zero", d);
+  if (!zc) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemcpyAsync(zc, zero.data(), (size_t)d * 4, hipMemcpyHostToDevice, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  uint32_t offs[2] = {0, (uint32_t)n_p};
+  lance_hip_index *ix = nullptr;
+  const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
+  LH_TRY(lance_hip_index_from_storage(ctx, dtype, scan_metric, d, zc, 1, codebook, m, nbits, offs, codes_transposed, 1, row_ids, n_p, &ix));
+  uint32_t *flags = nullptr;
+  int r = ivfpq_search_enqueue(ctx, ix, static_cast<const float *>(q_residual), 1, k, 1, 0, has_range, lower, upper, out_ids, out_dists, &flags);
+  if (r == LANCE_HIP_OK) r = check_flags(ctx, flags, 1);
+  if (r == LANCE_HIP_OK && out_n_host) {
+    std::vector<uint64_t> ih(k);
+    if (hipMemcpy(ih.data(), out_ids, (size_t)k * 8, hipMemcpyDeviceToHost) != hipSuccess) r = LANCE_HIP_ERUNTIME;
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < k; ++i) c += ih[i] != ~0ull ? 1 : 0;
+    *out_n_host = c;
+  }
+  lance_hip_index_destroy(ix);
+  return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+"""Thin Python host layer over the C ABI: device memory and streams come from torch
+(plumbing), every computation is a call into liblance_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import METRICS, check
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError("lance_amd needs an MI355X: no HIP device is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device(a, dtype=None):
+    """numpy / torch (cpu or cuda) -> contiguous cuda tensor"""
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        arr = np.ascontiguousarray(a)
+        if arr.dtype == np.uint64:  # torch has limited uint64 support: move the bits
+            t = torch.from_numpy(arr.view(np.int64))
+        elif arr.dtype == np.uint32:
+            t = torch.from_numpy(arr.view(np.int32))
+        else:
+            t = torch.from_numpy(arr)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(_dev()).contiguous()
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One context (stream + scratch arena) on the current device."""
+
+    def __init__(self, device=None, use_torch_stream=False):
+        self.lib = _lib.load()
+        if device is None:
+            device = _dev().index
+        self.device = device
+        stream = None
+        if use_torch_stream:
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        h = C.c_void_p()
+        check(self.lib.lance_hip_ctx_create(device, stream, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lance_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.lance_hip_synchronize(self.h))
+
+    # ---- building blocks ---------------------------------------------------------
+    def normalize(self, x):
+        x = to_device(x, torch.float32)
+        out = torch.empty_like(x)
+        n, d = x.shape
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_normalize(self.h, _lib.F32, _ptr(x), n, d, _ptr(out)))
+        return out
+
+    def assign(self, x, centroids, metric="l2", bias=None):
+        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
+        n, d = x.shape
+        k = centroids.shape[0]
+        ids = torch.empty(n, dtype=torch.int32, device=x.device)
+        dists = torch.empty(n, dtype=torch.float32, device=x.device)
+        b = None if bias is None else to_device(bias, torch.float32)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_assign(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(centroids), k, _ptr(b),
+                                        _ptr(ids), _ptr(dists)))
+        return ids, dists
+
+    def kmeans_train(self, x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2"):
+        x = to_device(x, torch.float32)
+        n, d = x.shape
+        cent = torch.empty((k, d), dtype=torch.float32, device=x.device)
+        init_t = None if init is None else to_device(init, torch.float32)
+        loss = C.c_double(0); iters = C.c_uint32(0)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_kmeans_train(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, k, max_iters, tol,
+                                              balance_factor, _ptr(init_t), seed, _ptr(cent), C.byref(loss), C.byref(iters)))
+        return cent, loss.value, iters.value
+
+    def kmeans_estep_partial(self, x, centroids, metric="l2", bias=None):
+        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
+        n, d = x.shape
+        k = centroids.shape[0]
+        buf = torch.empty(k * d + k, dtype=torch.float32, device=x.device)
+        b = None if bias is None else to_device(bias, torch.float32)
+        loss = C.c_double(0)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_kmeans_estep_partial(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(centroids), k,
+                                                      _ptr(b), _ptr(buf), C.byref(loss)))
+        return buf, loss.value
+
+    def kmeans_finalize(self, buf, k, d):
+        cent = torch.empty((k, d), dtype=torch.float32, device=buf.device)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_kmeans_finalize(self.h, _lib.F32, _ptr(buf), k, d, _ptr(cent)))
+        return cent
+
+    def pq_train(self, residuals, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
+        r = to_device(residuals, torch.float32)
+        n, d = r.shape
+        cb = torch.empty((m, 1 << nbits, d // m), dtype=torch.float32, device=r.device)
+        iters = np.zeros(m, np.uint32)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_pq_train(self.h, _lib.F32, _ptr(r), n, d, m, nbits, max_iters, sample_rate, seed, _ptr(cb),
+                                          iters.ctypes.data_as(C.c_void_p)))
+        return cb, iters
+
+    def residual(self, x, centroids, part_ids):
+        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
+        p = to_device(part_ids, torch.int32)
+        out = torch.empty_like(x)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_residual(self.h, _lib.F32, _ptr(x), x.shape[0], x.shape[1], _ptr(centroids), _ptr(p), _ptr(out)))
+        return out
+
+    def pq_encode(self, x, codebook, metric="l2"):
+        x = to_device(x, torch.float32); codebook = to_device(codebook, torch.float32)
+        n, d = x.shape
+        m = codebook.shape[0]
+        codes = torch.empty((n, m), dtype=torch.uint8, device=x.device)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_pq_encode(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(codebook), m, 8, _ptr(codes)))
+        return codes
+
+    def ivfpq_encode(self, x, centroids, codebook, metric="l2"):
+        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
+        codebook = to_device(codebook, torch.float32)
+        n, d = x.shape
+        m = codebook.shape[0]
+        part = torch.empty(n, dtype=torch.int32, device=x.device)
+        codes = torch.empty((n, m), dtype=torch.uint8, device=x.device)
+        loss = C.c_double(0)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_ivfpq_encode(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(centroids),
+                                              centroids.shape[0], _ptr(codebook), m, 8, _ptr(part), _ptr(codes), C.byref(loss)))
+        return part, codes, loss.value
+
+    def find_partitions(self, q, centroids, nprobes, metric="l2"):
+        q = to_device(q, torch.float32).reshape(-1, centroids.shape[1]); centroids = to_device(centroids, torch.float32)
+        nq, d = q.shape
+        nlist = centroids.shape[0]
+        nprobes = min(nprobes, nlist)
+        ids = torch.empty((nq, nprobes), dtype=torch.int32, device=q.device)
+        dists = torch.empty((nq, nprobes), dtype=torch.float32, device=q.device)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_find_partitions(self.h, _lib.F32, METRICS[metric], _ptr(q), nq, d, _ptr(centroids), nlist,
+                                                 nprobes, _ptr(ids), _ptr(dists)))
+        return ids, dists
+
+    def pq_scan_topk(self, q_residual, codebook, codes_transposed, row_ids, k, metric="l2", lower=None, upper=None):
+        q = to_device(q_residual, torch.float32).reshape(-1)
+        cb = to_device(codebook, torch.float32)
+        ct = to_device(codes_transposed, torch.uint8)
+        rid = to_device(row_ids, torch.int64)
+        m, n_p = ct.shape
+        out_i = torch.empty(k, dtype=torch.int64, device=q.device)
+        out_d = torch.empty(k, dtype=torch.float32, device=q.device)
+        cnt = C.c_uint32(0)
+        has = lower is not None or upper is not None
+        lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
+        hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_pq_scan_topk(self.h, _lib.F32, METRICS[metric], _ptr(q), q.numel(), _ptr(cb), m, 8, _ptr(ct),
+                                              _ptr(rid), n_p, k, int(has), lo, hi, _ptr(out_i), _ptr(out_d), C.byref(cnt)))
+        return out_i[:cnt.value], out_d[:cnt.value]
+
+    def flat_topk(self, x, q, k, metric="l2", row_ids=None):
+        x = to_device(x, torch.float32)
+        q = to_device(q, torch.float32).reshape(-1, x.shape[1])
+        n, d = x.shape
+        nq = q.shape[0]
+        rid = None if row_ids is None else to_device(row_ids, torch.int64)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=x.device)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=x.device)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_flat_topk(self.h, _lib.F32, METRICS[metric], _ptr(x), _ptr(rid), n, d, _ptr(q), nq, k,
+                                           _ptr(ids), _ptr(dists)))
+        return ids, dists
+
+    # ---- timing hooks --------------------------------------------------------------
+    def timing(self, on=True):
+        check(self.lib.lance_hip_timing_enable(self.h, int(on)))
+
+    def timing_query(self, kernel):
+        ms = C.c_double(0); n = C.c_uint64(0)
+        check(self.lib.lance_hip_timing_query(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class DeviceIndex:
+    """Handle of a device-resident IVF_PQ index (lance_hip_index)."""
+
+    def __init__(self, engine, handle, metric, centroids, codebook, raw=None):
+        self.engine = engine
+        self.h = handle
+        self.metric = metric
+        self.centroids = centroids
+        self.codebook = codebook
+        self._raw = None
+        if raw is not None:
+            self.set_raw(raw)
+
+    @classmethod
+    def create(cls, engine, metric, centroids, codebook, part_ids, codes, row_ids=None, raw=None):
+        cent = to_device(centroids, torch.float32); cb = to_device(codebook, torch.float32)
+        part = to_device(part_ids, torch.int32); codes = to_device(codes, torch.uint8)
+        rid = None if row_ids is None else to_device(row_ids, torch.int64)
+        n = part.numel()
+        nlist, d = cent.shape
+        m = cb.shape[0]
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(engine.lib.lance_hip_index_create(engine.h, _lib.F32, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
+                                                _ptr(part), _ptr(codes), _ptr(rid), n, C.byref(h)))
+        return cls(engine, h, metric, cent, cb, raw)
+
+    @classmethod
+    def from_storage(cls, engine, metric, centroids, codebook, part_offsets, codes, row_ids, transposed=True, raw=None):
+        cent = to_device(centroids, torch.float32); cb = to_device(codebook, torch.float32)
+        offs = np.ascontiguousarray(part_offsets, np.uint32)
+        codes = to_device(np.ascontiguousarray(codes, np.uint8).reshape(-1), torch.uint8)
+        rid = to_device(row_ids, torch.int64)
+        nlist, d = cent.shape
+        m = cb.shape[0]
+        n = rid.numel()
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(engine.lib.lance_hip_index_from_storage(engine.h, _lib.F32, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
+                                                      offs.ctypes.data_as(C.c_void_p), _ptr(codes), int(transposed), _ptr(rid), n,
+                                                      C.byref(h)))
+        return cls(engine, h, metric, cent, cb, raw)
+
+    def set_raw(self, raw):
+        self._raw = to_device(raw, torch.float32)
+        check(self.engine.lib.lance_hip_index_set_raw(self.h, _ptr(self._raw), self._raw.shape[0]))
+
+    def info(self):
+        n = C.c_uint64(); nlist = C.c_uint32(); m = C.c_uint32(); d = C.c_uint32()
+        check(self.engine.lib.lance_hip_index_info(self.h, C.byref(n), C.byref(nlist), C.byref(m), C.byref(d)))
+        return {"n": n.value, "nlist": nlist.value, "m": m.value, "d": d.value}
+
+    def export(self):
+        """-> (part_offsets u32[nlist+1], codes_transposed u8 (per-partition [m][n_p] blocks), row_ids u64[n])"""
+        inf = self.info()
+        offs = np.empty(inf["nlist"] + 1, np.uint32)
+        codes = np.empty(inf["n"] * inf["m"], np.uint8)
+        rid = np.empty(inf["n"], np.uint64)
+        check(self.engine.lib.lance_hip_index_export(self.engine.h, self.h, offs.ctypes.data_as(C.c_void_p),
+                                                     codes.ctypes.data_as(C.c_void_p), rid.ctypes.data_as(C.c_void_p)))
+        return offs, codes, rid
+
+    def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
+        d = self.centroids.shape[1]
+        q = to_device(q, torch.float32).reshape(-1, d)
+        nq = q.shape[0]
+        if out is None:
+            ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        else:
+            ids, dists = out
+        fn = self.engine.lib.lance_hip_ivfpq_search if sync else self.engine.lib.lance_hip_ivfpq_search_async
+        if sync:
+            torch.cuda.synchronize()
+        check(fn(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
+        return ids, dists
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.lib.lance_hip_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's IVF_PQ build / query interface for the hot path.
+
+Names, argument meaning and defaults follow the reference (citations relative to the
+lancedb/lance tree):
+  * create_index(..., "IVF_PQ", metric, num_partitions, num_sub_vectors, ivf_centroids=,
+    pq_codebook=, sample_rate, max_iters)          python/python/lance/dataset.py:2517-2545
+  * IvfBuildParams / PQBuildParams defaults        rust/lance-index/src/vector/ivf/builder.rs:62-78,
+                                                   pq/builder.rs:48-58
+  * build order: sample -> train IVF -> residuals -> train PQ -> transform all rows ->
+    per-partition storage                          rust/lance/src/index/vector/builder.rs:236-254,377-466
+  * nearest={"q", "k", "nprobes", "refine_factor"} python/src/dataset.rs:984-1095
+  * KMeans(k, metric_type, max_iters, centroids).fit/.predict   python/python/lance/util.py:45-170
+
+All computation happens in liblance_hip.so; this module only orchestrates.
+"""
+import time
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import METRICS, NONE
+from .engine import DeviceIndex, Engine, to_device
+
+_engine = None
+
+
+def default_engine():
+    global _engine
+    if _engine is None:
+        _engine = Engine()
+    return _engine
+
+
+def _normalize_metric_type(metric):
+    m = str(metric).lower()
+    if m == "euclidean":
+        m = "l2"
+    if m not in ("l2", "cosine", "dot"):
+        raise ValueError(f"Metric {metric} not supported.")
+    return m
+
+
+class KMeans:
+    """lance.util.KMeans (python/python/lance/util.py:45-170) on the MI355X engine."""
+
+    def __init__(self, k, metric_type="l2", max_iters=50, centroids=None, seed=0, engine=None):
+        self.k = k
+        self._metric_type = _normalize_metric_type(metric_type)
+        self.max_iters = max_iters
+        self.seed = seed
+        self._engine = engine or default_engine()
+        self._centroids = None if centroids is None else to_device(np.asarray(centroids, np.float32))
+        self.loss = None
+        self.iters = None
+
+    def __repr__(self):
+        return f"lance_amd.KMeans(k={self.k}, metric_type={self._metric_type})"
+
+    @property
+    def centroids(self):
+        return None if self._centroids is None else self._centroids.cpu().numpy()
+
+    @staticmethod
+    def _check(data):
+        if isinstance(data, torch.Tensor):
+            if data.dim() != 2 or data.dtype != torch.float32:
+                raise ValueError("Data must be a 2-D float32 array")
+            return data
+        data = np.asarray(data)
+        if data.ndim != 2:
+            raise ValueError(f"Numpy array must be a 2-D array, got {data.ndim}-D")
+        if data.dtype != np.float32:
+            raise ValueError(f"Numpy array must be float32 type, got: {data.dtype}")
+        return data
+
+    def fit(self, data):
+        x = to_device(self._check(data))
+        metric = self._metric_type
+        if metric == "cosine":  # python/src/utils.rs _KMeans::fit -> KMeans::new_with_params normalises for cosine
+            x = self._engine.normalize(x)
+            metric = "l2"
+        # _KMeans uses KMeansParams::new(...) (redos 1, no balance) and sample_rate 256 (python/src/utils.rs:75-109)
+        n = x.shape[0]
+        if n > 256 * self.k:
+            x = x[: 256 * self.k]
+        self._centroids, self.loss, self.iters = self._engine.kmeans_train(
+            x, self.k, max_iters=self.max_iters, init=self._centroids, seed=self.seed, metric=metric)
+
+    def predict(self, data):
+        if self._centroids is None:
+            raise ValueError("KMeans model is not trained")
+        x = to_device(self._check(data))
+        metric = self._metric_type
+        if metric == "cosine":
+            x = self._engine.normalize(x)
+            metric = "l2"
+        ids, _ = self._engine.assign(x, self._centroids, metric)
+        return ids.cpu().numpy().view(np.uint32)
+
+
+@dataclass
+class IvfPqParams:
+    num_partitions: int = 256
+    num_sub_vectors: int = 16
+    num_bits: int = 8
+    metric: str = "l2"
+    max_iters: int = 50          # IvfBuildParams::max_iters / PQBuildParams::max_iters
+    sample_rate: int = 256       # both default to 256
+    seed: int = 42
+
+
+@dataclass
+class BuildStats:
+    seconds: dict = field(default_factory=dict)
+    ivf_iters: int = 0
+    pq_iters: Optional[np.ndarray] = None
+    ivf_loss: float = 0.0
+
+    @property
+    def total(self):
+        return sum(self.seconds.values())
+
+
+class IvfPqIndex:
+    """An IVF_PQ index resident in HBM with the reference's query semantics."""
+
+    def __init__(self, dev_index, params, stats=None, part_ids=None, codes=None):
+        self._ix = dev_index
+        self.params = params
+        self.stats = stats
+        self.part_ids = part_ids   # shuffle-buffer columns (device), kept for hand-off to Lance
+        self.codes = codes
+
+    @property
+    def centroids(self):
+        return self._ix.centroids.cpu().numpy()
+
+    @property
+    def codebook(self):
+        """numpy (M, 256, d/M) -- the `pq_codebook` artefact (dataset.py:2928-2954)"""
+        return self._ix.codebook.cpu().numpy()
+
+    def info(self):
+        return self._ix.info()
+
+    def export_storage(self):
+        return self._ix.export()
+
+    def shuffle_buffers(self):
+        """(row_id u64, __ivf_part_id u32, __pq_code u8[M]) as numpy -- the artefact the reference's
+        `precomputed_shuffle_buffers` hand-off consumes (python/lance/vector.py:659-665)."""
+        part = self.part_ids.cpu().numpy().view(np.uint32)
+        keep = part != NONE
+        rid = np.arange(part.size, dtype=np.uint64)[keep]
+        return rid, part[keep], self.codes.cpu().numpy()[keep]
+
+    def nearest(self, q, k=10, nprobes=1, refine_factor=None):
+        """-> (row ids int64 [nq,k] (-1 = missing), distances f32 [nq,k]) as numpy"""
+        ids, dists = self._ix.search(q, k, nprobes, 0 if refine_factor is None else refine_factor)
+        return ids.cpu().numpy(), dists.cpu().numpy()
+
+    def search_device(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
+        return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync)
+
+
+def _sample_rows(n, size, rng):
+    """maybe_sample_training_data (rust/lance/src/index/vector/utils.rs:173): all rows when the
+    table is small, else `size` distinct random rows (ascending)."""
+    if n <= size:
+        return None
+    return np.sort(rng.choice(n, size=size, replace=False))
+
+
+def train_ivf_centroids(x, params: IvfPqParams, engine=None, init=None):
+    """build_ivf_model (rust/lance/src/index/vector/ivf.rs:1213-1272): sample num_partitions*sample_rate
+    rows, normalise for cosine, drop non-finite rows, k-means with balance factor 1.0 (:1846-1871)."""
+    eng = engine or default_engine()
+    metric = _normalize_metric_type(params.metric)
+    x = to_device(x)
+    rng = np.random.default_rng(params.seed)
+    idx = _sample_rows(x.shape[0], params.num_partitions * params.sample_rate, rng)
+    sample = x if idx is None else x[torch.from_numpy(idx).to(x.device)]
+    if metric == "cosine":
+        sample = eng.normalize(sample)
+    sample = sample[torch.isfinite(sample).all(dim=1)]
+    kmetric = "l2" if metric == "cosine" else metric
+    return eng.kmeans_train(sample, params.num_partitions, max_iters=params.max_iters, balance_factor=1.0, init=init,
+                            seed=params.seed, metric=kmetric)
+
+
+def train_pq_codebook(x, centroids, params: IvfPqParams, engine=None):
+    """load_or_build_quantizer (rust/lance/src/index/vector/builder.rs:399-466): sample
+    sample_rate * 2^nbits rows, normalise (cosine), drop non-finite, residual vs the IVF centroids
+    (L2/cosine), then PQBuildParams::build (L2 k-means per sub-vector)."""
+    eng = engine or default_engine()
+    metric = _normalize_metric_type(params.metric)
+    x = to_device(x)
+    rng = np.random.default_rng(params.seed + 1)
+    idx = _sample_rows(x.shape[0], params.sample_rate * (1 << params.num_bits), rng)
+    sample = x if idx is None else x[torch.from_numpy(idx).to(x.device)]
+    if metric == "cosine":
+        sample = eng.normalize(sample)
+    sample = sample[torch.isfinite(sample).all(dim=1)]
+    if metric in ("l2", "cosine"):
+        part, _ = eng.assign(sample, centroids, "l2")
+        sample = eng.residual(sample, centroids, part)
+    return eng.pq_train(sample, params.num_sub_vectors, params.num_bits, params.max_iters, params.sample_rate, params.seed + 2)
+
+
+def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_sub_vectors=16, num_bits=8, max_iters=50,
+                 sample_rate=256, ivf_centroids=None, pq_codebook=None, seed=42, keep_raw=True, engine=None):
+    """Dataset.create_index(column, "IVF_PQ", ...) for a vector matrix resident (or copied) in HBM."""
+    if str(index_type).upper() != "IVF_PQ":
+        raise NotImplementedError(f"index_type {index_type}: only IVF_PQ is on this engine's hot path")
+    eng = engine or default_engine()
+    params = IvfPqParams(num_partitions, num_sub_vectors, num_bits, _normalize_metric_type(metric), max_iters, sample_rate, seed)
+    x = to_device(x)
+    n, d = x.shape
+    if d % num_sub_vectors != 0:
+        raise ValueError(f"num_sub_vectors must divide vector dimension {d}, but got {num_sub_vectors}")
+    stats = BuildStats()
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        stats.seconds[name] = time.perf_counter() - t
+        return out
+
+    if ivf_centroids is not None:
+        cent = to_device(np.asarray(ivf_centroids, np.float32))
+        if cent.shape != (num_partitions, d):
+            raise ValueError(f"IVF centroids length mismatch: {tuple(cent.shape)} != {(num_partitions, d)}")
+    else:
+        cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
+    if pq_codebook is not None:
+        cb = to_device(np.asarray(pq_codebook, np.float32).reshape(num_sub_vectors, 1 << num_bits, d // num_sub_vectors))
+    else:
+        cb, stats.pq_iters = timed("train_pq", lambda: train_pq_codebook(x, cent, params, eng))
+    part, codes, _ = timed("transform", lambda: eng.ivfpq_encode(x, cent, cb, params.metric))
+    ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
+                                                              raw=x if keep_raw else None))
+    return IvfPqIndex(ix, params, stats, part, codes)
+
+
+def flat_knn(x, q, k=10, metric="l2", engine=None):
+    """Exhaustive KNN (`use_index=False`): (row ids, distances) sorted by (distance, row id)."""
+    eng = engine or default_engine()
+    ids, dists = eng.flat_topk(x, q, k, _normalize_metric_type(metric))
+    return ids, dists

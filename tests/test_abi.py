@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports
+every symbol include/lance_hip.h declares, and fails loudly (no fallback) without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from lance_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "lance_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lance_hip_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_are_exported(lib):
+    from lance_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/lance_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == syms, "python binding list out of sync with the header"
+
+
+def test_no_device_fails_loudly(lib):
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = lib.lance_hip_ctx_create(0, None, C.byref(h))
+    assert rc < 0
+    assert b"HIP" in lib.lance_hip_last_error() or b"device" in lib.lance_hip_last_error()
+    import lance_amd
+    with pytest.raises(RuntimeError):
+        lance_amd.create_index(__import__("numpy").zeros((10, 8), "float32"), num_partitions=2, num_sub_vectors=2)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under lance_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lance_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".cuh")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in txt and "lance_oracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)

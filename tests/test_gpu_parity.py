@@ -1,0 +1,267 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Mirrors the reference's own tests for this path (naive-argmin equality kmeans.rs:1398-1422,
+NaN rows :1447-1486, encode == naive pq.rs:628-665, ADC == LUT sum pq.rs:580-625, recall with
+nprobes = nlist v2.rs:1354-1381) but asserts EXACT equality of ids / codes / distances, which
+the reference never does between its CPU and accelerator paths.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def eng(engine):
+    from lance_amd.engine import Engine
+    e = Engine()
+    yield e
+    e.close()
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def sift_like(n, d, seed, ncl=32):
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(0, 128, (ncl, d))
+    x = centers[rng.integers(0, ncl, n)] + rng.normal(0, 24, (n, d))
+    return np.clip(np.rint(x), 0, 218).astype(f32)
+
+
+@pytest.mark.parametrize("d,k", [(128, 256), (128, 18), (8, 256), (16, 256), (4, 256), (32, 300), (64, 33), (96, 64),
+                                 (100, 40), (20, 7), (1536, 12)])
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_assign_matches_oracle(eng, oracle, d, k, metric):
+    rng = np.random.default_rng(d * 1000 + k)
+    n = 3000 if d <= 128 else 300
+    x = rng.standard_normal((n, d)).astype(f32) * 3
+    c = rng.standard_normal((k, d)).astype(f32) * 3
+    ids, dists = eng.assign(x, c, metric)
+    oi, od = oracle.assign(x, c, metric)
+    assert (_np(ids).view(np.uint32) == oi).all()
+    assert (_np(dists).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_assign_nan_inf_bias_ties(eng, oracle):
+    rng = np.random.default_rng(3)
+    x = sift_like(2000, 128, 1)
+    c = sift_like(64, 128, 2)
+    c[5] = c[3]                      # duplicate centroid: first index must win
+    x[10] = np.nan                   # all-NaN row -> None (kmeans.rs:1447-1486)
+    x[11, 7] = np.nan                # partially NaN -> every distance NaN -> None
+    x[12, 3] = np.inf
+    bias = rng.random(64).astype(f32) * 1000
+    for b in (None, bias):
+        ids, dists = eng.assign(x, c, "l2", bias=b)
+        oi, od = oracle.assign(x, c, "l2", bias=b)
+        assert (_np(ids).view(np.uint32) == oi).all()
+        ok = oi != oracle.NONE
+        assert (_np(dists)[ok].view(np.uint32) == od[ok].view(np.uint32)).all()
+    assert oi[10] == oracle.NONE and oi[11] == oracle.NONE
+
+
+@pytest.mark.parametrize("n,d,k,bf", [(4096, 32, 16, 0.0), (6000, 128, 64, 1.0), (3000, 8, 256, 0.0)])
+def test_kmeans_train_bit_exact(eng, oracle, n, d, k, bf):
+    x = sift_like(n, d, n + d)
+    cent, loss, iters = eng.kmeans_train(x, k, max_iters=30, balance_factor=bf, seed=7)
+    # train_kmeans (kmeans.rs:1344) scales the balance factor by 1/n before the loop
+    oc, ol, oit, _ = oracle.kmeans_train(x, k, max_iters=30, balance_factor=f32(bf) / f32(n), seed=7)
+    assert iters == oit
+    assert (_np(cent).view(np.uint32) == oc.view(np.uint32)).all()
+    assert loss == ol
+
+
+def test_kmeans_empty_cluster_split(eng, oracle):
+    # many duplicates -> empty clusters -> split_clusters (kmeans.rs:174-207) on both sides
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((6, 16)).astype(f32)
+    x = base[rng.integers(0, 6, 2000)]
+    x[:40] += rng.standard_normal((40, 16)).astype(f32) * 0.01
+    init = x[:12].copy()
+    cent, loss, iters = eng.kmeans_train(x, 12, max_iters=10, init=init, seed=3)
+    oc, ol, oit, _ = oracle.kmeans_train(x, 12, max_iters=10, init=init, seed=3)
+    assert iters == oit and loss == ol
+    assert (_np(cent).view(np.uint32) == oc.view(np.uint32)).all()
+
+
+def test_pq_train_and_encode_bit_exact(eng, oracle):
+    n, d, m = 5000, 64, 8
+    x = sift_like(n, d, 11)
+    cent = sift_like(16, d, 12)
+    part, _ = oracle.assign(x, cent)
+    res = oracle.residual(x, cent, part)
+    assert (_np(eng.residual(x, cent, part)) == res).all()
+    cb, iters = eng.pq_train(res, m, max_iters=12, seed=21)
+    ocb, oit = oracle.pq_train(res, m, max_iters=12, seed=21)
+    assert (iters == oit.astype(np.uint32)).all()
+    assert (_np(cb).view(np.uint32) == ocb.view(np.uint32)).all()
+    codes = eng.pq_encode(res, cb)
+    assert (_np(codes) == oracle.pq_encode(res, ocb)).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_ivfpq_encode_matches_transform_chain(eng, oracle, metric):
+    n, d, nlist, m = 4000, 32, 24, 4
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((n, d)).astype(f32)
+    x[17] = np.nan; x[99, 3] = np.inf; x[100] = 0.0      # non-finite rows are dropped (utils.rs:263-286)
+    cent = rng.standard_normal((nlist, d)).astype(f32)
+    if metric == "cosine":
+        cent = oracle.normalize(cent)
+    cb = rng.standard_normal((m, 256, d // m)).astype(f32) * 0.5
+    part, codes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+    oidx = oracle.build_index(x, cent, cb, metric)
+    part = _np(part).view(np.uint32)
+    keep = oracle.is_finite(oracle.normalize(x) if metric == "cosine" else x)
+    assert (part[~keep] == oracle.NONE).all()
+    assert (part[keep] == oidx.part_ids).all()
+    valid = keep & (part != oracle.NONE)
+    assert (_np(codes)[valid] == oidx.codes_rowmajor[oidx.part_ids != oracle.NONE]).all()
+
+
+def test_find_partitions(eng, oracle):
+    rng = np.random.default_rng(8)
+    cent = sift_like(256, 128, 5)
+    cent[9] = cent[200]     # tie -> (dist, id) order
+    q = sift_like(300, 128, 6)
+    for nprobes in (1, 10, 256):
+        ids, d = eng.find_partitions(q, cent, nprobes)
+        oi, od = oracle.find_partitions(q, cent, nprobes)
+        assert (_np(ids).view(np.uint32) == oi).all()
+        assert (_np(d).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def _build_pair(eng, oracle, x, nlist, m, metric="l2", seed=1):
+    from lance_amd.engine import DeviceIndex
+    d = x.shape[1]
+    xs = oracle.normalize(x) if metric == "cosine" else x
+    kmetric = "l2" if metric == "cosine" else metric
+    cent, _, _, _ = oracle.kmeans_train(xs[: nlist * 64], nlist, max_iters=8, seed=seed, metric=kmetric)
+    part, _ = oracle.assign(xs, cent, kmetric)
+    res = oracle.residual(xs, cent, part) if kmetric == "l2" else xs
+    cb, _ = oracle.pq_train(res[: 256 * 32], m, max_iters=6, seed=seed + 1)
+    oidx = oracle.build_index(x, cent, cb, metric)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+    gidx = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+    return oidx, gidx
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine", "dot"])
+def test_ivfpq_search_ids_bit_exact(eng, oracle, metric):
+    n, d, nlist, m = 20000, 64, 32, 8
+    x = sift_like(n, d, 31) if metric != "cosine" else sift_like(n, d, 31) + 1.0
+    q = sift_like(200, d, 32) + (1.0 if metric == "cosine" else 0.0)
+    oidx, gidx = _build_pair(eng, oracle, x, nlist, m, metric)
+    # storage layout round trip equals the oracle's canonical layout
+    offs, codes_t, rid = gidx.export()
+    assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all()
+    for k, nprobes in ((10, nlist), (10, 5), (1, 1), (100, nlist), (37, 3)):
+        gi, gd = gidx.search(q, k, nprobes)
+        oi, od = oidx.search(q, k, nprobes)
+        assert (_np(gi).view(np.uint64) == oi).all(), (metric, k, nprobes)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_ivfpq_search_refine_and_from_storage(eng, oracle):
+    from lance_amd.engine import DeviceIndex
+    n, d, nlist, m = 30000, 128, 64, 16
+    x = sift_like(n, d, 41)
+    q = sift_like(150, d, 42)
+    oidx, gidx = _build_pair(eng, oracle, x, nlist, m)
+    for k, nprobes, rf in ((10, nlist, 10), (10, 8, 5), (5, 2, 1)):
+        gi, gd = gidx.search(q, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    # load the reference storage layout (transposed codes) straight into HBM
+    g2 = DeviceIndex.from_storage(eng, "l2", oidx.centroids, oidx.codebook, oidx.part_offsets, oidx.codes_t, oidx.row_ids,
+                                  transposed=True)
+    gi, gd = g2.search(q, 10, 7)
+    oi, od = oidx.search(q, 10, 7)
+    assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    # single query / tiny batches take the probe-split path
+    for nq in (1, 3):
+        gi, gd = gidx.search(q[:nq], 10, nlist)
+        oi, od = oidx.search(q[:nq], 10, nlist)
+        assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_ivfpq_search_edge_cases(eng, oracle):
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(2)
+    n, d, nlist, m = 600, 16, 8, 4
+    x = rng.standard_normal((n, d)).astype(f32)
+    cent = rng.standard_normal((nlist, d)).astype(f32) * 2
+    cent[6] = 100.0  # an empty partition
+    cb = rng.standard_normal((m, 256, d // m)).astype(f32)
+    oidx = oracle.build_index(x, cent, cb)
+    part, codes, _ = eng.ivfpq_encode(x, cent, cb)
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, part, codes)
+    q = rng.standard_normal((20, d)).astype(f32)
+    # k larger than the rows in the probed partitions -> missing results padded
+    gi, gd = gidx.search(q, 100, 1)
+    oi, od = oidx.search(q, 100, 1)
+    assert (_np(gi).view(np.uint64) == oi).all()
+    assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    # empty query batch
+    gi, _ = gidx.search(np.zeros((0, d), f32), 5, 2)
+    assert gi.shape == (0, 5)
+
+
+def test_pq_scan_topk_single_partition(eng, oracle):
+    rng = np.random.default_rng(6)
+    d, m, n_p = 32, 8, 3000
+    cb = rng.standard_normal((m, 256, d // m)).astype(f32)
+    codes = rng.integers(0, 256, (n_p, m), dtype=np.uint8)
+    rid = rng.permutation(10 * n_p)[:n_p].astype(np.uint64)
+    qr = rng.standard_normal(d).astype(f32)
+    lut = oracle.build_lut(qr, cb)
+    dist = oracle.pq_scan(lut, oracle.transpose(codes))
+    gi, gd = eng.pq_scan_topk(qr, cb, oracle.transpose(codes), rid, 20)
+    hi, hd = oracle.heap_topk(dist, rid, 20)
+    ei, ed = oracle.sort_fetch(hi, hd, 20)
+    assert (_np(gi).view(np.uint64) == ei).all() and (_np(gd).view(np.uint32) == ed.view(np.uint32)).all()
+    lo, up = float(np.sort(dist)[50]), float(np.sort(dist)[400])
+    gi, gd = eng.pq_scan_topk(qr, cb, oracle.transpose(codes), rid, 30, lower=lo, upper=up)
+    hi, hd = oracle.heap_topk(dist, rid, 30, lower=lo, upper=up)
+    ei, ed = oracle.sort_fetch(hi, hd, 30)
+    assert (_np(gi).view(np.uint64) == ei).all() and (_np(gd).view(np.uint32) == ed.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("d", [128, 32, 100])
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_flat_knn_bit_exact_with_ties(eng, oracle, d, metric):
+    x = sift_like(20000, d, 51)          # integer-valued -> many exact distance ties
+    x[100:110] = x[5]                    # duplicates
+    q = sift_like(300, d, 52)
+    rid = np.random.default_rng(1).permutation(10 ** 6)[:20000].astype(np.uint64)
+    for k in (1, 10, 50):
+        gi, gd = eng.flat_topk(x, q, k, metric, row_ids=rid)
+        oi, od = oracle.flat_knn(x, q, k, metric, row_ids=rid)
+        assert (_np(gi).view(np.uint64) == oi).all(), (d, metric, k)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_python_api_end_to_end(engine, oracle):
+    """create_index / nearest / KMeans mirror the reference API; results equal the oracle run on the
+    engine's own trained artefacts (recall check as in v2.rs:1354-1381)."""
+    import lance_amd
+    x = sift_like(30000, 64, 61)
+    q = sift_like(100, 64, 62)
+    idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=32, num_sub_vectors=8, max_iters=10)
+    assert idx.info()["n"] == 30000
+    oidx = oracle.build_index(x, idx.centroids, idx.codebook)
+    ids, dists = idx.nearest(q, k=10, nprobes=32)
+    oi, od = oidx.search(q, 10, 32)
+    assert (ids.view(np.uint64) == oi).all() and (dists.view(np.uint32) == od.view(np.uint32)).all()
+    ids_r, _ = idx.nearest(q, k=10, nprobes=32, refine_factor=10)
+    gt, _ = oracle.flat_knn(x, q, 10)
+    recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10 for a, b in zip(ids_r.view(np.uint64), gt)])
+    assert recall >= 0.9
+    km = lance_amd.KMeans(8, max_iters=10)
+    km.fit(x[:4000])
+    assert km.centroids.shape == (8, 64)
+    assert (km.predict(x[:100]) == oracle.assign(x[:100], km.centroids)[0]).all()
