@@ -391,6 +391,172 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Exact fallback: one wave per FLAGGED query re-runs the query the way the reference
+// does -- per partition, rows in scan order through a max-heap with the semantics of
+// Rust's std BinaryHeap as FlatIndex::search drives it (flat/index.rs:94-126: push while
+// len < k, else replace the root only if root.dist > dist) -- so that the rows surviving
+// an over-full tie at the boundary are the reference's.  Distances are computed by all 64
+// lanes; a ballot pre-filters rows that cannot enter the heap (the root only decreases),
+// lane 0 replays the surviving rows in order.  Partition heaps are merged into a running
+// (dist, rowid)-sorted top list (the SortExec order).
+struct ExactArgs {
+  ScanArgs s;
+  const uint64_t *row_ids;
+  int k, refine;
+  uint64_t *out_ids;
+  float *out_dists;
+  uint64_t *cand_rid;
+  uint32_t *cand_cnt;
+  uint32_t *n_fallback;  // statistics
+};
+
+__device__ __forceinline__ void heap_sift_up(uint32_t *hk, uint32_t *hp, int start, int pos) {
+  const uint32_t ek = hk[pos], ep = hp[pos];
+  while (pos > start) {
+    const int parent = (pos - 1) / 2;
+    if (ek <= hk[parent]) break;
+    hk[pos] = hk[parent]; hp[pos] = hp[parent];
+    pos = parent;
+  }
+  hk[pos] = ek; hp[pos] = ep;
+}
+__device__ __forceinline__ void heap_push(uint32_t *hk, uint32_t *hp, int &len, uint32_t key, uint32_t pos) {
+  hk[len] = key; hp[len] = pos;
+  heap_sift_up(hk, hp, 0, len);
+  ++len;
+}
+// std BinaryHeap::pop: swap last into the root, sift_down_to_bottom(0), then sift_up
+__device__ __forceinline__ void heap_pop(uint32_t *hk, uint32_t *hp, int &len) {
+  --len;
+  if (len == 0) return;
+  const uint32_t ek = hk[len], ep = hp[len];
+  const int end = len;
+  int pos = 0, child = 1;
+  while (end >= 2 && child <= end - 2) {
+    if (hk[child] <= hk[child + 1]) child += 1;
+    hk[pos] = hk[child]; hp[pos] = hp[child];
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  if (child == end - 1) { hk[pos] = hk[child]; hp[pos] = hp[child]; pos = child; }
+  hk[pos] = ek; hp[pos] = ep;
+  heap_sift_up(hk, hp, 0, pos);
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ScanArgs &p = a.s;
+  const int qi = blockIdx.x;
+  if (!p.flags[qi]) return;
+  const int lane = threadIdx.x;
+  const int dpad = (p.d + 3) & ~3;
+  float *r = reinterpret_cast<float *>(smem);
+  float *lut = r + dpad;
+  uint64_t *trid = reinterpret_cast<uint64_t *>(lut + p.m * 256);
+  uint32_t *tkey = reinterpret_cast<uint32_t *>(trid + p.keff);
+  uint32_t *hk = tkey + p.keff;
+  uint32_t *hp = hk + p.keff + 1;
+  uint32_t *skey = hp + p.keff + 1;
+  __shared__ int s_hlen, s_tcnt;
+  if (lane == 0) { s_hlen = 0; s_tcnt = 0; }
+  const float *qv = p.q + (int64_t)qi * p.d;
+  const int m = p.m, sd = p.sd;
+  __syncthreads();
+  for (int pi = 0; pi < p.nprobes; ++pi) {
+    const uint32_t part = p.probes[(int64_t)qi * p.nprobes + pi];
+    const uint32_t off = p.part_offsets[part];
+    const int np = (int)(p.part_offsets[part + 1] - off);
+    if (np == 0) continue;
+    __syncthreads();
+    for (int t = lane; t < p.d; t += 64) r[t] = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+    __syncthreads();
+    for (int idx = lane; idx < m * 256; idx += 64)
+      lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&r[(idx >> 8) * sd], p.codebook + (int64_t)idx * sd, sd));
+    if (lane == 0) s_hlen = 0;
+    __syncthreads();
+    const uint8_t *pcodes = p.codes + (int64_t)off * m;
+    for (int base = 0; base < np; base += 64) {
+      const int row = base + lane;
+      uint32_t key = 0xFFFFFFFFu;
+      bool cand = false;
+      if (row < np) {
+        const uint8_t *rc = pcodes + (int64_t)row * m;
+        float dist = 0.0f;
+        for (int mm = 0; mm < m; ++mm) dist += lut[mm * 256 + rc[mm]];
+        if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);
+        key = order_key(dist);
+        const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);
+        cand = in_range && (s_hlen < p.keff || key < hk[0]);
+      }
+      const uint64_t mask = __ballot(cand);
+      skey[lane] = key;
+      __syncthreads();
+      if (lane == 0 && mask) {
+        int hl = s_hlen;
+        uint64_t mm = mask;
+        while (mm) {
+          const int b = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          const uint32_t kk = skey[b];
+          if (hl < p.keff) {
+            heap_push(hk, hp, hl, kk, off + (uint32_t)(base + b));
+          } else if (hk[0] > kk) {
+            heap_pop(hk, hp, hl);
+            heap_push(hk, hp, hl, kk, off + (uint32_t)(base + b));
+          }
+        }
+        s_hlen = hl;
+      }
+      __syncthreads();
+    }
+    // merge this partition's heap into the running (key, rowid)-sorted top list
+    if (lane == 0) {
+      int tc = s_tcnt;
+      for (int i = 0; i < s_hlen; ++i) {
+        const uint32_t kk = hk[i];
+        const uint64_t rr = a.row_ids[hp[i]];
+        if (tc == p.keff) {
+          const uint32_t wk = tkey[tc - 1];
+          const uint64_t wr = trid[tc - 1];
+          if (!(kk < wk || (kk == wk && rr < wr))) continue;
+        }
+        int pos = tc < p.keff ? tc : p.keff - 1;
+        while (pos > 0) {
+          const uint32_t pk = tkey[pos - 1];
+          const uint64_t pr = trid[pos - 1];
+          if (pk < kk || (pk == kk && pr < rr)) break;
+          tkey[pos] = pk; trid[pos] = pr;
+          --pos;
+        }
+        tkey[pos] = kk; trid[pos] = rr;
+        if (tc < p.keff) ++tc;
+      }
+      s_tcnt = tc;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int got = s_tcnt;
+  if (a.refine) {
+    for (int i = lane; i < p.keff; i += 64) a.cand_rid[(int64_t)qi * p.keff + i] = i < got ? trid[i] : ~0ull;
+    if (lane == 0) a.cand_cnt[qi] = (uint32_t)got;
+  } else {
+    for (int i = lane; i < a.k; i += 64) {
+      a.out_ids[(int64_t)qi * a.k + i] = i < got ? trid[i] : ~0ull;
+      a.out_dists[(int64_t)qi * a.k + i] = i < got ? key_to_float(tkey[i]) : INFINITY;
+    }
+  }
+  if (lane == 0) { p.flags[qi] = 0; atomicAdd(a.n_fallback, 1u); }
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, uint32_t v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // ------------------------------------------------------------------------------------
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
@@ -431,16 +597,18 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   LH_REQUIRE(nprobes > 0, "search: nprobes must be > 0");
   const uint32_t rf = refine_factor == 0 ? 1 : refine_factor;
   const uint32_t keff = k * rf;
-  LH_REQUIRE(keff <= (uint32_t)SCAN_MAX_KEFF, "search: k * refine_factor = %u > %d is not supported in this version", keff, SCAN_MAX_KEFF);
+  LH_REQUIRE(keff <= 2048, "search: k * refine_factor = %u > 2048 is not supported in this version", keff);
+  const bool fast = keff <= (uint32_t)SCAN_MAX_KEFF;  // larger k: every query takes the exact (slow) kernel
   const bool do_refine = refine_factor >= 1;  // Some(rf): re-rank even when rf == 1 (scanner.rs:2884)
   LH_REQUIRE(!do_refine || ix->raw != nullptr, "search: refine_factor needs raw vectors (lance_hip_index_set_raw)");
   LH_REQUIRE(!(do_refine && ix->metric == LANCE_HIP_COSINE), "search: refine on a cosine index is not implemented in this version");
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
 
-  uint32_t *flags = ctx->scratch_t<uint32_t>("search.flags", nq);
+  uint32_t *flags = ctx->scratch_t<uint32_t>("search.flags", (size_t)nq + 1);
   if (!flags) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)nq + 1) * 4, ctx->stream));
+  uint32_t *n_fallback = flags + nq;
   if (flags_out) *flags_out = flags;
   if (nq == 0) return LANCE_HIP_OK;
 
@@ -475,8 +643,8 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   uint32_t *cpos = ctx->scratch_t<uint32_t>("search.cpos", nblk * SCAN_LCAP);
   uint32_t *ccnt = ctx->scratch_t<uint32_t>("search.ccnt", nblk);
   if (!ckeys || !cpos || !ccnt) return LANCE_HIP_ENOMEM;
+  ScanArgs a;
   {
-    ScanArgs a;
     a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook;
     a.part_offsets = ix->part_offsets; a.codes = ix->codes;
     a.d = d; a.m = m; a.sd = sd; a.nprobes = (int)nprobes; a.nsplit = nsplit; a.keff = (int)keff;
@@ -493,9 +661,13 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const int dpad = (d + 3) & ~3;
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
-    ScopedTimer t(ctx, "ivfpq_scan");
-    if (scan_metric == LANCE_HIP_DOT) launch_scan<METRIC_DOT>(ctx, a, (int)nblk, lds);
-    else launch_scan<METRIC_L2>(ctx, a, (int)nblk, lds);
+    if (fast) {
+      ScopedTimer t(ctx, "ivfpq_scan");
+      if (scan_metric == LANCE_HIP_DOT) launch_scan<METRIC_DOT>(ctx, a, (int)nblk, lds);
+      else launch_scan<METRIC_L2>(ctx, a, (int)nblk, lds);
+    } else {
+      hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, flags, FLAG_OVERFLOW, (int64_t)nq);
+    }
   }
   // merge (+ refine)
   uint64_t *cand_rid = nullptr;
@@ -505,7 +677,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     cand_cnt = ctx->scratch_t<uint32_t>("search.cand_cnt", nq);
     if (!cand_rid || !cand_cnt) return LANCE_HIP_ENOMEM;
   }
-  {
+  if (fast) {
     MergeArgs ma;
     ma.keys = ckeys; ma.pos = cpos; ma.cnt = ccnt; ma.row_ids = ix->row_ids; ma.part_offsets = ix->part_offsets;
     ma.nlist = nlist; ma.nsplit = nsplit; ma.keff = (int)keff; ma.k = (int)k;
@@ -514,6 +686,18 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     ma.out_ids = ids; ma.out_dists = dists; ma.cand_rid = cand_rid; ma.cand_cnt = cand_cnt; ma.flags = flags;
     ScopedTimer t(ctx, "ivfpq_merge");
     hipLaunchKernelGGL(ivfpq_merge_kernel, dim3(nq), dim3(256), (size_t)ma.P * 16, ctx->stream, ma);
+  }
+  {
+    // exact replay of flagged queries (no-op workgroups for the rest)
+    ExactArgs ea;
+    ea.s = a; ea.row_ids = ix->row_ids; ea.k = (int)k; ea.refine = do_refine ? 1 : 0;
+    ea.out_ids = ids; ea.out_dists = dists; ea.cand_rid = cand_rid; ea.cand_cnt = cand_cnt; ea.n_fallback = n_fallback;
+    const int dpad = (d + 3) & ~3;
+    const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)keff * 12 + ((size_t)keff + 1) * 8 + 64 * 4 + 16;
+    LH_REQUIRE(lds <= 160 * 1024, "search: exact kernel does not fit in LDS (m=%d, k*refine=%u)", m, keff);
+    ScopedTimer t(ctx, "ivfpq_exact");
+    if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_DOT>), dim3(nq), dim3(64), lds, ctx->stream, ea);
+    else hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_L2>), dim3(nq), dim3(64), lds, ctx->stream, ea);
   }
   if (do_refine) {
     const int P = next_pow2(std::max((int)keff, 64));
@@ -536,11 +720,8 @@ static int check_flags(lance_hip_ctx *ctx, const uint32_t *flags, uint32_t nq) {
   uint32_t n_over = 0, n_amb = 0;
   for (uint32_t i = 0; i < nq; ++i) { n_over += (fh[i] & FLAG_OVERFLOW) ? 1 : 0; n_amb += (fh[i] & FLAG_AMBIGUOUS) ? 1 : 0; }
   if (n_over || n_amb) {
-    set_error("search: %u queries overflowed the candidate buffer and %u have more than k rows of one partition tied at the "
-              "boundary distance (result depends on the reference's heap internals); the exact-heap fallback is not "
-              "implemented in this version",
-              n_over, n_amb);
-    return LANCE_HIP_ENOTSUP;
+    set_error("search: internal error, %u overflow / %u ambiguous queries were not resolved by the exact kernel", n_over, n_amb);
+    return LANCE_HIP_ERUNTIME;
   }
   return LANCE_HIP_OK;
 }
