@@ -249,8 +249,9 @@ def test_python_api_end_to_end(engine, oracle):
     """create_index / nearest / KMeans mirror the reference API; results equal the oracle run on the
     engine's own trained artefacts (recall check as in v2.rs:1354-1381)."""
     import lance_amd
-    x = sift_like(30000, 64, 61)
-    q = sift_like(100, 64, 62)
+    from lance_amd.testing import sift_like as latent_sift
+    x = latent_sift(30000, 64, 61, n_clusters=32)
+    q = latent_sift(100, 64, 62, n_clusters=32)
     idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=32, num_sub_vectors=8, max_iters=10)
     assert idx.info()["n"] == 30000
     oidx = oracle.build_index(x, idx.centroids, idx.codebook)
