@@ -91,13 +91,14 @@ int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void
 
 /* Building blocks of one Lloyd iteration, for a host that owns the loop (multi-GPU:
  * one process per GPU, rows sharded, one all-reduce per iteration).
- * estep_partial: assign the local rows and accumulate, per centroid and in local row
- * order, sums[k][d] (f32), counts[k] (stored as f32 so that one all-reduce buffer
- * holds everything), and loss (f64 stored in 2 floats is NOT used: loss is returned to
- * the host).  buf layout: [k*d sums | k counts] floats.                              */
+ * estep_partial assigns the LOCAL rows and accumulates, per centroid and in local row
+ * order: buf = [k*d sums | k counts] as f32 (one all-reduce(sum) buffer), and optionally
+ * losses[k] (f64, all-reduce sum) and radius[k] (f32, all-reduce max) -- the inputs of
+ * compute_cluster_sizes / compute_balance_loss (kmeans.rs:210-237).                     */
 int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n,
                                    uint32_t d, const void *centroids, uint32_t k, const float *bias,
-                                   float *buf /* k*d + k */, double *loss_out_host);
+                                   float *buf /* k*d + k */, double *losses /* k or NULL */,
+                                   float *radius /* k or NULL */, double *loss_out_host);
 /* finalize: centroids = sums * (1/count) for count > 0 (kmeans.rs:410-418). */
 int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, uint32_t k, uint32_t d,
                               void *centroids_out);

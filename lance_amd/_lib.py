@@ -70,7 +70,7 @@ def load():
         "lance_hip_assign": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp]),
         "lance_hip_kmeans_train": (i32, [vp, i32, i32, vp, u64, u32, u32, u32, f64, f32, vp, u64, vp,
                                          C.POINTER(f64), C.POINTER(u32)]),
-        "lance_hip_kmeans_estep_partial": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, C.POINTER(f64)]),
+        "lance_hip_kmeans_estep_partial": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp, vp, C.POINTER(f64)]),
         "lance_hip_kmeans_finalize": (i32, [vp, i32, vp, u32, u32, vp]),
         "lance_hip_pq_train": (i32, [vp, i32, vp, u64, u32, u32, u32, u32, u32, u64, vp, vp]),
         "lance_hip_residual": (i32, [vp, i32, vp, u64, u32, vp, vp, vp]),

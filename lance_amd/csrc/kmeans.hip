@@ -323,8 +323,8 @@ int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void
 }
 
 int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
-                                   const void *centroids, uint32_t k, const float *bias, float *buf,
-                                   double *loss_out_host) {
+                                   const void *centroids, uint32_t k, const float *bias, float *buf, double *losses,
+                                   float *radius, double *loss_out_host) {
   LH_REQUIRE(ctx && x && centroids && buf, "kmeans_estep_partial: NULL argument");
   LH_REQUIRE(dtype == LANCE_HIP_F32, "kmeans_estep_partial: only f32 is implemented in this version");
   LH_REQUIRE(n < (1ull << 32) && k <= 4096, "kmeans_estep_partial: n or k too large for this version");
@@ -352,6 +352,8 @@ int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, co
                      (const uint8_t *)nullptr, 0);
   hipLaunchKernelGGL(counts_to_float_kernel, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, ctx->stream, starts, (int)k, buf + (size_t)k * d);
   LH_CHECK_HIP(hipGetLastError());
+  if (losses) LH_CHECK_HIP(hipMemcpyAsync(losses, losses_d, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  if (radius) LH_CHECK_HIP(hipMemcpyAsync(radius, radius_d, (size_t)k * 4, hipMemcpyDeviceToDevice, ctx->stream));
   if (loss_out_host) {
     std::vector<double> lh_(k);
     LH_CHECK_HIP(hipMemcpyAsync(lh_.data(), losses_d, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));

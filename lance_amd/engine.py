@@ -99,16 +99,18 @@ class Engine:
         return cent, loss.value, iters.value
 
     def kmeans_estep_partial(self, x, centroids, metric="l2", bias=None):
+        """-> (buf [k*d sums | k counts] f32, losses [k] f64, radius [k] f32) device tensors"""
         x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
         n, d = x.shape
         k = centroids.shape[0]
         buf = torch.empty(k * d + k, dtype=torch.float32, device=x.device)
+        losses = torch.empty(k, dtype=torch.float64, device=x.device)
+        radius = torch.empty(k, dtype=torch.float32, device=x.device)
         b = None if bias is None else to_device(bias, torch.float32)
-        loss = C.c_double(0)
         torch.cuda.synchronize()
         check(self.lib.lance_hip_kmeans_estep_partial(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(centroids), k,
-                                                      _ptr(b), _ptr(buf), C.byref(loss)))
-        return buf, loss.value
+                                                      _ptr(b), _ptr(buf), _ptr(losses), _ptr(radius), None))
+        return buf, losses, radius
 
     def kmeans_finalize(self, buf, k, d):
         cent = torch.empty((k, d), dtype=torch.float32, device=buf.device)
