@@ -212,8 +212,8 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   pa.x = xs; pa.n = (int64_t)n; pa.ldx = d;
   pa.cent = static_cast<const float *>(centroids); pa.k = (int)nlist;
   pa.ids = part_ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
+  pa.check_finite = true;  // KeepFiniteVectors fused into the assign kernel
   LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
-  hipLaunchKernelGGL(finite_mask_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d, part_ids);
   const float *enc_in = xs;
   if (scan_metric == LANCE_HIP_L2) {
     float *res = ctx->scratch_t<float>("encode.residual", (size_t)n * d);

@@ -89,17 +89,21 @@ __device__ __forceinline__ float dist_exact(const RegVec<D> &a, const float *__r
   }
   float tot = 0.0f;
   if constexpr (FULL > 0) {
+    constexpr int NJ = FULL / 16;
 #pragma unroll
     for (int ig = 0; ig < 4; ++ig) {
+      // issue all of this lane-group's tile reads first (one LDS latency per group, not per read)
+      f4 bv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const f4 *>(b + 16 * j + 4 * ig);
       f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int j = 0; j < FULL / 16; ++j) {
-        const f4 bv = *reinterpret_cast<const f4 *>(b + 16 * j + 4 * ig);
+      for (int j = 0; j < NJ; ++j) {
         const f4 av = a.q[4 * j + ig];
         if constexpr (METRIC == METRIC_DOT) {
-          acc += av * bv;
+          acc += av * bv[j];
         } else {
-          const f4 diff = BNEG ? av + bv : av - bv;
+          const f4 diff = BNEG ? av + bv[j] : av - bv[j];
           acc += diff * diff;
         }
       }

@@ -39,24 +39,48 @@ __global__ __launch_bounds__(64) void group_hist_kernel(const uint32_t *__restri
   for (int c = threadIdx.x; c < k; c += 64) out[(int64_t)c * nblocks + blk] = hist[c];
 }
 
-// exclusive scan of k*nblocks entries (key-major), one workgroup per batch entry.
-__global__ __launch_bounds__(256) void group_scan_kernel(uint32_t *__restrict__ blockhist, int k, int nblocks,
-                                                         uint32_t *__restrict__ starts,
-                                                         const uint8_t *__restrict__ active) {
+// Two-level exclusive scan.  (1) one wave per key: exclusive scan of that key's per-block
+// counts (in place) and the key total; (2) one workgroup per batch entry: exclusive scan of
+// the k totals -> starts[k+1].  The scatter adds starts[key] to the per-block offset.
+__global__ __launch_bounds__(64) void group_scan_blocks_kernel(uint32_t *__restrict__ blockhist, int k, int nblocks,
+                                                               uint32_t *__restrict__ totals,
+                                                               const uint8_t *__restrict__ active) {
+  const int b = blockIdx.y;
+  if (active && !active[b]) return;
+  const int c = blockIdx.x;
+  uint32_t *h = blockhist + ((int64_t)b * k + c) * nblocks;
+  const int lane = threadIdx.x;
+  uint32_t carry = 0;
+  for (int base = 0; base < nblocks; base += 64) {
+    const int i = base + lane;
+    const uint32_t v = i < nblocks ? h[i] : 0;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (i < nblocks) h[i] = carry + incl - v;
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) totals[(int64_t)b * k + c] = carry;
+}
+
+__global__ __launch_bounds__(256) void group_scan_totals_kernel(const uint32_t *__restrict__ totals, int k,
+                                                                uint32_t *__restrict__ starts,
+                                                                const uint8_t *__restrict__ active) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry_s;
   const int b = blockIdx.x;
   if (active && !active[b]) return;
-  uint32_t *h = blockhist + (int64_t)b * k * nblocks;
+  const uint32_t *tt = totals + (int64_t)b * k;
   uint32_t *st = starts + (int64_t)b * (k + 1);
-  const int64_t total = (int64_t)k * nblocks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int64_t base = 0; base < total; base += 256) {
-    const int64_t i = base + threadIdx.x;
-    const uint32_t v = i < total ? h[i] : 0;
-    // inclusive scan within the wave
+  for (int base = 0; base < k; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < k ? tt[i] : 0;
     uint32_t incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -68,11 +92,7 @@ __global__ __launch_bounds__(256) void group_scan_kernel(uint32_t *__restrict__ 
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
     const uint32_t carry = carry_s;
-    const uint32_t excl = carry + woff + incl - v;
-    if (i < total) {
-      h[i] = excl;
-      if (i % nblocks == 0) st[i / nblocks] = excl;
-    }
+    if (i < k) st[i] = carry + woff + incl - v;
     __syncthreads();
     if (threadIdx.x == 255) carry_s = carry + woff + incl;
     __syncthreads();
@@ -83,6 +103,7 @@ __global__ __launch_bounds__(256) void group_scan_kernel(uint32_t *__restrict__ 
 __global__ __launch_bounds__(64) void group_scatter_kernel(const uint32_t *__restrict__ ids, int64_t n, int64_t id_stride,
                                                            int k, int kbits, int nblocks,
                                                            const uint32_t *__restrict__ blockoffs,
+                                                           const uint32_t *__restrict__ starts,
                                                            uint32_t *__restrict__ sorted_rows, int64_t out_stride,
                                                            const uint8_t *__restrict__ active) {
   extern __shared__ uint32_t cursor[];
@@ -90,7 +111,8 @@ __global__ __launch_bounds__(64) void group_scatter_kernel(const uint32_t *__res
   if (active && !active[b]) return;
   const int blk = blockIdx.x;
   const uint32_t *offs = blockoffs + (int64_t)b * k * nblocks;
-  for (int c = threadIdx.x; c < k; c += 64) cursor[c] = offs[(int64_t)c * nblocks + blk];
+  const uint32_t *st = starts + (int64_t)b * (k + 1);
+  for (int c = threadIdx.x; c < k; c += 64) cursor[c] = st[c] + offs[(int64_t)c * nblocks + blk];
   __syncthreads();
   const uint32_t *idb = ids + (int64_t)b * id_stride;
   uint32_t *outb = sorted_rows + (int64_t)b * out_stride;
@@ -130,15 +152,17 @@ int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_
   if (batches == 0) return LANCE_HIP_OK;
   const int nblocks = (int)cdiv(n > 0 ? n : 1, GROUP_ROWS_PER_BLOCK);
   uint32_t *blockhist = ctx->scratch_t<uint32_t>("group.blockhist", (size_t)batches * k * nblocks);
-  if (!blockhist) return LANCE_HIP_ENOMEM;
+  uint32_t *totals = ctx->scratch_t<uint32_t>("group.totals", (size_t)batches * k);
+  if (!blockhist || !totals) return LANCE_HIP_ENOMEM;
   int kbits = 0;
   while ((1 << kbits) < k) ++kbits;
   const size_t lds = (size_t)k * sizeof(uint32_t);
   hipLaunchKernelGGL(group_hist_kernel, dim3(nblocks, batches), dim3(64), lds, ctx->stream, ids, n, id_stride, k,
                      nblocks, blockhist, active);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(batches), dim3(256), 0, ctx->stream, blockhist, k, nblocks, starts, active);
+  hipLaunchKernelGGL(group_scan_blocks_kernel, dim3(k, batches), dim3(64), 0, ctx->stream, blockhist, k, nblocks, totals, active);
+  hipLaunchKernelGGL(group_scan_totals_kernel, dim3(batches), dim3(256), 0, ctx->stream, totals, k, starts, active);
   hipLaunchKernelGGL(group_scatter_kernel, dim3(nblocks, batches), dim3(64), lds, ctx->stream, ids, n, id_stride, k,
-                     kbits, nblocks, blockhist, sorted_rows, out_stride, active);
+                     kbits, nblocks, blockhist, starts, sorted_rows, out_stride, active);
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

@@ -29,6 +29,10 @@ struct PairwiseArgs {
   const uint8_t *active = nullptr;
   bool x_aligned = false;
   bool cent_aligned = false;
+  bool check_finite = false;  // MODE 0: rows with a non-finite element get id NONE
+  float *part_vb = nullptr;   // k-split partials (set by the launcher)
+  float *part_v = nullptr;
+  uint32_t *part_idx = nullptr;
 };
 
 int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);

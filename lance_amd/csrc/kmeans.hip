@@ -45,12 +45,12 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
   const uint32_t s = st[c], e = st[c + 1];
   float acc = 0.0f;
   uint32_t i = s;
-  for (; i + 4 <= e; i += 4) {
-    const float v0 = xb[(int64_t)rows[i] * ldx];
-    const float v1 = xb[(int64_t)rows[i + 1] * ldx];
-    const float v2 = xb[(int64_t)rows[i + 2] * ldx];
-    const float v3 = xb[(int64_t)rows[i + 3] * ldx];
-    acc += v0; acc += v1; acc += v2; acc += v3;
+  for (; i + 8 <= e; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)rows[i + u] * ldx];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
   }
   for (; i < e; ++i) acc += xb[(int64_t)rows[i] * ldx];
   const uint32_t cnt = e - s;
@@ -77,9 +77,21 @@ __global__ __launch_bounds__(256) void kmeans_stats_kernel(const float *__restri
   double loss = 0.0;
   float rad = 0.0f;
   const uint32_t s = st[c], e = st[c + 1];
-  for (uint32_t i = s; i < e; ++i) {
+  uint32_t i = s;
+  // gathers issued 8 at a time; the f64 chain itself stays in row order (kmeans.rs:274-277)
+  for (; i + 8 <= e; i += 8) {
+    float dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dv[u] = db[rows[i + u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      rad = fmaxf(rad, dv[u]);  // f32::max
+      loss += (double)dv[u];
+    }
+  }
+  for (; i < e; ++i) {
     const float dv = db[rows[i]];
-    rad = fmaxf(rad, dv);  // f32::max
+    rad = fmaxf(rad, dv);
     loss += (double)dv;
   }
   losses[(int64_t)b * k + c] = loss;

@@ -12,6 +12,8 @@
 // reproduce the (x-y)^2 lane order, so it is deliberately not used here.
 #include "common.h"
 #include "exact.cuh"
+#include <algorithm>
+
 #include "kernels.h"
 
 #pragma clang fp contract(off)
@@ -37,16 +39,26 @@ __device__ __forceinline__ void zero_row(RegVec<D> &a) {
   for (int i = 0; i < RegVec<D>::Q; ++i) a.q[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// MODE 0: argmin  MODE 1: full distance matrix
-template <int D, int METRIC, int CT, int MODE>
-__global__ __launch_bounds__(256) void pairwise_kernel(PairwiseArgs p) {
+template <int D>
+__device__ __forceinline__ bool row_is_finite(const RegVec<D> &a) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < D; ++i) ok &= isfinite(a.get(i));
+  return ok;
+}
+
+// MODE 0: argmin  MODE 1: full distance matrix.  BS = workgroup size (rows per workgroup).
+// gridDim.z = ksplit: split z handles centroid tiles z, z+ksplit, ... (more workgroups for
+// small row counts); partial argmins are merged by argmin_merge_kernel.
+template <int D, int METRIC, int CT, int MODE, int BS>
+__global__ __launch_bounds__(BS) void pairwise_kernel(PairwiseArgs p) {
   __shared__ __attribute__((aligned(16))) float tile[CT * D];
   const int b = blockIdx.y;
   if (p.active && !p.active[b]) return;
   const float *xb = p.x + (int64_t)b * p.x_batch_off;
   const float *cb = p.cent + (int64_t)b * p.cent_batch_stride;
   const float *biasb = p.bias ? p.bias + (int64_t)b * p.bias_batch_stride : nullptr;
-  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = (int64_t)blockIdx.x * BS + threadIdx.x;
   const bool valid = row < p.n;
   RegVec<D> a;
   if (valid) {
@@ -54,22 +66,24 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseArgs p) {
   } else {
     zero_row<D>(a);
   }
+  // KeepFiniteVectors (lance-index utils.rs:263-286) fused: non-finite rows get no partition
+  const bool finite = (MODE == 0 && p.check_finite) ? row_is_finite<D>(a) : true;
   float minv = INFINITY, mino = INFINITY;
   uint32_t mini = LANCE_HIP_NONE;
   float *mrow = (MODE == 1 && valid) ? p.matrix + ((int64_t)b * p.n + row) * p.k : nullptr;
 
-  for (int c0 = 0; c0 < p.k; c0 += CT) {
+  for (int c0 = blockIdx.z * CT; c0 < p.k; c0 += CT * gridDim.z) {
     const int ct = min(CT, p.k - c0);
     __syncthreads();
     // L2: stage -c so the inner loop is x + (-c) (see dist_exact BNEG)
     constexpr bool NEG = METRIC != METRIC_DOT;
     if (p.cent_aligned) {
-      for (int i = threadIdx.x * 4; i < ct * D; i += 256 * 4) {
+      for (int i = threadIdx.x * 4; i < ct * D; i += BS * 4) {
         const f4 v = *reinterpret_cast<const f4 *>(&cb[(int64_t)c0 * D + i]);
         *reinterpret_cast<f4 *>(&tile[i]) = NEG ? -v : v;
       }
     } else {
-      for (int i = threadIdx.x; i < ct * D; i += 256) tile[i] = NEG ? -cb[(int64_t)c0 * D + i] : cb[(int64_t)c0 * D + i];
+      for (int i = threadIdx.x; i < ct * D; i += BS) tile[i] = NEG ? -cb[(int64_t)c0 * D + i] : cb[(int64_t)c0 * D + i];
     }
     __syncthreads();
     if (valid) {
@@ -99,11 +113,37 @@ __global__ __launch_bounds__(256) void pairwise_kernel(PairwiseArgs p) {
   }
   if constexpr (MODE == 0) {
     if (valid) {
-      if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = mini;
-      if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = mino;
-      if (p.codes) p.codes[row * p.codes_ld + b] = mini == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)mini;
+      if (!finite) { mini = LANCE_HIP_NONE; minv = INFINITY; }
+      if (gridDim.z > 1) {
+        const int64_t o = ((int64_t)blockIdx.z * gridDim.y + b) * p.n + row;
+        p.part_vb[o] = minv; p.part_v[o] = mino; p.part_idx[o] = mini;
+      } else {
+        if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = mini;
+        if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = mino;
+        if (p.codes) p.codes[row * p.codes_ld + b] = mini == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)mini;
+      }
     }
   }
+}
+
+// merge of k-split partial argmins: smallest biased value, ties -> smallest centroid index
+__global__ __launch_bounds__(256) void argmin_merge_kernel(PairwiseArgs p, int ksplit, int batches) {
+  const int b = blockIdx.y;
+  if (p.active && !p.active[b]) return;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= p.n) return;
+  float bvb = INFINITY, bv = INFINITY;
+  uint32_t bi = LANCE_HIP_NONE;
+  for (int z = 0; z < ksplit; ++z) {
+    const int64_t o = ((int64_t)z * batches + b) * p.n + row;
+    const uint32_t i = p.part_idx[o];
+    if (i == LANCE_HIP_NONE) continue;
+    const float vb = p.part_vb[o];
+    if (vb < bvb || (vb == bvb && i < bi)) { bvb = vb; bv = p.part_v[o]; bi = i; }
+  }
+  if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = bi;
+  if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = bv;
+  if (p.codes) p.codes[row * p.codes_ld + b] = bi == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)bi;
 }
 
 // Generic dimension: `a` streamed from global in 16-chunks, 4 centroids per pass share
@@ -120,6 +160,9 @@ __global__ __launch_bounds__(256) void pairwise_generic_kernel(PairwiseArgs p, i
   const bool valid = row < p.n;
   const float *arow = xb + (valid ? row : 0) * p.ldx;
   const int full = d / 16 * 16;
+  bool finite = true;
+  if (MODE == 0 && p.check_finite && valid)
+    for (int i = 0; i < d; ++i) finite &= isfinite(arow[i]);
   float minv = INFINITY, mino = INFINITY;
   uint32_t mini = LANCE_HIP_NONE;
   float *mrow = (MODE == 1 && valid) ? p.matrix + ((int64_t)b * p.n + row) * p.k : nullptr;
@@ -195,6 +238,7 @@ __global__ __launch_bounds__(256) void pairwise_generic_kernel(PairwiseArgs p, i
   }
   if constexpr (MODE == 0) {
     if (valid) {
+      if (!finite) mini = LANCE_HIP_NONE;
       if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = mini;
       if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = mino;
       if (p.codes) p.codes[row * p.codes_ld + b] = mini == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)mini;
@@ -202,14 +246,41 @@ __global__ __launch_bounds__(256) void pairwise_generic_kernel(PairwiseArgs p, i
   }
 }
 
-template <int D, int MODE>
-static void launch_fixed(lance_hip_ctx *ctx, const PairwiseArgs &p, int metric, int batches) {
+
+template <int D, int MODE, int BS>
+static void launch_fixed_bs(lance_hip_ctx *ctx, const PairwiseArgs &p, int metric, int batches, int ksplit) {
   constexpr int CT = (8192 / D) > 256 ? 256 : (8192 / D);
-  dim3 grid((unsigned)cdiv(p.n, 256), batches);
+  dim3 grid((unsigned)cdiv(p.n, BS), batches, ksplit);
   if (metric == METRIC_DOT)
-    hipLaunchKernelGGL((pairwise_kernel<D, METRIC_DOT, CT, MODE>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((pairwise_kernel<D, METRIC_DOT, CT, MODE, BS>), grid, dim3(BS), 0, ctx->stream, p);
   else
-    hipLaunchKernelGGL((pairwise_kernel<D, METRIC_L2, CT, MODE>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((pairwise_kernel<D, METRIC_L2, CT, MODE, BS>), grid, dim3(BS), 0, ctx->stream, p);
+}
+
+// Picks the workgroup size and the centroid split so that small problems (training samples,
+// query batches) still put >= 2 workgroups on every CU.
+template <int D, int MODE>
+static int launch_fixed(lance_hip_ctx *ctx, PairwiseArgs p, int metric, int batches) {
+  constexpr int CT = (8192 / D) > 256 ? 256 : (8192 / D);
+  const int ntiles = (int)cdiv(p.k, CT);
+  const int64_t want = 2ll * ctx->num_cus;
+  int bs = 256;
+  if ((int64_t)cdiv(p.n, 256) * batches * ntiles < want) bs = 64;
+  int ksplit = 1;
+  const int64_t blocks = (int64_t)cdiv(p.n, bs) * batches;
+  if (blocks < want) ksplit = (int)std::min<int64_t>(std::min(ntiles, 8), cdiv(want, blocks));
+  if (MODE == 0 && ksplit > 1) {
+    const size_t cnt = (size_t)ksplit * batches * p.n;
+    p.part_vb = ctx->scratch_t<float>("assign.part_vb", cnt);
+    p.part_v = ctx->scratch_t<float>("assign.part_v", cnt);
+    p.part_idx = ctx->scratch_t<uint32_t>("assign.part_idx", cnt);
+    if (!p.part_vb || !p.part_v || !p.part_idx) return LANCE_HIP_ENOMEM;
+  }
+  if (bs == 64) launch_fixed_bs<D, MODE, 64>(ctx, p, metric, batches, ksplit);
+  else launch_fixed_bs<D, MODE, 256>(ctx, p, metric, batches, ksplit);
+  if (MODE == 0 && ksplit > 1)
+    hipLaunchKernelGGL(argmin_merge_kernel, dim3((unsigned)cdiv(p.n, 256), batches), dim3(256), 0, ctx->stream, p, ksplit, batches);
+  return LANCE_HIP_OK;
 }
 
 template <int MODE>
@@ -224,13 +295,13 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
   const bool fixed_ok = p.cent_aligned;  // LDS tile float4 reads in dist_exact need 16B-aligned rows
   if (fixed_ok) {
     switch (d) {
-      case 4: launch_fixed<4, MODE>(ctx, p, metric, batches); goto done;
-      case 8: launch_fixed<8, MODE>(ctx, p, metric, batches); goto done;
-      case 16: launch_fixed<16, MODE>(ctx, p, metric, batches); goto done;
-      case 32: launch_fixed<32, MODE>(ctx, p, metric, batches); goto done;
-      case 64: launch_fixed<64, MODE>(ctx, p, metric, batches); goto done;
-      case 96: launch_fixed<96, MODE>(ctx, p, metric, batches); goto done;
-      case 128: launch_fixed<128, MODE>(ctx, p, metric, batches); goto done;
+      case 4: LH_TRY((launch_fixed<4, MODE>(ctx, p, metric, batches))); goto done;
+      case 8: LH_TRY((launch_fixed<8, MODE>(ctx, p, metric, batches))); goto done;
+      case 16: LH_TRY((launch_fixed<16, MODE>(ctx, p, metric, batches))); goto done;
+      case 32: LH_TRY((launch_fixed<32, MODE>(ctx, p, metric, batches))); goto done;
+      case 64: LH_TRY((launch_fixed<64, MODE>(ctx, p, metric, batches))); goto done;
+      case 96: LH_TRY((launch_fixed<96, MODE>(ctx, p, metric, batches))); goto done;
+      case 128: LH_TRY((launch_fixed<128, MODE>(ctx, p, metric, batches))); goto done;
       default: break;
     }
   }

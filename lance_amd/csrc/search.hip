@@ -23,6 +23,7 @@
 // that depends on the reference's heap internals -- a single partition holding more than
 // k rows tied at the boundary distance -- is detected and flagged.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -90,6 +91,7 @@ struct ScanArgs {
   uint32_t *out_pos;
   uint32_t *out_cnt;  // [nq*nsplit]
   uint32_t *flags;    // [nq]
+  int ablate;         // perf experiments only (LANCE_HIP_ABLATE): 1 = LUT once per query, 2 = no candidate appends, 4 = skip scan
 };
 
 struct ScanShared {
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
       s.r[t] = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
     __syncthreads();
     // pq/distance.rs:24-92: LUT[mm][c] = dist(q_sub[mm], codebook[mm][c]) in l2_scalar / dot_scalar order
+    if (!((p.ablate & 1) && pi > sp))
     for (int idx = threadIdx.x; idx < m * 256; idx += 256) {
       const int mm = idx >> 8;
       float v;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
     __syncthreads();
 
     const uint8_t *pcodes = p.codes + (int64_t)off * m;
-    for (int base = 0; base < np; base += SCAN_ROUND) {
+    for (int base = 0; base < ((p.ablate & 4) ? 0 : np); base += SCAN_ROUND) {
       if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);  // uniform: misc[0] stable after the barrier
       const uint32_t T = s.misc[1];
 #pragma unroll
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
           if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);  // pq/storage.rs:949-957
           const uint32_t key = order_key(dist);
           const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);  // flat/index.rs:98-105
-          if (in_range && key <= T) {
+          if (in_range && key <= T && !((p.ablate & 2) && base > 0)) {
             const uint32_t slot = atomicAdd(&s.misc[0], 1u);
             if (slot < SCAN_CAP) { s.ckey[slot] = key; s.cpos[slot] = off + (uint32_t)row; }
             else s.misc[3] = FLAG_OVERFLOW;
@@ -658,6 +661,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
       a.hi_key = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
     }
     a.out_keys = ckeys; a.out_pos = cpos; a.out_cnt = ccnt; a.flags = flags;
+    { const char *ab = getenv("LANCE_HIP_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     const int dpad = (d + 3) & ~3;
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
