@@ -154,6 +154,78 @@ __device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, cons
   return s + tot;
 }
 
+// ---- a3: flat cosine (cosine.rs:127-231, norm_l2.rs:106-129) ---------------------------
+// The reference's f32 cosine uses explicit SIMD types: on the default x86_64 build
+// (target-cpu=haswell) f32x16 is two __m256, multiply_add is vfmadd (simd/f32.rs:776-785) and
+// reduce_sum is the permute/hadd tree ((a0+a4)+(a2+a6))+((a1+a5)+(a3+a7)) (simd/f32.rs:203-218,
+// 625-644).  The fused multiply-adds are written with __fmaf_rn here on purpose.
+__device__ __forceinline__ float norm_l2_rt(const float *__restrict__ v, int d) {
+  const int full = d / 16 * 16;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (int i = full; i < d; ++i) acc = acc + v[i] * v[i];
+    s = acc;
+  }
+  float sums[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sums[i] = 0.0f;
+  for (int c = 0; c < full; c += 16)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sums[i] += v[c + i] * v[c + i];
+  float tot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tot = tot + sums[i];
+  return sqrtf(s + tot);
+}
+
+__device__ __forceinline__ float reduce8_tree(const float (&a)[8]) {
+  const float s0 = a[0] + a[4], s1 = a[1] + a[5], s2 = a[2] + a[6], s3 = a[3] + a[7];
+  return (s0 + s2) + (s1 + s3);
+}
+
+__device__ __forceinline__ float cosine_exact_rt(const float *__restrict__ x, float x_norm, const float *__restrict__ y, int d) {
+  if (d == 8 || d == 16) {  // cosine_once
+    float t[8], u[8];
+    if (d == 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        t[i] = x[i] * y[i] + x[i + 8] * y[i + 8];
+        u[i] = y[i] * y[i] + y[i + 8] * y[i + 8];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t[i] = x[i] * y[i]; u[i] = y[i] * y[i]; }
+    }
+    return 1.0f - reduce8_tree(t) / x_norm / sqrtf(reduce8_tree(u));
+  }
+  const int unrolled = d / 16 * 16, aligned = d / 8 * 8;
+  float xy16[16], yn16[16], xy8[8], yn8[8];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { xy16[i] = 0.0f; yn16[i] = 0.0f; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { xy8[i] = 0.0f; yn8[i] = 0.0f; }
+  for (int c = 0; c < unrolled; c += 16)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      xy16[i] = __fmaf_rn(x[c + i], y[c + i], xy16[i]);
+      yn16[i] = __fmaf_rn(y[c + i], y[c + i], yn16[i]);
+    }
+  for (int c = unrolled; c < aligned; c += 8)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xy8[i] = __fmaf_rn(x[c + i], y[c + i], xy8[i]);
+      yn8[i] = __fmaf_rn(y[c + i], y[c + i], yn8[i]);
+    }
+  float t16[8], u16[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { t16[i] = xy16[i] + xy16[i + 8]; u16[i] = yn16[i] + yn16[i + 8]; }
+  const float nrest = norm_l2_rt(y + aligned, d - aligned);
+  const float y_norm = reduce8_tree(u16) + reduce8_tree(yn8) + nrest * nrest;
+  const float xy = reduce8_tree(t16) + reduce8_tree(xy8) + dist_exact_rt<METRIC_DOT>(x + aligned, y + aligned, d - aligned);
+  return 1.0f - xy / x_norm / sqrtf(y_norm);
+}
+
 // metric value as the reference scans see it: L2 -> squared L2; DOT -> 1 - dot.
 template <int METRIC>
 __device__ __forceinline__ float finish_metric(float raw) {

@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void flat_scan_generic_kernel(FlatArgs p, int 
   uint64_t wrid = ~0ull;
   const int64_t r0 = (int64_t)sp * p.rows_per_split;
   const int64_t r1 = min(p.n, r0 + p.rows_per_split);
+  float qnorm = 0.0f;
+  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, p.d);
   for (int64_t t0 = r0; t0 < r1; t0 += tr_max) {
     const int tr = (int)min<int64_t>(tr_max, r1 - t0);
     __syncthreads();
@@ -118,7 +120,9 @@ __global__ __launch_bounds__(256) void flat_scan_generic_kernel(FlatArgs p, int 
     __syncthreads();
     if (valid) {
       for (int r = 0; r < tr; ++r) {
-        const float v = finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, &tile[r * p.d], p.d));
+        float v;
+        if constexpr (METRIC == METRIC_COSINE) v = cosine_exact_rt(qv, qnorm, &tile[r * p.d], p.d);
+        else v = finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, &tile[r * p.d], p.d));
         const uint32_t key = order_key(v);
         if (key < wkey || cnt < p.k || (key == wkey && trid[r] < wrid)) flat_insert(lk, lr, p.k, cnt, key, trid[r], wkey, wrid);
       }
@@ -185,7 +189,7 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
                                    float *dists) {
   LH_REQUIRE(ctx && (n == 0 || x) && (nq == 0 || (q && ids && dists)), "flat_topk: NULL argument");
   LH_REQUIRE(dtype == LANCE_HIP_F32, "flat_topk: only f32 is implemented in this version");
-  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT, "flat_topk: metric must be L2 or Dot in this version");
+  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "flat_topk: bad metric %d", metric);
   LH_REQUIRE(k > 0 && k <= 1024, "flat_topk: k=%u not supported (1..1024)", k);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nq == 0) return LANCE_HIP_OK;
@@ -203,7 +207,7 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
   const dim3 grid(qblocks, nsplit);
   {
     ScopedTimer t(ctx, "flat_scan");
-    switch (d) {
+    switch (metric == LANCE_HIP_COSINE ? 0u : d) {
       case 8: launch_flat_fixed<8>(ctx, a, metric, grid); break;
       case 16: launch_flat_fixed<16>(ctx, a, metric, grid); break;
       case 32: launch_flat_fixed<32>(ctx, a, metric, grid); break;
@@ -215,7 +219,9 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
         tr = std::max(1, std::min(tr, 256));
         const size_t lds = (size_t)tr * 8 + (size_t)tr * d * 4;
         LH_REQUIRE(lds <= 160 * 1024, "flat_topk: dimension %u too large", d);
-        if (metric == LANCE_HIP_DOT)
+        if (metric == LANCE_HIP_COSINE)
+          hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_COSINE>), grid, dim3(256), lds, ctx->stream, a, tr);
+        else if (metric == LANCE_HIP_DOT)
           hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_DOT>), grid, dim3(256), lds, ctx->stream, a, tr);
         else
           hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_L2>), grid, dim3(256), lds, ctx->stream, a, tr);

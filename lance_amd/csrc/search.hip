@@ -196,19 +196,38 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
       s.r[t] = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
     __syncthreads();
     // pq/distance.rs:24-92: LUT[mm][c] = dist(q_sub[mm], codebook[mm][c]) in l2_scalar / dot_scalar order
-    if (!((p.ablate & 1) && pi > sp))
-    for (int idx = threadIdx.x; idx < m * 256; idx += 256) {
-      const int mm = idx >> 8;
-      float v;
-      if constexpr (SD > 0) {
-        RegVec<SD> a;
+    if (!((p.ablate & 1) && pi > sp)) {
+      if constexpr (SD > 0 && SD % 4 == 0) {
+        // 4 entries per step: all codebook loads of the step are issued before the arithmetic,
+        // so one L2 round trip covers 4 entries (the codebook is 128 KiB, L2-resident).
+        constexpr int Q = SD / 4;
+        for (int i0 = 0; i0 < m; i0 += 4) {
+          f4 cbv[4][Q];
 #pragma unroll
-        for (int i = 0; i < RegVec<SD>::Q; ++i) a.q[i] = *reinterpret_cast<const f4 *>(&s.r[mm * SD + 4 * i]);
-        v = dist_exact<SD, METRIC>(a, p.codebook + (int64_t)idx * SD);
+          for (int u = 0; u < 4; ++u) {
+            const int mm = min(i0 + u, m - 1);
+            const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + threadIdx.x) * SD);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) cbv[u][i] = src[i];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int mm = i0 + u;
+            if (mm < m) {
+              RegVec<SD> a;
+#pragma unroll
+              for (int i = 0; i < Q; ++i) a.q[i] = *reinterpret_cast<const f4 *>(&s.r[mm * SD + 4 * i]);
+              const float v = dist_exact<SD, METRIC>(a, reinterpret_cast<const float *>(&cbv[u][0]));
+              s.lut[mm * 256 + threadIdx.x] = finish_metric<METRIC>(v);
+            }
+          }
+        }
       } else {
-        v = dist_exact_rt<METRIC>(&s.r[mm * sd], p.codebook + (int64_t)idx * sd, sd);
+        for (int idx = threadIdx.x; idx < m * 256; idx += 256) {
+          const int mm = idx >> 8;
+          s.lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&s.r[mm * sd], p.codebook + (int64_t)idx * sd, sd));
+        }
       }
-      s.lut[idx] = finish_metric<METRIC>(v);
     }
     __syncthreads();
 
@@ -376,12 +395,17 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
   const int qi = blockIdx.x;
   const int c = (int)cand_cnt[qi];
   const float *qv = q + (int64_t)qi * d;
+  float qnorm = 0.0f;
+  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, d);  // cosine_batch: x_norm = norm_l2(x)
   for (int i = threadIdx.x; i < P; i += 256) {
     uint32_t kk = 0xFFFFFFFFu;
     uint64_t r = ~0ull;
     if (i < c) {
       r = cand_rid[(int64_t)qi * keff + i];
-      if (r < n_raw) kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, raw + r * d, d)));
+      if (r < n_raw) {
+        if constexpr (METRIC == METRIC_COSINE) kk = order_key(cosine_exact_rt(qv, qnorm, raw + r * d, d));
+        else kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, raw + r * d, d)));
+      }
     }
     key[i] = kk; rid[i] = r; pos[i] = 0;
   }
@@ -604,7 +628,6 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   const bool fast = keff <= (uint32_t)SCAN_MAX_KEFF;  // larger k: every query takes the exact (slow) kernel
   const bool do_refine = refine_factor >= 1;  // Some(rf): re-rank even when rf == 1 (scanner.rs:2884)
   LH_REQUIRE(!do_refine || ix->raw != nullptr, "search: refine_factor needs raw vectors (lance_hip_index_set_raw)");
-  LH_REQUIRE(!(do_refine && ix->metric == LANCE_HIP_COSINE), "search: refine on a cosine index is not implemented in this version");
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
 
@@ -706,7 +729,10 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   if (do_refine) {
     const int P = next_pow2(std::max((int)keff, 64));
     ScopedTimer t(ctx, "refine");
-    if (ix->metric == LANCE_HIP_DOT)
+    if (ix->metric == LANCE_HIP_COSINE)  // flat_knn on the taken rows uses the index's metric with the ORIGINAL query
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+    else if (ix->metric == LANCE_HIP_DOT)
       hipLaunchKernelGGL((refine_kernel<METRIC_DOT>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
     else

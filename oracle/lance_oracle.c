@@ -236,6 +236,18 @@ static inline float orc_reduce8(const float *a) {
  * simd/f32.rs:625-644; .cargo/config.toml:12-13).  x_norm = norm_l2(x).
  * Used only by the flat cosine scan (un-indexed KNN / refine of a cosine index). */
 float orc_cosine_f32(const float *x, float x_norm, const float *y, size_t d) {
+  /* cosine_batch (cosine.rs:210-231): dimension 8 / 16 take cosine_once (plain products,
+   * SIMD tree reduce, cosine.rs:127-140); everything else cosine_fast. */
+  if (d == 8 || d == 16) {
+    float xy[16], y2[16], t[8], u[8];
+    for (size_t i = 0; i < d; i++) { xy[i] = x[i] * y[i]; y2[i] = y[i] * y[i]; }
+    if (d == 16) {
+      for (int i = 0; i < 8; i++) { t[i] = xy[i] + xy[i + 8]; u[i] = y2[i] + y2[i + 8]; }
+    } else {
+      for (int i = 0; i < 8; i++) { t[i] = xy[i]; u[i] = y2[i]; }
+    }
+    return 1.0f - orc_reduce8(t) / x_norm / sqrtf(orc_reduce8(u));
+  }
   size_t unrolled = d / 16 * 16, aligned = d / 8 * 8;
   float xy16[16], yn16[16], xy8[8], yn8[8];
   for (int i = 0; i < 16; i++) { xy16[i] = 0.0f; yn16[i] = 0.0f; }

@@ -245,6 +245,71 @@ def test_flat_knn_bit_exact_with_ties(eng, oracle, d, metric):
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("d", [8, 16, 20, 128, 200])
+def test_flat_cosine_bit_exact(eng, oracle, d):
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((5000, d)).astype(f32) * 2
+    q = rng.standard_normal((70, d)).astype(f32)
+    gi, gd = eng.flat_topk(x, q, 10, "cosine")
+    oi, od = oracle.flat_knn(x, q, 10, "cosine")
+    assert (_np(gi).view(np.uint64) == oi).all()
+    assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_cosine_index_refine_bit_exact(eng, oracle):
+    # dbpedia-style: cosine index = normalise + L2 residual PQ; refine re-ranks with the flat cosine
+    # kernel on the RAW vectors and the ORIGINAL query (scanner.rs:2884-2904)
+    n, d, nlist, m = 20000, 96, 32, 12
+    x = sift_like(n, d, 71) + 1.0
+    q = sift_like(120, d, 72) + 1.0
+    oidx, gidx = _build_pair(eng, oracle, x, nlist, m, "cosine")
+    for k, nprobes, rf in ((10, nlist, 10), (10, 4, 3), (5, 1, 1)):
+        gi, gd = gidx.search(q, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_full_size_properties_sift1m(engine, oracle):
+    """BASELINE config 2 at full size (1M x 128, IVF256, PQ16) through size-independent properties:
+    partition offsets cover every row exactly once, results are sorted by (dist, rowid), searching is
+    idempotent, self-queries with refine come back at distance 0 (lance/util.py:171-220 validate_vector_index),
+    and a slice of the batch equals the oracle bit for bit."""
+    import torch
+    import lance_amd
+    from lance_amd.testing import sift_like as latent_sift
+    x = latent_sift(1_000_000, 128, 1234, device="cuda")
+    idx = lance_amd.create_index(x, "IVF_PQ", num_partitions=256, num_sub_vectors=16)
+    offs, codes_t, rid = idx.export_storage()
+    assert offs[0] == 0 and offs[-1] == 1_000_000 and (np.diff(offs.astype(np.int64)) >= 0).all()
+    assert (np.sort(rid) == np.arange(1_000_000, dtype=np.uint64)).all()
+    q = latent_sift(2000, 128, 4321, device="cuda")
+    ids1, d1 = idx.search_device(q, 10, 10, 10)
+    ids2, d2 = idx.search_device(q, 10, 10, 10)
+    assert torch.equal(ids1, ids2) and torch.equal(d1, d2)
+    dd = d1.cpu().numpy(); ii = ids1.cpu().numpy().view(np.uint64)
+    assert (np.diff(dd, axis=1) >= 0).all()
+    tie = np.diff(dd, axis=1) == 0
+    assert (np.diff(ii.astype(np.int64), axis=1)[tie] > 0).all()
+    # self queries: the row itself is returned first with distance exactly 0 after refine
+    probe = torch.arange(0, 1_000_000, 997, device="cuda")[:1000]
+    si, sd = idx.search_device(x[probe], 1, 256, 10)
+    hit = (sd[:, 0] == 0).float().mean().item()
+    assert hit >= 0.99, hit
+    # oracle on the same artefacts, 64 queries, un-refined and refined, exhaustive probes included
+    oidx = oracle.IvfPqIndex("l2", idx.centroids, idx.codebook, offs, codes_t, rid)
+    qh = q[:64].cpu().numpy(); xh = x.cpu().numpy()
+    for nprobes, rf in ((256, 0), (10, 10)):
+        gi, gd = idx.search_device(q[:64], 10, nprobes, rf)
+        oi, od = oidx.search(qh, 10, nprobes, refine=rf, raw=xh)
+        assert (gi.cpu().numpy().view(np.uint64) == oi).all()
+        assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all()
+    # flat ground truth at full size equals the oracle for a few queries
+    gi, gd = lance_amd.flat_knn(x, q[:8], 10)
+    oi, od = oracle.flat_knn(xh, qh[:8], 10)
+    assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all()
+
+
 def test_python_api_end_to_end(engine, oracle):
     """create_index / nearest / KMeans mirror the reference API; results equal the oracle run on the
     engine's own trained artefacts (recall check as in v2.rs:1354-1381)."""

@@ -371,3 +371,62 @@ def test_kmeans_train_reference_loop(oracle):
     assert (cent == c).all()
     assert loss == last
     assert sizes.tolist() == csz.tolist()
+
+
+def np_cosine_fast(x, y):
+    """Independent restatement of Cosine for f32 (cosine.rs:127-231) for the default x86_64 build:
+    f32x16/f32x8 FMA accumulators + the permute/hadd reduce tree (simd/f32.rs:203-218,625-644,776-785).
+    fma(a,b,c) is emulated in float64 (exact product, one extra rounding that is harmless here)."""
+    x = np.asarray(x, f32); y = np.asarray(y, f32)
+    d = len(x)
+
+    def fma(a, b, c):
+        return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    def red8(a):
+        s0, s1, s2, s3 = f32(a[0] + a[4]), f32(a[1] + a[5]), f32(a[2] + a[6]), f32(a[3] + a[7])
+        return f32(f32(s0 + s2) + f32(s1 + s3))
+
+    def norm(v):
+        v = np.asarray(v, f32)
+        full = len(v) // 16 * 16
+        s = f32(0)
+        for i in range(full, len(v)):
+            s = f32(s + f32(v[i] * v[i]))
+        sums = np.zeros(16, f32)
+        for c in range(0, full, 16):
+            sums = (sums + (v[c:c + 16] * v[c:c + 16]).astype(f32)).astype(f32)
+        tot = f32(0)
+        for i in range(16):
+            tot = f32(tot + sums[i])
+        return f32(np.sqrt(f32(s + tot)))
+
+    xn = norm(x)
+    if d in (8, 16):
+        xy = (x * y).astype(f32); y2 = (y * y).astype(f32)
+        if d == 16:
+            xy = (xy[:8] + xy[8:]).astype(f32); y2 = (y2[:8] + y2[8:]).astype(f32)
+        return f32(f32(1) - f32(f32(red8(xy) / xn) / f32(np.sqrt(red8(y2)))))
+    un, al = d // 16 * 16, d // 8 * 8
+    xy16 = np.zeros(16, f32); yn16 = np.zeros(16, f32); xy8 = np.zeros(8, f32); yn8 = np.zeros(8, f32)
+    for c in range(0, un, 16):
+        for i in range(16):
+            xy16[i] = fma(x[c + i], y[c + i], xy16[i]); yn16[i] = fma(y[c + i], y[c + i], yn16[i])
+    for c in range(un, al, 8):
+        for i in range(8):
+            xy8[i] = fma(x[c + i], y[c + i], xy8[i]); yn8[i] = fma(y[c + i], y[c + i], yn8[i])
+    t16 = (xy16[:8] + xy16[8:]).astype(f32); u16 = (yn16[:8] + yn16[8:]).astype(f32)
+    nrest = norm(y[al:])
+    y_norm = f32(f32(red8(u16) + red8(yn8)) + f32(nrest * nrest))
+    xy = f32(f32(red8(t16) + red8(xy8)) + np_dot_scalar(x[al:], y[al:]))
+    return f32(f32(1) - f32(f32(xy / xn) / f32(np.sqrt(y_norm))))
+
+
+@pytest.mark.parametrize("d", [8, 16, 20, 24, 37, 128, 1536])
+def test_cosine_matches_independent_restatement(oracle, d):
+    rng = np.random.default_rng(d)
+    for _ in range(5):
+        x = rng.standard_normal(d).astype(f32); y = (rng.standard_normal(d) * 3).astype(f32)
+        assert np.float32(oracle.cosine(x, y)) == np_cosine_fast(x, y)
+        ref = 1.0 - np.dot(x.astype(np.float64), y.astype(np.float64)) / np.linalg.norm(x.astype(np.float64)) / np.linalg.norm(y.astype(np.float64))
+        assert abs(oracle.cosine(x, y) - ref) < 1e-5
