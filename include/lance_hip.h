@@ -83,11 +83,21 @@ int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, u
  * as train_kmeans does (:1344).  init_centroids: k*d or NULL (random rows from `seed`,
  * kmeans_random_init :149-170).  Given the same inputs, init and seed the centroids,
  * loss and iteration count are bit-identical to the reference algorithm (M-step sums
- * are accumulated per centroid in row order, :371-446).  k <= 4096 in this version.   */
+ * are accumulated per centroid in row order, :371-446).  As in the reference, k > 256
+ * takes the hierarchical path (see lance_hip_kmeans_train_ex).                          */
 int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                            uint32_t k, uint32_t max_iters, double tol, float balance_factor,
                            const void *init_centroids, uint64_t seed, void *centroids_out,
                            double *loss_out_host, uint32_t *iters_out_host);
+
+/* KMeans::new_with_params (kmeans.rs:1008-1073) with every KMeansParams field: k > 256 and
+ * hierarchical_k > 1 selects train_hierarchical_kmeans (:746-1003; init centroids unused, loss 0,
+ * *k_out_host = clusters produced, normally k).  lance_hip_kmeans_train == hierarchical_k 16.  */
+int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
+                              uint32_t k, uint32_t max_iters, double tol, float balance_factor,
+                              uint32_t hierarchical_k, const void *init_centroids, uint64_t seed,
+                              void *centroids_out, double *loss_out_host, uint32_t *iters_out_host,
+                              uint32_t *k_out_host);
 
 /* Building blocks of one Lloyd iteration, for a host that owns the loop (multi-GPU:
  * one process per GPU, rows sharded, one all-reduce per iteration).

@@ -21,7 +21,8 @@ METRICS = {"l2": L2, "L2": L2, "euclidean": L2, "cosine": COSINE, "dot": DOT, 0:
 SYMBOLS = [
     "lance_hip_ctx_create", "lance_hip_ctx_destroy", "lance_hip_last_error", "lance_hip_version",
     "lance_hip_synchronize", "lance_hip_malloc", "lance_hip_free", "lance_hip_memcpy_h2d", "lance_hip_memcpy_d2h",
-    "lance_hip_normalize", "lance_hip_assign", "lance_hip_kmeans_train", "lance_hip_kmeans_estep_partial",
+    "lance_hip_normalize", "lance_hip_assign", "lance_hip_kmeans_train", "lance_hip_kmeans_train_ex",
+    "lance_hip_kmeans_estep_partial",
     "lance_hip_kmeans_finalize", "lance_hip_pq_train", "lance_hip_residual", "lance_hip_pq_encode",
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
     "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
@@ -70,6 +71,8 @@ def load():
         "lance_hip_assign": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp]),
         "lance_hip_kmeans_train": (i32, [vp, i32, i32, vp, u64, u32, u32, u32, f64, f32, vp, u64, vp,
                                          C.POINTER(f64), C.POINTER(u32)]),
+        "lance_hip_kmeans_train_ex": (i32, [vp, i32, i32, vp, u64, u32, u32, u32, f64, f32, u32, vp, u64, vp,
+                                            C.POINTER(f64), C.POINTER(u32), C.POINTER(u32)]),
         "lance_hip_kmeans_estep_partial": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp, vp, C.POINTER(f64)]),
         "lance_hip_kmeans_finalize": (i32, [vp, i32, vp, u32, u32, vp]),
         "lance_hip_pq_train": (i32, [vp, i32, vp, u64, u32, u32, u32, u32, u32, u64, vp, vp]),

@@ -45,6 +45,8 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
                          int k, int B, uint32_t max_iters, double tol, float balance_factor_scaled, bool have_init,
                          const uint64_t *seeds, float *cent, double *loss_out, uint32_t *iters_out);
 
+int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, int target_k, uint32_t max_iters,
+                              double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
 
 }  // namespace lh

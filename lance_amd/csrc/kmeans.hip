@@ -15,6 +15,7 @@
 // row order -- the same f32 addition chain a reference rayon thread executes -- so given
 // the same initial centroids the trained centroids are bit-identical to the CPU result.
 // Per-cluster loss is accumulated in f64 in the same order (kmeans.rs:274-277).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <vector>
@@ -293,6 +294,159 @@ __global__ __launch_bounds__(256) void finalize_centroids_kernel(const float *__
   cent[g] = v;
 }
 
+__global__ __launch_bounds__(256) void gather_rows_u32_kernel(const float *__restrict__ x, int d, const uint32_t *__restrict__ idx,
+                                                              int64_t cnt, float *__restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= cnt * d) return;
+  const int64_t r = g / d;
+  out[g] = x[(int64_t)idx[r] * d + (g - r * d)];
+}
+
+// train_hierarchical_kmeans (kmeans.rs:746-1003): host-driven; every k-means / assignment runs on
+// the device.  The cluster heap follows Rust std BinaryHeap push/pop with Ord = (not finalized, size).
+namespace {
+struct HCluster {
+  size_t id;
+  std::vector<uint32_t> idx;
+  std::vector<float> centroid;
+  bool finalized;
+};
+inline bool hc_le(const HCluster &a, const HCluster &b) {
+  const int ka = a.finalized ? 0 : 1, kb = b.finalized ? 0 : 1;
+  if (ka != kb) return ka < kb;
+  return a.idx.size() <= b.idx.size();
+}
+struct HHeap {
+  std::vector<HCluster> d;
+  void sift_up(size_t start, size_t pos) {
+    HCluster e = std::move(d[pos]);
+    while (pos > start) {
+      const size_t parent = (pos - 1) / 2;
+      if (hc_le(e, d[parent])) break;
+      d[pos] = std::move(d[parent]);
+      pos = parent;
+    }
+    d[pos] = std::move(e);
+  }
+  void push(HCluster c) { d.push_back(std::move(c)); sift_up(0, d.size() - 1); }
+  HCluster pop() {
+    HCluster item = std::move(d.back());
+    d.pop_back();
+    if (!d.empty()) {
+      std::swap(item, d[0]);
+      const size_t end = d.size();
+      size_t pos = 0, child = 1;
+      HCluster e = std::move(d[0]);
+      while (end >= 2 && child <= end - 2) {
+        if (hc_le(d[child], d[child + 1])) child += 1;
+        d[pos] = std::move(d[child]);
+        pos = child;
+        child = 2 * pos + 1;
+      }
+      if (child == end - 1) { d[pos] = std::move(d[child]); pos = child; }
+      d[pos] = std::move(e);
+      sift_up(0, pos);
+    }
+    return item;
+  }
+};
+}  // namespace
+
+static int hier_assign_host(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, const float *cent, int k,
+                            std::vector<uint32_t> &mem) {
+  uint32_t *ids = ctx->scratch_t<uint32_t>("hier.ids", (size_t)n);
+  if (!ids) return LANCE_HIP_ENOMEM;
+  PairwiseArgs pa;
+  pa.x = x; pa.n = n; pa.ldx = d; pa.cent = cent; pa.k = k; pa.ids = ids; pa.out_batch_stride = n;
+  LH_TRY(launch_assign(ctx, pa, d, metric, 1));
+  mem.resize((size_t)n);
+  LH_CHECK_HIP(hipMemcpyAsync(mem.data(), ids, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, int target_k, uint32_t max_iters,
+                              double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out) {
+  uint64_t run = 0;
+  const int initial_k = (int)std::min<int64_t>(std::min(hierarchical_k, target_k), n);
+  float *cdev = ctx->scratch_t<float>("hier.cent", (size_t)std::max(hierarchical_k, initial_k) * d);
+  if (!cdev) return LANCE_HIP_ENOMEM;
+  uint64_t sd = seed + run++;
+  LH_TRY(kmeans_train_batched(ctx, metric, x, n, d, 0, d, initial_k, 1, max_iters, tol, bf_scaled, false, &sd, cdev, nullptr, nullptr));
+  std::vector<uint32_t> mem;
+  LH_TRY(hier_assign_host(ctx, metric, x, n, d, cdev, initial_k, mem));
+  std::vector<float> c0((size_t)initial_k * d);
+  LH_CHECK_HIP(hipMemcpyAsync(c0.data(), cdev, c0.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  HHeap heap;
+  size_t next_id = 0;
+  for (int i = 0; i < initial_k; ++i) {
+    HCluster c;
+    for (int64_t r = 0; r < n; ++r)
+      if (mem[r] == (uint32_t)i) c.idx.push_back((uint32_t)r);
+    if (c.idx.empty()) continue;
+    c.id = next_id++; c.finalized = false;
+    c.centroid.assign(c0.begin() + (size_t)i * d, c0.begin() + (size_t)(i + 1) * d);
+    heap.push(std::move(c));
+  }
+  std::vector<float> sc;
+  while ((int)heap.d.size() < target_k) {
+    if (heap.d.empty()) break;
+    HCluster big = heap.pop();
+    if (big.finalized || big.idx.size() <= 1) { heap.push(std::move(big)); break; }
+    const size_t cluster_size = big.idx.size();
+    const size_t remaining_k = (size_t)target_k - heap.d.size();
+    size_t cluster_k;
+    if (cluster_size <= (size_t)hierarchical_k) {
+      cluster_k = std::min<size_t>(std::min<size_t>(2, remaining_k), cluster_size);
+    } else {
+      cluster_k = std::max<size_t>(std::min<size_t>(std::min<size_t>(cluster_size / hierarchical_k, remaining_k), hierarchical_k), 2);
+    }
+    uint32_t *didx = ctx->scratch_t<uint32_t>("hier.idx", cluster_size);
+    float *sub = ctx->scratch_t<float>("hier.sub", cluster_size * d);
+    if (!didx || !sub) return LANCE_HIP_ENOMEM;
+    LH_CHECK_HIP(hipMemcpyAsync(didx, big.idx.data(), cluster_size * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(gather_rows_u32_kernel, dim3((unsigned)cdiv(cluster_size * d, 256)), dim3(256), 0, ctx->stream, x, d, didx,
+                       (int64_t)cluster_size, sub);
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    sd = seed + run++;
+    LH_TRY(kmeans_train_batched(ctx, metric, sub, (int64_t)cluster_size, d, 0, d, (int)cluster_k, 1, max_iters, tol, bf_scaled, false, &sd,
+                                cdev, nullptr, nullptr));
+    LH_TRY(hier_assign_host(ctx, metric, sub, (int64_t)cluster_size, d, cdev, (int)cluster_k, mem));
+    bool all_same = true, have_first = false;
+    uint32_t first = 0;
+    for (size_t r = 0; r < cluster_size; ++r) {
+      if (mem[r] == LANCE_HIP_NONE) continue;
+      if (have_first) { if (mem[r] != first) all_same = false; } else { first = mem[r]; have_first = true; }
+    }
+    if (all_same) {
+      big.finalized = true;
+      heap.push(std::move(big));
+      continue;
+    }
+    sc.resize(cluster_k * d);
+    LH_CHECK_HIP(hipMemcpyAsync(sc.data(), cdev, sc.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < cluster_k; ++i) {
+      HCluster c;
+      for (size_t r = 0; r < cluster_size; ++r)
+        if (mem[r] == (uint32_t)i) c.idx.push_back(big.idx[r]);
+      if (c.idx.empty()) continue;
+      c.id = next_id++; c.finalized = false;
+      c.centroid.assign(sc.begin() + i * d, sc.begin() + (i + 1) * d);
+      heap.push(std::move(c));
+    }
+  }
+  std::sort(heap.d.begin(), heap.d.end(), [](const HCluster &a, const HCluster &b) { return a.id < b.id; });
+  std::vector<float> flat;
+  flat.reserve(heap.d.size() * d);
+  for (auto &c : heap.d) flat.insert(flat.end(), c.centroid.begin(), c.centroid.end());
+  LH_CHECK_HIP(hipMemcpyAsync(cent_out, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (n_out) *n_out = (uint32_t)heap.d.size();
+  return LANCE_HIP_OK;
+}
+
 }  // namespace lh
 
 using namespace lh;
@@ -315,23 +469,41 @@ int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, u
   return LANCE_HIP_OK;
 }
 
+int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, uint32_t k,
+                              uint32_t max_iters, double tol, float balance_factor, uint32_t hierarchical_k,
+                              const void *init_centroids, uint64_t seed, void *centroids_out, double *loss_out_host,
+                              uint32_t *iters_out_host, uint32_t *k_out_host) {
+  LH_REQUIRE(ctx && x && centroids_out, "kmeans_train: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32, "kmeans_train: only f32 is implemented in this version");
+  LH_REQUIRE(d > 0 && k > 0 && n > 0, "kmeans_train: empty problem");
+  LH_REQUIRE(n >= k, "KMeans: training does not have sufficient data points: n(%llu) is smaller than k(%u)", (unsigned long long)n, k);
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  float *cent = static_cast<float *>(centroids_out);
+  const int km = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
+  // train_kmeans :1344: params.balance_factor /= data.len()
+  const float bf = balance_factor / (float)n;
+  if (k_out_host) *k_out_host = k;
+  // new_with_params :1027: hierarchical clustering if k > 256 and hierarchical_k > 1 (initial centroids are ignored there)
+  if (k > 256 && hierarchical_k > 1) {
+    if (loss_out_host) *loss_out_host = 0.0;  // "Loss is not meaningful for hierarchical clustering" (:1001)
+    if (iters_out_host) *iters_out_host = 0;
+    return kmeans_train_hierarchical(ctx, km, static_cast<const float *>(x), (int64_t)n, (int)d, (int)k, max_iters, tol, bf,
+                                     (int)hierarchical_k, seed, cent, k_out_host);
+  }
+  if (init_centroids && init_centroids != centroids_out)
+    LH_CHECK_HIP(hipMemcpyAsync(cent, init_centroids, (size_t)k * d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  uint64_t seeds[1] = {seed};
+  return kmeans_train_batched(ctx, km, static_cast<const float *>(x), (int64_t)n, d, 0, (int)d, (int)k, 1, max_iters, tol, bf,
+                              init_centroids != nullptr, seeds, cent, loss_out_host, iters_out_host);
+}
+
 int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                            uint32_t k, uint32_t max_iters, double tol, float balance_factor,
                            const void *init_centroids, uint64_t seed, void *centroids_out,
                            double *loss_out_host, uint32_t *iters_out_host) {
-  LH_REQUIRE(ctx && x && centroids_out, "kmeans_train: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "kmeans_train: only f32 is implemented in this version");
-  LH_REQUIRE(d > 0 && k > 0 && n > 0, "kmeans_train: empty problem");
-  LH_CHECK_HIP(hipSetDevice(ctx->device));
-  float *cent = static_cast<float *>(centroids_out);
-  if (init_centroids && init_centroids != centroids_out)
-    LH_CHECK_HIP(hipMemcpyAsync(cent, init_centroids, (size_t)k * d * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  // train_kmeans :1344: params.balance_factor /= data.len()
-  const float bf = balance_factor / (float)n;
-  uint64_t seeds[1] = {seed};
-  return kmeans_train_batched(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, static_cast<const float *>(x),
-                              (int64_t)n, d, 0, (int)d, (int)k, 1, max_iters, tol, bf, init_centroids != nullptr, seeds,
-                              cent, loss_out_host, iters_out_host);
+  // KMeansParams default hierarchical_k = 16 (kmeans.rs:92-103)
+  return lance_hip_kmeans_train_ex(ctx, dtype, metric, x, n, d, k, max_iters, tol, balance_factor, 16, init_centroids, seed,
+                                   centroids_out, loss_out_host, iters_out_host, nullptr);
 }
 
 int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,

@@ -87,16 +87,18 @@ class Engine:
                                         _ptr(ids), _ptr(dists)))
         return ids, dists
 
-    def kmeans_train(self, x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2"):
+    def kmeans_train(self, x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2", hierarchical_k=16):
+        """KMeans::new_with_params: flat Lloyd for k <= 256 (or hierarchical_k <= 1), hierarchical otherwise."""
         x = to_device(x, torch.float32)
         n, d = x.shape
-        cent = torch.empty((k, d), dtype=torch.float32, device=x.device)
+        cent = torch.zeros((k, d), dtype=torch.float32, device=x.device)
         init_t = None if init is None else to_device(init, torch.float32)
-        loss = C.c_double(0); iters = C.c_uint32(0)
+        loss = C.c_double(0); iters = C.c_uint32(0); kout = C.c_uint32(0)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_kmeans_train(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, k, max_iters, tol,
-                                              balance_factor, _ptr(init_t), seed, _ptr(cent), C.byref(loss), C.byref(iters)))
-        return cent, loss.value, iters.value
+        check(self.lib.lance_hip_kmeans_train_ex(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, k, max_iters, tol,
+                                                 balance_factor, hierarchical_k, _ptr(init_t), seed, _ptr(cent), C.byref(loss),
+                                                 C.byref(iters), C.byref(kout)))
+        return cent[: kout.value], loss.value, iters.value
 
     def kmeans_estep_partial(self, x, centroids, metric="l2", bias=None):
         """-> (buf [k*d sums | k counts] f32, losses [k] f64, radius [k] f32) device tensors"""

@@ -48,6 +48,7 @@ def lib():
         _lib.orc_sort_fetch.restype = C.c_size_t
         _lib.orc_partition_layout.restype = C.c_size_t
         _lib.orc_kmeans_train_f32.restype = C.c_int
+        _lib.orc_kmeans_train_hierarchical_f32.restype = C.c_size_t
     return _lib
 
 
@@ -161,6 +162,17 @@ def kmeans_train(x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, se
                                     C.c_uint32(max_iters), C.c_double(tol), C.c_float(balance_factor),
                                     _p(init_a), C.c_uint64(seed), _p(cent), C.byref(loss), _p(sizes))
     return cent, loss.value, int(it), sizes
+
+
+def kmeans_train_hierarchical(x, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, hierarchical_k=16, seed=0, metric="l2"):
+    """train_hierarchical_kmeans (kmeans.rs:746-1003) -> centroids [n_clusters, d]"""
+    x = _f32(x)
+    n, d = x.shape
+    cent = np.zeros((k, d), np.float32)
+    got = lib().orc_kmeans_train_hierarchical_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(k), C.c_uint32(max_iters),
+                                                  C.c_double(tol), C.c_float(balance_factor_scaled), C.c_size_t(hierarchical_k),
+                                                  C.c_uint64(seed), _p(cent))
+    return cent[:got]
 
 
 def residual(x, centroids, part_ids):

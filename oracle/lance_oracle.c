@@ -534,6 +534,140 @@ int orc_kmeans_train_f32(int metric, const float *x, size_t n, size_t d, size_t 
   return iters;
 }
 
+
+/* ------------------------------------------------------------------------- */
+/* a8: KMeans::train_hierarchical_kmeans  kmeans.rs:746-1003 (k > 256, hierarchical_k > 1;
+ * dispatcher new_with_params :1008-1073).  Start with hierarchical_k clusters, then repeatedly
+ * pop the largest non-finalized cluster from a std BinaryHeap (ordered by (not finalized, size))
+ * and split it with a sub-k-means; final centroids ordered by creation id; loss = 0.
+ * Each inner train_kmeans applies the k*512 row cap (:623-627).  Seeds: run r uses seed + r.   */
+typedef struct { size_t id; uint32_t *idx; size_t n; float *centroid; int finalized; } orc_cluster;
+static inline int orc_cluster_le(const orc_cluster *a, const orc_cluster *b) {
+  /* a <= b under Ord: non-finalized > finalized, then size */
+  int ka = a->finalized ? 0 : 1, kb = b->finalized ? 0 : 1;
+  if (ka != kb) return ka < kb;
+  return a->n <= b->n;
+}
+typedef struct { orc_cluster *d; size_t len; } orc_cheap;
+static void orc_cheap_sift_up(orc_cheap *h, size_t start, size_t pos) {
+  orc_cluster e = h->d[pos];
+  while (pos > start) {
+    size_t parent = (pos - 1) / 2;
+    if (orc_cluster_le(&e, &h->d[parent])) break;
+    h->d[pos] = h->d[parent];
+    pos = parent;
+  }
+  h->d[pos] = e;
+}
+static void orc_cheap_push(orc_cheap *h, orc_cluster c) { h->d[h->len] = c; orc_cheap_sift_up(h, 0, h->len); h->len++; }
+static orc_cluster orc_cheap_pop(orc_cheap *h) {
+  orc_cluster item = h->d[--h->len];
+  if (h->len > 0) {
+    orc_cluster t = h->d[0]; h->d[0] = item; item = t;
+    size_t end = h->len, pos = 0, child = 1;
+    orc_cluster e = h->d[0];
+    while (end >= 2 && child <= end - 2) {
+      if (orc_cluster_le(&h->d[child], &h->d[child + 1])) child += 1;
+      h->d[pos] = h->d[child]; pos = child; child = 2 * pos + 1;
+    }
+    if (child == end - 1) { h->d[pos] = h->d[child]; pos = child; }
+    h->d[pos] = e;
+    orc_cheap_sift_up(h, 0, pos);
+  }
+  return item;
+}
+
+static int orc_kmeans_capped(int metric, const float *x, size_t n, size_t d, size_t k, uint32_t max_iters, double tol,
+                             float bf, uint64_t seed, float *cent) {
+  size_t rows = n >= k * 512 ? k * 512 : n;
+  double loss;
+  return orc_kmeans_train_f32(metric, x, rows, d, k, max_iters, tol, bf, NULL, seed, cent, &loss, NULL);
+}
+
+/* returns the number of clusters produced (== target_k unless splitting stalls) */
+size_t orc_kmeans_train_hierarchical_f32(int metric, const float *x, size_t n, size_t d, size_t target_k,
+                                         uint32_t max_iters, double tol, float balance_factor_scaled,
+                                         size_t hierarchical_k, uint64_t seed, float *centroids_out) {
+  uint64_t run = 0;
+  size_t initial_k = hierarchical_k < target_k ? hierarchical_k : target_k;
+  if (initial_k > n) initial_k = n;
+  float *c0 = (float *)malloc(initial_k * d * sizeof(float));
+  orc_kmeans_capped(metric, x, n, d, initial_k, max_iters, tol, balance_factor_scaled, seed + run++, c0);
+  uint32_t *mem = (uint32_t *)malloc(n * sizeof(uint32_t));
+  orc_assign_f32(metric, x, n, d, c0, initial_k, NULL, mem, NULL);
+  orc_cheap heap; heap.d = (orc_cluster *)malloc((target_k + hierarchical_k + 2) * sizeof(orc_cluster)); heap.len = 0;
+  size_t next_id = 0;
+  for (size_t i = 0; i < initial_k; i++) {
+    size_t cnt = 0;
+    for (size_t r = 0; r < n; r++) cnt += mem[r] == (uint32_t)i;
+    if (!cnt) continue;
+    orc_cluster c; c.id = next_id++; c.n = cnt; c.finalized = 0;
+    c.idx = (uint32_t *)malloc(cnt * sizeof(uint32_t));
+    size_t w = 0;
+    for (size_t r = 0; r < n; r++) if (mem[r] == (uint32_t)i) c.idx[w++] = (uint32_t)r;
+    c.centroid = (float *)malloc(d * sizeof(float));
+    memcpy(c.centroid, c0 + i * d, d * sizeof(float));
+    orc_cheap_push(&heap, c);
+  }
+  free(c0); free(mem);
+  while (heap.len < target_k) {
+    if (heap.len == 0) break;
+    orc_cluster big = orc_cheap_pop(&heap);
+    if (big.finalized || big.n <= 1) { orc_cheap_push(&heap, big); break; }
+    size_t remaining_k = target_k - heap.len;
+    size_t cluster_k;
+    if (big.n <= hierarchical_k) {
+      cluster_k = 2; if (remaining_k < cluster_k) cluster_k = remaining_k; if (big.n < cluster_k) cluster_k = big.n;
+    } else {
+      cluster_k = big.n / hierarchical_k;
+      if (remaining_k < cluster_k) cluster_k = remaining_k;
+      if (hierarchical_k < cluster_k) cluster_k = hierarchical_k;
+      if (cluster_k < 2) cluster_k = 2;
+    }
+    float *sub = (float *)malloc(big.n * d * sizeof(float));
+    for (size_t r = 0; r < big.n; r++) memcpy(sub + r * d, x + (size_t)big.idx[r] * d, d * sizeof(float));
+    float *sc = (float *)malloc(cluster_k * d * sizeof(float));
+    orc_kmeans_capped(metric, sub, big.n, d, cluster_k, max_iters, tol, balance_factor_scaled, seed + run++, sc);
+    uint32_t *sm = (uint32_t *)malloc(big.n * sizeof(uint32_t));
+    orc_assign_f32(metric, sub, big.n, d, sc, cluster_k, NULL, sm, NULL);
+    int all_same = 1, have_first = 0; uint32_t first = 0;
+    for (size_t r = 0; r < big.n; r++) {
+      if (sm[r] == ORC_NONE) continue;
+      if (have_first) { if (sm[r] != first) all_same = 0; } else { first = sm[r]; have_first = 1; }
+    }
+    if (all_same) {
+      big.finalized = 1;
+      orc_cheap_push(&heap, big);
+    } else {
+      for (size_t i = 0; i < cluster_k; i++) {
+        size_t cnt = 0;
+        for (size_t r = 0; r < big.n; r++) cnt += sm[r] == (uint32_t)i;
+        if (!cnt) continue;
+        orc_cluster c; c.id = next_id++; c.n = cnt; c.finalized = 0;
+        c.idx = (uint32_t *)malloc(cnt * sizeof(uint32_t));
+        size_t w = 0;
+        for (size_t r = 0; r < big.n; r++) if (sm[r] == (uint32_t)i) c.idx[w++] = big.idx[r];
+        c.centroid = (float *)malloc(d * sizeof(float));
+        memcpy(c.centroid, sc + i * d, d * sizeof(float));
+        orc_cheap_push(&heap, c);
+      }
+      free(big.idx); free(big.centroid);
+    }
+    free(sub); free(sc); free(sm);
+  }
+  /* sort by id, emit */
+  size_t outn = heap.len;
+  for (size_t i = 0; i < outn; i++)
+    for (size_t j = i + 1; j < outn; j++)
+      if (heap.d[j].id < heap.d[i].id) { orc_cluster t = heap.d[i]; heap.d[i] = heap.d[j]; heap.d[j] = t; }
+  for (size_t i = 0; i < outn; i++) {
+    memcpy(centroids_out + i * d, heap.d[i].centroid, d * sizeof(float));
+    free(heap.d[i].idx); free(heap.d[i].centroid);
+  }
+  free(heap.d);
+  return outn;
+}
+
 /* ------------------------------------------------------------------------- */
 /* a10: do_compute_residual  residual.rs:58-102 */
 void orc_residual_f32(const float *x, size_t n, size_t d, const float *cent,

@@ -74,6 +74,16 @@ def test_kmeans_train_bit_exact(eng, oracle, n, d, k, bf):
     assert loss == ol
 
 
+@pytest.mark.parametrize("n,d,k", [(20000, 16, 300), (9000, 32, 257)])
+def test_hierarchical_kmeans_bit_exact(eng, oracle, n, d, k):
+    # k > 256 -> train_hierarchical_kmeans (kmeans.rs:746-1003, dispatcher :1027)
+    x = sift_like(n, d, n + k)
+    cent, loss, _ = eng.kmeans_train(x, k, max_iters=12, balance_factor=1.0, seed=5)
+    oc = oracle.kmeans_train_hierarchical(x, k, max_iters=12, balance_factor_scaled=f32(1.0) / f32(n), seed=5)
+    assert cent.shape[0] == oc.shape[0] == k and loss == 0.0
+    assert (_np(cent).view(np.uint32) == oc.view(np.uint32)).all()
+
+
 def test_kmeans_empty_cluster_split(eng, oracle):
     # many duplicates -> empty clusters -> split_clusters (kmeans.rs:174-207) on both sides
     rng = np.random.default_rng(5)
