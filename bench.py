@@ -50,8 +50,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("LANCE_BENCH_FORCE_DIST") == "1"   # exercise the sharded build with world_size 1
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import lance_amd
@@ -70,7 +72,7 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        if world > 1:
+        if world > 1 or force_dist:
             from lance_amd import dist as ld
             ix = ld.create_index_sharded(x, metric="l2", num_partitions=nlist, num_sub_vectors=m)
         else:
@@ -207,7 +209,7 @@ def main():
     elif world == 1:
         result["cpu_baseline"] = None
     print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
