@@ -2,13 +2,14 @@
 
 The reference has no distributed path; this is the MI355X-native extension:
 
-  * k-means (IVF and each PQ sub-quantiser): the training rows are sharded by contiguous row
-    ranges; centroids are replicated.  Each Lloyd iteration runs the local E-step and the
+  * IVF k-means: the training rows are sharded by contiguous row ranges; centroids are replicated.  Each Lloyd iteration runs the local E-step and the
     local per-centroid partial sums on the device (lance_hip_kmeans_estep_partial), then ONE
     all-reduce(sum) of the fused f32 buffer [k*d sums | k counts] (129 KiB for SIFT IVF256),
     one all-reduce(sum) of the f64 per-cluster losses and one all-reduce(max) of the radii,
     after which every rank finalises identical centroids and evaluates the same convergence
     test (kmeans.rs:665-712).  Empty-cluster splits use a seed shared by all ranks.
+  * PQ codebook: the M sub-quantisers are independent k-means problems (pq/builder.rs:109-138), so they
+    are spread over the ranks (M=16 >= 8) and the 8 KiB codebook slices are all-gathered.
   * transform (assign + residual + PQ encode): embarrassingly parallel by rows; the
     (part id, code) columns are all-gathered so that every rank holds a full replica of the
     index for search (16 MB of codes for SIFT-1M).
@@ -160,18 +161,29 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
         part, _ = eng.assign(psample, cent, "l2")
         psample = eng.residual(psample, cent, part)
     kc = 1 << num_bits
-    rows = min(psample.shape[0], sample_rate * kc)
-    rows = min(rows, kc * 512) if rows >= kc * 512 else rows
-    psample = psample[:rows]
     sd = d // num_sub_vectors
 
     def train_pq():
-        cbs, its = [], []
-        for mm in range(num_sub_vectors):
-            sub = shard(psample)[:, mm * sd:(mm + 1) * sd].contiguous()
-            c, _, it = train_kmeans_sharded(eng, sub, kc, rows, max_iters, 1e-4, 0.0, None, seed + 2 + mm, "l2", group)
-            cbs.append(c); its.append(it)
-        return torch.stack(cbs), np.array(its, np.uint32)
+        # model-parallel over the M independent sub-quantisers (pq/builder.rs:109-138 trains them one after the
+        # other): rank r trains a contiguous block with the batched single-GPU trainer on the (small, replicated)
+        # residual sample, seeds seed+2+m as in the single-GPU build, then the codebook slices are all-gathered.
+        per = (num_sub_vectors + world - 1) // world
+        m0, m1 = min(rank * per, num_sub_vectors), min((rank + 1) * per, num_sub_vectors)
+        cb_all = torch.zeros((per * world, kc, sd), dtype=torch.float32, device=x.device)
+        its_all = torch.zeros(per * world, dtype=torch.int32, device=x.device)
+        mine = torch.zeros((per, kc, sd), dtype=torch.float32, device=x.device)
+        its = torch.zeros(per, dtype=torch.int32, device=x.device)
+        if m1 > m0:
+            cols = psample[:, m0 * sd: m1 * sd].contiguous()
+            c, it = eng.pq_train(cols, m1 - m0, num_bits, max_iters, sample_rate, seed + 2 + m0)
+            mine[: m1 - m0] = c
+            its[: m1 - m0] = torch.from_numpy(it.astype(np.int32)).to(x.device)
+        dist.all_gather_into_tensor(cb_all, mine, group=group)
+        dist.all_gather_into_tensor(its_all, its, group=group)
+        # blocks are laid out rank-major with `per` slots each; compact to the first M
+        keep = torch.cat([torch.arange(r * per, r * per + max(0, min((r + 1) * per, num_sub_vectors) - min(r * per, num_sub_vectors)),
+                                       device=x.device) for r in range(world)])
+        return cb_all[keep].contiguous(), its_all[keep].cpu().numpy().astype(np.uint32)
 
     cb, stats.pq_iters = timed("train_pq", train_pq)
 
