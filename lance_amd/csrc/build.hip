@@ -13,6 +13,8 @@
 // import/export convert).
 #include <vector>
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 #include "exact.cuh"
 #include "index.h"
@@ -47,13 +49,15 @@ __global__ __launch_bounds__(256) void finite_mask_kernel(const float *__restric
 // a10: out[r] = x[r] - centroids[part_ids[r]] ; coalesced over the flattened [n*d] range.
 __global__ __launch_bounds__(256) void residual_kernel(const float *__restrict__ x, int64_t n, int d,
                                                        const float *__restrict__ cent, const uint32_t *__restrict__ part_ids,
-                                                       float *__restrict__ out) {
+                                                       float *__restrict__ out, int f16) {
   const int64_t total = n * d;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
     const int64_t r = g / d;
     const int t = (int)(g - r * d);
     const uint32_t p = part_ids[r];
-    out[g] = p == LANCE_HIP_NONE ? 0.0f : x[g] - cent[(int64_t)p * d + t];
+    float v = p == LANCE_HIP_NONE ? 0.0f : x[g] - cent[(int64_t)p * d + t];
+    if (f16) v = __half2float(__float2half_rn(v));  // `*v - *cent` in half::f16 (residual.rs:96)
+    out[g] = v;
   }
 }
 
@@ -121,6 +125,14 @@ static int check_pq_params(uint32_t d, uint32_t m, uint32_t nbits) {
   return LANCE_HIP_OK;
 }
 
+int launch_residual(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, float *out, bool f16) {
+  if (n == 0) return LANCE_HIP_OK;
+  const unsigned grid = (unsigned)std::min<uint64_t>(cdiv((uint64_t)n * d, 256), 65536);
+  hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, ctx->stream, x, n, d, cent, part_ids, out, f16 ? 1 : 0);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out) {
   if (n == 0) return LANCE_HIP_OK;
   hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
@@ -167,13 +179,30 @@ int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n
 int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, const void *centroids,
                        const uint32_t *part_ids, void *out) {
   LH_REQUIRE(ctx && x && centroids && part_ids && out, "residual: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "residual: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "residual"));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (n == 0) return LANCE_HIP_OK;
-  const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(n * d, 256), 65536);
-  hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const float *>(x), (int64_t)n,
-                     (int)d, static_cast<const float *>(centroids), part_ids, static_cast<float *>(out));
-  LH_CHECK_HIP(hipGetLastError());
+  const bool f16 = dtype == LANCE_HIP_F16;
+  const float *xf, *cf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  // the number of centroids is not part of this call: widen lazily is impossible, so f16 callers pass
+  // centroids through lance_hip_ivfpq_encode; here the f16 centroid table is bounded by max(part_ids)+1
+  uint32_t kmax = 0;
+  if (f16) {
+    std::vector<uint32_t> ph(n);
+    LH_CHECK_HIP(hipMemcpyAsync(ph.data(), part_ids, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint64_t r = 0; r < n; ++r)
+      if (ph[r] != LANCE_HIP_NONE) kmax = std::max(kmax, ph[r] + 1);
+  }
+  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)kmax * d, "f16.cent", &cf));
+  float *of = static_cast<float *>(out);
+  if (f16) {
+    of = ctx->scratch_t<float>("f16.residual_out", (size_t)n * d);
+    if (!of) return LANCE_HIP_ENOMEM;
+  }
+  LH_TRY(launch_residual(ctx, xf, (int64_t)n, (int)d, cf, part_ids, of, f16));
+  if (f16) LH_TRY(from_f32(ctx, dtype, of, out, (size_t)n * d));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
@@ -181,11 +210,14 @@ int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n,
 int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                         const void *codebook, uint32_t m, uint32_t nbits, uint8_t *codes) {
   LH_REQUIRE(ctx && x && codebook && codes, "pq_encode: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "pq_encode: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "pq_encode"));
   LH_TRY(check_pq_params(d, m, nbits));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, static_cast<const float *>(x),
-                          (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes));
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "pq_encode: f16 dot is not implemented in this version");
+  const float *xf, *cbf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  LH_TRY(as_f32(ctx, dtype, codebook, (size_t)256 * d, "f16.codebook", &cbf));
+  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, xf, (int64_t)n, (int)d, cbf, (int)m, codes));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
@@ -194,11 +226,17 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
                            const void *centroids, uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
                            uint32_t *part_ids, uint8_t *codes, double *loss_out_host) {
   LH_REQUIRE(ctx && x && centroids && codebook && part_ids && codes, "ivfpq_encode: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "ivfpq_encode: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "ivfpq_encode"));
   LH_TRY(check_pq_params(d, m, nbits));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (n == 0) { if (loss_out_host) *loss_out_host = 0.0; return LANCE_HIP_OK; }
-  const float *xs = static_cast<const float *>(x);
+  const bool f16 = dtype == LANCE_HIP_F16;
+  LH_REQUIRE(!(f16 && metric != LANCE_HIP_L2), "ivfpq_encode: f16 supports the L2 metric only in this version");
+  const float *xs, *centf, *cbf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xs));
+  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)nlist * d, "f16.cent", &centf));
+  LH_TRY(as_f32(ctx, dtype, codebook, (size_t)256 * d, "f16.codebook", &cbf));
+  centroids = centf; codebook = cbf;
   const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   if (metric == LANCE_HIP_COSINE) {
     float *xn = ctx->scratch_t<float>("encode.norm", (size_t)n * d);
@@ -218,9 +256,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   if (scan_metric == LANCE_HIP_L2) {
     float *res = ctx->scratch_t<float>("encode.residual", (size_t)n * d);
     if (!res) return LANCE_HIP_ENOMEM;
-    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(n * d, 256), 65536);
-    hipLaunchKernelGGL(residual_kernel, dim3(grid), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d,
-                       static_cast<const float *>(centroids), part_ids, res);
+    LH_TRY(launch_residual(ctx, xs, (int64_t)n, (int)d, static_cast<const float *>(centroids), part_ids, res, f16));
     enc_in = res;
   }
   LH_TRY(pq_encode_launch(ctx, scan_metric, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes));
@@ -246,15 +282,20 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
 static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,
                               const void *codebook, uint32_t m, uint32_t nbits, lance_hip_index **out) {
   LH_REQUIRE(ctx && centroids && codebook && out, "index: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "index: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "index"));
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "index: f16 supports the L2 metric only in this version");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_COSINE || metric == LANCE_HIP_DOT, "index: bad metric %d", metric);
   LH_REQUIRE(nlist > 0 && nlist <= 8192, "index: nlist=%u not supported in this version (1..8192)", nlist);
   LH_TRY(check_pq_params(d, m, nbits));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   auto *ix = new lance_hip_index();
   ix->device = ctx->device; ix->metric = metric; ix->d = d; ix->nlist = nlist; ix->m = m; ix->nbits = nbits;
-  int r = dev_dup(ctx, centroids, (size_t)nlist * d * 4, reinterpret_cast<void **>(&ix->centroids));
-  if (r == LANCE_HIP_OK) r = dev_dup(ctx, codebook, (size_t)m * 256 * (d / m) * 4, reinterpret_cast<void **>(&ix->codebook));
+  ix->dtype = dtype;
+  // the index keeps f32 copies of the model (f16 widens exactly); the scan rounds the residual query to f16 when dtype is f16
+  int r = dev_dup(ctx, nullptr, (size_t)nlist * d * 4, reinterpret_cast<void **>(&ix->centroids));
+  if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, centroids, (size_t)nlist * d, ix->centroids);
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)m * 256 * (d / m) * 4, reinterpret_cast<void **>(&ix->codebook));
+  if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, codebook, (size_t)m * 256 * (d / m), ix->codebook);
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)(nlist + 1) * 4, reinterpret_cast<void **>(&ix->part_offsets));
   if (r != LANCE_HIP_OK) { delete ix; return r; }
   *out = ix;
@@ -329,7 +370,7 @@ void lance_hip_index_destroy(lance_hip_index *idx) { delete idx; }
 
 int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw) {
   LH_REQUIRE(idx, "index is NULL");
-  idx->raw = static_cast<const float *>(x);
+  idx->raw = x;   // element type = the index's dtype
   idx->n_raw = n_raw;
   return LANCE_HIP_OK;
 }

@@ -1,0 +1,62 @@
+// dtype.hip -- element-type plumbing: f16 buffers are widened (exactly) to f32 scratch before
+// the f32 kernels run and narrowed on the way out.  See f16.h for where rounding is applied.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace lh {
+
+__global__ __launch_bounds__(256) void widen_f16_kernel(const __half *__restrict__ in, float *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = __half2float(in[i]);
+}
+__global__ __launch_bounds__(256) void narrow_f16_kernel(const float *__restrict__ in, __half *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = __float2half_rn(in[i]);
+}
+
+int check_dtype(int dtype, const char *what) {
+  LH_REQUIRE(dtype == LANCE_HIP_F32 || dtype == LANCE_HIP_F16, "%s: unsupported element type %d (f32 = 0, f16 = 1)", what, dtype);
+  return LANCE_HIP_OK;
+}
+
+int as_f32(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, const char *slot, const float **out) {
+  if (dtype == LANCE_HIP_F32 || p == nullptr) {
+    *out = static_cast<const float *>(p);
+    return LANCE_HIP_OK;
+  }
+  float *w = ctx->scratch_t<float>(slot, count ? count : 1);
+  if (!w) return LANCE_HIP_ENOMEM;
+  if (count) {
+    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(count, 256), 65536);
+    hipLaunchKernelGGL(widen_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const __half *>(p), w, (int64_t)count);
+    LH_CHECK_HIP(hipGetLastError());
+  }
+  *out = w;
+  return LANCE_HIP_OK;
+}
+
+int widen_into(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float *dst) {
+  if (count == 0) return LANCE_HIP_OK;
+  if (dtype == LANCE_HIP_F32) {
+    LH_CHECK_HIP(hipMemcpyAsync(dst, p, count * 4, hipMemcpyDefault, ctx->stream));
+  } else {
+    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(count, 256), 65536);
+    hipLaunchKernelGGL(widen_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const __half *>(p), dst, (int64_t)count);
+    LH_CHECK_HIP(hipGetLastError());
+  }
+  return LANCE_HIP_OK;
+}
+
+int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t count) {
+  if (count == 0 || static_cast<const void *>(src) == dst) return LANCE_HIP_OK;
+  if (dtype == LANCE_HIP_F32) {
+    LH_CHECK_HIP(hipMemcpyAsync(dst, src, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(count, 256), 65536);
+    hipLaunchKernelGGL(narrow_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, src, static_cast<__half *>(dst), (int64_t)count);
+    LH_CHECK_HIP(hipGetLastError());
+  }
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh

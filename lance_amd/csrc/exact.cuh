@@ -13,6 +13,7 @@
 // 16-chunk), which lets the compiler use packed v_pk_add_f32 / v_pk_mul_f32 -- the
 // element-wise IEEE result is unchanged, only two lanes share an instruction.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -116,10 +117,16 @@ __device__ __forceinline__ float dist_exact(const RegVec<D> &a, const float *__r
   return s + tot;
 }
 
+__device__ __forceinline__ float ld_elem(const float *p, int i) { return p[i]; }
+__device__ __forceinline__ float ld_elem(const __half *p, int i) { return __half2float(p[i]); }  // `as_()` widening, exact
+
 // Runtime-d version (both operands through pointers); same order.  Used by the
-// generic-dimension fallbacks and by small host-order helpers.
-template <int METRIC>
-__device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, const float *__restrict__ b, int d) {
+// generic-dimension fallbacks and by small host-order helpers.  TB = float or __half
+// (f16 elements are widened one by one, l2.rs:128-159).
+template <int METRIC, typename TB = float>
+__device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, const TB *__restrict__ bp, int d) {
+  struct BView { const TB *p; __device__ __forceinline__ float operator[](int i) const { return ld_elem(p, i); } };
+  const BView b{bp};
   const int full = d / 16 * 16;
   float s = 0.0f;
   if (full != d) {

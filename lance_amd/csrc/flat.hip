@@ -188,7 +188,8 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
                                    uint64_t n, uint32_t d, const void *q, uint32_t nq, uint32_t k, uint64_t *ids,
                                    float *dists) {
   LH_REQUIRE(ctx && (n == 0 || x) && (nq == 0 || (q && ids && dists)), "flat_topk: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "flat_topk: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "flat_topk"));
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "flat_topk: f16 supports L2 only in this version");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "flat_topk: bad metric %d", metric);
   LH_REQUIRE(k > 0 && k <= 1024, "flat_topk: k=%u not supported (1..1024)", k);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -198,8 +199,11 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
   nsplit = std::max(1, std::min<int>(nsplit, (int)(2048 / k)));
   nsplit = (int)std::min<uint64_t>(nsplit, std::max<uint64_t>(1, cdiv(n, 256)));
   FlatArgs a;
-  a.x = static_cast<const float *>(x); a.row_ids = row_ids; a.n = (int64_t)n; a.d = (int)d;
-  a.q = static_cast<const float *>(q); a.nq = (int)nq; a.k = (int)k; a.nsplit = nsplit;
+  const float *xf, *qf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf));
+  a.x = xf; a.row_ids = row_ids; a.n = (int64_t)n; a.d = (int)d;
+  a.q = qf; a.nq = (int)nq; a.k = (int)k; a.nsplit = nsplit;
   a.rows_per_split = (int64_t)cdiv(n > 0 ? n : 1, nsplit);
   a.lkeys = ctx->scratch_t<uint32_t>("flat.lkeys", (size_t)nsplit * nq * k);
   a.lrids = ctx->scratch_t<uint64_t>("flat.lrids", (size_t)nsplit * nq * k);

@@ -6,6 +6,7 @@
 struct lance_hip_index {
   int device = 0;
   int metric = 0;
+  int dtype = 0;                  // element type of queries / raw vectors (model is kept widened to f32)
   uint32_t d = 0, nlist = 0, m = 0, nbits = 8;
   uint64_t n = 0;                 // rows stored (rows with part id NONE are dropped)
   float *centroids = nullptr;     // [nlist][d]
@@ -14,7 +15,7 @@ struct lance_hip_index {
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][m] row-major, rows grouped by partition
   uint64_t *row_ids = nullptr;    // [n] in the same order
-  const float *raw = nullptr;     // borrowed raw vectors for refine, indexed by row id
+  const void *raw = nullptr;      // borrowed raw vectors (dtype elements) for refine, indexed by row id
   uint64_t n_raw = 0;
   uint32_t max_part = 0;
   ~lance_hip_index();

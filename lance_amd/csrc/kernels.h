@@ -41,12 +41,21 @@ int launch_dist_matrix(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
 int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_stride, int k, int batches,
                  uint32_t *starts, uint32_t *sorted_rows, int64_t out_stride, const uint8_t *active);
 
+// f16_arith: T = f16 -- x / cent hold f16-representable values and the M-step rounds like half::f16
 int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int64_t ldx, int x_batch_off, int d,
                          int k, int B, uint32_t max_iters, double tol, float balance_factor_scaled, bool have_init,
-                         const uint64_t *seeds, float *cent, double *loss_out, uint32_t *iters_out);
+                         const uint64_t *seeds, float *cent, double *loss_out, uint32_t *iters_out, bool f16_arith = false);
 
 int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, int target_k, uint32_t max_iters,
-                              double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out);
+                              double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out,
+                              bool f16_arith = false);
+// element-type plumbing (dtype.hip)
+int check_dtype(int dtype, const char *what);
+int as_f32(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, const char *slot, const float **out);
+int widen_into(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float *dst);
+int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t count);
+int launch_residual(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, float *out, bool f16);
+
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
 
 }  // namespace lh

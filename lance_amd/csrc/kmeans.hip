@@ -20,8 +20,11 @@
 #include <cmath>
 #include <vector>
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 #include "exact.cuh"
+#include "f16.h"
 #include "kernels.h"
 #include "rng.h"
 
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
                                                                 int d, int k, const uint32_t *__restrict__ sorted_rows,
                                                                 int64_t rows_stride, const uint32_t *__restrict__ starts,
                                                                 float *__restrict__ cent, int64_t cent_batch_stride,
-                                                                const uint8_t *__restrict__ active, int scale) {
+                                                                const uint8_t *__restrict__ active, int scale, int f16) {
   const int b = blockIdx.y;
   if (active && !active[b]) return;
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -46,18 +49,29 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
   const uint32_t s = st[c], e = st[c + 1];
   float acc = 0.0f;
   uint32_t i = s;
-  for (; i + 8 <= e; i += 8) {
-    float v[8];
+  if (f16) {
+    // T = half::f16: `*c += *v` and `*v *= norm` are f16 operations (f32 op, round to binary16)
+    for (; i < e; ++i) acc = __half2float(__float2half_rn(acc + xb[(int64_t)rows[i] * ldx]));
+  } else {
+    for (; i + 8 <= e; i += 8) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)rows[i + u] * ldx];
+      for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)rows[i + u] * ldx];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < e; ++i) acc += xb[(int64_t)rows[i] * ldx];
   }
-  for (; i < e; ++i) acc += xb[(int64_t)rows[i] * ldx];
   const uint32_t cnt = e - s;
   if (scale && cnt > 0) {
-    const float norm = 1.0f / (float)cnt;
-    acc *= norm;
+    if (f16) {
+      const float cnt_h = __half2float(__float2half_rn((float)cnt));        // T::from_usize(cnt)
+      const float norm = __half2float(__float2half_rn(1.0f / cnt_h));        // T::one() / cnt
+      acc = __half2float(__float2half_rn(acc * norm));
+    } else {
+      const float norm = 1.0f / (float)cnt;
+      acc *= norm;
+    }
   }
   cent[(int64_t)b * cent_batch_stride + (int64_t)c * d + dim] = acc;
 }
@@ -111,7 +125,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
 }
 
 // split_clusters (kmeans.rs:174-207), host side on the (rare) iteration that has an empty cluster.
-static void split_clusters_host(size_t n, std::vector<uint64_t> &cnts, float *centroids, size_t dim, Rng &rng) {
+static void split_clusters_host(size_t n, std::vector<uint64_t> &cnts, float *centroids, size_t dim, Rng &rng, bool f16) {
+  auto R = [f16](float v) { return f16 ? round_f16_host(v) : v; };
   const size_t k = cnts.size();
   const float eps = 1.0f / 1024.0f;
   for (size_t i = 0; i < k; i++) {
@@ -127,11 +142,11 @@ static void split_clusters_host(size_t n, std::vector<uint64_t> &cnts, float *ce
       cnts[j] -= cnts[i];
       for (size_t t = 0; t < dim; t++) {
         if (t % 2 == 0) {
-          centroids[i * dim + t] = centroids[j * dim + t] * (1.0f + eps);
-          centroids[j * dim + t] *= 1.0f - eps;
+          centroids[i * dim + t] = R(centroids[j * dim + t] * (1.0f + eps));
+          centroids[j * dim + t] = R(centroids[j * dim + t] * (1.0f - eps));
         } else {
-          centroids[i * dim + t] = centroids[j * dim + t] * (1.0f - eps);
-          centroids[j * dim + t] *= 1.0f + eps;
+          centroids[i * dim + t] = R(centroids[j * dim + t] * (1.0f - eps));
+          centroids[j * dim + t] = R(centroids[j * dim + t] * (1.0f + eps));
         }
       }
     }
@@ -142,7 +157,7 @@ static void split_clusters_host(size_t n, std::vector<uint64_t> &cnts, float *ce
 // cent: [B][k][d] (in/out: holds the initial centroids when have_init).
 int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int64_t ldx, int x_batch_off, int d,
                          int k, int B, uint32_t max_iters, double tol, float balance_factor_scaled, bool have_init,
-                         const uint64_t *seeds, float *cent, double *loss_out, uint32_t *iters_out) {
+                         const uint64_t *seeds, float *cent, double *loss_out, uint32_t *iters_out, bool f16_arith) {
   LH_REQUIRE(n >= k, "KMeans: training does not have sufficient data points: n(%lld) is smaller than k(%d)", (long long)n, k);
   LH_REQUIRE(k <= 4096, "kmeans_train: k=%d > 4096 not supported in this version", k);
   LH_REQUIRE(metric == METRIC_L2 || metric == METRIC_DOT, "kmeans_train: metric must be L2 or Dot");
@@ -214,7 +229,7 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
       hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 256), B), dim3(256), 0, ctx->stream, dists, n, k,
                          sorted_rows, n, starts, losses_d, radius_d, last_d, active_d);
       hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), B), dim3(256), 0, ctx->stream,
-                         x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1);
+                         x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1, f16_arith ? 1 : 0);
     }
     LH_CHECK_HIP(hipGetLastError());
     LH_CHECK_HIP(hipMemcpyAsync(stats_h.data(), stats_d, stats_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -258,7 +273,7 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
         float *cb = cent + (size_t)b * k * d;
         LH_CHECK_HIP(hipMemcpyAsync(cent_h.data(), cb, cent_h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        split_clusters_host((size_t)n, sizes[b], cent_h.data(), (size_t)d, split_rng[b]);
+        split_clusters_host((size_t)n, sizes[b], cent_h.data(), (size_t)d, split_rng[b], f16_arith);
         LH_CHECK_HIP(hipMemcpyAsync(cb, cent_h.data(), cent_h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
       }
@@ -366,13 +381,14 @@ static int hier_assign_host(lance_hip_ctx *ctx, int metric, const float *x, int6
 }
 
 int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, int target_k, uint32_t max_iters,
-                              double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out) {
+                              double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out,
+                              bool f16_arith) {
   uint64_t run = 0;
   const int initial_k = (int)std::min<int64_t>(std::min(hierarchical_k, target_k), n);
   float *cdev = ctx->scratch_t<float>("hier.cent", (size_t)std::max(hierarchical_k, initial_k) * d);
   if (!cdev) return LANCE_HIP_ENOMEM;
   uint64_t sd = seed + run++;
-  LH_TRY(kmeans_train_batched(ctx, metric, x, n, d, 0, d, initial_k, 1, max_iters, tol, bf_scaled, false, &sd, cdev, nullptr, nullptr));
+  LH_TRY(kmeans_train_batched(ctx, metric, x, n, d, 0, d, initial_k, 1, max_iters, tol, bf_scaled, false, &sd, cdev, nullptr, nullptr, f16_arith));
   std::vector<uint32_t> mem;
   LH_TRY(hier_assign_host(ctx, metric, x, n, d, cdev, initial_k, mem));
   std::vector<float> c0((size_t)initial_k * d);
@@ -411,7 +427,7 @@ int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, in
     LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     sd = seed + run++;
     LH_TRY(kmeans_train_batched(ctx, metric, sub, (int64_t)cluster_size, d, 0, d, (int)cluster_k, 1, max_iters, tol, bf_scaled, false, &sd,
-                                cdev, nullptr, nullptr));
+                                cdev, nullptr, nullptr, f16_arith));
     LH_TRY(hier_assign_host(ctx, metric, sub, (int64_t)cluster_size, d, cdev, (int)cluster_k, mem));
     bool all_same = true, have_first = false;
     uint32_t first = 0;
@@ -456,29 +472,27 @@ extern "C" {
 int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                      const void *centroids, uint32_t k, const float *bias, uint32_t *ids, float *dists) {
   LH_REQUIRE(ctx && x && centroids && ids, "assign: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "assign: only f32 is implemented in this version");
-  if (dtype != LANCE_HIP_F32) return LANCE_HIP_ENOTSUP;
+  LH_TRY(check_dtype(dtype, "assign"));
   LH_REQUIRE(d > 0 && k > 0, "assign: d and k must be > 0");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
+  // f16: l2_scalar<f16,f32,16> widens every element before the arithmetic (l2.rs:128-159)
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "assign: f16 dot (32-lane dot_scalar) is not implemented in this version");
+  const float *xf, *cf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)k * d, "f16.cent", &cf));
   PairwiseArgs pa;
-  pa.x = static_cast<const float *>(x); pa.n = (int64_t)n; pa.ldx = d;
-  pa.cent = static_cast<const float *>(centroids); pa.k = (int)k;
+  pa.x = xf; pa.n = (int64_t)n; pa.ldx = d;
+  pa.cent = cf; pa.k = (int)k;
   pa.bias = bias; pa.ids = ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
   LH_TRY(launch_assign(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
 
-int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, uint32_t k,
-                              uint32_t max_iters, double tol, float balance_factor, uint32_t hierarchical_k,
-                              const void *init_centroids, uint64_t seed, void *centroids_out, double *loss_out_host,
-                              uint32_t *iters_out_host, uint32_t *k_out_host) {
-  LH_REQUIRE(ctx && x && centroids_out, "kmeans_train: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "kmeans_train: only f32 is implemented in this version");
-  LH_REQUIRE(d > 0 && k > 0 && n > 0, "kmeans_train: empty problem");
-  LH_REQUIRE(n >= k, "KMeans: training does not have sufficient data points: n(%llu) is smaller than k(%u)", (unsigned long long)n, k);
-  LH_CHECK_HIP(hipSetDevice(ctx->device));
-  float *cent = static_cast<float *>(centroids_out);
+// KMeans::new_with_params on f32 containers (f16_arith: the values are f16, see f16.h)
+static int kmeans_train_impl(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, uint32_t k, uint32_t max_iters,
+                             double tol, float balance_factor, uint32_t hierarchical_k, const float *init, uint64_t seed, float *cent,
+                             double *loss_out_host, uint32_t *iters_out_host, uint32_t *k_out_host, bool f16_arith) {
   const int km = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   // train_kmeans :1344: params.balance_factor /= data.len()
   const float bf = balance_factor / (float)n;
@@ -487,14 +501,47 @@ int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const v
   if (k > 256 && hierarchical_k > 1) {
     if (loss_out_host) *loss_out_host = 0.0;  // "Loss is not meaningful for hierarchical clustering" (:1001)
     if (iters_out_host) *iters_out_host = 0;
-    return kmeans_train_hierarchical(ctx, km, static_cast<const float *>(x), (int64_t)n, (int)d, (int)k, max_iters, tol, bf,
-                                     (int)hierarchical_k, seed, cent, k_out_host);
+    return kmeans_train_hierarchical(ctx, km, x, (int64_t)n, (int)d, (int)k, max_iters, tol, bf, (int)hierarchical_k, seed, cent,
+                                     k_out_host, f16_arith);
   }
-  if (init_centroids && init_centroids != centroids_out)
-    LH_CHECK_HIP(hipMemcpyAsync(cent, init_centroids, (size_t)k * d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (init && init != cent) LH_CHECK_HIP(hipMemcpyAsync(cent, init, (size_t)k * d * 4, hipMemcpyDeviceToDevice, ctx->stream));
   uint64_t seeds[1] = {seed};
-  return kmeans_train_batched(ctx, km, static_cast<const float *>(x), (int64_t)n, d, 0, (int)d, (int)k, 1, max_iters, tol, bf,
-                              init_centroids != nullptr, seeds, cent, loss_out_host, iters_out_host);
+  return kmeans_train_batched(ctx, km, x, (int64_t)n, d, 0, (int)d, (int)k, 1, max_iters, tol, bf, init != nullptr, seeds, cent,
+                              loss_out_host, iters_out_host, f16_arith);
+}
+
+int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, uint32_t k,
+                              uint32_t max_iters, double tol, float balance_factor, uint32_t hierarchical_k,
+                              const void *init_centroids, uint64_t seed, void *centroids_out, double *loss_out_host,
+                              uint32_t *iters_out_host, uint32_t *k_out_host) {
+  LH_REQUIRE(ctx && x && centroids_out, "kmeans_train: NULL argument");
+  LH_TRY(check_dtype(dtype, "kmeans_train"));
+  LH_REQUIRE(d > 0 && k > 0 && n > 0, "kmeans_train: empty problem");
+  LH_REQUIRE(n >= k, "KMeans: training does not have sufficient data points: n(%llu) is smaller than k(%u)", (unsigned long long)n, k);
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (dtype == LANCE_HIP_F32)
+    return kmeans_train_impl(ctx, metric, static_cast<const float *>(x), n, d, k, max_iters, tol, balance_factor, hierarchical_k,
+                             static_cast<const float *>(init_centroids), seed, static_cast<float *>(centroids_out), loss_out_host,
+                             iters_out_host, k_out_host, false);
+  // f16: KMeansAlgoFloat<Float16Type> -- widen, train with f16 M-step arithmetic, narrow the model
+  LH_REQUIRE(metric != LANCE_HIP_DOT, "kmeans_train: f16 dot (32-lane dot_scalar) is not implemented in this version");
+  const float *xf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  float *cw = ctx->scratch_t<float>("f16.kmeans_out", (size_t)k * d);
+  float *iw = nullptr;
+  if (!cw) return LANCE_HIP_ENOMEM;
+  if (init_centroids) {
+    iw = ctx->scratch_t<float>("f16.kmeans_init", (size_t)k * d);
+    if (!iw) return LANCE_HIP_ENOMEM;
+    LH_TRY(widen_into(ctx, dtype, init_centroids, (size_t)k * d, iw));
+  }
+  uint32_t kout = k;
+  LH_TRY(kmeans_train_impl(ctx, metric, xf, n, d, k, max_iters, tol, balance_factor, hierarchical_k, iw, seed, cw, loss_out_host,
+                           iters_out_host, &kout, true));
+  if (k_out_host) *k_out_host = kout;
+  LH_TRY(from_f32(ctx, dtype, cw, centroids_out, (size_t)kout * d));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
 }
 
 int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
@@ -533,7 +580,7 @@ int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, co
                      sorted_rows, (int64_t)n, starts, losses_d, radius_d, last_d, (const uint8_t *)nullptr);
   hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), 1), dim3(256), 0, ctx->stream,
                      static_cast<const float *>(x), (int64_t)d, 0, (int)d, (int)k, sorted_rows, (int64_t)n, starts, buf, (int64_t)k * d,
-                     (const uint8_t *)nullptr, 0);
+                     (const uint8_t *)nullptr, 0, 0);
   hipLaunchKernelGGL(counts_to_float_kernel, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, ctx->stream, starts, (int)k, buf + (size_t)k * d);
   LH_CHECK_HIP(hipGetLastError());
   if (losses) LH_CHECK_HIP(hipMemcpyAsync(losses, losses_d, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -565,7 +612,7 @@ int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uin
                        uint32_t nbits, uint32_t max_iters, uint32_t sample_rate, uint64_t seed, void *codebook_out,
                        uint32_t *iters_out_host) {
   LH_REQUIRE(ctx && residuals && codebook_out, "pq_train: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "pq_train: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "pq_train"));
   LH_REQUIRE(m > 0 && d % m == 0, "num_sub_vectors must divide vector dimension %u, but got %u", d, m);
   LH_REQUIRE(nbits == 8, "pq_train: only num_bits=8 is implemented in this version (got %u)", nbits);
   const uint32_t kc = 1u << nbits;
@@ -577,10 +624,22 @@ int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uin
   std::vector<uint64_t> seeds(m);
   for (uint32_t i = 0; i < m; ++i) seeds[i] = seed + i;
   std::vector<double> loss(m);
+  const bool f16 = dtype == LANCE_HIP_F16;
+  const float *rf;
+  LH_TRY(as_f32(ctx, dtype, residuals, (size_t)rows * d, "f16.x", &rf));
+  float *cb = static_cast<float *>(codebook_out);
+  if (f16) {
+    cb = ctx->scratch_t<float>("f16.codebook_out", (size_t)m * kc * (d / m));
+    if (!cb) return LANCE_HIP_ENOMEM;
+  }
   // balance factor 0 (KMeansParams::new, pq/builder.rs:113-128); L2 always (builder.rs:455)
-  return kmeans_train_batched(ctx, LANCE_HIP_L2, static_cast<const float *>(residuals), (int64_t)rows, d, (int)(d / m),
-                              (int)(d / m), (int)kc, (int)m, max_iters, 1e-4, 0.0f, false, seeds.data(),
-                              static_cast<float *>(codebook_out), loss.data(), iters_out_host);
+  LH_TRY(kmeans_train_batched(ctx, LANCE_HIP_L2, rf, (int64_t)rows, d, (int)(d / m), (int)(d / m), (int)kc, (int)m, max_iters, 1e-4, 0.0f,
+                              false, seeds.data(), cb, loss.data(), iters_out_host, f16));
+  if (f16) {
+    LH_TRY(from_f32(ctx, dtype, cb, codebook_out, (size_t)m * kc * (d / m)));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return LANCE_HIP_OK;
 }
 
 }  // extern "C"

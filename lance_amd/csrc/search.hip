@@ -91,6 +91,7 @@ struct ScanArgs {
   uint32_t *out_pos;
   uint32_t *out_cnt;  // [nq*nsplit]
   uint32_t *flags;    // [nq]
+  int round_f16;      // index element type is f16: the residual query is an f16 subtraction (v2.rs:326)
   int ablate;         // perf experiments only (LANCE_HIP_ABLATE): 1 = LUT once per query, 2 = no candidate appends, 4 = skip scan
 };
 
@@ -192,8 +193,11 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
     if (np == 0) continue;
     __syncthreads();  // previous partition's LUT readers are done
     // v2.rs:316-332 residual query
-    for (int t = threadIdx.x; t < p.d; t += 256)
-      s.r[t] = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+    for (int t = threadIdx.x; t < p.d; t += 256) {
+      float rv = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+      if (p.round_f16 && p.residual) rv = __half2float(__float2half_rn(rv));
+      s.r[t] = rv;
+    }
     __syncthreads();
     // pq/distance.rs:24-92: LUT[mm][c] = dist(q_sub[mm], codebook[mm][c]) in l2_scalar / dot_scalar order
     if (!((p.ablate & 1) && pi > sp)) {
@@ -383,8 +387,8 @@ __global__ __launch_bounds__(256) void ivfpq_merge_kernel(MergeArgs p) {
 
 // refine: exact distance of the original query to the raw vectors of the candidates, then
 // (dist, rowid) order, fetch k  (scanner.rs:2884-2904 take + flat_knn :3336-3412)
-template <int METRIC>
-__global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const float *__restrict__ raw,
+template <int METRIC, typename TR>
+__global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw,
                                                      uint64_t n_raw, const uint64_t *__restrict__ cand_rid,
                                                      const uint32_t *__restrict__ cand_cnt, int keff, int k, int P,
                                                      uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
@@ -403,8 +407,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
     if (i < c) {
       r = cand_rid[(int64_t)qi * keff + i];
       if (r < n_raw) {
-        if constexpr (METRIC == METRIC_COSINE) kk = order_key(cosine_exact_rt(qv, qnorm, raw + r * d, d));
-        else kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, raw + r * d, d)));
+        if constexpr (METRIC == METRIC_COSINE) {
+          if constexpr (sizeof(TR) == 4) kk = order_key(cosine_exact_rt(qv, qnorm, reinterpret_cast<const float *>(raw) + r * d, d));
+        } else {
+          kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC, TR>(qv, raw + r * d, d)));
+        }
       }
     }
     key[i] = kk; rid[i] = r; pos[i] = 0;
@@ -498,7 +505,11 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
     const int np = (int)(p.part_offsets[part + 1] - off);
     if (np == 0) continue;
     __syncthreads();
-    for (int t = lane; t < p.d; t += 64) r[t] = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+    for (int t = lane; t < p.d; t += 64) {
+      float rv = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+      if (p.round_f16 && p.residual) rv = __half2float(__float2half_rn(rv));
+      r[t] = rv;
+    }
     __syncthreads();
     for (int idx = lane; idx < m * 256; idx += 64)
       lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&r[(idx >> 8) * sd], p.codebook + (int64_t)idx * sd, sd));
@@ -675,6 +686,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     a.part_offsets = ix->part_offsets; a.codes = ix->codes;
     a.d = d; a.m = m; a.sd = sd; a.nprobes = (int)nprobes; a.nsplit = nsplit; a.keff = (int)keff;
     a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
+    a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     a.has_range = has_range;
     a.lo_key = 0; a.hi_key = 0xFFFFFFFFu;
     if (has_range) {
@@ -729,14 +741,20 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   if (do_refine) {
     const int P = next_pow2(std::max((int)keff, 64));
     ScopedTimer t(ctx, "refine");
-    if (ix->metric == LANCE_HIP_COSINE)  // flat_knn on the taken rows uses the index's metric with the ORIGINAL query
-      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
+    const float *rawf = static_cast<const float *>(ix->raw);
+    const __half *rawh = static_cast<const __half *>(ix->raw);
+    // flat_knn on the taken rows uses the index's metric with the ORIGINAL query (q_orig = widened q for f16)
+    if (ix->dtype == LANCE_HIP_F16)
+      hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+    else if (ix->metric == LANCE_HIP_COSINE)
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
     else if (ix->metric == LANCE_HIP_DOT)
-      hipLaunchKernelGGL((refine_kernel<METRIC_DOT>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
+      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
     else
-      hipLaunchKernelGGL((refine_kernel<METRIC_L2>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, ix->raw, ix->n_raw,
+      hipLaunchKernelGGL((refine_kernel<METRIC_L2, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
   }
   LH_CHECK_HIP(hipGetLastError());
@@ -765,16 +783,20 @@ extern "C" {
 int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const void *q, uint32_t nq, uint32_t d,
                               const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids, float *dists) {
   LH_REQUIRE(ctx && q && centroids && part_ids, "find_partitions: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "find_partitions: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "find_partitions"));
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "find_partitions: f16 dot is not implemented in this version");
   LH_REQUIRE(nlist > 0 && nlist <= 8192, "find_partitions: nlist=%u not supported in this version (1..8192)", nlist);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nprobes > nlist) nprobes = nlist;
   if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
   float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
   if (!matrix) return LANCE_HIP_ENOMEM;
+  const float *qf, *cf;
+  LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf));
+  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)nlist * d, "f16.cent", &cf));
   PairwiseArgs pa;
-  pa.x = static_cast<const float *>(q); pa.n = nq; pa.ldx = d;
-  pa.cent = static_cast<const float *>(centroids); pa.k = (int)nlist; pa.matrix = matrix;
+  pa.x = qf; pa.n = nq; pa.ldx = d;
+  pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
   LH_TRY(launch_dist_matrix(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
   const int P = next_pow2((int)nlist);
   hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, (int)nlist, P, (int)nprobes,
@@ -789,7 +811,9 @@ int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx,
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search: NULL argument");
   LH_REQUIRE(ctx->device == idx->device, "search: context and index live on different devices");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  return ivfpq_search_enqueue(ctx, idx, static_cast<const float *>(q), nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, nullptr);
+  const float *qf;
+  LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
+  return ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, nullptr);
 }
 
 int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
@@ -798,7 +822,9 @@ int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const
   LH_REQUIRE(ctx->device == idx->device, "search: context and index live on different devices");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   uint32_t *flags = nullptr;
-  LH_TRY(ivfpq_search_enqueue(ctx, idx, static_cast<const float *>(q), nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags));
+  const float *qf;
+  LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags));
   return check_flags(ctx, flags, nq);
 }
 
@@ -807,7 +833,8 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
                            const uint64_t *row_ids, uint64_t n_p, uint32_t k, int has_range, float lower, float upper,
                            uint64_t *out_ids, float *out_dists, uint32_t *out_n_host) {
   LH_REQUIRE(ctx && q_residual && codebook && out_ids && out_dists, "pq_scan_topk: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "pq_scan_topk: only f32 is implemented in this version");
+  LH_TRY(check_dtype(dtype, "pq_scan_topk"));
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2 && metric != LANCE_HIP_COSINE), "pq_scan_topk: f16 supports L2 only in this version");
   LH_REQUIRE(n_p == 0 || (codes_transposed && row_ids), "pq_scan_topk: NULL codes");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   // a single-partition index whose centroid is 0: q_residual - 0 == q_residual exactly
@@ -821,7 +848,9 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
   const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   LH_TRY(lance_hip_index_from_storage(ctx, dtype, scan_metric, d, zc, 1, codebook, m, nbits, offs, codes_transposed, 1, row_ids, n_p, &ix));
   uint32_t *flags = nullptr;
-  int r = ivfpq_search_enqueue(ctx, ix, static_cast<const float *>(q_residual), 1, k, 1, 0, has_range, lower, upper, out_ids, out_dists, &flags);
+  const float *qf = nullptr;
+  int r = as_f32(ctx, dtype, q_residual, d, "f16.q", &qf);
+  if (r == LANCE_HIP_OK) r = ivfpq_search_enqueue(ctx, ix, qf, 1, k, 1, 0, has_range, lower, upper, out_ids, out_dists, &flags);
   if (r == LANCE_HIP_OK) r = check_flags(ctx, flags, 1);
   if (r == LANCE_HIP_OK && out_n_host) {
     std::vector<uint64_t> ih(k);

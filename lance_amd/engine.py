@@ -37,6 +37,20 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _vec(a):
+    """vector data -> (cuda tensor in its own element type, dtype code); float16 stays float16"""
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype == torch.float16:
+        return t.to(_dev()).contiguous(), _lib.F16
+    return t.to(torch.float32).to(_dev()).contiguous(), _lib.F32
+
+
+def _like(a, ref):
+    """model arrays (centroids, codebook, queries) are cast to the element type of the vectors"""
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(ref.dtype).to(_dev()).contiguous()
+
+
 class Engine:
     """One context (stream + scratch arena) on the current device."""
 
@@ -76,26 +90,26 @@ class Engine:
         return out
 
     def assign(self, x, centroids, metric="l2", bias=None):
-        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
+        x, dt = _vec(x); centroids = _like(centroids, x)
         n, d = x.shape
         k = centroids.shape[0]
         ids = torch.empty(n, dtype=torch.int32, device=x.device)
         dists = torch.empty(n, dtype=torch.float32, device=x.device)
         b = None if bias is None else to_device(bias, torch.float32)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_assign(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(centroids), k, _ptr(b),
+        check(self.lib.lance_hip_assign(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(centroids), k, _ptr(b),
                                         _ptr(ids), _ptr(dists)))
         return ids, dists
 
     def kmeans_train(self, x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2", hierarchical_k=16):
         """KMeans::new_with_params: flat Lloyd for k <= 256 (or hierarchical_k <= 1), hierarchical otherwise."""
-        x = to_device(x, torch.float32)
+        x, dt = _vec(x)
         n, d = x.shape
-        cent = torch.zeros((k, d), dtype=torch.float32, device=x.device)
-        init_t = None if init is None else to_device(init, torch.float32)
+        cent = torch.zeros((k, d), dtype=x.dtype, device=x.device)
+        init_t = None if init is None else _like(init, x)
         loss = C.c_double(0); iters = C.c_uint32(0); kout = C.c_uint32(0)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_kmeans_train_ex(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, k, max_iters, tol,
+        check(self.lib.lance_hip_kmeans_train_ex(self.h, dt, METRICS[metric], _ptr(x), n, d, k, max_iters, tol,
                                                  balance_factor, hierarchical_k, _ptr(init_t), seed, _ptr(cent), C.byref(loss),
                                                  C.byref(iters), C.byref(kout)))
         return cent[: kout.value], loss.value, iters.value
@@ -121,60 +135,61 @@ class Engine:
         return cent
 
     def pq_train(self, residuals, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
-        r = to_device(residuals, torch.float32)
+        r, dt = _vec(residuals)
         n, d = r.shape
-        cb = torch.empty((m, 1 << nbits, d // m), dtype=torch.float32, device=r.device)
+        cb = torch.empty((m, 1 << nbits, d // m), dtype=r.dtype, device=r.device)
         iters = np.zeros(m, np.uint32)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_pq_train(self.h, _lib.F32, _ptr(r), n, d, m, nbits, max_iters, sample_rate, seed, _ptr(cb),
+        check(self.lib.lance_hip_pq_train(self.h, dt, _ptr(r), n, d, m, nbits, max_iters, sample_rate, seed, _ptr(cb),
                                           iters.ctypes.data_as(C.c_void_p)))
         return cb, iters
 
     def residual(self, x, centroids, part_ids):
-        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
+        x, dt = _vec(x); centroids = _like(centroids, x)
         p = to_device(part_ids, torch.int32)
         out = torch.empty_like(x)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_residual(self.h, _lib.F32, _ptr(x), x.shape[0], x.shape[1], _ptr(centroids), _ptr(p), _ptr(out)))
+        check(self.lib.lance_hip_residual(self.h, dt, _ptr(x), x.shape[0], x.shape[1], _ptr(centroids), _ptr(p), _ptr(out)))
         return out
 
     def pq_encode(self, x, codebook, metric="l2"):
-        x = to_device(x, torch.float32); codebook = to_device(codebook, torch.float32)
+        x, dt = _vec(x); codebook = _like(codebook, x)
         n, d = x.shape
         m = codebook.shape[0]
         codes = torch.empty((n, m), dtype=torch.uint8, device=x.device)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_pq_encode(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(codebook), m, 8, _ptr(codes)))
+        check(self.lib.lance_hip_pq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(codebook), m, 8, _ptr(codes)))
         return codes
 
     def ivfpq_encode(self, x, centroids, codebook, metric="l2"):
-        x = to_device(x, torch.float32); centroids = to_device(centroids, torch.float32)
-        codebook = to_device(codebook, torch.float32)
+        x, dt = _vec(x); centroids = _like(centroids, x)
+        codebook = _like(codebook, x)
         n, d = x.shape
         m = codebook.shape[0]
         part = torch.empty(n, dtype=torch.int32, device=x.device)
         codes = torch.empty((n, m), dtype=torch.uint8, device=x.device)
         loss = C.c_double(0)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_ivfpq_encode(self.h, _lib.F32, METRICS[metric], _ptr(x), n, d, _ptr(centroids),
+        check(self.lib.lance_hip_ivfpq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(centroids),
                                               centroids.shape[0], _ptr(codebook), m, 8, _ptr(part), _ptr(codes), C.byref(loss)))
         return part, codes, loss.value
 
     def find_partitions(self, q, centroids, nprobes, metric="l2"):
-        q = to_device(q, torch.float32).reshape(-1, centroids.shape[1]); centroids = to_device(centroids, torch.float32)
+        centroids, dt = _vec(centroids)
+        q = _like(q, centroids).reshape(-1, centroids.shape[1])
         nq, d = q.shape
         nlist = centroids.shape[0]
         nprobes = min(nprobes, nlist)
         ids = torch.empty((nq, nprobes), dtype=torch.int32, device=q.device)
         dists = torch.empty((nq, nprobes), dtype=torch.float32, device=q.device)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_find_partitions(self.h, _lib.F32, METRICS[metric], _ptr(q), nq, d, _ptr(centroids), nlist,
+        check(self.lib.lance_hip_find_partitions(self.h, dt, METRICS[metric], _ptr(q), nq, d, _ptr(centroids), nlist,
                                                  nprobes, _ptr(ids), _ptr(dists)))
         return ids, dists
 
     def pq_scan_topk(self, q_residual, codebook, codes_transposed, row_ids, k, metric="l2", lower=None, upper=None):
-        q = to_device(q_residual, torch.float32).reshape(-1)
-        cb = to_device(codebook, torch.float32)
+        cb, dt = _vec(codebook)
+        q = _like(q_residual, cb).reshape(-1)
         ct = to_device(codes_transposed, torch.uint8)
         rid = to_device(row_ids, torch.int64)
         m, n_p = ct.shape
@@ -185,20 +200,20 @@ class Engine:
         lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
         hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_pq_scan_topk(self.h, _lib.F32, METRICS[metric], _ptr(q), q.numel(), _ptr(cb), m, 8, _ptr(ct),
+        check(self.lib.lance_hip_pq_scan_topk(self.h, dt, METRICS[metric], _ptr(q), q.numel(), _ptr(cb), m, 8, _ptr(ct),
                                               _ptr(rid), n_p, k, int(has), lo, hi, _ptr(out_i), _ptr(out_d), C.byref(cnt)))
         return out_i[:cnt.value], out_d[:cnt.value]
 
     def flat_topk(self, x, q, k, metric="l2", row_ids=None):
-        x = to_device(x, torch.float32)
-        q = to_device(q, torch.float32).reshape(-1, x.shape[1])
+        x, dt = _vec(x)
+        q = _like(q, x).reshape(-1, x.shape[1])
         n, d = x.shape
         nq = q.shape[0]
         rid = None if row_ids is None else to_device(row_ids, torch.int64)
         ids = torch.empty((nq, k), dtype=torch.int64, device=x.device)
         dists = torch.empty((nq, k), dtype=torch.float32, device=x.device)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_flat_topk(self.h, _lib.F32, METRICS[metric], _ptr(x), _ptr(rid), n, d, _ptr(q), nq, k,
+        check(self.lib.lance_hip_flat_topk(self.h, dt, METRICS[metric], _ptr(x), _ptr(rid), n, d, _ptr(q), nq, k,
                                            _ptr(ids), _ptr(dists)))
         return ids, dists
 
@@ -227,7 +242,7 @@ class DeviceIndex:
 
     @classmethod
     def create(cls, engine, metric, centroids, codebook, part_ids, codes, row_ids=None, raw=None):
-        cent = to_device(centroids, torch.float32); cb = to_device(codebook, torch.float32)
+        cent, dt = _vec(centroids); cb = _like(codebook, cent)
         part = to_device(part_ids, torch.int32); codes = to_device(codes, torch.uint8)
         rid = None if row_ids is None else to_device(row_ids, torch.int64)
         n = part.numel()
@@ -235,13 +250,13 @@ class DeviceIndex:
         m = cb.shape[0]
         h = C.c_void_p()
         torch.cuda.synchronize()
-        check(engine.lib.lance_hip_index_create(engine.h, _lib.F32, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
+        check(engine.lib.lance_hip_index_create(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
                                                 _ptr(part), _ptr(codes), _ptr(rid), n, C.byref(h)))
         return cls(engine, h, metric, cent, cb, raw)
 
     @classmethod
     def from_storage(cls, engine, metric, centroids, codebook, part_offsets, codes, row_ids, transposed=True, raw=None):
-        cent = to_device(centroids, torch.float32); cb = to_device(codebook, torch.float32)
+        cent, dt = _vec(centroids); cb = _like(codebook, cent)
         offs = np.ascontiguousarray(part_offsets, np.uint32)
         codes = to_device(np.ascontiguousarray(codes, np.uint8).reshape(-1), torch.uint8)
         rid = to_device(row_ids, torch.int64)
@@ -250,13 +265,13 @@ class DeviceIndex:
         n = rid.numel()
         h = C.c_void_p()
         torch.cuda.synchronize()
-        check(engine.lib.lance_hip_index_from_storage(engine.h, _lib.F32, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
+        check(engine.lib.lance_hip_index_from_storage(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
                                                       offs.ctypes.data_as(C.c_void_p), _ptr(codes), int(transposed), _ptr(rid), n,
                                                       C.byref(h)))
         return cls(engine, h, metric, cent, cb, raw)
 
     def set_raw(self, raw):
-        self._raw = to_device(raw, torch.float32)
+        self._raw = _like(raw, self.centroids)
         check(self.engine.lib.lance_hip_index_set_raw(self.h, _ptr(self._raw), self._raw.shape[0]))
 
     def info(self):
@@ -276,7 +291,7 @@ class DeviceIndex:
 
     def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
         d = self.centroids.shape[1]
-        q = to_device(q, torch.float32).reshape(-1, d)
+        q = _like(q, self.centroids).reshape(-1, d)
         nq = q.shape[0]
         if out is None:
             ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)

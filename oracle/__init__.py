@@ -48,6 +48,9 @@ def lib():
         _lib.orc_sort_fetch.restype = C.c_size_t
         _lib.orc_partition_layout.restype = C.c_size_t
         _lib.orc_kmeans_train_f32.restype = C.c_int
+        _lib.orc_kmeans_train_x.restype = C.c_int
+        _lib.orc_round_f16.restype = C.c_float
+        _lib.orc_round_f16.argtypes = [C.c_float]
         _lib.orc_kmeans_train_hierarchical_f32.restype = C.c_size_t
     return _lib
 
@@ -151,17 +154,19 @@ def kmeans_init_indices(n, k, seed):
 
 def kmeans_train(x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2"):
     """KMeans::train_kmeans on exactly the rows given (caller applies caps).
+    float16 input -> the Float16Type instantiation (f16 M-step arithmetic), centroids returned as float16.
     -> (centroids [k,d], loss, iters, cluster_sizes)"""
+    f16 = np.asarray(x).dtype == np.float16
     x = _f32(x)
     n, d = x.shape
     cent = np.empty((k, d), np.float32)
     loss = C.c_double(0)
     sizes = np.empty(k, np.uint64)
     init_a = None if init is None else _f32(init)
-    it = lib().orc_kmeans_train_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(k),
-                                    C.c_uint32(max_iters), C.c_double(tol), C.c_float(balance_factor),
-                                    _p(init_a), C.c_uint64(seed), _p(cent), C.byref(loss), _p(sizes))
-    return cent, loss.value, int(it), sizes
+    it = lib().orc_kmeans_train_x(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(k),
+                                  C.c_uint32(max_iters), C.c_double(tol), C.c_float(balance_factor),
+                                  _p(init_a), C.c_uint64(seed), _p(cent), C.byref(loss), _p(sizes), C.c_int(int(f16)))
+    return (cent.astype(np.float16) if f16 else cent), loss.value, int(it), sizes
 
 
 def kmeans_train_hierarchical(x, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, hierarchical_k=16, seed=0, metric="l2"):
@@ -176,11 +181,12 @@ def kmeans_train_hierarchical(x, k, max_iters=50, tol=1e-4, balance_factor_scale
 
 
 def residual(x, centroids, part_ids):
+    f16 = np.asarray(x).dtype == np.float16
     x = _f32(x); centroids = _f32(centroids)
     part_ids = np.ascontiguousarray(part_ids, np.uint32)
     out = np.empty_like(x)
-    lib().orc_residual_f32(_p(x), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]), _p(centroids), _p(part_ids), _p(out))
-    return out
+    lib().orc_residual_x(_p(x), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]), _p(centroids), _p(part_ids), _p(out), C.c_int(int(f16)))
+    return out.astype(np.float16) if f16 else out
 
 
 def divide_to_subvectors(x, m):
@@ -192,14 +198,15 @@ def divide_to_subvectors(x, m):
 
 
 def pq_train(resid, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
+    f16 = np.asarray(resid).dtype == np.float16
     resid = _f32(resid)
     n, d = resid.shape
     kc = 1 << nbits
     cb = np.empty((m, kc, d // m), np.float32)
     iters = np.zeros(m, np.int32)
-    lib().orc_pq_train_f32(_p(resid), C.c_size_t(n), C.c_size_t(d), C.c_size_t(m), C.c_uint32(nbits),
-                           C.c_uint32(max_iters), C.c_size_t(sample_rate), C.c_uint64(seed), _p(cb), _p(iters))
-    return cb, iters
+    lib().orc_pq_train_x(_p(resid), C.c_size_t(n), C.c_size_t(d), C.c_size_t(m), C.c_uint32(nbits),
+                         C.c_uint32(max_iters), C.c_size_t(sample_rate), C.c_uint64(seed), _p(cb), _p(iters), C.c_int(int(f16)))
+    return (cb.astype(np.float16) if f16 else cb), iters
 
 
 def pq_encode(x, codebook, metric="l2", nbits=8):
@@ -298,8 +305,9 @@ def partition_layout(part_ids, nlist):
 class IvfPqIndex:
     """Canonical CPU index (reference layout: per-partition transposed codes)."""
 
-    def __init__(self, metric, centroids, codebook, part_offsets, codes_t, row_ids):
+    def __init__(self, metric, centroids, codebook, part_offsets, codes_t, row_ids, f16=False):
         self.metric = _m(metric)
+        self.f16 = bool(f16) or np.asarray(centroids).dtype == np.float16
         self.centroids = _f32(centroids)
         self.codebook = _f32(codebook)
         self.part_offsets = np.ascontiguousarray(part_offsets, np.uint32)
@@ -311,10 +319,10 @@ class IvfPqIndex:
         nq, d = q.shape
         ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
         r = None if raw is None else _f32(raw)
-        lib().orc_ivfpq_search_f32(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
-                                   _p(self.codebook), C.c_size_t(self.codebook.shape[0]), _p(self.part_offsets),
-                                   _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq), C.c_size_t(k),
-                                   C.c_size_t(nprobes), C.c_size_t(refine), _p(r), _p(ids), _p(dists))
+        lib().orc_ivfpq_search_x(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
+                                 _p(self.codebook), C.c_size_t(self.codebook.shape[0]), _p(self.part_offsets),
+                                 _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq), C.c_size_t(k),
+                                 C.c_size_t(nprobes), C.c_size_t(refine), _p(r), _p(ids), _p(dists), C.c_int(int(self.f16)))
         return ids, dists
 
 
@@ -323,6 +331,8 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None):
     (builder.rs:685-846) in canonical stable row order:
     [normalise if cosine] -> keep finite -> assign -> residual (L2/cosine) -> PQ encode
     -> group by partition -> transpose each partition's codes."""
+    f16 = np.asarray(x).dtype == np.float16
+    xin = x
     x = _f32(x)
     m = _m(metric)
     if row_ids is None:
@@ -333,7 +343,7 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None):
     xs = xs[keep]; rid = row_ids[keep]
     sm = L2 if m == COSINE else m
     part, _ = assign(xs, centroids, sm)
-    res = residual(xs, centroids, np.where(part == NONE, 0, part)) if sm == L2 else xs
+    res = residual(xs.astype(np.float16) if f16 else xs, centroids, np.where(part == NONE, 0, part)) if sm == L2 else xs
     codes = pq_encode(res, codebook, sm)
     nlist = centroids.shape[0]
     offs, perm = partition_layout(part, nlist)
@@ -344,7 +354,7 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None):
         a, b = int(offs[p]), int(offs[p + 1])
         if b > a:
             codes_t[a * mm:b * mm] = transpose(codes_sorted[a:b]).ravel()
-    idx = IvfPqIndex(m, centroids, codebook, offs, codes_t, rid[perm])
+    idx = IvfPqIndex(m, centroids, codebook, offs, codes_t, rid[perm], f16=f16)
     idx.part_ids = part
     idx.codes_rowmajor = codes
     idx.perm = perm

@@ -96,6 +96,12 @@ static inline uint16_t orc_f2h(float f) {
   return h;
 }
 
+/* f16 arithmetic as the `half` crate 2.7.1 does it on x86_64: operate in f32, round the result
+ * to binary16 (binary16/arch.rs fallbacks).  f16 data is carried in f32 containers holding
+ * f16-representable values; ORC_RH marks every point where the reference rounds to f16. */
+static inline float orc_rh(float x) { return orc_h2f(orc_f2h(x)); }
+#define ORC_RH(f16, x) ((f16) ? orc_rh(x) : (x))
+float orc_round_f16(float x) { return orc_rh(x); }
 uint16_t orc_f32_to_f16(float f) { return orc_f2h(f); }
 float orc_f16_to_f32(uint16_t h) { return orc_h2f(h); }
 
@@ -411,7 +417,7 @@ void orc_kmeans_init_indices(uint64_t n, uint32_t k, uint64_t seed, uint64_t *ou
 
 /* split_clusters  kmeans.rs:174-207 (f32) */
 static void orc_split_clusters(size_t n, uint64_t *cnts, size_t k, float *centroids, size_t dim,
-                               orc_rng *rng) {
+                               orc_rng *rng, int f16) {
   const float eps = 1.0f / 1024.0f;
   for (size_t i = 0; i < k; i++) {
     if (cnts[i] == 0) {
@@ -426,11 +432,11 @@ static void orc_split_clusters(size_t n, uint64_t *cnts, size_t k, float *centro
       cnts[j] -= cnts[i];
       for (size_t t = 0; t < dim; t++) {
         if (t % 2 == 0) {
-          centroids[i * dim + t] = centroids[j * dim + t] * (1.0f + eps);
-          centroids[j * dim + t] *= 1.0f - eps;
+          centroids[i * dim + t] = ORC_RH(f16, centroids[j * dim + t] * (1.0f + eps));
+          centroids[j * dim + t] = ORC_RH(f16, centroids[j * dim + t] * (1.0f - eps));
         } else {
-          centroids[i * dim + t] = centroids[j * dim + t] * (1.0f - eps);
-          centroids[j * dim + t] *= 1.0f + eps;
+          centroids[i * dim + t] = ORC_RH(f16, centroids[j * dim + t] * (1.0f - eps));
+          centroids[j * dim + t] = ORC_RH(f16, centroids[j * dim + t] * (1.0f + eps));
         }
       }
     }
@@ -444,10 +450,23 @@ static void orc_split_clusters(size_t n, uint64_t *cnts, size_t k, float *centro
  * The caller applies the k*512 / sample_rate*k row caps (:623-627, :1328-1340).
  * init_centroids NULL -> random init from `seed`; split RNG = seed ^ 0x5bd1e995.
  * Returns the number of iterations executed.                                   */
+int orc_kmeans_train_x(int metric, const float *x, size_t n, size_t d, size_t k,
+                       uint32_t max_iters, double tol, float balance_factor,
+                       const float *init_centroids, uint64_t seed, float *centroids_out,
+                       double *loss_out, uint64_t *sizes_out, int f16);
 int orc_kmeans_train_f32(int metric, const float *x, size_t n, size_t d, size_t k,
                          uint32_t max_iters, double tol, float balance_factor,
                          const float *init_centroids, uint64_t seed, float *centroids_out,
                          double *loss_out, uint64_t *sizes_out) {
+  return orc_kmeans_train_x(metric, x, n, d, k, max_iters, tol, balance_factor, init_centroids, seed, centroids_out,
+                            loss_out, sizes_out, 0);
+}
+/* f16 != 0: T = half::f16 (KMeansAlgoFloat<Float16Type>): x / centroids are f16 values in f32
+ * containers; the M-step accumulates, scales and splits in f16 arithmetic (kmeans.rs:380,405-418). */
+int orc_kmeans_train_x(int metric, const float *x, size_t n, size_t d, size_t k,
+                       uint32_t max_iters, double tol, float balance_factor,
+                       const float *init_centroids, uint64_t seed, float *centroids_out,
+                       double *loss_out, uint64_t *sizes_out, int f16) {
   float *cent = centroids_out;
   if (init_centroids) {
     memcpy(cent, init_centroids, k * d * sizeof(float));
@@ -513,16 +532,17 @@ int orc_kmeans_train_f32(int metric, const float *x, size_t n, size_t d, size_t 
       if (membership[r] != ORC_NONE) {
         float *c = newc + (size_t)membership[r] * d;
         const float *v = x + r * d;
-        for (size_t t = 0; t < d; t++) c[t] += v[t];
+        for (size_t t = 0; t < d; t++) c[t] = ORC_RH(f16, c[t] + v[t]);
       }
     }
     for (size_t c = 0; c < k; c++) {
       if (cluster_sizes[c] > 0) {
-        float norm = 1.0f / (float)cluster_sizes[c];
-        for (size_t t = 0; t < d; t++) newc[c * d + t] *= norm;
+        /* T::one() / T::from_usize(cnt) */
+        float norm = ORC_RH(f16, 1.0f / ORC_RH(f16, (float)cluster_sizes[c]));
+        for (size_t t = 0; t < d; t++) newc[c * d + t] = ORC_RH(f16, newc[c * d + t] * norm);
       }
     }
-    orc_split_clusters(n, cluster_sizes, k, newc, d, &split_rng);
+    orc_split_clusters(n, cluster_sizes, k, newc, d, &split_rng, f16);
     memcpy(cent, newc, k * d * sizeof(float));
 
     if (fabs(loss - last_loss) < tol * last_loss) break;
@@ -670,13 +690,17 @@ size_t orc_kmeans_train_hierarchical_f32(int metric, const float *x, size_t n, s
 
 /* ------------------------------------------------------------------------- */
 /* a10: do_compute_residual  residual.rs:58-102 */
-void orc_residual_f32(const float *x, size_t n, size_t d, const float *cent,
-                      const uint32_t *part_ids, float *out) {
+void orc_residual_x(const float *x, size_t n, size_t d, const float *cent,
+                    const uint32_t *part_ids, float *out, int f16) {
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < n; r++) {
     const float *c = cent + (size_t)part_ids[r] * d;
-    for (size_t t = 0; t < d; t++) out[r * d + t] = x[r * d + t] - c[t];
+    for (size_t t = 0; t < d; t++) out[r * d + t] = ORC_RH(f16, x[r * d + t] - c[t]);
   }
+}
+void orc_residual_f32(const float *x, size_t n, size_t d, const float *cent,
+                      const uint32_t *part_ids, float *out) {
+  orc_residual_x(x, n, d, cent, part_ids, out, 0);
 }
 
 /* divide_to_subvectors  pq/utils.rs:14-49: sub-matrix m = columns [m*sd,(m+1)*sd) */
@@ -691,9 +715,17 @@ void orc_divide_to_subvectors_f32(const float *x, size_t n, size_t d, size_t m_c
  * (k=2^nbits, L2, balance 0) on sub-vector matrices; codebook laid out [M][k][sd].
  * Sub-quantiser m uses seed + m.  Inner train_kmeans applies the sample_rate*k
  * slice (kmeans.rs:1328-1340) and the k*512 cap (:623-627).                    */
+void orc_pq_train_x(const float *resid, size_t n, size_t d, size_t m_count, uint32_t nbits,
+                    uint32_t max_iters, size_t sample_rate, uint64_t seed, float *codebook_out,
+                    int *iters_out, int f16);
 void orc_pq_train_f32(const float *resid, size_t n, size_t d, size_t m_count, uint32_t nbits,
                       uint32_t max_iters, size_t sample_rate, uint64_t seed, float *codebook_out,
                       int *iters_out) {
+  orc_pq_train_x(resid, n, d, m_count, nbits, max_iters, sample_rate, seed, codebook_out, iters_out, 0);
+}
+void orc_pq_train_x(const float *resid, size_t n, size_t d, size_t m_count, uint32_t nbits,
+                    uint32_t max_iters, size_t sample_rate, uint64_t seed, float *codebook_out,
+                    int *iters_out, int f16) {
   size_t sd = d / m_count, kc = (size_t)1 << nbits;
   size_t rows = n;
   if (rows > sample_rate * kc) rows = sample_rate * kc;
@@ -702,8 +734,8 @@ void orc_pq_train_f32(const float *resid, size_t n, size_t d, size_t m_count, ui
   for (size_t m = 0; m < m_count; m++) {
     for (size_t r = 0; r < rows; r++) memcpy(sub + r * sd, resid + r * d + m * sd, sd * sizeof(float));
     double loss;
-    int it = orc_kmeans_train_f32(ORC_L2, sub, rows, sd, kc, max_iters, 1e-4, 0.0f, NULL, seed + m,
-                                  codebook_out + m * kc * sd, &loss, NULL);
+    int it = orc_kmeans_train_x(ORC_L2, sub, rows, sd, kc, max_iters, 1e-4, 0.0f, NULL, seed + m,
+                                codebook_out + m * kc * sd, &loss, NULL, f16);
     if (iters_out) iters_out[m] = it;
   }
   free(sub);
@@ -941,11 +973,26 @@ void orc_flat_knn_f32(int metric, const float *x, const uint64_t *row_ids, size_
  * blocks concatenated (block p starts at part_offsets[p]*M); row_ids[N] in
  * partition order.  raw/raw_pos: raw vectors [*][d] and, for slot i, raw row of
  * row_ids[i] given through rowid_to_raw (NULL => rowid is the raw row index).   */
+void orc_ivfpq_search_x(int metric, const float *centroids, size_t nlist, size_t d,
+                        const float *codebook, size_t m_count, const uint32_t *part_offsets,
+                        const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                        size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                        uint64_t *out_ids, float *out_dists, int f16);
 void orc_ivfpq_search_f32(int metric, const float *centroids, size_t nlist, size_t d,
                           const float *codebook, size_t m_count, const uint32_t *part_offsets,
                           const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
                           size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
                           uint64_t *out_ids, float *out_dists) {
+  orc_ivfpq_search_x(metric, centroids, nlist, d, codebook, m_count, part_offsets, codes_t, row_ids, queries, nq, k,
+                     nprobes, refine, raw, out_ids, out_dists, 0);
+}
+/* f16 != 0: the query, centroids, codebook and raw vectors are f16 (in f32 containers); the
+ * residual query is an f16 subtraction (arrow `sub` on Float16, v2.rs:326). */
+void orc_ivfpq_search_x(int metric, const float *centroids, size_t nlist, size_t d,
+                        const float *codebook, size_t m_count, const uint32_t *part_offsets,
+                        const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                        size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                        uint64_t *out_ids, float *out_dists, int f16) {
   if (nprobes > nlist) nprobes = nlist;
   int scan_metric = (metric == ORC_COSINE) ? ORC_L2 : metric;
   size_t keff = k * (refine ? refine : 1);
@@ -982,7 +1029,7 @@ void orc_ivfpq_search_f32(int metric, const float *centroids, size_t nlist, size
       size_t off = part_offsets[p], np_ = part_offsets[p + 1] - off;
       if (np_ == 0) continue;
       if (scan_metric == ORC_L2) {
-        for (size_t t = 0; t < d; t++) qr[t] = q[t] - centroids[p * d + t];
+        for (size_t t = 0; t < d; t++) qr[t] = ORC_RH(f16, q[t] - centroids[p * d + t]);
       } else {
         memcpy(qr, q, d * sizeof(float));
       }

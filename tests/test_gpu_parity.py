@@ -320,6 +320,64 @@ def test_full_size_properties_sift1m(engine, oracle):
     assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all()
 
 
+def f16_data(n, d, seed, ncl=16):
+    # small-magnitude f16-exact values (like C4's f16 vectors)
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((ncl, d)) * 2
+    return (c[rng.integers(0, ncl, n)] + rng.standard_normal((n, d)) * 0.7).astype(np.float16)
+
+
+def test_f16_assign_kmeans_pq_bit_exact(eng, oracle):
+    """Float16Type instantiation: distances widen every element (l2.rs:128-159), the M-step sums / scales /
+    splits in half::f16 arithmetic (kmeans.rs:380,405-418), residuals are f16 subtractions."""
+    x = f16_data(6000, 32, 1)
+    c0 = f16_data(24, 32, 2)
+    ids, dists = eng.assign(x, c0)
+    oi, od = oracle.assign(x, c0)
+    assert (_np(ids).view(np.uint32) == oi).all() and (_np(dists).view(np.uint32) == od.view(np.uint32)).all()
+    cent, loss, iters = eng.kmeans_train(x, 24, max_iters=15, balance_factor=1.0, seed=3)
+    oc, ol, oit, _ = oracle.kmeans_train(x, 24, max_iters=15, balance_factor=f32(1.0) / f32(6000), seed=3)
+    assert cent.dtype == __import__("torch").float16 and iters == oit and loss == ol
+    assert (_np(cent).view(np.uint16) == oc.view(np.uint16)).all()
+    part, _ = oracle.assign(x, oc)
+    res = oracle.residual(x, oc, part)
+    gres = eng.residual(x, oc, part)
+    assert (_np(gres).view(np.uint16) == res.view(np.uint16)).all()
+    cb, it = eng.pq_train(res, 4, max_iters=10, seed=9)
+    ocb, oit2 = oracle.pq_train(res, 4, max_iters=10, seed=9)
+    assert (it == oit2.astype(np.uint32)).all()
+    assert (_np(cb).view(np.uint16) == ocb.view(np.uint16)).all()
+    assert (_np(eng.pq_encode(res, cb)) == oracle.pq_encode(res.astype(f32), ocb.astype(f32))).all()
+
+
+def test_f16_index_build_and_search_bit_exact(eng, oracle):
+    from lance_amd.engine import DeviceIndex
+    n, d, nlist, m = 20000, 64, 32, 8
+    x = f16_data(n, d, 5)
+    q = f16_data(150, d, 6)
+    cent, _, _, _ = oracle.kmeans_train(x[:4096], nlist, max_iters=8, seed=1)
+    part, _ = oracle.assign(x, cent)
+    res = oracle.residual(x, cent, part)
+    cb, _ = oracle.pq_train(res[:8192], m, max_iters=6, seed=2)
+    oidx = oracle.build_index(x, cent, cb)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb)
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all()
+    assert (_np(gcodes) == oidx.codes_rowmajor).all()
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    xf = x.astype(f32)
+    for k, nprobes, rf in ((10, nlist, 0), (10, 6, 0), (10, 6, 10), (100, nlist, 0)):
+        gi, gd = gidx.search(q, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=xf)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    gi, gd = eng.flat_topk(x, q[:40], 10)
+    oi, od = oracle.flat_knn(xf, q[:40].astype(f32), 10)
+    assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    gp, gpd = eng.find_partitions(q, cent, 5)
+    op, opd = oracle.find_partitions(q.astype(f32), cent.astype(f32), 5)
+    assert (_np(gp).view(np.uint32) == op).all() and (_np(gpd).view(np.uint32) == opd.view(np.uint32)).all()
+
+
 def test_python_api_end_to_end(engine, oracle):
     """create_index / nearest / KMeans mirror the reference API; results equal the oracle run on the
     engine's own trained artefacts (recall check as in v2.rs:1354-1381)."""
