@@ -320,6 +320,37 @@ def test_full_size_properties_sift1m(engine, oracle):
     assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all()
 
 
+def test_dbpedia_shape_cosine_m96(eng, oracle):
+    """BASELINE config 3 shape at reduced N: d=1536 f32 cosine, M=96 (sub-dim 16, 96 KiB LUT), hierarchical
+    IVF training (nlist > 256), refine with the flat cosine kernel."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(77)
+    n, d, nlist, m = 6000, 1536, 260, 96
+    centers = rng.standard_normal((40, d)).astype(f32)
+    x = centers[rng.integers(0, 40, n)] + rng.standard_normal((n, d)).astype(f32) * 0.5
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(f32)      # ada-002 embeddings are unit norm
+    q = centers[rng.integers(0, 40, 40)] + rng.standard_normal((40, d)).astype(f32) * 0.5
+    xs = oracle.normalize(x)
+    # IVF: k=260 > 256 -> hierarchical on both sides, bit-exact
+    cent, loss, _ = eng.kmeans_train(xs, nlist, max_iters=6, balance_factor=1.0, seed=4)
+    oc = oracle.kmeans_train_hierarchical(xs, nlist, max_iters=6, balance_factor_scaled=f32(1.0) / f32(n), seed=4)
+    assert (_np(cent).view(np.uint32) == oc.view(np.uint32)).all()
+    part, _ = oracle.assign(xs, oc)
+    res = oracle.residual(xs, oc, part)
+    cb, it = eng.pq_train(res, m, max_iters=4, seed=8)
+    ocb, _ = oracle.pq_train(res, m, max_iters=4, seed=8)
+    assert (_np(cb).view(np.uint32) == ocb.view(np.uint32)).all()
+    oidx = oracle.build_index(x, oc, ocb, "cosine")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, oc, ocb, "cosine")
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all() and (_np(gcodes) == oidx.codes_rowmajor).all()
+    gidx = DeviceIndex.create(eng, "cosine", oc, ocb, gpart, gcodes, None, raw=x)
+    for k, nprobes, rf in ((10, nlist, 0), (10, 20, 10), (10, 3, 0)):
+        gi, gd = gidx.search(q, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
 def f16_data(n, d, seed, ncl=16):
     # small-magnitude f16-exact values (like C4's f16 vectors)
     rng = np.random.default_rng(seed)
