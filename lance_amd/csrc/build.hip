@@ -121,7 +121,8 @@ static int dev_dup(lance_hip_ctx *ctx, const void *src, size_t bytes, void **out
 
 static int check_pq_params(uint32_t d, uint32_t m, uint32_t nbits) {
   LH_REQUIRE(m > 0 && d % m == 0, "num_sub_vectors must divide vector dimension %u, but got %u", d, m);
-  LH_REQUIRE(nbits == 8, "ProductQuantization: num_bits %u not supported in this version (8 only)", nbits);
+  LH_REQUIRE(nbits == 8 || nbits == 4, "ProductQuantization: num_bits %u not supported", nbits);   // pq.rs:104-112
+  LH_REQUIRE(!(nbits == 4 && m % 2 != 0), "PQ: num_sub_vectors must be divisible by 2 for num_bits=4, but got %u", m);  // pq.rs:134-142
   return LANCE_HIP_OK;
 }
 
@@ -140,13 +141,33 @@ int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float
   return LANCE_HIP_OK;
 }
 
+// 4-bit packing, pq.rs:168-172: byte b = (code[2b+1] << 4) | code[2b]
+__global__ __launch_bounds__(256) void pack_nibbles_kernel(const uint8_t *__restrict__ in, int64_t n, int m, uint8_t *__restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n * (m / 2)) return;
+  const int64_t r = g / (m / 2);
+  const int b = (int)(g % (m / 2));
+  out[g] = (uint8_t)((in[r * m + 2 * b + 1] << 4) | in[r * m + 2 * b]);
+}
+
 int pq_encode_launch(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, const float *codebook, int m,
-                     uint8_t *codes) {
+                     uint8_t *codes, int nbits) {
+  const int kc = 1 << nbits;
+  uint8_t *dst = codes;
+  if (nbits == 4) {
+    dst = ctx->scratch_t<uint8_t>("encode.codes8", (size_t)n * m);
+    if (!dst) return LANCE_HIP_ENOMEM;
+  }
   PairwiseArgs pa;
   pa.x = x; pa.n = n; pa.ldx = d; pa.x_batch_off = d / m;
-  pa.cent = codebook; pa.k = 256; pa.cent_batch_stride = (int64_t)256 * (d / m);
-  pa.codes = codes; pa.codes_ld = m;
-  return launch_assign(ctx, pa, d / m, metric, m);
+  pa.cent = codebook; pa.k = kc; pa.cent_batch_stride = (int64_t)kc * (d / m);
+  pa.codes = dst; pa.codes_ld = m;
+  LH_TRY(launch_assign(ctx, pa, d / m, metric, m));
+  if (nbits == 4 && n > 0) {
+    hipLaunchKernelGGL(pack_nibbles_kernel, dim3((unsigned)cdiv((uint64_t)n * (m / 2), 256)), dim3(256), 0, ctx->stream, dst, n, m, codes);
+    LH_CHECK_HIP(hipGetLastError());
+  }
+  return LANCE_HIP_OK;
 }
 
 }  // namespace lh
@@ -216,8 +237,8 @@ int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "pq_encode: f16 dot is not implemented in this version");
   const float *xf, *cbf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
-  LH_TRY(as_f32(ctx, dtype, codebook, (size_t)256 * d, "f16.codebook", &cbf));
-  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, xf, (int64_t)n, (int)d, cbf, (int)m, codes));
+  LH_TRY(as_f32(ctx, dtype, codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
+  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, xf, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
@@ -235,7 +256,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   const float *xs, *centf, *cbf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xs));
   LH_TRY(as_f32(ctx, dtype, centroids, (size_t)nlist * d, "f16.cent", &centf));
-  LH_TRY(as_f32(ctx, dtype, codebook, (size_t)256 * d, "f16.codebook", &cbf));
+  LH_TRY(as_f32(ctx, dtype, codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
   centroids = centf; codebook = cbf;
   const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   if (metric == LANCE_HIP_COSINE) {
@@ -259,7 +280,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
     LH_TRY(launch_residual(ctx, xs, (int64_t)n, (int)d, static_cast<const float *>(centroids), part_ids, res, f16));
     enc_in = res;
   }
-  LH_TRY(pq_encode_launch(ctx, scan_metric, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes));
+  LH_TRY(pq_encode_launch(ctx, scan_metric, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes, (int)nbits));
   LH_CHECK_HIP(hipGetLastError());
   if (loss_out_host) {
     // sum of the assignment distances (compute_partitions, kmeans.rs:1276-1290): f64, host side
@@ -294,8 +315,9 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
   // the index keeps f32 copies of the model (f16 widens exactly); the scan rounds the residual query to f16 when dtype is f16
   int r = dev_dup(ctx, nullptr, (size_t)nlist * d * 4, reinterpret_cast<void **>(&ix->centroids));
   if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, centroids, (size_t)nlist * d, ix->centroids);
-  if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)m * 256 * (d / m) * 4, reinterpret_cast<void **>(&ix->codebook));
-  if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, codebook, (size_t)m * 256 * (d / m), ix->codebook);
+  const size_t cb_elems = (size_t)m * ((size_t)1 << nbits) * (d / m);
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, cb_elems * 4, reinterpret_cast<void **>(&ix->codebook));
+  if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, codebook, cb_elems, ix->codebook);
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)(nlist + 1) * 4, reinterpret_cast<void **>(&ix->part_offsets));
   if (r != LANCE_HIP_OK) { delete ix; return r; }
   *out = ix;
@@ -325,12 +347,12 @@ int lance_hip_index_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d
   if (r == LANCE_HIP_OK) r = index_finish_offsets(ctx, ix);
   if (r == LANCE_HIP_OK) {
     ix->n = ix->part_offsets_h[nlist];
-    r = dev_dup(ctx, nullptr, (size_t)ix->n * m, reinterpret_cast<void **>(&ix->codes));
+    r = dev_dup(ctx, nullptr, (size_t)ix->n * ix->code_bytes(), reinterpret_cast<void **>(&ix->codes));
     if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)ix->n * 8, reinterpret_cast<void **>(&ix->row_ids));
   }
   if (r == LANCE_HIP_OK && ix->n > 0) {
     hipLaunchKernelGGL(gather_codes_kernel, dim3((unsigned)cdiv(ix->n, 256)), dim3(256), 0, ctx->stream, codes, row_ids, perm,
-                       (int64_t)ix->n, (int)m, ix->codes, ix->row_ids);
+                       (int64_t)ix->n, (int)ix->code_bytes(), ix->codes, ix->row_ids);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
       set_error("index_create: gather kernel failed");
       r = LANCE_HIP_ERUNTIME;
@@ -353,11 +375,12 @@ int lance_hip_index_from_storage(lance_hip_ctx *ctx, int dtype, int metric, uint
   ix->n = n;
   if (hipMemcpyAsync(ix->part_offsets, part_offsets_host, (size_t)(nlist + 1) * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) r = LANCE_HIP_ERUNTIME;
   if (r == LANCE_HIP_OK) r = index_finish_offsets(ctx, ix);
-  if (r == LANCE_HIP_OK) r = dev_dup(ctx, transposed ? nullptr : codes, (size_t)n * m, reinterpret_cast<void **>(&ix->codes));
+  const uint32_t mbytes = ix ? ix->code_bytes() : m;
+  if (r == LANCE_HIP_OK) r = dev_dup(ctx, transposed ? nullptr : codes, (size_t)n * mbytes, reinterpret_cast<void **>(&ix->codes));
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, row_ids, (size_t)n * 8, reinterpret_cast<void **>(&ix->row_ids));
   if (r == LANCE_HIP_OK && transposed && n > 0) {
-    hipLaunchKernelGGL(retile_codes_kernel, dim3((unsigned)cdiv(n * m, 256)), dim3(256), 0, ctx->stream, codes, ix->codes,
-                       (int64_t)n, (int)m, ix->part_offsets, (int)nlist, 0);
+    hipLaunchKernelGGL(retile_codes_kernel, dim3((unsigned)cdiv(n * mbytes, 256)), dim3(256), 0, ctx->stream, codes, ix->codes,
+                       (int64_t)n, (int)mbytes, ix->part_offsets, (int)nlist, 0);
     if (hipGetLastError() != hipSuccess) r = LANCE_HIP_ERUNTIME;
   }
   if (r == LANCE_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = LANCE_HIP_ERUNTIME;
@@ -390,12 +413,13 @@ int lance_hip_index_export(lance_hip_ctx *ctx, const lance_hip_index *idx, uint3
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (part_offsets_host) memcpy(part_offsets_host, idx->part_offsets_h.data(), (size_t)(idx->nlist + 1) * 4);
   if (codes_transposed_host && idx->n > 0) {
-    uint8_t *tmp = ctx->scratch_t<uint8_t>("index.export", (size_t)idx->n * idx->m);
+    const uint32_t mbytes = idx->code_bytes();
+    uint8_t *tmp = ctx->scratch_t<uint8_t>("index.export", (size_t)idx->n * mbytes);
     if (!tmp) return LANCE_HIP_ENOMEM;
-    hipLaunchKernelGGL(retile_codes_kernel, dim3((unsigned)cdiv(idx->n * idx->m, 256)), dim3(256), 0, ctx->stream, idx->codes, tmp,
-                       (int64_t)idx->n, (int)idx->m, idx->part_offsets, (int)idx->nlist, 1);
+    hipLaunchKernelGGL(retile_codes_kernel, dim3((unsigned)cdiv(idx->n * mbytes, 256)), dim3(256), 0, ctx->stream, idx->codes, tmp,
+                       (int64_t)idx->n, (int)mbytes, idx->part_offsets, (int)idx->nlist, 1);
     LH_CHECK_HIP(hipGetLastError());
-    LH_CHECK_HIP(hipMemcpyAsync(codes_transposed_host, tmp, (size_t)idx->n * idx->m, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipMemcpyAsync(codes_transposed_host, tmp, (size_t)idx->n * mbytes, hipMemcpyDeviceToHost, ctx->stream));
   }
   if (row_ids_host && idx->n > 0)
     LH_CHECK_HIP(hipMemcpyAsync(row_ids_host, idx->row_ids, (size_t)idx->n * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -13,10 +13,11 @@ struct lance_hip_index {
   float *codebook = nullptr;      // [m][256][d/m]
   uint32_t *part_offsets = nullptr;  // [nlist+1] device
   std::vector<uint32_t> part_offsets_h;
-  uint8_t *codes = nullptr;       // [n][m] row-major, rows grouped by partition
+  uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition
   uint64_t *row_ids = nullptr;    // [n] in the same order
   const void *raw = nullptr;      // borrowed raw vectors (dtype elements) for refine, indexed by row id
   uint64_t n_raw = 0;
   uint32_t max_part = 0;
+  uint32_t code_bytes() const { return nbits == 4 ? m / 2 : m; }   // bytes of PQ code per row
   ~lance_hip_index();
 };

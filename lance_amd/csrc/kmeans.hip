@@ -614,7 +614,7 @@ int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uin
   LH_REQUIRE(ctx && residuals && codebook_out, "pq_train: NULL argument");
   LH_TRY(check_dtype(dtype, "pq_train"));
   LH_REQUIRE(m > 0 && d % m == 0, "num_sub_vectors must divide vector dimension %u, but got %u", d, m);
-  LH_REQUIRE(nbits == 8, "pq_train: only num_bits=8 is implemented in this version (got %u)", nbits);
+  LH_REQUIRE(nbits == 8 || nbits == 4, "ProductQuantization: num_bits %u not supported", nbits);
   const uint32_t kc = 1u << nbits;
   LH_REQUIRE(n >= kc, "Not enough rows to train PQ. Requires %u rows but only %llu available", kc, (unsigned long long)n);
   LH_CHECK_HIP(hipSetDevice(ctx->device));

@@ -84,6 +84,7 @@ struct ScanArgs {
   const uint32_t *part_offsets;
   const uint8_t *codes;
   int d, m, sd, nprobes, nsplit, keff;
+  int nbits;     // 8, or 4 (a18)
   int residual;  // 1: q - centroid (L2 / cosine), 0: dot
   int has_range;
   uint32_t lo_key, hi_key;
@@ -272,6 +273,151 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
     }
   }
   // final: shrink to <= LCAP entries (exact threshold once <= 256 entries remain)
+  __syncthreads();
+  for (int iter = 0; iter < 8 && (int)s.misc[0] > SCAN_LCAP; ++iter) tighten(s, p.keff);
+  __syncthreads();
+  int c = min((int)s.misc[0], SCAN_CAP);
+  uint32_t fl = s.misc[3];
+  if (c > SCAN_LCAP) { c = SCAN_LCAP; fl |= FLAG_OVERFLOW; }
+  const int64_t ob = (int64_t)blockIdx.x * SCAN_LCAP;
+  for (int i = threadIdx.x; i < c; i += 256) { p.out_keys[ob + i] = s.ckey[i]; p.out_pos[ob + i] = s.cpos[i]; }
+  if (threadIdx.x == 0) {
+    p.out_cnt[blockIdx.x] = (uint32_t)c;
+    if (fl) atomicOr(&p.flags[qi], fl);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------
+// a18: 4-bit PQ (compute_pq_distance_4bit, pq/distance.rs:147-284).  Per (query, partition):
+// the first flat_num = max(200, min(k_hint, n_p)) rows and the n_p % 16 tail get exact f32 LUT
+// sums; every other row gets the saturating u8 sum of the table quantised to [qmin, qmax]
+// (qmax = largest exact distance of the flat rows) and is de-quantised as q*range + qmin.
+// Codes are row-major [n_p][M/2] here (low nibble = sub-vector 2b, high = 2b+1).
+struct Pq4Shared {
+  float *fd;        // exact distances of the flat rows
+  uint8_t *qt;      // quantised table [M][16]
+  uint32_t *sc;     // [0] = qmax key, [1] = qmin key, [2] = flat_num
+};
+
+template <int METRIC>
+__device__ __forceinline__ float pq4_exact_row(const float *lut, const uint8_t *rc, int mb) {
+  float dist = 0.0f;
+  for (int b = 0; b < mb; ++b) {
+    const uint32_t c = rc[b];
+    dist += lut[(2 * b) * 16 + (c & 15u)];
+    dist += lut[(2 * b + 1) * 16 + (c >> 4)];
+  }
+  return dist;
+}
+
+template <int METRIC, int BS>
+__device__ __forceinline__ void pq4_prelude(const float *lut, int m, const uint8_t *pcodes, int np, int keff, const Pq4Shared &q4) {
+  const int mb = m / 2;
+  const int flat_num = min(max(200, min(keff, np)), np);
+  if (threadIdx.x == 0) { q4.sc[0] = 0u; q4.sc[1] = order_key(INFINITY); q4.sc[2] = (uint32_t)flat_num; }
+  __syncthreads();
+  for (int row = threadIdx.x; row < flat_num; row += BS) {
+    const float dv = pq4_exact_row<METRIC>(lut, pcodes + (int64_t)row * mb, mb);
+    q4.fd[row] = dv;
+    atomicMax(&q4.sc[0], order_key(dv));  // max_by(total_cmp)
+  }
+  for (int idx = threadIdx.x; idx < m * 16; idx += BS) {
+    const float v = lut[idx];
+    if (v == v) atomicMin(&q4.sc[1], order_key(v));  // fold(INFINITY, f32::min): NaN is ignored
+  }
+  __syncthreads();
+  const float qmax = key_to_float(q4.sc[0]), qmin = key_to_float(q4.sc[1]);
+  const float factor = 255.0f / (qmax - qmin);
+  for (int idx = threadIdx.x; idx < m * 16; idx += BS) {
+    const float v = roundf((lut[idx] - qmin) * factor);  // f32::round (half away from zero); `as u8` saturates, NaN -> 0
+    q4.qt[idx] = v != v ? (uint8_t)0 : (v <= 0.0f ? (uint8_t)0 : (v >= 255.0f ? (uint8_t)255 : (uint8_t)v));
+  }
+  __syncthreads();
+}
+
+template <int METRIC>
+__device__ __forceinline__ float pq4_row_distance(const float *lut, int m, const uint8_t *pcodes, int np, int row, const Pq4Shared &q4) {
+  const int mb = m / 2;
+  const int flat_num = (int)q4.sc[2];
+  const int rem = np % 16;
+  const uint8_t *rc = pcodes + (int64_t)row * mb;
+  float dist;
+  if (row < flat_num) {
+    dist = q4.fd[row];
+  } else if (row < np - rem) {
+    uint32_t acc = 0;
+    for (int b = 0; b < mb; ++b) {
+      const uint32_t c = rc[b];
+      acc = min(255u, acc + q4.qt[(2 * b) * 16 + (c & 15u)]);      // _mm_adds_epu8
+      acc = min(255u, acc + q4.qt[(2 * b + 1) * 16 + (c >> 4)]);
+    }
+    const float qmax = key_to_float(q4.sc[0]), qmin = key_to_float(q4.sc[1]);
+    const float range = (qmax - qmin) / 255.0f;
+    dist = (float)acc * range + qmin;
+  } else {
+    dist = pq4_exact_row<METRIC>(lut, rc, mb);
+  }
+  if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);
+  return dist;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void ivfpq_scan4_kernel(ScanArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ScanShared s;
+  Pq4Shared q4;
+  const int dpad = (p.d + 3) & ~3;
+  const int m = p.m, sd = p.sd, mb = p.m / 2;
+  s.r = reinterpret_cast<float *>(smem);
+  s.lut = s.r + dpad;
+  s.ckey = reinterpret_cast<uint32_t *>(s.lut + m * 16);
+  s.cpos = s.ckey + SCAN_CAP;
+  s.sorted = s.cpos + SCAN_CAP;
+  s.misc = s.sorted + 256;
+  q4.sc = s.misc + 8;
+  q4.fd = reinterpret_cast<float *>(q4.sc + 4);
+  q4.qt = reinterpret_cast<uint8_t *>(q4.fd + 256);
+
+  const int qi = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit;
+  const float *qv = p.q + (int64_t)qi * p.d;
+  if (threadIdx.x == 0) { s.misc[0] = 0; s.misc[1] = 0xFFFFFFFFu; s.misc[3] = 0; }
+  __syncthreads();
+  for (int pi = sp; pi < p.nprobes; pi += p.nsplit) {
+    const uint32_t part = p.probes[(int64_t)qi * p.nprobes + pi];
+    const uint32_t off = p.part_offsets[part];
+    const int np = (int)(p.part_offsets[part + 1] - off);
+    if (np == 0) continue;
+    __syncthreads();
+    for (int t = threadIdx.x; t < p.d; t += 256) {
+      float rv = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
+      if (p.round_f16 && p.residual) rv = __half2float(__float2half_rn(rv));
+      s.r[t] = rv;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < m * 16; idx += 256)
+      s.lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&s.r[(idx >> 4) * sd], p.codebook + (int64_t)idx * sd, sd));
+    __syncthreads();
+    const uint8_t *pcodes = p.codes + (int64_t)off * mb;
+    pq4_prelude<METRIC, 256>(s.lut, m, pcodes, np, p.keff, q4);
+    for (int base = 0; base < np; base += SCAN_ROUND) {
+      if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);
+      const uint32_t T = s.misc[1];
+      for (int u = 0; u < SCAN_ROUND / 256; ++u) {
+        const int row = base + u * 256 + threadIdx.x;
+        if (row < np) {
+          const uint32_t key = order_key(pq4_row_distance<METRIC>(s.lut, m, pcodes, np, row, q4));
+          const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);
+          if (in_range && key <= T) {
+            const uint32_t slot = atomicAdd(&s.misc[0], 1u);
+            if (slot < SCAN_CAP) { s.ckey[slot] = key; s.cpos[slot] = off + (uint32_t)row; }
+            else s.misc[3] = FLAG_OVERFLOW;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
   __syncthreads();
   for (int iter = 0; iter < 8 && (int)s.misc[0] > SCAN_LCAP; ++iter) tighten(s, p.keff);
   __syncthreads();
@@ -479,7 +625,7 @@ __device__ __forceinline__ void heap_pop(uint32_t *hk, uint32_t *hp, int &len) {
   heap_sift_up(hk, hp, 0, pos);
 }
 
-template <int METRIC>
+template <int METRIC, int NBITS>
 __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ScanArgs &p = a.s;
@@ -487,13 +633,18 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
   if (!p.flags[qi]) return;
   const int lane = threadIdx.x;
   const int dpad = (p.d + 3) & ~3;
+  constexpr int KC = NBITS == 4 ? 16 : 256;
   float *r = reinterpret_cast<float *>(smem);
   float *lut = r + dpad;
-  uint64_t *trid = reinterpret_cast<uint64_t *>(lut + p.m * 256);
+  uint64_t *trid = reinterpret_cast<uint64_t *>(lut + p.m * 256);   // sized for 8-bit in both cases
   uint32_t *tkey = reinterpret_cast<uint32_t *>(trid + p.keff);
   uint32_t *hk = tkey + p.keff;
   uint32_t *hp = hk + p.keff + 1;
   uint32_t *skey = hp + p.keff + 1;
+  Pq4Shared q4;
+  q4.sc = skey + 64;
+  q4.fd = reinterpret_cast<float *>(q4.sc + 4);
+  q4.qt = reinterpret_cast<uint8_t *>(q4.fd + max(200, p.keff));
   __shared__ int s_hlen, s_tcnt;
   if (lane == 0) { s_hlen = 0; s_tcnt = 0; }
   const float *qv = p.q + (int64_t)qi * p.d;
@@ -511,20 +662,25 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
       r[t] = rv;
     }
     __syncthreads();
-    for (int idx = lane; idx < m * 256; idx += 64)
-      lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&r[(idx >> 8) * sd], p.codebook + (int64_t)idx * sd, sd));
+    for (int idx = lane; idx < m * KC; idx += 64)
+      lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&r[(idx / KC) * sd], p.codebook + (int64_t)idx * sd, sd));
     if (lane == 0) s_hlen = 0;
     __syncthreads();
-    const uint8_t *pcodes = p.codes + (int64_t)off * m;
+    const uint8_t *pcodes = p.codes + (int64_t)off * (NBITS == 4 ? m / 2 : m);
+    if constexpr (NBITS == 4) pq4_prelude<METRIC, 64>(lut, m, pcodes, np, p.keff, q4);
     for (int base = 0; base < np; base += 64) {
       const int row = base + lane;
       uint32_t key = 0xFFFFFFFFu;
       bool cand = false;
       if (row < np) {
-        const uint8_t *rc = pcodes + (int64_t)row * m;
         float dist = 0.0f;
-        for (int mm = 0; mm < m; ++mm) dist += lut[mm * 256 + rc[mm]];
-        if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);
+        if constexpr (NBITS == 4) {
+          dist = pq4_row_distance<METRIC>(lut, m, pcodes, np, row, q4);
+        } else {
+          const uint8_t *rc = pcodes + (int64_t)row * m;
+          for (int mm = 0; mm < m; ++mm) dist += lut[mm * 256 + rc[mm]];
+          if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);
+        }
         key = order_key(dist);
         const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);
         cand = in_range && (s_hlen < p.keff || key < hk[0]);
@@ -685,6 +841,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook;
     a.part_offsets = ix->part_offsets; a.codes = ix->codes;
     a.d = d; a.m = m; a.sd = sd; a.nprobes = (int)nprobes; a.nsplit = nsplit; a.keff = (int)keff;
+    a.nbits = (int)ix->nbits;
     a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
     a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     a.has_range = has_range;
@@ -700,7 +857,12 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const int dpad = (d + 3) & ~3;
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
-    if (fast) {
+    if (fast && ix->nbits == 4) {
+      const size_t lds4 = (size_t)dpad * 4 + (size_t)m * 16 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4 + 16 + 256 * 4 + (size_t)m * 16 + 16;
+      ScopedTimer t(ctx, "ivfpq_scan");
+      if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_scan4_kernel<METRIC_DOT>), dim3((unsigned)nblk), dim3(256), lds4, ctx->stream, a);
+      else hipLaunchKernelGGL((ivfpq_scan4_kernel<METRIC_L2>), dim3((unsigned)nblk), dim3(256), lds4, ctx->stream, a);
+    } else if (fast) {
       ScopedTimer t(ctx, "ivfpq_scan");
       if (scan_metric == LANCE_HIP_DOT) launch_scan<METRIC_DOT>(ctx, a, (int)nblk, lds);
       else launch_scan<METRIC_L2>(ctx, a, (int)nblk, lds);
@@ -732,11 +894,17 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     ea.s = a; ea.row_ids = ix->row_ids; ea.k = (int)k; ea.refine = do_refine ? 1 : 0;
     ea.out_ids = ids; ea.out_dists = dists; ea.cand_rid = cand_rid; ea.cand_cnt = cand_cnt; ea.n_fallback = n_fallback;
     const int dpad = (d + 3) & ~3;
-    const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)keff * 12 + ((size_t)keff + 1) * 8 + 64 * 4 + 16;
+    const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)keff * 12 + ((size_t)keff + 1) * 8 + 64 * 4 + 16 +
+                       16 + (size_t)std::max<uint32_t>(200, keff) * 4 + (size_t)m * 16 + 16;
     LH_REQUIRE(lds <= 160 * 1024, "search: exact kernel does not fit in LDS (m=%d, k*refine=%u)", m, keff);
     ScopedTimer t(ctx, "ivfpq_exact");
-    if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_DOT>), dim3(nq), dim3(64), lds, ctx->stream, ea);
-    else hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_L2>), dim3(nq), dim3(64), lds, ctx->stream, ea);
+    if (ix->nbits == 4) {
+      if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_DOT, 4>), dim3(nq), dim3(64), lds, ctx->stream, ea);
+      else hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_L2, 4>), dim3(nq), dim3(64), lds, ctx->stream, ea);
+    } else {
+      if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_DOT, 8>), dim3(nq), dim3(64), lds, ctx->stream, ea);
+      else hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_L2, 8>), dim3(nq), dim3(64), lds, ctx->stream, ea);
+    }
   }
   if (do_refine) {
     const int P = next_pow2(std::max((int)keff, 64));

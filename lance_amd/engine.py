@@ -45,6 +45,14 @@ def _vec(a):
     return t.to(torch.float32).to(_dev()).contiguous(), _lib.F32
 
 
+def _nbits(codebook):
+    """num_bits from the codebook shape (M, 2^nbits, d/M)"""
+    kc = int(codebook.shape[1])
+    if kc not in (16, 256):
+        raise ValueError(f"codebook must have 16 or 256 centroids per sub-vector, got {kc}")
+    return 4 if kc == 16 else 8
+
+
 def _like(a, ref):
     """model arrays (centroids, codebook, queries) are cast to the element type of the vectors"""
     t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
@@ -156,9 +164,10 @@ class Engine:
         x, dt = _vec(x); codebook = _like(codebook, x)
         n, d = x.shape
         m = codebook.shape[0]
-        codes = torch.empty((n, m), dtype=torch.uint8, device=x.device)
+        nb = _nbits(codebook)
+        codes = torch.empty((n, m if nb == 8 else m // 2), dtype=torch.uint8, device=x.device)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_pq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(codebook), m, 8, _ptr(codes)))
+        check(self.lib.lance_hip_pq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(codebook), m, nb, _ptr(codes)))
         return codes
 
     def ivfpq_encode(self, x, centroids, codebook, metric="l2"):
@@ -166,12 +175,13 @@ class Engine:
         codebook = _like(codebook, x)
         n, d = x.shape
         m = codebook.shape[0]
+        nb = _nbits(codebook)
         part = torch.empty(n, dtype=torch.int32, device=x.device)
-        codes = torch.empty((n, m), dtype=torch.uint8, device=x.device)
+        codes = torch.empty((n, m if nb == 8 else m // 2), dtype=torch.uint8, device=x.device)
         loss = C.c_double(0)
         torch.cuda.synchronize()
         check(self.lib.lance_hip_ivfpq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(centroids),
-                                              centroids.shape[0], _ptr(codebook), m, 8, _ptr(part), _ptr(codes), C.byref(loss)))
+                                              centroids.shape[0], _ptr(codebook), m, nb, _ptr(part), _ptr(codes), C.byref(loss)))
         return part, codes, loss.value
 
     def find_partitions(self, q, centroids, nprobes, metric="l2"):
@@ -192,7 +202,9 @@ class Engine:
         q = _like(q_residual, cb).reshape(-1)
         ct = to_device(codes_transposed, torch.uint8)
         rid = to_device(row_ids, torch.int64)
-        m, n_p = ct.shape
+        nb = _nbits(cb)
+        m = cb.shape[0]
+        n_p = ct.shape[1]
         out_i = torch.empty(k, dtype=torch.int64, device=q.device)
         out_d = torch.empty(k, dtype=torch.float32, device=q.device)
         cnt = C.c_uint32(0)
@@ -200,7 +212,7 @@ class Engine:
         lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
         hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_pq_scan_topk(self.h, dt, METRICS[metric], _ptr(q), q.numel(), _ptr(cb), m, 8, _ptr(ct),
+        check(self.lib.lance_hip_pq_scan_topk(self.h, dt, METRICS[metric], _ptr(q), q.numel(), _ptr(cb), m, nb, _ptr(ct),
                                               _ptr(rid), n_p, k, int(has), lo, hi, _ptr(out_i), _ptr(out_d), C.byref(cnt)))
         return out_i[:cnt.value], out_d[:cnt.value]
 
@@ -250,7 +262,7 @@ class DeviceIndex:
         m = cb.shape[0]
         h = C.c_void_p()
         torch.cuda.synchronize()
-        check(engine.lib.lance_hip_index_create(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
+        check(engine.lib.lance_hip_index_create(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, _nbits(cb),
                                                 _ptr(part), _ptr(codes), _ptr(rid), n, C.byref(h)))
         return cls(engine, h, metric, cent, cb, raw)
 
@@ -265,7 +277,7 @@ class DeviceIndex:
         n = rid.numel()
         h = C.c_void_p()
         torch.cuda.synchronize()
-        check(engine.lib.lance_hip_index_from_storage(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, 8,
+        check(engine.lib.lance_hip_index_from_storage(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, _nbits(cb),
                                                       offs.ctypes.data_as(C.c_void_p), _ptr(codes), int(transposed), _ptr(rid), n,
                                                       C.byref(h)))
         return cls(engine, h, metric, cent, cb, raw)
@@ -283,7 +295,8 @@ class DeviceIndex:
         """-> (part_offsets u32[nlist+1], codes_transposed u8 (per-partition [m][n_p] blocks), row_ids u64[n])"""
         inf = self.info()
         offs = np.empty(inf["nlist"] + 1, np.uint32)
-        codes = np.empty(inf["n"] * inf["m"], np.uint8)
+        mb = inf["m"] if _nbits(self.codebook) == 8 else inf["m"] // 2
+        codes = np.empty(inf["n"] * mb, np.uint8)
         rid = np.empty(inf["n"], np.uint64)
         check(self.engine.lib.lance_hip_index_export(self.engine.h, self.h, offs.ctypes.data_as(C.c_void_p),
                                                      codes.ctypes.data_as(C.c_void_p), rid.ctypes.data_as(C.c_void_p)))

@@ -238,6 +238,8 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
         cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
     if pq_codebook is not None:
         cb = to_device(np.asarray(pq_codebook, np.float32).reshape(num_sub_vectors, 1 << num_bits, d // num_sub_vectors))
+    if num_bits not in (4, 8):
+        raise ValueError(f"ProductQuantization: num_bits {num_bits} not supported")
     else:
         cb, stats.pq_iters = timed("train_pq", lambda: train_pq_codebook(x, cent, params, eng))
     part, codes, _ = timed("transform", lambda: eng.ivfpq_encode(x, cent, cb, params.metric))

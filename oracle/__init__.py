@@ -255,6 +255,22 @@ def pq_scan_rowmajor(lut, codes):
     return out
 
 
+def pq_scan4(lut, codes_t, k_hint, metric="l2"):
+    """compute_pq_distance_4bit over transposed packed codes [M/2][n]"""
+    lut = _f32(lut); codes_t = np.ascontiguousarray(codes_t, np.uint8)
+    mb, n_p = codes_t.shape
+    out = np.empty(n_p, np.float32)
+    lib().orc_pq_scan4_f32(_m(metric), _p(lut), C.c_size_t(mb * 2), _p(codes_t), C.c_size_t(n_p), C.c_size_t(k_hint), _p(out))
+    return out
+
+
+def sum_4bit_dist_table(codes, code_len, dist_table, n):
+    codes = np.ascontiguousarray(codes, np.uint8); dist_table = np.ascontiguousarray(dist_table, np.uint8)
+    dists = np.zeros(n, np.uint16)
+    lib().orc_sum_4bit_dist_table(C.c_size_t(n), C.c_size_t(code_len), _p(codes), _p(dist_table), _p(dists))
+    return dists
+
+
 def heap_topk(dists, row_ids, k, lower=None, upper=None):
     dists = _f32(dists); row_ids = np.ascontiguousarray(row_ids, np.uint64)
     out_i = np.empty(max(k, 1), np.uint64); out_d = np.empty(max(k, 1), np.float32)
@@ -305,8 +321,9 @@ def partition_layout(part_ids, nlist):
 class IvfPqIndex:
     """Canonical CPU index (reference layout: per-partition transposed codes)."""
 
-    def __init__(self, metric, centroids, codebook, part_offsets, codes_t, row_ids, f16=False):
+    def __init__(self, metric, centroids, codebook, part_offsets, codes_t, row_ids, f16=False, nbits=8):
         self.metric = _m(metric)
+        self.nbits = nbits
         self.f16 = bool(f16) or np.asarray(centroids).dtype == np.float16
         self.centroids = _f32(centroids)
         self.codebook = _f32(codebook)
@@ -319,14 +336,14 @@ class IvfPqIndex:
         nq, d = q.shape
         ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
         r = None if raw is None else _f32(raw)
-        lib().orc_ivfpq_search_x(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
-                                 _p(self.codebook), C.c_size_t(self.codebook.shape[0]), _p(self.part_offsets),
+        lib().orc_ivfpq_search_x2(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
+                                 _p(self.codebook), C.c_size_t(self.codebook.shape[0]), C.c_uint32(self.nbits), _p(self.part_offsets),
                                  _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq), C.c_size_t(k),
                                  C.c_size_t(nprobes), C.c_size_t(refine), _p(r), _p(ids), _p(dists), C.c_int(int(self.f16)))
         return ids, dists
 
 
-def build_index(x, centroids, codebook, metric="l2", row_ids=None):
+def build_index(x, centroids, codebook, metric="l2", row_ids=None, nbits=8):
     """Transform chain of lance-index ivf.rs:188-236 + per-partition storage
     (builder.rs:685-846) in canonical stable row order:
     [normalise if cosine] -> keep finite -> assign -> residual (L2/cosine) -> PQ encode
@@ -344,7 +361,7 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None):
     sm = L2 if m == COSINE else m
     part, _ = assign(xs, centroids, sm)
     res = residual(xs.astype(np.float16) if f16 else xs, centroids, np.where(part == NONE, 0, part)) if sm == L2 else xs
-    codes = pq_encode(res, codebook, sm)
+    codes = pq_encode(res, codebook, sm, nbits=nbits)
     nlist = centroids.shape[0]
     offs, perm = partition_layout(part, nlist)
     codes_sorted = codes[perm]
@@ -354,7 +371,7 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None):
         a, b = int(offs[p]), int(offs[p + 1])
         if b > a:
             codes_t[a * mm:b * mm] = transpose(codes_sorted[a:b]).ravel()
-    idx = IvfPqIndex(m, centroids, codebook, offs, codes_t, rid[perm], f16=f16)
+    idx = IvfPqIndex(m, centroids, codebook, offs, codes_t, rid[perm], f16=f16, nbits=nbits)
     idx.part_ids = part
     idx.codes_rowmajor = codes
     idx.perm = perm

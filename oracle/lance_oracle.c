@@ -814,6 +814,93 @@ void orc_pq_scan_rowmajor_f32(const float *lut, size_t m_count, const uint8_t *c
   }
 }
 
+
+/* ------------------------------------------------------------------------- */
+static inline uint32_t orc_key(float f);
+/* a18: 4-bit PQ.  compute_pq_distance_4bit  pq/distance.rs:147-242 with
+ * compute_pq_distance_4bit_flat :246-268 and quantize_distance_table :275-284.
+ * code: transposed [M/2][n] bytes, byte b of a row = sub-vector 2b (low nibble) | 2b+1 (high).
+ * The first flat_num = max(200, min(k_hint, n)) rows and the n%16 tail are exact f32 sums; the
+ * rest are saturating u8 sums of the quantised table (u8x16 `+=` is _mm_adds_epu8,
+ * simd/u8.rs:303-309), de-quantised as q*range + qmin (no fma).                              */
+static void orc_pq4_flat(const float *lut, size_t n, const uint8_t *code, size_t m_count, size_t offset,
+                         size_t length, float *dists) {
+  for (size_t b = 0; b < m_count / 2; b++) {
+    const uint8_t *vi = code + b * n + offset;
+    const float *t0 = lut + (b * 2) * 16, *t1 = lut + (b * 2 + 1) * 16;
+    for (size_t i = 0; i < length; i++) {
+      dists[offset + i] += t0[vi[i] & 0xF];
+      dists[offset + i] += t1[vi[i] >> 4];
+    }
+  }
+}
+void orc_pq_scan4_f32(int metric, const float *lut, size_t m_count, const uint8_t *code, size_t n,
+                      size_t k_hint, float *dists) {
+  if (n == 0) return;
+  for (size_t j = 0; j < n; j++) dists[j] = 0.0f;
+  if (k_hint > n) k_hint = n;
+  size_t flat_num = k_hint > 200 ? k_hint : 200;
+  if (flat_num > n) flat_num = n;
+  orc_pq4_flat(lut, n, code, m_count, 0, flat_num, dists);
+  float qmax = dists[0];
+  for (size_t j = 1; j < flat_num; j++)
+    if (orc_key(dists[j]) >= orc_key(qmax)) qmax = dists[j]; /* max_by(total_cmp): last maximum */
+  float qmin = INFINITY;
+  for (size_t i = 0; i < m_count * 16; i++) qmin = fminf(qmin, lut[i]); /* f32::min */
+  float factor = 255.0f / (qmax - qmin);
+  uint8_t *qt = (uint8_t *)malloc(m_count * 16);
+  for (size_t i = 0; i < m_count * 16; i++) {
+    float v = roundf((lut[i] - qmin) * factor); /* f32::round: half away from zero; `as u8` saturates, NaN -> 0 */
+    qt[i] = v != v ? 0 : (v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (uint8_t)v));
+  }
+  size_t remainder = n % 16;
+  float range = (qmax - qmin) / 255.0f;
+  for (size_t j = flat_num; j < n - remainder; j++) {
+    unsigned acc = 0;
+    for (size_t b = 0; b < m_count / 2; b++) {
+      uint8_t c = code[b * n + j];
+      acc += qt[(b * 2) * 16 + (c & 0xF)]; if (acc > 255) acc = 255;
+      acc += qt[(b * 2 + 1) * 16 + (c >> 4)]; if (acc > 255) acc = 255;
+    }
+    dists[j] = (float)acc * range + qmin;
+  }
+  if (remainder > 0) {
+    size_t offset = n - remainder > flat_num ? n - remainder : flat_num;
+    orc_pq4_flat(lut, n, code, m_count, offset, n - offset, dists);
+  }
+  free(qt);
+  if (metric == ORC_DOT) {
+    float diff = (float)m_count - 1.0f;
+    for (size_t j = 0; j < n; j++) dists[j] = dists[j] - diff;
+  }
+}
+
+/* sum_4bit_dist_table_scalar  lance-linalg/src/simd/dist_table.rs:65-91 (PERM0 layout, u16
+ * saturating sums; RabitQ fast-scan).  Pinned against the reference's own C kernel
+ * (simd/dist_table.c built into oracle/_ref) and its known answer dists[1] == 38 (:178-217). */
+static const size_t ORC_PERM0[16] = {0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15};
+void orc_sum_4bit_dist_table(size_t n, size_t code_len, const uint8_t *codes, const uint8_t *dist_table,
+                             uint16_t *dists) {
+  for (size_t vb = 0; vb < n / 32; vb++) {
+    const uint8_t *blocks = codes + vb * 32 * code_len;
+    for (size_t sv = 0; sv < code_len; sv++) {
+      const uint8_t *block = blocks + sv * 32;
+      const uint8_t *cur = dist_table + sv * 2 * 16, *nxt = dist_table + (sv * 2 + 1) * 16;
+      for (size_t j = 0; j < 16; j++) {
+        size_t lo_id = vb * 32 + ORC_PERM0[j], hi_id = lo_id + 16;
+        unsigned a = dists[lo_id];
+        a += cur[block[j] & 0x0F]; if (a > 65535) a = 65535;
+        a += nxt[block[j + 16] & 0x0F]; if (a > 65535) a = 65535;
+        dists[lo_id] = (uint16_t)a;
+        unsigned b = dists[hi_id];
+        b += cur[block[j] >> 4]; if (b > 65535) b = 65535;
+        b += nxt[block[j + 16] >> 4]; if (b > 65535) b = 65535;
+        dists[hi_id] = (uint16_t)b;
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* f32::total_cmp key (graph.rs:66-82 OrderedFloat): monotone u32 */
 static inline uint32_t orc_key(float f) {
@@ -978,6 +1065,11 @@ void orc_ivfpq_search_x(int metric, const float *centroids, size_t nlist, size_t
                         const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
                         size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
                         uint64_t *out_ids, float *out_dists, int f16);
+void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_t d,
+                         const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
+                         const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                         size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                         uint64_t *out_ids, float *out_dists, int f16);
 void orc_ivfpq_search_f32(int metric, const float *centroids, size_t nlist, size_t d,
                           const float *codebook, size_t m_count, const uint32_t *part_offsets,
                           const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
@@ -993,6 +1085,17 @@ void orc_ivfpq_search_x(int metric, const float *centroids, size_t nlist, size_t
                         const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
                         size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
                         uint64_t *out_ids, float *out_dists, int f16) {
+  orc_ivfpq_search_x2(metric, centroids, nlist, d, codebook, m_count, 8, part_offsets, codes_t, row_ids, queries, nq, k,
+                      nprobes, refine, raw, out_ids, out_dists, f16);
+}
+/* nbits = 4: codes_t blocks are [M/2][n_p] packed bytes and distance_all takes the 4-bit path with
+ * k_hint = k*refine (flat/index.rs:94 `dist_calc.distance_all(k)`). */
+void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_t d,
+                         const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
+                         const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                         size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                         uint64_t *out_ids, float *out_dists, int f16) {
+  const size_t mbytes = nbits == 4 ? m_count / 2 : m_count;
   if (nprobes > nlist) nprobes = nlist;
   int scan_metric = (metric == ORC_COSINE) ? ORC_L2 : metric;
   size_t keff = k * (refine ? refine : 1);
@@ -1033,8 +1136,9 @@ void orc_ivfpq_search_x(int metric, const float *centroids, size_t nlist, size_t
       } else {
         memcpy(qr, q, d * sizeof(float));
       }
-      orc_build_lut_f32(scan_metric, qr, d, codebook, m_count, 8, lut);
-      orc_pq_scan_f32(scan_metric, lut, m_count, codes_t + off * m_count, np_, pd);
+      orc_build_lut_f32(scan_metric, qr, d, codebook, m_count, nbits, lut);
+      if (nbits == 4) orc_pq_scan4_f32(scan_metric, lut, m_count, codes_t + off * mbytes, np_, keff, pd);
+      else orc_pq_scan_f32(scan_metric, lut, m_count, codes_t + off * mbytes, np_, pd);
       ncand += orc_heap_topk(pd, row_ids + off, np_, keff, 0, 0, 0, cand_ids + ncand, cand_d + ncand);
     }
     size_t got = orc_sort_fetch(cand_ids, cand_d, ncand, keff);

@@ -351,6 +351,48 @@ def test_dbpedia_shape_cosine_m96(eng, oracle):
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_4bit_pq_bit_exact(eng, oracle, metric):
+    """num_bits = 4 (a18): k=16 sub-quantisers, nibble packing (pq.rs:168-172), and the quantised fast-scan
+    compute_pq_distance_4bit (pq/distance.rs:147-284) with its exact head/tail rows."""
+    from lance_amd.engine import DeviceIndex
+    n, d, nlist, m = 20000, 64, 16, 16
+    x = sift_like(n, d, 91)
+    q = sift_like(100, d, 92)
+    kmetric = metric
+    cent, _, _, _ = oracle.kmeans_train(x[:2048], nlist, max_iters=6, seed=1, metric=kmetric)
+    part, _ = oracle.assign(x, cent, kmetric)
+    res = oracle.residual(x, cent, part) if metric == "l2" else x
+    cb, it = eng.pq_train(res[:8192], m, nbits=4, max_iters=8, seed=2)
+    ocb, oit = oracle.pq_train(res[:8192], m, nbits=4, max_iters=8, seed=2)
+    assert cb.shape == (m, 16, d // m) and (it == oit.astype(np.uint32)).all()
+    assert (_np(cb).view(np.uint32) == ocb.view(np.uint32)).all()
+    codes = eng.pq_encode(res, ocb, metric)
+    assert codes.shape == (n, m // 2)
+    assert (_np(codes) == oracle.pq_encode(res, ocb, metric, nbits=4)).all()
+    oidx = oracle.build_index(x, cent, ocb, metric, nbits=4)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, ocb, metric)
+    gidx = DeviceIndex.create(eng, metric, cent, ocb, gpart, gcodes, None, raw=x)
+    offs, codes_t, rid = gidx.export()
+    assert (offs == oidx.part_offsets).all() and (codes_t == oidx.codes_t).all()
+    for k, nprobes, rf in ((10, nlist, 0), (10, 3, 0), (10, 4, 5), (100, nlist, 0), (1, 1, 0)):
+        gi, gd = gidx.search(q, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x)
+        assert (_np(gi).view(np.uint64) == oi).all(), (metric, k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    # single partition entry point, small partition (all rows exact) and a 16-multiple boundary
+    for n_p in (150, 1008, 1013):
+        ct = oracle.transpose(oracle.pq_encode(res[:n_p], ocb, metric, nbits=4))
+        ridp = np.arange(n_p, dtype=np.uint64) * 3
+        qr = res[5]
+        lut = oracle.build_lut(qr, ocb, metric, nbits=4)
+        dist = oracle.pq_scan4(lut, ct, 10, metric)
+        hi, hd = oracle.heap_topk(dist, ridp, 10)
+        ei, ed = oracle.sort_fetch(hi, hd, 10)
+        gi, gd = eng.pq_scan_topk(qr, ocb, ct, ridp, 10, metric)
+        assert (_np(gi).view(np.uint64) == ei).all() and (_np(gd).view(np.uint32) == ed.view(np.uint32)).all()
+
+
 def f16_data(n, d, seed, ncl=16):
     # small-magnitude f16-exact values (like C4's f16 vectors)
     rng = np.random.default_rng(seed)

@@ -430,3 +430,48 @@ def test_cosine_matches_independent_restatement(oracle, d):
         assert np.float32(oracle.cosine(x, y)) == np_cosine_fast(x, y)
         ref = 1.0 - np.dot(x.astype(np.float64), y.astype(np.float64)) / np.linalg.norm(x.astype(np.float64)) / np.linalg.norm(y.astype(np.float64))
         assert abs(oracle.cosine(x, y) - ref) < 1e-5
+
+
+def test_sum_4bit_dist_table_known_answer_and_reference_c(oracle):
+    """simd/dist_table.rs:178-217: dists[1] == 38; and, when the reference tree is present, the oracle
+    restatement equals the reference's own C kernel (simd/dist_table.c compiled into oracle/_ref)."""
+    import ctypes as C
+    import os
+    base = [0x12, 0x34, 0x56, 0x78, 0x9a, 0xbc, 0xde, 0xf0, 0x11, 0x22, 0x33, 0x44, 0x55, 0x66, 0x77, 0x88,
+            0x99, 0xaa, 0xbb, 0xcc, 0xdd, 0xee, 0xff, 0x00, 0x12, 0x34, 0x56, 0x78, 0x9a, 0xbc, 0xde, 0xf0]
+    codes = np.array(base * 2, np.uint8)
+    dt = np.array([(i % 16) + 1 for i in range(64)], np.uint8)
+    d = oracle.sum_4bit_dist_table(codes, 2, dt, 32)
+    assert d[1] == 38
+    so = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libref_dist_table.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    ref = C.CDLL(so)
+    rng = np.random.default_rng(0)
+    for code_len in (2, 4, 8):          # the AVX-512 kernel consumes 64 code bytes per step = 2 sub-vector pairs
+        codes = rng.integers(0, 256, 32 * code_len, dtype=np.uint8)
+        dt = rng.integers(0, 256, code_len * 32, dtype=np.uint8)
+        out = np.zeros(32, np.uint16)
+        ref.sum_4bit_dist_table_32bytes_batch_avx512(codes.ctypes.data_as(C.c_void_p), C.c_size_t(codes.size),
+                                                     dt.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert (out == oracle.sum_4bit_dist_table(codes, code_len, dt, 32)).all()
+
+
+def test_pq4_scan_structure(oracle):
+    # pq/distance.rs:147-242: rows < flat_num and the n%16 tail are exact, the rest quantised within one step
+    rng = np.random.default_rng(4)
+    m, n = 8, 1013
+    lut = rng.random((m, 16)).astype(f32) * 10
+    codes_t = rng.integers(0, 256, (m // 2, n), dtype=np.uint8)
+    d = oracle.pq_scan4(lut, codes_t, 10)
+    exact = np.zeros(n, f32)
+    for b in range(m // 2):
+        exact = (exact + lut[2 * b][codes_t[b] & 15]).astype(f32)
+        exact = (exact + lut[2 * b + 1][codes_t[b] >> 4]).astype(f32)
+    assert (d[:200] == exact[:200]).all()
+    assert (d[n - n % 16:] == exact[n - n % 16:]).all()
+    qmax, qmin = exact[:200].max(), lut.min()
+    step = (qmax - qmin) / 255
+    mid = slice(200, n - n % 16)
+    sat = exact[mid] < qmax          # below saturation the error is at most m half-steps
+    assert np.abs(d[mid][sat] - exact[mid][sat]).max() <= m * step / 2 + 1e-4
