@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblance_hip.so")
+LIB_PATH = os.environ.get("LANCE_HIP_LIB") or os.path.join(_HERE, "liblance_hip.so")   # override: kernel-variant A/B runs
 
 OK, EINVAL, ERUNTIME, ENOTSUP, ENOMEM = 0, -1, -2, -3, -4
 L2, COSINE, DOT = 0, 1, 2

@@ -35,8 +35,17 @@
 
 namespace lh {
 
-constexpr int SCAN_CAP = 2048;    // LDS candidate buffer entries
-constexpr int SCAN_ROUND = 1024;  // rows per round (4 per lane)
+#ifndef LH_SCAN_CAP
+#define LH_SCAN_CAP 1024
+#endif
+#ifndef LH_SCAN_ROUND
+#define LH_SCAN_ROUND 512
+#endif
+#ifndef LH_LUT_BATCH
+#define LH_LUT_BATCH 4
+#endif
+constexpr int SCAN_CAP = LH_SCAN_CAP;      // LDS candidate buffer entries
+constexpr int SCAN_ROUND = LH_SCAN_ROUND;  // rows per round
 constexpr int SCAN_LCAP = 256;    // entries handed to the merge kernel per (query, split)
 constexpr int SCAN_MAX_KEFF = 128;
 constexpr uint32_t FLAG_OVERFLOW = 1u, FLAG_AMBIGUOUS = 2u;
@@ -206,17 +215,18 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
         // 4 entries per step: all codebook loads of the step are issued before the arithmetic,
         // so one L2 round trip covers 4 entries (the codebook is 128 KiB, L2-resident).
         constexpr int Q = SD / 4;
-        for (int i0 = 0; i0 < m; i0 += 4) {
-          f4 cbv[4][Q];
+        constexpr int LB = LH_LUT_BATCH;
+        for (int i0 = 0; i0 < m; i0 += LB) {
+          f4 cbv[LB][Q];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < LB; ++u) {
             const int mm = min(i0 + u, m - 1);
             const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + threadIdx.x) * SD);
 #pragma unroll
             for (int i = 0; i < Q; ++i) cbv[u][i] = src[i];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < LB; ++u) {
             const int mm = i0 + u;
             if (mm < m) {
               RegVec<SD> a;
@@ -871,7 +881,9 @@ template <int SD, int METRIC>
 static void launch_scan_mu(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t lds) {
   const int mu = (a.m % 16 == 0) ? a.m / 16 : 0;
   // register-resident codebook: d = m*SD <= 128 and enough items to amortise the per-workgroup load
-  static const bool no_persist = getenv("LANCE_HIP_NO_PERSIST") != nullptr;
+  // measured 2x SLOWER than the plain kernel (181 VGPRs -> 2 waves/SIMD: the LDS gathers need occupancy);
+  // kept behind LANCE_HIP_PERSIST=1 for experiments only
+  static const bool no_persist = getenv("LANCE_HIP_PERSIST") == nullptr;
   if (!no_persist && !a.ablate && mu > 0 && mu * 16 * SD <= 128 && grid >= 4 * ctx->num_cus) {
     const int g = 2 * ctx->num_cus;
     if constexpr (SD == 8) {
