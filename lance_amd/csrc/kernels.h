@@ -56,6 +56,11 @@ int widen_into(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float
 int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t count);
 int launch_residual(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, float *out, bool f16);
 
+
+bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range);
+int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
+                        uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
+                        uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
 
 }  // namespace lh

@@ -30,6 +30,7 @@
 #include "exact.cuh"
 #include "index.h"
 #include "kernels.h"
+#include "search_common.cuh"
 
 #pragma clang fp contract(off)
 
@@ -46,9 +47,6 @@ namespace lh {
 #endif
 constexpr int SCAN_CAP = LH_SCAN_CAP;      // LDS candidate buffer entries
 constexpr int SCAN_ROUND = LH_SCAN_ROUND;  // rows per round
-constexpr int SCAN_LCAP = 256;    // entries handed to the merge kernel per (query, split)
-constexpr int SCAN_MAX_KEFF = 128;
-constexpr uint32_t FLAG_OVERFLOW = 1u, FLAG_AMBIGUOUS = 2u;
 
 // ------------------------------------------------------------------------------------
 // bitonic sort of P (power of two) 64-bit keys in LDS with 256 threads
@@ -566,36 +564,6 @@ struct MergeArgs {
   uint32_t *flags;
 };
 
-__device__ __forceinline__ uint32_t find_partition_dev(const uint32_t *__restrict__ offs, int nlist, uint32_t slot) {
-  int lo = 0, hi = nlist;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (offs[mid] <= slot) lo = mid; else hi = mid;
-  }
-  return (uint32_t)lo;
-}
-
-// sort entries by (key, rowid) -- the SortExec order -- with pos as payload
-__device__ __forceinline__ void bitonic_sort_kr(uint32_t *key, uint64_t *rid, uint32_t *pos, int P) {
-  for (int k2 = 2; k2 <= P; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < P / 2; i += 256) {
-        const int ix = 2 * j * (i / j) + (i % j);
-        const int px = ix + j;
-        const bool up = (ix & k2) == 0;
-        const uint32_t kx = key[ix], ky = key[px];
-        const uint64_t rx = rid[ix], ry = rid[px];
-        const bool gt = kx > ky || (kx == ky && rx > ry);
-        if (gt == up) {
-          key[ix] = ky; key[px] = kx; rid[ix] = ry; rid[px] = rx;
-          const uint32_t t = pos[ix]; pos[ix] = pos[px]; pos[px] = t;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void ivfpq_merge_kernel(MergeArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
@@ -875,7 +843,6 @@ __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------
-static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 template <int SD, int METRIC>
 static void launch_scan_mu(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t lds) {
@@ -962,17 +929,30 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, nlist, P, (int)nprobes,
                        probes, (float *)nullptr);
   }
-  // scan
+  uint64_t *cand_rid = nullptr;
+  uint32_t *cand_cnt = nullptr;
+  if (do_refine) {
+    cand_rid = ctx->scratch_t<uint64_t>("search.cand_rid", (size_t)nq * keff);
+    cand_cnt = ctx->scratch_t<uint32_t>("search.cand_cnt", nq);
+    if (!cand_rid || !cand_cnt) return LANCE_HIP_ENOMEM;
+  }
+  // scan: partition-major (two queries per LDS gather) when the batch is large enough to pair queries,
+  // query-major otherwise
+  static const bool no_pm = getenv("LANCE_HIP_NO_PM") != nullptr;
+  const bool use_pm = fast && !no_pm && pm_supported(ix, keff, has_range) && (uint64_t)nq * nprobes >= 4096;
   int nsplit = 1;
   if (nq < (uint32_t)(2 * ctx->num_cus)) {
     nsplit = (int)std::min<uint64_t>({8ull, (uint64_t)nprobes, cdiv(2ull * ctx->num_cus, nq)});
     if (nsplit < 1) nsplit = 1;
   }
   const size_t nblk = (size_t)nq * nsplit;
-  uint32_t *ckeys = ctx->scratch_t<uint32_t>("search.ckeys", nblk * SCAN_LCAP);
-  uint32_t *cpos = ctx->scratch_t<uint32_t>("search.cpos", nblk * SCAN_LCAP);
-  uint32_t *ccnt = ctx->scratch_t<uint32_t>("search.ccnt", nblk);
-  if (!ckeys || !cpos || !ccnt) return LANCE_HIP_ENOMEM;
+  uint32_t *ckeys = nullptr, *cpos = nullptr, *ccnt = nullptr;
+  if (!use_pm) {
+    ckeys = ctx->scratch_t<uint32_t>("search.ckeys", nblk * SCAN_LCAP);
+    cpos = ctx->scratch_t<uint32_t>("search.cpos", nblk * SCAN_LCAP);
+    ccnt = ctx->scratch_t<uint32_t>("search.ccnt", nblk);
+    if (!ckeys || !cpos || !ccnt) return LANCE_HIP_ENOMEM;
+  }
   ScanArgs a;
   {
     a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook;
@@ -994,7 +974,9 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const int dpad = (d + 3) & ~3;
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
-    if (fast && ix->nbits == 4) {
+    if (use_pm) {
+      LH_TRY(ivfpq_scan_merge_pm(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags));
+    } else if (fast && ix->nbits == 4) {
       const size_t lds4 = (size_t)dpad * 4 + (size_t)m * 16 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4 + 16 + 256 * 4 + (size_t)m * 16 + 16;
       ScopedTimer t(ctx, "ivfpq_scan");
       if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_scan4_kernel<METRIC_DOT>), dim3((unsigned)nblk), dim3(256), lds4, ctx->stream, a);
@@ -1008,14 +990,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     }
   }
   // merge (+ refine)
-  uint64_t *cand_rid = nullptr;
-  uint32_t *cand_cnt = nullptr;
-  if (do_refine) {
-    cand_rid = ctx->scratch_t<uint64_t>("search.cand_rid", (size_t)nq * keff);
-    cand_cnt = ctx->scratch_t<uint32_t>("search.cand_cnt", nq);
-    if (!cand_rid || !cand_cnt) return LANCE_HIP_ENOMEM;
-  }
-  if (fast) {
+  if (fast && !use_pm) {
     MergeArgs ma;
     ma.keys = ckeys; ma.pos = cpos; ma.cnt = ccnt; ma.row_ids = ix->row_ids; ma.part_offsets = ix->part_offsets;
     ma.nlist = nlist; ma.nsplit = nsplit; ma.keff = (int)keff; ma.k = (int)k;

@@ -1,0 +1,454 @@
+// search_pm.hip -- partition-major ADC scan: two queries share every LDS gather.
+//
+// Why: the query-major scan (search.hip) is bound by random 4-byte LDS gathers -- 32 lanes hitting
+// 32 banks collide ~3.5 deep, which measures 9.15 lookups/clk/CU on gfx950 (scripts/ubench/lds_gather.hip).
+// An 8-byte gather costs the same LDS cycles, so interleaving the LUTs of TWO queries that probe the SAME
+// partition ([m][256][2] floats, one ds_read_b64 per (row, m)) doubles the useful lookups per LDS cycle
+// (17.9 values/clk/CU measured), halves the code-byte loads and halves the codebook reads of the LUT build.
+//
+// Pipeline (all on the stream, no host round trip):
+//   1. (query, probe) pairs are grouped by partition with the stable counting sort of group.hip;
+//   2. item table: partition p with c_p probing queries contributes ceil(c_p / 2) work items;
+//   3. scan: one 512-lane workgroup per item builds the interleaved LUT pair, streams the partition once
+//      and keeps, per query, every row with key <= T in an LDS buffer (T tightened exactly as in the
+//      query-major kernel).  Each query also owns a global bound Tglobal[q] = min over its finished
+//      partitions of their k-th-smallest bound -- a valid upper bound of the final k-th distance, so later
+//      partitions of the same query prune with it.  Survivors are appended to a per-query pool;
+//   4. merge: per query, the pool is reduced with the same threshold machinery, sorted by (dist, rowid),
+//      tie-checked and emitted (identical outputs to the query-major merge kernel).
+// The union of the pool always contains every scanned row with dist <= final T, whatever order the items
+// ran in, so results are deterministic and equal to the reference's SortExec over per-partition heaps.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "exact.cuh"
+#include "index.h"
+#include "kernels.h"
+#include "search_common.cuh"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+constexpr int PM_BS = 512;       // lanes per workgroup
+constexpr int PM_CAP = 768;      // candidate buffer entries per query
+constexpr int PM_ROUND = 512;    // rows per round (one per lane)
+constexpr int PM_POOL = 2048;    // pool entries per query
+
+struct PmArgs {
+  const float *q;               // [nq][d]
+  const uint32_t *probes;       // [nq*nprobes] partition of each (query, probe) pair
+  const uint32_t *pair_starts;  // [nlist+1] pairs grouped by partition
+  const uint32_t *pair_idx;     // [nq*nprobes] pair index (q = idx / nprobes), grouped
+  const uint32_t *item_start;   // [nlist+1] exclusive scan of ceil(c_p / 2)
+  const float *centroids, *codebook;
+  const uint32_t *part_offsets;
+  const uint8_t *codes;
+  int d, m, nprobes, nlist, keff;
+  int residual, round_f16;
+  uint32_t *tglobal;            // [nq] running upper bound of the keff-th distance (key)
+  uint32_t *pool_key, *pool_pos, *pool_cnt;  // [nq][PM_POOL], [nq]
+  uint32_t *flags;
+};
+
+// ---- threshold machinery, generic in the workgroup size ---------------------------------------------
+struct CandBuf {
+  uint32_t *key, *pos;  // [CAP]
+  uint32_t *cnt;        // current entries
+  uint32_t *T;          // current threshold (key)
+};
+
+// k-th smallest (0-based rank kk) of one value per lane; result in *out (LDS), broadcast after the barrier
+template <int BS>
+__device__ __forceinline__ void kth_smallest_bs(uint32_t v, int kk, uint32_t *sorted, uint32_t *out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const uint32_t o = __shfl_xor(v, j, 64);
+      const bool up = (lane & k2) == 0;
+      const bool lower = (lane & j) == 0;
+      v = (lower == up) ? min(v, o) : max(v, o);
+    }
+  }
+  sorted[threadIdx.x] = v;
+  __syncthreads();
+  int rank = lane;
+  for (int w = 0; w < BS / 64; ++w) {
+    if (w == wave) continue;
+    const uint32_t *run = sorted + w * 64;
+    int lo = 0, hi = 64;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const bool before = w < wave ? run[mid] <= v : run[mid] < v;
+      if (before) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  if (rank == kk) *out = v;
+  __syncthreads();
+}
+
+// T <- upper bound of the keff-th smallest key in the buffer (exact once <= BS entries remain); drop key > T
+template <int BS, int CAP>
+__device__ __forceinline__ void tighten_bs(const CandBuf &b, int keff, uint32_t *sorted, uint32_t *tnew_slot) {
+  __syncthreads();
+  const int c = min((int)*b.cnt, CAP);
+  if (c < keff) return;  // uniform
+  constexpr int PER = (CAP + BS - 1) / BS;
+  uint32_t ek[PER], ep[PER];
+  uint32_t mymin = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = threadIdx.x + BS * j;
+    ek[j] = 0xFFFFFFFFu; ep[j] = 0;
+    if (i < c) { ek[j] = b.key[i]; ep[j] = b.pos[i]; mymin = min(mymin, ek[j]); }
+  }
+  kth_smallest_bs<BS>(mymin, keff - 1, sorted, tnew_slot);
+  const uint32_t tnew = *tnew_slot;
+  __syncthreads();
+  if (threadIdx.x == 0) { *b.cnt = 0; *b.T = tnew; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = threadIdx.x + BS * j;
+    if (i < c && ek[j] <= tnew) {
+      const uint32_t slot = atomicAdd(b.cnt, 1u);
+      b.key[slot] = ek[j]; b.pos[slot] = ep[j];
+    }
+  }
+  __syncthreads();
+}
+
+// ---- item table ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pm_item_table_kernel(const uint32_t *__restrict__ pair_starts, int nlist,
+                                                            uint32_t *__restrict__ item_start) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nlist; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < nlist ? (pair_starts[i + 1] - pair_starts[i] + 1) / 2 : 0;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint32_t carry = carry_s;
+    if (i < nlist) item_start[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) item_start[nlist] = carry_s;
+}
+
+// ---- scan -----------------------------------------------------------------------------------------------
+template <int SD, int METRIC, int MU>
+__global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int m = MU * 16;
+  constexpr int Q = SD / 4;
+  const int dpad = (p.d + 3) & ~3;
+  float *r0 = reinterpret_cast<float *>(smem);
+  float *r1 = r0 + dpad;
+  f2 *lut2 = reinterpret_cast<f2 *>(r1 + dpad);  // [m][256] pairs
+  uint32_t *ck0 = reinterpret_cast<uint32_t *>(lut2 + m * 256);
+  uint32_t *cp0 = ck0 + PM_CAP;
+  uint32_t *ck1 = cp0 + PM_CAP;
+  uint32_t *cp1 = ck1 + PM_CAP;
+  uint32_t *sorted = cp1 + PM_CAP;   // [PM_BS]
+  uint32_t *misc = sorted + PM_BS;   // [0]=cnt0 [1]=T0 [2]=cnt1 [3]=T1 [4]=tnew [5]=flags
+  __shared__ int s_part, s_q0, s_q1, s_valid;
+
+  if (threadIdx.x == 0) {
+    const uint32_t item = blockIdx.x;
+    int valid = item < p.item_start[p.nlist];
+    int part = 0, q0 = -1, q1 = -1;
+    if (valid) {
+      part = (int)find_partition_dev(p.item_start, p.nlist, item);
+      // partitions without probing queries have empty item ranges; find_partition_dev returns the last
+      // partition whose start <= item, which is the owner because empty ranges share their successor's start
+      while (p.item_start[part + 1] <= item) ++part;
+      const uint32_t g = item - p.item_start[part];
+      const uint32_t ps = p.pair_starts[part], pe = p.pair_starts[part + 1];
+      const uint32_t i0 = ps + 2 * g;
+      q0 = (int)(p.pair_idx[i0] / (uint32_t)p.nprobes);
+      if (i0 + 1 < pe) q1 = (int)(p.pair_idx[i0 + 1] / (uint32_t)p.nprobes);
+    }
+    s_valid = valid; s_part = part; s_q0 = q0; s_q1 = q1;
+    misc[0] = 0; misc[2] = 0; misc[5] = 0;
+    misc[1] = valid ? p.tglobal[q0] : 0xFFFFFFFFu;
+    misc[3] = (valid && q1 >= 0) ? p.tglobal[q1] : 0u;   // no second query: nothing passes key <= 0 ... except key 0
+  }
+  __syncthreads();
+  if (!s_valid) return;
+  const int part = s_part, q0 = s_q0, q1 = s_q1;
+  const bool has1 = q1 >= 0;
+  const uint32_t off = p.part_offsets[part];
+  const int np = (int)(p.part_offsets[part + 1] - off);
+  if (np == 0) return;
+  CandBuf b0{ck0, cp0, &misc[0], &misc[1]}, b1{ck1, cp1, &misc[2], &misc[3]};
+
+  // residual queries (v2.rs:316-332)
+  {
+    const float *qa = p.q + (int64_t)q0 * p.d;
+    const float *qb = p.q + (int64_t)(has1 ? q1 : q0) * p.d;
+    for (int t = threadIdx.x; t < p.d; t += PM_BS) {
+      const float c = p.residual ? p.centroids[(int64_t)part * p.d + t] : 0.0f;
+      float a = p.residual ? qa[t] - c : qa[t];
+      float bq = p.residual ? qb[t] - c : qb[t];
+      if (p.round_f16 && p.residual) { a = __half2float(__float2half_rn(a)); bq = __half2float(__float2half_rn(bq)); }
+      r0[t] = a; r1[t] = bq;
+    }
+  }
+  __syncthreads();
+  // LUT pair: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half*m/2, (half+1)*m/2); each
+  // codebook entry is fetched once and used for both residuals
+  {
+    const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
+    constexpr int MH = m / 2;
+#pragma unroll 2
+    for (int i = 0; i < MH; ++i) {
+      const int mm = half * MH + i;
+      const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
+      f4 cbv[Q];
+#pragma unroll
+      for (int u = 0; u < Q; ++u) cbv[u] = src[u];
+      RegVec<SD> a0, a1;
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        a0.q[u] = *reinterpret_cast<const f4 *>(&r0[mm * SD + 4 * u]);
+        a1.q[u] = *reinterpret_cast<const f4 *>(&r1[mm * SD + 4 * u]);
+      }
+      f2 v;
+      v.x = finish_metric<METRIC>(dist_exact<SD, METRIC>(a0, reinterpret_cast<const float *>(&cbv[0])));
+      v.y = finish_metric<METRIC>(dist_exact<SD, METRIC>(a1, reinterpret_cast<const float *>(&cbv[0])));
+      lut2[mm * 256 + c] = v;
+    }
+  }
+  __syncthreads();
+
+  const uint8_t *pcodes = p.codes + (int64_t)off * m;
+  for (int base = 0; base < np; base += PM_ROUND) {
+    if ((int)misc[0] > PM_CAP - PM_ROUND) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
+    if ((int)misc[2] > PM_CAP - PM_ROUND) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
+    const uint32_t T0 = misc[1], T1 = misc[3];
+    const int row = base + threadIdx.x;
+    if (row < np) {
+      float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
+#pragma unroll
+      for (int w = 0; w < MU; ++w) {
+        const uint4 cw = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * m + w * 16);
+        const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+            d0 += v.x; d1 += v.y;
+          }
+      }
+      if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
+      const uint32_t k0 = order_key(d0), k1 = order_key(d1);
+      if (k0 <= T0) {
+        const uint32_t slot = atomicAdd(&misc[0], 1u);
+        if (slot < PM_CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
+      }
+      if (has1 && k1 <= T1) {
+        const uint32_t slot = atomicAdd(&misc[2], 1u);
+        if (slot < PM_CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
+      }
+    }
+    __syncthreads();
+  }
+  // publish: shrink each buffer once, lower the query's global bound, append the survivors to its pool
+  for (int j = 0; j < 2; ++j) {
+    if (j == 1 && !has1) break;
+    const CandBuf &b = j ? b1 : b0;
+    const int qj = j ? q1 : q0;
+    if ((int)*b.cnt > 256) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
+    __syncthreads();
+    const int c = min((int)*b.cnt, PM_CAP);
+    __shared__ uint32_t s_base, s_tg;
+    if (threadIdx.x == 0) {
+      // *b.T is always a valid upper bound of this query's final keff-th distance: it is either the value read
+      // from tglobal or the keff-th-smallest bound of >= keff real rows of this query
+      const uint32_t mineT = *b.T;
+      const uint32_t old = atomicMin(&p.tglobal[qj], mineT);
+      s_tg = min(old, mineT);
+    }
+    __syncthreads();
+    const uint32_t tg = s_tg;
+    // count survivors (key <= tg), reserve pool space, write
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < c; i += PM_BS) mine += b.key[i] <= tg ? 1u : 0u;
+    if (threadIdx.x == 0) misc[4] = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&misc[4], mine);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = misc[4] ? atomicAdd(&p.pool_cnt[qj], misc[4]) : 0u;
+    __syncthreads();
+    const uint32_t basep = s_base, tot = misc[4];
+    __syncthreads();
+    if (tot) {
+      if (basep + tot > (uint32_t)PM_POOL) {
+        if (threadIdx.x == 0) atomicOr(&p.flags[qj], FLAG_OVERFLOW);
+      } else {
+        if (threadIdx.x == 0) misc[4] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < c; i += PM_BS) {
+          if (b.key[i] <= tg) {
+            const uint32_t slot = basep + atomicAdd(&misc[4], 1u);
+            p.pool_key[(int64_t)qj * PM_POOL + slot] = b.key[i];
+            p.pool_pos[(int64_t)qj * PM_POOL + slot] = b.pos[i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && misc[5]) {
+    atomicOr(&p.flags[q0], misc[5]);
+    if (has1) atomicOr(&p.flags[q1], misc[5]);
+  }
+}
+
+// ---- merge: pool -> top keff by (dist, rowid) ---------------------------------------------------------
+constexpr int PMM_CAP = 1024;
+__global__ __launch_bounds__(256) void ivfpq_merge_pm_kernel(const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_pos,
+                                                             const uint32_t *__restrict__ pool_cnt, const uint32_t *__restrict__ tglobal,
+                                                             const uint64_t *__restrict__ row_ids, SelectOut o) {
+  __shared__ uint32_t ckey[PMM_CAP], cpos[PMM_CAP], sorted[256], misc[8];
+  __shared__ uint64_t rid[SCAN_LCAP];
+  __shared__ uint32_t skey[SCAN_LCAP], spos[SCAN_LCAP];
+  __shared__ int s_amb;
+  const int q = blockIdx.x;
+  if (o.flags[q] & FLAG_OVERFLOW) return;  // pool incomplete: the exact kernel recomputes this query
+  const int n = min((int)pool_cnt[q], PM_POOL);
+  if (threadIdx.x == 0) { misc[0] = 0; misc[1] = tglobal[q]; s_amb = 0; }
+  __syncthreads();
+  CandBuf b{ckey, cpos, &misc[0], &misc[1]};
+  const uint32_t *pk = pool_key + (int64_t)q * PM_POOL, *pp = pool_pos + (int64_t)q * PM_POOL;
+  for (int base = 0; base < n; base += 512) {
+    if ((int)misc[0] > PMM_CAP - 512) tighten_bs<256, PMM_CAP>(b, o.keff, sorted, &misc[2]);
+    const uint32_t T = misc[1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      if (i < n) {
+        const uint32_t kk = pk[i];
+        if (kk <= T) {
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < PMM_CAP) { ckey[slot] = kk; cpos[slot] = pp[i]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<256, PMM_CAP>(b, o.keff, sorted, &misc[2]);
+  __syncthreads();
+  int c = min((int)misc[0], PMM_CAP);
+  if (c > SCAN_LCAP) {
+    if (threadIdx.x == 0) atomicOr(&o.flags[q], FLAG_OVERFLOW);
+    c = SCAN_LCAP;
+  }
+  for (int i = threadIdx.x; i < SCAN_LCAP; i += 256) {
+    if (i < c) { skey[i] = ckey[i]; spos[i] = cpos[i]; rid[i] = row_ids[cpos[i]]; }
+    else { skey[i] = 0xFFFFFFFFu; spos[i] = 0; rid[i] = ~0ull; }
+  }
+  __syncthreads();
+  int Pq = 64;
+  while (Pq < c) Pq <<= 1;
+  bitonic_sort_kr<256>(skey, rid, spos, Pq);
+  select_and_emit<256>(o, q, skey, rid, spos, c, &s_amb);
+}
+
+// ---- host ---------------------------------------------------------------------------------------------
+template <int SD, int METRIC>
+static bool launch_pm_mu(lance_hip_ctx *ctx, const PmArgs &a, unsigned grid, size_t lds) {
+  switch (a.m / 16) {
+    case 1: hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true;
+    case 2: hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true;
+    default: return false;
+  }
+}
+
+bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range) {
+  const int d = (int)ix->d, m = (int)ix->m;
+  if (ix->nbits != 8 || has_range || keff > (uint32_t)SCAN_MAX_KEFF) return false;
+  if (m % 16 != 0 || m / 16 > 2) return false;
+  const int sd = d / m;
+  if (sd != 4 && sd != 8 && sd != 16) return false;
+  if ((reinterpret_cast<uintptr_t>(ix->codebook) & 15) || (reinterpret_cast<uintptr_t>(ix->codes) & 15)) return false;
+  return true;
+}
+
+// scan + merge for the whole batch; outputs as the query-major path (ids/dists or refine candidates)
+int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
+                        uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
+                        uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags) {
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
+  const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
+  const size_t npairs = (size_t)nq * nprobes;
+  uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)nlist + 1);
+  uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);
+  uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)nlist + 1);
+  uint32_t *tglobal = ctx->scratch_t<uint32_t>("pm.tglobal", (size_t)nq * 2);
+  uint32_t *pool_key = ctx->scratch_t<uint32_t>("pm.pool_key", (size_t)nq * PM_POOL);
+  uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * PM_POOL);
+  if (!pair_starts || !pair_idx || !item_start || !tglobal || !pool_key || !pool_pos) return LANCE_HIP_ENOMEM;
+  uint32_t *pool_cnt = tglobal + nq;
+  LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(hipMemsetAsync(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  {
+    ScopedTimer t(ctx, "pm_group");
+    LH_TRY(stable_group(ctx, probes, (int64_t)npairs, (int64_t)npairs, nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
+    hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, item_start);
+  }
+  PmArgs a;
+  a.q = qs; a.probes = probes; a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.item_start = item_start;
+  a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
+  a.d = d; a.m = m; a.nprobes = (int)nprobes; a.nlist = nlist; a.keff = (int)keff;
+  a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
+  a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+  a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.flags = flags;
+  const int dpad = (d + 3) & ~3;
+  const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + (size_t)PM_CAP * 16 + PM_BS * 4 + 8 * 4;
+  const unsigned grid = (unsigned)(npairs / 2 + nlist + 1);  // upper bound of sum ceil(c_p / 2); surplus workgroups exit
+  {
+    ScopedTimer t(ctx, "ivfpq_scan");
+    bool ok = false;
+    if (scan_metric == LANCE_HIP_DOT) {
+      if (sd == 4) ok = launch_pm_mu<4, METRIC_DOT>(ctx, a, grid, lds);
+      else if (sd == 8) ok = launch_pm_mu<8, METRIC_DOT>(ctx, a, grid, lds);
+      else if (sd == 16) ok = launch_pm_mu<16, METRIC_DOT>(ctx, a, grid, lds);
+    } else {
+      if (sd == 4) ok = launch_pm_mu<4, METRIC_L2>(ctx, a, grid, lds);
+      else if (sd == 8) ok = launch_pm_mu<8, METRIC_L2>(ctx, a, grid, lds);
+      else if (sd == 16) ok = launch_pm_mu<16, METRIC_L2>(ctx, a, grid, lds);
+    }
+    LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  }
+  {
+    SelectOut o;
+    o.keff = (int)keff; o.k = (int)k; o.refine = do_refine ? 1 : 0;
+    o.out_ids = ids; o.out_dists = dists; o.cand_rid = cand_rid; o.cand_cnt = cand_cnt; o.flags = flags;
+    o.part_offsets = ix->part_offsets; o.nlist = nlist;
+    ScopedTimer t(ctx, "ivfpq_merge");
+    hipLaunchKernelGGL(ivfpq_merge_pm_kernel, dim3(nq), dim3(256), 0, ctx->stream, pool_key, pool_pos, pool_cnt, tglobal, ix->row_ids, o);
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh
