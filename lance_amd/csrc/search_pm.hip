@@ -39,9 +39,10 @@ constexpr int PM_POOL = 2048;    // pool entries per query
 struct PmArgs {
   const float *q;               // [nq][d]
   const uint32_t *probes;       // [nq*nprobes] partition of each (query, probe) pair
-  const uint32_t *pair_starts;  // [nlist+1] pairs grouped by partition
+  const uint32_t *pair_starts;  // [2*nlist+1] pairs grouped by virtual partition = cls*nlist + partition
   const uint32_t *pair_idx;     // [nq*nprobes] pair index (q = idx / nprobes), grouped
-  const uint32_t *item_start;   // [nlist+1] exclusive scan of ceil(c_p / 2)
+  const uint32_t *item_start;   // [2*nlist+1] exclusive scan of ceil(c_vp / 2) over virtual partitions
+  int cls;                      // which class this launch covers: 0 = nearest-partition pairs, 1 = the rest
   const float *centroids, *codebook;
   const uint32_t *part_offsets;
   const uint8_t *codes;
@@ -122,6 +123,17 @@ __device__ __forceinline__ void tighten_bs(const CandBuf &b, int keff, uint32_t 
   __syncthreads();
 }
 
+// ---- grouping keys --------------------------------------------------------------------------------------
+// Class 0 = the pair whose partition is the query's nearest centroid (probe rank 0), class 1 = all others.
+// Class 0 is scanned first (own launch): it fixes a tight Tglobal[q] for every query, so the other 90 % of the
+// pairs prune with it from their first row and almost never have to tighten.
+__global__ __launch_bounds__(256) void pm_keys_kernel(const uint32_t *__restrict__ probes, int64_t npairs, int nprobes, int nlist,
+                                                      uint32_t *__restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npairs) return;
+  keys[i] = probes[i] + ((i % nprobes) == 0 ? 0u : (uint32_t)nlist);
+}
+
 // ---- item table ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pm_item_table_kernel(const uint32_t *__restrict__ pair_starts, int nlist,
                                                             uint32_t *__restrict__ item_start) {
@@ -171,16 +183,16 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   __shared__ int s_part, s_q0, s_q1, s_valid;
 
   if (threadIdx.x == 0) {
-    const uint32_t item = blockIdx.x;
-    int valid = item < p.item_start[p.nlist];
+    const uint32_t item = blockIdx.x + (p.cls ? p.item_start[p.nlist] : 0u);
+    int valid = item < p.item_start[(p.cls + 1) * p.nlist];
     int part = 0, q0 = -1, q1 = -1;
     if (valid) {
-      part = (int)find_partition_dev(p.item_start, p.nlist, item);
-      // partitions without probing queries have empty item ranges; find_partition_dev returns the last
-      // partition whose start <= item, which is the owner because empty ranges share their successor's start
-      while (p.item_start[part + 1] <= item) ++part;
-      const uint32_t g = item - p.item_start[part];
-      const uint32_t ps = p.pair_starts[part], pe = p.pair_starts[part + 1];
+      // virtual partitions without pairs have empty item ranges; the last one whose start <= item owns it
+      int vp = (int)find_partition_dev(p.item_start, 2 * p.nlist, item);
+      while (p.item_start[vp + 1] <= item) ++vp;
+      part = vp % p.nlist;
+      const uint32_t g = item - p.item_start[vp];
+      const uint32_t ps = p.pair_starts[vp], pe = p.pair_starts[vp + 1];
       const uint32_t i0 = ps + 2 * g;
       q0 = (int)(p.pair_idx[i0] / (uint32_t)p.nprobes);
       if (i0 + 1 < pe) q1 = (int)(p.pair_idx[i0 + 1] / (uint32_t)p.nprobes);
@@ -400,9 +412,9 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
   const size_t npairs = (size_t)nq * nprobes;
-  uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)nlist + 1);
+  uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)2 * nlist + 1);
   uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);
-  uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)nlist + 1);
+  uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)2 * nlist + 1);
   uint32_t *tglobal = ctx->scratch_t<uint32_t>("pm.tglobal", (size_t)nq * 2);
   uint32_t *pool_key = ctx->scratch_t<uint32_t>("pm.pool_key", (size_t)nq * PM_POOL);
   uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * PM_POOL);
@@ -410,10 +422,14 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   uint32_t *pool_cnt = tglobal + nq;
   LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
   LH_CHECK_HIP(hipMemsetAsync(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  uint32_t *keys = ctx->scratch_t<uint32_t>("pm.keys", npairs);
+  if (!keys) return LANCE_HIP_ENOMEM;
   {
     ScopedTimer t(ctx, "pm_group");
-    LH_TRY(stable_group(ctx, probes, (int64_t)npairs, (int64_t)npairs, nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
-    hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, item_start);
+    hipLaunchKernelGGL(pm_keys_kernel, dim3((unsigned)cdiv(npairs, 256)), dim3(256), 0, ctx->stream, probes, (int64_t)npairs, (int)nprobes,
+                       nlist, keys);
+    LH_TRY(stable_group(ctx, keys, (int64_t)npairs, (int64_t)npairs, 2 * nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
+    hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, 2 * nlist, item_start);
   }
   PmArgs a;
   a.q = qs; a.probes = probes; a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.item_start = item_start;
@@ -424,20 +440,26 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.flags = flags;
   const int dpad = (d + 3) & ~3;
   const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + (size_t)PM_CAP * 16 + PM_BS * 4 + 8 * 4;
-  const unsigned grid = (unsigned)(npairs / 2 + nlist + 1);  // upper bound of sum ceil(c_p / 2); surplus workgroups exit
   {
     ScopedTimer t(ctx, "ivfpq_scan");
-    bool ok = false;
-    if (scan_metric == LANCE_HIP_DOT) {
-      if (sd == 4) ok = launch_pm_mu<4, METRIC_DOT>(ctx, a, grid, lds);
-      else if (sd == 8) ok = launch_pm_mu<8, METRIC_DOT>(ctx, a, grid, lds);
-      else if (sd == 16) ok = launch_pm_mu<16, METRIC_DOT>(ctx, a, grid, lds);
-    } else {
-      if (sd == 4) ok = launch_pm_mu<4, METRIC_L2>(ctx, a, grid, lds);
-      else if (sd == 8) ok = launch_pm_mu<8, METRIC_L2>(ctx, a, grid, lds);
-      else if (sd == 16) ok = launch_pm_mu<16, METRIC_L2>(ctx, a, grid, lds);
+    for (int cls = 0; cls < 2; ++cls) {
+      if (cls == 1 && nprobes == 1) break;
+      a.cls = cls;
+      // upper bound of sum ceil(c_vp / 2) over the class; surplus workgroups exit at once
+      const size_t cpairs = cls == 0 ? (size_t)nq : (size_t)nq * (nprobes - 1);
+      const unsigned grid = (unsigned)(cpairs / 2 + nlist + 1);
+      bool ok = false;
+      if (scan_metric == LANCE_HIP_DOT) {
+        if (sd == 4) ok = launch_pm_mu<4, METRIC_DOT>(ctx, a, grid, lds);
+        else if (sd == 8) ok = launch_pm_mu<8, METRIC_DOT>(ctx, a, grid, lds);
+        else if (sd == 16) ok = launch_pm_mu<16, METRIC_DOT>(ctx, a, grid, lds);
+      } else {
+        if (sd == 4) ok = launch_pm_mu<4, METRIC_L2>(ctx, a, grid, lds);
+        else if (sd == 8) ok = launch_pm_mu<8, METRIC_L2>(ctx, a, grid, lds);
+        else if (sd == 16) ok = launch_pm_mu<16, METRIC_L2>(ctx, a, grid, lds);
+      }
+      LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
     }
-    LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
   }
   {
     SelectOut o;
