@@ -43,6 +43,7 @@ struct PmArgs {
   const uint32_t *pair_idx;     // [nq*nprobes] pair index (q = idx / nprobes), grouped
   const uint32_t *item_start;   // [2*nlist+1] exclusive scan of ceil(c_vp / 2) over virtual partitions
   int cls;                      // which class this launch covers: 0 = nearest-partition pairs, 1 = the rest
+  const int4 *desc;             // [items] {partition, q0, q1 (-1 = none), 0}: filled by pm_item_desc_kernel
   const float *centroids, *codebook;
   const uint32_t *part_offsets;
   const uint8_t *codes;
@@ -164,6 +165,27 @@ __global__ __launch_bounds__(256) void pm_item_table_kernel(const uint32_t *__re
   if (threadIdx.x == 0) item_start[nlist] = carry_s;
 }
 
+// one lane per item: resolve (virtual partition, query pair) once, in parallel, instead of a serial binary search
+// at the head of every scan workgroup
+__global__ __launch_bounds__(256) void pm_item_desc_kernel(const uint32_t *__restrict__ item_start, const uint32_t *__restrict__ pair_starts,
+                                                           const uint32_t *__restrict__ pair_idx, int nlist, int nprobes, uint32_t max_items,
+                                                           int4 *__restrict__ desc) {
+  const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= max_items) return;
+  int4 dsc = make_int4(-1, -1, -1, 0);
+  if (item < item_start[2 * nlist]) {
+    int vp = (int)find_partition_dev(item_start, 2 * nlist, item);
+    while (item_start[vp + 1] <= item) ++vp;  // empty ranges share their successor's start
+    const uint32_t g = item - item_start[vp];
+    const uint32_t ps = pair_starts[vp], pe = pair_starts[vp + 1];
+    const uint32_t i0 = ps + 2 * g;
+    dsc.x = vp % nlist;
+    dsc.y = (int)(pair_idx[i0] / (uint32_t)nprobes);
+    dsc.z = i0 + 1 < pe ? (int)(pair_idx[i0 + 1] / (uint32_t)nprobes) : -1;
+  }
+  desc[item] = dsc;
+}
+
 // ---- scan -----------------------------------------------------------------------------------------------
 template <int SD, int METRIC, int MU>
 __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
@@ -184,23 +206,14 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
 
   if (threadIdx.x == 0) {
     const uint32_t item = blockIdx.x + (p.cls ? p.item_start[p.nlist] : 0u);
-    int valid = item < p.item_start[(p.cls + 1) * p.nlist];
-    int part = 0, q0 = -1, q1 = -1;
-    if (valid) {
-      // virtual partitions without pairs have empty item ranges; the last one whose start <= item owns it
-      int vp = (int)find_partition_dev(p.item_start, 2 * p.nlist, item);
-      while (p.item_start[vp + 1] <= item) ++vp;
-      part = vp % p.nlist;
-      const uint32_t g = item - p.item_start[vp];
-      const uint32_t ps = p.pair_starts[vp], pe = p.pair_starts[vp + 1];
-      const uint32_t i0 = ps + 2 * g;
-      q0 = (int)(p.pair_idx[i0] / (uint32_t)p.nprobes);
-      if (i0 + 1 < pe) q1 = (int)(p.pair_idx[i0 + 1] / (uint32_t)p.nprobes);
-    }
+    const int valid = item < p.item_start[(p.cls + 1) * p.nlist];
+    int4 dsc = make_int4(0, -1, -1, 0);
+    if (valid) dsc = p.desc[item];
+    const int part = dsc.x, q0 = dsc.y, q1 = dsc.z;
     s_valid = valid; s_part = part; s_q0 = q0; s_q1 = q1;
     misc[0] = 0; misc[2] = 0; misc[5] = 0;
     misc[1] = valid ? p.tglobal[q0] : 0xFFFFFFFFu;
-    misc[3] = (valid && q1 >= 0) ? p.tglobal[q1] : 0u;   // no second query: nothing passes key <= 0 ... except key 0
+    misc[3] = (valid && q1 >= 0) ? p.tglobal[q1] : 0u;
   }
   __syncthreads();
   if (!s_valid) return;
@@ -251,17 +264,30 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   __syncthreads();
 
   const uint8_t *pcodes = p.codes + (int64_t)off * m;
+  // software pipeline: the code bytes of round r+1 are requested before round r's gathers, so the L2/HBM
+  // latency of the (only) global load in the loop overlaps LDS work
+  uint4 cwn[MU];
+  if ((int)threadIdx.x < np) {
+#pragma unroll
+    for (int w = 0; w < MU; ++w) cwn[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)threadIdx.x * m + w * 16);
+  }
   for (int base = 0; base < np; base += PM_ROUND) {
     if ((int)misc[0] > PM_CAP - PM_ROUND) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
     if ((int)misc[2] > PM_CAP - PM_ROUND) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
     const uint32_t T0 = misc[1], T1 = misc[3];
     const int row = base + threadIdx.x;
+    uint4 cwc[MU];
+#pragma unroll
+    for (int w = 0; w < MU; ++w) cwc[w] = cwn[w];
+    if (row + PM_ROUND < np) {
+#pragma unroll
+      for (int w = 0; w < MU; ++w) cwn[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)(row + PM_ROUND) * m + w * 16);
+    }
     if (row < np) {
       float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
 #pragma unroll
       for (int w = 0; w < MU; ++w) {
-        const uint4 cw = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * m + w * 16);
-        const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+        const uint32_t cws[4] = {cwc[w].x, cwc[w].y, cwc[w].z, cwc[w].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -288,6 +314,7 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     if (j == 1 && !has1) break;
     const CandBuf &b = j ? b1 : b0;
     const int qj = j ? q1 : q0;
+    if (*b.cnt == 0) continue;  // uniform: nothing of this partition can reach the query's top list
     if ((int)*b.cnt > 256) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
     __syncthreads();
     const int c = min((int)*b.cnt, PM_CAP);
@@ -423,13 +450,17 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
   LH_CHECK_HIP(hipMemsetAsync(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
   uint32_t *keys = ctx->scratch_t<uint32_t>("pm.keys", npairs);
-  if (!keys) return LANCE_HIP_ENOMEM;
+  const uint32_t max_items = (uint32_t)(npairs / 2 + 2 * nlist + 2);   // >= sum over virtual partitions of ceil(c / 2)
+  int4 *desc = ctx->scratch_t<int4>("pm.desc", max_items);
+  if (!keys || !desc) return LANCE_HIP_ENOMEM;
   {
     ScopedTimer t(ctx, "pm_group");
     hipLaunchKernelGGL(pm_keys_kernel, dim3((unsigned)cdiv(npairs, 256)), dim3(256), 0, ctx->stream, probes, (int64_t)npairs, (int)nprobes,
                        nlist, keys);
     LH_TRY(stable_group(ctx, keys, (int64_t)npairs, (int64_t)npairs, 2 * nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
     hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, 2 * nlist, item_start);
+    hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, pair_idx,
+                       nlist, (int)nprobes, max_items, desc);
   }
   PmArgs a;
   a.q = qs; a.probes = probes; a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.item_start = item_start;
@@ -437,6 +468,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.d = d; a.m = m; a.nprobes = (int)nprobes; a.nlist = nlist; a.keff = (int)keff;
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+  a.desc = desc;
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.flags = flags;
   const int dpad = (d + 3) & ~3;
   const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + (size_t)PM_CAP * 16 + PM_BS * 4 + 8 * 4;
