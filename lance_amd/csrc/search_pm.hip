@@ -204,6 +204,18 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   uint32_t *misc = sorted + PM_BS;   // [0]=cnt0 [1]=T0 [2]=cnt1 [3]=T1 [4]=tnew [5]=flags
   __shared__ int s_part, s_q0, s_q1, s_valid;
 
+  // Stage A (independent of the work item): request the first half of this lane's codebook entries now, so
+  // their L2 latency overlaps the descriptor / query / centroid loads below.
+  const int cb_c = threadIdx.x & 255, cb_half = threadIdx.x >> 8;
+  constexpr int MH = m / 2, MA = MH / 2;
+  f4 cbA[MA][Q];
+#pragma unroll
+  for (int i = 0; i < MA; ++i) {
+    const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)(cb_half * MH + i) * 256 + cb_c) * SD);
+#pragma unroll
+    for (int u = 0; u < Q; ++u) cbA[i][u] = src[u];
+  }
+
   if (threadIdx.x == 0) {
     const uint32_t item = blockIdx.x + (p.cls ? p.item_start[p.nlist] : 0u);
     const int valid = item < p.item_start[(p.cls + 1) * p.nlist];
@@ -212,53 +224,61 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     const int part = dsc.x, q0 = dsc.y, q1 = dsc.z;
     s_valid = valid; s_part = part; s_q0 = q0; s_q1 = q1;
     misc[0] = 0; misc[2] = 0; misc[5] = 0;
-    misc[1] = valid ? p.tglobal[q0] : 0xFFFFFFFFu;
-    misc[3] = (valid && q1 >= 0) ? p.tglobal[q1] : 0u;
   }
   __syncthreads();
   if (!s_valid) return;
   const int part = s_part, q0 = s_q0, q1 = s_q1;
   const bool has1 = q1 >= 0;
+  // Stage B: everything that depends only on the descriptor is requested together (one memory round trip):
+  // query / centroid elements, partition bounds, the queries' global bounds
+  float qa_v = 0.0f, qb_v = 0.0f, cen_v = 0.0f;
+  if ((int)threadIdx.x < p.d) {
+    qa_v = p.q[(int64_t)q0 * p.d + threadIdx.x];
+    qb_v = p.q[(int64_t)(has1 ? q1 : q0) * p.d + threadIdx.x];
+    cen_v = p.residual ? p.centroids[(int64_t)part * p.d + threadIdx.x] : 0.0f;
+  }
+  if (threadIdx.x == 0) {
+    misc[1] = p.tglobal[q0];
+    misc[3] = has1 ? p.tglobal[q1] : 0u;
+  }
   const uint32_t off = p.part_offsets[part];
   const int np = (int)(p.part_offsets[part + 1] - off);
   if (np == 0) return;
   CandBuf b0{ck0, cp0, &misc[0], &misc[1]}, b1{ck1, cp1, &misc[2], &misc[3]};
 
-  // residual queries (v2.rs:316-332)
-  {
-    const float *qa = p.q + (int64_t)q0 * p.d;
-    const float *qb = p.q + (int64_t)(has1 ? q1 : q0) * p.d;
-    for (int t = threadIdx.x; t < p.d; t += PM_BS) {
-      const float c = p.residual ? p.centroids[(int64_t)part * p.d + t] : 0.0f;
-      float a = p.residual ? qa[t] - c : qa[t];
-      float bq = p.residual ? qb[t] - c : qb[t];
-      if (p.round_f16 && p.residual) { a = __half2float(__float2half_rn(a)); bq = __half2float(__float2half_rn(bq)); }
-      r0[t] = a; r1[t] = bq;
-    }
+  // residual queries (v2.rs:316-332); d = M*SD <= 512 lanes for every supported shape
+  if ((int)threadIdx.x < p.d) {
+    float a = p.residual ? qa_v - cen_v : qa_v;
+    float bq = p.residual ? qb_v - cen_v : qb_v;
+    if (p.round_f16 && p.residual) { a = __half2float(__float2half_rn(a)); bq = __half2float(__float2half_rn(bq)); }
+    r0[threadIdx.x] = a; r1[threadIdx.x] = bq;
   }
   __syncthreads();
   // LUT pair: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half*m/2, (half+1)*m/2); each
-  // codebook entry is fetched once and used for both residuals
+  // codebook entry is fetched once and used for both residuals.  Second half of the entries is requested
+  // before the first half is consumed.
   {
-    const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
-    constexpr int MH = m / 2;
-#pragma unroll 2
-    for (int i = 0; i < MH; ++i) {
-      const int mm = half * MH + i;
-      const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
-      f4 cbv[Q];
+    f4 cbB[MH - MA][Q];
 #pragma unroll
-      for (int u = 0; u < Q; ++u) cbv[u] = src[u];
+    for (int i = MA; i < MH; ++i) {
+      const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)(cb_half * MH + i) * 256 + cb_c) * SD);
+#pragma unroll
+      for (int u = 0; u < Q; ++u) cbB[i - MA][u] = src[u];
+    }
+#pragma unroll
+    for (int i = 0; i < MH; ++i) {
+      const int mm = cb_half * MH + i;
       RegVec<SD> a0, a1;
 #pragma unroll
       for (int u = 0; u < Q; ++u) {
         a0.q[u] = *reinterpret_cast<const f4 *>(&r0[mm * SD + 4 * u]);
         a1.q[u] = *reinterpret_cast<const f4 *>(&r1[mm * SD + 4 * u]);
       }
+      const float *cbp = i < MA ? reinterpret_cast<const float *>(&cbA[i < MA ? i : 0][0]) : reinterpret_cast<const float *>(&cbB[i >= MA ? i - MA : 0][0]);
       f2 v;
-      v.x = finish_metric<METRIC>(dist_exact<SD, METRIC>(a0, reinterpret_cast<const float *>(&cbv[0])));
-      v.y = finish_metric<METRIC>(dist_exact<SD, METRIC>(a1, reinterpret_cast<const float *>(&cbv[0])));
-      lut2[mm * 256 + c] = v;
+      v.x = finish_metric<METRIC>(dist_exact<SD, METRIC>(a0, cbp));
+      v.y = finish_metric<METRIC>(dist_exact<SD, METRIC>(a1, cbp));
+      lut2[mm * 256 + cb_c] = v;
     }
   }
   __syncthreads();
