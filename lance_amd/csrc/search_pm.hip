@@ -187,7 +187,11 @@ __global__ __launch_bounds__(256) void pm_item_desc_kernel(const uint32_t *__res
 }
 
 // ---- scan -----------------------------------------------------------------------------------------------
-template <int SD, int METRIC, int MU>
+// RPL = rows per lane per round.  Class 0 (threshold starts at +inf, every row is a candidate) uses 1 so that
+// the buffer can never overflow between two capacity checks; class 1 starts from a tight bound, appends are
+// rare, so it streams 4 rows per lane between barriers (an overflow there is flagged and the query replayed
+// by the exact kernel).
+template <int SD, int METRIC, int MU, int RPL>
 __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int m = MU * 16;
@@ -286,45 +290,60 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   const uint8_t *pcodes = p.codes + (int64_t)off * m;
   // software pipeline: the code bytes of round r+1 are requested before round r's gathers, so the L2/HBM
   // latency of the (only) global load in the loop overlaps LDS work
-  uint4 cwn[MU];
-  if ((int)threadIdx.x < np) {
+  constexpr int ROUND = PM_BS * RPL;
+  uint4 cwn[RPL][MU];
 #pragma unroll
-    for (int w = 0; w < MU; ++w) cwn[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)threadIdx.x * m + w * 16);
-  }
-  for (int base = 0; base < np; base += PM_ROUND) {
-    if ((int)misc[0] > PM_CAP - PM_ROUND) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
-    if ((int)misc[2] > PM_CAP - PM_ROUND) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
-    const uint32_t T0 = misc[1], T1 = misc[3];
-    const int row = base + threadIdx.x;
-    uint4 cwc[MU];
-#pragma unroll
-    for (int w = 0; w < MU; ++w) cwc[w] = cwn[w];
-    if (row + PM_ROUND < np) {
-#pragma unroll
-      for (int w = 0; w < MU; ++w) cwn[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)(row + PM_ROUND) * m + w * 16);
-    }
+  for (int u = 0; u < RPL; ++u) {
+    const int row = u * PM_BS + threadIdx.x;
     if (row < np) {
-      float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
 #pragma unroll
-      for (int w = 0; w < MU; ++w) {
-        const uint32_t cws[4] = {cwc[w].x, cwc[w].y, cwc[w].z, cwc[w].w};
+      for (int w = 0; w < MU; ++w) cwn[u][w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * m + w * 16);
+    }
+  }
+  for (int base = 0; base < np; base += ROUND) {
+    constexpr int LIMIT = RPL == 1 ? PM_CAP - PM_BS : PM_CAP / 2;
+    if ((int)misc[0] > LIMIT) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
+    if ((int)misc[2] > LIMIT) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
+    const uint32_t T0 = misc[1], T1 = misc[3];
+    uint4 cwc[RPL][MU];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+    for (int u = 0; u < RPL; ++u)
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
-            d0 += v.x; d1 += v.y;
-          }
+      for (int w = 0; w < MU; ++w) cwc[u][w] = cwn[u][w];
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+      const int rown = base + ROUND + u * PM_BS + threadIdx.x;
+      if (rown < np) {
+#pragma unroll
+        for (int w = 0; w < MU; ++w) cwn[u][w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)rown * m + w * 16);
       }
-      if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
-      const uint32_t k0 = order_key(d0), k1 = order_key(d1);
-      if (k0 <= T0) {
-        const uint32_t slot = atomicAdd(&misc[0], 1u);
-        if (slot < PM_CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
-      }
-      if (has1 && k1 <= T1) {
-        const uint32_t slot = atomicAdd(&misc[2], 1u);
-        if (slot < PM_CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
+    }
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+      const int row = base + u * PM_BS + threadIdx.x;
+      if (row < np) {
+        float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
+#pragma unroll
+        for (int w = 0; w < MU; ++w) {
+          const uint32_t cws[4] = {cwc[u][w].x, cwc[u][w].y, cwc[u][w].z, cwc[u][w].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+              d0 += v.x; d1 += v.y;
+            }
+        }
+        if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
+        const uint32_t k0 = order_key(d0), k1 = order_key(d1);
+        if (k0 <= T0) {
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < PM_CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
+        }
+        if (has1 && k1 <= T1) {
+          const uint32_t slot = atomicAdd(&misc[2], 1u);
+          if (slot < PM_CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
+        }
       }
     }
     __syncthreads();
@@ -435,11 +454,15 @@ __global__ __launch_bounds__(256) void ivfpq_merge_pm_kernel(const uint32_t *__r
 // ---- host ---------------------------------------------------------------------------------------------
 template <int SD, int METRIC>
 static bool launch_pm_mu(lance_hip_ctx *ctx, const PmArgs &a, unsigned grid, size_t lds) {
-  switch (a.m / 16) {
-    case 1: hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true;
-    case 2: hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true;
-    default: return false;
+  const int mu = a.m / 16;
+  if (a.cls == 0) {
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+  } else {
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 4>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 2>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   }
+  return false;
 }
 
 bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range) {
