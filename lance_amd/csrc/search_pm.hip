@@ -35,6 +35,13 @@ constexpr int PM_BS = 512;       // lanes per workgroup
 constexpr int PM_CAP = 768;      // candidate buffer entries per query
 constexpr int PM_ROUND = 512;    // rows per round (one per lane)
 constexpr int PM_POOL = 2048;    // pool entries per query
+#ifndef LH_PM_EARLY
+#define LH_PM_EARLY 1
+#endif
+#ifndef LH_PM_RPL1
+#define LH_PM_RPL1 2
+#endif
+constexpr int PM_RPL1 = LH_PM_RPL1;  // rows per lane per round for the pruned class (4 measured slower: > 80 VGPRs drop a workgroup)
 
 struct PmArgs {
   const float *q;               // [nq][d]
@@ -323,17 +330,30 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
       const int row = base + u * PM_BS + threadIdx.x;
       if (row < np) {
         float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
+        bool dead = false;
 #pragma unroll
         for (int w = 0; w < MU; ++w) {
           const uint32_t cws[4] = {cwc[u][w].x, cwc[u][w].y, cwc[u][w].z, cwc[u][w].w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (METRIC == METRIC_L2 && LH_PM_EARLY) {
+              // L2 table entries are >= 0, so the running sum is a lower bound of the row's distance (f32 addition of
+              // non-negative terms is monotone): once every lane of the wave is already above both thresholds the
+              // rest of the row cannot matter.  Checked after 8 sub-quantisers.
+              if (w * 4 + e == 2) {
+                const bool lane_dead = order_key(d0) > T0 && (!has1 || order_key(d1) > T1);
+                if (__all(lane_dead)) { dead = true; }
+              }
+              if (dead) continue;
+            }
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
               const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
               d0 += v.x; d1 += v.y;
             }
+          }
         }
+        if (dead) continue;
         if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
         const uint32_t k0 = order_key(d0), k1 = order_key(d1);
         if (k0 <= T0) {
@@ -459,8 +479,8 @@ static bool launch_pm_mu(lance_hip_ctx *ctx, const PmArgs &a, unsigned grid, siz
     if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
     if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   } else {
-    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 4>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
-    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 2>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, PM_RPL1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   }
   return false;
 }
