@@ -31,12 +31,15 @@
 
 namespace lh {
 
-constexpr int PM_BS = 512;       // lanes per workgroup
-constexpr int PM_CAP = 768;      // candidate buffer entries per query
+#ifndef LH_PM_BS
+#define LH_PM_BS 512
+#endif
+constexpr int PM_BS = LH_PM_BS;            // lanes per workgroup (512: 3 workgroups x 8 waves per CU)
+constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query (one class-0 round + slack)
 constexpr int PM_ROUND = 512;    // rows per round (one per lane)
 constexpr int PM_POOL = 2048;    // pool entries per query
 #ifndef LH_PM_EARLY
-#define LH_PM_EARLY 1
+#define LH_PM_EARLY 0   /* wave-level early abandon measured 2-3 % slower: a wave is rarely all-dead */
 #endif
 #ifndef LH_PM_RPL1
 #define LH_PM_RPL1 2
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
 
   // Stage A (independent of the work item): request the first half of this lane's codebook entries now, so
   // their L2 latency overlaps the descriptor / query / centroid loads below.
-  const int cb_c = threadIdx.x & 255, cb_half = threadIdx.x >> 8;
-  constexpr int MH = m / 2, MA = MH / 2;
+  const int cb_c = threadIdx.x & 255, cb_half = threadIdx.x >> 8;   // cb_half = which 256-lane part of the workgroup
+  constexpr int MH = m / (PM_BS / 256), MA = MH / 2;
   f4 cbA[MA][Q];
 #pragma unroll
   for (int i = 0; i < MA; ++i) {
