@@ -127,6 +127,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     eng.timing(False)
+    exact_replays = eng.search_stats()
     kt = {kname: eng.timing_query(kname) for kname in ("dist_matrix", "select_probes", "ivfpq_scan", "ivfpq_merge", "ivfpq_exact", "refine")}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -170,6 +171,7 @@ def main():
                    "nprobes": args.nprobes, "refine_factor": args.refine,
                    "parallelism": f"replica x{world}" if world > 1 else "single"},
         "recall_at_10": recall,
+        "exact_replays_last_step": exact_replays,
         "build_sec": build_sec,
         "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
         "kernel_ms_per_step": {k_: round(v[0] / max(v[1], 1), 4) for k_, v in kt.items()},

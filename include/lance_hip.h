@@ -195,6 +195,10 @@ int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx,
                                  uint32_t k, uint32_t nprobes, uint32_t refine_factor, uint64_t *ids,
                                  float *dists);
 
+/* Number of queries of the most recent search on this context that had to be replayed by the exact
+ * (heap-emulating) kernel -- ties at a partition's k-th distance, or candidate-buffer overflow.      */
+int lance_hip_search_stats(lance_hip_ctx *ctx, uint32_t *n_exact_replays_host);
+
 /* ---- a20+a21: flat KNN (flat.rs:95-148, l2.rs:245-266, scanner.rs:3386-3411) ------- */
 /* Exhaustive scan of x[n][d] for nq queries; result sorted by (dist, row id).
  * row_ids NULL -> row index.                                                          */

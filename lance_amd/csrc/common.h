@@ -57,6 +57,7 @@ struct lance_hip_ctx {
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
   bool timing = false;
+  const uint32_t *last_replay_counter = nullptr;  // device word written by the exact kernel of the last search
   std::map<std::string, lh::KernelTimer> timers;
 
   // returns nullptr on failure (error set)

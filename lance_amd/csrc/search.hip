@@ -906,6 +906,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   if (!flags) return LANCE_HIP_ENOMEM;
   LH_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)nq + 1) * 4, ctx->stream));
   uint32_t *n_fallback = flags + nq;
+  ctx->last_replay_counter = n_fallback;
   if (flags_out) *flags_out = flags;
   if (nq == 0) return LANCE_HIP_OK;
 
@@ -1106,6 +1107,15 @@ int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
   LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags));
   return check_flags(ctx, flags, nq);
+}
+
+int lance_hip_search_stats(lance_hip_ctx *ctx, uint32_t *n_exact_replays_host) {
+  LH_REQUIRE(ctx && n_exact_replays_host, "search_stats: NULL argument");
+  *n_exact_replays_host = 0;
+  if (!ctx->last_replay_counter) return LANCE_HIP_OK;
+  LH_CHECK_HIP(hipMemcpyAsync(n_exact_replays_host, ctx->last_replay_counter, 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
 }
 
 int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *q_residual, uint32_t d,

@@ -37,7 +37,6 @@ namespace lh {
 constexpr int PM_BS = LH_PM_BS;            // lanes per workgroup (512: 3 workgroups x 8 waves per CU)
 constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query (one class-0 round + slack)
 constexpr int PM_ROUND = 512;    // rows per round (one per lane)
-constexpr int PM_POOL = 2048;    // pool entries per query
 #ifndef LH_PM_EARLY
 #define LH_PM_EARLY 0   /* wave-level early abandon measured 2-3 % slower: a wave is rarely all-dead */
 #endif
@@ -60,7 +59,8 @@ struct PmArgs {
   int d, m, nprobes, nlist, keff;
   int residual, round_f16;
   uint32_t *tglobal;            // [nq] running upper bound of the keff-th distance (key)
-  uint32_t *pool_key, *pool_pos, *pool_cnt;  // [nq][PM_POOL], [nq]
+  uint32_t *pool_key, *pool_pos, *pool_cnt;  // [nq][pool_cap], [nq]
+  int pool_cap;                 // pool entries per query
   uint32_t *flags;
 };
 
@@ -310,10 +310,38 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
       for (int w = 0; w < MU; ++w) cwn[u][w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * m + w * 16);
     }
   }
+  constexpr uint32_t ROUND_OVF = 0x100u;   // round-local overflow marker in misc[5]
+  auto scan_rows = [&](int base, int u, const uint4 (&cw)[MU], uint32_t T0, uint32_t T1) {
+    const int row = base + u * PM_BS + threadIdx.x;
+    if (row >= np) return;
+    float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
+#pragma unroll
+    for (int w = 0; w < MU; ++w) {
+      const uint32_t cws[4] = {cw[w].x, cw[w].y, cw[w].z, cw[w].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+          d0 += v.x; d1 += v.y;
+        }
+    }
+    if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
+    const uint32_t k0 = order_key(d0), k1 = order_key(d1);
+    if (k0 <= T0) {
+      const uint32_t slot = atomicAdd(&misc[0], 1u);
+      if (slot < PM_CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+    }
+    if (has1 && k1 <= T1) {
+      const uint32_t slot = atomicAdd(&misc[2], 1u);
+      if (slot < PM_CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+    }
+  };
   for (int base = 0; base < np; base += ROUND) {
     constexpr int LIMIT = RPL == 1 ? PM_CAP - PM_BS : PM_CAP / 2;
     if ((int)misc[0] > LIMIT) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
     if ((int)misc[2] > LIMIT) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
+    const uint32_t cnt0_before = misc[0], cnt1_before = misc[2];
     const uint32_t T0 = misc[1], T1 = misc[3];
     uint4 cwc[RPL][MU];
 #pragma unroll
@@ -329,47 +357,36 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < RPL; ++u) {
-      const int row = base + u * PM_BS + threadIdx.x;
-      if (row < np) {
-        float d0 = 0.0f, d1 = 0.0f;  // pq/distance.rs:128-141: += table[code] for m = 0..M-1, per query
-        bool dead = false;
+    for (int u = 0; u < RPL; ++u) scan_rows(base, u, cwc[u], T0, T1);
+    __syncthreads();
+    if constexpr (RPL > 1) {
+      // optimistic round overflowed a buffer (more than PM_CAP/2 rows under the bound in 2 sub-rounds): roll the
+      // round back and replay it one sub-round at a time with a capacity check before each (cannot overflow
+      // unless more than 256 rows tie at the bound, which is flagged for the exact kernel)
+      if (misc[5] & ROUND_OVF) {
+        __syncthreads();
+        if (threadIdx.x == 0) { misc[0] = cnt0_before; misc[2] = cnt1_before; misc[5] &= ~ROUND_OVF; }
+        __syncthreads();
 #pragma unroll
-        for (int w = 0; w < MU; ++w) {
-          const uint32_t cws[4] = {cwc[u][w].x, cwc[u][w].y, cwc[u][w].z, cwc[u][w].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if constexpr (METRIC == METRIC_L2 && LH_PM_EARLY) {
-              // L2 table entries are >= 0, so the running sum is a lower bound of the row's distance (f32 addition of
-              // non-negative terms is monotone): once every lane of the wave is already above both thresholds the
-              // rest of the row cannot matter.  Checked after 8 sub-quantisers.
-              if (w * 4 + e == 2) {
-                const bool lane_dead = order_key(d0) > T0 && (!has1 || order_key(d1) > T1);
-                if (__all(lane_dead)) { dead = true; }
-              }
-              if (dead) continue;
-            }
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-              const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
-              d0 += v.x; d1 += v.y;
-            }
-          }
+        for (int u = 0; u < RPL; ++u) {
+          if ((int)misc[0] > PM_CAP - PM_BS) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
+          if ((int)misc[2] > PM_CAP - PM_BS) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
+          scan_rows(base, u, cwc[u], misc[1], misc[3]);
+          __syncthreads();
         }
-        if (dead) continue;
-        if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
-        const uint32_t k0 = order_key(d0), k1 = order_key(d1);
-        if (k0 <= T0) {
-          const uint32_t slot = atomicAdd(&misc[0], 1u);
-          if (slot < PM_CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
-        }
-        if (has1 && k1 <= T1) {
-          const uint32_t slot = atomicAdd(&misc[2], 1u);
-          if (slot < PM_CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = FLAG_OVERFLOW;
+        if (misc[5] & ROUND_OVF) {
+          __syncthreads();
+          if (threadIdx.x == 0) misc[5] = (misc[5] & ~ROUND_OVF) | FLAG_OVERFLOW;
+          __syncthreads();
         }
       }
+    } else {
+      if (misc[5] & ROUND_OVF) {
+        __syncthreads();
+        if (threadIdx.x == 0) misc[5] = (misc[5] & ~ROUND_OVF) | FLAG_OVERFLOW;
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
   // publish: shrink each buffer once, lower the query's global bound, append the survivors to its pool
   for (int j = 0; j < 2; ++j) {
@@ -377,7 +394,9 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     const CandBuf &b = j ? b1 : b0;
     const int qj = j ? q1 : q0;
     if (*b.cnt == 0) continue;  // uniform: nothing of this partition can reach the query's top list
-    if ((int)*b.cnt > 256) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
+    // <= PM_BS entries -> one entry per lane -> the bound is the exact keff-th smallest: publish ~keff rows
+    if ((int)*b.cnt > p.keff + 32) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
+    if ((int)*b.cnt > PM_BS) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
     __syncthreads();
     const int c = min((int)*b.cnt, PM_CAP);
     __shared__ uint32_t s_base, s_tg;
@@ -402,7 +421,7 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     const uint32_t basep = s_base, tot = misc[4];
     __syncthreads();
     if (tot) {
-      if (basep + tot > (uint32_t)PM_POOL) {
+      if (basep + tot > (uint32_t)p.pool_cap) {
         if (threadIdx.x == 0) atomicOr(&p.flags[qj], FLAG_OVERFLOW);
       } else {
         if (threadIdx.x == 0) misc[4] = 0;
@@ -410,17 +429,17 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
         for (int i = threadIdx.x; i < c; i += PM_BS) {
           if (b.key[i] <= tg) {
             const uint32_t slot = basep + atomicAdd(&misc[4], 1u);
-            p.pool_key[(int64_t)qj * PM_POOL + slot] = b.key[i];
-            p.pool_pos[(int64_t)qj * PM_POOL + slot] = b.pos[i];
+            p.pool_key[(int64_t)qj * p.pool_cap + slot] = b.key[i];
+            p.pool_pos[(int64_t)qj * p.pool_cap + slot] = b.pos[i];
           }
         }
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && misc[5]) {
-    atomicOr(&p.flags[q0], misc[5]);
-    if (has1) atomicOr(&p.flags[q1], misc[5]);
+  if (threadIdx.x == 0 && (misc[5] & FLAG_OVERFLOW)) {
+    atomicOr(&p.flags[q0], FLAG_OVERFLOW);
+    if (has1) atomicOr(&p.flags[q1], FLAG_OVERFLOW);
   }
 }
 
@@ -428,18 +447,18 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
 constexpr int PMM_CAP = 1024;
 __global__ __launch_bounds__(256) void ivfpq_merge_pm_kernel(const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_pos,
                                                              const uint32_t *__restrict__ pool_cnt, const uint32_t *__restrict__ tglobal,
-                                                             const uint64_t *__restrict__ row_ids, SelectOut o) {
+                                                             const uint64_t *__restrict__ row_ids, int pool_cap, SelectOut o) {
   __shared__ uint32_t ckey[PMM_CAP], cpos[PMM_CAP], sorted[256], misc[8];
   __shared__ uint64_t rid[SCAN_LCAP];
   __shared__ uint32_t skey[SCAN_LCAP], spos[SCAN_LCAP];
   __shared__ int s_amb;
   const int q = blockIdx.x;
   if (o.flags[q] & FLAG_OVERFLOW) return;  // pool incomplete: the exact kernel recomputes this query
-  const int n = min((int)pool_cnt[q], PM_POOL);
+  const int n = min((int)pool_cnt[q], pool_cap);
   if (threadIdx.x == 0) { misc[0] = 0; misc[1] = tglobal[q]; s_amb = 0; }
   __syncthreads();
   CandBuf b{ckey, cpos, &misc[0], &misc[1]};
-  const uint32_t *pk = pool_key + (int64_t)q * PM_POOL, *pp = pool_pos + (int64_t)q * PM_POOL;
+  const uint32_t *pk = pool_key + (int64_t)q * pool_cap, *pp = pool_pos + (int64_t)q * pool_cap;
   for (int base = 0; base < n; base += 512) {
     if ((int)misc[0] > PMM_CAP - 512) tighten_bs<256, PMM_CAP>(b, o.keff, sorted, &misc[2]);
     const uint32_t T = misc[1];
@@ -509,8 +528,11 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);
   uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)2 * nlist + 1);
   uint32_t *tglobal = ctx->scratch_t<uint32_t>("pm.tglobal", (size_t)nq * 2);
-  uint32_t *pool_key = ctx->scratch_t<uint32_t>("pm.pool_key", (size_t)nq * PM_POOL);
-  uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * PM_POOL);
+  // every (query, partition) publishes at most ~keff (+ ties) rows, usually far fewer once Tglobal is tight
+  int pool_cap = (int)std::min<uint64_t>(8192, std::max<uint64_t>(512, (uint64_t)nprobes * (keff + 28)));
+  pool_cap = (pool_cap + 255) & ~255;
+  uint32_t *pool_key = ctx->scratch_t<uint32_t>("pm.pool_key", (size_t)nq * pool_cap);
+  uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * pool_cap);
   if (!pair_starts || !pair_idx || !item_start || !tglobal || !pool_key || !pool_pos) return LANCE_HIP_ENOMEM;
   uint32_t *pool_cnt = tglobal + nq;
   LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
@@ -535,7 +557,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.desc = desc;
-  a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.flags = flags;
+  a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const int dpad = (d + 3) & ~3;
   const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + (size_t)PM_CAP * 16 + PM_BS * 4 + 8 * 4;
   {
@@ -565,7 +587,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
     o.out_ids = ids; o.out_dists = dists; o.cand_rid = cand_rid; o.cand_cnt = cand_cnt; o.flags = flags;
     o.part_offsets = ix->part_offsets; o.nlist = nlist;
     ScopedTimer t(ctx, "ivfpq_merge");
-    hipLaunchKernelGGL(ivfpq_merge_pm_kernel, dim3(nq), dim3(256), 0, ctx->stream, pool_key, pool_pos, pool_cnt, tglobal, ix->row_ids, o);
+    hipLaunchKernelGGL(ivfpq_merge_pm_kernel, dim3(nq), dim3(256), 0, ctx->stream, pool_key, pool_pos, pool_cnt, tglobal, ix->row_ids, pool_cap, o);
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;

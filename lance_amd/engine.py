@@ -229,6 +229,12 @@ class Engine:
                                            _ptr(ids), _ptr(dists)))
         return ids, dists
 
+    def search_stats(self):
+        """queries of the last search replayed by the exact (heap-emulating) kernel"""
+        n = C.c_uint32(0)
+        check(self.lib.lance_hip_search_stats(self.h, C.byref(n)))
+        return n.value
+
     # ---- timing hooks --------------------------------------------------------------
     def timing(self, on=True):
         check(self.lib.lance_hip_timing_enable(self.h, int(on)))
