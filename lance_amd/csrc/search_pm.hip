@@ -561,9 +561,9 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   const int dpad = (d + 3) & ~3;
   const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + (size_t)PM_CAP * 16 + PM_BS * 4 + 8 * 4;
   {
-    ScopedTimer t(ctx, "ivfpq_scan");
     for (int cls = 0; cls < 2; ++cls) {
       if (cls == 1 && nprobes == 1) break;
+      ScopedTimer t(ctx, cls == 0 ? "ivfpq_scan_c0" : "ivfpq_scan_c1");
       a.cls = cls;
       // upper bound of sum ceil(c_vp / 2) over the class; surplus workgroups exit at once
       const size_t cpairs = cls == 0 ? (size_t)nq : (size_t)nq * (nprobes - 1);
