@@ -14,7 +14,9 @@
  *
  * Parity pins: tests/test_oracle_golden.py transcribes the reference's own
  * known-answer tests (l2.rs:281-375,432-447; dot.rs; kernels.rs:278-300;
- * kmeans.rs:1398-1486; pq.rs:580-665; pq/distance.rs:337-364; pq/utils.rs:84-99).
+ * kmeans.rs:1398-1486; pq.rs:580-665; pq/distance.rs:337-364; pq/utils.rs:84-99;
+ * simd/dist_table.rs:178-217) and checks orc_sum_4bit_dist_table against the reference's own C kernel
+ * (rust/lance-linalg/src/simd/dist_table.c compiled from where it lies into oracle/_ref/ by oracle/Makefile).
  *
  * Not pinned by any reference test (reference is OS-seeded, kmeans.rs:181,646):
  * the RNG stream used for k-means initialisation and empty-cluster splitting.
