@@ -1,0 +1,135 @@
+"""SURVEY 8(d) measurement grid on one MI355X (not the contract bench -- bench.py is).
+
+Writes one JSON document with: measured device-copy bandwidth (the "peak_measured" denominator), the C1 flat
+scan, the C2 recall/QPS grid nprobes x refine, the bit-exact id check at nprobes = nlist against the CPU oracle,
+and (with --c3) the C3-shaped cosine build + search.  Usage: python scripts/measure_grid.py [--c3] > out.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import lance_amd
+from lance_amd.testing import sift_like
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def recall_of(ids, gt):
+    return (ids.unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().mean().item()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c3", action="store_true")
+    ap.add_argument("--c3-n", type=int, default=1_000_000)
+    ap.add_argument("--skip-c2", action="store_true")
+    args = ap.parse_args()
+    eng = lance_amd.default_engine()
+    dev = torch.device("cuda", 0)
+    out = {"device": torch.cuda.get_device_name(0)}
+
+    # ---- peak_measured: device-to-device copy of 4 GiB (read + write counted) ------------------------
+    a = torch.empty(1 << 30, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    dt = timed(lambda: b.copy_(a), reps=5)
+    out["peak_measured"] = {"copy_GBps": 2 * a.numel() * 4 / dt / 1e9, "bytes": a.numel() * 4}
+    del a, b
+
+    if not args.skip_c2:
+        d, nlist, m = 128, 256, 16
+        x = sift_like(1_000_000, d, seed=1234, device=dev)
+        q = sift_like(10_000, d, seed=4321, device=dev)
+
+        # ---- C1: flat scan ------------------------------------------------------------------------
+        flat = {}
+        for nq in (1, 100, 1000, 10_000):
+            qs = q[:nq]
+            dt = timed(lambda: eng.flat_topk(x, qs, 10), reps=2 if nq >= 1000 else 5)
+            flat[str(nq)] = {"ms": dt * 1e3, "qps": nq / dt, "algorithmic_GBps_per_batch": x.numel() * 4 / dt / 1e9,
+                             "algorithmic_TFLOPs": 3 * x.shape[0] * d * nq / dt / 1e12}
+        out["c1_flat"] = {"n": 1_000_000, "d": d, "k": 10, "by_batch_size": flat,
+                          "note": "bytes = N*d*4 once per batch (SURVEY 8d); flops counted as 3 per element (sub, mul, add: no FMA by contract)"}
+        gt, _ = eng.flat_topk(x, q[:1000], 10)
+
+        # ---- C2: build + recall/QPS grid ---------------------------------------------------------------
+        idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=nlist, num_sub_vectors=m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=nlist, num_sub_vectors=m)
+        torch.cuda.synchronize()
+        out["c2_build"] = {"sec": time.perf_counter() - t0, "stages_ms": {k: round(v * 1e3, 3) for k, v in idx.stats.seconds.items()},
+                           "ivf_iters": idx.stats.ivf_iters, "pq_iters": idx.stats.pq_iters}
+        grid = []
+        for nprobes in (1, 10, 25, 50, nlist):
+            for rf in (0, 10):
+                nq = 10_000 if nprobes <= 50 else 2_000
+                qq = q[:nq]
+                dt = timed(lambda: idx.search_device(qq, 10, nprobes, rf), reps=3)
+                ids, _ = idx.search_device(q[:1000], 10, nprobes, rf)
+                grid.append({"nprobes": nprobes, "refine_factor": rf, "recall_at_10": recall_of(ids, gt), "nq": nq,
+                             "ms_per_batch": dt * 1e3, "qps": nq / dt, "exact_replays": eng.search_stats()})
+        out["c2_grid"] = grid
+
+        # ---- bit-exact id check at nprobes = nlist against the oracle (same centroids/codebook/codes) ----
+        import oracle as orc
+        offs, codes_t, rid = idx.export_storage()
+        oidx = orc.IvfPqIndex("l2", idx.centroids, idx.codebook, offs, codes_t, rid)
+        nchk = 64
+        xq = q[:nchk].cpu().numpy()
+        raw = x.cpu().numpy()
+        chk = {}
+        for rf in (0, 10):
+            oi, od = oidx.search(xq, 10, nlist, refine=rf, raw=raw if rf else None)
+            gi, gd = idx.search_device(q[:nchk], 10, nlist, rf)
+            chk[f"refine{rf}"] = {"ids_equal": bool((oi == gi.cpu().numpy().view(np.uint64)).all()),
+                                  "dists_bit_equal": bool((od.view(np.uint32) == gd.cpu().numpy().view(np.uint32)).all())}
+        out["c2_exhaustive_vs_oracle"] = {"queries": nchk, "nprobes": nlist, **chk}
+        del x, q, idx, raw
+
+    if args.c3:
+        d, nlist, m = 1536, 1024, 96
+        n = args.c3_n
+        x = sift_like(n, d, seed=77, device=dev, n_clusters=1024, latent=48, model_seed=77)
+        x = x - 64.0                                   # centre: embeddings are not all-positive
+        q = (sift_like(1000, d, seed=78, device=dev, n_clusters=1024, latent=48, model_seed=77) - 64.0).contiguous()
+        x = torch.nn.functional.normalize(x, dim=1).contiguous()
+        q = torch.nn.functional.normalize(q, dim=1).contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx = lance_amd.create_index(x, "IVF_PQ", metric="cosine", num_partitions=nlist, num_sub_vectors=m)
+        torch.cuda.synchronize()
+        c3 = {"n": n, "d": d, "nlist": nlist, "m": m, "build_sec_cold": time.perf_counter() - t0,
+              "stages_ms": {k: round(v * 1e3, 3) for k, v in idx.stats.seconds.items()},
+              "ivf_iters": idx.stats.ivf_iters, "pq_iters": idx.stats.pq_iters}
+        dt = timed(lambda: eng.flat_topk(x, q, 10, metric="cosine"), reps=1)
+        c3["flat_1000q_ms"] = dt * 1e3
+        gt, _ = eng.flat_topk(x, q, 10, metric="cosine")
+        grid = []
+        for nprobes, rf in ((1, 0), (10, 0), (10, 10), (25, 10), (50, 10)):
+            dt = timed(lambda: idx.search_device(q, 10, nprobes, rf), reps=2)
+            ids, _ = idx.search_device(q, 10, nprobes, rf)
+            grid.append({"nprobes": nprobes, "refine_factor": rf, "recall_at_10": recall_of(ids, gt), "nq": 1000,
+                         "ms_per_batch": dt * 1e3, "qps": 1000 / dt, "exact_replays": eng.search_stats()})
+        c3["grid"] = grid
+        out["c3"] = c3
+    print(json.dumps(out, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else str(o)))
+
+
+if __name__ == "__main__":
+    main()
