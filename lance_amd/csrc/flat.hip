@@ -12,6 +12,7 @@
 // the final (dist, rowid) order -- a total order, so the result equals the reference's
 // SortExec exactly, ties included.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "exact.cuh"
@@ -171,6 +172,234 @@ __global__ __launch_bounds__(256) void flat_merge_kernel(const uint32_t *__restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// v2 (fixed D, k <= 128, L2 / dot): lanes own DATABASE ROWS (row vector in VGPRs, the pairwise.hip shape,
+// which streams rows at ~4 TB/s and runs the distance loop at ~70% of the non-FMA VALU rate), queries are
+// staged in LDS tiles together with a per-query threshold pair T = (key, rowid).  A row whose (key, rowid)
+// is <= T is appended to that query's candidate pool (wave-aggregated atomic).  The rows are visited in a
+// few EPOCHS of geometrically growing size; after each epoch a per-query select kernel sorts the pool by
+// (key, rowid), keeps the best k and tightens T to the k-th pair.  T is always the k-th smallest pair of a
+// SUBSET of the rows, hence never below the true k-th pair: no row of the exact answer is ever filtered,
+// and the final (key, rowid) sort reproduces SortExec's total order, ties included.  A pool overflow
+// (possible only for adversarial row orders) is detected and repaired by re-running the scan with the
+// tightened T, which strictly decreases each round.
+struct FlatPool {
+  const float *x;
+  const uint64_t *row_ids;
+  int64_t r0, r1;       // rows of this epoch
+  const float *q;       // queries of this chunk
+  int nq, k, cap;
+  uint32_t *tkey;       // [nq]
+  uint64_t *trid;       // [nq]
+  uint32_t *cnt;        // [nq]
+  uint32_t *pkeys;      // [nq][cap]
+  uint64_t *prids;      // [nq][cap]
+  uint32_t *overflow;   // [1]
+};
+
+template <int D, int METRIC, int QT, int BS>
+__global__ __launch_bounds__(BS) void flat_filter_kernel(FlatPool p) {
+  __shared__ __attribute__((aligned(16))) float tile[QT * D];
+  __shared__ uint32_t tk[QT];
+  __shared__ uint64_t tr[QT];
+  const int64_t row = p.r0 + (int64_t)blockIdx.x * BS + threadIdx.x;
+  const bool valid = row < p.r1;
+  RegVec<D> a;
+#pragma unroll
+  for (int i = 0; i < RegVec<D>::Q; ++i) a.q[i] = f4{0.f, 0.f, 0.f, 0.f};
+  uint64_t rid = ~0ull;
+  if (valid) {
+    const float *src = p.x + row * D;
+    if constexpr (D % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < D / 4; ++i) a.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) a.q[i >> 2][i & 3] = src[i];
+    }
+    rid = p.row_ids ? p.row_ids[row] : (uint64_t)row;
+  }
+  const int lane = threadIdx.x & 63;
+  constexpr bool NEG = METRIC != METRIC_DOT;
+  for (int q0 = blockIdx.z * QT; q0 < p.nq; q0 += QT * gridDim.z) {
+    const int qt = min(QT, p.nq - q0);
+    __syncthreads();
+    for (int i = threadIdx.x * 4; i < qt * D; i += BS * 4) {
+      const f4 v = *reinterpret_cast<const f4 *>(&p.q[(int64_t)q0 * D + i]);
+      *reinterpret_cast<f4 *>(&tile[i]) = NEG ? -v : v;
+    }
+    for (int i = threadIdx.x; i < qt; i += BS) { tk[i] = p.tkey[q0 + i]; tr[i] = p.trid[q0 + i]; }
+    __syncthreads();
+    for (int c = 0; c < qt; ++c) {
+      const float v = finish_metric<METRIC>(dist_exact<D, METRIC, NEG>(a, &tile[c * D]));
+      const uint32_t key = order_key(v);
+      const uint32_t t = tk[c];
+      bool pass = valid && key <= t;
+      if (pass && key == t) pass = rid <= tr[c];
+      const uint64_t m = __ballot(pass);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&p.cnt[q0 + c], (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (pass) {
+          const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < (uint32_t)p.cap) {
+            p.pkeys[(int64_t)(q0 + c) * p.cap + pos] = key;
+            p.prids[(int64_t)(q0 + c) * p.cap + pos] = rid;
+          }
+        }
+      }
+    }
+  }
+}
+
+// per-query: sort the pool by (key, rowid), keep the best k, tighten T; on the last epoch emit the answer
+__global__ __launch_bounds__(256) void flat_select_kernel(FlatPool p, int last, uint64_t *__restrict__ out_ids,
+                                                          float *__restrict__ out_dists) {
+  extern __shared__ __attribute__((aligned(16))) char ssm[];
+  const int q = blockIdx.x;
+  const uint32_t total = p.cnt[q];
+  const int c = (int)min(total, (uint32_t)p.cap);
+  if (total > (uint32_t)p.cap && threadIdx.x == 0) atomicOr(p.overflow, 1u);
+  int P = 64;
+  while (P < c) P <<= 1;
+  uint64_t *rid = reinterpret_cast<uint64_t *>(ssm);
+  uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
+  uint32_t *pk = p.pkeys + (int64_t)q * p.cap;
+  uint64_t *pr = p.prids + (int64_t)q * p.cap;
+  for (int i = threadIdx.x; i < P; i += 256) {
+    key[i] = i < c ? pk[i] : 0xFFFFFFFFu;
+    rid[i] = i < c ? pr[i] : ~0ull;
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P / 2; i += 256) {
+        const int ix = 2 * j * (i / j) + (i % j);
+        const int px = ix + j;
+        const bool up = (ix & k2) == 0;
+        const uint32_t kx = key[ix], ky = key[px];
+        const uint64_t rx = rid[ix], ry = rid[px];
+        const bool gt = kx > ky || (kx == ky && rx > ry);
+        if (gt == up) { key[ix] = ky; key[px] = kx; rid[ix] = ry; rid[px] = rx; }
+      }
+      __syncthreads();
+    }
+  }
+  const int keep = min(c, p.k);
+  for (int i = threadIdx.x; i < keep; i += 256) { pk[i] = key[i]; pr[i] = rid[i]; }
+  if (threadIdx.x == 0) {
+    p.cnt[q] = (uint32_t)keep;
+    if (c >= p.k) { p.tkey[q] = key[p.k - 1]; p.trid[q] = rid[p.k - 1]; }
+  }
+  if (last) {
+    for (int i = threadIdx.x; i < p.k; i += 256) {
+      const bool ok = i < keep;
+      out_ids[(int64_t)q * p.k + i] = ok ? rid[i] : ~0ull;
+      out_dists[(int64_t)q * p.k + i] = ok ? key_to_float(key[i]) : INFINITY;
+    }
+  }
+}
+
+__global__ void flat_pool_reset_kernel(FlatPool p, int reset_t) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < p.nq) {
+    p.cnt[i] = 0;
+    if (reset_t) { p.tkey[i] = 0xFFFFFFFFu; p.trid[i] = ~0ull; }
+  }
+  if (i == 0) *p.overflow = 0;
+}
+
+template <int D>
+static void launch_flat_filter(lance_hip_ctx *ctx, const FlatPool &a, int metric) {
+  constexpr int QT = D <= 32 ? 256 : 64;
+  constexpr int BS = 256;
+  const int64_t rows = a.r1 - a.r0;
+  const int rblocks = (int)cdiv((uint64_t)rows, BS);
+  const int qtiles = (int)cdiv((uint64_t)a.nq, QT);
+  int z = (int)cdiv(4ull * ctx->num_cus, (uint64_t)rblocks);
+  z = std::max(1, std::min(z, qtiles));
+  const dim3 grid(rblocks, 1, z);
+  if (metric == METRIC_DOT)
+    hipLaunchKernelGGL((flat_filter_kernel<D, METRIC_DOT, QT, BS>), grid, dim3(BS), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL((flat_filter_kernel<D, METRIC_L2, QT, BS>), grid, dim3(BS), 0, ctx->stream, a);
+}
+
+constexpr int FLAT_CAP = 4096;      // pool entries per query
+constexpr int FLAT_QCHUNK = 2048;   // queries per pass over the rows (pool = 2048 x 4096 x 12 B = 100 MB)
+
+static bool flat_v2_supported(int metric, uint32_t d, uint32_t k) {
+  if (metric == LANCE_HIP_COSINE || k > 128) return false;
+  return d == 8 || d == 16 || d == 32 || d == 64 || d == 96 || d == 128;
+}
+
+static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const uint64_t *row_ids, int64_t n, int d, const float *q,
+                        int nq, int k, uint64_t *ids, float *dists) {
+  const int qch = std::min(nq, FLAT_QCHUNK);
+  FlatPool a;
+  a.x = x; a.row_ids = row_ids; a.k = k; a.cap = FLAT_CAP;
+  a.tkey = ctx->scratch_t<uint32_t>("flat2.tkey", qch);
+  a.trid = ctx->scratch_t<uint64_t>("flat2.trid", qch);
+  a.cnt = ctx->scratch_t<uint32_t>("flat2.cnt", qch);
+  a.pkeys = ctx->scratch_t<uint32_t>("flat2.pkeys", (size_t)qch * FLAT_CAP);
+  a.prids = ctx->scratch_t<uint64_t>("flat2.prids", (size_t)qch * FLAT_CAP);
+  a.overflow = ctx->scratch_t<uint32_t>("flat2.ovf", 1);
+  if (!a.tkey || !a.trid || !a.cnt || !a.pkeys || !a.prids || !a.overflow) return LANCE_HIP_ENOMEM;
+  const int64_t growth = std::max<int64_t>(2, FLAT_CAP / (16 * (int64_t)k));
+  auto filter = [&](const FlatPool &e) {
+    switch (d) {
+      case 8: launch_flat_filter<8>(ctx, e, metric); break;
+      case 16: launch_flat_filter<16>(ctx, e, metric); break;
+      case 32: launch_flat_filter<32>(ctx, e, metric); break;
+      case 64: launch_flat_filter<64>(ctx, e, metric); break;
+      case 96: launch_flat_filter<96>(ctx, e, metric); break;
+      default: launch_flat_filter<128>(ctx, e, metric); break;
+    }
+  };
+  const size_t sel_lds = (size_t)FLAT_CAP * 12;
+  for (int qc0 = 0; qc0 < nq; qc0 += qch) {
+    a.q = q + (int64_t)qc0 * d;
+    a.nq = std::min(qch, nq - qc0);
+    uint64_t *oid = ids + (int64_t)qc0 * k;
+    float *od = dists + (int64_t)qc0 * k;
+    hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(a.nq, 256)), dim3(256), 0, ctx->stream, a, 1);
+    int64_t seen = 0;
+    if (n == 0) {
+      a.r0 = a.r1 = 0;
+      hipLaunchKernelGGL(flat_select_kernel, dim3(a.nq), dim3(256), sel_lds, ctx->stream, a, 1, oid, od);
+    }
+    while (seen < n) {
+      const int64_t want = seen == 0 ? FLAT_CAP / 2 : seen * (growth - 1);
+      a.r0 = seen;
+      a.r1 = std::min<int64_t>(n, seen + std::max<int64_t>(want, 1));
+      if (n - a.r1 < (a.r1 - a.r0) / 4) a.r1 = n;            // do not leave a small tail epoch
+      {
+        ScopedTimer t(ctx, "flat_scan");
+        filter(a);
+      }
+      seen = a.r1;
+      hipLaunchKernelGGL(flat_select_kernel, dim3(a.nq), dim3(256), sel_lds, ctx->stream, a, seen == n ? 1 : 0, oid, od);
+    }
+    // overflow repair: rows <= T (T only ever tightens) are re-collected from scratch until every pool fits
+    for (int round = 0; round < 64; ++round) {
+      uint32_t ovf = 0;
+      LH_CHECK_HIP(hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (!ovf) break;
+      LH_REQUIRE(round < 63, "flat_topk: candidate pool did not converge");
+      hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(a.nq, 256)), dim3(256), 0, ctx->stream, a, 0);
+      a.r0 = 0; a.r1 = n;
+      filter(a);
+      hipLaunchKernelGGL(flat_select_kernel, dim3(a.nq), dim3(256), sel_lds, ctx->stream, a, 1, oid, od);
+    }
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 template <int D>
 static void launch_flat_fixed(lance_hip_ctx *ctx, const FlatArgs &a, int metric, dim3 grid) {
   constexpr int TR = (8192 / D) > 256 ? 256 : (8192 / D);
@@ -194,6 +423,13 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
   LH_REQUIRE(k > 0 && k <= 1024, "flat_topk: k=%u not supported (1..1024)", k);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nq == 0) return LANCE_HIP_OK;
+  if (flat_v2_supported(metric, d, k) && !getenv("LANCE_HIP_FLAT_V1")) {
+    const float *xf2, *qf2;
+    LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf2));
+    LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf2));
+    if ((((uintptr_t)xf2 | (uintptr_t)qf2) & 15) == 0)
+      return flat_topk_v2(ctx, metric, xf2, row_ids, (int64_t)n, (int)d, qf2, (int)nq, (int)k, ids, dists);
+  }
   const int qblocks = (int)cdiv(nq, 256);
   int nsplit = (int)cdiv(2ull * ctx->num_cus, qblocks);
   nsplit = std::max(1, std::min<int>(nsplit, (int)(2048 / k)));
