@@ -13,6 +13,7 @@
 #include "common.h"
 #include "exact.cuh"
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -284,6 +285,9 @@ static int launch_fixed(lance_hip_ctx *ctx, PairwiseArgs p, int metric, int batc
 }
 
 template <int MODE>
+int launch_wide(lance_hip_ctx *ctx, PairwiseArgs &p, int d, int metric, int batches, int *ksplit_out);   // wide.hip
+
+template <int MODE>
 static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric, int batches) {
   if (p.n == 0 || batches == 0) return LANCE_HIP_OK;
   LH_REQUIRE(p.k > 0, "pairwise: k must be > 0");
@@ -305,7 +309,12 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
       default: break;
     }
   }
-  {
+  if (!getenv("LANCE_HIP_NO_WIDE")) {
+    int ks = 1;
+    LH_TRY(launch_wide<MODE>(ctx, p, d, metric, batches, &ks));
+    if (MODE == 0 && ks > 1)
+      hipLaunchKernelGGL(argmin_merge_kernel, dim3((unsigned)cdiv(p.n, 256), batches), dim3(256), 0, ctx->stream, p, ks, batches);
+  } else {
     int ct = 8192 / d;
     if (ct < 4) ct = 4;
     if (ct > 256) ct = 256;
