@@ -184,19 +184,6 @@ __global__ __launch_bounds__(256) void flat_merge_kernel(const uint32_t *__restr
 // and the final (key, rowid) sort reproduces SortExec's total order, ties included.  A pool overflow
 // (possible only for adversarial row orders) is detected and repaired by re-running the scan with the
 // tightened T, which strictly decreases each round.
-struct FlatPool {
-  const float *x;
-  const uint64_t *row_ids;
-  int64_t r0, r1;       // rows of this epoch
-  const float *q;       // queries of this chunk
-  int nq, k, cap;
-  uint32_t *tkey;       // [nq]
-  uint64_t *trid;       // [nq]
-  uint32_t *cnt;        // [nq]
-  uint32_t *pkeys;      // [nq][cap]
-  uint64_t *prids;      // [nq][cap]
-  uint32_t *overflow;   // [1]
-};
 
 template <int D, int METRIC, int QT, int BS>
 __global__ __launch_bounds__(BS) void flat_filter_kernel(FlatPool p) {
@@ -312,6 +299,30 @@ __global__ void flat_pool_reset_kernel(FlatPool p, int reset_t) {
   if (i == 0) *p.overflow = 0;
 }
 
+// cosine_fast's y-side norm for every row, d % 16 == 0: 16 FMA lane accumulators -> f32x8 tree (cosine.rs:143-175).
+// One 16-lane group per row (coalesced 64-byte reads), the tree via shuffles.  out = sqrt(y_norm).
+__global__ __launch_bounds__(256) void cosine_rownorm_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, i = lane & 15;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  float a = 0.0f;
+  if (row < n) {
+    const float *src = x + row * d;
+    for (int c = 0; c < d; c += 16) { const float v = src[c + i]; a = __fmaf_rn(v, v, a); }
+  }
+  const float t = a + __shfl(a, lane + 8);        // i < 8: t_i = a_i + a_{i+8}
+  const float s = t + __shfl(t, lane + 4);        // i < 4: s_i = t_i + t_{i+4}
+  const float u = s + __shfl(s, lane + 2);        // i < 2: u0 = s0 + s2, u1 = s1 + s3
+  float y = u + __shfl(u, lane + 1);              // i = 0: (s0+s2) + (s1+s3)
+  y = y + 0.0f;                                   // + reduce_sum(yn8 = 0)
+  y = y + 0.0f;                                   // + norm_l2(empty tail)^2
+  if (row < n && i == 0) out[row] = sqrtf(y);
+}
+
+__global__ __launch_bounds__(64) void query_norm_kernel(const float *__restrict__ q, int nq, int d, float *__restrict__ out) {
+  const int qi = blockIdx.x * 64 + threadIdx.x;
+  if (qi < nq) out[qi] = norm_l2_rt(q + (int64_t)qi * d, d);
+}
+
 template <int D>
 static void launch_flat_filter(lance_hip_ctx *ctx, const FlatPool &a, int metric) {
   constexpr int QT = D <= 32 ? 256 : 64;
@@ -331,9 +342,12 @@ static void launch_flat_filter(lance_hip_ctx *ctx, const FlatPool &a, int metric
 constexpr int FLAT_CAP = 4096;      // pool entries per query
 constexpr int FLAT_QCHUNK = 2048;   // queries per pass over the rows (pool = 2048 x 4096 x 12 B = 100 MB)
 
+static bool flat_fixed_dim(uint32_t d) { return d == 8 || d == 16 || d == 32 || d == 64 || d == 96 || d == 128; }
+
 static bool flat_v2_supported(int metric, uint32_t d, uint32_t k) {
-  if (metric == LANCE_HIP_COSINE || k > 128) return false;
-  return d == 8 || d == 16 || d == 32 || d == 64 || d == 96 || d == 128;
+  if (k > 128) return false;
+  if (metric == LANCE_HIP_COSINE) return d % 16 == 0 && d >= 32;     // d = 8 / 16 take cosine_once (cosine.rs:233-238)
+  return true;
 }
 
 static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const uint64_t *row_ids, int64_t n, int d, const float *q,
@@ -349,7 +363,19 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const ui
   a.overflow = ctx->scratch_t<uint32_t>("flat2.ovf", 1);
   if (!a.tkey || !a.trid || !a.cnt || !a.pkeys || !a.prids || !a.overflow) return LANCE_HIP_ENOMEM;
   const int64_t growth = std::max<int64_t>(2, FLAT_CAP / (16 * (int64_t)k));
+  const bool fixed = metric != LANCE_HIP_COSINE && flat_fixed_dim((uint32_t)d) &&
+                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q)) & 15) == 0);
+  if (metric == LANCE_HIP_COSINE) {
+    float *sy = ctx->scratch_t<float>("flat2.row_sy", (size_t)std::max<int64_t>(n, 1));
+    float *qn = ctx->scratch_t<float>("flat2.q_norm", (size_t)nq);
+    if (!sy || !qn) return LANCE_HIP_ENOMEM;
+    if (n > 0) hipLaunchKernelGGL(cosine_rownorm_kernel, dim3((unsigned)cdiv((uint64_t)n * 16, 256)), dim3(256), 0, ctx->stream, x, n, d, sy);
+    hipLaunchKernelGGL(query_norm_kernel, dim3(cdiv(nq, 64)), dim3(64), 0, ctx->stream, q, nq, d, qn);
+    a.row_sy = sy;
+  }
+  const float *qn_all = metric == LANCE_HIP_COSINE ? ctx->scratch_t<float>("flat2.q_norm", (size_t)nq) : nullptr;
   auto filter = [&](const FlatPool &e) {
+    if (!fixed) { launch_wide_filter(ctx, e, d, metric); return; }
     switch (d) {
       case 8: launch_flat_filter<8>(ctx, e, metric); break;
       case 16: launch_flat_filter<16>(ctx, e, metric); break;
@@ -362,6 +388,7 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const ui
   const size_t sel_lds = (size_t)FLAT_CAP * 12;
   for (int qc0 = 0; qc0 < nq; qc0 += qch) {
     a.q = q + (int64_t)qc0 * d;
+    a.q_norm = qn_all ? qn_all + qc0 : nullptr;
     a.nq = std::min(qch, nq - qc0);
     uint64_t *oid = ids + (int64_t)qc0 * k;
     float *od = dists + (int64_t)qc0 * k;
@@ -427,8 +454,7 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
     const float *xf2, *qf2;
     LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf2));
     LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf2));
-    if ((((uintptr_t)xf2 | (uintptr_t)qf2) & 15) == 0)
-      return flat_topk_v2(ctx, metric, xf2, row_ids, (int64_t)n, (int)d, qf2, (int)nq, (int)k, ids, dists);
+    return flat_topk_v2(ctx, metric, xf2, row_ids, (int64_t)n, (int)d, qf2, (int)nq, (int)k, ids, dists);
   }
   const int qblocks = (int)cdiv(nq, 256);
   int nsplit = (int)cdiv(2ull * ctx->num_cus, qblocks);

@@ -35,6 +35,25 @@ struct PairwiseArgs {
   uint32_t *part_idx = nullptr;
 };
 
+// flat scan v2: per-query candidate pools + threshold pairs (flat.hip)
+struct FlatPool {
+  const float *x;
+  const uint64_t *row_ids;
+  int64_t r0, r1;       // rows of this epoch
+  const float *q;       // queries of this chunk
+  int nq, k, cap;
+  uint32_t *tkey;       // [nq]
+  uint64_t *trid;       // [nq]
+  uint32_t *cnt;        // [nq]
+  uint32_t *pkeys;      // [nq][cap]
+  uint64_t *prids;      // [nq][cap]
+  uint32_t *overflow;   // [1]
+  const float *row_sy = nullptr;   // cosine: sqrt(y_norm) per row   (cosine.rs:143-175)
+  const float *q_norm = nullptr;   // cosine: norm_l2(query)
+};
+
+int launch_wide_filter(lance_hip_ctx *ctx, const FlatPool &fp, int d, int metric);   // wide.hip, any d
+
 int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
 int launch_dist_matrix(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
 

@@ -13,6 +13,10 @@
 //
 //   MODE 0  argmin (+bias, first index wins, non-finite rows -> NONE)   kmeans.rs:317-369, kernels.rs:79-111
 //   MODE 1  full distance matrix                                        kmeans.rs:1134-1158
+//   MODE 2  flat-scan filter: "centroids" are the queries; every (row, query) distance whose (key, rowid) is
+//           <= the query's threshold pair goes to that query's candidate pool (flat.hip v2).  METRIC_COSINE
+//           (d % 16 == 0) accumulates x.y with FMA in the 16 lanes and reduces with the f32x16 -> f32x8 tree of
+//           cosine_fast (cosine.rs:143-175, simd/f32.rs:203-218,625-644); row / query norms come precomputed.
 #include <algorithm>
 
 #include "common.h"
@@ -26,11 +30,16 @@ namespace lh {
 constexpr int W_ROWS = 32, W_CENTS = 64, W_DK = 64, W_LD = 80, W_BS = 512, W_RLD = 20;
 
 template <int METRIC, int MODE>
-__global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int d) {
+__global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int d, FlatPool fp) {
   __shared__ __attribute__((aligned(16))) float xt[W_ROWS * W_LD];    // 10 KB  rows x 64-slice (+pad: bank shift per row)
   __shared__ __attribute__((aligned(16))) float ct[W_CENTS * W_LD];   // 20 KB  centroids x 64-slice; reused as transpose scratch
   __shared__ float res[W_ROWS][W_CENTS + 1];
   __shared__ uint32_t nonfinite[W_ROWS];
+  __shared__ uint32_t tk[MODE == 2 ? W_CENTS : 1];
+  __shared__ uint64_t tr[MODE == 2 ? W_CENTS : 1];
+  __shared__ float qn[MODE == 2 ? W_CENTS : 1];
+  __shared__ uint64_t trid[MODE == 2 ? W_ROWS : 1];
+  __shared__ float tsy[MODE == 2 ? W_ROWS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, i = lane & 15;
   const int wr = wave >> 1, wc = wave & 1;
@@ -42,9 +51,17 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
   const int64_t row0 = (int64_t)blockIdx.x * W_ROWS;
   const int full = d / 16 * 16;
   const bool vec_ok = p.x_aligned && p.cent_aligned && (d % 4 == 0);
-  constexpr bool NEG = METRIC != METRIC_DOT;
+  constexpr bool NEG = METRIC == METRIC_L2;
 
   if (tid < W_ROWS) nonfinite[tid] = 0;
+  if constexpr (MODE == 2) {
+    if (tid < W_ROWS) {
+      const int64_t row = fp.r0 + row0 + tid;
+      const bool ok = row0 + tid < p.n;
+      trid[tid] = !ok ? ~0ull : (fp.row_ids ? fp.row_ids[row] : (uint64_t)row);
+      tsy[tid] = (METRIC == METRIC_COSINE && ok) ? fp.row_sy[row] : 1.0f;
+    }
+  }
   float minv = INFINITY, mino = INFINITY;      // thread t < 32 keeps the running argmin of row row0 + t
   uint32_t mini = LANCE_HIP_NONE;
 
@@ -107,7 +124,9 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
         const f2 xs = f2{xv[r], xv[r]};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          if constexpr (METRIC == METRIC_DOT) {
+          if constexpr (METRIC == METRIC_COSINE) {
+            acc[r][c] = __builtin_elementwise_fma(xs, cv[c], acc[r][c]);
+          } else if constexpr (METRIC == METRIC_DOT) {
             acc[r][c] = acc[r][c] + xs * cv[c];
           } else {
             const f2 df = xs + cv[c];
@@ -133,10 +152,20 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
       if (i < 8) {
         const float *src = mine + i * W_RLD;
         float tot = 0.0f;
+        if constexpr (METRIC == METRIC_COSINE) {
+          const f4 a0 = *reinterpret_cast<const f4 *>(src), a1 = *reinterpret_cast<const f4 *>(src + 4);
+          const f4 a2 = *reinterpret_cast<const f4 *>(src + 8), a3 = *reinterpret_cast<const f4 *>(src + 12);
+          const f4 lo = a0 + a2, hi = a1 + a3;          // t[i] = a[i] + a[i+8]   (f32x16 -> f32x8)
+          const f4 s4 = lo + hi;                         // s_i = t_i + t_{i+4}
+          tot = (s4.x + s4.z) + (s4.y + s4.w);           // ((t0+t4)+(t2+t6)) + ((t1+t5)+(t3+t7))
+          tot = tot + 0.0f;                              // + reduce_sum(xy8 = 0)
+          tot = tot + 0.0f;                              // + dot(tail of 0 elements)
+        } else {
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) {
-          const f4 v = *reinterpret_cast<const f4 *>(src + e);
-          tot = tot + v.x; tot = tot + v.y; tot = tot + v.z; tot = tot + v.w;
+          for (int e = 0; e < 16; e += 4) {
+            const f4 v = *reinterpret_cast<const f4 *>(src + e);
+            tot = tot + v.x; tot = tot + v.y; tot = tot + v.z; tot = tot + v.w;
+          }
         }
         float *dst = &res[wr * 8 + r][wc * 32 + g + 4 * i];
         *dst = first ? tot : *dst + tot;
@@ -149,6 +178,15 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
     const int c0 = cbi * W_CENTS;
     // remainder first (sequential sum of the d % 16 tail products): lane i holds product i, lanes >= rem hold 0
     bool first = true;
+    if constexpr (MODE == 2) {
+      __syncthreads();
+      if (tid < W_CENTS) {
+        const bool ok = c0 + tid < p.k;
+        tk[tid] = ok ? fp.tkey[c0 + tid] : 0u;
+        tr[tid] = ok ? fp.trid[c0 + tid] : 0ull;
+        qn[tid] = (METRIC == METRIC_COSINE && ok) ? fp.q_norm[c0 + tid] : 1.0f;
+      }
+    }
     if (full != d) {
       zero_acc();
       __syncthreads();
@@ -177,6 +215,24 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
         const int r = idx >> 6, c = idx & 63;
         if (row0 + r < p.n && c < ct_n)
           p.matrix[((int64_t)b * p.n + row0 + r) * p.k + c0 + c] = finish_metric<METRIC>(res[r][c]);
+      }
+    } else if constexpr (MODE == 2) {
+      for (int idx = tid; idx < W_ROWS * W_CENTS; idx += W_BS) {
+        const int r = idx >> 6, c = idx & 63;
+        if (row0 + r < p.n && c < ct_n) {
+          float v;
+          if constexpr (METRIC == METRIC_COSINE) v = 1.0f - res[r][c] / qn[c] / tsy[r];
+          else v = finish_metric<METRIC>(res[r][c]);
+          const uint32_t key = order_key(v);
+          const uint64_t rid = trid[r];
+          if (key < tk[c] || (key == tk[c] && rid <= tr[c])) {
+            const uint32_t pos = atomicAdd(&fp.cnt[c0 + c], 1u);
+            if (pos < (uint32_t)fp.cap) {
+              fp.pkeys[(int64_t)(c0 + c) * fp.cap + pos] = key;
+              fp.prids[(int64_t)(c0 + c) * fp.cap + pos] = rid;
+            }
+          }
+        }
       }
     } else {
       if (tid < W_ROWS && row0 + tid < p.n) {
@@ -221,14 +277,41 @@ int launch_wide(lance_hip_ctx *ctx, PairwiseArgs &p, int d, int metric, int batc
   }
   const dim3 grid((unsigned)cdiv(p.n, W_ROWS), batches, ksplit);
   if (metric == METRIC_DOT)
-    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_DOT, MODE>), grid, dim3(W_BS), 0, ctx->stream, p, d);
+    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_DOT, MODE>), grid, dim3(W_BS), 0, ctx->stream, p, d, FlatPool{});
   else
-    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_L2, MODE>), grid, dim3(W_BS), 0, ctx->stream, p, d);
+    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_L2, MODE>), grid, dim3(W_BS), 0, ctx->stream, p, d, FlatPool{});
   *ksplit_out = ksplit;
   return LANCE_HIP_OK;
 }
 
 template int launch_wide<0>(lance_hip_ctx *, PairwiseArgs &, int, int, int, int *);
 template int launch_wide<1>(lance_hip_ctx *, PairwiseArgs &, int, int, int, int *);
+
+// flat-scan filter over rows [fp.r0, fp.r1) for the queries of fp (any dimension; cosine needs d % 16 == 0)
+int launch_wide_filter(lance_hip_ctx *ctx, const FlatPool &fp, int d, int metric) {
+  PairwiseArgs p;
+  p.x = fp.x + fp.r0 * (int64_t)d;
+  p.n = fp.r1 - fp.r0;
+  p.ldx = d;
+  p.cent = fp.q;
+  p.k = fp.nq;
+  p.x_aligned = ((reinterpret_cast<uintptr_t>(fp.x) & 15) == 0) && (d % 4 == 0);
+  p.cent_aligned = ((reinterpret_cast<uintptr_t>(fp.q) & 15) == 0) && (d % 4 == 0);
+  if (p.n <= 0 || fp.nq <= 0) return LANCE_HIP_OK;
+  const int nblocks = (fp.nq + W_CENTS - 1) / W_CENTS;
+  const int64_t rblocks = (int64_t)cdiv(p.n, W_ROWS);
+  int z = 1;
+  if (rblocks < 2ll * ctx->num_cus) z = (int)std::min<int64_t>(nblocks, cdiv(2ll * ctx->num_cus, rblocks));
+  const dim3 grid((unsigned)rblocks, 1, z);
+  if (metric == METRIC_COSINE) {
+    LH_REQUIRE(d % 16 == 0 && fp.row_sy && fp.q_norm, "wide filter: cosine needs d %% 16 == 0 and precomputed norms");
+    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_COSINE, 2>), grid, dim3(W_BS), 0, ctx->stream, p, d, fp);
+  } else if (metric == METRIC_DOT) {
+    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_DOT, 2>), grid, dim3(W_BS), 0, ctx->stream, p, d, fp);
+  } else {
+    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_L2, 2>), grid, dim3(W_BS), 0, ctx->stream, p, d, fp);
+  }
+  return LANCE_HIP_OK;
+}
 
 }  // namespace lh

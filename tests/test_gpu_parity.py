@@ -241,7 +241,7 @@ def test_pq_scan_topk_single_partition(eng, oracle):
     assert (_np(gi).view(np.uint64) == ei).all() and (_np(gd).view(np.uint32) == ed.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("d", [128, 32, 100])
+@pytest.mark.parametrize("d", [128, 32, 100, 7, 20, 200, 384])
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 def test_flat_knn_bit_exact_with_ties(eng, oracle, d, metric):
     x = sift_like(20000, d, 51)          # integer-valued -> many exact distance ties
@@ -255,7 +255,7 @@ def test_flat_knn_bit_exact_with_ties(eng, oracle, d, metric):
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("d", [8, 16, 20, 128, 200])
+@pytest.mark.parametrize("d", [8, 16, 20, 32, 48, 128, 200, 1536])
 def test_flat_cosine_bit_exact(eng, oracle, d):
     rng = np.random.default_rng(d)
     x = rng.standard_normal((5000, d)).astype(f32) * 2
@@ -264,6 +264,24 @@ def test_flat_cosine_bit_exact(eng, oracle, d):
     oi, od = oracle.flat_knn(x, q, 10, "cosine")
     assert (_np(gi).view(np.uint64) == oi).all()
     assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_flat_large_k_and_adversarial_order(eng, oracle):
+    """k > 128 keeps the lanes-own-queries kernel; rows sorted farthest-first force the candidate-pool
+    overflow repair of the v2 path (every epoch passes the stale threshold)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((30000, 64)).astype(f32)
+    q = rng.standard_normal((9, 64)).astype(f32)
+    gi, gd = eng.flat_topk(x, q, 200)
+    oi, od = oracle.flat_knn(x, q, 200)
+    assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    order = np.argsort(-((x - q[0]) ** 2).sum(1), kind="stable")
+    xs = np.ascontiguousarray(x[order])
+    for d_sel in (slice(None), slice(0, 40)):         # fixed-D path (64) and the any-dimension path (40)
+        xa, qa = np.ascontiguousarray(xs[:, d_sel]), np.ascontiguousarray(q[:, d_sel])
+        gi, gd = eng.flat_topk(xa, qa, 10)
+        oi, od = oracle.flat_knn(xa, qa, 10)
+        assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
 
 
 def test_cosine_index_refine_bit_exact(eng, oracle):
