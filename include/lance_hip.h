@@ -44,8 +44,11 @@ extern "C" {
 /* lance_linalg::distance::DistanceType (distance.rs:36).  Cosine is handled the way
  * the reference index does: normalise, then L2 (lance-index ivf.rs:198-205).        */
 enum { LANCE_HIP_L2 = 0, LANCE_HIP_COSINE = 1, LANCE_HIP_DOT = 2 };
-/* element type of vectors / centroids / codebook */
-enum { LANCE_HIP_F32 = 0, LANCE_HIP_F16 = 1 };
+/* element type of vectors / centroids / codebook.
+ * LANCE_HIP_I8: the DATA operands (vectors x, queries q, raw vectors for refine) are int8 and are widened to
+ * f32 exactly, as the reference does for Int8 columns (kmeans.rs:1216-1224 convert_to_floating_point,
+ * l2.rs:253-260); the MODEL operands (centroids, codebook, init centroids, residual query, every output) are f32. */
+enum { LANCE_HIP_F32 = 0, LANCE_HIP_F16 = 1, LANCE_HIP_I8 = 2 };
 
 typedef struct lance_hip_ctx lance_hip_ctx;
 typedef struct lance_hip_index lance_hip_index;

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("LANCE_HIP_LIB") or os.path.join(_HERE, "liblance_hip.
 
 OK, EINVAL, ERUNTIME, ENOTSUP, ENOMEM = 0, -1, -2, -3, -4
 L2, COSINE, DOT = 0, 1, 2
-F32, F16 = 0, 1
+F32, F16, I8 = 0, 1, 2
 NONE = 0xFFFFFFFF
 U64_MAX = 0xFFFFFFFFFFFFFFFF
 

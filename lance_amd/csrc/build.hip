@@ -216,7 +216,7 @@ int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n,
     for (uint64_t r = 0; r < n; ++r)
       if (ph[r] != LANCE_HIP_NONE) kmax = std::max(kmax, ph[r] + 1);
   }
-  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)kmax * d, "f16.cent", &cf));
+  LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)kmax * d, "f16.cent", &cf));
   float *of = static_cast<float *>(out);
   if (f16) {
     of = ctx->scratch_t<float>("f16.residual_out", (size_t)n * d);
@@ -237,7 +237,7 @@ int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "pq_encode: f16 dot is not implemented in this version");
   const float *xf, *cbf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
-  LH_TRY(as_f32(ctx, dtype, codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
+  LH_TRY(as_f32(ctx, model_dtype(dtype), codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
   LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, xf, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
@@ -255,8 +255,8 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   LH_REQUIRE(!(f16 && metric != LANCE_HIP_L2), "ivfpq_encode: f16 supports the L2 metric only in this version");
   const float *xs, *centf, *cbf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xs));
-  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)nlist * d, "f16.cent", &centf));
-  LH_TRY(as_f32(ctx, dtype, codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
+  LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, "f16.cent", &centf));
+  LH_TRY(as_f32(ctx, model_dtype(dtype), codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
   centroids = centf; codebook = cbf;
   const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   if (metric == LANCE_HIP_COSINE) {
@@ -314,10 +314,10 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
   ix->dtype = dtype;
   // the index keeps f32 copies of the model (f16 widens exactly); the scan rounds the residual query to f16 when dtype is f16
   int r = dev_dup(ctx, nullptr, (size_t)nlist * d * 4, reinterpret_cast<void **>(&ix->centroids));
-  if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, centroids, (size_t)nlist * d, ix->centroids);
+  if (r == LANCE_HIP_OK) r = widen_into(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, ix->centroids);
   const size_t cb_elems = (size_t)m * ((size_t)1 << nbits) * (d / m);
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, cb_elems * 4, reinterpret_cast<void **>(&ix->codebook));
-  if (r == LANCE_HIP_OK) r = widen_into(ctx, dtype, codebook, cb_elems, ix->codebook);
+  if (r == LANCE_HIP_OK) r = widen_into(ctx, model_dtype(dtype), codebook, cb_elems, ix->codebook);
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)(nlist + 1) * 4, reinterpret_cast<void **>(&ix->part_offsets));
   if (r != LANCE_HIP_OK) { delete ix; return r; }
   *out = ix;

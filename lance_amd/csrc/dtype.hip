@@ -14,9 +14,25 @@ __global__ __launch_bounds__(256) void narrow_f16_kernel(const float *__restrict
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = __float2half_rn(in[i]);
 }
 
+__global__ __launch_bounds__(256) void widen_i8_kernel(const int8_t *__restrict__ in, float *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+
 int check_dtype(int dtype, const char *what) {
-  LH_REQUIRE(dtype == LANCE_HIP_F32 || dtype == LANCE_HIP_F16, "%s: unsupported element type %d (f32 = 0, f16 = 1)", what, dtype);
+  LH_REQUIRE(dtype == LANCE_HIP_F32 || dtype == LANCE_HIP_F16 || dtype == LANCE_HIP_I8,
+             "%s: unsupported element type %d (f32 = 0, f16 = 1, i8 = 2)", what, dtype);
   return LANCE_HIP_OK;
+}
+
+// element type of the model operands (centroids, codebook, outputs) that go with data of type `dtype`
+int model_dtype(int dtype) { return dtype == LANCE_HIP_I8 ? LANCE_HIP_F32 : dtype; }
+
+static void launch_widen(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float *dst) {
+  const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(count, 256), 65536);
+  if (dtype == LANCE_HIP_I8)
+    hipLaunchKernelGGL(widen_i8_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const int8_t *>(p), dst, (int64_t)count);
+  else
+    hipLaunchKernelGGL(widen_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const __half *>(p), dst, (int64_t)count);
 }
 
 int as_f32(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, const char *slot, const float **out) {
@@ -27,8 +43,7 @@ int as_f32(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, const cha
   float *w = ctx->scratch_t<float>(slot, count ? count : 1);
   if (!w) return LANCE_HIP_ENOMEM;
   if (count) {
-    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(count, 256), 65536);
-    hipLaunchKernelGGL(widen_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const __half *>(p), w, (int64_t)count);
+    launch_widen(ctx, dtype, p, count, w);
     LH_CHECK_HIP(hipGetLastError());
   }
   *out = w;
@@ -40,8 +55,7 @@ int widen_into(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float
   if (dtype == LANCE_HIP_F32) {
     LH_CHECK_HIP(hipMemcpyAsync(dst, p, count * 4, hipMemcpyDefault, ctx->stream));
   } else {
-    const unsigned grid = (unsigned)std::min<uint64_t>(cdiv(count, 256), 65536);
-    hipLaunchKernelGGL(widen_f16_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const __half *>(p), dst, (int64_t)count);
+    launch_widen(ctx, dtype, p, count, dst);
     LH_CHECK_HIP(hipGetLastError());
   }
   return LANCE_HIP_OK;
@@ -49,6 +63,7 @@ int widen_into(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float
 
 int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t count) {
   if (count == 0 || static_cast<const void *>(src) == dst) return LANCE_HIP_OK;
+  LH_REQUIRE(dtype != LANCE_HIP_I8, "internal: int8 is never an output element type");
   if (dtype == LANCE_HIP_F32) {
     LH_CHECK_HIP(hipMemcpyAsync(dst, src, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
   } else {

@@ -119,6 +119,7 @@ __device__ __forceinline__ float dist_exact(const RegVec<D> &a, const float *__r
 
 __device__ __forceinline__ float ld_elem(const float *p, int i) { return p[i]; }
 __device__ __forceinline__ float ld_elem(const __half *p, int i) { return __half2float(p[i]); }  // `as_()` widening, exact
+__device__ __forceinline__ float ld_elem(const int8_t *p, int i) { return (float)p[i]; }          // Int8 -> f32 (l2.rs:253-260)
 
 // Runtime-d version (both operands through pointers); same order.  Used by the
 // generic-dimension fallbacks and by small host-order helpers.  TB = float or __half
@@ -166,7 +167,10 @@ __device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, cons
 // (target-cpu=haswell) f32x16 is two __m256, multiply_add is vfmadd (simd/f32.rs:776-785) and
 // reduce_sum is the permute/hadd tree ((a0+a4)+(a2+a6))+((a1+a5)+(a3+a7)) (simd/f32.rs:203-218,
 // 625-644).  The fused multiply-adds are written with __fmaf_rn here on purpose.
-__device__ __forceinline__ float norm_l2_rt(const float *__restrict__ v, int d) {
+template <typename TB = float>
+__device__ __forceinline__ float norm_l2_rt(const TB *__restrict__ vp, int d) {
+  struct VView { const TB *p; __device__ __forceinline__ float operator[](int i) const { return ld_elem(p, i); } };
+  const VView v{vp};
   const int full = d / 16 * 16;
   float s = 0.0f;
   if (full != d) {
@@ -191,7 +195,10 @@ __device__ __forceinline__ float reduce8_tree(const float (&a)[8]) {
   return (s0 + s2) + (s1 + s3);
 }
 
-__device__ __forceinline__ float cosine_exact_rt(const float *__restrict__ x, float x_norm, const float *__restrict__ y, int d) {
+template <typename TB = float>
+__device__ __forceinline__ float cosine_exact_rt(const float *__restrict__ x, float x_norm, const TB *__restrict__ yp, int d) {
+  struct YView { const TB *p; __device__ __forceinline__ float operator[](int i) const { return ld_elem(p, i); } };
+  const YView y{yp};
   if (d == 8 || d == 16) {  // cosine_once
     float t[8], u[8];
     if (d == 16) {
@@ -227,9 +234,9 @@ __device__ __forceinline__ float cosine_exact_rt(const float *__restrict__ x, fl
   float t16[8], u16[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { t16[i] = xy16[i] + xy16[i + 8]; u16[i] = yn16[i] + yn16[i + 8]; }
-  const float nrest = norm_l2_rt(y + aligned, d - aligned);
+  const float nrest = norm_l2_rt<TB>(yp + aligned, d - aligned);
   const float y_norm = reduce8_tree(u16) + reduce8_tree(yn8) + nrest * nrest;
-  const float xy = reduce8_tree(t16) + reduce8_tree(xy8) + dist_exact_rt<METRIC_DOT>(x + aligned, y + aligned, d - aligned);
+  const float xy = reduce8_tree(t16) + reduce8_tree(xy8) + dist_exact_rt<METRIC_DOT, TB>(x + aligned, yp + aligned, d - aligned);
   return 1.0f - xy / x_norm / sqrtf(y_norm);
 }
 

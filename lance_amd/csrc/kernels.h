@@ -70,6 +70,7 @@ int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, in
                               bool f16_arith = false);
 // element-type plumbing (dtype.hip)
 int check_dtype(int dtype, const char *what);
+int model_dtype(int dtype);   // f32 for int8 data, else the data type itself
 int as_f32(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, const char *slot, const float **out);
 int widen_into(lance_hip_ctx *ctx, int dtype, const void *p, size_t count, float *dst);
 int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t count);

@@ -479,7 +479,7 @@ int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, u
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "assign: f16 dot (32-lane dot_scalar) is not implemented in this version");
   const float *xf, *cf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
-  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)k * d, "f16.cent", &cf));
+  LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)k * d, "f16.cent", &cf));
   PairwiseArgs pa;
   pa.x = xf; pa.n = (int64_t)n; pa.ldx = d;
   pa.cent = cf; pa.k = (int)k;
@@ -523,6 +523,13 @@ int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const v
     return kmeans_train_impl(ctx, metric, static_cast<const float *>(x), n, d, k, max_iters, tol, balance_factor, hierarchical_k,
                              static_cast<const float *>(init_centroids), seed, static_cast<float *>(centroids_out), loss_out_host,
                              iters_out_host, k_out_host, false);
+  if (dtype == LANCE_HIP_I8) {   // Int8 columns train on the f32 conversion (lance-arrow lib.rs:284-306); the model is f32
+    const float *xw;
+    LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xw));
+    return kmeans_train_impl(ctx, metric, xw, n, d, k, max_iters, tol, balance_factor, hierarchical_k,
+                             static_cast<const float *>(init_centroids), seed, static_cast<float *>(centroids_out), loss_out_host,
+                             iters_out_host, k_out_host, false);
+  }
   // f16: KMeansAlgoFloat<Float16Type> -- widen, train with f16 M-step arithmetic, narrow the model
   LH_REQUIRE(metric != LANCE_HIP_DOT, "kmeans_train: f16 dot (32-lane dot_scalar) is not implemented in this version");
   const float *xf;
@@ -533,13 +540,13 @@ int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const v
   if (init_centroids) {
     iw = ctx->scratch_t<float>("f16.kmeans_init", (size_t)k * d);
     if (!iw) return LANCE_HIP_ENOMEM;
-    LH_TRY(widen_into(ctx, dtype, init_centroids, (size_t)k * d, iw));
+    LH_TRY(widen_into(ctx, model_dtype(dtype), init_centroids, (size_t)k * d, iw));
   }
   uint32_t kout = k;
   LH_TRY(kmeans_train_impl(ctx, metric, xf, n, d, k, max_iters, tol, balance_factor, hierarchical_k, iw, seed, cw, loss_out_host,
                            iters_out_host, &kout, true));
   if (k_out_host) *k_out_host = kout;
-  LH_TRY(from_f32(ctx, dtype, cw, centroids_out, (size_t)kout * d));
+  LH_TRY(from_f32(ctx, model_dtype(dtype), cw, centroids_out, (size_t)kout * d));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
@@ -636,7 +643,7 @@ int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uin
   LH_TRY(kmeans_train_batched(ctx, LANCE_HIP_L2, rf, (int64_t)rows, d, (int)(d / m), (int)(d / m), (int)kc, (int)m, max_iters, 1e-4, 0.0f,
                               false, seeds.data(), cb, loss.data(), iters_out_host, f16));
   if (f16) {
-    LH_TRY(from_f32(ctx, dtype, cb, codebook_out, (size_t)m * kc * (d / m)));
+    LH_TRY(from_f32(ctx, model_dtype(dtype), cb, codebook_out, (size_t)m * kc * (d / m)));
     LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   return LANCE_HIP_OK;

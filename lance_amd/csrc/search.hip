@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
       r = cand_rid[(int64_t)qi * keff + i];
       if (r < n_raw) {
         if constexpr (METRIC == METRIC_COSINE) {
-          if constexpr (sizeof(TR) == 4) kk = order_key(cosine_exact_rt(qv, qnorm, reinterpret_cast<const float *>(raw) + r * d, d));
+          kk = order_key(cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
         } else {
           kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC, TR>(qv, raw + r * d, d)));
         }
@@ -1025,7 +1025,17 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const float *rawf = static_cast<const float *>(ix->raw);
     const __half *rawh = static_cast<const __half *>(ix->raw);
     // flat_knn on the taken rows uses the index's metric with the ORIGINAL query (q_orig = widened q for f16)
-    if (ix->dtype == LANCE_HIP_F16)
+    const int8_t *rawi = static_cast<const int8_t *>(ix->raw);
+    if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_COSINE)
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+    else if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_DOT)
+      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+    else if (ix->dtype == LANCE_HIP_I8)
+      hipLaunchKernelGGL((refine_kernel<METRIC_L2, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+    else if (ix->dtype == LANCE_HIP_F16)
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
     else if (ix->metric == LANCE_HIP_COSINE)
@@ -1074,7 +1084,7 @@ int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const v
   if (!matrix) return LANCE_HIP_ENOMEM;
   const float *qf, *cf;
   LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf));
-  LH_TRY(as_f32(ctx, dtype, centroids, (size_t)nlist * d, "f16.cent", &cf));
+  LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, "f16.cent", &cf));
   PairwiseArgs pa;
   pa.x = qf; pa.n = nq; pa.ldx = d;
   pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
@@ -1139,7 +1149,7 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
   LH_TRY(lance_hip_index_from_storage(ctx, dtype, scan_metric, d, zc, 1, codebook, m, nbits, offs, codes_transposed, 1, row_ids, n_p, &ix));
   uint32_t *flags = nullptr;
   const float *qf = nullptr;
-  int r = as_f32(ctx, dtype, q_residual, d, "f16.q", &qf);
+  int r = as_f32(ctx, model_dtype(dtype), q_residual, d, "f16.q", &qf);
   if (r == LANCE_HIP_OK) r = ivfpq_search_enqueue(ctx, ix, qf, 1, k, 1, 0, has_range, lower, upper, out_ids, out_dists, &flags);
   if (r == LANCE_HIP_OK) r = check_flags(ctx, flags, 1);
   if (r == LANCE_HIP_OK && out_n_host) {

@@ -42,6 +42,8 @@ def _vec(a):
     t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
     if t.dtype == torch.float16:
         return t.to(_dev()).contiguous(), _lib.F16
+    if t.dtype == torch.int8:      # Int8 columns: data stays int8, the model (centroids, codebook) is float32
+        return t.to(_dev()).contiguous(), _lib.I8
     return t.to(torch.float32).to(_dev()).contiguous(), _lib.F32
 
 
@@ -54,9 +56,18 @@ def _nbits(codebook):
 
 
 def _like(a, ref):
-    """model arrays (centroids, codebook, queries) are cast to the element type of the vectors"""
+    """data arrays (queries, raw vectors) are cast to the element type of the vectors"""
     t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
     return t.to(ref.dtype).to(_dev()).contiguous()
+
+
+def _model(a, ref):
+    """model arrays (centroids, codebook) take the element type of the vectors, float32 for int8 vectors"""
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(torch.float32 if ref.dtype == torch.int8 else ref.dtype).to(_dev()).contiguous()
+
+
+_DT = {"float32": (torch.float32, 0), "float16": (torch.float16, 1), "int8": (torch.int8, 2)}
 
 
 class Engine:
@@ -98,7 +109,7 @@ class Engine:
         return out
 
     def assign(self, x, centroids, metric="l2", bias=None):
-        x, dt = _vec(x); centroids = _like(centroids, x)
+        x, dt = _vec(x); centroids = _model(centroids, x)
         n, d = x.shape
         k = centroids.shape[0]
         ids = torch.empty(n, dtype=torch.int32, device=x.device)
@@ -113,8 +124,9 @@ class Engine:
         """KMeans::new_with_params: flat Lloyd for k <= 256 (or hierarchical_k <= 1), hierarchical otherwise."""
         x, dt = _vec(x)
         n, d = x.shape
-        cent = torch.zeros((k, d), dtype=x.dtype, device=x.device)
-        init_t = None if init is None else _like(init, x)
+        mdt = torch.float32 if x.dtype == torch.int8 else x.dtype
+        cent = torch.zeros((k, d), dtype=mdt, device=x.device)
+        init_t = None if init is None else _model(init, x)
         loss = C.c_double(0); iters = C.c_uint32(0); kout = C.c_uint32(0)
         torch.cuda.synchronize()
         check(self.lib.lance_hip_kmeans_train_ex(self.h, dt, METRICS[metric], _ptr(x), n, d, k, max_iters, tol,
@@ -145,7 +157,7 @@ class Engine:
     def pq_train(self, residuals, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
         r, dt = _vec(residuals)
         n, d = r.shape
-        cb = torch.empty((m, 1 << nbits, d // m), dtype=r.dtype, device=r.device)
+        cb = torch.empty((m, 1 << nbits, d // m), dtype=torch.float32 if r.dtype == torch.int8 else r.dtype, device=r.device)
         iters = np.zeros(m, np.uint32)
         torch.cuda.synchronize()
         check(self.lib.lance_hip_pq_train(self.h, dt, _ptr(r), n, d, m, nbits, max_iters, sample_rate, seed, _ptr(cb),
@@ -153,15 +165,15 @@ class Engine:
         return cb, iters
 
     def residual(self, x, centroids, part_ids):
-        x, dt = _vec(x); centroids = _like(centroids, x)
+        x, dt = _vec(x); centroids = _model(centroids, x)
         p = to_device(part_ids, torch.int32)
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, dtype=centroids.dtype, device=x.device)
         torch.cuda.synchronize()
         check(self.lib.lance_hip_residual(self.h, dt, _ptr(x), x.shape[0], x.shape[1], _ptr(centroids), _ptr(p), _ptr(out)))
         return out
 
     def pq_encode(self, x, codebook, metric="l2"):
-        x, dt = _vec(x); codebook = _like(codebook, x)
+        x, dt = _vec(x); codebook = _model(codebook, x)
         n, d = x.shape
         m = codebook.shape[0]
         nb = _nbits(codebook)
@@ -171,8 +183,8 @@ class Engine:
         return codes
 
     def ivfpq_encode(self, x, centroids, codebook, metric="l2"):
-        x, dt = _vec(x); centroids = _like(centroids, x)
-        codebook = _like(codebook, x)
+        x, dt = _vec(x); centroids = _model(centroids, x)
+        codebook = _model(codebook, x)
         n, d = x.shape
         m = codebook.shape[0]
         nb = _nbits(codebook)
@@ -186,7 +198,11 @@ class Engine:
 
     def find_partitions(self, q, centroids, nprobes, metric="l2"):
         centroids, dt = _vec(centroids)
-        q = _like(q, centroids).reshape(-1, centroids.shape[1])
+        if isinstance(q, (torch.Tensor, np.ndarray)) and str(q.dtype).endswith("int8"):
+            q, dt = _vec(q)                       # int8 queries against the f32 centroids of an Int8 column
+            q = q.reshape(-1, centroids.shape[1])
+        else:
+            q = _like(q, centroids).reshape(-1, centroids.shape[1])
         nq, d = q.shape
         nlist = centroids.shape[0]
         nprobes = min(nprobes, nlist)
@@ -248,7 +264,8 @@ class Engine:
 class DeviceIndex:
     """Handle of a device-resident IVF_PQ index (lance_hip_index)."""
 
-    def __init__(self, engine, handle, metric, centroids, codebook, raw=None):
+    def __init__(self, engine, handle, metric, centroids, codebook, raw=None, data_dtype=None):
+        self.data_dtype = data_dtype if data_dtype is not None else centroids.dtype   # element type of queries / raw vectors
         self.engine = engine
         self.h = handle
         self.metric = metric
@@ -259,8 +276,11 @@ class DeviceIndex:
             self.set_raw(raw)
 
     @classmethod
-    def create(cls, engine, metric, centroids, codebook, part_ids, codes, row_ids=None, raw=None):
+    def create(cls, engine, metric, centroids, codebook, part_ids, codes, row_ids=None, raw=None, dtype=None):
         cent, dt = _vec(centroids); cb = _like(codebook, cent)
+        ddt = cent.dtype
+        if dtype is not None:
+            ddt, dt = _DT[dtype]
         part = to_device(part_ids, torch.int32); codes = to_device(codes, torch.uint8)
         rid = None if row_ids is None else to_device(row_ids, torch.int64)
         n = part.numel()
@@ -270,11 +290,14 @@ class DeviceIndex:
         torch.cuda.synchronize()
         check(engine.lib.lance_hip_index_create(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, _nbits(cb),
                                                 _ptr(part), _ptr(codes), _ptr(rid), n, C.byref(h)))
-        return cls(engine, h, metric, cent, cb, raw)
+        return cls(engine, h, metric, cent, cb, raw, ddt)
 
     @classmethod
-    def from_storage(cls, engine, metric, centroids, codebook, part_offsets, codes, row_ids, transposed=True, raw=None):
+    def from_storage(cls, engine, metric, centroids, codebook, part_offsets, codes, row_ids, transposed=True, raw=None, dtype=None):
         cent, dt = _vec(centroids); cb = _like(codebook, cent)
+        ddt = cent.dtype
+        if dtype is not None:
+            ddt, dt = _DT[dtype]
         offs = np.ascontiguousarray(part_offsets, np.uint32)
         codes = to_device(np.ascontiguousarray(codes, np.uint8).reshape(-1), torch.uint8)
         rid = to_device(row_ids, torch.int64)
@@ -286,10 +309,11 @@ class DeviceIndex:
         check(engine.lib.lance_hip_index_from_storage(engine.h, dt, METRICS[metric], d, _ptr(cent), nlist, _ptr(cb), m, _nbits(cb),
                                                       offs.ctypes.data_as(C.c_void_p), _ptr(codes), int(transposed), _ptr(rid), n,
                                                       C.byref(h)))
-        return cls(engine, h, metric, cent, cb, raw)
+        return cls(engine, h, metric, cent, cb, raw, ddt)
 
     def set_raw(self, raw):
-        self._raw = _like(raw, self.centroids)
+        t = raw if isinstance(raw, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(raw))
+        self._raw = t.to(self.data_dtype).to(_dev()).contiguous()
         check(self.engine.lib.lance_hip_index_set_raw(self.h, _ptr(self._raw), self._raw.shape[0]))
 
     def info(self):
@@ -310,7 +334,8 @@ class DeviceIndex:
 
     def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
         d = self.centroids.shape[1]
-        q = _like(q, self.centroids).reshape(-1, d)
+        t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
+        q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
         nq = q.shape[0]
         if out is None:
             ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)

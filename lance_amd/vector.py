@@ -218,6 +218,8 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
     params = IvfPqParams(num_partitions, num_sub_vectors, num_bits, _normalize_metric_type(metric), max_iters, sample_rate, seed)
     x = to_device(x)
     n, d = x.shape
+    if x.dtype == torch.int8 and params.metric == "cosine":
+        raise NotImplementedError("int8 vectors with the cosine metric are not supported by this engine (use l2 or dot)")
     if d % num_sub_vectors != 0:
         raise ValueError(f"num_sub_vectors must divide vector dimension {d}, but got {num_sub_vectors}")
     stats = BuildStats()
@@ -236,15 +238,16 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
             raise ValueError(f"IVF centroids length mismatch: {tuple(cent.shape)} != {(num_partitions, d)}")
     else:
         cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
-    if pq_codebook is not None:
-        cb = to_device(np.asarray(pq_codebook, np.float32).reshape(num_sub_vectors, 1 << num_bits, d // num_sub_vectors))
     if num_bits not in (4, 8):
         raise ValueError(f"ProductQuantization: num_bits {num_bits} not supported")
+    if pq_codebook is not None:
+        cb = to_device(np.asarray(pq_codebook, np.float32).reshape(num_sub_vectors, 1 << num_bits, d // num_sub_vectors))
     else:
         cb, stats.pq_iters = timed("train_pq", lambda: train_pq_codebook(x, cent, params, eng))
     part, codes, _ = timed("transform", lambda: eng.ivfpq_encode(x, cent, cb, params.metric))
     ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
-                                                              raw=x if keep_raw else None))
+                                                              raw=x if keep_raw else None,
+                                                              dtype="int8" if x.dtype == torch.int8 else None))
     return IvfPqIndex(ix, params, stats, part, codes)
 
 

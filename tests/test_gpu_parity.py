@@ -490,3 +490,50 @@ def test_python_api_end_to_end(engine, oracle):
     km.fit(x[:4000])
     assert km.centroids.shape == (8, 64)
     assert (km.predict(x[:100]) == oracle.assign(x[:100], km.centroids)[0]).all()
+
+
+def test_int8_vectors_widen_to_f32(eng, oracle):
+    """Int8 columns (BigANN-style): the reference converts the vectors to f32 and keeps an f32
+    model (kmeans.rs:1216-1224, l2.rs:253-260); the int8 element type of the C ABI must equal the oracle
+    run on the widened data, bit for bit, through train -> encode -> search -> refine and the flat scan."""
+    import torch
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(8)
+    n, d, nlist, m = 12000, 64, 16, 8
+    centers = rng.integers(-90, 90, (40, d))
+    x8 = np.clip(centers[rng.integers(0, 40, n)] + rng.normal(0, 12, (n, d)), -128, 127).astype(np.int8)
+    q8 = np.clip(centers[rng.integers(0, 40, 64)] + rng.normal(0, 12, (64, d)), -128, 127).astype(np.int8)
+    xf, qf = x8.astype(f32), q8.astype(f32)
+    init = xf[oracle.kmeans_init_indices(n, nlist, 3)]
+    cent, loss, iters = eng.kmeans_train(torch.from_numpy(x8), nlist, max_iters=10, balance_factor=1.0, init=init, seed=1)
+    # the engine applies the reference's k*512 row cap (kmeans.rs:623-627) itself; the oracle trains on the rows it is given
+    oc, ol, oit, _ = oracle.kmeans_train(xf[: nlist * 512], nlist, max_iters=10, balance_factor=f32(1.0) / f32(n), init=init, seed=1)
+    assert cent.dtype == torch.float32 and (_np(cent).view(np.uint32) == oc.view(np.uint32)).all() and loss == ol and iters == oit
+    ids, dists = eng.assign(torch.from_numpy(x8), oc)
+    oi, od = oracle.assign(xf, oc)
+    assert (_np(ids).view(np.uint32) == oi).all() and (_np(dists).view(np.uint32) == od.view(np.uint32)).all()
+    res = eng.residual(torch.from_numpy(x8), oc, oi)
+    ores = oracle.residual(xf, oc, oi)
+    assert (_np(res).view(np.uint32) == ores.view(np.uint32)).all()
+    cb, _ = eng.pq_train(res, m, max_iters=8, seed=2)
+    ocb, _ = oracle.pq_train(ores, m, max_iters=8, seed=2)
+    assert (_np(cb).view(np.uint32) == ocb.view(np.uint32)).all()
+    for metric in ("l2", "dot"):
+        part, codes, _ = eng.ivfpq_encode(torch.from_numpy(x8), oc, ocb, metric)
+        oidx = oracle.build_index(xf, oc, ocb, metric=metric)
+        assert (_np(part).view(np.uint32) == oidx.part_ids).all() and (_np(codes) == oidx.codes_rowmajor).all()
+        g = DeviceIndex.create(eng, metric, oc, ocb, part, codes, None, raw=torch.from_numpy(x8), dtype="int8")
+        for nprobes, rf in ((4, 0), (nlist, 0), (4, 5)):
+            gi, gd = g.search(torch.from_numpy(q8), 10, nprobes, rf)
+            oi2, od2 = oidx.search(qf, 10, nprobes, refine=rf, raw=xf if rf else None)
+            assert (_np(gi).view(np.uint64) == oi2).all(), (metric, nprobes, rf)
+            assert (_np(gd).view(np.uint32) == od2.view(np.uint32)).all()
+        pid, pd = eng.find_partitions(torch.from_numpy(q8), oc, 5, metric)
+        opid, opd = oracle.find_partitions(qf, oc, 5, metric)
+        assert (_np(pid).view(np.uint32) == opid).all() and (_np(pd).view(np.uint32) == opd.view(np.uint32)).all()
+        gi, gd = eng.flat_topk(torch.from_numpy(x8), torch.from_numpy(q8), 10, metric)
+        oi3, od3 = oracle.flat_knn(xf, qf, 10, metric)
+        assert (_np(gi).view(np.uint64) == oi3).all() and (_np(gd).view(np.uint32) == od3.view(np.uint32)).all()
+    gi, gd = eng.flat_topk(torch.from_numpy(x8), torch.from_numpy(q8), 10, "cosine")
+    oi3, od3 = oracle.flat_knn(xf, qf, 10, "cosine")
+    assert (_np(gi).view(np.uint64) == oi3).all() and (_np(gd).view(np.uint32) == od3.view(np.uint32)).all()
