@@ -131,6 +131,11 @@ static void split_clusters_host(size_t n, std::vector<uint64_t> &cnts, float *ce
   const float eps = 1.0f / 1024.0f;
   for (size_t i = 0; i < k; i++) {
     if (cnts[i] == 0) {
+      // The reference's rejection loop (kmeans.rs:184-192) never terminates when no cluster has >= 2 members
+      // (all p <= 0: e.g. every distance NaN after an f16 M-step overflow).  Stop splitting instead of hanging.
+      bool splittable = false;
+      for (size_t c = 0; c < k; c++) if (cnts[c] >= 2) { splittable = true; break; }
+      if (!splittable) return;
       size_t j = 0;
       for (;;) {
         const float p = ((float)cnts[j] - 1.0f) / (float)(n - k);

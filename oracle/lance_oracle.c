@@ -423,6 +423,11 @@ static void orc_split_clusters(size_t n, uint64_t *cnts, size_t k, float *centro
   const float eps = 1.0f / 1024.0f;
   for (size_t i = 0; i < k; i++) {
     if (cnts[i] == 0) {
+      /* the reference's rejection loop never ends when no cluster has >= 2 members (every p <= 0, e.g. all
+       * distances NaN after an f16 overflow): stop splitting there instead of hanging -- the only deviation */
+      int splittable = 0;
+      for (size_t c = 0; c < k; c++) if (cnts[c] >= 2) { splittable = 1; break; }
+      if (!splittable) return;
       size_t j = 0;
       for (;;) {
         float p = ((float)cnts[j] - 1.0f) / (float)(n - k);

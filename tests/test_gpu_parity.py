@@ -537,3 +537,18 @@ def test_int8_vectors_widen_to_f32(eng, oracle):
     gi, gd = eng.flat_topk(torch.from_numpy(x8), torch.from_numpy(q8), 10, "cosine")
     oi3, od3 = oracle.flat_knn(xf, qf, 10, "cosine")
     assert (_np(gi).view(np.uint64) == oi3).all() and (_np(gd).view(np.uint32) == od3.view(np.uint32)).all()
+
+
+def test_f16_mstep_overflow_terminates_like_oracle(eng, oracle):
+    """KMeansAlgoFloat<Float16Type> sums the members of a cluster in f16 (kmeans.rs:403-406): SIFT-range values
+    overflow to inf, every later distance is NaN and the reference's split_clusters rejection loop would spin
+    forever once no cluster has two members.  Engine and oracle must both terminate, and agree."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = rng.integers(150, 218, (4096, 16)).astype(np.float16)     # 512 members x ~184 > 65504 in every cluster
+    cent, loss, iters = eng.kmeans_train(torch.from_numpy(x), 8, max_iters=5, seed=1)
+    oc, ol, oit, _ = oracle.kmeans_train(x, 8, max_iters=5, seed=1)
+    g = _np(cent).astype(f32); o = oc.astype(f32)
+    assert iters == oit
+    assert (np.isnan(g) == np.isnan(o)).all()
+    assert (g[~np.isnan(g)].view(np.uint32) == o[~np.isnan(o)].view(np.uint32)).all()
