@@ -97,8 +97,9 @@ def main():
     recall = (ids_s.unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().mean().item()
 
     # ---- algorithmic bytes of the ADC scan: sum over (query, probe) pairs of n_p * M code bytes.
-    # The scan runs as two launches of ivfpq_scan_pm_kernel: class 0 = each query's nearest partition,
-    # class 1 = the other nprobes-1 partitions (the dominant launch).
+    # The scan runs as two launches of ivfpq_scan_pm_kernel: a bound pass over each query's nearest partition
+    # (seeds the per-query threshold, keeps nothing) and the main pass over ALL nprobes partitions (the dominant
+    # launch; with LANCE_HIP_PM_NOBOUND=1 the earlier flow: class 0 / class 1 = the other nprobes-1 partitions).
     offs = torch.from_numpy(idx.export_storage()[0].astype(np.int64)).to(dev)
     sizes = offs[1:] - offs[:-1]
     scan_bytes, scan_bytes_c1 = [], []
@@ -148,7 +149,10 @@ def main():
     qps = world * args.nq * args.steps / elapsed
     if kt["ivfpq_scan_c1"][1] > 0:      # partition-major path: dominant launch = class 1
         scan_ms, scan_launches = kt["ivfpq_scan_c1"]
-        bytes_list, kernel_name = scan_bytes_c1, "ivfpq_scan_pm_kernel<SD=8,L2,MU=1,RPL=2> (class-1 launch: the nprobes-1 farther partitions)"
+        if os.environ.get("LANCE_HIP_PM_NOBOUND"):
+            bytes_list, kernel_name = scan_bytes_c1, "ivfpq_scan_pm_kernel<SD=8,L2,MU=1,RPL=2> (class-1 launch: the nprobes-1 farther partitions)"
+        else:
+            bytes_list, kernel_name = scan_bytes, "ivfpq_scan_pm_kernel<SD=8,L2,MU=1,RPL=2> (main pass: all nprobes partitions of every query)"
     else:
         scan_ms, scan_launches = kt["ivfpq_scan"]
         bytes_list, kernel_name = scan_bytes, "ivfpq_scan_kernel<SD=8,L2,MU=1>"

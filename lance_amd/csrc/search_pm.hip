@@ -19,6 +19,7 @@
 // The union of the pool always contains every scanned row with dist <= final T, whatever order the items
 // ran in, so results are deterministic and equal to the reference's SortExec over per-partition heaps.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -35,8 +36,7 @@ namespace lh {
 #define LH_PM_BS 512
 #endif
 constexpr int PM_BS = LH_PM_BS;            // lanes per workgroup (512: 3 workgroups x 8 waves per CU)
-constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query (one class-0 round + slack)
-constexpr int PM_ROUND = 512;    // rows per round (one per lane)
+constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query, pruned class (one round + slack)
 #ifndef LH_PM_EARLY
 #define LH_PM_EARLY 0   /* wave-level early abandon measured 2-3 % slower: a wave is rarely all-dead */
 #endif
@@ -51,7 +51,8 @@ struct PmArgs {
   const uint32_t *pair_starts;  // [2*nlist+1] pairs grouped by virtual partition = cls*nlist + partition
   const uint32_t *pair_idx;     // [nq*nprobes] pair index (q = idx / nprobes), grouped
   const uint32_t *item_start;   // [2*nlist+1] exclusive scan of ceil(c_vp / 2) over virtual partitions
-  int cls;                      // which class this launch covers: 0 = nearest-partition pairs, 1 = the rest
+  int cls;                      // which items this launch covers: 0 = nearest-partition pairs, 1 = the rest, 2 = all
+  int bound_pass;               // class 0 only: compute Tglobal bounds, keep no candidates (RPL = 0 instantiation)
   const int4 *desc;             // [items] {partition, q0, q1 (-1 = none), 0}: filled by pm_item_desc_kernel
   const float *centroids, *codebook;
   const uint32_t *part_offsets;
@@ -61,6 +62,7 @@ struct PmArgs {
   uint32_t *tglobal;            // [nq] running upper bound of the keff-th distance (key)
   uint32_t *pool_key, *pool_pos, *pool_cnt;  // [nq][pool_cap], [nq]
   int pool_cap;                 // pool entries per query
+  int ablate;                   // perf experiments only (LANCE_HIP_PM_ABLATE): 1 no appends, 2 no tighten in the loop, 4 skip gathers, 8 per-lane atomics
   uint32_t *flags;
 };
 
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void pm_item_desc_kernel(const uint32_t *__res
 // the buffer can never overflow between two capacity checks; class 1 starts from a tight bound, appends are
 // rare, so it streams 4 rows per lane between barriers (an overflow there is flagged and the query replayed
 // by the exact kernel).
-template <int SD, int METRIC, int MU, int RPL>
+template <int SD, int METRIC, int MU, int RPL, int CAP>
 __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int m = MU * 16;
@@ -211,10 +213,10 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   float *r1 = r0 + dpad;
   f2 *lut2 = reinterpret_cast<f2 *>(r1 + dpad);  // [m][256] pairs
   uint32_t *ck0 = reinterpret_cast<uint32_t *>(lut2 + m * 256);
-  uint32_t *cp0 = ck0 + PM_CAP;
-  uint32_t *ck1 = cp0 + PM_CAP;
-  uint32_t *cp1 = ck1 + PM_CAP;
-  uint32_t *sorted = cp1 + PM_CAP;   // [PM_BS]
+  uint32_t *cp0 = ck0 + CAP;
+  uint32_t *ck1 = cp0 + CAP;
+  uint32_t *cp1 = ck1 + CAP;
+  uint32_t *sorted = cp1 + CAP;   // [PM_BS]
   uint32_t *misc = sorted + PM_BS;   // [0]=cnt0 [1]=T0 [2]=cnt1 [3]=T1 [4]=tnew [5]=flags
   __shared__ int s_part, s_q0, s_q1, s_valid;
 
@@ -231,8 +233,8 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   }
 
   if (threadIdx.x == 0) {
-    const uint32_t item = blockIdx.x + (p.cls ? p.item_start[p.nlist] : 0u);
-    const int valid = item < p.item_start[(p.cls + 1) * p.nlist];
+    const uint32_t item = blockIdx.x + (p.cls == 1 ? p.item_start[p.nlist] : 0u);
+    const int valid = item < p.item_start[(p.cls == 0 ? 1 : 2) * p.nlist];
     int4 dsc = make_int4(0, -1, -1, 0);
     if (valid) dsc = p.desc[item];
     const int part = dsc.x, q0 = dsc.y, q1 = dsc.z;
@@ -298,12 +300,61 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   __syncthreads();
 
   const uint8_t *pcodes = p.codes + (int64_t)off * m;
+  if constexpr (RPL == 0) {
+    // BOUND pass (class 0): no candidates are kept.  Every lane tracks the smallest key among its rows; the
+    // keff-th smallest of the 512 lane minima -- keys of keff distinct rows of this query -- is an upper bound of
+    // the query's final keff-th distance (within a few ranks of the partition's exact keff-th: two of the best
+    // keff rows rarely share a lane).  It seeds Tglobal, so the main pass prunes every partition, this one
+    // included, from its first row, and nobody pays for selecting among unfiltered rows.
+    uint32_t mn0 = 0xFFFFFFFFu, mn1 = 0xFFFFFFFFu;
+    uint4 cwb[MU];
+    if ((int)threadIdx.x < np) {
+#pragma unroll
+      for (int w = 0; w < MU; ++w) cwb[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)threadIdx.x * m + w * 16);
+    }
+    for (int base = 0; base < np; base += PM_BS) {
+      const int row = base + threadIdx.x;
+      uint4 cwc[MU];
+#pragma unroll
+      for (int w = 0; w < MU; ++w) cwc[w] = cwb[w];
+      if (row + PM_BS < np) {
+#pragma unroll
+        for (int w = 0; w < MU; ++w) cwb[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)(row + PM_BS) * m + w * 16);
+      }
+      if (row < np) {
+        float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MU; ++w) {
+          const uint32_t cws[4] = {cwc[w].x, cwc[w].y, cwc[w].z, cwc[w].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+              d0 += v.x; d1 += v.y;
+            }
+        }
+        if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
+        mn0 = min(mn0, order_key(d0));
+        mn1 = min(mn1, order_key(d1));
+      }
+    }
+    kth_smallest_bs<PM_BS>(mn0, p.keff - 1, sorted, &misc[4]);
+    if (threadIdx.x == 0 && misc[4] != 0xFFFFFFFFu) atomicMin(&p.tglobal[q0], misc[4]);
+    __syncthreads();
+    if (has1) {
+      kth_smallest_bs<PM_BS>(mn1, p.keff - 1, sorted, &misc[4]);
+      if (threadIdx.x == 0 && misc[4] != 0xFFFFFFFFu) atomicMin(&p.tglobal[q1], misc[4]);
+    }
+    return;
+  }
+  constexpr int RP = RPL == 0 ? 1 : RPL;
   // software pipeline: the code bytes of round r+1 are requested before round r's gathers, so the L2/HBM
   // latency of the (only) global load in the loop overlaps LDS work
-  constexpr int ROUND = PM_BS * RPL;
-  uint4 cwn[RPL][MU];
+  constexpr int ROUND = PM_BS * RP;
+  uint4 cwn[RP][MU];
 #pragma unroll
-  for (int u = 0; u < RPL; ++u) {
+  for (int u = 0; u < RP; ++u) {
     const int row = u * PM_BS + threadIdx.x;
     if (row < np) {
 #pragma unroll
@@ -330,37 +381,84 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     const uint32_t k0 = order_key(d0), k1 = order_key(d1);
     if (k0 <= T0) {
       const uint32_t slot = atomicAdd(&misc[0], 1u);
-      if (slot < PM_CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+      if (slot < CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
     }
     if (has1 && k1 <= T1) {
       const uint32_t slot = atomicAdd(&misc[2], 1u);
-      if (slot < PM_CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+      if (slot < CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+    }
+  };
+  // class 0 (no bound yet: most rows are candidates): one LDS atomic per wave and buffer instead of one per lane
+  auto scan_rows_agg = [&](int base, int u, const uint4 (&cw)[MU], uint32_t T0, uint32_t T1) {
+    const int row = base + u * PM_BS + threadIdx.x;
+    const bool live = row < np;
+    float d0 = 0.0f, d1 = 0.0f;
+    if (live && !(p.ablate & 4)) {
+#pragma unroll
+      for (int w = 0; w < MU; ++w) {
+        const uint32_t cws[4] = {cw[w].x, cw[w].y, cw[w].z, cw[w].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+            d0 += v.x; d1 += v.y;
+          }
+      }
+    }
+    if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
+    const uint32_t k0 = order_key(d0), k1 = order_key(d1);
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const bool p0 = live && k0 <= T0 && !(p.ablate & 1), p1 = live && has1 && k1 <= T1 && !(p.ablate & 1);
+    const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
+    if (m0) {
+      uint32_t b0s = 0;
+      if (lane == __ffsll((long long)m0) - 1) b0s = atomicAdd(&misc[0], (uint32_t)__popcll(m0));
+      b0s = __shfl(b0s, __ffsll((long long)m0) - 1);
+      if (p0) {
+        const uint32_t slot = b0s + (uint32_t)__popcll(m0 & below);
+        if (slot < CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+      }
+    }
+    if (m1) {
+      uint32_t b1s = 0;
+      if (lane == __ffsll((long long)m1) - 1) b1s = atomicAdd(&misc[2], (uint32_t)__popcll(m1));
+      b1s = __shfl(b1s, __ffsll((long long)m1) - 1);
+      if (p1) {
+        const uint32_t slot = b1s + (uint32_t)__popcll(m1 & below);
+        if (slot < CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
+      }
     }
   };
   for (int base = 0; base < np; base += ROUND) {
-    constexpr int LIMIT = RPL == 1 ? PM_CAP - PM_BS : PM_CAP / 2;
-    if ((int)misc[0] > LIMIT) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
-    if ((int)misc[2] > LIMIT) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
+    constexpr int LIMIT = RP == 1 ? CAP - PM_BS : CAP / 2;
+    if ((int)misc[0] > LIMIT && !(p.ablate & 2)) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
+    if ((int)misc[2] > LIMIT && !(p.ablate & 2)) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
     const uint32_t cnt0_before = misc[0], cnt1_before = misc[2];
     const uint32_t T0 = misc[1], T1 = misc[3];
-    uint4 cwc[RPL][MU];
+    uint4 cwc[RP][MU];
 #pragma unroll
-    for (int u = 0; u < RPL; ++u)
+    for (int u = 0; u < RP; ++u)
 #pragma unroll
       for (int w = 0; w < MU; ++w) cwc[u][w] = cwn[u][w];
 #pragma unroll
-    for (int u = 0; u < RPL; ++u) {
+    for (int u = 0; u < RP; ++u) {
       const int rown = base + ROUND + u * PM_BS + threadIdx.x;
       if (rown < np) {
 #pragma unroll
         for (int w = 0; w < MU; ++w) cwn[u][w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)rown * m + w * 16);
       }
     }
+    if (RP == 1 && (p.ablate & 8)) {
+      scan_rows_agg(base, 0, cwc[0], T0, T1);
+    } else {
 #pragma unroll
-    for (int u = 0; u < RPL; ++u) scan_rows(base, u, cwc[u], T0, T1);
+      for (int u = 0; u < RP; ++u) scan_rows(base, u, cwc[u], T0, T1);
+    }
     __syncthreads();
-    if constexpr (RPL > 1) {
-      // optimistic round overflowed a buffer (more than PM_CAP/2 rows under the bound in 2 sub-rounds): roll the
+    if constexpr (RP > 1) {
+      // optimistic round overflowed a buffer (more than CAP/2 rows under the bound in 2 sub-rounds): roll the
       // round back and replay it one sub-round at a time with a capacity check before each (cannot overflow
       // unless more than 256 rows tie at the bound, which is flagged for the exact kernel)
       if (misc[5] & ROUND_OVF) {
@@ -368,9 +466,9 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
         if (threadIdx.x == 0) { misc[0] = cnt0_before; misc[2] = cnt1_before; misc[5] &= ~ROUND_OVF; }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < RPL; ++u) {
-          if ((int)misc[0] > PM_CAP - PM_BS) tighten_bs<PM_BS, PM_CAP>(b0, p.keff, sorted, &misc[4]);
-          if ((int)misc[2] > PM_CAP - PM_BS) tighten_bs<PM_BS, PM_CAP>(b1, p.keff, sorted, &misc[4]);
+        for (int u = 0; u < RP; ++u) {
+          if ((int)misc[0] > CAP - PM_BS) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
+          if ((int)misc[2] > CAP - PM_BS) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
           scan_rows(base, u, cwc[u], misc[1], misc[3]);
           __syncthreads();
         }
@@ -395,10 +493,10 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     const int qj = j ? q1 : q0;
     if (*b.cnt == 0) continue;  // uniform: nothing of this partition can reach the query's top list
     // <= PM_BS entries -> one entry per lane -> the bound is the exact keff-th smallest: publish ~keff rows
-    if ((int)*b.cnt > p.keff + 32) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
-    if ((int)*b.cnt > PM_BS) tighten_bs<PM_BS, PM_CAP>(b, p.keff, sorted, &misc[4]);
+    if ((int)*b.cnt > p.keff + 32) tighten_bs<PM_BS, CAP>(b, p.keff, sorted, &misc[4]);
+    if ((int)*b.cnt > PM_BS) tighten_bs<PM_BS, CAP>(b, p.keff, sorted, &misc[4]);
     __syncthreads();
-    const int c = min((int)*b.cnt, PM_CAP);
+    const int c = min((int)*b.cnt, CAP);
     __shared__ uint32_t s_base, s_tg;
     if (threadIdx.x == 0) {
       // *b.T is always a valid upper bound of this query's final keff-th distance: it is either the value read
@@ -497,12 +595,15 @@ __global__ __launch_bounds__(256) void ivfpq_merge_pm_kernel(const uint32_t *__r
 template <int SD, int METRIC>
 static bool launch_pm_mu(lance_hip_ctx *ctx, const PmArgs &a, unsigned grid, size_t lds) {
   const int mu = a.m / 16;
-  if (a.cls == 0) {
-    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
-    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+  if (a.cls == 0 && a.bound_pass) {
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 0, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 0, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+  } else if (a.cls == 0) {   // LANCE_HIP_PM_NOBOUND=1: the earlier two-class flow (class 0 selects among unfiltered rows)
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   } else {
-    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, PM_RPL1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
-    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, PM_RPL1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   }
   return false;
 }
@@ -557,17 +658,22 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.desc = desc;
+  { const char *ab = getenv("LANCE_HIP_PM_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const int dpad = (d + 3) & ~3;
-  const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + (size_t)PM_CAP * 16 + PM_BS * 4 + 8 * 4;
+  const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4 + (size_t)PM_CAP * 16;
   {
-    for (int cls = 0; cls < 2; ++cls) {
-      if (cls == 1 && nprobes == 1) break;
-      ScopedTimer t(ctx, cls == 0 ? "ivfpq_scan_c0" : "ivfpq_scan_c1");
-      a.cls = cls;
-      // upper bound of sum ceil(c_vp / 2) over the class; surplus workgroups exit at once
-      const size_t cpairs = cls == 0 ? (size_t)nq : (size_t)nq * (nprobes - 1);
-      const unsigned grid = (unsigned)(cpairs / 2 + nlist + 1);
+    // pass 0 (bound): every query's nearest partition is streamed once to seed Tglobal[q]; pass 1 (main): all
+    // (query, probe) pairs, nearest partition included, prune with that bound from their first row.
+    const bool nobound = getenv("LANCE_HIP_PM_NOBOUND") != nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (nobound && pass == 1 && nprobes == 1) break;
+      ScopedTimer t(ctx, pass == 0 ? "ivfpq_scan_c0" : "ivfpq_scan_c1");
+      a.cls = pass == 0 ? 0 : (nobound ? 1 : 2);
+      a.bound_pass = (pass == 0 && !nobound) ? 1 : 0;
+      // upper bound of sum ceil(c_vp / 2) over the covered virtual partitions; surplus workgroups exit at once
+      const size_t cpairs = a.cls == 0 ? (size_t)nq : (a.cls == 1 ? (size_t)nq * (nprobes - 1) : (size_t)nq * nprobes);
+      const unsigned grid = (unsigned)(cpairs / 2 + (a.cls == 2 ? 2 : 1) * nlist + 1);
       bool ok = false;
       if (scan_metric == LANCE_HIP_DOT) {
         if (sd == 4) ok = launch_pm_mu<4, METRIC_DOT>(ctx, a, grid, lds);
