@@ -53,6 +53,13 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
     // T = half::f16: `*c += *v` and `*v *= norm` are f16 operations (f32 op, round to binary16)
     for (; i < e; ++i) acc = __half2float(__float2half_rn(acc + xb[(int64_t)rows[i] * ldx]));
   } else {
+    for (; i + 32 <= e; i += 32) {      // 32 gathers in flight per lane; the adds stay in row order
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = xb[(int64_t)rows[i + u] * ldx];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += v[u];
+    }
     for (; i + 8 <= e; i += 8) {
       float v[8];
 #pragma unroll
@@ -76,15 +83,19 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
   cent[(int64_t)b * cent_batch_stride + (int64_t)c * d + dim] = acc;
 }
 
-// one lane per centroid: loss (f64, row order), radius, index of the last member row.
+// one WAVE per centroid: the 64 lanes fetch 64 member distances at a time (two dependent loads, but 64 wide),
+// lane 0 then adds them in row order -- the f64 chain of kmeans.rs:274-277 is kept, only its operands are
+// fetched in parallel.  (One lane per centroid spent 70 us per iteration on 2 x 32 serial memory round trips.)
 __global__ __launch_bounds__(256) void kmeans_stats_kernel(const float *__restrict__ dists, int64_t dist_stride, int k,
                                                            const uint32_t *__restrict__ sorted_rows, int64_t rows_stride,
                                                            const uint32_t *__restrict__ starts, double *__restrict__ losses,
                                                            float *__restrict__ radius, uint32_t *__restrict__ last_row,
                                                            const uint8_t *__restrict__ active) {
+  __shared__ __attribute__((aligned(16))) float buf[4][2][64];
   const int b = blockIdx.y;
   if (active && !active[b]) return;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + wave;
   if (c >= k) return;
   const uint32_t *st = starts + (int64_t)b * (k + 1);
   const uint32_t *rows = sorted_rows + (int64_t)b * rows_stride;
@@ -92,26 +103,35 @@ __global__ __launch_bounds__(256) void kmeans_stats_kernel(const float *__restri
   double loss = 0.0;
   float rad = 0.0f;
   const uint32_t s = st[c], e = st[c + 1];
-  uint32_t i = s;
-  // gathers issued 8 at a time; the f64 chain itself stays in row order (kmeans.rs:274-277)
-  for (; i + 8 <= e; i += 8) {
-    float dv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dv[u] = db[rows[i + u]];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      rad = fmaxf(rad, dv[u]);  // f32::max
-      loss += (double)dv[u];
+  int pb = 0;
+  float nxt = (s + lane < e) ? db[rows[s + lane]] : 0.0f;
+  for (uint32_t i = s; i < e; i += 64) {
+    buf[wave][pb][lane] = nxt;
+    const uint32_t j = i + 64 + lane;
+    nxt = j < e ? db[rows[j]] : 0.0f;           // next chunk in flight while lane 0 adds this one
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      const int cnt = (int)min(64u, e - i);
+      const float *v = buf[wave][pb];
+      int t = 0;
+      for (; t + 4 <= cnt; t += 4) {
+        const f4 q4 = *reinterpret_cast<const f4 *>(v + t);
+        rad = fmaxf(rad, q4.x); loss += (double)q4.x;   // f32::max; f64 chain in row order
+        rad = fmaxf(rad, q4.y); loss += (double)q4.y;
+        rad = fmaxf(rad, q4.z); loss += (double)q4.z;
+        rad = fmaxf(rad, q4.w); loss += (double)q4.w;
+      }
+      for (; t < cnt; ++t) { rad = fmaxf(rad, v[t]); loss += (double)v[t]; }
     }
+    pb ^= 1;
   }
-  for (; i < e; ++i) {
-    const float dv = db[rows[i]];
-    rad = fmaxf(rad, dv);
-    loss += (double)dv;
+  if (lane == 0) {
+    losses[(int64_t)b * k + c] = loss;
+    radius[(int64_t)b * k + c] = rad;
+    last_row[(int64_t)b * k + c] = e > s ? rows[e - 1] : 0xFFFFFFFFu;
   }
-  losses[(int64_t)b * k + c] = loss;
-  radius[(int64_t)b * k + c] = rad;
-  last_row[(int64_t)b * k + c] = e > s ? rows[e - 1] : 0xFFFFFFFFu;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, int64_t ldx, int x_batch_off, int d,
@@ -231,7 +251,7 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
     LH_TRY(stable_group(ctx, ids, n, n, k, B, starts, sorted_rows, n, active_d));
     {
       ScopedTimer t(ctx, "kmeans_mstep");
-      hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 256), B), dim3(256), 0, ctx->stream, dists, n, k,
+      hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 4), B), dim3(256), 0, ctx->stream, dists, n, k,
                          sorted_rows, n, starts, losses_d, radius_d, last_d, active_d);
       hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), B), dim3(256), 0, ctx->stream,
                          x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1, f16_arith ? 1 : 0);
@@ -588,7 +608,7 @@ int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, co
   pa.ids = ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
   LH_TRY(launch_assign(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
   LH_TRY(stable_group(ctx, ids, (int64_t)n, (int64_t)n, (int)k, 1, starts, sorted_rows, (int64_t)n, nullptr));
-  hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 256), 1), dim3(256), 0, ctx->stream, dists, (int64_t)n, (int)k,
+  hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 4), 1), dim3(256), 0, ctx->stream, dists, (int64_t)n, (int)k,
                      sorted_rows, (int64_t)n, starts, losses_d, radius_d, last_d, (const uint8_t *)nullptr);
   hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), 1), dim3(256), 0, ctx->stream,
                      static_cast<const float *>(x), (int64_t)d, 0, (int)d, (int)k, sorted_rows, (int64_t)n, starts, buf, (int64_t)k * d,

@@ -264,7 +264,8 @@ template <int D, int MODE>
 static int launch_fixed(lance_hip_ctx *ctx, PairwiseArgs p, int metric, int batches) {
   constexpr int CT = (8192 / D) > 256 ? 256 : (8192 / D);
   const int ntiles = (int)cdiv(p.k, CT);
-  const int64_t want = 2ll * ctx->num_cus;
+  static const int want_mul = getenv("LANCE_HIP_ASSIGN_WANT") ? atoi(getenv("LANCE_HIP_ASSIGN_WANT")) : 2;
+  const int64_t want = (int64_t)want_mul * ctx->num_cus;
   int bs = 256;
   if ((int64_t)cdiv(p.n, 256) * batches * ntiles < want) bs = 64;
   int ksplit = 1;
