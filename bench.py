@@ -145,6 +145,30 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- informational (never `value`): the same steps when the boundary hands over HOST buffers -- every step
+    # copies its query batch from pinned host memory and its results back (PCIe inclusive) ------------------
+    pcie_qps = None
+    if world == 1:
+        hq = [qb.cpu().pin_memory() for qb in qbatches]
+        h_ids = torch.empty((args.nq, args.k), dtype=torch.int64).pin_memory()
+        h_d = torch.empty((args.nq, args.k), dtype=torch.float32).pin_memory()
+        dq = torch.empty_like(qbatches[0])
+
+        def host_step(i):
+            dq.copy_(hq[i % 4], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            idx.search_device(dq, args.k, args.nprobes, args.refine, out=(out_ids, out_d), sync=False)
+            eng.synchronize()
+            h_ids.copy_(out_ids, non_blocking=True); h_d.copy_(out_d, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+
+        for i in range(2):
+            host_step(i)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            host_step(i)
+        pcie_qps = args.nq * args.steps / (time.perf_counter() - t1)
+
     ms_per_step = elapsed / args.steps * 1e3
     qps = world * args.nq * args.steps / elapsed
     if kt["ivfpq_scan_c1"][1] > 0:      # partition-major path: dominant launch = class 1
@@ -186,6 +210,7 @@ def main():
                    "parallelism": f"replica x{world}" if world > 1 else "single"},
         "recall_at_10": recall,
         "exact_replays_last_step": exact_replays,
+        "host_buffers_qps_pcie_inclusive": pcie_qps,
         "build_sec": build_sec,
         "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
         "kernel_ms_per_step": {k_: round(v[0] / max(v[1], 1), 4) for k_, v in kt.items()},

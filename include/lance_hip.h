@@ -209,6 +209,19 @@ int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x
                         uint64_t n, uint32_t d, const void *q, uint32_t nq, uint32_t k, uint64_t *ids,
                         float *dists);
 
+/* ---- N4: IVF_FLAT (FlatIndex sub-index over raw vectors: flat/index.rs:82-177, flat/storage.rs:345-402) ------ */
+/* Builds the per-partition FlatFloatStorage on the device: x[n][d] (dtype elements, widened exactly to f32) is
+ * gathered into partition order (stable, rows with part id LANCE_HIP_NONE dropped).  L2 and Dot.
+ * The handle is destroyed with lance_hip_index_destroy.                                               */
+int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids,
+                             uint32_t nlist, const void *x, const uint32_t *part_ids, const uint64_t *row_ids,
+                             uint64_t n, lance_hip_index **out);
+/* find_partitions + exact scan of the nprobes partitions + SortExec(dist, rowid).fetch(k); k <= 128.
+ * When one partition holds more than k rows at or below a tied k-th distance, the survivors are those FlatIndex's
+ * BinaryHeap keeps (such queries are replayed through a heap with std's push/pop, as in the IVF_PQ path). */
+int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                             uint32_t nprobes, uint64_t *ids, float *dists);
+
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx stream --- */
 /* When enabled, each internal launch of the named hot kernels is bracketed by events;
  * query returns accumulated milliseconds and launch count, then resets.              */

@@ -181,6 +181,7 @@ lance_hip_index::~lance_hip_index() {
   if (part_offsets) (void)hipFree(part_offsets);
   if (codes) (void)hipFree(codes);
   if (row_ids) (void)hipFree(row_ids);
+  if (vectors) (void)hipFree(vectors);
 }
 
 extern "C" {

@@ -16,7 +16,9 @@
 
 #include "common.h"
 #include "exact.cuh"
+#include "index.h"
 #include "kernels.h"
+#include "search_common.cuh"
 
 #pragma clang fp contract(off)
 
@@ -436,9 +438,399 @@ static void launch_flat_fixed(lance_hip_ctx *ctx, const FlatArgs &a, int metric,
     hipLaunchKernelGGL((flat_scan_kernel<D, METRIC_L2, TR>), grid, dim3(256), 0, ctx->stream, a);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// IVF_FLAT (IvfSubIndex = FlatIndex over FlatFloatStorage): find_partitions, then an exact scan of the raw
+// vectors of every probed partition and the (dist, rowid) merge.
+//   FlatIndex::search            lance-index/src/vector/flat/index.rs:82-177
+//   FlatDistanceCal::distance_all  flat/storage.rs:345-402  (distance_type.func()(query, vector): a1 / a2 order)
+//   SortExec merge               lance/src/dataset/scanner.rs:3440-3468
+// One workgroup per (query, probe): the query sits in LDS (negated for L2), lanes own rows of the partition.
+// Pass 0 (bound) walks each query's nearest partition and takes the k-th smallest of the 256 lane minima as the
+// query's threshold; pass 1 walks all probed partitions and appends rows under the threshold to the query's
+// pool; flat_select_kernel sorts the pool by (dist, rowid).  Same pool / overflow-repair machinery as flat v2.
+struct IvfFlatArgs {
+  const float *vec;              // [n][d] partition-ordered
+  const uint64_t *row_ids;       // [n]
+  const uint32_t *part_offsets;  // [nlist+1]
+  const uint32_t *probes;        // [nq][nprobes]
+  const float *q;                // [nq][d]
+  int nprobes, d, bound;
+  uint32_t *ppart;               // [nq][cap] partition of every pool entry (boundary-tie check)
+  uint32_t *flags;               // [nq] 1 = the survivors of a boundary tie depend on the reference heap: replay
+  FlatPool pool;
+};
+
+// k-th smallest (rank kk) of one u32 per lane of a 256-lane workgroup
+__device__ __forceinline__ uint32_t kth_smallest_256(uint32_t v, int kk, uint32_t *sorted, uint32_t *slot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      const uint32_t o = __shfl_xor(v, j, 64);
+      const bool up = (lane & k2) == 0, lower = (lane & j) == 0;
+      v = (lower == up) ? min(v, o) : max(v, o);
+    }
+  }
+  sorted[threadIdx.x] = v;
+  __syncthreads();
+  int rank = lane;
+  for (int w = 0; w < 4; ++w) {
+    if (w == wave) continue;
+    const uint32_t *run = sorted + w * 64;
+    int lo = 0, hi = 64;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const bool before = w < wave ? run[mid] <= v : run[mid] < v;
+      if (before) lo = mid + 1; else hi = mid;
+    }
+    rank += lo;
+  }
+  if (rank == kk) *slot = v;
+  __syncthreads();
+  return *slot;
+}
+
+template <int D, int METRIC>   // D = 0: run-time dimension
+__global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float qt[];   // [d padded to 4]
+  __shared__ uint32_t sorted[256];
+  __shared__ uint32_t slot;
+  const int qi = a.bound ? blockIdx.x : blockIdx.x / a.nprobes;
+  const int pr = a.bound ? 0 : blockIdx.x % a.nprobes;
+  const uint32_t part = a.probes[(int64_t)qi * a.nprobes + pr];
+  const uint32_t r0 = a.part_offsets[part], r1 = a.part_offsets[part + 1];
+  constexpr bool NEG = METRIC != METRIC_DOT && D != 0;
+  for (int i = threadIdx.x; i < a.d; i += 256) {
+    const float v = a.q[(int64_t)qi * a.d + i];
+    qt[i] = NEG ? -v : v;
+  }
+  const uint32_t tk = a.bound ? 0xFFFFFFFFu : a.pool.tkey[qi];
+  const uint64_t tr = ~0ull;   // every row tied with the bound stays in the pool: the tie check below needs all of them
+  __syncthreads();
+  uint32_t mn = 0xFFFFFFFFu;
+  for (uint32_t base = r0; base < r1; base += 256) {
+    const uint32_t row = base + threadIdx.x;
+    if (row < r1) {
+      float v;
+      if constexpr (D != 0) {
+        RegVec<D> rv;
+        const float *src = a.vec + (int64_t)row * D;
+#pragma unroll
+        for (int i = 0; i < D / 4; ++i) rv.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
+        v = finish_metric<METRIC>(dist_exact<D, METRIC, NEG>(rv, qt));
+      } else {
+        v = finish_metric<METRIC>(dist_exact_rt<METRIC>(qt, a.vec + (int64_t)row * a.d, a.d));
+      }
+      const uint32_t key = order_key(v);
+      if (a.bound) {
+        mn = min(mn, key);
+      } else {
+        const uint64_t rid = a.row_ids[row];
+        if (key < tk || (key == tk && rid <= tr)) {
+          const uint32_t pos = atomicAdd(&a.pool.cnt[qi], 1u);
+          if (pos < (uint32_t)a.pool.cap) {
+            a.pool.pkeys[(int64_t)qi * a.pool.cap + pos] = key;
+            a.pool.prids[(int64_t)qi * a.pool.cap + pos] = rid;
+            a.ppart[(int64_t)qi * a.pool.cap + pos] = part;
+          }
+        }
+      }
+    }
+  }
+  if (a.bound) {
+    if (threadIdx.x == 0) slot = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t t = kth_smallest_256(mn, a.pool.k - 1, sorted, &slot);
+    if (threadIdx.x == 0) a.pool.tkey[qi] = t;     // 0xFFFFFFFF when the partition has fewer than k rows
+  }
+}
+
+
+// per-query: sort the pool by (key, rowid), emit the best k, tighten T (repair rounds), and detect the one case
+// the (dist, rowid) order cannot decide: more than k rows of ONE partition at or below the k-th distance with a tie
+// at the boundary -- there FlatIndex's BinaryHeap (flat/index.rs:113-123) decides which tied rows survive.
+__global__ __launch_bounds__(256) void ivfflat_select_kernel(IvfFlatArgs a, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
+  extern __shared__ __attribute__((aligned(16))) char ssm[];
+  const FlatPool &p = a.pool;
+  const int q = blockIdx.x;
+  const uint32_t total = p.cnt[q];
+  const int c = (int)min(total, (uint32_t)p.cap);
+  if (total > (uint32_t)p.cap && threadIdx.x == 0) atomicOr(p.overflow, 1u);
+  int P = 64;
+  while (P < c) P <<= 1;
+  uint64_t *rid = reinterpret_cast<uint64_t *>(ssm);
+  uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
+  uint32_t *prt = key + P;
+  __shared__ int s_amb;
+  if (threadIdx.x == 0) s_amb = 0;
+  for (int i = threadIdx.x; i < P; i += 256) {
+    key[i] = i < c ? p.pkeys[(int64_t)q * p.cap + i] : 0xFFFFFFFFu;
+    rid[i] = i < c ? p.prids[(int64_t)q * p.cap + i] : ~0ull;
+    prt[i] = i < c ? a.ppart[(int64_t)q * p.cap + i] : 0u;
+  }
+  __syncthreads();
+  bitonic_sort_kr<256>(key, rid, prt, P);
+  if (threadIdx.x == 0 && c >= p.k) { p.tkey[q] = key[p.k - 1]; p.trid[q] = ~0ull; }
+  if (c > p.k && key[p.k] == key[p.k - 1]) {
+    const uint32_t tf = key[p.k - 1];
+    int lo = p.k, hi = c;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] <= tf) lo = mid + 1; else hi = mid; }
+    const int L = lo;
+    for (int i = threadIdx.x; i < L; i += 256) {
+      int same = 0;
+      for (int j = 0; j < L; ++j) same += prt[j] == prt[i] ? 1 : 0;
+      if (same > p.k) s_amb = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.flags[q] = (uint32_t)s_amb;
+  const int keep = min(c, p.k);
+  for (int i = threadIdx.x; i < p.k; i += 256) {
+    const bool ok = i < keep;
+    out_ids[(int64_t)q * p.k + i] = ok ? rid[i] : ~0ull;
+    out_dists[(int64_t)q * p.k + i] = ok ? key_to_float(key[i]) : INFINITY;
+  }
+}
+
+// Exact replay of a flagged query: every probed partition through a max-heap of k with std BinaryHeap semantics
+// (push while len < k, else replace the root only if root.dist > dist), rows in scan order; distances by all 64
+// lanes, a ballot drops rows that cannot enter, lane 0 replays the rest; partition heaps are merged by (dist, rowid).
+template <int METRIC>
+__global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int qi = blockIdx.x;
+  if (!a.flags[qi]) return;
+  const int lane = threadIdx.x, k = a.pool.k;
+  const int dpad = (a.d + 3) & ~3;
+  float *qv = reinterpret_cast<float *>(smem);
+  uint64_t *trid = reinterpret_cast<uint64_t *>(qv + dpad + (dpad & 1));
+  uint32_t *tkey = reinterpret_cast<uint32_t *>(trid + k);
+  uint32_t *hk = tkey + k;
+  uint32_t *hp = hk + k + 1;
+  uint32_t *skey = hp + k + 1;
+  __shared__ int s_hlen, s_tcnt;
+  if (lane == 0) { s_hlen = 0; s_tcnt = 0; }
+  for (int t = lane; t < a.d; t += 64) qv[t] = a.q[(int64_t)qi * a.d + t];
+  __syncthreads();
+  for (int pi = 0; pi < a.nprobes; ++pi) {
+    const uint32_t part = a.probes[(int64_t)qi * a.nprobes + pi];
+    const uint32_t off = a.part_offsets[part];
+    const int np = (int)(a.part_offsets[part + 1] - off);
+    if (np == 0) continue;
+    if (lane == 0) s_hlen = 0;
+    __syncthreads();
+    for (int base = 0; base < np; base += 64) {
+      const int row = base + lane;
+      uint32_t key = 0xFFFFFFFFu;
+      bool cand = false;
+      if (row < np) {
+        key = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, a.vec + (int64_t)(off + row) * a.d, a.d)));
+        cand = s_hlen < k || key < hk[0];
+      }
+      const uint64_t mask = __ballot(cand);
+      skey[lane] = key;
+      __syncthreads();
+      if (lane == 0 && mask) {
+        int hl = s_hlen;
+        uint64_t mm = mask;
+        while (mm) {
+          const int b = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          const uint32_t kk = skey[b];
+          if (hl < k) {
+            heap_push(hk, hp, hl, kk, off + (uint32_t)(base + b));
+          } else if (hk[0] > kk) {
+            heap_pop(hk, hp, hl);
+            heap_push(hk, hp, hl, kk, off + (uint32_t)(base + b));
+          }
+        }
+        s_hlen = hl;
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      int tc = s_tcnt;
+      for (int i = 0; i < s_hlen; ++i) {
+        const uint32_t kk = hk[i];
+        const uint64_t rr = a.row_ids[hp[i]];
+        if (tc == k) {
+          const uint32_t wk = tkey[tc - 1];
+          const uint64_t wr = trid[tc - 1];
+          if (!(kk < wk || (kk == wk && rr < wr))) continue;
+        }
+        int pos = tc < k ? tc : k - 1;
+        while (pos > 0) {
+          const uint32_t pk = tkey[pos - 1];
+          const uint64_t pr = trid[pos - 1];
+          if (pk < kk || (pk == kk && pr < rr)) break;
+          tkey[pos] = pk; trid[pos] = pr;
+          --pos;
+        }
+        tkey[pos] = kk; trid[pos] = rr;
+        if (tc < k) ++tc;
+      }
+      s_tcnt = tc;
+    }
+    __syncthreads();
+  }
+  const int got = s_tcnt;
+  for (int i = lane; i < k; i += 64) {
+    out_ids[(int64_t)qi * k + i] = i < got ? trid[i] : ~0ull;
+    out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(tkey[i]) : INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_vectors_kernel(const float *__restrict__ x, const uint64_t *__restrict__ row_ids,
+                                                             const uint32_t *__restrict__ perm, int64_t n_out, int d,
+                                                             float *__restrict__ out, uint64_t *__restrict__ rid_out) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n_out * d) return;
+  const int64_t s = g / d;
+  const uint32_t r = perm[s];
+  out[g] = x[(int64_t)r * d + (g - s * d)];
+  if (g == s * d) rid_out[s] = row_ids ? row_ids[r] : (uint64_t)r;
+}
+
+template <int METRIC>
+static void launch_ivfflat(lance_hip_ctx *ctx, const IvfFlatArgs &a, unsigned grid, bool fixed) {
+  const size_t lds = (size_t)((a.d + 3) & ~3) * 4;
+  if (fixed) {
+    switch (a.d) {
+      case 8: hipLaunchKernelGGL((ivfflat_kernel<8, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
+      case 16: hipLaunchKernelGGL((ivfflat_kernel<16, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
+      case 32: hipLaunchKernelGGL((ivfflat_kernel<32, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
+      case 64: hipLaunchKernelGGL((ivfflat_kernel<64, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
+      case 96: hipLaunchKernelGGL((ivfflat_kernel<96, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
+      case 128: hipLaunchKernelGGL((ivfflat_kernel<128, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
+      default: break;
+    }
+  }
+  hipLaunchKernelGGL((ivfflat_kernel<0, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a);
+}
+
 }  // namespace lh
 
 using namespace lh;
+
+extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,
+                                        const void *x, const uint32_t *part_ids, const uint64_t *row_ids, uint64_t n,
+                                        lance_hip_index **out) {
+  LH_REQUIRE(ctx && centroids && out && (n == 0 || (x && part_ids)), "ivfflat_create: NULL argument");
+  LH_TRY(check_dtype(dtype, "ivfflat_create"));
+  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT, "ivfflat_create: metric must be L2 or Dot in this version");
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "ivfflat_create: f16 dot is not implemented in this version");
+  LH_REQUIRE(nlist > 0 && nlist <= 8192 && d > 0, "ivfflat_create: nlist=%u / d=%u not supported", nlist, d);
+  LH_REQUIRE(n < (1ull << 32), "ivfflat_create: n too large for this version");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  auto *ix = new lance_hip_index();
+  ix->device = ctx->device; ix->metric = metric; ix->dtype = dtype; ix->d = d; ix->nlist = nlist; ix->m = 0;
+  auto fail = [&](int r) { delete ix; return r; };
+  if (hipMalloc(reinterpret_cast<void **>(&ix->centroids), (size_t)nlist * d * 4) != hipSuccess) return fail(LANCE_HIP_ENOMEM);
+  if (hipMalloc(reinterpret_cast<void **>(&ix->part_offsets), (size_t)(nlist + 1) * 4) != hipSuccess) return fail(LANCE_HIP_ENOMEM);
+  int r = widen_into(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, ix->centroids);
+  if (r != LANCE_HIP_OK) return fail(r);
+  uint32_t *perm = ctx->scratch_t<uint32_t>("index.perm", (size_t)(n ? n : 1));
+  if (!perm) return fail(LANCE_HIP_ENOMEM);
+  r = stable_group(ctx, part_ids, (int64_t)n, (int64_t)n, (int)nlist, 1, ix->part_offsets, perm, (int64_t)n, nullptr);
+  if (r != LANCE_HIP_OK) return fail(r);
+  ix->part_offsets_h.resize(nlist + 1);
+  if (hipMemcpyAsync(ix->part_offsets_h.data(), ix->part_offsets, (size_t)(nlist + 1) * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("ivfflat_create: HIP failure"); return fail(LANCE_HIP_ERUNTIME); }
+  ix->n = ix->part_offsets_h[nlist];       // rows with part id NONE (non-finite vectors) are dropped
+  for (uint32_t p = 0; p < nlist; ++p) ix->max_part = std::max(ix->max_part, ix->part_offsets_h[p + 1] - ix->part_offsets_h[p]);
+  if (hipMalloc(reinterpret_cast<void **>(&ix->vectors), std::max<size_t>((size_t)ix->n * d * 4, 16)) != hipSuccess) return fail(LANCE_HIP_ENOMEM);
+  if (hipMalloc(reinterpret_cast<void **>(&ix->row_ids), std::max<size_t>((size_t)ix->n * 8, 16)) != hipSuccess) return fail(LANCE_HIP_ENOMEM);
+  const float *xf;
+  r = as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf);
+  if (r != LANCE_HIP_OK) return fail(r);
+  if (ix->n > 0) {
+    hipLaunchKernelGGL(gather_vectors_kernel, dim3((unsigned)cdiv((uint64_t)ix->n * d, 256)), dim3(256), 0, ctx->stream, xf, row_ids, perm,
+                       (int64_t)ix->n, (int)d, ix->vectors, ix->row_ids);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      set_error("ivfflat_create: gather kernel failed");
+      return fail(LANCE_HIP_ERUNTIME);
+    }
+  }
+  *out = ix;
+  return LANCE_HIP_OK;
+}
+
+extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                        uint32_t nprobes, uint64_t *ids, float *dists) {
+  LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "ivfflat_search: NULL argument");
+  LH_REQUIRE(idx->m == 0 && idx->vectors, "ivfflat_search: not an IVF_FLAT index");
+  LH_REQUIRE(k > 0 && k <= 128, "ivfflat_search: k=%u not supported (1..128)", k);
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (nq == 0) return LANCE_HIP_OK;
+  if (nprobes > idx->nlist) nprobes = idx->nlist;
+  LH_REQUIRE(nprobes > 0, "ivfflat_search: nprobes must be > 0");
+  const int d = (int)idx->d;
+  const float *qf;
+  LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * d, "f16.q", &qf));
+  uint32_t *probes = ctx->scratch_t<uint32_t>("ivfflat.probes", (size_t)nq * nprobes);
+  float *pd = ctx->scratch_t<float>("ivfflat.pdists", (size_t)nq * nprobes);
+  if (!probes || !pd) return LANCE_HIP_ENOMEM;
+  LH_TRY(lance_hip_find_partitions(ctx, LANCE_HIP_F32, idx->metric, qf, nq, idx->d, idx->centroids, idx->nlist, nprobes, probes, pd));
+  const int qch = (int)std::min<uint32_t>(nq, FLAT_QCHUNK);
+  IvfFlatArgs a;
+  a.vec = idx->vectors; a.row_ids = idx->row_ids; a.part_offsets = idx->part_offsets; a.nprobes = (int)nprobes; a.d = d;
+  FlatPool &pl = a.pool;
+  constexpr int IVFFLAT_CAP = FLAT_CAP / 2;       // 2048 pool entries per query: (key, rowid, partition) sorted in 32 KiB of LDS
+  pl.x = nullptr; pl.row_ids = nullptr; pl.r0 = pl.r1 = 0; pl.k = (int)k; pl.cap = IVFFLAT_CAP;
+  a.ppart = ctx->scratch_t<uint32_t>("ivfflat.ppart", (size_t)qch * IVFFLAT_CAP);
+  a.flags = ctx->scratch_t<uint32_t>("ivfflat.flags", (size_t)qch);
+  if (!a.ppart || !a.flags) return LANCE_HIP_ENOMEM;
+  pl.tkey = ctx->scratch_t<uint32_t>("flat2.tkey", qch);
+  pl.trid = ctx->scratch_t<uint64_t>("flat2.trid", qch);
+  pl.cnt = ctx->scratch_t<uint32_t>("flat2.cnt", qch);
+  pl.pkeys = ctx->scratch_t<uint32_t>("flat2.pkeys", (size_t)qch * FLAT_CAP);
+  pl.prids = ctx->scratch_t<uint64_t>("flat2.prids", (size_t)qch * FLAT_CAP);
+  pl.overflow = ctx->scratch_t<uint32_t>("flat2.ovf", 1);
+  if (!pl.tkey || !pl.trid || !pl.cnt || !pl.pkeys || !pl.prids || !pl.overflow) return LANCE_HIP_ENOMEM;
+  const bool fixed = flat_fixed_dim(idx->d);
+  const size_t sel_lds = (size_t)IVFFLAT_CAP * 16;
+  const size_t ex_lds = (size_t)(((d + 3) & ~3) + 2) * 4 + (size_t)k * 12 + (size_t)(k + 1) * 8 + 64 * 4 + 64;
+  auto finish = [&](int nqc, uint64_t *oid, float *od) {
+    hipLaunchKernelGGL(ivfflat_select_kernel, dim3(nqc), dim3(256), sel_lds, ctx->stream, a, oid, od);
+    ScopedTimer t(ctx, "ivfflat_exact");
+    if (idx->metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
+    else hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_L2>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
+  };
+  auto scan = [&](int bound, int nqc) {
+    a.bound = bound;
+    const unsigned grid = (unsigned)(bound ? nqc : nqc * (int)nprobes);
+    ScopedTimer t(ctx, bound ? "ivfflat_bound" : "ivfflat_scan");
+    if (idx->metric == LANCE_HIP_DOT) launch_ivfflat<METRIC_DOT>(ctx, a, grid, fixed);
+    else launch_ivfflat<METRIC_L2>(ctx, a, grid, fixed);
+  };
+  for (uint32_t qc0 = 0; qc0 < nq; qc0 += (uint32_t)qch) {
+    const int nqc = (int)std::min<uint32_t>((uint32_t)qch, nq - qc0);
+    a.q = qf + (int64_t)qc0 * d;
+    a.probes = probes + (int64_t)qc0 * nprobes;
+    pl.q = a.q; pl.nq = nqc;
+    uint64_t *oid = ids + (int64_t)qc0 * k;
+    float *od = dists + (int64_t)qc0 * k;
+    hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, pl, 1);
+    scan(1, nqc);
+    scan(0, nqc);
+    finish(nqc, oid, od);
+    for (int round = 0; round < 64; ++round) {
+      uint32_t ovf = 0;
+      LH_CHECK_HIP(hipMemcpyAsync(&ovf, pl.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (!ovf) break;
+      LH_REQUIRE(round < 63, "ivfflat_search: candidate pool did not converge");
+      hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, pl, 0);
+      scan(0, nqc);
+      finish(nqc, oid, od);
+    }
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
 
 extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x, const uint64_t *row_ids,
                                    uint64_t n, uint32_t d, const void *q, uint32_t nq, uint32_t k, uint64_t *ids,

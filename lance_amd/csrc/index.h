@@ -15,6 +15,7 @@ struct lance_hip_index {
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition
   uint64_t *row_ids = nullptr;    // [n] in the same order
+  float *vectors = nullptr;       // IVF_FLAT only (m == 0): [n][d] f32 vectors in the same order (flat/storage.rs FlatFloatStorage)
   const void *raw = nullptr;      // borrowed raw vectors (dtype elements) for refine, indexed by row id
   uint64_t n_raw = 0;
   uint32_t max_part = 0;

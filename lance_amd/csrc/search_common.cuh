@@ -90,4 +90,39 @@ __device__ __forceinline__ void select_and_emit(const SelectOut &o, int q, uint3
   }
 }
 
+// ---- std BinaryHeap emulation (shared by the IVF_PQ and IVF_FLAT exact-replay kernels) ----------------
+__device__ __forceinline__ void heap_sift_up(uint32_t *hk, uint32_t *hp, int start, int pos) {
+  const uint32_t ek = hk[pos], ep = hp[pos];
+  while (pos > start) {
+    const int parent = (pos - 1) / 2;
+    if (ek <= hk[parent]) break;
+    hk[pos] = hk[parent]; hp[pos] = hp[parent];
+    pos = parent;
+  }
+  hk[pos] = ek; hp[pos] = ep;
+}
+__device__ __forceinline__ void heap_push(uint32_t *hk, uint32_t *hp, int &len, uint32_t key, uint32_t pos) {
+  hk[len] = key; hp[len] = pos;
+  heap_sift_up(hk, hp, 0, len);
+  ++len;
+}
+// std BinaryHeap::pop: swap last into the root, sift_down_to_bottom(0), then sift_up
+__device__ __forceinline__ void heap_pop(uint32_t *hk, uint32_t *hp, int &len) {
+  --len;
+  if (len == 0) return;
+  const uint32_t ek = hk[len], ep = hp[len];
+  const int end = len;
+  int pos = 0, child = 1;
+  while (end >= 2 && child <= end - 2) {
+    if (hk[child] <= hk[child + 1]) child += 1;
+    hk[pos] = hk[child]; hp[pos] = hp[child];
+    pos = child;
+    child = 2 * pos + 1;
+  }
+  if (child == end - 1) { hk[pos] = hk[child]; hp[pos] = hp[child]; pos = child; }
+  hk[pos] = ek; hp[pos] = ep;
+  heap_sift_up(hk, hp, 0, pos);
+}
+
+
 }  // namespace lh

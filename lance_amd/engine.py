@@ -261,6 +261,52 @@ class Engine:
         return ms.value, n.value
 
 
+class DeviceFlatIndex:
+    """Handle of a device-resident IVF_FLAT index (FlatIndex sub-index over the raw vectors of each partition)."""
+
+    def __init__(self, engine, handle, metric, centroids, data_dtype):
+        self.engine = engine
+        self.h = handle
+        self.metric = metric
+        self.centroids = centroids
+        self.data_dtype = data_dtype
+
+    @classmethod
+    def create(cls, engine, metric, centroids, x, part_ids, row_ids=None):
+        x, dt = _vec(x)
+        cent = _model(centroids, x)
+        part = to_device(part_ids, torch.int32)
+        rid = None if row_ids is None else to_device(row_ids, torch.int64)
+        n, d = x.shape
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(engine.lib.lance_hip_ivfflat_create(engine.h, dt, METRICS[metric], d, _ptr(cent), cent.shape[0], _ptr(x), _ptr(part),
+                                                  _ptr(rid), n, C.byref(h)))
+        return cls(engine, h, metric, cent, x.dtype)
+
+    def search(self, q, k, nprobes):
+        d = self.centroids.shape[1]
+        t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
+        q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
+        nq = q.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        torch.cuda.synchronize()
+        check(self.engine.lib.lance_hip_ivfflat_search(self.engine.h, self.h, _ptr(q), nq, k, nprobes, _ptr(ids), _ptr(dists)))
+        return ids, dists
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.engine.lib.lance_hip_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceIndex:
     """Handle of a device-resident IVF_PQ index (lance_hip_index)."""
 

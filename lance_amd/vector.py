@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ._lib import METRICS, NONE
-from .engine import DeviceIndex, Engine, to_device
+from .engine import DeviceFlatIndex, DeviceIndex, Engine, to_device
 
 _engine = None
 
@@ -165,6 +165,27 @@ class IvfPqIndex:
         return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync)
 
 
+class IvfFlatIndex:
+    """IVF_FLAT: IVF partitions over the raw vectors (exact distances inside the probed partitions)."""
+
+    def __init__(self, ix, params, stats, part_ids):
+        self._ix = ix
+        self.params = params
+        self.stats = stats
+        self.part_ids = part_ids
+
+    @property
+    def centroids(self):
+        return self._ix.centroids.cpu().numpy()
+
+    def search_device(self, q, k, nprobes):
+        return self._ix.search(q, k, nprobes)
+
+    def nearest(self, q, k=10, nprobes=1):
+        ids, dists = self._ix.search(q, k, nprobes)
+        return ids.cpu().numpy().view(np.uint64), dists.cpu().numpy()
+
+
 def _sample_rows(n, size, rng):
     """maybe_sample_training_data (rust/lance/src/index/vector/utils.rs:173): all rows when the
     table is small, else `size` distinct random rows (ascending)."""
@@ -212,8 +233,9 @@ def train_pq_codebook(x, centroids, params: IvfPqParams, engine=None):
 def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_sub_vectors=16, num_bits=8, max_iters=50,
                  sample_rate=256, ivf_centroids=None, pq_codebook=None, seed=42, keep_raw=True, engine=None):
     """Dataset.create_index(column, "IVF_PQ", ...) for a vector matrix resident (or copied) in HBM."""
-    if str(index_type).upper() != "IVF_PQ":
-        raise NotImplementedError(f"index_type {index_type}: only IVF_PQ is on this engine's hot path")
+    itype = str(index_type).upper()
+    if itype not in ("IVF_PQ", "IVF_FLAT"):
+        raise NotImplementedError(f"index_type {index_type}: IVF_PQ and IVF_FLAT are on this engine's hot path")
     eng = engine or default_engine()
     params = IvfPqParams(num_partitions, num_sub_vectors, num_bits, _normalize_metric_type(metric), max_iters, sample_rate, seed)
     x = to_device(x)
@@ -238,6 +260,12 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
             raise ValueError(f"IVF centroids length mismatch: {tuple(cent.shape)} != {(num_partitions, d)}")
     else:
         cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
+    if itype == "IVF_FLAT":
+        if params.metric == "cosine":
+            raise NotImplementedError("IVF_FLAT with the cosine metric is not supported by this engine yet (use l2 or dot)")
+        part, _ = timed("transform", lambda: eng.assign(x, cent, params.metric))
+        fx = timed("build_partitions", lambda: DeviceFlatIndex.create(eng, params.metric, cent, x, part))
+        return IvfFlatIndex(fx, params, stats, part)
     if num_bits not in (4, 8):
         raise ValueError(f"ProductQuantization: num_bits {num_bits} not supported")
     if pq_codebook is not None:

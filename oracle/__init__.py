@@ -376,3 +376,32 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None, nbits=8):
     idx.codes_rowmajor = codes
     idx.perm = perm
     return idx
+
+
+def ivfflat_search(x, centroids, queries, k, nprobes, metric="l2", row_ids=None):
+    """IVF_FLAT: per probed partition FlatIndex::search over the raw vectors (flat/index.rs:82-177 -- a max-heap of
+    k, the earlier-scanned row wins a tie; distances = distance_type.func()(query, vector), flat/storage.rs:345-402),
+    then SortExec([_distance, _rowid]).fetch(k) (scanner.rs:3440-3468).  Rows are stored per partition in ascending
+    input order; rows without a partition (non-finite) are dropped."""
+    x = _f32(x); centroids = _f32(centroids)
+    q = _f32(queries).reshape(-1, x.shape[1])
+    nlist = centroids.shape[0]
+    rid = np.arange(x.shape[0], dtype=np.uint64) if row_ids is None else np.asarray(row_ids, np.uint64)
+    part, _ = assign(x, centroids, metric)
+    offs, perm = partition_layout(part, nlist)
+    probes, _ = find_partitions(q, centroids, nprobes, metric)
+    out_i = np.full((q.shape[0], k), np.iinfo(np.uint64).max, np.uint64)
+    out_d = np.full((q.shape[0], k), np.inf, np.float32)
+    for qi in range(q.shape[0]):
+        ci, cd = [], []
+        for p in probes[qi]:
+            rows = perm[int(offs[p]):int(offs[p + 1])]
+            if len(rows) == 0:
+                continue
+            d = distance_batch(metric, q[qi], x[rows])
+            hi, hd = heap_topk(d, rid[rows], k)
+            ci.append(hi); cd.append(hd)
+        if ci:
+            si, sd = sort_fetch(np.concatenate(ci), np.concatenate(cd), k)
+            out_i[qi, :len(si)] = si; out_d[qi, :len(sd)] = sd
+    return out_i, out_d

@@ -552,3 +552,30 @@ def test_f16_mstep_overflow_terminates_like_oracle(eng, oracle):
     assert iters == oit
     assert (np.isnan(g) == np.isnan(o)).all()
     assert (g[~np.isnan(g)].view(np.uint32) == o[~np.isnan(o)].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("d", [32, 128, 40])
+def test_ivf_flat_matches_oracle(eng, oracle, metric, d):
+    """IVF_FLAT: exact distances inside the probed partitions, FlatIndex heap per partition + SortExec."""
+    from lance_amd.engine import DeviceFlatIndex
+    n, nlist = 20000, 24
+    x = sift_like(n, d, 90 + d)
+    x[50:60] = x[7]                      # duplicates: exact ties
+    q = sift_like(48, d, 91 + d)
+    cent, _, _, _ = oracle.kmeans_train(x[:4096], nlist, max_iters=6, seed=2)
+    part, _ = eng.assign(x, cent, metric)
+    g = DeviceFlatIndex.create(eng, metric, cent, x, part)
+    for k, nprobes in ((10, 5), (1, 3), (50, nlist)):     # the last one hits a boundary tie inside one partition (heap replay)
+        gi, gd = g.search(q, k, nprobes)
+        oi, od = oracle.ivfflat_search(x, cent, q, k, nprobes, metric)
+        assert (_np(gi).view(np.uint64) == oi).all(), (metric, d, k, nprobes)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    if metric == "l2" and d == 128:      # exhaustive probing == flat KNN
+        gi, gd = g.search(q, 10, nlist)
+        fi, fd = eng.flat_topk(x, q, 10, metric)
+        assert (gi == fi).all() and (_np(gd).view(np.uint32) == _np(fd).view(np.uint32)).all()
+        import lance_amd
+        ix = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=nlist, sample_rate=64)
+        ids, dd = ix.search_device(q, 10, nlist)
+        assert (ids == fi).all()
