@@ -182,6 +182,7 @@ lance_hip_index::~lance_hip_index() {
   if (codes) (void)hipFree(codes);
   if (row_ids) (void)hipFree(row_ids);
   if (vectors) (void)hipFree(vectors);
+  if (flat_items) (void)hipFree(flat_items);
 }
 
 extern "C" {

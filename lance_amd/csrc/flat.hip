@@ -457,6 +457,11 @@ struct IvfFlatArgs {
   const float *q;                // [nq][d]
   int nprobes, d, bound;
   uint32_t *ppart;               // [nq][cap] partition of every pool entry (boundary-tie check)
+  const int2_host *items;        // partition-major pass: (partition, first row) per 256-row block
+  const uint32_t *pair_starts;   // [nlist+1] (query, probe) pairs grouped by partition
+  const uint32_t *pair_idx;      // [nq*nprobes] pair index (query = idx / pdiv), grouped
+  int pdiv;                      // nprobes for the main pass, 1 for the bound pass (pairs = queries)
+  uint32_t *lanemin;             // bound pass: [nq][256] running minimum key per (query, lane)
   uint32_t *flags;               // [nq] 1 = the survivors of a boundary tie depend on the reference heap: replay
   FlatPool pool;
 };
@@ -693,6 +698,108 @@ __global__ __launch_bounds__(256) void gather_vectors_kernel(const float *__rest
   if (g == s * d) rid_out[s] = row_ids ? row_ids[r] : (uint64_t)r;
 }
 
+
+// Partition-major main pass (fixed D): one workgroup per 256-row block of a partition.  Lanes own the rows (vector
+// in VGPRs, loaded once); the queries that probe this partition -- found by grouping the (query, probe) pairs by
+// partition with the stable counting sort -- stream through LDS tiles with their thresholds.  Rows are read once
+// per block instead of once per (query, probe) pair: the query-major kernel moved 40 GB through L2 per 2000-query
+// batch at C2, this one moves the 512 MB of vectors once.
+template <int D, int METRIC, int QT, bool BOUND>
+__global__ __launch_bounds__(256) void ivfflat_pm_kernel(IvfFlatArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[QT * D];
+  __shared__ uint32_t tk[QT];
+  __shared__ int tq[QT];
+  const int part = a.items[blockIdx.x].x;
+  const uint32_t row = (uint32_t)a.items[blockIdx.x].y + threadIdx.x;
+  const bool valid = row < a.part_offsets[part + 1];
+  const uint32_t qs = a.pair_starts[part], qe = a.pair_starts[part + 1];
+  if (qs == qe) return;
+  RegVec<D> rv;
+#pragma unroll
+  for (int i = 0; i < RegVec<D>::Q; ++i) rv.q[i] = f4{0.f, 0.f, 0.f, 0.f};
+  uint64_t rid = ~0ull;
+  if (valid) {
+    const float *src = a.vec + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < D / 4; ++i) rv.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
+    rid = a.row_ids[row];
+  }
+  const int lane = threadIdx.x & 63;
+  constexpr bool NEG = METRIC != METRIC_DOT;
+  for (uint32_t j0 = qs; j0 < qe; j0 += QT) {
+    const int qt = (int)min((uint32_t)QT, qe - j0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < qt; j += 256) {
+      const int qi = (int)(a.pair_idx[j0 + j] / (uint32_t)a.pdiv);
+      tq[j] = qi;
+      tk[j] = BOUND ? 0xFFFFFFFFu : a.pool.tkey[qi];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x * 4; i < qt * D; i += 256 * 4) {
+      const int j = i / D, e = i - j * D;
+      const f4 v = *reinterpret_cast<const f4 *>(&a.q[(int64_t)tq[j] * D + e]);
+      *reinterpret_cast<f4 *>(&tile[i]) = NEG ? -v : v;
+    }
+    __syncthreads();
+    for (int c = 0; c < qt; ++c) {
+      const float v = finish_metric<METRIC>(dist_exact<D, METRIC, NEG>(rv, &tile[c * D]));
+      const uint32_t key = order_key(v);
+      if constexpr (BOUND) {
+        // lane l of every block of this partition folds its row into lanemin[q][l]: 256 minima over distinct rows,
+        // whose k-th smallest (ivfflat_kth_kernel) is the query's bound
+        if (valid) atomicMin(&a.lanemin[(int64_t)tq[c] * 256 + threadIdx.x], key);
+        continue;
+      }
+      const bool pass = valid && key <= tk[c];       // ties with the bound are kept (the boundary-tie check needs them)
+      const uint64_t m = __ballot(pass);
+      if (m) {
+        const int qi = tq[c];
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&a.pool.cnt[qi], (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (pass) {
+          const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < (uint32_t)a.pool.cap) {
+            a.pool.pkeys[(int64_t)qi * a.pool.cap + pos] = key;
+            a.pool.prids[(int64_t)qi * a.pool.cap + pos] = rid;
+            a.ppart[(int64_t)qi * a.pool.cap + pos] = (uint32_t)part;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int METRIC, bool BOUND>
+static bool launch_ivfflat_pm(lance_hip_ctx *ctx, const IvfFlatArgs &a, unsigned n_items) {
+  switch (a.d) {
+    case 8: hipLaunchKernelGGL((ivfflat_pm_kernel<8, METRIC, 256, BOUND>), dim3(n_items), dim3(256), 0, ctx->stream, a); return true;
+    case 16: hipLaunchKernelGGL((ivfflat_pm_kernel<16, METRIC, 256, BOUND>), dim3(n_items), dim3(256), 0, ctx->stream, a); return true;
+    case 32: hipLaunchKernelGGL((ivfflat_pm_kernel<32, METRIC, 256, BOUND>), dim3(n_items), dim3(256), 0, ctx->stream, a); return true;
+    case 64: hipLaunchKernelGGL((ivfflat_pm_kernel<64, METRIC, 64, BOUND>), dim3(n_items), dim3(256), 0, ctx->stream, a); return true;
+    case 96: hipLaunchKernelGGL((ivfflat_pm_kernel<96, METRIC, 64, BOUND>), dim3(n_items), dim3(256), 0, ctx->stream, a); return true;
+    case 128: hipLaunchKernelGGL((ivfflat_pm_kernel<128, METRIC, 64, BOUND>), dim3(n_items), dim3(256), 0, ctx->stream, a); return true;
+    default: return false;
+  }
+}
+
+__global__ __launch_bounds__(256) void ivfflat_first_probe_kernel(const uint32_t *__restrict__ probes, int nq, int nprobes, uint32_t *__restrict__ keys,
+                                                                  uint32_t *__restrict__ lanemin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nq) keys[i] = probes[(int64_t)i * nprobes];
+  for (int64_t j = i; j < (int64_t)nq * 256; j += (int64_t)gridDim.x * 256) lanemin[j] = 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void ivfflat_kth_kernel(const uint32_t *__restrict__ lanemin, int k, uint32_t *__restrict__ tkey) {
+  __shared__ uint32_t sorted[256];
+  __shared__ uint32_t slot;
+  if (threadIdx.x == 0) slot = 0xFFFFFFFFu;
+  __syncthreads();
+  const uint32_t t = kth_smallest_256(lanemin[(int64_t)blockIdx.x * 256 + threadIdx.x], k - 1, sorted, &slot);
+  if (threadIdx.x == 0) tkey[blockIdx.x] = t;
+}
+
 template <int METRIC>
 static void launch_ivfflat(lance_hip_ctx *ctx, const IvfFlatArgs &a, unsigned grid, bool fixed) {
   const size_t lds = (size_t)((a.d + 3) & ~3) * 4;
@@ -753,6 +860,17 @@ extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metri
       return fail(LANCE_HIP_ERUNTIME);
     }
   }
+  {  // 256-row blocks of every partition for the partition-major pass
+    std::vector<int2_host> items;
+    for (uint32_t p = 0; p < nlist; ++p)
+      for (uint32_t r0 = ix->part_offsets_h[p]; r0 < ix->part_offsets_h[p + 1]; r0 += 256) items.push_back(int2_host{(int)p, (int)r0});
+    ix->n_flat_items = (uint32_t)items.size();
+    if (hipMalloc(reinterpret_cast<void **>(&ix->flat_items), std::max<size_t>(items.size() * sizeof(int2_host), 16)) != hipSuccess) return fail(LANCE_HIP_ENOMEM);
+    if (!items.empty() && hipMemcpy(ix->flat_items, items.data(), items.size() * sizeof(int2_host), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("ivfflat_create: HIP failure");
+      return fail(LANCE_HIP_ERUNTIME);
+    }
+  }
   *out = ix;
   return LANCE_HIP_OK;
 }
@@ -798,10 +916,50 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
     if (idx->metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
     else hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_L2>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
   };
+  const bool pm = fixed && idx->n_flat_items > 0 && !getenv("LANCE_HIP_IVFFLAT_QM") &&
+                  ((reinterpret_cast<uintptr_t>(qf) & 15) == 0);
+  uint32_t *pair_starts = nullptr, *pair_idx = nullptr;
+  if (pm) {
+    pair_starts = ctx->scratch_t<uint32_t>("ivfflat.pair_starts", (size_t)idx->nlist + 1);
+    pair_idx = ctx->scratch_t<uint32_t>("ivfflat.pair_idx", (size_t)qch * nprobes);
+    if (!pair_starts || !pair_idx) return LANCE_HIP_ENOMEM;
+  }
+  uint32_t *pair_starts0 = nullptr, *pair_idx0 = nullptr, *keys0 = nullptr, *lanemin = nullptr;
+  if (pm) {
+    pair_starts0 = ctx->scratch_t<uint32_t>("ivfflat.pair_starts0", (size_t)idx->nlist + 1);
+    pair_idx0 = ctx->scratch_t<uint32_t>("ivfflat.pair_idx0", (size_t)qch);
+    keys0 = ctx->scratch_t<uint32_t>("ivfflat.keys0", (size_t)qch);
+    lanemin = ctx->scratch_t<uint32_t>("ivfflat.lanemin", (size_t)qch * 256);
+    if (!pair_starts0 || !pair_idx0 || !keys0 || !lanemin) return LANCE_HIP_ENOMEM;
+  }
+  a.items = idx->flat_items; a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.pdiv = (int)nprobes; a.lanemin = lanemin;
+  bool grouped = false;
   auto scan = [&](int bound, int nqc) {
     a.bound = bound;
     const unsigned grid = (unsigned)(bound ? nqc : nqc * (int)nprobes);
     ScopedTimer t(ctx, bound ? "ivfflat_bound" : "ivfflat_scan");
+    if (bound && pm) {
+      // bound pass, partition-major: group the queries by their nearest partition, fold every row of that partition
+      // into 256 per-query lane minima, take the k-th smallest
+      hipLaunchKernelGGL(ivfflat_first_probe_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, a.probes, nqc, (int)nprobes, keys0, lanemin);
+      (void)stable_group(ctx, keys0, (int64_t)nqc, (int64_t)nqc, (int)idx->nlist, 1, pair_starts0, pair_idx0, (int64_t)nqc, nullptr);
+      IvfFlatArgs b = a;
+      b.pair_starts = pair_starts0; b.pair_idx = pair_idx0; b.pdiv = 1;
+      if (idx->metric == LANCE_HIP_DOT) launch_ivfflat_pm<METRIC_DOT, true>(ctx, b, idx->n_flat_items);
+      else launch_ivfflat_pm<METRIC_L2, true>(ctx, b, idx->n_flat_items);
+      hipLaunchKernelGGL(ivfflat_kth_kernel, dim3(nqc), dim3(256), 0, ctx->stream, lanemin, (int)k, pl.tkey);
+      return;
+    }
+    if (!bound && pm) {
+      if (!grouped) {
+        (void)stable_group(ctx, a.probes, (int64_t)nqc * nprobes, (int64_t)nqc * nprobes, (int)idx->nlist, 1, pair_starts, pair_idx,
+                           (int64_t)nqc * nprobes, nullptr);
+        grouped = true;
+      }
+      if (idx->metric == LANCE_HIP_DOT) launch_ivfflat_pm<METRIC_DOT, false>(ctx, a, idx->n_flat_items);
+      else launch_ivfflat_pm<METRIC_L2, false>(ctx, a, idx->n_flat_items);
+      return;
+    }
     if (idx->metric == LANCE_HIP_DOT) launch_ivfflat<METRIC_DOT>(ctx, a, grid, fixed);
     else launch_ivfflat<METRIC_L2>(ctx, a, grid, fixed);
   };
@@ -813,6 +971,7 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
     uint64_t *oid = ids + (int64_t)qc0 * k;
     float *od = dists + (int64_t)qc0 * k;
     hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, pl, 1);
+    grouped = false;
     scan(1, nqc);
     scan(0, nqc);
     finish(nqc, oid, od);

@@ -3,6 +3,8 @@
 #include <cstdint>
 #include <vector>
 
+struct int2_host { int x, y; };
+
 struct lance_hip_index {
   int device = 0;
   int metric = 0;
@@ -15,6 +17,8 @@ struct lance_hip_index {
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition
   uint64_t *row_ids = nullptr;    // [n] in the same order
+  int2_host *flat_items = nullptr;   // IVF_FLAT only: (partition, first row) of every 256-row block, device
+  uint32_t n_flat_items = 0;
   float *vectors = nullptr;       // IVF_FLAT only (m == 0): [n][d] f32 vectors in the same order (flat/storage.rs FlatFloatStorage)
   const void *raw = nullptr;      // borrowed raw vectors (dtype elements) for refine, indexed by row id
   uint64_t n_raw = 0;

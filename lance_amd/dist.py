@@ -204,3 +204,97 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
     ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
                                                               raw=x if keep_raw else None))
     return lv.IvfPqIndex(ix, params, stats, part, codes)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Search over IVF lists SHARDED across the ranks (the C5 shape: 32 GB of codes + 8 GB of row ids do
+# not belong on one GPU next to the raw vectors).  List p lives on rank p % world.  Centroids and codebook are
+# replicated, so every rank picks the same probes for a query and simply finds the lists it does not own empty.
+# Each rank answers with its local top-keff (k * refine_factor) by PQ distance, ONE all-gather moves
+# nq * keff * 16 bytes per rank, and every rank merges by (distance, row id) -- the order of the reference's
+# SortExec over the per-partition heaps (scanner.rs:3440-3468), which is a total order, so the merged result is
+# identical to the single-GPU one.  With refine the merged PQ top-keff is re-ranked by the exact distances the
+# owning ranks computed for their own candidates (scanner.rs:2884-2904), again identical.
+
+def _order_key(d):
+    """f32::total_cmp as an int64 sort key (lance-index graph.rs:66-82)."""
+    u = d.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return torch.where((u & 0x80000000) != 0, (~u) & 0xFFFFFFFF, u | 0x80000000)
+
+
+def merge_topk(ids, dists, k):
+    """ids [nq, C] int64 (-1 = none), dists [nq, C] f32 -> top-k per row by (dist, row id); missing = (-1, +inf)."""
+    none = ids < 0
+    big = torch.iinfo(torch.int64).max
+    idk = torch.where(none, torch.full_like(ids, big), ids)
+    dk = torch.where(none, torch.full_like(ids, 1 << 40), _order_key(dists))
+    o1 = torch.sort(idk, dim=1, stable=True).indices
+    dk1 = torch.gather(dk, 1, o1)
+    o2 = torch.sort(dk1, dim=1, stable=True).indices
+    order = torch.gather(o1, 1, o2)[:, :k]
+    out_i = torch.gather(ids, 1, order)
+    out_d = torch.where(out_i < 0, torch.full_like(dists[:, :1], float("inf")).expand(-1, order.shape[1]), torch.gather(dists, 1, order))
+    if out_i.shape[1] < k:
+        pad = k - out_i.shape[1]
+        out_i = torch.cat([out_i, torch.full((out_i.shape[0], pad), -1, dtype=out_i.dtype, device=out_i.device)], 1)
+        out_d = torch.cat([out_d, torch.full((out_d.shape[0], pad), float("inf"), dtype=out_d.dtype, device=out_d.device)], 1)
+    return out_i, out_d
+
+
+def local_list_rows(part_ids, world, rank):
+    """indices (ascending) of the rows whose IVF list is owned by `rank` (list p -> rank p % world)."""
+    p = torch.as_tensor(part_ids).to(torch.int64)
+    return torch.nonzero((p >= 0) & (p < (1 << 31)) & (p % world == rank)).reshape(-1)
+
+
+def create_list_shard(engine, metric, centroids, codebook, part_ids, codes, raw=None, group=None):
+    """Device index over THIS rank's lists only.  Local row ids are the ranks of the global ones (0..n_local-1,
+    ascending), so every (dist, rowid) comparison made on the device orders rows exactly as the global ids would;
+    `l2g` maps them back.  raw (optional, [n][d] by global row id) is sliced to the local rows for refine."""
+    from .engine import DeviceIndex
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    part = torch.as_tensor(part_ids)
+    rows = local_list_rows(part, world, rank)       # part ids are int32 on the device, NONE = -1
+    pl = part[rows.to(part.device)]
+    cl = torch.as_tensor(codes)[rows.to(torch.as_tensor(codes).device)]
+    raw_l = None if raw is None else torch.as_tensor(raw)[rows.to(torch.as_tensor(raw).device)].contiguous()
+    ix = DeviceIndex.create(engine, metric, centroids, codebook, pl, cl, None, raw=raw_l)
+    return ix, rows
+
+
+def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group=None):
+    """local_search(q, kk, nprobes, refine_factor) -> (local ids int64 [-1 = none], dists) over this rank's lists.
+    Every rank passes the SAME query batch and gets the same (ids [nq,k] int64 global, dists [nq,k])."""
+    world = dist.get_world_size(group)
+    keff = k * refine_factor if refine_factor else k
+    li, ld = local_search(q, keff, nprobes, 0)
+    li = torch.as_tensor(li).to(torch.int64); ld = torch.as_tensor(ld).to(torch.float32)
+    l2g = torch.as_tensor(l2g).to(li.device)
+    gi = torch.where(li < 0, li, l2g[li.clamp(min=0)]) if l2g.numel() else li
+    payload = [gi.contiguous(), ld.contiguous()]
+    if refine_factor:
+        # exact distances of the same keff local candidates (k = keff, refine_factor = 1 re-ranks without dropping any)
+        ri, rd = local_search(q, keff, nprobes, 1)
+        ri = torch.as_tensor(ri).to(torch.int64); rd = torch.as_tensor(rd).to(torch.float32)
+        # align the exact distances with the PQ-ordered candidate list (same id set, different order)
+        so = torch.sort(torch.where(ri < 0, torch.full_like(ri, torch.iinfo(torch.int64).max), ri), dim=1)
+        qo = torch.sort(torch.where(li < 0, torch.full_like(li, torch.iinfo(torch.int64).max), li), dim=1)
+        ex_sorted = torch.gather(rd, 1, so.indices)
+        ex = torch.empty_like(ld)
+        ex.scatter_(1, qo.indices, ex_sorted)
+        payload.append(ex.contiguous())
+    gathered = []
+    for t in payload:
+        buf = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(buf, t, group=group)
+        gathered.append(torch.cat(buf, dim=1))
+    if not refine_factor:
+        return merge_topk(gathered[0], gathered[1], k)
+    # global top-keff by (PQ distance, row id), then order those by (exact distance, row id) and fetch k
+    ci, cd = gathered[0], gathered[1]
+    none = ci < 0
+    big = torch.iinfo(torch.int64).max
+    o1 = torch.sort(torch.where(none, torch.full_like(ci, big), ci), dim=1, stable=True).indices
+    dk1 = torch.gather(torch.where(none, torch.full_like(ci, 1 << 40), _order_key(cd)), 1, o1)
+    order = torch.gather(o1, 1, torch.sort(dk1, dim=1, stable=True).indices)[:, :keff]
+    return merge_topk(torch.gather(ci, 1, order), torch.gather(gathered[2], 1, order), k)

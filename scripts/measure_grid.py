@@ -100,7 +100,16 @@ def main():
             chk[f"refine{rf}"] = {"ids_equal": bool((oi == gi.cpu().numpy().view(np.uint64)).all()),
                                   "dists_bit_equal": bool((od.view(np.uint32) == gd.cpu().numpy().view(np.uint32)).all())}
         out["c2_exhaustive_vs_oracle"] = {"queries": nchk, "nprobes": nlist, **chk}
-        del x, q, idx, raw
+        # ---- IVF_FLAT (N4) on the same data: exact distances inside the probed partitions -------------------
+        fx = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=nlist)
+        fl = []
+        for nprobes in (1, 10, 50):
+            qq = q[:2000]
+            dt = timed(lambda: fx.search_device(qq, 10, nprobes), reps=2)
+            ids, _ = fx.search_device(q[:1000], 10, nprobes)
+            fl.append({"nprobes": nprobes, "recall_at_10": recall_of(ids, gt), "nq": 2000, "ms_per_batch": dt * 1e3, "qps": 2000 / dt})
+        out["c2_ivf_flat"] = {"build_stages_ms": {k: round(v * 1e3, 3) for k, v in fx.stats.seconds.items()}, "grid": fl}
+        del x, q, idx, raw, fx
 
     if args.c3:
         d, nlist, m = 1536, 1024, 96

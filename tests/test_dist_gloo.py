@@ -107,3 +107,67 @@ def test_sharded_kmeans_two_ranks(case):
         assert abs(l0 - ol) <= 1e-5 * abs(ol)
     else:
         assert np.isfinite(c0).all() and i0 >= 1
+
+
+# ---- search with IVF lists sharded over the ranks (lance_amd/dist.py: search_list_sharded) -----------------
+def _shard_case():
+    import oracle
+    rng = np.random.default_rng(23)
+    n, d, nlist, m = 6000, 32, 12, 8
+    centers = rng.integers(0, 120, (30, d))
+    x = np.clip(np.rint(centers[rng.integers(0, 30, n)] + rng.normal(0, 14, (n, d))), 0, 200).astype(f32)   # integer-valued: ties
+    x[40:48] = x[3]
+    q = np.clip(np.rint(centers[rng.integers(0, 30, 40)] + rng.normal(0, 14, (40, d))), 0, 200).astype(f32)
+    cent, _, _, _ = oracle.kmeans_train(x[:3000], nlist, max_iters=6, seed=4)
+    part, _ = oracle.assign(x, cent, "l2")
+    cb, _ = oracle.pq_train(oracle.residual(x[:3000], cent, part[:3000]), m, max_iters=6, seed=6)
+    return x, q, cent, cb, part
+
+
+def _search_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from lance_amd.dist import local_list_rows, search_list_sharded
+    x, q, cent, cb, part = _shard_case()
+    rows = local_list_rows(part.astype(np.int64), world, rank).numpy()
+    xl = x[rows]
+    oidx = oracle.build_index(xl, cent, cb, metric="l2")          # local row ids = 0..n_local-1, ascending with the global ids
+
+    def local_search(qq, kk, nprobes, rf):
+        ids, dd = oidx.search(np.asarray(qq, f32), kk, nprobes, refine=rf, raw=xl if rf else None)
+        ids = ids.astype(np.int64)                                # UINT64_MAX (none) -> -1
+        return torch.from_numpy(ids), torch.from_numpy(dd)
+
+    res = {}
+    for k, nprobes, rf in ((10, 3, 0), (10, 12, 0), (5, 4, 4), (10, 12, 3)):
+        gi, gd = search_list_sharded(local_search, torch.from_numpy(rows), torch.from_numpy(q), k, nprobes, rf)
+        res[(k, nprobes, rf)] = (gi.numpy(), gd.numpy())
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_list_sharded_search_two_ranks_equals_single_index():
+    import oracle
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, q, cent, cb, part = _shard_case()
+    full = oracle.build_index(x, cent, cb, metric="l2")
+    for key, (gi0, gd0) in res[0][1].items():
+        gi1, gd1 = res[1][1][key]
+        assert (gi0 == gi1).all() and (gd0.view(np.uint32) == gd1.view(np.uint32)).all()      # every rank holds the same answer
+        k, nprobes, rf = key
+        oi, od = full.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        assert (gi0.astype(np.uint64) == oi).all(), key
+        assert (gd0.view(np.uint32) == od.view(np.uint32)).all(), key

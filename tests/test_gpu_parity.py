@@ -579,3 +579,37 @@ def test_ivf_flat_matches_oracle(eng, oracle, metric, d):
         ix = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=nlist, sample_rate=64)
         ids, dd = ix.search_device(q, 10, nlist)
         assert (ids == fi).all()
+
+
+def test_list_sharded_search_on_device_world1(eng, oracle):
+    """lance_amd.dist.search_list_sharded with the real DeviceIndex as the local searcher (world_size 1: the collective
+    code runs, the shard is the whole index) must equal the plain search; the 2-rank logic is covered on CPU by
+    tests/test_dist_gloo.py."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import lance_amd
+    from lance_amd.dist import create_list_shard, search_list_sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29777")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        x = sift_like(30000, 64, 301)
+        q = sift_like(200, 64, 302)
+        idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=32, num_sub_vectors=8, sample_rate=64, engine=eng)
+        shard, l2g = create_list_shard(eng, "l2", idx._ix.centroids, idx._ix.codebook, idx.part_ids, idx.codes, raw=torch.from_numpy(x))
+
+        def local_search(qq, kk, nprobes, rf):
+            i, d = shard.search(qq, kk, nprobes, rf)
+            return i.cpu(), d.cpu()
+
+        for k, nprobes, rf in ((10, 4, 0), (10, 32, 0), (10, 4, 5)):
+            gi, gd = search_list_sharded(local_search, l2g.cpu(), torch.from_numpy(q), k, nprobes, rf)
+            ri, rd = idx.search_device(q, k, nprobes, rf)
+            assert (gi == ri.cpu()).all(), (k, nprobes, rf)
+            assert (gd.numpy().view(np.uint32) == rd.cpu().numpy().view(np.uint32)).all()
+    finally:
+        if created:
+            dist.destroy_process_group()
