@@ -916,7 +916,7 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
     if (idx->metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
     else hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_L2>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
   };
-  const bool pm = fixed && idx->n_flat_items > 0 && !getenv("LANCE_HIP_IVFFLAT_QM") &&
+  const bool pm = fixed && idx->n_flat_items > 0 &&     // partition-major for the fixed dimensions, query-major kernel otherwise
                   ((reinterpret_cast<uintptr_t>(qf) & 15) == 0);
   uint32_t *pair_starts = nullptr, *pair_idx = nullptr;
   if (pm) {

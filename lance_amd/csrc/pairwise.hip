@@ -147,106 +147,6 @@ __global__ __launch_bounds__(256) void argmin_merge_kernel(PairwiseArgs p, int k
   if (p.codes) p.codes[row * p.codes_ld + b] = bi == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)bi;
 }
 
-// Generic dimension: `a` streamed from global in 16-chunks, 4 centroids per pass share
-// each chunk; centroid tile in dynamic LDS.  Same arithmetic order (16 lane sums).
-template <int METRIC, int MODE>
-__global__ __launch_bounds__(256) void pairwise_generic_kernel(PairwiseArgs p, int d, int ct_max) {
-  extern __shared__ __attribute__((aligned(16))) float gtile[];
-  const int b = blockIdx.y;
-  if (p.active && !p.active[b]) return;
-  const float *xb = p.x + (int64_t)b * p.x_batch_off;
-  const float *cb = p.cent + (int64_t)b * p.cent_batch_stride;
-  const float *biasb = p.bias ? p.bias + (int64_t)b * p.bias_batch_stride : nullptr;
-  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = row < p.n;
-  const float *arow = xb + (valid ? row : 0) * p.ldx;
-  const int full = d / 16 * 16;
-  bool finite = true;
-  if (MODE == 0 && p.check_finite && valid)
-    for (int i = 0; i < d; ++i) finite &= isfinite(arow[i]);
-  float minv = INFINITY, mino = INFINITY;
-  uint32_t mini = LANCE_HIP_NONE;
-  float *mrow = (MODE == 1 && valid) ? p.matrix + ((int64_t)b * p.n + row) * p.k : nullptr;
-
-  for (int c0 = 0; c0 < p.k; c0 += ct_max) {
-    const int ct = min(ct_max, p.k - c0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < ct * d; i += 256) gtile[i] = cb[(int64_t)c0 * d + i];
-    __syncthreads();
-    if (!valid) continue;
-    for (int cc = 0; cc < ct; cc += 4) {
-      const int nc = min(4, ct - cc);
-      float sums[4][16];
-      float rem[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rem[q] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sums[q][i] = 0.0f;
-      }
-      for (int i = full; i < d; ++i) {
-        const float av = arow[i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q < nc) {
-            const float bv = gtile[(cc + q) * d + i];
-            if constexpr (METRIC == METRIC_DOT) {
-              rem[q] = rem[q] + av * bv;
-            } else {
-              const float diff = av - bv;
-              rem[q] = rem[q] + diff * diff;
-            }
-          }
-        }
-      }
-      for (int j = 0; j < full; j += 16) {
-        float av[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) av[i] = arow[j + i];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q < nc) {
-            const float *bp = &gtile[(cc + q) * d + j];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              if constexpr (METRIC == METRIC_DOT) {
-                sums[q][i] += av[i] * bp[i];
-              } else {
-                const float diff = av[i] - bp[i];
-                sums[q][i] += diff * diff;
-              }
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < nc) {
-          float tot = 0.0f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) tot = tot + sums[q][i];
-          const float v = finish_metric<METRIC>(rem[q] + tot);
-          const int c = c0 + cc + q;
-          if constexpr (MODE == 1) {
-            mrow[c] = v;
-          } else {
-            const float vb = biasb ? v + biasb[c] : v;
-            if (vb < minv) { minv = vb; mino = v; mini = (uint32_t)c; }
-          }
-        }
-      }
-    }
-  }
-  if constexpr (MODE == 0) {
-    if (valid) {
-      if (!finite) mini = LANCE_HIP_NONE;
-      if (p.ids) p.ids[(int64_t)b * p.out_batch_stride + row] = mini;
-      if (p.dists) p.dists[(int64_t)b * p.out_batch_stride + row] = mino;
-      if (p.codes) p.codes[row * p.codes_ld + b] = mini == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)mini;
-    }
-  }
-}
-
 
 template <int D, int MODE, int BS>
 static void launch_fixed_bs(lance_hip_ctx *ctx, const PairwiseArgs &p, int metric, int batches, int ksplit) {
@@ -264,8 +164,7 @@ template <int D, int MODE>
 static int launch_fixed(lance_hip_ctx *ctx, PairwiseArgs p, int metric, int batches) {
   constexpr int CT = (8192 / D) > 256 ? 256 : (8192 / D);
   const int ntiles = (int)cdiv(p.k, CT);
-  static const int want_mul = getenv("LANCE_HIP_ASSIGN_WANT") ? atoi(getenv("LANCE_HIP_ASSIGN_WANT")) : 2;
-  const int64_t want = (int64_t)want_mul * ctx->num_cus;
+  const int64_t want = 2ll * ctx->num_cus;    // 4x and 8x measured: no gain / slower on the 65,536-row training E-step
   int bs = 256;
   if ((int64_t)cdiv(p.n, 256) * batches * ntiles < want) bs = 64;
   int ksplit = 1;
@@ -310,23 +209,11 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
       default: break;
     }
   }
-  if (!getenv("LANCE_HIP_NO_WIDE")) {
+  {   // any other dimension: the 16-lanes-per-pair kernel of wide.hip
     int ks = 1;
     LH_TRY(launch_wide<MODE>(ctx, p, d, metric, batches, &ks));
     if (MODE == 0 && ks > 1)
       hipLaunchKernelGGL(argmin_merge_kernel, dim3((unsigned)cdiv(p.n, 256), batches), dim3(256), 0, ctx->stream, p, ks, batches);
-  } else {
-    int ct = 8192 / d;
-    if (ct < 4) ct = 4;
-    if (ct > 256) ct = 256;
-    ct = ct / 4 * 4;
-    size_t lds = (size_t)ct * d * sizeof(float);
-    LH_REQUIRE(lds <= 160 * 1024, "pairwise: dimension %d too large", d);
-    dim3 grid((unsigned)cdiv(p.n, 256), batches);
-    if (metric == METRIC_DOT)
-      hipLaunchKernelGGL((pairwise_generic_kernel<METRIC_DOT, MODE>), grid, dim3(256), lds, ctx->stream, p, d, ct);
-    else
-      hipLaunchKernelGGL((pairwise_generic_kernel<METRIC_L2, MODE>), grid, dim3(256), lds, ctx->stream, p, d, ct);
   }
 done:
   LH_CHECK_HIP(hipGetLastError());

@@ -296,116 +296,6 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
 }
 
 
-// Persistent variant for d = M*SD <= 128 (C2/C4/C5 shapes): each lane keeps ITS slice of the codebook
-// -- entry c = threadIdx.x of every sub-quantiser, M*SD floats -- in VGPRs for the lifetime of the
-// workgroup, so building a LUT is pure VALU + LDS broadcast and the 128 KiB-per-probe L2 reads of the
-// plain kernel disappear.  Workgroups loop over (query, split) items with a grid stride.
-template <int SD, int METRIC, int MU>
-__global__ __launch_bounds__(256, 2) void ivfpq_scan_persist_kernel(ScanArgs p, int nitems) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ScanShared s;
-  const int dpad = (p.d + 3) & ~3;
-  s.r = reinterpret_cast<float *>(smem);
-  s.lut = s.r + dpad;
-  s.ckey = reinterpret_cast<uint32_t *>(s.lut + p.m * 256);
-  s.cpos = s.ckey + SCAN_CAP;
-  s.sorted = s.cpos + SCAN_CAP;
-  s.misc = s.sorted + 256;
-
-  constexpr int m = MU * 16;
-  constexpr int Q = SD / 4;
-  f4 cbreg[m][Q];
-#pragma unroll
-  for (int mm = 0; mm < m; ++mm) {
-    const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + threadIdx.x) * SD);
-#pragma unroll
-    for (int i = 0; i < Q; ++i) cbreg[mm][i] = src[i];
-  }
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-  const int qi = item / p.nsplit, sp = item % p.nsplit;
-  const float *qv = p.q + (int64_t)qi * p.d;
-  __syncthreads();
-  if (threadIdx.x == 0) { s.misc[0] = 0; s.misc[1] = 0xFFFFFFFFu; s.misc[3] = 0; }
-  __syncthreads();
-
-  for (int pi = sp; pi < p.nprobes; pi += p.nsplit) {
-    const uint32_t part = p.probes[(int64_t)qi * p.nprobes + pi];
-    const uint32_t off = p.part_offsets[part];
-    const int np = (int)(p.part_offsets[part + 1] - off);
-    if (np == 0) continue;
-    __syncthreads();  // previous partition's LUT readers are done
-    // v2.rs:316-332 residual query
-    for (int t = threadIdx.x; t < p.d; t += 256) {
-      float rv = p.residual ? qv[t] - p.centroids[(int64_t)part * p.d + t] : qv[t];
-      if (p.round_f16 && p.residual) rv = __half2float(__float2half_rn(rv));
-      s.r[t] = rv;
-    }
-    __syncthreads();
-    // pq/distance.rs:24-92: LUT[mm][c] = dist(q_sub[mm], codebook[mm][c]) in l2_scalar / dot_scalar order
-#pragma unroll
-    for (int mm = 0; mm < m; ++mm) {
-      RegVec<SD> a;
-#pragma unroll
-      for (int i = 0; i < Q; ++i) a.q[i] = *reinterpret_cast<const f4 *>(&s.r[mm * SD + 4 * i]);
-      const float v = dist_exact<SD, METRIC>(a, reinterpret_cast<const float *>(&cbreg[mm][0]));
-      s.lut[mm * 256 + threadIdx.x] = finish_metric<METRIC>(v);
-    }
-    __syncthreads();
-
-    const uint8_t *pcodes = p.codes + (int64_t)off * m;
-    for (int base = 0; base < np; base += SCAN_ROUND) {
-      if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);  // uniform: misc[0] stable after the barrier
-      const uint32_t T = s.misc[1];
-#pragma unroll
-      for (int u = 0; u < SCAN_ROUND / 256; ++u) {
-        const int row = base + u * 256 + threadIdx.x;
-        if (row < np) {
-          float dist = 0.0f;  // pq/distance.rs:128-141: distances start at 0.0, += table[code] for m = 0..M-1
-          if constexpr (MU > 0) {
-#pragma unroll
-            for (int w = 0; w < MU; ++w) {
-              const uint4 cw = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * (MU * 16) + w * 16);
-              const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) dist += s.lut[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
-            }
-          } else {
-            const uint8_t *rc = pcodes + (int64_t)row * m;
-            for (int mm = 0; mm < m; ++mm) dist += s.lut[mm * 256 + rc[mm]];
-          }
-          if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);  // pq/storage.rs:949-957
-          const uint32_t key = order_key(dist);
-          const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);  // flat/index.rs:98-105
-          if (in_range && key <= T) {
-            const uint32_t slot = atomicAdd(&s.misc[0], 1u);
-            if (slot < SCAN_CAP) { s.ckey[slot] = key; s.cpos[slot] = off + (uint32_t)row; }
-            else s.misc[3] = FLAG_OVERFLOW;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // final: shrink to <= LCAP entries (exact threshold once <= 256 entries remain)
-  __syncthreads();
-  for (int iter = 0; iter < 8 && (int)s.misc[0] > SCAN_LCAP; ++iter) tighten(s, p.keff);
-  __syncthreads();
-  int c = min((int)s.misc[0], SCAN_CAP);
-  uint32_t fl = s.misc[3];
-  if (c > SCAN_LCAP) { c = SCAN_LCAP; fl |= FLAG_OVERFLOW; }
-  const int64_t ob = (int64_t)item * SCAN_LCAP;
-  for (int i = threadIdx.x; i < c; i += 256) { p.out_keys[ob + i] = s.ckey[i]; p.out_pos[ob + i] = s.cpos[i]; }
-  if (threadIdx.x == 0) {
-    p.out_cnt[item] = (uint32_t)c;
-    if (fl) atomicOr(&p.flags[qi], fl);
-  }
-  }  // item loop
-}
-
-
-
 // ------------------------------------------------------------------------------------
 // a18: 4-bit PQ (compute_pq_distance_4bit, pq/distance.rs:147-284).  Per (query, partition):
 // the first flat_num = max(200, min(k_hint, n_p)) rows and the n_p % 16 tail get exact f32 LUT
@@ -814,20 +704,8 @@ __global__ void fill_u32_kernel(uint32_t *p, uint32_t v, int64_t n) {
 template <int SD, int METRIC>
 static void launch_scan_mu(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t lds) {
   const int mu = (a.m % 16 == 0) ? a.m / 16 : 0;
-  // register-resident codebook: d = m*SD <= 128 and enough items to amortise the per-workgroup load
-  // measured 2x SLOWER than the plain kernel (181 VGPRs -> 2 waves/SIMD: the LDS gathers need occupancy);
-  // kept behind LANCE_HIP_PERSIST=1 for experiments only
-  static const bool no_persist = getenv("LANCE_HIP_PERSIST") == nullptr;
-  if (!no_persist && !a.ablate && mu > 0 && mu * 16 * SD <= 128 && grid >= 4 * ctx->num_cus) {
-    const int g = 2 * ctx->num_cus;
-    if constexpr (SD == 8) {
-      if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_persist_kernel<8, METRIC, 1>), dim3(g), dim3(256), lds, ctx->stream, a, grid); return; }
-    }
-    if constexpr (SD == 4) {
-      if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_persist_kernel<4, METRIC, 1>), dim3(g), dim3(256), lds, ctx->stream, a, grid); return; }
-      if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_persist_kernel<4, METRIC, 2>), dim3(g), dim3(256), lds, ctx->stream, a, grid); return; }
-    }
-  }
+  // (a register-resident-codebook persistent variant was measured 2x slower -- 181 VGPRs leave 2 waves/SIMD and the
+  // LDS gathers need occupancy -- and removed)
   switch (mu) {
     case 1: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 1>), dim3(grid), dim3(256), lds, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL((ivfpq_scan_kernel<SD, METRIC, 2>), dim3(grid), dim3(256), lds, ctx->stream, a); break;

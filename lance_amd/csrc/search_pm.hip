@@ -37,9 +37,6 @@ namespace lh {
 #endif
 constexpr int PM_BS = LH_PM_BS;            // lanes per workgroup (512: 3 workgroups x 8 waves per CU)
 constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query, pruned class (one round + slack)
-#ifndef LH_PM_EARLY
-#define LH_PM_EARLY 0   /* wave-level early abandon measured 2-3 % slower: a wave is rarely all-dead */
-#endif
 #ifndef LH_PM_RPL1
 #define LH_PM_RPL1 2
 #endif
@@ -62,7 +59,6 @@ struct PmArgs {
   uint32_t *tglobal;            // [nq] running upper bound of the keff-th distance (key)
   uint32_t *pool_key, *pool_pos, *pool_cnt;  // [nq][pool_cap], [nq]
   int pool_cap;                 // pool entries per query
-  int ablate;                   // perf experiments only (LANCE_HIP_PM_ABLATE): 1 no appends, 2 no tighten in the loop, 4 skip gathers, 8 per-lane atomics
   uint32_t *flags;
 };
 
@@ -388,53 +384,10 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
       if (slot < CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
     }
   };
-  // class 0 (no bound yet: most rows are candidates): one LDS atomic per wave and buffer instead of one per lane
-  auto scan_rows_agg = [&](int base, int u, const uint4 (&cw)[MU], uint32_t T0, uint32_t T1) {
-    const int row = base + u * PM_BS + threadIdx.x;
-    const bool live = row < np;
-    float d0 = 0.0f, d1 = 0.0f;
-    if (live && !(p.ablate & 4)) {
-#pragma unroll
-      for (int w = 0; w < MU; ++w) {
-        const uint32_t cws[4] = {cw[w].x, cw[w].y, cw[w].z, cw[w].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            const f2 v = lut2[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
-            d0 += v.x; d1 += v.y;
-          }
-      }
-    }
-    if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
-    const uint32_t k0 = order_key(d0), k1 = order_key(d1);
-    const int lane = threadIdx.x & 63;
-    const uint64_t below = (1ull << lane) - 1ull;
-    const bool p0 = live && k0 <= T0 && !(p.ablate & 1), p1 = live && has1 && k1 <= T1 && !(p.ablate & 1);
-    const uint64_t m0 = __ballot(p0), m1 = __ballot(p1);
-    if (m0) {
-      uint32_t b0s = 0;
-      if (lane == __ffsll((long long)m0) - 1) b0s = atomicAdd(&misc[0], (uint32_t)__popcll(m0));
-      b0s = __shfl(b0s, __ffsll((long long)m0) - 1);
-      if (p0) {
-        const uint32_t slot = b0s + (uint32_t)__popcll(m0 & below);
-        if (slot < CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
-      }
-    }
-    if (m1) {
-      uint32_t b1s = 0;
-      if (lane == __ffsll((long long)m1) - 1) b1s = atomicAdd(&misc[2], (uint32_t)__popcll(m1));
-      b1s = __shfl(b1s, __ffsll((long long)m1) - 1);
-      if (p1) {
-        const uint32_t slot = b1s + (uint32_t)__popcll(m1 & below);
-        if (slot < CAP) { ck1[slot] = k1; cp1[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
-      }
-    }
-  };
   for (int base = 0; base < np; base += ROUND) {
     constexpr int LIMIT = RP == 1 ? CAP - PM_BS : CAP / 2;
-    if ((int)misc[0] > LIMIT && !(p.ablate & 2)) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
-    if ((int)misc[2] > LIMIT && !(p.ablate & 2)) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
+    if ((int)misc[0] > LIMIT) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
+    if ((int)misc[2] > LIMIT) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
     const uint32_t cnt0_before = misc[0], cnt1_before = misc[2];
     const uint32_t T0 = misc[1], T1 = misc[3];
     uint4 cwc[RP][MU];
@@ -450,12 +403,8 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
         for (int w = 0; w < MU; ++w) cwn[u][w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)rown * m + w * 16);
       }
     }
-    if (RP == 1 && (p.ablate & 8)) {
-      scan_rows_agg(base, 0, cwc[0], T0, T1);
-    } else {
 #pragma unroll
-      for (int u = 0; u < RP; ++u) scan_rows(base, u, cwc[u], T0, T1);
-    }
+    for (int u = 0; u < RP; ++u) scan_rows(base, u, cwc[u], T0, T1);
     __syncthreads();
     if constexpr (RP > 1) {
       // optimistic round overflowed a buffer (more than CAP/2 rows under the bound in 2 sub-rounds): roll the
@@ -658,7 +607,6 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.desc = desc;
-  { const char *ab = getenv("LANCE_HIP_PM_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const int dpad = (d + 3) & ~3;
   const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4 + (size_t)PM_CAP * 16;
