@@ -1,7 +1,7 @@
 """SURVEY 8(d) measurement grid on one MI355X (not the contract bench -- bench.py is).
 
 Writes one JSON document with: measured device-copy bandwidth (the "peak_measured" denominator), the C1 flat
-scan, the C2 recall/QPS grid nprobes x refine, the bit-exact id check at nprobes = nlist against the CPU oracle,
+scan, the C2 recall/QPS grid nprobes x refine, IVF_FLAT on the same data,
 and (with --c3) the C3-shaped cosine build + search.  Usage: python scripts/measure_grid.py [--c3] > out.json
 """
 import argparse
@@ -86,20 +86,9 @@ def main():
                              "ms_per_batch": dt * 1e3, "qps": nq / dt, "exact_replays": eng.search_stats()})
         out["c2_grid"] = grid
 
-        # ---- bit-exact id check at nprobes = nlist against the oracle (same centroids/codebook/codes) ----
-        import oracle as orc
-        offs, codes_t, rid = idx.export_storage()
-        oidx = orc.IvfPqIndex("l2", idx.centroids, idx.codebook, offs, codes_t, rid)
-        nchk = 64
-        xq = q[:nchk].cpu().numpy()
-        raw = x.cpu().numpy()
-        chk = {}
-        for rf in (0, 10):
-            oi, od = oidx.search(xq, 10, nlist, refine=rf, raw=raw if rf else None)
-            gi, gd = idx.search_device(q[:nchk], 10, nlist, rf)
-            chk[f"refine{rf}"] = {"ids_equal": bool((oi == gi.cpu().numpy().view(np.uint64)).all()),
-                                  "dists_bit_equal": bool((od.view(np.uint32) == gd.cpu().numpy().view(np.uint32)).all())}
-        out["c2_exhaustive_vs_oracle"] = {"queries": nchk, "nprobes": nlist, **chk}
+        # (the bit-exact id check at nprobes = nlist against the CPU oracle lives in tests/test_gpu_parity.py::
+        #  test_full_size_properties_sift1m -- only tests, smoke() and bench.py's cpu_baseline may touch oracle/)
+        raw = None
         # ---- IVF_FLAT (N4) on the same data: exact distances inside the probed partitions -------------------
         fx = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=nlist)
         fl = []

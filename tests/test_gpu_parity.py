@@ -327,7 +327,7 @@ def test_full_size_properties_sift1m(engine, oracle):
     # oracle on the same artefacts, 64 queries, un-refined and refined, exhaustive probes included
     oidx = oracle.IvfPqIndex("l2", idx.centroids, idx.codebook, offs, codes_t, rid)
     qh = q[:64].cpu().numpy(); xh = x.cpu().numpy()
-    for nprobes, rf in ((256, 0), (10, 10)):
+    for nprobes, rf in ((256, 0), (256, 10), (10, 10)):     # the bit-exact id check at nprobes = nlist
         gi, gd = idx.search_device(q[:64], 10, nprobes, rf)
         oi, od = oidx.search(qh, 10, nprobes, refine=rf, raw=xh)
         assert (gi.cpu().numpy().view(np.uint64) == oi).all()
