@@ -117,6 +117,7 @@ class BuildStats:
     ivf_iters: int = 0
     pq_iters: Optional[np.ndarray] = None
     ivf_loss: float = 0.0
+    ivf_training: str = "single"      # multi-GPU builds: "replicated" | "sharded" (lance_amd/dist.py)
 
     @property
     def total(self):

@@ -613,3 +613,32 @@ def test_list_sharded_search_on_device_world1(eng, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_sharded_build_world1_is_bit_identical_to_single_gpu(eng, oracle):
+    """lance_amd.dist.create_index_sharded with replicated IVF training, model-parallel PQ and a row-sharded transform
+    (RCCL, world_size 1 here) must produce the single-GPU index bit for bit; the row-sharded k-means variant agrees
+    to f32 round-off."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import lance_amd
+    from lance_amd.dist import create_index_sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29791"
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x = torch.from_numpy(sift_like(40000, 64, 411)).cuda()
+        a = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=32, num_sub_vectors=8, sample_rate=64, engine=eng)
+        b = create_index_sharded(x, metric="l2", num_partitions=32, num_sub_vectors=8, sample_rate=64, engine=eng)
+        assert b.stats.ivf_training == "replicated"
+        assert (a.centroids.view(np.uint32) == b.centroids.view(np.uint32)).all()
+        assert (a.codebook.view(np.uint32) == b.codebook.view(np.uint32)).all()
+        assert torch.equal(a.part_ids, b.part_ids) and torch.equal(a.codes, b.codes)
+        c = create_index_sharded(x, metric="l2", num_partitions=32, num_sub_vectors=8, sample_rate=64, engine=eng, ivf_training="sharded")
+        assert np.allclose(a.centroids, c.centroids, rtol=1e-4, atol=1e-3)
+    finally:
+        if created:
+            dist.destroy_process_group()
