@@ -221,6 +221,7 @@ def main():
 
     if not args.no_cpu_baseline and world == 1:
         import oracle as orc
+        native = orc.use_native_build()      # time the CPU side with code generated for THIS host
         o_offs, o_codes_t, o_rid = idx.export_storage()
         oidx = orc.IvfPqIndex("l2", idx.centroids, idx.codebook, o_offs, o_codes_t, o_rid)
         xq = qbatches[0].cpu().numpy()
@@ -246,6 +247,7 @@ def main():
                                   "sample": f"the same {args.nq}-query batch, same index/nprobes/refine, best of {reps} runs "
                                             f"of oracle/lance_oracle.c (OpenMP over queries)",
                                   "ids_equal_gpu": same,
+                                  "oracle_march": "native" if native else "x86-64-v3",
                                   "ivf_kmeans_sec_per_iter_65536x128_k256": cpu_iter}
     elif world == 1:
         result["cpu_baseline"] = None

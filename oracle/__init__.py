@@ -28,6 +28,20 @@ def build(force=False):
 _lib = None
 
 
+def use_native_build():
+    """bench.py cpu_baseline: rebuild the oracle for the host it is timed on (-march=native) and switch to it.
+    Same arithmetic (-ffp-contract=off), only the vector width of the compiler's code changes.  -> True if active."""
+    global _SO, _lib
+    out = os.path.join(_HERE, "liblance_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native", "MARCH=native", "OUT=liblance_oracle_native.so"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    _SO, _lib = out, None
+    return True
+
+
 def lib():
     global _lib
     if _lib is None:
