@@ -19,6 +19,8 @@
 // The union of the pool always contains every scanned row with dist <= final T, whatever order the items
 // ran in, so results are deterministic and equal to the reference's SortExec over per-partition heaps.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 #include <vector>
 
@@ -60,6 +62,7 @@ struct PmArgs {
   uint32_t *pool_key, *pool_pos, *pool_cnt;  // [nq][pool_cap], [nq]
   int pool_cap;                 // pool entries per query
   uint32_t *flags;
+  unsigned long long *prof;     // optional [8]: summed shader clocks per phase of the scan kernel (thread 0 of every item)
 };
 
 // ---- threshold machinery, generic in the workgroup size ---------------------------------------------
@@ -237,8 +240,10 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     s_valid = valid; s_part = part; s_q0 = q0; s_q1 = q1;
     misc[0] = 0; misc[2] = 0; misc[5] = 0;
   }
+  const long long pt0 = p.prof ? clock64() : 0;
   __syncthreads();
   if (!s_valid) return;
+  const long long pt1 = p.prof ? clock64() : 0;
   const int part = s_part, q0 = s_q0, q1 = s_q1;
   const bool has1 = q1 >= 0;
   // Stage B: everything that depends only on the descriptor is requested together (one memory round trip):
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   if (threadIdx.x == 0) {
     misc[1] = p.tglobal[q0];
     misc[3] = has1 ? p.tglobal[q1] : 0u;
+    misc[6] = misc[1]; misc[7] = misc[3];     // the bounds this item started from (publish skips the atomicMin if unchanged)
   }
   const uint32_t off = p.part_offsets[part];
   const int np = (int)(p.part_offsets[part + 1] - off);
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     r0[threadIdx.x] = a; r1[threadIdx.x] = bq;
   }
   __syncthreads();
+  const long long pt2 = p.prof ? clock64() : 0;
   // LUT pair: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half*m/2, (half+1)*m/2); each
   // codebook entry is fetched once and used for both residuals.  Second half of the entries is requested
   // before the first half is consumed.
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   }
   __syncthreads();
 
+  const long long pt3 = p.prof ? clock64() : 0;
   const uint8_t *pcodes = p.codes + (int64_t)off * m;
   if constexpr (RPL == 0) {
     // BOUND pass (class 0): no candidates are kept.  Every lane tracks the smallest key among its rows; the
@@ -435,54 +443,70 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
       }
     }
   }
-  // publish: shrink each buffer once, lower the query's global bound, append the survivors to its pool
+  const long long pt4 = p.prof ? clock64() : 0;
+  // publish: shrink each buffer once, lower the query's global bound, append the survivors to its pool.  The two
+  // queries go through it TOGETHER so that their global atomics (the only long-latency operations here) are in
+  // flight at the same time, and a query whose threshold was never tightened locally skips the atomicMin round trip
+  // (its T is still the value read from Tglobal at item start: stale at worst, never invalid).
+  __shared__ uint32_t s_tg[2], s_base[2], s_tot[2], s_wr[2];
   for (int j = 0; j < 2; ++j) {
     if (j == 1 && !has1) break;
     const CandBuf &b = j ? b1 : b0;
-    const int qj = j ? q1 : q0;
-    if (*b.cnt == 0) continue;  // uniform: nothing of this partition can reach the query's top list
     // <= PM_BS entries -> one entry per lane -> the bound is the exact keff-th smallest: publish ~keff rows
     if ((int)*b.cnt > p.keff + 32) tighten_bs<PM_BS, CAP>(b, p.keff, sorted, &misc[4]);
     if ((int)*b.cnt > PM_BS) tighten_bs<PM_BS, CAP>(b, p.keff, sorted, &misc[4]);
-    __syncthreads();
-    const int c = min((int)*b.cnt, CAP);
-    __shared__ uint32_t s_base, s_tg;
-    if (threadIdx.x == 0) {
-      // *b.T is always a valid upper bound of this query's final keff-th distance: it is either the value read
-      // from tglobal or the keff-th-smallest bound of >= keff real rows of this query
-      const uint32_t mineT = *b.T;
-      const uint32_t old = atomicMin(&p.tglobal[qj], mineT);
-      s_tg = min(old, mineT);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int j = threadIdx.x;
+    const CandBuf &b = j ? b1 : b0;
+    const bool on = j == 0 || has1;
+    uint32_t tg = on ? *b.T : 0u;
+    // *b.T is always a valid upper bound of this query's final keff-th distance: it is either the value read
+    // from tglobal or the keff-th-smallest bound of >= keff real rows of this query
+    if (on && *b.cnt > 0 && tg < misc[6 + j]) tg = min(atomicMin(&p.tglobal[j ? q1 : q0], tg), tg);
+    s_tg[j] = tg; s_tot[j] = 0; s_wr[j] = 0;
+  }
+  __syncthreads();
+  const int c0n = min((int)*b0.cnt, CAP), c1n = has1 ? min((int)*b1.cnt, CAP) : 0;
+  {
+    uint32_t m0 = 0, m1 = 0;
+    const uint32_t tg0 = s_tg[0], tg1 = s_tg[1];
+    for (int i = threadIdx.x; i < c0n; i += PM_BS) m0 += ck0[i] <= tg0 ? 1u : 0u;
+    for (int i = threadIdx.x; i < c1n; i += PM_BS) m1 += ck1[i] <= tg1 ? 1u : 0u;
+    if (m0) atomicAdd(&s_tot[0], m0);
+    if (m1) atomicAdd(&s_tot[1], m1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int j = threadIdx.x;
+    const uint32_t tot = s_tot[j];
+    s_base[j] = tot ? atomicAdd(&p.pool_cnt[j ? q1 : q0], tot) : 0u;
+  }
+  __syncthreads();
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t tot = s_tot[j], basep = s_base[j], tg = s_tg[j];
+    if (!tot) continue;
+    const int qj = j ? q1 : q0;
+    if (basep + tot > (uint32_t)p.pool_cap) {
+      if (threadIdx.x == 0) atomicOr(&p.flags[qj], FLAG_OVERFLOW);
+      continue;
     }
-    __syncthreads();
-    const uint32_t tg = s_tg;
-    // count survivors (key <= tg), reserve pool space, write
-    uint32_t mine = 0;
-    for (int i = threadIdx.x; i < c; i += PM_BS) mine += b.key[i] <= tg ? 1u : 0u;
-    if (threadIdx.x == 0) misc[4] = 0;
-    __syncthreads();
-    if (mine) atomicAdd(&misc[4], mine);
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = misc[4] ? atomicAdd(&p.pool_cnt[qj], misc[4]) : 0u;
-    __syncthreads();
-    const uint32_t basep = s_base, tot = misc[4];
-    __syncthreads();
-    if (tot) {
-      if (basep + tot > (uint32_t)p.pool_cap) {
-        if (threadIdx.x == 0) atomicOr(&p.flags[qj], FLAG_OVERFLOW);
-      } else {
-        if (threadIdx.x == 0) misc[4] = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < c; i += PM_BS) {
-          if (b.key[i] <= tg) {
-            const uint32_t slot = basep + atomicAdd(&misc[4], 1u);
-            p.pool_key[(int64_t)qj * p.pool_cap + slot] = b.key[i];
-            p.pool_pos[(int64_t)qj * p.pool_cap + slot] = b.pos[i];
-          }
-        }
+    const uint32_t *bk = j ? ck1 : ck0, *bp = j ? cp1 : cp0;
+    const int c = j ? c1n : c0n;
+    for (int i = threadIdx.x; i < c; i += PM_BS) {
+      if (bk[i] <= tg) {
+        const uint32_t slot = basep + atomicAdd(&s_wr[j], 1u);
+        p.pool_key[(int64_t)qj * p.pool_cap + slot] = bk[i];
+        p.pool_pos[(int64_t)qj * p.pool_cap + slot] = bp[i];
       }
     }
-    __syncthreads();
+  }
+  if (p.prof && threadIdx.x == 0) {
+    const long long pt5 = clock64();
+    atomicAdd(&p.prof[0], (unsigned long long)(pt1 - pt0)); atomicAdd(&p.prof[1], (unsigned long long)(pt2 - pt1));
+    atomicAdd(&p.prof[2], (unsigned long long)(pt3 - pt2)); atomicAdd(&p.prof[3], (unsigned long long)(pt4 - pt3));
+    atomicAdd(&p.prof[4], (unsigned long long)(pt5 - pt4)); atomicAdd(&p.prof[5], 1ull);
   }
   if (threadIdx.x == 0 && (misc[5] & FLAG_OVERFLOW)) {
     atomicOr(&p.flags[q0], FLAG_OVERFLOW);
@@ -607,6 +631,11 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.desc = desc;
+  a.prof = nullptr;
+  if (getenv("LANCE_HIP_PM_PROF")) {
+    a.prof = ctx->scratch_t<unsigned long long>("pm.prof", 8);
+    if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
+  }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const int dpad = (d + 3) & ~3;
   const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4 + (size_t)PM_CAP * 16;
@@ -633,6 +662,14 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
         else if (sd == 16) ok = launch_pm_mu<16, METRIC_L2>(ctx, a, grid, lds);
       }
       LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
+      if (a.prof && pass == 1) {
+        unsigned long long h[8];
+        (void)hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (h[5]) fprintf(stderr, "[pm prof] items=%llu clocks/item: desc %.0f | q,centroid,residual %.0f | LUT %.0f | scan %.0f | publish %.0f\n", h[5],
+                          (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+        (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
+      }
     }
   }
   {
