@@ -82,6 +82,65 @@ __global__ __launch_bounds__(256) void select_probes_kernel(const float *__restr
   }
 }
 
+// nlist <= 256 (C2): one WAVE per query, the 256 (dist, id) keys live 4 per lane and the whole bitonic network runs on
+// registers and shuffles -- no LDS, no barriers (the workgroup-wide LDS version spends its time in 36 __syncthreads).
+// Element e of the network sits in register e / 64 of lane e % 64.
+__global__ __launch_bounds__(256) void select_probes_wave_kernel(const float *__restrict__ matrix, int nlist, int nprobes, int nq,
+                                                                 uint32_t *__restrict__ part_ids, float *__restrict__ dists) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const float *row = matrix + (int64_t)q * nlist;
+  unsigned long long v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = j * 64 + lane;
+    v[j] = e < nlist ? ((unsigned long long)order_key(row[e]) << 32) | (uint32_t)e : ~0ull;
+  }
+#pragma unroll
+  for (int k2 = 2; k2 <= 256; k2 <<= 1) {
+#pragma unroll
+    for (int dd = k2 >> 1; dd > 0; dd >>= 1) {
+      if (dd >= 64) {
+        const int jd = dd >> 6;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if ((j & jd) == 0) {
+            const bool up = ((j * 64) & k2) == 0;          // lane bits never reach k2 >= 128
+            const unsigned long long a = v[j], b = v[j | jd];
+            if ((a > b) == up) { v[j] = b; v[j | jd] = a; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = j * 64 + lane;
+          const unsigned long long o = __shfl_xor(v[j], dd, 64);
+          const bool up = (e & k2) == 0, lower = (lane & dd) == 0;
+          v[j] = (lower == up) ? (v[j] < o ? v[j] : o) : (v[j] > o ? v[j] : o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = j * 64 + lane;
+    if (e < nprobes) {
+      part_ids[(int64_t)q * nprobes + e] = (uint32_t)v[j];
+      if (dists) dists[(int64_t)q * nprobes + e] = key_to_float((uint32_t)(v[j] >> 32));
+    }
+  }
+}
+
+static void launch_select_probes(lance_hip_ctx *ctx, const float *matrix, int nlist, int nprobes, int nq, uint32_t *part_ids, float *dists) {
+  if (nlist <= 256) {
+    hipLaunchKernelGGL(select_probes_wave_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, ctx->stream, matrix, nlist, nprobes, nq, part_ids, dists);
+  } else {
+    const int P = next_pow2(nlist);
+    hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, nlist, P, nprobes, part_ids, dists);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 struct ScanArgs {
   const float *q;  // [nq][d], normalised for cosine
@@ -771,9 +830,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     pa.x = qs; pa.n = nq; pa.ldx = d; pa.cent = ix->centroids; pa.k = nlist; pa.matrix = matrix;
     LH_TRY(launch_dist_matrix(ctx, pa, d, scan_metric, 1));
     ScopedTimer t(ctx, "select_probes");
-    const int P = next_pow2(nlist);
-    hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, nlist, P, (int)nprobes,
-                       probes, (float *)nullptr);
+    launch_select_probes(ctx, matrix, nlist, (int)nprobes, (int)nq, probes, nullptr);
   }
   uint64_t *cand_rid = nullptr;
   uint32_t *cand_cnt = nullptr;
@@ -934,9 +991,7 @@ int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const v
   pa.x = qf; pa.n = nq; pa.ldx = d;
   pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
   LH_TRY(launch_dist_matrix(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
-  const int P = next_pow2((int)nlist);
-  hipLaunchKernelGGL(select_probes_kernel, dim3(nq), dim3(256), (size_t)P * 8, ctx->stream, matrix, (int)nlist, P, (int)nprobes,
-                     part_ids, dists);
+  launch_select_probes(ctx, matrix, (int)nlist, (int)nprobes, (int)nq, part_ids, dists);
   LH_CHECK_HIP(hipGetLastError());
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
