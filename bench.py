@@ -46,6 +46,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        # only rank 0 reports; keep the other ranks' stdout (RCCL prints a version banner through C stdio) out of the
+        # launcher's combined output so that the JSON line stays the only thing on it
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -251,9 +255,16 @@ def main():
                                   "ivf_kmeans_sec_per_iter_65536x128_k256": cpu_iter}
     elif world == 1:
         result["cpu_baseline"] = None
-    print(json.dumps(result))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    # RCCL's banner sits in the C stdio buffer until exit: push it out first so that the JSON line is the LAST line
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
