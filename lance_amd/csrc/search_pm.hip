@@ -39,6 +39,7 @@ namespace lh {
 #endif
 constexpr int PM_BS = LH_PM_BS;            // lanes per workgroup (512: 3 workgroups x 8 waves per CU)
 constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query, pruned class (one round + slack)
+constexpr int PM_CAP_BOUND = 16;           // the bound pass keeps no candidates: its LDS is the LUT pair only (4 workgroups per CU)
 #ifndef LH_PM_RPL1
 #define LH_PM_RPL1 2
 #endif
@@ -569,8 +570,8 @@ template <int SD, int METRIC>
 static bool launch_pm_mu(lance_hip_ctx *ctx, const PmArgs &a, unsigned grid, size_t lds) {
   const int mu = a.m / 16;
   if (a.cls == 0 && a.bound_pass) {
-    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 0, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
-    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 0, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 0, PM_CAP_BOUND>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 0, PM_CAP_BOUND>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   } else if (a.cls == 0) {   // LANCE_HIP_PM_NOBOUND=1: the earlier two-class flow (class 0 selects among unfiltered rows)
     if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
     if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
@@ -638,7 +639,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const int dpad = (d + 3) & ~3;
-  const size_t lds = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4 + (size_t)PM_CAP * 16;
+  const size_t lds_base = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4;
   {
     // pass 0 (bound): every query's nearest partition is streamed once to seed Tglobal[q]; pass 1 (main): all
     // (query, probe) pairs, nearest partition included, prune with that bound from their first row.
@@ -648,6 +649,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
       ScopedTimer t(ctx, pass == 0 ? "ivfpq_scan_c0" : "ivfpq_scan_c1");
       a.cls = pass == 0 ? 0 : (nobound ? 1 : 2);
       a.bound_pass = (pass == 0 && !nobound) ? 1 : 0;
+      const size_t lds = lds_base + (size_t)(a.bound_pass ? PM_CAP_BOUND : PM_CAP) * 16;
       // upper bound of sum ceil(c_vp / 2) over the covered virtual partitions; surplus workgroups exit at once
       const size_t cpairs = a.cls == 0 ? (size_t)nq : (a.cls == 1 ? (size_t)nq * (nprobes - 1) : (size_t)nq * nprobes);
       const unsigned grid = (unsigned)(cpairs / 2 + (a.cls == 2 ? 2 : 1) * nlist + 1);
