@@ -121,7 +121,8 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
         65,536-row sample takes 0.17 ms, less than one all-reduce round trip), or
       * "sharded": rows split over the ranks, one all-reduce per Lloyd iteration (train_kmeans_sharded) -- for
         training sets large enough that the E-step dominates (C4 and up).
-    "auto" picks by the E-step size.  With replicated training the whole index is bit-identical to the
+    "auto" picks by the E-step size and keeps nlist > 256 replicated (the reference's hierarchical trainer is a chain
+    of small sub-problems; "sharded" always means the flat Lloyd loop).  With replicated training the whole index is bit-identical to the
     single-GPU build (same sample, same seeds, independent sub-quantisers, per-row encode)."""
     import time
 
