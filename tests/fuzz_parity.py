@@ -1,0 +1,89 @@
+"""Randomised differential run: HIP path vs CPU oracle on random shapes (not collected by pytest; GPU only).
+
+    python tests/fuzz_parity.py [seconds] [seed]
+
+Every case builds an IVF_PQ index from oracle-trained models, then compares encode output, storage layout, searches
+(random k / nprobes / refine), the flat scan and IVF_FLAT, bit for bit.  Prints the failing configuration and exits 1.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+f32 = np.float32
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    import torch
+    import oracle
+    from lance_amd.engine import Engine, DeviceIndex, DeviceFlatIndex
+    eng = Engine()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    ncase = 0
+    while time.time() < t_end:
+        sd = int(rng.choice([4, 8, 16, 5]))
+        m = int(rng.choice([1, 2, 4, 8, 16, 32])) if sd != 5 else int(rng.choice([4, 8]))
+        d = m * sd
+        if d > 256:
+            continue
+        n = int(rng.integers(600, 12000))
+        nlist = int(rng.integers(2, 40))
+        metric = str(rng.choice(["l2", "dot", "cosine"]))
+        integer = bool(rng.integers(0, 2))
+        if integer:
+            x = rng.integers(0, 30, (n, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
+            q = rng.integers(0, 30, (40, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
+        else:
+            x = (rng.standard_normal((n, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
+            q = (rng.standard_normal((40, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
+        cfg = dict(seed=seed, case=ncase, n=n, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer)
+        try:
+            xs = oracle.normalize(x) if metric == "cosine" else x
+            km = "l2" if metric == "cosine" else metric
+            cent, _, _, _ = oracle.kmeans_train(xs[: max(nlist * 32, nlist)], nlist, max_iters=5, seed=ncase, metric=km)
+            part, _ = oracle.assign(xs, cent, km)
+            res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
+            cb, _ = oracle.pq_train(res[: 256 * 8], m, max_iters=4, seed=ncase + 1)
+            oidx = oracle.build_index(x, cent, cb, metric)
+            gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+            assert (gpart.cpu().numpy().view(np.uint32) == oidx.part_ids).all(), "part ids"
+            assert (gcodes.cpu().numpy() == oidx.codes_rowmajor).all(), "codes"
+            g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+            offs, codes_t, rid = g.export()
+            assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all(), "layout"
+            for _ in range(3):
+                k = int(rng.integers(1, 60)); nprobes = int(rng.integers(1, nlist + 1)); rf = int(rng.choice([0, 0, 1, 3]))
+                if k * max(rf, 1) > 128:
+                    rf = 0
+                gi, gd = g.search(q, k, nprobes, rf)
+                oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+                assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
+                assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
+            k = int(rng.integers(1, 40))
+            gi, gd = eng.flat_topk(x, q, k, metric)
+            oi, od = oracle.flat_knn(x, q, k, metric)
+            assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"flat k={k}"
+            if metric != "cosine":
+                fpart, _ = eng.assign(x, cent, metric)
+                fx = DeviceFlatIndex.create(eng, metric, cent, x, fpart)
+                nprobes = int(rng.integers(1, nlist + 1))
+                gi, gd = fx.search(q[:8], k, nprobes)
+                oi, od = oracle.ivfflat_search(x, cent, q[:8], k, nprobes, metric)
+                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat k={k} nprobes={nprobes}"
+                fx.close()
+            g.close()
+        except AssertionError as e:
+            print("MISMATCH", e, cfg, flush=True)
+            sys.exit(1)
+        ncase += 1
+    print(f"fuzz ok: {ncase} random configurations, seed {seed}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
