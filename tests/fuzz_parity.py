@@ -36,44 +36,52 @@ def main():
         nlist = int(rng.integers(2, 40))
         metric = str(rng.choice(["l2", "dot", "cosine"]))
         integer = bool(rng.integers(0, 2))
+        int8 = metric != "cosine" and rng.random() < 0.25          # Int8 column: data int8, model f32
+        nbits = 4 if (m % 2 == 0 and rng.random() < 0.2) else 8
+        if int8:
+            integer = True
         if integer:
             x = rng.integers(0, 30, (n, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
             q = rng.integers(0, 30, (40, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
         else:
             x = (rng.standard_normal((n, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
             q = (rng.standard_normal((40, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
-        cfg = dict(seed=seed, case=ncase, n=n, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer)
+        if int8:
+            x = (x - 15.0).astype(f32); q = (q - 15.0).astype(f32)
+        xg = torch.from_numpy(x.astype(np.int8)) if int8 else x     # what the engine sees
+        qg = torch.from_numpy(q.astype(np.int8)) if int8 else q
+        cfg = dict(seed=seed, case=ncase, n=n, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer, int8=int8, nbits=nbits)
         try:
             xs = oracle.normalize(x) if metric == "cosine" else x
             km = "l2" if metric == "cosine" else metric
             cent, _, _, _ = oracle.kmeans_train(xs[: max(nlist * 32, nlist)], nlist, max_iters=5, seed=ncase, metric=km)
             part, _ = oracle.assign(xs, cent, km)
             res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
-            cb, _ = oracle.pq_train(res[: 256 * 8], m, max_iters=4, seed=ncase + 1)
-            oidx = oracle.build_index(x, cent, cb, metric)
-            gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+            cb, _ = oracle.pq_train(res[: 256 * 8], m, nbits=nbits, max_iters=4, seed=ncase + 1)
+            oidx = oracle.build_index(x, cent, cb, metric, nbits=nbits)
+            gpart, gcodes, _ = eng.ivfpq_encode(xg, cent, cb, metric)
             assert (gpart.cpu().numpy().view(np.uint32) == oidx.part_ids).all(), "part ids"
             assert (gcodes.cpu().numpy() == oidx.codes_rowmajor).all(), "codes"
-            g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+            g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=xg, dtype="int8" if int8 else None)
             offs, codes_t, rid = g.export()
             assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all(), "layout"
             for _ in range(3):
                 k = int(rng.integers(1, 60)); nprobes = int(rng.integers(1, nlist + 1)); rf = int(rng.choice([0, 0, 1, 3]))
                 if k * max(rf, 1) > 128:
                     rf = 0
-                gi, gd = g.search(q, k, nprobes, rf)
+                gi, gd = g.search(qg, k, nprobes, rf)
                 oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
                 assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
                 assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
             k = int(rng.integers(1, 40))
-            gi, gd = eng.flat_topk(x, q, k, metric)
+            gi, gd = eng.flat_topk(xg, qg, k, metric)
             oi, od = oracle.flat_knn(x, q, k, metric)
             assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"flat k={k}"
             if metric != "cosine":
-                fpart, _ = eng.assign(x, cent, metric)
-                fx = DeviceFlatIndex.create(eng, metric, cent, x, fpart)
+                fpart, _ = eng.assign(xg, cent, metric)
+                fx = DeviceFlatIndex.create(eng, metric, cent, xg, fpart)
                 nprobes = int(rng.integers(1, nlist + 1))
-                gi, gd = fx.search(q[:8], k, nprobes)
+                gi, gd = fx.search(qg[:8], k, nprobes)
                 oi, od = oracle.ivfflat_search(x, cent, q[:8], k, nprobes, metric)
                 assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat k={k} nprobes={nprobes}"
                 fx.close()
