@@ -169,7 +169,8 @@ int lance_hip_index_export(lance_hip_ctx *ctx, const lance_hip_index *idx, uint3
 /* ---- a14: IvfModel::find_partitions (ivf/storage.rs:107-119, kmeans.rs:1134-1158) -- */
 /* Batched.  Ascending by distance; equal distances ordered by partition id (the
  * reference's partial sort is unstable, so any order of equals is a valid outcome).
- * part_ids / dists: [nq][nprobes].  Cosine: q must already be normalised.            */
+ * part_ids / dists: [nq][nprobes].  Cosine: q must already be normalised.
+ * nlist <= 65536; with more than 8192 partitions nprobes <= 256.                        */
 int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const void *q, uint32_t nq, uint32_t d,
                               const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids,
                               float *dists);

@@ -308,7 +308,7 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
   LH_TRY(check_dtype(dtype, "index"));
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "index: f16 supports the L2 metric only in this version");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_COSINE || metric == LANCE_HIP_DOT, "index: bad metric %d", metric);
-  LH_REQUIRE(nlist > 0 && nlist <= 8192, "index: nlist=%u not supported in this version (1..8192)", nlist);
+  LH_REQUIRE(nlist > 0 && nlist <= 65536, "index: nlist=%u not supported in this version (1..65536)", nlist);
   LH_TRY(check_pq_params(d, m, nbits));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   auto *ix = new lance_hip_index();

@@ -828,7 +828,7 @@ extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metri
   LH_TRY(check_dtype(dtype, "ivfflat_create"));
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT, "ivfflat_create: metric must be L2 or Dot in this version");
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "ivfflat_create: f16 dot is not implemented in this version");
-  LH_REQUIRE(nlist > 0 && nlist <= 8192 && d > 0, "ivfflat_create: nlist=%u / d=%u not supported", nlist, d);
+  LH_REQUIRE(nlist > 0 && nlist <= 65536 && d > 0, "ivfflat_create: nlist=%u / d=%u not supported", nlist, d);
   LH_REQUIRE(n < (1ull << 32), "ivfflat_create: n too large for this version");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   auto *ix = new lance_hip_index();

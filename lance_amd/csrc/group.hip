@@ -142,14 +142,65 @@ __global__ __launch_bounds__(64) void group_scatter_kernel(const uint32_t *__res
   }
 }
 
+// ---- keys with more than 16384 distinct values (nlist up to 65536 and the 2 x nlist virtual partitions of the
+// partition-major scan): two stable passes, low 8 bits then the remaining high bits (LSD radix), each one the
+// LDS-histogram sort below; offsets come from a global histogram.
+__global__ __launch_bounds__(256) void group_digit_lo_kernel(const uint32_t *__restrict__ ids, int64_t n, int k, uint32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = ids[i] < (uint32_t)k ? (ids[i] & 255u) : LANCE_HIP_NONE;
+}
+__global__ __launch_bounds__(256) void group_digit_hi_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ p1,
+                                                             const uint32_t *__restrict__ nvalid, int64_t n, uint32_t *__restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) out[j] = j < (int64_t)*nvalid ? (ids[p1[j]] >> 8) : LANCE_HIP_NONE;
+}
+__global__ __launch_bounds__(256) void group_compose_kernel(const uint32_t *__restrict__ p1, const uint32_t *__restrict__ p2,
+                                                            const uint32_t *__restrict__ nvalid, int64_t n, uint32_t *__restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n && j < (int64_t)*nvalid) out[j] = p1[p2[j]];
+}
+__global__ __launch_bounds__(256) void group_count_kernel(const uint32_t *__restrict__ ids, int64_t n, int k, uint32_t *__restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && ids[i] < (uint32_t)k) atomicAdd(&counts[ids[i]], 1u);
+}
+
+int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_stride, int k, int batches,
+                 uint32_t *starts, uint32_t *sorted_rows, int64_t out_stride, const uint8_t *active);
+
+static int stable_group_wide(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int k, uint32_t *starts, uint32_t *sorted_rows) {
+  LH_REQUIRE(k <= (1 << 22), "stable_group: k=%d not supported (<= 4194304)", k);
+  const int k2 = (k + 255) / 256;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  uint32_t *klo = ctx->scratch_t<uint32_t>("group.klo", nn), *khi = ctx->scratch_t<uint32_t>("group.khi", nn);
+  uint32_t *p1 = ctx->scratch_t<uint32_t>("group.p1", nn), *p2 = ctx->scratch_t<uint32_t>("group.p2", nn);
+  uint32_t *st1 = ctx->scratch_t<uint32_t>("group.st1", 257), *st2 = ctx->scratch_t<uint32_t>("group.st2", (size_t)k2 + 1);
+  uint32_t *counts = ctx->scratch_t<uint32_t>("group.counts", (size_t)k);
+  if (!klo || !khi || !p1 || !p2 || !st1 || !st2 || !counts) return LANCE_HIP_ENOMEM;
+  const unsigned grid = (unsigned)cdiv(nn, 256);
+  hipLaunchKernelGGL(group_digit_lo_kernel, dim3(grid), dim3(256), 0, ctx->stream, ids, n, k, klo);
+  LH_TRY(stable_group(ctx, klo, n, n, 256, 1, st1, p1, n, nullptr));
+  hipLaunchKernelGGL(group_digit_hi_kernel, dim3(grid), dim3(256), 0, ctx->stream, ids, p1, st1 + 256, n, khi);
+  LH_TRY(stable_group(ctx, khi, n, n, k2, 1, st2, p2, n, nullptr));
+  hipLaunchKernelGGL(group_compose_kernel, dim3(grid), dim3(256), 0, ctx->stream, p1, p2, st1 + 256, n, sorted_rows);
+  LH_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)k * 4, ctx->stream));
+  hipLaunchKernelGGL(group_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, ids, n, k, counts);
+  hipLaunchKernelGGL(group_scan_totals_kernel, dim3(1), dim3(256), 0, ctx->stream, counts, k, starts, (const uint8_t *)nullptr);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 // ids: [batches][n] (stride id_stride) keys in [0,k) or NONE.  Outputs per batch:
 // starts[k+1] (exclusive offsets, starts[k] = number of grouped rows) and sorted_rows
 // (row indices grouped by key, ascending inside a group).
 int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_stride, int k, int batches,
                  uint32_t *starts, uint32_t *sorted_rows, int64_t out_stride, const uint8_t *active) {
-  LH_REQUIRE(k > 0 && k <= 16384, "stable_group: k=%d not supported (1..16384)", k);
+  LH_REQUIRE(k > 0, "stable_group: k=%d not supported", k);
   LH_REQUIRE(n < (1ll << 32), "stable_group: n too large");
   if (batches == 0) return LANCE_HIP_OK;
+  if (k > 16384) {
+    LH_REQUIRE(batches == 1 && active == nullptr, "stable_group: more than 16384 keys only for a single problem");
+    return stable_group_wide(ctx, ids, n, k, starts, sorted_rows);
+  }
   const int nblocks = (int)cdiv(n > 0 ? n : 1, GROUP_ROWS_PER_BLOCK);
   uint32_t *blockhist = ctx->scratch_t<uint32_t>("group.blockhist", (size_t)batches * k * nblocks);
   uint32_t *totals = ctx->scratch_t<uint32_t>("group.totals", (size_t)batches * k);

@@ -132,8 +132,60 @@ __global__ __launch_bounds__(256) void select_probes_wave_kernel(const float *__
   }
 }
 
+// nlist > 8192: the keys no longer fit an LDS sort.  Pass 1: every lane scans its share of the row and keeps its smallest
+// (dist, id) key; the nprobes-th smallest of the 256 lane minima is an upper bound T of the answer's last key.  Pass 2:
+// keys <= T go to an LDS list (first-come, 4096 entries); if more exist the list's own nprobes-th smallest replaces T
+// (it removes at least 4096 - nprobes of them) and the pass repeats.  The list is sorted and the first nprobes emitted.
+constexpr int SELBIG_CAP = 4096;
+__global__ __launch_bounds__(256) void select_probes_big_kernel(const float *__restrict__ matrix, int nlist, int nprobes,
+                                                                uint32_t *__restrict__ part_ids, float *__restrict__ dists) {
+  __shared__ uint64_t list[SELBIG_CAP];
+  __shared__ uint64_t lmin[256];
+  __shared__ uint32_t s_cnt;
+  const int q = blockIdx.x;
+  const float *row = matrix + (int64_t)q * nlist;
+  uint64_t mn = ~0ull;
+  for (int i = threadIdx.x; i < nlist; i += 256) {
+    const uint64_t v = ((uint64_t)order_key(row[i]) << 32) | (uint32_t)i;
+    mn = v < mn ? v : mn;
+  }
+  lmin[threadIdx.x] = mn;
+  __syncthreads();
+  bitonic_sort_u64(lmin, 256);
+  uint64_t T = lmin[min(nprobes, 256) - 1];
+  for (int round = 0; round < 64; ++round) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nlist; i += 256) {
+      const uint64_t v = ((uint64_t)order_key(row[i]) << 32) | (uint32_t)i;
+      if (v <= T) {
+        const uint32_t slot = atomicAdd(&s_cnt, 1u);
+        if (slot < (uint32_t)SELBIG_CAP) list[slot] = v;
+      }
+    }
+    __syncthreads();
+    const int c = (int)min(s_cnt, (uint32_t)SELBIG_CAP);
+    const bool over = s_cnt > (uint32_t)SELBIG_CAP;
+    int P = 64;
+    while (P < c) P <<= 1;
+    for (int i = c + threadIdx.x; i < P; i += 256) list[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort_u64(list, P);
+    if (!over) break;
+    T = list[nprobes - 1];          // strictly smaller than before: at least CAP - nprobes collected keys exceed it
+  }
+  for (int i = threadIdx.x; i < nprobes; i += 256) {
+    const uint64_t e = list[i];
+    part_ids[(int64_t)q * nprobes + i] = (uint32_t)e;
+    if (dists) dists[(int64_t)q * nprobes + i] = key_to_float((uint32_t)(e >> 32));
+  }
+}
+
 static void launch_select_probes(lance_hip_ctx *ctx, const float *matrix, int nlist, int nprobes, int nq, uint32_t *part_ids, float *dists) {
-  if (nlist <= 256) {
+  if (nlist > 8192) {
+    hipLaunchKernelGGL(select_probes_big_kernel, dim3(nq), dim3(256), 0, ctx->stream, matrix, nlist, nprobes, part_ids, dists);
+  } else if (nlist <= 256) {
     hipLaunchKernelGGL(select_probes_wave_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, ctx->stream, matrix, nlist, nprobes, nq, part_ids, dists);
   } else {
     const int P = next_pow2(nlist);
@@ -796,6 +848,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
                          uint64_t *ids, float *dists, uint32_t **flags_out) {
   LH_REQUIRE(k > 0, "search: k must be > 0");
   if (nprobes > ix->nlist) nprobes = ix->nlist;
+  LH_REQUIRE(ix->nlist <= 8192 || nprobes <= 256, "search: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
   LH_REQUIRE(nprobes > 0, "search: nprobes must be > 0");
   const uint32_t rf = refine_factor == 0 ? 1 : refine_factor;
   const uint32_t keff = k * rf;
@@ -978,9 +1031,10 @@ int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const v
   LH_REQUIRE(ctx && q && centroids && part_ids, "find_partitions: NULL argument");
   LH_TRY(check_dtype(dtype, "find_partitions"));
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "find_partitions: f16 dot is not implemented in this version");
-  LH_REQUIRE(nlist > 0 && nlist <= 8192, "find_partitions: nlist=%u not supported in this version (1..8192)", nlist);
+  LH_REQUIRE(nlist > 0 && nlist <= 65536, "find_partitions: nlist=%u not supported in this version (1..65536)", nlist);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nprobes > nlist) nprobes = nlist;
+  LH_REQUIRE(nlist <= 8192 || nprobes <= 256, "find_partitions: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
   if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
   float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
   if (!matrix) return LANCE_HIP_ENOMEM;

@@ -667,3 +667,34 @@ def test_query_chunking_flat_and_ivf_flat(eng, oracle):
     same = _np(gi).view(np.uint64) == fi
     # a boundary tie inside one partition follows the reference heap, not the row id: distances must agree everywhere
     assert (_np(gd).view(np.uint32) == fd.view(np.uint32)).all() and same.mean() > 0.99
+
+
+def test_many_partitions_nlist_20000(eng, oracle):
+    """nlist beyond the LDS-sorted range (C5 shape: nlist 65,536): the two-digit stable partition sort (index layout and
+    the 2 x nlist virtual partitions of the partition-major scan) and the pool-based probe selection."""
+    from lance_amd.engine import DeviceIndex, DeviceFlatIndex
+    rng = np.random.default_rng(21)
+    n, d, nlist, m = 100000, 32, 20000, 8
+    x = sift_like(n, d, 501)
+    q = sift_like(320, d, 502)
+    cent = x[rng.permutation(n)[:nlist]].copy() + f32(0.25)          # distinct, well spread centroids
+    part, _ = oracle.assign(x, cent, "l2")
+    cb, _ = oracle.pq_train(oracle.residual(x[:8192], cent, part[:8192]), m, max_iters=4, seed=3)
+    oidx = oracle.build_index(x, cent, cb, "l2")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "l2")
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all() and (_np(gcodes) == oidx.codes_rowmajor).all()
+    g = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    offs, codes_t, rid = g.export()
+    assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all()
+    pid, pd = eng.find_partitions(q, cent, 20)
+    opid, opd = oracle.find_partitions(q, cent, 20)
+    assert (_np(pid).view(np.uint32) == opid).all() and (_np(pd).view(np.uint32) == opd.view(np.uint32)).all()
+    for k, nprobes, rf in ((10, 20, 0), (10, 64, 5), (5, 3, 0)):       # 320 x 20 pairs -> partition-major path
+        gi, gd = g.search(q, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    fx = DeviceFlatIndex.create(eng, "l2", cent, x, gpart)
+    gi, gd = fx.search(q[:32], 10, 30)
+    oi, od = oracle.ivfflat_search(x, cent, q[:32], 10, 30, "l2")
+    assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
