@@ -282,7 +282,9 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
     LH_TRY(launch_residual(ctx, xs, (int64_t)n, (int)d, static_cast<const float *>(centroids), part_ids, res, f16));
     enc_in = res;
   }
-  LH_TRY(pq_encode_launch(ctx, scan_metric, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes, (int)nbits));
+  // the quantizer is built with DistanceType::L2 whatever the index metric (lance/src/index/vector/builder.rs:456) and
+  // ProductQuantizer::transform encodes with the quantizer's distance type (pq.rs:143,165): L2-nearest codeword, dot too
+  LH_TRY(pq_encode_launch(ctx, LANCE_HIP_L2, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes, (int)nbits));
   LH_CHECK_HIP(hipGetLastError());
   if (loss_out_host) {
     // sum of the assignment distances (compute_partitions, kmeans.rs:1276-1290): f64, host side

@@ -375,7 +375,10 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None, nbits=8):
     sm = L2 if m == COSINE else m
     part, _ = assign(xs, centroids, sm)
     res = residual(xs.astype(np.float16) if f16 else xs, centroids, np.where(part == NONE, 0, part)) if sm == L2 else xs
-    codes = pq_encode(res, codebook, sm, nbits=nbits)
+    # the quantizer is always BUILT with DistanceType::L2 (lance/src/index/vector/builder.rs:456 `Q::build(&training_data,
+    # DistanceType::L2, ..)`), and ProductQuantizer::transform encodes with the quantizer's own distance type
+    # (pq.rs:143,165): nearest codeword in L2 even for a dot index; only the query-side LUT uses the index metric
+    codes = pq_encode(res, codebook, L2, nbits=nbits)
     nlist = centroids.shape[0]
     offs, perm = partition_layout(part, nlist)
     codes_sorted = codes[perm]

@@ -476,3 +476,26 @@ def test_pq4_scan_structure(oracle):
     sat = exact[mid] < qmax          # below saturation: each of the m entries loses qmin (added back once) +- half a step
     err = exact[mid][sat] - d[mid][sat]
     assert np.abs(err - (m - 1) * qmin).max() <= m * step / 2 + 1e-3
+
+
+@pytest.mark.parametrize("nlist,metric,req", [(1, "l2", 0.9), (1, "cosine", 0.9), (1, "dot", 0.85),
+                                              (4, "l2", 0.9), (4, "cosine", 0.9), (4, "dot", 0.85)])
+def test_build_ivf_pq_recall_like_reference(oracle, nlist, metric, req):
+    """lance/src/index/vector/ivf/v2.rs:1354-1381 (test_build_ivf_pq_v3) + test_recall :1962-2007: 512 x 32 uniform
+    vectors, IVF(nlist) + default PQ (16 sub-vectors, 8 bits), query = row 0, k = 100, nprobes = nlist; recall against
+    the flat ground truth must reach the reference's requirement.  Pins the oracle's whole train -> encode -> search
+    pipeline the way the reference pins its own."""
+    rng = np.random.default_rng(1000 + nlist)
+    x = rng.random((512, 32)).astype(f32)
+    xs = oracle.normalize(x) if metric == "cosine" else x
+    km = "l2" if metric == "cosine" else metric
+    cent, _, _, _ = oracle.kmeans_train(xs, nlist, max_iters=50, balance_factor=f32(1.0) / f32(512), seed=3, metric=km)
+    part, _ = oracle.assign(xs, cent, km)
+    res = oracle.residual(xs, cent, part) if km == "l2" else xs
+    cb, _ = oracle.pq_train(res, 16, max_iters=50, seed=4)
+    idx = oracle.build_index(x, cent, cb, metric)
+    ids, dists = idx.search(x[:1], 100, nlist)
+    assert len(set(ids[0].tolist())) == 100
+    gt, _ = oracle.flat_knn(x, x[:1], 100, metric)
+    recall = len(set(ids[0].tolist()) & set(gt[0].tolist())) / 100.0
+    assert recall >= req, recall
