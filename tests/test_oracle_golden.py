@@ -536,3 +536,55 @@ def test_ivf_flat_exhaustive_equals_flat(oracle, metric):
     ids, dd = oracle.ivfflat_search(x, cent, x[:3], 100, 4, metric)
     gt, gd = oracle.flat_knn(x, x[:3], 100, metric)
     assert (np.sort(ids, axis=1) == np.sort(gt, axis=1)).all() and (dd.view(np.uint32) == gd.view(np.uint32)).all()
+
+
+def test_cosine_known_answers(oracle):
+    """cosine.rs:361-392: scipy / sklearn known answers, a 1024-long vector against a brute-force f32 evaluation, and the
+    d = 2 batch case; assert_relative_eq! default tolerance is f32::EPSILON relative."""
+    x = np.arange(1, 9, dtype=f32); y = np.arange(100, 108, dtype=f32)
+    assert abs(oracle.cosine(x, y) - (1.0 - 0.900_957)) <= 1e-6
+    x = np.array([3.0, 45.0, 7.0, 2.0, 5.0, 20.0, 13.0, 12.0], f32)
+    y = np.array([2.0, 54.0, 13.0, 15.0, 22.0, 34.0, 50.0, 1.0], f32)
+    assert abs(oracle.cosine(x, y) - (1.0 - 0.873_580_63)) <= 1e-6
+    x = np.arange(0, 1024, dtype=f32); y = np.arange(1024, 2048, dtype=f32)
+    xy = np.dot(x.astype(np.float64), y.astype(np.float64))
+    brute = 1.0 - xy / np.sqrt(np.dot(x.astype(np.float64), x.astype(np.float64))) / np.sqrt(np.dot(y.astype(np.float64), y.astype(np.float64)))
+    assert abs(oracle.cosine(x, y) - brute) <= 2e-6
+    x = np.array([16.0, 32.0], f32)
+    for yy in (np.array([1.0, 2.0], f32), np.array([4.0, 8.0], f32)):      # cosine_distance_batch(x, [1,2,4,8], 2)
+        assert abs(oracle.cosine(x, yy)) <= 1e-6
+
+
+def test_normalize_known_answer(oracle):
+    """kernels.rs:370-381: [1..5] / sqrt(55), squared norm of the result == 1 (relative f32 epsilon)."""
+    v = np.array([[1.0, 2.0, 3.0, 4.0, 5.0]], f32)
+    n = oracle.normalize(v)[0]
+    for i in range(5):
+        assert abs(n[i] - f32(i + 1) / np.sqrt(f32(55.0))) <= 2e-7 * abs(n[i])
+    assert abs(float((n.astype(np.float64) ** 2).sum()) - 1.0) <= 2e-7
+
+
+def test_membership_and_loss_like_reference(oracle):
+    """kmeans.rs:1425-1444: 20 random 256-d rows against 18 random centroids: every row gets a partition, loss > 0."""
+    rng = np.random.default_rng(0)
+    cent = rng.random((18, 256)).astype(f32); data = rng.random((20, 256)).astype(f32)
+    ids, dists = oracle.assign(data, cent)
+    assert (ids != oracle.NONE).all() and float(dists.astype(np.float64).sum()) > 0.0
+
+
+def test_hierarchical_kmeans_like_reference(oracle):
+    """kmeans.rs:1511-1537 at reduced size: K = 257 > 256 triggers the hierarchical trainer, hierarchical_k = 16,
+    max_iters = 10: exactly K centroids, none NaN."""
+    rng = np.random.default_rng(1)
+    x = rng.random((257 * 64, 32)).astype(f32)
+    c = oracle.kmeans_train_hierarchical(x, 257, max_iters=10, hierarchical_k=16, seed=2)
+    assert c.shape == (257, 32) and not np.isnan(c).any()
+
+
+def test_float16_underflow_fix_like_reference(oracle):
+    """kmeans.rs:1540-1575: K = 2 on 131,072 two-dimensional f16 rows; the k*512 row cap (kmeans.rs:623-627, applied by
+    the caller here as in the engine) keeps the f16 centroid sums from degenerating: no NaN, no zero."""
+    rng = np.random.default_rng(3)
+    x = rng.random((2 * 65536, 2)).astype(np.float16)
+    c, _, _, _ = oracle.kmeans_train(x[: 2 * 512], 2, max_iters=10, seed=4)
+    assert c.dtype == np.float16 and not np.isnan(c.astype(f32)).any() and (c.astype(f32) != 0).all()
