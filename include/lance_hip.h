@@ -128,7 +128,8 @@ int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n,
                        const void *centroids, const uint32_t *part_ids, void *out);
 
 /* ---- a12: ProductQuantizer::transform_impl (pq.rs:116-191) ----------------------- */
-/* codes: [n][m] (nbits = 8) */
+/* codes: [n][m] (nbits = 8) or [n][m/2] (nbits = 4).  `metric` is the QUANTIZER's distance type (pq.rs:143): a quantizer
+ * produced by an index build is always an L2 one (lance/src/index/vector/builder.rs:456), whatever the index metric. */
 int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                         const void *codebook, uint32_t m, uint32_t nbits, uint8_t *codes);
 
@@ -136,7 +137,9 @@ int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x
  * precedent: one_pass_assign_ivf_pq_on_accelerator, python/lance/vector.py:607-755) --- */
 /* [cosine: normalise] -> assign -> residual (L2/cosine) -> PQ encode.  Emits the
  * shuffle-buffer columns (__ivf_part_id u32, __pq_code u8[m]).  Non-finite rows get
- * part id LANCE_HIP_NONE (KeepFiniteVectors, utils.rs:263-286).                      */
+ * part id LANCE_HIP_NONE (KeepFiniteVectors, utils.rs:263-286).  `metric` is the INDEX metric: it selects the
+ * partition assignment (dot indices assign by dot product and take no residual); the PQ step always encodes with the
+ * L2-nearest codeword, as the reference's build does (builder.rs:456 + pq.rs:143,165).   */
 int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                            const void *centroids, uint32_t nlist, const void *codebook, uint32_t m,
                            uint32_t nbits, uint32_t *part_ids, uint8_t *codes, double *loss_out_host);
