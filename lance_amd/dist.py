@@ -112,8 +112,31 @@ def train_kmeans_sharded(engine, x_local, k, n_total, max_iters=50, tol=1e-4, ba
     return cent, last_loss, iters
 
 
+def block_ranges(total, world):
+    """contiguous blocks of ceil(total / world) items per rank (the last ranks may be short or empty)"""
+    per = (total + world - 1) // world
+    return per, [(min(r * per, total), min((r + 1) * per, total)) for r in range(world)]
+
+
+def all_gather_blocks(local, total, group=None):
+    """Every rank holds the rows [lo_r, hi_r) of a `total`-row array (block_ranges); returns the whole array on every
+    rank.  One all_gather_into_tensor of equally sized, zero-padded blocks; the padding is dropped afterwards."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per, ranges = block_ranges(total, world)
+    lo, hi = ranges[rank]
+    assert local.shape[0] == hi - lo, (local.shape, lo, hi)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: hi - lo] = local
+    out = torch.empty((per * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if per * world == total:
+        return out
+    keep = torch.cat([torch.arange(r * per, r * per + (b - a), device=local.device) for r, (a, b) in enumerate(ranges)])
+    return out[keep].contiguous()
+
+
 def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16, num_bits=8, max_iters=50, sample_rate=256,
-                         seed=42, engine=None, group=None, keep_raw=True, ivf_training="auto"):
+                         seed=42, engine=None, group=None, keep_raw=True, ivf_training="auto", index_factory=None):
     """create_index over N ranks.  `x` is the full matrix on every rank in this version (the bench generates it
     from a shared seed).  Work split: the PQ sub-quantisers are trained model-parallel, the transform (assign +
     residual + encode) is sharded by rows, and the IVF k-means is either
@@ -123,25 +146,31 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
         training sets large enough that the E-step dominates (C4 and up).
     "auto" picks by the E-step size and keeps nlist > 256 replicated (the reference's hierarchical trainer is a chain
     of small sub-problems; "sharded" always means the flat Lloyd loop).  With replicated training the whole index is bit-identical to the
-    single-GPU build (same sample, same seeds, independent sub-quantisers, per-row encode)."""
+    single-GPU build (same sample, same seeds, independent sub-quantisers, per-row encode).
+    `index_factory` (default DeviceIndex.create) exists so that the collective logic can be driven on CPU by the
+    world_size > 1 gloo tests with a stand-in engine."""
     import time
 
     from . import vector as lv
     from .engine import DeviceIndex, to_device
     eng = engine or lv.default_engine()
+    on_gpu = torch.cuda.is_available()
+    make_index = index_factory or DeviceIndex.create
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     params = lv.IvfPqParams(num_partitions, num_sub_vectors, num_bits, lv._normalize_metric_type(metric), max_iters, sample_rate, seed)
-    x = to_device(x)
+    x = to_device(x) if on_gpu else torch.as_tensor(x)
     n, d = x.shape
     stats = lv.BuildStats()
     kmetric = "l2" if params.metric == "cosine" else params.metric
 
     def timed(name, fn):
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         t = time.perf_counter()
         out = fn()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         stats.seconds[name] = time.perf_counter() - t
         return out
 
@@ -182,42 +211,35 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
         # model-parallel over the M independent sub-quantisers (pq/builder.rs:109-138 trains them one after the
         # other): rank r trains a contiguous block with the batched single-GPU trainer on the (small, replicated)
         # residual sample, seeds seed+2+m as in the single-GPU build, then the codebook slices are all-gathered.
-        per = (num_sub_vectors + world - 1) // world
-        m0, m1 = min(rank * per, num_sub_vectors), min((rank + 1) * per, num_sub_vectors)
-        cb_all = torch.zeros((per * world, kc, sd), dtype=torch.float32, device=x.device)
-        its_all = torch.zeros(per * world, dtype=torch.int32, device=x.device)
-        mine = torch.zeros((per, kc, sd), dtype=torch.float32, device=x.device)
-        its = torch.zeros(per, dtype=torch.int32, device=x.device)
+        _, ranges = block_ranges(num_sub_vectors, world)
+        m0, m1 = ranges[rank]
+        mine = torch.zeros((m1 - m0, kc, sd), dtype=torch.float32, device=x.device)
+        its = torch.zeros(m1 - m0, dtype=torch.int32, device=x.device)
         if m1 > m0:
             cols = psample[:, m0 * sd: m1 * sd].contiguous()
             c, it = eng.pq_train(cols, m1 - m0, num_bits, max_iters, sample_rate, seed + 2 + m0)
-            mine[: m1 - m0] = c
-            its[: m1 - m0] = torch.from_numpy(it.astype(np.int32)).to(x.device)
-        dist.all_gather_into_tensor(cb_all, mine, group=group)
-        dist.all_gather_into_tensor(its_all, its, group=group)
-        # blocks are laid out rank-major with `per` slots each; compact to the first M
-        keep = torch.cat([torch.arange(r * per, r * per + max(0, min((r + 1) * per, num_sub_vectors) - min(r * per, num_sub_vectors)),
-                                       device=x.device) for r in range(world)])
-        return cb_all[keep].contiguous(), its_all[keep].cpu().numpy().astype(np.uint32)
+            mine[:] = c
+            its[:] = torch.from_numpy(it.astype(np.int32)).to(x.device)
+        cb_all = all_gather_blocks(mine, num_sub_vectors, group)
+        its_all = all_gather_blocks(its, num_sub_vectors, group)
+        return cb_all, its_all.cpu().numpy().astype(np.uint32)
 
     cb, stats.pq_iters = timed("train_pq", train_pq)
 
     # transform: each rank encodes its row shard, then all-gather the shuffle-buffer columns
     def transform():
-        per = (n + world - 1) // world
-        lo, hi = rank * per, min(n, (rank + 1) * per)
-        part_l, codes_l, _ = eng.ivfpq_encode(x[lo:hi], cent, cb, params.metric)
-        part = torch.empty(per * world, dtype=torch.int32, device=x.device)
-        codes = torch.empty((per * world, num_sub_vectors), dtype=torch.uint8, device=x.device)
-        pl = torch.full((per,), -1, dtype=torch.int32, device=x.device); pl[: hi - lo] = part_l
-        cl = torch.zeros((per, num_sub_vectors), dtype=torch.uint8, device=x.device); cl[: hi - lo] = codes_l
-        dist.all_gather_into_tensor(part, pl, group=group)
-        dist.all_gather_into_tensor(codes, cl, group=group)
-        return part[:n].contiguous(), codes[:n].contiguous()
+        _, ranges = block_ranges(n, world)
+        lo, hi = ranges[rank]
+        if hi > lo:
+            part_l, codes_l, _ = eng.ivfpq_encode(x[lo:hi], cent, cb, params.metric)
+        else:
+            part_l = torch.empty(0, dtype=torch.int32, device=x.device)
+            codes_l = torch.empty((0, num_sub_vectors if num_bits == 8 else num_sub_vectors // 2), dtype=torch.uint8, device=x.device)
+        return all_gather_blocks(part_l, n, group), all_gather_blocks(codes_l, n, group)
 
     part, codes = timed("transform", transform)
-    ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
-                                                              raw=x if keep_raw else None))
+    ix = timed("build_partitions", lambda: make_index(eng, params.metric, cent, cb, part, codes, None,
+                                                      raw=x if keep_raw else None))
     return lv.IvfPqIndex(ix, params, stats, part, codes)
 
 

@@ -171,3 +171,134 @@ def test_list_sharded_search_two_ranks_equals_single_index():
         oi, od = full.search(q, k, nprobes, refine=rf, raw=x if rf else None)
         assert (gi0.astype(np.uint64) == oi).all(), key
         assert (gd0.view(np.uint32) == od.view(np.uint32)).all(), key
+
+
+# ---- block gathers of the multi-GPU build (model-parallel PQ codebook slices, row-sharded transform output) ----------
+def _gather_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lance_amd.dist import all_gather_blocks, block_ranges
+    res = {}
+    for total in (16, 7, 2, 1000, 1001, world - 1 if world > 1 else 1):      # even, uneven, fewer items than ranks
+        _, ranges = block_ranges(total, world)
+        lo, hi = ranges[rank]
+        full2 = torch.arange(total * 3, dtype=torch.float32).reshape(total, 3) * 0.5
+        full1 = (torch.arange(total, dtype=torch.int32) * 7) % 11
+        res[total] = (all_gather_blocks(full2[lo:hi].clone(), total).numpy(), all_gather_blocks(full1[lo:hi].clone(), total).numpy())
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_all_gather_blocks_reassembles_the_array(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        for total, (a2, a1) in r.items():
+            assert (a2 == (np.arange(total * 3, dtype=f32).reshape(total, 3) * 0.5)).all(), (world, rank, total)
+            assert (a1 == (np.arange(total, dtype=np.int32) * 7) % 11).all()
+
+
+def test_block_ranges_cover_everything():
+    from lance_amd.dist import block_ranges
+    for total in (0, 1, 5, 16, 1_000_000):
+        for world in (1, 2, 3, 8):
+            per, ranges = block_ranges(total, world)
+            assert ranges[0][0] == 0 and ranges[-1][1] == total and len(ranges) == world
+            assert all(a <= b and b - a <= per for a, b in ranges)
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+
+
+# ---- the whole multi-rank build on CPU: create_index_sharded with an oracle-backed stand-in engine -----------------
+class OracleBuildEngine:
+    """Engine stand-in for create_index_sharded (CPU tensors in, CPU tensors out), every step computed by the oracle."""
+
+    def _np(self, t):
+        return t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def normalize(self, x):
+        import oracle
+        return torch.from_numpy(oracle.normalize(self._np(x)))
+
+    def kmeans_train(self, x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, seed=0, metric="l2", hierarchical_k=16):
+        import oracle
+        xn = self._np(x)
+        n = xn.shape[0]
+        c, loss, iters, _ = oracle.kmeans_train(xn[: min(n, k * 512)], k, max_iters=max_iters, tol=tol,
+                                                balance_factor=f32(balance_factor) / f32(n), seed=seed, metric=metric)
+        return torch.from_numpy(c), loss, iters
+
+    def assign(self, x, cent, metric="l2", bias=None):
+        import oracle
+        ids, d = oracle.assign(self._np(x), self._np(cent), metric)
+        return torch.from_numpy(ids.view(np.int32).copy()), torch.from_numpy(d)
+
+    def residual(self, x, cent, part):
+        import oracle
+        return torch.from_numpy(oracle.residual(self._np(x), self._np(cent), self._np(part).view(np.uint32)))
+
+    def pq_train(self, r, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
+        import oracle
+        cb, it = oracle.pq_train(np.ascontiguousarray(self._np(r)), m, nbits=nbits, max_iters=max_iters, sample_rate=sample_rate, seed=seed)
+        return torch.from_numpy(cb), it.astype(np.uint32)
+
+    def ivfpq_encode(self, x, cent, cb, metric="l2"):
+        import oracle
+        xn = np.ascontiguousarray(self._np(x))
+        nb = 4 if cb.shape[1] == 16 else 8
+        oi = oracle.build_index(xn, self._np(cent), self._np(cb), metric, nbits=nb)
+        return torch.from_numpy(oi.part_ids.view(np.int32).copy()), torch.from_numpy(oi.codes_rowmajor.copy()), 0.0
+
+
+def _build_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lance_amd.dist import create_index_sharded
+    rng = np.random.default_rng(5)
+    res = {}
+    for metric, n, nbits in (("l2", 3001, 8), ("dot", 2000, 8), ("cosine", 2500, 4)):
+        x = torch.from_numpy((rng.standard_normal((n, 24)) * 2 + 1).astype(f32))
+        ix = create_index_sharded(x, metric=metric, num_partitions=6, num_sub_vectors=6, num_bits=nbits, max_iters=6, sample_rate=64,
+                                  seed=11, engine=OracleBuildEngine(), index_factory=lambda *a, **k: None)
+        res[metric] = (ix.part_ids.numpy(), ix.codes.numpy(), ix.stats.ivf_training, np.asarray(ix.stats.pq_iters))
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_create_index_sharded_is_independent_of_the_rank_count():
+    """Replicated IVF training + model-parallel PQ (6 sub-quantisers over 1 / 2 / 3 ranks, uneven for none of them but the
+    row split of 3001 rows is) + row-sharded transform: every rank of every world size must end with the same index."""
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2, 3):
+        out = ctx.Queue()
+        port = 35500 + (os.getpid() % 2000) + world
+        procs = [ctx.Process(target=_build_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [out.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[world] = dict(got)
+    ref = results[1][0]
+    for world, per_rank in results.items():
+        for rank, res in per_rank.items():
+            for metric, (part, codes, mode, its) in res.items():
+                assert mode == "replicated"
+                assert (part == ref[metric][0]).all() and (codes == ref[metric][1]).all(), (world, rank, metric)
+                assert (its == ref[metric][3]).all()
