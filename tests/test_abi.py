@@ -53,3 +53,17 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".cuh")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in txt and "lance_oracle" not in txt and "oracle/" not in txt, os.path.join(dirpath, f)
+
+
+def test_bench_and_smoke_refuse_to_run_without_a_gpu():
+    """bench.py and __graft_entry__.smoke() measure / check the HIP path only: without a device they must stop with a
+    clear message instead of timing or checking anything on the CPU."""
+    import subprocess
+    import sys
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout) and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
