@@ -165,6 +165,15 @@ class IvfPqIndex:
     def search_device(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
         return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync)
 
+    def to_arrow_artifacts(self, batch_size=10240):
+        """-> (ivf_centroids RecordBatch, pq_codebook RecordBatch, iterator of shuffle-buffer RecordBatches): the three
+        arguments `Dataset.create_index(..., ivf_centroids=, pq_codebook=, precomputed_shuffle_buffers=)` takes
+        (python/python/lance/dataset.py:2780-2954, vector.py:659-665); see lance_amd/arrow_io.py."""
+        from . import arrow_io
+        rid, part, codes = self.shuffle_buffers()
+        return (arrow_io.ivf_centroids_batch(self.centroids), arrow_io.pq_codebook_batch(self.codebook),
+                arrow_io.shuffle_buffer_batches(rid, part, codes, batch_size))
+
 
 class IvfFlatIndex:
     """IVF_FLAT: IVF partitions over the raw vectors (exact distances inside the probed partitions)."""

@@ -71,3 +71,49 @@ def test_local_list_rows_partitions_the_rows():
     seen = torch.cat([local_list_rows(part, 3, r) for r in range(3)])
     assert sorted(seen.tolist()) == [0, 1, 2, 4, 5, 6, 7]          # row 3 has no partition
     assert local_list_rows(part, 3, 2).tolist() == [1, 2, 5, 6]    # lists 5 and 2 -> rank 2
+
+
+def test_arrow_artifacts_match_the_accelerator_seam_contract(tmp_path):
+    """The three artefacts pylance's create_index accepts (python/src/dataset.rs:3026-3051, :3109-3118;
+    python/python/lance/vector.py:659-665): column names, list sizes, element types, row order, NONE rows dropped."""
+    import pyarrow as pa
+    from lance_amd import arrow_io
+    rng = np.random.default_rng(0)
+    nlist, d, m, n = 5, 16, 4, 1000
+    cent = rng.standard_normal((nlist, d)).astype(f32)
+    cb = rng.standard_normal((m, 256, d // m)).astype(f32)
+    part = rng.integers(0, nlist, n).astype(np.uint32); part[[3, 77]] = arrow_io.NONE
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    rid = np.arange(n, dtype=np.uint64)
+
+    b = arrow_io.ivf_centroids_batch(cent)
+    assert b.schema.field(0).name == "_ivf_centroids" and b.num_rows == nlist
+    assert b.schema.field(0).type == pa.list_(pa.float32(), d)
+    assert (arrow_io.centroids_from_batch(b) == cent).all()
+
+    b = arrow_io.pq_codebook_batch(cb)
+    assert b.schema.field(0).name == "_pq_codebook" and b.num_rows == m * 256
+    assert b.schema.field(0).type == pa.list_(pa.float32(), d // m)          # dataset.py:2948-2950: list size = sub-dimension
+    assert (np.asarray(b.column(0).values) == cb.reshape(-1)).all()          # Rust takes .values(): [M][256][d/M] flattened
+    assert (arrow_io.codebook_from_batch(b, m) == cb).all()
+
+    batches = list(arrow_io.shuffle_buffer_batches(rid, part, codes, batch_size=300))
+    assert all(x.schema == arrow_io.shuffle_buffer_schema(m) for x in batches)
+    assert [f.name for f in batches[0].schema] == ["row_id", "__ivf_part_id", "__pq_code"]
+    assert batches[0].schema.field(2).type == pa.list_(pa.uint8(), m)
+    t = pa.Table.from_batches(batches)
+    assert t.num_rows == n - 2 and 3 not in t["row_id"].to_pylist() and 77 not in t["row_id"].to_pylist()
+    keep = part != arrow_io.NONE
+    assert (np.asarray(t["row_id"]) == rid[keep]).all() and (np.asarray(t["__ivf_part_id"]) == part[keep]).all()
+    got = np.asarray(t["__pq_code"].combine_chunks().values).reshape(-1, m)
+    assert (got == codes[keep]).all()
+
+    path = str(tmp_path / "shuffle.arrow")
+    assert arrow_io.write_shuffle_buffers_ipc(path, rid, part.view(np.int32), codes) == n - 2     # int32 part ids (device layout) too
+    back = pa.ipc.open_file(path).read_all()
+    assert back.schema == arrow_io.shuffle_buffer_schema(m) and back.num_rows == n - 2
+
+    with pytest.raises(ValueError):
+        arrow_io.pq_codebook_batch(cb[:, :100])
+    with pytest.raises(TypeError):
+        arrow_io.ivf_centroids_batch(cent.astype(np.int32))
