@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import LanceHipError
 
 __all__ = ["_lib", "LanceHipError", "Engine", "DeviceIndex", "KMeans", "IvfPqParams", "IvfPqIndex", "create_index",
-           "flat_knn", "train_ivf_centroids", "train_pq_codebook", "default_engine"]
+           "flat_knn", "train_ivf_centroids", "train_pq_codebook", "default_engine", "IndicesBuilder", "IvfModel", "PqModel"]
 
 
 def __getattr__(name):
@@ -22,4 +22,7 @@ def __getattr__(name):
                 "train_pq_codebook", "default_engine"):
         from . import vector
         return getattr(vector, name)
+    if name in ("IndicesBuilder", "IvfModel", "PqModel"):
+        from . import indices
+        return getattr(indices, name)
     raise AttributeError(name)

@@ -117,3 +117,53 @@ def test_arrow_artifacts_match_the_accelerator_seam_contract(tmp_path):
         arrow_io.pq_codebook_batch(cb[:, :100])
     with pytest.raises(TypeError):
         arrow_io.ivf_centroids_batch(cent.astype(np.int32))
+
+
+def test_indices_builder_argument_rules_and_models(tmp_path):
+    """lance_amd.IndicesBuilder mirrors lance.indices.IndicesBuilder (python/python/lance/indices/builder.py): defaults
+    and validation errors of :409-487 (no device needed for those), IvfModel / PqModel layouts and save / load."""
+    import pyarrow as pa
+    import lance_amd
+    x = np.zeros((70000, 32), f32)
+    b = lance_amd.IndicesBuilder(x)
+    assert b.dimension == 32 and b.num_rows == 70000
+    assert b._determine_num_partitions(None, 70000) == round(70000 ** 0.5) and b._determine_num_partitions(12, 70000) == 12
+    assert b._normalize_pq_params(None, 32) == 2 and b._normalize_pq_params(None, 24) == 3 and b._normalize_pq_params(8, 32) == 8
+    with pytest.raises(ValueError, match="not divisible by 16 or 8"):
+        b._normalize_pq_params(None, 20)
+    with pytest.raises(ValueError, match="must be divisible by num_subvectors"):
+        b._normalize_pq_params(5, 32)
+    with pytest.raises(ValueError, match="greater than 0"):
+        b._normalize_pq_params(0, 32)
+    with pytest.raises(ValueError, match="less than or equal to the dimension"):
+        b._normalize_pq_params(64, 32)
+    with pytest.raises(ValueError, match="must be an int"):
+        b._normalize_pq_params(2.0, 32)
+    with pytest.raises(ValueError, match="sample_rate must be an int greater than 1"):
+        b.train_ivf(16, sample_rate=1)
+    with pytest.raises(ValueError, match="not enough rows in the dataset to create IVF centroids"):
+        b.train_ivf(1024, sample_rate=256)
+    with pytest.raises(ValueError, match="Distance type hamming not supported"):
+        b.train_ivf(16, distance_type="hamming")
+    with pytest.raises(TypeError):                       # as in the reference: the sample-rate check trips over the str first
+        b.train_ivf("16")
+    with pytest.raises(TypeError, match="num_partitions must be int"):
+        b._verify_ivf_params("16")
+    with pytest.raises(ValueError, match="not enough rows in the dataset to create PQ"):
+        lance_amd.IndicesBuilder(np.zeros((1000, 32), f32))._verify_pq_sample_rate(1000, 256)
+    with pytest.raises(TypeError):
+        lance_amd.IndicesBuilder(np.zeros(10, f32))
+
+    rng = np.random.default_rng(0)
+    cent = rng.standard_normal((6, 32)).astype(f32)
+    ivf = lance_amd.IvfModel(pa.FixedSizeListArray.from_arrays(pa.array(cent.reshape(-1)), 32), "cosine")
+    assert ivf.num_partitions == 6 and (ivf.to_numpy() == cent).all()
+    ivf.save(str(tmp_path / "ivf.arrow"))
+    back = lance_amd.IvfModel.load(str(tmp_path / "ivf.arrow"))
+    assert back.distance_type == "cosine" and (back.to_numpy() == cent).all()
+    cb = rng.standard_normal((4, 256, 8)).astype(f32)
+    pq = lance_amd.PqModel(4, pa.FixedSizeListArray.from_arrays(pa.array(cb.reshape(-1)), 32))
+    assert pq.dimension == 32 and len(pq.codebook) == 256 and (pq.to_numpy() == cb).all()      # FSL[d] with 256 rows (pq/builder.rs:139-154)
+    pq.save(str(tmp_path / "pq.arrow"))
+    back = lance_amd.PqModel.load(str(tmp_path / "pq.arrow"))
+    assert back.num_subvectors == 4 and (back.to_numpy() == cb).all()
