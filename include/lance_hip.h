@@ -38,6 +38,7 @@ extern "C" {
 #define LANCE_HIP_ERUNTIME -2  /* HIP runtime error */
 #define LANCE_HIP_ENOTSUP -3   /* combination not implemented */
 #define LANCE_HIP_ENOMEM -4
+#define LANCE_HIP_EIO -5       /* file cannot be opened / read / written */
 
 #define LANCE_HIP_NONE 0xFFFFFFFFu
 
@@ -225,6 +226,46 @@ int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t
  * BinaryHeap keeps (such queries are replayed through a heap with std's push/pop, as in the IVF_PQ path). */
 int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                              uint32_t nprobes, uint64_t *ids, float *dists);
+
+/* ---- a22 / 8(f) N3: index files (lance/src/index/vector/builder.rs:938-1079 merge_partitions) ---------------------- */
+/* The `index.idx` + `auxiliary.idx` pair of an IVF_PQ / IVF_FLAT index directory, Lance file format 2.0 (the
+ * FileWriter default, lance-file/src/writer.rs:553-561).  Host-side: nothing here needs a GPU except load/save.
+ * Readers replaced: IvfQuantizationStorage::try_new (lance-index/src/vector/storage.rs:182-243),
+ * ProductQuantizationMetadata (pq/storage.rs:52-144), IvfModel <-> pb (ivf/storage.rs:181-244).                    */
+enum { LANCE_HIP_IVF_PQ = 0, LANCE_HIP_IVF_FLAT = 1 };
+typedef struct lance_hip_index_file lance_hip_index_file;
+typedef struct lance_hip_index_file_view {
+  int index_type;               /* LANCE_HIP_IVF_PQ / LANCE_HIP_IVF_FLAT */
+  int metric;
+  int dtype;                    /* element type of the stored tensors / flat vectors: LANCE_HIP_F32 or LANCE_HIP_F16 */
+  uint32_t d, nlist, m, nbits;  /* m = nbits = 0 for IVF_FLAT */
+  uint64_t n_rows;
+  int transposed;               /* codes are [code bytes][n_p] inside each partition (pq/storage.rs:430-449) */
+  int has_loss;
+  double loss;
+  const float *centroids;       /* [nlist][d], widened to f32 */
+  const float *codebook;        /* [m][2^nbits][d/m] f32 (pq/builder.rs:139-154 layout); NULL for IVF_FLAT */
+  const uint32_t *part_offsets; /* [nlist+1] row offsets */
+  const uint64_t *row_ids;      /* [n_rows], partition order */
+  const uint8_t *codes;         /* IVF_PQ: n_rows * (nbits == 4 ? m/2 : m) bytes */
+  const void *vectors;          /* IVF_FLAT: [n_rows][d] of dtype */
+} lance_hip_index_file_view;
+/* Maps and validates both files; the view's pointers stay valid until close.  Files written by Lance <= 0.27 (PQ
+ * codebook inline in the schema metadata) are read too; legacy v1 index files and other index types are refused. */
+int lance_hip_index_file_open(const char *index_dir, lance_hip_index_file **out);
+int lance_hip_index_file_get(const lance_hip_index_file *f, lance_hip_index_file_view *view);
+void lance_hip_index_file_close(lance_hip_index_file *f);
+/* Writes the pair (creating index_dir if needed) in the layout merge_partitions produces: global buffers
+ * (pb IVF, pb Tensor codebook) ahead of the pages, 64-byte aligned buffers, transposed codes.                      */
+int lance_hip_index_file_write(const char *index_dir, const lance_hip_index_file_view *view);
+/* Files -> device-resident index.  dtype is the indexed column's element type (F32 / F16 / I8).                   */
+int lance_hip_index_load(lance_hip_ctx *ctx, const char *index_dir, int dtype, lance_hip_index **out);
+/* Device-resident index -> files.  loss is the k-means loss recorded in index.idx (has_loss = 0 to omit).        */
+int lance_hip_index_save(lance_hip_ctx *ctx, const lance_hip_index *idx, const char *index_dir, int has_loss, double loss);
+/* One top-level fixed-width column (scalar or fixed-size list, uncompressed, no nulls) of a format-2.0 Lance file,
+ * e.g. the vector column of a data file.  dst NULL: only reports rows / bytes per row.                           */
+int lance_hip_file_read_column(const char *path, const char *column, void *dst, uint64_t dst_bytes, uint64_t *rows,
+                               uint32_t *row_bytes);
 
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx stream --- */
 /* When enabled, each internal launch of the named hot kernels is bracketed by events;

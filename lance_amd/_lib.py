@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LANCE_HIP_LIB") or os.path.join(_HERE, "liblance_hip.so")   # override: kernel-variant A/B runs
 
-OK, EINVAL, ERUNTIME, ENOTSUP, ENOMEM = 0, -1, -2, -3, -4
+OK, EINVAL, ERUNTIME, ENOTSUP, ENOMEM, EIO = 0, -1, -2, -3, -4, -5
+IVF_PQ, IVF_FLAT = 0, 1
 L2, COSINE, DOT = 0, 1, 2
 F32, F16, I8 = 0, 1, 2
 NONE = 0xFFFFFFFF
@@ -28,8 +29,21 @@ SYMBOLS = [
     "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
     "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_search_stats",
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search",
+    "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
+    "lance_hip_index_load", "lance_hip_index_save", "lance_hip_file_read_column",
     "lance_hip_timing_enable", "lance_hip_timing_query",
 ]
+
+
+class IndexFileView(C.Structure):
+    """lance_hip_index_file_view (include/lance_hip.h)."""
+    _fields_ = [
+        ("index_type", C.c_int), ("metric", C.c_int), ("dtype", C.c_int),
+        ("d", C.c_uint32), ("nlist", C.c_uint32), ("m", C.c_uint32), ("nbits", C.c_uint32),
+        ("n_rows", C.c_uint64), ("transposed", C.c_int), ("has_loss", C.c_int), ("loss", C.c_double),
+        ("centroids", C.c_void_p), ("codebook", C.c_void_p), ("part_offsets", C.c_void_p),
+        ("row_ids", C.c_void_p), ("codes", C.c_void_p), ("vectors", C.c_void_p),
+    ]
 
 
 class LanceHipError(RuntimeError):
@@ -96,6 +110,13 @@ def load():
         "lance_hip_flat_topk": (i32, [vp, i32, i32, vp, vp, u64, u32, vp, u32, u32, vp, vp]),
         "lance_hip_ivfflat_create": (i32, [vp, i32, i32, u32, vp, u32, vp, vp, vp, u64, C.POINTER(vp)]),
         "lance_hip_ivfflat_search": (i32, [vp, vp, vp, u32, u32, u32, vp, vp]),
+        "lance_hip_index_file_open": (i32, [C.c_char_p, C.POINTER(vp)]),
+        "lance_hip_index_file_get": (i32, [vp, C.POINTER(IndexFileView)]),
+        "lance_hip_index_file_close": (None, [vp]),
+        "lance_hip_index_file_write": (i32, [C.c_char_p, C.POINTER(IndexFileView)]),
+        "lance_hip_index_load": (i32, [vp, C.c_char_p, i32, C.POINTER(vp)]),
+        "lance_hip_index_save": (i32, [vp, vp, C.c_char_p, i32, f64]),
+        "lance_hip_file_read_column": (i32, [C.c_char_p, C.c_char_p, vp, u64, C.POINTER(u64), C.POINTER(u32)]),
         "lance_hip_timing_enable": (i32, [vp, i32]),
         "lance_hip_timing_query": (i32, [vp, C.c_char_p, C.POINTER(f64), C.POINTER(u64)]),
     }

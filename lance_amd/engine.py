@@ -2,6 +2,7 @@
 (plumbing), every computation is a call into liblance_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -284,6 +285,24 @@ class DeviceFlatIndex:
                                                   _ptr(rid), n, C.byref(h)))
         return cls(engine, h, metric, cent, x.dtype)
 
+    @classmethod
+    def load(cls, engine, index_dir, dtype=None):
+        """IVF_FLAT index files -> HBM (lance_hip_index_load)."""
+        from . import index_file
+        c = index_file.read_index_files(index_dir)
+        if c.index_type != "IVF_FLAT":
+            raise ValueError(f"{index_dir} holds an {c.index_type} index; use DeviceIndex.load")
+        ddt, dt = _DT[dtype if dtype is not None else c.dtype]
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(engine.lib.lance_hip_index_load(engine.h, os.fspath(index_dir).encode(), dt, C.byref(h)))
+        return cls(engine, h, c.metric, to_device(c.centroids, torch.float16 if c.dtype == "float16" else torch.float32), ddt)
+
+    def save(self, index_dir, loss=None):
+        torch.cuda.synchronize()
+        check(self.engine.lib.lance_hip_index_save(self.engine.h, self.h, os.fspath(index_dir).encode(),
+                                                   0 if loss is None else 1, 0.0 if loss is None else float(loss)))
+
     def search(self, q, k, nprobes):
         d = self.centroids.shape[1]
         t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
@@ -356,6 +375,28 @@ class DeviceIndex:
                                                       offs.ctypes.data_as(C.c_void_p), _ptr(codes), int(transposed), _ptr(rid), n,
                                                       C.byref(h)))
         return cls(engine, h, metric, cent, cb, raw, ddt)
+
+    @classmethod
+    def load(cls, engine, index_dir, dtype=None, raw=None):
+        """`<index_dir>/index.idx` + `auxiliary.idx` (an IVF_PQ index the reference wrote, or `save`) -> HBM, through
+        lance_hip_index_load.  dtype: element type of the indexed column ("float32" | "float16" | "int8"); default = the
+        element type of the stored tensors."""
+        from . import index_file
+        c = index_file.read_index_files(index_dir)
+        if c.index_type != "IVF_PQ":
+            raise ValueError(f"{index_dir} holds an {c.index_type} index; use DeviceFlatIndex.load")
+        ddt, dt = _DT[dtype if dtype is not None else c.dtype]
+        mdt = torch.float16 if c.dtype == "float16" else torch.float32
+        h = C.c_void_p()
+        torch.cuda.synchronize()
+        check(engine.lib.lance_hip_index_load(engine.h, os.fspath(index_dir).encode(), dt, C.byref(h)))
+        return cls(engine, h, c.metric, to_device(c.centroids, mdt), to_device(c.codebook, mdt), raw, ddt)
+
+    def save(self, index_dir, loss=None):
+        """HBM -> the file pair, in the layout merge_partitions writes (builder.rs:938-1079), through lance_hip_index_save."""
+        torch.cuda.synchronize()
+        check(self.engine.lib.lance_hip_index_save(self.engine.h, self.h, os.fspath(index_dir).encode(),
+                                                   0 if loss is None else 1, 0.0 if loss is None else float(loss)))
 
     def set_raw(self, raw):
         t = raw if isinstance(raw, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(raw))

@@ -165,6 +165,12 @@ class IvfPqIndex:
     def search_device(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
         return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync)
 
+    def save(self, index_dir):
+        """Writes `index.idx` + `auxiliary.idx` under index_dir -- the files IvfIndexBuilder::merge_partitions produces
+        (rust/lance/src/index/vector/builder.rs:938-1079), loadable by `load_index` here (and laid out for the
+        reference's IvfQuantizationStorage reader)."""
+        self._ix.save(index_dir, None if self.stats is None else self.stats.ivf_loss)
+
     def to_arrow_artifacts(self, batch_size=10240):
         """-> (ivf_centroids RecordBatch, pq_codebook RecordBatch, iterator of shuffle-buffer RecordBatches): the three
         arguments `Dataset.create_index(..., ivf_centroids=, pq_codebook=, precomputed_shuffle_buffers=)` takes
@@ -194,6 +200,25 @@ class IvfFlatIndex:
     def nearest(self, q, k=10, nprobes=1):
         ids, dists = self._ix.search(q, k, nprobes)
         return ids.cpu().numpy().view(np.uint64), dists.cpu().numpy()
+
+    def save(self, index_dir):
+        self._ix.save(index_dir, None if self.stats is None else self.stats.ivf_loss)
+
+
+def load_index(index_dir, dtype=None, raw=None, engine=None):
+    """Opens an index directory (`index.idx` + `auxiliary.idx`, written by the reference or by `save`) straight into
+    HBM -> IvfPqIndex | IvfFlatIndex.  dtype: element type of the indexed column when it differs from the stored model
+    tensors ("int8" columns keep an f32 model); raw: the column's vectors for refine, indexed by row id."""
+    from . import index_file
+    from .engine import DeviceFlatIndex, DeviceIndex
+    eng = engine or default_engine()
+    c = index_file.read_index_files(index_dir)
+    params = IvfPqParams(num_partitions=c.centroids.shape[0], num_sub_vectors=c.num_sub_vectors, num_bits=c.nbits or 8,
+                         metric=c.metric)
+    stats = BuildStats(ivf_loss=c.loss if c.loss is not None else 0.0)
+    if c.index_type == "IVF_PQ":
+        return IvfPqIndex(DeviceIndex.load(eng, index_dir, dtype=dtype, raw=raw), params, stats)
+    return IvfFlatIndex(DeviceFlatIndex.load(eng, index_dir, dtype=dtype), params, stats, None)
 
 
 def _sample_rows(n, size, rng):

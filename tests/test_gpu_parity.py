@@ -698,3 +698,84 @@ def test_many_partitions_nlist_20000(eng, oracle):
     gi, gd = fx.search(q[:32], 10, 30)
     oi, od = oracle.ivfflat_search(x, cent, q[:32], 10, 30, "l2")
     assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+# ---- index files <-> HBM -------------------------------------------------------------------
+def test_load_reference_written_index_and_search(eng, oracle):
+    """An index directory written by real Lance (tests/golden/ref_index, 512 x 32, IVF1,PQ4) goes files -> HBM through
+    lance_hip_index_load and answers queries exactly as the oracle does on the same stored model (the oracle's encode of
+    the fixture's raw vectors equals the stored codes: tests/test_index_files.py)."""
+    import os
+    import lance_amd
+    from lance_amd import index_file as IF
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index", "v0.27.1_pq_in_schema")
+    c = IF.read_index_files(ref)
+    x = IF.read_column(os.path.join(ref, "data.lance"), "vec", np.float32, 32)
+    ix = lance_amd.load_index(ref, raw=x, engine=eng)
+    assert ix.info() == {"n": 512, "nlist": 1, "m": 4, "d": 32}
+    offs, codes_t, rid = ix.export_storage()
+    assert (offs == c.part_offsets).all() and (codes_t == c.codes).all() and (rid == c.row_ids).all()
+    oidx = oracle.build_index(x, c.centroids, c.codebook)
+    assert (oidx.codes_t == c.codes).all()
+    rng = np.random.default_rng(5)
+    q = np.concatenate([x[:40], rng.random((60, 32)).astype(f32)])
+    for k, rf in ((10, 0), (1, 0), (100, 0), (10, 5)):
+        gi, gd = ix.search_device(q, k, 1, rf)
+        oi, od = oidx.search(q, k, 1, refine=rf, raw=x) if rf else oidx.search(q, k, 1)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("kind", ["f32", "f16", "4bit", "dot"])
+def test_index_save_load_roundtrip(eng, oracle, tmp_path, kind):
+    """HBM -> files (lance_hip_index_save) -> HBM (lance_hip_index_load): identical storage and identical answers; the
+    files equal what the host-side writer produces from the exported arrays."""
+    import lance_amd
+    from lance_amd import index_file as IF
+    from lance_amd.engine import DeviceIndex
+    n, d, nlist, m = 12000, 64, 20, 8
+    x = sift_like(n, d, 77)
+    q = sift_like(64, d, 78)
+    metric = "dot" if kind == "dot" else "l2"
+    if kind == "f16":
+        x = (x / 4).astype(np.float16); q = (q / 4).astype(np.float16)
+    ix = lance_amd.create_index(x, "IVF_PQ", metric=metric, num_partitions=nlist, num_sub_vectors=m, max_iters=6, sample_rate=64,
+                                num_bits=4 if kind == "4bit" else 8)
+    ix.save(tmp_path / "a")
+    c = IF.read_index_files(tmp_path / "a")
+    offs, codes_t, rid = ix.export_storage()
+    assert c.metric == metric and c.dtype == ("float16" if kind == "f16" else "float32") and c.nbits == (4 if kind == "4bit" else 8)
+    assert (c.part_offsets == offs).all() and (c.codes == codes_t).all() and (c.row_ids == rid).all()
+    assert (c.centroids == ix.centroids.astype(f32)).all() and (c.codebook == ix.codebook.astype(f32)).all()
+    assert c.loss == ix.stats.ivf_loss
+    IF.write_index_files(tmp_path / "b", c)            # host writer on the same contents: same bytes
+    for name in ("index.idx", "auxiliary.idx"):
+        assert (tmp_path / "a" / name).read_bytes() == (tmp_path / "b" / name).read_bytes(), name
+    ix2 = lance_amd.load_index(tmp_path / "a", engine=eng)
+    o2, c2, r2 = ix2.export_storage()
+    assert (o2 == offs).all() and (c2 == codes_t).all() and (r2 == rid).all()
+    for k, nprobes in ((10, nlist), (10, 3)):
+        a = ix.search_device(q, k, nprobes)
+        b = ix2.search_device(q, k, nprobes)
+        assert (a[0] == b[0]).all() and (_np(a[1]).view(np.uint32) == _np(b[1]).view(np.uint32)).all()
+    # the composed path (parsed arrays -> from_storage) lands on the same index
+    ix3 = DeviceIndex.from_storage(eng, metric, c.centroids.astype(np.float16) if kind == "f16" else c.centroids,
+                                   c.codebook.astype(np.float16) if kind == "f16" else c.codebook, c.part_offsets, c.codes, c.row_ids)
+    a = ix.search_device(q, 10, 5); b = ix3.search(q, 10, 5)
+    assert (a[0] == b[0]).all()
+
+
+def test_ivf_flat_save_load_roundtrip(eng, oracle, tmp_path):
+    import lance_amd
+    from lance_amd import index_file as IF
+    x = sift_like(9000, 48, 81)
+    q = sift_like(40, 48, 82)
+    ix = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=12, sample_rate=64)
+    ix.save(tmp_path / "f")
+    c = IF.read_index_files(tmp_path / "f")
+    assert c.index_type == "IVF_FLAT" and c.vectors.shape == (9000, 48)
+    assert (c.vectors == x[c.row_ids.astype(np.int64)]).all()
+    ix2 = lance_amd.load_index(tmp_path / "f", engine=eng)
+    for k, nprobes in ((10, 4), (5, 12)):
+        a = ix.search_device(q, k, nprobes); b = ix2.search_device(q, k, nprobes)
+        assert (a[0] == b[0]).all() and (_np(a[1]).view(np.uint32) == _np(b[1]).view(np.uint32)).all()
