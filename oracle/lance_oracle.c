@@ -18,6 +18,12 @@
  * simd/dist_table.rs:178-217) and checks orc_sum_4bit_dist_table against the reference's own C kernel
  * (rust/lance-linalg/src/simd/dist_table.c compiled from where it lies into oracle/_ref/ by oracle/Makefile).
  *
+ * Pinned on outputs of the reference itself (tests/test_index_files.py, fixtures under tests/golden/ref_index copied
+ * from the reference's test_data/ by tests/golden/make_ref_index_fixtures.py -- index directories written by Lance
+ * 0.21.0 / 0.27.1 together with the data they were built from): orc residual + PQ encode reproduce the stored PQ
+ * codes byte for byte, the f64 sum of orc assign distances equals the recorded k-means loss to the bit, and orc k-means
+ * over the rows the reference trained a single IVF centroid on reproduces that centroid bit for bit (M-step order).
+ *
  * Not pinned by any reference test (reference is OS-seeded, kmeans.rs:181,646):
  * the RNG stream used for k-means initialisation and empty-cluster splitting.
  * The oracle and the product share the RNG specified below (xoshiro256++ seeded

@@ -779,3 +779,30 @@ def test_ivf_flat_save_load_roundtrip(eng, oracle, tmp_path):
     for k, nprobes in ((10, 4), (5, 12)):
         a = ix.search_device(q, k, nprobes); b = ix2.search_device(q, k, nprobes)
         assert (a[0] == b[0]).all() and (_np(a[1]).view(np.uint32) == _np(b[1]).view(np.uint32)).all()
+
+
+def test_gpu_reproduces_what_the_reference_stored(eng, oracle):
+    """The HIP path against the reference's OWN outputs (no oracle in between): index files written by Lance 0.27.1 /
+    0.21.0 (tests/golden/ref_index; see tests/test_index_files.py for how they are parsed and pinned on the CPU side).
+    encode: assign + residual + PQ codes == the stored `__pq_code` bytes; loss == the recorded k-means loss (f64, to the
+    bit); k-means over the 256 rows the reference trained on == its stored IVF centroid, bit for bit."""
+    import os
+    from lance_amd import index_file as IF
+    from test_index_files import _legacy_index
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index")
+    c = IF.read_index_files(os.path.join(gold, "v0.27.1_pq_in_schema"))
+    x = IF.read_column(os.path.join(gold, "v0.27.1_pq_in_schema", "data.lance"), "vec", np.float32, 32)
+    x = x[c.row_ids.astype(np.int64)]
+    part, codes, loss = eng.ivfpq_encode(x, c.centroids, c.codebook, "l2")
+    assert (_np(part).view(np.uint32) == c.part_ids()).all()
+    assert (_np(codes) == c.codes_row_major()).all()
+    assert loss == c.loss
+    base = os.path.join(gold, "v0.21.0_legacy")
+    cent, cb, lengths, raw = _legacy_index(os.path.join(base, "index_256.idx"))
+    x2 = IF.read_column(os.path.join(base, "data_256.lance"), "vector", np.float32, 16)
+    gc, _, _ = eng.kmeans_train(x2, 1, max_iters=50, seed=9)
+    assert (_np(gc).view(np.uint32) == cent.view(np.uint32)).all()
+    rid = np.frombuffer(raw[256:256 + 8 * 256], np.uint64)
+    rows = (rid & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    _, codes2, _ = eng.ivfpq_encode(x2[rows], cent, cb, "l2")
+    assert (_np(codes2)[:, 0] == np.frombuffer(raw[:256], np.uint8)).all()

@@ -99,6 +99,53 @@ def test_oracle_search_on_reference_index_is_self_consistent():
     assert lut_hits >= 30
 
 
+def _legacy_index(path):
+    """Legacy (v1, Lance <= 0.21) index.idx: [per partition: PQ codes n*m u8, row ids n*8] ... pb Index (length-prefixed)
+    at the position held in the 16-byte footer.  Test-side parse only -- the engine does not read this format.
+    -> (centroids [nlist,d], codebook [m,256,d/m], lengths, raw bytes)"""
+    import struct
+    b = open(path, "rb").read()
+    assert b[-4:] == b"LANC"
+    pos = struct.unpack("<Q", b[-16:-8])[0]
+    ln = struct.unpack_from("<I", b, pos)[0]
+    vi = [v for fn, _, v in fields(b[pos + 4:pos + 4 + ln]) if fn == 5][0]          # Index.vector_index
+    stages = [v for fn, _, v in fields(vi) if fn == 3]
+    ivf = [v for fn, _, v in fields(stages[0]) if fn == 2][0]
+    pq = [v for fn, _, v in fields(stages[1]) if fn == 3][0]
+    ivf_f = {fn: v for fn, _, v in fields(ivf)}
+    pq_f = {fn: v for fn, _, v in fields(pq)}
+    from lance_file_probe import packed
+    lengths = packed(ivf_f[3])
+    d, m = pq_f[3], pq_f[2]
+    cent = np.frombuffer({fn: v for fn, _, v in fields(ivf_f[4])}[3], np.float32).reshape(len(lengths), d)
+    cb = np.frombuffer({fn: v for fn, _, v in fields(pq_f[5])}[3], np.float32).reshape(m, 256, d // m)
+    return cent, cb, lengths, b
+
+
+def test_oracle_kmeans_reproduces_reference_trained_centroid():
+    """tests/golden/ref_index/v0.21.0_legacy: Lance 0.21.0 built IVF1/PQ1 over 256 x 16 random vectors, so the IVF
+    k-means trained on ALL rows (256 <= sample_rate * 1) and its one centroid is the M-step mean of every row -- free of
+    the unseeded initialisation.  The oracle's k-means (f32 running sum per cluster in row order, then the division:
+    kmeans.rs:371-446) lands on the stored centroid bit for bit; a float64 mean does not."""
+    base = os.path.join(HERE, "golden", "ref_index", "v0.21.0_legacy")
+    cent, cb, lengths, raw = _legacy_index(os.path.join(base, "index_256.idx"))
+    x = IF.read_column(os.path.join(base, "data_256.lance"), "vector", np.float32, 16)
+    assert lengths == [256] and cent.shape == (1, 16) and x.shape == (256, 16)
+    c, _, _, _ = oracle.kmeans_train(x, 1, max_iters=50, seed=123)
+    assert np.array_equal(c.view(np.uint32), cent.view(np.uint32))
+    assert not np.array_equal(x.mean(0, dtype=np.float64).astype(np.float32).view(np.uint32), cent[0].view(np.uint32))
+    # and the stored codes of both the 256-row index and the 32-row delta are the oracle's residual + encode
+    for idx_name, data_name, n in (("index_256.idx", "data_256.lance", 256), ("index_delta32.idx", "data_32.lance", 32)):
+        cent2, cb2, lengths2, raw2 = _legacy_index(os.path.join(base, idx_name))
+        assert lengths2 == [n] and np.array_equal(cent2, cent) and np.array_equal(cb2, cb)
+        xs = IF.read_column(os.path.join(base, data_name), "vector", np.float32, 16)
+        codes = np.frombuffer(raw2[:n], np.uint8)
+        rid = np.frombuffer(raw2[n:n + 8 * n], np.uint64)
+        rows = (rid & np.uint64(0xFFFFFFFF)).astype(np.int64)          # row address = fragment << 32 | offset
+        res = oracle.residual(xs[rows], cent, np.zeros(n, np.uint32))
+        assert np.array_equal(oracle.pq_encode(res, cb, "l2")[:, 0], codes)
+
+
 # ---- writing -----------------------------------------------------------------------------------------------------------
 def _same(a: IF.IndexFileContents, b: IF.IndexFileContents):
     assert (a.index_type, a.metric, a.dtype, a.num_sub_vectors, a.nbits, a.loss) == (b.index_type, b.metric, b.dtype, b.num_sub_vectors, b.nbits, b.loss)
