@@ -22,7 +22,9 @@
  * from the reference's test_data/ by tests/golden/make_ref_index_fixtures.py -- index directories written by Lance
  * 0.21.0 / 0.27.1 together with the data they were built from): orc residual + PQ encode reproduce the stored PQ
  * codes byte for byte, the f64 sum of orc assign distances equals the recorded k-means loss to the bit, and orc k-means
- * over the rows the reference trained a single IVF centroid on reproduces that centroid bit for bit (M-step order).
+ * over the rows the reference trained a single IVF centroid on reproduces that centroid bit for bit (M-step order);
+ * on Lance 0.8.14's IVF4/PQ16 indices (d = 128) orc assign + encode reproduce the stored partition and all 16 code
+ * bytes of each of 3000 rows.
  *
  * Not pinned by any reference test (reference is OS-seeded, kmeans.rs:181,646):
  * the RNG stream used for k-means initialisation and empty-cluster splitting.

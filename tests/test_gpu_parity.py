@@ -806,3 +806,10 @@ def test_gpu_reproduces_what_the_reference_stored(eng, oracle):
     rows = (rid & np.uint64(0xFFFFFFFF)).astype(np.int64)
     _, codes2, _ = eng.ivfpq_encode(x2[rows], cent, cb, "l2")
     assert (_np(codes2)[:, 0] == np.frombuffer(raw[:256], np.uint8)).all()
+    # Lance 0.8.14, IVF4 / PQ16 over 128-d vectors (the BASELINE C2 shape): stored partition and 16 code bytes of 3000 rows
+    z = np.load(os.path.join(gold, "v0.8.14_ivf4_pq16.npz"))
+    for k in (0, 1):
+        xs = z["x"][z[f"rows{k}"]]
+        part, codes, _ = eng.ivfpq_encode(xs, z[f"centroids{k}"], z[f"codebook{k}"], "l2")
+        assert (_np(part).view(np.uint32) == z[f"part{k}"]).all()
+        assert (_np(codes) == z[f"codes{k}"]).all()

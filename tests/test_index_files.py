@@ -146,6 +146,26 @@ def test_oracle_kmeans_reproduces_reference_trained_centroid():
         assert np.array_equal(oracle.pq_encode(res, cb, "l2")[:, 0], codes)
 
 
+def test_oracle_reproduces_reference_ivf4_pq16_assignment_and_codes():
+    """tests/golden/ref_index/v0.8.14_ivf4_pq16.npz: two IVF_PQ indices Lance 0.8.14 built over 1000 / 2000 rows of
+    128-d vectors with 4 partitions and 16 sub-vectors (the SIFT / BASELINE C2 shape: sub-dimension 8).  With the
+    reference's own centroids and codebook the oracle must put every row in the partition the reference stored it
+    under (argmin over several centroids, kmeans.rs:1350-1369) and produce its 16 code bytes (pq.rs:116-191) --
+    3000 rows, 48,000 bytes, all equal; encoding WITHOUT the residual step reproduces only ~90%, so the check bites."""
+    z = np.load(os.path.join(HERE, "golden", "ref_index", "v0.8.14_ivf4_pq16.npz"))
+    for k in (0, 1):
+        x = z["x"][z[f"rows{k}"]]
+        cent, cb = z[f"centroids{k}"], z[f"codebook{k}"]
+        part, _ = oracle.assign(x, cent, "l2")
+        assert np.array_equal(part, z[f"part{k}"])
+        codes = oracle.pq_encode(oracle.residual(x, cent, part), cb, "l2")
+        assert np.array_equal(codes, z[f"codes{k}"])
+        assert (oracle.pq_encode(x, cb, "l2") == z[f"codes{k}"]).mean() < 0.97
+        # the whole transform chain + per-partition storage the oracle builds == the reference's grouping
+        oidx = oracle.build_index(x, cent, cb)
+        assert np.array_equal(oidx.part_offsets, np.concatenate([[0], np.cumsum(np.bincount(z[f"part{k}"], minlength=4))]))
+
+
 # ---- writing -----------------------------------------------------------------------------------------------------------
 def _same(a: IF.IndexFileContents, b: IF.IndexFileContents):
     assert (a.index_type, a.metric, a.dtype, a.num_sub_vectors, a.nbits, a.loss) == (b.index_type, b.metric, b.dtype, b.num_sub_vectors, b.nbits, b.loss)
