@@ -726,43 +726,47 @@ def test_load_reference_written_index_and_search(eng, oracle):
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("kind", ["f32", "f16", "4bit", "dot"])
+@pytest.mark.parametrize("kind", ["f32", "f16", "4bit", "dot", "cosine"])
 def test_index_save_load_roundtrip(eng, oracle, tmp_path, kind):
     """HBM -> files (lance_hip_index_save) -> HBM (lance_hip_index_load): identical storage and identical answers; the
-    files equal what the host-side writer produces from the exported arrays."""
-    import lance_amd
+    files equal what the host-side writer produces from the exported arrays, and the oracle agrees with the re-loaded
+    index.  The indices are built exactly as in the tests above (oracle-trained model, lance_hip_ivfpq_encode)."""
     from lance_amd import index_file as IF
     from lance_amd.engine import DeviceIndex
-    n, d, nlist, m = 12000, 64, 20, 8
-    x = sift_like(n, d, 77)
-    q = sift_like(64, d, 78)
-    metric = "dot" if kind == "dot" else "l2"
+    n, d, nlist = 12000, 64, 20
+    metric = kind if kind in ("dot", "cosine") else "l2"
+    nbits, m = (4, 16) if kind == "4bit" else (8, 8)
     if kind == "f16":
-        x = (x / 4).astype(np.float16); q = (q / 4).astype(np.float16)
-    ix = lance_amd.create_index(x, "IVF_PQ", metric=metric, num_partitions=nlist, num_sub_vectors=m, max_iters=6, sample_rate=64,
-                                num_bits=4 if kind == "4bit" else 8)
-    ix.save(tmp_path / "a")
+        x, q = f16_data(n, d, 77), f16_data(64, d, 78)
+    else:
+        x, q = sift_like(n, d, 77) + (1.0 if kind == "cosine" else 0.0), sift_like(64, d, 78) + (1.0 if kind == "cosine" else 0.0)
+    xs = oracle.normalize(x) if metric == "cosine" else x
+    kmetric = "l2" if metric == "cosine" else metric
+    cent, _, _, _ = oracle.kmeans_train(xs[:4096], nlist, max_iters=6, seed=1, metric=kmetric)
+    part, _ = oracle.assign(xs, cent, kmetric)
+    res = oracle.residual(xs, cent, part) if kmetric == "l2" else xs
+    cb, _ = oracle.pq_train(res[:8192], m, nbits=nbits, max_iters=6, seed=2)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+    ix = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes)
+    ix.save(tmp_path / "a", loss=1234.5678)
     c = IF.read_index_files(tmp_path / "a")
-    offs, codes_t, rid = ix.export_storage()
-    assert c.metric == metric and c.dtype == ("float16" if kind == "f16" else "float32") and c.nbits == (4 if kind == "4bit" else 8)
+    offs, codes_t, rid = ix.export()
+    assert (c.metric, c.dtype, c.nbits, c.num_sub_vectors, c.loss) == (metric, "float16" if kind == "f16" else "float32", nbits, m, 1234.5678)
     assert (c.part_offsets == offs).all() and (c.codes == codes_t).all() and (c.row_ids == rid).all()
-    assert (c.centroids == ix.centroids.astype(f32)).all() and (c.codebook == ix.codebook.astype(f32)).all()
-    assert c.loss == ix.stats.ivf_loss
+    assert (c.centroids == np.asarray(cent, f32)).all() and (c.codebook == np.asarray(cb, f32)).all()
     IF.write_index_files(tmp_path / "b", c)            # host writer on the same contents: same bytes
     for name in ("index.idx", "auxiliary.idx"):
         assert (tmp_path / "a" / name).read_bytes() == (tmp_path / "b" / name).read_bytes(), name
-    ix2 = lance_amd.load_index(tmp_path / "a", engine=eng)
-    o2, c2, r2 = ix2.export_storage()
+    ix2 = DeviceIndex.load(eng, tmp_path / "a")
+    o2, c2, r2 = ix2.export()
     assert (o2 == offs).all() and (c2 == codes_t).all() and (r2 == rid).all()
+    oidx = oracle.build_index(x, cent, cb, metric, nbits=nbits)
     for k, nprobes in ((10, nlist), (10, 3)):
-        a = ix.search_device(q, k, nprobes)
-        b = ix2.search_device(q, k, nprobes)
+        a = ix.search(q, k, nprobes)
+        b = ix2.search(q, k, nprobes)
         assert (a[0] == b[0]).all() and (_np(a[1]).view(np.uint32) == _np(b[1]).view(np.uint32)).all()
-    # the composed path (parsed arrays -> from_storage) lands on the same index
-    ix3 = DeviceIndex.from_storage(eng, metric, c.centroids.astype(np.float16) if kind == "f16" else c.centroids,
-                                   c.codebook.astype(np.float16) if kind == "f16" else c.codebook, c.part_offsets, c.codes, c.row_ids)
-    a = ix.search_device(q, 10, 5); b = ix3.search(q, 10, 5)
-    assert (a[0] == b[0]).all()
+        oi, od = oidx.search(q, k, nprobes)
+        assert (_np(b[0]).view(np.uint64) == oi).all() and (_np(b[1]).view(np.uint32) == od.view(np.uint32)).all()
 
 
 def test_ivf_flat_save_load_roundtrip(eng, oracle, tmp_path):
