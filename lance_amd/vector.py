@@ -157,10 +157,51 @@ class IvfPqIndex:
         rid = np.arange(part.size, dtype=np.uint64)[keep]
         return rid, part[keep], self.codes.cpu().numpy()[keep]
 
-    def nearest(self, q, k=10, nprobes=1, refine_factor=None):
-        """-> (row ids int64 [nq,k] (-1 = missing), distances f32 [nq,k]) as numpy"""
-        ids, dists = self._ix.search(q, k, nprobes, 0 if refine_factor is None else refine_factor)
+    def nearest(self, q, k=10, nprobes=1, refine_factor=None, prefilter=None):
+        """-> (row ids int64 [nq,k] (-1 = missing), distances f32 [nq,k]) as numpy.
+        prefilter: boolean array over row ids (True = row may be returned) -- `nearest=..., filter=..., prefilter=True`
+        of the reference (scanner.rs prefilter -> FlatIndex::search's RowIdMask branch, flat/index.rs:129-165)."""
+        ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
+        ids, dists = ix.search(q, k, nprobes, 0 if refine_factor is None else refine_factor)
         return ids.cpu().numpy(), dists.cpu().numpy()
+
+    def _storage_rows(self):
+        """(part ids int32 [n], row-major codes u8 [n, code bytes], row ids int64 [n] | None) on the device, in an order
+        whose stable grouping by partition is the stored order"""
+        if self.part_ids is not None and self.codes is not None:
+            return self.part_ids, self.codes, None
+        offs, codes_t, rid = self._ix.export()          # an index opened from files: undo the per-partition transpose
+        cb = codes_t.size // max(len(rid), 1) if len(rid) else 1
+        rm = np.empty((len(rid), cb), np.uint8)
+        for p in range(len(offs) - 1):
+            a, b = int(offs[p]), int(offs[p + 1])
+            rm[a:b] = codes_t[a * cb:b * cb].reshape(cb, b - a).T
+        part = np.repeat(np.arange(len(offs) - 1, dtype=np.int32), np.diff(offs.astype(np.int64)))
+        return to_device(part), to_device(rm), to_device(rid)
+
+    def prefiltered(self, allow):
+        """The index restricted to the rows whose id is selected by `allow` (bool over row ids).  Under a prefilter the
+        reference visits a partition's rows in storage order, skips the unselected ones and feeds the rest to the same
+        k-heap (flat/index.rs:129-165); for 8-bit PQ `distance(id)` sums the same table entries in the same order as
+        `distance_all` (pq/storage.rs:893-960), so searching a compacted copy of the storage -- unselected rows dropped,
+        order kept -- gives bit-identical results (tests/test_oracle_golden.py::test_prefilter_equals_compaction).  The
+        compacted copy is built by lance_hip_index_create, which already drops rows without a partition.  One O(n) pass
+        per distinct filter; queries sharing a filter should share the returned index."""
+        from .engine import DeviceIndex
+        if self.params.num_bits == 4:
+            raise NotImplementedError("prefilter on a 4-bit PQ index: the reference scores filtered rows with the unquantised "
+                                      "table (pq/storage.rs:897-908), which this engine's 4-bit scan does not implement yet")
+        part, codes, rid = self._storage_rows()
+        allow_t = to_device(np.ascontiguousarray(allow, dtype=bool)) if not isinstance(allow, torch.Tensor) else allow.to(part.device)
+        ids = torch.arange(part.numel(), device=part.device) if rid is None else rid
+        inside = ids < allow_t.numel()
+        sel = torch.zeros_like(inside)
+        sel[inside] = allow_t[ids[inside]]
+        masked = torch.where(sel, part, torch.full_like(part, -1))          # -1 = LANCE_HIP_NONE: dropped by index_create
+        ix = self._ix
+        dtype = {torch.float16: "float16", torch.int8: "int8"}.get(ix.data_dtype, "float32")
+        sub = DeviceIndex.create(ix.engine, ix.metric, ix.centroids, ix.codebook, masked, codes, rid, raw=ix._raw, dtype=dtype)
+        return IvfPqIndex(sub, self.params, self.stats, masked, codes if rid is None else None)
 
     def search_device(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
         return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync)
@@ -197,9 +238,28 @@ class IvfFlatIndex:
     def search_device(self, q, k, nprobes):
         return self._ix.search(q, k, nprobes)
 
-    def nearest(self, q, k=10, nprobes=1):
-        ids, dists = self._ix.search(q, k, nprobes)
+    def nearest(self, q, k=10, nprobes=1, prefilter=None):
+        ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
+        ids, dists = ix.search(q, k, nprobes)
         return ids.cpu().numpy().view(np.uint64), dists.cpu().numpy()
+
+    def prefiltered(self, allow):
+        """IVF_FLAT under a row-id prefilter: FlatIndex::search scores each selected row with the same distance function
+        as the unfiltered scan (flat/storage.rs:345-402), so the compacted copy is exact (see IvfPqIndex.prefiltered)."""
+        from .engine import DeviceFlatIndex
+        if self.part_ids is None or getattr(self, "_x", None) is None:
+            raise NotImplementedError("prefilter needs the index's vectors and partition ids (an index built by create_index)")
+        part = self.part_ids
+        allow_t = to_device(np.ascontiguousarray(allow, dtype=bool)) if not isinstance(allow, torch.Tensor) else allow.to(part.device)
+        ids = torch.arange(part.numel(), device=part.device)
+        inside = ids < allow_t.numel()
+        sel = torch.zeros_like(inside)
+        sel[inside] = allow_t[ids[inside]]
+        masked = torch.where(sel, part, torch.full_like(part, -1))
+        sub = DeviceFlatIndex.create(self._ix.engine, self._ix.metric, self._ix.centroids, self._x, masked)
+        out = IvfFlatIndex(sub, self.params, self.stats, masked)
+        out._x = self._x
+        return out
 
     def save(self, index_dir):
         self._ix.save(index_dir, None if self.stats is None else self.stats.ivf_loss)
@@ -300,7 +360,9 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
             raise NotImplementedError("IVF_FLAT with the cosine metric is not supported by this engine yet (use l2 or dot)")
         part, _ = timed("transform", lambda: eng.assign(x, cent, params.metric))
         fx = timed("build_partitions", lambda: DeviceFlatIndex.create(eng, params.metric, cent, x, part))
-        return IvfFlatIndex(fx, params, stats, part)
+        out = IvfFlatIndex(fx, params, stats, part)
+        out._x = x if keep_raw else None      # the column itself (borrowed): needed to re-partition under a prefilter
+        return out
     if num_bits not in (4, 8):
         raise ValueError(f"ProductQuantization: num_bits {num_bits} not supported")
     if pq_codebook is not None:
@@ -314,8 +376,15 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
     return IvfPqIndex(ix, params, stats, part, codes)
 
 
-def flat_knn(x, q, k=10, metric="l2", engine=None):
-    """Exhaustive KNN (`use_index=False`): (row ids, distances) sorted by (distance, row id)."""
+def flat_knn(x, q, k=10, metric="l2", engine=None, prefilter=None):
+    """Exhaustive KNN (`use_index=False`): (row ids, distances) sorted by (distance, row id).
+    prefilter: boolean array over rows; the scan then covers the selected rows only, as the reference's filtered
+    scan feeds KNNVectorDistanceExec (scanner.rs:3386-3411) -- row ids stay those of the full table."""
     eng = engine or default_engine()
+    if prefilter is not None:
+        xt = to_device(x)
+        keep = torch.nonzero(to_device(np.ascontiguousarray(prefilter, dtype=bool)) if not isinstance(prefilter, torch.Tensor)
+                             else prefilter.to(xt.device)).reshape(-1)
+        return eng.flat_topk(xt[keep].contiguous(), q, k, _normalize_metric_type(metric), row_ids=keep)
     ids, dists = eng.flat_topk(x, q, k, _normalize_metric_type(metric))
     return ids, dists

@@ -345,11 +345,21 @@ class IvfPqIndex:
         self.codes_t = np.ascontiguousarray(codes_t, np.uint8)
         self.row_ids = np.ascontiguousarray(row_ids, np.uint64)
 
-    def search(self, queries, k, nprobes, refine=0, raw=None):
+    def search(self, queries, k, nprobes, refine=0, raw=None, prefilter=None):
+        """prefilter: boolean array over row ids (True = selected), the RowIdMask of a prefiltered query
+        (flat/index.rs:129-165); every selected row goes through DistCalculator::distance(id)."""
         q = _f32(queries).reshape(-1, self.centroids.shape[1])
         nq, d = q.shape
         ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
         r = None if raw is None else _f32(raw)
+        if prefilter is not None:
+            allow = np.ascontiguousarray(prefilter, dtype=np.uint8)
+            lib().orc_ivfpq_search_filtered(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
+                                            _p(self.codebook), C.c_size_t(self.codebook.shape[0]), C.c_uint32(self.nbits),
+                                            _p(self.part_offsets), _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq),
+                                            C.c_size_t(k), C.c_size_t(nprobes), C.c_size_t(refine), _p(r), _p(ids), _p(dists),
+                                            C.c_int(int(self.f16)), _p(allow), C.c_size_t(allow.size))
+            return ids, dists
         lib().orc_ivfpq_search_x2(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
                                  _p(self.codebook), C.c_size_t(self.codebook.shape[0]), C.c_uint32(self.nbits), _p(self.part_offsets),
                                  _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq), C.c_size_t(k),

@@ -1105,11 +1105,30 @@ void orc_ivfpq_search_x(int metric, const float *centroids, size_t nlist, size_t
 }
 /* nbits = 4: codes_t blocks are [M/2][n_p] packed bytes and distance_all takes the 4-bit path with
  * k_hint = k*refine (flat/index.rs:94 `dist_calc.distance_all(k)`). */
-void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_t d,
+/* DistCalculator::distance(id) of PQDistCalculator (pq/storage.rs:893-919), the per-row form the PREFILTER branch of
+ * FlatIndex::search uses (flat/index.rs:129-165): 8-bit = Iterator::sum over the M table entries in order (the same
+ * association as distance_all); 4-bit = per code byte (table[2i][lo] + table[2i+1][hi]), those pair sums added in
+ * order, on the UNQUANTISED f32 table (distance_all quantises it); dot: minus (M-1).                                */
+static float orc_pq_distance_one(int metric, const float *lut, size_t m_count, uint32_t nbits, const uint8_t *codes_t,
+                                 size_t n_p, size_t j) {
+  float s = -0.0f;   /* f32::sum folds from -0.0 (core::iter::traits::accum, Rust >= 1.81) */
+  if (nbits == 4) {
+    for (size_t i = 0; i < m_count / 2; i++) {
+      const uint8_t c = codes_t[i * n_p + j];
+      s += lut[(2 * i) * 16 + (c & 0x0F)] + lut[(2 * i + 1) * 16 + (c >> 4)];
+    }
+  } else {
+    for (size_t m = 0; m < m_count; m++) s += lut[m * 256 + codes_t[m * n_p + j]];
+  }
+  if (metric == ORC_DOT) s = s - ((float)m_count - 1.0f);
+  return s;
+}
+
+static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nlist, size_t d,
                          const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
                          const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
                          size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
-                         uint64_t *out_ids, float *out_dists, int f16) {
+                         uint64_t *out_ids, float *out_dists, int f16, const uint8_t *allow, size_t n_allow) {
   const size_t mbytes = nbits == 4 ? m_count / 2 : m_count;
   if (nprobes > nlist) nprobes = nlist;
   int scan_metric = (metric == ORC_COSINE) ? ORC_L2 : metric;
@@ -1125,6 +1144,7 @@ void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_
     float *qr = (float *)malloc(d * sizeof(float));
     float *lut = (float *)malloc(m_count * 256 * sizeof(float));
     float *pd = (float *)malloc((max_np ? max_np : 1) * sizeof(float));
+    uint64_t *pid = (uint64_t *)malloc((max_np ? max_np : 1) * sizeof(uint64_t));
     uint32_t *parts = (uint32_t *)malloc(nprobes * sizeof(uint32_t));
     uint64_t *cand_ids = (uint64_t *)malloc((nprobes * keff + 1) * sizeof(uint64_t));
     float *cand_d = (float *)malloc((nprobes * keff + 1) * sizeof(float));
@@ -1152,6 +1172,19 @@ void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_
         memcpy(qr, q, d * sizeof(float));
       }
       orc_build_lut_f32(scan_metric, qr, d, codebook, m_count, nbits, lut);
+      if (allow) {
+        /* prefilter branch: only selected rows, in storage order, each through distance(id); the heap sees the same
+         * (row id, distance) sequence as FlatIndex::search's loop */
+        size_t na = 0;
+        for (size_t j = 0; j < np_; j++) {
+          const uint64_t rid = row_ids[off + j];
+          if (rid >= n_allow || !allow[rid]) continue;
+          pd[na] = orc_pq_distance_one(scan_metric, lut, m_count, nbits, codes_t + off * mbytes, np_, j);
+          pid[na++] = rid;
+        }
+        ncand += orc_heap_topk(pd, pid, na, keff, 0, 0, 0, cand_ids + ncand, cand_d + ncand);
+        continue;
+      }
       if (nbits == 4) orc_pq_scan4_f32(scan_metric, lut, m_count, codes_t + off * mbytes, np_, keff, pd);
       else orc_pq_scan_f32(scan_metric, lut, m_count, codes_t + off * mbytes, np_, pd);
       ncand += orc_heap_topk(pd, row_ids + off, np_, keff, 0, 0, 0, cand_ids + ncand, cand_d + ncand);
@@ -1174,8 +1207,28 @@ void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_
       out_ids[i * k + j] = j < got ? cand_ids[j] : UINT64_MAX;
       out_dists[i * k + j] = j < got ? cand_d[j] : INFINITY;
     }
-    free(q); free(qr); free(lut); free(pd); free(parts); free(cand_ids); free(cand_d);
+    free(q); free(qr); free(lut); free(pd); free(pid); free(parts); free(cand_ids); free(cand_d);
   }
+}
+
+void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_t d,
+                         const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
+                         const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                         size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                         uint64_t *out_ids, float *out_dists, int f16) {
+  orc_ivfpq_search_impl(metric, centroids, nlist, d, codebook, m_count, nbits, part_offsets, codes_t, row_ids, queries, nq, k,
+                        nprobes, refine, raw, out_ids, out_dists, f16, NULL, 0);
+}
+
+/* The same search under a row-id prefilter (scanner prefilter=True -> PreFilter::mask, flat/index.rs:129-165):
+ * allow[row id] != 0 selects a row; ids >= n_allow are not selected. */
+void orc_ivfpq_search_filtered(int metric, const float *centroids, size_t nlist, size_t d,
+                               const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
+                               const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                               size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
+                               uint64_t *out_ids, float *out_dists, int f16, const uint8_t *allow, size_t n_allow) {
+  orc_ivfpq_search_impl(metric, centroids, nlist, d, codebook, m_count, nbits, part_offsets, codes_t, row_ids, queries, nq, k,
+                        nprobes, refine, raw, out_ids, out_dists, f16, allow, n_allow);
 }
 
 /* Index build glue (builder.rs:555-846 in canonical, stable row order):

@@ -817,3 +817,30 @@ def test_gpu_reproduces_what_the_reference_stored(eng, oracle):
         part, codes, _ = eng.ivfpq_encode(xs, z[f"centroids{k}"], z[f"codebook{k}"], "l2")
         assert (_np(part).view(np.uint32) == z[f"part{k}"]).all()
         assert (_np(codes) == z[f"codes{k}"]).all()
+
+
+def test_prefilter_matches_reference_branch(engine, oracle):
+    """`nearest=..., filter=..., prefilter=True`: FlatIndex::search's RowIdMask branch (flat/index.rs:129-165) restated in
+    the oracle (orc_ivfpq_search_filtered) against the device path (compacted storage, lance_amd/vector.py prefiltered);
+    IVF_FLAT and flat KNN under the same masks."""
+    import lance_amd
+    x = sift_like(20000, 64, 131)
+    q = sift_like(50, 64, 132)
+    rng = np.random.default_rng(7)
+    ix = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=16, num_sub_vectors=8, max_iters=6, sample_rate=64)
+    oidx = oracle.build_index(x, ix.centroids, ix.codebook)
+    fx = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=16, max_iters=6, sample_rate=64)
+    for frac in (0.5, 0.02, 1.0):
+        allow = rng.random(x.shape[0]) < frac
+        keep = np.nonzero(allow)[0]
+        for k, nprobes, rf in ((10, 5, None), (10, 16, 4)):
+            gi, gd = ix.nearest(q, k, nprobes, refine_factor=rf, prefilter=allow)
+            oi, od = oidx.search(q, k, nprobes, refine=rf or 0, raw=x if rf else None, prefilter=allow)
+            assert (gi.view(np.uint64) == oi).all(), (frac, k, nprobes, rf)
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+        gi, gd = fx.nearest(q, 10, 6, prefilter=allow)
+        oi, od = oracle.ivfflat_search(x[keep], fx.centroids, q, 10, 6, "l2", row_ids=keep.astype(np.uint64))
+        assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+        fi, fd = lance_amd.flat_knn(x, q, 10, "l2", prefilter=allow)
+        oi, od = oracle.flat_knn(x[keep], q, 10, "l2", row_ids=keep.astype(np.uint64))
+        assert (_np(fi).view(np.uint64) == oi).all() and (_np(fd).view(np.uint32) == od.view(np.uint32)).all()

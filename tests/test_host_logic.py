@@ -167,3 +167,79 @@ def test_indices_builder_argument_rules_and_models(tmp_path):
     pq.save(str(tmp_path / "pq.arrow"))
     back = lance_amd.PqModel.load(str(tmp_path / "pq.arrow"))
     assert back.num_subvectors == 4 and (back.to_numpy() == cb).all()
+
+
+# ---- prefilter: host-side compaction logic against the oracle's literal restatement of the prefilter branch ----------
+class _OracleDeviceIndex:
+    """DeviceIndex stand-in on CPU tensors: groups (part ids, row-major codes, row ids) exactly as lance_hip_index_create
+    does (stable, rows without a partition dropped) and answers through the oracle's unfiltered search."""
+
+    def __init__(self, engine, metric, centroids, codebook, part, codes, rid, raw, dtype):
+        import oracle
+        self.engine, self.metric, self.centroids, self.codebook, self._raw = engine, metric, centroids, codebook, raw
+        self.data_dtype = torch.float32
+        part = np.ascontiguousarray(part.numpy()).view(np.uint32)
+        codes = codes.numpy()
+        rid = np.arange(part.size, dtype=np.uint64) if rid is None else rid.numpy().view(np.uint64)
+        cent, cb = centroids.numpy(), codebook.numpy()
+        offs, perm = oracle.partition_layout(part, cent.shape[0])
+        cs = codes[perm]
+        m = codes.shape[1]
+        ct = np.empty(cs.size, np.uint8)
+        for p in range(cent.shape[0]):
+            a, b = int(offs[p]), int(offs[p + 1])
+            ct[a * m:b * m] = cs[a:b].T.reshape(-1)
+        self.o = oracle.IvfPqIndex(metric, cent, cb, offs, ct, rid[perm], nbits=4 if cb.shape[1] == 16 else 8)
+
+    @classmethod
+    def create(cls, engine, metric, centroids, codebook, part_ids, codes, row_ids=None, raw=None, dtype=None):
+        return cls(engine, metric, centroids, codebook, part_ids, codes, row_ids, raw, dtype)
+
+    def export(self):
+        return self.o.part_offsets, self.o.codes_t, self.o.row_ids
+
+    def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
+        i, d = self.o.search(np.asarray(q), k, nprobes, refine=refine_factor, raw=None if self._raw is None else self._raw.numpy())
+        return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
+def test_prefilter_compaction_equals_reference_prefilter_branch(oracle, monkeypatch, metric):
+    """IvfPqIndex.nearest(prefilter=) compacts the storage and searches it unfiltered.  That must equal the reference's
+    prefilter branch (flat/index.rs:129-165: skip unselected rows, DistCalculator::distance(id) for the rest, same heap),
+    restated literally in the oracle (orc_ivfpq_search_filtered) -- with refine, for an index built by create_index and
+    for one opened from files (storage order + explicit row ids)."""
+    import lance_amd.vector as V
+    import lance_amd.engine as E
+    cpu = lambda a, dtype=None: (a if isinstance(a, torch.Tensor) else torch.from_numpy(
+        np.ascontiguousarray(a).view(np.int64) if np.asarray(a).dtype == np.uint64 else np.ascontiguousarray(a)))
+    monkeypatch.setattr(V, "to_device", cpu)
+    monkeypatch.setattr(E, "DeviceIndex", _OracleDeviceIndex)
+    rng = np.random.default_rng(3)
+    n, d, nlist, m = 5000, 32, 10, 4
+    x = (rng.standard_normal((n, d)) * 2 + 1).astype(f32)
+    q = (rng.standard_normal((30, d)) * 2 + 1).astype(f32)
+    xs = oracle.normalize(x) if metric == "cosine" else x
+    km = "l2" if metric == "cosine" else metric
+    cent, _, _, _ = oracle.kmeans_train(xs[:2000], nlist, max_iters=5, seed=1, metric=km)
+    part, _ = oracle.assign(xs, cent, km)
+    cb, _ = oracle.pq_train((oracle.residual(xs, cent, part) if km == "l2" else xs)[:3000], m, max_iters=4, seed=2)
+    oidx = oracle.build_index(x, cent, cb, metric)
+    base = _OracleDeviceIndex(None, metric, torch.from_numpy(cent), torch.from_numpy(cb), torch.from_numpy(oidx.part_ids.view(np.int32).copy()),
+                              torch.from_numpy(oidx.codes_rowmajor.copy()), None, torch.from_numpy(x), None)
+    params = V.IvfPqParams(nlist, m, 8, metric)
+    built = V.IvfPqIndex(base, params, None, torch.from_numpy(oidx.part_ids.view(np.int32).copy()), torch.from_numpy(oidx.codes_rowmajor.copy()))
+    opened = V.IvfPqIndex(base, params, None)                       # as after load_index: no shuffle-buffer columns kept
+    for frac in (0.5, 0.05, 1.0, 0.0):
+        allow = rng.random(n) < frac
+        for k, nprobes, rf in ((10, 4, None), (5, nlist, 3)):
+            want_i, want_d = oidx.search(q, k, nprobes, refine=rf or 0, raw=x if rf else None, prefilter=allow)
+            for ix in (built, opened):
+                got_i, got_d = ix.nearest(q, k, nprobes, refine_factor=rf, prefilter=allow)
+                assert np.array_equal(got_i.view(np.uint64), want_i), (metric, frac, k)
+                assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+    short = np.ones(100, bool)                                      # a mask shorter than the table selects nothing beyond it
+    got_i, _ = built.nearest(q, 5, nlist, prefilter=short)
+    assert (got_i.view(np.uint64)[got_i != -1] < 100).all()
+    with pytest.raises(NotImplementedError):
+        V.IvfPqIndex(base, V.IvfPqParams(nlist, m, 4, metric), None).prefiltered(np.ones(n, bool))

@@ -588,3 +588,33 @@ def test_float16_underflow_fix_like_reference(oracle):
     x = rng.random((2 * 65536, 2)).astype(np.float16)
     c, _, _, _ = oracle.kmeans_train(x[: 2 * 512], 2, max_iters=10, seed=4)
     assert c.dtype == np.float16 and not np.isnan(c.astype(f32)).any() and (c.astype(f32) != 0).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_prefilter_equals_compaction(metric):
+    """flat/index.rs:129-165 + pq/storage.rs:893-960: under a row-id prefilter the reference scores each selected row
+    with DistCalculator::distance(id).  For 8-bit PQ that is the same sum as distance_all, so the filtered search equals
+    an unfiltered search over storage with the unselected rows removed (what the engine does); for 4-bit it is NOT --
+    distance(id) uses the unquantised table and adds per-byte pair sums -- so even an all-true filter changes 4-bit
+    results, and the engine refuses that combination instead of answering differently."""
+    import oracle as orc
+    rng = np.random.default_rng(21)
+    n, d, nlist = 6000, 64, 12
+    x = np.clip(np.rint(rng.normal(60, 30, (n, d))), 0, 218).astype(np.float32)
+    q = np.clip(np.rint(rng.normal(60, 30, (40, d))), 0, 218).astype(np.float32)
+    cent, _, _, _ = orc.kmeans_train(x[:2048], nlist, max_iters=5, seed=1, metric=metric)
+    part, _ = orc.assign(x, cent, metric)
+    res = orc.residual(x, cent, part) if metric == "l2" else x
+    allow = rng.random(n) < 0.3
+    keep = np.nonzero(allow)[0]
+    for nbits, m in ((8, 8), (4, 16)):
+        cb, _ = orc.pq_train(res[:4096], m, nbits=nbits, max_iters=5, seed=2)
+        full = orc.build_index(x, cent, cb, metric, nbits=nbits)
+        fi, fd = full.search(q, 10, 4, prefilter=allow)
+        assert allow[fi[fi != np.iinfo(np.uint64).max].astype(np.int64)].all()
+        ci, cd = orc.build_index(x[keep], cent, cb, metric, row_ids=keep.astype(np.uint64), nbits=nbits).search(q, 10, 4)
+        ai, ad = full.search(q, 10, 4, prefilter=np.ones(n, bool))
+        ui, ud = full.search(q, 10, 4)
+        same_compact = np.array_equal(fi, ci) and np.array_equal(fd.view(np.uint32), cd.view(np.uint32))
+        same_alltrue = np.array_equal(ai, ui) and np.array_equal(ad.view(np.uint32), ud.view(np.uint32))
+        assert (same_compact, same_alltrue) == ((True, True) if nbits == 8 else (False, False))
