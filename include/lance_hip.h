@@ -229,7 +229,8 @@ int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, con
 
 /* ---- a22 / 8(f) N3: index files (lance/src/index/vector/builder.rs:938-1079 merge_partitions) ---------------------- */
 /* The `index.idx` + `auxiliary.idx` pair of an IVF_PQ / IVF_FLAT index directory, Lance file format 2.0 (the
- * FileWriter default, lance-file/src/writer.rs:553-561).  Host-side: nothing here needs a GPU except load/save.
+ * FileWriter default, lance-file/src/writer.rs:553-561).  Host-side: nothing here needs a GPU except load/save, and every
+ * pointer of the view below is a HOST pointer (the exception to this header's device-pointer convention).
  * Readers replaced: IvfQuantizationStorage::try_new (lance-index/src/vector/storage.rs:182-243),
  * ProductQuantizationMetadata (pq/storage.rs:52-144), IvfModel <-> pb (ivf/storage.rs:181-244).                    */
 enum { LANCE_HIP_IVF_PQ = 0, LANCE_HIP_IVF_FLAT = 1 };

@@ -67,3 +67,23 @@ def test_bench_and_smoke_refuse_to_run_without_a_gpu():
     assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout) and "{" not in r.stdout
     r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_header_is_plain_c_and_usable_from_c(tmp_path):
+    """include/lance_hip.h compiles as strict C99 and a C program linked against liblance_hip.so drives the index-file
+    entry points (open / view / write / re-open / column read / error channel) -- the shape a cgo or Rust `extern "C"`
+    binding has.  Host-only calls: no GPU needed."""
+    import subprocess
+    from lance_amd import _lib
+    src = os.path.join(ROOT, "tests", "c", "index_file_roundtrip.c")
+    exe = str(tmp_path / "ifr")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+           "-L", libdir, "-llance_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    ref = os.path.join(ROOT, "tests", "golden", "ref_index", "v0.27.1_pq_in_schema")
+    r = subprocess.run([exe, ref, str(tmp_path / "out"), os.path.join(ref, "data.lance")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "d=32 nlist=1 m=4 nbits=8 rows=512" in r.stdout and "loss=1394.7242410182953" in r.stdout
+    assert "rows=512 row_bytes=128" in r.stdout and r.stdout.strip().endswith("ok")
