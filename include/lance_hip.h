@@ -252,7 +252,9 @@ typedef struct lance_hip_index_file_view {
   const void *vectors;          /* IVF_FLAT: [n_rows][d] of dtype */
 } lance_hip_index_file_view;
 /* Maps and validates both files; the view's pointers stay valid until close.  Files written by Lance <= 0.27 (PQ
- * codebook inline in the schema metadata) are read too; legacy v1 index files and other index types are refused. */
+ * codebook inline in the schema metadata) are read too, and so is the legacy single-file layout of Lance <= 0.21
+ * (`index.idx` only: pb Index behind a 16-byte footer; lance/src/index/vector/ivf.rs IVFIndex::try_new, pq.rs
+ * PQIndex::load) -- its codes come back row-major (transposed = 0).  Other index types are refused.             */
 int lance_hip_index_file_open(const char *index_dir, lance_hip_index_file **out);
 int lance_hip_index_file_get(const lance_hip_index_file *f, lance_hip_index_file_view *view);
 void lance_hip_index_file_close(lance_hip_index_file *f);

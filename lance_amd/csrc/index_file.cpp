@@ -109,6 +109,8 @@ struct lance_hip_index_file {
   std::vector<uint32_t> part_offsets;
   std::vector<uint8_t> rowid_buf, payload_buf;   // only filled when a column spans several pages
   std::vector<uint8_t> inline_codebook;          // v0.27-style codebook_tensor bytes
+  std::vector<uint8_t> legacy;                   // whole legacy (v1) index.idx, when that is what the directory holds
+  std::vector<uint64_t> legacy_row_ids;
 };
 
 #define IO_FAIL(code, ...)       \
@@ -117,8 +119,150 @@ struct lance_hip_index_file {
     return code;                 \
   } while (0)
 
+// Legacy (v1) vector index, written by Lance up to 0.21 and still opened by the reference (lance/src/index/vector/ivf.rs
+// IVFIndex::try_new + pq.rs PQIndex::load): ONE file `index.idx` = for every partition [PQ codes n_p x m, row-major]
+// [row ids n_p x u64] at the byte offset IVF.offsets[p], then a length-prefixed pb `Index` message whose position is in
+// the 16-byte footer [u64 position][u16 major = 0][u16 minor <= 2]["LANC"] (protos/index.proto:13-34,131-160).
+static int open_legacy(const std::string &path, lance_hip_index_file *f) {
+  FILE *fp = fopen(path.c_str(), "rb");
+  if (!fp) IO_FAIL(LANCE_HIP_EIO, "index_file_open: cannot open %s: %s", path.c_str(), strerror(errno));
+  fseek(fp, 0, SEEK_END);
+  const long sz = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  f->legacy.resize(sz > 0 ? (size_t)sz : 0);
+  const bool rd = sz > 0 && fread(f->legacy.data(), 1, (size_t)sz, fp) == (size_t)sz;
+  fclose(fp);
+  if (!rd || sz < 20) IO_FAIL(LANCE_HIP_EIO, "index_file_open: cannot read %s", path.c_str());
+  const uint8_t *b = f->legacy.data();
+  const uint64_t size = (uint64_t)sz;
+  uint64_t pos;
+  memcpy(&pos, b + size - 16, 8);
+  uint32_t len = 0;
+  if (pos > size - 20) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: corrupt legacy footer", path.c_str());
+  memcpy(&len, b + pos, 4);
+  if (len > size - 16 - 4 - pos) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: corrupt legacy index message", path.c_str());
+  lance_hip_index_file_view &v = f->v;
+  const uint8_t *vi = nullptr; size_t vi_n = 0;
+  {
+    PbReader r(b + pos + 4, len);
+    bool ok = true;
+    for (PbField g; r.next(&g, &ok);)
+      if (g.number == 5 && g.wire == 2) { vi = g.data; vi_n = g.size; }
+    if (!ok || !vi) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s holds no vector index", path.c_str());
+  }
+  IvfPb ivf;
+  bool have_ivf = false, have_pq = false;
+  uint64_t dim = 0, metric = 0, nbits = 0, m = 0, pq_dim = 0;
+  Tensor cb_tensor;
+  bool cb_has_tensor = false;
+  std::vector<float> cb_floats, cent_floats;
+  {
+    PbReader r(vi, vi_n);
+    bool ok = true;
+    for (PbField g; r.next(&g, &ok);) {
+      if (g.number == 2 && g.wire == 0) dim = g.value;
+      else if (g.number == 4 && g.wire == 0) metric = g.value;
+      else if (g.number == 3 && g.wire == 2) {                       // VectorIndexStage
+        PbReader rs(g.data, g.size);
+        bool oks = true;
+        for (PbField h; rs.next(&h, &oks);) {
+          if (h.number == 2 && h.wire == 2) {                        // IVF
+            have_ivf = true;
+            if (!parse_ivf(h.data, h.size, &ivf)) oks = false;
+            if (!ivf.has_tensor && ivf.n_legacy_centroids) {         // repeated float centroids = 1 (packed)
+              PbReader ri(h.data, h.size);
+              bool oki = true;
+              for (PbField k; ri.next(&k, &oki);)
+                if (k.number == 1 && k.wire == 2) { const size_t o = cent_floats.size(); cent_floats.resize(o + k.size / 4); memcpy(cent_floats.data() + o, k.data, k.size / 4 * 4); }
+            }
+          } else if (h.number == 3 && h.wire == 2) {                 // PQ
+            have_pq = true;
+            PbReader rp(h.data, h.size);
+            bool okp = true;
+            for (PbField k; rp.next(&k, &okp);) {
+              if (k.number == 1 && k.wire == 0) nbits = k.value;
+              else if (k.number == 2 && k.wire == 0) m = k.value;
+              else if (k.number == 3 && k.wire == 0) pq_dim = k.value;
+              else if (k.number == 4 && k.wire == 2) { const size_t o = cb_floats.size(); cb_floats.resize(o + k.size / 4); memcpy(cb_floats.data() + o, k.data, k.size / 4 * 4); }
+              else if (k.number == 5 && k.wire == 2) { cb_has_tensor = true; if (!parse_tensor(k.data, k.size, &cb_tensor)) okp = false; }
+            }
+            if (!okp) oks = false;
+          } else if (h.wire == 2) {
+            IO_FAIL(LANCE_HIP_ENOTSUP, "index_file_open: %s: legacy index stage %u (OPQ transform / flat / DiskANN) is not supported", path.c_str(), h.number);
+          }
+        }
+        if (!oks) ok = false;
+      }
+    }
+    if (!ok) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: malformed legacy vector index", path.c_str());
+  }
+  if (!have_ivf || !have_pq) IO_FAIL(LANCE_HIP_ENOTSUP, "index_file_open: %s: only legacy IVF_PQ indices are supported", path.c_str());
+  if (metric != 0 && metric != 2) IO_FAIL(LANCE_HIP_ENOTSUP, "index_file_open: %s: legacy index with metric %llu (cosine / hamming) is not supported", path.c_str(), (unsigned long long)metric);
+  if (nbits != 8 || m == 0 || dim == 0 || dim > (1u << 20) || m > dim || pq_dim != dim || dim % m) IO_FAIL(LANCE_HIP_ENOTSUP, "index_file_open: %s: legacy PQ nbits=%llu m=%llu dim=%llu is not supported", path.c_str(), (unsigned long long)nbits, (unsigned long long)m, (unsigned long long)dim);
+  v.index_type = LANCE_HIP_IVF_PQ;
+  v.metric = metric == 0 ? LANCE_HIP_L2 : LANCE_HIP_DOT;
+  v.d = (uint32_t)dim; v.m = (uint32_t)m; v.nbits = 8; v.transposed = 0;
+  v.nlist = (uint32_t)ivf.lengths.size();
+  if (v.nlist == 0 || ivf.offsets.size() != v.nlist) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: legacy IVF without partitions / offsets", path.c_str());
+  std::string err;
+  if (ivf.has_tensor) {
+    if (ivf.centroids.shape.size() != 2 || ivf.centroids.shape[0] != v.nlist || ivf.centroids.shape[1] != v.d) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: centroid tensor shape mismatch", path.c_str());
+    if (!tensor_to_f32(ivf.centroids, (size_t)v.nlist * v.d, &f->centroids, &v.dtype, &err)) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: centroids: %s", err.c_str());
+  } else {
+    if (cent_floats.size() != (size_t)v.nlist * v.d) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: %zu centroid values for [%u][%u]", path.c_str(), cent_floats.size(), v.nlist, v.d);
+    f->centroids = std::move(cent_floats);
+    v.dtype = LANCE_HIP_F32;
+  }
+  int cb_dtype = LANCE_HIP_F32;
+  if (cb_has_tensor) {
+    if (cb_tensor.shape.size() != 2 || cb_tensor.shape[0] != 256 || cb_tensor.shape[1] != v.d) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: codebook tensor shape mismatch", path.c_str());
+    if (!tensor_to_f32(cb_tensor, (size_t)256 * v.d, &f->codebook, &cb_dtype, &err)) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: codebook: %s", err.c_str());
+  } else {
+    if (cb_floats.size() != (size_t)256 * v.d) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: %zu codebook values for [256][%u]", path.c_str(), cb_floats.size(), v.d);
+    f->codebook = std::move(cb_floats);
+  }
+  if (cb_dtype != v.dtype) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: codebook and centroids have different element types");
+  v.centroids = f->centroids.data();
+  v.codebook = f->codebook.data();
+  v.has_loss = ivf.has_loss; v.loss = ivf.loss;
+  // gather the per-partition [codes][row ids] blocks into the two arrays of the view
+  f->part_offsets.assign(v.nlist + 1, 0);
+  uint64_t total = 0;
+  for (uint32_t p = 0; p < v.nlist; ++p) {
+    if (ivf.lengths[p] >= (1ull << 32)) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: partition %u length is not a u32", p);
+    total += ivf.lengths[p];
+    if (total >= (1ull << 32)) IO_FAIL(LANCE_HIP_ENOTSUP, "index_file_open: more than 2^32 rows");
+    f->part_offsets[p + 1] = (uint32_t)total;
+  }
+  f->payload_buf.resize((size_t)total * v.m);
+  f->legacy_row_ids.resize((size_t)total);
+  for (uint32_t p = 0; p < v.nlist; ++p) {
+    const uint64_t n = ivf.lengths[p], off = ivf.offsets[p], need = n * (v.m + 8);
+    if (off > pos || need > pos - off) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: %s: partition %u lies outside the data section", path.c_str(), p);
+    memcpy(f->payload_buf.data() + (size_t)f->part_offsets[p] * v.m, b + off, (size_t)(n * v.m));
+    memcpy(f->legacy_row_ids.data() + f->part_offsets[p], b + off + n * v.m, (size_t)(n * 8));
+  }
+  v.part_offsets = f->part_offsets.data();
+  v.n_rows = total;
+  v.codes = f->payload_buf.data();
+  v.row_ids = f->legacy_row_ids.data();
+  return LANCE_HIP_OK;
+}
+
 static int open_impl(const std::string &dir, lance_hip_index_file *f) {
   std::string err;
+  {   // a directory whose index.idx carries the legacy footer (format 0.1 / 0.2) has no auxiliary.idx
+    const std::string ip = dir + "/index.idx";
+    FILE *fp = fopen(ip.c_str(), "rb");
+    if (fp) {
+      uint8_t foot[8] = {0};
+      const bool got = fseek(fp, -8, SEEK_END) == 0 && fread(foot, 1, 8, fp) == 8;
+      fclose(fp);
+      uint16_t major, minor;
+      memcpy(&major, foot, 2); memcpy(&minor, foot + 2, 2);
+      if (got && memcmp(foot + 4, "LANC", 4) == 0 && major == 0 && minor < 3) return open_legacy(ip, f);
+    }
+  }
   f->idx = FileReader::open(dir + "/index.idx", &err);
   if (!f->idx) IO_FAIL(LANCE_HIP_EIO, "index_file_open: %s", err.c_str());
   f->aux = FileReader::open(dir + "/auxiliary.idx", &err);
@@ -169,6 +313,7 @@ static int open_impl(const std::string &dir, lance_hip_index_file *f) {
   for (uint32_t p = 0; p < v.nlist; ++p) {
     // ivf/storage.rs:216-229: offsets absent -> prefix sums of lengths; present -> row offsets, which the writer makes the same
     if (!ivf_aux.offsets.empty() && (ivf_aux.offsets.size() != v.nlist || ivf_aux.offsets[p] != total)) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: partition %u offset is not the running row count", p);
+    if (ivf_aux.lengths[p] >= (1ull << 32)) IO_FAIL(LANCE_HIP_EINVAL, "index_file_open: partition %u length is not a u32", p);
     total += ivf_aux.lengths[p];
     if (total >= (1ull << 32)) IO_FAIL(LANCE_HIP_ENOTSUP, "index_file_open: more than 2^32 rows");
     f->part_offsets[p + 1] = (uint32_t)total;
@@ -299,7 +444,6 @@ extern "C" int lance_hip_index_file_write(const char *index_dir, const lance_hip
   if (pq) {
     LH_REQUIRE((v->nbits == 8 || v->nbits == 4) && v->m > 0 && v->d % v->m == 0 && !(v->nbits == 4 && v->m % 2), "index_file_write: bad PQ shape m=%u nbits=%u", v->m, v->nbits);
     LH_REQUIRE(v->codebook && (v->n_rows == 0 || v->codes), "index_file_write: codebook / codes missing");
-    LH_REQUIRE(v->transposed, "index_file_write: codes must be in the transposed per-partition layout (builder.rs:1039-1043 always writes transposed:true)");
     code_bytes = v->nbits == 4 ? v->m / 2 : v->m;
   } else {
     LH_REQUIRE(v->n_rows == 0 || v->vectors, "index_file_write: vectors missing");
@@ -340,7 +484,20 @@ extern "C" int lance_hip_index_file_write(const char *index_dir, const lance_hip
     }
     w->add_schema_metadata("storage_metadata", "[" + json_quote(meta) + "]");
     w->set_column(0, v->row_ids, v->n_rows, 64, 1);
-    if (pq) w->set_column(1, v->codes, v->n_rows, 8, code_bytes);
+    std::vector<uint8_t> tcodes;
+    const uint8_t *codes = v->codes;
+    if (pq && !v->transposed && v->n_rows) {   // builder.rs:1039-1043 always stores transposed:true (pq/storage.rs:430-449)
+      tcodes.resize((size_t)v->n_rows * code_bytes);
+      for (uint32_t p = 0; p < v->nlist; ++p) {
+        const size_t a = v->part_offsets[p], np_ = v->part_offsets[p + 1] - a;
+        const uint8_t *src = v->codes + a * code_bytes;
+        uint8_t *dst = tcodes.data() + a * code_bytes;
+        for (size_t r = 0; r < np_; ++r)
+          for (uint32_t c = 0; c < code_bytes; ++c) dst[(size_t)c * np_ + r] = src[r * code_bytes + c];
+      }
+      codes = tcodes.data();
+    }
+    if (pq) w->set_column(1, codes, v->n_rows, 8, code_bytes);
     else w->set_column(1, v->vectors, v->n_rows, v->dtype == LANCE_HIP_F16 ? 16 : 32, v->d);
     if (!w->finish(&err)) IO_FAIL(LANCE_HIP_EIO, "index_file_write: auxiliary.idx: %s", err.c_str());
   }

@@ -166,6 +166,44 @@ def test_oracle_reproduces_reference_ivf4_pq16_assignment_and_codes():
         assert np.array_equal(oidx.part_offsets, np.concatenate([[0], np.cumsum(np.bincount(z[f"part{k}"], minlength=4))]))
 
 
+def _as_dir(tmp_path, src, name):
+    d = tmp_path / name
+    d.mkdir()
+    shutil.copyfile(src, d / "index.idx")
+    return d
+
+
+def test_native_reader_opens_legacy_v1_indices(tmp_path):
+    """Index directories of Lance <= 0.21 hold one legacy-format index.idx (pb Index behind a 16-byte footer, per
+    partition [row-major codes][row ids]).  The native reader returns the same arrays as the independent Python
+    extraction behind the npz / the test-side parser, and `write` upgrades them to the current two-file layout."""
+    base = os.path.join(HERE, "golden", "ref_index")
+    z = np.load(os.path.join(base, "v0.8.14_ivf4_pq16.npz"))
+    for k, name in enumerate(("index_1000.idx", "index_2000.idx")):          # repeated-float codebook, 4 partitions
+        c = IF.read_index_files(_as_dir(tmp_path, os.path.join(base, "v0.8.14_legacy", name), f"a{k}"))
+        assert (c.index_type, c.metric, c.dtype, c.num_sub_vectors, c.nbits, c.transposed) == ("IVF_PQ", "l2", "float32", 16, 8, False)
+        assert np.array_equal(c.centroids, z[f"centroids{k}"]) and np.array_equal(c.codebook, z[f"codebook{k}"])
+        assert np.array_equal(c.codes_row_major(), z[f"codes{k}"]) and np.array_equal(c.part_ids(), z[f"part{k}"])
+    for name, n in (("index_256.idx", 256), ("index_delta32.idx", 32)):      # tensor codebook, 1 partition
+        src = os.path.join(base, "v0.21.0_legacy", name)
+        c = IF.read_index_files(_as_dir(tmp_path, src, name[:-4]))
+        cent, cb, lengths, raw = _legacy_index(src)
+        assert np.array_equal(c.centroids, cent) and np.array_equal(c.codebook, cb) and c.part_offsets.tolist() == [0, n]
+        assert c.codes.tobytes() == raw[:n] and c.row_ids.tobytes() == raw[n:9 * n]
+        IF.write_index_files(tmp_path / (name[:-4] + "_v3"), c)              # upgrade: transposed storage, two files
+        up = IF.read_index_files(tmp_path / (name[:-4] + "_v3"))
+        assert up.transposed and np.array_equal(up.codes_row_major(), c.codes_row_major()) and np.array_equal(up.row_ids, c.row_ids)
+        assert np.array_equal(up.codebook, c.codebook) and np.array_equal(up.centroids, c.centroids)
+    # truncations of a legacy file are errors, not crashes
+    raw = open(os.path.join(base, "v0.21.0_legacy", "index_256.idx"), "rb").read()
+    for cut in (2304 + 20, 2000, 30):
+        d = tmp_path / f"cut{cut}"
+        d.mkdir()
+        (d / "index.idx").write_bytes(raw[:cut] + raw[-16:])
+        with pytest.raises(_lib.LanceHipError):
+            IF.read_index_files(d)
+
+
 # ---- writing -----------------------------------------------------------------------------------------------------------
 def _same(a: IF.IndexFileContents, b: IF.IndexFileContents):
     assert (a.index_type, a.metric, a.dtype, a.num_sub_vectors, a.nbits, a.loss) == (b.index_type, b.metric, b.dtype, b.num_sub_vectors, b.nbits, b.loss)
@@ -339,15 +377,29 @@ def test_reader_survives_corrupted_metadata(tmp_path):
         else:
             assert rc in (_lib.EINVAL, _lib.EIO, _lib.ENOTSUP) and lib.lance_hip_last_error()
     assert sum(outcomes.values()) == 300 and len(outcomes) > 1
+    # the same for the legacy (v1) reader: flips inside the pb Index message and the footer
+    raw = bytearray(open(os.path.join(HERE, "golden", "ref_index", "v0.21.0_legacy", "index_256.idx"), "rb").read())
+    d2 = tmp_path / "fz_legacy"
+    d2.mkdir()
+    seen = set()
+    for _ in range(300):
+        b = bytearray(raw)
+        for pos in rng.integers(2304, len(b), rng.integers(1, 4)):
+            b[pos] = rng.integers(0, 256)
+        (d2 / "index.idx").write_bytes(bytes(b))
+        h = C.c_void_p()
+        rc = lib.lance_hip_index_file_open(os.fspath(d2).encode(), C.byref(h))
+        seen.add(rc)
+        if rc == 0:
+            lib.lance_hip_index_file_close(h)
+        else:
+            assert rc in (_lib.EINVAL, _lib.EIO, _lib.ENOTSUP)
+    assert 0 in seen and len(seen) > 1
 
 
 def test_write_validates_arguments(tmp_path):
     rng = np.random.default_rng(8)
     c, _ = _random_pq(rng, 50, 16, 3, 4, 8)
-    c.transposed = False
-    with pytest.raises(_lib.LanceHipError, match="transposed"):
-        IF.write_index_files(tmp_path / "x", c)
-    c.transposed = True
     c.part_offsets = c.part_offsets.copy()
     c.part_offsets[-1] -= 1
     with pytest.raises(_lib.LanceHipError, match="offsets"):
