@@ -844,3 +844,33 @@ def test_prefilter_matches_reference_branch(engine, oracle):
         fi, fd = lance_amd.flat_knn(x, q, 10, "l2", prefilter=allow)
         oi, od = oracle.flat_knn(x[keep], q, 10, "l2", row_ids=keep.astype(np.uint64))
         assert (_np(fi).view(np.uint64) == oi).all() and (_np(fd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_load_legacy_reference_index_c2_shape(eng, oracle, tmp_path):
+    """A legacy-format IVF_PQ index written by Lance 0.8.14 (2000 x 128, 4 partitions, 16 sub-vectors: the BASELINE C2
+    shape) goes file -> HBM (row-major codes, row addresses as ids) and is searched exactly as the oracle searches the
+    same stored model and codes."""
+    import os
+    import shutil
+    import lance_amd
+    from lance_amd import index_file as IF
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index")
+    d = tmp_path / "legacy"
+    d.mkdir()
+    shutil.copyfile(os.path.join(gold, "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
+    c = IF.read_index_files(d)
+    rm = c.codes_row_major()
+    codes_t = np.concatenate([rm[c.part_offsets[p]:c.part_offsets[p + 1]].T.reshape(-1) for p in range(4)])
+    oidx = oracle.IvfPqIndex("l2", c.centroids, c.codebook, c.part_offsets, codes_t, c.row_ids)
+    ix = lance_amd.load_index(d, engine=eng)
+    assert ix.info() == {"n": 2000, "nlist": 4, "m": 16, "d": 128}
+    offs, ct, rid = ix.export_storage()
+    assert (offs == c.part_offsets).all() and (ct == codes_t).all() and (rid == c.row_ids).all()
+    z = np.load(os.path.join(gold, "v0.8.14_ivf4_pq16.npz"))
+    rng = np.random.default_rng(17)
+    q = np.concatenate([z["x"][:50], z["x"][50:100] + rng.normal(0, 0.05, (50, 128)).astype(f32)]).astype(f32)
+    for k, nprobes in ((10, 4), (10, 1), (100, 2), (1, 4)):
+        gi, gd = ix.search_device(q, k, nprobes)
+        oi, od = oidx.search(q, k, nprobes)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
