@@ -299,6 +299,40 @@ def create_list_shard(engine, metric, centroids, codebook, part_ids, codes, raw=
     return ix, rows
 
 
+def shard_index_contents(c, world, rank):
+    """The part of an index file's contents (lance_amd.index_file.IndexFileContents) that rank `rank` of `world` owns
+    under the list -> rank (p % world) placement: same centroids / codebook, foreign lists emptied.
+    -> (part_offsets u32 [nlist+1], codes u8 (stored layout of the owned lists, concatenated), row_ids u64)"""
+    nlist = len(c.part_offsets) - 1
+    cb = c.code_bytes
+    lens = np.diff(c.part_offsets.astype(np.int64))
+    own = (np.arange(nlist) % world) == rank
+    offs = np.zeros(nlist + 1, np.uint32)
+    np.cumsum(np.where(own, lens, 0), out=offs[1:])
+    codes = [c.codes[int(c.part_offsets[p]) * cb:int(c.part_offsets[p + 1]) * cb] for p in range(nlist) if own[p]]
+    rids = [c.row_ids[int(c.part_offsets[p]):int(c.part_offsets[p + 1])] for p in range(nlist) if own[p]]
+    return (offs, np.concatenate(codes) if codes else np.empty(0, np.uint8),
+            np.concatenate(rids) if rids else np.empty(0, np.uint64))
+
+
+def load_list_shard(engine, index_dir, raw=None, dtype=None, group=None):
+    """Opens an IVF_PQ index directory (lance_amd/index_file.py) and puts THIS rank's lists into HBM: every rank parses
+    the (small) metadata and copies only its own code blocks.  Row ids are the stored ones, so `search_list_sharded`
+    needs no local->global map (pass the returned empty tensor as l2g).  raw: the column's vectors for refine, indexed
+    by row id (only meaningful when the ids are row offsets)."""
+    from . import index_file
+    from .engine import DeviceIndex
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    c = index_file.read_index_files(index_dir)
+    if c.index_type != "IVF_PQ":
+        raise ValueError(f"{index_dir}: list-sharded search is implemented for IVF_PQ, not {c.index_type}")
+    offs, codes, rid = shard_index_contents(c, world, rank)
+    model = np.float16 if c.dtype == "float16" else np.float32
+    ix = DeviceIndex.from_storage(engine, c.metric, c.centroids.astype(model), c.codebook.astype(model), offs, codes, rid,
+                                  transposed=c.transposed, raw=raw, dtype=dtype)
+    return ix, torch.empty(0, dtype=torch.int64)
+
+
 def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group=None):
     """local_search(q, kk, nprobes, refine_factor) -> (local ids int64 [-1 = none], dists) over this rank's lists.
     Every rank passes the SAME query batch and gets the same (ids [nq,k] int64 global, dists [nq,k])."""

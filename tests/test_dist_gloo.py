@@ -302,3 +302,80 @@ def test_create_index_sharded_is_independent_of_the_rank_count():
                 assert mode == "replicated"
                 assert (part == ref[metric][0]).all() and (codes == ref[metric][1]).all(), (world, rank, metric)
                 assert (its == ref[metric][3]).all()
+
+
+# ---- list-sharded search straight from index files (lance_amd/dist.py: load_list_shard) ------------------------------
+class _OracleStorageIndex:
+    """DeviceIndex.from_storage stand-in: the oracle over exactly the arrays the rank was handed."""
+
+    @classmethod
+    def from_storage(cls, engine, metric, centroids, codebook, part_offsets, codes, row_ids, transposed=True, raw=None, dtype=None):
+        import oracle
+        self = cls()
+        m = codebook.shape[0]
+        offs = np.asarray(part_offsets, np.uint32)
+        codes = np.asarray(codes, np.uint8)
+        if not transposed:
+            codes = np.concatenate([codes[int(offs[p]) * m:int(offs[p + 1]) * m].reshape(-1, m).T.reshape(-1)
+                                    for p in range(len(offs) - 1)]) if codes.size else codes
+        self.o = oracle.IvfPqIndex(metric, centroids, codebook, offs, codes, np.asarray(row_ids, np.uint64))
+        return self
+
+    def search(self, q, k, nprobes, refine_factor=0):
+        i, d = self.o.search(np.asarray(q, f32), k, nprobes)
+        return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d)
+
+
+def _file_shard_worker(rank, world, port, index_dir, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lance_amd.engine as E
+    E.DeviceIndex = _OracleStorageIndex
+    from lance_amd.dist import load_list_shard, search_list_sharded
+    ix, l2g = load_list_shard(None, index_dir)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_index", "v0.8.14_ivf4_pq16.npz"))
+    q = torch.from_numpy(np.ascontiguousarray(z["x"][:64]))
+    res = {"rows": int(ix.o.row_ids.size)}
+    for k, nprobes in ((10, 4), (10, 2), (50, 3)):
+        gi, gd = search_list_sharded(lambda qq, kk, npb, rf: ix.search(qq, kk, npb, rf), l2g, q, k, nprobes)
+        res[(k, nprobes)] = (gi.numpy(), gd.numpy())
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_list_sharded_search_from_reference_index_files(world, tmp_path):
+    """Each rank opens the index Lance 0.8.14 wrote (4 lists, legacy layout), keeps lists p % world == rank, and the
+    all-gather + (dist, rowid) merge returns what a search of the whole index returns -- ids are row addresses
+    (fragment << 32 | offset), not row numbers, so no local->global map is involved."""
+    import shutil
+    import oracle
+    from lance_amd import index_file as IF
+    d = tmp_path / "idx"
+    d.mkdir()
+    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "ref_index", "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_file_shard_worker, args=(r, world, port, str(d), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r[1]["rows"] for r in res) == 2000
+    c = IF.read_index_files(d)
+    rm = c.codes_row_major()
+    codes_t = np.concatenate([rm[c.part_offsets[p]:c.part_offsets[p + 1]].T.reshape(-1) for p in range(4)])
+    full = oracle.IvfPqIndex("l2", c.centroids, c.codebook, c.part_offsets, codes_t, c.row_ids)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_index", "v0.8.14_ivf4_pq16.npz"))
+    for key in ((10, 4), (10, 2), (50, 3)):
+        oi, od = full.search(z["x"][:64], key[0], key[1])
+        for r in res:
+            gi, gd = r[1][key]
+            assert (gi.astype(np.uint64) == oi).all(), (world, key, r[0])
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()

@@ -874,3 +874,41 @@ def test_load_legacy_reference_index_c2_shape(eng, oracle, tmp_path):
         oi, od = oidx.search(q, k, nprobes)
         assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes)
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_load_list_shard_world1(eng, oracle, tmp_path):
+    """lance_amd.dist.load_list_shard (index files -> this rank's lists in HBM) with world_size 1: the shard is the whole
+    index, so search_list_sharded must equal the search of lance_amd.load_index on the same directory.  The multi-rank
+    placement is covered on CPU (tests/test_dist_gloo.py::test_list_sharded_search_from_reference_index_files)."""
+    import os
+    import shutil
+    import torch
+    import torch.distributed as dist
+    import lance_amd
+    from lance_amd.dist import load_list_shard, search_list_sharded
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index")
+    d = tmp_path / "legacy"
+    d.mkdir()
+    shutil.copyfile(os.path.join(gold, "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29778")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        whole = lance_amd.load_index(d, engine=eng)
+        shard, l2g = load_list_shard(eng, d)
+        q = np.load(os.path.join(gold, "v0.8.14_ivf4_pq16.npz"))["x"][:80]
+
+        def local_search(qq, kk, nprobes, rf):
+            i, dd = shard.search(qq, kk, nprobes, rf)
+            return i.cpu(), dd.cpu()
+
+        for k, nprobes in ((10, 4), (10, 2), (50, 1)):
+            gi, gd = search_list_sharded(local_search, l2g, torch.from_numpy(q), k, nprobes)
+            ri, rd = whole.search_device(q, k, nprobes)
+            assert (gi == ri.cpu()).all(), (k, nprobes)
+            assert (gd.numpy().view(np.uint32) == rd.cpu().numpy().view(np.uint32)).all()
+    finally:
+        if created:
+            dist.destroy_process_group()
