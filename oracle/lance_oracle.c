@@ -18,7 +18,7 @@
  * simd/dist_table.rs:178-217) and checks orc_sum_4bit_dist_table against the reference's own C kernel
  * (rust/lance-linalg/src/simd/dist_table.c compiled from where it lies into oracle/_ref/ by oracle/Makefile).
  *
- * Pinned on outputs of the reference itself (tests/test_index_files.py, fixtures under tests/golden/ref_index copied
+ * Pinned on outputs of the reference itself (tests/test_index_files.py, fixtures in tests/golden/ref_index.npz archived
  * from the reference's test_data/ by tests/golden/make_ref_index_fixtures.py -- index directories written by Lance
  * 0.21.0 / 0.27.1 together with the data they were built from): orc residual + PQ encode reproduce the stored PQ
  * codes byte for byte, the f64 sum of orc assign distances equals the recorded k-means loss to the bit, and orc k-means

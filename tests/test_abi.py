@@ -82,7 +82,8 @@ def test_header_is_plain_c_and_usable_from_c(tmp_path):
            "-L", libdir, "-llance_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    ref = os.path.join(ROOT, "tests", "golden", "ref_index", "v0.27.1_pq_in_schema")
+    from ref_fixtures import ref_index_dir
+    ref = os.path.join(ref_index_dir(), "v0.27.1_pq_in_schema")
     r = subprocess.run([exe, ref, str(tmp_path / "out"), os.path.join(ref, "data.lance")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "d=32 nlist=1 m=4 nbits=8 rows=512" in r.stdout and "loss=1394.7242410182953" in r.stdout

@@ -335,7 +335,9 @@ def _file_shard_worker(rank, world, port, index_dir, out):
     E.DeviceIndex = _OracleStorageIndex
     from lance_amd.dist import load_list_shard, search_list_sharded
     ix, l2g = load_list_shard(None, index_dir)
-    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_index", "v0.8.14_ivf4_pq16.npz"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ref_fixtures import ref_index_dir
+    z = np.load(os.path.join(ref_index_dir(), "v0.8.14_ivf4_pq16.npz"))
     q = torch.from_numpy(np.ascontiguousarray(z["x"][:64]))
     res = {"rows": int(ix.o.row_ids.size)}
     for k, nprobes in ((10, 4), (10, 2), (50, 3)):
@@ -356,7 +358,8 @@ def test_list_sharded_search_from_reference_index_files(world, tmp_path):
     from lance_amd import index_file as IF
     d = tmp_path / "idx"
     d.mkdir()
-    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "ref_index", "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
+    from ref_fixtures import ref_index_dir
+    shutil.copyfile(os.path.join(ref_index_dir(), "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 33500 + (os.getpid() % 2000) + world
@@ -372,7 +375,7 @@ def test_list_sharded_search_from_reference_index_files(world, tmp_path):
     rm = c.codes_row_major()
     codes_t = np.concatenate([rm[c.part_offsets[p]:c.part_offsets[p + 1]].T.reshape(-1) for p in range(4)])
     full = oracle.IvfPqIndex("l2", c.centroids, c.codebook, c.part_offsets, codes_t, c.row_ids)
-    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_index", "v0.8.14_ivf4_pq16.npz"))
+    z = np.load(os.path.join(ref_index_dir(), "v0.8.14_ivf4_pq16.npz"))
     for key in ((10, 4), (10, 2), (50, 3)):
         oi, od = full.search(z["x"][:64], key[0], key[1])
         for r in res:

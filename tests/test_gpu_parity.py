@@ -702,13 +702,14 @@ def test_many_partitions_nlist_20000(eng, oracle):
 
 # ---- index files <-> HBM -------------------------------------------------------------------
 def test_load_reference_written_index_and_search(eng, oracle):
-    """An index directory written by real Lance (tests/golden/ref_index, 512 x 32, IVF1,PQ4) goes files -> HBM through
+    """An index directory written by real Lance (tests/golden/ref_index.npz, 512 x 32, IVF1,PQ4) goes files -> HBM through
     lance_hip_index_load and answers queries exactly as the oracle does on the same stored model (the oracle's encode of
     the fixture's raw vectors equals the stored codes: tests/test_index_files.py)."""
     import os
     import lance_amd
     from lance_amd import index_file as IF
-    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index", "v0.27.1_pq_in_schema")
+    from ref_fixtures import ref_index_dir
+    ref = os.path.join(ref_index_dir(), "v0.27.1_pq_in_schema")
     c = IF.read_index_files(ref)
     x = IF.read_column(os.path.join(ref, "data.lance"), "vec", np.float32, 32)
     ix = lance_amd.load_index(ref, raw=x, engine=eng)
@@ -787,13 +788,14 @@ def test_ivf_flat_save_load_roundtrip(eng, oracle, tmp_path):
 
 def test_gpu_reproduces_what_the_reference_stored(eng, oracle):
     """The HIP path against the reference's OWN outputs (no oracle in between): index files written by Lance 0.27.1 /
-    0.21.0 (tests/golden/ref_index; see tests/test_index_files.py for how they are parsed and pinned on the CPU side).
+    0.21.0 (tests/golden/ref_index.npz; see tests/test_index_files.py for how they are parsed and pinned on the CPU side).
     encode: assign + residual + PQ codes == the stored `__pq_code` bytes; loss == the recorded k-means loss (f64, to the
     bit); k-means over the 256 rows the reference trained on == its stored IVF centroid, bit for bit."""
     import os
     from lance_amd import index_file as IF
     from test_index_files import _legacy_index
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index")
+    from ref_fixtures import ref_index_dir
+    gold = ref_index_dir()
     c = IF.read_index_files(os.path.join(gold, "v0.27.1_pq_in_schema"))
     x = IF.read_column(os.path.join(gold, "v0.27.1_pq_in_schema", "data.lance"), "vec", np.float32, 32)
     x = x[c.row_ids.astype(np.int64)]
@@ -854,7 +856,8 @@ def test_load_legacy_reference_index_c2_shape(eng, oracle, tmp_path):
     import shutil
     import lance_amd
     from lance_amd import index_file as IF
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index")
+    from ref_fixtures import ref_index_dir
+    gold = ref_index_dir()
     d = tmp_path / "legacy"
     d.mkdir()
     shutil.copyfile(os.path.join(gold, "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
@@ -886,7 +889,8 @@ def test_load_list_shard_world1(eng, oracle, tmp_path):
     import torch.distributed as dist
     import lance_amd
     from lance_amd.dist import load_list_shard, search_list_sharded
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_index")
+    from ref_fixtures import ref_index_dir
+    gold = ref_index_dir()
     d = tmp_path / "legacy"
     d.mkdir()
     shutil.copyfile(os.path.join(gold, "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")

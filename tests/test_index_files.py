@@ -1,5 +1,5 @@
 """Index files: the native reader/writer of `index.idx` + `auxiliary.idx` against index
-files written by real Lance releases (tests/golden/ref_index, copied from the reference's own backward-compatibility
+files written by real Lance releases (tests/golden/ref_index.npz, archived from the reference's own backward-compatibility
 fixtures by tests/golden/make_ref_index_fixtures.py), and -- the strongest parity pin in this repo -- the oracle's
 assign / residual / PQ-encode / loss arithmetic against what the reference itself stored in those files.
 
@@ -17,10 +17,11 @@ import oracle
 from lance_amd import _lib
 from lance_amd import index_file as IF
 from lance_file_probe import Probe, fields
+from ref_fixtures import ref_index_dir
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF27 = os.path.join(HERE, "golden", "ref_index", "v0.27.1_pq_in_schema")
-REF29 = os.path.join(HERE, "golden", "ref_index", "v0.29.0_index")
+REF27 = os.path.join(ref_index_dir(), "v0.27.1_pq_in_schema")
+REF29 = os.path.join(ref_index_dir(), "v0.29.0_index")
 
 
 # ---- reading what the reference wrote --------------------------------------------------------------------------------
@@ -123,11 +124,11 @@ def _legacy_index(path):
 
 
 def test_oracle_kmeans_reproduces_reference_trained_centroid():
-    """tests/golden/ref_index/v0.21.0_legacy: Lance 0.21.0 built IVF1/PQ1 over 256 x 16 random vectors, so the IVF
+    """v0.21.0_legacy (in tests/golden/ref_index.npz): Lance 0.21.0 built IVF1/PQ1 over 256 x 16 random vectors, so the IVF
     k-means trained on ALL rows (256 <= sample_rate * 1) and its one centroid is the M-step mean of every row -- free of
     the unseeded initialisation.  The oracle's k-means (f32 running sum per cluster in row order, then the division:
     kmeans.rs:371-446) lands on the stored centroid bit for bit; a float64 mean does not."""
-    base = os.path.join(HERE, "golden", "ref_index", "v0.21.0_legacy")
+    base = os.path.join(ref_index_dir(), "v0.21.0_legacy")
     cent, cb, lengths, raw = _legacy_index(os.path.join(base, "index_256.idx"))
     x = IF.read_column(os.path.join(base, "data_256.lance"), "vector", np.float32, 16)
     assert lengths == [256] and cent.shape == (1, 16) and x.shape == (256, 16)
@@ -147,12 +148,12 @@ def test_oracle_kmeans_reproduces_reference_trained_centroid():
 
 
 def test_oracle_reproduces_reference_ivf4_pq16_assignment_and_codes():
-    """tests/golden/ref_index/v0.8.14_ivf4_pq16.npz: two IVF_PQ indices Lance 0.8.14 built over 1000 / 2000 rows of
+    """v0.8.14_ivf4_pq16.npz (in tests/golden/ref_index.npz): two IVF_PQ indices Lance 0.8.14 built over 1000 / 2000 rows of
     128-d vectors with 4 partitions and 16 sub-vectors (the SIFT / BASELINE C2 shape: sub-dimension 8).  With the
     reference's own centroids and codebook the oracle must put every row in the partition the reference stored it
     under (argmin over several centroids, kmeans.rs:1350-1369) and produce its 16 code bytes (pq.rs:116-191) --
     3000 rows, 48,000 bytes, all equal; encoding WITHOUT the residual step reproduces only ~90%, so the check bites."""
-    z = np.load(os.path.join(HERE, "golden", "ref_index", "v0.8.14_ivf4_pq16.npz"))
+    z = np.load(os.path.join(ref_index_dir(), "v0.8.14_ivf4_pq16.npz"))
     for k in (0, 1):
         x = z["x"][z[f"rows{k}"]]
         cent, cb = z[f"centroids{k}"], z[f"codebook{k}"]
@@ -177,7 +178,7 @@ def test_native_reader_opens_legacy_v1_indices(tmp_path):
     """Index directories of Lance <= 0.21 hold one legacy-format index.idx (pb Index behind a 16-byte footer, per
     partition [row-major codes][row ids]).  The native reader returns the same arrays as the independent Python
     extraction behind the npz / the test-side parser, and `write` upgrades them to the current two-file layout."""
-    base = os.path.join(HERE, "golden", "ref_index")
+    base = ref_index_dir()
     z = np.load(os.path.join(base, "v0.8.14_ivf4_pq16.npz"))
     for k, name in enumerate(("index_1000.idx", "index_2000.idx")):          # repeated-float codebook, 4 partitions
         c = IF.read_index_files(_as_dir(tmp_path, os.path.join(base, "v0.8.14_legacy", name), f"a{k}"))
@@ -378,7 +379,7 @@ def test_reader_survives_corrupted_metadata(tmp_path):
             assert rc in (_lib.EINVAL, _lib.EIO, _lib.ENOTSUP) and lib.lance_hip_last_error()
     assert sum(outcomes.values()) == 300 and len(outcomes) > 1
     # the same for the legacy (v1) reader: flips inside the pb Index message and the footer
-    raw = bytearray(open(os.path.join(HERE, "golden", "ref_index", "v0.21.0_legacy", "index_256.idx"), "rb").read())
+    raw = bytearray(open(os.path.join(ref_index_dir(), "v0.21.0_legacy", "index_256.idx"), "rb").read())
     d2 = tmp_path / "fz_legacy"
     d2.mkdir()
     seen = set()
