@@ -328,17 +328,48 @@ def train_pq_codebook(x, centroids, params: IvfPqParams, engine=None):
 def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_sub_vectors=16, num_bits=8, max_iters=50,
                  sample_rate=256, ivf_centroids=None, pq_codebook=None, seed=42, keep_raw=True, engine=None):
     """Dataset.create_index(column, "IVF_PQ", ...) for a vector matrix resident (or copied) in HBM."""
+    # ---- argument rules of Dataset.create_index (python/python/lance/dataset.py:2708-2960), checked before any device work
+    if not isinstance(metric, str):
+        raise ValueError(f"Metric {metric} not supported.")
+    metric_n = _normalize_metric_type(metric)
     itype = str(index_type).upper()
     if itype not in ("IVF_PQ", "IVF_FLAT"):
         raise NotImplementedError(f"index_type {index_type}: IVF_PQ and IVF_FLAT are on this engine's hot path")
+    if isinstance(num_partitions, float):
+        import warnings
+        warnings.warn("num_partitions is float, converting to int")
+        num_partitions = int(num_partitions)
+    elif num_partitions is not None and not isinstance(num_partitions, (int, np.integer)):
+        raise TypeError(f"num_partitions must be int, got {type(num_partitions)}")
+    shape = tuple(x.shape)
+    if len(shape) != 2:
+        raise TypeError(f"Vector column must be a 2-D (rows, dimension) array, got shape {shape}")
+    d = shape[1]
+    if "PQ" in itype:
+        if num_sub_vectors is None or num_partitions is None:
+            raise ValueError("num_partitions and num_sub_vectors are required for IVF_PQ")
+        if d % num_sub_vectors != 0:
+            raise ValueError(f"dimension ({d}) must be divisible by num_sub_vectors ({num_sub_vectors})")
+    if ivf_centroids is None and pq_codebook is not None:
+        raise ValueError("ivf_centroids must be specified when pq_codebook is provided")
+    if ivf_centroids is not None:
+        ivf_centroids = np.asarray(ivf_centroids)
+        if ivf_centroids.ndim != 2 or ivf_centroids.shape[0] != num_partitions:
+            raise ValueError(f"Ivf centroids must be 2D array: (clusters, dim), got {ivf_centroids.shape}")
+        if ivf_centroids.dtype not in (np.float16, np.float32, np.float64):
+            raise TypeError("IVF centroids must be floating number" + f"got {ivf_centroids.dtype}")
+    if pq_codebook is not None:
+        pq_codebook = np.asarray(pq_codebook)
+        if pq_codebook.ndim != 3 or pq_codebook.shape[0] != num_sub_vectors or pq_codebook.shape[1] != (1 << num_bits):
+            raise ValueError(f"PQ codebook must be 3D array: (sub_vectors, {1 << num_bits}, dim), got {pq_codebook.shape}")
+        if pq_codebook.dtype not in (np.float16, np.float32, np.float64):
+            raise TypeError("PQ codebook must be floating number" + f"got {pq_codebook.dtype}")
     eng = engine or default_engine()
-    params = IvfPqParams(num_partitions, num_sub_vectors, num_bits, _normalize_metric_type(metric), max_iters, sample_rate, seed)
+    params = IvfPqParams(num_partitions, num_sub_vectors, num_bits, metric_n, max_iters, sample_rate, seed)
     x = to_device(x)
     n, d = x.shape
     if x.dtype == torch.int8 and params.metric == "cosine":
         raise NotImplementedError("int8 vectors with the cosine metric are not supported by this engine (use l2 or dot)")
-    if d % num_sub_vectors != 0:
-        raise ValueError(f"num_sub_vectors must divide vector dimension {d}, but got {num_sub_vectors}")
     stats = BuildStats()
 
     def timed(name, fn):

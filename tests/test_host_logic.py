@@ -243,3 +243,40 @@ def test_prefilter_compaction_equals_reference_prefilter_branch(oracle, monkeypa
     assert (got_i.view(np.uint64)[got_i != -1] < 100).all()
     with pytest.raises(NotImplementedError):
         V.IvfPqIndex(base, V.IvfPqParams(nlist, m, 4, metric), None).prefiltered(np.ones(n, bool))
+
+
+def test_create_index_argument_rules_mirror_pylance():
+    """The checks Dataset.create_index makes before building (python/python/lance/dataset.py:2708-2960), same exception
+    types and wording; they run before any device work, so they hold without a GPU."""
+    import warnings
+    import lance_amd
+    x = np.zeros((100, 32), f32)
+    with pytest.raises(ValueError, match="Metric manhattan not supported."):
+        lance_amd.create_index(x, "IVF_PQ", metric="manhattan")
+    with pytest.raises(ValueError, match="not supported"):
+        lance_amd.create_index(x, "IVF_PQ", metric=3)
+    with pytest.raises(NotImplementedError):
+        lance_amd.create_index(x, "IVF_HNSW_SQ")
+    with pytest.raises(ValueError, match=r"dimension \(32\) must be divisible by num_sub_vectors \(5\)"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions=4, num_sub_vectors=5)
+    with pytest.raises(ValueError, match="num_partitions and num_sub_vectors are required for IVF_PQ"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions=4, num_sub_vectors=None)
+    with pytest.raises(TypeError, match="num_partitions must be int"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions="4", num_sub_vectors=4)
+    with pytest.raises(ValueError, match="ivf_centroids must be specified when pq_codebook is provided"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions=4, num_sub_vectors=4, pq_codebook=np.zeros((4, 256, 8), f32))
+    with pytest.raises(ValueError, match="Ivf centroids must be 2D array"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions=4, num_sub_vectors=4, ivf_centroids=np.zeros((3, 32), f32))
+    with pytest.raises(TypeError, match="IVF centroids must be floating number"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions=4, num_sub_vectors=4, ivf_centroids=np.zeros((4, 32), np.int32))
+    with pytest.raises(ValueError, match="PQ codebook must be 3D array"):
+        lance_amd.create_index(x, "IVF_PQ", num_partitions=4, num_sub_vectors=4, ivf_centroids=np.zeros((4, 32), f32),
+                               pq_codebook=np.zeros((4, 128, 8), f32))
+    with pytest.raises(TypeError, match="2-D"):
+        lance_amd.create_index(np.zeros(32, f32), "IVF_PQ", num_partitions=4, num_sub_vectors=4)
+    if not torch.cuda.is_available():                       # valid arguments get as far as the device and stop there
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with pytest.raises(RuntimeError, match="MI355X"):
+                lance_amd.create_index(x, "IVF_PQ", num_partitions=4.0, num_sub_vectors=4)
+        assert any("num_partitions is float" in str(i.message) for i in w)
