@@ -352,14 +352,15 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
             raise ValueError(f"dimension ({d}) must be divisible by num_sub_vectors ({num_sub_vectors})")
     if ivf_centroids is None and pq_codebook is not None:
         raise ValueError("ivf_centroids must be specified when pq_codebook is provided")
+    as_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     if ivf_centroids is not None:
-        ivf_centroids = np.asarray(ivf_centroids)
+        ivf_centroids = as_np(ivf_centroids)
         if ivf_centroids.ndim != 2 or ivf_centroids.shape[0] != num_partitions:
             raise ValueError(f"Ivf centroids must be 2D array: (clusters, dim), got {ivf_centroids.shape}")
         if ivf_centroids.dtype not in (np.float16, np.float32, np.float64):
             raise TypeError("IVF centroids must be floating number" + f"got {ivf_centroids.dtype}")
     if pq_codebook is not None:
-        pq_codebook = np.asarray(pq_codebook)
+        pq_codebook = as_np(pq_codebook)
         if pq_codebook.ndim != 3 or pq_codebook.shape[0] != num_sub_vectors or pq_codebook.shape[1] != (1 << num_bits):
             raise ValueError(f"PQ codebook must be 3D array: (sub_vectors, {1 << num_bits}, dim), got {pq_codebook.shape}")
         if pq_codebook.dtype not in (np.float16, np.float32, np.float64):
