@@ -321,6 +321,20 @@ def test_ivf_flat_roundtrip(tmp_path, dtype):
     assert json.loads(Probe(tmp_path / "f" / "index.idx").metadata["lance:index"]) == {"type": "IVF_FLAT", "distance_type": "l2"}
 
 
+@pytest.mark.parametrize("dtype,code,width", [("float16", 1, 2), ("float32", 2, 4)])
+def test_fsl_to_tensor_like_reference(tmp_path, dtype, code, width):
+    """lance-index/src/vector/utils.rs:298-320 `test_fsl_to_tensor`: a 4 x 5 zero matrix becomes pb Tensor{data_type,
+    shape [4, 5], data 20 * width bytes} -- here through the writer's centroid tensor (f64 tensors are not written:
+    the engine's models are f32 / f16)."""
+    c = IF.IndexFileContents(index_type="IVF_FLAT", metric="l2", dtype=dtype, centroids=np.zeros((4, 5), np.float32),
+                             part_offsets=np.zeros(5, np.uint32), row_ids=np.empty(0, np.uint64), vectors=np.empty((0, 5), dtype))
+    IF.write_index_files(tmp_path / "t", c)
+    ivf = {fn: v for fn, _, v in fields(Probe(tmp_path / "t" / "index.idx").global_buffer(1))}
+    tensor = {fn: v for fn, _, v in fields(ivf[4])}
+    from lance_file_probe import packed
+    assert tensor[1] == code and packed(tensor[2]) == [4, 5] and len(tensor[3]) == 20 * width
+
+
 # ---- refusing what is not understood ---------------------------------------------------------------------------------
 def _open_err(path):
     with pytest.raises(_lib.LanceHipError) as e:
