@@ -10,7 +10,7 @@ from . import _lib
 from ._lib import LanceHipError
 
 __all__ = ["_lib", "LanceHipError", "Engine", "DeviceIndex", "KMeans", "IvfPqParams", "IvfPqIndex", "create_index",
-           "flat_knn", "train_ivf_centroids", "train_pq_codebook", "default_engine", "load_index", "IndicesBuilder", "IvfModel", "PqModel"]
+           "flat_knn", "train_ivf_centroids", "train_pq_codebook", "default_engine", "load_index", "validate_vector_index", "IndicesBuilder", "IvfModel", "PqModel"]
 
 
 def __getattr__(name):
@@ -19,7 +19,7 @@ def __getattr__(name):
         from . import engine
         return getattr(engine, name)
     if name in ("KMeans", "IvfPqParams", "IvfPqIndex", "create_index", "flat_knn", "train_ivf_centroids",
-                "train_pq_codebook", "default_engine", "load_index"):
+                "train_pq_codebook", "default_engine", "load_index", "validate_vector_index"):
         from . import vector
         return getattr(vector, name)
     if name in ("IndicesBuilder", "IvfModel", "PqModel"):

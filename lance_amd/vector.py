@@ -408,6 +408,24 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
     return IvfPqIndex(ix, params, stats, part, codes)
 
 
+def validate_vector_index(index, vectors, refine_factor=5, sample_size=None, pass_threshold=1.0, seed=0):
+    """lance.util.validate_vector_index (python/python/lance/util.py:171-220): in-sample queries with k=1, nprobes=1 and
+    a refine factor must come back at distance ~0 (|d| < 1e-6) for at least `pass_threshold` of the non-NaN vectors,
+    else ValueError with the reference's message.  One batched device search instead of one query per row."""
+    vecs = np.asarray(vectors.detach().cpu().numpy() if isinstance(vectors, torch.Tensor) else vectors)
+    if sample_size is not None and sample_size < len(vecs):
+        vecs = vecs[np.sort(np.random.default_rng(seed).choice(len(vecs), size=sample_size, replace=False))]
+    ok = ~np.isnan(vecs.astype(np.float32)).any(axis=1)
+    total = int(ok.sum())
+    passes = 0
+    if total:
+        _, dist = index.nearest(vecs[ok], k=1, nprobes=1, refine_factor=refine_factor)
+        passes = int((np.abs(dist[:, 0]) < 1e-6).sum())
+    if total and passes / total < pass_threshold:
+        raise ValueError(f"Vector index failed sanity check, only {passes}/{total} passed")
+    return passes, total
+
+
 def flat_knn(x, q, k=10, metric="l2", engine=None, prefilter=None):
     """Exhaustive KNN (`use_index=False`): (row ids, distances) sorted by (distance, row id).
     prefilter: boolean array over rows; the scan then covers the selected rows only, as the reference's filtered

@@ -280,3 +280,29 @@ def test_create_index_argument_rules_mirror_pylance():
             with pytest.raises(RuntimeError, match="MI355X"):
                 lance_amd.create_index(x, "IVF_PQ", num_partitions=4.0, num_sub_vectors=4)
         assert any("num_partitions is float" in str(i.message) for i in w)
+
+
+def test_validate_vector_index_mirrors_lance_util():
+    """python/python/lance/util.py:171-220: k=1 / nprobes=1 / refine in-sample queries, NaN rows skipped, ValueError with
+    the reference's message below the threshold (index stubbed: the rule is host logic)."""
+    import lance_amd
+
+    class Stub:
+        def __init__(self, bad):
+            self.bad, self.calls = bad, []
+
+        def nearest(self, q, k=10, nprobes=1, refine_factor=None):
+            self.calls.append((len(q), k, nprobes, refine_factor))
+            d = np.zeros((len(q), 1), f32)
+            d[: self.bad, 0] = 0.5
+            return np.zeros((len(q), 1), np.int64), d
+
+    x = np.ones((50, 8), f32)
+    x[3, 2] = np.nan
+    s = Stub(0)
+    assert lance_amd.validate_vector_index(s, x) == (49, 49) and s.calls == [(49, 1, 1, 5)]
+    with pytest.raises(ValueError, match="Vector index failed sanity check, only 44/49 passed"):
+        lance_amd.validate_vector_index(Stub(5), x)
+    assert lance_amd.validate_vector_index(Stub(5), x, pass_threshold=0.8) == (44, 49)
+    s = Stub(0)
+    assert lance_amd.validate_vector_index(s, x, sample_size=10, refine_factor=2)[1] in (9, 10) and s.calls[0][3] == 2
