@@ -96,6 +96,55 @@ def test_hip_assign_equals_reference_torch_kernels(eng, ref):
     np.testing.assert_allclose(dists.cpu().numpy(), ref["f_l2_min"], rtol=1e-4)
 
 
+def _check_accelerator_module(acc, engine, ref):
+    """lance_amd.accelerator (the lance.torch.distance / lance.torch.kmeans names) against the outputs of the reference's
+    own module stored in ref_torch_assign.npz: same ids (int64), same distances, same NaN convention, same messages."""
+    import torch
+    idx, d = acc.l2_distance(torch.from_numpy(ref["int_x"]), torch.from_numpy(ref["int_c"]), engine=engine)
+    assert idx.dtype == torch.int64 and d.dtype == torch.float32 and idx.shape == (599,)
+    assert (idx.cpu().numpy() == ref["int_l2_ids"].astype(np.int64)).all() and (_bits(d.cpu().numpy()) == _bits(ref["int_l2_min"])).all()
+    idx, d = acc.dot_distance(torch.from_numpy(ref["int_dot_x"]), torch.from_numpy(ref["int_c"]), engine=engine)
+    assert (idx.cpu().numpy() == ref["int_dot_ids"].astype(np.int64)).all() and (_bits(d.cpu().numpy()) == _bits(ref["int_dot_min"])).all()
+    x = ref["int_x"][:8].copy()
+    x[2, 5] = np.nan                                              # distance.py:199,265: NaN distance -> id -1
+    idx, d = acc.l2_distance(torch.from_numpy(x), torch.from_numpy(ref["int_c"]), engine=engine)
+    assert idx[2].item() == -1 and np.isnan(d.cpu().numpy()[2]) and (idx.cpu().numpy()[[0, 1, 3]] == ref["int_l2_ids"][[0, 1, 3]]).all()
+    with pytest.raises(ValueError, match="x and y must be 2-D matrix"):
+        acc.l2_distance(torch.zeros(4), torch.zeros(2, 4), engine=engine)
+    ci, cd = acc.cosine_distance(torch.from_numpy(ref["f_x"]), torch.from_numpy(ref["f_c"]), engine=engine)
+    xn = ref["f_x"] / np.linalg.norm(ref["f_x"], axis=1, keepdims=True)
+    cn = ref["f_c"] / np.linalg.norm(ref["f_c"], axis=1, keepdims=True)
+    want = 1.0 - xn @ cn.T
+    assert np.allclose(cd.cpu().numpy(), want.min(1), atol=1e-5) and (ci.cpu().numpy() == want.argmin(1)).mean() > 0.99
+    km = acc.KMeans(8, metric="l2", max_iters=10, seed=3, engine=engine)
+    km.fit(ref["f_x"])
+    assert tuple(km.centroids.shape) == (8, 40) and km.total_distance > 0
+    part = km.transform(ref["f_x"])
+    assert part.dtype == torch.int64 and (part.cpu().numpy() == acc.l2_distance(torch.from_numpy(ref["f_x"]), km.centroids, engine=engine)[0].cpu().numpy()).all()
+    km2 = acc.KMeans(8, metric="cosine", max_iters=5, seed=3, engine=engine)
+    km2.fit(iter([{"v": torch.from_numpy(ref["f_x"][:256])}, {"v": torch.from_numpy(ref["f_x"][256:])}]), column="v")
+    nrm = np.linalg.norm(km2.centroids.cpu().numpy(), axis=1)       # means of unit vectors: inside the unit ball
+    assert tuple(km2.centroids.shape) == (8, 40) and np.isfinite(nrm).all() and (nrm <= 1.0 + 1e-5).all() and (nrm > 0).all()
+    with pytest.raises(ValueError, match="Only random initialization"):
+        acc.KMeans(4, init="kmeans++")
+    with pytest.raises(ValueError, match="not supported"):
+        acc.KMeans(4, metric="hamming")
+
+
+def test_accelerator_module_on_oracle_backed_engine(ref):
+    """CPU: the wrapper logic (dtypes, NaN convention, cosine route, KMeans plumbing) with the device steps computed by
+    the oracle stand-in used by the multi-rank build tests."""
+    from lance_amd import accelerator
+    from test_dist_gloo import OracleBuildEngine
+    _check_accelerator_module(accelerator, OracleBuildEngine(), ref)
+
+
+@pytest.mark.gpu
+def test_accelerator_module_on_device(eng, ref):
+    from lance_amd import accelerator
+    _check_accelerator_module(accelerator, eng, ref)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 def test_hip_reproduces_frozen_e2e(eng, e2e, metric):
