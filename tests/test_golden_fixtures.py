@@ -140,12 +140,6 @@ def test_accelerator_module_on_oracle_backed_engine(ref):
 
 
 @pytest.mark.gpu
-def test_accelerator_module_on_device(eng, ref):
-    from lance_amd import accelerator
-    _check_accelerator_module(accelerator, eng, ref)
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 def test_hip_reproduces_frozen_e2e(eng, e2e, metric):
     from lance_amd.engine import DeviceIndex
