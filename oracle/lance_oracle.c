@@ -16,7 +16,8 @@
  * known-answer tests (l2.rs:281-375,432-447; dot.rs; kernels.rs:278-300;
  * kmeans.rs:1398-1486; pq.rs:580-665; pq/distance.rs:337-364; pq/utils.rs:84-99;
  * simd/dist_table.rs:178-217) and checks orc_sum_4bit_dist_table against the reference's own C kernel
- * (rust/lance-linalg/src/simd/dist_table.c compiled from where it lies into oracle/_ref/ by oracle/Makefile).
+ * (rust/lance-linalg/src/simd/dist_table.c compiled from where it lies into oracle/_ref/ by oracle/Makefile), and the
+ * f16 distances against simd/f16.c built the same way (bit-equal where f32 arithmetic is exact: the C file is -ffast-math).
  *
  * Pinned on outputs of the reference itself (tests/test_index_files.py, fixtures in tests/golden/ref_index.npz archived
  * from the reference's test_data/ by tests/golden/make_ref_index_fixtures.py -- index directories written by Lance

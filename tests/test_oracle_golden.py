@@ -618,3 +618,36 @@ def test_prefilter_equals_compaction(metric):
         same_compact = np.array_equal(fi, ci) and np.array_equal(fd.view(np.uint32), cd.view(np.uint32))
         same_alltrue = np.array_equal(ai, ui) and np.array_equal(ad.view(np.uint32), ud.view(np.uint32))
         assert (same_compact, same_alltrue) == ((True, True) if nbits == 8 else (False, False))
+
+
+def test_f16_kernels_against_reference_c(oracle):
+    """rust/lance-linalg/src/simd/f16.c (the reference's own f16 kernels, compiled from where they lie into oracle/_ref
+    with build.rs's AVX2 flags): on integer-valued f16 vectors every product and partial sum is exact in f32, so the
+    -ffast-math reordering cannot matter and the oracle's l2 / dot / norm must equal the C kernels bit for bit; on real
+    values they agree to the reorder error (the oracle follows the Rust fallback l2_scalar<f16,f32,16>, l2.rs:128-159)."""
+    import ctypes as C
+    import os
+    so = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libref_f16.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_f16.so not built (reference tree or ROCm clang absent)")
+    ref = C.CDLL(so)
+    for fn in (ref.l2_f16_avx2, ref.dot_f16_avx2, ref.norm_l2_f16_avx2, ref.cosine_f16_avx2):
+        fn.restype = C.c_float
+    ref.cosine_f16_avx2.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(12)
+    for d in (4, 16, 20, 128, 333, 1536):
+        xi = rng.integers(-6, 7, d).astype(np.float16)
+        yi = rng.integers(-6, 7, d).astype(np.float16)
+        px, py = xi.ctypes.data_as(C.c_void_p), yi.ctypes.data_as(C.c_void_p)
+        assert np.float32(ref.l2_f16_avx2(px, py, C.c_uint32(d))).view(np.uint32) == np.float32(oracle.l2(xi, yi)).view(np.uint32)
+        assert np.float32(ref.dot_f16_avx2(px, py, C.c_uint32(d))).view(np.uint32) == np.float32(oracle.dot(xi, yi)).view(np.uint32)
+        n2 = np.float32(ref.norm_l2_f16_avx2(px, C.c_uint32(d)))
+        assert n2 == np.sqrt(np.float32((xi.astype(f32) ** 2).sum(dtype=np.float64)))
+        xr = (rng.standard_normal(d) * 2).astype(np.float16)
+        yr = (rng.standard_normal(d) * 2).astype(np.float16)
+        px, py = xr.ctypes.data_as(C.c_void_p), yr.ctypes.data_as(C.c_void_p)
+        assert abs(ref.l2_f16_avx2(px, py, C.c_uint32(d)) - oracle.l2(xr, yr)) <= 1e-5 * max(1.0, oracle.l2(xr, yr))
+        assert abs(ref.dot_f16_avx2(px, py, C.c_uint32(d)) - oracle.dot(xr, yr)) <= 1e-4 * max(1.0, float(np.abs(xr.astype(f32) * yr.astype(f32)).sum()))
+        xn = ref.norm_l2_f16_avx2(px, C.c_uint32(d))
+        want = 1.0 - float(xr.astype(np.float64) @ yr.astype(np.float64)) / (np.linalg.norm(xr.astype(np.float64)) * np.linalg.norm(yr.astype(np.float64)))
+        assert abs(ref.cosine_f16_avx2(px, C.c_float(xn), py, C.c_uint32(d)) - want) < 1e-4
