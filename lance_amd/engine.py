@@ -289,7 +289,7 @@ class DeviceFlatIndex:
     def load(cls, engine, index_dir, dtype=None):
         """IVF_FLAT index files -> HBM (lance_hip_index_load)."""
         from . import index_file
-        c = index_file.read_index_files(index_dir)
+        c = index_file.read_index_files(index_dir, with_rows=False)
         if c.index_type != "IVF_FLAT":
             raise ValueError(f"{index_dir} holds an {c.index_type} index; use DeviceIndex.load")
         ddt, dt = _DT[dtype if dtype is not None else c.dtype]
@@ -382,7 +382,7 @@ class DeviceIndex:
         lance_hip_index_load.  dtype: element type of the indexed column ("float32" | "float16" | "int8"); default = the
         element type of the stored tensors."""
         from . import index_file
-        c = index_file.read_index_files(index_dir)
+        c = index_file.read_index_files(index_dir, with_rows=False)
         if c.index_type != "IVF_PQ":
             raise ValueError(f"{index_dir} holds an {c.index_type} index; use DeviceFlatIndex.load")
         ddt, dt = _DT[dtype if dtype is not None else c.dtype]

@@ -60,8 +60,9 @@ def _arr(ptr, count, dtype):
     return np.frombuffer(buf, dtype=dtype, count=count).copy()
 
 
-def read_index_files(index_dir) -> IndexFileContents:
-    """Parses and validates `<index_dir>/index.idx` + `auxiliary.idx` (no GPU needed)."""
+def read_index_files(index_dir, with_rows=True) -> IndexFileContents:
+    """Parses and validates `<index_dir>/index.idx` + `auxiliary.idx` (no GPU needed).  with_rows=False returns the model
+    and the partition offsets only (row ids / codes / vectors stay in the file mapping: what DeviceIndex.load needs)."""
     lib = _lib.load()
     h = C.c_void_p()
     _lib.check(lib.lance_hip_index_file_open(os.fspath(index_dir).encode(), C.byref(h)))
@@ -75,7 +76,7 @@ def read_index_files(index_dir) -> IndexFileContents:
             dtype="float16" if v.dtype == _lib.F16 else "float32",
             centroids=_arr(v.centroids, nlist * d, np.float32).reshape(nlist, d),
             part_offsets=_arr(v.part_offsets, nlist + 1, np.uint32),
-            row_ids=_arr(v.row_ids, n, np.uint64),
+            row_ids=_arr(v.row_ids, n if with_rows else 0, np.uint64),
             transposed=bool(v.transposed),
             loss=float(v.loss) if v.has_loss else None,
         )
@@ -83,9 +84,10 @@ def read_index_files(index_dir) -> IndexFileContents:
             m, nbits = int(v.m), int(v.nbits)
             out.num_sub_vectors, out.nbits = m, nbits
             out.codebook = _arr(v.codebook, (1 << nbits) * d, np.float32).reshape(m, 1 << nbits, d // m)
-            out.codes = _arr(v.codes, n * out.code_bytes, np.uint8)
+            out.codes = _arr(v.codes, n * out.code_bytes if with_rows else 0, np.uint8)
         else:
-            out.vectors = _arr(v.vectors, n * d, np.float16 if v.dtype == _lib.F16 else np.float32).reshape(n, d)
+            nv = n if with_rows else 0
+            out.vectors = _arr(v.vectors, nv * d, np.float16 if v.dtype == _lib.F16 else np.float32).reshape(nv, d)
         return out
     finally:
         lib.lance_hip_index_file_close(h)
