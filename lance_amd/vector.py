@@ -170,14 +170,18 @@ class IvfPqIndex:
         whose stable grouping by partition is the stored order"""
         if self.part_ids is not None and self.codes is not None:
             return self.part_ids, self.codes, None
-        offs, codes_t, rid = self._ix.export()          # an index opened from files: undo the per-partition transpose
-        cb = codes_t.size // max(len(rid), 1) if len(rid) else 1
-        rm = np.empty((len(rid), cb), np.uint8)
-        for p in range(len(offs) - 1):
+        offs, codes_t, rid = self._ix.export()          # an index opened from files: undo the per-partition transpose,
+        n, nlist = len(rid), len(offs) - 1              # on the device (torch is only moving bytes here)
+        cb = codes_t.size // n if n else 1
+        ct = to_device(codes_t)
+        rm = torch.empty((n, cb), dtype=torch.uint8, device=ct.device)
+        for p in range(nlist):
             a, b = int(offs[p]), int(offs[p + 1])
-            rm[a:b] = codes_t[a * cb:b * cb].reshape(cb, b - a).T
-        part = np.repeat(np.arange(len(offs) - 1, dtype=np.int32), np.diff(offs.astype(np.int64)))
-        return to_device(part), to_device(rm), to_device(rid)
+            if b > a:
+                rm[a:b] = ct[a * cb:b * cb].view(cb, b - a).t()
+        lens = to_device(np.diff(offs.astype(np.int64)))
+        part = torch.repeat_interleave(torch.arange(nlist, dtype=torch.int32, device=ct.device), lens)
+        return part, rm, to_device(rid)
 
     def prefiltered(self, allow):
         """The index restricted to the rows whose id is selected by `allow` (bool over row ids).  Under a prefilter the
