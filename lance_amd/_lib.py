@@ -27,7 +27,8 @@ SYMBOLS = [
     "lance_hip_kmeans_finalize", "lance_hip_pq_train", "lance_hip_residual", "lance_hip_pq_encode",
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
     "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
-    "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_search_stats",
+    "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_ivfpq_search_range",
+    "lance_hip_search_stats",
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search",
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
     "lance_hip_index_load", "lance_hip_index_save", "lance_hip_file_read_column",
@@ -106,6 +107,7 @@ def load():
                                          C.POINTER(u32)]),
         "lance_hip_ivfpq_search": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
         "lance_hip_ivfpq_search_async": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
+        "lance_hip_ivfpq_search_range": (i32, [vp, vp, vp, u32, u32, u32, f32, f32, vp, vp]),
         "lance_hip_search_stats": (i32, [vp, C.POINTER(u32)]),
         "lance_hip_flat_topk": (i32, [vp, i32, i32, vp, vp, u64, u32, vp, u32, u32, vp, vp]),
         "lance_hip_ivfflat_create": (i32, [vp, i32, i32, u32, vp, u32, vp, vp, vp, u64, C.POINTER(vp)]),

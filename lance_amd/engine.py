@@ -435,6 +435,20 @@ class DeviceIndex:
         check(fn(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
         return ids, dists
 
+    def search_range(self, q, k, nprobes, lower=None, upper=None):
+        """Distance-range query: only rows with lower <= d < upper (ADC distance) enter the per-partition heaps."""
+        d = self.centroids.shape[1]
+        t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
+        q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
+        nq = q.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
+        hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
+        torch.cuda.synchronize()
+        check(self.engine.lib.lance_hip_ivfpq_search_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes, lo, hi, _ptr(ids), _ptr(dists)))
+        return ids, dists
+
     def close(self):
         if getattr(self, "h", None):
             self.engine.lib.lance_hip_index_destroy(self.h)

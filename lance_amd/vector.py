@@ -157,11 +157,19 @@ class IvfPqIndex:
         rid = np.arange(part.size, dtype=np.uint64)[keep]
         return rid, part[keep], self.codes.cpu().numpy()[keep]
 
-    def nearest(self, q, k=10, nprobes=1, refine_factor=None, prefilter=None):
+    def nearest(self, q, k=10, nprobes=1, refine_factor=None, prefilter=None, distance_range=None):
         """-> (row ids int64 [nq,k] (-1 = missing), distances f32 [nq,k]) as numpy.
         prefilter: boolean array over row ids (True = row may be returned) -- `nearest=..., filter=..., prefilter=True`
-        of the reference (scanner.rs prefilter -> FlatIndex::search's RowIdMask branch, flat/index.rs:129-165)."""
+        of the reference (scanner.rs prefilter -> FlatIndex::search's RowIdMask branch, flat/index.rs:129-165).
+        distance_range: (lower, upper), either may be None -- rows with lower <= d < upper only (Query::lower_bound /
+        upper_bound, flat/index.rs:98-113)."""
         ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
+        if distance_range is not None:
+            if refine_factor is not None:
+                raise NotImplementedError("distance_range together with refine_factor is not supported by this engine yet")
+            lo, hi = distance_range
+            ids, dists = ix.search_range(q, k, nprobes, lo, hi)
+            return ids.cpu().numpy(), dists.cpu().numpy()
         ids, dists = ix.search(q, k, nprobes, 0 if refine_factor is None else refine_factor)
         return ids.cpu().numpy(), dists.cpu().numpy()
 

@@ -345,13 +345,25 @@ class IvfPqIndex:
         self.codes_t = np.ascontiguousarray(codes_t, np.uint8)
         self.row_ids = np.ascontiguousarray(row_ids, np.uint64)
 
-    def search(self, queries, k, nprobes, refine=0, raw=None, prefilter=None):
+    def search(self, queries, k, nprobes, refine=0, raw=None, prefilter=None, lower=None, upper=None):
         """prefilter: boolean array over row ids (True = selected), the RowIdMask of a prefiltered query
-        (flat/index.rs:129-165); every selected row goes through DistCalculator::distance(id)."""
+        (flat/index.rs:129-165); every selected row goes through DistCalculator::distance(id).
+        lower / upper: distance range [lower, upper) applied inside every partition's heap (flat/index.rs:98-113)."""
         q = _f32(queries).reshape(-1, self.centroids.shape[1])
         nq, d = q.shape
         ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
         r = None if raw is None else _f32(raw)
+        if lower is not None or upper is not None:
+            assert not refine, "the oracle models distance ranges without a refine step"
+            allow = None if prefilter is None else np.ascontiguousarray(prefilter, dtype=np.uint8)
+            lo = np.float32(np.finfo(np.float32).min if lower is None else lower)
+            hi = np.float32(np.finfo(np.float32).max if upper is None else upper)
+            lib().orc_ivfpq_search_range(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),
+                                         _p(self.codebook), C.c_size_t(self.codebook.shape[0]), C.c_uint32(self.nbits),
+                                         _p(self.part_offsets), _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq),
+                                         C.c_size_t(k), C.c_size_t(nprobes), _p(ids), _p(dists), C.c_int(int(self.f16)),
+                                         _p(allow), C.c_size_t(0 if allow is None else allow.size), C.c_float(lo), C.c_float(hi))
+            return ids, dists
         if prefilter is not None:
             allow = np.ascontiguousarray(prefilter, dtype=np.uint8)
             lib().orc_ivfpq_search_filtered(self.metric, _p(self.centroids), C.c_size_t(self.centroids.shape[0]), C.c_size_t(d),

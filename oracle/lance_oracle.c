@@ -1129,7 +1129,8 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
                          const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
                          const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
                          size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
-                         uint64_t *out_ids, float *out_dists, int f16, const uint8_t *allow, size_t n_allow) {
+                         uint64_t *out_ids, float *out_dists, int f16, const uint8_t *allow, size_t n_allow,
+                         int has_range, float lower, float upper) {
   const size_t mbytes = nbits == 4 ? m_count / 2 : m_count;
   if (nprobes > nlist) nprobes = nlist;
   int scan_metric = (metric == ORC_COSINE) ? ORC_L2 : metric;
@@ -1183,12 +1184,12 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
           pd[na] = orc_pq_distance_one(scan_metric, lut, m_count, nbits, codes_t + off * mbytes, np_, j);
           pid[na++] = rid;
         }
-        ncand += orc_heap_topk(pd, pid, na, keff, 0, 0, 0, cand_ids + ncand, cand_d + ncand);
+        ncand += orc_heap_topk(pd, pid, na, keff, has_range, lower, upper, cand_ids + ncand, cand_d + ncand);
         continue;
       }
       if (nbits == 4) orc_pq_scan4_f32(scan_metric, lut, m_count, codes_t + off * mbytes, np_, keff, pd);
       else orc_pq_scan_f32(scan_metric, lut, m_count, codes_t + off * mbytes, np_, pd);
-      ncand += orc_heap_topk(pd, row_ids + off, np_, keff, 0, 0, 0, cand_ids + ncand, cand_d + ncand);
+      ncand += orc_heap_topk(pd, row_ids + off, np_, keff, has_range, lower, upper, cand_ids + ncand, cand_d + ncand);
     }
     size_t got = orc_sort_fetch(cand_ids, cand_d, ncand, keff);
     if (refine && raw) {
@@ -1218,7 +1219,7 @@ void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_
                          size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
                          uint64_t *out_ids, float *out_dists, int f16) {
   orc_ivfpq_search_impl(metric, centroids, nlist, d, codebook, m_count, nbits, part_offsets, codes_t, row_ids, queries, nq, k,
-                        nprobes, refine, raw, out_ids, out_dists, f16, NULL, 0);
+                        nprobes, refine, raw, out_ids, out_dists, f16, NULL, 0, 0, 0.0f, 0.0f);
 }
 
 /* The same search under a row-id prefilter (scanner prefilter=True -> PreFilter::mask, flat/index.rs:129-165):
@@ -1229,7 +1230,20 @@ void orc_ivfpq_search_filtered(int metric, const float *centroids, size_t nlist,
                                size_t nq, size_t k, size_t nprobes, size_t refine, const float *raw,
                                uint64_t *out_ids, float *out_dists, int f16, const uint8_t *allow, size_t n_allow) {
   orc_ivfpq_search_impl(metric, centroids, nlist, d, codebook, m_count, nbits, part_offsets, codes_t, row_ids, queries, nq, k,
-                        nprobes, refine, raw, out_ids, out_dists, f16, allow, n_allow);
+                        nprobes, refine, raw, out_ids, out_dists, f16, allow, n_allow, 0, 0.0f, 0.0f);
+}
+
+/* Distance-range query: Query::lower_bound / upper_bound reach FlatIndex::search (flat/index.rs:98-113, 131-146): in each
+ * probed partition a row enters the heap only if lower <= dist < upper (total order on f32), with or without a
+ * prefilter.  allow may be NULL.  (The refine step filters the exact distances the same way -- scanner.rs:3334-3377 --
+ * which this restatement does not model: call it with refine = 0.) */
+void orc_ivfpq_search_range(int metric, const float *centroids, size_t nlist, size_t d,
+                            const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
+                            const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
+                            size_t nq, size_t k, size_t nprobes, uint64_t *out_ids, float *out_dists, int f16,
+                            const uint8_t *allow, size_t n_allow, float lower, float upper) {
+  orc_ivfpq_search_impl(metric, centroids, nlist, d, codebook, m_count, nbits, part_offsets, codes_t, row_ids, queries, nq, k,
+                        nprobes, 0, NULL, out_ids, out_dists, f16, allow, n_allow, 1, lower, upper);
 }
 
 /* Index build glue (builder.rs:555-846 in canonical, stable row order):

@@ -168,6 +168,13 @@ class OracleDeviceIndex:
         return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
 
 
+    def search_range(self, q, k, nprobes, lower=None, upper=None):
+        lo = np.finfo(f32).min if lower is None else lower
+        hi = np.finfo(f32).max if upper is None else upper
+        i, d = self.o.search(_np(q).astype(f32), k, nprobes, lower=lo, upper=hi)
+        return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
+
+
 class OracleDeviceFlatIndex:
     """DeviceFlatIndex: create / load / save / search."""
 

@@ -47,3 +47,8 @@ def test_dryrun_legacy_index(fake, oracle, tmp_path):
 
 def test_dryrun_load_list_shard(fake, oracle, tmp_path):
     G.test_load_list_shard_world1(fake, oracle, tmp_path)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_dryrun_distance_range(fake, oracle, metric):
+    G.test_distance_range_search(fake, oracle, metric)

@@ -927,3 +927,28 @@ def test_load_list_shard_world1(eng, oracle, tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_distance_range_search(eng, oracle, metric):
+    """`nearest={..., "distance_range": (lower, upper)}`: inside each probed partition only rows with lower <= d < upper
+    enter the k-heap (flat/index.rs:98-113; v2.rs distance-range tests).  Batched form of what lance_hip_pq_scan_topk
+    does for one partition; large batches leave the partition-major path for the query-major kernel."""
+    from lance_amd.vector import IvfPqIndex, IvfPqParams
+    n, d, nlist, m = 20000, 64, 24, 8
+    x = sift_like(n, d, 141)
+    oidx, gidx = _build_pair(eng, oracle, x, nlist, m, metric)
+    ix = IvfPqIndex(gidx, IvfPqParams(nlist, m, 8, metric))
+    for nq in (40, 600):                               # 600 x 8 probes >= 4096 pairs: would take the PM path without a range
+        q = sift_like(nq, d, 142 + nq)
+        _, ud = oidx.search(q, 60, 8)
+        fin = ud[np.isfinite(ud)]
+        lo, hi = float(np.quantile(fin, 0.2)), float(np.quantile(fin, 0.6))
+        for k, nprobes, rng_ in ((10, 8, (lo, hi)), (10, 8, (None, hi)), (25, 3, (lo, None)), (5, nlist, (hi, hi))):
+            gi, gd = ix.nearest(q, k, nprobes, distance_range=rng_)
+            oi, od = oidx.search(q, k, nprobes, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
+                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
+            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rng_)
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+    with pytest.raises(NotImplementedError):
+        ix.nearest(q, 10, 4, refine_factor=2, distance_range=(lo, hi))

@@ -651,3 +651,30 @@ def test_f16_kernels_against_reference_c(oracle):
         xn = ref.norm_l2_f16_avx2(px, C.c_uint32(d))
         want = 1.0 - float(xr.astype(np.float64) @ yr.astype(np.float64)) / (np.linalg.norm(xr.astype(np.float64)) * np.linalg.norm(yr.astype(np.float64)))
         assert abs(ref.cosine_f16_avx2(px, C.c_float(xn), py, C.c_uint32(d)) - want) < 1e-4
+
+
+def test_distance_range_search_semantics(oracle):
+    """flat/index.rs:98-113: a row enters a partition's heap only if lower <= d < upper; open ends are f32::MIN / f32::MAX;
+    the union over the probed partitions is then sorted (dist, rowid) and cut to k.  Cross-check: the ranged search equals
+    filtering each partition's FULL distance list by the range and taking the k best (k-heaps of in-range rows only)."""
+    rng = np.random.default_rng(31)
+    n, d, nlist, m = 6000, 32, 10, 4
+    x = np.clip(np.rint(rng.normal(60, 30, (n, d))), 0, 218).astype(np.float32)
+    q = np.clip(np.rint(rng.normal(60, 30, (25, d))), 0, 218).astype(np.float32)
+    cent, _, _, _ = oracle.kmeans_train(x[:2048], nlist, max_iters=5, seed=1)
+    part, _ = oracle.assign(x, cent)
+    cb, _ = oracle.pq_train(oracle.residual(x, cent, part)[:4096], m, max_iters=5, seed=2)
+    idx = oracle.build_index(x, cent, cb)
+    none = np.iinfo(np.uint64).max
+    ui, ud = idx.search(q, 10, 4)
+    assert np.array_equal(idx.search(q, 10, 4, lower=np.finfo(np.float32).min, upper=np.finfo(np.float32).max)[0], ui)
+    allrows_i, allrows_d = idx.search(q, 4000, 4)          # every row of the 4 probed partitions, sorted (dist, rowid)
+    lo, hi = np.float32(np.median(ud[:, 3])), np.float32(np.median(ud[:, 9]))
+    ri, rd = idx.search(q, 10, 4, lower=lo, upper=hi)
+    for i in range(len(q)):
+        ok = (allrows_i[i] != none) & (allrows_d[i] >= lo) & (allrows_d[i] < hi)
+        want_i, want_d = allrows_i[i][ok][:10], allrows_d[i][ok][:10]
+        got = ri[i] != none
+        assert np.array_equal(ri[i][got], want_i) and np.array_equal(rd[i][got].view(np.uint32), want_d.view(np.uint32))
+    ei, _ = idx.search(q, 5, 4, lower=hi, upper=hi)          # empty interval
+    assert (ei == none).all()
