@@ -270,6 +270,10 @@ void lance_hip_index_file_close(lance_hip_index_file *f);
 int lance_hip_index_file_write(const char *index_dir, const lance_hip_index_file_view *view);
 /* Files -> device-resident index.  dtype is the indexed column's element type (F32 / F16 / I8).                   */
 int lance_hip_index_load(lance_hip_ctx *ctx, const char *index_dir, int dtype, lance_hip_index **out);
+/* The same for one list shard of a multi-GPU search: only the IVF lists p with p % list_mod == list_rem are
+ * copied to this GPU, the others are left empty; centroids and codebook are complete, row ids are the stored ones.   */
+int lance_hip_index_load_lists(lance_hip_ctx *ctx, const char *index_dir, int dtype, uint32_t list_mod, uint32_t list_rem,
+                               lance_hip_index **out);
 /* Device-resident index -> files.  loss is the k-means loss recorded in index.idx (has_loss = 0 to omit).        */
 int lance_hip_index_save(lance_hip_ctx *ctx, const lance_hip_index *idx, const char *index_dir, int has_loss, double loss);
 /* One top-level fixed-width column (scalar or fixed-size list, uncompressed, no nulls) of a format-2.0 Lance file,

@@ -31,7 +31,7 @@ SYMBOLS = [
     "lance_hip_search_stats",
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search",
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
-    "lance_hip_index_load", "lance_hip_index_save", "lance_hip_file_read_column",
+    "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
     "lance_hip_timing_enable", "lance_hip_timing_query",
 ]
 
@@ -117,6 +117,7 @@ def load():
         "lance_hip_index_file_close": (None, [vp]),
         "lance_hip_index_file_write": (i32, [C.c_char_p, C.POINTER(IndexFileView)]),
         "lance_hip_index_load": (i32, [vp, C.c_char_p, i32, C.POINTER(vp)]),
+        "lance_hip_index_load_lists": (i32, [vp, C.c_char_p, i32, u32, u32, C.POINTER(vp)]),
         "lance_hip_index_save": (i32, [vp, vp, C.c_char_p, i32, f64]),
         "lance_hip_file_read_column": (i32, [C.c_char_p, C.c_char_p, vp, u64, C.POINTER(u64), C.POINTER(u32)]),
         "lance_hip_timing_enable": (i32, [vp, i32]),

@@ -575,7 +575,13 @@ struct DevTmp {   // device staging freed on scope exit
 }  // namespace
 
 extern "C" int lance_hip_index_load(lance_hip_ctx *ctx, const char *index_dir, int dtype, lance_hip_index **out) {
+  return lance_hip_index_load_lists(ctx, index_dir, dtype, 1, 0, out);
+}
+
+extern "C" int lance_hip_index_load_lists(lance_hip_ctx *ctx, const char *index_dir, int dtype, uint32_t list_mod, uint32_t list_rem,
+                                          lance_hip_index **out) {
   LH_REQUIRE(ctx && index_dir && out, "index_load: NULL argument");
+  LH_REQUIRE(list_mod >= 1 && list_rem < list_mod, "index_load: bad list shard %u of %u", list_rem, list_mod);
   lance_hip_index_file *f = nullptr;
   LH_TRY(lance_hip_index_file_open(index_dir, &f));
   std::unique_ptr<lance_hip_index_file> guard(f);
@@ -602,13 +608,36 @@ extern "C" int lance_hip_index_load(lance_hip_ctx *ctx, const char *index_dir, i
     }
     const uint32_t code_bytes = v.nbits == 4 ? v.m / 2 : v.m;
     void *dcodes = nullptr, *drid = nullptr;
-    LH_TRY(tmp.upload(ctx, v.codes, (size_t)v.n_rows * code_bytes, &dcodes));
-    LH_TRY(tmp.upload(ctx, v.row_ids, (size_t)v.n_rows * 8, &drid));
-    r = lance_hip_index_from_storage(ctx, dtype, v.metric, v.d, cent, v.nlist, cb, v.m, v.nbits, v.part_offsets,
-                                     static_cast<const uint8_t *>(dcodes), v.transposed, static_cast<const uint64_t *>(drid),
-                                     v.n_rows, out);
+    if (list_mod == 1) {
+      LH_TRY(tmp.upload(ctx, v.codes, (size_t)v.n_rows * code_bytes, &dcodes));
+      LH_TRY(tmp.upload(ctx, v.row_ids, (size_t)v.n_rows * 8, &drid));
+      r = lance_hip_index_from_storage(ctx, dtype, v.metric, v.d, cent, v.nlist, cb, v.m, v.nbits, v.part_offsets,
+                                       static_cast<const uint8_t *>(dcodes), v.transposed, static_cast<const uint64_t *>(drid),
+                                       v.n_rows, out);
+    } else {
+      // list shard (lists p with p % list_mod == list_rem): the foreign lists are emptied, the owned code blocks and row
+      // ids -- each contiguous in the file, in either layout -- are packed into host buffers and uploaded once
+      std::vector<uint32_t> offs(v.nlist + 1, 0);
+      for (uint32_t p = 0; p < v.nlist; ++p)
+        offs[p + 1] = offs[p] + (p % list_mod == list_rem ? v.part_offsets[p + 1] - v.part_offsets[p] : 0);
+      const uint64_t nloc = offs[v.nlist];
+      std::vector<uint8_t> hcodes((size_t)nloc * code_bytes);
+      std::vector<uint64_t> hrid((size_t)nloc);
+      for (uint32_t p = 0; p < v.nlist; ++p) {
+        const size_t np_ = offs[p + 1] - offs[p];
+        if (np_ == 0) continue;
+        memcpy(hcodes.data() + (size_t)offs[p] * code_bytes, v.codes + (size_t)v.part_offsets[p] * code_bytes, np_ * code_bytes);
+        memcpy(hrid.data() + offs[p], v.row_ids + v.part_offsets[p], np_ * 8);
+      }
+      LH_TRY(tmp.upload(ctx, hcodes.data(), hcodes.size(), &dcodes));
+      LH_TRY(tmp.upload(ctx, hrid.data(), hrid.size() * 8, &drid));
+      r = lance_hip_index_from_storage(ctx, dtype, v.metric, v.d, cent, v.nlist, cb, v.m, v.nbits, offs.data(),
+                                       static_cast<const uint8_t *>(dcodes), v.transposed, static_cast<const uint64_t *>(drid),
+                                       nloc, out);
+    }
   } else {
     LH_REQUIRE(dtype != LANCE_HIP_I8, "index_load: IVF_FLAT files hold float vectors; int8 columns are not stored this way");
+    LH_REQUIRE(list_mod == 1, "index_load: list shards are implemented for IVF_PQ indices only");
     std::vector<uint32_t> part_ids((size_t)v.n_rows);
     for (uint32_t p = 0; p < v.nlist; ++p) std::fill(part_ids.begin() + v.part_offsets[p], part_ids.begin() + v.part_offsets[p + 1], p);
     const size_t es = dtype == LANCE_HIP_F16 ? 2 : 4;

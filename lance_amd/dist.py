@@ -316,20 +316,13 @@ def shard_index_contents(c, world, rank):
 
 
 def load_list_shard(engine, index_dir, raw=None, dtype=None, group=None):
-    """Opens an IVF_PQ index directory (lance_amd/index_file.py) and puts THIS rank's lists into HBM: every rank parses
-    the (small) metadata and copies only its own code blocks.  Row ids are the stored ones, so `search_list_sharded`
+    """Opens an IVF_PQ index directory and puts THIS rank's lists into HBM (lance_hip_index_load_lists): every rank maps
+    the files, parses the (small) metadata and copies only its own code blocks -- at C5 scale 1/8 of 40 GB per GPU.  Row ids are the stored ones, so `search_list_sharded`
     needs no local->global map (pass the returned empty tensor as l2g).  raw: the column's vectors for refine, indexed
     by row id (only meaningful when the ids are row offsets)."""
-    from . import index_file
     from .engine import DeviceIndex
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    c = index_file.read_index_files(index_dir)
-    if c.index_type != "IVF_PQ":
-        raise ValueError(f"{index_dir}: list-sharded search is implemented for IVF_PQ, not {c.index_type}")
-    offs, codes, rid = shard_index_contents(c, world, rank)
-    model = np.float16 if c.dtype == "float16" else np.float32
-    ix = DeviceIndex.from_storage(engine, c.metric, c.centroids.astype(model), c.codebook.astype(model), offs, codes, rid,
-                                  transposed=c.transposed, raw=raw, dtype=dtype)
+    ix = DeviceIndex.load(engine, index_dir, dtype=dtype, raw=raw, lists=(world, rank))   # lance_hip_index_load_lists
     return ix, torch.empty(0, dtype=torch.int64)
 
 

@@ -377,10 +377,10 @@ class DeviceIndex:
         return cls(engine, h, metric, cent, cb, raw, ddt)
 
     @classmethod
-    def load(cls, engine, index_dir, dtype=None, raw=None):
+    def load(cls, engine, index_dir, dtype=None, raw=None, lists=None):
         """`<index_dir>/index.idx` + `auxiliary.idx` (an IVF_PQ index the reference wrote, or `save`) -> HBM, through
         lance_hip_index_load.  dtype: element type of the indexed column ("float32" | "float16" | "int8"); default = the
-        element type of the stored tensors."""
+        element type of the stored tensors.  lists = (world, rank): only the IVF lists p with p % world == rank."""
         from . import index_file
         c = index_file.read_index_files(index_dir, with_rows=False)
         if c.index_type != "IVF_PQ":
@@ -389,7 +389,8 @@ class DeviceIndex:
         mdt = torch.float16 if c.dtype == "float16" else torch.float32
         h = C.c_void_p()
         torch.cuda.synchronize()
-        check(engine.lib.lance_hip_index_load(engine.h, os.fspath(index_dir).encode(), dt, C.byref(h)))
+        mod, rem = (1, 0) if lists is None else (int(lists[0]), int(lists[1]))
+        check(engine.lib.lance_hip_index_load_lists(engine.h, os.fspath(index_dir).encode(), dt, mod, rem, C.byref(h)))
         return cls(engine, h, c.metric, to_device(c.centroids, mdt), to_device(c.codebook, mdt), raw, ddt)
 
     def save(self, index_dir, loss=None):

@@ -135,13 +135,15 @@ class OracleDeviceIndex:
         return cls(engine, o, metric, cpu_to_device(centroids), cpu_to_device(codebook), raw)
 
     @classmethod
-    def load(cls, engine, index_dir, dtype=None, raw=None):
+    def load(cls, engine, index_dir, dtype=None, raw=None, lists=None):
         from lance_amd import index_file
+        from lance_amd.dist import shard_index_contents
         c = index_file.read_index_files(index_dir)
         if c.index_type != "IVF_PQ":
             raise ValueError("not IVF_PQ")
         model = np.float16 if c.dtype == "float16" else np.float32
-        return cls.from_storage(engine, c.metric, c.centroids.astype(model), c.codebook.astype(model), c.part_offsets, c.codes, c.row_ids,
+        offs, codes, rid = (c.part_offsets, c.codes, c.row_ids) if lists is None else shard_index_contents(c, lists[0], lists[1])
+        return cls.from_storage(engine, c.metric, c.centroids.astype(model), c.codebook.astype(model), offs, codes, rid,
                                 transposed=c.transposed, raw=raw)
 
     def save(self, index_dir, loss=None):

@@ -305,34 +305,15 @@ def test_create_index_sharded_is_independent_of_the_rank_count():
 
 
 # ---- list-sharded search straight from index files (lance_amd/dist.py: load_list_shard) ------------------------------
-class _OracleStorageIndex:
-    """DeviceIndex.from_storage stand-in: the oracle over exactly the arrays the rank was handed."""
-
-    @classmethod
-    def from_storage(cls, engine, metric, centroids, codebook, part_offsets, codes, row_ids, transposed=True, raw=None, dtype=None):
-        import oracle
-        self = cls()
-        m = codebook.shape[0]
-        offs = np.asarray(part_offsets, np.uint32)
-        codes = np.asarray(codes, np.uint8)
-        if not transposed:
-            codes = np.concatenate([codes[int(offs[p]) * m:int(offs[p + 1]) * m].reshape(-1, m).T.reshape(-1)
-                                    for p in range(len(offs) - 1)]) if codes.size else codes
-        self.o = oracle.IvfPqIndex(metric, centroids, codebook, offs, codes, np.asarray(row_ids, np.uint64))
-        return self
-
-    def search(self, q, k, nprobes, refine_factor=0):
-        i, d = self.o.search(np.asarray(q, f32), k, nprobes)
-        return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d)
-
-
 def _file_shard_worker(rank, world, port, index_dir, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import lance_amd.engine as E
-    E.DeviceIndex = _OracleStorageIndex
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_engine import OracleDeviceIndex
+    E.DeviceIndex = OracleDeviceIndex                      # load(lists=) -> lance_amd.dist.shard_index_contents -> oracle
     from lance_amd.dist import load_list_shard, search_list_sharded
     ix, l2g = load_list_shard(None, index_dir)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
