@@ -52,3 +52,8 @@ def test_dryrun_load_list_shard(fake, oracle, tmp_path):
 @pytest.mark.parametrize("metric", ["l2", "dot"])
 def test_dryrun_distance_range(fake, oracle, metric):
     G.test_distance_range_search(fake, oracle, metric)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dryrun_load_lists_shards(fake, oracle, tmp_path, world):
+    G.test_load_lists_shards_on_one_gpu(fake, oracle, tmp_path, world)

@@ -952,3 +952,34 @@ def test_distance_range_search(eng, oracle, metric):
             assert (gd.view(np.uint32) == od.view(np.uint32)).all()
     with pytest.raises(NotImplementedError):
         ix.nearest(q, 10, 4, refine_factor=2, distance_range=(lo, hi))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_load_lists_shards_on_one_gpu(eng, oracle, tmp_path, world):
+    """lance_hip_index_load_lists: every shard (lists p % world == r) of the Lance-0.8.14 index loaded on this one GPU; the
+    shards' answers merged by (dist, rowid) must be the whole index's answer.  No process group: the placement and the
+    native shard loader are what is under test."""
+    import os
+    import shutil
+    import torch
+    import lance_amd
+    from lance_amd.dist import merge_topk
+    from lance_amd.engine import DeviceIndex
+    from ref_fixtures import ref_index_dir
+    d = tmp_path / "legacy"
+    d.mkdir()
+    shutil.copyfile(os.path.join(ref_index_dir(), "v0.8.14_legacy", "index_2000.idx"), d / "index.idx")
+    whole = lance_amd.load_index(d, engine=eng)
+    shards = [DeviceIndex.load(eng, d, lists=(world, r)) for r in range(world)]
+    assert sum(s.info()["n"] for s in shards) == 2000
+    for r, s in enumerate(shards):
+        offs, _, _ = s.export()
+        lens = np.diff(offs.astype(np.int64))
+        assert all(lens[p] == 0 for p in range(4) if p % world != r) and lens.sum() == s.info()["n"]
+    q = np.load(os.path.join(ref_index_dir(), "v0.8.14_ivf4_pq16.npz"))["x"][:80]
+    for k, nprobes in ((10, 4), (10, 2), (40, 3)):
+        parts = [s.search(q, k, nprobes) for s in shards]
+        gi, gd = merge_topk(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
+        ri, rd = whole.search_device(q, k, nprobes)
+        assert (gi == ri).all(), (world, k, nprobes)
+        assert (_np(gd).view(np.uint32) == _np(rd).view(np.uint32)).all()
