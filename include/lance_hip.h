@@ -206,9 +206,13 @@ int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx,
 /* Distance-range query (`nearest={..., "distance_range": (lower, upper)}`; Query::lower_bound / upper_bound): inside
  * every probed partition only rows with lower <= d < upper enter the k-heap (FlatIndex::search, flat/index.rs:98-113),
  * d being the ADC distance (after the dot offset).  An open end is -FLT_MAX / FLT_MAX as in the reference
- * (`unwrap_or(f32::MIN)` / `unwrap_or(f32::MAX)`).  No refine step in this version.                                 */
+ * (`unwrap_or(f32::MIN)` / `unwrap_or(f32::MAX)`).  refine_factor as in lance_hip_ivfpq_search: the k * refine_factor
+ * candidates that passed the ADC range are re-ranked by exact distance -- the exact distances are NOT filtered here; a
+ * caller reproducing the reference plan (scanner.rs:3334-3377 filters them before the final fetch) asks for all
+ * candidates (k = k * rf, refine_factor = 1) and applies the range to the returned exact distances.                 */
 int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
-                                 uint32_t nprobes, float lower, float upper, uint64_t *ids, float *dists);
+                                 uint32_t nprobes, uint32_t refine_factor, float lower, float upper, uint64_t *ids,
+                                 float *dists);
 
 /* Number of queries of the most recent search on this context that had to be replayed by the exact
  * (heap-emulating) kernel -- ties at a partition's k-th distance, or candidate-buffer overflow.      */

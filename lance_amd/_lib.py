@@ -107,7 +107,7 @@ def load():
                                          C.POINTER(u32)]),
         "lance_hip_ivfpq_search": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
         "lance_hip_ivfpq_search_async": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
-        "lance_hip_ivfpq_search_range": (i32, [vp, vp, vp, u32, u32, u32, f32, f32, vp, vp]),
+        "lance_hip_ivfpq_search_range": (i32, [vp, vp, vp, u32, u32, u32, u32, f32, f32, vp, vp]),
         "lance_hip_search_stats": (i32, [vp, C.POINTER(u32)]),
         "lance_hip_flat_topk": (i32, [vp, i32, i32, vp, vp, u64, u32, vp, u32, u32, vp, vp]),
         "lance_hip_ivfflat_create": (i32, [vp, i32, i32, u32, vp, u32, vp, vp, vp, u64, C.POINTER(vp)]),

@@ -1074,7 +1074,7 @@ int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const
 }
 
 int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
-                                 uint32_t nprobes, float lower, float upper, uint64_t *ids, float *dists) {
+                                 uint32_t nprobes, uint32_t refine_factor, float lower, float upper, uint64_t *ids, float *dists) {
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search_range: NULL argument");
   LH_REQUIRE(ctx->device == idx->device, "search_range: context and index live on different devices");
   LH_REQUIRE(idx->m != 0, "search_range: not an IVF_PQ index");
@@ -1083,7 +1083,7 @@ int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx,
   uint32_t *flags = nullptr;
   const float *qf;
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
-  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, 0, 1, lower, upper, ids, dists, &flags));
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 1, lower, upper, ids, dists, &flags));
   return check_flags(ctx, flags, nq);
 }
 

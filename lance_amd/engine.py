@@ -436,8 +436,25 @@ class DeviceIndex:
         check(fn(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
         return ids, dists
 
-    def search_range(self, q, k, nprobes, lower=None, upper=None):
-        """Distance-range query: only rows with lower <= d < upper (ADC distance) enter the per-partition heaps."""
+    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0):
+        """Distance-range query: only rows with lower <= d < upper (ADC distance) enter the per-partition heaps.  With a
+        refine factor the reference also filters the exact distances before the final fetch (scanner.rs:3334-3377): all
+        k * refine_factor candidates come back re-ranked from the device and the range is applied to them here."""
+        if refine_factor and refine_factor > 0:
+            keff = k * refine_factor
+            ci, cd = self.search_range(q, keff, nprobes, lower, upper, refine_factor=-1)       # -1: re-rank, keep all
+            lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
+            hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
+            ok = (ci >= 0) & (cd >= lo) & (cd < hi)
+            # first k in-range entries of every row, order kept (the device returned them sorted by (distance, row id))
+            rank = torch.cumsum(ok.to(torch.int64), dim=1) - 1
+            ids = torch.full((ci.shape[0], k), -1, dtype=torch.int64, device=ci.device)
+            dists = torch.full((ci.shape[0], k), float("inf"), dtype=torch.float32, device=ci.device)
+            take = ok & (rank < k)
+            rows = torch.arange(ci.shape[0], device=ci.device).unsqueeze(1).expand_as(ci)
+            ids[rows[take], rank[take]] = ci[take]
+            dists[rows[take], rank[take]] = cd[take]
+            return ids, dists
         d = self.centroids.shape[1]
         t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
         q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
@@ -447,7 +464,8 @@ class DeviceIndex:
         lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
         hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
         torch.cuda.synchronize()
-        check(self.engine.lib.lance_hip_ivfpq_search_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes, lo, hi, _ptr(ids), _ptr(dists)))
+        check(self.engine.lib.lance_hip_ivfpq_search_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes, 1 if refine_factor == -1 else 0,
+                                                           lo, hi, _ptr(ids), _ptr(dists)))
         return ids, dists
 
     def close(self):

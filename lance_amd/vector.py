@@ -165,10 +165,8 @@ class IvfPqIndex:
         upper_bound, flat/index.rs:98-113)."""
         ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
         if distance_range is not None:
-            if refine_factor is not None:
-                raise NotImplementedError("distance_range together with refine_factor is not supported by this engine yet")
             lo, hi = distance_range
-            ids, dists = ix.search_range(q, k, nprobes, lo, hi)
+            ids, dists = ix.search_range(q, k, nprobes, lo, hi, refine_factor=0 if refine_factor is None else refine_factor)
             return ids.cpu().numpy(), dists.cpu().numpy()
         ids, dists = ix.search(q, k, nprobes, 0 if refine_factor is None else refine_factor)
         return ids.cpu().numpy(), dists.cpu().numpy()

@@ -354,7 +354,6 @@ class IvfPqIndex:
         ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
         r = None if raw is None else _f32(raw)
         if lower is not None or upper is not None:
-            assert not refine, "the oracle models distance ranges without a refine step"
             allow = None if prefilter is None else np.ascontiguousarray(prefilter, dtype=np.uint8)
             lo = np.float32(np.finfo(np.float32).min if lower is None else lower)
             hi = np.float32(np.finfo(np.float32).max if upper is None else upper)
@@ -362,7 +361,8 @@ class IvfPqIndex:
                                          _p(self.codebook), C.c_size_t(self.codebook.shape[0]), C.c_uint32(self.nbits),
                                          _p(self.part_offsets), _p(self.codes_t), _p(self.row_ids), _p(q), C.c_size_t(nq),
                                          C.c_size_t(k), C.c_size_t(nprobes), _p(ids), _p(dists), C.c_int(int(self.f16)),
-                                         _p(allow), C.c_size_t(0 if allow is None else allow.size), C.c_float(lo), C.c_float(hi))
+                                         _p(allow), C.c_size_t(0 if allow is None else allow.size), C.c_float(lo), C.c_float(hi),
+                                         C.c_size_t(refine), _p(r))
             return ids, dists
         if prefilter is not None:
             allow = np.ascontiguousarray(prefilter, dtype=np.uint8)

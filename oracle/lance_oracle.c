@@ -1197,11 +1197,17 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
        * (scanner.rs:2884-2904): KNNVectorDistanceExec + SortExec(dist,rowid).fetch(k) */
       const float *qo = queries + i * d;
       float qn = metric == ORC_COSINE ? orc_norm_l2_f32(qo, d) : 0.0f;
+      size_t kept = 0;
       for (size_t c = 0; c < got; c++) {
         const float *rv = raw + cand_ids[c] * d;
-        cand_d[c] = metric == ORC_COSINE ? orc_cosine_f32(qo, qn, rv, d) : orc_dist(metric, qo, rv, d);
+        const float ex = metric == ORC_COSINE ? orc_cosine_f32(qo, qn, rv, d) : orc_dist(metric, qo, rv, d);
+        /* a distance range is applied to the exact distances too: LanceFilterExec(dist >= lower AND dist < upper)
+         * between KNNVectorDistanceExec and the final SortExec (scanner.rs:3334-3377) */
+        if (has_range && !(ex >= lower && ex < upper)) continue;
+        cand_ids[kept] = cand_ids[c];
+        cand_d[kept++] = ex;
       }
-      got = orc_sort_fetch(cand_ids, cand_d, got, k);
+      got = orc_sort_fetch(cand_ids, cand_d, kept, k);
     } else if (got > k) {
       got = k;
     }
@@ -1235,15 +1241,15 @@ void orc_ivfpq_search_filtered(int metric, const float *centroids, size_t nlist,
 
 /* Distance-range query: Query::lower_bound / upper_bound reach FlatIndex::search (flat/index.rs:98-113, 131-146): in each
  * probed partition a row enters the heap only if lower <= dist < upper (total order on f32), with or without a
- * prefilter.  allow may be NULL.  (The refine step filters the exact distances the same way -- scanner.rs:3334-3377 --
- * which this restatement does not model: call it with refine = 0.) */
+ * prefilter.  allow may be NULL.  With refine the exact distances are filtered by the same range before the final fetch
+ * (scanner.rs:3334-3377). */
 void orc_ivfpq_search_range(int metric, const float *centroids, size_t nlist, size_t d,
                             const float *codebook, size_t m_count, uint32_t nbits, const uint32_t *part_offsets,
                             const uint8_t *codes_t, const uint64_t *row_ids, const float *queries,
                             size_t nq, size_t k, size_t nprobes, uint64_t *out_ids, float *out_dists, int f16,
-                            const uint8_t *allow, size_t n_allow, float lower, float upper) {
+                            const uint8_t *allow, size_t n_allow, float lower, float upper, size_t refine, const float *raw) {
   orc_ivfpq_search_impl(metric, centroids, nlist, d, codebook, m_count, nbits, part_offsets, codes_t, row_ids, queries, nq, k,
-                        nprobes, 0, NULL, out_ids, out_dists, f16, allow, n_allow, 1, lower, upper);
+                        nprobes, refine, raw, out_ids, out_dists, f16, allow, n_allow, 1, lower, upper);
 }
 
 /* Index build glue (builder.rs:555-846 in canonical, stable row order):

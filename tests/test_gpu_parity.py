@@ -950,8 +950,17 @@ def test_distance_range_search(eng, oracle, metric):
                                  upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
             assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rng_)
             assert (gd.view(np.uint32) == od.view(np.uint32)).all()
-    with pytest.raises(NotImplementedError):
-        ix.nearest(q, 10, 4, refine_factor=2, distance_range=(lo, hi))
+        # with refine: ADC range in the partitions, exact re-rank of the k * rf candidates, exact distances filtered by the
+        # same range before the fetch (scanner.rs:3334-3377) -- exact L2 / dot distances live on another scale than the
+        # ADC ones, so take the bounds from the exact neighbourhood
+        _, ed = oracle.flat_knn(x, q, 40, metric)
+        elo, ehi = float(np.quantile(ed, 0.1)), float(np.quantile(ed, 0.9))
+        for k, nprobes, rf, rng_ in ((10, 8, 4, (elo, ehi)), (5, nlist, 10, (None, ehi))):
+            gi, gd = ix.nearest(q, k, nprobes, refine_factor=rf, distance_range=rng_)
+            oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
+                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
+            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rf, rng_)
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -306,3 +306,41 @@ def test_validate_vector_index_mirrors_lance_util():
     assert lance_amd.validate_vector_index(Stub(5), x, pass_threshold=0.8) == (44, 49)
     s = Stub(0)
     assert lance_amd.validate_vector_index(s, x, sample_size=10, refine_factor=2)[1] in (9, 10) and s.calls[0][3] == 2
+
+
+def test_range_with_refine_selection_logic(oracle):
+    """DeviceIndex.search_range(refine_factor=rf): the device returns the k*rf ADC-ranged candidates re-ranked by exact
+    distance; the exact-range filter + first-k selection done on top of it (torch) must equal the oracle's restatement of
+    the reference plan (partition heaps with the ADC range, exact distances, LanceFilterExec, SortExec.fetch(k))."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(41)
+    n, d, nlist, m = 5000, 32, 8, 4
+    x = np.clip(np.rint(rng.normal(60, 30, (n, d))), 0, 218).astype(f32)
+    q = np.clip(np.rint(rng.normal(60, 30, (30, d))), 0, 218).astype(f32)
+    cent, _, _, _ = oracle.kmeans_train(x[:2048], nlist, max_iters=5, seed=1)
+    part, _ = oracle.assign(x, cent)
+    cb, _ = oracle.pq_train(oracle.residual(x, cent, part)[:4096], m, max_iters=5, seed=2)
+    oidx = oracle.build_index(x, cent, cb)
+    _, ed = oracle.flat_knn(x, q, 40, "l2")
+    lo, hi = float(np.quantile(ed, 0.15)), float(np.quantile(ed, 0.85))
+    none = np.iinfo(np.uint64).max
+
+    class Stub:
+        def search_range(self, qq, keff, nprobes, lower, upper, refine_factor=0):
+            assert refine_factor == -1
+            ci, _ = oidx.search(qq, keff, nprobes, lower=np.finfo(f32).min if lower is None else lower,
+                                upper=np.finfo(f32).max if upper is None else upper)      # ADC-ranged candidates, no refine
+            out_i = np.full(ci.shape, -1, np.int64); out_d = np.full(ci.shape, np.inf, f32)
+            for i in range(len(qq)):
+                ids = ci[i][ci[i] != none]
+                ex = oracle.distance_batch("l2", qq[i], x[ids.astype(np.int64)]) if len(ids) else np.empty(0, f32)
+                si, sd = oracle.sort_fetch(ids, ex, len(ids))
+                out_i[i, :len(si)] = si.astype(np.int64); out_d[i, :len(sd)] = sd
+            return torch.from_numpy(out_i), torch.from_numpy(out_d)
+
+    for k, nprobes, rf, (a, b) in ((10, 4, 4, (lo, hi)), (5, nlist, 6, (None, hi)), (8, 3, 2, (lo, None)), (4, 4, 3, (hi, hi))):
+        gi, gd = DeviceIndex.search_range(Stub(), q, k, nprobes, a, b, refine_factor=rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, lower=np.finfo(f32).min if a is None else a,
+                             upper=np.finfo(f32).max if b is None else b)
+        assert np.array_equal(gi.numpy().view(np.uint64), oi), (k, nprobes, rf)
+        assert np.array_equal(gd.numpy().view(np.uint32), od.view(np.uint32))
