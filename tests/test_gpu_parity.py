@@ -774,6 +774,40 @@ def test_gpu_reproduces_what_the_reference_stored(eng, oracle):
         assert (_np(codes) == z[f"codes{k}"]).all()
 
 
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_distance_range_search(eng, oracle, metric):
+    """`nearest={..., "distance_range": (lower, upper)}`: inside each probed partition only rows with lower <= d < upper
+    enter the k-heap (flat/index.rs:98-113; v2.rs distance-range tests).  Batched form of what lance_hip_pq_scan_topk
+    does for one partition; large batches leave the partition-major path for the query-major kernel."""
+    from lance_amd.vector import IvfPqIndex, IvfPqParams
+    n, d, nlist, m = 20000, 64, 24, 8
+    x = sift_like(n, d, 141)
+    oidx, gidx = _build_pair(eng, oracle, x, nlist, m, metric)
+    ix = IvfPqIndex(gidx, IvfPqParams(nlist, m, 8, metric))
+    for nq in (40, 600):                               # 600 x 8 probes >= 4096 pairs: would take the PM path without a range
+        q = sift_like(nq, d, 142 + nq)
+        _, ud = oidx.search(q, 60, 8)
+        fin = ud[np.isfinite(ud)]
+        lo, hi = float(np.quantile(fin, 0.2)), float(np.quantile(fin, 0.6))
+        for k, nprobes, rng_ in ((10, 8, (lo, hi)), (10, 8, (None, hi)), (25, 3, (lo, None)), (5, nlist, (hi, hi))):
+            gi, gd = ix.nearest(q, k, nprobes, distance_range=rng_)
+            oi, od = oidx.search(q, k, nprobes, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
+                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
+            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rng_)
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+        # with refine: ADC range in the partitions, exact re-rank of the k * rf candidates, exact distances filtered by the
+        # same range before the fetch (scanner.rs:3334-3377) -- exact L2 / dot distances live on another scale than the
+        # ADC ones, so take the bounds from the exact neighbourhood
+        _, ed = oracle.flat_knn(x, q, 40, metric)
+        elo, ehi = float(np.quantile(ed, 0.1)), float(np.quantile(ed, 0.9))
+        for k, nprobes, rf, rng_ in ((10, 8, 4, (elo, ehi)), (5, nlist, 10, (None, ehi))):
+            gi, gd = ix.nearest(q, k, nprobes, refine_factor=rf, distance_range=rng_)
+            oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
+                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
+            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rf, rng_)
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+
+
 def test_load_reference_written_index_and_search(eng, oracle):
     """An index directory written by real Lance (tests/golden/ref_index.npz, 512 x 32, IVF1,PQ4) goes files -> HBM through
     lance_hip_index_load and answers queries exactly as the oracle does on the same stored model (the oracle's encode of
@@ -927,40 +961,6 @@ def test_load_list_shard_world1(eng, oracle, tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("metric", ["l2", "dot"])
-def test_distance_range_search(eng, oracle, metric):
-    """`nearest={..., "distance_range": (lower, upper)}`: inside each probed partition only rows with lower <= d < upper
-    enter the k-heap (flat/index.rs:98-113; v2.rs distance-range tests).  Batched form of what lance_hip_pq_scan_topk
-    does for one partition; large batches leave the partition-major path for the query-major kernel."""
-    from lance_amd.vector import IvfPqIndex, IvfPqParams
-    n, d, nlist, m = 20000, 64, 24, 8
-    x = sift_like(n, d, 141)
-    oidx, gidx = _build_pair(eng, oracle, x, nlist, m, metric)
-    ix = IvfPqIndex(gidx, IvfPqParams(nlist, m, 8, metric))
-    for nq in (40, 600):                               # 600 x 8 probes >= 4096 pairs: would take the PM path without a range
-        q = sift_like(nq, d, 142 + nq)
-        _, ud = oidx.search(q, 60, 8)
-        fin = ud[np.isfinite(ud)]
-        lo, hi = float(np.quantile(fin, 0.2)), float(np.quantile(fin, 0.6))
-        for k, nprobes, rng_ in ((10, 8, (lo, hi)), (10, 8, (None, hi)), (25, 3, (lo, None)), (5, nlist, (hi, hi))):
-            gi, gd = ix.nearest(q, k, nprobes, distance_range=rng_)
-            oi, od = oidx.search(q, k, nprobes, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
-                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
-            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rng_)
-            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
-        # with refine: ADC range in the partitions, exact re-rank of the k * rf candidates, exact distances filtered by the
-        # same range before the fetch (scanner.rs:3334-3377) -- exact L2 / dot distances live on another scale than the
-        # ADC ones, so take the bounds from the exact neighbourhood
-        _, ed = oracle.flat_knn(x, q, 40, metric)
-        elo, ehi = float(np.quantile(ed, 0.1)), float(np.quantile(ed, 0.9))
-        for k, nprobes, rf, rng_ in ((10, 8, 4, (elo, ehi)), (5, nlist, 10, (None, ehi))):
-            gi, gd = ix.nearest(q, k, nprobes, refine_factor=rf, distance_range=rng_)
-            oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
-                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
-            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rf, rng_)
-            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("world", [2, 3])
