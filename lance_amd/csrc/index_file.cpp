@@ -559,7 +559,11 @@ struct DevTmp {   // device staging freed on scope exit
     void *p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) IO_FAIL(LANCE_HIP_ENOMEM, "index_load: hipMalloc(%zu) failed", bytes);
     ptrs.push_back(p);
-    constexpr size_t kChunk = (size_t)64 << 20;
+    size_t kChunk = (size_t)64 << 20;
+    if (const char *e = getenv("LANCE_HIP_STAGE_CHUNK")) {   // tests: many small chunks
+      const unsigned long long ov = strtoull(e, nullptr, 10);
+      if (ov) kChunk = (size_t)ov;
+    }
     for (size_t off = 0; off < bytes; off += kChunk) {
       const size_t nb = std::min(kChunk, bytes - off);
       void *stage = ctx->host_staging(nb);
