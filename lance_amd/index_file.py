@@ -136,3 +136,26 @@ def read_column(path, column, dtype, width=1) -> np.ndarray:
     _lib.check(lib.lance_hip_file_read_column(os.fspath(path).encode(), column.encode(), out.ctypes.data_as(C.c_void_p),
                                               out.nbytes, None, None))
     return out
+
+
+def describe(index_dir) -> dict:
+    """Summary of an index directory (host-only): what `python -m lance_amd.index_file <dir>` prints."""
+    c = read_index_files(index_dir)
+    lens = np.diff(c.part_offsets.astype(np.int64))
+    out = {
+        "index_type": c.index_type, "metric": c.metric, "model_dtype": c.dtype, "dimension": int(c.centroids.shape[1]),
+        "num_partitions": int(c.centroids.shape[0]), "rows": int(len(c.row_ids)), "loss": c.loss,
+        "partition_rows": {"min": int(lens.min()), "max": int(lens.max()), "mean": float(lens.mean()), "empty": int((lens == 0).sum())},
+    }
+    if c.index_type == "IVF_PQ":
+        out.update({"num_sub_vectors": c.num_sub_vectors, "num_bits": c.nbits, "code_bytes_per_row": c.code_bytes,
+                    "codes_transposed": c.transposed, "code_bytes_total": int(c.codes.size)})
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    if len(sys.argv) != 2:
+        sys.exit("usage: python -m lance_amd.index_file <index directory holding index.idx [+ auxiliary.idx]>")
+    print(json.dumps(describe(sys.argv[1]), indent=1))
