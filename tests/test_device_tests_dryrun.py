@@ -57,3 +57,33 @@ def test_dryrun_distance_range(fake, oracle, metric):
 @pytest.mark.parametrize("world", [2, 3])
 def test_dryrun_load_lists_shards(fake, oracle, tmp_path, world):
     G.test_load_lists_shards_on_one_gpu(fake, oracle, tmp_path, world)
+
+
+# ---- tests that HAVE run on hardware but go through host code edited since (create_index argument checks, nearest /
+# ---- flat_knn signatures, IvfFlatIndex construction): a regression there would only show on the GPU box otherwise
+def test_dryrun_python_api_end_to_end(fake, oracle):
+    import lance_amd
+    G.test_python_api_end_to_end(lance_amd, oracle)
+
+
+@pytest.mark.parametrize("metric,d", [("l2", 128), ("dot", 40)])
+def test_dryrun_ivf_flat_matches_oracle(fake, oracle, metric, d):
+    G.test_ivf_flat_matches_oracle(fake, oracle, metric, d)
+
+
+def test_dryrun_list_sharded_world1(fake, oracle):
+    G.test_list_sharded_search_on_device_world1(fake, oracle)
+
+
+def test_dryrun_smoke_flow(fake, oracle):
+    """the calls __graft_entry__.smoke() makes, in the same order"""
+    import numpy as np
+    import lance_amd
+    rng = np.random.default_rng(0)
+    centers = rng.uniform(0, 128, (16, 32))
+    x = np.clip(np.rint(centers[rng.integers(0, 16, 8000)] + rng.normal(0, 20, (8000, 32))), 0, 218).astype(np.float32)
+    q = x[:64] + 1.0
+    idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=16, num_sub_vectors=4, max_iters=8)
+    ids, dists = idx.nearest(q, k=10, nprobes=16)
+    oi, od = oracle.build_index(x, idx.centroids, idx.codebook).search(q, 10, 16)
+    assert (ids.view(np.uint64) == oi).all() and (dists.view(np.uint32) == od.view(np.uint32)).all()
