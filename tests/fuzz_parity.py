@@ -3,10 +3,12 @@
     python tests/fuzz_parity.py [seconds] [seed]
 
 Every case builds an IVF_PQ index from oracle-trained models, then compares encode output, storage layout, searches
-(random k / nprobes / refine), the flat scan and IVF_FLAT, bit for bit.  Prints the failing configuration and exits 1.
+(random k / nprobes / refine), distance ranges, row-id prefilters, a save -> load round trip through the index files, the
+flat scan and IVF_FLAT, bit for bit.  Prints the failing configuration and exits 1.
 """
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -22,6 +24,7 @@ def main():
     import torch
     import oracle
     from lance_amd.engine import Engine, DeviceIndex, DeviceFlatIndex
+    from lance_amd.vector import IvfPqIndex, IvfPqParams
     eng = Engine()
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
@@ -73,6 +76,29 @@ def main():
                 oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
                 assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
                 assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
+            # distance range (no refine) and, for 8-bit codes, a row-id prefilter -- against the oracle's restatements
+            k = int(rng.integers(1, 40)); nprobes = int(rng.integers(1, nlist + 1))
+            _, ud = oidx.search(q, 50, nprobes)
+            fin = ud[np.isfinite(ud)]
+            if fin.size > 10:
+                lo, hi = float(np.quantile(fin, 0.25)), float(np.quantile(fin, 0.7))
+                gi, gd = g.search_range(qg, k, nprobes, lo, hi)
+                oi, od = oidx.search(q, k, nprobes, lower=lo, upper=hi)
+                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"range k={k} nprobes={nprobes}"
+            if nbits == 8:
+                allow = rng.random(n) < float(rng.choice([0.05, 0.5, 0.95]))
+                vi = IvfPqIndex(g, IvfPqParams(nlist, m, 8, metric), None, gpart, gcodes)
+                gi, gd = vi.nearest(qg, k, nprobes, prefilter=allow)
+                oi, od = oidx.search(q, k, nprobes, prefilter=allow)
+                assert (gi.view(np.uint64) == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), f"prefilter k={k} nprobes={nprobes}"
+            # files: HBM -> index.idx + auxiliary.idx -> HBM answers the same (f32 / int8 columns)
+            if ncase % 4 == 0:
+                with tempfile.TemporaryDirectory() as tdir:
+                    g.save(tdir, loss=1.0)
+                    g2 = DeviceIndex.load(eng, tdir, dtype="int8" if int8 else None, raw=xg)
+                    a = g.search(qg, k, nprobes); b = g2.search(qg, k, nprobes)
+                    assert (a[0] == b[0]).all() and (a[1].cpu().numpy().view(np.uint32) == b[1].cpu().numpy().view(np.uint32)).all(), "save/load"
+                    g2.close()
             k = int(rng.integers(1, 40))
             gi, gd = eng.flat_topk(xg, qg, k, metric)
             oi, od = oracle.flat_knn(x, q, k, metric)

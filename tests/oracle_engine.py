@@ -157,6 +157,9 @@ class OracleDeviceIndex:
     def set_raw(self, raw):
         self._raw = cpu_to_device(raw).to(self.data_dtype)
 
+    def close(self):
+        pass
+
     def info(self):
         return {"n": int(self.o.row_ids.size), "nlist": int(self.o.centroids.shape[0]), "m": int(self.o.codebook.shape[0]),
                 "d": int(self.o.centroids.shape[1])}
@@ -208,6 +211,9 @@ class OracleDeviceFlatIndex:
         index_file.write_index_files(index_dir, index_file.IndexFileContents(
             index_type="IVF_FLAT", metric=self.metric, dtype="float32", centroids=_np(self.centroids).astype(f32), part_offsets=offs,
             row_ids=self.rid[perm], vectors=self.x[perm].astype(f32), loss=loss))
+
+    def close(self):
+        pass
 
     def search(self, q, k, nprobes):
         # the stored partition of every row is authoritative (it may come from a file or carry a prefilter's holes)
