@@ -443,8 +443,9 @@ class DeviceIndex:
         if refine_factor and refine_factor > 0:
             keff = k * refine_factor
             ci, cd = self.search_range(q, keff, nprobes, lower, upper, refine_factor=-1)       # -1: re-rank, keep all
-            lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
-            hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
+            # the bounds are f32 values in the reference (Query::lower_bound: Option<f32>): round before comparing
+            lo = float(np.finfo(np.float32).min) if lower is None else float(np.float32(lower))
+            hi = float(np.finfo(np.float32).max) if upper is None else float(np.float32(upper))
             ok = (ci >= 0) & (cd >= lo) & (cd < hi)
             # first k in-range entries of every row, order kept (the device returned them sorted by (distance, row id))
             rank = torch.cumsum(ok.to(torch.int64), dim=1) - 1
@@ -461,8 +462,8 @@ class DeviceIndex:
         nq = q.shape[0]
         ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
         dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
-        lo = float(np.finfo(np.float32).min) if lower is None else float(lower)
-        hi = float(np.finfo(np.float32).max) if upper is None else float(upper)
+        lo = float(np.finfo(np.float32).min) if lower is None else float(np.float32(lower))
+        hi = float(np.finfo(np.float32).max) if upper is None else float(np.float32(upper))
         torch.cuda.synchronize()
         check(self.engine.lib.lance_hip_ivfpq_search_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes, 1 if refine_factor == -1 else 0,
                                                            lo, hi, _ptr(ids), _ptr(dists)))
