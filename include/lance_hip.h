@@ -290,6 +290,11 @@ int lance_hip_file_read_column(const char *path, const char *column, void *dst, 
  * query returns accumulated milliseconds and launch count, then resets.              */
 int lance_hip_timing_enable(lance_hip_ctx *ctx, int on);
 int lance_hip_timing_query(lance_hip_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches);
+/* Ceilings measured in-process for bench.py's roofline denominators (no reference counterpart; SURVEY 8(d) asks for
+ * peaks "re-measured on the box").  what: 0 / 1 / 2 = random LDS gathers of 4 / 8 / 16-byte PQ-LUT entries, result in
+ * lane-gathers per second; 3 = device copy, bytes (read + written) per second; 4 / 5 = v_add_f32 / v_pk_add_f32
+ * wave-instructions per second.                                                                                    */
+int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ SYMBOLS = [
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search",
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
     "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
-    "lance_hip_timing_enable", "lance_hip_timing_query",
+    "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench",
 ]
 
 
@@ -122,6 +122,7 @@ def load():
         "lance_hip_file_read_column": (i32, [C.c_char_p, C.c_char_p, vp, u64, C.POINTER(u64), C.POINTER(u32)]),
         "lance_hip_timing_enable": (i32, [vp, i32]),
         "lance_hip_timing_query": (i32, [vp, C.c_char_p, C.POINTER(f64), C.POINTER(u64)]),
+        "lance_hip_ubench": (i32, [vp, i32, C.POINTER(f64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -37,6 +37,9 @@ namespace lh {
 #ifndef LH_PM_BS
 #define LH_PM_BS 512
 #endif
+#ifndef LH_PM_STATIC_LUT
+#define LH_PM_STATIC_LUT 0
+#endif
 constexpr int PM_BS = LH_PM_BS;            // lanes per workgroup (512: 3 workgroups x 8 waves per CU)
 constexpr int PM_CAP = PM_BS + 256;        // candidate buffer entries per query, pruned class (one round + slack)
 constexpr int PM_CAP_BOUND = 16;           // the bound pass keeps no candidates: its LDS is the LUT pair only (4 workgroups per CU)
@@ -211,8 +214,15 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   const int dpad = (p.d + 3) & ~3;
   float *r0 = reinterpret_cast<float *>(smem);
   float *r1 = r0 + dpad;
+#if LH_PM_STATIC_LUT
+  // [m][256] pairs in STATIC LDS: its base is a compile-time constant, so the gather address is one SDWA shift of the
+  // code byte plus an immediate offset instead of bfe + lshl_add(base SGPR) (scripts/ubench/scan_addr.hip)
+  __shared__ __attribute__((aligned(16))) f2 lut2[m * 256];
+  uint32_t *ck0 = reinterpret_cast<uint32_t *>(r1 + dpad);
+#else
   f2 *lut2 = reinterpret_cast<f2 *>(r1 + dpad);  // [m][256] pairs
   uint32_t *ck0 = reinterpret_cast<uint32_t *>(lut2 + m * 256);
+#endif
   uint32_t *cp0 = ck0 + CAP;
   uint32_t *ck1 = cp0 + CAP;
   uint32_t *cp1 = ck1 + CAP;
@@ -639,7 +649,11 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const int dpad = (d + 3) & ~3;
+#if LH_PM_STATIC_LUT
+  const size_t lds_base = (size_t)dpad * 8 + PM_BS * 4 + 8 * 4;   // the LUT pair table is static LDS
+#else
   const size_t lds_base = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4;
+#endif
   {
     // pass 0 (bound): every query's nearest partition is streamed once to seed Tglobal[q]; pass 1 (main): all
     // (query, probe) pairs, nearest partition included, prune with that bound from their first row.

@@ -262,6 +262,14 @@ class Engine:
         return ms.value, n.value
 
 
+    def ubench(self, what):
+        """in-process ceilings for bench.py (lance_hip_ubench): "lds4" / "lds8" / "lds16" lane-gathers per second,
+        "copy" bytes per second, "valu" / "valu_pk" f32 wave-instructions per second"""
+        r = C.c_double(0)
+        check(self.lib.lance_hip_ubench(self.h, {"lds4": 0, "lds8": 1, "lds16": 2, "copy": 3, "valu": 4, "valu_pk": 5}[what], C.byref(r)))
+        return r.value
+
+
 class DeviceFlatIndex:
     """Handle of a device-resident IVF_FLAT index (FlatIndex sub-index over the raw vectors of each partition)."""
 

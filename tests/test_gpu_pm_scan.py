@@ -1,0 +1,237 @@
+"""GPU parity of the PARTITION-MAJOR ADC scan (search_pm.hip) -- the kernel the bench times.
+
+The engine takes the partition-major path when `nq * nprobes >= 4096` and the shape is one it supports
+(M in {16, 32}, sub-dimension in {4, 8, 16}, 8-bit codes, k * refine <= 128).  Every case here is sized to take it
+and ASSERTS that it did (the `ivfpq_scan_c1` timer counts main-pass launches), then compares ids and distances
+with the CPU oracle bit for bit.  Covers every template instantiation of the scan: sub-dimension 4 / 8 / 16 x
+L2 / dot x M 16 / 32, the cosine route (normalise + L2), f16 columns (`round_f16` residuals, the C4 shape at reduced N),
+int8 columns (C5 shape: M = 32), refine on / off, the two-class flow (LANCE_HIP_PM_NOBOUND=1) and the overflow ->
+exact-replay path (more rows tied at the bound inside one partition than a candidate buffer holds).
+
+Reference behaviour matched: pq/distance.rs:109-144 (sequential-m ADC sum), flat/index.rs:94-126 (per-partition heap,
+earlier row wins ties), scanner.rs:3440-3468 ((dist, rowid) merge), v2.rs:316-332 (residual query).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def eng(engine):
+    from lance_amd.engine import Engine
+    e = Engine()
+    yield e
+    e.close()
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def clustered(n, d, seed, ncl=48, lo=0.0, hi=128.0, sigma=20.0, integer=True):
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(lo, hi, (ncl, d))
+    x = centers[rng.integers(0, ncl, n)] + rng.normal(0, sigma, (n, d))
+    if integer:
+        x = np.clip(np.rint(x), 0, 218)
+    return x.astype(f32)
+
+
+def _models(oracle, x, nlist, m, metric, seed):
+    xs = oracle.normalize(x) if metric == "cosine" else x
+    km = "l2" if metric == "cosine" else metric
+    cent, _, _, _ = oracle.kmeans_train(xs[: nlist * 48], nlist, max_iters=6, seed=seed, metric=km)
+    part, _ = oracle.assign(xs, cent, km)
+    res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
+    cb, _ = oracle.pq_train(res[: 256 * 24], m, max_iters=4, seed=seed + 1)
+    return cent, cb
+
+
+class _pm_used:
+    """context manager: the searches inside must have launched the partition-major main pass"""
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def __enter__(self):
+        self.eng.timing(True)
+        self.before = self.eng.timing_query("ivfpq_scan_c1")[1]
+        return self
+
+    def __exit__(self, *a):
+        self.eng.synchronize()
+        after = self.eng.timing_query("ivfpq_scan_c1")[1]
+        self.eng.timing(False)
+        if a[0] is None:
+            assert after > self.before, "the partition-major scan was not taken (nq * nprobes < 4096 or unsupported shape?)"
+
+
+def _check(eng, oracle, gidx, oidx, qg, q, raw, cases):
+    for k, nprobes, rf in cases:
+        with _pm_used(eng):
+            gi, gd = gidx.search(qg, k, nprobes, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=raw if rf else None)
+        bad = np.nonzero((_np(gi).view(np.uint64) != oi).any(axis=1))[0]
+        assert bad.size == 0, f"ids differ for {bad.size} queries (first {bad[:5]}) at k={k} nprobes={nprobes} refine={rf}"
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all(), (k, nprobes, rf)
+
+
+# (d, M): sub-dimension 4 / 8 / 16 with M = 16 (MU = 1) and M = 32 (MU = 2)
+PM_SHAPES = [(64, 16), (128, 16), (256, 16), (128, 32), (256, 32), (512, 32)]
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
+@pytest.mark.parametrize("d,m", PM_SHAPES)
+def test_pm_scan_f32_every_instantiation(eng, oracle, d, m, metric):
+    from lance_amd.engine import DeviceIndex
+    n, nlist, nq = 24000, 32, 640
+    x = clustered(n, d, 100 + d + m) + (1.0 if metric == "cosine" else 0.0)
+    q = clustered(nq, d, 200 + d + m) + (1.0 if metric == "cosine" else 0.0)
+    cent, cb = _models(oracle, x, nlist, m, metric, seed=d + m)
+    oidx = oracle.build_index(x, cent, cb, metric)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all() and (_np(gcodes) == oidx.codes_rowmajor).all()
+    gidx = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+    # nq * nprobes >= 4096 in every case: 640 x 7 = 4480
+    _check(eng, oracle, gidx, oidx, q, q, x, [(10, 8, 0), (10, 8, 10), (10, nlist, 0), (100, 7, 0), (1, 7, 1), (37, 9, 3)])
+    gidx.close()
+
+
+@pytest.mark.parametrize("d,m", [(128, 16), (128, 32)])
+def test_pm_scan_f16_column_c4_shape(eng, oracle, d, m):
+    """C4 shape at reduced N: f16 vectors, L2, nlist = 4096 (hierarchically trained in the reference; here the centroids are
+    sampled rows, which exercises the same scan), M = 16; the residual query is rounded to f16 (`round_f16`)."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(9)
+    n, nlist, nq = 60000, 4096, 512
+    c = rng.standard_normal((64, d)) * 2
+    x = (c[rng.integers(0, 64, n)] + rng.standard_normal((n, d)) * 0.7).astype(np.float16)
+    q = (c[rng.integers(0, 64, nq)] + rng.standard_normal((nq, d)) * 0.7).astype(np.float16)
+    cent = x[rng.choice(n, nlist, replace=False)].copy()
+    part, _ = oracle.assign(x, cent)
+    res = oracle.residual(x, cent, part)
+    cb, _ = oracle.pq_train(res[:8192], m, max_iters=4, seed=2)
+    oidx = oracle.build_index(x, cent, cb)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb)
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all() and (_np(gcodes) == oidx.codes_rowmajor).all()
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    _check(eng, oracle, gidx, oidx, q, q, x.astype(f32), [(10, 10, 0), (10, 10, 10), (10, 64, 0), (50, 8, 2)])
+    gidx.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_pm_scan_int8_column_c5_shape(eng, oracle, metric):
+    """C5 shape at reduced N: int8 vectors (model kept in f32), d = 128, M = 32 (sub-dimension 4, MU = 2)."""
+    import torch
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(12)
+    n, d, nlist, m, nq = 40000, 128, 64, 32, 600
+    centers = rng.integers(-90, 90, (80, d))
+    x8 = np.clip(centers[rng.integers(0, 80, n)] + rng.normal(0, 14, (n, d)), -128, 127).astype(np.int8)
+    q8 = np.clip(centers[rng.integers(0, 80, nq)] + rng.normal(0, 14, (nq, d)), -128, 127).astype(np.int8)
+    xf, qf = x8.astype(f32), q8.astype(f32)
+    cent, cb = _models(oracle, xf, nlist, m, metric, seed=3)
+    oidx = oracle.build_index(xf, cent, cb, metric=metric)
+    part, codes, _ = eng.ivfpq_encode(torch.from_numpy(x8), cent, cb, metric)
+    assert (_np(part).view(np.uint32) == oidx.part_ids).all() and (_np(codes) == oidx.codes_rowmajor).all()
+    g = DeviceIndex.create(eng, metric, cent, cb, part, codes, None, raw=torch.from_numpy(x8), dtype="int8")
+    _check(eng, oracle, g, oidx, torch.from_numpy(q8), qf, xf, [(10, 8, 0), (10, 8, 10), (10, nlist, 0), (64, 7, 2)])
+    g.close()
+
+
+@pytest.mark.parametrize("d,m,metric", [(128, 16, "l2"), (128, 32, "dot"), (256, 16, "l2")])
+def test_pm_scan_two_class_flow(eng, oracle, d, m, metric):
+    """LANCE_HIP_PM_NOBOUND=1: the earlier flow (class 0 = nearest partition scanned with candidate selection, class 1 = the
+    rest) -- the <.., RPL=1, PM_CAP> class-0 and class-1 instantiations."""
+    from lance_amd.engine import DeviceIndex
+    n, nlist, nq = 20000, 24, 600
+    x = clustered(n, d, 7 + d)
+    q = clustered(nq, d, 8 + d)
+    cent, cb = _models(oracle, x, nlist, m, metric, seed=5)
+    oidx = oracle.build_index(x, cent, cb, metric)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+    gidx = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+    os.environ["LANCE_HIP_PM_NOBOUND"] = "1"
+    try:
+        _check(eng, oracle, gidx, oidx, q, q, x, [(10, 8, 0), (10, 8, 10), (100, nlist, 0)])
+    finally:
+        del os.environ["LANCE_HIP_PM_NOBOUND"]
+    gidx.close()
+
+
+@pytest.mark.parametrize("ndup", [400, 1500])
+def test_pm_scan_overflow_goes_to_exact_replay(eng, oracle, ndup):
+    """More rows tied at the k-th distance inside ONE partition than the candidate buffers hold: the partition-major scan
+    must flag those queries and the exact kernel must replay them through the BinaryHeap emulation (flat/index.rs:94-126:
+    which of the tied rows survive depends on heap order).  `ndup` copies of one vector share a code, hence a distance."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(4)
+    n, d, nlist, m, nq = 16000, 128, 16, 16, 512
+    x = clustered(n, d, 21, ncl=16)
+    hot = x[5].copy()
+    pos = rng.choice(np.arange(100, n), ndup, replace=False)
+    x[pos] = hot                                  # ndup identical rows, scattered over the input order
+    q = clustered(nq, d, 22, ncl=16)
+    q[: nq // 2] = hot + rng.integers(-1, 2, (nq // 2, d)).astype(f32)     # half the queries sit on the duplicated vector
+    cent, cb = _models(oracle, x, nlist, m, "l2", seed=6)
+    oidx = oracle.build_index(x, cent, cb)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb)
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    replays = 0
+    for k, nprobes, rf in ((10, 8, 0), (10, 8, 10), (100, nlist, 0)):
+        with _pm_used(eng):
+            gi, gd = gidx.search(q, k, nprobes, rf)
+        replays += eng.search_stats()
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        assert (_np(gi).view(np.uint64) == oi).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    assert replays > 0, "no query was replayed by the exact kernel: the tie case was not exercised"
+    gidx.close()
+
+
+def test_pm_scan_random_shapes(eng, oracle):
+    """The randomised differential run of tests/fuzz_parity.py restricted to shapes and batch sizes that take the
+    partition-major path (>= 256 queries, nq * nprobes >= 4096)."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(1)
+    for case in range(10):
+        sd = int(rng.choice([4, 8, 16]))
+        m = int(rng.choice([16, 32]))
+        d = m * sd
+        n = int(rng.integers(3000, 30000))
+        nlist = int(rng.integers(1, 48))
+        metric = str(rng.choice(["l2", "dot", "cosine"]))
+        integer = bool(rng.integers(0, 2))
+        if integer:
+            x = rng.integers(0, 30, (n, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
+            q = rng.integers(0, 30, (512, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
+        else:
+            x = (rng.standard_normal((n, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
+            q = (rng.standard_normal((512, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
+        xs = oracle.normalize(x) if metric == "cosine" else x
+        km = "l2" if metric == "cosine" else metric
+        cent, _, _, _ = oracle.kmeans_train(xs[: max(nlist * 32, nlist)], nlist, max_iters=4, seed=case, metric=km)
+        part, _ = oracle.assign(xs, cent, km)
+        res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
+        cb, _ = oracle.pq_train(res[: 256 * 8], m, max_iters=3, seed=case + 1)
+        oidx = oracle.build_index(x, cent, cb, metric)
+        gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+        g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+        for _ in range(3):
+            nprobes = int(rng.integers(1, nlist + 1))
+            nq = max(256, -(-4096 // nprobes))
+            qq = np.concatenate([q] * (-(-nq // 512)))[:nq]
+            k = int(rng.integers(1, 60)); rf = int(rng.choice([0, 0, 1, 3]))
+            if k * max(rf, 1) > 128:
+                rf = 0
+            cfg = dict(case=case, n=n, d=d, m=m, nlist=nlist, metric=metric, integer=integer, k=k, nprobes=nprobes, rf=rf, nq=nq)
+            with _pm_used(eng):
+                gi, gd = g.search(qq, k, nprobes, rf)
+            oi, od = oidx.search(qq, k, nprobes, refine=rf, raw=x if rf else None)
+            assert (_np(gi).view(np.uint64) == oi).all(), cfg
+            assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all(), cfg
+        g.close()
