@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
+LDS_B64_CONFLICT_FREE_PER_CLK_CU = 32.0   # MI355X_MICROARCH.md, LDS table: ds_read_b64 = 2 cycles per wave-instruction
 
 
 def main():
@@ -175,25 +176,37 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     qps = world * args.nq * args.steps / elapsed
-    if kt["ivfpq_scan_c1"][1] > 0:      # partition-major path: dominant launch = class 1
+    quantised = kt["ivfpq_scan_c1"][1] > 0 and not os.environ.get("LANCE_HIP_NO_QSCAN") and not os.environ.get("LANCE_HIP_PM_NOBOUND")
+    if kt["ivfpq_scan_c1"][1] > 0:      # partition-major path: dominant launch = the main pass
         scan_ms, scan_launches = kt["ivfpq_scan_c1"]
-        if os.environ.get("LANCE_HIP_PM_NOBOUND"):
+        if quantised:
+            bytes_list = scan_bytes
+            kernel_name = "ivfpq_qscan_kernel<SD=8,MU=1> (main pass: 4-query u16 filter scan of all nprobes partitions)"
+            queries_per_gather = 4
+        elif os.environ.get("LANCE_HIP_PM_NOBOUND"):
             bytes_list, kernel_name = scan_bytes_c1, "ivfpq_scan_pm_kernel<SD=8,L2,MU=1,RPL=2> (class-1 launch: the nprobes-1 farther partitions)"
+            queries_per_gather = 2
         else:
             bytes_list, kernel_name = scan_bytes, "ivfpq_scan_pm_kernel<SD=8,L2,MU=1,RPL=2> (main pass: all nprobes partitions of every query)"
+            queries_per_gather = 2
     else:
         scan_ms, scan_launches = kt["ivfpq_scan"]
         bytes_list, kernel_name = scan_bytes, "ivfpq_scan_kernel<SD=8,L2,MU=1>"
+        queries_per_gather = 1
     avg_scan_ms = scan_ms / max(scan_launches, 1)
     avg_bytes = float(np.mean([bytes_list[i % 4] for i in range(args.steps)]))
-    achieved = avg_bytes / (avg_scan_ms * 1e-3) / 1e9 if avg_scan_ms > 0 else 0.0
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_scan_pmc.json")   # rocprofv3 --pmc summary of this same command (committed)
-    if os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # The scan's binding resource is the LDS gather (with the VALU issue slots next to it), NOT HBM: partition-major order
+    # keeps the 16 MB code table in L2 (rocprofv3 FETCH/WRITE: 4 % of HBM peak, profiles/).  Roofline unit = lane-gathers:
+    # one (row, sub-quantiser) table lookup serving `queries_per_gather` queries.  Algorithmic gathers per launch =
+    # sum over (query, probe) pairs of n_p * M / queries_per_gather; peak = the random-gather rate of the same table shape
+    # ([16][256] entries of 8 bytes) measured IN THIS RUN by lance_hip_ubench.
+    lut_values = avg_bytes                     # n_p * M summed over pairs: one LUT value per (row, sub-quantiser, query)
+    gathers = lut_values / queries_per_gather
+    gather_rate = gathers / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0
+    ceil_key = {1: "lds4", 2: "lds8", 4: "lds8"}[queries_per_gather]
+    ceiling = eng.ubench(ceil_key)
+    copy_bw = eng.ubench("copy")
+    hbm_equiv = avg_bytes / (avg_scan_ms * 1e-3) / 1e9 if avg_scan_ms > 0 else 0.0
 
     result = {
         "metric": "QPS @ recall@10 (SIFT-1M IVF_PQ nlist=256 M=16) + index-build sec",
@@ -218,9 +231,17 @@ def main():
         "build_sec": build_sec,
         "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
         "kernel_ms_per_step": {k_: round(v[0] / max(v[1], 1), 4) for k_, v in kt.items()},
-        "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_scan_ms},
+        "roofline": {"kernel": kernel_name, "bound": "lds", "achieved": gather_rate / 1e9, "peak": ceiling / 1e9,
+                     "unit": "G lane-gathers/s", "frac": gather_rate / ceiling if ceiling else None, "traffic": None,
+                     "peak_source": f"lance_hip_ubench({ceil_key}): random ds_read_b64 gathers of a [16][256] table, measured in this run",
+                     "queries_per_gather": queries_per_gather,
+                     "lut_values_per_s": lut_values / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0,
+                     "conflict_free_b64_peak_G_per_s": LDS_B64_CONFLICT_FREE_PER_CLK_CU * 256 * 2.4,
+                     "algorithmic_gathers_per_launch": gathers, "avg_launch_ms": avg_scan_ms,
+                     "survey_8d_code_bytes_per_launch": avg_bytes, "survey_8d_byte_rate_GBps": hbm_equiv,
+                     "hbm_peak_GBps": HBM_PEAK_GBS, "device_copy_GBps_measured": copy_bw / 1e9,
+                     "note": "HBM is not the bound (code table is L2-resident); PMC evidence (LDS busy, VALU issue, bank "
+                             "conflicts, FETCH/WRITE) is under profiles/"},
     }
 
     if not args.no_cpu_baseline and world == 1:
@@ -242,16 +263,33 @@ def main():
             reps += 1
         gi, _ = idx.search_device(qbatches[0], args.k, args.nprobes, args.refine)
         same = bool((oi == gi.cpu().numpy().view(np.uint64)).all())
-        # CPU index build on a bounded sample: 3 Lloyd iterations of the IVF k-means on the 65,536-row sample
+        # CPU index build, full (the other half of the metric): sample -> IVF k-means (<= 50 iterations, tol 1e-4) -> residuals
+        # -> 16 PQ k-means -> assign + encode all rows + per-partition layout, mirroring the reference's stage log lines
+        # (ivf.rs:1239-1272, builder.rs:415-466)
+        cpu_build = {}
         samp = raw[: nlist * 256]
         t1 = time.perf_counter()
-        orc.kmeans_train(samp, nlist, max_iters=3, tol=0.0, balance_factor=1.0 / samp.shape[0], seed=1)
-        cpu_iter = (time.perf_counter() - t1) / 3
+        ocent, _, oiters, _ = orc.kmeans_train(samp, nlist, max_iters=50, balance_factor=np.float32(1.0) / np.float32(samp.shape[0]), seed=1)
+        cpu_build["train_ivf"] = time.perf_counter() - t1
+        cpu_iter = cpu_build["train_ivf"] / max(int(oiters), 1)
+        t1 = time.perf_counter()
+        opart, _ = orc.assign(samp, ocent)
+        ores = orc.residual(samp, ocent, opart)
+        ocb, _ = orc.pq_train(ores, m, max_iters=50, seed=2)
+        cpu_build["train_pq"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        orc.build_index(raw, ocent, ocb)
+        cpu_build["transform+partitions"] = time.perf_counter() - t1
+        cpu_build_sec = sum(cpu_build.values())
         result["cpu_baseline"] = {"value": args.nq / best, "unit": "queries/s", "cores": cores, "kind": "port",
                                   "sample": f"the same {args.nq}-query batch, same index/nprobes/refine, best of {reps} runs "
                                             f"of oracle/lance_oracle.c (OpenMP over queries)",
                                   "ids_equal_gpu": same,
                                   "oracle_march": "native" if native else "x86-64-v3",
+                                  "build_sec": cpu_build_sec,
+                                  "build_stages_sec": {k_: round(v, 3) for k_, v in cpu_build.items()},
+                                  "build_sample": "the full build: 65,536-row training sample, 1,000,000 rows encoded",
+                                  "ivf_kmeans_iterations": int(oiters),
                                   "ivf_kmeans_sec_per_iter_65536x128_k256": cpu_iter}
     elif world == 1:
         result["cpu_baseline"] = None

@@ -541,7 +541,9 @@ extern "C" int lance_hip_file_read_column(const char *path, const char *column, 
   if (rows) *rows = col.rows;
   if (row_bytes) *row_bytes = col.row_bytes;
   if (!dst) return LANCE_HIP_OK;
-  LH_REQUIRE(dst_bytes >= col.rows * col.row_bytes, "file_read_column: destination holds %llu bytes, column needs %llu", (unsigned long long)dst_bytes, (unsigned long long)(col.rows * col.row_bytes));
+  uint64_t need = 0;
+  LH_REQUIRE(!__builtin_mul_overflow(col.rows, (uint64_t)col.row_bytes, &need), "file_read_column: column size overflows");
+  LH_REQUIRE(dst_bytes >= need, "file_read_column: destination holds %llu bytes, column needs %llu", (unsigned long long)dst_bytes, (unsigned long long)need);
   if (!r->read_rows((size_t)c, 0, col.rows, dst, &err)) IO_FAIL(LANCE_HIP_EIO, "file_read_column: %s", err.c_str());
   return LANCE_HIP_OK;
 }

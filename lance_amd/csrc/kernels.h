@@ -55,6 +55,9 @@ struct FlatPool {
 int launch_wide_filter(lance_hip_ctx *ctx, const FlatPool &fp, int d, int metric);   // wide.hip, any d
 
 int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
+// bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
+bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
+int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);
 int launch_dist_matrix(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
 
 int stable_group(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n, int64_t id_stride, int k, int batches,
@@ -82,5 +85,20 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
                         uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
+
+// quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
+constexpr int QSCAN_SEG_CAP = 256;   // survivors kept per (query, probe)
+struct SelectOut;
+bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
+int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys);
+int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
+                uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
+                uint32_t max_items4);
+int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
+                 const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
+                 uint32_t *seg_pos, uint32_t *qovf);
+int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
+                  const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
+                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o);
 
 }  // namespace lh

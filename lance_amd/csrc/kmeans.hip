@@ -144,37 +144,136 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
   out[(int64_t)b * out_batch_stride + g] = x[(int64_t)idx[(int64_t)b * k + c] * ldx + (int64_t)b * x_batch_off + dim];
 }
 
-// split_clusters (kmeans.rs:174-207), host side on the (rare) iteration that has an empty cluster.
-static void split_clusters_host(size_t n, std::vector<uint64_t> &cnts, float *centroids, size_t dim, Rng &rng, bool f16) {
-  auto R = [f16](float v) { return f16 ? round_f16_host(v) : v; };
-  const size_t k = cnts.size();
-  const float eps = 1.0f / 1024.0f;
-  for (size_t i = 0; i < k; i++) {
-    if (cnts[i] == 0) {
-      // The reference's rejection loop (kmeans.rs:184-192) never terminates when no cluster has >= 2 members
-      // (all p <= 0: e.g. every distance NaN after an f16 M-step overflow).  Stop splitting instead of hanging.
-      bool splittable = false;
-      for (size_t c = 0; c < k; c++) if (cnts[c] >= 2) { splittable = true; break; }
-      if (!splittable) return;
-      size_t j = 0;
-      for (;;) {
-        const float p = ((float)cnts[j] - 1.0f) / (float)(n - k);
-        if (rng.next_f32() < p) break;
-        j += 1;
-        j %= k;
-      }
-      cnts[i] = cnts[j] / 2;
-      cnts[j] -= cnts[i];
-      for (size_t t = 0; t < dim; t++) {
-        if (t % 2 == 0) {
-          centroids[i * dim + t] = R(centroids[j * dim + t] * (1.0f + eps));
-          centroids[j * dim + t] = R(centroids[j * dim + t] * (1.0f - eps));
-        } else {
-          centroids[i * dim + t] = R(centroids[j * dim + t] * (1.0f - eps));
-          centroids[j * dim + t] = R(centroids[j * dim + t] * (1.0f + eps));
+// ---- per-iteration control on the device -------------------------------------------------------------------------
+// Everything train_kmeans does between two E-steps besides the sums -- cluster sizes and the largest cluster
+// (compute_cluster_sizes :210-232), the balance factor update and loss (:234-237, :680-704), the empty-cluster split
+// (split_clusters :174-207, same RNG stream as the oracle), the convergence test (:704) and the next iteration's bias --
+// runs in one small workgroup per problem, so the Lloyd loop needs no host round trip per iteration.  The scalar chains
+// (f64 loss sum in cluster order, the running-max rule, the split's rejection loop) are executed by lane 0 in the
+// reference's order; only order-free work (sizes, sum of squares, bias) is spread over the lanes.
+struct KmState {
+  double loss, last_loss;
+  float adjusted, bf_used;
+  uint32_t iters, pad;
+  Rng rng;
+};
+
+struct KmCtl {
+  KmState *state;               // [B]
+  uint8_t *active;              // [B]
+  const uint32_t *starts;       // [B][k+1]
+  const double *losses;         // [B][k]
+  const float *radius;          // [B][k]
+  const uint32_t *last_row;     // [B][k]
+  float *bias;                  // [B][k]
+  float *cent;                  // [B][k][d]
+  uint32_t *sizes;              // [B][k] cluster sizes carried to the next iteration (after a split)
+  int64_t n;
+  int k, d, f16, use_bias;
+  float balance_factor_scaled;
+  double tol;
+};
+
+__global__ __launch_bounds__(64) void kmeans_state_init_kernel(KmCtl c, const uint64_t *__restrict__ seeds) {
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    KmState &s = c.state[b];
+    s.loss = DBL_MAX; s.last_loss = DBL_MAX; s.adjusted = FLT_MAX; s.iters = 0; s.pad = 0;
+    s.bf_used = FLT_MAX < c.balance_factor_scaled ? FLT_MAX : c.balance_factor_scaled;   // f32::min(adjusted, balance_factor)
+    s.rng.seed(seeds[b] ^ 0x5bd1e995ULL);
+    c.active[b] = 1;
+  }
+  for (int i = threadIdx.x; i < c.k; i += 64) { c.sizes[(int64_t)b * c.k + i] = 0; c.bias[(int64_t)b * c.k + i] = 0.0f; }
+}
+
+__device__ __forceinline__ float km_round(float v, int f16) { return f16 ? __half2float(__float2half_rn(v)) : v; }
+
+__global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t it) {
+  extern __shared__ uint32_t sz[];   // [k] cluster sizes
+  __shared__ unsigned long long s_sq;
+  __shared__ int s_empty;
+  const int b = blockIdx.x, k = c.k;
+  if (!c.active[b]) return;
+  const uint32_t *st = c.starts + (int64_t)b * (k + 1);
+  if (threadIdx.x == 0) { s_sq = 0ull; s_empty = 0; }
+  __syncthreads();
+  unsigned long long sq = 0ull;
+  int empty = 0;
+  for (int i = threadIdx.x; i < k; i += 256) {
+    const uint32_t v = st[i + 1] - st[i];
+    sz[i] = v;
+    sq += (unsigned long long)v * v;
+    empty |= v == 0;
+  }
+  atomicAdd(&s_sq, sq);
+  if (empty) s_empty = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    KmState &s = c.state[b];
+    const double *lb = c.losses + (int64_t)b * k;
+    const float *rb = c.radius + (int64_t)b * k;
+    const uint32_t *lastr = c.last_row + (int64_t)b * k;
+    s.iters = it;
+    // compute_cluster_sizes: the running-max rule picks, among the clusters of maximal size, the one whose last member
+    // comes first in row order
+    uint64_t max_size = 0;
+    int max_id = 0;
+    uint32_t max_last = 0xFFFFFFFFu;
+    for (int i = 0; i < k; ++i) {
+      const uint64_t v = sz[i];
+      const uint32_t lr = lastr[i];
+      if (v > max_size || (v == max_size && max_size > 0 && lr < max_last)) { max_size = v; max_id = i; max_last = lr; }
+    }
+    s.adjusted = (rb[max_id] - (float)lb[max_id] / (float)sz[max_id]) / (float)c.n;
+    const float size_loss = (float)(uint64_t)s_sq;
+    const float balance_loss = s.bf_used * (size_loss - (float)((uint64_t)c.n * (uint64_t)c.n) / (float)k);
+    double lsum = 0.0;
+    for (int i = 0; i < k; ++i) lsum = lsum + lb[i];
+    s.last_loss = lsum + (double)balance_loss;
+    if (s_empty) {
+      // split_clusters: an empty cluster takes half of a size-weighted random one, both perturbed by +-1/1024 on
+      // alternating dimensions.  The reference's rejection loop never terminates when no cluster has >= 2 members (all
+      // p <= 0, e.g. every distance NaN after an f16 M-step overflow): stop splitting instead of hanging.
+      float *cent = c.cent + (int64_t)b * k * c.d;
+      const float eps = 1.0f / 1024.0f;
+      for (int i = 0; i < k; ++i) {
+        if (sz[i] != 0) continue;
+        bool splittable = false;
+        for (int t = 0; t < k; ++t) if (sz[t] >= 2) { splittable = true; break; }
+        if (!splittable) break;
+        int j = 0;
+        for (;;) {
+          const float p = ((float)sz[j] - 1.0f) / (float)(c.n - k);
+          if (s.rng.next_f32() < p) break;
+          j += 1;
+          j %= k;
+        }
+        sz[i] = sz[j] / 2;
+        sz[j] -= sz[i];
+        for (int t = 0; t < c.d; ++t) {
+          const float cj = cent[(int64_t)j * c.d + t];
+          if (t % 2 == 0) {
+            cent[(int64_t)i * c.d + t] = km_round(cj * (1.0f + eps), c.f16);
+            cent[(int64_t)j * c.d + t] = km_round(cj * (1.0f - eps), c.f16);
+          } else {
+            cent[(int64_t)i * c.d + t] = km_round(cj * (1.0f - eps), c.f16);
+            cent[(int64_t)j * c.d + t] = km_round(cj * (1.0f + eps), c.f16);
+          }
         }
       }
     }
+    if (fabs(s.loss - s.last_loss) < c.tol * s.last_loss) {
+      c.active[b] = 0;
+    } else {
+      s.loss = s.last_loss;
+    }
+    s.bf_used = s.adjusted < c.balance_factor_scaled ? s.adjusted : c.balance_factor_scaled;   // next iteration's factor
+  }
+  __syncthreads();
+  const float bf = c.state[b].bf_used;
+  for (int i = threadIdx.x; i < k; i += 256) {
+    c.sizes[(int64_t)b * k + i] = sz[i];
+    if (c.use_bias) c.bias[(int64_t)b * k + i] = bf * (float)sz[i];
   }
 }
 
@@ -189,9 +288,9 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
   // kmeans.rs:623-627
   if (n >= (int64_t)k * 512) n = (int64_t)k * 512;
 
-  std::vector<Rng> split_rng(B);
-  for (int b = 0; b < B; ++b) split_rng[b].seed(seeds[b] ^ 0x5bd1e995ULL);
-
+  uint64_t *seeds_d = ctx->scratch_t<uint64_t>("kmeans.seeds", (size_t)B);
+  if (!seeds_d) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemcpyAsync(seeds_d, seeds, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
   if (!have_init) {
     // kmeans_random_init: reservoir choose_multiple on the host, gather on the device
     std::vector<uint64_t> idx((size_t)B * k);
@@ -210,37 +309,28 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
   uint32_t *sorted_rows = ctx->scratch_t<uint32_t>("kmeans.sorted", (size_t)B * n);
   float *bias = ctx->scratch_t<float>("kmeans.bias", (size_t)B * k);
   uint8_t *active_d = ctx->scratch_t<uint8_t>("kmeans.active", (size_t)B);
-  // stats block: [losses f64 B*k][radius f32 B*k][last_row u32 B*k][starts copy u32 B*(k+1)]
+  uint32_t *sizes_d = ctx->scratch_t<uint32_t>("kmeans.sizes", (size_t)B * k);
+  KmState *state_d = ctx->scratch_t<KmState>("kmeans.state", (size_t)B);
+  // stats block: [losses f64 B*k][radius f32 B*k][last_row u32 B*k]
   const size_t stats_bytes = (size_t)B * k * (8 + 4 + 4);
   char *stats_d = reinterpret_cast<char *>(ctx->scratch("kmeans.stats", stats_bytes));
-  if (!ids || !dists || !starts || !sorted_rows || !bias || !active_d || !stats_d) return LANCE_HIP_ENOMEM;
+  if (!ids || !dists || !starts || !sorted_rows || !bias || !active_d || !sizes_d || !state_d || !stats_d) return LANCE_HIP_ENOMEM;
   double *losses_d = reinterpret_cast<double *>(stats_d);
   float *radius_d = reinterpret_cast<float *>(stats_d + (size_t)B * k * 8);
   uint32_t *last_d = reinterpret_cast<uint32_t *>(stats_d + (size_t)B * k * 12);
-
-  std::vector<char> stats_h(stats_bytes);
-  std::vector<uint32_t> starts_h((size_t)B * (k + 1));
-  std::vector<std::vector<uint64_t>> sizes(B, std::vector<uint64_t>(k, 0));
-  std::vector<float> adjusted(B, FLT_MAX);
-  std::vector<double> loss(B, DBL_MAX), last_loss(B, DBL_MAX);
-  std::vector<uint8_t> active(B, 1);
-  std::vector<uint32_t> iters(B, 0);
-  std::vector<float> bias_h((size_t)B * k, 0.0f);
-  std::vector<float> cent_h;
   const bool use_bias = balance_factor_scaled != 0.0f;
-  int n_active = B;
 
-  for (uint32_t it = 1; it <= max_iters && n_active > 0; ++it) {
-    std::vector<float> bf_used(B, 0.0f);
-    for (int b = 0; b < B; ++b) {
-      const float bf = adjusted[b] < balance_factor_scaled ? adjusted[b] : balance_factor_scaled;  // f32::min
-      bf_used[b] = bf;
-      if (use_bias)
-        for (int c = 0; c < k; ++c) bias_h[(size_t)b * k + c] = bf * (float)sizes[b][c];
-    }
-    LH_CHECK_HIP(hipMemcpyAsync(active_d, active.data(), B, hipMemcpyHostToDevice, ctx->stream));
-    if (use_bias) LH_CHECK_HIP(hipMemcpyAsync(bias, bias_h.data(), bias_h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  KmCtl ctl;
+  ctl.state = state_d; ctl.active = active_d; ctl.starts = starts; ctl.losses = losses_d; ctl.radius = radius_d; ctl.last_row = last_d;
+  ctl.bias = bias; ctl.cent = cent; ctl.sizes = sizes_d; ctl.n = n; ctl.k = k; ctl.d = d; ctl.f16 = f16_arith ? 1 : 0;
+  ctl.use_bias = use_bias ? 1 : 0; ctl.balance_factor_scaled = balance_factor_scaled; ctl.tol = tol;
+  hipLaunchKernelGGL(kmeans_state_init_kernel, dim3(B), dim3(64), 0, ctx->stream, ctl, seeds_d);
 
+  // The iterations are enqueued back to back; converged problems turn themselves off on the device (`active`).  The host
+  // looks at the flags only every few iterations to stop enqueueing once every problem has converged.
+  static const uint32_t check_every = getenv("LANCE_HIP_KMEANS_CHECK") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_KMEANS_CHECK"))) : 8;
+  std::vector<uint8_t> active(B, 1);
+  for (uint32_t it = 1; it <= max_iters; ++it) {
     PairwiseArgs pa;
     pa.x = x; pa.n = n; pa.ldx = ldx; pa.x_batch_off = x_batch_off;
     pa.cent = cent; pa.k = k; pa.cent_batch_stride = (int64_t)k * d;
@@ -255,64 +345,23 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
                          sorted_rows, n, starts, losses_d, radius_d, last_d, active_d);
       hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), B), dim3(256), 0, ctx->stream,
                          x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1, f16_arith ? 1 : 0);
+      hipLaunchKernelGGL(kmeans_control_kernel, dim3(B), dim3(256), (size_t)k * 4, ctx->stream, ctl, it);
     }
     LH_CHECK_HIP(hipGetLastError());
-    LH_CHECK_HIP(hipMemcpyAsync(stats_h.data(), stats_d, stats_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    LH_CHECK_HIP(hipMemcpyAsync(starts_h.data(), starts, starts_h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    const double *losses_h = reinterpret_cast<const double *>(stats_h.data());
-    const float *radius_h = reinterpret_cast<const float *>(stats_h.data() + (size_t)B * k * 8);
-    const uint32_t *last_h = reinterpret_cast<const uint32_t *>(stats_h.data() + (size_t)B * k * 12);
-
-    for (int b = 0; b < B; ++b) {
-      if (!active[b]) continue;
-      iters[b] = it;
-      const uint32_t *st = &starts_h[(size_t)b * (k + 1)];
-      // compute_cluster_sizes: the running-max rule picks, among the clusters of maximal
-      // size, the one whose last member comes first in row order.
-      uint64_t max_size = 0;
-      int max_id = 0;
-      uint32_t max_last = 0xFFFFFFFFu;
-      for (int c = 0; c < k; ++c) {
-        sizes[b][c] = st[c + 1] - st[c];
-        const uint32_t lr = last_h[(size_t)b * k + c];
-        if (sizes[b][c] > max_size || (sizes[b][c] == max_size && max_size > 0 && lr < max_last)) {
-          max_size = sizes[b][c]; max_id = c; max_last = lr;
-        }
-      }
-      const double *lb = losses_h + (size_t)b * k;
-      const float *rb = radius_h + (size_t)b * k;
-      adjusted[b] = (rb[max_id] - (float)lb[max_id] / (float)sizes[b][max_id]) / (float)n;
-      uint64_t size_loss_u = 0;
-      for (int c = 0; c < k; ++c) size_loss_u += sizes[b][c] * sizes[b][c];
-      const float size_loss = (float)size_loss_u;
-      const float balance_loss = bf_used[b] * (size_loss - (float)((uint64_t)n * (uint64_t)n) / (float)k);
-      double lsum = 0.0;
-      for (int c = 0; c < k; ++c) lsum = lsum + lb[c];
-      last_loss[b] = lsum + (double)balance_loss;
-
-      bool any_empty = false;
-      for (int c = 0; c < k; ++c) any_empty |= sizes[b][c] == 0;
-      if (any_empty) {
-        cent_h.resize((size_t)k * d);
-        float *cb = cent + (size_t)b * k * d;
-        LH_CHECK_HIP(hipMemcpyAsync(cent_h.data(), cb, cent_h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        split_clusters_host((size_t)n, sizes[b], cent_h.data(), (size_t)d, split_rng[b], f16_arith);
-        LH_CHECK_HIP(hipMemcpyAsync(cb, cent_h.data(), cent_h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-      }
-      if (std::fabs(loss[b] - last_loss[b]) < tol * last_loss[b]) {
-        active[b] = 0;
-        --n_active;
-      } else {
-        loss[b] = last_loss[b];
-      }
+    if (it % check_every == 0 && it < max_iters) {
+      LH_CHECK_HIP(hipMemcpyAsync(active.data(), active_d, B, hipMemcpyDeviceToHost, ctx->stream));
+      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      bool any = false;
+      for (int b = 0; b < B; ++b) any |= active[b] != 0;
+      if (!any) break;
     }
   }
+  std::vector<KmState> st_h(B);
+  LH_CHECK_HIP(hipMemcpyAsync(st_h.data(), state_d, (size_t)B * sizeof(KmState), hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   for (int b = 0; b < B; ++b) {
-    if (loss_out) loss_out[b] = last_loss[b];
-    if (iters_out) iters_out[b] = iters[b];
+    if (loss_out) loss_out[b] = st_h[b].last_loss;
+    if (iters_out) iters_out[b] = st_h[b].iters;
   }
   return LANCE_HIP_OK;
 }

@@ -351,7 +351,7 @@ bool decode_array_encoding(const uint8_t *p, size_t n, uint32_t *bits, uint32_t 
         else if (g.number == 3 && g.wire == 0 && g.value) { *err = "fixed-size lists with validity are not supported"; return false; }
       }
       if (!okl || d == 0 || !items) { *err = "malformed FixedSizeList encoding"; return false; }
-      *dim *= d;
+      if (__builtin_mul_overflow(*dim, d, dim)) { *err = "fixed-size-list dimension overflows"; return false; }
       if (!decode_array_encoding(items, items_n, bits, dim, err, depth + 1)) return false;
     } else {
       *err = "unsupported page encoding (ArrayEncoding field " + std::to_string(f.number) + "); only flat / fixed-size-list pages are read";
@@ -510,10 +510,11 @@ bool FileReader::parse(std::string *err) {
       if (pg.bits_per_value == 0 || pg.bits_per_value % 8) { *err = "column " + std::to_string(c) + ": " + std::to_string(pg.bits_per_value) + "-bit values are not supported"; return false; }
       const uint64_t rb = (uint64_t)(pg.bits_per_value / 8) * pg.dimension;
       if (pg.buffer_offsets.size() != 1 || pg.buffer_sizes.size() != 1) { *err = "column " + std::to_string(c) + ": flat page with " + std::to_string(pg.buffer_offsets.size()) + " buffers"; return false; }
-      if (pg.buffer_offsets[0] > body || pg.buffer_sizes[0] > body - pg.buffer_offsets[0] || pg.buffer_sizes[0] < pg.length * rb) { *err = "column " + std::to_string(c) + ": page buffer out of bounds"; return false; }
+      // rb > 0 here; the length check divides instead of multiplying: two file-controlled u64 values must not wrap
+      if (pg.buffer_offsets[0] > body || pg.buffer_sizes[0] > body - pg.buffer_offsets[0] || pg.length > pg.buffer_sizes[0] / rb) { *err = "column " + std::to_string(c) + ": page buffer out of bounds"; return false; }
       if (col.pages.empty()) col.row_bytes = (uint32_t)rb;
       else if (col.row_bytes != rb) { *err = "column " + std::to_string(c) + ": pages disagree on the value width"; return false; }
-      col.rows += pg.length;
+      if (__builtin_add_overflow(col.rows, pg.length, &col.rows)) { *err = "column " + std::to_string(c) + ": row count overflows"; return false; }
       col.pages.push_back(std::move(pg));
     }
     if (!_ok) { *err = "malformed column metadata"; return false; }

@@ -1,0 +1,401 @@
+// mfma_assign.hip -- the IVF coarse quantiser on the matrix cores: bf16x3 MFMA candidates + exact re-check.
+//
+//   assign / compute_partitions   kmeans.rs:317-369, :1187-1246, ivf/transform.rs:75-137  (argmin over centroids)
+//
+// The reference's argmin is defined on f32 distances computed in l2_scalar order (no FMA), which no matrix instruction
+// reproduces.  But the ARGMIN only needs exact arithmetic where two centroids are close: this path computes, for every
+// (row, centroid), the surrogate  s(c) = |c|^2 - 2 x.c (+ bias[c])   (dot: s(c) = -x.c + bias[c])
+// with x.c from v_mfma_f32_32x32x16_bf16 on a two-term bf16 split of both operands (x = xh + xl, c = ch + cl; products
+// xh.ch + xl.ch + xh.cl, f32 accumulation: |error| <= 2^-14 |x||c|), keeps the four smallest per row, and classifies:
+//   second - first > 2E  -> the winner is certain; its exact distance is computed once (reference order);
+//   third / fourth - first > 2E -> two / three candidates: their exact distances, reference rule (smaller value, then index);
+//   otherwise            -> a wave recomputes that row exactly against all k centroids.
+// E = 2^-13 (|x|^2 + max|c|^2 + max|bias|) dominates the surrogate error (split + accumulation: < 2^-14 (|x|^2+|c|^2)), the f32 error of
+// |c|^2 and the rounding of the reference's own distance (<= 2^-18 of its value), so every centroid the reference could
+// pick is among the candidates: ids and distances are bit-equal to the exact kernels (tests: test_assign_*, k-means, encode).
+// Operand roles: A = centroid tile (32 x 16 per MFMA), B = 32 data rows held in registers for the whole centroid sweep;
+// D[centroid][row] puts one data row per lane (two lanes per row), so the running top-4 is a per-lane register update.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "exact.cuh"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MA_ROWS = 128;   // data rows per workgroup (4 waves x 32)
+constexpr int MA_CT = 64;      // centroids per LDS tile (2 MFMA row blocks)
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-nearest-even bf16, NaN kept
+  const uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+
+// ---- centroid preparation: hi / lo bf16 planes, squared norms, maxima for the error bound ------------------------
+__global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ cent, int k, int d, const float *__restrict__ bias,
+                                                     uint16_t *__restrict__ chi, uint16_t *__restrict__ clo, float *__restrict__ cn,
+                                                     uint32_t *__restrict__ maxbits /* [0] = max |c|^2, [1] = max |bias| (float bits) */,
+                                                     const uint8_t *__restrict__ active) {
+  if (active && !active[0]) return;
+  const int c = blockIdx.x;
+  float s = 0.0f;
+  for (int e = threadIdx.x; e < d; e += 64) {
+    const float v = cent[(int64_t)c * d + e];
+    const uint32_t hb = bf16_rne_bits(v);
+    const float lo = v - bf16_bits_to_float(hb);
+    chi[(int64_t)c * d + e] = (uint16_t)hb;
+    clo[(int64_t)c * d + e] = (uint16_t)bf16_rne_bits(lo);
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) {
+    cn[c] = s;
+    if (s == s) atomicMax(&maxbits[0], __float_as_uint(fabsf(s)));
+    if (bias) { const float b = fabsf(bias[c]); if (b == b) atomicMax(&maxbits[1], __float_as_uint(b)); }
+  }
+}
+
+struct MaArgs {
+  const float *x;        // [n][ldx] f32
+  int64_t n, ldx;
+  int d, k;
+  const uint16_t *chi, *clo;   // [k][d] bf16 planes
+  const float *cn;             // [k] |c|^2
+  const float *bias;           // [k] or NULL
+  const uint32_t *maxbits;
+  const float *cent;           // [k][d] f32 (exact re-check)
+  uint32_t *id1, *id2, *id3;   // [n] three nearest by surrogate
+  uint8_t *cls;                // [n] 0 certain, 1 / 2: two / three candidates, 3 recompute
+  uint32_t *ids;               // outputs of the finalize kernel
+  float *dists;
+  int check_finite;
+  uint32_t *fb_cnt, *fb_rows;  // rows left to ma_recompute_kernel
+  const uint8_t *active;       // k-means: the (single) problem has converged -> every kernel returns at once
+};
+
+// running four smallest (values m1 <= m2 <= m3 <= m4, centroid ids of the first three)
+struct Top4 {
+  float m1, m2, m3, m4;
+  uint32_t i1, i2, i3;
+};
+__device__ __forceinline__ void top4_insert(Top4 &t, float v, uint32_t i) {
+  if (v < t.m4) {
+    if (v < t.m3) {
+      t.m4 = t.m3;
+      if (v < t.m2) {
+        t.m3 = t.m2; t.i3 = t.i2;
+        if (v < t.m1) { t.m2 = t.m1; t.i2 = t.i1; t.m1 = v; t.i1 = i; }
+        else { t.m2 = v; t.i2 = i; }
+      } else {
+        t.m3 = v; t.i3 = i;
+      }
+    } else {
+      t.m4 = v;
+    }
+  }
+}
+
+// KS = d / 16 MFMA k-steps (d <= 128).  DOT: surrogate = -x.c + bias.
+template <int KS, int METRIC>
+__global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.active && !p.active[0]) return;
+  constexpr int D = KS * 16;
+  constexpr int XS = D + 4;          // f32 row stride of the x staging tile
+  constexpr int CS = D + 8;          // bf16 row stride of a centroid plane (16-byte skew: conflict-free ds_read_b128)
+  float *xs = reinterpret_cast<float *>(smem);                       // [MA_ROWS][XS]            (phase 1)
+  uint16_t *cbuf = reinterpret_cast<uint16_t *>(smem);               // [2][2][MA_CT][CS] bf16   (phase 2, same bytes)
+  float *cns = reinterpret_cast<float *>(smem + (size_t)2 * 2 * MA_CT * CS * 2);   // [2][2][MA_CT]: |c|^2, bias
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * MA_ROWS;
+
+  // phase 1: coalesced f32 rows -> LDS -> per-lane fragments (8 consecutive dims per k-step and half), split hi / lo
+  for (int idx = threadIdx.x; idx < MA_ROWS * (D / 4); idx += 256) {
+    const int r = idx / (D / 4), c4 = idx - r * (D / 4);
+    f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (row0 + r < p.n) v = *reinterpret_cast<const f4 *>(p.x + (row0 + r) * p.ldx + 4 * c4);
+    *reinterpret_cast<f4 *>(&xs[r * XS + 4 * c4]) = v;
+  }
+  __syncthreads();
+  bf16x8 xh[KS], xl[KS];
+  float xn2 = 0.0f;
+  {
+    const float *xr = xs + (wave * 32 + j) * XS + g * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f4 a = *reinterpret_cast<const f4 *>(xr + s * 16), b = *reinterpret_cast<const f4 *>(xr + s * 16 + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t hb = bf16_rne_bits(v[e]);
+        const uint32_t lb = bf16_rne_bits(v[e] - bf16_bits_to_float(hb));
+        xh[s][e] = (short)hb; xl[s][e] = (short)lb;
+        xn2 += v[e] * v[e];
+      }
+    }
+  }
+  xn2 += __shfl_xor(xn2, 32, 64);
+  __syncthreads();   // xs is dead: the same LDS now holds centroid tiles
+
+  const int ntiles = (p.k + MA_CT - 1) / MA_CT;
+  constexpr int NCH = MA_CT * D / 8;          // 16-byte chunks per plane
+  constexpr int CH = (NCH + 255) / 256;       // per thread (4 at D = 128)
+  uint4 ph[CH], pl[CH];
+  float pcn = 0.0f, pbias = 0.0f;
+  auto tile_fetch = [&](int t) {
+    const int c0 = t * MA_CT;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int ch = threadIdx.x + 256 * u;           // chunk -> (centroid, 8-element column group)
+      const int cr = ch / (D / 8), cc = ch - cr * (D / 8);
+      ph[u] = make_uint4(0, 0, 0, 0); pl[u] = make_uint4(0, 0, 0, 0);
+      if (ch < NCH && c0 + cr < p.k) {
+        ph[u] = *reinterpret_cast<const uint4 *>(p.chi + (int64_t)(c0 + cr) * D + cc * 8);
+        pl[u] = *reinterpret_cast<const uint4 *>(p.clo + (int64_t)(c0 + cr) * D + cc * 8);
+      }
+    }
+    if (threadIdx.x < MA_CT) {
+      const int c = c0 + threadIdx.x;
+      pcn = c < p.k ? p.cn[c] : 0.0f;
+      pbias = (c < p.k && p.bias) ? p.bias[c] : 0.0f;
+    }
+  };
+  auto tile_store = [&](int buf) {
+    uint16_t *hi = cbuf + (size_t)(buf * 2 + 0) * MA_CT * CS, *lo = cbuf + (size_t)(buf * 2 + 1) * MA_CT * CS;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int ch = threadIdx.x + 256 * u;
+      const int cr = ch / (D / 8), cc = ch - cr * (D / 8);
+      if (ch < NCH) {
+        *reinterpret_cast<uint4 *>(hi + cr * CS + cc * 8) = ph[u];
+        *reinterpret_cast<uint4 *>(lo + cr * CS + cc * 8) = pl[u];
+      }
+    }
+    if (threadIdx.x < MA_CT) { cns[(buf * 2 + 0) * MA_CT + threadIdx.x] = pcn; cns[(buf * 2 + 1) * MA_CT + threadIdx.x] = pbias; }
+  };
+  Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
+  tile_fetch(0);
+  tile_store(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) tile_fetch(t + 1);
+    const uint16_t *hi = cbuf + (size_t)(buf * 2 + 0) * MA_CT * CS, *lo = cbuf + (size_t)(buf * 2 + 1) * MA_CT * CS;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(hi + j * CS + s * 16 + g * 8);
+      const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lo + j * CS + s * 16 + g * 8);
+      const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(hi + (32 + j) * CS + s * 16 + g * 8);
+      const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lo + (32 + j) * CS + s * 16 + g * 8);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xh[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xh[s], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xl[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xl[s], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, xh[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, xh[s], acc1, 0, 0, 0);
+    }
+    // D[centroid i][row j]: lane (j, g) holds centroids i = (v & 3) + 8 (v >> 2) + 4 g of each 32-block
+    const int c0 = t * MA_CT;
+    const float *cnb = cns + (buf * 2 + 0) * MA_CT, *bib = cns + (buf * 2 + 1) * MA_CT;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int vq = 0; vq < 4; ++vq) {
+        const int ib = blk * 32 + 8 * vq + 4 * g;
+        const f4 cn4 = *reinterpret_cast<const f4 *>(cnb + ib), bi4 = *reinterpret_cast<const f4 *>(bib + ib);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dot = blk ? acc1[vq * 4 + e] : acc0[vq * 4 + e];
+          float sv = METRIC == METRIC_DOT ? -dot : __builtin_fmaf(-2.0f, dot, cn4[e]);
+          sv += bi4[e];
+          const int ci = c0 + ib + e;
+          if (ci < p.k) top4_insert(tp, sv, (uint32_t)ci);
+        }
+      }
+    }
+    if (t + 1 < ntiles) tile_store(buf ^ 1);
+    __syncthreads();
+  }
+  // the two lanes of a row hold disjoint centroid subsets: merge the partner's four
+  {
+    const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
+    const uint32_t pi1 = __shfl_xor(tp.i1, 32, 64), pi2 = __shfl_xor(tp.i2, 32, 64), pi3 = __shfl_xor(tp.i3, 32, 64);
+    top4_insert(tp, pm1, pi1);
+    top4_insert(tp, pm2, pi2);
+    top4_insert(tp, pm3, pi3);
+    top4_insert(tp, pm4, LANCE_HIP_NONE);   // >= the three just inserted: can only land in the fourth (index-free) slot
+  }
+  const int64_t row = row0 + wave * 32 + j;
+  if (g == 0 && row < p.n) {
+    const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
+    const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2 + bmax);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
+    uint8_t cl = 3;                       // number of exact candidates - 1; 3 = recompute against every centroid
+    if (tp.m2 - tp.m1 > E2) cl = 0;
+    else if (tp.m3 - tp.m1 > E2) cl = 1;
+    else if (tp.m4 - tp.m1 > E2) cl = 2;
+    if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY)) cl = 3;   // NaN / overflow anywhere: recompute exactly
+    p.id1[row] = tp.i1; p.id2[row] = tp.i2; p.id3[row] = tp.i3; p.cls[row] = cl;
+  }
+}
+
+// ---- exact re-check: lane = row (vector in VGPRs), reference arithmetic --------------------------------------------
+template <int D, int METRIC>
+__global__ __launch_bounds__(256) void ma_finalize_kernel(MaArgs p) {
+  if (p.active && !p.active[0]) return;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = row < p.n;
+  RegVec<D> a;
+#pragma unroll
+  for (int i = 0; i < D / 4; ++i) a.q[i] = valid ? *reinterpret_cast<const f4 *>(p.x + row * p.ldx + 4 * i) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+  bool finite = true;
+  if (p.check_finite) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) finite &= isfinite(a.get(i));
+  }
+  const uint8_t cl = valid ? p.cls[row] : 0;
+  uint32_t best = LANCE_HIP_NONE;
+  float bestv = INFINITY;
+  if (valid && cl < 3) {
+    // argmin_value_float over the candidates: strictly smallest biased value, smallest index on ties, NaN never selected
+    const uint32_t cand[3] = {p.id1[row], p.id2[row], p.id3[row]};
+    float bestb = INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t <= cl && cand[t] != LANCE_HIP_NONE) {
+        const float v = finish_metric<METRIC>(dist_exact<D, METRIC>(a, p.cent + (int64_t)cand[t] * D));
+        const float vb = p.bias ? v + p.bias[cand[t]] : v;
+        if (vb < bestb || (vb == bestb && best != LANCE_HIP_NONE && cand[t] < best)) { bestb = vb; bestv = v; best = cand[t]; }
+      }
+    }
+  }
+  // rows the surrogate could not decide go to a list; ma_recompute_kernel redoes them against all k centroids
+  if (valid && cl == 3) {
+    const uint32_t slot = atomicAdd(p.fb_cnt, 1u);
+    p.fb_rows[slot] = (uint32_t)row;
+    return;
+  }
+  if (valid) {
+    if (!finite) { best = LANCE_HIP_NONE; bestv = INFINITY; }
+    if (best == LANCE_HIP_NONE) bestv = INFINITY;
+    if (p.ids) p.ids[row] = best;
+    if (p.dists) p.dists[row] = bestv;
+  }
+}
+
+// One wave per undecided row: exact distances to all k centroids (reference order), argmin_value_float semantics --
+// strictly smallest biased value, first index on ties, NaN never selected (kernels.rs:79-111).
+template <int METRIC>
+__global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.active && !p.active[0]) return;
+  float *wrow = reinterpret_cast<float *>(smem) + (threadIdx.x >> 6) * p.d;
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t cnt = *p.fb_cnt;
+  for (uint32_t it = w0; it < cnt; it += nwaves) {
+    const int64_t row = p.fb_rows[it];
+    bool fin = true;
+    for (int e = lane; e < p.d; e += 64) {
+      const float v = p.x[row * p.ldx + e];
+      wrow[e] = v;
+      fin &= isfinite(v);
+    }
+    const bool finite = !p.check_finite || __all(fin);
+    __builtin_amdgcn_wave_barrier();
+    float bb = INFINITY, bv = INFINITY;
+    uint32_t bi = LANCE_HIP_NONE;
+    for (int c = lane; c < p.k; c += 64) {
+      const float v = finish_metric<METRIC>(dist_exact_rt<METRIC>(wrow, p.cent + (int64_t)c * p.d, p.d));
+      const float vb = p.bias ? v + p.bias[c] : v;
+      if (vb < bb) { bb = vb; bv = v; bi = (uint32_t)c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(bb, o, 64), ov = __shfl_xor(bv, o, 64);
+      const uint32_t oi = __shfl_xor(bi, o, 64);
+      if (oi != LANCE_HIP_NONE && (bi == LANCE_HIP_NONE || ob < bb || (ob == bb && oi < bi))) { bb = ob; bv = ov; bi = oi; }
+    }
+    if (!finite || bi == LANCE_HIP_NONE) { bi = LANCE_HIP_NONE; bv = INFINITY; }
+    if (lane == 0) {
+      if (p.ids) p.ids[row] = bi;
+      if (p.dists) p.dists[row] = bv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int KS>
+static void ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric) {
+  constexpr int D = KS * 16;
+  const size_t lds_x = (size_t)MA_ROWS * (D + 4) * 4;
+  const size_t lds_c = (size_t)2 * 2 * MA_CT * (D + 8) * 2 + (size_t)2 * 2 * MA_CT * 4;
+  const size_t lds = std::max(lds_x, lds_c);
+  const unsigned grid = (unsigned)cdiv(a.n, MA_ROWS);
+  if (metric == METRIC_DOT) {
+    hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_DOT>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC_DOT>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((ma_recompute_kernel<METRIC_DOT>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
+  } else {
+    hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_L2>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC_L2>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((ma_recompute_kernel<METRIC_L2>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
+  }
+}
+
+bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr;
+  if (off || batches != 1 || p.codes || p.matrix) return false;
+  if (d % 16 != 0 || d < 16 || d > 128) return false;
+  if (p.k < 32 || p.n < 2048) return false;     // small problems: the exact kernel's fixed cost is lower
+  if (!p.x_aligned || !p.cent_aligned) return false;
+  return true;
+}
+
+// ids / dists of PairwiseArgs are filled exactly as launch_assign's exact kernels fill them.
+int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric) {
+  const size_t kd = (size_t)p.k * d;
+  uint16_t *chi = ctx->scratch_t<uint16_t>("ma.chi", kd), *clo = ctx->scratch_t<uint16_t>("ma.clo", kd);
+  float *cn = ctx->scratch_t<float>("ma.cn", (size_t)p.k);
+  uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);   // [0] max |c|^2, [1] max |bias|, [2] rows left to the recompute kernel
+  uint32_t *id1 = ctx->scratch_t<uint32_t>("ma.id1", (size_t)p.n), *id2 = ctx->scratch_t<uint32_t>("ma.id2", (size_t)p.n);
+  uint32_t *id3 = ctx->scratch_t<uint32_t>("ma.id3", (size_t)p.n);
+  uint8_t *cls = ctx->scratch_t<uint8_t>("ma.cls", (size_t)p.n);
+  uint32_t *fb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)p.n);
+  if (!chi || !clo || !cn || !maxbits || !id1 || !id2 || !id3 || !cls || !fb_rows) return LANCE_HIP_ENOMEM;
+  LH_REQUIRE(p.n < (1ll << 32), "assign: more than 2^32 rows per call");
+  LH_CHECK_HIP(hipMemsetAsync(maxbits, 0, 12, ctx->stream));
+  hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, p.bias, chi, clo, cn, maxbits, p.active);
+  MaArgs a;
+  a.x = p.x; a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
+  a.chi = chi; a.clo = clo; a.cn = cn; a.bias = p.bias; a.maxbits = maxbits; a.cent = p.cent;
+  a.fb_cnt = maxbits + 2; a.fb_rows = fb_rows; a.active = p.active;
+  a.id1 = id1; a.id2 = id2; a.id3 = id3; a.cls = cls; a.ids = p.ids; a.dists = p.dists; a.check_finite = p.check_finite ? 1 : 0;
+  switch (d / 16) {
+    case 1: ma_launch_ks<1>(ctx, a, metric); break;
+    case 2: ma_launch_ks<2>(ctx, a, metric); break;
+    case 3: ma_launch_ks<3>(ctx, a, metric); break;
+    case 4: ma_launch_ks<4>(ctx, a, metric); break;
+    case 5: ma_launch_ks<5>(ctx, a, metric); break;
+    case 6: ma_launch_ks<6>(ctx, a, metric); break;
+    case 7: ma_launch_ks<7>(ctx, a, metric); break;
+    case 8: ma_launch_ks<8>(ctx, a, metric); break;
+    default: return LANCE_HIP_EINVAL;
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh

@@ -208,6 +208,7 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
   p.cent_aligned = ((reinterpret_cast<uintptr_t>(p.cent) & 15) == 0) && (((int64_t)p.cent_batch_stride) % 4 == 0) && (d % 4 == 0);
   const char *tname = MODE == 0 ? "assign" : "dist_matrix";
   ScopedTimer t(ctx, tname);
+  if (MODE == 0 && mfma_assign_supported(p, d, batches)) return launch_assign_mfma(ctx, p, d, metric);
   bool fixed_ok = p.cent_aligned;  // LDS tile float4 reads in dist_exact need 16B-aligned rows
   // distance matrices of query batches (find_partitions): too few rows to fill the chip with one lane per row;
   // the 32 x 64 tiles of wide.hip measured 44 us against 62 us for 10,000 x 256 x 128

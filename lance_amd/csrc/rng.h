@@ -5,21 +5,27 @@
 #pragma once
 #include <cstdint>
 
+#if defined(__HIPCC__)
+#define LH_HD __host__ __device__
+#else
+#define LH_HD
+#endif
+
 namespace lh {
 
 struct Rng {
   uint64_t s[4];
-  static uint64_t splitmix(uint64_t &x) {
+  LH_HD static uint64_t splitmix(uint64_t &x) {
     uint64_t z = (x += 0x9e3779b97f4a7c15ULL);
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
   }
-  void seed(uint64_t v) {
+  LH_HD void seed(uint64_t v) {
     for (int i = 0; i < 4; ++i) s[i] = splitmix(v);
   }
-  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-  uint64_t next() {
+  LH_HD static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  LH_HD uint64_t next() {
     const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
     const uint64_t t = s[1] << 17;
     s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
@@ -27,9 +33,9 @@ struct Rng {
     return result;
   }
   // uniform in [0,1): top 24 bits
-  float next_f32() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
+  LH_HD float next_f32() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }
   // uniform integer in [0, n] inclusive, rejection on the masked top bits
-  uint64_t upto(uint64_t n) {
+  LH_HD uint64_t upto(uint64_t n) {
     const uint64_t range = n + 1;
     uint64_t mask = range - 1;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;

@@ -629,7 +629,7 @@ template <int METRIC, typename TR>
 __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw,
                                                      uint64_t n_raw, const uint64_t *__restrict__ cand_rid,
                                                      const uint32_t *__restrict__ cand_cnt, int keff, int k, int P,
-                                                     uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
+                                                     uint64_t *__restrict__ out_ids, float *__restrict__ out_dists, uint32_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
   uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
     uint64_t r = ~0ull;
     if (i < c) {
       r = cand_rid[(int64_t)qi * keff + i];
+      if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);   // stored row id beyond the raw vectors handed to set_raw: reported, not ranked
       if (r < n_raw) {
         if constexpr (METRIC == METRIC_COSINE) {
           kk = order_key(cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
@@ -851,8 +852,9 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   LH_REQUIRE(ix->nlist <= 8192 || nprobes <= 256, "search: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
   LH_REQUIRE(nprobes > 0, "search: nprobes must be > 0");
   const uint32_t rf = refine_factor == 0 ? 1 : refine_factor;
-  const uint32_t keff = k * rf;
-  LH_REQUIRE(keff <= 2048, "search: k * refine_factor = %u > 2048 is not supported in this version", keff);
+  const uint64_t keff64 = (uint64_t)k * rf;
+  LH_REQUIRE(keff64 <= 2048, "search: k * refine_factor = %llu > 2048 is not supported in this version", (unsigned long long)keff64);
+  const uint32_t keff = (uint32_t)keff64;
   const bool fast = keff <= (uint32_t)SCAN_MAX_KEFF;  // larger k: every query takes the exact (slow) kernel
   const bool do_refine = refine_factor >= 1;  // Some(rf): re-rank even when rf == 1 (scanner.rs:2884)
   LH_REQUIRE(!do_refine || ix->raw != nullptr, "search: refine_factor needs raw vectors (lance_hip_index_set_raw)");
@@ -983,25 +985,25 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const int8_t *rawi = static_cast<const int8_t *>(ix->raw);
     if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_COSINE)
       hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_DOT)
       hipLaunchKernelGGL((refine_kernel<METRIC_DOT, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->dtype == LANCE_HIP_I8)
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->dtype == LANCE_HIP_F16)
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->metric == LANCE_HIP_COSINE)
       hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->metric == LANCE_HIP_DOT)
       hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists);
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
@@ -1011,8 +1013,13 @@ static int check_flags(lance_hip_ctx *ctx, const uint32_t *flags, uint32_t nq) {
   std::vector<uint32_t> fh(nq);
   LH_CHECK_HIP(hipMemcpyAsync(fh.data(), flags, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  uint32_t n_over = 0, n_amb = 0;
-  for (uint32_t i = 0; i < nq; ++i) { n_over += (fh[i] & FLAG_OVERFLOW) ? 1 : 0; n_amb += (fh[i] & FLAG_AMBIGUOUS) ? 1 : 0; }
+  uint32_t n_over = 0, n_amb = 0, n_bad = 0;
+  for (uint32_t i = 0; i < nq; ++i) { n_over += (fh[i] & FLAG_OVERFLOW) ? 1 : 0; n_amb += (fh[i] & FLAG_AMBIGUOUS) ? 1 : 0; n_bad += (fh[i] & FLAG_BADROW) ? 1 : 0; }
+  if (n_bad) {
+    set_error("search: refine met row ids beyond the %s raw vectors given to lance_hip_index_set_raw (%u queries): the raw array must be "
+              "indexed by the stored row ids", "attached", n_bad);
+    return LANCE_HIP_EINVAL;
+  }
   if (n_over || n_amb) {
     set_error("search: internal error, %u overflow / %u ambiguous queries were not resolved by the exact kernel", n_over, n_amb);
     return LANCE_HIP_ERUNTIME;

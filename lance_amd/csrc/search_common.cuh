@@ -8,7 +8,7 @@
 
 namespace lh {
 
-constexpr uint32_t FLAG_OVERFLOW = 1u, FLAG_AMBIGUOUS = 2u;
+constexpr uint32_t FLAG_OVERFLOW = 1u, FLAG_AMBIGUOUS = 2u, FLAG_BADROW = 4u;
 constexpr int SCAN_LCAP = 256;    // entries handed to the merge kernel per (query, split)
 constexpr int SCAN_MAX_KEFF = 128;
 

@@ -29,6 +29,7 @@
 #include "index.h"
 #include "kernels.h"
 #include "search_common.cuh"
+#include "pm_common.cuh"
 
 #pragma clang fp contract(off)
 
@@ -55,6 +56,8 @@ struct PmArgs {
   const uint32_t *pair_idx;     // [nq*nprobes] pair index (q = idx / nprobes), grouped
   const uint32_t *item_start;   // [2*nlist+1] exclusive scan of ceil(c_vp / 2) over virtual partitions
   int cls;                      // which items this launch covers: 0 = nearest-partition pairs, 1 = the rest, 2 = all
+  int unbounded;                // class-1 launch whose queries start without a bound (quantised flow, class B)
+  int loop;                     // 1: workgroups loop over the items of their class (item count known on the device only)
   int bound_pass;               // class 0 only: compute Tglobal bounds, keep no candidates (RPL = 0 instantiation)
   const int4 *desc;             // [items] {partition, q0, q1 (-1 = none), 0}: filled by pm_item_desc_kernel
   const float *centroids, *codebook;
@@ -68,76 +71,6 @@ struct PmArgs {
   uint32_t *flags;
   unsigned long long *prof;     // optional [8]: summed shader clocks per phase of the scan kernel (thread 0 of every item)
 };
-
-// ---- threshold machinery, generic in the workgroup size ---------------------------------------------
-struct CandBuf {
-  uint32_t *key, *pos;  // [CAP]
-  uint32_t *cnt;        // current entries
-  uint32_t *T;          // current threshold (key)
-};
-
-// k-th smallest (0-based rank kk) of one value per lane; result in *out (LDS), broadcast after the barrier
-template <int BS>
-__device__ __forceinline__ void kth_smallest_bs(uint32_t v, int kk, uint32_t *sorted, uint32_t *out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      const uint32_t o = __shfl_xor(v, j, 64);
-      const bool up = (lane & k2) == 0;
-      const bool lower = (lane & j) == 0;
-      v = (lower == up) ? min(v, o) : max(v, o);
-    }
-  }
-  sorted[threadIdx.x] = v;
-  __syncthreads();
-  int rank = lane;
-  for (int w = 0; w < BS / 64; ++w) {
-    if (w == wave) continue;
-    const uint32_t *run = sorted + w * 64;
-    int lo = 0, hi = 64;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      const bool before = w < wave ? run[mid] <= v : run[mid] < v;
-      if (before) lo = mid + 1; else hi = mid;
-    }
-    rank += lo;
-  }
-  if (rank == kk) *out = v;
-  __syncthreads();
-}
-
-// T <- upper bound of the keff-th smallest key in the buffer (exact once <= BS entries remain); drop key > T
-template <int BS, int CAP>
-__device__ __forceinline__ void tighten_bs(const CandBuf &b, int keff, uint32_t *sorted, uint32_t *tnew_slot) {
-  __syncthreads();
-  const int c = min((int)*b.cnt, CAP);
-  if (c < keff) return;  // uniform
-  constexpr int PER = (CAP + BS - 1) / BS;
-  uint32_t ek[PER], ep[PER];
-  uint32_t mymin = 0xFFFFFFFFu;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int i = threadIdx.x + BS * j;
-    ek[j] = 0xFFFFFFFFu; ep[j] = 0;
-    if (i < c) { ek[j] = b.key[i]; ep[j] = b.pos[i]; mymin = min(mymin, ek[j]); }
-  }
-  kth_smallest_bs<BS>(mymin, keff - 1, sorted, tnew_slot);
-  const uint32_t tnew = *tnew_slot;
-  __syncthreads();
-  if (threadIdx.x == 0) { *b.cnt = 0; *b.T = tnew; }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int i = threadIdx.x + BS * j;
-    if (i < c && ek[j] <= tnew) {
-      const uint32_t slot = atomicAdd(b.cnt, 1u);
-      b.key[slot] = ek[j]; b.pos[slot] = ep[j];
-    }
-  }
-  __syncthreads();
-}
 
 // ---- grouping keys --------------------------------------------------------------------------------------
 // Class 0 = the pair whose partition is the query's nearest centroid (probe rank 0), class 1 = all others.
@@ -183,13 +116,13 @@ __global__ __launch_bounds__(256) void pm_item_table_kernel(const uint32_t *__re
 // one lane per item: resolve (virtual partition, query pair) once, in parallel, instead of a serial binary search
 // at the head of every scan workgroup
 __global__ __launch_bounds__(256) void pm_item_desc_kernel(const uint32_t *__restrict__ item_start, const uint32_t *__restrict__ pair_starts,
-                                                           const uint32_t *__restrict__ pair_idx, int nlist, int nprobes, uint32_t max_items,
+                                                           const uint32_t *__restrict__ pair_idx, int nvp, int nlist, int nprobes, uint32_t max_items,
                                                            int4 *__restrict__ desc) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
   if (item >= max_items) return;
   int4 dsc = make_int4(-1, -1, -1, 0);
-  if (item < item_start[2 * nlist]) {
-    int vp = (int)find_partition_dev(item_start, 2 * nlist, item);
+  if (item < item_start[nvp]) {
+    int vp = (int)find_partition_dev(item_start, nvp, item);
     while (item_start[vp + 1] <= item) ++vp;  // empty ranges share their successor's start
     const uint32_t g = item - item_start[vp];
     const uint32_t ps = pair_starts[vp], pe = pair_starts[vp + 1];
@@ -207,7 +140,7 @@ __global__ __launch_bounds__(256) void pm_item_desc_kernel(const uint32_t *__res
 // rare, so it streams 4 rows per lane between barriers (an overflow there is flagged and the query replayed
 // by the exact kernel).
 template <int SD, int METRIC, int MU, int RPL, int CAP>
-__global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
+__device__ __forceinline__ void pm_scan_item(const PmArgs &p, const uint32_t item) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int m = MU * 16;
   constexpr int Q = SD / 4;
@@ -243,10 +176,11 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   }
 
   if (threadIdx.x == 0) {
-    const uint32_t item = blockIdx.x + (p.cls == 1 ? p.item_start[p.nlist] : 0u);
-    const int valid = item < p.item_start[(p.cls == 0 ? 1 : 2) * p.nlist];
+    // direct mode (one workgroup per grid slot): the slot may lie beyond this class's items
+    const uint32_t it = p.loop ? item : item + (p.cls == 1 ? p.item_start[p.nlist] : 0u);
+    const int valid = p.loop ? 1 : (it < p.item_start[(p.cls == 0 ? 1 : 2) * p.nlist]);
     int4 dsc = make_int4(0, -1, -1, 0);
-    if (valid) dsc = p.desc[item];
+    if (valid) dsc = p.desc[it];
     const int part = dsc.x, q0 = dsc.y, q1 = dsc.z;
     s_valid = valid; s_part = part; s_q0 = q0; s_q1 = q1;
     misc[0] = 0; misc[2] = 0; misc[5] = 0;
@@ -280,7 +214,10 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
     float a = p.residual ? qa_v - cen_v : qa_v;
     float bq = p.residual ? qb_v - cen_v : qb_v;
     if (p.round_f16 && p.residual) { a = __half2float(__float2half_rn(a)); bq = __half2float(__float2half_rn(bq)); }
-    r0[threadIdx.x] = a; r1[threadIdx.x] = bq;
+    // L2: the LDS copy is NEGATED so that the table build evaluates (r - c)^2 as (c + (-r))^2 -- the same bits (IEEE negation
+    // and subtraction are exact mirror images, the square drops the sign) with packed adds (dist_exact BNEG)
+    constexpr bool NEG = METRIC != METRIC_DOT;
+    r0[threadIdx.x] = NEG ? -a : a; r1[threadIdx.x] = NEG ? -bq : bq;
   }
   __syncthreads();
   const long long pt2 = p.prof ? clock64() : 0;
@@ -298,16 +235,12 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
 #pragma unroll
     for (int i = 0; i < MH; ++i) {
       const int mm = cb_half * MH + i;
-      RegVec<SD> a0, a1;
+      RegVec<SD> cv;
 #pragma unroll
-      for (int u = 0; u < Q; ++u) {
-        a0.q[u] = *reinterpret_cast<const f4 *>(&r0[mm * SD + 4 * u]);
-        a1.q[u] = *reinterpret_cast<const f4 *>(&r1[mm * SD + 4 * u]);
-      }
-      const float *cbp = i < MA ? reinterpret_cast<const float *>(&cbA[i < MA ? i : 0][0]) : reinterpret_cast<const float *>(&cbB[i >= MA ? i - MA : 0][0]);
+      for (int u = 0; u < Q; ++u) cv.q[u] = i < MA ? cbA[i < MA ? i : 0][u] : cbB[i >= MA ? i - MA : 0][u];
       f2 v;
-      v.x = finish_metric<METRIC>(dist_exact<SD, METRIC>(a0, cbp));
-      v.y = finish_metric<METRIC>(dist_exact<SD, METRIC>(a1, cbp));
+      v.x = finish_metric<METRIC>(dist_exact<SD, METRIC, METRIC != METRIC_DOT>(cv, &r0[mm * SD]));
+      v.y = finish_metric<METRIC>(dist_exact<SD, METRIC, METRIC != METRIC_DOT>(cv, &r1[mm * SD]));
       lut2[mm * 256 + cb_c] = v;
     }
   }
@@ -525,6 +458,23 @@ __global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
   }
 }
 
+template <int SD, int METRIC, int MU, int RPL, int CAP>
+__global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_kernel(PmArgs p) {
+  pm_scan_item<SD, METRIC, MU, RPL, CAP>(p, blockIdx.x);
+}
+
+// Class-B launch of the quantised flow: the item count is only known on the device, so a fixed grid of workgroups loops
+// over the items.  A separate kernel: the loop costs registers (107 instead of 62 VGPRs) that the hot launches must not pay.
+template <int SD, int METRIC, int MU, int RPL, int CAP>
+__global__ __launch_bounds__(PM_BS) void ivfpq_scan_pm_loop_kernel(PmArgs p) {
+  const uint32_t lo = p.cls == 1 ? p.item_start[p.nlist] : 0u;
+  const uint32_t hi = p.item_start[(p.cls == 0 ? 1 : 2) * p.nlist];
+  for (uint32_t item = lo + blockIdx.x; item < hi; item += gridDim.x) {
+    pm_scan_item<SD, METRIC, MU, RPL, CAP>(p, item);
+    __syncthreads();   // the next item re-initialises the LDS state
+  }
+}
+
 // ---- merge: pool -> top keff by (dist, rowid) ---------------------------------------------------------
 constexpr int PMM_CAP = 1024;
 __global__ __launch_bounds__(256) void ivfpq_merge_pm_kernel(const uint32_t *__restrict__ pool_key, const uint32_t *__restrict__ pool_pos,
@@ -585,10 +535,21 @@ static bool launch_pm_mu(lance_hip_ctx *ctx, const PmArgs &a, unsigned grid, siz
   } else if (a.cls == 0) {   // LANCE_HIP_PM_NOBOUND=1: the earlier two-class flow (class 0 selects among unfiltered rows)
     if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
     if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+  } else if (a.unbounded) {   // queries without a bound: every row is a candidate at first -> one row per lane per round
+    if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_loop_kernel<SD, METRIC, 1, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
+    if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_loop_kernel<SD, METRIC, 2, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   } else {
     if (mu == 1) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 1, PM_RPL1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
     if (mu == 2) { hipLaunchKernelGGL((ivfpq_scan_pm_kernel<SD, METRIC, 2, 1, PM_CAP>), dim3(grid), dim3(PM_BS), lds, ctx->stream, a); return true; }
   }
+  return false;
+}
+
+template <int METRIC>
+static bool launch_pm_sd(lance_hip_ctx *ctx, const PmArgs &a, int sd, unsigned grid, size_t lds) {
+  if (sd == 4) return launch_pm_mu<4, METRIC>(ctx, a, grid, lds);
+  if (sd == 8) return launch_pm_mu<8, METRIC>(ctx, a, grid, lds);
+  if (sd == 16) return launch_pm_mu<16, METRIC>(ctx, a, grid, lds);
   return false;
 }
 
@@ -602,12 +563,128 @@ bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range) {
   return true;
 }
 
+static size_t pm_lds_base(int d, int m) {
+  const int dpad = (d + 3) & ~3;
+#if LH_PM_STATIC_LUT
+  return (size_t)dpad * 8 + PM_BS * 4 + 8 * 4;   // the LUT pair table is static LDS
+#else
+  return (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4;
+#endif
+}
+
+// Quantised flow (L2 / cosine): exact bound pass over every query's nearest partition -> 4-query integer filter scan of all
+// probed partitions (search_q.hip) -> exact re-evaluation of the survivors + (dist, rowid) selection.  Queries whose bound
+// pass found fewer than keff rows have no bound: they go through the exact pair kernel (class B) and its pool.
+static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
+                              uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
+                              uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags) {
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
+  const size_t npairs = (size_t)nq * nprobes;
+  const uint32_t max_items0 = (uint32_t)(nq / 2 + nlist + 2);
+  const uint32_t max_items2 = (uint32_t)(npairs / 2 + 2 * nlist + 2);
+  const uint32_t max_items4 = (uint32_t)(npairs / 4 + nlist + 2);
+  uint32_t *keys = ctx->scratch_t<uint32_t>("pm.keys", npairs);
+  uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)2 * nlist + 1);
+  uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);
+  uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)2 * nlist + 1);
+  int4 *desc = ctx->scratch_t<int4>("pm.desc", max_items2);
+  uint32_t *pair_starts0 = ctx->scratch_t<uint32_t>("q.pair_starts0", (size_t)nlist + 1);
+  uint32_t *pair_idx0 = ctx->scratch_t<uint32_t>("q.pair_idx0", nq);
+  uint32_t *item_start0 = ctx->scratch_t<uint32_t>("q.item_start0", (size_t)nlist + 1);
+  int4 *desc0 = ctx->scratch_t<int4>("q.desc0", max_items0);
+  uint32_t *item_start4 = ctx->scratch_t<uint32_t>("q.item_start4", (size_t)nlist + 1);
+  int4 *desc4 = ctx->scratch_t<int4>("q.desc4", max_items4);
+  uint32_t *tglobal = ctx->scratch_t<uint32_t>("pm.tglobal", (size_t)nq * 4);
+  uint32_t *seg_cnt = ctx->scratch_t<uint32_t>("q.seg_cnt", npairs);
+  uint32_t *seg_pos = ctx->scratch_t<uint32_t>("q.seg_pos", npairs * QSCAN_SEG_CAP);
+  int pool_cap = (int)std::min<uint64_t>(8192, std::max<uint64_t>(512, (uint64_t)nprobes * (keff + 28)));
+  pool_cap = (pool_cap + 255) & ~255;
+  uint32_t *pool_key = ctx->scratch_t<uint32_t>("pm.pool_key", (size_t)nq * pool_cap);
+  uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * pool_cap);
+  if (!keys || !pair_starts || !pair_idx || !item_start || !desc || !pair_starts0 || !pair_idx0 || !item_start0 || !desc0 || !item_start4 ||
+      !desc4 || !tglobal || !seg_cnt || !seg_pos || !pool_key || !pool_pos)
+    return LANCE_HIP_ENOMEM;
+  uint32_t *pool_cnt = tglobal + nq, *tbound = tglobal + 2 * (size_t)nq, *qovf = tglobal + 3 * (size_t)nq;
+  LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(hipMemsetAsync(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  PmArgs a;
+  a.q = qs; a.probes = probes;
+  a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
+  a.d = d; a.m = m; a.nprobes = (int)nprobes; a.nlist = nlist; a.keff = (int)keff;
+  a.residual = 1;
+  a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+  a.prof = nullptr;
+  a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
+  a.unbounded = 0; a.loop = 0;
+  {
+    // bound pass: the nq (query, nearest partition) pairs grouped by partition, two queries per item
+    ScopedTimer t(ctx, "pm_group");
+    LH_TRY(qscan_nearest_keys(ctx, probes, nq, nprobes, keys));
+    LH_TRY(stable_group(ctx, keys, (int64_t)nq, (int64_t)nq, nlist, 1, pair_starts0, pair_idx0, (int64_t)nq, nullptr));
+    hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts0, nlist, item_start0);
+    hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items0, 256)), dim3(256), 0, ctx->stream, item_start0, pair_starts0, pair_idx0,
+                       nlist, nlist, 1, max_items0, desc0);
+  }
+  {
+    ScopedTimer t(ctx, "ivfpq_scan_c0");
+    a.pair_starts = pair_starts0; a.pair_idx = pair_idx0; a.item_start = item_start0; a.desc = desc0;
+    a.cls = 0; a.bound_pass = 1;
+    const size_t lds = pm_lds_base(d, m) + (size_t)PM_CAP_BOUND * 16;
+    const bool ok = launch_pm_sd<METRIC_L2>(ctx, a, sd, (unsigned)(nq / 2 + nlist + 1), lds);
+    LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  }
+  {
+    // main pass grouping: class A (bounded) pairs by partition for the filter scan, class B for the exact pair kernel
+    ScopedTimer t(ctx, "pm_group");
+    LH_TRY(qscan_group(ctx, probes, nq, nprobes, nlist, tglobal, keys, tbound, pair_starts, pair_idx, item_start4, desc4, max_items4));
+    hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, 2 * nlist, item_start);
+    hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items2, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, pair_idx,
+                       2 * nlist, nlist, (int)nprobes, max_items2, desc);
+  }
+  {
+    ScopedTimer t(ctx, "ivfpq_scan_c1");
+    LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf));
+  }
+  if (getenv("LANCE_HIP_Q_STATS")) {   // diagnosis: how many rows survive the integer filter
+    std::vector<uint32_t> sc(npairs), tb(nq);
+    (void)hipMemcpyAsync(sc.data(), seg_cnt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(tb.data(), tbound, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    uint64_t tot = 0, ovf = 0, mx = 0, nb = 0, r0 = 0;
+    for (size_t i = 0; i < npairs; ++i) { tot += std::min<uint32_t>(sc[i], QSCAN_SEG_CAP); ovf += sc[i] > (uint32_t)QSCAN_SEG_CAP; mx = std::max<uint64_t>(mx, sc[i]); if (i % nprobes == 0) r0 += sc[i]; }
+    for (uint32_t i = 0; i < nq; ++i) nb += tb[i] == 0xFFFFFFFFu;
+    fprintf(stderr, "[qscan] nq=%u nprobes=%u keff=%u survivors/query %.1f (nearest partition %.1f) max segment %llu overflowed segments %llu class-B queries %llu\n",
+            nq, nprobes, keff, (double)tot / nq, (double)r0 / nq, (unsigned long long)mx, (unsigned long long)ovf, (unsigned long long)nb);
+  }
+  {
+    ScopedTimer t(ctx, "ivfpq_scan_cb");
+    a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.item_start = item_start; a.desc = desc;
+    a.cls = 1; a.bound_pass = 0; a.unbounded = 1; a.loop = 1;
+    const size_t lds = pm_lds_base(d, m) + (size_t)PM_CAP * 16;
+    const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 3, (uint64_t)max_items2);
+    const bool ok = launch_pm_sd<METRIC_L2>(ctx, a, sd, grid, lds);
+    LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  }
+  {
+    SelectOut o;
+    o.keff = (int)keff; o.k = (int)k; o.refine = do_refine ? 1 : 0;
+    o.out_ids = ids; o.out_dists = dists; o.cand_rid = cand_rid; o.cand_cnt = cand_cnt; o.flags = flags;
+    o.part_offsets = ix->part_offsets; o.nlist = nlist;
+    ScopedTimer t(ctx, "ivfpq_merge");
+    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o));
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 // scan + merge for the whole batch; outputs as the query-major path (ids/dists or refine candidates)
 int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
                         uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
+  if (getenv("LANCE_HIP_PM_NOBOUND") == nullptr && qscan_supported(ix, nq, nprobes))
+    return ivfpq_scan_merge_q(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags);
   const size_t npairs = (size_t)nq * nprobes;
   uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)2 * nlist + 1);
   uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);
@@ -633,7 +710,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
     LH_TRY(stable_group(ctx, keys, (int64_t)npairs, (int64_t)npairs, 2 * nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
     hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, 2 * nlist, item_start);
     hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, pair_idx,
-                       nlist, (int)nprobes, max_items, desc);
+                       2 * nlist, nlist, (int)nprobes, max_items, desc);
   }
   PmArgs a;
   a.q = qs; a.probes = probes; a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.item_start = item_start;
@@ -642,18 +719,14 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.desc = desc;
+  a.unbounded = 0; a.loop = 0;
   a.prof = nullptr;
   if (getenv("LANCE_HIP_PM_PROF")) {
     a.prof = ctx->scratch_t<unsigned long long>("pm.prof", 8);
     if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
   }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
-  const int dpad = (d + 3) & ~3;
-#if LH_PM_STATIC_LUT
-  const size_t lds_base = (size_t)dpad * 8 + PM_BS * 4 + 8 * 4;   // the LUT pair table is static LDS
-#else
-  const size_t lds_base = (size_t)dpad * 8 + (size_t)m * 256 * 8 + PM_BS * 4 + 8 * 4;
-#endif
+  const size_t lds_base = pm_lds_base(d, m);
   {
     // pass 0 (bound): every query's nearest partition is streamed once to seed Tglobal[q]; pass 1 (main): all
     // (query, probe) pairs, nearest partition included, prune with that bound from their first row.

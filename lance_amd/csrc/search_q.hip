@@ -1,0 +1,607 @@
+// search_q.hip -- quantised filter scan: FOUR queries share every LDS gather, survivors are re-evaluated exactly.
+//
+// Why: rocprofv3 counters of the exact partition-major pair scan (search_pm.hip; profiles/r02_*): 84 % of the VALU issue
+// slots and 68 % of the LDS cycles are busy -- the scan is instruction-issue bound, and what it issues is (a) the exact f32
+// LUT build (35 % of a work item) and (b) one ds_read_b64 + two f32 adds + two address ops per (row, sub-quantiser) per PAIR of
+// queries.  Bit-exact results only need the exact arithmetic for rows that can reach the output.  So the main pass becomes a
+// FILTER with a rigorous lower bound, in integer arithmetic:
+//   * the bound pass (unchanged, exact) gives every query an upper bound T of its final k-th distance;
+//   * per (partition, 4 queries): e[m][c] = min(floor(L[m][c] * SE / T), CAPE) as u16, four queries packed in 8 bytes
+//     ([m][256] x uint2 at LDS offset 0: one ds_read_b64 serves four queries); L >= 0 (squared L2), CAPE = 65535 / M, so the
+//     sum of M entries cannot carry between the packed u16 fields and two v_add_u32 add all four queries;
+//   * a row can only have ADC distance <= T if sum_m e[m][code_m] <= SE + 2 (floor() only lowers, the head-room covers
+//     the f32 rounding of the reference's sequential sum and of the FMA-evaluated L): everything else is dropped without ever
+//     touching f32;
+//   * the survivors (a few hundred per query) go to per-(query, probe) segments; ivfpq_qmerge_kernel recomputes THEIR
+//     distances exactly as the reference does (l2_scalar order per sub-vector, sequential-m sum), keeps key <= T, and runs the
+//     same (dist, rowid) selection / tie check as the exact path -- so ids and distances stay bit-equal to the oracle.
+// The quantised LUT may be computed with FMAs (it is a bound, not a result): half the VALU of the exact build.
+// Queries without a usable bound (fewer than k*refine rows in the nearest partition, T = 0, NaN) take the exact pair kernel.
+// Reference behaviour preserved: pq/distance.rs:109-144, flat/index.rs:94-126, scanner.rs:3440-3468, v2.rs:316-332.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+#include "exact.cuh"
+#include "index.h"
+#include "kernels.h"
+#include "search_common.cuh"
+#include "pm_common.cuh"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+constexpr int Q_BS = 512;      // lanes per scan workgroup
+constexpr int Q_G = 4;         // queries per work item (4 x u16 = one ds_read_b64)
+#ifndef LH_Q_WAVES
+#define LH_Q_WAVES 6
+#endif
+constexpr int Q_WAVES = LH_Q_WAVES;   // launch-bounds hint for M = 16, sub-dimension <= 8: waves per SIMD (6 = three 512-lane workgroups per CU, <= 80 VGPRs; 8 spills and measured 25 % slower)
+constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); more -> that partition is rescanned exactly for the query
+#ifndef LH_Q_MPF
+#define LH_Q_MPF 8
+#endif
+constexpr int Q_MPF = LH_Q_MPF;        // merge kernel: codebook entries fetched together per candidate row (registers vs round trips)
+
+// ---- grouping by (partition, bound class) ---------------------------------------------------------------------
+// class A (virtual partition = partition): the query has a usable bound 0 < T < inf -> quantised scan;
+// class B (virtual partition = nlist + partition): exact pair kernel.  tbound[q] = T for class A, 0xFFFFFFFF for class B.
+__global__ __launch_bounds__(256) void q_tclass_keys_kernel(const uint32_t *__restrict__ probes, int64_t npairs, int nprobes, int nlist,
+                                                            const uint32_t *__restrict__ tglobal, uint32_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ tbound) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npairs) return;
+  const int64_t q = i / nprobes;
+  const uint32_t T = tglobal[q];
+  const bool usable = T > 0x80000000u && T < 0xFF800000u;   // order_key(+0.0) < T < order_key(+inf)
+  keys[i] = probes[i] + (usable ? 0u : (uint32_t)nlist);
+  if (i % nprobes == 0) tbound[q] = usable ? T : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void q_nearest_keys_kernel(const uint32_t *__restrict__ probes, int nq, int nprobes, uint32_t *__restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nq) keys[i] = probes[(int64_t)i * nprobes];
+}
+
+// item_start[vp] = exclusive scan of ceil(c_vp / G) over the first nvp virtual partitions
+__global__ __launch_bounds__(256) void q_item_table_kernel(const uint32_t *__restrict__ pair_starts, int nvp, int G, uint32_t *__restrict__ item_start) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nvp; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < nvp ? (pair_starts[i + 1] - pair_starts[i] + G - 1) / G : 0;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint32_t carry = carry_s;
+    if (i < nvp) item_start[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) item_start[nvp] = carry_s;
+}
+
+// desc[item] = {partition, first grouped pair, number of pairs (1..G), 0}
+__global__ __launch_bounds__(256) void q_item_desc_kernel(const uint32_t *__restrict__ item_start, const uint32_t *__restrict__ pair_starts,
+                                                          int nvp, int G, uint32_t max_items, int4 *__restrict__ desc) {
+  const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= max_items) return;
+  int4 dsc = make_int4(-1, 0, 0, 0);
+  if (item < item_start[nvp]) {
+    int vp = (int)find_partition_dev(item_start, nvp, item);
+    while (item_start[vp + 1] <= item) ++vp;   // empty ranges share their successor's start
+    const uint32_t g = item - item_start[vp];
+    const uint32_t ps = pair_starts[vp], pe = pair_starts[vp + 1];
+    const uint32_t i0 = ps + (uint32_t)G * g;
+    dsc.x = vp;
+    dsc.y = (int)i0;
+    dsc.z = (int)min((uint32_t)G, pe - i0);
+  }
+  desc[item] = dsc;
+}
+
+// ---- the filter scan ------------------------------------------------------------------------------------------
+struct QscanArgs {
+  const float *q;               // [nq][d]
+  const uint32_t *pair_idx;     // grouped pair indices (pair = q * nprobes + rank)
+  const uint32_t *item_start;   // [nlist+1]: items of class A
+  const int4 *desc;
+  const float *centroids, *codebook;
+  const uint32_t *part_offsets;
+  const uint8_t *codes;
+  int d, nprobes, nlist, round_f16;
+  const uint32_t *tbound;       // [nq] bound key per query (class A: 0 < T < inf)
+  uint32_t *seg_cnt;            // [nq * nprobes] survivors of (query, probe) -- zeroed before the launch
+  uint32_t *seg_pos;            // [nq * nprobes][Q_CAP] storage positions
+  uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
+};
+
+template <int SD, int MU>
+__global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16;
+  constexpr int QV = SD / 4;
+  constexpr uint32_t CAPE = 65535u / M;        // largest entry: M of them cannot overflow a u16 field
+  constexpr uint32_t SE = CAPE - CAPE / 32;     // the bound T maps to SE; ~3 % head-room below CAPE
+  constexpr uint32_t LIM = SE + 2;              // floor() never raises a sum; +2 covers the f32 rounding terms (see header)
+  const int dpad = (p.d + 3) & ~3;
+  // [M][256] x (4 x u16) in STATIC LDS at offset 0: the gather address is one SDWA shift of the code byte plus an immediate
+  __shared__ __attribute__((aligned(16))) uint2 lutq[M * 256];
+  float *rq = reinterpret_cast<float *>(smem);                        // [4][dpad]: NEGATED residuals, query-major
+  uint32_t *cand = reinterpret_cast<uint32_t *>(rq + (size_t)dpad * 4);   // [4][Q_CAP]
+  uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
+  float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T (1e30: no such query in this item)
+
+  const uint32_t nitems = p.item_start[p.nlist];
+  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int4 dsc = p.desc[item];
+    const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
+    const uint32_t off = p.part_offsets[part];
+    const int np = (int)(p.part_offsets[part + 1] - off);
+    if (np == 0) continue;   // uniform; seg_cnt stays 0
+    uint32_t qj[Q_G], rk[Q_G];
+#pragma unroll
+    for (int j = 0; j < Q_G; ++j) {
+      const uint32_t pr = p.pair_idx[i0 + (j < cnt ? j : 0)];
+      qj[j] = pr / (uint32_t)p.nprobes;
+      rk[j] = pr % (uint32_t)p.nprobes;
+    }
+    if ((int)threadIdx.x < p.d) {
+      const float cen = p.centroids[(int64_t)part * p.d + threadIdx.x];
+#pragma unroll
+      for (int j = 0; j < Q_G; ++j) {
+        float v = p.q[(int64_t)qj[j] * p.d + threadIdx.x] - cen;      // v2.rs:316-332, same subtraction as the exact path
+        if (p.round_f16) v = __half2float(__float2half_rn(v));
+        rq[j * dpad + threadIdx.x] = -v;   // NEGATED: (r - c)^2 is evaluated as (c + (-r))^2 so that the add packs (v_pk_add_f32)
+      }
+    }
+    if (threadIdx.x < Q_G) {
+      misc[threadIdx.x] = 0;
+      float s = 1e30f;   // absent query: every entry saturates, nothing survives
+      if ((int)threadIdx.x < cnt) {
+        const float T = key_to_float(p.tbound[qj[threadIdx.x]]);    // 0 < T < inf (class A)
+        s = fminf((float)SE / T, 1e30f);
+      }
+      sc[threadIdx.x] = s;
+    }
+    __syncthreads();
+    // quantised LUT: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half * M/2, (half+1) * M/2).  A bound, not a
+    // result: even / odd dimensions accumulate separately with packed FMAs.  e = min(u32(L * s), CAPE): the conversion
+    // saturates, a NaN becomes 0 (the row then survives the filter and the exact pass drops it).
+    {
+      const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
+      constexpr int MH = M / 2;
+      const f4 s4 = *reinterpret_cast<const f4 *>(sc);
+#pragma unroll 2
+      for (int i = 0; i < MH; ++i) {
+        const int mm = half * MH + i;
+        const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
+        f4 cb[QV];
+#pragma unroll
+        for (int u = 0; u < QV; ++u) cb[u] = src[u];
+        uint32_t e[Q_G];
+#pragma unroll
+        for (int j = 0; j < Q_G; ++j) {
+          f2 acc = {0.0f, 0.0f};
+#pragma unroll
+          for (int u = 0; u < QV; ++u) {
+            const f4 r4 = *reinterpret_cast<const f4 *>(&rq[j * dpad + mm * SD + 4 * u]);
+            const f2 d0 = f2{r4.x, r4.y} + f2{cb[u].x, cb[u].y};
+            const f2 d1 = f2{r4.z, r4.w} + f2{cb[u].z, cb[u].w};
+            acc = __builtin_elementwise_fma(d0, d0, acc);
+            acc = __builtin_elementwise_fma(d1, d1, acc);
+          }
+          const float v = (acc.x + acc.y) * s4[j];
+          e[j] = min((uint32_t)v, CAPE);
+        }
+        lutq[mm * 256 + c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+      }
+    }
+    __syncthreads();
+    // scan: no barrier inside; survivors go to the per-query LDS lists
+    {
+      const uint8_t *pcodes = p.codes + (int64_t)off * M;
+      uint4 cwn[MU];
+      if ((int)threadIdx.x < np) {
+#pragma unroll
+        for (int w = 0; w < MU; ++w) cwn[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)threadIdx.x * M + w * 16);
+      }
+      for (int base = 0; base < np; base += Q_BS) {
+        const int row = base + threadIdx.x;
+        uint4 cw[MU];
+#pragma unroll
+        for (int w = 0; w < MU; ++w) cw[w] = cwn[w];
+        if (row + Q_BS < np) {
+#pragma unroll
+          for (int w = 0; w < MU; ++w) cwn[w] = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)(row + Q_BS) * M + w * 16);
+        }
+        if (row < np) {
+          uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+          for (int w = 0; w < MU; ++w) {
+            const uint32_t cws[4] = {cw[w].x, cw[w].y, cw[w].z, cw[w].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) {
+                const uint2 v = lutq[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+                a0 += v.x; a1 += v.y;
+              }
+          }
+          const bool p0 = (a0 & 0xFFFFu) <= LIM, p1 = (a0 >> 16) <= LIM, p2 = (a1 & 0xFFFFu) <= LIM, p3 = (a1 >> 16) <= LIM;
+          if (p0 | p1 | p2 | p3) {
+            const uint32_t pos = off + (uint32_t)row;
+            if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) cand[0 * Q_CAP + slot] = pos; }
+            if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) cand[1 * Q_CAP + slot] = pos; }
+            if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) cand[2 * Q_CAP + slot] = pos; }
+            if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) cand[3 * Q_CAP + slot] = pos; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Q_G; ++j) {
+      if (j < cnt) {
+        const uint32_t raw = misc[j];
+        const uint32_t n = min(raw, (uint32_t)Q_CAP);
+        const int64_t seg = (int64_t)qj[j] * p.nprobes + rk[j];
+        if (threadIdx.x == 0) {
+          p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
+          if (raw > (uint32_t)Q_CAP) p.qovf[qj[j]] = 1u;
+        }
+        for (uint32_t i = threadIdx.x; i < n; i += Q_BS) p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
+      }
+    }
+    __syncthreads();   // the next item reuses the LDS
+  }
+}
+
+// ---- exact re-evaluation + merge --------------------------------------------------------------------------------
+constexpr int QM_G = 8;        // probes whose residuals are staged together
+
+struct QmergeArgs {
+  const float *q;
+  const uint32_t *probes;        // [nq][nprobes]
+  const float *centroids, *codebook;
+  const uint8_t *codes;
+  const uint64_t *row_ids;
+  int d, nprobes, round_f16;
+  const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
+  uint32_t *tglobal;             // class B: running bound of the exact pair kernel
+  const uint32_t *seg_cnt, *seg_pos;
+  uint32_t *pool_key, *pool_pos, *pool_cnt;
+  int pool_cap;
+  const uint32_t *qovf;          // [nq] != 0: some segment of the query overflowed (its rows come through the pool)
+  SelectOut o;
+};
+
+// Segments that lost survivors (more than Q_CAP rows under the bound: it was loose for this query) are rescanned with the
+// exact f32 table, one workgroup per affected query; what stays under the (tightened) threshold goes to the query's pool,
+// which the merge kernel reads besides the segments.  Rare (a few queries per 10,000), so it has its own small kernel
+// instead of 16-32 KiB of LDS in every merge workgroup.
+template <int SD, int MU>
+__global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16;
+  constexpr int QV = SD / 4;
+  constexpr int CAP = 1024;
+  const int q = blockIdx.x;
+  if (!a.qovf[q]) return;
+  __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[256], misc[8];
+  const SelectOut &o = a.o;
+  const int dpad = (a.d + 3) & ~3;
+  float *r = reinterpret_cast<float *>(smem);   // [dpad]
+  float *lutx = r + dpad;                       // [M][256] exact table
+  const float *qv = a.q + (int64_t)q * a.d;
+  if (threadIdx.x == 0) { misc[0] = 0; misc[1] = a.tbound[q]; misc[3] = 0; }
+  __syncthreads();
+  CandBuf b{ckey, cpos, &misc[0], &misc[1]};
+  for (int rank = 0; rank < a.nprobes; ++rank) {
+    if (a.seg_cnt[(int64_t)q * a.nprobes + rank] <= (uint32_t)Q_CAP) continue;   // uniform
+    const uint32_t part = a.probes[(int64_t)q * a.nprobes + rank];
+    __syncthreads();
+    for (int e = threadIdx.x; e < a.d; e += 256) {
+      float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
+      if (a.round_f16) v = __half2float(__float2half_rn(v));
+      r[e] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < M * 256; idx += 256) {
+      const int mm = idx >> 8;
+      RegVec<SD> av;
+#pragma unroll
+      for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&r[mm * SD + 4 * u]);
+      lutx[idx] = finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, a.codebook + (int64_t)idx * SD));
+    }
+    __syncthreads();
+    const uint32_t off = o.part_offsets[part];
+    const int np = (int)(o.part_offsets[part + 1] - off);
+    for (int base = 0; base < np; base += 256) {
+      if ((int)misc[0] > CAP - 256) tighten_bs<256, CAP>(b, o.keff, sorted, &misc[2]);
+      const uint32_t T = misc[1];
+      const int row = base + threadIdx.x;
+      if (row < np) {
+        const uint8_t *rc = a.codes + ((int64_t)off + row) * M;
+        float dist = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MU; ++w) {
+          const uint4 cw = *reinterpret_cast<const uint4 *>(rc + w * 16);
+          const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) dist += lutx[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+        }
+        const uint32_t kk = order_key(dist);
+        if (kk <= T) {
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = off + (uint32_t)row; } else misc[3] = 1u;   // an entry was lost
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int iter = 0; iter < 8 && (int)misc[0] > a.pool_cap; ++iter) tighten_bs<256, CAP>(b, o.keff, sorted, &misc[2]);
+  __syncthreads();
+  const int c = min((int)misc[0], CAP);
+  if (c > a.pool_cap || misc[3]) {   // more rows tied under the bound than the buffers hold: the exact kernel replays the query
+    if (threadIdx.x == 0) atomicOr(&o.flags[q], FLAG_OVERFLOW);
+    return;
+  }
+  for (int i = threadIdx.x; i < c; i += 256) {
+    a.pool_key[(int64_t)q * a.pool_cap + i] = ckey[i];
+    a.pool_pos[(int64_t)q * a.pool_cap + i] = cpos[i];
+  }
+  if (threadIdx.x == 0) { a.pool_cnt[q] = (uint32_t)c; atomicMin(&a.tglobal[q], misc[1]); }
+}
+
+// One workgroup of BS lanes per query.  The kernel is latency-bound (dependent position -> code -> codebook loads, selection
+// rounds), so what counts is the number of queries in flight, not lanes per query: BS = 128 is the smallest group the
+// threshold machinery allows (the k-th smallest of one value per lane needs BS >= k * refine, at most 128 here).
+template <int SD, int MU, int BS>
+__global__ __launch_bounds__(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16;
+  constexpr int QV = SD / 4;
+  constexpr int CAP = BS == 128 ? 512 : 1024;   // (key, pos) entries under selection
+  static_assert(BS >= SCAN_MAX_KEFF, "tighten_bs selects among one value per lane");
+  __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
+  __shared__ uint64_t rid[SCAN_LCAP];
+  __shared__ uint32_t skey[SCAN_LCAP], spos[SCAN_LCAP];
+  __shared__ uint32_t s_cnt[QM_G + 1];
+  __shared__ int s_amb;
+  const SelectOut &o = a.o;
+  const int q = blockIdx.x;
+  if (o.flags[q] & FLAG_OVERFLOW) return;   // the exact kernel recomputes this query
+  const uint32_t tb = a.tbound[q];
+  const bool class_a = tb != 0xFFFFFFFFu;
+  if (threadIdx.x == 0) { misc[0] = 0; misc[1] = a.tglobal[q]; misc[3] = 0; s_amb = 0; }   // class A: the bound (lowered by a rescan, if any)
+  __syncthreads();
+  CandBuf b{ckey, cpos, &misc[0], &misc[1]};
+  // rows with exact keys already: class B's pool (exact pair kernel) or the rescan of overflowed segments
+  if (!class_a || a.qovf[q]) {
+    const int n = min((int)a.pool_cnt[q], a.pool_cap);
+    const uint32_t *pk = a.pool_key + (int64_t)q * a.pool_cap, *pp = a.pool_pos + (int64_t)q * a.pool_cap;
+    for (int base = 0; base < n; base += BS) {
+      if ((int)misc[0] > CAP - BS) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+      const uint32_t T = misc[1];
+      const int i = base + threadIdx.x;
+      if (i < n) {
+        const uint32_t kk = pk[i];
+        if (kk <= T) {
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = pp[i]; } else misc[3] = 1u;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (class_a) {
+    const int dpad = (a.d + 3) & ~3;
+    float *r = reinterpret_cast<float *>(smem);   // [QM_G][dpad]
+    const float *qv = a.q + (int64_t)q * a.d;
+    for (int g0 = 0; g0 < a.nprobes; g0 += QM_G) {
+      const int ng = min(QM_G, a.nprobes - g0);
+      __syncthreads();
+      if ((int)threadIdx.x < ng) {
+        const uint32_t c = a.seg_cnt[(int64_t)q * a.nprobes + g0 + threadIdx.x];
+        s_cnt[threadIdx.x] = c > (uint32_t)Q_CAP ? 0u : c;    // an overflowed segment comes through the pool (rescan kernel)
+      }
+      for (int t = threadIdx.x; t < ng * a.d; t += BS) {
+        const int rr = t / a.d, e = t - rr * a.d;
+        const uint32_t part = a.probes[(int64_t)q * a.nprobes + g0 + rr];
+        float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
+        if (a.round_f16) v = __half2float(__float2half_rn(v));
+        r[rr * dpad + e] = v;
+      }
+      __syncthreads();
+      int pre[QM_G + 1];
+      pre[0] = 0;
+#pragma unroll
+      for (int i = 0; i < QM_G; ++i) pre[i + 1] = pre[i] + (i < ng ? (int)s_cnt[i] : 0);
+      const int total = pre[QM_G];
+      for (int base = 0; base < total; base += BS) {
+        if ((int)misc[0] > CAP - BS) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+        const uint32_t T = misc[1];
+        const int t = base + threadIdx.x;
+        if (t < total) {
+          int rr = 0, st = 0;
+#pragma unroll
+          for (int i = 1; i < QM_G; ++i)
+            if (t >= pre[i]) { rr = i; st = pre[i]; }   // pre[] is non-decreasing and t < pre[QM_G]: the last hit is the segment
+          const uint32_t pos = a.seg_pos[((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st)];
+          const uint8_t *rc = a.codes + (int64_t)pos * M;
+          const float *rres = r + rr * dpad;
+          float dist = 0.0f;   // pq/distance.rs:128-141: += table[code] for m = 0..M-1 -- the table entry is recomputed here
+#pragma unroll
+          for (int w = 0; w < MU; ++w) {
+            const uint4 cw = *reinterpret_cast<const uint4 *>(rc + w * 16);
+            const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int hh = 0; hh < 16 / Q_MPF; ++hh) {
+              // the codebook entries of Q_MPF sub-quantisers are requested together (one L2 round trip for all of them)
+              f4 cbv[Q_MPF][QV];
+#pragma unroll
+              for (int t8 = 0; t8 < Q_MPF; ++t8) {
+                const int mi = hh * Q_MPF + t8, mm = w * 16 + mi;
+                const uint32_t code = (cws[mi >> 2] >> (8 * (mi & 3))) & 255u;
+                const f4 *src = reinterpret_cast<const f4 *>(a.codebook + ((int64_t)mm * 256 + code) * SD);
+#pragma unroll
+                for (int u = 0; u < QV; ++u) cbv[t8][u] = src[u];
+              }
+#pragma unroll
+              for (int t8 = 0; t8 < Q_MPF; ++t8) {
+                const int mm = w * 16 + hh * Q_MPF + t8;
+                RegVec<SD> av;
+#pragma unroll
+                for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&rres[mm * SD + 4 * u]);
+                dist += finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
+              }
+            }
+          }
+          const uint32_t kk = order_key(dist);
+          if (kk <= T) {
+            const uint32_t slot = atomicAdd(&misc[0], 1u);
+            if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = pos; } else misc[3] = 1u;   // an entry was lost (ties at the bound)
+          }
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+  __syncthreads();
+  int c = min((int)misc[0], CAP);
+  if (c > SCAN_LCAP || misc[3]) {
+    if (threadIdx.x == 0) atomicOr(&o.flags[q], FLAG_OVERFLOW);
+    c = min(c, SCAN_LCAP);
+  }
+  for (int i = threadIdx.x; i < SCAN_LCAP; i += BS) {
+    if (i < c) { skey[i] = ckey[i]; spos[i] = cpos[i]; rid[i] = a.row_ids[cpos[i]]; }
+    else { skey[i] = 0xFFFFFFFFu; spos[i] = 0; rid[i] = ~0ull; }
+  }
+  __syncthreads();
+  int Pq = 64;
+  while (Pq < c) Pq <<= 1;
+  bitonic_sort_kr<BS>(skey, rid, spos, Pq);
+  select_and_emit<BS>(o, q, skey, rid, spos, c, &s_amb);
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------
+bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
+  static const bool off = getenv("LANCE_HIP_NO_QSCAN") != nullptr;
+  if (off) return false;
+  const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
+  if (scan_metric != LANCE_HIP_L2) return false;                    // entries must be >= 0 (squared L2)
+  if ((uint64_t)nq * nprobes * Q_CAP * 4 > (2ull << 30)) return false;   // survivor segments: at most 2 GiB of scratch
+  return true;
+}
+
+size_t qscan_lds_bytes(int d, int m) {   // dynamic part (the quantised LUT is static LDS)
+  const int dpad = (d + 3) & ~3;
+  (void)m;
+  return (size_t)dpad * 16 + (size_t)4 * Q_CAP * 4 + 8 * 4;
+}
+
+int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
+                uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
+                uint32_t max_items4) {
+  const size_t npairs = (size_t)nq * nprobes;
+  hipLaunchKernelGGL(q_tclass_keys_kernel, dim3((unsigned)cdiv(npairs, 256)), dim3(256), 0, ctx->stream, probes, (int64_t)npairs, (int)nprobes,
+                     nlist, tglobal, keys, tbound);
+  LH_TRY(stable_group(ctx, keys, (int64_t)npairs, (int64_t)npairs, 2 * nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
+  hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, Q_G, item_start4);
+  hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items4, 256)), dim3(256), 0, ctx->stream, item_start4, pair_starts, nlist, Q_G,
+                     max_items4, desc4);
+  return LANCE_HIP_OK;
+}
+
+int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys) {
+  hipLaunchKernelGGL(q_nearest_keys_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, probes, (int)nq, (int)nprobes, keys);
+  return LANCE_HIP_OK;
+}
+
+template <int SD>
+static bool launch_qscan_sd(lance_hip_ctx *ctx, const QscanArgs &a, int m, unsigned grid, size_t lds) {
+  if (m == 16) { hipLaunchKernelGGL((ivfpq_qscan_kernel<SD, 1>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
+  if (m == 32) { hipLaunchKernelGGL((ivfpq_qscan_kernel<SD, 2>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
+  return false;
+}
+
+int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
+                 const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
+                 uint32_t *seg_pos, uint32_t *qovf) {
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
+  QscanArgs a;
+  a.q = qs; a.pair_idx = pair_idx; a.item_start = item_start4; a.desc = desc4;
+  a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
+  a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+  a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
+  LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
+  LH_CHECK_HIP(hipMemsetAsync(qovf, 0, (size_t)nq * 4, ctx->stream));
+  const size_t lds = qscan_lds_bytes(d, m);
+  // one workgroup per item up to a few waves of the chip, then workgroups loop over items
+  static const int wg_per_cu = getenv("LANCE_HIP_QSCAN_WGS") ? atoi(getenv("LANCE_HIP_QSCAN_WGS")) : 0;
+  unsigned grid = max_items4;
+  if (wg_per_cu > 0) grid = std::min<unsigned>(grid, (unsigned)(ctx->num_cus * wg_per_cu));
+  bool ok = false;
+  if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
+  else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
+  else if (sd == 16) ok = launch_qscan_sd<16>(ctx, a, m, grid, lds);
+  LH_REQUIRE(ok, "quantised scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  return LANCE_HIP_OK;
+}
+
+template <int SD, int MU>
+static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned nq, int bs) {
+  const int dpad = (a.d + 3) & ~3;
+  const size_t lds_rescan = (size_t)dpad * 4 + (size_t)MU * 16 * 256 * 4;
+  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU>), dim3(nq), dim3(256), lds_rescan, ctx->stream, a);
+  const size_t lds = (size_t)QM_G * dpad * 4;
+  if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
+}
+
+int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
+                  const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
+                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o) {
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
+  QmergeArgs a;
+  a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
+  a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+  a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
+  a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap;
+  a.o = o;
+  static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
+  bool ok = true;
+  if (m == 16) {
+    if (sd == 4) launch_qmerge_mu<4, 1>(ctx, a, nq, bs);
+    else if (sd == 8) launch_qmerge_mu<8, 1>(ctx, a, nq, bs);
+    else if (sd == 16) launch_qmerge_mu<16, 1>(ctx, a, nq, bs);
+    else ok = false;
+  } else if (m == 32) {
+    if (sd == 4) launch_qmerge_mu<4, 2>(ctx, a, nq, bs);
+    else if (sd == 8) launch_qmerge_mu<8, 2>(ctx, a, nq, bs);
+    else if (sd == 16) launch_qmerge_mu<16, 2>(ctx, a, nq, bs);
+    else ok = false;
+  } else ok = false;
+  LH_REQUIRE(ok, "quantised scan merge: unsupported shape (m=%d, sd=%d)", m, sd);
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh

@@ -2,6 +2,7 @@
 (plumbing), every computation is a call into liblance_hip.so.
 """
 import ctypes as C
+import functools
 import os
 
 import numpy as np
@@ -71,6 +72,26 @@ def _model(a, ref):
 _DT = {"float32": (torch.float32, 0), "float16": (torch.float16, 1), "int8": (torch.int8, 2)}
 
 
+def _on_engine_device(fn):
+    """Every tensor a method allocates or moves must live on the GPU the context was created on (two Engines in one process
+    may sit on different GPUs): run the method with that device current."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        eng = self if isinstance(self, Engine) else getattr(self, "engine", None)
+        if eng is None or not torch.cuda.is_available() or torch.cuda.current_device() == eng.device:
+            return fn(self, *a, **kw)
+        with torch.cuda.device(eng.device):
+            return fn(self, *a, **kw)
+    return wrapper
+
+
+def _wrap_methods(cls, skip=()):
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and not name.startswith("__") and name not in skip and not isinstance(fn, (classmethod, staticmethod)):
+            setattr(cls, name, _on_engine_device(fn))
+    return cls
+
+
 class Engine:
     """One context (stream + scratch arena) on the current device."""
 
@@ -79,6 +100,7 @@ class Engine:
         if device is None:
             device = _dev().index
         self.device = device
+        self.use_torch_stream = bool(use_torch_stream)
         stream = None
         if use_torch_stream:
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -270,6 +292,9 @@ class Engine:
         return r.value
 
 
+_wrap_methods(Engine, skip=("close",))
+
+
 class DeviceFlatIndex:
     """Handle of a device-resident IVF_FLAT index (FlatIndex sub-index over the raw vectors of each partition)."""
 
@@ -441,6 +466,10 @@ class DeviceIndex:
         fn = self.engine.lib.lance_hip_ivfpq_search if sync else self.engine.lib.lance_hip_ivfpq_search_async
         if sync:
             torch.cuda.synchronize()
+        elif not self.engine.use_torch_stream and (q is not t or out is None):
+            # the batch was converted / allocated by torch kernels on torch's stream: they must finish before the engine's own
+            # stream reads them (a caller that hands over ready tensors pays nothing)
+            torch.cuda.current_stream().synchronize()
         check(fn(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
         return ids, dists
 
@@ -487,3 +516,7 @@ class DeviceIndex:
             self.close()
         except Exception:
             pass
+
+
+_wrap_methods(DeviceFlatIndex, skip=("close",))
+_wrap_methods(DeviceIndex, skip=("close",))

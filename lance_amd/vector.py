@@ -282,7 +282,7 @@ def load_index(index_dir, dtype=None, raw=None, engine=None):
     from . import index_file
     from .engine import DeviceFlatIndex, DeviceIndex
     eng = engine or default_engine()
-    c = index_file.read_index_files(index_dir)
+    c = index_file.read_index_files(index_dir, with_rows=False)    # model + metadata only: the rows go files -> HBM natively
     params = IvfPqParams(num_partitions=c.centroids.shape[0], num_sub_vectors=c.num_sub_vectors, num_bits=c.nbits or 8,
                          metric=c.metric)
     stats = BuildStats(ivf_loss=c.loss if c.loss is not None else 0.0)
