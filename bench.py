@@ -8,10 +8,12 @@ find_partitions -> residual LUT -> ADC scan -> per-partition top-k -> (dist,rowi
 refine, with k=10, nprobes=10, refine_factor=10.  Inputs are resident in HBM before the timed
 region.  value = whole-job queries/s (N ranks x 10,000 queries / max-over-ranks time).
 
-Multi-GPU (one process per GPU, torch.distributed/RCCL): the index build shards the k-means
-E-step over the ranks with one all-reduce per Lloyd iteration and the encode pass by rows
-(lance_amd/dist.py); search is embarrassingly parallel -- every rank holds a replica of the
-16 MB code table and serves its own query batch ("weak" scaling, no data-path collective).
+Multi-GPU (one process per GPU, torch.distributed/RCCL): every rank generates and keeps only its block of the rows.  The
+build runs the IVF k-means with one all-reduce of the fused [k*d sums | k counts] buffer per Lloyd iteration, trains the PQ
+sub-quantisers model-parallel and encodes its own rows (lance_amd/dist.py: create_index_rowsharded); `build_sec` is that
+build plus the all-gather of the 20 bytes per row that gives every rank a replica.  `value` = the replicas serving their own
+query batches ("weak" scaling, no data-path collective); `multi_gpu.list_sharded_qps_strong_scaling` = the same batch
+answered jointly by IVF lists sharded over the ranks (all_to_all by list owner, one all-gather + device merge per batch).
 """
 import argparse
 import json
@@ -67,32 +69,84 @@ def main():
 
     eng = lance_amd.default_engine()
     d, nlist, m = 128, 256, 16
-    x = sift_like(args.n, d, seed=1234, device=dev)
+    multi = world > 1 or force_dist
     # 4 different query batches per rank, cycled over the steps
     qbatches = [sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev) for i in range(4)]
+    mg = {}            # multi-GPU extras of the bench line
 
-    # ---- index build (timed separately: "index-build sec") ----------------------------
-    def build_once():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        if world > 1 or force_dist:
-            from lance_amd import dist as ld
-            ix = ld.create_index_sharded(x, metric="l2", num_partitions=nlist, num_sub_vectors=m)
-        else:
+    if not multi:
+        x = sift_like(args.n, d, seed=1234, device=dev)
+
+        def build_once():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             ix = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=nlist, num_sub_vectors=m)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        return ix, time.perf_counter() - t0
+            torch.cuda.synchronize()
+            return ix, time.perf_counter() - t0
 
-    idx, _ = build_once()            # warm-up build (kernel load, scratch allocation)
-    build_secs = []
-    for _ in range(2):
-        idx, bs = build_once()
-        build_secs.append(bs)
-    build_sec = min(build_secs)
+        idx, _ = build_once()            # warm-up build (kernel load, scratch allocation)
+        build_secs = []
+        for _ in range(2):
+            idx, bs = build_once()
+            build_secs.append(bs)
+        build_sec = min(build_secs)
+    else:
+        # One node, N ranks: every rank generates and keeps ONLY its block of the 1M rows (same mixture, own draws); the
+        # vectors never leave their GPU during the build.  IVF k-means = Lloyd iterations with one RCCL all-reduce of the
+        # fused [k*d sums | k counts] buffer per iteration ("sharded"; the replicated-training time is reported beside it),
+        # PQ sub-quantisers model-parallel, transform local (lance_amd/dist.py: create_index_rowsharded).
+        from lance_amd import dist as ld
+        _, ranges = ld.block_ranges(args.n, world)
+        lo, hi = ranges[rank]
+        x_local = sift_like(hi - lo, d, seed=1234 + 7919 * rank, device=dev)
+
+        def build_once(mode):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            b = ld.create_index_rowsharded(x_local, metric="l2", num_partitions=nlist, num_sub_vectors=m, ivf_training=mode)
+            ix, _ = ld.replica_index(b, None)          # all-gather of the 20 bytes per row (partition id, code): a replica per rank
+            torch.cuda.synchronize()
+            dist.barrier()
+            return ix, b, time.perf_counter() - t0
+
+        build_once("sharded")            # warm-up
+        secs = {}
+        for mode in ("replicated", "sharded"):
+            best = float("inf")
+            for _ in range(2):
+                idx, bld, bs = build_once(mode)
+                best = min(best, bs)
+            secs[mode] = best
+        build_sec = secs["sharded"]
+        t0 = time.perf_counter()
+        x, _ = ld.all_gather_var(x_local)             # refine on a replica needs every raw vector on every rank (512 MB over xGMI)
+        idx._ix.set_raw(x)
+        torch.cuda.synchronize()
+        mg = {"rccl_ranks": world, "rows_per_rank": hi - lo, "build_sec_ivf_sharded_allreduce": secs["sharded"],
+              "build_sec_ivf_replicated": secs["replicated"], "raw_vectors_allgather_sec": time.perf_counter() - t0,
+              "build_stages_ms_sharded": {k_: round(v * 1e3, 3) for k_, v in bld.stats.seconds.items()}}
+        # strong-scaling line: the IVF lists sharded over the ranks (list p -> rank p % N, rows moved by all_to_all), every
+        # rank answers the SAME query batches with its lists, one all-gather + device (dist, rowid) merge per batch
+        shard, l2g = ld.list_shard_index(bld, x_local)
+        common = [sift_like(args.nq, d, seed=9000 + i, device=dev) for i in range(2)]
+
+        def lstep(i):
+            return ld.search_list_sharded(lambda qq, kk, npb, rf: shard.search(qq, kk, npb, rf), l2g, common[i % 2], args.k, args.nprobes,
+                                          args.refine, engine=eng)
+
+        li, _ = lstep(0)
+        ri, _ = idx.search_device(common[0], args.k, args.nprobes, args.refine)
+        mg["list_sharded_equals_replica"] = bool(torch.equal(li, ri))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            lstep(i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        mg["list_sharded_qps_strong_scaling"] = args.nq * args.steps / (time.perf_counter() - t0)
+        shard.close()
 
     # ---- recall@10 on a 1000-query sample against exact flat top-10 (GPU flat kernel,
     # itself parity-tested against the oracle) ----------------------------------------------
@@ -144,6 +198,10 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+        if "list_sharded_qps_strong_scaling" in mg:
+            tl = torch.tensor([mg["list_sharded_qps_strong_scaling"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tl, op=dist.ReduceOp.MIN)
+            mg["list_sharded_qps_strong_scaling"] = tl.item()
 
     if rank != 0:
         if world > 1:
@@ -224,11 +282,13 @@ def main():
         "config": {"workload": "SIFT-1M-like 1Mx128 f32, IVF_PQ nlist=256 M=16 nbits=8, build+search on MI355X",
                    "n": args.n, "d": d, "nlist": nlist, "m": m, "queries_per_step_per_gpu": args.nq, "k": args.k,
                    "nprobes": args.nprobes, "refine_factor": args.refine,
-                   "parallelism": f"replica x{world}" if world > 1 else "single"},
+                   "parallelism": (f"build: rows sharded over {world} ranks, RCCL all-reduce per Lloyd iteration; search: replica x{world} "
+                                   f"(weak) + list-sharded (strong)") if multi else "single"},
         "recall_at_10": recall,
         "exact_replays_last_step": exact_replays,
         "host_buffers_qps_pcie_inclusive": pcie_qps,
         "build_sec": build_sec,
+        "multi_gpu": mg or None,
         "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
         "kernel_ms_per_step": {k_: round(v[0] / max(v[1], 1), 4) for k_, v in kt.items()},
         "roofline": {"kernel": kernel_name, "bound": "lds", "achieved": gather_rate / 1e9, "peak": ceiling / 1e9,

@@ -117,6 +117,24 @@ int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, co
 int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, uint32_t k, uint32_t d,
                               void *centroids_out);
 
+/* Row-sharded Lloyd iteration WITHOUT host round trips (multi-GPU build).  Per iteration the caller enqueues, on
+ * the stream the context was created on (e.g. torch's current stream, so that RCCL collectives are ordered with it):
+ *   shard_estep  -- local E-step + local partials: buf = [k*d sums | k counts] (f32), losses [k] (f64), radius [k] (f32);
+ *   all-reduce SUM of buf and of losses, all-reduce MAX of radius (the caller's collective library);
+ *   shard_update -- on the reduced numbers: centroids = sums / counts, loss, balance-factor update, convergence test,
+ *                   empty-cluster split (RNG seeded identically on every rank), bias of the next iteration.
+ * `state` is an opaque device block of LANCE_HIP_KMEANS_SHARD_STATE_BYTES bytes; `bias` k device floats.  Once the run has
+ * converged the state turns inactive: further estep / update calls leave every buffer untouched.  shard_end synchronises and
+ * reports (loss, iterations, still active).  Reference loop: KMeans::train_kmeans, kmeans.rs:610-719.                     */
+#define LANCE_HIP_KMEANS_SHARD_STATE_BYTES 128
+int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_factor_scaled, uint64_t seed, void *state, float *bias);
+int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
+                                 const float *bias, const void *state, float *buf, double *losses, float *radius);
+int lance_hip_kmeans_shard_update(lance_hip_ctx *ctx, void *state, const float *buf, const double *losses, const float *radius,
+                                  float *centroids, float *bias, uint32_t k, uint32_t d, uint64_t n_total, float balance_factor_scaled,
+                                  double tol, uint32_t it);
+int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *loss_host, uint32_t *iters_host, int *active_host);
+
 /* ---- a11: PQBuildParams::build_from_fsl (pq/builder.rs:89-157) ------------------- */
 /* M independent k-means (k = 2^nbits, L2, no balance) over the sub-vector columns of
  * `residuals`; sub-quantiser m uses seed + m.  codebook_out: [m][2^nbits][d/m].      */
@@ -214,6 +232,16 @@ int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx,
                                  uint32_t nprobes, uint32_t refine_factor, float lower, float upper, uint64_t *ids,
                                  float *dists);
 
+/* The same search under a row-id prefilter (`nearest=..., filter=..., prefilter=True`: scanner.rs -> DatasetPreFilter ->
+ * FlatIndex::search's RowIdMask branch, flat/index.rs:129-165).  allow_by_rowid[r] != 0 <=> row id r may be returned; rows
+ * whose id is >= n_allow are filtered out.  The mask is applied INSIDE the scan kernels (one bit per stored row, tested
+ * before a row can become a candidate, bound pass included): no per-filter copy of the index.  For 8-bit PQ the result is
+ * identical to the reference's per-row distance(id) loop; 4-bit PQ is refused (the reference scores filtered rows with
+ * the unquantised table, a different arithmetic from its own unfiltered fast-scan).                                      */
+int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                    uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
+                                    uint64_t *ids, float *dists);
+
 /* Number of queries of the most recent search on this context that had to be replayed by the exact
  * (heap-emulating) kernel -- ties at a partition's k-th distance, or candidate-buffer overflow.      */
 int lance_hip_search_stats(lance_hip_ctx *ctx, uint32_t *n_exact_replays_host);
@@ -284,6 +312,13 @@ int lance_hip_index_save(lance_hip_ctx *ctx, const lance_hip_index *idx, const c
  * e.g. the vector column of a data file.  dst NULL: only reports rows / bytes per row.                           */
 int lance_hip_file_read_column(const char *path, const char *column, void *dst, uint64_t dst_bytes, uint64_t *rows,
                                uint32_t *row_bytes);
+
+/* ---- multi-GPU: merge of per-shard candidate lists (list-sharded search) -------------------------------- */
+/* SortExec([_distance asc, _rowid asc]).with_fetch(k) (lance scanner.rs:3440-3468) over `c` candidates per query gathered
+ * from the list shards: ids [nq][c] (int64, -1 = none), dists [nq][c].  With exact_dists != NULL (refine, scanner.rs:2884-
+ * 2904) the keff best by (dists, id) are re-ranked by (exact_dists, id) before the fetch.  Outputs [nq][k] (-1 / +inf pad). */
+int lance_hip_merge_topk(lance_hip_ctx *ctx, const int64_t *ids, const float *dists, const float *exact_dists, uint32_t nq,
+                         uint32_t c, uint32_t keff, uint32_t k, int64_t *out_ids, float *out_dists);
 
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx stream --- */
 /* When enabled, each internal launch of the named hot kernels is bracketed by events;

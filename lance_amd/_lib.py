@@ -23,16 +23,17 @@ SYMBOLS = [
     "lance_hip_ctx_create", "lance_hip_ctx_destroy", "lance_hip_last_error", "lance_hip_version",
     "lance_hip_synchronize", "lance_hip_malloc", "lance_hip_free", "lance_hip_memcpy_h2d", "lance_hip_memcpy_d2h",
     "lance_hip_normalize", "lance_hip_assign", "lance_hip_kmeans_train", "lance_hip_kmeans_train_ex",
-    "lance_hip_kmeans_estep_partial",
+    "lance_hip_kmeans_estep_partial", "lance_hip_kmeans_shard_begin", "lance_hip_kmeans_shard_estep", "lance_hip_kmeans_shard_update",
+    "lance_hip_kmeans_shard_end",
     "lance_hip_kmeans_finalize", "lance_hip_pq_train", "lance_hip_residual", "lance_hip_pq_encode",
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
     "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
     "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_ivfpq_search_range",
-    "lance_hip_search_stats",
+    "lance_hip_search_stats", "lance_hip_ivfpq_search_filtered",
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search",
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
     "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
-    "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench",
+    "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench", "lance_hip_merge_topk",
 ]
 
 
@@ -91,6 +92,10 @@ def load():
                                             C.POINTER(f64), C.POINTER(u32), C.POINTER(u32)]),
         "lance_hip_kmeans_estep_partial": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp, vp, C.POINTER(f64)]),
         "lance_hip_kmeans_finalize": (i32, [vp, i32, vp, u32, u32, vp]),
+        "lance_hip_kmeans_shard_begin": (i32, [vp, u32, f32, u64, vp, vp]),
+        "lance_hip_kmeans_shard_estep": (i32, [vp, i32, vp, u64, u32, vp, u32, vp, vp, vp, vp, vp]),
+        "lance_hip_kmeans_shard_update": (i32, [vp, vp, vp, vp, vp, vp, vp, u32, u32, u64, f32, f64, u32]),
+        "lance_hip_kmeans_shard_end": (i32, [vp, vp, C.POINTER(f64), C.POINTER(u32), C.POINTER(i32)]),
         "lance_hip_pq_train": (i32, [vp, i32, vp, u64, u32, u32, u32, u32, u32, u64, vp, vp]),
         "lance_hip_residual": (i32, [vp, i32, vp, u64, u32, vp, vp, vp]),
         "lance_hip_pq_encode": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, u32, vp]),
@@ -109,6 +114,7 @@ def load():
         "lance_hip_ivfpq_search_async": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
         "lance_hip_ivfpq_search_range": (i32, [vp, vp, vp, u32, u32, u32, u32, f32, f32, vp, vp]),
         "lance_hip_search_stats": (i32, [vp, C.POINTER(u32)]),
+        "lance_hip_ivfpq_search_filtered": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, u64, vp, vp]),
         "lance_hip_flat_topk": (i32, [vp, i32, i32, vp, vp, u64, u32, vp, u32, u32, vp, vp]),
         "lance_hip_ivfflat_create": (i32, [vp, i32, i32, u32, vp, u32, vp, vp, vp, u64, C.POINTER(vp)]),
         "lance_hip_ivfflat_search": (i32, [vp, vp, vp, u32, u32, u32, vp, vp]),
@@ -123,6 +129,7 @@ def load():
         "lance_hip_timing_enable": (i32, [vp, i32]),
         "lance_hip_timing_query": (i32, [vp, C.c_char_p, C.POINTER(f64), C.POINTER(u64)]),
         "lance_hip_ubench": (i32, [vp, i32, C.POINTER(f64)]),
+        "lance_hip_merge_topk": (i32, [vp, vp, vp, vp, u32, u32, u32, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -83,7 +83,7 @@ int launch_residual(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const 
 bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range);
 int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
                         uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
-                        uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags);
+                        uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
 
 // quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
@@ -96,9 +96,9 @@ int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_
                 uint32_t max_items4);
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
-                 uint32_t *seg_pos, uint32_t *qovf);
+                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow);
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
-                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o);
+                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow);
 
 }  // namespace lh

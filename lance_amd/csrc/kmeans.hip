@@ -189,7 +189,11 @@ __global__ __launch_bounds__(64) void kmeans_state_init_kernel(KmCtl c, const ui
 __device__ __forceinline__ float km_round(float v, int f16) { return f16 ? __half2float(__float2half_rn(v)) : v; }
 
 __global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t it) {
-  extern __shared__ uint32_t sz[];   // [k] cluster sizes
+  extern __shared__ __attribute__((aligned(8))) char km_smem[];
+  // per-cluster inputs staged in LDS by all lanes, so that lane 0's sequential chains read LDS, not one global word at a time
+  double *lbs = reinterpret_cast<double *>(km_smem);            // [k] per-cluster losses
+  uint32_t *sz = reinterpret_cast<uint32_t *>(lbs + c.k);       // [k] cluster sizes
+  uint32_t *lasts = sz + c.k;                                   // [k] last member row
   __shared__ unsigned long long s_sq;
   __shared__ int s_empty;
   const int b = blockIdx.x, k = c.k;
@@ -202,6 +206,8 @@ __global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t i
   for (int i = threadIdx.x; i < k; i += 256) {
     const uint32_t v = st[i + 1] - st[i];
     sz[i] = v;
+    lbs[i] = c.losses[(int64_t)b * k + i];
+    lasts[i] = c.last_row[(int64_t)b * k + i];
     sq += (unsigned long long)v * v;
     empty |= v == 0;
   }
@@ -210,9 +216,9 @@ __global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t i
   __syncthreads();
   if (threadIdx.x == 0) {
     KmState &s = c.state[b];
-    const double *lb = c.losses + (int64_t)b * k;
+    const double *lb = lbs;
     const float *rb = c.radius + (int64_t)b * k;
-    const uint32_t *lastr = c.last_row + (int64_t)b * k;
+    const uint32_t *lastr = lasts;
     s.iters = it;
     // compute_cluster_sizes: the running-max rule picks, among the clusters of maximal size, the one whose last member
     // comes first in row order
@@ -345,7 +351,7 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
                          sorted_rows, n, starts, losses_d, radius_d, last_d, active_d);
       hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), B), dim3(256), 0, ctx->stream,
                          x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1, f16_arith ? 1 : 0);
-      hipLaunchKernelGGL(kmeans_control_kernel, dim3(B), dim3(256), (size_t)k * 4, ctx->stream, ctl, it);
+      hipLaunchKernelGGL(kmeans_control_kernel, dim3(B), dim3(256), (size_t)k * 16, ctx->stream, ctl, it);
     }
     LH_CHECK_HIP(hipGetLastError());
     if (it % check_every == 0 && it < max_iters) {
@@ -675,6 +681,167 @@ int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, co
     *loss_out_host = tot;
   }
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
+// ---- row-sharded Lloyd iteration without host round trips (multi-GPU) ---------------------------------------
+// One iteration = shard_estep (local E-step + local partial sums / losses / radii, enqueued) -> the caller's collectives
+// on the same stream (all-reduce SUM of [k*d sums | k counts] and of the f64 losses, MAX of the radii) -> shard_update
+// (finalise centroids, loss, balance factor, convergence, empty-cluster split with the shared seed, next bias; enqueued).
+// Nothing synchronises with the host until shard_end.  Every rank executes the same update on the same reduced numbers, so
+// all ranks hold identical centroids and take identical decisions.
+struct KmShardState {
+  KmState s;
+  uint32_t active, pad;
+};
+
+__global__ __launch_bounds__(256) void kmeans_shard_update_kernel(KmShardState *__restrict__ st, const float *__restrict__ buf,
+                                                                  const double *__restrict__ losses, const float *__restrict__ radius,
+                                                                  float *__restrict__ cent, float *__restrict__ bias, int k, int d, int64_t n_total,
+                                                                  float balance_factor_scaled, double tol, uint32_t it) {
+  extern __shared__ __attribute__((aligned(8))) char km_smem[];
+  double *lbs = reinterpret_cast<double *>(km_smem);
+  uint32_t *sz = reinterpret_cast<uint32_t *>(lbs + k);
+  __shared__ unsigned long long s_sq;
+  __shared__ int s_empty;
+  if (!st->active) return;
+  if (threadIdx.x == 0) { s_sq = 0ull; s_empty = 0; }
+  __syncthreads();
+  // centroids = sums / counts (to_kmeans :410-418); counts travel as f32 in the reduced buffer
+  for (int64_t g = threadIdx.x; g < (int64_t)k * d; g += 256) {
+    const float cnt = buf[(int64_t)k * d + g / d];
+    float v = buf[g];
+    if (cnt > 0.0f) { const float norm = 1.0f / cnt; v *= norm; }
+    cent[g] = v;
+  }
+  unsigned long long sq = 0ull;
+  int empty = 0;
+  for (int i = threadIdx.x; i < k; i += 256) {
+    const uint32_t v = (uint32_t)buf[(int64_t)k * d + i];
+    sz[i] = v; lbs[i] = losses[i];
+    sq += (unsigned long long)v * v;
+    empty |= v == 0;
+  }
+  atomicAdd(&s_sq, sq);
+  if (empty) s_empty = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    KmState &s = st->s;
+    s.iters = it;
+    uint64_t max_size = 0;
+    int max_id = 0;
+    for (int i = 0; i < k; ++i) if (sz[i] > max_size) { max_size = sz[i]; max_id = i; }   // first maximal cluster
+    s.adjusted = (radius[max_id] - (float)lbs[max_id] / (float)sz[max_id]) / (float)n_total;
+    const float size_loss = (float)(uint64_t)s_sq;
+    const float balance_loss = s.bf_used * (size_loss - (float)((uint64_t)n_total * (uint64_t)n_total) / (float)k);
+    double lsum = 0.0;
+    for (int i = 0; i < k; ++i) lsum = lsum + lbs[i];
+    s.last_loss = lsum + (double)balance_loss;
+    if (s_empty) {
+      const float eps = 1.0f / 1024.0f;
+      for (int i = 0; i < k; ++i) {
+        if (sz[i] != 0) continue;
+        bool splittable = false;
+        for (int t = 0; t < k; ++t) if (sz[t] >= 2) { splittable = true; break; }
+        if (!splittable) break;
+        int j = 0;
+        for (;;) {
+          const float p = ((float)sz[j] - 1.0f) / (float)(n_total - k);
+          if (s.rng.next_f32() < p) break;
+          j += 1;
+          j %= k;
+        }
+        sz[i] = sz[j] / 2;
+        sz[j] -= sz[i];
+        for (int t = 0; t < d; ++t) {
+          const float cj = cent[(int64_t)j * d + t];
+          cent[(int64_t)i * d + t] = cj * ((t % 2 == 0) ? (1.0f + eps) : (1.0f - eps));
+          cent[(int64_t)j * d + t] = cj * ((t % 2 == 0) ? (1.0f - eps) : (1.0f + eps));
+        }
+      }
+    }
+    if (fabs(s.loss - s.last_loss) < tol * s.last_loss) st->active = 0;
+    else s.loss = s.last_loss;
+    s.bf_used = s.adjusted < balance_factor_scaled ? s.adjusted : balance_factor_scaled;
+  }
+  __syncthreads();
+  const float bf = st->s.bf_used;
+  for (int i = threadIdx.x; i < k; i += 256) bias[i] = bf * (float)sz[i];
+}
+
+__global__ void kmeans_shard_init_kernel(KmShardState *st, float *bias, int k, float balance_factor_scaled, uint64_t seed) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    KmState &s = st->s;
+    s.loss = DBL_MAX; s.last_loss = DBL_MAX; s.adjusted = FLT_MAX; s.iters = 0; s.pad = 0;
+    s.bf_used = FLT_MAX < balance_factor_scaled ? FLT_MAX : balance_factor_scaled;
+    s.rng.seed(seed ^ 0x5bd1e995ULL);
+    st->active = 1; st->pad = 0;
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k; i += gridDim.x * blockDim.x) bias[i] = 0.0f;
+}
+
+// a converged run must keep contributing ZEROS? no: every rank converges at the same iteration (same reduced numbers), and
+// the caller stops issuing collectives once shard_end reports inactive; estep on an inactive state leaves the buffers as is.
+__global__ void kmeans_shard_gate_kernel(const KmShardState *st, uint8_t *active_byte) { *active_byte = st->active ? 1 : 0; }
+
+int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_factor_scaled, uint64_t seed, void *state, float *bias) {
+  LH_REQUIRE(ctx && state && bias, "kmeans_shard_begin: NULL argument");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(kmeans_shard_init_kernel, dim3(4), dim3(256), 0, ctx->stream, static_cast<KmShardState *>(state), bias, (int)k,
+                     balance_factor_scaled, seed);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
+                                 const float *bias, const void *state, float *buf, double *losses, float *radius) {
+  LH_REQUIRE(ctx && centroids && buf && losses && radius && state && (n == 0 || x), "kmeans_shard_estep: NULL argument");
+  LH_REQUIRE(n < (1ull << 32) && k <= 4096, "kmeans_shard_estep: n or k too large for this version");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  const size_t nn = n ? n : 1;
+  uint32_t *ids = ctx->scratch_t<uint32_t>("kmeans.ids", nn);
+  float *dists = ctx->scratch_t<float>("kmeans.dists", nn);
+  uint32_t *starts = ctx->scratch_t<uint32_t>("kmeans.starts", (size_t)k + 1);
+  uint32_t *sorted_rows = ctx->scratch_t<uint32_t>("kmeans.sorted", nn);
+  uint32_t *last_d = ctx->scratch_t<uint32_t>("kmeans.last", (size_t)k);
+  uint8_t *act = ctx->scratch_t<uint8_t>("kmeans.active", 1);
+  if (!ids || !dists || !starts || !sorted_rows || !last_d || !act) return LANCE_HIP_ENOMEM;
+  hipLaunchKernelGGL(kmeans_shard_gate_kernel, dim3(1), dim3(1), 0, ctx->stream, static_cast<const KmShardState *>(state), act);
+  PairwiseArgs pa;
+  pa.x = x; pa.n = (int64_t)n; pa.ldx = d;
+  pa.cent = centroids; pa.k = (int)k; pa.bias = bias;
+  pa.ids = ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
+  pa.active = act;
+  if (n > 0) LH_TRY(launch_assign(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
+  LH_TRY(stable_group(ctx, ids, (int64_t)n, (int64_t)n, (int)k, 1, starts, sorted_rows, (int64_t)n, act));
+  hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 4), 1), dim3(256), 0, ctx->stream, dists, (int64_t)n, (int)k, sorted_rows,
+                     (int64_t)n, starts, losses, radius, last_d, act);
+  hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), 1), dim3(256), 0, ctx->stream, x, (int64_t)d, 0,
+                     (int)d, (int)k, sorted_rows, (int64_t)n, starts, buf, (int64_t)k * d, act, 0, 0);
+  hipLaunchKernelGGL(counts_to_float_kernel, dim3((unsigned)cdiv(k, 256)), dim3(256), 0, ctx->stream, starts, (int)k, buf + (size_t)k * d);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_kmeans_shard_update(lance_hip_ctx *ctx, void *state, const float *buf, const double *losses, const float *radius,
+                                  float *centroids, float *bias, uint32_t k, uint32_t d, uint64_t n_total, float balance_factor_scaled,
+                                  double tol, uint32_t it) {
+  LH_REQUIRE(ctx && state && buf && losses && radius && centroids && bias, "kmeans_shard_update: NULL argument");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(kmeans_shard_update_kernel, dim3(1), dim3(256), (size_t)k * 12 + 8, ctx->stream, static_cast<KmShardState *>(state), buf,
+                     losses, radius, centroids, bias, (int)k, (int)d, (int64_t)n_total, balance_factor_scaled, tol, it);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *loss_host, uint32_t *iters_host, int *active_host) {
+  LH_REQUIRE(ctx && state, "kmeans_shard_end: NULL argument");
+  KmShardState h;
+  LH_CHECK_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (loss_host) *loss_host = h.s.last_loss;
+  if (iters_host) *iters_host = h.s.iters;
+  if (active_host) *active_host = (int)h.active;
   return LANCE_HIP_OK;
 }
 

@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
     const float *cnb = cns + (buf * 2 + 0) * MA_CT, *bib = cns + (buf * 2 + 1) * MA_CT;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
+      // surrogates of this lane's 16 centroids of the block; the insertions only run when one of them is below the current
+      // fourth-smallest (rare once a few tiles have been seen: with k = 4096 about one block in twenty)
+      float sv[16];
+      float bm = INFINITY;
 #pragma unroll
       for (int vq = 0; vq < 4; ++vq) {
         const int ib = blk * 32 + 8 * vq + 4 * g;
@@ -219,11 +223,18 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dot = blk ? acc1[vq * 4 + e] : acc0[vq * 4 + e];
-          float sv = METRIC == METRIC_DOT ? -dot : __builtin_fmaf(-2.0f, dot, cn4[e]);
-          sv += bi4[e];
-          const int ci = c0 + ib + e;
-          if (ci < p.k) top4_insert(tp, sv, (uint32_t)ci);
+          float v = METRIC == METRIC_DOT ? -dot : __builtin_fmaf(-2.0f, dot, cn4[e]);
+          v += bi4[e];
+          if (c0 + ib + e >= p.k) v = INFINITY;
+          sv[vq * 4 + e] = v;
+          bm = fminf(bm, v);
         }
+      }
+      if (bm < tp.m4) {
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) top4_insert(tp, sv[vq * 4 + e], (uint32_t)(c0 + blk * 32 + 8 * vq + 4 * g + e));
       }
     }
     if (t + 1 < ntiles) tile_store(buf ^ 1);

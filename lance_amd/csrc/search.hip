@@ -212,6 +212,7 @@ struct ScanArgs {
   uint32_t *flags;    // [nq]
   int round_f16;      // index element type is f16: the residual query is an f16 subtraction (v2.rs:326)
   int ablate;         // perf experiments only (LANCE_HIP_ABLATE): 1 = LUT once per query, 2 = no candidate appends, 4 = skip scan
+  const uint32_t *allow;   // prefilter bitmap over storage positions or NULL
 };
 
 struct ScanShared {
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
           if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);  // pq/storage.rs:949-957
           const uint32_t key = order_key(dist);
           const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);  // flat/index.rs:98-105
-          if (in_range && key <= T && !((p.ablate & 2) && base > 0)) {
+          if (in_range && key <= T && !((p.ablate & 2) && base > 0) && row_allowed(p.allow, off + (uint32_t)row)) {
             const uint32_t slot = atomicAdd(&s.misc[0], 1u);
             if (slot < SCAN_CAP) { s.ckey[slot] = key; s.cpos[slot] = off + (uint32_t)row; }
             else s.misc[3] = FLAG_OVERFLOW;
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
         }
         key = order_key(dist);
         const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);
-        cand = in_range && (s_hlen < p.keff || key < hk[0]);
+        cand = in_range && row_allowed(p.allow, off + (uint32_t)row) && (s_hlen < p.keff || key < hk[0]);
       }
       const uint64_t mask = __ballot(cand);
       skey[lane] = key;
@@ -846,7 +847,7 @@ static void launch_scan(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t 
 // The whole query pipeline, enqueued on ctx->stream.  flags_out: device [nq] (zeroed here).
 int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
                          uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
-                         uint64_t *ids, float *dists, uint32_t **flags_out) {
+                         uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow) {
   LH_REQUIRE(k > 0, "search: k must be > 0");
   if (nprobes > ix->nlist) nprobes = ix->nlist;
   LH_REQUIRE(ix->nlist <= 8192 || nprobes <= 256, "search: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
@@ -920,6 +921,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
     a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     a.has_range = has_range;
+    a.allow = allow;
     a.lo_key = 0; a.hi_key = 0xFFFFFFFFu;
     if (has_range) {
       uint32_t lb, ub;
@@ -933,8 +935,10 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
     if (use_pm) {
-      LH_TRY(ivfpq_scan_merge_pm(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags));
+      LH_TRY(ivfpq_scan_merge_pm(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags, allow));
     } else if (fast && ix->nbits == 4) {
+      LH_REQUIRE(allow == nullptr, "search: a prefilter on 4-bit PQ is not supported (the reference scores filtered rows with the "
+                                   "unquantised table, a different arithmetic from its unfiltered fast-scan)");
       const size_t lds4 = (size_t)dpad * 4 + (size_t)m * 16 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4 + 16 + 256 * 4 + (size_t)m * 16 + 16;
       ScopedTimer t(ctx, "ivfpq_scan");
       if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_scan4_kernel<METRIC_DOT>), dim3((unsigned)nblk), dim3(256), lds4, ctx->stream, a);
@@ -1065,7 +1069,7 @@ int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx,
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   const float *qf;
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
-  return ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, nullptr);
+  return ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, nullptr, nullptr);
 }
 
 int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
@@ -1076,7 +1080,7 @@ int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const
   uint32_t *flags = nullptr;
   const float *qf;
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
-  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags));
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags, nullptr));
   return check_flags(ctx, flags, nq);
 }
 
@@ -1090,7 +1094,42 @@ int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx,
   uint32_t *flags = nullptr;
   const float *qf;
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
-  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 1, lower, upper, ids, dists, &flags));
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 1, lower, upper, ids, dists, &flags, nullptr));
+  return check_flags(ctx, flags, nq);
+}
+
+// bit[pos] = allow_by_rowid[row_ids[pos]] (rows whose id lies beyond the array are filtered out)
+__global__ __launch_bounds__(256) void build_allow_bits_kernel(const uint64_t *__restrict__ row_ids, uint64_t n, const uint8_t *__restrict__ allow,
+                                                               uint64_t n_allow, uint32_t *__restrict__ bits) {
+  const uint64_t pos = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool ok = false;
+  if (pos < n) {
+    const uint64_t r = row_ids[pos];
+    ok = r < n_allow && allow[r] != 0;
+  }
+  const uint64_t m = __ballot(ok);
+  const int lane = threadIdx.x & 63;
+  const uint64_t w0 = (pos - lane) >> 5;   // first 32-bit word of this wave's 64 positions
+  if (lane == 0 && pos < n + 64) { bits[w0] = (uint32_t)m; bits[w0 + 1] = (uint32_t)(m >> 32); }
+}
+
+int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                    uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
+                                    uint64_t *ids, float *dists) {
+  LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search_filtered: NULL argument");
+  LH_REQUIRE(ctx->device == idx->device, "search_filtered: context and index live on different devices");
+  LH_REQUIRE(idx->m != 0, "search_filtered: not an IVF_PQ index");
+  LH_REQUIRE(allow_by_rowid || n_allow == 0, "search_filtered: NULL filter");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  const uint64_t n = idx->n;
+  uint32_t *bits = ctx->scratch_t<uint32_t>("search.allow_bits", (size_t)(n / 32 + 4));
+  if (!bits) return LANCE_HIP_ENOMEM;
+  if (n > 0)
+    hipLaunchKernelGGL(build_allow_bits_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, idx->row_ids, n, allow_by_rowid, n_allow, bits);
+  uint32_t *flags = nullptr;
+  const float *qf;
+  LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags, bits));
   return check_flags(ctx, flags, nq);
 }
 
@@ -1125,7 +1164,7 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
   uint32_t *flags = nullptr;
   const float *qf = nullptr;
   int r = as_f32(ctx, model_dtype(dtype), q_residual, d, "f16.q", &qf);
-  if (r == LANCE_HIP_OK) r = ivfpq_search_enqueue(ctx, ix, qf, 1, k, 1, 0, has_range, lower, upper, out_ids, out_dists, &flags);
+  if (r == LANCE_HIP_OK) r = ivfpq_search_enqueue(ctx, ix, qf, 1, k, 1, 0, has_range, lower, upper, out_ids, out_dists, &flags, nullptr);
   if (r == LANCE_HIP_OK) r = check_flags(ctx, flags, 1);
   if (r == LANCE_HIP_OK && out_n_host) {
     std::vector<uint64_t> ih(k);

@@ -12,6 +12,11 @@ constexpr uint32_t FLAG_OVERFLOW = 1u, FLAG_AMBIGUOUS = 2u, FLAG_BADROW = 4u;
 constexpr int SCAN_LCAP = 256;    // entries handed to the merge kernel per (query, split)
 constexpr int SCAN_MAX_KEFF = 128;
 
+// prefilter (flat/index.rs:129-165, RowIdMask): one bit per STORAGE position, NULL = no filter
+__device__ __forceinline__ bool row_allowed(const uint32_t *__restrict__ allow, uint32_t pos) {
+  return allow == nullptr || ((allow[pos >> 5] >> (pos & 31u)) & 1u) != 0u;
+}
+
 static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 __device__ __forceinline__ uint32_t find_partition_dev(const uint32_t *__restrict__ offs, int nlist, uint32_t slot) {

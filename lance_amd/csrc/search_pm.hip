@@ -58,6 +58,7 @@ struct PmArgs {
   int cls;                      // which items this launch covers: 0 = nearest-partition pairs, 1 = the rest, 2 = all
   int unbounded;                // class-1 launch whose queries start without a bound (quantised flow, class B)
   int loop;                     // 1: workgroups loop over the items of their class (item count known on the device only)
+  const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
   int bound_pass;               // class 0 only: compute Tglobal bounds, keep no candidates (RPL = 0 instantiation)
   const int4 *desc;             // [items] {partition, q0, q1 (-1 = none), 0}: filled by pm_item_desc_kernel
   const float *centroids, *codebook;
@@ -283,8 +284,10 @@ __device__ __forceinline__ void pm_scan_item(const PmArgs &p, const uint32_t ite
             }
         }
         if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
-        mn0 = min(mn0, order_key(d0));
-        mn1 = min(mn1, order_key(d1));
+        if (row_allowed(p.allow, off + (uint32_t)row)) {   // a filtered row cannot be one of the k the bound stands on
+          mn0 = min(mn0, order_key(d0));
+          mn1 = min(mn1, order_key(d1));
+        }
       }
     }
     kth_smallest_bs<PM_BS>(mn0, p.keff - 1, sorted, &misc[4]);
@@ -327,6 +330,7 @@ __device__ __forceinline__ void pm_scan_item(const PmArgs &p, const uint32_t ite
     }
     if constexpr (METRIC == METRIC_DOT) { d0 = d0 - ((float)m - 1.0f); d1 = d1 - ((float)m - 1.0f); }
     const uint32_t k0 = order_key(d0), k1 = order_key(d1);
+    if ((k0 <= T0 || (has1 && k1 <= T1)) && !row_allowed(p.allow, off + (uint32_t)row)) return;
     if (k0 <= T0) {
       const uint32_t slot = atomicAdd(&misc[0], 1u);
       if (slot < CAP) { ck0[slot] = k0; cp0[slot] = off + (uint32_t)row; } else misc[5] = misc[5] | ROUND_OVF;
@@ -577,7 +581,7 @@ static size_t pm_lds_base(int d, int m) {
 // pass found fewer than keff rows have no bound: they go through the exact pair kernel (class B) and its pool.
 static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
                               uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
-                              uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags) {
+                              uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const size_t npairs = (size_t)nq * nprobes;
   const uint32_t max_items0 = (uint32_t)(nq / 2 + nlist + 2);
@@ -615,7 +619,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.prof = nullptr;
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
-  a.unbounded = 0; a.loop = 0;
+  a.unbounded = 0; a.loop = 0; a.allow = allow;
   {
     // bound pass: the nq (query, nearest partition) pairs grouped by partition, two queries per item
     ScopedTimer t(ctx, "pm_group");
@@ -643,7 +647,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   }
   {
     ScopedTimer t(ctx, "ivfpq_scan_c1");
-    LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf));
+    LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow));
   }
   if (getenv("LANCE_HIP_Q_STATS")) {   // diagnosis: how many rows survive the integer filter
     std::vector<uint32_t> sc(npairs), tb(nq);
@@ -671,7 +675,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     o.out_ids = ids; o.out_dists = dists; o.cand_rid = cand_rid; o.cand_cnt = cand_cnt; o.flags = flags;
     o.part_offsets = ix->part_offsets; o.nlist = nlist;
     ScopedTimer t(ctx, "ivfpq_merge");
-    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o));
+    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o, allow));
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
@@ -680,11 +684,11 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
 // scan + merge for the whole batch; outputs as the query-major path (ids/dists or refine candidates)
 int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
                         uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
-                        uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags) {
+                        uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
   if (getenv("LANCE_HIP_PM_NOBOUND") == nullptr && qscan_supported(ix, nq, nprobes))
-    return ivfpq_scan_merge_q(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags);
+    return ivfpq_scan_merge_q(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags, allow);
   const size_t npairs = (size_t)nq * nprobes;
   uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)2 * nlist + 1);
   uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);
@@ -719,7 +723,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.desc = desc;
-  a.unbounded = 0; a.loop = 0;
+  a.unbounded = 0; a.loop = 0; a.allow = allow;
   a.prof = nullptr;
   if (getenv("LANCE_HIP_PM_PROF")) {
     a.prof = ctx->scratch_t<unsigned long long>("pm.prof", 8);

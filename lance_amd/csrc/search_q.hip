@@ -127,6 +127,7 @@ struct QscanArgs {
   uint32_t *seg_cnt;            // [nq * nprobes] survivors of (query, probe) -- zeroed before the launch
   uint32_t *seg_pos;            // [nq * nprobes][Q_CAP] storage positions
   uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
+  const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
 };
 
 template <int SD, int MU>
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
               }
           }
           const bool p0 = (a0 & 0xFFFFu) <= LIM, p1 = (a0 >> 16) <= LIM, p2 = (a1 & 0xFFFFu) <= LIM, p3 = (a1 >> 16) <= LIM;
-          if (p0 | p1 | p2 | p3) {
+          if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
             const uint32_t pos = off + (uint32_t)row;
             if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) cand[0 * Q_CAP + slot] = pos; }
             if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) cand[1 * Q_CAP + slot] = pos; }
@@ -286,6 +287,7 @@ struct QmergeArgs {
   uint32_t *pool_key, *pool_pos, *pool_cnt;
   int pool_cap;
   const uint32_t *qovf;          // [nq] != 0: some segment of the query overflowed (its rows come through the pool)
+  const uint32_t *allow;         // prefilter bitmap (rescan)
   SelectOut o;
 };
 
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
             for (int bb = 0; bb < 4; ++bb) dist += lutx[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
         }
         const uint32_t kk = order_key(dist);
-        if (kk <= T) {
+        if (kk <= T && row_allowed(a.allow, off + (uint32_t)row)) {
           const uint32_t slot = atomicAdd(&misc[0], 1u);
           if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = off + (uint32_t)row; } else misc[3] = 1u;   // an entry was lost
         }
@@ -545,13 +547,13 @@ static bool launch_qscan_sd(lance_hip_ctx *ctx, const QscanArgs &a, int m, unsig
 
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
-                 uint32_t *seg_pos, uint32_t *qovf) {
+                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QscanArgs a;
   a.q = qs; a.pair_idx = pair_idx; a.item_start = item_start4; a.desc = desc4;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
-  a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
+  a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
   LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
   LH_CHECK_HIP(hipMemsetAsync(qovf, 0, (size_t)nq * 4, ctx->stream));
   const size_t lds = qscan_lds_bytes(d, m);
@@ -579,13 +581,13 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
 
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
-                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o) {
+                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
   a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
   a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
-  a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap;
+  a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.allow = allow;
   a.o = o;
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
   bool ok = true;

@@ -74,8 +74,10 @@ def train_kmeans_sharded(engine, x_local, k, n_total, max_iters=50, tol=1e-4, ba
             dist.broadcast(cent, src=0, group=group)
     else:
         cent = torch.as_tensor(init, dtype=torch.float32).to(dev).clone()
-    split_rng = Rng(seed ^ 0x5BD1E995)
     bf_param = f32(balance_factor) / f32(n_total)          # train_kmeans :1344
+    if hasattr(engine, "kmeans_shard_begin") and isinstance(x_local, torch.Tensor) and x_local.is_cuda:
+        return _train_kmeans_sharded_device(engine, x_local, cent, k, n_total, max_iters, tol, float(bf_param), seed, metric, group, world)
+    split_rng = Rng(seed ^ 0x5BD1E995)
     sizes = np.zeros(k, np.int64)
     adjusted = f32(FLT_MAX)
     loss = float(np.finfo(np.float64).max)
@@ -110,6 +112,45 @@ def train_kmeans_sharded(engine, x_local, k, n_total, max_iters=50, tol=1e-4, ba
             break
         loss = last_loss
     return cent, last_loss, iters
+
+
+def _train_kmeans_sharded_device(engine, x_local, cent, k, n_total, max_iters, tol, bf_scaled, seed, metric, group, world):
+    """The same loop with every step enqueued on ONE stream (the engine twin bound to torch's current stream, on which
+    torch.distributed orders its RCCL kernels): local E-step + partials -> all-reduce SUM of the fused f32 buffer [k*d sums | k
+    counts] and of the f64 losses, all-reduce MAX of the radii -> update kernel (centroids, loss, balance factor,
+    convergence, shared-seed split, next bias).  The host only looks at the state every 8 iterations to stop enqueueing."""
+    from .engine import Engine
+    twin = getattr(engine, "_torch_stream_twin", None)
+    if twin is None:
+        # a dedicated (non-default) torch stream: kernels enqueued through the twin context and the collectives torch.distributed
+        # enqueues while this stream is current are ordered on it, without the legacy default stream's implicit joins
+        side = torch.cuda.Stream(device=engine.device)
+        with torch.cuda.stream(side):
+            twin = Engine(device=engine.device, use_torch_stream=True)
+        twin._side_stream = side
+        engine._torch_stream_twin = twin
+    side = twin._side_stream
+    side.wait_stream(torch.cuda.current_stream())
+    x_local = x_local.to(torch.float32).contiguous()
+    cent = cent.contiguous()
+    loss, iters = 0.0, 0
+    with torch.cuda.stream(side):
+        st = twin.kmeans_shard_begin(k, x_local.shape[1], bf_scaled, seed)
+        for it in range(1, max_iters + 1):
+            twin.kmeans_shard_estep(st, x_local, cent, metric)
+            if world > 1:
+                dist.all_reduce(st["buf"], op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(st["losses"], op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(st["radius"], op=dist.ReduceOp.MAX, group=group)
+            twin.kmeans_shard_update(st, cent, n_total, tol, it)
+            if it % 8 == 0 or it == max_iters:
+                loss, iters, active = twin.kmeans_shard_end(st)
+                if not active:
+                    break
+        if iters == 0:
+            loss, iters, _ = twin.kmeans_shard_end(st)
+    torch.cuda.current_stream().wait_stream(side)
+    return cent, loss, iters
 
 
 def block_ranges(total, world):
@@ -243,6 +284,188 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
     return lv.IvfPqIndex(ix, params, stats, part, codes)
 
 
+def all_gather_var(local, group=None):
+    """all-gather of row blocks of DIFFERENT lengths (rank order): one all-gather of the lengths, one of the zero-padded
+    blocks."""
+    world = dist.get_world_size(group)
+    nloc = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(nloc) for _ in range(world)]
+    dist.all_gather(counts, nloc, group=group)
+    counts = [int(c.item()) for c in counts]
+    per = max(counts) if counts else 0
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((per * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return torch.cat([out[r * per: r * per + c] for r, c in enumerate(counts)]).contiguous(), counts
+
+
+def exchange_by_owner(owner, tensors, group=None):
+    """Rows go to the rank that owns them (`owner` int64 [n], -1 = dropped): one all_to_all_single per tensor after one for
+    the counts.  Rows arrive grouped by source rank, in the source's order.  -> list of received tensors."""
+    world = dist.get_world_size(group)
+    keep = owner >= 0
+    order = torch.argsort(owner[keep], stable=True)
+    sel = torch.nonzero(keep).reshape(-1)[order]
+    send_counts = torch.bincount(owner[keep], minlength=world).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc, rc = [int(v) for v in send_counts.tolist()], [int(v) for v in recv_counts.tolist()]
+    out = []
+    for t in tensors:
+        src = t[sel].contiguous()
+        dst = torch.empty((sum(rc),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        out.append(dst)
+    return out
+
+
+class RowShardedBuild:
+    """What create_index_rowsharded leaves on every rank."""
+
+    def __init__(self, centroids, codebook, part_local, codes_local, row0, n_total, stats, params):
+        self.centroids, self.codebook = centroids, codebook
+        self.part_local, self.codes_local = part_local, codes_local    # this rank's rows only
+        self.row0, self.n_total = row0, n_total                          # global row id of local row i = row0 + i
+        self.stats, self.params = stats, params
+
+
+def create_index_rowsharded(x_local, metric="l2", num_partitions=256, num_sub_vectors=16, num_bits=8, max_iters=50, sample_rate=256,
+                            seed=42, engine=None, group=None, ivf_training="sharded"):
+    """IVF_PQ build where every rank holds ONLY its contiguous block of the rows (rank r: rows block_ranges(n_total)[r]; the
+    vectors never leave their GPU).  Per stage:
+      * IVF k-means -- each rank samples its share of the num_partitions * sample_rate training rows from its own block;
+        "sharded": Lloyd iterations with one all-reduce of [k*d sums | k counts] (+ the per-cluster loss / radius reductions)
+        per iteration over RCCL (train_kmeans_sharded); "replicated": the 33 MB sample is all-gathered once and every rank
+        runs the same deterministic single-GPU training (no collective inside the loop);
+      * PQ -- each rank computes the residuals of its share of the training rows, the residual sample is all-gathered and the
+        M independent sub-quantisers are trained model-parallel, then the codebook slices are all-gathered;
+      * transform -- every rank encodes its own rows.  Nothing else is exchanged here: `replica_index` / `list_shard_index`
+        move the 20 bytes per row of (partition id, PQ code) -- and the raw vectors only if refine needs them on another GPU.
+    -> RowShardedBuild"""
+    import time
+
+    from . import vector as lv
+    from .engine import to_device
+    eng = engine or lv.default_engine()
+    on_gpu = torch.cuda.is_available()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    params = lv.IvfPqParams(num_partitions, num_sub_vectors, num_bits, lv._normalize_metric_type(metric), max_iters, sample_rate, seed)
+    x_local = to_device(x_local) if on_gpu else torch.as_tensor(x_local)
+    n_local, d = x_local.shape
+    dev = x_local.device
+    nl = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(nl) for _ in range(world)]
+    dist.all_gather(counts, nl, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_total, row0 = sum(counts), sum(counts[:rank])
+    stats = lv.BuildStats()
+    stats.ivf_training = ivf_training
+    kmetric = "l2" if params.metric == "cosine" else params.metric
+
+    def timed(name, fn):
+        if on_gpu:
+            torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = fn()
+        if on_gpu:
+            torch.cuda.synchronize()
+        stats.seconds[name] = time.perf_counter() - t
+        return out
+
+    def local_sample(target_total, salt):
+        # this rank's proportional share of a `target_total`-row training sample, drawn from its own rows
+        share = n_local if n_total <= target_total else int(round(target_total * n_local / n_total))
+        rng = np.random.default_rng(seed + salt + 7919 * rank)
+        idx = lv._sample_rows(n_local, share, rng)
+        s = x_local if idx is None else x_local[torch.from_numpy(idx).to(dev)]
+        if params.metric == "cosine":
+            s = eng.normalize(s)
+        return s[torch.isfinite(s).all(dim=1)]
+
+    def train_ivf():
+        samp = local_sample(num_partitions * sample_rate, 0)
+        if ivf_training == "replicated":
+            full, _ = all_gather_var(samp, group)
+            return eng.kmeans_train(full, num_partitions, max_iters=max_iters, balance_factor=1.0, seed=seed, metric=kmetric)
+        nt = torch.tensor([samp.shape[0]], dtype=torch.int64, device=dev)
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM, group=group)
+        return train_kmeans_sharded(eng, samp, num_partitions, int(nt.item()), max_iters, 1e-4, 1.0, None, seed, kmetric, group)
+
+    cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", train_ivf)
+    kc = 1 << num_bits
+    sd = d // num_sub_vectors
+
+    def train_pq():
+        ps = local_sample(sample_rate * kc, 1)
+        if kmetric == "l2":
+            part, _ = eng.assign(ps, cent, "l2")
+            ps = eng.residual(ps, cent, part)
+        psample, _ = all_gather_var(ps.to(torch.float32), group)
+        _, ranges = block_ranges(num_sub_vectors, world)
+        m0, m1 = ranges[rank]
+        mine = torch.zeros((m1 - m0, kc, sd), dtype=torch.float32, device=dev)
+        its = torch.zeros(m1 - m0, dtype=torch.int32, device=dev)
+        if m1 > m0:
+            cols = psample[:, m0 * sd: m1 * sd].contiguous()
+            c, it = eng.pq_train(cols, m1 - m0, num_bits, max_iters, sample_rate, seed + 2 + m0)
+            mine[:] = c
+            its[:] = torch.from_numpy(np.asarray(it).astype(np.int32)).to(dev)
+        return all_gather_blocks(mine, num_sub_vectors, group), all_gather_blocks(its, num_sub_vectors, group).cpu().numpy().astype(np.uint32)
+
+    cb, stats.pq_iters = timed("train_pq", train_pq)
+
+    def transform():
+        if n_local == 0:
+            return (torch.empty(0, dtype=torch.int32, device=dev),
+                    torch.empty((0, num_sub_vectors if num_bits == 8 else num_sub_vectors // 2), dtype=torch.uint8, device=dev))
+        p, c, _ = eng.ivfpq_encode(x_local, cent, cb, params.metric)
+        return p, c
+
+    part_l, codes_l = timed("transform", transform)
+    return RowShardedBuild(cent, cb, part_l, codes_l, row0, n_total, stats, params)
+
+
+def replica_index(build, x_local=None, engine=None, group=None, index_factory=None):
+    """Full index replica on every rank from a row-sharded build: all-gather of the (partition id, code) columns -- 20 bytes per
+    row -- and, when refine is wanted (x_local given), of the raw vectors.  Row ids are global row numbers."""
+    from . import vector as lv
+    from .engine import DeviceIndex
+    eng = engine or lv.default_engine()
+    make_index = index_factory or DeviceIndex.create
+    part, _ = all_gather_var(build.part_local, group)
+    codes, _ = all_gather_var(build.codes_local, group)
+    raw = None
+    if x_local is not None:
+        raw, _ = all_gather_var(torch.as_tensor(x_local), group)
+    ix = make_index(eng, build.params.metric, build.centroids, build.codebook, part, codes, None, raw=raw)
+    return lv.IvfPqIndex(ix, build.params, build.stats, part, codes), raw
+
+
+def list_shard_index(build, x_local=None, engine=None, group=None, index_factory=None):
+    """IVF lists sharded over the ranks (list p -> rank p % world) from a row-sharded build: every row's (partition id, code,
+    global row id [, raw vector]) goes to the rank that owns its list with one all_to_all per column.  The device index
+    stores local row numbers (ascending in global id within a source rank, sources in rank order -- so (dist, rowid)
+    comparisons on the device order rows as the global ids would) and `l2g` maps them back.  -> (DeviceIndex, l2g)"""
+    from . import vector as lv
+    from .engine import DeviceIndex
+    eng = engine or lv.default_engine()
+    make_index = index_factory or DeviceIndex.create
+    world = dist.get_world_size(group)
+    part = build.part_local.to(torch.int64)
+    owner = torch.where((part >= 0) & (part < (1 << 31)), part % world, torch.full_like(part, -1))
+    gid = build.row0 + torch.arange(part.shape[0], dtype=torch.int64, device=part.device)
+    cols = [build.part_local, build.codes_local, gid]
+    if x_local is not None:
+        cols.append(torch.as_tensor(x_local))
+    got = exchange_by_owner(owner, cols, group)
+    pl, cl, l2g = got[0], got[1], got[2]
+    # sources arrive in rank order and every source block is ascending in global id, and rank blocks are contiguous in the
+    # global numbering: l2g is ascending, local order == global order
+    ix = make_index(eng, build.params.metric, build.centroids, build.codebook, pl, cl, None, raw=got[3] if x_local is not None else None)
+    return ix, l2g
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Search over IVF lists SHARDED across the ranks (SURVEY 8e, the C5 shape: 32 GB of codes + 8 GB of row ids do
 # not belong on one GPU next to the raw vectors).  List p lives on rank p % world.  Centroids and codebook are
@@ -326,9 +549,10 @@ def load_list_shard(engine, index_dir, raw=None, dtype=None, group=None):
     return ix, torch.empty(0, dtype=torch.int64)
 
 
-def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group=None):
+def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group=None, engine=None):
     """local_search(q, kk, nprobes, refine_factor) -> (local ids int64 [-1 = none], dists) over this rank's lists.
-    Every rank passes the SAME query batch and gets the same (ids [nq,k] int64 global, dists [nq,k])."""
+    Every rank passes the SAME query batch and gets the same (ids [nq,k] int64 global, dists [nq,k]).
+    engine: merge the gathered candidates with the device kernel (lance_hip_merge_topk) instead of torch sorts."""
     world = dist.get_world_size(group)
     keff = k * refine_factor if refine_factor else k
     li, ld = local_search(q, keff, nprobes, 0)
@@ -352,6 +576,8 @@ def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group
         buf = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(buf, t, group=group)
         gathered.append(torch.cat(buf, dim=1))
+    if engine is not None and gathered[0].shape[1] <= 4096:
+        return engine.merge_topk(gathered[0], gathered[1], k, exact=gathered[2] if refine_factor else None, keff=keff)
     if not refine_factor:
         return merge_topk(gathered[0], gathered[1], k)
     # global top-keff by (PQ distance, row id), then order those by (exact distance, row id) and fetch k

@@ -177,6 +177,31 @@ class Engine:
         check(self.lib.lance_hip_kmeans_finalize(self.h, _lib.F32, _ptr(buf), k, d, _ptr(cent)))
         return cent
 
+    # ---- row-sharded Lloyd loop, enqueue-only (lance_hip_kmeans_shard_*): see lance_amd/dist.py -------------------------
+    def kmeans_shard_begin(self, k, d, balance_factor_scaled, seed):
+        """-> dict of the device buffers one sharded training run needs (state, bias, reduce buffers)"""
+        dev = _dev()
+        st = {"state": torch.zeros(128, dtype=torch.uint8, device=dev), "bias": torch.zeros(k, dtype=torch.float32, device=dev),
+              "buf": torch.zeros(k * d + k, dtype=torch.float32, device=dev), "losses": torch.zeros(k, dtype=torch.float64, device=dev),
+              "radius": torch.zeros(k, dtype=torch.float32, device=dev), "k": k, "d": d, "bfs": float(balance_factor_scaled)}
+        check(self.lib.lance_hip_kmeans_shard_begin(self.h, k, st["bfs"], seed, _ptr(st["state"]), _ptr(st["bias"])))
+        return st
+
+    def kmeans_shard_estep(self, st, x_local, cent, metric="l2"):
+        n = x_local.shape[0]
+        check(self.lib.lance_hip_kmeans_shard_estep(self.h, METRICS[metric], _ptr(x_local) if n else None, n, st["d"], _ptr(cent), st["k"],
+                                                    _ptr(st["bias"]) if st["bfs"] != 0 else None, _ptr(st["state"]), _ptr(st["buf"]),
+                                                    _ptr(st["losses"]), _ptr(st["radius"])))
+
+    def kmeans_shard_update(self, st, cent, n_total, tol, it):
+        check(self.lib.lance_hip_kmeans_shard_update(self.h, _ptr(st["state"]), _ptr(st["buf"]), _ptr(st["losses"]), _ptr(st["radius"]),
+                                                     _ptr(cent), _ptr(st["bias"]), st["k"], st["d"], n_total, st["bfs"], tol, it))
+
+    def kmeans_shard_end(self, st):
+        loss = C.c_double(0); iters = C.c_uint32(0); active = C.c_int(0)
+        check(self.lib.lance_hip_kmeans_shard_end(self.h, _ptr(st["state"]), C.byref(loss), C.byref(iters), C.byref(active)))
+        return loss.value, iters.value, bool(active.value)
+
     def pq_train(self, residuals, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
         r, dt = _vec(residuals)
         n, d = r.shape
@@ -283,6 +308,19 @@ class Engine:
         check(self.lib.lance_hip_timing_query(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+
+    def merge_topk(self, ids, dists, k, exact=None, keff=None):
+        """(dist, rowid) merge of gathered candidate lists on the device (lance_hip_merge_topk): ids [nq, C] int64 (-1 = none),
+        dists [nq, C]; with `exact` the keff best by PQ distance are re-ranked by the exact distances.  -> ([nq,k], [nq,k])"""
+        ids = to_device(ids, torch.int64); dists = to_device(dists, torch.float32)
+        ex = None if exact is None else to_device(exact, torch.float32)
+        nq, c = ids.shape
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=ids.device)
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=ids.device)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_merge_topk(self.h, _ptr(ids), _ptr(dists), _ptr(ex), nq, c, keff if keff is not None else k, k,
+                                            _ptr(out_i), _ptr(out_d)))
+        return out_i, out_d
 
     def ubench(self, what):
         """in-process ceilings for bench.py (lance_hip_ubench): "lds4" / "lds8" / "lds16" lane-gathers per second,
@@ -471,6 +509,22 @@ class DeviceIndex:
             # stream reads them (a caller that hands over ready tensors pays nothing)
             torch.cuda.current_stream().synchronize()
         check(fn(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
+        return ids, dists
+
+    def search_filtered(self, q, k, nprobes, allow, refine_factor=0):
+        """Search under a row-id prefilter (lance_hip_ivfpq_search_filtered): `allow` = boolean array indexed by row id.  The
+        mask is tested inside the scan kernels; no filtered copy of the index is built."""
+        d = self.centroids.shape[1]
+        t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
+        q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
+        a = allow if isinstance(allow, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(allow, dtype=bool))
+        a = a.to(torch.uint8).to(_dev()).contiguous()
+        nq = q.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        torch.cuda.synchronize()
+        check(self.engine.lib.lance_hip_ivfpq_search_filtered(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(a),
+                                                              a.numel(), _ptr(ids), _ptr(dists)))
         return ids, dists
 
     def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0):

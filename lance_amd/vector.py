@@ -157,18 +157,54 @@ class IvfPqIndex:
         rid = np.arange(part.size, dtype=np.uint64)[keep]
         return rid, part[keep], self.codes.cpu().numpy()[keep]
 
-    def nearest(self, q, k=10, nprobes=1, refine_factor=None, prefilter=None, distance_range=None):
+    def nearest(self, q, k=10, nprobes=1, refine_factor=None, prefilter=None, distance_range=None, minimum_nprobes=None,
+                maximum_nprobes=None):
         """-> (row ids int64 [nq,k] (-1 = missing), distances f32 [nq,k]) as numpy.
         prefilter: boolean array over row ids (True = row may be returned) -- `nearest=..., filter=..., prefilter=True`
-        of the reference (scanner.rs prefilter -> FlatIndex::search's RowIdMask branch, flat/index.rs:129-165).
+        of the reference (scanner.rs prefilter -> FlatIndex::search's RowIdMask branch, flat/index.rs:129-165).  The mask is
+        tested inside the scan kernels (lance_hip_ivfpq_search_filtered); no filtered copy of the index is built.
         distance_range: (lower, upper), either may be None -- rows with lower <= d < upper only (Query::lower_bound /
-        upper_bound, flat/index.rs:98-113)."""
-        ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
+        upper_bound, flat/index.rs:98-113).
+        minimum_nprobes / maximum_nprobes: adaptive probing (Query::minimum_nprobes / maximum_nprobes; ANNIvfSubIndexExec
+        initial_search + late_search, knn.rs:714-860): every query searches its `minimum_nprobes` nearest partitions; a query
+        that found fewer than k rows (a selective prefilter, tiny partitions) goes on through further partitions, nearest
+        first, until it has k rows or `maximum_nprobes` (default: all) partitions were searched.  `nprobes=n` alone means
+        minimum = maximum = n, as in pylance (python/src/dataset.rs:984-1020).  The reference extends the search one
+        partition at a time from concurrently running tasks, so how far it overshoots depends on thread timing; here the
+        extension is deterministic: the number of partitions doubles until the query is satisfied."""
+        rf = 0 if refine_factor is None else refine_factor
+        nlist = self.params.num_partitions
+        min_np = nprobes if minimum_nprobes is None else minimum_nprobes
+        max_np = (min_np if minimum_nprobes is None else nlist) if maximum_nprobes is None else maximum_nprobes
+        max_np = max(min(max_np, nlist), min(min_np, nlist))
+        min_np = min(min_np, max_np)
+        if prefilter is not None and self.params.num_bits == 4:
+            raise NotImplementedError("prefilter on a 4-bit PQ index: the reference scores filtered rows with the unquantised "
+                                      "table (pq/storage.rs:897-908), which this engine's 4-bit scan does not implement yet")
         if distance_range is not None:
+            ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
             lo, hi = distance_range
-            ids, dists = ix.search_range(q, k, nprobes, lo, hi, refine_factor=0 if refine_factor is None else refine_factor)
+            ids, dists = ix.search_range(q, k, min_np, lo, hi, refine_factor=rf)
             return ids.cpu().numpy(), dists.cpu().numpy()
-        ids, dists = ix.search(q, k, nprobes, 0 if refine_factor is None else refine_factor)
+
+        def run(qq, npb):
+            if prefilter is None:
+                return self._ix.search(qq, k, npb, rf)
+            return self._ix.search_filtered(qq, k, npb, prefilter, rf)
+
+        ids, dists = run(q, min_np)
+        if max_np > min_np:
+            qt = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
+            qt = qt.reshape(-1, self._ix.centroids.shape[1])
+            npb = min_np
+            while npb < max_np:
+                starved = torch.nonzero((ids < 0).any(dim=1)).reshape(-1)     # fewer than k rows found so far
+                if starved.numel() == 0:
+                    break
+                npb = min(max_np, max(npb * 2, npb + 1))
+                si, sd = run(qt[starved.cpu()] if not qt.is_cuda else qt[starved], npb)
+                ids[starved] = si
+                dists[starved] = sd
         return ids.cpu().numpy(), dists.cpu().numpy()
 
     def _storage_rows(self):

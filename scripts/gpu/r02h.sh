@@ -1,0 +1,14 @@
+# GPU call r02h: bench N=1, bench with the distributed path forced on one rank (nccl world 1), gated top-4, probe seed fix
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02h; mkdir -p $O
+cd $R
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -4 $O/pytest.log | cut -c1-300
+timeout 300 python scripts/probe_assign.py > $O/assign.log 2>&1; grep -v amdgpu.ids $O/assign.log | cut -c1-900
+run() { # name, env...
+  name=$1; shift
+  env "$@" timeout 400 python bench.py --steps 20 --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err
+  python -c "import json,sys; r=json.loads(open('$O/bench_$name.json').read().strip().splitlines()[-1]); print('$name', round(r['value']), round(r['ms_per_step'],4), r['recall_at_10'], r['exact_replays_last_step'], r['build_sec'], r['build_stages_ms'], r['multi_gpu'])" || tail -15 $O/bench_$name.err
+}
+run n1 A=1
+run dist1 LANCE_BENCH_FORCE_DIST=1

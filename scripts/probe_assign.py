@@ -31,6 +31,21 @@ def run(tag):
                      "ids_head": ids[:8].tolist()}
         np.save(f"/tmp/assign_{tag}_{name}.npy", ids.cpu().numpy())
         np.save(f"/tmp/assign_{tag}_{name}_d.npy", d.cpu().numpy())
+    # PQ encode: 1M residual-like rows, M = 16 sub-quantisers of 8 dimensions (and M = 32 x 4, M = 8 x 16)
+    for m in (16, 32, 8):
+        x = sift_like(1_000_000, 128, seed=77, device="cuda") - 60.0
+        cb = (torch.randn((m, 256, 128 // m), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + m)) * 40.0).contiguous()
+        codes = eng.pq_encode(x, cb)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            codes = eng.pq_encode(x, cb)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        name = f"pq_encode_1Mx128_m{m}"
+        out[name] = {"ms": min(ts) * 1e3, "sum": int(codes.long().sum().item())}
+        np.save(f"/tmp/assign_{tag}_{name}.npy", codes.cpu().numpy())
     print(json.dumps(out))
 
 
@@ -48,3 +63,7 @@ if __name__ == "__main__":
             da, db = np.load(f"/tmp/assign_mfma_{name}_d.npy"), np.load(f"/tmp/assign_exact_{name}_d.npy")
             print(name, "ids equal:", bool((a == b).all()), "mismatches:", int((a != b).sum()), "dists bit-equal:",
                   bool((da.view(np.uint32) == db.view(np.uint32)).all()))
+        for m in (16, 32, 8):
+            name = f"pq_encode_1Mx128_m{m}"
+            a, b = np.load(f"/tmp/assign_mfma_{name}.npy"), np.load(f"/tmp/assign_exact_{name}.npy")
+            print(name, "codes equal:", bool((a == b).all()), "mismatches:", int((a != b).sum()))

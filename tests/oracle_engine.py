@@ -173,6 +173,12 @@ class OracleDeviceIndex:
         return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
 
 
+    def search_filtered(self, q, k, nprobes, allow, refine_factor=0):
+        raw = None if self._raw is None else self._raw.numpy().astype(f32)
+        i, d = self.o.search(_np(q).astype(f32), k, nprobes, refine=refine_factor, raw=raw if refine_factor else None,
+                             prefilter=np.ascontiguousarray(_np(allow), dtype=bool))
+        return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
+
     def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0):
         lo = np.finfo(f32).min if lower is None else lower
         hi = np.finfo(f32).max if upper is None else upper

@@ -87,3 +87,9 @@ def test_dryrun_smoke_flow(fake, oracle):
     ids, dists = idx.nearest(q, k=10, nprobes=16)
     oi, od = oracle.build_index(x, idx.centroids, idx.codebook).search(q, 10, 16)
     assert (ids.view(np.uint64) == oi).all() and (dists.view(np.uint32) == od.view(np.uint32)).all()
+
+
+def test_dryrun_adaptive_probing(fake, oracle):
+    import lance_amd
+    import test_gpu_pm_scan as P
+    P.test_adaptive_probing_extends_starved_queries(lance_amd, oracle)

@@ -363,3 +363,72 @@ def test_list_sharded_search_from_reference_index_files(world, tmp_path):
             gi, gd = r[1][key]
             assert (gi.astype(np.uint64) == oi).all(), (world, key, r[0])
             assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+
+
+# ---- row-sharded build: every rank holds only its block of rows (lance_amd/dist.py: create_index_rowsharded) --------
+def _rowshard_worker(rank, world, port, mode, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from oracle_engine import OracleDeviceIndex, OracleEngine as FullOracleEngine
+    from lance_amd.dist import (block_ranges, create_index_rowsharded, list_shard_index, replica_index, search_list_sharded)
+
+    class Eng(FullOracleEngine, OracleEngine):      # the host-loop contract (estep_partial / finalize) + the build steps
+        pass
+
+    rng = np.random.default_rng(3)
+    n, d, nlist, m = 3001, 32, 8, 4
+    x = (rng.standard_normal((n, d)) * 2 + 1).astype(f32)
+    q = (rng.standard_normal((40, d)) * 2 + 1).astype(f32)
+    _, ranges = block_ranges(n, world)
+    lo, hi = ranges[rank]
+    xl = torch.from_numpy(x[lo:hi].copy())
+    eng = Eng()
+    b = create_index_rowsharded(xl, metric="l2", num_partitions=nlist, num_sub_vectors=m, max_iters=5, sample_rate=32, seed=7,
+                                engine=eng, ivf_training=mode)
+    assert b.row0 == lo and b.n_total == n and b.part_local.shape[0] == hi - lo
+    cent, cb = b.centroids.numpy(), b.codebook.numpy()
+    # the single-index oracle on the same model: what every distributed search below must return
+    oidx = oracle.build_index(x, cent, cb)
+    assert (b.part_local.numpy().view(np.uint32) == oidx.part_ids[lo:hi]).all()
+    assert (b.codes_local.numpy() == oidx.codes_rowmajor[lo:hi]).all()
+    factory = lambda e, metric, c, cbk, part, codes, rid, raw=None: OracleDeviceIndex.create(e, metric, c, cbk, part, codes, rid, raw=raw)
+    rep, raw = replica_index(b, xl, engine=eng, index_factory=factory)
+    assert raw.shape[0] == n and (raw.numpy() == x).all()
+    res = {"cent": cent, "cb": cb}
+    for k, nprobes, rf in ((10, 3, 0), (5, nlist, 0), (10, 4, 3)):
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        gi, gd = rep._ix.search(q, k, nprobes, rf)
+        assert (gi.numpy().view(np.uint64) == oi).all() and (gd.numpy().view(np.uint32) == od.view(np.uint32)).all(), ("replica", k, nprobes, rf)
+    shard, l2g = list_shard_index(b, xl, engine=eng, index_factory=factory)
+    assert (np.diff(l2g.numpy()) > 0).all()          # local order == global order
+    for k, nprobes, rf in ((10, 3, 0), (5, nlist, 0), (10, 4, 3)):
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        gi, gd = search_list_sharded(lambda qq, kk, npb, r: shard.search(qq, kk, npb, r), l2g, torch.from_numpy(q), k, nprobes, rf)
+        assert (gi.numpy().view(np.uint64) == oi).all() and (gd.numpy().view(np.uint32) == od.view(np.uint32)).all(), ("lists", k, nprobes, rf)
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "replicated"), (2, "replicated")])
+def test_rowsharded_build_replica_and_list_shards(world, mode):
+    """No rank ever sees another rank's vectors during the build (sampling, training, encode are local or collective); the
+    replica (all-gather of codes) and the list shards (all_to_all by list owner) both answer like one index built by the
+    oracle from the same model; every rank ends with the same model."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 36100 + (os.getpid() % 1500) + 3 * world + (0 if mode == "sharded" else 1)
+    procs = [ctx.Process(target=_rowshard_worker, args=(r, world, port, mode, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert (got[r]["cent"].view(np.uint32) == got[0]["cent"].view(np.uint32)).all()
+        assert (got[r]["cb"].view(np.uint32) == got[0]["cb"].view(np.uint32)).all()

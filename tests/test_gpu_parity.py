@@ -992,3 +992,51 @@ def test_load_lists_shards_on_one_gpu(eng, oracle, tmp_path, world):
         ri, rd = whole.search_device(q, k, nprobes)
         assert (gi == ri).all(), (world, k, nprobes)
         assert (_np(gd).view(np.uint32) == _np(rd).view(np.uint32)).all()
+
+
+def test_rowsharded_build_and_list_shards_world1(eng, oracle):
+    """lance_amd.dist.create_index_rowsharded (device-resident sharded Lloyd loop: enqueue-only E-step / all-reduce / update),
+    replica_index, list_shard_index (all_to_all by list owner) and search_list_sharded with the device (dist, rowid) merge --
+    RCCL with one rank here; the 2- and 3-rank logic runs on CPU in tests/test_dist_gloo.py.  Everything searched must equal the
+    oracle on the trained model, and the device merge must equal the torch-sort merge."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from lance_amd import dist as ld
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29793"
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        xh = sift_like(40000, 64, 511)
+        qh = sift_like(300, 64, 512)
+        x = torch.from_numpy(xh).cuda()
+        for mode in ("sharded", "replicated"):
+            b = ld.create_index_rowsharded(x, metric="l2", num_partitions=32, num_sub_vectors=16, sample_rate=64, engine=eng, ivf_training=mode)
+            assert b.stats.ivf_iters >= 1 and b.n_total == 40000 and b.row0 == 0
+            cent, cb = b.centroids.cpu().numpy(), b.codebook.cpu().numpy()
+            oidx = oracle.build_index(xh, cent, cb)
+            assert (b.part_local.cpu().numpy().view(np.uint32) == oidx.part_ids).all() and (b.codes_local.cpu().numpy() == oidx.codes_rowmajor).all()
+            rep, _ = ld.replica_index(b, x, engine=eng)
+            shard, l2g = ld.list_shard_index(b, x, engine=eng)
+            for k, nprobes, rf in ((10, 6, 0), (10, 32, 0), (10, 6, 5)):
+                oi, od = oidx.search(qh, k, nprobes, refine=rf, raw=xh if rf else None)
+                gi, gd = rep.search_device(qh, k, nprobes, rf)
+                assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all(), (mode, "replica", k, nprobes, rf)
+                fn = lambda qq, kk, npb, r: shard.search(qq, kk, npb, r)
+                li, ldist = ld.search_list_sharded(fn, l2g, torch.from_numpy(qh).cuda(), k, nprobes, rf, engine=eng)      # device merge
+                ti, td = ld.search_list_sharded(fn, l2g, torch.from_numpy(qh).cuda(), k, nprobes, rf)                 # torch-sort merge
+                assert (_np(li).view(np.uint64) == oi).all() and (_np(ldist).view(np.uint32) == od.view(np.uint32)).all(), (mode, "lists", k, nprobes, rf)
+                assert torch.equal(li, ti) and torch.equal(ldist, td)
+            shard.close()
+        # the sharded loop on one rank adds the rows in the single-GPU order: same centroids as the single-GPU trainer
+        samp = x[:16384]
+        c1, l1, i1 = eng.kmeans_train(samp, 32, max_iters=20, balance_factor=1.0, seed=3)
+        c2, l2, i2 = ld.train_kmeans_sharded(eng, samp, 32, 16384, max_iters=20, balance_factor=1.0, init=None, seed=3)
+        init = samp[torch.from_numpy(oracle.kmeans_init_indices(16384, 32, 3).astype(np.int64)).cuda()]
+        c3, l3, i3 = eng.kmeans_train(samp, 32, max_iters=20, balance_factor=1.0, init=init, seed=3)
+        assert i2 >= 1 and np.allclose(_np(c2), _np(c3), rtol=1e-5, atol=1e-4)
+    finally:
+        if created:
+            dist.destroy_process_group()

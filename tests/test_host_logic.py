@@ -205,8 +205,9 @@ class _OracleDeviceIndex:
 
 @pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
 def test_prefilter_compaction_equals_reference_prefilter_branch(oracle, monkeypatch, metric):
-    """IvfPqIndex.nearest(prefilter=) compacts the storage and searches it unfiltered.  That must equal the reference's
-    prefilter branch (flat/index.rs:129-165: skip unselected rows, DistCalculator::distance(id) for the rest, same heap),
+    """IvfPqIndex.prefiltered() (used with distance ranges; `nearest(prefilter=)` itself now tests the mask inside the scan
+    kernels, GPU test test_prefilter_mask_fused_in_every_scan_kernel) compacts the storage and searches it unfiltered.  That
+    must equal the reference's prefilter branch (flat/index.rs:129-165: skip unselected rows, DistCalculator::distance(id) for the rest, same heap),
     restated literally in the oracle (orc_ivfpq_search_filtered) -- with refine, for an index built by create_index and
     for one opened from files (storage order + explicit row ids)."""
     import lance_amd.vector as V
@@ -235,11 +236,11 @@ def test_prefilter_compaction_equals_reference_prefilter_branch(oracle, monkeypa
         for k, nprobes, rf in ((10, 4, None), (5, nlist, 3)):
             want_i, want_d = oidx.search(q, k, nprobes, refine=rf or 0, raw=x if rf else None, prefilter=allow)
             for ix in (built, opened):
-                got_i, got_d = ix.nearest(q, k, nprobes, refine_factor=rf, prefilter=allow)
+                got_i, got_d = ix.prefiltered(allow).nearest(q, k, nprobes, refine_factor=rf)
                 assert np.array_equal(got_i.view(np.uint64), want_i), (metric, frac, k)
                 assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
     short = np.ones(100, bool)                                      # a mask shorter than the table selects nothing beyond it
-    got_i, _ = built.nearest(q, 5, nlist, prefilter=short)
+    got_i, _ = built.prefiltered(short).nearest(q, 5, nlist)
     assert (got_i.view(np.uint64)[got_i != -1] < 100).all()
     with pytest.raises(NotImplementedError):
         V.IvfPqIndex(base, V.IvfPqParams(nlist, m, 4, metric), None).prefiltered(np.ones(n, bool))
