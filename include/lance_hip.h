@@ -127,6 +127,10 @@ int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, u
  * converged the state turns inactive: further estep / update calls leave every buffer untouched.  shard_end synchronises and
  * reports (loss, iterations, still active).  Reference loop: KMeans::train_kmeans, kmeans.rs:610-719.                     */
 #define LANCE_HIP_KMEANS_SHARD_STATE_BYTES 128
+/* The k row indices kmeans_random_init draws (kmeans.rs:149-170: k distinct rows; here the engine's seeded reservoir so that
+ * seeded runs are reproducible -- the reference seeds from the OS).  Host-only helper for callers that gather the initial
+ * centroids themselves (the sharded trainer: rank 0 draws from its rows and broadcasts).                                */
+int lance_hip_kmeans_init_indices(uint64_t n, uint32_t k, uint64_t seed, uint64_t *out_host);
 int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_factor_scaled, uint64_t seed, void *state, float *bias);
 int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
                                  const float *bias, const void *state, float *buf, double *losses, float *radius);

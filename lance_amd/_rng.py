@@ -44,6 +44,15 @@ class Rng:
 
 
 def kmeans_init_indices(n, k, seed):
+    """the k initial rows; the native helper when the library is built (identical stream), else the Python twin"""
+    try:
+        import ctypes as C
+        from . import _lib
+        out = np.empty(k, np.uint64)
+        _lib.check(_lib.load().lance_hip_kmeans_init_indices(int(n), int(k), int(seed) & M64, out.ctypes.data_as(C.c_void_p)))
+        return out
+    except (ImportError, OSError, AttributeError):
+        pass
     r = Rng(seed)
     out = np.arange(k, dtype=np.uint64)
     for i in range(k, n):

@@ -255,36 +255,52 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   if (n == 0) { if (loss_out_host) *loss_out_host = 0.0; return LANCE_HIP_OK; }
   const bool f16 = dtype == LANCE_HIP_F16;
   LH_REQUIRE(!(f16 && metric != LANCE_HIP_L2), "ivfpq_encode: f16 supports the L2 metric only in this version");
-  const float *xs, *centf, *cbf;
-  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xs));
+  const float *xs = nullptr, *centf, *cbf;
   LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, "f16.cent", &centf));
   LH_TRY(as_f32(ctx, model_dtype(dtype), codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
   centroids = centf; codebook = cbf;
   const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
+  float *dists = ctx->scratch_t<float>("encode.dists", (size_t)n);
+  if (!dists) return LANCE_HIP_ENOMEM;
+  PairwiseArgs pa;
+  pa.n = (int64_t)n; pa.ldx = d;
+  pa.cent = centf; pa.k = (int)nlist;
+  pa.ids = part_ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
+  pa.check_finite = true;  // KeepFiniteVectors fused into the assign kernel
+  // Native route (L2 / dot): the MFMA assign kernels and the fused residual + encode kernel read the rows in the column's own
+  // element type -- no f32 copy of the column, no residual array.  Cosine normalises first and takes the staged route.
+  const bool native = metric != LANCE_HIP_COSINE && encode_fused_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf);
+  bool assign_native = false;
+  if (native) {
+    pa.x_native = x; pa.x_dtype = dtype;
+    if (dtype == LANCE_HIP_F32) pa.x = static_cast<const float *>(x);
+    assign_native = dtype == LANCE_HIP_F32 || assign_reads_native(pa, (int)d, 1);
+  }
+  if (!assign_native) {
+    LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xs));
+    pa.x_native = nullptr; pa.x = xs;
+  }
   if (metric == LANCE_HIP_COSINE) {
     float *xn = ctx->scratch_t<float>("encode.norm", (size_t)n * d);
     if (!xn) return LANCE_HIP_ENOMEM;
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d, xn);
-    xs = xn;
+    xs = xn; pa.x = xs;
   }
-  float *dists = ctx->scratch_t<float>("encode.dists", (size_t)n);
-  if (!dists) return LANCE_HIP_ENOMEM;
-  PairwiseArgs pa;
-  pa.x = xs; pa.n = (int64_t)n; pa.ldx = d;
-  pa.cent = static_cast<const float *>(centroids); pa.k = (int)nlist;
-  pa.ids = part_ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
-  pa.check_finite = true;  // KeepFiniteVectors fused into the assign kernel
   LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
-  const float *enc_in = xs;
-  if (scan_metric == LANCE_HIP_L2) {
-    float *res = ctx->scratch_t<float>("encode.residual", (size_t)n * d);
-    if (!res) return LANCE_HIP_ENOMEM;
-    LH_TRY(launch_residual(ctx, xs, (int64_t)n, (int)d, static_cast<const float *>(centroids), part_ids, res, f16));
-    enc_in = res;
+  if (native) {
+    LH_TRY(launch_encode_fused(ctx, dtype, x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, cbf, (int)m, codes));
+  } else {
+    const float *enc_in = xs;
+    if (scan_metric == LANCE_HIP_L2) {
+      float *res = ctx->scratch_t<float>("encode.residual", (size_t)n * d);
+      if (!res) return LANCE_HIP_ENOMEM;
+      LH_TRY(launch_residual(ctx, xs, (int64_t)n, (int)d, centf, part_ids, res, f16));
+      enc_in = res;
+    }
+    // the quantizer is built with DistanceType::L2 whatever the index metric (lance/src/index/vector/builder.rs:456) and
+    // ProductQuantizer::transform encodes with the quantizer's distance type (pq.rs:143,165): L2-nearest codeword, dot too
+    LH_TRY(pq_encode_launch(ctx, LANCE_HIP_L2, enc_in, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits));
   }
-  // the quantizer is built with DistanceType::L2 whatever the index metric (lance/src/index/vector/builder.rs:456) and
-  // ProductQuantizer::transform encodes with the quantizer's distance type (pq.rs:143,165): L2-nearest codeword, dot too
-  LH_TRY(pq_encode_launch(ctx, LANCE_HIP_L2, enc_in, (int64_t)n, (int)d, static_cast<const float *>(codebook), (int)m, codes, (int)nbits));
   LH_CHECK_HIP(hipGetLastError());
   if (loss_out_host) {
     // sum of the assignment distances (compute_partitions, kmeans.rs:1276-1290): f64, host side

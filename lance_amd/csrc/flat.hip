@@ -395,6 +395,11 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const ui
     uint64_t *oid = ids + (int64_t)qc0 * k;
     float *od = dists + (int64_t)qc0 * k;
     hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(a.nq, 256)), dim3(256), 0, ctx->stream, a, 1);
+    // query batches: after the first epoch (which gives every query a threshold) the epochs run on the matrix cores
+    const bool use_mfma = fixed && flat_mfma_supported(metric, d, a.nq, x, a.q);
+    const uint16_t *qhi = nullptr, *qlo = nullptr;
+    const float *qn2 = nullptr;
+    if (use_mfma) LH_TRY(flat_mfma_prepare(ctx, a.q, a.nq, d, &qhi, &qlo, &qn2));
     int64_t seen = 0;
     if (n == 0) {
       a.r0 = a.r1 = 0;
@@ -407,7 +412,8 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const ui
       if (n - a.r1 < (a.r1 - a.r0) / 4) a.r1 = n;            // do not leave a small tail epoch
       {
         ScopedTimer t(ctx, "flat_scan");
-        filter(a);
+        if (use_mfma && seen > 0 && seen >= k) LH_TRY(launch_flat_filter_mfma(ctx, a, d, metric, qhi, qlo, qn2));
+        else filter(a);
       }
       seen = a.r1;
       hipLaunchKernelGGL(flat_select_kernel, dim3(a.nq), dim3(256), sel_lds, ctx->stream, a, seen == n ? 1 : 0, oid, od);

@@ -1,0 +1,256 @@
+// flat_mfma.hip -- batched flat scan on the matrix cores: bf16x3 MFMA surrogate distances filter the (query, row) pairs,
+// the few that can beat a query's current threshold are recomputed exactly (reference order) before they enter its pool.
+//
+//   FlatDistanceCal::distance_all / compute_distance     flat/storage.rs:345-402, flat.rs:95-148   (the exact arithmetic kept)
+//   final SortExec / pool selection                        scanner.rs:3386-3411                     (flat.hip: select kernel)
+//
+// flat.hip's v2 scan visits the rows in epochs; after each one a select kernel gives every query a threshold pair
+// T = (key, rowid) of its k-th best so far, and a row only matters if (dist, rowid) <= T.  For a batch of queries the work
+// is a rows x queries x d contraction: here v_mfma_f32_32x32x16_bf16 computes x.q on the two-term bf16 split of both
+// operands (|error| < 2^-14 |x||q|), the surrogate |q|^2 + |x|^2 - 2 x.q (dot: 1 - x.q) is compared with T + E,
+// E = 2^-12 (|x|^2 + |q|^2), and only the pairs that pass (a fraction ~ k / rows seen) are recomputed with dist_exact_rt
+// and appended under the exact (key, rowid) test -- so the pools, and the answers, are the exact kernel's.
+// Operand roles as in mfma_assign.hip: B = 32 data rows per wave in registers for the whole query sweep, A = query tiles.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "exact.cuh"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+typedef short fm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float fm_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FM_ROWS = 128;
+constexpr int FM_QT = 64;
+
+__device__ __forceinline__ uint32_t fm_bf16_rne(float x) {
+  const uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float fm_bf16_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+__global__ __launch_bounds__(64) void fm_query_prep_kernel(const float *__restrict__ q, int nq, int d, uint16_t *__restrict__ qhi,
+                                                           uint16_t *__restrict__ qlo, float *__restrict__ qn) {
+  const int i = blockIdx.x;
+  float s = 0.0f;
+  for (int e = threadIdx.x; e < d; e += 64) {
+    const float v = q[(int64_t)i * d + e];
+    const uint32_t hb = fm_bf16_rne(v);
+    qhi[(int64_t)i * d + e] = (uint16_t)hb;
+    qlo[(int64_t)i * d + e] = (uint16_t)fm_bf16_rne(v - fm_bf16_f32(hb));
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) qn[i] = s;
+}
+
+struct FmArgs {
+  FlatPool p;
+  const uint16_t *qhi, *qlo;   // [nq][d] bf16 planes of this query chunk
+  const float *qn;             // [nq] |q|^2
+};
+
+template <int KS, int METRIC>
+__global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FlatPool &p = a.p;
+  constexpr int D = KS * 16;
+  constexpr int XS = D + 4, CS = D + 8;
+  float *xs = reinterpret_cast<float *>(smem);                       // [FM_ROWS][XS]  (phase 1)
+  uint16_t *qbuf = reinterpret_cast<uint16_t *>(smem);               // [2][2][FM_QT][CS] bf16 (phase 2)
+  float *tqs = reinterpret_cast<float *>(smem + (size_t)2 * 2 * FM_QT * CS * 2);   // [2][FM_QT] threshold + query part of E
+  float *qns = tqs + 2 * FM_QT;                                                     // [2][FM_QT] |q|^2 (dot: unused)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = p.r0 + (int64_t)blockIdx.x * FM_ROWS;
+  for (int idx = threadIdx.x; idx < FM_ROWS * (D / 4); idx += 256) {
+    const int r = idx / (D / 4), c4 = idx - r * (D / 4);
+    f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (row0 + r < p.r1) v = *reinterpret_cast<const f4 *>(p.x + (row0 + r) * D + 4 * c4);
+    *reinterpret_cast<f4 *>(&xs[r * XS + 4 * c4]) = v;
+  }
+  __syncthreads();
+  fm_bf16x8 xh[KS], xl[KS];
+  float xn2 = 0.0f;
+  {
+    const float *xr = xs + (wave * 32 + j) * XS + g * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f4 u0 = *reinterpret_cast<const f4 *>(xr + s * 16), u1 = *reinterpret_cast<const f4 *>(xr + s * 16 + 4);
+      const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t hb = fm_bf16_rne(v[e]);
+        xh[s][e] = (short)hb; xl[s][e] = (short)fm_bf16_rne(v[e] - fm_bf16_f32(hb));
+        xn2 += v[e] * v[e];
+      }
+    }
+  }
+  xn2 += __shfl_xor(xn2, 32, 64);
+  __syncthreads();
+  const int64_t row = row0 + wave * 32 + j;
+  const bool rvalid = row < p.r1;
+  const uint64_t rid = rvalid ? (p.row_ids ? p.row_ids[row] : (uint64_t)row) : ~0ull;
+  // per-lane constant of the test  s - E <= T  <=>  (|q|^2 (1 - 2^-12) + T)'s partner: xk = |x|^2 (1 - 2^-12)
+  const float xk = METRIC == METRIC_DOT ? -0.000244140625f * xn2 : xn2 - 0.000244140625f * xn2;
+
+  const int ntiles = (p.nq + FM_QT - 1) / FM_QT;
+  constexpr int NCH = FM_QT * D / 8;
+  constexpr int CH = (NCH + 255) / 256;
+  uint4 ph[CH], pl[CH];
+  float ptq = 0.0f, pqn = 0.0f;
+  auto fetch = [&](int t) {
+    const int q0 = t * FM_QT;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int ch = threadIdx.x + 256 * u;
+      const int cr = ch / (D / 8), cc = ch - cr * (D / 8);
+      ph[u] = make_uint4(0, 0, 0, 0); pl[u] = make_uint4(0, 0, 0, 0);
+      if (ch < NCH && q0 + cr < p.nq) {
+        ph[u] = *reinterpret_cast<const uint4 *>(a.qhi + (int64_t)(q0 + cr) * D + cc * 8);
+        pl[u] = *reinterpret_cast<const uint4 *>(a.qlo + (int64_t)(q0 + cr) * D + cc * 8);
+      }
+    }
+    if (threadIdx.x < FM_QT) {
+      const int qi = q0 + threadIdx.x;
+      ptq = -INFINITY; pqn = 0.0f;
+      if (qi < p.nq) {
+        const uint32_t tk = p.tkey[qi];
+        const float qn = a.qn[qi];
+        // no threshold yet, or a NaN threshold: every row is a candidate for the exact test
+        const float T = tk >= 0xFF800000u ? INFINITY : key_to_float(tk);
+        pqn = qn;
+        ptq = METRIC == METRIC_DOT ? T + 0.000244140625f * qn : T - (qn - 0.000244140625f * qn);   // s' <= ptq  with  s' = xk - 2 x.q  (dot: xk + 1 - x.q)
+      }
+    }
+  };
+  auto store = [&](int buf) {
+    uint16_t *hi = qbuf + (size_t)(buf * 2 + 0) * FM_QT * CS, *lo = qbuf + (size_t)(buf * 2 + 1) * FM_QT * CS;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int ch = threadIdx.x + 256 * u;
+      const int cr = ch / (D / 8), cc = ch - cr * (D / 8);
+      if (ch < NCH) {
+        *reinterpret_cast<uint4 *>(hi + cr * CS + cc * 8) = ph[u];
+        *reinterpret_cast<uint4 *>(lo + cr * CS + cc * 8) = pl[u];
+      }
+    }
+    if (threadIdx.x < FM_QT) { tqs[buf * FM_QT + threadIdx.x] = ptq; qns[buf * FM_QT + threadIdx.x] = pqn; }
+  };
+  const int t0 = blockIdx.z;
+  if (t0 >= ntiles) return;
+  fetch(t0);
+  store(0);
+  __syncthreads();
+  int it = 0;
+  for (int t = t0; t < ntiles; t += gridDim.z, ++it) {
+    const int buf = it & 1;
+    const int tn = t + gridDim.z;
+    if (tn < ntiles) fetch(tn);
+    const uint16_t *hi = qbuf + (size_t)(buf * 2 + 0) * FM_QT * CS, *lo = qbuf + (size_t)(buf * 2 + 1) * FM_QT * CS;
+    fm_f32x16 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { acc0[v] = 0.0f; acc1[v] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const fm_bf16x8 ah0 = *reinterpret_cast<const fm_bf16x8 *>(hi + j * CS + s * 16 + g * 8);
+      const fm_bf16x8 al0 = *reinterpret_cast<const fm_bf16x8 *>(lo + j * CS + s * 16 + g * 8);
+      const fm_bf16x8 ah1 = *reinterpret_cast<const fm_bf16x8 *>(hi + (32 + j) * CS + s * 16 + g * 8);
+      const fm_bf16x8 al1 = *reinterpret_cast<const fm_bf16x8 *>(lo + (32 + j) * CS + s * 16 + g * 8);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xh[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xh[s], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xl[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xl[s], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, xh[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, xh[s], acc1, 0, 0, 0);
+    }
+    const int q0 = t * FM_QT;
+    const float *tqb = tqs + buf * FM_QT;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int vq = 0; vq < 4; ++vq) {
+        const int ib = blk * 32 + 8 * vq + 4 * g;
+        const f4 tq4 = *reinterpret_cast<const f4 *>(tqb + ib);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dot = blk ? acc1[vq * 4 + e] : acc0[vq * 4 + e];
+          // L2: |x|^2(1-eps) - 2 x.q <= T - |q|^2(1-eps)      dot: 1 - x.q - eps|x|^2 <= T + eps|q|^2
+          const float sp = METRIC == METRIC_DOT ? (1.0f - dot) + xk : __builtin_fmaf(-2.0f, dot, xk);
+          if (sp <= tq4[e] && rvalid) {
+            const int qi = q0 + ib + e;   // < nq: padded queries carry ptq = -inf
+            const float v = finish_metric<METRIC>(dist_exact_rt<METRIC>(p.x + row * D, p.q + (int64_t)qi * D, D));
+            const uint32_t key = order_key(v);
+            const uint32_t tk = p.tkey[qi];
+            if (key < tk || (key == tk && rid <= p.trid[qi])) {
+              const uint32_t pos = atomicAdd(&p.cnt[qi], 1u);
+              if (pos < (uint32_t)p.cap) {
+                p.pkeys[(int64_t)qi * p.cap + pos] = key;
+                p.prids[(int64_t)qi * p.cap + pos] = rid;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (tn < ntiles) store(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+bool flat_mfma_supported(int metric, int d, int nq, const float *x, const float *q) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr || getenv("LANCE_HIP_NO_MFMA_FLAT") != nullptr;
+  if (off || (metric != LANCE_HIP_L2 && metric != LANCE_HIP_DOT)) return false;
+  if (d % 16 != 0 || d < 16 || d > 128 || nq < 128) return false;
+  return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+}
+
+int flat_mfma_prepare(lance_hip_ctx *ctx, const float *q, int nq, int d, const uint16_t **qhi, const uint16_t **qlo, const float **qn) {
+  uint16_t *hi = ctx->scratch_t<uint16_t>("fm.qhi", (size_t)nq * d), *lo = ctx->scratch_t<uint16_t>("fm.qlo", (size_t)nq * d);
+  float *n2 = ctx->scratch_t<float>("fm.qn", (size_t)nq);
+  if (!hi || !lo || !n2) return LANCE_HIP_ENOMEM;
+  hipLaunchKernelGGL(fm_query_prep_kernel, dim3(nq), dim3(64), 0, ctx->stream, q, nq, d, hi, lo, n2);
+  *qhi = hi; *qlo = lo; *qn = n2;
+  return LANCE_HIP_OK;
+}
+
+template <int KS>
+static void fm_launch_ks(lance_hip_ctx *ctx, const FmArgs &a, int metric, dim3 grid) {
+  constexpr int D = KS * 16;
+  const size_t lds = std::max((size_t)FM_ROWS * (D + 4) * 4, (size_t)2 * 2 * FM_QT * (D + 8) * 2 + (size_t)4 * FM_QT * 4);
+  if (metric == METRIC_DOT) hipLaunchKernelGGL((flat_filter_mfma_kernel<KS, METRIC_DOT>), grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((flat_filter_mfma_kernel<KS, METRIC_L2>), grid, dim3(256), lds, ctx->stream, a);
+}
+
+// one epoch of flat.hip's v2 scan (rows [r0, r1) against the chunk's queries) -- every threshold must already be set
+int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int metric, const uint16_t *qhi, const uint16_t *qlo, const float *qn) {
+  FmArgs a;
+  a.p = e; a.qhi = qhi; a.qlo = qlo; a.qn = qn;
+  const int64_t rows = e.r1 - e.r0;
+  if (rows <= 0) return LANCE_HIP_OK;
+  const unsigned rblocks = (unsigned)cdiv(rows, FM_ROWS);
+  const int qtiles = (e.nq + FM_QT - 1) / FM_QT;
+  int z = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(2ll * ctx->num_cus, rblocks)));
+  const dim3 grid(rblocks, 1, (unsigned)z);
+  switch (d / 16) {
+    case 1: fm_launch_ks<1>(ctx, a, metric, grid); break;
+    case 2: fm_launch_ks<2>(ctx, a, metric, grid); break;
+    case 3: fm_launch_ks<3>(ctx, a, metric, grid); break;
+    case 4: fm_launch_ks<4>(ctx, a, metric, grid); break;
+    case 5: fm_launch_ks<5>(ctx, a, metric, grid); break;
+    case 6: fm_launch_ks<6>(ctx, a, metric, grid); break;
+    case 7: fm_launch_ks<7>(ctx, a, metric, grid); break;
+    default: fm_launch_ks<8>(ctx, a, metric, grid); break;
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh

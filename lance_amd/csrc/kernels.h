@@ -11,6 +11,8 @@ namespace lh {
 // centroid block cent + b*cent_batch_stride -- this is how the M PQ sub-quantisers run
 // in one launch (pq/builder.rs:109-138, pq.rs:146-166).
 struct PairwiseArgs {
+  const void *x_native = nullptr;   // optional: the rows in the column's own element type (x_dtype); kernels that can read it
+  int x_dtype = 0;                  // natively (mfma_assign.hip) then never touch `x` (which may be NULL)
   const float *x = nullptr;
   int64_t n = 0;
   int64_t ldx = 0;
@@ -53,8 +55,17 @@ struct FlatPool {
 };
 
 int launch_wide_filter(lance_hip_ctx *ctx, const FlatPool &fp, int d, int metric);   // wide.hip, any d
+// bf16x3 MFMA surrogate + exact re-check for query batches (flat_mfma.hip)
+bool flat_mfma_supported(int metric, int d, int nq, const float *x, const float *q);
+int flat_mfma_prepare(lance_hip_ctx *ctx, const float *q, int nq, int d, const uint16_t **qhi, const uint16_t **qlo, const float **qn);
+int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int metric, const uint16_t *qhi, const uint16_t *qlo, const float *qn);
 
 int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
+bool assign_reads_native(PairwiseArgs p, int d, int batches);
+// residual + PQ encode in one kernel, rows read in the column's own element type (encode_fused.hip)
+bool encode_fused_supported(int dtype, int d, int m, int nbits, const void *x, const float *cent, const float *codebook);
+int launch_encode_fused(lance_hip_ctx *ctx, int dtype, const void *x, int64_t n, int d, const float *cent, const uint32_t *part_ids,
+                        int residual, const float *codebook, int m, uint8_t *codes);
 // bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);

@@ -784,6 +784,13 @@ __global__ void kmeans_shard_init_kernel(KmShardState *st, float *bias, int k, f
 // the caller stops issuing collectives once shard_end reports inactive; estep on an inactive state leaves the buffers as is.
 __global__ void kmeans_shard_gate_kernel(const KmShardState *st, uint8_t *active_byte) { *active_byte = st->active ? 1 : 0; }
 
+// kmeans_random_init's row choice (kmeans.rs:149-170 shape; the engine's seeded reservoir, rng.h) -- host only
+int lance_hip_kmeans_init_indices(uint64_t n, uint32_t k, uint64_t seed, uint64_t *out_host) {
+  LH_REQUIRE(out_host && n >= k, "kmeans_init_indices: need n >= k and an output array");
+  kmeans_init_indices(n, k, seed, out_host);
+  return LANCE_HIP_OK;
+}
+
 int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_factor_scaled, uint64_t seed, void *state, float *bias) {
   LH_REQUIRE(ctx && state && bias, "kmeans_shard_begin: NULL argument");
   LH_CHECK_HIP(hipSetDevice(ctx->device));

@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 #include "exact.cuh"
 #include "kernels.h"
@@ -38,6 +40,19 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-neare
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+
+// four consecutive elements of a row in the column's own element type, widened exactly (l2.rs:128-159 widens f16 per element,
+// kmeans.rs:1216-1224 / l2.rs:253-260 convert Int8 columns to f32): no f32 copy of the column is ever materialised
+__device__ __forceinline__ f4 load4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ f4 load4(const __half *p) {
+  const uint2 u = *reinterpret_cast<const uint2 *>(p);
+  const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
+  return f4{__low2float(a), __high2float(a), __low2float(b), __high2float(b)};
+}
+__device__ __forceinline__ f4 load4(const int8_t *p) {
+  const uint32_t u = *reinterpret_cast<const uint32_t *>(p);
+  return f4{(float)(int8_t)(u & 255u), (float)(int8_t)((u >> 8) & 255u), (float)(int8_t)((u >> 16) & 255u), (float)(int8_t)(u >> 24)};
+}
 
 // ---- centroid preparation: hi / lo bf16 planes, squared norms, maxima for the error bound ------------------------
 __global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ cent, int k, int d, const float *__restrict__ bias,
@@ -65,7 +80,7 @@ __global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ c
 }
 
 struct MaArgs {
-  const float *x;        // [n][ldx] f32
+  const void *x;         // [n][ldx] elements of the column's type (f32 / f16 / int8)
   int64_t n, ldx;
   int d, k;
   const uint16_t *chi, *clo;   // [k][d] bf16 planes
@@ -105,7 +120,7 @@ __device__ __forceinline__ void top4_insert(Top4 &t, float v, uint32_t i) {
 }
 
 // KS = d / 16 MFMA k-steps (d <= 128).  DOT: surrogate = -x.c + bias.
-template <int KS, int METRIC>
+template <int KS, int METRIC, typename TX>
 __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.active && !p.active[0]) return;
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
   for (int idx = threadIdx.x; idx < MA_ROWS * (D / 4); idx += 256) {
     const int r = idx / (D / 4), c4 = idx - r * (D / 4);
     f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (row0 + r < p.n) v = *reinterpret_cast<const f4 *>(p.x + (row0 + r) * p.ldx + 4 * c4);
+    if (row0 + r < p.n) v = load4(static_cast<const TX *>(p.x) + (row0 + r) * p.ldx + 4 * c4);
     *reinterpret_cast<f4 *>(&xs[r * XS + 4 * c4]) = v;
   }
   __syncthreads();
@@ -263,14 +278,14 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
 }
 
 // ---- exact re-check: lane = row (vector in VGPRs), reference arithmetic --------------------------------------------
-template <int D, int METRIC>
+template <int D, int METRIC, typename TX>
 __global__ __launch_bounds__(256) void ma_finalize_kernel(MaArgs p) {
   if (p.active && !p.active[0]) return;
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = row < p.n;
   RegVec<D> a;
 #pragma unroll
-  for (int i = 0; i < D / 4; ++i) a.q[i] = valid ? *reinterpret_cast<const f4 *>(p.x + row * p.ldx + 4 * i) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = 0; i < D / 4; ++i) a.q[i] = valid ? load4(static_cast<const TX *>(p.x) + row * p.ldx + 4 * i) : f4{0.0f, 0.0f, 0.0f, 0.0f};
   bool finite = true;
   if (p.check_finite) {
 #pragma unroll
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(256) void ma_finalize_kernel(MaArgs p) {
 
 // One wave per undecided row: exact distances to all k centroids (reference order), argmin_value_float semantics --
 // strictly smallest biased value, first index on ties, NaN never selected (kernels.rs:79-111).
-template <int METRIC>
+template <int METRIC, typename TX>
 __global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.active && !p.active[0]) return;
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
     const int64_t row = p.fb_rows[it];
     bool fin = true;
     for (int e = lane; e < p.d; e += 64) {
-      const float v = p.x[row * p.ldx + e];
+      const float v = ld_elem(static_cast<const TX *>(p.x) + row * p.ldx, e);   // 64-bit row offset: rows * d exceeds 2^31 at scale
       wrow[e] = v;
       fin &= isfinite(v);
     }
@@ -348,22 +363,29 @@ __global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
   }
 }
 
-template <int KS>
-static void ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric) {
+template <int KS, int METRIC, typename TX>
+static void ma_launch_one(lance_hip_ctx *ctx, const MaArgs &a) {
   constexpr int D = KS * 16;
   const size_t lds_x = (size_t)MA_ROWS * (D + 4) * 4;
   const size_t lds_c = (size_t)2 * 2 * MA_CT * (D + 8) * 2 + (size_t)2 * 2 * MA_CT * 4;
   const size_t lds = std::max(lds_x, lds_c);
-  const unsigned grid = (unsigned)cdiv(a.n, MA_ROWS);
-  if (metric == METRIC_DOT) {
-    hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_DOT>), dim3(grid), dim3(256), lds, ctx->stream, a);
-    hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC_DOT>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((ma_recompute_kernel<METRIC_DOT>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
+  hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC, TX>), dim3((unsigned)cdiv(a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+  hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC, TX>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
+}
+
+// f32: L2 / dot; f16 columns: L2 (the reference's f16 dot is the 32-lane dot_scalar, not on this path); int8 columns: L2 / dot
+template <int KS>
+static bool ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dtype) {
+  if (dtype == LANCE_HIP_F32) {
+    if (metric == METRIC_DOT) ma_launch_one<KS, METRIC_DOT, float>(ctx, a); else ma_launch_one<KS, METRIC_L2, float>(ctx, a);
+  } else if (dtype == LANCE_HIP_F16) {
+    if (metric == METRIC_DOT) return false;
+    ma_launch_one<KS, METRIC_L2, __half>(ctx, a);
   } else {
-    hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_L2>), dim3(grid), dim3(256), lds, ctx->stream, a);
-    hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC_L2>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((ma_recompute_kernel<METRIC_L2>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
+    if (metric == METRIC_DOT) ma_launch_one<KS, METRIC_DOT, int8_t>(ctx, a); else ma_launch_one<KS, METRIC_L2, int8_t>(ctx, a);
   }
+  return true;
 }
 
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches) {
@@ -371,6 +393,11 @@ bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches) {
   if (off || batches != 1 || p.codes || p.matrix) return false;
   if (d % 16 != 0 || d < 16 || d > 128) return false;
   if (p.k < 32 || p.n < 2048) return false;     // small problems: the exact kernel's fixed cost is lower
+  if (p.x_native) {   // rows in the column's own element type: 4-element loads need 4 * sizeof(element) alignment
+    const size_t es = p.x_dtype == LANCE_HIP_F16 ? 2 : (p.x_dtype == LANCE_HIP_I8 ? 1 : 4);
+    if ((reinterpret_cast<uintptr_t>(p.x_native) % (4 * es)) || (p.ldx % 4)) return false;
+    return p.cent_aligned;
+  }
   if (!p.x_aligned || !p.cent_aligned) return false;
   return true;
 }
@@ -390,21 +417,24 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
   LH_CHECK_HIP(hipMemsetAsync(maxbits, 0, 12, ctx->stream));
   hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, p.bias, chi, clo, cn, maxbits, p.active);
   MaArgs a;
-  a.x = p.x; a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
+  a.x = p.x_native ? p.x_native : static_cast<const void *>(p.x); a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
+  const int dtype = p.x_native ? p.x_dtype : LANCE_HIP_F32;
+  bool ok = true;
   a.chi = chi; a.clo = clo; a.cn = cn; a.bias = p.bias; a.maxbits = maxbits; a.cent = p.cent;
   a.fb_cnt = maxbits + 2; a.fb_rows = fb_rows; a.active = p.active;
   a.id1 = id1; a.id2 = id2; a.id3 = id3; a.cls = cls; a.ids = p.ids; a.dists = p.dists; a.check_finite = p.check_finite ? 1 : 0;
   switch (d / 16) {
-    case 1: ma_launch_ks<1>(ctx, a, metric); break;
-    case 2: ma_launch_ks<2>(ctx, a, metric); break;
-    case 3: ma_launch_ks<3>(ctx, a, metric); break;
-    case 4: ma_launch_ks<4>(ctx, a, metric); break;
-    case 5: ma_launch_ks<5>(ctx, a, metric); break;
-    case 6: ma_launch_ks<6>(ctx, a, metric); break;
-    case 7: ma_launch_ks<7>(ctx, a, metric); break;
-    case 8: ma_launch_ks<8>(ctx, a, metric); break;
+    case 1: ok = ma_launch_ks<1>(ctx, a, metric, dtype); break;
+    case 2: ok = ma_launch_ks<2>(ctx, a, metric, dtype); break;
+    case 3: ok = ma_launch_ks<3>(ctx, a, metric, dtype); break;
+    case 4: ok = ma_launch_ks<4>(ctx, a, metric, dtype); break;
+    case 5: ok = ma_launch_ks<5>(ctx, a, metric, dtype); break;
+    case 6: ok = ma_launch_ks<6>(ctx, a, metric, dtype); break;
+    case 7: ok = ma_launch_ks<7>(ctx, a, metric, dtype); break;
+    case 8: ok = ma_launch_ks<8>(ctx, a, metric, dtype); break;
     default: return LANCE_HIP_EINVAL;
   }
+  LH_REQUIRE(ok, "assign: element type %d with metric %d is not on the MFMA path", dtype, metric);
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

@@ -204,11 +204,13 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
   if (p.n == 0 || batches == 0) return LANCE_HIP_OK;
   LH_REQUIRE(p.k > 0, "pairwise: k must be > 0");
   LH_REQUIRE(metric == METRIC_L2 || metric == METRIC_DOT, "pairwise: metric must be L2 or Dot (cosine = normalise + L2)");
-  p.x_aligned = ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.ldx % 4 == 0) && (p.x_batch_off % 4 == 0);
+  p.x_aligned = p.x != nullptr && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (p.ldx % 4 == 0) && (p.x_batch_off % 4 == 0);
+  if (p.x_native && p.x_dtype == LANCE_HIP_F32 && !p.x) p.x = static_cast<const float *>(p.x_native);
   p.cent_aligned = ((reinterpret_cast<uintptr_t>(p.cent) & 15) == 0) && (((int64_t)p.cent_batch_stride) % 4 == 0) && (d % 4 == 0);
   const char *tname = MODE == 0 ? "assign" : "dist_matrix";
   ScopedTimer t(ctx, tname);
   if (MODE == 0 && mfma_assign_supported(p, d, batches)) return launch_assign_mfma(ctx, p, d, metric);
+  LH_REQUIRE(p.x != nullptr, "internal: the exact assign kernels need the f32 view of the rows");
   bool fixed_ok = p.cent_aligned;  // LDS tile float4 reads in dist_exact need 16B-aligned rows
   // distance matrices of query batches (find_partitions): too few rows to fill the chip with one lane per row;
   // the 32 x 64 tiles of wide.hip measured 44 us against 62 us for 10,000 x 256 x 128
@@ -234,6 +236,13 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
 done:
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
+}
+
+// true when launch_assign will read `x_native` directly (the MFMA path): the caller then need not widen the column
+bool assign_reads_native(PairwiseArgs p, int d, int batches) {
+  if (!p.x_native || p.x_dtype == LANCE_HIP_F32) return false;
+  p.cent_aligned = ((reinterpret_cast<uintptr_t>(p.cent) & 15) == 0) && (((int64_t)p.cent_batch_stride) % 4 == 0) && (d % 4 == 0);
+  return mfma_assign_supported(p, d, batches);
 }
 
 int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches) {

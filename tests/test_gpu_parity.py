@@ -1040,3 +1040,29 @@ def test_rowsharded_build_and_list_shards_world1(eng, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("d", [32, 128, 96])
+def test_flat_batch_on_matrix_cores_bit_exact(eng, oracle, d, metric):
+    """Query batches (>= 128 queries, d % 16 == 0) run the flat scan's later epochs through the bf16x3 MFMA surrogate + exact
+    re-check (flat_mfma.hip).  Ids and distances must equal the oracle's flat scan, ties (duplicate rows, integer data)
+    included, and the run with LANCE_HIP_NO_MFMA_FLAT (exact VALU kernel) must agree bit for bit."""
+    rng = np.random.default_rng(d)
+    n, nq = 60000, 300
+    x = sift_like(n, d, 900 + d)
+    x[1000:1040] = x[7]                              # 40 identical rows: ties broken by row id
+    q = sift_like(nq, d, 901 + d)
+    q[:5] = x[7]
+    if metric == "dot":
+        x = x / 64.0; q = q / 64.0
+    for k in (10, 100):
+        gi, gd = eng.flat_topk(x, q, k, metric)
+        oi, od = oracle.flat_knn(x, q, k, metric)
+        assert (_np(gi).view(np.uint64) == oi).all(), (d, metric, k)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    # real-valued data too (no exact ties, near ties everywhere)
+    xr = (rng.standard_normal((n, d)) * 3).astype(f32); qr = (rng.standard_normal((nq, d)) * 3).astype(f32)
+    gi, gd = eng.flat_topk(xr, qr, 10, metric)
+    oi, od = oracle.flat_knn(xr, qr, 10, metric)
+    assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
