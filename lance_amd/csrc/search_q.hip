@@ -36,10 +36,13 @@ namespace lh {
 constexpr int Q_BS = 512;      // lanes per scan workgroup
 constexpr int Q_G = 4;         // queries per work item (4 x u16 = one ds_read_b64)
 #ifndef LH_Q_WAVES
-#define LH_Q_WAVES 6
+#define LH_Q_WAVES 8
 #endif
-constexpr int Q_WAVES = LH_Q_WAVES;   // launch-bounds hint for M = 16, sub-dimension <= 8: waves per SIMD (6 = three 512-lane workgroups per CU, <= 80 VGPRs; 8 spills and measured 25 % slower)
+constexpr int Q_WAVES = LH_Q_WAVES;   // launch-bounds hint for M = 16, sub-dimension <= 8: waves per SIMD (8 = FOUR 512-lane workgroups per CU, <= 64 VGPRs: fits without spills once the table build is not unrolled -- main pass 0.52 -> 0.42 ms; with the build unrolled by 2 it spilled and lost 25 %)
 constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); more -> that partition is rescanned exactly for the query
+#ifndef LH_Q_LUT_UNROLL
+#define LH_Q_LUT_UNROLL 1
+#endif
 #ifndef LH_Q_MPF
 #define LH_Q_MPF 8
 #endif
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
       const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
       constexpr int MH = M / 2;
       const f4 s4 = *reinterpret_cast<const f4 *>(sc);
-#pragma unroll 2
+#pragma unroll LH_Q_LUT_UNROLL
       for (int i = 0; i < MH; ++i) {
         const int mm = half * MH + i;
         const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
 }
 
 // ---- exact re-evaluation + merge --------------------------------------------------------------------------------
-constexpr int QM_G = 8;        // probes whose residuals are staged together
+constexpr int QM_G = 16;       // probes whose residuals are staged together (nprobes <= 16: one staging, no second pass)
 
 struct QmergeArgs {
   const float *q;

@@ -491,7 +491,9 @@ class DeviceIndex:
                                                      codes.ctypes.data_as(C.c_void_p), rid.ctypes.data_as(C.c_void_p)))
         return offs, codes, rid
 
-    def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
+    def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True, engine=None):
+        """engine: another Engine (own stream + scratch arena) on the same GPU to run this batch on -- the index is read-only
+        during searches, so batches enqueued through different engines overlap on the device (sync=False)."""
         d = self.centroids.shape[1]
         t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
         q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
@@ -501,14 +503,15 @@ class DeviceIndex:
             dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         else:
             ids, dists = out
-        fn = self.engine.lib.lance_hip_ivfpq_search if sync else self.engine.lib.lance_hip_ivfpq_search_async
+        eng = engine if engine is not None else self.engine
+        fn = eng.lib.lance_hip_ivfpq_search if sync else eng.lib.lance_hip_ivfpq_search_async
         if sync:
             torch.cuda.synchronize()
-        elif not self.engine.use_torch_stream and (q is not t or out is None):
+        elif not eng.use_torch_stream and (q is not t or out is None):
             # the batch was converted / allocated by torch kernels on torch's stream: they must finish before the engine's own
             # stream reads them (a caller that hands over ready tensors pays nothing)
             torch.cuda.current_stream().synchronize()
-        check(fn(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
+        check(fn(eng.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
         return ids, dists
 
     def search_filtered(self, q, k, nprobes, allow, refine_factor=0):

@@ -249,8 +249,8 @@ class IvfPqIndex:
         sub = DeviceIndex.create(ix.engine, ix.metric, ix.centroids, ix.codebook, masked, codes, rid, raw=ix._raw, dtype=dtype)
         return IvfPqIndex(sub, self.params, self.stats, masked, codes if rid is None else None)
 
-    def search_device(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
-        return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync)
+    def search_device(self, q, k, nprobes, refine_factor=0, out=None, sync=True, engine=None):
+        return self._ix.search(q, k, nprobes, refine_factor, out=out, sync=sync, engine=engine)
 
     def save(self, index_dir):
         """Writes `index.idx` + `auxiliary.idx` under index_dir -- the files IvfIndexBuilder::merge_partitions produces

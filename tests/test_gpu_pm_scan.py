@@ -44,10 +44,10 @@ def clustered(n, d, seed, ncl=48, lo=0.0, hi=128.0, sigma=20.0, integer=True):
 def _models(oracle, x, nlist, m, metric, seed):
     xs = oracle.normalize(x) if metric == "cosine" else x
     km = "l2" if metric == "cosine" else metric
-    cent, _, _, _ = oracle.kmeans_train(xs[: nlist * 48], nlist, max_iters=6, seed=seed, metric=km)
+    cent, _, _, _ = oracle.kmeans_train(xs[: nlist * 40], nlist, max_iters=4, seed=seed, metric=km)
     part, _ = oracle.assign(xs, cent, km)
     res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
-    cb, _ = oracle.pq_train(res[: 256 * 24], m, max_iters=4, seed=seed + 1)
+    cb, _ = oracle.pq_train(res[: 256 * 12], m, max_iters=3, seed=seed + 1)
     return cent, cb
 
 
@@ -88,7 +88,7 @@ PM_SHAPES = [(64, 16), (128, 16), (256, 16), (128, 32), (256, 32), (512, 32)]
 @pytest.mark.parametrize("d,m", PM_SHAPES)
 def test_pm_scan_f32_every_instantiation(eng, oracle, d, m, metric):
     from lance_amd.engine import DeviceIndex
-    n, nlist, nq = 24000, 32, 640
+    n, nlist, nq = 16000, 32, 640
     x = clustered(n, d, 100 + d + m) + (1.0 if metric == "cosine" else 0.0)
     q = clustered(nq, d, 200 + d + m) + (1.0 if metric == "cosine" else 0.0)
     cent, cb = _models(oracle, x, nlist, m, metric, seed=d + m)
@@ -107,14 +107,14 @@ def test_pm_scan_f16_column_c4_shape(eng, oracle, d, m):
     sampled rows, which exercises the same scan), M = 16; the residual query is rounded to f16 (`round_f16`)."""
     from lance_amd.engine import DeviceIndex
     rng = np.random.default_rng(9)
-    n, nlist, nq = 60000, 4096, 512
+    n, nlist, nq = 40000, 4096, 512
     c = rng.standard_normal((64, d)) * 2
     x = (c[rng.integers(0, 64, n)] + rng.standard_normal((n, d)) * 0.7).astype(np.float16)
     q = (c[rng.integers(0, 64, nq)] + rng.standard_normal((nq, d)) * 0.7).astype(np.float16)
     cent = x[rng.choice(n, nlist, replace=False)].copy()
     part, _ = oracle.assign(x, cent)
     res = oracle.residual(x, cent, part)
-    cb, _ = oracle.pq_train(res[:8192], m, max_iters=4, seed=2)
+    cb, _ = oracle.pq_train(res[:4096], m, max_iters=3, seed=2)
     oidx = oracle.build_index(x, cent, cb)
     gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb)
     assert (_np(gpart).view(np.uint32) == oidx.part_ids).all() and (_np(gcodes) == oidx.codes_rowmajor).all()
@@ -129,7 +129,7 @@ def test_pm_scan_int8_column_c5_shape(eng, oracle, metric):
     import torch
     from lance_amd.engine import DeviceIndex
     rng = np.random.default_rng(12)
-    n, d, nlist, m, nq = 40000, 128, 64, 32, 600
+    n, d, nlist, m, nq = 24000, 128, 64, 32, 600
     centers = rng.integers(-90, 90, (80, d))
     x8 = np.clip(centers[rng.integers(0, 80, n)] + rng.normal(0, 14, (n, d)), -128, 127).astype(np.int8)
     q8 = np.clip(centers[rng.integers(0, 80, nq)] + rng.normal(0, 14, (nq, d)), -128, 127).astype(np.int8)
@@ -245,7 +245,7 @@ def test_prefilter_mask_fused_in_every_scan_kernel(eng, oracle, metric, d, m):
     and for permissive filters, with and without refine."""
     from lance_amd.engine import DeviceIndex
     rng = np.random.default_rng(31)
-    n, nlist, nq = 24000, 24, 640
+    n, nlist, nq = 16000, 24, 640
     x = clustered(n, d, 300 + d) + (1.0 if metric == "cosine" else 0.0)
     q = clustered(nq, d, 301 + d) + (1.0 if metric == "cosine" else 0.0)
     cent, cb = _models(oracle, x, nlist, m, metric, seed=9)
