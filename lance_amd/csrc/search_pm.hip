@@ -620,22 +620,28 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   a.prof = nullptr;
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   a.unbounded = 0; a.loop = 0; a.allow = allow;
+  static const bool exact_bound = getenv("LANCE_HIP_EXACT_BOUND") != nullptr;
   {
-    // bound pass: the nq (query, nearest partition) pairs grouped by partition, two queries per item
+    // bound pass: the nq (query, nearest partition) pairs grouped by partition
     ScopedTimer t(ctx, "pm_group");
     LH_TRY(qscan_nearest_keys(ctx, probes, nq, nprobes, keys));
     LH_TRY(stable_group(ctx, keys, (int64_t)nq, (int64_t)nq, nlist, 1, pair_starts0, pair_idx0, (int64_t)nq, nullptr));
-    hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts0, nlist, item_start0);
-    hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items0, 256)), dim3(256), 0, ctx->stream, item_start0, pair_starts0, pair_idx0,
-                       nlist, nlist, 1, max_items0, desc0);
+    if (exact_bound) {
+      hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts0, nlist, item_start0);
+      hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items0, 256)), dim3(256), 0, ctx->stream, item_start0, pair_starts0, pair_idx0,
+                         nlist, nlist, 1, max_items0, desc0);
+    }
   }
-  {
+  if (exact_bound) {   // round-1 bound: exact f32 pair scan of the nearest partition (two queries per item)
     ScopedTimer t(ctx, "ivfpq_scan_c0");
     a.pair_starts = pair_starts0; a.pair_idx = pair_idx0; a.item_start = item_start0; a.desc = desc0;
     a.cls = 0; a.bound_pass = 1;
     const size_t lds = pm_lds_base(d, m) + (size_t)PM_CAP_BOUND * 16;
     const bool ok = launch_pm_sd<METRIC_L2>(ctx, a, sd, (unsigned)(nq / 2 + nlist + 1), lds);
     LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  } else {             // integer histogram bound, four queries per gather (search_q.hip)
+    ScopedTimer t(ctx, "ivfpq_scan_c0");
+    LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));
   }
   {
     // main pass grouping: class A (bounded) pairs by partition for the filter scan, class B for the exact pair kernel

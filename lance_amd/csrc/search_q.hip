@@ -274,6 +274,186 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
   }
 }
 
+// ---- integer bound pass ---------------------------------------------------------------------------------------------------
+// Every query needs an upper bound T of its final k*refine-th distance before the filter scan.  Round 1 got it from an exact
+// f32 scan of the query's nearest partition (0.17 ms per 10,000 queries).  A bound does not need exact distances either:
+// with e[m][c] = min(floor(L * s), CAPE) a row's integer sum S satisfies  dist * s < S + M  as long as no entry saturated
+// (S <= HMAX < CAPE guarantees that), so if at least k*refine rows of the partition have S <= B then the k*refine-th smallest
+// ADC distance is below (B + M + 1) / s -- a valid T from a HISTOGRAM of integer sums, four queries per gather, no f32 scan.
+// The scale s only affects tightness: it is set from the mean table entry (the expected distance of a random code), which puts
+// the nearest 1-3 % of a partition's rows around a quarter of the histogram range (slack ~3 % on T: ~8 % more survivors).
+// A query whose partition has fewer than k*refine countable rows gets no bound (class B: exact pair kernel), as before.
+constexpr int QB_BINS = 512;      // histogram bins per query
+constexpr int QB_SHIFT = 3;       // bin width 8: sums 0 .. 4095
+struct QboundArgs {
+  const float *q;
+  const uint32_t *pair_idx;     // nearest-partition pairs grouped by partition: entries are query indices
+  const uint32_t *item_start;   // [nlist+1], groups of 4
+  const int4 *desc;
+  const float *centroids, *codebook;
+  const uint32_t *part_offsets;
+  const uint8_t *codes;
+  int d, nlist, keff, round_f16;
+  uint32_t *tglobal;            // [nq] bound key (atomicMin)
+  const uint32_t *allow;
+};
+
+template <int SD, int MU>
+__global__ __launch_bounds__(Q_BS, (MU == 1 ? 6 : 4)) void ivfpq_qbound_kernel(QboundArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16;
+  constexpr int QV = SD / 4;
+  constexpr uint32_t CAPE = 65535u / M;
+  constexpr uint32_t SE = CAPE - CAPE / 32;
+  constexpr uint32_t HMAX = (uint32_t)(QB_BINS << QB_SHIFT) - 1u < CAPE - 1u ? (uint32_t)(QB_BINS << QB_SHIFT) - 1u : CAPE - 1u;
+  const int dpad = (p.d + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) uint2 lutq[M * 256];
+  float *rq = reinterpret_cast<float *>(smem);                          // [4][dpad] negated residuals
+  uint32_t *hist = reinterpret_cast<uint32_t *>(rq + (size_t)dpad * 4);   // [4][QB_BINS]
+  float *sums = reinterpret_cast<float *>(hist + 4 * QB_BINS);            // [4] sum of all table entries
+  float *sc = sums + 4;                                                   // [4] scale
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nitems = p.item_start[p.nlist];
+  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int4 dsc = p.desc[item];
+    const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
+    const uint32_t off = p.part_offsets[part];
+    const int np = (int)(p.part_offsets[part + 1] - off);
+    if (np < p.keff) continue;   // uniform: fewer rows than k*refine -> no bound from this partition
+    uint32_t qj[Q_G];
+#pragma unroll
+    for (int j = 0; j < Q_G; ++j) qj[j] = p.pair_idx[i0 + (j < cnt ? j : 0)];
+    if ((int)threadIdx.x < p.d) {
+      const float cen = p.centroids[(int64_t)part * p.d + threadIdx.x];
+#pragma unroll
+      for (int j = 0; j < Q_G; ++j) {
+        float v = p.q[(int64_t)qj[j] * p.d + threadIdx.x] - cen;
+        if (p.round_f16) v = __half2float(__float2half_rn(v));
+        rq[j * dpad + threadIdx.x] = -v;
+      }
+    }
+    for (int i = threadIdx.x; i < 4 * QB_BINS; i += Q_BS) hist[i] = 0u;
+    if (threadIdx.x < 4) sums[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
+    constexpr int MH = M / 2;
+    auto entry = [&](int mm, f4 &L) {   // the 4 queries' table entries (mm, c), FMA-evaluated
+      const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
+      f4 cb[QV];
+#pragma unroll
+      for (int u = 0; u < QV; ++u) cb[u] = src[u];
+#pragma unroll
+      for (int j = 0; j < Q_G; ++j) {
+        f2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < QV; ++u) {
+          const f4 r4 = *reinterpret_cast<const f4 *>(&rq[j * dpad + mm * SD + 4 * u]);
+          const f2 d0 = f2{r4.x, r4.y} + f2{cb[u].x, cb[u].y};
+          const f2 d1 = f2{r4.z, r4.w} + f2{cb[u].z, cb[u].w};
+          acc = __builtin_elementwise_fma(d0, d0, acc);
+          acc = __builtin_elementwise_fma(d1, d1, acc);
+        }
+        L[j] = acc.x + acc.y;
+      }
+    };
+    {
+      f4 tot = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+      for (int i = 0; i < MH; ++i) {
+        f4 L;
+        entry(half * MH + i, L);
+        tot += L;
+      }
+#pragma unroll
+      for (int j = 0; j < Q_G; ++j) {
+        float t = tot[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) atomicAdd(&sums[j], t);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < Q_G) {
+      const float mean = sums[threadIdx.x] * (1.0f / 256.0f);   // sum over m of the mean entry: distance of a random code
+      float s = 1e30f;                                           // absent query / degenerate mean: everything saturates
+      if ((int)threadIdx.x < cnt && mean > 0.0f && mean < INFINITY) s = fminf((float)SE / mean, 1e30f);
+      sc[threadIdx.x] = s;
+    }
+    __syncthreads();
+    {
+      const f4 s4 = *reinterpret_cast<const f4 *>(sc);
+#pragma unroll 1
+      for (int i = 0; i < MH; ++i) {
+        const int mm = half * MH + i;
+        f4 L;
+        entry(mm, L);
+        uint32_t e[Q_G];
+#pragma unroll
+        for (int j = 0; j < Q_G; ++j) e[j] = min((uint32_t)(L[j] * s4[j]), CAPE);
+        lutq[mm * 256 + c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+      }
+    }
+    __syncthreads();
+    {
+      const uint8_t *pcodes = p.codes + (int64_t)off * M;
+      for (int row = threadIdx.x; row < np; row += Q_BS) {
+        uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+        for (int w = 0; w < MU; ++w) {
+          const uint4 cw = *reinterpret_cast<const uint4 *>(pcodes + (int64_t)row * M + w * 16);
+          const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+              const uint2 v = lutq[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
+              a0 += v.x; a1 += v.y;
+            }
+        }
+        const uint32_t sj[4] = {a0 & 0xFFFFu, a0 >> 16, a1 & 0xFFFFu, a1 >> 16};
+        if (row_allowed(p.allow, off + (uint32_t)row)) {
+#pragma unroll
+          for (int j = 0; j < Q_G; ++j)
+            if (sj[j] <= HMAX) atomicAdd(&hist[j * QB_BINS + (sj[j] >> QB_SHIFT)], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    // wave j (< cnt) finds the first bin where the cumulative count reaches keff
+    if (wave < cnt) {
+      const uint32_t *h = hist + wave * QB_BINS;
+      constexpr int PER = QB_BINS / 64;
+      uint32_t loc[PER], tot = 0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) { loc[i] = h[lane * PER + i]; tot += loc[i]; }
+      uint32_t incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      uint32_t run = incl - tot;
+      int found = -1;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        run += loc[i];
+        if (found < 0 && run >= (uint32_t)p.keff) found = lane * PER + i;
+      }
+      const uint64_t mask = __ballot(found >= 0);
+      if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        const int bin = __shfl(found, leader, 64);
+        if (lane == 0) {
+          const float B = (float)(((uint32_t)bin + 1u) << QB_SHIFT);     // every counted row has S <= B - 1
+          const float T = (B + (float)M) / sc[wave] * 1.000001f;          // dist * s < S + M; margin for the f32 / FMA rounding terms
+          if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[qj[wave]], order_key(T));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- exact re-evaluation + merge --------------------------------------------------------------------------------
 constexpr int QM_G = 16;       // probes whose residuals are staged together (nprobes <= 16: one staging, no second pass)
 
@@ -569,6 +749,36 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
   else if (sd == 16) ok = launch_qscan_sd<16>(ctx, a, m, grid, lds);
   LH_REQUIRE(ok, "quantised scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  return LANCE_HIP_OK;
+}
+
+template <int SD>
+static bool launch_qbound_sd(lance_hip_ctx *ctx, const QboundArgs &a, int m, unsigned grid, size_t lds) {
+  if (m == 16) { hipLaunchKernelGGL((ivfpq_qbound_kernel<SD, 1>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
+  if (m == 32) { hipLaunchKernelGGL((ivfpq_qbound_kernel<SD, 2>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
+  return false;
+}
+
+// bound pass on the integer table: pair_starts0 / pair_idx0 = the nq (query, nearest partition) pairs grouped by partition
+int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
+                  const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow) {
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
+  hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts0, nlist, Q_G, item_start);
+  hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts0, nlist, Q_G,
+                     max_items, desc);
+  QboundArgs a;
+  a.q = qs; a.pair_idx = pair_idx0; a.item_start = item_start; a.desc = desc;
+  a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
+  a.d = d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+  a.tglobal = tglobal; a.allow = allow;
+  const int dpad = (d + 3) & ~3;
+  const size_t lds = (size_t)dpad * 16 + (size_t)4 * QB_BINS * 4 + 8 * 4;
+  bool ok = false;
+  if (sd == 4) ok = launch_qbound_sd<4>(ctx, a, m, max_items, lds);
+  else if (sd == 8) ok = launch_qbound_sd<8>(ctx, a, m, max_items, lds);
+  else if (sd == 16) ok = launch_qbound_sd<16>(ctx, a, m, max_items, lds);
+  LH_REQUIRE(ok, "integer bound pass: unsupported shape (m=%d, sd=%d)", m, sd);
+  (void)nq;
   return LANCE_HIP_OK;
 }
 
