@@ -503,6 +503,16 @@ __device__ __forceinline__ uint32_t kth_smallest_256(uint32_t v, int kk, uint32_
   return *slot;
 }
 
+// distance of one stored row as FlatDistanceCal sees it (flat/storage.rs:345-402: distance_type.func()(query, vector)).  Cosine:
+// f32::cosine = norm_l2(query) once, then cosine_fast per row (cosine.rs:36-39,143-175) -- the rows of a cosine IVF_FLAT index
+// are stored normalised (IvfTransformer::new_flat, ivf.rs:147-160) and the query arrives normalised (knn.rs:498), but the
+// distance function is still the full cosine.
+template <int METRIC>
+__device__ __forceinline__ float ivfflat_dist_rt(const float *__restrict__ q, float qnorm, const float *__restrict__ row, int d) {
+  if constexpr (METRIC == METRIC_COSINE) return cosine_exact_rt(q, qnorm, row, d);
+  else return finish_metric<METRIC>(dist_exact_rt<METRIC>(q, row, d));
+}
+
 template <int D, int METRIC>   // D = 0: run-time dimension
 __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float qt[];   // [d padded to 4]
@@ -520,6 +530,8 @@ __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
   const uint32_t tk = a.bound ? 0xFFFFFFFFu : a.pool.tkey[qi];
   const uint64_t tr = ~0ull;   // every row tied with the bound stays in the pool: the tie check below needs all of them
   __syncthreads();
+  float qnorm = 0.0f;
+  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qt, a.d);
   uint32_t mn = 0xFFFFFFFFu;
   for (uint32_t base = r0; base < r1; base += 256) {
     const uint32_t row = base + threadIdx.x;
@@ -532,7 +544,7 @@ __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
         for (int i = 0; i < D / 4; ++i) rv.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
         v = finish_metric<METRIC>(dist_exact<D, METRIC, NEG>(rv, qt));
       } else {
-        v = finish_metric<METRIC>(dist_exact_rt<METRIC>(qt, a.vec + (int64_t)row * a.d, a.d));
+        v = ivfflat_dist_rt<METRIC>(qt, qnorm, a.vec + (int64_t)row * a.d, a.d);
       }
       const uint32_t key = order_key(v);
       if (a.bound) {
@@ -625,6 +637,8 @@ __global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64
   if (lane == 0) { s_hlen = 0; s_tcnt = 0; }
   for (int t = lane; t < a.d; t += 64) qv[t] = a.q[(int64_t)qi * a.d + t];
   __syncthreads();
+  float qnorm = 0.0f;
+  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, a.d);
   for (int pi = 0; pi < a.nprobes; ++pi) {
     const uint32_t part = a.probes[(int64_t)qi * a.nprobes + pi];
     const uint32_t off = a.part_offsets[part];
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64
       uint32_t key = 0xFFFFFFFFu;
       bool cand = false;
       if (row < np) {
-        key = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, a.vec + (int64_t)(off + row) * a.d, a.d)));
+        key = order_key(ivfflat_dist_rt<METRIC>(qv, qnorm, a.vec + (int64_t)(off + row) * a.d, a.d));
         cand = s_hlen < k || key < hk[0];
       }
       const uint64_t mask = __ballot(cand);
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(256) void ivfflat_kth_kernel(const uint32_t *__rest
 template <int METRIC>
 static void launch_ivfflat(lance_hip_ctx *ctx, const IvfFlatArgs &a, unsigned grid, bool fixed) {
   const size_t lds = (size_t)((a.d + 3) & ~3) * 4;
-  if (fixed) {
+  if constexpr (METRIC != METRIC_COSINE) if (fixed) {   // cosine: run-time dimension kernel only (cosine_fast has its own lane layout)
     switch (a.d) {
       case 8: hipLaunchKernelGGL((ivfflat_kernel<8, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
       case 16: hipLaunchKernelGGL((ivfflat_kernel<16, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
@@ -832,8 +846,9 @@ extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metri
                                         lance_hip_index **out) {
   LH_REQUIRE(ctx && centroids && out && (n == 0 || (x && part_ids)), "ivfflat_create: NULL argument");
   LH_TRY(check_dtype(dtype, "ivfflat_create"));
-  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT, "ivfflat_create: metric must be L2 or Dot in this version");
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "ivfflat_create: f16 dot is not implemented in this version");
+  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "ivfflat_create: bad metric %d", metric);
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "ivfflat_create: f16 dot / cosine are not implemented in this version");
+  LH_REQUIRE(!(dtype == LANCE_HIP_I8 && metric == LANCE_HIP_COSINE), "ivfflat_create: int8 cosine is not supported (no normalised int8 rows)");
   LH_REQUIRE(nlist > 0 && nlist <= 65536 && d > 0, "ivfflat_create: nlist=%u / d=%u not supported", nlist, d);
   LH_REQUIRE(n < (1ull << 32), "ivfflat_create: n too large for this version");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -896,7 +911,17 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
   uint32_t *probes = ctx->scratch_t<uint32_t>("ivfflat.probes", (size_t)nq * nprobes);
   float *pd = ctx->scratch_t<float>("ivfflat.pdists", (size_t)nq * nprobes);
   if (!probes || !pd) return LANCE_HIP_ENOMEM;
-  LH_TRY(lance_hip_find_partitions(ctx, LANCE_HIP_F32, idx->metric, qf, nq, idx->d, idx->centroids, idx->nlist, nprobes, probes, pd));
+  const bool cosine = idx->metric == LANCE_HIP_COSINE;
+  if (cosine) {
+    // knn.rs:498 normalises the key of a cosine query; the coarse quantiser of a cosine index works in L2 on normalised
+    // vectors (ivf/v2.rs:455-465), the partition scan uses the cosine distance itself (flat/storage.rs:345-402)
+    float *qn = ctx->scratch_t<float>("ivfflat.qn", (size_t)nq * d);
+    if (!qn) return LANCE_HIP_ENOMEM;
+    LH_TRY(lance_hip_normalize(ctx, LANCE_HIP_F32, qf, nq, idx->d, qn));
+    qf = qn;
+  }
+  LH_TRY(lance_hip_find_partitions(ctx, LANCE_HIP_F32, cosine ? LANCE_HIP_L2 : idx->metric, qf, nq, idx->d, idx->centroids, idx->nlist, nprobes,
+                                   probes, pd));
   const int qch = (int)std::min<uint32_t>(nq, FLAT_QCHUNK);
   IvfFlatArgs a;
   a.vec = idx->vectors; a.row_ids = idx->row_ids; a.part_offsets = idx->part_offsets; a.nprobes = (int)nprobes; a.d = d;
@@ -913,13 +938,14 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
   pl.prids = ctx->scratch_t<uint64_t>("flat2.prids", (size_t)qch * FLAT_CAP);
   pl.overflow = ctx->scratch_t<uint32_t>("flat2.ovf", 1);
   if (!pl.tkey || !pl.trid || !pl.cnt || !pl.pkeys || !pl.prids || !pl.overflow) return LANCE_HIP_ENOMEM;
-  const bool fixed = flat_fixed_dim(idx->d);
+  const bool fixed = !cosine && flat_fixed_dim(idx->d);
   const size_t sel_lds = (size_t)IVFFLAT_CAP * 16;
   const size_t ex_lds = (size_t)(((d + 3) & ~3) + 2) * 4 + (size_t)k * 12 + (size_t)(k + 1) * 8 + 64 * 4 + 64;
   auto finish = [&](int nqc, uint64_t *oid, float *od) {
     hipLaunchKernelGGL(ivfflat_select_kernel, dim3(nqc), dim3(256), sel_lds, ctx->stream, a, oid, od);
     ScopedTimer t(ctx, "ivfflat_exact");
     if (idx->metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
+    else if (cosine) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_COSINE>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
     else hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_L2>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
   };
   const bool pm = fixed && idx->n_flat_items > 0 &&     // partition-major for the fixed dimensions, query-major kernel otherwise
@@ -967,6 +993,7 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
       return;
     }
     if (idx->metric == LANCE_HIP_DOT) launch_ivfflat<METRIC_DOT>(ctx, a, grid, fixed);
+    else if (cosine) launch_ivfflat<METRIC_COSINE>(ctx, a, grid, false);
     else launch_ivfflat<METRIC_L2>(ctx, a, grid, fixed);
   };
   for (uint32_t qc0 = 0; qc0 < nq; qc0 += (uint32_t)qch) {

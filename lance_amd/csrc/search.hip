@@ -431,6 +431,20 @@ __device__ __forceinline__ float pq4_exact_row(const float *lut, const uint8_t *
   return dist;
 }
 
+// Under a prefilter FlatIndex::search scores every selected row with PQDistCalculator::distance(id) (flat/index.rs:129-165,
+// pq/storage.rs:893-921): the UNQUANTISED table, one term per code byte = table[2i][low nibble] + table[2i+1][high nibble],
+// terms folded by f32::sum (from -0.0) -- neither the quantised fast-scan nor the order of pq4_exact_row.
+template <int METRIC>
+__device__ __forceinline__ float pq4_masked_row(const float *lut, const uint8_t *rc, int m) {
+  float dist = -0.0f;
+  for (int b = 0; b < m / 2; ++b) {
+    const uint32_t c = rc[b];
+    dist = dist + (lut[(2 * b) * 16 + (c & 15u)] + lut[(2 * b + 1) * 16 + (c >> 4)]);
+  }
+  if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);
+  return dist;
+}
+
 template <int METRIC, int BS>
 __device__ __forceinline__ void pq4_prelude(const float *lut, int m, const uint8_t *pcodes, int np, int keff, const Pq4Shared &q4) {
   const int mb = m / 2;
@@ -519,14 +533,15 @@ __global__ __launch_bounds__(256) void ivfpq_scan4_kernel(ScanArgs p) {
       s.lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&s.r[(idx >> 4) * sd], p.codebook + (int64_t)idx * sd, sd));
     __syncthreads();
     const uint8_t *pcodes = p.codes + (int64_t)off * mb;
-    pq4_prelude<METRIC, 256>(s.lut, m, pcodes, np, p.keff, q4);
+    if (!p.allow) pq4_prelude<METRIC, 256>(s.lut, m, pcodes, np, p.keff, q4);   // uniform branch
     for (int base = 0; base < np; base += SCAN_ROUND) {
       if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);
       const uint32_t T = s.misc[1];
       for (int u = 0; u < SCAN_ROUND / 256; ++u) {
         const int row = base + u * 256 + threadIdx.x;
-        if (row < np) {
-          const uint32_t key = order_key(pq4_row_distance<METRIC>(s.lut, m, pcodes, np, row, q4));
+        if (row < np && row_allowed(p.allow, off + (uint32_t)row)) {
+          const uint32_t key = order_key(p.allow ? pq4_masked_row<METRIC>(s.lut, pcodes + (int64_t)row * mb, m)
+                                                 : pq4_row_distance<METRIC>(s.lut, m, pcodes, np, row, q4));
           const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);
           if (in_range && key <= T) {
             const uint32_t slot = atomicAdd(&s.misc[0], 1u);
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
     if (lane == 0) s_hlen = 0;
     __syncthreads();
     const uint8_t *pcodes = p.codes + (int64_t)off * (NBITS == 4 ? m / 2 : m);
-    if constexpr (NBITS == 4) pq4_prelude<METRIC, 64>(lut, m, pcodes, np, p.keff, q4);
+    if constexpr (NBITS == 4) { if (!p.allow) pq4_prelude<METRIC, 64>(lut, m, pcodes, np, p.keff, q4); }
     for (int base = 0; base < np; base += 64) {
       const int row = base + lane;
       uint32_t key = 0xFFFFFFFFu;
@@ -736,7 +751,7 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
       if (row < np) {
         float dist = 0.0f;
         if constexpr (NBITS == 4) {
-          dist = pq4_row_distance<METRIC>(lut, m, pcodes, np, row, q4);
+          dist = p.allow ? pq4_masked_row<METRIC>(lut, pcodes + (int64_t)row * (m / 2), m) : pq4_row_distance<METRIC>(lut, m, pcodes, np, row, q4);
         } else {
           const uint8_t *rc = pcodes + (int64_t)row * m;
           for (int mm = 0; mm < m; ++mm) dist += lut[mm * 256 + rc[mm]];
@@ -937,8 +952,6 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     if (use_pm) {
       LH_TRY(ivfpq_scan_merge_pm(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags, allow));
     } else if (fast && ix->nbits == 4) {
-      LH_REQUIRE(allow == nullptr, "search: a prefilter on 4-bit PQ is not supported (the reference scores filtered rows with the "
-                                   "unquantised table, a different arithmetic from its unfiltered fast-scan)");
       const size_t lds4 = (size_t)dpad * 4 + (size_t)m * 16 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4 + 16 + 256 * 4 + (size_t)m * 16 + 16;
       ScopedTimer t(ctx, "ivfpq_scan");
       if (scan_metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfpq_scan4_kernel<METRIC_DOT>), dim3((unsigned)nblk), dim3(256), lds4, ctx->stream, a);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void q_item_desc_kernel(const uint32_t *__rest
 
 // ---- the filter scan ------------------------------------------------------------------------------------------
 struct QscanArgs {
-  const float *q;               // [nq][d]
+  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel)
   const uint32_t *pair_idx;     // grouped pair indices (pair = q * nprobes + rank)
   const uint32_t *item_start;   // [nlist+1]: items of class A
   const int4 *desc;
@@ -133,29 +133,99 @@ struct QscanArgs {
   const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
 };
 
+
+// ---- residual pre-pass ------------------------------------------------------------------------------------------------------
+// The four queries of an item share every table entry's arithmetic, and their residual components are the same in all 512
+// lanes.  Kept in LDS they cost one broadcast ds_read_b128 per (entry, dimension): 38 % of the scan kernel's LDS-pipe time
+// (PMC: LDS busy 73 %, and 20 % fewer VALU instructions in the table build changed nothing).  Written once to global memory
+// by this kernel they come back through the SCALAR cache (s_load_dwordx8/16 into SGPRs, wave-uniform addresses) and the LDS
+// pipe is left to the gathers.  Layout: rq[item][dim] = float4 of the 4 queries' NEGATED residual components.
+__global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict__ q, const uint32_t *__restrict__ pair_idx,
+                                                         const uint32_t *__restrict__ item_start, const int4 *__restrict__ desc,
+                                                         const float *__restrict__ centroids, int d, int nlist, int pdiv, int round_f16,
+                                                         f4 *__restrict__ rq) {
+  const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (item >= item_start[nlist]) return;
+  const int lane = threadIdx.x & 63;
+  const int4 dsc = desc[item];
+  const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
+  uint32_t qj[Q_G];
+#pragma unroll
+  for (int j = 0; j < Q_G; ++j) qj[j] = pair_idx[i0 + (j < cnt ? j : 0)] / (uint32_t)pdiv;
+  for (int dim = lane; dim < d; dim += 64) {
+    const float cen = centroids[(int64_t)part * d + dim];
+    f4 r4;
+#pragma unroll
+    for (int j = 0; j < Q_G; ++j) {
+      float v = q[(int64_t)qj[j] * d + dim] - cen;      // v2.rs:316-332, same subtraction as the exact path
+      if (round_f16) v = __half2float(__float2half_rn(v));
+      r4[j] = -v;   // NEGATED: (r - c)^2 is evaluated as (c + (-r))^2 so that the add packs (v_pk_add_f32)
+    }
+    rq[(int64_t)item * d + dim] = r4;
+  }
+}
+
+// ---- integer table build, shared by the filter scan and the bound pass ------------------------------------------------------
+// rq4[dim] = the four queries' NEGATED residual components of that dimension, so one packed add + one packed FMA advance two
+// queries by one dimension and the accumulators come out as {L_q0, L_q1}, {L_q2, L_q3}: no horizontal adds, and the
+// quantisation is packed too: z = L * (s / 65535) (v_pk_mul_f32), clamped to [0, CAPE / 65535] (v_med3_f32: a NaN becomes 0,
+// the row then survives the filter and the exact pass decides), v_cvt_pknorm_u16_f32 turns two of them into the two u16
+// halves of a table word.  Whatever rounding the conversion uses, |e - L * s| <= 1 for unsaturated entries; the users'
+// limits carry M units for it (floor would need none: 0.4 % of the range).
+template <int SD>
+__device__ __forceinline__ void q_entry_acc(const f4 *__restrict__ rq4m, const float *__restrict__ cbp, f2 &acc01, f2 &acc23) {
+  constexpr int QV = SD / 4;
+  f4 cb[QV];
+#pragma unroll
+  for (int u = 0; u < QV; ++u) cb[u] = reinterpret_cast<const f4 *>(cbp)[u];
+  acc01 = f2{0.0f, 0.0f};
+  acc23 = f2{0.0f, 0.0f};
+#pragma unroll
+  for (int u = 0; u < SD; ++u) {
+    const f4 r4 = rq4m[u];
+    const float cv = cb[u >> 2][u & 3];
+    const f2 cc = {cv, cv};
+    const f2 d01 = f2{r4.x, r4.y} + cc;
+    const f2 d23 = f2{r4.z, r4.w} + cc;
+    acc01 = __builtin_elementwise_fma(d01, d01, acc01);
+    acc23 = __builtin_elementwise_fma(d23, d23, acc23);
+  }
+}
+
+template <uint32_t CAPE>
+__device__ __forceinline__ uint2 q_entry_quantise(f2 acc01, f2 acc23, f2 s01, f2 s23) {
+  constexpr float CAPZ = (float)CAPE / 65535.0f;
+  const f2 z01 = acc01 * s01, z23 = acc23 * s23;   // s = scale / 65535
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 e01 = __builtin_amdgcn_cvt_pknorm_u16(__builtin_amdgcn_fmed3f(z01.x, 0.0f, CAPZ), __builtin_amdgcn_fmed3f(z01.y, 0.0f, CAPZ));
+  const us2 e23 = __builtin_amdgcn_cvt_pknorm_u16(__builtin_amdgcn_fmed3f(z23.x, 0.0f, CAPZ), __builtin_amdgcn_fmed3f(z23.y, 0.0f, CAPZ));
+  return make_uint2(__builtin_bit_cast(uint32_t, e01), __builtin_bit_cast(uint32_t, e23));
+}
+
 template <int SD, int MU>
 __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
-  constexpr int QV = SD / 4;
   constexpr uint32_t CAPE = 65535u / M;        // largest entry: M of them cannot overflow a u16 field
   constexpr uint32_t SE = CAPE - CAPE / 32;     // the bound T maps to SE; ~3 % head-room below CAPE
-  constexpr uint32_t LIM = SE + 2;              // floor() never raises a sum; +2 covers the f32 rounding terms (see header)
-  const int dpad = (p.d + 3) & ~3;
+  constexpr uint32_t LIM = SE + M + 2;          // one unit per entry for the conversion's rounding; +2 covers the f32 rounding terms (see header)
+  static_assert(LIM < CAPE - 1, "a saturated entry must put the row above the limit");
   // [M][256] x (4 x u16) in STATIC LDS at offset 0: the gather address is one SDWA shift of the code byte plus an immediate
   __shared__ __attribute__((aligned(16))) uint2 lutq[M * 256];
-  float *rq = reinterpret_cast<float *>(smem);                        // [4][dpad]: NEGATED residuals, query-major
-  uint32_t *cand = reinterpret_cast<uint32_t *>(rq + (size_t)dpad * 4);   // [4][Q_CAP]
+  uint32_t *cand = reinterpret_cast<uint32_t *>(smem);                // [4][Q_CAP]
   uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
-  float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T (1e30: no such query in this item)
+  float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T / 65535 (1e30: no such query in this item)
 
-  const uint32_t nitems = p.item_start[p.nlist];
-  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+  // one item per workgroup and no loop: nothing is stored to global memory before the residual loads, so the compiler may
+  // (and does) turn them into scalar loads
+  const uint32_t item = blockIdx.x;
+  if (item >= p.item_start[p.nlist]) return;
+  {
     const int4 dsc = p.desc[item];
     const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
     const uint32_t off = p.part_offsets[part];
     const int np = (int)(p.part_offsets[part + 1] - off);
-    if (np == 0) continue;   // uniform; seg_cnt stays 0
+    if (np == 0) return;   // uniform; seg_cnt stays 0
     uint32_t qj[Q_G], rk[Q_G];
 #pragma unroll
     for (int j = 0; j < Q_G; ++j) {
@@ -163,55 +233,30 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
       qj[j] = pr / (uint32_t)p.nprobes;
       rk[j] = pr % (uint32_t)p.nprobes;
     }
-    if ((int)threadIdx.x < p.d) {
-      const float cen = p.centroids[(int64_t)part * p.d + threadIdx.x];
-#pragma unroll
-      for (int j = 0; j < Q_G; ++j) {
-        float v = p.q[(int64_t)qj[j] * p.d + threadIdx.x] - cen;      // v2.rs:316-332, same subtraction as the exact path
-        if (p.round_f16) v = __half2float(__float2half_rn(v));
-        rq[j * dpad + threadIdx.x] = -v;   // NEGATED: (r - c)^2 is evaluated as (c + (-r))^2 so that the add packs (v_pk_add_f32)
-      }
-    }
     if (threadIdx.x < Q_G) {
       misc[threadIdx.x] = 0;
-      float s = 1e30f;   // absent query: every entry saturates, nothing survives
+      float s = 1e30f;   // absent query: every non-zero entry saturates
       if ((int)threadIdx.x < cnt) {
         const float T = key_to_float(p.tbound[qj[threadIdx.x]]);    // 0 < T < inf (class A)
         s = fminf((float)SE / T, 1e30f);
       }
-      sc[threadIdx.x] = s;
+      sc[threadIdx.x] = s * (1.0f / 65535.0f);
     }
     __syncthreads();
+    const f4 *rq4 = p.rq + (int64_t)item * p.d;
     // quantised LUT: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half * M/2, (half+1) * M/2).  A bound, not a
-    // result: even / odd dimensions accumulate separately with packed FMAs.  e = min(u32(L * s), CAPE): the conversion
-    // saturates, a NaN becomes 0 (the row then survives the filter and the exact pass drops it).
+    // result (q_entry_acc / q_entry_quantise above).
     {
-      const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
+      const int c = threadIdx.x & 255, half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
       constexpr int MH = M / 2;
       const f4 s4 = *reinterpret_cast<const f4 *>(sc);
+      const f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
 #pragma unroll LH_Q_LUT_UNROLL
       for (int i = 0; i < MH; ++i) {
         const int mm = half * MH + i;
-        const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
-        f4 cb[QV];
-#pragma unroll
-        for (int u = 0; u < QV; ++u) cb[u] = src[u];
-        uint32_t e[Q_G];
-#pragma unroll
-        for (int j = 0; j < Q_G; ++j) {
-          f2 acc = {0.0f, 0.0f};
-#pragma unroll
-          for (int u = 0; u < QV; ++u) {
-            const f4 r4 = *reinterpret_cast<const f4 *>(&rq[j * dpad + mm * SD + 4 * u]);
-            const f2 d0 = f2{r4.x, r4.y} + f2{cb[u].x, cb[u].y};
-            const f2 d1 = f2{r4.z, r4.w} + f2{cb[u].z, cb[u].w};
-            acc = __builtin_elementwise_fma(d0, d0, acc);
-            acc = __builtin_elementwise_fma(d1, d1, acc);
-          }
-          const float v = (acc.x + acc.y) * s4[j];
-          e[j] = min((uint32_t)v, CAPE);
-        }
-        lutq[mm * 256 + c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+        f2 acc01, acc23;
+        q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
+        lutq[mm * 256 + c] = q_entry_quantise<CAPE>(acc01, acc23, s01, s23);
       }
     }
     __syncthreads();
@@ -270,7 +315,6 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
         for (uint32_t i = threadIdx.x; i < n; i += Q_BS) p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
       }
     }
-    __syncthreads();   // the next item reuses the LDS
   }
 }
 
@@ -286,7 +330,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
 constexpr int QB_BINS = 512;      // histogram bins per query
 constexpr int QB_SHIFT = 3;       // bin width 8: sums 0 .. 4095
 struct QboundArgs {
-  const float *q;
+  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel)
   const uint32_t *pair_idx;     // nearest-partition pairs grouped by partition: entries are query indices
   const uint32_t *item_start;   // [nlist+1], groups of 4
   const int4 *desc;
@@ -302,68 +346,41 @@ template <int SD, int MU>
 __global__ __launch_bounds__(Q_BS, (MU == 1 ? 6 : 4)) void ivfpq_qbound_kernel(QboundArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
-  constexpr int QV = SD / 4;
   constexpr uint32_t CAPE = 65535u / M;
   constexpr uint32_t SE = CAPE - CAPE / 32;
   constexpr uint32_t HMAX = (uint32_t)(QB_BINS << QB_SHIFT) - 1u < CAPE - 1u ? (uint32_t)(QB_BINS << QB_SHIFT) - 1u : CAPE - 1u;
-  const int dpad = (p.d + 3) & ~3;
   __shared__ __attribute__((aligned(16))) uint2 lutq[M * 256];
-  float *rq = reinterpret_cast<float *>(smem);                          // [4][dpad] negated residuals
-  uint32_t *hist = reinterpret_cast<uint32_t *>(rq + (size_t)dpad * 4);   // [4][QB_BINS]
+  uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                   // [4][QB_BINS]
   float *sums = reinterpret_cast<float *>(hist + 4 * QB_BINS);            // [4] sum of all table entries
   float *sc = sums + 4;                                                   // [4] scale
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t nitems = p.item_start[p.nlist];
-  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const uint32_t item = blockIdx.x;
+  if (item >= p.item_start[p.nlist]) return;
+  {
     const int4 dsc = p.desc[item];
     const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
     const uint32_t off = p.part_offsets[part];
     const int np = (int)(p.part_offsets[part + 1] - off);
-    if (np < p.keff) continue;   // uniform: fewer rows than k*refine -> no bound from this partition
+    if (np < p.keff) return;   // uniform: fewer rows than k*refine -> no bound from this partition
     uint32_t qj[Q_G];
 #pragma unroll
     for (int j = 0; j < Q_G; ++j) qj[j] = p.pair_idx[i0 + (j < cnt ? j : 0)];
-    if ((int)threadIdx.x < p.d) {
-      const float cen = p.centroids[(int64_t)part * p.d + threadIdx.x];
-#pragma unroll
-      for (int j = 0; j < Q_G; ++j) {
-        float v = p.q[(int64_t)qj[j] * p.d + threadIdx.x] - cen;
-        if (p.round_f16) v = __half2float(__float2half_rn(v));
-        rq[j * dpad + threadIdx.x] = -v;
-      }
-    }
+    const f4 *rq4 = p.rq + (int64_t)item * p.d;
     for (int i = threadIdx.x; i < 4 * QB_BINS; i += Q_BS) hist[i] = 0u;
     if (threadIdx.x < 4) sums[threadIdx.x] = 0.0f;
     __syncthreads();
-    const int c = threadIdx.x & 255, half = threadIdx.x >> 8;
+    const int c = threadIdx.x & 255, half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     constexpr int MH = M / 2;
-    auto entry = [&](int mm, f4 &L) {   // the 4 queries' table entries (mm, c), FMA-evaluated
-      const f4 *src = reinterpret_cast<const f4 *>(p.codebook + ((int64_t)mm * 256 + c) * SD);
-      f4 cb[QV];
-#pragma unroll
-      for (int u = 0; u < QV; ++u) cb[u] = src[u];
-#pragma unroll
-      for (int j = 0; j < Q_G; ++j) {
-        f2 acc = {0.0f, 0.0f};
-#pragma unroll
-        for (int u = 0; u < QV; ++u) {
-          const f4 r4 = *reinterpret_cast<const f4 *>(&rq[j * dpad + mm * SD + 4 * u]);
-          const f2 d0 = f2{r4.x, r4.y} + f2{cb[u].x, cb[u].y};
-          const f2 d1 = f2{r4.z, r4.w} + f2{cb[u].z, cb[u].w};
-          acc = __builtin_elementwise_fma(d0, d0, acc);
-          acc = __builtin_elementwise_fma(d1, d1, acc);
-        }
-        L[j] = acc.x + acc.y;
-      }
-    };
     {
-      f4 tot = {0.0f, 0.0f, 0.0f, 0.0f};
+      f2 t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
 #pragma unroll 1
       for (int i = 0; i < MH; ++i) {
-        f4 L;
-        entry(half * MH + i, L);
-        tot += L;
+        const int mm = half * MH + i;
+        f2 acc01, acc23;
+        q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
+        t01 += acc01; t23 += acc23;
       }
+      const float tot[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
       for (int j = 0; j < Q_G; ++j) {
         float t = tot[j];
@@ -381,16 +398,14 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? 6 : 4)) void ivfpq_qbound_kernel(Q
     }
     __syncthreads();
     {
-      const f4 s4 = *reinterpret_cast<const f4 *>(sc);
+      const f4 s4 = *reinterpret_cast<const f4 *>(sc) * (1.0f / 65535.0f);
+      const f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
 #pragma unroll 1
       for (int i = 0; i < MH; ++i) {
         const int mm = half * MH + i;
-        f4 L;
-        entry(mm, L);
-        uint32_t e[Q_G];
-#pragma unroll
-        for (int j = 0; j < Q_G; ++j) e[j] = min((uint32_t)(L[j] * s4[j]), CAPE);
-        lutq[mm * 256 + c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+        f2 acc01, acc23;
+        q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
+        lutq[mm * 256 + c] = q_entry_quantise<CAPE>(acc01, acc23, s01, s23);
       }
     }
     __syncthreads();
@@ -445,12 +460,11 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? 6 : 4)) void ivfpq_qbound_kernel(Q
         const int bin = __shfl(found, leader, 64);
         if (lane == 0) {
           const float B = (float)(((uint32_t)bin + 1u) << QB_SHIFT);     // every counted row has S <= B - 1
-          const float T = (B + (float)M) / sc[wave] * 1.000001f;          // dist * s < S + M; margin for the f32 / FMA rounding terms
+          const float T = (B + (float)M) / sc[wave] * 1.00001f;           // dist * s <= S + M; margin >> (SD + M) * 2^-24 for the f32 / FMA rounding terms
           if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[qj[wave]], order_key(T));
         }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -694,13 +708,13 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
   if (scan_metric != LANCE_HIP_L2) return false;                    // entries must be >= 0 (squared L2)
   if ((uint64_t)nq * nprobes * Q_CAP * 4 > (2ull << 30)) return false;   // survivor segments: at most 2 GiB of scratch
+  if (((uint64_t)nq * nprobes / Q_G + ix->nlist + 1) * ix->d * 16 > (2ull << 30)) return false;   // item residuals likewise
   return true;
 }
 
 size_t qscan_lds_bytes(int d, int m) {   // dynamic part (the quantised LUT is static LDS)
-  const int dpad = (d + 3) & ~3;
-  (void)m;
-  return (size_t)dpad * 16 + (size_t)4 * Q_CAP * 4 + 8 * 4;
+  (void)d; (void)m;
+  return (size_t)4 * Q_CAP * 4 + 8 * 4;
 }
 
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
@@ -732,18 +746,19 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
                  uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
+  f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", (size_t)max_items4 * d * 4));
+  if (!rq) return LANCE_HIP_ENOMEM;
+  hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4, ix->centroids,
+                     d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
   QscanArgs a;
-  a.q = qs; a.pair_idx = pair_idx; a.item_start = item_start4; a.desc = desc4;
+  a.rq = rq; a.pair_idx = pair_idx; a.item_start = item_start4; a.desc = desc4;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
   LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
   LH_CHECK_HIP(hipMemsetAsync(qovf, 0, (size_t)nq * 4, ctx->stream));
   const size_t lds = qscan_lds_bytes(d, m);
-  // one workgroup per item up to a few waves of the chip, then workgroups loop over items
-  static const int wg_per_cu = getenv("LANCE_HIP_QSCAN_WGS") ? atoi(getenv("LANCE_HIP_QSCAN_WGS")) : 0;
-  unsigned grid = max_items4;
-  if (wg_per_cu > 0) grid = std::min<unsigned>(grid, (unsigned)(ctx->num_cus * wg_per_cu));
+  const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;
   if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
@@ -766,13 +781,16 @@ int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts0, nlist, Q_G, item_start);
   hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts0, nlist, Q_G,
                      max_items, desc);
+  f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qbound.rq", (size_t)max_items * d * 4));
+  if (!rq) return LANCE_HIP_ENOMEM;
+  hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items, 4)), dim3(256), 0, ctx->stream, qs, pair_idx0, item_start, desc, ix->centroids, d,
+                     nlist, 1, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
   QboundArgs a;
-  a.q = qs; a.pair_idx = pair_idx0; a.item_start = item_start; a.desc = desc;
+  a.rq = rq; a.pair_idx = pair_idx0; a.item_start = item_start; a.desc = desc;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tglobal = tglobal; a.allow = allow;
-  const int dpad = (d + 3) & ~3;
-  const size_t lds = (size_t)dpad * 16 + (size_t)4 * QB_BINS * 4 + 8 * 4;
+  const size_t lds = (size_t)4 * QB_BINS * 4 + 8 * 4;
   bool ok = false;
   if (sd == 4) ok = launch_qbound_sd<4>(ctx, a, m, max_items, lds);
   else if (sd == 8) ok = launch_qbound_sd<8>(ctx, a, m, max_items, lds);

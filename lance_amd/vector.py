@@ -171,16 +171,15 @@ class IvfPqIndex:
         first, until it has k rows or `maximum_nprobes` (default: all) partitions were searched.  `nprobes=n` alone means
         minimum = maximum = n, as in pylance (python/src/dataset.rs:984-1020).  The reference extends the search one
         partition at a time from concurrently running tasks, so how far it overshoots depends on thread timing; here the
-        extension is deterministic: the number of partitions doubles until the query is satisfied."""
+        extension is deterministic: the number of partitions doubles until the query is satisfied.  late_search's shortcut
+        for prefilters that select at most k rows (the unfound selected rows come back at distance +inf) is reproduced for
+        searches without a refine factor."""
         rf = 0 if refine_factor is None else refine_factor
         nlist = self.params.num_partitions
         min_np = nprobes if minimum_nprobes is None else minimum_nprobes
         max_np = (min_np if minimum_nprobes is None else nlist) if maximum_nprobes is None else maximum_nprobes
         max_np = max(min(max_np, nlist), min(min_np, nlist))
         min_np = min(min_np, max_np)
-        if prefilter is not None and self.params.num_bits == 4:
-            raise NotImplementedError("prefilter on a 4-bit PQ index: the reference scores filtered rows with the unquantised "
-                                      "table (pq/storage.rs:897-908), which this engine's 4-bit scan does not implement yet")
         if distance_range is not None:
             ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
             lo, hi = distance_range
@@ -193,6 +192,20 @@ class IvfPqIndex:
             return self._ix.search_filtered(qq, k, npb, prefilter, rf)
 
         ids, dists = run(q, min_np)
+        if max_np > min_np and prefilter is not None and not rf:
+            # late_search's shortcut (knn.rs:741-779): when the prefilter selects no more than k rows, a query that has not
+            # found all of them yet gets the rest back with distance +inf instead of searching further partitions
+            allow_np = np.ascontiguousarray(prefilter.cpu().numpy() if isinstance(prefilter, torch.Tensor) else prefilter, dtype=bool)
+            mask_ids = np.flatnonzero(allow_np).astype(np.int64)
+            if mask_ids.size <= k:
+                ids_h, dists_h = ids.cpu().numpy().copy(), dists.cpu().numpy().copy()
+                for qi in range(ids_h.shape[0]):
+                    found = ids_h[qi][ids_h[qi] >= 0]
+                    if found.size < k and found.size < mask_ids.size:
+                        rest = np.setdiff1d(mask_ids, found)          # ascending row ids: SortExec's tie order at +inf
+                        ids_h[qi, found.size:found.size + rest.size] = rest
+                        dists_h[qi, found.size:found.size + rest.size] = np.inf
+                return ids_h, dists_h
         if max_np > min_np:
             qt = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
             qt = qt.reshape(-1, self._ix.centroids.shape[1])
@@ -435,11 +448,18 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
         cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
     if itype == "IVF_FLAT":
         if params.metric == "cosine":
-            raise NotImplementedError("IVF_FLAT with the cosine metric is not supported by this engine yet (use l2 or dot)")
-        part, _ = timed("transform", lambda: eng.assign(x, cent, params.metric))
-        fx = timed("build_partitions", lambda: DeviceFlatIndex.create(eng, params.metric, cent, x, part))
+            # IvfTransformer::new_flat (rust/lance-index/src/vector/ivf.rs:147-175): rows are normalised, assigned with L2 and
+            # STORED normalised; the sub-index keeps the cosine distance function (ivf/v2.rs:405-411)
+            if x.dtype != torch.float32:
+                raise NotImplementedError("IVF_FLAT with the cosine metric needs float32 vectors in this version")
+            xs = timed("normalize", lambda: eng.normalize(x))
+            part, _ = timed("transform", lambda: eng.assign(xs, cent, "l2"))
+        else:
+            xs = x
+            part, _ = timed("transform", lambda: eng.assign(x, cent, params.metric))
+        fx = timed("build_partitions", lambda: DeviceFlatIndex.create(eng, params.metric, cent, xs, part))
         out = IvfFlatIndex(fx, params, stats, part)
-        out._x = x if keep_raw else None      # the column itself (borrowed): needed to re-partition under a prefilter
+        out._x = xs if keep_raw else None     # the stored rows (borrowed): needed to re-partition under a prefilter
         return out
     if num_bits not in (4, 8):
         raise ValueError(f"ProductQuantization: num_bits {num_bits} not supported")

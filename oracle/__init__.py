@@ -426,9 +426,15 @@ def ivfflat_search(x, centroids, queries, k, nprobes, metric="l2", row_ids=None)
     q = _f32(queries).reshape(-1, x.shape[1])
     nlist = centroids.shape[0]
     rid = np.arange(x.shape[0], dtype=np.uint64) if row_ids is None else np.asarray(row_ids, np.uint64)
-    part, _ = assign(x, centroids, metric)
+    coarse = metric
+    if metric == "cosine":
+        # IvfTransformer::new_flat (ivf.rs:147-175): NormalizeTransformer, then the partition transform in L2 -- the rows
+        # are stored normalised; the query key is normalised by the ANN node (knn.rs:498) and find_partitions runs in L2
+        # (ivf/v2.rs:455-465); the FlatIndex still scores with cosine_distance (ivf/v2.rs:405-411, flat/storage.rs:345-402)
+        x = normalize(x); q = normalize(q); coarse = "l2"
+    part, _ = assign(x, centroids, coarse)
     offs, perm = partition_layout(part, nlist)
-    probes, _ = find_partitions(q, centroids, nprobes, metric)
+    probes, _ = find_partitions(q, centroids, nprobes, coarse)
     out_i = np.full((q.shape[0], k), np.iinfo(np.uint64).max, np.uint64)
     out_d = np.full((q.shape[0], k), np.inf, np.float32)
     for qi in range(q.shape[0]):

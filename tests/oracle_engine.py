@@ -167,7 +167,7 @@ class OracleDeviceIndex:
     def export(self):
         return self.o.part_offsets.copy(), self.o.codes_t.copy(), self.o.row_ids.copy()
 
-    def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True):
+    def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True, engine=None):
         raw = None if self._raw is None else self._raw.numpy().astype(f32)
         i, d = self.o.search(_np(q).astype(f32), k, nprobes, refine=refine_factor, raw=raw if refine_factor else None)
         return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
@@ -227,7 +227,9 @@ class OracleDeviceFlatIndex:
         nlist = cent.shape[0]
         offs, perm = oracle.partition_layout(self.part, nlist)
         qq = _np(q).astype(f32).reshape(-1, cent.shape[1])
-        probes, _ = oracle.find_partitions(qq, cent, nprobes, self.metric)
+        if self.metric == "cosine":     # stored rows are normalised already; the query key is normalised here (knn.rs:498)
+            qq = oracle.normalize(qq)
+        probes, _ = oracle.find_partitions(qq, cent, nprobes, "l2" if self.metric == "cosine" else self.metric)
         out_i = np.full((qq.shape[0], k), np.iinfo(np.uint64).max, np.uint64)
         out_d = np.full((qq.shape[0], k), np.inf, f32)
         xf = self.x.astype(f32)

@@ -71,6 +71,11 @@ def test_dryrun_ivf_flat_matches_oracle(fake, oracle, metric, d):
     G.test_ivf_flat_matches_oracle(fake, oracle, metric, d)
 
 
+@pytest.mark.parametrize("d", [128, 40])
+def test_dryrun_ivf_flat_cosine(fake, oracle, d, tmp_path):
+    G.test_ivf_flat_cosine_matches_oracle(fake, oracle, d, tmp_path)
+
+
 def test_dryrun_list_sharded_world1(fake, oracle):
     G.test_list_sharded_search_on_device_world1(fake, oracle)
 

@@ -398,6 +398,15 @@ def test_4bit_pq_bit_exact(eng, oracle, metric):
         oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x)
         assert (_np(gi).view(np.uint64) == oi).all(), (metric, k, nprobes, rf)
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    # under a prefilter the reference scores the selected rows with distance(id): the unquantised table, byte-wise terms
+    # (pq/storage.rs:893-921) -- a third arithmetic, fused into the 4-bit scan and its exact replay
+    rng = np.random.default_rng(17)
+    for frac, k, nprobes, rf in ((0.5, 10, nlist, 0), (0.05, 10, 4, 0), (0.3, 100, nlist, 0), (0.5, 10, 4, 5), (0.002, 10, nlist, 0)):
+        allow = rng.random(n) < frac
+        gi, gd = gidx.search_filtered(q, k, nprobes, allow, rf)
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, prefilter=allow)
+        assert (_np(gi).view(np.uint64) == oi).all(), (metric, "prefilter", frac, k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
     # single partition entry point, small partition (all rows exact) and a 16-multiple boundary
     for n_p in (150, 1008, 1013):
         ct = oracle.transpose(oracle.pq_encode(res[:n_p], ocb, metric, nbits=4))
@@ -579,6 +588,31 @@ def test_ivf_flat_matches_oracle(eng, oracle, metric, d):
         ix = lance_amd.create_index(x, "IVF_FLAT", metric="l2", num_partitions=nlist, sample_rate=64)
         ids, dd = ix.search_device(q, 10, nlist)
         assert (ids == fi).all()
+
+
+@pytest.mark.parametrize("d", [128, 40])
+def test_ivf_flat_cosine_matches_oracle(eng, oracle, d, tmp_path):
+    """IVF_FLAT with the cosine metric (VERDICT missing #5): rows normalised + L2 coarse quantiser at build
+    (ivf.rs:147-175), normalised query key (knn.rs:498), cosine_distance inside the partitions; save / load round trip."""
+    import lance_amd
+    n, nlist = 12000, 16
+    x = sift_like(n, d, 190 + d)
+    x[50:60] = x[7]                      # duplicates: exact ties
+    x[70] = 3.0 * x[71]                  # same direction, different length: a tie only after normalisation
+    q = sift_like(40, d, 191 + d)
+    cent, _, _, _ = oracle.kmeans_train(oracle.normalize(x[:4096]), nlist, max_iters=6, seed=2)
+    ix = lance_amd.create_index(x, "IVF_FLAT", metric="cosine", num_partitions=nlist, ivf_centroids=cent)
+    for k, nprobes in ((10, 4), (1, 2), (40, nlist)):
+        gi, gd = ix.nearest(q, k=k, nprobes=nprobes)
+        oi, od = oracle.ivfflat_search(x, cent, q, k, nprobes, "cosine")
+        assert (gi.view(np.uint64) == oi).all(), (d, k, nprobes)
+        assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+    ix.save(tmp_path / "ivfflat_cos")
+    iy = lance_amd.load_index(tmp_path / "ivfflat_cos")
+    assert iy.params.metric == "cosine"
+    gi2, gd2 = iy.nearest(q, k=10, nprobes=4)
+    oi, od = oracle.ivfflat_search(x, cent, q, 10, 4, "cosine")
+    assert (gi2.view(np.uint64) == oi).all() and (gd2.view(np.uint32) == od.view(np.uint32)).all()
 
 
 def test_list_sharded_search_on_device_world1(eng, oracle):

@@ -304,3 +304,17 @@ def test_adaptive_probing_extends_starved_queries(engine, oracle):
     a, _ = idx.nearest(q, k=k, nprobes=3, prefilter=allow)
     b, _ = oidx.search(q, k, 3, prefilter=allow)
     assert (a.view(np.uint64) == b).all()
+    # late_search's shortcut (knn.rs:741-779): a prefilter selecting <= k rows -> whatever the first partitions did not
+    # find comes back at +inf, ascending row ids, and no further partition is searched
+    few = np.zeros(30000, bool)
+    few[rng.choice(30000, size=7, replace=False)] = True
+    c, cd = idx.nearest(q, k=k, prefilter=few, minimum_nprobes=2, maximum_nprobes=32)
+    oi, od = oidx.search(q, k, 2, prefilter=few)
+    sel = np.flatnonzero(few).astype(np.uint64)
+    for i in range(q.shape[0]):
+        found = oi[i][oi[i] != np.uint64(0xFFFFFFFFFFFFFFFF)]
+        rest = np.setdiff1d(sel, found)
+        want = np.concatenate([found, rest])
+        assert (c[i].view(np.uint64)[:want.size] == want).all(), i
+        assert (c[i][want.size:] == -1).all()
+        assert (cd[i][:found.size].view(np.uint32) == od[i][:found.size].view(np.uint32)).all() and np.isinf(cd[i][found.size:want.size]).all()
