@@ -212,7 +212,7 @@ def main():
     eng.timing(False)
     exact_replays = eng.search_stats()
     kt = {kname: eng.timing_query(kname) for kname in ("dist_matrix", "select_probes", "pm_group", "ivfpq_scan", "ivfpq_scan_c0",
-                                                       "ivfpq_scan_c1", "ivfpq_merge", "ivfpq_exact", "refine")}
+                                                       "q_residual", "ivfpq_scan_c1", "ivfpq_merge", "ivfpq_exact", "refine")}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

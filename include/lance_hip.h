@@ -259,7 +259,10 @@ int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x
 
 /* ---- N4: IVF_FLAT (FlatIndex sub-index over raw vectors: flat/index.rs:82-177, flat/storage.rs:345-402) ------ */
 /* Builds the per-partition FlatFloatStorage on the device: x[n][d] (dtype elements, widened exactly to f32) is
- * gathered into partition order (stable, rows with part id LANCE_HIP_NONE dropped).  L2 and Dot.
+ * gathered into partition order (stable, rows with part id LANCE_HIP_NONE dropped).  L2, Dot and (f32 only) Cosine.
+ * Cosine (IvfTransformer::new_flat, ivf.rs:147-175): the caller passes the rows ALREADY NORMALISED (lance_hip_normalize) with
+ * part ids assigned in L2 -- the reference stores the normalised rows too; lance_hip_ivfflat_search normalises the query
+ * key (knn.rs:498), finds the partitions in L2 (ivf/v2.rs:455-465) and scores rows with cosine_distance (ivf/v2.rs:405-411).
  * The handle is destroyed with lance_hip_index_destroy.                                               */
 int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids,
                              uint32_t nlist, const void *x, const uint32_t *part_ids, const uint64_t *row_ids,

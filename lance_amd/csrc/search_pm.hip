@@ -651,10 +651,8 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items2, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, pair_idx,
                        2 * nlist, nlist, (int)nprobes, max_items2, desc);
   }
-  {
-    ScopedTimer t(ctx, "ivfpq_scan_c1");
-    LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow));
-  }
+  // timers inside: "q_residual" (memsets + residual pre-pass) and "ivfpq_scan_c1" (the filter scan kernel alone)
+  LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow));
   if (getenv("LANCE_HIP_Q_STATS")) {   // diagnosis: how many rows survive the integer filter
     std::vector<uint32_t> sc(npairs), tb(nq);
     (void)hipMemcpyAsync(sc.data(), seg_cnt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream);

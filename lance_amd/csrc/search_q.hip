@@ -748,15 +748,19 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", (size_t)max_items4 * d * 4));
   if (!rq) return LANCE_HIP_ENOMEM;
-  hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4, ix->centroids,
-                     d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
+  {
+    ScopedTimer t(ctx, "q_residual");
+    hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4,
+                       ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
+    LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
+    LH_CHECK_HIP(hipMemsetAsync(qovf, 0, (size_t)nq * 4, ctx->stream));
+  }
+  ScopedTimer t(ctx, "ivfpq_scan_c1");
   QscanArgs a;
   a.rq = rq; a.pair_idx = pair_idx; a.item_start = item_start4; a.desc = desc4;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
-  LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
-  LH_CHECK_HIP(hipMemsetAsync(qovf, 0, (size_t)nq * 4, ctx->stream));
   const size_t lds = qscan_lds_bytes(d, m);
   const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;

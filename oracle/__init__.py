@@ -28,6 +28,34 @@ def build(force=False):
 _lib = None
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  A container that sees 128+
+    cores behind an 8-core quota would otherwise run every OpenMP loop with 128 threads on 8 cores."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")    # idle OpenMP workers sleep instead of spinning between short calls
+
+
 def use_native_build():
     """bench.py cpu_baseline: rebuild the oracle for the host it is timed on (-march=native) and switch to it.
     Same arithmetic (-ffp-contract=off), only the vector width of the compiler's code changes.  -> True if active."""
@@ -66,6 +94,7 @@ def lib():
         _lib.orc_round_f16.restype = C.c_float
         _lib.orc_round_f16.argtypes = [C.c_float]
         _lib.orc_kmeans_train_hierarchical_f32.restype = C.c_size_t
+        _lib.orc_set_threads(min(int(_lib.orc_num_threads()), usable_cpus()))
     return _lib
 
 

@@ -289,7 +289,7 @@ float orc_cosine_f32(const float *x, float x_norm, const float *y, size_t d) {
 
 /* a4: normalize  kernels.rs:141-146 -- l2_norm = sqrt(sequential sum of x^2 in T) */
 void orc_normalize_f32(const float *x, size_t n, size_t d, float *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n * d >= 65536)
   for (size_t r = 0; r < n; r++) {
     const float *v = x + r * d;
     float acc = 0.0f;
@@ -317,7 +317,9 @@ static inline float orc_dist(int metric, const float *x, const float *y, size_t 
 void orc_distance_batch_f32(int metric, const float *q, const float *x, size_t n, size_t d,
                             float *out) {
   float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q, d) : 0.0f;
-#pragma omp parallel for schedule(static)
+  /* small batches (one partition of an IVF_FLAT test) stay on the calling thread: a fork/join per call costs more than the
+   * loop, and on a CPU-quota'd container with many visible cores it costs milliseconds */
+#pragma omp parallel for schedule(static) if (n * d >= 65536)
   for (size_t r = 0; r < n; r++)
     out[r] = metric == ORC_COSINE ? orc_cosine_f32(q, qn, x + r * d, d) : orc_dist(metric, q, x + r * d, d);
 }

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # before anything loads libgomp: the oracle's workers must not spin
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
