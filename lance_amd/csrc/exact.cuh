@@ -121,6 +121,19 @@ __device__ __forceinline__ float ld_elem(const float *p, int i) { return p[i]; }
 __device__ __forceinline__ float ld_elem(const __half *p, int i) { return __half2float(p[i]); }  // `as_()` widening, exact
 __device__ __forceinline__ float ld_elem(const int8_t *p, int i) { return (float)p[i]; }          // Int8 -> f32 (l2.rs:253-260)
 
+// four consecutive elements of a row in the column's own element type, widened exactly (l2.rs:128-159 widens f16 per element,
+// kmeans.rs:1216-1224 / l2.rs:253-260 convert Int8 columns to f32): no f32 copy of the column is ever materialised
+__device__ __forceinline__ f4 load4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ f4 load4(const __half *p) {
+  const uint2 u = *reinterpret_cast<const uint2 *>(p);
+  const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
+  return f4{__low2float(a), __high2float(a), __low2float(b), __high2float(b)};
+}
+__device__ __forceinline__ f4 load4(const int8_t *p) {
+  const uint32_t u = *reinterpret_cast<const uint32_t *>(p);
+  return f4{(float)(int8_t)(u & 255u), (float)(int8_t)((u >> 8) & 255u), (float)(int8_t)((u >> 16) & 255u), (float)(int8_t)(u >> 24)};
+}
+
 // Runtime-d version (both operands through pointers); same order.  Used by the
 // generic-dimension fallbacks and by small host-order helpers.  TB = float or __half
 // (f16 elements are widened one by one, l2.rs:128-159).

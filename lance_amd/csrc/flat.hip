@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void flat_merge_kernel(const uint32_t *__restr
 // (possible only for adversarial row orders) is detected and repaired by re-running the scan with the
 // tightened T, which strictly decreases each round.
 
-template <int D, int METRIC, int QT, int BS>
+template <int D, int METRIC, int QT, int BS, typename TX>
 __global__ __launch_bounds__(BS) void flat_filter_kernel(FlatPool p) {
   __shared__ __attribute__((aligned(16))) float tile[QT * D];
   __shared__ uint32_t tk[QT];
@@ -199,13 +199,14 @@ __global__ __launch_bounds__(BS) void flat_filter_kernel(FlatPool p) {
   for (int i = 0; i < RegVec<D>::Q; ++i) a.q[i] = f4{0.f, 0.f, 0.f, 0.f};
   uint64_t rid = ~0ull;
   if (valid) {
-    const float *src = p.x + row * D;
+    // the row in the column's own element type, widened per element (l2.rs:128-159 / :253-260): no f32 copy of the column
+    const TX *src = static_cast<const TX *>(p.x_native) + row * D;
     if constexpr (D % 4 == 0) {
 #pragma unroll
-      for (int i = 0; i < D / 4; ++i) a.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
+      for (int i = 0; i < D / 4; ++i) a.q[i] = load4(src + 4 * i);
     } else {
 #pragma unroll
-      for (int i = 0; i < D; ++i) a.q[i >> 2][i & 3] = src[i];
+      for (int i = 0; i < D; ++i) a.q[i >> 2][i & 3] = ld_elem(src, i);
     }
     rid = p.row_ids ? p.row_ids[row] : (uint64_t)row;
   }
@@ -335,10 +336,16 @@ static void launch_flat_filter(lance_hip_ctx *ctx, const FlatPool &a, int metric
   int z = (int)cdiv(4ull * ctx->num_cus, (uint64_t)rblocks);
   z = std::max(1, std::min(z, qtiles));
   const dim3 grid(rblocks, 1, z);
-  if (metric == METRIC_DOT)
-    hipLaunchKernelGGL((flat_filter_kernel<D, METRIC_DOT, QT, BS>), grid, dim3(BS), 0, ctx->stream, a);
-  else
-    hipLaunchKernelGGL((flat_filter_kernel<D, METRIC_L2, QT, BS>), grid, dim3(BS), 0, ctx->stream, a);
+  auto go = [&](auto tag) {
+    using TX = decltype(tag);
+    if (metric == METRIC_DOT)
+      hipLaunchKernelGGL((flat_filter_kernel<D, METRIC_DOT, QT, BS, TX>), grid, dim3(BS), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((flat_filter_kernel<D, METRIC_L2, QT, BS, TX>), grid, dim3(BS), 0, ctx->stream, a);
+  };
+  if (a.x_dtype == LANCE_HIP_F16) go(__half());
+  else if (a.x_dtype == LANCE_HIP_I8) go(int8_t());
+  else go(float());
 }
 
 constexpr int FLAT_CAP = 4096;      // pool entries per query
@@ -352,11 +359,13 @@ static bool flat_v2_supported(int metric, uint32_t d, uint32_t k) {
   return true;
 }
 
-static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const uint64_t *row_ids, int64_t n, int d, const float *q,
-                        int nq, int k, uint64_t *ids, float *dists) {
+// x: the rows as f32, or NULL when flat_reads_native() said the kernels take the column (x_native, x_dtype) as it is
+static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const void *x_native, int x_dtype, const uint64_t *row_ids, int64_t n,
+                        int d, const float *q, int nq, int k, uint64_t *ids, float *dists) {
   const int qch = std::min(nq, FLAT_QCHUNK);
   FlatPool a;
-  a.x = x; a.row_ids = row_ids; a.k = k; a.cap = FLAT_CAP;
+  a.x = x; a.x_native = x ? static_cast<const void *>(x) : x_native; a.x_dtype = x ? LANCE_HIP_F32 : x_dtype;
+  a.row_ids = row_ids; a.k = k; a.cap = FLAT_CAP;
   a.tkey = ctx->scratch_t<uint32_t>("flat2.tkey", qch);
   a.trid = ctx->scratch_t<uint64_t>("flat2.trid", qch);
   a.cnt = ctx->scratch_t<uint32_t>("flat2.cnt", qch);
@@ -366,7 +375,8 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const ui
   if (!a.tkey || !a.trid || !a.cnt || !a.pkeys || !a.prids || !a.overflow) return LANCE_HIP_ENOMEM;
   const int64_t growth = std::max<int64_t>(2, FLAT_CAP / (16 * (int64_t)k));
   const bool fixed = metric != LANCE_HIP_COSINE && flat_fixed_dim((uint32_t)d) &&
-                     (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(q)) & 15) == 0);
+                     (((reinterpret_cast<uintptr_t>(a.x_native) | reinterpret_cast<uintptr_t>(q)) & 15) == 0);
+  LH_REQUIRE(x || fixed, "flat_topk: internal: native rows need the fixed-dimension kernels");
   if (metric == LANCE_HIP_COSINE) {
     float *sy = ctx->scratch_t<float>("flat2.row_sy", (size_t)std::max<int64_t>(n, 1));
     float *qn = ctx->scratch_t<float>("flat2.q_norm", (size_t)nq);
@@ -396,7 +406,7 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const ui
     float *od = dists + (int64_t)qc0 * k;
     hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(a.nq, 256)), dim3(256), 0, ctx->stream, a, 1);
     // query batches: after the first epoch (which gives every query a threshold) the epochs run on the matrix cores
-    const bool use_mfma = fixed && flat_mfma_supported(metric, d, a.nq, x, a.q);
+    const bool use_mfma = fixed && flat_mfma_supported(metric, d, a.nq, a.x_native, a.q);
     const uint16_t *qhi = nullptr, *qlo = nullptr;
     const float *qn2 = nullptr;
     if (use_mfma) LH_TRY(flat_mfma_prepare(ctx, a.q, a.nq, d, &qhi, &qlo, &qn2));
@@ -1035,10 +1045,15 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nq == 0) return LANCE_HIP_OK;
   if (flat_v2_supported(metric, d, k) && !getenv("LANCE_HIP_FLAT_V1")) {
-    const float *xf2, *qf2;
-    LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf2));
+    const float *xf2 = nullptr, *qf2;
     LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf2));
-    return flat_topk_v2(ctx, metric, xf2, row_ids, (int64_t)n, (int)d, qf2, (int)nq, (int)k, ids, dists);
+    // f16 / int8 columns: the fixed-dimension L2 / dot kernels (exact filter and MFMA filter) read the rows as they are;
+    // cosine and the any-dimension kernels still take an f32 copy
+    const size_t esz = dtype == LANCE_HIP_F16 ? 2 : 1;
+    const bool native = dtype != LANCE_HIP_F32 && metric != LANCE_HIP_COSINE && flat_fixed_dim(d) && ((size_t)d * esz) % 16 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(qf2)) & 15) == 0 && !getenv("LANCE_HIP_NO_NATIVE_FLAT");
+    if (!native) LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf2));
+    return flat_topk_v2(ctx, metric, xf2, x, dtype, row_ids, (int64_t)n, (int)d, qf2, (int)nq, (int)k, ids, dists);
   }
   const int qblocks = (int)cdiv(nq, 256);
   int nsplit = (int)cdiv(2ull * ctx->num_cus, qblocks);

@@ -57,7 +57,7 @@ struct FmArgs {
   const float *qn;             // [nq] |q|^2
 };
 
-template <int KS, int METRIC>
+template <int KS, int METRIC, typename TX>
 __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FlatPool &p = a.p;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
   for (int idx = threadIdx.x; idx < FM_ROWS * (D / 4); idx += 256) {
     const int r = idx / (D / 4), c4 = idx - r * (D / 4);
     f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (row0 + r < p.r1) v = *reinterpret_cast<const f4 *>(p.x + (row0 + r) * D + 4 * c4);
+    if (row0 + r < p.r1) v = load4(static_cast<const TX *>(p.x_native) + (row0 + r) * D + 4 * c4);
     *reinterpret_cast<f4 *>(&xs[r * XS + 4 * c4]) = v;
   }
   __syncthreads();
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
           const float sp = METRIC == METRIC_DOT ? (1.0f - dot) + xk : __builtin_fmaf(-2.0f, dot, xk);
           if (sp <= tq4[e] && rvalid) {
             const int qi = q0 + ib + e;   // < nq: padded queries carry ptq = -inf
-            const float v = finish_metric<METRIC>(dist_exact_rt<METRIC>(p.x + row * D, p.q + (int64_t)qi * D, D));
+            // (q - x)^2 == (x - q)^2 and q*x == x*q bit for bit: the query is the f32 operand, the row is widened per element
+            const float v = finish_metric<METRIC>(dist_exact_rt<METRIC, TX>(p.q + (int64_t)qi * D, static_cast<const TX *>(p.x_native) + row * D, D));
             const uint32_t key = order_key(v);
             const uint32_t tk = p.tkey[qi];
             if (key < tk || (key == tk && rid <= p.trid[qi])) {
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
   }
 }
 
-bool flat_mfma_supported(int metric, int d, int nq, const float *x, const float *q) {
+bool flat_mfma_supported(int metric, int d, int nq, const void *x, const float *q) {
   static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr || getenv("LANCE_HIP_NO_MFMA_FLAT") != nullptr;
   if (off || (metric != LANCE_HIP_L2 && metric != LANCE_HIP_DOT)) return false;
   if (d % 16 != 0 || d < 16 || d > 128 || nq < 128) return false;
@@ -225,8 +226,14 @@ template <int KS>
 static void fm_launch_ks(lance_hip_ctx *ctx, const FmArgs &a, int metric, dim3 grid) {
   constexpr int D = KS * 16;
   const size_t lds = std::max((size_t)FM_ROWS * (D + 4) * 4, (size_t)2 * 2 * FM_QT * (D + 8) * 2 + (size_t)4 * FM_QT * 4);
-  if (metric == METRIC_DOT) hipLaunchKernelGGL((flat_filter_mfma_kernel<KS, METRIC_DOT>), grid, dim3(256), lds, ctx->stream, a);
-  else hipLaunchKernelGGL((flat_filter_mfma_kernel<KS, METRIC_L2>), grid, dim3(256), lds, ctx->stream, a);
+  auto go = [&](auto tag) {
+    using TX = decltype(tag);
+    if (metric == METRIC_DOT) hipLaunchKernelGGL((flat_filter_mfma_kernel<KS, METRIC_DOT, TX>), grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((flat_filter_mfma_kernel<KS, METRIC_L2, TX>), grid, dim3(256), lds, ctx->stream, a);
+  };
+  if (a.p.x_dtype == LANCE_HIP_F16) go(__half());
+  else if (a.p.x_dtype == LANCE_HIP_I8) go(int8_t());
+  else go(float());
 }
 
 // one epoch of flat.hip's v2 scan (rows [r0, r1) against the chunk's queries) -- every threshold must already be set

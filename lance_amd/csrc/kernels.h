@@ -39,7 +39,9 @@ struct PairwiseArgs {
 
 // flat scan v2: per-query candidate pools + threshold pairs (flat.hip)
 struct FlatPool {
-  const float *x;
+  const float *x;       // rows as f32 (NULL when the fixed-dimension kernels read the column in its own element type)
+  const void *x_native = nullptr;   // the column itself: f32 / f16 / int8 rows, widened per element in registers
+  int x_dtype = 0;                  // LANCE_HIP_F32 / F16 / I8
   const uint64_t *row_ids;
   int64_t r0, r1;       // rows of this epoch
   const float *q;       // queries of this chunk
@@ -56,7 +58,7 @@ struct FlatPool {
 
 int launch_wide_filter(lance_hip_ctx *ctx, const FlatPool &fp, int d, int metric);   // wide.hip, any d
 // bf16x3 MFMA surrogate + exact re-check for query batches (flat_mfma.hip)
-bool flat_mfma_supported(int metric, int d, int nq, const float *x, const float *q);
+bool flat_mfma_supported(int metric, int d, int nq, const void *x, const float *q);
 int flat_mfma_prepare(lance_hip_ctx *ctx, const float *q, int nq, int d, const uint16_t **qhi, const uint16_t **qlo, const float **qn);
 int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int metric, const uint16_t *qhi, const uint16_t *qlo, const float *qn);
 

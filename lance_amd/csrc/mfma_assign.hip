@@ -41,19 +41,6 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-neare
 }
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
 
-// four consecutive elements of a row in the column's own element type, widened exactly (l2.rs:128-159 widens f16 per element,
-// kmeans.rs:1216-1224 / l2.rs:253-260 convert Int8 columns to f32): no f32 copy of the column is ever materialised
-__device__ __forceinline__ f4 load4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
-__device__ __forceinline__ f4 load4(const __half *p) {
-  const uint2 u = *reinterpret_cast<const uint2 *>(p);
-  const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
-  return f4{__low2float(a), __high2float(a), __low2float(b), __high2float(b)};
-}
-__device__ __forceinline__ f4 load4(const int8_t *p) {
-  const uint32_t u = *reinterpret_cast<const uint32_t *>(p);
-  return f4{(float)(int8_t)(u & 255u), (float)(int8_t)((u >> 8) & 255u), (float)(int8_t)((u >> 16) & 255u), (float)(int8_t)(u >> 24)};
-}
-
 // ---- centroid preparation: hi / lo bf16 planes, squared norms, maxima for the error bound ------------------------
 __global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ cent, int k, int d, const float *__restrict__ bias,
                                                      uint16_t *__restrict__ chi, uint16_t *__restrict__ clo, float *__restrict__ cn,

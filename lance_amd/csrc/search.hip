@@ -655,21 +655,31 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
   const float *qv = q + (int64_t)qi * d;
   float qnorm = 0.0f;
   if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, d);  // cosine_batch: x_norm = norm_l2(x)
-  for (int i = threadIdx.x; i < P; i += 256) {
-    uint32_t kk = 0xFFFFFFFFu;
-    uint64_t r = ~0ull;
-    if (i < c) {
-      r = cand_rid[(int64_t)qi * keff + i];
-      if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);   // stored row id beyond the raw vectors handed to set_raw: reported, not ranked
-      if (r < n_raw) {
-        if constexpr (METRIC == METRIC_COSINE) {
-          kk = order_key(cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
-        } else {
-          kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC, TR>(qv, raw + r * d, d)));
-        }
+  if constexpr (METRIC == METRIC_COSINE) {
+    for (int i = threadIdx.x; i < P; i += 256) {
+      uint32_t kk = 0xFFFFFFFFu;
+      uint64_t r = ~0ull;
+      if (i < c) {
+        r = cand_rid[(int64_t)qi * keff + i];
+        if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);   // stored row id beyond the raw vectors handed to set_raw: reported, not ranked
+        if (r < n_raw) kk = order_key(cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
       }
+      key[i] = kk; rid[i] = r; pos[i] = 0;
     }
-    key[i] = kk; rid[i] = r; pos[i] = 0;
+  } else {
+    // one lane per candidate row.  (Measured alternative: 16 lanes per row = the 16 lane accumulators, coalesced 64-byte
+    // reads, lane-order fold through shuffles: bit-equal but 0.21 ms instead of 0.11 per 10k queries -- the serial fold and the
+    // eight dependent passes cost more than the strided reads.)
+    for (int i = threadIdx.x; i < P; i += 256) {
+      uint32_t kk = 0xFFFFFFFFu;
+      uint64_t r = ~0ull;
+      if (i < c) {
+        r = cand_rid[(int64_t)qi * keff + i];
+        if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);
+        if (r < n_raw) kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC, TR>(qv, raw + r * d, d)));
+      }
+      key[i] = kk; rid[i] = r; pos[i] = 0;
+    }
   }
   __syncthreads();
   bitonic_sort_kr(key, rid, pos, P);

@@ -44,7 +44,7 @@ constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); mor
 #define LH_Q_LUT_UNROLL 1
 #endif
 #ifndef LH_Q_MPF
-#define LH_Q_MPF 8
+#define LH_Q_MPF 4
 #endif
 constexpr int Q_MPF = LH_Q_MPF;        // merge kernel: codebook entries fetched together per candidate row (registers vs round trips)
 
@@ -571,17 +571,28 @@ __global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
 // One workgroup of BS lanes per query.  The kernel is latency-bound (dependent position -> code -> codebook loads, selection
 // rounds), so what counts is the number of queries in flight, not lanes per query: BS = 128 is the smallest group the
 // threshold machinery allows (the k-th smallest of one value per lane needs BS >= k * refine, at most 128 here).
+#ifndef LH_QM_WAVES
+#define LH_QM_WAVES 6
+#endif
+#if LH_QM_WAVES > 0
+#define LH_QM_BOUNDS(BS) __launch_bounds__(BS, (SD <= 8 && MU == 1 ? LH_QM_WAVES : 4))
+#else
+#define LH_QM_BOUNDS(BS) __launch_bounds__(BS)
+#endif
 template <int SD, int MU, int BS>
-__global__ __launch_bounds__(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
+__global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
   constexpr int QV = SD / 4;
   constexpr int CAP = BS == 128 ? 512 : 1024;   // (key, pos) entries under selection
   static_assert(BS >= SCAN_MAX_KEFF, "tighten_bs selects among one value per lane");
   __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
-  __shared__ uint64_t rid[SCAN_LCAP];
-  __shared__ uint32_t skey[SCAN_LCAP], spos[SCAN_LCAP];
-  __shared__ uint32_t s_cnt[QM_G + 1];
+  // the sort buffers of the last phase live in the dynamic region, which holds the staged residuals until then
+  // (qmerge_lds_bytes): less LDS per workgroup = more queries in flight on a CU, which is what this kernel is bound by
+  uint64_t *rid = reinterpret_cast<uint64_t *>(smem);                    // [SCAN_LCAP]
+  uint32_t *skey = reinterpret_cast<uint32_t *>(rid + SCAN_LCAP);        // [SCAN_LCAP]
+  uint32_t *spos = skey + SCAN_LCAP;                                     // [SCAN_LCAP]
+  __shared__ uint32_t s_cnt[QM_G + 1], s_pre[QM_G + 1];
   __shared__ int s_amb;
   const SelectOut &o = a.o;
   const int q = blockIdx.x;
@@ -628,11 +639,14 @@ __global__ __launch_bounds__(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         r[rr * dpad + e] = v;
       }
       __syncthreads();
-      int pre[QM_G + 1];
-      pre[0] = 0;
-#pragma unroll
-      for (int i = 0; i < QM_G; ++i) pre[i + 1] = pre[i] + (i < ng ? (int)s_cnt[i] : 0);
-      const int total = pre[QM_G];
+      // prefix of the segment sizes, kept in LDS (17 registers less per lane: occupancy is what this kernel lives on)
+      if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < QM_G; ++i) { s_pre[i] = run; run += i < ng ? s_cnt[i] : 0u; }
+        s_pre[QM_G] = run;
+      }
+      __syncthreads();
+      const int total = (int)s_pre[QM_G];
       for (int base = 0; base < total; base += BS) {
         if ((int)misc[0] > CAP - BS) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
         const uint32_t T = misc[1];
@@ -640,8 +654,10 @@ __global__ __launch_bounds__(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         if (t < total) {
           int rr = 0, st = 0;
 #pragma unroll
-          for (int i = 1; i < QM_G; ++i)
-            if (t >= pre[i]) { rr = i; st = pre[i]; }   // pre[] is non-decreasing and t < pre[QM_G]: the last hit is the segment
+          for (int i = 1; i < QM_G; ++i) {
+            const int pi = (int)s_pre[i];
+            if (t >= pi) { rr = i; st = pi; }   // s_pre[] is non-decreasing and t < s_pre[QM_G]: the last hit is the segment
+          }
           const uint32_t pos = a.seg_pos[((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st)];
           const uint8_t *rc = a.codes + (int64_t)pos * M;
           const float *rres = r + rr * dpad;
@@ -684,7 +700,7 @@ __global__ __launch_bounds__(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
     __syncthreads();
   }
   for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
-  __syncthreads();
+  __syncthreads();   // also: every lane is done with the staged residuals, the region is reused below
   int c = min((int)misc[0], CAP);
   if (c > SCAN_LCAP || misc[3]) {
     if (threadIdx.x == 0) atomicOr(&o.flags[q], FLAG_OVERFLOW);
@@ -809,7 +825,8 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
   const int dpad = (a.d + 3) & ~3;
   const size_t lds_rescan = (size_t)dpad * 4 + (size_t)MU * 16 * 256 * 4;
   hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU>), dim3(nq), dim3(256), lds_rescan, ctx->stream, a);
-  const size_t lds = (size_t)QM_G * dpad * 4;
+  // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
+  const size_t lds = std::max((size_t)std::min<int>(QM_G, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
   if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
   else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
 }

@@ -1100,3 +1100,29 @@ def test_flat_batch_on_matrix_cores_bit_exact(eng, oracle, d, metric):
     gi, gd = eng.flat_topk(xr, qr, 10, metric)
     oi, od = oracle.flat_knn(xr, qr, 10, metric)
     assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("kind,metric", [("f16", "l2"), ("int8", "l2"), ("int8", "dot")])
+@pytest.mark.parametrize("d", [64, 128])
+def test_flat_scan_reads_f16_int8_rows_natively(eng, oracle, monkeypatch, kind, metric, d):
+    """f16 / int8 columns: the fixed-dimension flat kernels (exact filter for small batches, MFMA filter + exact re-check for
+    batches of >= 128 queries) read the rows in the column's own element type and widen per element in registers
+    (l2.rs:128-159, :253-260) -- no f32 copy of the column.  Same bits as the oracle and as the widened route."""
+    import torch
+    rng = np.random.default_rng(3 * d + len(kind))
+    n = 50000
+    if kind == "f16":
+        xs = (rng.standard_normal((n, d)) * 4).astype(np.float16); qs = (rng.standard_normal((260, d)) * 4).astype(np.float16)
+    else:
+        xs = rng.integers(-100, 100, (n, d)).astype(np.int8); qs = rng.integers(-100, 100, (260, d)).astype(np.int8)
+    xs[2000:2030] = xs[11]                           # ties broken by row id
+    xf, qf = xs.astype(f32), qs.astype(f32)
+    for nq in (7, 260):
+        gi, gd = eng.flat_topk(torch.from_numpy(xs), torch.from_numpy(qs[:nq]), 10, metric)
+        oi, od = oracle.flat_knn(xf, qf[:nq], 10, metric)
+        assert (_np(gi).view(np.uint64) == oi).all(), (kind, metric, d, nq)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+        monkeypatch.setenv("LANCE_HIP_NO_NATIVE_FLAT", "1")
+        wi, wd = eng.flat_topk(torch.from_numpy(xs), torch.from_numpy(qs[:nq]), 10, metric)
+        monkeypatch.delenv("LANCE_HIP_NO_NATIVE_FLAT")
+        assert (gi == wi).all() and (_np(gd).view(np.uint32) == _np(wd).view(np.uint32)).all()
