@@ -246,6 +246,12 @@ int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *i
                                     uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
                                     uint64_t *ids, float *dists);
 
+/* Prefilter and distance range together: FlatIndex::search's RowIdMask branch with lower / upper bounds
+ * (flat/index.rs:131-149: selected rows only, each scored with distance(id), kept when lower <= d < upper). */
+int lance_hip_ivfpq_search_filtered_range(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                          uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
+                                          float lower, float upper, uint64_t *ids, float *dists);
+
 /* Number of queries of the most recent search on this context that had to be replayed by the exact
  * (heap-emulating) kernel -- ties at a partition's k-th distance, or candidate-buffer overflow.      */
 int lance_hip_search_stats(lance_hip_ctx *ctx, uint32_t *n_exact_replays_host);
@@ -272,6 +278,11 @@ int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t
  * BinaryHeap keeps (such queries are replayed through a heap with std's push/pop, as in the IVF_PQ path). */
 int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                              uint32_t nprobes, uint64_t *ids, float *dists);
+/* IVF_FLAT under a row-id prefilter (FlatIndex::search's RowIdMask branch, flat/index.rs:129-165): allow_by_rowid[r] != 0
+ * <=> row id r may be returned.  The mask is tested inside the scan kernels (bound pass, main pass, exact replay) -- the
+ * selected rows are scored by the same distance function, so no filtered copy of the index is needed.      */
+int lance_hip_ivfflat_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                      uint32_t nprobes, const uint8_t *allow_by_rowid, uint64_t n_allow, uint64_t *ids, float *dists);
 
 /* ---- a22 / 8(f) N3: index files (lance/src/index/vector/builder.rs:938-1079 merge_partitions) ---------------------- */
 /* The `index.idx` + `auxiliary.idx` pair of an IVF_PQ / IVF_FLAT index directory, Lance file format 2.0 (the

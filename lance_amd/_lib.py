@@ -29,8 +29,8 @@ SYMBOLS = [
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
     "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
     "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_ivfpq_search_range",
-    "lance_hip_search_stats", "lance_hip_ivfpq_search_filtered",
-    "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search",
+    "lance_hip_search_stats", "lance_hip_ivfpq_search_filtered", "lance_hip_ivfpq_search_filtered_range",
+    "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search", "lance_hip_ivfflat_search_filtered",
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
     "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
     "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench", "lance_hip_merge_topk",
@@ -116,9 +116,11 @@ def load():
         "lance_hip_ivfpq_search_range": (i32, [vp, vp, vp, u32, u32, u32, u32, f32, f32, vp, vp]),
         "lance_hip_search_stats": (i32, [vp, C.POINTER(u32)]),
         "lance_hip_ivfpq_search_filtered": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, u64, vp, vp]),
+        "lance_hip_ivfpq_search_filtered_range": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, u64, f32, f32, vp, vp]),
         "lance_hip_flat_topk": (i32, [vp, i32, i32, vp, vp, u64, u32, vp, u32, u32, vp, vp]),
         "lance_hip_ivfflat_create": (i32, [vp, i32, i32, u32, vp, u32, vp, vp, vp, u64, C.POINTER(vp)]),
         "lance_hip_ivfflat_search": (i32, [vp, vp, vp, u32, u32, u32, vp, vp]),
+        "lance_hip_ivfflat_search_filtered": (i32, [vp, vp, vp, u32, u32, u32, vp, u64, vp, vp]),
         "lance_hip_index_file_open": (i32, [C.c_char_p, C.POINTER(vp)]),
         "lance_hip_index_file_get": (i32, [vp, C.POINTER(IndexFileView)]),
         "lance_hip_index_file_close": (None, [vp]),

@@ -479,6 +479,7 @@ struct IvfFlatArgs {
   int pdiv;                      // nprobes for the main pass, 1 for the bound pass (pairs = queries)
   uint32_t *lanemin;             // bound pass: [nq][256] running minimum key per (query, lane)
   uint32_t *flags;               // [nq] 1 = the survivors of a boundary tie depend on the reference heap: replay
+  const uint32_t *allow = nullptr;   // prefilter: one bit per storage position (flat/index.rs:129-165), NULL = none
   FlatPool pool;
 };
 
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
   uint32_t mn = 0xFFFFFFFFu;
   for (uint32_t base = r0; base < r1; base += 256) {
     const uint32_t row = base + threadIdx.x;
-    if (row < r1) {
+    if (row < r1 && row_allowed(a.allow, row)) {
       float v;
       if constexpr (D != 0) {
         RegVec<D> rv;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64
       const int row = base + lane;
       uint32_t key = 0xFFFFFFFFu;
       bool cand = false;
-      if (row < np) {
+      if (row < np && row_allowed(a.allow, off + (uint32_t)row)) {
         key = order_key(ivfflat_dist_rt<METRIC>(qv, qnorm, a.vec + (int64_t)(off + row) * a.d, a.d));
         cand = s_hlen < k || key < hk[0];
       }
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256) void ivfflat_pm_kernel(IvfFlatArgs a) {
   __shared__ int tq[QT];
   const int part = a.items[blockIdx.x].x;
   const uint32_t row = (uint32_t)a.items[blockIdx.x].y + threadIdx.x;
-  const bool valid = row < a.part_offsets[part + 1];
+  const bool valid = row < a.part_offsets[part + 1] && row_allowed(a.allow, row);
   const uint32_t qs = a.pair_starts[part], qe = a.pair_starts[part + 1];
   if (qs == qe) return;
   RegVec<D> rv;
@@ -906,8 +907,8 @@ extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metri
   return LANCE_HIP_OK;
 }
 
-extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
-                                        uint32_t nprobes, uint64_t *ids, float *dists) {
+static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k, uint32_t nprobes,
+                               const uint32_t *allow, uint64_t *ids, float *dists) {
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "ivfflat_search: NULL argument");
   LH_REQUIRE(idx->m == 0 && idx->vectors, "ivfflat_search: not an IVF_FLAT index");
   LH_REQUIRE(k > 0 && k <= 128, "ivfflat_search: k=%u not supported (1..128)", k);
@@ -935,6 +936,7 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
   const int qch = (int)std::min<uint32_t>(nq, FLAT_QCHUNK);
   IvfFlatArgs a;
   a.vec = idx->vectors; a.row_ids = idx->row_ids; a.part_offsets = idx->part_offsets; a.nprobes = (int)nprobes; a.d = d;
+  a.allow = allow;
   FlatPool &pl = a.pool;
   constexpr int IVFFLAT_CAP = FLAT_CAP / 2;       // 2048 pool entries per query: (key, rowid, partition) sorted in 32 KiB of LDS
   pl.x = nullptr; pl.row_ids = nullptr; pl.r0 = pl.r1 = 0; pl.k = (int)k; pl.cap = IVFFLAT_CAP;
@@ -1032,6 +1034,22 @@ extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_inde
   LH_CHECK_HIP(hipGetLastError());
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
+}
+
+extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                        uint32_t nprobes, uint64_t *ids, float *dists) {
+  return ivfflat_search_impl(ctx, idx, q, nq, k, nprobes, nullptr, ids, dists);
+}
+
+extern "C" int lance_hip_ivfflat_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                                 uint32_t nprobes, const uint8_t *allow_by_rowid, uint64_t n_allow, uint64_t *ids,
+                                                 float *dists) {
+  LH_REQUIRE(ctx && idx && (allow_by_rowid || n_allow == 0), "ivfflat_search_filtered: NULL argument");
+  LH_REQUIRE(idx->m == 0 && idx->vectors, "ivfflat_search_filtered: not an IVF_FLAT index");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  const uint32_t *bits = nullptr;
+  LH_TRY(build_allow_bits(ctx, idx->row_ids, idx->n, allow_by_rowid, n_allow, &bits));
+  return ivfflat_search_impl(ctx, idx, q, nq, k, nprobes, bits, ids, dists);
 }
 
 extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x, const uint64_t *row_ids,

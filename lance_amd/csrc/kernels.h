@@ -57,6 +57,8 @@ struct FlatPool {
 };
 
 int launch_wide_filter(lance_hip_ctx *ctx, const FlatPool &fp, int d, int metric);   // wide.hip, any d
+// search.hip: prefilter by row id -> one bit per storage position (scratch "search.allow_bits")
+int build_allow_bits(lance_hip_ctx *ctx, const uint64_t *row_ids, uint64_t n, const uint8_t *allow_by_rowid, uint64_t n_allow, const uint32_t **bits_out);
 // bf16x3 MFMA surrogate + exact re-check for query batches (flat_mfma.hip)
 bool flat_mfma_supported(int metric, int d, int nq, const void *x, const float *q);
 int flat_mfma_prepare(lance_hip_ctx *ctx, const float *q, int nq, int d, const uint16_t **qhi, const uint16_t **qlo, const float **qn);

@@ -1136,24 +1136,49 @@ __global__ __launch_bounds__(256) void build_allow_bits_kernel(const uint64_t *_
   if (lane == 0 && pos < n + 64) { bits[w0] = (uint32_t)m; bits[w0 + 1] = (uint32_t)(m >> 32); }
 }
 
-int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
-                                    uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
-                                    uint64_t *ids, float *dists) {
+}  // extern "C"
+
+// prefilter by row id -> one bit per storage position, in the context's scratch arena ("search.allow_bits")
+int lh::build_allow_bits(lance_hip_ctx *ctx, const uint64_t *row_ids, uint64_t n, const uint8_t *allow_by_rowid, uint64_t n_allow,
+                     const uint32_t **bits_out) {
+  uint32_t *bits = ctx->scratch_t<uint32_t>("search.allow_bits", (size_t)(n / 32 + 4));
+  if (!bits) return LANCE_HIP_ENOMEM;
+  if (n > 0)
+    hipLaunchKernelGGL(build_allow_bits_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, row_ids, n, allow_by_rowid, n_allow, bits);
+  *bits_out = bits;
+  return LANCE_HIP_OK;
+}
+
+extern "C" {
+
+static int search_filtered_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k, uint32_t nprobes,
+                                uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow, int has_range, float lower, float upper,
+                                uint64_t *ids, float *dists) {
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search_filtered: NULL argument");
   LH_REQUIRE(ctx->device == idx->device, "search_filtered: context and index live on different devices");
   LH_REQUIRE(idx->m != 0, "search_filtered: not an IVF_PQ index");
   LH_REQUIRE(allow_by_rowid || n_allow == 0, "search_filtered: NULL filter");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  const uint64_t n = idx->n;
-  uint32_t *bits = ctx->scratch_t<uint32_t>("search.allow_bits", (size_t)(n / 32 + 4));
-  if (!bits) return LANCE_HIP_ENOMEM;
-  if (n > 0)
-    hipLaunchKernelGGL(build_allow_bits_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, idx->row_ids, n, allow_by_rowid, n_allow, bits);
+  const uint32_t *bits = nullptr;
+  LH_TRY(build_allow_bits(ctx, idx->row_ids, idx->n, allow_by_rowid, n_allow, &bits));
   uint32_t *flags = nullptr;
   const float *qf;
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
-  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags, bits));
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, &flags, bits));
   return check_flags(ctx, flags, nq);
+}
+
+int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                    uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
+                                    uint64_t *ids, float *dists) {
+  return search_filtered_impl(ctx, idx, q, nq, k, nprobes, refine_factor, allow_by_rowid, n_allow, 0, 0.f, 0.f, ids, dists);
+}
+
+int lance_hip_ivfpq_search_filtered_range(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
+                                          uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
+                                          float lower, float upper, uint64_t *ids, float *dists) {
+  LH_REQUIRE(!(lower > upper), "search_filtered_range: lower bound %g is above the upper bound %g", (double)lower, (double)upper);
+  return search_filtered_impl(ctx, idx, q, nq, k, nprobes, refine_factor, allow_by_rowid, n_allow, 1, lower, upper, ids, dists);
 }
 
 int lance_hip_search_stats(lance_hip_ctx *ctx, uint32_t *n_exact_replays_host) {

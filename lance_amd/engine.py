@@ -374,13 +374,22 @@ class DeviceFlatIndex:
         check(self.engine.lib.lance_hip_index_save(self.engine.h, self.h, os.fspath(index_dir).encode(),
                                                    0 if loss is None else 1, 0.0 if loss is None else float(loss)))
 
-    def search(self, q, k, nprobes):
+    def search(self, q, k, nprobes, allow=None):
+        """allow: boolean array indexed by row id (a prefilter) -- tested inside the scan kernels
+        (lance_hip_ivfflat_search_filtered), no filtered copy of the index"""
         d = self.centroids.shape[1]
         t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
         q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
         nq = q.shape[0]
         ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
         dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        if allow is not None:
+            a = allow if isinstance(allow, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(allow, dtype=bool))
+            a = a.to(torch.uint8).to(_dev()).contiguous()
+            torch.cuda.synchronize()
+            check(self.engine.lib.lance_hip_ivfflat_search_filtered(self.engine.h, self.h, _ptr(q), nq, k, nprobes, _ptr(a), a.numel(),
+                                                                    _ptr(ids), _ptr(dists)))
+            return ids, dists
         torch.cuda.synchronize()
         check(self.engine.lib.lance_hip_ivfflat_search(self.engine.h, self.h, _ptr(q), nq, k, nprobes, _ptr(ids), _ptr(dists)))
         return ids, dists
@@ -530,13 +539,15 @@ class DeviceIndex:
                                                               a.numel(), _ptr(ids), _ptr(dists)))
         return ids, dists
 
-    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0):
+    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0, allow=None):
         """Distance-range query: only rows with lower <= d < upper (ADC distance) enter the per-partition heaps.  With a
         refine factor the reference also filters the exact distances before the final fetch (scanner.rs:3334-3377): all
-        k * refine_factor candidates come back re-ranked from the device and the range is applied to them here."""
+        k * refine_factor candidates come back re-ranked from the device and the range is applied to them here.
+        allow: boolean array indexed by row id -- the range combined with a row-id prefilter, tested inside the scan
+        kernels (lance_hip_ivfpq_search_filtered_range; flat/index.rs:131-149)."""
         if refine_factor and refine_factor > 0:
             keff = k * refine_factor
-            ci, cd = self.search_range(q, keff, nprobes, lower, upper, refine_factor=-1)       # -1: re-rank, keep all
+            ci, cd = self.search_range(q, keff, nprobes, lower, upper, refine_factor=-1, allow=allow)       # -1: re-rank, keep all
             # the bounds are f32 values in the reference (Query::lower_bound: Option<f32>): round before comparing
             lo = float(np.finfo(np.float32).min) if lower is None else float(np.float32(lower))
             hi = float(np.finfo(np.float32).max) if upper is None else float(np.float32(upper))
@@ -558,6 +569,14 @@ class DeviceIndex:
         dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         lo = float(np.finfo(np.float32).min) if lower is None else float(np.float32(lower))
         hi = float(np.finfo(np.float32).max) if upper is None else float(np.float32(upper))
+        if allow is not None:
+            a = allow if isinstance(allow, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(allow, dtype=bool))
+            a = a.to(torch.uint8).to(_dev()).contiguous()
+            torch.cuda.synchronize()
+            check(self.engine.lib.lance_hip_ivfpq_search_filtered_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes,
+                                                                        1 if refine_factor == -1 else 0, _ptr(a), a.numel(), lo, hi,
+                                                                        _ptr(ids), _ptr(dists)))
+            return ids, dists
         torch.cuda.synchronize()
         check(self.engine.lib.lance_hip_ivfpq_search_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes, 1 if refine_factor == -1 else 0,
                                                            lo, hi, _ptr(ids), _ptr(dists)))

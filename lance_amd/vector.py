@@ -181,9 +181,8 @@ class IvfPqIndex:
         max_np = max(min(max_np, nlist), min(min_np, nlist))
         min_np = min(min_np, max_np)
         if distance_range is not None:
-            ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
             lo, hi = distance_range
-            ids, dists = ix.search_range(q, k, min_np, lo, hi, refine_factor=rf)
+            ids, dists = self._ix.search_range(q, k, min_np, lo, hi, refine_factor=rf, allow=prefilter)
             return ids.cpu().numpy(), dists.cpu().numpy()
 
         def run(qq, npb):
@@ -298,13 +297,14 @@ class IvfFlatIndex:
         return self._ix.search(q, k, nprobes)
 
     def nearest(self, q, k=10, nprobes=1, prefilter=None):
-        ix = self._ix if prefilter is None else self.prefiltered(prefilter)._ix
-        ids, dists = ix.search(q, k, nprobes)
+        """prefilter: boolean array over row ids; the mask is tested inside the scan kernels (no copy of the index)"""
+        ids, dists = self._ix.search(q, k, nprobes) if prefilter is None else self._ix.search(q, k, nprobes, allow=prefilter)
         return ids.cpu().numpy().view(np.uint64), dists.cpu().numpy()
 
     def prefiltered(self, allow):
-        """IVF_FLAT under a row-id prefilter: FlatIndex::search scores each selected row with the same distance function
-        as the unfiltered scan (flat/storage.rs:345-402), so the compacted copy is exact (see IvfPqIndex.prefiltered)."""
+        """A compacted copy of the index restricted to the selected rows (kept for callers that reuse one filter for many
+        batches; `nearest(prefilter=)` does not need it).  FlatIndex::search scores each selected row with the same distance
+        function as the unfiltered scan (flat/storage.rs:345-402), so the compacted copy is exact."""
         from .engine import DeviceFlatIndex
         if self.part_ids is None or getattr(self, "_x", None) is None:
             raise NotImplementedError("prefilter needs the index's vectors and partition ids (an index built by create_index)")

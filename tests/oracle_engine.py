@@ -179,11 +179,12 @@ class OracleDeviceIndex:
                              prefilter=np.ascontiguousarray(_np(allow), dtype=bool))
         return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
 
-    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0):
+    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0, allow=None):
         lo = np.finfo(f32).min if lower is None else lower
         hi = np.finfo(f32).max if upper is None else upper
         raw = None if self._raw is None else self._raw.numpy().astype(f32)
-        i, d = self.o.search(_np(q).astype(f32), k, nprobes, lower=lo, upper=hi, refine=refine_factor, raw=raw if refine_factor else None)
+        i, d = self.o.search(_np(q).astype(f32), k, nprobes, lower=lo, upper=hi, refine=refine_factor, raw=raw if refine_factor else None,
+                             prefilter=None if allow is None else np.ascontiguousarray(_np(allow), dtype=bool))
         return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
 
 
@@ -221,7 +222,12 @@ class OracleDeviceFlatIndex:
     def close(self):
         pass
 
-    def search(self, q, k, nprobes):
+    def search(self, q, k, nprobes, allow=None):
+        if allow is not None:      # the fused mask == a compacted copy (same distance function per selected row)
+            al = np.ascontiguousarray(_np(allow), dtype=bool)
+            keep = (self.rid < al.size) & al[np.minimum(self.rid, max(al.size, 1) - 1).astype(np.int64)] if al.size else np.zeros(self.rid.size, bool)
+            sub = OracleDeviceFlatIndex(self.engine, self.metric, self.centroids, self.x[keep], self.part[keep], self.rid[keep], self.data_dtype)
+            return sub.search(q, k, nprobes)
         # the stored partition of every row is authoritative (it may come from a file or carry a prefilter's holes)
         cent = _np(self.centroids).astype(f32)
         nlist = cent.shape[0]

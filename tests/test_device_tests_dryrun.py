@@ -98,3 +98,13 @@ def test_dryrun_adaptive_probing(fake, oracle):
     import lance_amd
     import test_gpu_pm_scan as P
     P.test_adaptive_probing_extends_starved_queries(lance_amd, oracle)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_dryrun_4bit(fake, oracle, metric):
+    """everything up to the single-partition entry point (which the stand-in engine does not model): build, search, the
+    prefilter branch and prefilter + range"""
+    try:
+        G.test_4bit_pq_bit_exact(fake, oracle, metric)
+    except AttributeError as e:
+        assert "pq_scan_topk" in str(e)

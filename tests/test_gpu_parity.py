@@ -407,6 +407,13 @@ def test_4bit_pq_bit_exact(eng, oracle, metric):
         oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, prefilter=allow)
         assert (_np(gi).view(np.uint64) == oi).all(), (metric, "prefilter", frac, k, nprobes, rf)
         assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+    allow = rng.random(n) < 0.5                      # ... and together with a distance range
+    _, ud = oidx.search(q, 40, nlist, prefilter=allow)
+    fin = ud[np.isfinite(ud)]
+    lo, hi = float(np.quantile(fin, 0.2)), float(np.quantile(fin, 0.7))
+    gi, gd = gidx.search_range(q, 10, 4, lo, hi, allow=allow)
+    oi, od = oidx.search(q, 10, 4, prefilter=allow, lower=lo, upper=hi)
+    assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
     # single partition entry point, small partition (all rows exact) and a 16-multiple boundary
     for n_p in (150, 1008, 1013):
         ct = oracle.transpose(oracle.pq_encode(res[:n_p], ocb, metric, nbits=4))
@@ -839,6 +846,15 @@ def test_distance_range_search(eng, oracle, metric):
             oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x, lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
                                  upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
             assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rf, rng_)
+            assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+        # range + row-id prefilter, both tested inside the scan (flat/index.rs:131-149); no filtered copy of the index
+        allow = np.random.default_rng(nq).random(n) < 0.4
+        for k, nprobes, rf, rng_ in ((10, 8, 0, (lo, hi)), (10, nlist, 0, (None, hi)), (5, 8, 4, (elo, ehi))):
+            gi, gd = ix.nearest(q, k, nprobes, refine_factor=rf or None, distance_range=rng_, prefilter=allow)
+            oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None, prefilter=allow,
+                                 lower=rng_[0] if rng_[0] is not None else np.finfo(f32).min,
+                                 upper=rng_[1] if rng_[1] is not None else np.finfo(f32).max)
+            assert (gi.view(np.uint64) == oi).all(), (metric, nq, k, nprobes, rf, rng_, "prefilter")
             assert (gd.view(np.uint32) == od.view(np.uint32)).all()
 
 

@@ -327,7 +327,7 @@ def test_range_with_refine_selection_logic(oracle):
     none = np.iinfo(np.uint64).max
 
     class Stub:
-        def search_range(self, qq, keff, nprobes, lower, upper, refine_factor=0):
+        def search_range(self, qq, keff, nprobes, lower, upper, refine_factor=0, allow=None):
             assert refine_factor == -1
             ci, _ = oidx.search(qq, keff, nprobes, lower=np.finfo(f32).min if lower is None else lower,
                                 upper=np.finfo(f32).max if upper is None else upper)      # ADC-ranged candidates, no refine
