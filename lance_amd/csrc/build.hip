@@ -24,16 +24,38 @@
 
 namespace lh {
 
-// a4: l2_norm = sqrt(sequential sum of x^2 in f32); out = x / l2_norm.  One lane per row.
+// a4: l2_norm = sqrt(sequential sum of x^2 in T); out = x / l2_norm (kernels.rs:141-146).  One lane per row.
+// F16: T = half::f16 (do_normalize_fsl::<Float16Type>) on f32 containers holding f16 values -- every operation of the `half`
+// crate (2.7.1, x86_64) is the f32 operation rounded to binary16: powi(2) -> rh(x*x); `Sum for f16` adds the widened terms
+// in f32 and rounds once; sqrt -> rh(sqrtf); x / l2_norm -> rh(x / norm).
+template <bool F16>
 __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   const float *v = x + r * d;
   float acc = 0.0f;
-  for (int i = 0; i < d; ++i) acc = acc + v[i] * v[i];
-  const float norm = sqrtf(acc);
+  for (int i = 0; i < d; ++i) {
+    float p = v[i] * v[i];
+    if (F16) p = __half2float(__float2half_rn(p));
+    acc = acc + p;
+  }
+  if (F16) acc = __half2float(__float2half_rn(acc));
+  float norm = sqrtf(acc);
+  if (F16) norm = __half2float(__float2half_rn(norm));
   float *o = out + r * d;
-  for (int i = 0; i < d; ++i) o[i] = v[i] / norm;
+  for (int i = 0; i < d; ++i) {
+    float qv = v[i] / norm;
+    if (F16) qv = __half2float(__float2half_rn(qv));
+    o[i] = qv;
+  }
+}
+
+int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16) {
+  if (n <= 0) return LANCE_HIP_OK;
+  if (f16) hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
+  else hipLaunchKernelGGL(normalize_kernel<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
 }
 
 // KeepFiniteVectors: rows with any non-finite element get part id NONE.
@@ -134,13 +156,6 @@ int launch_residual(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const 
   return LANCE_HIP_OK;
 }
 
-int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out) {
-  if (n == 0) return LANCE_HIP_OK;
-  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
-  LH_CHECK_HIP(hipGetLastError());
-  return LANCE_HIP_OK;
-}
-
 // 4-bit packing, pq.rs:168-172: byte b = (code[2b+1] << 4) | code[2b]
 __global__ __launch_bounds__(256) void pack_nibbles_kernel(const uint8_t *__restrict__ in, int64_t n, int m, uint8_t *__restrict__ out) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -189,12 +204,19 @@ extern "C" {
 
 int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, void *out) {
   LH_REQUIRE(ctx && x && out, "normalize: NULL argument");
-  LH_REQUIRE(dtype == LANCE_HIP_F32, "normalize: only f32 is implemented in this version");
+  LH_REQUIRE(dtype == LANCE_HIP_F32 || dtype == LANCE_HIP_F16, "normalize: f32 and f16 columns (normalize_fsl accepts float arrays only, kernels.rs:170-186)");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (n == 0) return LANCE_HIP_OK;
-  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream,
-                     static_cast<const float *>(x), (int64_t)n, (int)d, static_cast<float *>(out));
-  LH_CHECK_HIP(hipGetLastError());
+  if (dtype == LANCE_HIP_F16) {   // f16 in, f16 out, f16 arithmetic
+    const float *xf;
+    LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+    float *of = ctx->scratch_t<float>("f16.normalize_out", (size_t)n * d);
+    if (!of) return LANCE_HIP_ENOMEM;
+    LH_TRY(launch_normalize(ctx, xf, (int64_t)n, (int)d, of, true));
+    LH_TRY(from_f32(ctx, dtype, of, out, (size_t)n * d));
+  } else {
+    LH_TRY(launch_normalize(ctx, static_cast<const float *>(x), (int64_t)n, (int)d, static_cast<float *>(out), false));
+  }
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
@@ -236,7 +258,9 @@ int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x
   LH_TRY(check_dtype(dtype, "pq_encode"));
   LH_TRY(check_pq_params(d, m, nbits));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "pq_encode: f16 dot is not implemented in this version");
+  // f16 columns: L2 takes l2_scalar::<f16, f32, 16> (as f32 does); dot products of f16 sub-vectors are dot_scalar::<f16, f32, 32>
+  // (dot.rs:91-102), which for sub-vectors of up to 16 elements is the same sequence of additions as the 16-lane form
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d / m > 16), "pq_encode: f16 dot with sub-vectors longer than 16 is not supported");
   const float *xf, *cbf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
   LH_TRY(as_f32(ctx, model_dtype(dtype), codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
@@ -254,7 +278,6 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (n == 0) { if (loss_out_host) *loss_out_host = 0.0; return LANCE_HIP_OK; }
   const bool f16 = dtype == LANCE_HIP_F16;
-  LH_REQUIRE(!(f16 && metric != LANCE_HIP_L2), "ivfpq_encode: f16 supports the L2 metric only in this version");
   const float *xs = nullptr, *centf, *cbf;
   LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, "f16.cent", &centf));
   LH_TRY(as_f32(ctx, model_dtype(dtype), codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
@@ -267,6 +290,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   pa.cent = centf; pa.k = (int)nlist;
   pa.ids = part_ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
   pa.check_finite = true;  // KeepFiniteVectors fused into the assign kernel
+  pa.lanes32 = f16 && metric == LANCE_HIP_DOT && d > 16;   // coarse quantiser of an f16 column under dot: dot_scalar::<f16, f32, 32>
   // Native route (L2 / dot): the MFMA assign kernels and the fused residual + encode kernel read the rows in the column's own
   // element type -- no f32 copy of the column, no residual array.  Cosine normalises first and takes the staged route.
   const bool native = metric != LANCE_HIP_COSINE && encode_fused_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf);
@@ -283,7 +307,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   if (metric == LANCE_HIP_COSINE) {
     float *xn = ctx->scratch_t<float>("encode.norm", (size_t)n * d);
     if (!xn) return LANCE_HIP_ENOMEM;
-    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, xs, (int64_t)n, (int)d, xn);
+    LH_TRY(launch_normalize(ctx, xs, (int64_t)n, (int)d, xn, f16));
     xs = xn; pa.x = xs;
   }
   LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
@@ -324,7 +348,9 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
                               const void *codebook, uint32_t m, uint32_t nbits, lance_hip_index **out) {
   LH_REQUIRE(ctx && centroids && codebook && out, "index: NULL argument");
   LH_TRY(check_dtype(dtype, "index"));
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "index: f16 supports the L2 metric only in this version");
+  // f16 columns under dot: the table entries are dot products of f16 sub-vectors (32-lane dot_scalar, dot.rs:91-102) -- identical
+  // to the 16-lane form up to 16 elements, which is what the table kernels implement
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && m != 0 && d / m > 16), "index: f16 dot with sub-vectors longer than 16 is not supported");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_COSINE || metric == LANCE_HIP_DOT, "index: bad metric %d", metric);
   LH_REQUIRE(nlist > 0 && nlist <= 65536, "index: nlist=%u not supported in this version (1..65536)", nlist);
   LH_TRY(check_pq_params(d, m, nbits));

@@ -52,9 +52,12 @@ struct RegVec {
 // BNEG: `b` holds the NEGATED operand (tiles are negated once when staged into LDS), so
 // x - y is evaluated as x + (-y): bit-identical in IEEE-754, and it lets the backend emit
 // v_pk_add_f32 instead of two scalar v_sub_f32 plus register shuffles.
-template <int D, int METRIC, bool BNEG = false>
+// LANES = 16 for f32 / widened-f16 L2 and f32 dot; 32 for dot products of f16 columns (dot_scalar::<f16, f32, 32>,
+// dot.rs:91-102,138-161): same shape, twice as many lane accumulators per chunk.
+template <int D, int METRIC, bool BNEG = false, int LANES = 16>
 __device__ __forceinline__ float dist_exact(const RegVec<D> &a, const float *__restrict__ b) {
-  constexpr int FULL = D / 16 * 16;
+  static_assert(LANES == 16 || LANES == 32, "lane accumulators: 16 or 32");
+  constexpr int FULL = D / LANES * LANES;
   float s = 0.0f;
   if constexpr (FULL != D) {
     float acc = 0.0f;
@@ -90,17 +93,17 @@ __device__ __forceinline__ float dist_exact(const RegVec<D> &a, const float *__r
   }
   float tot = 0.0f;
   if constexpr (FULL > 0) {
-    constexpr int NJ = FULL / 16;
+    constexpr int NJ = FULL / LANES;
 #pragma unroll
-    for (int ig = 0; ig < 4; ++ig) {
+    for (int ig = 0; ig < LANES / 4; ++ig) {
       // issue all of this lane-group's tile reads first (one LDS latency per group, not per read)
       f4 bv[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const f4 *>(b + 16 * j + 4 * ig);
+      for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const f4 *>(b + LANES * j + 4 * ig);
       f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const f4 av = a.q[4 * j + ig];
+        const f4 av = a.q[(LANES / 4) * j + ig];
         if constexpr (METRIC == METRIC_DOT) {
           acc += av * bv[j];
         } else {
@@ -137,11 +140,11 @@ __device__ __forceinline__ f4 load4(const int8_t *p) {
 // Runtime-d version (both operands through pointers); same order.  Used by the
 // generic-dimension fallbacks and by small host-order helpers.  TB = float or __half
 // (f16 elements are widened one by one, l2.rs:128-159).
-template <int METRIC, typename TB = float>
+template <int METRIC, typename TB = float, int LANES = 16>
 __device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, const TB *__restrict__ bp, int d) {
   struct BView { const TB *p; __device__ __forceinline__ float operator[](int i) const { return ld_elem(p, i); } };
   const BView b{bp};
-  const int full = d / 16 * 16;
+  const int full = d / LANES * LANES;
   float s = 0.0f;
   if (full != d) {
     float acc = 0.0f;
@@ -155,12 +158,12 @@ __device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, cons
     }
     s = acc;
   }
-  float sums[16];
+  float sums[LANES];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) sums[i] = 0.0f;
-  for (int c = 0; c < full; c += 16) {
+  for (int i = 0; i < LANES; ++i) sums[i] = 0.0f;
+  for (int c = 0; c < full; c += LANES) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < LANES; ++i) {
       if constexpr (METRIC == METRIC_DOT) {
         sums[i] += a[c + i] * b[c + i];
       } else {
@@ -171,7 +174,7 @@ __device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, cons
   }
   float tot = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) tot = tot + sums[i];
+  for (int i = 0; i < LANES; ++i) tot = tot + sums[i];
   return s + tot;
 }
 
@@ -180,27 +183,54 @@ __device__ __forceinline__ float dist_exact_rt(const float *__restrict__ a, cons
 // (target-cpu=haswell) f32x16 is two __m256, multiply_add is vfmadd (simd/f32.rs:776-785) and
 // reduce_sum is the permute/hadd tree ((a0+a4)+(a2+a6))+((a1+a5)+(a3+a7)) (simd/f32.rs:203-218,
 // 625-644).  The fused multiply-adds are written with __fmaf_rn here on purpose.
-template <typename TB = float>
+template <typename TB = float, int LANES = 16>
 __device__ __forceinline__ float norm_l2_rt(const TB *__restrict__ vp, int d) {
   struct VView { const TB *p; __device__ __forceinline__ float operator[](int i) const { return ld_elem(p, i); } };
   const VView v{vp};
-  const int full = d / 16 * 16;
+  const int full = d / LANES * LANES;
   float s = 0.0f;
   if (full != d) {
     float acc = 0.0f;
     for (int i = full; i < d; ++i) acc = acc + v[i] * v[i];
     s = acc;
   }
-  float sums[16];
+  float sums[LANES];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) sums[i] = 0.0f;
-  for (int c = 0; c < full; c += 16)
+  for (int i = 0; i < LANES; ++i) sums[i] = 0.0f;
+  for (int c = 0; c < full; c += LANES)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sums[i] += v[c + i] * v[c + i];
+    for (int i = 0; i < LANES; ++i) sums[i] += v[c + i] * v[c + i];
   float tot = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) tot = tot + sums[i];
+  for (int i = 0; i < LANES; ++i) tot = tot + sums[i];
   return sqrtf(s + tot);
+}
+
+// Cosine distance of f16 columns: the trait default `cosine_scalar` (cosine.rs:171-179, the arm `impl Cosine for f16` takes
+// without the fp16kernels feature): xy = dot(x, y), y_sq = dot(y, y), both dot_scalar::<f16, f32, 32>;
+// 1 - xy / (x_norm * sqrt(y_sq)) with x_norm = norm_l2_impl::<f16, f32, 32>(x) (norm_l2.rs:60-85).  Operands arrive widened.
+template <typename TB = float>
+__device__ __forceinline__ float cosine_scalar32_rt(const float *__restrict__ x, float x_norm, const TB *__restrict__ yp, int d) {
+  struct YView { const TB *p; __device__ __forceinline__ float operator[](int i) const { return ld_elem(p, i); } };
+  const YView y{yp};
+  const int full = d / 32 * 32;
+  float sxy = 0.0f, syy = 0.0f;
+  if (full != d) {
+    float axy = 0.0f, ayy = 0.0f;
+    for (int i = full; i < d; ++i) { const float yv = y[i]; axy = axy + x[i] * yv; ayy = ayy + yv * yv; }
+    sxy = axy; syy = ayy;
+  }
+  float pxy[32], pyy[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { pxy[i] = 0.0f; pyy[i] = 0.0f; }
+  for (int c = 0; c < full; c += 32)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float yv = y[c + i]; pxy[i] += x[c + i] * yv; pyy[i] += yv * yv; }
+  float txy = 0.0f, tyy = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { txy = txy + pxy[i]; tyy = tyy + pyy[i]; }
+  const float xy = sxy + txy, y_sq = syy + tyy;
+  return 1.0f - xy / (x_norm * sqrtf(y_sq));
 }
 
 __device__ __forceinline__ float reduce8_tree(const float (&a)[8]) {

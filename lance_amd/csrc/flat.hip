@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(FlatArgs p) {
 }
 
 // generic dimension: query read through global/L1 per row (correctness fallback)
-template <int METRIC>
+// H32: f16 column (operands arrive widened) -- dot products / norms in the 32-lane order (dot.rs:91-102, norm_l2.rs:60-85) and
+// the scalar cosine of the Cosine trait default (cosine.rs:171-179)
+template <int METRIC, bool H32 = false>
 __global__ __launch_bounds__(256) void flat_scan_generic_kernel(FlatArgs p, int tr_max) {
   extern __shared__ __attribute__((aligned(16))) char fsm[];
   uint64_t *trid = reinterpret_cast<uint64_t *>(fsm);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void flat_scan_generic_kernel(FlatArgs p, int 
   const int64_t r0 = (int64_t)sp * p.rows_per_split;
   const int64_t r1 = min(p.n, r0 + p.rows_per_split);
   float qnorm = 0.0f;
-  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, p.d);
+  if constexpr (METRIC == METRIC_COSINE) qnorm = H32 ? norm_l2_rt<float, 32>(qv, p.d) : norm_l2_rt(qv, p.d);
   for (int64_t t0 = r0; t0 < r1; t0 += tr_max) {
     const int tr = (int)min<int64_t>(tr_max, r1 - t0);
     __syncthreads();
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(256) void flat_scan_generic_kernel(FlatArgs p, int 
     if (valid) {
       for (int r = 0; r < tr; ++r) {
         float v;
-        if constexpr (METRIC == METRIC_COSINE) v = cosine_exact_rt(qv, qnorm, &tile[r * p.d], p.d);
-        else v = finish_metric<METRIC>(dist_exact_rt<METRIC>(qv, &tile[r * p.d], p.d));
+        if constexpr (METRIC == METRIC_COSINE) v = H32 ? cosine_scalar32_rt(qv, qnorm, &tile[r * p.d], p.d) : cosine_exact_rt(qv, qnorm, &tile[r * p.d], p.d);
+        else v = finish_metric<METRIC>(dist_exact_rt<METRIC, float, (H32 && METRIC == METRIC_DOT) ? 32 : 16>(qv, &tile[r * p.d], p.d));
         const uint32_t key = order_key(v);
         if (key < wkey || cnt < p.k || (key == wkey && trid[r] < wrid)) flat_insert(lk, lr, p.k, cnt, key, trid[r], wkey, wrid);
       }
@@ -518,14 +520,17 @@ __device__ __forceinline__ uint32_t kth_smallest_256(uint32_t v, int kk, uint32_
 // f32::cosine = norm_l2(query) once, then cosine_fast per row (cosine.rs:36-39,143-175) -- the rows of a cosine IVF_FLAT index
 // are stored normalised (IvfTransformer::new_flat, ivf.rs:147-160) and the query arrives normalised (knn.rs:498), but the
 // distance function is still the full cosine.
-template <int METRIC>
+// H32: the rows are widened f16 values -- FlatDistanceCal over a Float16 column calls f16's dot / cosine (32-lane dot_scalar and
+// norm_l2_impl, the scalar cosine; dot.rs:91-102, norm_l2.rs:60-85, cosine.rs:171-179); L2 stays the 16-lane l2_scalar.
+template <int METRIC, bool H32 = false>
 __device__ __forceinline__ float ivfflat_dist_rt(const float *__restrict__ q, float qnorm, const float *__restrict__ row, int d) {
-  if constexpr (METRIC == METRIC_COSINE) return cosine_exact_rt(q, qnorm, row, d);
-  else return finish_metric<METRIC>(dist_exact_rt<METRIC>(q, row, d));
+  if constexpr (METRIC == METRIC_COSINE) return H32 ? cosine_scalar32_rt(q, qnorm, row, d) : cosine_exact_rt(q, qnorm, row, d);
+  else return finish_metric<METRIC>(dist_exact_rt<METRIC, float, (H32 && METRIC == METRIC_DOT) ? 32 : 16>(q, row, d));
 }
 
-template <int D, int METRIC>   // D = 0: run-time dimension
+template <int D, int METRIC, bool H32 = false>   // D = 0: run-time dimension (H32 only there)
 __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
+  static_assert(!H32 || D == 0, "the f16 orders run on the run-time-dimension kernel");
   extern __shared__ __attribute__((aligned(16))) float qt[];   // [d padded to 4]
   __shared__ uint32_t sorted[256];
   __shared__ uint32_t slot;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
   const uint64_t tr = ~0ull;   // every row tied with the bound stays in the pool: the tie check below needs all of them
   __syncthreads();
   float qnorm = 0.0f;
-  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qt, a.d);
+  if constexpr (METRIC == METRIC_COSINE) qnorm = H32 ? norm_l2_rt<float, 32>(qt, a.d) : norm_l2_rt(qt, a.d);
   uint32_t mn = 0xFFFFFFFFu;
   for (uint32_t base = r0; base < r1; base += 256) {
     const uint32_t row = base + threadIdx.x;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(256) void ivfflat_kernel(IvfFlatArgs a) {
         for (int i = 0; i < D / 4; ++i) rv.q[i] = *reinterpret_cast<const f4 *>(src + 4 * i);
         v = finish_metric<METRIC>(dist_exact<D, METRIC, NEG>(rv, qt));
       } else {
-        v = ivfflat_dist_rt<METRIC>(qt, qnorm, a.vec + (int64_t)row * a.d, a.d);
+        v = ivfflat_dist_rt<METRIC, H32>(qt, qnorm, a.vec + (int64_t)row * a.d, a.d);
       }
       const uint32_t key = order_key(v);
       if (a.bound) {
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256) void ivfflat_select_kernel(IvfFlatArgs a, uint
 // Exact replay of a flagged query: every probed partition through a max-heap of k with std BinaryHeap semantics
 // (push while len < k, else replace the root only if root.dist > dist), rows in scan order; distances by all 64
 // lanes, a ballot drops rows that cannot enter, lane 0 replays the rest; partition heaps are merged by (dist, rowid).
-template <int METRIC>
+template <int METRIC, bool H32 = false>
 __global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int qi = blockIdx.x;
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64
   for (int t = lane; t < a.d; t += 64) qv[t] = a.q[(int64_t)qi * a.d + t];
   __syncthreads();
   float qnorm = 0.0f;
-  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, a.d);
+  if constexpr (METRIC == METRIC_COSINE) qnorm = H32 ? norm_l2_rt<float, 32>(qv, a.d) : norm_l2_rt(qv, a.d);
   for (int pi = 0; pi < a.nprobes; ++pi) {
     const uint32_t part = a.probes[(int64_t)qi * a.nprobes + pi];
     const uint32_t off = a.part_offsets[part];
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(64) void ivfflat_exact_kernel(IvfFlatArgs a, uint64
       uint32_t key = 0xFFFFFFFFu;
       bool cand = false;
       if (row < np && row_allowed(a.allow, off + (uint32_t)row)) {
-        key = order_key(ivfflat_dist_rt<METRIC>(qv, qnorm, a.vec + (int64_t)(off + row) * a.d, a.d));
+        key = order_key(ivfflat_dist_rt<METRIC, H32>(qv, qnorm, a.vec + (int64_t)(off + row) * a.d, a.d));
         cand = s_hlen < k || key < hk[0];
       }
       const uint64_t mask = __ballot(cand);
@@ -832,8 +837,12 @@ __global__ __launch_bounds__(256) void ivfflat_kth_kernel(const uint32_t *__rest
 }
 
 template <int METRIC>
-static void launch_ivfflat(lance_hip_ctx *ctx, const IvfFlatArgs &a, unsigned grid, bool fixed) {
+static void launch_ivfflat(lance_hip_ctx *ctx, const IvfFlatArgs &a, unsigned grid, bool fixed, bool h32 = false) {
   const size_t lds = (size_t)((a.d + 3) & ~3) * 4;
+  if constexpr (METRIC != METRIC_L2) if (h32) {   // f16 column under dot / cosine: the 32-lane orders, run-time dimension
+    hipLaunchKernelGGL((ivfflat_kernel<0, METRIC, true>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    return;
+  }
   if constexpr (METRIC != METRIC_COSINE) if (fixed) {   // cosine: run-time dimension kernel only (cosine_fast has its own lane layout)
     switch (a.d) {
       case 8: hipLaunchKernelGGL((ivfflat_kernel<8, METRIC>), dim3(grid), dim3(256), lds, ctx->stream, a); return;
@@ -858,7 +867,6 @@ extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metri
   LH_REQUIRE(ctx && centroids && out && (n == 0 || (x && part_ids)), "ivfflat_create: NULL argument");
   LH_TRY(check_dtype(dtype, "ivfflat_create"));
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "ivfflat_create: bad metric %d", metric);
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "ivfflat_create: f16 dot / cosine are not implemented in this version");
   LH_REQUIRE(!(dtype == LANCE_HIP_I8 && metric == LANCE_HIP_COSINE), "ivfflat_create: int8 cosine is not supported (no normalised int8 rows)");
   LH_REQUIRE(nlist > 0 && nlist <= 65536 && d > 0, "ivfflat_create: nlist=%u / d=%u not supported", nlist, d);
   LH_REQUIRE(n < (1ull << 32), "ivfflat_create: n too large for this version");
@@ -928,11 +936,13 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
     // vectors (ivf/v2.rs:455-465), the partition scan uses the cosine distance itself (flat/storage.rs:345-402)
     float *qn = ctx->scratch_t<float>("ivfflat.qn", (size_t)nq * d);
     if (!qn) return LANCE_HIP_ENOMEM;
-    LH_TRY(lance_hip_normalize(ctx, LANCE_HIP_F32, qf, nq, idx->d, qn));
+    LH_TRY(launch_normalize(ctx, qf, (int64_t)nq, d, qn, idx->dtype == LANCE_HIP_F16));   // an f16 key is normalised in f16 arithmetic
     qf = qn;
   }
-  LH_TRY(lance_hip_find_partitions(ctx, LANCE_HIP_F32, cosine ? LANCE_HIP_L2 : idx->metric, qf, nq, idx->d, idx->centroids, idx->nlist, nprobes,
-                                   probes, pd));
+  // f16 column under dot / cosine: the distance functions of half::f16 (32-lane dot / norm, scalar cosine) on the widened values
+  const bool h32 = idx->dtype == LANCE_HIP_F16 && idx->metric != LANCE_HIP_L2;
+  LH_TRY(find_partitions_f32(ctx, cosine ? LANCE_HIP_L2 : idx->metric, qf, nq, idx->d, idx->centroids, idx->nlist, nprobes, probes, pd,
+                             idx->dtype == LANCE_HIP_F16 && idx->metric == LANCE_HIP_DOT && d > 16));
   const int qch = (int)std::min<uint32_t>(nq, FLAT_QCHUNK);
   IvfFlatArgs a;
   a.vec = idx->vectors; a.row_ids = idx->row_ids; a.part_offsets = idx->part_offsets; a.nprobes = (int)nprobes; a.d = d;
@@ -950,13 +960,15 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
   pl.prids = ctx->scratch_t<uint64_t>("flat2.prids", (size_t)qch * FLAT_CAP);
   pl.overflow = ctx->scratch_t<uint32_t>("flat2.ovf", 1);
   if (!pl.tkey || !pl.trid || !pl.cnt || !pl.pkeys || !pl.prids || !pl.overflow) return LANCE_HIP_ENOMEM;
-  const bool fixed = !cosine && flat_fixed_dim(idx->d);
+  const bool fixed = !cosine && !h32 && flat_fixed_dim(idx->d);
   const size_t sel_lds = (size_t)IVFFLAT_CAP * 16;
   const size_t ex_lds = (size_t)(((d + 3) & ~3) + 2) * 4 + (size_t)k * 12 + (size_t)(k + 1) * 8 + 64 * 4 + 64;
   auto finish = [&](int nqc, uint64_t *oid, float *od) {
     hipLaunchKernelGGL(ivfflat_select_kernel, dim3(nqc), dim3(256), sel_lds, ctx->stream, a, oid, od);
     ScopedTimer t(ctx, "ivfflat_exact");
-    if (idx->metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
+    if (h32 && cosine) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_COSINE, true>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
+    else if (h32) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT, true>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
+    else if (idx->metric == LANCE_HIP_DOT) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
     else if (cosine) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_COSINE>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
     else hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_L2>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
   };
@@ -1004,8 +1016,8 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
       else launch_ivfflat_pm<METRIC_L2, false>(ctx, a, idx->n_flat_items);
       return;
     }
-    if (idx->metric == LANCE_HIP_DOT) launch_ivfflat<METRIC_DOT>(ctx, a, grid, fixed);
-    else if (cosine) launch_ivfflat<METRIC_COSINE>(ctx, a, grid, false);
+    if (idx->metric == LANCE_HIP_DOT) launch_ivfflat<METRIC_DOT>(ctx, a, grid, fixed, h32);
+    else if (cosine) launch_ivfflat<METRIC_COSINE>(ctx, a, grid, false, h32);
     else launch_ivfflat<METRIC_L2>(ctx, a, grid, fixed);
   };
   for (uint32_t qc0 = 0; qc0 < nq; qc0 += (uint32_t)qch) {
@@ -1057,12 +1069,14 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
                                    float *dists) {
   LH_REQUIRE(ctx && (n == 0 || x) && (nq == 0 || (q && ids && dists)), "flat_topk: NULL argument");
   LH_TRY(check_dtype(dtype, "flat_topk"));
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2), "flat_topk: f16 supports L2 only in this version");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "flat_topk: bad metric %d", metric);
   LH_REQUIRE(k > 0 && k <= 1024, "flat_topk: k=%u not supported (1..1024)", k);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nq == 0) return LANCE_HIP_OK;
-  if (flat_v2_supported(metric, d, k) && !getenv("LANCE_HIP_FLAT_V1")) {
+  // f16 columns under dot / cosine: half::f16's own distance functions (32-lane dot_scalar / norm_l2_impl, scalar cosine;
+  // dot.rs:91-102, norm_l2.rs:60-85, cosine.rs:171-179) -- the run-time-dimension kernel below carries those orders
+  const bool h32 = dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2;
+  if (!h32 && flat_v2_supported(metric, d, k) && !getenv("LANCE_HIP_FLAT_V1")) {
     const float *xf2 = nullptr, *qf2;
     LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf2));
     // f16 / int8 columns: the fixed-dimension L2 / dot kernels (exact filter and MFMA filter) read the rows as they are;
@@ -1090,7 +1104,7 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
   const dim3 grid(qblocks, nsplit);
   {
     ScopedTimer t(ctx, "flat_scan");
-    switch (metric == LANCE_HIP_COSINE ? 0u : d) {
+    switch ((metric == LANCE_HIP_COSINE || h32) ? 0u : d) {
       case 8: launch_flat_fixed<8>(ctx, a, metric, grid); break;
       case 16: launch_flat_fixed<16>(ctx, a, metric, grid); break;
       case 32: launch_flat_fixed<32>(ctx, a, metric, grid); break;
@@ -1102,7 +1116,11 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
         tr = std::max(1, std::min(tr, 256));
         const size_t lds = (size_t)tr * 8 + (size_t)tr * d * 4;
         LH_REQUIRE(lds <= 160 * 1024, "flat_topk: dimension %u too large", d);
-        if (metric == LANCE_HIP_COSINE)
+        if (h32 && metric == LANCE_HIP_COSINE)
+          hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_COSINE, true>), grid, dim3(256), lds, ctx->stream, a, tr);
+        else if (h32)
+          hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_DOT, true>), grid, dim3(256), lds, ctx->stream, a, tr);
+        else if (metric == LANCE_HIP_COSINE)
           hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_COSINE>), grid, dim3(256), lds, ctx->stream, a, tr);
         else if (metric == LANCE_HIP_DOT)
           hipLaunchKernelGGL((flat_scan_generic_kernel<METRIC_DOT>), grid, dim3(256), lds, ctx->stream, a, tr);

@@ -14,6 +14,8 @@ struct PairwiseArgs {
   const void *x_native = nullptr;   // optional: the rows in the column's own element type (x_dtype); kernels that can read it
   int x_dtype = 0;                  // natively (mfma_assign.hip) then never touch `x` (which may be NULL)
   const float *x = nullptr;
+  bool lanes32 = false;             // dot products in the 32-lane order of f16 columns (dot_scalar::<f16, f32, 32>, dot.rs:91-102);
+                                    // set by the callers only when the operands are widened f16 values, metric = dot and d > 16
   int64_t n = 0;
   int64_t ldx = 0;
   int x_batch_off = 0;
@@ -99,7 +101,9 @@ bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range);
 int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
                         uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow);
-int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out);
+int find_partitions_f32(lance_hip_ctx *ctx, int metric, const float *qf, uint32_t nq, uint32_t d, const float *cf, uint32_t nlist,
+                        uint32_t nprobes, uint32_t *part_ids, float *dists, bool lanes32);   // search.hip
+int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16);   // f16: half-precision arithmetic on f32 containers
 
 // quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
 constexpr int QSCAN_SEG_CAP = 256;   // survivors kept per (query, probe)

@@ -343,6 +343,7 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
     pa.bias = use_bias ? bias : nullptr; pa.bias_batch_stride = k;
     pa.ids = ids; pa.dists = dists; pa.out_batch_stride = n;
     pa.active = active_d;
+    pa.lanes32 = f16_arith && metric == LANCE_HIP_DOT && d > 16;   // KMeansAlgoFloat<Float16Type> + dot: dot_scalar::<f16, f32, 32>
     LH_TRY(launch_assign(ctx, pa, d, metric, B));
     LH_TRY(stable_group(ctx, ids, n, n, k, B, starts, sorted_rows, n, active_d));
     {
@@ -448,11 +449,12 @@ struct HHeap {
 }  // namespace
 
 static int hier_assign_host(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, const float *cent, int k,
-                            std::vector<uint32_t> &mem) {
+                            std::vector<uint32_t> &mem, bool f16_arith) {
   uint32_t *ids = ctx->scratch_t<uint32_t>("hier.ids", (size_t)n);
   if (!ids) return LANCE_HIP_ENOMEM;
   PairwiseArgs pa;
   pa.x = x; pa.n = n; pa.ldx = d; pa.cent = cent; pa.k = k; pa.ids = ids; pa.out_batch_stride = n;
+  pa.lanes32 = f16_arith && metric == LANCE_HIP_DOT && d > 16;
   LH_TRY(launch_assign(ctx, pa, d, metric, 1));
   mem.resize((size_t)n);
   LH_CHECK_HIP(hipMemcpyAsync(mem.data(), ids, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -470,7 +472,7 @@ int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, in
   uint64_t sd = seed + run++;
   LH_TRY(kmeans_train_batched(ctx, metric, x, n, d, 0, d, initial_k, 1, max_iters, tol, bf_scaled, false, &sd, cdev, nullptr, nullptr, f16_arith));
   std::vector<uint32_t> mem;
-  LH_TRY(hier_assign_host(ctx, metric, x, n, d, cdev, initial_k, mem));
+  LH_TRY(hier_assign_host(ctx, metric, x, n, d, cdev, initial_k, mem, f16_arith));
   std::vector<float> c0((size_t)initial_k * d);
   LH_CHECK_HIP(hipMemcpyAsync(c0.data(), cdev, c0.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -508,7 +510,7 @@ int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, in
     sd = seed + run++;
     LH_TRY(kmeans_train_batched(ctx, metric, sub, (int64_t)cluster_size, d, 0, d, (int)cluster_k, 1, max_iters, tol, bf_scaled, false, &sd,
                                 cdev, nullptr, nullptr, f16_arith));
-    LH_TRY(hier_assign_host(ctx, metric, sub, (int64_t)cluster_size, d, cdev, (int)cluster_k, mem));
+    LH_TRY(hier_assign_host(ctx, metric, sub, (int64_t)cluster_size, d, cdev, (int)cluster_k, mem, f16_arith));
     bool all_same = true, have_first = false;
     uint32_t first = 0;
     for (size_t r = 0; r < cluster_size; ++r) {
@@ -555,8 +557,7 @@ int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, u
   LH_TRY(check_dtype(dtype, "assign"));
   LH_REQUIRE(d > 0 && k > 0, "assign: d and k must be > 0");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  // f16: l2_scalar<f16,f32,16> widens every element before the arithmetic (l2.rs:128-159)
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "assign: f16 dot (32-lane dot_scalar) is not implemented in this version");
+  // f16: l2_scalar<f16,f32,16> / dot_scalar<f16,f32,32> widen every element before the arithmetic (l2.rs:128-159, dot.rs:91-102)
   const float *xf, *cf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
   LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)k * d, "f16.cent", &cf));
@@ -564,6 +565,7 @@ int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, u
   pa.x = xf; pa.n = (int64_t)n; pa.ldx = d;
   pa.cent = cf; pa.k = (int)k;
   pa.bias = bias; pa.ids = ids; pa.dists = dists; pa.out_batch_stride = (int64_t)n;
+  pa.lanes32 = dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d > 16;
   LH_TRY(launch_assign(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
@@ -611,7 +613,6 @@ int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const v
                              iters_out_host, k_out_host, false);
   }
   // f16: KMeansAlgoFloat<Float16Type> -- widen, train with f16 M-step arithmetic, narrow the model
-  LH_REQUIRE(metric != LANCE_HIP_DOT, "kmeans_train: f16 dot (32-lane dot_scalar) is not implemented in this version");
   const float *xf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
   float *cw = ctx->scratch_t<float>("f16.kmeans_out", (size_t)k * d);

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
 }
 
 // ---- exact re-check: lane = row (vector in VGPRs), reference arithmetic --------------------------------------------
-template <int D, int METRIC, typename TX>
+template <int D, int METRIC, typename TX, int LANES>
 __global__ __launch_bounds__(256) void ma_finalize_kernel(MaArgs p) {
   if (p.active && !p.active[0]) return;
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void ma_finalize_kernel(MaArgs p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       if (t <= cl && cand[t] != LANCE_HIP_NONE) {
-        const float v = finish_metric<METRIC>(dist_exact<D, METRIC>(a, p.cent + (int64_t)cand[t] * D));
+        const float v = finish_metric<METRIC>(dist_exact<D, METRIC, false, LANES>(a, p.cent + (int64_t)cand[t] * D));
         const float vb = p.bias ? v + p.bias[cand[t]] : v;
         if (vb < bestb || (vb == bestb && best != LANCE_HIP_NONE && cand[t] < best)) { bestb = vb; bestv = v; best = cand[t]; }
       }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void ma_finalize_kernel(MaArgs p) {
 
 // One wave per undecided row: exact distances to all k centroids (reference order), argmin_value_float semantics --
 // strictly smallest biased value, first index on ties, NaN never selected (kernels.rs:79-111).
-template <int METRIC, typename TX>
+template <int METRIC, typename TX, int LANES>
 __global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.active && !p.active[0]) return;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
     float bb = INFINITY, bv = INFINITY;
     uint32_t bi = LANCE_HIP_NONE;
     for (int c = lane; c < p.k; c += 64) {
-      const float v = finish_metric<METRIC>(dist_exact_rt<METRIC>(wrow, p.cent + (int64_t)c * p.d, p.d));
+      const float v = finish_metric<METRIC>(dist_exact_rt<METRIC, float, LANES>(wrow, p.cent + (int64_t)c * p.d, p.d));
       const float vb = p.bias ? v + p.bias[c] : v;
       if (vb < bb) { bb = vb; bv = v; bi = (uint32_t)c; }
     }
@@ -350,24 +350,38 @@ __global__ __launch_bounds__(256) void ma_recompute_kernel(MaArgs p) {
   }
 }
 
-template <int KS, int METRIC, typename TX>
+// LANES: lane accumulators of the exact re-check (16; 32 for the dot products of f16 columns, dot.rs:91-102) -- the surrogate's
+// error bound does not depend on the summation order, only the deciding arithmetic does
+template <int KS, int METRIC, typename TX, int LANES = 16>
 static void ma_launch_one(lance_hip_ctx *ctx, const MaArgs &a) {
   constexpr int D = KS * 16;
   const size_t lds_x = (size_t)MA_ROWS * (D + 4) * 4;
   const size_t lds_c = (size_t)2 * 2 * MA_CT * (D + 8) * 2 + (size_t)2 * 2 * MA_CT * 4;
   const size_t lds = std::max(lds_x, lds_c);
   hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC, TX>), dim3((unsigned)cdiv(a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
-  hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC, TX>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
-  hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
+  hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC, TX, LANES>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX, LANES>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
 }
 
-// f32: L2 / dot; f16 columns: L2 (the reference's f16 dot is the 32-lane dot_scalar, not on this path); int8 columns: L2 / dot
+// f32: L2 / dot; f16 columns: L2, and dot in the 32-lane order (`lanes32`: set by the callers for widened f16 operands, whether the
+// rows are read as f16 or from their f32 copy); int8 columns: L2 / dot
 template <int KS>
-static bool ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dtype) {
+static bool ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dtype, bool lanes32) {
+  if (lanes32) {
+    if constexpr (KS < 2) {
+      return false;                       // d = 16: the callers clear the flag (both orders coincide)
+    } else {
+      if (metric != METRIC_DOT) return false;
+      if (dtype == LANCE_HIP_F32) ma_launch_one<KS, METRIC_DOT, float, 32>(ctx, a);
+      else if (dtype == LANCE_HIP_F16) ma_launch_one<KS, METRIC_DOT, __half, 32>(ctx, a);
+      else return false;
+      return true;
+    }
+  }
   if (dtype == LANCE_HIP_F32) {
     if (metric == METRIC_DOT) ma_launch_one<KS, METRIC_DOT, float>(ctx, a); else ma_launch_one<KS, METRIC_L2, float>(ctx, a);
   } else if (dtype == LANCE_HIP_F16) {
-    if (metric == METRIC_DOT) return false;
+    if (metric == METRIC_DOT) return false;   // f16 rows with a dot metric always arrive with lanes32 (d > 16) or as their f32 copy
     ma_launch_one<KS, METRIC_L2, __half>(ctx, a);
   } else {
     if (metric == METRIC_DOT) ma_launch_one<KS, METRIC_DOT, int8_t>(ctx, a); else ma_launch_one<KS, METRIC_L2, int8_t>(ctx, a);
@@ -411,14 +425,14 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
   a.fb_cnt = maxbits + 2; a.fb_rows = fb_rows; a.active = p.active;
   a.id1 = id1; a.id2 = id2; a.id3 = id3; a.cls = cls; a.ids = p.ids; a.dists = p.dists; a.check_finite = p.check_finite ? 1 : 0;
   switch (d / 16) {
-    case 1: ok = ma_launch_ks<1>(ctx, a, metric, dtype); break;
-    case 2: ok = ma_launch_ks<2>(ctx, a, metric, dtype); break;
-    case 3: ok = ma_launch_ks<3>(ctx, a, metric, dtype); break;
-    case 4: ok = ma_launch_ks<4>(ctx, a, metric, dtype); break;
-    case 5: ok = ma_launch_ks<5>(ctx, a, metric, dtype); break;
-    case 6: ok = ma_launch_ks<6>(ctx, a, metric, dtype); break;
-    case 7: ok = ma_launch_ks<7>(ctx, a, metric, dtype); break;
-    case 8: ok = ma_launch_ks<8>(ctx, a, metric, dtype); break;
+    case 1: ok = ma_launch_ks<1>(ctx, a, metric, dtype, p.lanes32); break;
+    case 2: ok = ma_launch_ks<2>(ctx, a, metric, dtype, p.lanes32); break;
+    case 3: ok = ma_launch_ks<3>(ctx, a, metric, dtype, p.lanes32); break;
+    case 4: ok = ma_launch_ks<4>(ctx, a, metric, dtype, p.lanes32); break;
+    case 5: ok = ma_launch_ks<5>(ctx, a, metric, dtype, p.lanes32); break;
+    case 6: ok = ma_launch_ks<6>(ctx, a, metric, dtype, p.lanes32); break;
+    case 7: ok = ma_launch_ks<7>(ctx, a, metric, dtype, p.lanes32); break;
+    case 8: ok = ma_launch_ks<8>(ctx, a, metric, dtype, p.lanes32); break;
     default: return LANCE_HIP_EINVAL;
   }
   LH_REQUIRE(ok, "assign: element type %d with metric %d is not on the MFMA path", dtype, metric);

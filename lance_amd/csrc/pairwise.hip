@@ -209,9 +209,14 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
   p.cent_aligned = ((reinterpret_cast<uintptr_t>(p.cent) & 15) == 0) && (((int64_t)p.cent_batch_stride) % 4 == 0) && (d % 4 == 0);
   const char *tname = MODE == 0 ? "assign" : "dist_matrix";
   ScopedTimer t(ctx, tname);
+  if (p.lanes32) {
+    LH_REQUIRE(metric == METRIC_DOT, "internal: the 32-lane order exists for dot products only");
+    if (d <= 16) p.lanes32 = false;   // up to 16 elements both orders are the same sequence of additions
+  }
   if (MODE == 0 && mfma_assign_supported(p, d, batches)) return launch_assign_mfma(ctx, p, d, metric);
   LH_REQUIRE(p.x != nullptr, "internal: the exact assign kernels need the f32 view of the rows");
   bool fixed_ok = p.cent_aligned;  // LDS tile float4 reads in dist_exact need 16B-aligned rows
+  if (p.lanes32) fixed_ok = false;  // f16 dot products (32 lane accumulators): the two-pass kernel of wide.hip, any dimension
   // distance matrices of query batches (find_partitions): too few rows to fill the chip with one lane per row;
   // the 32 x 64 tiles of wide.hip measured 44 us against 62 us for 10,000 x 256 x 128
   if (MODE == 1 && d >= 64 && p.n <= 65536) fixed_ok = false;

@@ -641,7 +641,9 @@ __global__ __launch_bounds__(256) void ivfpq_merge_kernel(MergeArgs p) {
 
 // refine: exact distance of the original query to the raw vectors of the candidates, then
 // (dist, rowid) order, fetch k  (scanner.rs:2884-2904 take + flat_knn :3336-3412)
-template <int METRIC, typename TR>
+// H32: the column is f16 -- its dot products and norms are the 32-lane dot_scalar / norm_l2_impl (dot.rs:91-102, norm_l2.rs:60-85)
+// and its cosine distance is the trait default cosine_scalar (cosine.rs:171-179), not f32's cosine_fast.
+template <int METRIC, typename TR, bool H32 = false>
 __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw,
                                                      uint64_t n_raw, const uint64_t *__restrict__ cand_rid,
                                                      const uint32_t *__restrict__ cand_cnt, int keff, int k, int P,
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
   const int c = (int)cand_cnt[qi];
   const float *qv = q + (int64_t)qi * d;
   float qnorm = 0.0f;
-  if constexpr (METRIC == METRIC_COSINE) qnorm = norm_l2_rt(qv, d);  // cosine_batch: x_norm = norm_l2(x)
+  if constexpr (METRIC == METRIC_COSINE) qnorm = H32 ? norm_l2_rt<float, 32>(qv, d) : norm_l2_rt(qv, d);  // cosine_batch: x_norm = norm_l2(x)
   if constexpr (METRIC == METRIC_COSINE) {
     for (int i = threadIdx.x; i < P; i += 256) {
       uint32_t kk = 0xFFFFFFFFu;
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
       if (i < c) {
         r = cand_rid[(int64_t)qi * keff + i];
         if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);   // stored row id beyond the raw vectors handed to set_raw: reported, not ranked
-        if (r < n_raw) kk = order_key(cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
+        if (r < n_raw) kk = order_key(H32 ? cosine_scalar32_rt<TR>(qv, qnorm, raw + r * d, d) : cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
       }
       key[i] = kk; rid[i] = r; pos[i] = 0;
     }
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
       if (i < c) {
         r = cand_rid[(int64_t)qi * keff + i];
         if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);
-        if (r < n_raw) kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC, TR>(qv, raw + r * d, d)));
+        if (r < n_raw) kk = order_key(finish_metric<METRIC>(dist_exact_rt<METRIC, TR, (H32 && METRIC == METRIC_DOT) ? 32 : 16>(qv, raw + r * d, d)));
       }
       key[i] = kk; rid[i] = r; pos[i] = 0;
     }
@@ -899,7 +901,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   if (ix->metric == LANCE_HIP_COSINE) {  // knn.rs:495-498
     float *qn = ctx->scratch_t<float>("search.qnorm", (size_t)nq * d);
     if (!qn) return LANCE_HIP_ENOMEM;
-    LH_TRY(launch_normalize(ctx, q, (int64_t)nq, d, qn));
+    LH_TRY(launch_normalize(ctx, q, (int64_t)nq, d, qn, ix->dtype == LANCE_HIP_F16));   // an f16 key is normalised in f16 arithmetic
     qs = qn;
   }
   // coarse quantiser: all distances, then per-query partial sort
@@ -909,6 +911,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   {
     PairwiseArgs pa;
     pa.x = qs; pa.n = nq; pa.ldx = d; pa.cent = ix->centroids; pa.k = nlist; pa.matrix = matrix;
+    pa.lanes32 = ix->dtype == LANCE_HIP_F16 && scan_metric == LANCE_HIP_DOT && d > 16;
     LH_TRY(launch_dist_matrix(ctx, pa, d, scan_metric, 1));
     ScopedTimer t(ctx, "select_probes");
     launch_select_probes(ctx, matrix, nlist, (int)nprobes, (int)nq, probes, nullptr);
@@ -1019,6 +1022,12 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     else if (ix->dtype == LANCE_HIP_I8)
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+    else if (ix->dtype == LANCE_HIP_F16 && ix->metric == LANCE_HIP_COSINE)
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, __half, true>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+    else if (ix->dtype == LANCE_HIP_F16 && ix->metric == LANCE_HIP_DOT)
+      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, __half, true>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->dtype == LANCE_HIP_F16)
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
@@ -1033,6 +1042,26 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
   }
   LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+// find_partitions on f32 operands (kmeans.rs:1134-1158): all distances, per-query partial sort.  lanes32: the operands are
+// widened f16 values and the metric is dot -- 32 lane accumulators.  Synchronises the stream.
+int find_partitions_f32(lance_hip_ctx *ctx, int metric, const float *qf, uint32_t nq, uint32_t d, const float *cf, uint32_t nlist,
+                        uint32_t nprobes, uint32_t *part_ids, float *dists, bool lanes32) {
+  if (nprobes > nlist) nprobes = nlist;
+  LH_REQUIRE(nlist <= 8192 || nprobes <= 256, "find_partitions: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
+  if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
+  float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
+  if (!matrix) return LANCE_HIP_ENOMEM;
+  PairwiseArgs pa;
+  pa.x = qf; pa.n = nq; pa.ldx = d;
+  pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
+  pa.lanes32 = lanes32;
+  LH_TRY(launch_dist_matrix(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
+  launch_select_probes(ctx, matrix, (int)nlist, (int)nprobes, (int)nq, part_ids, dists);
+  LH_CHECK_HIP(hipGetLastError());
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
 
@@ -1064,25 +1093,13 @@ int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const v
                               const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids, float *dists) {
   LH_REQUIRE(ctx && q && centroids && part_ids, "find_partitions: NULL argument");
   LH_TRY(check_dtype(dtype, "find_partitions"));
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT), "find_partitions: f16 dot is not implemented in this version");
   LH_REQUIRE(nlist > 0 && nlist <= 65536, "find_partitions: nlist=%u not supported in this version (1..65536)", nlist);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  if (nprobes > nlist) nprobes = nlist;
-  LH_REQUIRE(nlist <= 8192 || nprobes <= 256, "find_partitions: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
-  if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
-  float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
-  if (!matrix) return LANCE_HIP_ENOMEM;
   const float *qf, *cf;
   LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf));
   LH_TRY(as_f32(ctx, model_dtype(dtype), centroids, (size_t)nlist * d, "f16.cent", &cf));
-  PairwiseArgs pa;
-  pa.x = qf; pa.n = nq; pa.ldx = d;
-  pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
-  LH_TRY(launch_dist_matrix(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
-  launch_select_probes(ctx, matrix, (int)nlist, (int)nprobes, (int)nq, part_ids, dists);
-  LH_CHECK_HIP(hipGetLastError());
-  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  return LANCE_HIP_OK;
+  // f16 columns under dot: dot_scalar::<f16, f32, 32> (dot.rs:91-102)
+  return find_partitions_f32(ctx, metric, qf, nq, d, cf, nlist, nprobes, part_ids, dists, dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d > 16);
 }
 
 int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
@@ -1196,7 +1213,7 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
                            uint64_t *out_ids, float *out_dists, uint32_t *out_n_host) {
   LH_REQUIRE(ctx && q_residual && codebook && out_ids && out_dists, "pq_scan_topk: NULL argument");
   LH_TRY(check_dtype(dtype, "pq_scan_topk"));
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2 && metric != LANCE_HIP_COSINE), "pq_scan_topk: f16 supports L2 only in this version");
+  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && m != 0 && d / m > 16), "pq_scan_topk: f16 dot with sub-vectors longer than 16 is not supported");
   LH_REQUIRE(n_p == 0 || (codes_transposed && row_ids), "pq_scan_topk: NULL codes");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   // a single-partition index whose centroid is 0: q_residual - 0 == q_residual exactly

@@ -29,11 +29,18 @@ namespace lh {
 
 constexpr int W_ROWS = 32, W_CENTS = 64, W_DK = 64, W_LD = 80, W_BS = 512, W_RLD = 20;
 
-template <int METRIC, int MODE>
+// L32 (dot only): the dot products of f16 columns, dot_scalar::<f16, f32, 32> (dot.rs:91-102,138-161) -- 32 lane accumulators
+// per pair.  Accumulator i < 16 of the 32 sums the EVEN 16-chunks of the dimension, accumulator 16 + i the ODD ones, so the 16
+// hardware lanes of a pair make two passes over the staged slices (even chunks, then odd chunks) and the lane-ordered sum
+// continues from the first pass's total: tot = fold(fold(0, even lanes 0..15), odd lanes 0..15).  The remainder (d % 32, up to
+// 31 products) is summed sequentially first, in two 16-wide pieces, into its own buffer; result = remainder + tot.
+template <int METRIC, int MODE, bool L32 = false>
 __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int d, FlatPool fp) {
+  static_assert(!L32 || (METRIC == METRIC_DOT && MODE != 2), "32-lane order: dot products of f16 columns, assign / matrix modes");
   __shared__ __attribute__((aligned(16))) float xt[W_ROWS * W_LD];    // 10 KB  rows x 64-slice (+pad: bank shift per row)
   __shared__ __attribute__((aligned(16))) float ct[W_CENTS * W_LD];   // 20 KB  centroids x 64-slice; reused as transpose scratch
   __shared__ float res[W_ROWS][W_CENTS + 1];
+  __shared__ float res2[L32 ? W_ROWS : 1][L32 ? W_CENTS + 1 : 1];     // L32: the sequential remainder sum of every pair
   __shared__ uint32_t nonfinite[W_ROWS];
   __shared__ uint32_t tk[MODE == 2 ? W_CENTS : 1];
   __shared__ uint64_t tr[MODE == 2 ? W_CENTS : 1];
@@ -49,7 +56,8 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
   const float *cb = p.cent + (int64_t)b * p.cent_batch_stride;
   const float *biasb = p.bias ? p.bias + (int64_t)b * p.bias_batch_stride : nullptr;
   const int64_t row0 = (int64_t)blockIdx.x * W_ROWS;
-  const int full = d / 16 * 16;
+  constexpr int LW = L32 ? 32 : 16;
+  const int full = d / LW * LW;
   const bool vec_ok = p.x_aligned && p.cent_aligned && (d % 4 == 0);
   constexpr bool NEG = METRIC == METRIC_L2;
 
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
       }
     }
   };
-  auto compute = [&](int nchunks) {
-    for (int ch = 0; ch < nchunks; ++ch) {
+  auto compute = [&](int nchunks, int ch0 = 0, int chstep = 1) {
+    for (int ch = ch0; ch < nchunks; ch += chstep) {
       float xv[8];
       f2 cv[4];
 #pragma unroll
@@ -137,7 +145,8 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
     }
   };
   // lane-ordered sum of every pair's 16 partials: res[row][cent] (first ? = : +=) ((0 + a0) + a1) + ... + a15
-  auto reduce = [&](bool first) {
+  // `cont` (L32): the fold continues from the value already stored, ((v + a0) + a1) + ... + a15; `to2`: into res2
+  auto reduce = [&](bool first, bool cont = false, bool to2 = false) {
     float *red = ct;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -152,6 +161,9 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
       if (i < 8) {
         const float *src = mine + i * W_RLD;
         float tot = 0.0f;
+        if constexpr (L32) {
+          if (cont) tot = to2 ? res2[L32 ? wr * 8 + r : 0][L32 ? wc * 32 + g + 4 * i : 0] : res[wr * 8 + r][wc * 32 + g + 4 * i];
+        }
         if constexpr (METRIC == METRIC_COSINE) {
           const f4 a0 = *reinterpret_cast<const f4 *>(src), a1 = *reinterpret_cast<const f4 *>(src + 4);
           const f4 a2 = *reinterpret_cast<const f4 *>(src + 8), a3 = *reinterpret_cast<const f4 *>(src + 12);
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
             tot = tot + v.x; tot = tot + v.y; tot = tot + v.z; tot = tot + v.w;
           }
         }
-        float *dst = &res[wr * 8 + r][wc * 32 + g + 4 * i];
+        float *dst = (L32 && to2) ? &res2[L32 ? wr * 8 + r : 0][L32 ? wc * 32 + g + 4 * i : 0] : &res[wr * 8 + r][wc * 32 + g + 4 * i];
         *dst = first ? tot : *dst + tot;
       }
     }
@@ -187,6 +199,42 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
         qn[tid] = (METRIC == METRIC_COSINE && ok) ? fp.q_norm[c0 + tid] : 1.0f;
       }
     }
+    if constexpr (L32) {
+      const int rem = d - full;
+      if (rem > 0) {           // res2 = the d % 32 tail products summed in element order (two 16-wide pieces)
+        zero_acc();
+        __syncthreads();
+        stage(c0, full, min(rem, 16));
+        __syncthreads();
+        compute(1);
+        reduce(true, false, true);
+        if (rem > 16) {
+          zero_acc();
+          __syncthreads();
+          stage(c0, full + 16, rem - 16);
+          __syncthreads();
+          compute(1);
+          reduce(true, true, true);          // first = true: the store is `= tot`, and tot started from res2
+        }
+      }
+      for (int par = 0; par < 2; ++par) {   // accumulators 0..15 = even 16-chunks, 16..31 = odd 16-chunks
+        zero_acc();
+        for (int d0 = 0; d0 < full; d0 += W_DK) {
+          const int width = min(W_DK, full - d0);   // a multiple of 32: chunk parity inside the slice = parity in the row
+          __syncthreads();
+          stage(c0, d0, width);
+          __syncthreads();
+          compute(width / 16, par, 2);
+        }
+        if (full == 0) __syncthreads();
+        reduce(true, par == 1);              // res = fold(par ? res : 0, this pass's 16 lane sums)
+      }
+      __syncthreads();
+      if (rem > 0) {                         // `sum + sums.iter().sum()` (dot.rs:57)
+        for (int idx = tid; idx < W_ROWS * W_CENTS; idx += W_BS) res[idx >> 6][idx & 63] = res2[L32 ? idx >> 6 : 0][L32 ? idx & 63 : 0] + res[idx >> 6][idx & 63];
+      }
+      __syncthreads();
+    } else {
     if (full != d) {
       zero_acc();
       __syncthreads();
@@ -209,6 +257,7 @@ __global__ __launch_bounds__(W_BS) void pairwise_wide_kernel(PairwiseArgs p, int
     }
     reduce(first);             // res = s + tot  (l2.rs:90 `s + sums.sum()`; 0 + tot when there is no remainder)
     __syncthreads();
+    }
     const int ct_n = min(W_CENTS, p.k - c0);
     if constexpr (MODE == 1) {
       for (int idx = tid; idx < W_ROWS * W_CENTS; idx += W_BS) {
@@ -276,7 +325,10 @@ int launch_wide(lance_hip_ctx *ctx, PairwiseArgs &p, int d, int metric, int batc
     if (!p.part_vb || !p.part_v || !p.part_idx) return LANCE_HIP_ENOMEM;
   }
   const dim3 grid((unsigned)cdiv(p.n, W_ROWS), batches, ksplit);
-  if (metric == METRIC_DOT)
+  if (p.lanes32) {
+    LH_REQUIRE(metric == METRIC_DOT, "internal: the 32-lane order exists for dot products only");
+    hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_DOT, MODE, true>), grid, dim3(W_BS), 0, ctx->stream, p, d, FlatPool{});
+  } else if (metric == METRIC_DOT)
     hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_DOT, MODE>), grid, dim3(W_BS), 0, ctx->stream, p, d, FlatPool{});
   else
     hipLaunchKernelGGL((pairwise_wide_kernel<METRIC_L2, MODE>), grid, dim3(W_BS), 0, ctx->stream, p, d, FlatPool{});

@@ -124,11 +124,15 @@ class Engine:
 
     # ---- building blocks ---------------------------------------------------------
     def normalize(self, x):
-        x = to_device(x, torch.float32)
+        """normalize_fsl (kernels.rs:141-186): float32 rows in f32 arithmetic; float16 rows stay float16 and are normalised in
+        half-precision arithmetic, as do_normalize_fsl::<Float16Type> does"""
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+        f16 = t.dtype == torch.float16
+        x = t.to(_dev()).contiguous() if f16 else to_device(x, torch.float32)
         out = torch.empty_like(x)
         n, d = x.shape
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_normalize(self.h, _lib.F32, _ptr(x), n, d, _ptr(out)))
+        check(self.lib.lance_hip_normalize(self.h, _lib.F16 if f16 else _lib.F32, _ptr(x), n, d, _ptr(out)))
         return out
 
     def assign(self, x, centroids, metric="l2", bias=None):

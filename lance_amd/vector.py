@@ -450,8 +450,8 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
         if params.metric == "cosine":
             # IvfTransformer::new_flat (rust/lance-index/src/vector/ivf.rs:147-175): rows are normalised, assigned with L2 and
             # STORED normalised; the sub-index keeps the cosine distance function (ivf/v2.rs:405-411)
-            if x.dtype != torch.float32:
-                raise NotImplementedError("IVF_FLAT with the cosine metric needs float32 vectors in this version")
+            if x.dtype not in (torch.float32, torch.float16):
+                raise NotImplementedError("IVF_FLAT with the cosine metric needs float32 or float16 vectors (normalize_fsl accepts float arrays only)")
             xs = timed("normalize", lambda: eng.normalize(x))
             part, _ = timed("transform", lambda: eng.assign(xs, cent, "l2"))
         else:

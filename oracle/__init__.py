@@ -83,6 +83,10 @@ def lib():
         _lib.orc_norm_l2_f32.restype = C.c_float
         _lib.orc_cosine_f32.restype = C.c_float
         _lib.orc_cosine_f32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_size_t]
+        _lib.orc_dot32_f32.restype = C.c_float
+        _lib.orc_norm_l2_32_f32.restype = C.c_float
+        _lib.orc_cosine_scalar32_f32.restype = C.c_float
+        _lib.orc_cosine_scalar32_f32.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_size_t]
         _lib.orc_f16_to_f32.restype = C.c_float
         _lib.orc_f32_to_f16.restype = C.c_uint16
         _lib.orc_f32_to_f16.argtypes = [C.c_float]
@@ -108,6 +112,24 @@ def _f32(a):
 
 def _m(metric):
     return _METRICS[metric]
+
+
+DOT_H, COSINE_H = 3, 4      # lance_oracle.c ORC_DOT_H / ORC_COSINE_H: the metric on a Float16 column (half::f16's own arms)
+
+
+def _is_f16(*arrays):
+    return any(a is not None and np.asarray(a).dtype == np.float16 for a in arrays)
+
+
+def _mh(metric, f16):
+    """metric code; on a float16 column dot / cosine become the f16 variants (32-lane dot_scalar / norm_l2_impl, scalar
+    cosine, half-precision normalize)"""
+    m = metric if isinstance(metric, (int, np.integer)) else _m(metric)
+    if f16 and m == _METRICS["dot"]:
+        return DOT_H
+    if f16 and m == _METRICS["cosine"]:
+        return COSINE_H
+    return int(m)
 
 
 def set_threads(n):
@@ -138,27 +160,40 @@ def dot(x, y):
 
 
 def norm_l2(x):
+    h = _is_f16(x)
     x = _f32(x)
+    if h:       # norm_l2_impl::<f16, f32, 32>
+        return float(lib().orc_norm_l2_32_f32(_p(x), C.c_size_t(x.size)))
     return float(lib().orc_norm_l2_f32(_p(x), C.c_size_t(x.size)))
 
 
 def cosine(x, y):
+    h = _is_f16(x, y)
+    xn = norm_l2(x)
     x = _f32(x); y = _f32(y)
-    return float(lib().orc_cosine_f32(_p(x), C.c_float(norm_l2(x)), _p(y), C.c_size_t(x.size)))
+    if h:       # f16: the trait default cosine_scalar over the 32-lane dot
+        return float(lib().orc_cosine_scalar32_f32(_p(x), C.c_float(xn), _p(y), C.c_size_t(x.size)))
+    return float(lib().orc_cosine_f32(_p(x), C.c_float(xn), _p(y), C.c_size_t(x.size)))
 
 
 def distance_batch(metric, q, x):
+    h = _is_f16(x)
     q = _f32(q); x = _f32(x)
     n, d = x.shape
     out = np.empty(n, np.float32)
-    lib().orc_distance_batch_f32(_m(metric), _p(q), _p(x), C.c_size_t(n), C.c_size_t(d), _p(out))
+    lib().orc_distance_batch_f32(_mh(metric, h), _p(q), _p(x), C.c_size_t(n), C.c_size_t(d), _p(out))
     return out
 
 
 def normalize(x):
+    """float16 in -> float16 out, normalised in half-precision arithmetic (do_normalize_fsl::<Float16Type>)"""
+    h = _is_f16(x)
     x = _f32(x)
     x2 = x.reshape(-1, x.shape[-1])
     out = np.empty_like(x2)
+    if h:
+        lib().orc_normalize_h(_p(x2), C.c_size_t(x2.shape[0]), C.c_size_t(x2.shape[1]), _p(out))
+        return out.reshape(x.shape).astype(np.float16)
     lib().orc_normalize_f32(_p(x2), C.c_size_t(x2.shape[0]), C.c_size_t(x2.shape[1]), _p(out))
     return out.reshape(x.shape)
 
@@ -332,23 +367,26 @@ def sort_fetch(ids, dists, k):
 
 
 def find_partitions(q, centroids, nprobes, metric="l2"):
+    h = _is_f16(q, centroids)
+    metric = _mh(metric, h)
     q = _f32(q).reshape(-1, centroids.shape[1]); centroids = _f32(centroids)
     nq, d = q.shape
     nlist = centroids.shape[0]
     nprobes = min(nprobes, nlist)
     ids = np.empty((nq, nprobes), np.uint32); dists = np.empty((nq, nprobes), np.float32)
-    lib().orc_find_partitions_f32(_m(metric), _p(q), C.c_size_t(nq), C.c_size_t(d), _p(centroids), C.c_size_t(nlist),
+    lib().orc_find_partitions_f32(C.c_int(metric), _p(q), C.c_size_t(nq), C.c_size_t(d), _p(centroids), C.c_size_t(nlist),
                                   C.c_size_t(nprobes), _p(ids), _p(dists))
     return ids, dists
 
 
 def flat_knn(x, q, k, metric="l2", row_ids=None):
+    metric = _mh(metric, _is_f16(x))
     x = _f32(x); q = _f32(q).reshape(-1, x.shape[1])
     n, d = x.shape
     nq = q.shape[0]
     rid = None if row_ids is None else np.ascontiguousarray(row_ids, np.uint64)
     ids = np.empty((nq, k), np.uint64); dists = np.empty((nq, k), np.float32)
-    lib().orc_flat_knn_f32(_m(metric), _p(x), _p(rid), C.c_size_t(n), C.c_size_t(d), _p(q), C.c_size_t(nq),
+    lib().orc_flat_knn_f32(C.c_int(metric), _p(x), _p(rid), C.c_size_t(n), C.c_size_t(d), _p(q), C.c_size_t(nq),
                            C.c_size_t(k), _p(ids), _p(dists))
     return ids, dists
 
@@ -420,11 +458,11 @@ def build_index(x, centroids, codebook, metric="l2", row_ids=None, nbits=8):
     if row_ids is None:
         row_ids = np.arange(x.shape[0], dtype=np.uint64)
     row_ids = np.asarray(row_ids, np.uint64)
-    xs = normalize(x) if m == COSINE else x
+    xs = _f32(normalize(x.astype(np.float16) if f16 else x)) if m == COSINE else x     # f16 rows: half-precision normalize
     keep = is_finite(xs)
     xs = xs[keep]; rid = row_ids[keep]
     sm = L2 if m == COSINE else m
-    part, _ = assign(xs, centroids, sm)
+    part, _ = assign(xs.astype(np.float16) if f16 else xs, centroids, sm)    # f16 rows: l2_scalar 16 lanes / dot_scalar 32 lanes
     res = residual(xs.astype(np.float16) if f16 else xs, centroids, np.where(part == NONE, 0, part)) if sm == L2 else xs
     # the quantizer is always BUILT with DistanceType::L2 (lance/src/index/vector/builder.rs:456 `Q::build(&training_data,
     # DistanceType::L2, ..)`), and ProductQuantizer::transform encodes with the quantizer's own distance type
@@ -451,8 +489,13 @@ def ivfflat_search(x, centroids, queries, k, nprobes, metric="l2", row_ids=None)
     k, the earlier-scanned row wins a tie; distances = distance_type.func()(query, vector), flat/storage.rs:345-402),
     then SortExec([_distance, _rowid]).fetch(k) (scanner.rs:3440-3468).  Rows are stored per partition in ascending
     input order; rows without a partition (non-finite) are dropped."""
-    x = _f32(x); centroids = _f32(centroids)
-    q = _f32(queries).reshape(-1, x.shape[1])
+    h = _is_f16(x)
+    if h:       # Float16 column: rows, key and centroids are f16; distances are half::f16's (see ORC_DOT_H / ORC_COSINE_H)
+        x = np.ascontiguousarray(x, np.float16); centroids = np.ascontiguousarray(centroids, np.float16)
+        q = np.ascontiguousarray(queries, np.float16).reshape(-1, x.shape[1])
+    else:
+        x = _f32(x); centroids = _f32(centroids)
+        q = _f32(queries).reshape(-1, x.shape[1])
     nlist = centroids.shape[0]
     rid = np.arange(x.shape[0], dtype=np.uint64) if row_ids is None else np.asarray(row_ids, np.uint64)
     coarse = metric

@@ -52,6 +52,19 @@
 #define ORC_L2 0
 #define ORC_COSINE 1
 #define ORC_DOT 2
+/* The same metrics on a Float16 column (values carried in f32 containers).  half::f16 has its own arms of the distance traits
+ * (without the optional fp16kernels feature): Dot = dot_scalar::<f16, f32, 32> (dot.rs:91-102,138-161), Normalize =
+ * norm_l2_impl::<f16, f32, 32> (norm_l2.rs:60-85), Cosine = the trait default cosine_scalar (cosine.rs:36-45,171-179);
+ * normalize_fsl::<Float16Type> runs in half-precision arithmetic (kernels.rs:141-186).  L2 stays l2_scalar::<f16, f32, 16>. */
+#define ORC_DOT_H 3
+#define ORC_COSINE_H 4
+static inline int orc_is_dot(int m) { return m == ORC_DOT || m == ORC_DOT_H; }
+static inline int orc_is_cos(int m) { return m == ORC_COSINE || m == ORC_COSINE_H; }
+static inline int orc_metric_h(int metric, int f16) {
+  if (f16 && metric == ORC_DOT) return ORC_DOT_H;
+  if (f16 && metric == ORC_COSINE) return ORC_COSINE_H;
+  return metric;
+}
 #define ORC_NONE 0xFFFFFFFFu
 
 /* ------------------------------------------------------------------------- */
@@ -299,6 +312,64 @@ void orc_normalize_f32(const float *x, size_t n, size_t d, float *out) {
   }
 }
 
+/* dot_scalar::<f16, f32, 32> on widened values (dot.rs:30-58 with LANES = 32) */
+float orc_dot32_f32(const float *x, const float *y, size_t d) {
+  const size_t LANES = 32;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (size_t i = full; i < d; i++) acc = acc + x[i] * y[i];
+    s = acc;
+  }
+  float sums[32];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) sums[i] += x[c + i] * y[c + i];
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return s + tot;
+}
+
+/* norm_l2_impl::<f16, f32, 32>  norm_l2.rs:106-129 */
+float orc_norm_l2_32_f32(const float *x, size_t d) {
+  const size_t LANES = 32;
+  size_t full = d / LANES * LANES;
+  float s = 0.0f;
+  if (full != d) {
+    float acc = 0.0f;
+    for (size_t i = full; i < d; i++) acc = acc + x[i] * x[i];
+    s = acc;
+  }
+  float sums[32];
+  for (size_t i = 0; i < LANES; i++) sums[i] = 0.0f;
+  for (size_t c = 0; c < full; c += LANES)
+    for (size_t i = 0; i < LANES; i++) sums[i] += x[c + i] * x[c + i];
+  float tot = 0.0f;
+  for (size_t i = 0; i < LANES; i++) tot = tot + sums[i];
+  return sqrtf(s + tot);
+}
+
+/* cosine_scalar  cosine.rs:171-179: y_sq = dot(y, y); xy = dot(x, y); 1 - xy / (x_norm * sqrt(y_sq)) -- f16's cosine_fast */
+float orc_cosine_scalar32_f32(const float *x, float x_norm, const float *y, size_t d) {
+  float y_sq = orc_dot32_f32(y, y, d);
+  float xy = orc_dot32_f32(x, y, d);
+  return 1.0f - xy / (x_norm * sqrtf(y_sq));
+}
+
+/* normalize::<f16>  kernels.rs:141-146 in the `half` crate's arithmetic (2.7.1: every operator is the f32 operation rounded
+ * to binary16; Float::powi / sqrt likewise; `impl Sum for f16` adds the widened terms in f32 and rounds once). */
+void orc_normalize_h(const float *x, size_t n, size_t d, float *out) {
+#pragma omp parallel for schedule(static) if (n * d >= 65536)
+  for (size_t r = 0; r < n; r++) {
+    const float *v = x + r * d;
+    float acc = 0.0f;
+    for (size_t i = 0; i < d; i++) acc = acc + orc_rh(v[i] * v[i]);
+    float norm = orc_rh(sqrtf(orc_rh(acc)));
+    for (size_t i = 0; i < d; i++) out[r * d + i] = orc_rh(v[i] / norm);
+  }
+}
+
 /* utils.rs:263-286 is_finite: 1 if every element finite */
 void orc_is_finite_f32(const float *x, size_t n, size_t d, uint8_t *out) {
   for (size_t r = 0; r < n; r++) {
@@ -310,18 +381,20 @@ void orc_is_finite_f32(const float *x, size_t n, size_t d, uint8_t *out) {
 }
 
 static inline float orc_dist(int metric, const float *x, const float *y, size_t d) {
+  if (metric == ORC_DOT_H) return 1.0f - orc_dot32_f32(x, y, d);
   return metric == ORC_DOT ? orc_dot_distance_f32(x, y, d) : orc_l2_f32(x, y, d);
 }
 
 /* DistanceType::func / arrow_batch_func  distance.rs:56-75 for the flat scan */
 void orc_distance_batch_f32(int metric, const float *q, const float *x, size_t n, size_t d,
                             float *out) {
-  float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q, d) : 0.0f;
+  float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q, d) : (metric == ORC_COSINE_H ? orc_norm_l2_32_f32(q, d) : 0.0f);
   /* small batches (one partition of an IVF_FLAT test) stay on the calling thread: a fork/join per call costs more than the
    * loop, and on a CPU-quota'd container with many visible cores it costs milliseconds */
 #pragma omp parallel for schedule(static) if (n * d >= 65536)
   for (size_t r = 0; r < n; r++)
-    out[r] = metric == ORC_COSINE ? orc_cosine_f32(q, qn, x + r * d, d) : orc_dist(metric, q, x + r * d, d);
+    out[r] = metric == ORC_COSINE ? orc_cosine_f32(q, qn, x + r * d, d)
+           : metric == ORC_COSINE_H ? orc_cosine_scalar32_f32(q, qn, x + r * d, d) : orc_dist(metric, q, x + r * d, d);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -370,7 +443,7 @@ void orc_assign_f16(int metric, const uint16_t *x, size_t n, size_t d, const uin
   for (size_t r = 0; r < n; r++) {
     int found = 0; uint32_t mi = 0; float mv = INFINITY;
     for (size_t c = 0; c < k; c++) {
-      float value = metric == ORC_DOT ? 1.0f - orc_dot_f16(x + r * d, cent + c * d, d)
+      float value = orc_is_dot(metric) ? 1.0f - orc_dot_f16(x + r * d, cent + c * d, d)
                                       : orc_l2_f16(x + r * d, cent + c * d, d);
       if (value < mv) { mv = value; mi = (uint32_t)c; found = 1; }
     }
@@ -485,6 +558,7 @@ int orc_kmeans_train_x(int metric, const float *x, size_t n, size_t d, size_t k,
                        uint32_t max_iters, double tol, float balance_factor,
                        const float *init_centroids, uint64_t seed, float *centroids_out,
                        double *loss_out, uint64_t *sizes_out, int f16) {
+  metric = orc_metric_h(metric, f16);     /* Float16Type + dot: compute_partitions calls f16's 32-lane dot */
   float *cent = centroids_out;
   if (init_centroids) {
     memcpy(cent, init_centroids, k * d * sizeof(float));
@@ -816,7 +890,7 @@ void orc_pq_scan_f32(int metric, const float *lut, size_t m_count, const uint8_t
     const uint8_t *c = codes_t + m * n_p;
     for (size_t j = 0; j < n_p; j++) dists[j] += t[c[j]];
   }
-  if (metric == ORC_DOT) {
+  if (orc_is_dot(metric)) {
     float diff = (float)m_count - 1.0f;
     for (size_t j = 0; j < n_p; j++) dists[j] = dists[j] - diff;
   }
@@ -887,7 +961,7 @@ void orc_pq_scan4_f32(int metric, const float *lut, size_t m_count, const uint8_
     orc_pq4_flat(lut, n, code, m_count, offset, n - offset, dists);
   }
   free(qt);
-  if (metric == ORC_DOT) {
+  if (orc_is_dot(metric)) {
     float diff = (float)m_count - 1.0f;
     for (size_t j = 0; j < n; j++) dists[j] = dists[j] - diff;
   }
@@ -1046,9 +1120,10 @@ void orc_flat_knn_f32(int metric, const float *x, const uint64_t *row_ids, size_
     /* keep the k best in a small sorted array (k is small) */
     orc_pair *best = (orc_pair *)malloc((k + 1) * sizeof(orc_pair));
     size_t cnt = 0;
-    float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q + i * d, d) : 0.0f;
+    float qn = metric == ORC_COSINE ? orc_norm_l2_f32(q + i * d, d) : (metric == ORC_COSINE_H ? orc_norm_l2_32_f32(q + i * d, d) : 0.0f);
     for (size_t r = 0; r < n; r++) {
       float v = metric == ORC_COSINE ? orc_cosine_f32(q + i * d, qn, x + r * d, d)
+              : metric == ORC_COSINE_H ? orc_cosine_scalar32_f32(q + i * d, qn, x + r * d, d)
                                      : orc_dist(metric, q + i * d, x + r * d, d);
       orc_pair e; e.key = orc_key(v); e.dist = v; e.id = row_ids ? row_ids[r] : (uint64_t)r;
       if (cnt == k && orc_pair_cmp(&e, &best[k - 1]) >= 0) continue;
@@ -1123,7 +1198,7 @@ static float orc_pq_distance_one(int metric, const float *lut, size_t m_count, u
   } else {
     for (size_t m = 0; m < m_count; m++) s += lut[m * 256 + codes_t[m * n_p + j]];
   }
-  if (metric == ORC_DOT) s = s - ((float)m_count - 1.0f);
+  if (orc_is_dot(metric)) s = s - ((float)m_count - 1.0f);
   return s;
 }
 
@@ -1135,7 +1210,8 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
                          int has_range, float lower, float upper) {
   const size_t mbytes = nbits == 4 ? m_count / 2 : m_count;
   if (nprobes > nlist) nprobes = nlist;
-  int scan_metric = (metric == ORC_COSINE) ? ORC_L2 : metric;
+  metric = orc_metric_h(metric, f16);     /* Float16 column: half::f16's dot / cosine / normalize */
+  int scan_metric = orc_is_cos(metric) ? ORC_L2 : metric;
   size_t keff = k * (refine ? refine : 1);
   size_t max_np = 0;
   for (size_t p = 0; p < nlist; p++) {
@@ -1154,6 +1230,7 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
     float *cand_d = (float *)malloc((nprobes * keff + 1) * sizeof(float));
     size_t ncand = 0;
     if (metric == ORC_COSINE) orc_normalize_f32(queries + i * d, 1, d, q);
+    else if (metric == ORC_COSINE_H) orc_normalize_h(queries + i * d, 1, d, q);
     else memcpy(q, queries + i * d, d * sizeof(float));
     /* single-query find_partitions (serial inside the parallel region) */
     {
@@ -1198,11 +1275,12 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
       /* flat_knn on the taken rows with the index's metric and the ORIGINAL query
        * (scanner.rs:2884-2904): KNNVectorDistanceExec + SortExec(dist,rowid).fetch(k) */
       const float *qo = queries + i * d;
-      float qn = metric == ORC_COSINE ? orc_norm_l2_f32(qo, d) : 0.0f;
+      float qn = metric == ORC_COSINE ? orc_norm_l2_f32(qo, d) : (metric == ORC_COSINE_H ? orc_norm_l2_32_f32(qo, d) : 0.0f);
       size_t kept = 0;
       for (size_t c = 0; c < got; c++) {
         const float *rv = raw + cand_ids[c] * d;
-        const float ex = metric == ORC_COSINE ? orc_cosine_f32(qo, qn, rv, d) : orc_dist(metric, qo, rv, d);
+        const float ex = metric == ORC_COSINE ? orc_cosine_f32(qo, qn, rv, d)
+                       : metric == ORC_COSINE_H ? orc_cosine_scalar32_f32(qo, qn, rv, d) : orc_dist(metric, qo, rv, d);
         /* a distance range is applied to the exact distances too: LanceFilterExec(dist >= lower AND dist < upper)
          * between KNNVectorDistanceExec and the final SortExec (scanner.rs:3334-3377) */
         if (has_range && !(ex >= lower && ex < upper)) continue;

@@ -36,7 +36,8 @@ class OracleEngine:
     """Engine: CPU tensors in, CPU tensors out, same return conventions (int32 ids with -1 = none, float32 distances)."""
 
     def normalize(self, x):
-        return torch.from_numpy(oracle.normalize(_np(x).astype(f32)))
+        xn = _np(x)
+        return torch.from_numpy(oracle.normalize(xn if xn.dtype == np.float16 else xn.astype(f32)))     # float16 stays float16
 
     def assign(self, x, cent, metric="l2", bias=None):
         ids, d = oracle.assign(np.ascontiguousarray(_np(x)), _np(cent), metric, bias=None if bias is None else _np(bias))
@@ -69,23 +70,29 @@ class OracleEngine:
         xn = np.ascontiguousarray(_np(x))
         cbn = _np(cb)
         oi = oracle.build_index(xn, _np(cent), cbn, metric, nbits=4 if cbn.shape[1] == 16 else 8)
-        xs = oracle.normalize(xn.astype(f32)) if metric == "cosine" else xn.astype(f32)
+        h = xn.dtype == np.float16        # a Float16 column keeps its own normalize / dot (oracle: ORC_COSINE_H / ORC_DOT_H)
+        xs = oracle.normalize(xn if h else xn.astype(f32)) if metric == "cosine" else xn
+        xs = xs if h else xs.astype(f32)
         keep = oracle.is_finite(xs)
         part = np.full(xn.shape[0], oracle.NONE, np.uint32)
         part[keep] = oi.part_ids
         codes = np.zeros((xn.shape[0], oi.codes_rowmajor.shape[1]), np.uint8)
         codes[keep] = oi.codes_rowmajor
-        _, dist = oracle.assign(xs[keep], _np(cent).astype(f32), "l2" if metric == "cosine" else metric)
+        _, dist = oracle.assign(xs[keep], _np(cent) if h else _np(cent).astype(f32), "l2" if metric == "cosine" else metric)
         ok = oi.part_ids != oracle.NONE
         return torch.from_numpy(part.view(np.int32).copy()), torch.from_numpy(codes), float(dist[ok].astype(np.float64).sum())
 
     def find_partitions(self, q, cent, nprobes, metric="l2"):
-        p, d = oracle.find_partitions(_np(q).astype(f32), _np(cent).astype(f32), nprobes, metric)
+        qn, cn = _np(q), _np(cent)
+        if not (qn.dtype == np.float16 and cn.dtype == np.float16):
+            qn, cn = qn.astype(f32), cn.astype(f32)
+        p, d = oracle.find_partitions(qn, cn, nprobes, metric)
         return torch.from_numpy(p.view(np.int32).copy()), torch.from_numpy(d)
 
     def flat_topk(self, x, q, k, metric="l2", row_ids=None):
         rid = None if row_ids is None else np.ascontiguousarray(_np(row_ids)).view(np.uint64)
-        i, d = oracle.flat_knn(np.ascontiguousarray(_np(x)).astype(f32), _np(q).astype(f32), k, metric, row_ids=rid)
+        xn = np.ascontiguousarray(_np(x))
+        i, d = oracle.flat_knn(xn if xn.dtype == np.float16 else xn.astype(f32), _np(q).astype(f32), k, metric, row_ids=rid)
         return torch.from_numpy(i.view(np.int64)), torch.from_numpy(d)
 
 
@@ -229,16 +236,17 @@ class OracleDeviceFlatIndex:
             sub = OracleDeviceFlatIndex(self.engine, self.metric, self.centroids, self.x[keep], self.part[keep], self.rid[keep], self.data_dtype)
             return sub.search(q, k, nprobes)
         # the stored partition of every row is authoritative (it may come from a file or carry a prefilter's holes)
-        cent = _np(self.centroids).astype(f32)
+        et = np.float16 if self.data_dtype == torch.float16 else f32      # a Float16 column: key, centroids and rows are f16
+        cent = _np(self.centroids).astype(et)
         nlist = cent.shape[0]
         offs, perm = oracle.partition_layout(self.part, nlist)
-        qq = _np(q).astype(f32).reshape(-1, cent.shape[1])
+        qq = _np(q).astype(et).reshape(-1, cent.shape[1])
         if self.metric == "cosine":     # stored rows are normalised already; the query key is normalised here (knn.rs:498)
             qq = oracle.normalize(qq)
         probes, _ = oracle.find_partitions(qq, cent, nprobes, "l2" if self.metric == "cosine" else self.metric)
         out_i = np.full((qq.shape[0], k), np.iinfo(np.uint64).max, np.uint64)
         out_d = np.full((qq.shape[0], k), np.inf, f32)
-        xf = self.x.astype(f32)
+        xf = self.x.astype(et)
         for qi in range(qq.shape[0]):
             ci, cd = [], []
             for p in probes[qi]:

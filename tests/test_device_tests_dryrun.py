@@ -108,3 +108,29 @@ def test_dryrun_4bit(fake, oracle, metric):
         G.test_4bit_pq_bit_exact(fake, oracle, metric)
     except AttributeError as e:
         assert "pq_scan_topk" in str(e)
+
+
+# ---- Float16 columns under dot / cosine (tests/test_zz_gpu_f16_metrics.py): the host layer and the tests' own expectations
+@pytest.mark.parametrize("d", [32, 56, 20])
+def test_dryrun_f16_dot_assign(fake, oracle, d):
+    import test_zz_gpu_f16_metrics as Z
+    Z.test_f16_dot_assign_and_find_partitions(fake, oracle, d)
+
+
+def test_dryrun_f16_normalize_and_kmeans(fake, oracle):
+    import test_zz_gpu_f16_metrics as Z
+    Z.test_f16_normalize_half_precision(fake, oracle)
+    Z.test_f16_dot_kmeans_training(fake, oracle)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cosine"])
+def test_dryrun_f16_index(fake, oracle, metric):
+    import test_zz_gpu_f16_metrics as Z
+    Z.test_f16_index_build_search_refine(fake, oracle, metric)
+    Z.test_f16_python_api(fake, oracle, metric)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cosine"])
+def test_dryrun_f16_flat_and_ivfflat(fake, oracle, metric):
+    import test_zz_gpu_f16_metrics as Z
+    Z.test_f16_flat_and_ivfflat(fake, oracle, metric, 40)

@@ -643,6 +643,13 @@ def test_f16_kernels_against_reference_c(oracle):
         assert np.float32(ref.dot_f16_avx2(px, py, C.c_uint32(d))).view(np.uint32) == np.float32(oracle.dot(xi, yi)).view(np.uint32)
         n2 = np.float32(ref.norm_l2_f16_avx2(px, C.c_uint32(d)))
         assert n2 == np.sqrt(np.float32((xi.astype(f32) ** 2).sum(dtype=np.float64)))
+        # the oracle's f16 arms (norm_l2_impl::<f16, f32, 32>, cosine_scalar over the 32-lane dot): exact sums -> same bits
+        assert n2.view(np.uint32) == np.float32(oracle.norm_l2(xi)).view(np.uint32)
+        if (xi != 0).any() and (yi != 0).any():
+            cref = np.float32(ref.cosine_f16_avx2(px, C.c_float(float(n2)), py, C.c_uint32(d)))
+            # f16.c divides xy / (x_norm * sqrt(y_sq)) like cosine_scalar, but -ffast-math may turn the division into a
+            # reciprocal multiply: allow one ulp
+            assert abs(int(cref.view(np.uint32)) - int(np.float32(oracle.cosine(xi, yi)).view(np.uint32))) <= 1
         xr = (rng.standard_normal(d) * 2).astype(np.float16)
         yr = (rng.standard_normal(d) * 2).astype(np.float16)
         px, py = xr.ctypes.data_as(C.c_void_p), yr.ctypes.data_as(C.c_void_p)
@@ -651,6 +658,83 @@ def test_f16_kernels_against_reference_c(oracle):
         xn = ref.norm_l2_f16_avx2(px, C.c_uint32(d))
         want = 1.0 - float(xr.astype(np.float64) @ yr.astype(np.float64)) / (np.linalg.norm(xr.astype(np.float64)) * np.linalg.norm(yr.astype(np.float64)))
         assert abs(ref.cosine_f16_avx2(px, C.c_float(xn), py, C.c_uint32(d)) - want) < 1e-4
+        assert abs(oracle.cosine(xr, yr) - want) < 1e-4 and abs(oracle.norm_l2(xr) - xn) <= 1e-5 * xn
+
+
+def test_f16_column_dot_cosine_normalize_arms(oracle):
+    """A Float16 column takes half::f16's own arms of the distance traits (no fp16kernels feature): Dot = dot_scalar::<f16,
+    f32, 32> (dot.rs:91-102), Normalize = norm_l2_impl::<f16, f32, 32> (norm_l2.rs:60-85), Cosine = the trait default
+    cosine_scalar (cosine.rs:36-45,171-179); normalize_fsl::<Float16Type> runs in half-precision arithmetic
+    (kernels.rs:141-186; half 2.7.1: every operator is the f32 operation rounded to binary16, `Sum for f16` adds the widened
+    terms in f32 and rounds once).  Checked against straight numpy restatements of those definitions."""
+    rng = np.random.default_rng(5)
+
+    def dot32(x, y):
+        x = x.astype(f32); y = y.astype(f32)
+        d = x.size; full = d // 32 * 32
+        s = f32(0)
+        for i in range(full, d):
+            s = f32(s + f32(x[i] * y[i]))
+        sums = np.zeros(32, f32)
+        for c in range(0, full, 32):
+            sums = (sums + x[c:c + 32] * y[c:c + 32]).astype(f32)
+        tot = f32(0)
+        for i in range(32):
+            tot = f32(tot + sums[i])
+        return f32(s + tot)
+
+    for d in (3, 16, 17, 31, 32, 33, 48, 64, 100, 128, 1536):
+        x = rng.standard_normal(d).astype(np.float16); y = rng.standard_normal(d).astype(np.float16)
+        assert f32(oracle.dot(x, y)).view(np.uint32) == dot32(x, y).view(np.uint32)
+        xn = f32(np.sqrt(dot32(x, x)))
+        assert f32(oracle.norm_l2(x)).view(np.uint32) == xn.view(np.uint32)
+        want = f32(f32(1) - f32(dot32(x, y) / f32(xn * f32(np.sqrt(dot32(y, y))))))
+        assert f32(oracle.cosine(x, y)).view(np.uint32) == want.view(np.uint32)
+        # up to 16 elements the 32-lane and the 16-lane forms are the same sequence of additions (the table kernels rely on it)
+        if d <= 16:
+            assert f32(oracle.dot(x, y)).view(np.uint32) == f32(oracle.dot(x.astype(f32), y.astype(f32))).view(np.uint32)
+        # distance_batch / flat_knn / find_partitions route float16 inputs to the same arms
+        rows = rng.standard_normal((5, d)).astype(np.float16)
+        db = oracle.distance_batch("dot", x, rows)
+        assert all(db[i].view(np.uint32) == f32(f32(1) - dot32(x, rows[i])).view(np.uint32) for i in range(5))
+        dc = oracle.distance_batch("cosine", x, rows)
+        assert all(dc[i].view(np.uint32) == f32(oracle.cosine(x, rows[i])).view(np.uint32) for i in range(5))
+        fi, fd = oracle.flat_knn(rows, x, 3, "dot")
+        order = np.lexsort((np.arange(5), db.view(np.uint32) ^ np.where(db.view(np.int32) < 0, 0xFFFFFFFF, 0x80000000).astype(np.uint32)))
+        assert (fi[0] == order[:3]).all() and (fd[0].view(np.uint32) == db[order[:3]].view(np.uint32)).all()
+        pi, pdist = oracle.find_partitions(x, rows, 2, "dot")
+        assert (pi[0] == order[:2]).all() and (pdist[0].view(np.uint32) == db[order[:2]].view(np.uint32)).all()
+    # normalize: half-precision arithmetic
+    h = np.float16
+    x = (rng.standard_normal((6, 40)) * 3).astype(h)
+    got = oracle.normalize(x)
+    assert got.dtype == np.float16
+    for r in range(6):
+        acc = f32(0)
+        for v in x[r]:
+            acc = f32(acc + f32(h(f32(v) * f32(v))))           # powi(2) rounds to f16; Sum adds the widened terms in f32
+        norm = h(np.sqrt(f32(h(acc))))                          # ... and rounds once; sqrt rounds to f16
+        want = (x[r].astype(f32) / f32(norm)).astype(h)        # f16 / f16: f32 division rounded to f16
+        assert (got[r].view(np.uint16) == want.view(np.uint16)).all()
+    # an f16 index: build + search agree between the f16-typed call and explicit f32 containers handed to the f16 paths
+    xs = (rng.standard_normal((600, 32)) * 2).astype(h); q = (rng.standard_normal((9, 32)) * 2).astype(h)
+    for metric in ("dot", "cosine"):
+        tr = oracle.normalize(xs[:256]) if metric == "cosine" else xs[:256]
+        cent, _, _, _ = oracle.kmeans_train(tr, 4, max_iters=5, seed=3, metric="l2" if metric == "cosine" else metric)
+        part, _ = oracle.assign(tr, cent, "l2" if metric == "cosine" else metric)
+        res = oracle.residual(tr, cent, part) if metric == "cosine" else tr
+        cb, _ = oracle.pq_train(res, 4, max_iters=4, seed=1)
+        idx = oracle.build_index(xs, cent, cb, metric)
+        assert idx.f16
+        ids, dd = idx.search(q, 5, 4, refine=3, raw=xs)
+        # refine distances are the f16 column's own distance function on the original key
+        for i in range(9):
+            for j in range(5):
+                if ids[i, j] == np.iinfo(np.uint64).max:
+                    continue
+                row = xs[int(ids[i, j])]
+                want = f32(1) - f32(oracle.dot(q[i], row)) if metric == "dot" else f32(oracle.cosine(q[i], row))
+                assert dd[i, j].view(np.uint32) == f32(want).view(np.uint32)
 
 
 def test_distance_range_search_semantics(oracle):
