@@ -85,6 +85,14 @@ def main():
                 grid.append({"nprobes": nprobes, "refine_factor": rf, "recall_at_10": recall_of(ids, gt), "nq": nq,
                              "ms_per_batch": dt * 1e3, "qps": nq / dt, "exact_replays": eng.search_stats()})
         out["c2_grid"] = grid
+        # small batches (the reference publishes single-query latencies: benchmarks/sift/lance_sift1m_stats.csv) -- wall time of one
+        # call through the Python binding, results on the device
+        lat = []
+        for nq in (1, 16, 256, 2048):
+            qq = q[:nq].contiguous()
+            dt = timed(lambda: idx.search_device(qq, 10, 10, 10), reps=20 if nq <= 256 else 5)
+            lat.append({"nq": nq, "nprobes": 10, "refine_factor": 10, "ms_per_call": dt * 1e3, "qps": nq / dt})
+        out["c2_small_batches"] = lat
 
         # (the bit-exact id check at nprobes = nlist against the CPU oracle lives in tests/test_gpu_parity.py::
         #  test_full_size_properties_sift1m -- only tests, smoke() and bench.py's cpu_baseline may touch oracle/)
