@@ -17,6 +17,8 @@
 
 #include "common.h"
 #include "exact.cuh"
+#include <cstdlib>
+
 #include "index.h"
 #include "kernels.h"
 
@@ -50,10 +52,67 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict_
   }
 }
 
+// The same arithmetic for long rows (C3: d = 1536), coalesced: a workgroup takes 64 rows and walks them in 64-column tiles staged
+// through LDS (each row segment is one 256-byte read); lane r of the first wave adds row r's squares in element order -- the
+// reference's sequential sum, untouched -- and in a second sweep every lane rescales the tile it loads.  With one lane per row
+// reading its own row (normalize_kernel) every load instruction touches 64 cache lines: 44 ms per 1M x 1536 against the
+// 18 GB / 4 TB/s = 4.5 ms this layout moves.
+template <bool F16>
+__global__ __launch_bounds__(256) void normalize_tiled_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
+  __shared__ float tile[64][65];
+  __shared__ float norms[64];
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int tid = threadIdx.x, col = tid & 63, rsub = tid >> 6;
+  float acc = 0.0f;
+  for (int c0 = 0; c0 < d; c0 += 64) {
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int r = rsub + 4 * j;
+      float v = 0.0f;
+      if (row0 + r < n && c0 + col < d) v = x[(row0 + r) * d + c0 + col];
+      tile[r][col] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int w = min(64, d - c0);
+      for (int i = 0; i < w; ++i) {
+        float p = tile[tid][i] * tile[tid][i];
+        if (F16) p = __half2float(__float2half_rn(p));
+        acc = acc + p;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {
+    if (F16) acc = __half2float(__float2half_rn(acc));
+    float norm = sqrtf(acc);
+    if (F16) norm = __half2float(__float2half_rn(norm));
+    norms[tid] = norm;
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < d; c0 += 64) {
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int r = rsub + 4 * j;
+      if (row0 + r < n && c0 + col < d) {
+        float qv = x[(row0 + r) * d + c0 + col] / norms[r];
+        if (F16) qv = __half2float(__float2half_rn(qv));
+        out[(row0 + r) * d + c0 + col] = qv;
+      }
+    }
+  }
+}
+
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16) {
   if (n <= 0) return LANCE_HIP_OK;
-  if (f16) hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
-  else hipLaunchKernelGGL(normalize_kernel<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
+  static const bool no_tiled = getenv("LANCE_HIP_NO_TILED_NORMALIZE") != nullptr;
+  if (d >= 64 && !no_tiled) {
+    if (f16) hipLaunchKernelGGL(normalize_tiled_kernel<true>, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, ctx->stream, x, n, d, out);
+    else hipLaunchKernelGGL(normalize_tiled_kernel<false>, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, ctx->stream, x, n, d, out);
+  } else {
+    if (f16) hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
+    else hipLaunchKernelGGL(normalize_kernel<false>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, ctx->stream, x, n, d, out);
+  }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

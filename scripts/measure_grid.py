@@ -121,8 +121,15 @@ def main():
         idx = lance_amd.create_index(x, "IVF_PQ", metric="cosine", num_partitions=nlist, num_sub_vectors=m)
         torch.cuda.synchronize()
         c3 = {"n": n, "d": d, "nlist": nlist, "m": m, "build_sec_cold": time.perf_counter() - t0,
-              "stages_ms": {k: round(v * 1e3, 3) for k, v in idx.stats.seconds.items()},
+              "stages_ms_cold": {k: round(v * 1e3, 3) for k, v in idx.stats.seconds.items()},
               "ivf_iters": idx.stats.ivf_iters, "pq_iters": idx.stats.pq_iters}
+        del idx          # the first build pays for the scratch arenas (3 x 7.7 GB of hipMalloc at this shape); time a second one
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx = lance_amd.create_index(x, "IVF_PQ", metric="cosine", num_partitions=nlist, num_sub_vectors=m)
+        torch.cuda.synchronize()
+        c3["build_sec"] = time.perf_counter() - t0
+        c3["stages_ms"] = {k: round(v * 1e3, 3) for k, v in idx.stats.seconds.items()}
         dt = timed(lambda: eng.flat_topk(x, q, 10, metric="cosine"), reps=1)
         c3["flat_1000q_ms"] = dt * 1e3
         gt, _ = eng.flat_topk(x, q, 10, metric="cosine")

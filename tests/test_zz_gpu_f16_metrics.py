@@ -57,10 +57,13 @@ def test_f16_dot_assign_and_find_partitions(eng, oracle, d):
 
 
 def test_f16_normalize_half_precision(eng, oracle):
-    x = (f16_data(3000, 40, 3) * 3).astype(np.float16)
-    got = eng.normalize(x)
-    assert got.dtype == __import__("torch").float16
-    assert (_np(got).view(np.uint16) == oracle.normalize(x).view(np.uint16)).all()
+    for n, d in ((3000, 40), (1000, 96), (130, 200)):        # lane-per-row kernel (d < 64) and the tiled one (ragged last tile too)
+        x = (f16_data(n, d, 3 + d) * 3).astype(np.float16)
+        got = eng.normalize(x)
+        assert got.dtype == __import__("torch").float16
+        assert (_np(got).view(np.uint16) == oracle.normalize(x).view(np.uint16)).all(), (n, d)
+    xf = (f16_data(777, 1536, 9) * 3).astype(f32)              # f32 rows, C3 dimension, rows not a multiple of 64
+    assert (_np(eng.normalize(xf)).view(np.uint32) == oracle.normalize(xf).view(np.uint32)).all()
 
 
 def test_f16_dot_kmeans_training(eng, oracle):
