@@ -42,19 +42,20 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-neare
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
 
 // ---- centroid preparation: hi / lo bf16 planes, squared norms, maxima for the error bound ------------------------
-__global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ cent, int k, int d, const float *__restrict__ bias,
+// dp = row stride of the planes (d, or d rounded up to the K-chunk of the wide kernel: the padding is zero-filled)
+__global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ cent, int k, int d, int dp, const float *__restrict__ bias,
                                                      uint16_t *__restrict__ chi, uint16_t *__restrict__ clo, float *__restrict__ cn,
                                                      uint32_t *__restrict__ maxbits /* [0] = max |c|^2, [1] = max |bias| (float bits) */,
                                                      const uint8_t *__restrict__ active) {
   if (active && !active[0]) return;
   const int c = blockIdx.x;
   float s = 0.0f;
-  for (int e = threadIdx.x; e < d; e += 64) {
-    const float v = cent[(int64_t)c * d + e];
+  for (int e = threadIdx.x; e < dp; e += 64) {
+    const float v = e < d ? cent[(int64_t)c * d + e] : 0.0f;
     const uint32_t hb = bf16_rne_bits(v);
     const float lo = v - bf16_bits_to_float(hb);
-    chi[(int64_t)c * d + e] = (uint16_t)hb;
-    clo[(int64_t)c * d + e] = (uint16_t)bf16_rne_bits(lo);
+    chi[(int64_t)c * dp + e] = (uint16_t)hb;
+    clo[(int64_t)c * dp + e] = (uint16_t)bf16_rne_bits(lo);
     s += v * v;
   }
 #pragma unroll
@@ -82,6 +83,10 @@ struct MaArgs {
   int check_finite;
   uint32_t *fb_cnt, *fb_rows;  // rows left to ma_recompute_kernel
   const uint8_t *active;       // k-means: the (single) problem has converged -> every kernel returns at once
+  // wide rows (d > 128, ma_top3_wide_kernel): the rows pre-split into bf16 planes of stride dp, and their squared norms
+  const uint16_t *xhi = nullptr, *xlo = nullptr;
+  const float *xn2 = nullptr;
+  int dp = 0;
 };
 
 // running four smallest (values m1 <= m2 <= m3 <= m4, centroid ids of the first three)
@@ -389,9 +394,231 @@ static bool ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dt
   return true;
 }
 
+// =====================================================================================================================
+// Wide rows (d > 128: C3's 1536-dimensional embeddings).  The kernel above keeps a row's bf16 fragments in registers for the
+// whole centroid sweep, which stops at d = 128.  Here the contraction is tiled over the dimension: the rows are split once
+// into bf16 hi / lo planes (ma_split_rows_kernel; stride dp = d rounded up to 32, zero padded), a workgroup owns 128 rows
+// and walks the centroids in super-tiles of 128 (four 32 x 32 accumulator blocks per wave = 64 VGPRs); per 32-dimension
+// chunk both operands go global -> LDS (16-byte skewed rows: conflict-free ds_read_b128) -> the same fragment layout as
+// above, 3 MFMAs per (fragment pair) for the two-term split.  The surrogate, the running top-4, the classification and the
+// exact re-check (reference arithmetic, ma_finalize_wide_kernel / ma_recompute_kernel) are unchanged, so ids and distances
+// stay bit-equal to the exact kernels.  E = 2^-12 (|x|^2 + max|c|^2 + max|bias|): the split error is as above, the f32
+// accumulation over up to 4096 / 16 x 3 MFMA steps adds < 2^-15 |x||c|.
+constexpr int MW_ROWS = 128, MW_CT = 128, MW_KC = 32, MW_LS = MW_KC + 8;   // LDS row stride in bf16 elements (80 bytes)
+
+template <typename TX>
+__global__ __launch_bounds__(256) void ma_split_rows_kernel(const TX *__restrict__ x, int64_t n, int64_t ldx, int d, int dp,
+                                                            uint16_t *__restrict__ xhi, uint16_t *__restrict__ xlo, float *__restrict__ xn2,
+                                                            const uint8_t *__restrict__ active) {
+  if (active && !active[0]) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float s = 0.0f;
+  for (int e = 2 * lane; e < dp; e += 128) {     // two elements per lane: one 4-byte store per plane
+    const float v0 = e < d ? ld_elem(x + row * ldx, e) : 0.0f;
+    const float v1 = e + 1 < d ? ld_elem(x + row * ldx, e + 1) : 0.0f;
+    const uint32_t h0 = bf16_rne_bits(v0), h1 = bf16_rne_bits(v1);
+    const uint32_t l0 = bf16_rne_bits(v0 - bf16_bits_to_float(h0)), l1 = bf16_rne_bits(v1 - bf16_bits_to_float(h1));
+    *reinterpret_cast<uint32_t *>(xhi + row * dp + e) = (h0 & 0xFFFFu) | (h1 << 16);
+    *reinterpret_cast<uint32_t *>(xlo + row * dp + e) = (l0 & 0xFFFFu) | (l1 << 16);
+    s += v0 * v0 + v1 * v1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) xn2[row] = s;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
+  __shared__ __attribute__((aligned(16))) uint16_t abuf[2][MW_CT][MW_LS];     // centroid chunk: hi / lo planes   20 KB
+  __shared__ __attribute__((aligned(16))) uint16_t bbuf[2][MW_ROWS][MW_LS];   // row chunk: hi / lo planes        20 KB
+  __shared__ __attribute__((aligned(16))) float cns[2][MW_CT];                // |c|^2, bias of the super-tile
+  if (p.active && !p.active[0]) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * MW_ROWS;
+  const int dp = p.dp;
+  Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
+  // chunk loads: 128 rows x 32 elements = 512 16-byte pieces per plane; thread -> (row = idx >> 2, piece = idx & 3), 2 per plane
+  const int lr0 = threadIdx.x >> 2, lc = threadIdx.x & 3;
+  for (int c0 = 0; c0 < p.k; c0 += MW_CT) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[b][v] = 0.0f;
+    for (int k0 = 0; k0 < dp; k0 += MW_KC) {
+      uint4 ga[2][2], gb[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = lr0 + 64 * u;
+        ga[0][u] = ga[1][u] = gb[0][u] = gb[1][u] = make_uint4(0, 0, 0, 0);
+        if (c0 + r < p.k) {
+          ga[0][u] = *reinterpret_cast<const uint4 *>(p.chi + (int64_t)(c0 + r) * dp + k0 + lc * 8);
+          ga[1][u] = *reinterpret_cast<const uint4 *>(p.clo + (int64_t)(c0 + r) * dp + k0 + lc * 8);
+        }
+        if (row0 + r < p.n) {
+          gb[0][u] = *reinterpret_cast<const uint4 *>(p.xhi + (row0 + r) * dp + k0 + lc * 8);
+          gb[1][u] = *reinterpret_cast<const uint4 *>(p.xlo + (row0 + r) * dp + k0 + lc * 8);
+        }
+      }
+      __syncthreads();          // the previous chunk's fragments have been read
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = lr0 + 64 * u;
+        *reinterpret_cast<uint4 *>(&abuf[0][r][lc * 8]) = ga[0][u];
+        *reinterpret_cast<uint4 *>(&abuf[1][r][lc * 8]) = ga[1][u];
+        *reinterpret_cast<uint4 *>(&bbuf[0][r][lc * 8]) = gb[0][u];
+        *reinterpret_cast<uint4 *>(&bbuf[1][r][lc * 8]) = gb[1][u];
+      }
+      if (k0 == 0 && threadIdx.x < MW_CT) {
+        const int c = c0 + threadIdx.x;
+        cns[0][threadIdx.x] = c < p.k ? p.cn[c] : 0.0f;
+        cns[1][threadIdx.x] = (c < p.k && p.bias) ? p.bias[c] : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < MW_KC / 16; ++s) {
+        const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(&bbuf[0][wave * 32 + j][s * 16 + g * 8]);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(&bbuf[1][wave * 32 + j][s * 16 + g * 8]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&abuf[0][b * 32 + j][s * 16 + g * 8]);
+          const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&abuf[1][b * 32 + j][s * 16 + g * 8]);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[b], 0, 0, 0);
+        }
+      }
+    }
+    // D[centroid i][row j]: lane (j, g) holds centroids i = (v & 3) + 8 (v >> 2) + 4 g of each 32-block (as in ma_top3_kernel)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float sv[16];
+      float bm = INFINITY;
+#pragma unroll
+      for (int vq = 0; vq < 4; ++vq) {
+        const int ib = b * 32 + 8 * vq + 4 * g;
+        const f4 cn4 = *reinterpret_cast<const f4 *>(&cns[0][ib]), bi4 = *reinterpret_cast<const f4 *>(&cns[1][ib]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dot = acc[b][vq * 4 + e];
+          float v = METRIC == METRIC_DOT ? -dot : __builtin_fmaf(-2.0f, dot, cn4[e]);
+          v += bi4[e];
+          if (c0 + ib + e >= p.k) v = INFINITY;
+          sv[vq * 4 + e] = v;
+          bm = fminf(bm, v);
+        }
+      }
+      if (bm < tp.m4) {
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) top4_insert(tp, sv[vq * 4 + e], (uint32_t)(c0 + b * 32 + 8 * vq + 4 * g + e));
+      }
+    }
+    // (the next super-tile's first __syncthreads orders these cns reads before its cns writes)
+  }
+  {
+    const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
+    const uint32_t pi1 = __shfl_xor(tp.i1, 32, 64), pi2 = __shfl_xor(tp.i2, 32, 64), pi3 = __shfl_xor(tp.i3, 32, 64);
+    top4_insert(tp, pm1, pi1);
+    top4_insert(tp, pm2, pi2);
+    top4_insert(tp, pm3, pi3);
+    top4_insert(tp, pm4, LANCE_HIP_NONE);
+  }
+  const int64_t row = row0 + wave * 32 + j;
+  if (g == 0 && row < p.n) {
+    const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
+    const float E2 = 2.0f * 0.000244140625f * (p.xn2[row] + cmax2 + bmax);   // 2E, E = 2^-12 (|x|^2 + max|c|^2 + max|bias|)
+    uint8_t cl = 3;
+    if (tp.m2 - tp.m1 > E2) cl = 0;
+    else if (tp.m3 - tp.m1 > E2) cl = 1;
+    else if (tp.m4 - tp.m1 > E2) cl = 2;
+    if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY)) cl = 3;
+    p.id1[row] = tp.i1; p.id2[row] = tp.i2; p.id3[row] = tp.i3; p.cls[row] = cl;
+  }
+}
+
+// exact re-check for wide rows: one wave per row, the row staged in LDS, lane t < 3 takes candidate t (reference arithmetic,
+// run-time dimension); lane 0 applies argmin_value_float's rule -- strictly smallest biased value, smallest index on ties,
+// NaN never selected (kernels.rs:79-111).  Undecided rows go to ma_recompute_kernel's list.
+template <int METRIC, typename TX, int LANES>
+__global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.active && !p.active[0]) return;
+  float *wrow = reinterpret_cast<float *>(smem) + (threadIdx.x >> 6) * p.d;
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.n; row += nwaves) {
+    const uint8_t cl = p.cls[row];
+    if (cl == 3) {       // wave-uniform
+      if (lane == 0) { const uint32_t slot = atomicAdd(p.fb_cnt, 1u); p.fb_rows[slot] = (uint32_t)row; }
+      continue;
+    }
+    bool fin = true;
+    for (int e = lane; e < p.d; e += 64) {
+      const float v = ld_elem(static_cast<const TX *>(p.x) + row * p.ldx, e);
+      wrow[e] = v;
+      fin &= isfinite(v);
+    }
+    const bool finite = !p.check_finite || __all(fin);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t c = LANCE_HIP_NONE;
+    float v = INFINITY, vb = INFINITY;
+    if (lane <= (int)cl) {
+      c = lane == 0 ? p.id1[row] : (lane == 1 ? p.id2[row] : p.id3[row]);
+      if (c != LANCE_HIP_NONE) {
+        v = finish_metric<METRIC>(dist_exact_rt<METRIC, float, LANES>(wrow, p.cent + (int64_t)c * p.d, p.d));
+        vb = p.bias ? v + p.bias[c] : v;
+      }
+    }
+    uint32_t best = LANCE_HIP_NONE;
+    float bestv = INFINITY, bestb = INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const uint32_t ct = __shfl(c, t, 64);
+      const float vt = __shfl(v, t, 64), vbt = __shfl(vb, t, 64);
+      if (t <= (int)cl && ct != LANCE_HIP_NONE) {
+        if (vbt < bestb || (vbt == bestb && best != LANCE_HIP_NONE && ct < best)) { bestb = vbt; bestv = vt; best = ct; }
+      }
+    }
+    if (!finite) { best = LANCE_HIP_NONE; bestv = INFINITY; }
+    if (best == LANCE_HIP_NONE) bestv = INFINITY;
+    if (lane == 0) {
+      if (p.ids) p.ids[row] = best;
+      if (p.dists) p.dists[row] = bestv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int METRIC, typename TX>
+static void ma_launch_wide(lance_hip_ctx *ctx, const MaArgs &a, uint16_t *xhi, uint16_t *xlo, float *xn2) {
+  hipLaunchKernelGGL((ma_split_rows_kernel<TX>), dim3((unsigned)cdiv(a.n, 4)), dim3(256), 0, ctx->stream, static_cast<const TX *>(a.x), a.n, a.ldx,
+                     a.d, a.dp, xhi, xlo, xn2, a.active);
+  hipLaunchKernelGGL((ma_top3_wide_kernel<METRIC>), dim3((unsigned)cdiv(a.n, MW_ROWS)), dim3(256), 0, ctx->stream, a);
+  const unsigned fgrid = (unsigned)std::min<int64_t>(cdiv(a.n, 4), 16384);
+  hipLaunchKernelGGL((ma_finalize_wide_kernel<METRIC, TX, 16>), dim3(fgrid), dim3(256), (size_t)4 * a.d * 4, ctx->stream, a);
+  hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX, 16>), dim3(512), dim3(256), (size_t)4 * a.d * 4, ctx->stream, a);
+}
+
+// rows of more than 128 elements (any length up to 4096; planes padded to a multiple of 32)
+static bool mfma_wide_supported(const PairwiseArgs &p, int d) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA_WIDE") != nullptr;
+  if (off || d <= 128 || d > 4096 || p.lanes32) return false;
+  if (p.x_native && p.x_dtype != LANCE_HIP_F32) return false;   // f16 / int8 columns of this width arrive as their f32 copy
+  if (p.k < 64 || p.n < 2048) return false;
+  const int64_t dp = (d + MW_KC - 1) / MW_KC * MW_KC;
+  if ((int64_t)p.n * dp * 4 > (16ll << 30)) return false;       // the two bf16 planes of the rows: at most 16 GiB of scratch
+  return true;
+}
+
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches) {
   static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr;
   if (off || batches != 1 || p.codes || p.matrix) return false;
+  if (d > 128) return mfma_wide_supported(p, d);
   if (d % 16 != 0 || d < 16 || d > 128) return false;
   if (p.k < 32 || p.n < 2048) return false;     // small problems: the exact kernel's fixed cost is lower
   if (p.x_native) {   // rows in the column's own element type: 4-element loads need 4 * sizeof(element) alignment
@@ -405,7 +632,9 @@ bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches) {
 
 // ids / dists of PairwiseArgs are filled exactly as launch_assign's exact kernels fill them.
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric) {
-  const size_t kd = (size_t)p.k * d;
+  const bool wide = d > 128;
+  const int dp = wide ? (d + MW_KC - 1) / MW_KC * MW_KC : d;
+  const size_t kd = (size_t)p.k * dp;
   uint16_t *chi = ctx->scratch_t<uint16_t>("ma.chi", kd), *clo = ctx->scratch_t<uint16_t>("ma.clo", kd);
   float *cn = ctx->scratch_t<float>("ma.cn", (size_t)p.k);
   uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);   // [0] max |c|^2, [1] max |bias|, [2] rows left to the recompute kernel
@@ -416,7 +645,7 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
   if (!chi || !clo || !cn || !maxbits || !id1 || !id2 || !id3 || !cls || !fb_rows) return LANCE_HIP_ENOMEM;
   LH_REQUIRE(p.n < (1ll << 32), "assign: more than 2^32 rows per call");
   LH_CHECK_HIP(hipMemsetAsync(maxbits, 0, 12, ctx->stream));
-  hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, p.bias, chi, clo, cn, maxbits, p.active);
+  hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, dp, p.bias, chi, clo, cn, maxbits, p.active);
   MaArgs a;
   a.x = p.x_native ? p.x_native : static_cast<const void *>(p.x); a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
   const int dtype = p.x_native ? p.x_dtype : LANCE_HIP_F32;
@@ -424,6 +653,17 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
   a.chi = chi; a.clo = clo; a.cn = cn; a.bias = p.bias; a.maxbits = maxbits; a.cent = p.cent;
   a.fb_cnt = maxbits + 2; a.fb_rows = fb_rows; a.active = p.active;
   a.id1 = id1; a.id2 = id2; a.id3 = id3; a.cls = cls; a.ids = p.ids; a.dists = p.dists; a.check_finite = p.check_finite ? 1 : 0;
+  if (wide) {
+    uint16_t *xhi = ctx->scratch_t<uint16_t>("ma.xhi", (size_t)p.n * dp), *xlo = ctx->scratch_t<uint16_t>("ma.xlo", (size_t)p.n * dp);
+    float *xn2 = ctx->scratch_t<float>("ma.xn2", (size_t)p.n);
+    if (!xhi || !xlo || !xn2) return LANCE_HIP_ENOMEM;
+    a.xhi = xhi; a.xlo = xlo; a.xn2 = xn2; a.dp = dp;
+    LH_REQUIRE(metric == METRIC_L2 || metric == METRIC_DOT, "assign: metric %d is not on the MFMA path", metric);
+    LH_REQUIRE(dtype == LANCE_HIP_F32, "assign: wide rows reach the MFMA path as f32 (element type %d)", dtype);
+    if (metric == METRIC_DOT) ma_launch_wide<METRIC_DOT, float>(ctx, a, xhi, xlo, xn2); else ma_launch_wide<METRIC_L2, float>(ctx, a, xhi, xlo, xn2);
+    LH_CHECK_HIP(hipGetLastError());
+    return LANCE_HIP_OK;
+  }
   switch (d / 16) {
     case 1: ok = ma_launch_ks<1>(ctx, a, metric, dtype, p.lanes32); break;
     case 2: ok = ma_launch_ks<2>(ctx, a, metric, dtype, p.lanes32); break;

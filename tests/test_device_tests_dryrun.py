@@ -134,3 +134,11 @@ def test_dryrun_f16_index(fake, oracle, metric):
 def test_dryrun_f16_flat_and_ivfflat(fake, oracle, metric):
     import test_zz_gpu_f16_metrics as Z
     Z.test_f16_flat_and_ivfflat(fake, oracle, metric, 40)
+
+
+# ---- wide rows on the matrix cores (tests/test_zz_gpu_wide_mfma.py): the tests' own expectations
+def test_dryrun_wide_rows(fake, oracle):
+    import test_zz_gpu_wide_mfma as W
+    W.test_wide_rows_assign_on_matrix_cores(fake, oracle, 144, "dot")
+    W.test_wide_rows_assign_on_matrix_cores(fake, oracle, 200, "l2")
+    W.test_wide_rows_kmeans_and_encode_chain(fake, oracle)
