@@ -1,6 +1,9 @@
 """Randomised differential run: HIP path vs CPU oracle on random shapes (not collected by pytest; GPU only).
 
-    python tests/fuzz_parity.py [seconds] [seed]
+    python tests/fuzz_parity.py [seconds] [seed] [--dry]
+
+--dry replaces the device classes with the oracle-backed stand-ins of tests/oracle_engine.py (CPU): it checks this harness
+itself -- argument order, dtypes, the expectations -- where no GPU exists.
 
 Every case builds an IVF_PQ index from oracle-trained models, then compares encode output, storage layout, searches
 (random k / nprobes / refine), distance ranges, row-id prefilters, a save -> load round trip through the index files, the
@@ -19,12 +22,22 @@ f32 = np.float32
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dry = "--dry" in sys.argv
+    args = [a for a in sys.argv[1:] if a != "--dry"]
+    budget = float(args[0]) if len(args) > 0 else 60.0
+    seed = int(args[1]) if len(args) > 1 else 0
     import torch
     import oracle
-    from lance_amd.engine import Engine, DeviceIndex, DeviceFlatIndex
     from lance_amd.vector import IvfPqIndex, IvfPqParams
+    if dry:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import oracle_engine as OE
+        import lance_amd.vector as V
+        Engine, DeviceIndex, DeviceFlatIndex = OE.OracleEngine, OE.OracleDeviceIndex, OE.OracleDeviceFlatIndex
+        V.to_device = OE.cpu_to_device
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        from lance_amd.engine import Engine, DeviceIndex, DeviceFlatIndex
     eng = Engine()
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
@@ -40,6 +53,7 @@ def main():
         metric = str(rng.choice(["l2", "dot", "cosine"]))
         integer = bool(rng.integers(0, 2))
         int8 = metric != "cosine" and rng.random() < 0.25          # Int8 column: data int8, model f32
+        f16 = (not int8) and rng.random() < 0.3                    # Float16 column: data and model f16, half::f16's own dot / cosine
         nbits = 4 if (m % 2 == 0 and rng.random() < 0.2) else 8
         if int8:
             integer = True
@@ -51,9 +65,13 @@ def main():
             q = (rng.standard_normal((40, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
         if int8:
             x = (x - 15.0).astype(f32); q = (q - 15.0).astype(f32)
+        if f16:
+            if not integer:
+                x = x / 3; q = q / 3                                # keep the f16 M-step sums well inside the f16 range
+            x = x.astype(np.float16); q = q.astype(np.float16)     # the oracle calls below take the f16 arrays (dtype-aware arms)
         xg = torch.from_numpy(x.astype(np.int8)) if int8 else x     # what the engine sees
         qg = torch.from_numpy(q.astype(np.int8)) if int8 else q
-        cfg = dict(seed=seed, case=ncase, n=n, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer, int8=int8, nbits=nbits)
+        cfg = dict(seed=seed, case=ncase, n=n, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer, int8=int8, f16=f16, nbits=nbits)
         try:
             xs = oracle.normalize(x) if metric == "cosine" else x
             km = "l2" if metric == "cosine" else metric
@@ -73,7 +91,7 @@ def main():
                 if k * max(rf, 1) > 128:
                     rf = 0
                 gi, gd = g.search(qg, k, nprobes, rf)
-                oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+                oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x.astype(f32) if rf else None)
                 assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
                 assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
             # distance range (no refine) and, for 8-bit codes, a row-id prefilter -- against the oracle's restatements
@@ -91,6 +109,11 @@ def main():
                 gi, gd = vi.nearest(qg, k, nprobes, prefilter=allow)
                 oi, od = oidx.search(q, k, nprobes, prefilter=allow)
                 assert (gi.view(np.uint64) == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), f"prefilter k={k} nprobes={nprobes}"
+            if fin.size > 10:     # prefilter and distance range together, both tested inside the scan (flat/index.rs:131-149); 4-bit too
+                allow = rng.random(n) < float(rng.choice([0.1, 0.6]))
+                gi, gd = g.search_range(qg, k, nprobes, lo, hi, allow=allow)
+                oi, od = oidx.search(q, k, nprobes, lower=lo, upper=hi, prefilter=allow)
+                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"range+prefilter k={k} nprobes={nprobes}"
             # files: HBM -> index.idx + auxiliary.idx -> HBM answers the same (f32 / int8 columns)
             if ncase % 4 == 0:
                 with tempfile.TemporaryDirectory() as tdir:
@@ -103,13 +126,21 @@ def main():
             gi, gd = eng.flat_topk(xg, qg, k, metric)
             oi, od = oracle.flat_knn(x, q, k, metric)
             assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"flat k={k}"
-            if metric != "cosine":
-                fpart, _ = eng.assign(xg, cent, metric)
-                fx = DeviceFlatIndex.create(eng, metric, cent, xg, fpart)
+            if not (int8 and metric == "cosine"):
+                # IVF_FLAT; cosine: rows normalised and stored normalised, L2 coarse quantiser, cosine inside the partitions
+                xs_g = eng.normalize(xg) if metric == "cosine" else xg
+                fpart, _ = eng.assign(xs_g, cent, "l2" if metric == "cosine" else metric)
+                fx = DeviceFlatIndex.create(eng, metric, cent, xs_g, fpart)
                 nprobes = int(rng.integers(1, nlist + 1))
+                k = min(k, 128)
                 gi, gd = fx.search(qg[:8], k, nprobes)
                 oi, od = oracle.ivfflat_search(x, cent, q[:8], k, nprobes, metric)
                 assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat k={k} nprobes={nprobes}"
+                allow = rng.random(n) < float(rng.choice([0.03, 0.5]))       # the mask is tested inside the IVF_FLAT kernels
+                keep = np.nonzero(allow)[0]
+                gi, gd = fx.search(qg[:8], k, nprobes, allow=allow)
+                oi, od = oracle.ivfflat_search(x[keep], cent, q[:8], k, nprobes, metric, row_ids=keep.astype(np.uint64))
+                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat prefilter k={k} nprobes={nprobes}"
                 fx.close()
             g.close()
         except AssertionError as e:
