@@ -915,6 +915,14 @@ extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metri
   return LANCE_HIP_OK;
 }
 
+// More rows tie at a query's bound than its pool holds (thousands of duplicate vectors, or distances that are all NaN): the
+// threshold cannot separate them, so the repair rounds never fit.  Those queries -- and only those -- are handed to the
+// heap-emulating exact kernel, which needs no pool.
+__global__ __launch_bounds__(256) void ivfflat_flag_overfull_kernel(FlatPool p, int nq, uint32_t *__restrict__ flags) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < nq) flags[q] = p.cnt[q] > (uint32_t)p.cap ? 1u : 0u;
+}
+
 static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k, uint32_t nprobes,
                                const uint32_t *allow, uint64_t *ids, float *dists) {
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "ivfflat_search: NULL argument");
@@ -963,8 +971,8 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
   const bool fixed = !cosine && !h32 && flat_fixed_dim(idx->d);
   const size_t sel_lds = (size_t)IVFFLAT_CAP * 16;
   const size_t ex_lds = (size_t)(((d + 3) & ~3) + 2) * 4 + (size_t)k * 12 + (size_t)(k + 1) * 8 + 64 * 4 + 64;
-  auto finish = [&](int nqc, uint64_t *oid, float *od) {
-    hipLaunchKernelGGL(ivfflat_select_kernel, dim3(nqc), dim3(256), sel_lds, ctx->stream, a, oid, od);
+  auto finish = [&](int nqc, uint64_t *oid, float *od, bool select = true) {
+    if (select) hipLaunchKernelGGL(ivfflat_select_kernel, dim3(nqc), dim3(256), sel_lds, ctx->stream, a, oid, od);
     ScopedTimer t(ctx, "ivfflat_exact");
     if (h32 && cosine) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_COSINE, true>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
     else if (h32) hipLaunchKernelGGL((ivfflat_exact_kernel<METRIC_DOT, true>), dim3(nqc), dim3(64), ex_lds, ctx->stream, a, oid, od);
@@ -1037,7 +1045,12 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
       LH_CHECK_HIP(hipMemcpyAsync(&ovf, pl.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
       LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
       if (!ovf) break;
-      LH_REQUIRE(round < 63, "ivfflat_search: candidate pool did not converge");
+      if (round >= 6) {
+        // the bound stopped tightening: the overfull queries are replayed exactly (every other query already has its answer)
+        hipLaunchKernelGGL(ivfflat_flag_overfull_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, pl, nqc, a.flags);
+        finish(nqc, oid, od, false);
+        break;
+      }
       hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, pl, 0);
       scan(0, nqc);
       finish(nqc, oid, od);

@@ -142,3 +142,9 @@ def test_dryrun_wide_rows(fake, oracle):
     W.test_wide_rows_assign_on_matrix_cores(fake, oracle, 144, "dot")
     W.test_wide_rows_assign_on_matrix_cores(fake, oracle, 200, "l2")
     W.test_wide_rows_kmeans_and_encode_chain(fake, oracle)
+
+
+def test_dryrun_ivfflat_ties(fake, oracle):
+    import test_zz_gpu_zz_ivfflat_ties as T
+    T.test_ivf_flat_more_ties_than_the_pool_holds(oracle)
+    T.test_ivf_flat_f16_cosine_norm_overflow_gives_nan_like_the_reference(oracle)
