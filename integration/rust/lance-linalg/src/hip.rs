@@ -84,6 +84,17 @@ extern "C" {
         nprobes: u32, refine_factor: u32, allow_by_rowid: *const u8, n_allow: u64, ids: *mut u64, dists: *mut f32) -> i32;
     pub fn lance_hip_ivfpq_search_range(ctx: *mut LanceHipCtx, idx: *const LanceHipIndex, q: *const c_void, nq: u32, k: u32,
         nprobes: u32, refine_factor: u32, lower: f32, upper: f32, ids: *mut u64, dists: *mut f32) -> i32;
+    // PreFilter::mask with Query::lower_bound / upper_bound (flat/index.rs:131-149): both tested inside the scan kernels
+    pub fn lance_hip_ivfpq_search_filtered_range(ctx: *mut LanceHipCtx, idx: *const LanceHipIndex, q: *const c_void, nq: u32, k: u32,
+        nprobes: u32, refine_factor: u32, allow_by_rowid: *const u8, n_allow: u64, lower: f32, upper: f32,
+        ids: *mut u64, dists: *mut f32) -> i32;
+    // IVF_FLAT sub-index (FlatIndex over FlatFloatStorage, flat/index.rs:82-177), with and without a RowIdMask
+    pub fn lance_hip_ivfflat_create(ctx: *mut LanceHipCtx, dtype: i32, metric: i32, d: u32, centroids: *const c_void, nlist: u32,
+        x: *const c_void, part_ids: *const u32, row_ids: *const u64, n: u64, out: *mut *mut LanceHipIndex) -> i32;
+    pub fn lance_hip_ivfflat_search(ctx: *mut LanceHipCtx, idx: *const LanceHipIndex, q: *const c_void, nq: u32, k: u32, nprobes: u32,
+        ids: *mut u64, dists: *mut f32) -> i32;
+    pub fn lance_hip_ivfflat_search_filtered(ctx: *mut LanceHipCtx, idx: *const LanceHipIndex, q: *const c_void, nq: u32, k: u32,
+        nprobes: u32, allow_by_rowid: *const u8, n_allow: u64, ids: *mut u64, dists: *mut f32) -> i32;
     pub fn lance_hip_flat_topk(ctx: *mut LanceHipCtx, dtype: i32, metric: i32, x: *const c_void, row_ids: *const u64,
         n: u64, d: u32, q: *const c_void, nq: u32, k: u32, ids: *mut u64, dists: *mut f32) -> i32;
 }
