@@ -9,6 +9,7 @@ import ctypes as C
 import json
 import os
 import shutil
+import struct
 
 import numpy as np
 import pytest
@@ -410,6 +411,48 @@ def test_reader_survives_corrupted_metadata(tmp_path):
         else:
             assert rc in (_lib.EINVAL, _lib.EIO, _lib.ENOTSUP)
     assert 0 in seen and len(seen) > 1
+
+
+def test_reader_survives_corrupted_multi_page_metadata(tmp_path, monkeypatch):
+    """The same on columns cut into several pages: flips inside the column metadata (page lengths, buffer offsets and sizes,
+    priorities), the offset tables and the footer of a multi-page auxiliary.idx.  A wrapped `length * row_bytes` or row count
+    must be caught by the overflow-checked arithmetic of lance_file.cpp, not lead to a read past the mapping; values that stay
+    consistent simply decode to different rows."""
+    monkeypatch.setenv("LANCE_HIP_MAX_PAGE_BYTES", "1000")
+    rng = np.random.default_rng(21)
+    c, _ = _random_pq(rng, 900, 16, 5, 4, 8)
+    IF.write_index_files(tmp_path / "i", c)
+    aux = tmp_path / "i" / "auxiliary.idx"
+    raw = bytearray(aux.read_bytes())
+    p = Probe(aux)
+    data_end = max(pg["offsets"][i] + pg["sizes"][i] for col in p.pages for pg in col for i in range(len(pg["offsets"])))
+    assert len(p.pages[0]) > 1 and data_end < len(raw) - 40
+    lib = _lib.load()
+    outcomes = {}
+    for it in range(400):
+        b = bytearray(raw)
+        if it % 4 == 0:
+            # targeted: overwrite a varint inside a column's metadata with a huge value (page length / buffer size wrap-around)
+            ccol = int(rng.integers(0, p.ncol))
+            pos, sz = struct.unpack_from("<QQ", raw, p.cmo + 16 * ccol)
+            at = int(pos + rng.integers(0, max(sz - 10, 1)))
+            b[at:at + 10] = bytes([0xFF] * 9 + [0x01])              # 2^64 - 1 as a varint
+        else:
+            for q in rng.integers(data_end, len(b), rng.integers(1, 4)):
+                b[q] = rng.integers(0, 256)
+        aux.write_bytes(bytes(b))
+        h = C.c_void_p()
+        rc = lib.lance_hip_index_file_open(os.fspath(tmp_path / "i").encode(), C.byref(h))
+        outcomes[rc] = outcomes.get(rc, 0) + 1
+        if rc == 0:
+            v = _lib.IndexFileView()
+            assert lib.lance_hip_index_file_get(h, C.byref(v)) == 0
+            if v.n_rows:      # every byte the view exposes must be readable
+                np.ctypeslib.as_array(C.cast(v.row_ids, C.POINTER(C.c_uint64)), shape=(v.n_rows,)).sum()
+            lib.lance_hip_index_file_close(h)
+        else:
+            assert rc in (_lib.EINVAL, _lib.EIO, _lib.ENOTSUP) and lib.lance_hip_last_error()
+    assert sum(outcomes.values()) == 400 and len(outcomes) > 1 and any(rc != 0 for rc in outcomes)
 
 
 def test_write_validates_arguments(tmp_path):
