@@ -46,10 +46,12 @@ def main():
         sd = int(rng.choice([4, 8, 16, 5]))
         m = int(rng.choice([1, 2, 4, 8, 16, 32])) if sd != 5 else int(rng.choice([4, 8]))
         d = m * sd
-        if d > 256:
+        if d > 512:
             continue
         n = int(rng.integers(600, 12000))
         nlist = 1 if rng.random() < 0.08 else int(rng.integers(2, 40))   # the reference's own fixtures use one partition
+        if rng.random() < 0.15:
+            nlist = int(rng.integers(64, 130))                           # enough centroids for the MFMA assign (k >= 32 / 64)
         metric = str(rng.choice(["l2", "dot", "cosine"]))
         integer = bool(rng.integers(0, 2))
         int8 = metric != "cosine" and rng.random() < 0.25          # Int8 column: data int8, model f32
@@ -146,6 +148,9 @@ def main():
         except AssertionError as e:
             print("MISMATCH", e, cfg, flush=True)
             sys.exit(1)
+        except Exception as e:        # an error code from the engine is a finding too: print the configuration that caused it
+            print("ERROR", repr(e), cfg, flush=True)
+            raise
         ncase += 1
     print(f"fuzz ok: {ncase} random configurations, seed {seed}", flush=True)
 
