@@ -737,6 +737,40 @@ def test_f16_column_dot_cosine_normalize_arms(oracle):
                 assert dd[i, j].view(np.uint32) == f32(want).view(np.uint32)
 
 
+def test_f16_arms_pass_the_reference_property_tests(oracle):
+    """The reference's own tests of half::f16's arms, transcribed: dot.rs:265-267 (integer-valued known answer), the property
+    tests dot.rs:278-335 (Higham bound: k eps sum|x_i||y_i| with k = 2n - 1, or 2 eps sum|x_i||y_i| when k eps >= 1; eps of
+    f16 = 2^-10), cosine.rs:395-439 (f64 reference, dot products perturbed by 1e-6) and norm_l2.rs:178-203 (relative 1e-6),
+    on random f16 vectors of 4..4048 elements."""
+    x = np.arange(0, 20).astype(np.float16); y = np.arange(100, 120).astype(np.float16)
+    assert oracle.dot(x, y) == 21470.0 == float((x.astype(np.float64) * y.astype(np.float64)).sum())
+    rng = np.random.default_rng(99)
+    eps = 2.0 ** -10
+    for _ in range(60):
+        n = int(rng.integers(4, 4048))
+        scale = float(rng.choice([0.01, 1.0, 30.0]))
+        x = (rng.standard_normal(n) * scale).astype(np.float16); y = (rng.standard_normal(n) * scale).astype(np.float16)
+        x64, y64 = x.astype(np.float64), y.astype(np.float64)
+        expected = f32((x64 * y64).sum())
+        absdot = (np.abs(x64) * np.abs(y64)).sum()
+        k_eps = (2 * n - 1) * eps
+        max_error = f32(k_eps * absdot) if k_eps < 1.0 else f32(2.0 * eps * absdot)
+        got = f32(oracle.dot(x, y))
+        assert abs(float(got) - float(expected)) <= max(float(max_error), float(max_error) * max(abs(float(got)), abs(float(expected))))
+        # norm_l2: relative 1e-6 of the f64 reference
+        ref = f32(np.sqrt((x64 * x64).sum()))
+        assert abs(oracle.norm_l2(x) - float(ref)) <= 1e-6 * max(abs(oracle.norm_l2(x)), abs(float(ref))) + 1e-30
+        # cosine: the f64 reference with its 1e-6 error band (cosine.rs:395-414)
+        if oracle.norm_l2(x) > 1e-6 and oracle.norm_l2(y) > 1e-6:
+            xy = (x64 * y64).sum(); xs = np.sqrt((x64 * x64).sum()); ys = np.sqrt((y64 * y64).sum())
+            exp_c = f32(1.0 - xy / xs / ys)
+            fct = 1.0 + 1e-6
+            low = f32(1.0 - (xy * fct) / (xs / fct) / (ys / fct)); high = f32(1.0 - (xy / fct) / (xs * fct) / (ys * fct))
+            err = max(abs(float(exp_c) - float(low)), abs(float(exp_c) - float(high)))
+            got_c = f32(oracle.cosine(x, y))
+            assert abs(float(got_c) - float(exp_c)) <= max(err, err * max(abs(float(got_c)), abs(float(exp_c))))
+
+
 def test_distance_range_search_semantics(oracle):
     """flat/index.rs:98-113: a row enters a partition's heap only if lower <= d < upper; open ends are f32::MIN / f32::MAX;
     the union over the probed partitions is then sorted (dist, rowid) and cut to k.  Cross-check: the ranged search equals
