@@ -39,6 +39,12 @@
  *     several equal-distance rows survive in a full heap.
  *   - rand 0.9 IteratorRandom::choose_multiple (reservoir) shape for
  *     kmeans_random_init (kmeans.rs:149-170); stream itself is unpinned.
+ *   - half 2.7.1 (Cargo.lock) binary16 arithmetic, the non-intrinsic x86_64 arms: every operator, Float::powi and
+ *     Float::sqrt convert to f32, operate, and round the result to binary16 (round-to-nearest-even); `impl Sum for f16`
+ *     adds the widened terms in f32 and rounds once.  Used by the Float16Type k-means M-step (kmeans.rs:380,405-418),
+ *     the f16 residual (residual.rs:96) and normalize_fsl::<Float16Type> (kernels.rs:141-186, orc_normalize_h).
+ *     The f16 distance arms themselves (dot_scalar::<f16, f32, 32>, norm_l2_impl::<f16, f32, 32>, cosine_scalar) are in the
+ *     reference tree and are pinned on its own simd/f16.c and on its property tests (tests/test_oracle_golden.py).
  */
 #include <math.h>
 #include <stdint.h>
