@@ -239,9 +239,10 @@ int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx,
 /* The same search under a row-id prefilter (`nearest=..., filter=..., prefilter=True`: scanner.rs -> DatasetPreFilter ->
  * FlatIndex::search's RowIdMask branch, flat/index.rs:129-165).  allow_by_rowid[r] != 0 <=> row id r may be returned; rows
  * whose id is >= n_allow are filtered out.  The mask is applied INSIDE the scan kernels (one bit per stored row, tested
- * before a row can become a candidate, bound pass included): no per-filter copy of the index.  For 8-bit PQ the result is
- * identical to the reference's per-row distance(id) loop; 4-bit PQ is refused (the reference scores filtered rows with
- * the unquantised table, a different arithmetic from its own unfiltered fast-scan).                                      */
+ * before a row can become a candidate, bound pass included): no per-filter copy of the index.  The result is identical
+ * to the reference's per-row distance(id) loop.  4-bit PQ: the reference scores filtered rows with the UNQUANTISED f32
+ * table, byte-wise terms (pq/storage.rs:893-921) -- a different arithmetic from its own unfiltered fast-scan -- and so do
+ * the 4-bit scan kernel and its exact replay here when a mask is given (search.hip pq4_masked_row).                     */
 int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                     uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
                                     uint64_t *ids, float *dists);
@@ -265,7 +266,8 @@ int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x
 
 /* ---- N4: IVF_FLAT (FlatIndex sub-index over raw vectors: flat/index.rs:82-177, flat/storage.rs:345-402) ------ */
 /* Builds the per-partition FlatFloatStorage on the device: x[n][d] (dtype elements, widened exactly to f32) is
- * gathered into partition order (stable, rows with part id LANCE_HIP_NONE dropped).  L2, Dot and (f32 only) Cosine.
+ * gathered into partition order (stable, rows with part id LANCE_HIP_NONE dropped).  L2, Dot and Cosine (f32 and f16 columns;
+ * an int8 column under cosine is refused).
  * Cosine (IvfTransformer::new_flat, ivf.rs:147-175): the caller passes the rows ALREADY NORMALISED (lance_hip_normalize) with
  * part ids assigned in L2 -- the reference stores the normalised rows too; lance_hip_ivfflat_search normalises the query
  * key (knn.rs:498), finds the partitions in L2 (ivf/v2.rs:455-465) and scores rows with cosine_distance (ivf/v2.rs:405-411).

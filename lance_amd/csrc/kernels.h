@@ -97,7 +97,7 @@ int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t 
 int launch_residual(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, float *out, bool f16);
 
 
-bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range);
+bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range, uint32_t nq, uint32_t nprobes);
 int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes,
                         uint32_t nprobes, uint32_t keff, uint32_t k, bool do_refine, uint64_t *ids, float *dists,
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow);
@@ -109,6 +109,9 @@ int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float
 constexpr int QSCAN_SEG_CAP = 256;   // survivors kept per (query, probe)
 struct SelectOut;
 bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
+// search_qt.hip: M = 48 / 64 / 96 (table tiled over the sub-quantisers); class-B queries of those shapes go to the rescan kernel
+bool qscan_tiled_shape(int m, int sd);
+int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t nq, uint32_t nprobes, uint32_t *seg_cnt, uint32_t *qovf);
 int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys);
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,

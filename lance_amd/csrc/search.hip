@@ -643,6 +643,9 @@ __global__ __launch_bounds__(256) void ivfpq_merge_kernel(MergeArgs p) {
 // (dist, rowid) order, fetch k  (scanner.rs:2884-2904 take + flat_knn :3336-3412)
 // H32: the column is f16 -- its dot products and norms are the 32-lane dot_scalar / norm_l2_impl (dot.rs:91-102, norm_l2.rs:60-85)
 // and its cosine distance is the trait default cosine_scalar (cosine.rs:171-179), not f32's cosine_fast.
+// rows long enough for the four-lanes-per-candidate cosine path (no f32x8 / scalar tail: d % 16 == 0; 16-byte aligned rows)
+__host__ __device__ __forceinline__ bool refine_wide_rows(int d) { return d >= 256 && (d & 15) == 0; }
+
 template <int METRIC, typename TR, bool H32 = false>
 __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw,
                                                      uint64_t n_raw, const uint64_t *__restrict__ cand_rid,
@@ -656,8 +659,80 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
   const int c = (int)cand_cnt[qi];
   const float *qv = q + (int64_t)qi * d;
   float qnorm = 0.0f;
-  if constexpr (METRIC == METRIC_COSINE) qnorm = H32 ? norm_l2_rt<float, 32>(qv, d) : norm_l2_rt(qv, d);  // cosine_batch: x_norm = norm_l2(x)
+  const bool wide = METRIC == METRIC_COSINE && !H32 && sizeof(TR) == 4 && refine_wide_rows(d) && (reinterpret_cast<uintptr_t>(raw) & 15) == 0;
   if constexpr (METRIC == METRIC_COSINE) {
+    if (!wide) qnorm = H32 ? norm_l2_rt<float, 32>(qv, d) : norm_l2_rt(qv, d);  // cosine_batch: x_norm = norm_l2(x)
+  }
+  if constexpr (METRIC == METRIC_COSINE && !H32 && sizeof(TR) == 4) {
+    if (wide) {
+      // Long f32 rows (C3: d = 1536): FOUR lanes per candidate.  cosine_fast (cosine.rs:143-175) keeps 16 FMA accumulators,
+      // accumulator i taking the elements = i (mod 16); lane s of a quad owns accumulators 4s .. 4s+3, i.e. one 16-byte load per
+      // 16-element chunk, and the quad reads 64 contiguous bytes -- 64 candidates in flight per workgroup instead of one lane
+      // walking a 6 KB row with 4-byte strided loads (0.46 ms per 1000 queries at refine 10).  The f32x16 reduce_sum tree
+      // ((a_i + a_{i+8}) -> reduce8_tree) runs across the quad with two xor-shuffles; additions are commutative, so both sides
+      // of a shuffle pair hold the same bits.  The d % 16 == 0 rows have neither the f32x8 nor the scalar tail (their +0.0 terms
+      // are kept).  Query row staged in LDS once.
+      float *qs = reinterpret_cast<float *>(pos + P);
+      __shared__ float s_qnorm;
+      for (int e = threadIdx.x; e < d; e += 256) qs[e] = qv[e];
+      __syncthreads();
+      if (threadIdx.x < 64) {   // norm_l2_impl::<f32, f32, 16> (norm_l2.rs:106-129): 16 lane sums (mul, then add), folded 0..15, no remainder here
+        const int ln = threadIdx.x & 15;
+        float sacc = 0.0f;
+        for (int e = ln; e < d; e += 16) sacc += qs[e] * qs[e];
+        float tot = 0.0f;
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) tot = tot + __shfl(sacc, i2, 16);
+        if (threadIdx.x == 0) s_qnorm = sqrtf(0.0f + tot);
+      }
+      __syncthreads();
+      qnorm = s_qnorm;
+      const int sub = threadIdx.x & 3, slot = threadIdx.x >> 2;   // 64 candidates per round
+      for (int i0 = 0; i0 < P; i0 += 64) {
+        const int i = i0 + slot;
+        uint64_t r = ~0ull;
+        if (i < c) {
+          r = cand_rid[(int64_t)qi * keff + i];
+          if (r >= n_raw && sub == 0) atomicOr(&flags[qi], FLAG_BADROW);
+        }
+        const bool ok = i < c && r < n_raw;
+        f4 xy = {0.0f, 0.0f, 0.0f, 0.0f}, yn = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (ok) {
+          const f4 *yp = reinterpret_cast<const f4 *>(reinterpret_cast<const float *>(raw) + r * d) + sub;
+          const f4 *xp = reinterpret_cast<const f4 *>(qs) + sub;
+#pragma unroll 4
+          for (int cch = 0; cch < d / 16; ++cch) {
+            const f4 yv = yp[cch * 4], xv = xp[cch * 4];
+            xy = __builtin_elementwise_fma(xv, yv, xy);
+            yn = __builtin_elementwise_fma(yv, yv, yn);
+          }
+        }
+        // a_i + a_{i+8}: quad lane s <-> s ^ 2; then t_i + t_{i+4}: s <-> s ^ 1; then (s0 + s2) + (s1 + s3) in the lane
+        f4 t, u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t[e] = xy[e] + __shfl_xor(xy[e], 2, 64); u[e] = yn[e] + __shfl_xor(yn[e], 2, 64); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t[e] = t[e] + __shfl_xor(t[e], 1, 64); u[e] = u[e] + __shfl_xor(u[e], 1, 64); }
+        const float xyr = ((t[0] + t[2]) + (t[1] + t[3])) + 0.0f + 0.0f;
+        const float ynr = ((u[0] + u[2]) + (u[1] + u[3])) + 0.0f + 0.0f;
+        if (sub == 0 && i < P) {
+          key[i] = ok ? order_key(1.0f - xyr / qnorm / sqrtf(ynr)) : 0xFFFFFFFFu;
+          rid[i] = r; pos[i] = 0;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < P; i += 256) {
+        uint32_t kk = 0xFFFFFFFFu;
+        uint64_t r = ~0ull;
+        if (i < c) {
+          r = cand_rid[(int64_t)qi * keff + i];
+          if (r >= n_raw) atomicOr(&flags[qi], FLAG_BADROW);
+          if (r < n_raw) kk = order_key(cosine_exact_rt<TR>(qv, qnorm, raw + r * d, d));
+        }
+        key[i] = kk; rid[i] = r; pos[i] = 0;
+      }
+    }
+  } else if constexpr (METRIC == METRIC_COSINE) {
     for (int i = threadIdx.x; i < P; i += 256) {
       uint32_t kk = 0xFFFFFFFFu;
       uint64_t r = ~0ull;
@@ -926,7 +1001,9 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   // scan: partition-major (two queries per LDS gather) when the batch is large enough to pair queries,
   // query-major otherwise
   static const bool no_pm = getenv("LANCE_HIP_NO_PM") != nullptr;
-  const bool use_pm = fast && !no_pm && pm_supported(ix, keff, has_range) && (uint64_t)nq * nprobes >= 4096;
+  // (tiled shapes, M >= 48: a work item's table build is as long as a query-major workgroup's, so sharing it pays earlier)
+  const uint64_t pm_min_pairs = qscan_tiled_shape(m, sd) ? 2048 : 4096;
+  const bool use_pm = fast && !no_pm && pm_supported(ix, keff, has_range, nq, nprobes) && (uint64_t)nq * nprobes >= pm_min_pairs;
   int nsplit = 1;
   if (nq < (uint32_t)(2 * ctx->num_cus)) {
     nsplit = (int)std::min<uint64_t>({8ull, (uint64_t)nprobes, cdiv(2ull * ctx->num_cus, nq)});
@@ -958,7 +1035,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
       a.hi_key = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
     }
     a.out_keys = ckeys; a.out_pos = cpos; a.out_cnt = ccnt; a.flags = flags;
-    { const char *ab = getenv("LANCE_HIP_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    { static const int ablate = getenv("LANCE_HIP_ABLATE") ? atoi(getenv("LANCE_HIP_ABLATE")) : 0; a.ablate = ablate; }
     const int dpad = (d + 3) & ~3;
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);
@@ -1032,7 +1109,8 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
       hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->metric == LANCE_HIP_COSINE)
-      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256),
+                         (size_t)P * 16 + (refine_wide_rows(d) ? (size_t)d * 4 : 0), ctx->stream, q, d, rawf, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
     else if (ix->metric == LANCE_HIP_DOT)
       hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,

@@ -557,13 +557,19 @@ static bool launch_pm_sd(lance_hip_ctx *ctx, const PmArgs &a, int sd, unsigned g
   return false;
 }
 
-bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range) {
+// A/B switches, read once per process
+static bool pm_nobound() { static const bool v = getenv("LANCE_HIP_PM_NOBOUND") != nullptr; return v; }
+
+bool pm_supported(const lance_hip_index *ix, uint32_t keff, int has_range, uint32_t nq, uint32_t nprobes) {
   const int d = (int)ix->d, m = (int)ix->m;
   if (ix->nbits != 8 || has_range || keff > (uint32_t)SCAN_MAX_KEFF) return false;
-  if (m % 16 != 0 || m / 16 > 2) return false;
+  if (m == 0 || d % m != 0) return false;
   const int sd = d / m;
   if (sd != 4 && sd != 8 && sd != 16) return false;
   if ((reinterpret_cast<uintptr_t>(ix->codebook) & 15) || (reinterpret_cast<uintptr_t>(ix->codes) & 15)) return false;
+  if (qscan_tiled_shape(m, sd))    // M = 48 / 64 / 96: only the quantised flow exists (the exact pair table would not fit in LDS)
+    return !pm_nobound() && qscan_supported(ix, nq, nprobes);
+  if (m % 16 != 0 || m / 16 > 2) return false;
   return true;
 }
 
@@ -620,7 +626,9 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   a.prof = nullptr;
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   a.unbounded = 0; a.loop = 0; a.allow = allow;
-  static const bool exact_bound = getenv("LANCE_HIP_EXACT_BOUND") != nullptr;
+  const bool tiled = qscan_tiled_shape(m, sd);
+  static const bool exact_bound_env = getenv("LANCE_HIP_EXACT_BOUND") != nullptr;
+  const bool exact_bound = exact_bound_env && !tiled;   // the exact pair kernel has no M > 32 instantiation
   {
     // bound pass: the nq (query, nearest partition) pairs grouped by partition
     ScopedTimer t(ctx, "pm_group");
@@ -653,7 +661,8 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   }
   // timers inside: "q_residual" (memsets + residual pre-pass) and "ivfpq_scan_c1" (the filter scan kernel alone)
   LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow));
-  if (getenv("LANCE_HIP_Q_STATS")) {   // diagnosis: how many rows survive the integer filter
+  static const bool q_stats = getenv("LANCE_HIP_Q_STATS") != nullptr;
+  if (q_stats) {   // diagnosis: how many rows survive the integer filter
     std::vector<uint32_t> sc(npairs), tb(nq);
     (void)hipMemcpyAsync(sc.data(), seg_cnt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream);
     (void)hipMemcpyAsync(tb.data(), tbound, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -664,7 +673,10 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     fprintf(stderr, "[qscan] nq=%u nprobes=%u keff=%u survivors/query %.1f (nearest partition %.1f) max segment %llu overflowed segments %llu class-B queries %llu\n",
             nq, nprobes, keff, (double)tot / nq, (double)r0 / nq, (unsigned long long)mx, (unsigned long long)ovf, (unsigned long long)nb);
   }
-  {
+  if (tiled) {   // no exact pair kernel at these sizes: class-B queries are scanned by the rescan kernel (exact f32 table)
+    ScopedTimer t(ctx, "ivfpq_scan_cb");
+    LH_TRY(qscan_classb_to_rescan(ctx, tbound, nq, nprobes, seg_cnt, qovf));
+  } else {
     ScopedTimer t(ctx, "ivfpq_scan_cb");
     a.pair_starts = pair_starts; a.pair_idx = pair_idx; a.item_start = item_start; a.desc = desc;
     a.cls = 1; a.bound_pass = 0; a.unbounded = 1; a.loop = 1;
@@ -691,7 +703,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
-  if (getenv("LANCE_HIP_PM_NOBOUND") == nullptr && qscan_supported(ix, nq, nprobes))
+  if (!pm_nobound() && qscan_supported(ix, nq, nprobes))
     return ivfpq_scan_merge_q(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags, allow);
   const size_t npairs = (size_t)nq * nprobes;
   uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)2 * nlist + 1);
@@ -729,7 +741,8 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   a.desc = desc;
   a.unbounded = 0; a.loop = 0; a.allow = allow;
   a.prof = nullptr;
-  if (getenv("LANCE_HIP_PM_PROF")) {
+  static const bool pm_prof = getenv("LANCE_HIP_PM_PROF") != nullptr;
+  if (pm_prof) {
     a.prof = ctx->scratch_t<unsigned long long>("pm.prof", 8);
     if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
   }
@@ -738,7 +751,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   {
     // pass 0 (bound): every query's nearest partition is streamed once to seed Tglobal[q]; pass 1 (main): all
     // (query, probe) pairs, nearest partition included, prune with that bound from their first row.
-    const bool nobound = getenv("LANCE_HIP_PM_NOBOUND") != nullptr;
+    const bool nobound = pm_nobound();
     for (int pass = 0; pass < 2; ++pass) {
       if (nobound && pass == 1 && nprobes == 1) break;
       ScopedTimer t(ctx, pass == 0 ? "ivfpq_scan_c0" : "ivfpq_scan_c1");

@@ -28,25 +28,11 @@
 #include "kernels.h"
 #include "search_common.cuh"
 #include "pm_common.cuh"
+#include "q_common.cuh"
 
 #pragma clang fp contract(off)
 
 namespace lh {
-
-constexpr int Q_BS = 512;      // lanes per scan workgroup
-constexpr int Q_G = 4;         // queries per work item (4 x u16 = one ds_read_b64)
-#ifndef LH_Q_WAVES
-#define LH_Q_WAVES 8
-#endif
-constexpr int Q_WAVES = LH_Q_WAVES;   // launch-bounds hint for M = 16, sub-dimension <= 8: waves per SIMD (8 = FOUR 512-lane workgroups per CU, <= 64 VGPRs: fits without spills once the table build is not unrolled -- main pass 0.52 -> 0.42 ms; with the build unrolled by 2 it spilled and lost 25 %)
-constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); more -> that partition is rescanned exactly for the query
-#ifndef LH_Q_LUT_UNROLL
-#define LH_Q_LUT_UNROLL 1
-#endif
-#ifndef LH_Q_MPF
-#define LH_Q_MPF 4
-#endif
-constexpr int Q_MPF = LH_Q_MPF;        // merge kernel: codebook entries fetched together per candidate row (registers vs round trips)
 
 // ---- grouping by (partition, bound class) ---------------------------------------------------------------------
 // class A (virtual partition = partition): the query has a usable bound 0 < T < inf -> quantised scan;
@@ -116,24 +102,6 @@ __global__ __launch_bounds__(256) void q_item_desc_kernel(const uint32_t *__rest
   desc[item] = dsc;
 }
 
-// ---- the filter scan ------------------------------------------------------------------------------------------
-struct QscanArgs {
-  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel)
-  const uint32_t *pair_idx;     // grouped pair indices (pair = q * nprobes + rank)
-  const uint32_t *item_start;   // [nlist+1]: items of class A
-  const int4 *desc;
-  const float *centroids, *codebook;
-  const uint32_t *part_offsets;
-  const uint8_t *codes;
-  int d, nprobes, nlist, round_f16;
-  const uint32_t *tbound;       // [nq] bound key per query (class A: 0 < T < inf)
-  uint32_t *seg_cnt;            // [nq * nprobes] survivors of (query, probe) -- zeroed before the launch
-  uint32_t *seg_pos;            // [nq * nprobes][Q_CAP] storage positions
-  uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
-  const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
-};
-
-
 // ---- residual pre-pass ------------------------------------------------------------------------------------------------------
 // The four queries of an item share every table entry's arithmetic, and their residual components are the same in all 512
 // lanes.  Kept in LDS they cost one broadcast ds_read_b128 per (entry, dimension): 38 % of the scan kernel's LDS-pipe time
@@ -163,43 +131,6 @@ __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict
     }
     rq[(int64_t)item * d + dim] = r4;
   }
-}
-
-// ---- integer table build, shared by the filter scan and the bound pass ------------------------------------------------------
-// rq4[dim] = the four queries' NEGATED residual components of that dimension, so one packed add + one packed FMA advance two
-// queries by one dimension and the accumulators come out as {L_q0, L_q1}, {L_q2, L_q3}: no horizontal adds, and the
-// quantisation is packed too: z = L * (s / 65535) (v_pk_mul_f32), clamped to [0, CAPE / 65535] (v_med3_f32: a NaN becomes 0,
-// the row then survives the filter and the exact pass decides), v_cvt_pknorm_u16_f32 turns two of them into the two u16
-// halves of a table word.  Whatever rounding the conversion uses, |e - L * s| <= 1 for unsaturated entries; the users'
-// limits carry M units for it (floor would need none: 0.4 % of the range).
-template <int SD>
-__device__ __forceinline__ void q_entry_acc(const f4 *__restrict__ rq4m, const float *__restrict__ cbp, f2 &acc01, f2 &acc23) {
-  constexpr int QV = SD / 4;
-  f4 cb[QV];
-#pragma unroll
-  for (int u = 0; u < QV; ++u) cb[u] = reinterpret_cast<const f4 *>(cbp)[u];
-  acc01 = f2{0.0f, 0.0f};
-  acc23 = f2{0.0f, 0.0f};
-#pragma unroll
-  for (int u = 0; u < SD; ++u) {
-    const f4 r4 = rq4m[u];
-    const float cv = cb[u >> 2][u & 3];
-    const f2 cc = {cv, cv};
-    const f2 d01 = f2{r4.x, r4.y} + cc;
-    const f2 d23 = f2{r4.z, r4.w} + cc;
-    acc01 = __builtin_elementwise_fma(d01, d01, acc01);
-    acc23 = __builtin_elementwise_fma(d23, d23, acc23);
-  }
-}
-
-template <uint32_t CAPE>
-__device__ __forceinline__ uint2 q_entry_quantise(f2 acc01, f2 acc23, f2 s01, f2 s23) {
-  constexpr float CAPZ = (float)CAPE / 65535.0f;
-  const f2 z01 = acc01 * s01, z23 = acc23 * s23;   // s = scale / 65535
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const us2 e01 = __builtin_amdgcn_cvt_pknorm_u16(__builtin_amdgcn_fmed3f(z01.x, 0.0f, CAPZ), __builtin_amdgcn_fmed3f(z01.y, 0.0f, CAPZ));
-  const us2 e23 = __builtin_amdgcn_cvt_pknorm_u16(__builtin_amdgcn_fmed3f(z23.x, 0.0f, CAPZ), __builtin_amdgcn_fmed3f(z23.y, 0.0f, CAPZ));
-  return make_uint2(__builtin_bit_cast(uint32_t, e01), __builtin_bit_cast(uint32_t, e23));
 }
 
 template <int SD, int MU>
@@ -327,21 +258,6 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
 // The scale s only affects tightness: it is set from the mean table entry (the expected distance of a random code), which puts
 // the nearest 1-3 % of a partition's rows around a quarter of the histogram range (slack ~3 % on T: ~8 % more survivors).
 // A query whose partition has fewer than k*refine countable rows gets no bound (class B: exact pair kernel), as before.
-constexpr int QB_BINS = 512;      // histogram bins per query
-constexpr int QB_SHIFT = 3;       // bin width 8: sums 0 .. 4095
-struct QboundArgs {
-  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel)
-  const uint32_t *pair_idx;     // nearest-partition pairs grouped by partition: entries are query indices
-  const uint32_t *item_start;   // [nlist+1], groups of 4
-  const int4 *desc;
-  const float *centroids, *codebook;
-  const uint32_t *part_offsets;
-  const uint8_t *codes;
-  int d, nlist, keff, round_f16;
-  uint32_t *tglobal;            // [nq] bound key (atomicMin)
-  const uint32_t *allow;
-};
-
 template <int SD, int MU>
 __global__ __launch_bounds__(Q_BS, (MU == 1 ? 6 : 4)) void ivfpq_qbound_kernel(QboundArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -478,6 +394,7 @@ struct QmergeArgs {
   const uint8_t *codes;
   const uint64_t *row_ids;
   int d, nprobes, round_f16;
+  int qm_g;                      // probes whose residuals are staged together (<= QM_G; fewer for long rows: LDS = occupancy)
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
   uint32_t *tglobal;             // class B: running bound of the exact pair kernel
   const uint32_t *seg_cnt, *seg_pos;
@@ -624,8 +541,8 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
     const int dpad = (a.d + 3) & ~3;
     float *r = reinterpret_cast<float *>(smem);   // [QM_G][dpad]
     const float *qv = a.q + (int64_t)q * a.d;
-    for (int g0 = 0; g0 < a.nprobes; g0 += QM_G) {
-      const int ng = min(QM_G, a.nprobes - g0);
+    for (int g0 = 0; g0 < a.nprobes; g0 += a.qm_g) {
+      const int ng = min(a.qm_g, a.nprobes - g0);
       __syncthreads();
       if ((int)threadIdx.x < ng) {
         const uint32_t c = a.seg_cnt[(int64_t)q * a.nprobes + g0 + threadIdx.x];
@@ -723,6 +640,10 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   if (off) return false;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
   if (scan_metric != LANCE_HIP_L2) return false;                    // entries must be >= 0 (squared L2)
+  {
+    const int m = (int)ix->m, sd = (int)(ix->d / ix->m);
+    if (!((m == 16 || m == 32) && (sd == 4 || sd == 8 || sd == 16)) && !qscan_tiled_shape(m, sd)) return false;
+  }
   if ((uint64_t)nq * nprobes * Q_CAP * 4 > (2ull << 30)) return false;   // survivor segments: at most 2 GiB of scratch
   if (((uint64_t)nq * nprobes / Q_G + ix->nlist + 1) * ix->d * 16 > (2ull << 30)) return false;   // item residuals likewise
   return true;
@@ -780,7 +701,8 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   const size_t lds = qscan_lds_bytes(d, m);
   const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;
-  if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
+  if (qscan_tiled_shape(m, sd)) ok = qscan_tiled_launch(ctx, a, m, sd, grid);
+  else if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
   else if (sd == 16) ok = launch_qscan_sd<16>(ctx, a, m, grid, lds);
   LH_REQUIRE(ok, "quantised scan: unsupported shape (m=%d, sd=%d)", m, sd);
@@ -812,7 +734,8 @@ int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   a.tglobal = tglobal; a.allow = allow;
   const size_t lds = (size_t)4 * QB_BINS * 4 + 8 * 4;
   bool ok = false;
-  if (sd == 4) ok = launch_qbound_sd<4>(ctx, a, m, max_items, lds);
+  if (qscan_tiled_shape(m, sd)) ok = qbound_tiled_launch(ctx, a, m, sd, max_items);
+  else if (sd == 4) ok = launch_qbound_sd<4>(ctx, a, m, max_items, lds);
   else if (sd == 8) ok = launch_qbound_sd<8>(ctx, a, m, max_items, lds);
   else if (sd == 16) ok = launch_qbound_sd<16>(ctx, a, m, max_items, lds);
   LH_REQUIRE(ok, "integer bound pass: unsupported shape (m=%d, sd=%d)", m, sd);
@@ -826,7 +749,7 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
   const size_t lds_rescan = (size_t)dpad * 4 + (size_t)MU * 16 * 256 * 4;
   hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU>), dim3(nq), dim3(256), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
-  const size_t lds = std::max((size_t)std::min<int>(QM_G, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
+  const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
   if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
   else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
 }
@@ -841,6 +764,10 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
   a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.allow = allow;
   a.o = o;
+  {   // staged residuals: at most 32 KiB per workgroup (d = 1536: 5 probes at a time)
+    const int dpad = (d + 3) & ~3;
+    a.qm_g = std::max(1, std::min(QM_G, 32768 / (dpad * 4)));
+  }
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
   bool ok = true;
   if (m == 16) {
@@ -852,6 +779,21 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     if (sd == 4) launch_qmerge_mu<4, 2>(ctx, a, nq, bs);
     else if (sd == 8) launch_qmerge_mu<8, 2>(ctx, a, nq, bs);
     else if (sd == 16) launch_qmerge_mu<16, 2>(ctx, a, nq, bs);
+    else ok = false;
+  } else if (m == 48) {
+    if (sd == 4) launch_qmerge_mu<4, 3>(ctx, a, nq, bs);
+    else if (sd == 8) launch_qmerge_mu<8, 3>(ctx, a, nq, bs);
+    else if (sd == 16) launch_qmerge_mu<16, 3>(ctx, a, nq, bs);
+    else ok = false;
+  } else if (m == 64) {
+    if (sd == 4) launch_qmerge_mu<4, 4>(ctx, a, nq, bs);
+    else if (sd == 8) launch_qmerge_mu<8, 4>(ctx, a, nq, bs);
+    else if (sd == 16) launch_qmerge_mu<16, 4>(ctx, a, nq, bs);
+    else ok = false;
+  } else if (m == 96) {
+    if (sd == 4) launch_qmerge_mu<4, 6>(ctx, a, nq, bs);
+    else if (sd == 8) launch_qmerge_mu<8, 6>(ctx, a, nq, bs);
+    else if (sd == 16) launch_qmerge_mu<16, 6>(ctx, a, nq, bs);
     else ok = false;
   } else ok = false;
   LH_REQUIRE(ok, "quantised scan merge: unsupported shape (m=%d, sd=%d)", m, sd);

@@ -44,6 +44,98 @@ __global__ __launch_bounds__(512) void ub_lds_gather_kernel(const uint8_t *__res
   out[(size_t)blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// Code-major, m-staggered table: entry (c, m) of 8 bytes (4 x u16) at byte c * 8M + 8m; lane l visits the
+// sub-quantisers in the order m = (l + s) mod M (integer sums are order-free).  Bank pair of a ds_read_b64 = (c * M + m) mod 32:
+// for M = 32 every lane of a 32-lane group has its own pair whatever the codes are (conflict-free by construction), for M = 16
+// lanes l and l + 16 share a pair when their codes have the same parity.  Price, modelled here exactly as a scan kernel would
+// pay it: the row's code bytes are rotated once per row by (l mod M) bytes (v_alignbyte + two / three levels of v_cndmask)
+// so that step s reads a compile-time byte position, and the lane-dependent part of the address, 8 * ((l + s) mod M), sits in
+// M registers computed once per kernel; per lookup: byte -> c << log2(8M) (SDWA shift), OR with the step's offset, ds_read_b64,
+// two v_add_u32.
+template <int M>
+__global__ __launch_bounds__(512) void ub_lds_stagger_kernel(const uint8_t *__restrict__ codes, uint32_t *__restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) uint2 slut[];   // [256][M]
+  for (int i = threadIdx.x; i < 256 * M; i += 512) slut[i] = make_uint2((uint32_t)(i % 97), (uint32_t)(i % 89));
+  __syncthreads();
+  constexpr int W = M / 4;                      // code dwords per row
+  constexpr int SH = M == 16 ? 7 : 8;           // log2(8 * M)
+  const uint32_t r = threadIdx.x & (M - 1);
+  uint32_t off[M];
+#pragma unroll
+  for (int s = 0; s < M; ++s) off[s] = ((r + s) & (M - 1)) * 8u;
+  const uint32_t *cw = reinterpret_cast<const uint32_t *>(codes) + ((size_t)blockIdx.x * 512 + threadIdx.x) * 16;
+  uint32_t a0 = 0, a1 = 0;
+  const char *base = reinterpret_cast<const char *>(slut);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16 / W; ++u) {
+      uint32_t b[W], t[W];
+#pragma unroll
+      for (int i = 0; i < W; ++i) b[i] = cw[u * W + i] + it;
+      // bytes rotated left by r: first the in-dword part, then whole dwords by r >> 2
+#pragma unroll
+      for (int i = 0; i < W; ++i) t[i] = __builtin_amdgcn_alignbyte(b[(i + 1) % W], b[i], r & 3u);
+#pragma unroll
+      for (int lvl = 0; (1 << lvl) < W; ++lvl) {
+        const bool on = ((r >> 2) >> lvl) & 1u;
+#pragma unroll
+        for (int i = 0; i < W; ++i) b[i] = on ? t[(i + (1 << lvl)) % W] : t[i];
+#pragma unroll
+        for (int i = 0; i < W; ++i) t[i] = b[i];
+      }
+#pragma unroll
+      for (int s = 0; s < M; ++s) {
+        const uint32_t c = (t[s >> 2] >> (8 * (s & 3))) & 255u;
+        const uint2 v = *reinterpret_cast<const uint2 *>(base + ((c << SH) | off[s]));
+        a0 += v.x; a1 += v.y;
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = a0 ^ a1;
+}
+
+// the same loop on today's [m][code] layout with the same integer accumulate (reference point for the staggered variant)
+__global__ __launch_bounds__(512) void ub_lds_u16x4_kernel(const uint8_t *__restrict__ codes, uint32_t *__restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) uint2 slut[];   // [16][256]
+  for (int i = threadIdx.x; i < 256 * 16; i += 512) slut[i] = make_uint2((uint32_t)(i % 97), (uint32_t)(i % 89));
+  __syncthreads();
+  const uint4 *c4 = reinterpret_cast<const uint4 *>(codes) + ((size_t)blockIdx.x * 512 + threadIdx.x) * 4;
+  uint32_t a0 = 0, a1 = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint4 cw = c4[u];
+      const uint32_t cws[4] = {cw.x + it, cw.y + it, cw.z + it, cw.w + it};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const uint2 v = slut[(e * 4 + b) * 256 + ((cws[e] >> (8 * b)) & 255u)];
+          a0 += v.x; a1 += v.y;
+        }
+    }
+  }
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = a0 ^ a1;
+}
+
+// conflict-free ds_read_b64 stream (lane l reads entry l of a rotating window): the LDS pipe's own ceiling on this box
+__global__ __launch_bounds__(512) void ub_lds_linear_kernel(uint32_t *__restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) uint2 slut[4096];
+  for (int i = threadIdx.x; i < 4096; i += 512) slut[i] = make_uint2((uint32_t)i, (uint32_t)(i * 3));
+  __syncthreads();
+  uint32_t a0 = 0, a1 = 0;
+  uint32_t idx = threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+      const uint2 v = slut[(idx + s * 64) & 4095u];
+      a0 += v.x; a1 += v.y;
+    }
+    idx += a0 & 64u;   // data-dependent so that the loads cannot be hoisted
+  }
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = a0 ^ a1;
+}
+
 __global__ __launch_bounds__(256) void ub_copy_kernel(const f4u *__restrict__ src, f4u *__restrict__ dst, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -78,10 +170,11 @@ extern "C" {
 
 // what: 0..2 = LDS random gather of 4 / 8 / 16-byte entries (result: gathers per second, one gather = one lane's read);
 //       3 = device copy (bytes read + written per second); 4 / 5 = f32 VALU wave-instructions per second (v_add_f32 /
-//       v_pk_add_f32, 64 lanes each)
+//       v_pk_add_f32, 64 lanes each); 6 / 7 = code-major m-staggered u16x4 table, M = 16 / 32 (lane-gathers per second, all
+//       address work included); 8 = today's [m][code] u16x4 table with the same integer accumulate; 9 = conflict-free ds_read_b64
 int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result) {
   LH_REQUIRE(ctx && result, "ubench: NULL argument");
-  LH_REQUIRE(what >= 0 && what <= 5, "ubench: unknown measurement %d", what);
+  LH_REQUIRE(what >= 0 && what <= 9, "ubench: unknown measurement %d", what);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   hipEvent_t e0, e1;
   LH_CHECK_HIP(hipEventCreate(&e0));
@@ -113,6 +206,31 @@ int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result) {
       if (rep) best = std::min(best, ms);
     }
     work = (double)blocks * 512 * iters * 64;
+  } else if (what >= 6) {
+    // 6 / 7: staggered code-major table, M = 16 / 32; 8: today's layout with the integer accumulate; 9: conflict-free ds_read_b64
+    const int blocks = ctx->num_cus * 12, iters = 100;
+    const size_t nbytes = (size_t)blocks * 512 * 64;
+    uint8_t *codes = ctx->scratch_t<uint8_t>("ubench.codes", nbytes);
+    uint32_t *out = ctx->scratch_t<uint32_t>("ubench.out", (size_t)blocks * 512);
+    if (!codes || !out) return LANCE_HIP_ENOMEM;
+    std::vector<uint8_t> h(nbytes);
+    uint32_t s = 12345u;
+    for (auto &v : h) { s = s * 1664525u + 1013904223u; v = (uint8_t)(s >> 24); }
+    LH_CHECK_HIP(hipMemcpyAsync(codes, h.data(), nbytes, hipMemcpyHostToDevice, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int rep = 0; rep < 4; ++rep) {
+      LH_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+      if (what == 6) hipLaunchKernelGGL(ub_lds_stagger_kernel<16>, dim3(blocks), dim3(512), (size_t)256 * 16 * 8, ctx->stream, codes, out, iters);
+      if (what == 7) hipLaunchKernelGGL(ub_lds_stagger_kernel<32>, dim3(blocks), dim3(512), (size_t)256 * 32 * 8, ctx->stream, codes, out, iters);
+      if (what == 8) hipLaunchKernelGGL(ub_lds_u16x4_kernel, dim3(blocks), dim3(512), (size_t)256 * 16 * 8, ctx->stream, codes, out, iters);
+      if (what == 9) hipLaunchKernelGGL(ub_lds_linear_kernel, dim3(blocks), dim3(512), 0, ctx->stream, out, iters);
+      LH_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+      LH_CHECK_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      LH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) best = std::min(best, ms);
+    }
+    work = (double)blocks * 512 * iters * 64;   // lane-gathers: 64 per lane per iteration in every variant
   } else if (what == 3) {
     const size_t n4 = (size_t)64 << 20;   // 1 GiB each way
     f4u *src = ctx->scratch_t<f4u>("ubench.src", n4);

@@ -130,9 +130,13 @@ def _train_kmeans_sharded_device(engine, x_local, cent, k, n_total, max_iters, t
         twin._side_stream = side
         engine._torch_stream_twin = twin
     side = twin._side_stream
-    side.wait_stream(torch.cuda.current_stream())
+    # conversions run on torch's current stream: enqueue them BEFORE the side stream takes its dependency on that stream, so
+    # the E-step never reads a widened / compacted copy that is still being written (f16 or strided shards)
     x_local = x_local.to(torch.float32).contiguous()
     cent = cent.contiguous()
+    side.wait_stream(torch.cuda.current_stream())
+    x_local.record_stream(side)
+    cent.record_stream(side)
     loss, iters = 0.0, 0
     with torch.cuda.stream(side):
         st = twin.kmeans_shard_begin(k, x_local.shape[1], bf_scaled, seed)

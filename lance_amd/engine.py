@@ -330,7 +330,11 @@ class Engine:
         """in-process ceilings for bench.py (lance_hip_ubench): "lds4" / "lds8" / "lds16" lane-gathers per second,
         "copy" bytes per second, "valu" / "valu_pk" f32 wave-instructions per second"""
         r = C.c_double(0)
-        check(self.lib.lance_hip_ubench(self.h, {"lds4": 0, "lds8": 1, "lds16": 2, "copy": 3, "valu": 4, "valu_pk": 5}[what], C.byref(r)))
+        codes = {"lds4": 0, "lds8": 1, "lds16": 2, "copy": 3, "valu": 4, "valu_pk": 5,
+                 # round 3: code-major m-staggered u16x4 table (M = 16 / 32), today's layout with the integer accumulate, and the
+                 # conflict-free ds_read_b64 stream (the LDS pipe's own ceiling)
+                 "lds8_stagger16": 6, "lds8_stagger32": 7, "lds8_u16x4": 8, "lds8_linear": 9}
+        check(self.lib.lance_hip_ubench(self.h, codes[what], C.byref(r)))
         return r.value
 
 
@@ -520,9 +524,10 @@ class DeviceIndex:
         fn = eng.lib.lance_hip_ivfpq_search if sync else eng.lib.lance_hip_ivfpq_search_async
         if sync:
             torch.cuda.synchronize()
-        elif not eng.use_torch_stream and (q is not t or out is None):
-            # the batch was converted / allocated by torch kernels on torch's stream: they must finish before the engine's own
-            # stream reads them (a caller that hands over ready tensors pays nothing)
+        elif not eng.use_torch_stream and (q.data_ptr() != t.data_ptr() or out is None):
+            # the batch was converted / moved / allocated by torch kernels on torch's stream: they must finish before the
+            # engine's own stream reads them.  reshape() always makes a new tensor OBJECT, so the test is on the storage: a
+            # caller that hands over ready device tensors of the index's element type (and `out`) pays nothing
             torch.cuda.current_stream().synchronize()
         check(fn(eng.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
         return ids, dists

@@ -180,18 +180,17 @@ class IvfPqIndex:
         max_np = (min_np if minimum_nprobes is None else nlist) if maximum_nprobes is None else maximum_nprobes
         max_np = max(min(max_np, nlist), min(min_np, nlist))
         min_np = min(min_np, max_np)
-        if distance_range is not None:
-            lo, hi = distance_range
-            ids, dists = self._ix.search_range(q, k, min_np, lo, hi, refine_factor=rf, allow=prefilter)
-            return ids.cpu().numpy(), dists.cpu().numpy()
 
         def run(qq, npb):
+            if distance_range is not None:      # late_search extends range queries too (knn.rs:714-860)
+                lo, hi = distance_range
+                return self._ix.search_range(qq, k, npb, lo, hi, refine_factor=rf, allow=prefilter)
             if prefilter is None:
                 return self._ix.search(qq, k, npb, rf)
             return self._ix.search_filtered(qq, k, npb, prefilter, rf)
 
         ids, dists = run(q, min_np)
-        if max_np > min_np and prefilter is not None and not rf:
+        if max_np > min_np and prefilter is not None and not rf and distance_range is None:
             # late_search's shortcut (knn.rs:741-779): when the prefilter selects no more than k rows, a query that has not
             # found all of them yet gets the rest back with distance +inf instead of searching further partitions
             allow_np = np.ascontiguousarray(prefilter.cpu().numpy() if isinstance(prefilter, torch.Tensor) else prefilter, dtype=bool)

@@ -1,13 +1,21 @@
 """Randomised differential run: HIP path vs CPU oracle on random shapes (not collected by pytest; GPU only).
 
-    python tests/fuzz_parity.py [seconds] [seed] [--dry]
+    python tests/fuzz_parity.py [seconds] [seed] [--dry] [--log FILE] [--case N] [--first N]
 
 --dry replaces the device classes with the oracle-backed stand-ins of tests/oracle_engine.py (CPU): it checks this harness
 itself -- argument order, dtypes, the expectations -- where no GPU exists.
 
-Every case builds an IVF_PQ index from oracle-trained models, then compares encode output, storage layout, searches
+Every case draws its configuration from its own generator seeded with (seed, case number), so `--case N` replays exactly one
+case.  A case builds an IVF_PQ index from oracle-trained models, then compares encode output, storage layout, searches
 (random k / nprobes / refine), distance ranges, row-id prefilters, a save -> load round trip through the index files, the
-flat scan and IVF_FLAT, bit for bit.  Prints the failing configuration and exits 1.
+flat scan and IVF_FLAT, bit for bit.  Three case families:
+  small  -- 40 queries, every shape the query-major kernels take (any M / sub-dimension, 4-bit, one partition ...);
+  batch  -- 600..3000 queries so that nq * nprobes >= 4096: the partition-major path with its surrogates (integer bound pass,
+            u16 filter scan, exact re-evaluation; M in {16, 32, 96}, sub-dimension 4 / 8 / 16, f32 / f16 / int8 columns),
+            the MFMA flat filter (batched flat scan) and the MFMA assign;
+  wide   -- rows of more than 128 elements (up to 1536 = the dbpedia shape): K-tiled MFMA assign, any-dimension kernels.
+A mismatch does not stop the run: the failing configuration is printed (and appended to FILE), the case's device objects are
+released and the next case starts; the exit status is 1 if any case failed (at most 25 are collected).
 """
 import os
 import sys
@@ -21,9 +29,186 @@ sys.path.insert(0, ROOT)
 f32 = np.float32
 
 
+def draw_config(rng):
+    fam = str(rng.choice(["small", "small", "batch", "batch", "wide"]))
+    if fam == "small":
+        sd = int(rng.choice([4, 8, 16, 5]))
+        m = int(rng.choice([1, 2, 4, 8, 16, 32])) if sd != 5 else int(rng.choice([4, 8]))
+        n = int(rng.integers(600, 12000))
+        nq = 40
+    elif fam == "batch":
+        sd = int(rng.choice([4, 8, 16]))
+        m = int(rng.choice([16, 16, 32, 96])) if sd != 16 else int(rng.choice([16, 32, 96]))
+        if m == 96 and sd == 4 and rng.random() < 0.5:
+            sd = 16
+        n = int(rng.integers(3000, 40000))
+        nq = int(rng.integers(600, 3000))
+    else:
+        sd = int(rng.choice([8, 16]))
+        m = int(rng.choice([24, 32, 48, 64, 96]))
+        n = int(rng.integers(2000, 9000))
+        nq = int(rng.choice([40, 40, 700]))
+    d = m * sd
+    if fam == "small" and d > 512:
+        return None
+    nlist = 1 if rng.random() < 0.08 else int(rng.integers(2, 40))   # the reference's own fixtures use one partition
+    if rng.random() < 0.2:
+        nlist = int(rng.integers(64, 130))                           # enough centroids for the MFMA assign (k >= 32 / 64)
+    if fam == "batch" and rng.random() < 0.3:
+        nlist = int(rng.integers(130, 600))
+    metric = str(rng.choice(["l2", "dot", "cosine"]))
+    integer = bool(rng.integers(0, 2))
+    int8 = metric != "cosine" and rng.random() < 0.25          # Int8 column: data int8, model f32
+    f16 = (not int8) and rng.random() < 0.3                    # Float16 column: data and model f16, half::f16's own dot / cosine
+    nbits = 4 if (m % 2 == 0 and rng.random() < 0.2) else 8
+    if int8:
+        integer = True
+    clustered = bool(rng.random() < 0.5)                       # mixture data: partitions of very different sizes, tight bounds
+    return dict(fam=fam, n=n, nq=nq, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer, int8=int8, f16=f16, nbits=nbits,
+                clustered=clustered)
+
+
+def make_data(rng, c):
+    n, nq, d, metric = c["n"], c["nq"], c["d"], c["metric"]
+    shift = 1.0 if metric == "cosine" else 0.0
+    if c["clustered"]:
+        nc = int(rng.integers(3, 30))
+        if c["integer"]:
+            cen = rng.integers(0, 30, (nc, d)).astype(f32)
+            x = cen[rng.integers(0, nc, n)] + rng.integers(-3, 4, (n, d)).astype(f32)
+            q = cen[rng.integers(0, nc, nq)] + rng.integers(-3, 4, (nq, d)).astype(f32)
+            x = np.clip(x, 0, 29) + shift; q = np.clip(q, 0, 29) + shift
+        else:
+            cen = (rng.standard_normal((nc, d)) * 3).astype(f32)
+            x = (cen[rng.integers(0, nc, n)] + rng.standard_normal((n, d)).astype(f32) + 2 * shift).astype(f32)
+            q = (cen[rng.integers(0, nc, nq)] + rng.standard_normal((nq, d)).astype(f32) + 2 * shift).astype(f32)
+    elif c["integer"]:
+        x = rng.integers(0, 30, (n, d)).astype(f32) + shift
+        q = rng.integers(0, 30, (nq, d)).astype(f32) + shift
+    else:
+        x = (rng.standard_normal((n, d)) * 3 + 2 * shift).astype(f32)
+        q = (rng.standard_normal((nq, d)) * 3 + 2 * shift).astype(f32)
+    if c["int8"]:
+        x = (x - 15.0).astype(f32); q = (q - 15.0).astype(f32)
+    if c["f16"]:
+        if not c["integer"]:
+            x = x / 3; q = q / 3                                # keep the f16 M-step sums well inside the f16 range
+        x = x.astype(np.float16); q = q.astype(np.float16)     # the oracle calls below take the f16 arrays (dtype-aware arms)
+    return x, q
+
+
+def run_case(rng, c, ncase, eng, classes, torch, oracle):
+    DeviceIndex, DeviceFlatIndex, IvfPqIndex, IvfPqParams = classes
+    n, nq, d, m, nlist, metric, nbits, int8 = c["n"], c["nq"], c["d"], c["m"], c["nlist"], c["metric"], c["nbits"], c["int8"]
+    x, q = make_data(rng, c)
+    xg = torch.from_numpy(x.astype(np.int8)) if int8 else x     # what the engine sees
+    qg = torch.from_numpy(q.astype(np.int8)) if int8 else q
+    held = []
+    try:
+        xs = oracle.normalize(x) if metric == "cosine" else x
+        km = "l2" if metric == "cosine" else metric
+        cent, _, _, _ = oracle.kmeans_train(xs[: max(nlist * 32, nlist)], nlist, max_iters=5, seed=ncase, metric=km)
+        part, _ = oracle.assign(xs, cent, km)
+        res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
+        cb, _ = oracle.pq_train(res[: 256 * 8], m, nbits=nbits, max_iters=4, seed=ncase + 1)
+        oidx = oracle.build_index(x, cent, cb, metric, nbits=nbits)
+        gpart, gcodes, _ = eng.ivfpq_encode(xg, cent, cb, metric)
+        assert (gpart.cpu().numpy().view(np.uint32) == oidx.part_ids).all(), "part ids"
+        assert (gcodes.cpu().numpy() == oidx.codes_rowmajor).all(), "codes"
+        g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=xg, dtype="int8" if int8 else None)
+        held.append(g)
+        offs, codes_t, rid = g.export()
+        assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all(), "layout"
+        big = nq > 100
+        for rep in range(3):
+            k = int(rng.integers(1, 60)); nprobes = int(rng.integers(1, nlist + 1)); rf = int(rng.choice([0, 0, 1, 3]))
+            if big and rep == 0:
+                nprobes = max(nprobes, min(nlist, -(-4096 // nq) + 1))          # nq * nprobes >= 4096: partition-major path
+            if big and rep == 1:
+                nprobes = nlist                                                 # exhaustive probe (v2.rs:1354-1381)
+            if k * max(rf, 1) > 128:
+                rf = 0
+            gi, gd = g.search(qg, k, nprobes, rf)
+            oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x.astype(f32) if rf else None)
+            assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
+            assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
+        # distance range (no refine) and, for 8-bit codes, a row-id prefilter -- against the oracle's restatements
+        k = int(rng.integers(1, 40)); nprobes = int(rng.integers(1, nlist + 1))
+        if big and rng.random() < 0.7:
+            nprobes = max(nprobes, min(nlist, -(-4096 // nq) + 1))
+        _, ud = oidx.search(q[:40], 50, nprobes)
+        fin = ud[np.isfinite(ud)]
+        if fin.size > 10:
+            lo, hi = float(np.quantile(fin, 0.25)), float(np.quantile(fin, 0.7))
+            gi, gd = g.search_range(qg, k, nprobes, lo, hi)
+            oi, od = oidx.search(q, k, nprobes, lower=lo, upper=hi)
+            assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"range k={k} nprobes={nprobes}"
+        if nbits == 8:
+            allow = rng.random(n) < float(rng.choice([0.05, 0.5, 0.95]))
+            vi = IvfPqIndex(g, IvfPqParams(nlist, m, 8, metric), None, gpart, gcodes)
+            gi, gd = vi.nearest(qg, k, nprobes, prefilter=allow)
+            oi, od = oidx.search(q, k, nprobes, prefilter=allow)
+            assert (gi.view(np.uint64) == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), f"prefilter k={k} nprobes={nprobes}"
+        if fin.size > 10:     # prefilter and distance range together, both tested inside the scan (flat/index.rs:131-149); 4-bit too
+            allow = rng.random(n) < float(rng.choice([0.1, 0.6]))
+            gi, gd = g.search_range(qg, k, nprobes, lo, hi, allow=allow)
+            oi, od = oidx.search(q, k, nprobes, lower=lo, upper=hi, prefilter=allow)
+            assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"range+prefilter k={k} nprobes={nprobes}"
+        # files: HBM -> index.idx + auxiliary.idx -> HBM answers the same (f32 / int8 columns)
+        if ncase % 4 == 0:
+            with tempfile.TemporaryDirectory() as tdir:
+                g.save(tdir, loss=1.0)
+                g2 = DeviceIndex.load(eng, tdir, dtype="int8" if int8 else None, raw=xg)
+                held.append(g2)
+                a = g.search(qg, k, nprobes); b = g2.search(qg, k, nprobes)
+                assert (a[0] == b[0]).all() and (a[1].cpu().numpy().view(np.uint32) == b[1].cpu().numpy().view(np.uint32)).all(), "save/load"
+        k = int(rng.integers(1, 40))
+        nqf = nq if (big and d <= 128) else min(nq, 40)          # batches go through the MFMA flat filter (d <= 128)
+        gi, gd = eng.flat_topk(xg, qg[:nqf], k, metric)
+        oi, od = oracle.flat_knn(x, q[:nqf], k, metric)
+        assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"flat k={k} nq={nqf}"
+        if not (int8 and metric == "cosine"):
+            # IVF_FLAT; cosine: rows normalised and stored normalised, L2 coarse quantiser, cosine inside the partitions
+            xs_g = eng.normalize(xg) if metric == "cosine" else xg
+            fpart, _ = eng.assign(xs_g, cent, "l2" if metric == "cosine" else metric)
+            fx = DeviceFlatIndex.create(eng, metric, cent, xs_g, fpart)
+            held.append(fx)
+            nprobes = int(rng.integers(1, nlist + 1))
+            k = min(k, 128)
+            nqi = 8 if not big else int(rng.choice([8, 64]))
+            gi, gd = fx.search(qg[:nqi], k, nprobes)
+            oi, od = oracle.ivfflat_search(x, cent, q[:nqi], k, nprobes, metric)
+            assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat k={k} nprobes={nprobes}"
+            allow = rng.random(n) < float(rng.choice([0.03, 0.5]))       # the mask is tested inside the IVF_FLAT kernels
+            keep = np.nonzero(allow)[0]
+            gi, gd = fx.search(qg[:8], k, nprobes, allow=allow)
+            oi, od = oracle.ivfflat_search(x[keep], cent, q[:8], k, nprobes, metric, row_ids=keep.astype(np.uint64))
+            assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat prefilter k={k} nprobes={nprobes}"
+    finally:
+        for h in held:
+            try:
+                h.close()
+            except Exception:
+                pass
+
+
 def main():
     dry = "--dry" in sys.argv
     args = [a for a in sys.argv[1:] if a != "--dry"]
+    opts = {}
+    for name in ("--log", "--case", "--first"):
+        if name in args:
+            i = args.index(name)
+            opts[name] = args[i + 1]
+            del args[i:i + 2]
+    logf = open(opts["--log"], "a") if "--log" in opts else None
+
+    def say(*a):
+        line = " ".join(str(v) for v in a)
+        print(line, flush=True)
+        if logf:
+            logf.write(line + "\n"); logf.flush()
+
     budget = float(args[0]) if len(args) > 0 else 60.0
     seed = int(args[1]) if len(args) > 1 else 0
     import torch
@@ -39,120 +224,34 @@ def main():
     else:
         from lance_amd.engine import Engine, DeviceIndex, DeviceFlatIndex
     eng = Engine()
-    rng = np.random.default_rng(seed)
-    t_end = time.time() + budget
-    ncase = 0
-    while time.time() < t_end:
-        sd = int(rng.choice([4, 8, 16, 5]))
-        m = int(rng.choice([1, 2, 4, 8, 16, 32])) if sd != 5 else int(rng.choice([4, 8]))
-        d = m * sd
-        if d > 512:
-            continue
-        n = int(rng.integers(600, 12000))
-        nlist = 1 if rng.random() < 0.08 else int(rng.integers(2, 40))   # the reference's own fixtures use one partition
-        if rng.random() < 0.15:
-            nlist = int(rng.integers(64, 130))                           # enough centroids for the MFMA assign (k >= 32 / 64)
-        metric = str(rng.choice(["l2", "dot", "cosine"]))
-        integer = bool(rng.integers(0, 2))
-        int8 = metric != "cosine" and rng.random() < 0.25          # Int8 column: data int8, model f32
-        f16 = (not int8) and rng.random() < 0.3                    # Float16 column: data and model f16, half::f16's own dot / cosine
-        nbits = 4 if (m % 2 == 0 and rng.random() < 0.2) else 8
-        if int8:
-            integer = True
-        if integer:
-            x = rng.integers(0, 30, (n, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
-            q = rng.integers(0, 30, (40, d)).astype(f32) + (1.0 if metric == "cosine" else 0.0)
-        else:
-            x = (rng.standard_normal((n, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
-            q = (rng.standard_normal((40, d)) * 3 + (2.0 if metric == "cosine" else 0.0)).astype(f32)
-        if int8:
-            x = (x - 15.0).astype(f32); q = (q - 15.0).astype(f32)
-        if f16:
-            if not integer:
-                x = x / 3; q = q / 3                                # keep the f16 M-step sums well inside the f16 range
-            x = x.astype(np.float16); q = q.astype(np.float16)     # the oracle calls below take the f16 arrays (dtype-aware arms)
-        xg = torch.from_numpy(x.astype(np.int8)) if int8 else x     # what the engine sees
-        qg = torch.from_numpy(q.astype(np.int8)) if int8 else q
-        cfg = dict(seed=seed, case=ncase, n=n, d=d, m=m, sd=sd, nlist=nlist, metric=metric, integer=integer, int8=int8, f16=f16, nbits=nbits)
-        try:
-            xs = oracle.normalize(x) if metric == "cosine" else x
-            km = "l2" if metric == "cosine" else metric
-            cent, _, _, _ = oracle.kmeans_train(xs[: max(nlist * 32, nlist)], nlist, max_iters=5, seed=ncase, metric=km)
-            part, _ = oracle.assign(xs, cent, km)
-            res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
-            cb, _ = oracle.pq_train(res[: 256 * 8], m, nbits=nbits, max_iters=4, seed=ncase + 1)
-            oidx = oracle.build_index(x, cent, cb, metric, nbits=nbits)
-            gpart, gcodes, _ = eng.ivfpq_encode(xg, cent, cb, metric)
-            assert (gpart.cpu().numpy().view(np.uint32) == oidx.part_ids).all(), "part ids"
-            assert (gcodes.cpu().numpy() == oidx.codes_rowmajor).all(), "codes"
-            g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=xg, dtype="int8" if int8 else None)
-            offs, codes_t, rid = g.export()
-            assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all(), "layout"
-            for _ in range(3):
-                k = int(rng.integers(1, 60)); nprobes = int(rng.integers(1, nlist + 1)); rf = int(rng.choice([0, 0, 1, 3]))
-                if k * max(rf, 1) > 128:
-                    rf = 0
-                gi, gd = g.search(qg, k, nprobes, rf)
-                oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x.astype(f32) if rf else None)
-                assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
-                assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
-            # distance range (no refine) and, for 8-bit codes, a row-id prefilter -- against the oracle's restatements
-            k = int(rng.integers(1, 40)); nprobes = int(rng.integers(1, nlist + 1))
-            _, ud = oidx.search(q, 50, nprobes)
-            fin = ud[np.isfinite(ud)]
-            if fin.size > 10:
-                lo, hi = float(np.quantile(fin, 0.25)), float(np.quantile(fin, 0.7))
-                gi, gd = g.search_range(qg, k, nprobes, lo, hi)
-                oi, od = oidx.search(q, k, nprobes, lower=lo, upper=hi)
-                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"range k={k} nprobes={nprobes}"
-            if nbits == 8:
-                allow = rng.random(n) < float(rng.choice([0.05, 0.5, 0.95]))
-                vi = IvfPqIndex(g, IvfPqParams(nlist, m, 8, metric), None, gpart, gcodes)
-                gi, gd = vi.nearest(qg, k, nprobes, prefilter=allow)
-                oi, od = oidx.search(q, k, nprobes, prefilter=allow)
-                assert (gi.view(np.uint64) == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), f"prefilter k={k} nprobes={nprobes}"
-            if fin.size > 10:     # prefilter and distance range together, both tested inside the scan (flat/index.rs:131-149); 4-bit too
-                allow = rng.random(n) < float(rng.choice([0.1, 0.6]))
-                gi, gd = g.search_range(qg, k, nprobes, lo, hi, allow=allow)
-                oi, od = oidx.search(q, k, nprobes, lower=lo, upper=hi, prefilter=allow)
-                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"range+prefilter k={k} nprobes={nprobes}"
-            # files: HBM -> index.idx + auxiliary.idx -> HBM answers the same (f32 / int8 columns)
-            if ncase % 4 == 0:
-                with tempfile.TemporaryDirectory() as tdir:
-                    g.save(tdir, loss=1.0)
-                    g2 = DeviceIndex.load(eng, tdir, dtype="int8" if int8 else None, raw=xg)
-                    a = g.search(qg, k, nprobes); b = g2.search(qg, k, nprobes)
-                    assert (a[0] == b[0]).all() and (a[1].cpu().numpy().view(np.uint32) == b[1].cpu().numpy().view(np.uint32)).all(), "save/load"
-                    g2.close()
-            k = int(rng.integers(1, 40))
-            gi, gd = eng.flat_topk(xg, qg, k, metric)
-            oi, od = oracle.flat_knn(x, q, k, metric)
-            assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"flat k={k}"
-            if not (int8 and metric == "cosine"):
-                # IVF_FLAT; cosine: rows normalised and stored normalised, L2 coarse quantiser, cosine inside the partitions
-                xs_g = eng.normalize(xg) if metric == "cosine" else xg
-                fpart, _ = eng.assign(xs_g, cent, "l2" if metric == "cosine" else metric)
-                fx = DeviceFlatIndex.create(eng, metric, cent, xs_g, fpart)
-                nprobes = int(rng.integers(1, nlist + 1))
-                k = min(k, 128)
-                gi, gd = fx.search(qg[:8], k, nprobes)
-                oi, od = oracle.ivfflat_search(x, cent, q[:8], k, nprobes, metric)
-                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat k={k} nprobes={nprobes}"
-                allow = rng.random(n) < float(rng.choice([0.03, 0.5]))       # the mask is tested inside the IVF_FLAT kernels
-                keep = np.nonzero(allow)[0]
-                gi, gd = fx.search(qg[:8], k, nprobes, allow=allow)
-                oi, od = oracle.ivfflat_search(x[keep], cent, q[:8], k, nprobes, metric, row_ids=keep.astype(np.uint64))
-                assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"ivf_flat prefilter k={k} nprobes={nprobes}"
-                fx.close()
-            g.close()
-        except AssertionError as e:
-            print("MISMATCH", e, cfg, flush=True)
-            sys.exit(1)
-        except Exception as e:        # an error code from the engine is a finding too: print the configuration that caused it
-            print("ERROR", repr(e), cfg, flush=True)
-            raise
+    classes = (DeviceIndex, DeviceFlatIndex, IvfPqIndex, IvfPqParams)
+    t0 = time.time()
+    t_end = t0 + budget
+    first = int(opts.get("--first", 0))
+    only = int(opts["--case"]) if "--case" in opts else None
+    ncase = first if only is None else only
+    done, failures, fams = 0, [], {}
+    while time.time() < t_end and len(failures) < 25:
+        rng = np.random.default_rng([seed, ncase])
+        c = draw_config(rng)
+        if c is not None:
+            cfg = dict(seed=seed, case=ncase, **c)
+            try:
+                run_case(rng, c, ncase, eng, classes, torch, oracle)
+                fams[c["fam"]] = fams.get(c["fam"], 0) + 1
+                done += 1
+            except AssertionError as e:
+                say("MISMATCH", e, cfg)
+                failures.append(cfg)
+            except Exception as e:        # an error code from the engine is a finding too: print the configuration that caused it
+                say("ERROR", repr(e), cfg)
+                failures.append(cfg)
         ncase += 1
-    print(f"fuzz ok: {ncase} random configurations, seed {seed}", flush=True)
+        if only is not None:
+            break
+    say(f"fuzz {'ok' if not failures else 'FAILED'}: {done} configurations passed ({fams}), {len(failures)} failed, seed {seed}, "
+        f"cases {first if only is None else only}..{ncase - 1}, {time.time() - t0:.0f} s" + (" [dry]" if dry else ""))
+    sys.exit(1 if failures else 0)
 
 
 if __name__ == "__main__":

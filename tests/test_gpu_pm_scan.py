@@ -318,3 +318,66 @@ def test_adaptive_probing_extends_starved_queries(engine, oracle):
         assert (c[i].view(np.uint64)[:want.size] == want).all(), i
         assert (c[i][want.size:] == -1).all()
         assert (cd[i][:found.size].view(np.uint32) == od[i][:found.size].view(np.uint32)).all() and np.isinf(cd[i][found.size:want.size]).all()
+
+
+# ---- M = 48 / 64 / 96: the table tiled over the sub-quantisers (search_qt.hip), 32-bit sums, class B through the rescan kernel
+TILED_SHAPES = [(96 * 16, 96), (96 * 8, 96), (96 * 4, 96), (64 * 16, 64), (64 * 4, 64), (48 * 8, 48), (48 * 16, 48)]
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("d,m", TILED_SHAPES)
+def test_pm_scan_tiled_table_m48_m64_m96(eng, oracle, d, m, metric):
+    """BASELINE config 3's PQ shape (M = 96, sub-dimension 16) and its neighbours at reduced N.  nq * nprobes >= 2048 takes the
+    partition-major path for these shapes.  Partition sizes straddle the 2048-row block of the tiled kernel (one huge
+    partition: the table is rebuilt per row block) and k * refine (tiny partitions: no bound -> class B -> exact rescan)."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(d + m)
+    n, nlist, nq = 18000, 24, 300
+    ncl = 12
+    centers = rng.standard_normal((ncl, d)).astype(f32) * 2
+    w = np.array([30] + [3] * (ncl - 1), dtype=np.float64); w /= w.sum()        # one dominant cluster -> one partition of > 2048 rows
+    x = (centers[rng.choice(ncl, n, p=w)] + rng.standard_normal((n, d)).astype(f32) * 0.7 + (3.0 if metric == "cosine" else 0.0)).astype(f32)
+    q = (centers[rng.choice(ncl, nq, p=w)] + rng.standard_normal((nq, d)).astype(f32) * 0.7 + (3.0 if metric == "cosine" else 0.0)).astype(f32)
+    cent, cb = _models(oracle, x, nlist, m, metric, seed=d + m)
+    oidx = oracle.build_index(x, cent, cb, metric)
+    sizes = np.diff(oidx.part_offsets.astype(np.int64))
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all() and (_np(gcodes) == oidx.codes_rowmajor).all()
+    gidx = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
+    # 300 x 7 = 2100 pairs; k * refine = 120 exceeds the small partitions' row counts for some queries (class B)
+    _check(eng, oracle, gidx, oidx, q, q, x, [(10, 8, 0), (10, 8, 10), (10, nlist, 0), (100, 7, 0), (1, 7, 1), (40, 9, 3)])
+    assert sizes.max() > 1024 and sizes.min() < 100, sizes    # two rows per lane (most cases: several 2048-row blocks) and tiny partitions were really there
+    gidx.close()
+
+
+def test_pm_scan_tiled_table_prefilter_and_class_b(eng, oracle):
+    """M = 96: a selective prefilter (tested inside the tiled bound and scan kernels) and an index whose partitions all hold
+    fewer rows than k * refine, so that EVERY query is class B (no bound -> rescan kernel -> merge)."""
+    from lance_amd.engine import DeviceIndex
+    from lance_amd.vector import IvfPqIndex, IvfPqParams
+    rng = np.random.default_rng(5)
+    n, d, m, nlist, nq = 6000, 96 * 4, 96, 40, 256
+    x = clustered(n, d, 71, ncl=20, integer=False)
+    q = clustered(nq, d, 72, ncl=20, integer=False)
+    cent, cb = _models(oracle, x, nlist, m, "l2", seed=9)
+    oidx = oracle.build_index(x, cent, cb, "l2")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "l2")
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    allow = rng.random(n) < 0.2
+    vi = IvfPqIndex(gidx, IvfPqParams(nlist, m, 8, "l2"), None, gpart, gcodes)
+    with _pm_used(eng):
+        gi, gd = vi.nearest(q, 10, 10, prefilter=allow)
+    oi, od = oidx.search(q, 10, 10, prefilter=allow)
+    assert (gi.view(np.uint64) == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    gidx.close()
+    # 6000 rows over 400 partitions: ~15 rows each, k * refine = 100 -> nobody gets a bound
+    nlist2 = 400
+    cent2 = x[rng.choice(n, nlist2, replace=False)].copy()
+    part2, _ = oracle.assign(x, cent2)
+    res2 = oracle.residual(x, cent2, part2)
+    cb2, _ = oracle.pq_train(res2[:3072], m, max_iters=3, seed=4)
+    oidx2 = oracle.build_index(x, cent2, cb2, "l2")
+    gpart2, gcodes2, _ = eng.ivfpq_encode(x, cent2, cb2, "l2")
+    gidx2 = DeviceIndex.create(eng, "l2", cent2, cb2, gpart2, gcodes2, None, raw=x)
+    _check(eng, oracle, gidx2, oidx2, q, q, x, [(10, 12, 10), (100, 9, 0), (10, 40, 0)])
+    gidx2.close()

@@ -1,0 +1,96 @@
+"""BASELINE configs 3 and 5 at their REAL index parameters (C3: d 1536 cosine, nlist 1024 hierarchical, M 96; C5: int8 rows,
+nlist 65,536, M 32) end to end on the GPU -- training, assign, encode, storage layout, find_partitions, searches up to the
+exhaustive probe (v2.rs:1354-1381: nprobes = nlist), refine, flat ground truth -- against results the CPU oracle produced once
+in the build container (tests/golden/fullconfig.npz, written by tests/golden/make_fullconfig_golden.py; large arrays are
+recorded as SHA-256 digests, search results verbatim).  Every surrogate is on its default setting: K-tiled / register-resident
+MFMA assign, integer bound pass, u16 filter scan, exact re-evaluation."""
+import os
+
+import numpy as np
+import pytest
+
+from fullconfig_spec import C3, C5, c3_data, c5_data, digest, f32
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullconfig.npz")
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import lance_amd
+    return lance_amd.default_engine()
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def same(a, d):
+    return (digest(_np(a)) == d).all()
+
+
+def test_c3_dbpedia_parameters_100k_rows(eng, gold):
+    from lance_amd.engine import DeviceIndex
+    c = C3
+    x, q = c3_data()
+    xs = eng.normalize(x)
+    cent, _, _ = eng.kmeans_train(xs, c["nlist"], max_iters=c["ivf_iters"], balance_factor=1.0, seed=c["seed"])
+    assert cent.shape[0] == c["nlist"]
+    assert same(_np(cent).astype(f32), gold["c3_centroids"]), "hierarchical IVF centroids differ from the oracle's"
+    part, _ = eng.assign(xs, cent, "l2")
+    res = eng.residual(xs, cent, part)
+    cb, its = eng.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=c["seed"] + 1)
+    assert (_np(its).astype(np.uint32) == gold["c3_pq_iters"]).all()
+    assert same(_np(cb).astype(f32), gold["c3_codebook"]), "PQ codebook differs from the oracle's"
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "cosine")
+    assert same(_np(gpart).view(np.uint32), gold["c3_part_ids"]) and same(_np(gcodes), gold["c3_codes"])
+    g = DeviceIndex.create(eng, "cosine", cent, cb, gpart, gcodes, None, raw=x)
+    offs, _, _ = g.export()
+    assert (offs == gold["c3_part_offsets"]).all()
+    for (k, nprobes, rf) in c["searches"]:
+        gi, gd = g.search(q, k, nprobes, rf)
+        assert (_np(gi).view(np.uint64) == gold[f"c3_ids_{k}_{nprobes}_{rf}"]).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == gold[f"c3_dists_{k}_{nprobes}_{rf}"].view(np.uint32)).all(), (k, nprobes, rf)
+    # a batch large enough for the partition-major path (nq * nprobes >= 4096): the same 200 queries tiled, same answers per copy
+    qq = np.tile(q, (3, 1))
+    gi, gd = g.search(qq, 10, 10, 10)
+    want = np.tile(gold["c3_ids_10_10_10"], (3, 1))
+    assert (_np(gi).view(np.uint64) == want).all()
+    assert (_np(gd).view(np.uint32) == np.tile(gold["c3_dists_10_10_10"], (3, 1)).view(np.uint32)).all()
+    gi, gd = eng.flat_topk(x, q[:50], 10, "cosine")
+    assert (_np(gi).view(np.uint64) == gold["c3_flat_ids"]).all() and (_np(gd).view(np.uint32) == gold["c3_flat_dists"].view(np.uint32)).all()
+    g.close()
+
+
+def test_c5_bigann_parameters_nlist_65536_int8(eng, gold):
+    import torch
+    from lance_amd.engine import DeviceIndex
+    c = C5
+    xi, qi = c5_data()
+    xt, qt = torch.from_numpy(xi), torch.from_numpy(qi)
+    init = xi[gold["c5_init_rows"].astype(np.int64)].astype(f32)
+    cent, loss, _ = eng.kmeans_train(xt, c["nlist"], max_iters=1, init=init, seed=c["seed"], hierarchical_k=1)
+    assert loss == float(gold["c5_loss"])
+    assert same(_np(cent).astype(f32), gold["c5_centroids"]), "centroids after one Lloyd iteration differ from the oracle's"
+    part, _ = eng.assign(xt, cent, "l2")
+    res = eng.residual(xi.astype(f32), cent, part)
+    cb, its = eng.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=c["seed"] + 1)
+    assert (_np(its).astype(np.uint32) == gold["c5_pq_iters"]).all()
+    assert same(_np(cb).astype(f32), gold["c5_codebook"])
+    gpart, gcodes, _ = eng.ivfpq_encode(xt, cent, cb, "l2")
+    assert same(_np(gpart).view(np.uint32), gold["c5_part_ids"]) and same(_np(gcodes), gold["c5_codes"])
+    g = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=xt, dtype="int8")
+    offs, _, _ = g.export()
+    assert same(offs.astype(np.uint32), gold["c5_part_offsets_digest"])
+    pi, pd = eng.find_partitions(qt[:200], cent, 64, "l2")
+    assert (_np(pi).view(np.uint32) == gold["c5_probe_ids"]).all() and (_np(pd).view(np.uint32) == gold["c5_probe_dists"].view(np.uint32)).all()
+    for (k, nprobes, rf) in c["searches"]:
+        gi, gd = g.search(qt, k, nprobes, rf)
+        assert (_np(gi).view(np.uint64) == gold[f"c5_ids_{k}_{nprobes}_{rf}"]).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == gold[f"c5_dists_{k}_{nprobes}_{rf}"].view(np.uint32)).all(), (k, nprobes, rf)
+    g.close()
