@@ -34,7 +34,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 (default, the contract workload): SIFT-1M-like f32, IVF_PQ(256, 16).  c4: BASELINE config 4's shape -- "
+                         "f16 rows, IVF_PQ(4096, 16), 12.5M rows PER RANK (100M on 8 GPUs): the configuration where the E-step "
+                         "outweighs the per-iteration all-reduce of the sharded k-means")
+    ap.add_argument("--n", type=int, default=None, help="total rows (default: 1,000,000 for c2; 12,500,000 x ranks for c4)")
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--nprobes", type=int, default=10)
     ap.add_argument("--refine", type=int, default=10)
@@ -69,14 +73,28 @@ def main():
     from lance_amd import vector as lv
 
     eng = lance_amd.default_engine()
-    d, nlist, m = 128, 256, 16
+    d, nlist, m = (128, 256, 16) if args.config == "c2" else (128, 4096, 16)
+    half = args.config == "c4"                      # Float16 column (C4)
+    if args.n is None:
+        args.n = 1_000_000 if args.config == "c2" else 12_500_000 * world
     multi = world > 1 or force_dist
+
+    def gen_rows(count, seed):
+        # c4: 100M rows do not fit through one f32 staging tensor comfortably -- generate in 4M-row pieces, keep f16
+        if not half:
+            return sift_like(count, d, seed=seed, device=dev)
+        out = torch.empty((count, d), dtype=torch.float16, device=dev)
+        for a in range(0, count, 4_000_000):
+            b = min(count, a + 4_000_000)
+            out[a:b] = sift_like(b - a, d, seed=seed + 31 * (a // 4_000_000), device=dev, n_clusters=4096).to(torch.float16)
+        return out
     # 4 different query batches per rank, cycled over the steps
-    qbatches = [sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev) for i in range(4)]
+    qbatches = [(sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev, n_clusters=4096).to(torch.float16) if half else
+                 sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev)) for i in range(4)]
     mg = {}            # multi-GPU extras of the bench line
 
     if not multi:
-        x = sift_like(args.n, d, seed=1234, device=dev)
+        x = gen_rows(args.n, 1234)
 
         def build_once():
             torch.cuda.synchronize()
@@ -99,7 +117,7 @@ def main():
         from lance_amd import dist as ld
         _, ranges = ld.block_ranges(args.n, world)
         lo, hi = ranges[rank]
-        x_local = sift_like(hi - lo, d, seed=1234 + 7919 * rank, device=dev)
+        x_local = gen_rows(hi - lo, 1234 + 7919 * rank)
 
         def build_once(mode):
             torch.cuda.synchronize()
@@ -130,7 +148,8 @@ def main():
         # strong-scaling line: the IVF lists sharded over the ranks (list p -> rank p % N, rows moved by all_to_all), every
         # rank answers the SAME query batches with its lists, one all-gather + device (dist, rowid) merge per batch
         shard, l2g = ld.list_shard_index(bld, x_local)
-        common = [sift_like(args.nq, d, seed=9000 + i, device=dev) for i in range(2)]
+        common = [(sift_like(args.nq, d, seed=9000 + i, device=dev, n_clusters=4096).to(torch.float16) if half else
+                   sift_like(args.nq, d, seed=9000 + i, device=dev)) for i in range(2)]
 
         def lstep(i):
             return ld.search_list_sharded(lambda qq, kk, npb, rf: shard.search(qq, kk, npb, rf), l2g, common[i % 2], args.k, args.nprobes,
@@ -285,8 +304,24 @@ def main():
     copy_bw = eng.ubench("copy")
     hbm_equiv = avg_bytes / (avg_scan_ms * 1e-3) / 1e9 if avg_scan_ms > 0 else 0.0
 
+    # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected separately with rocprofv3 on this
+    # same command and committed under profiles/; gfx950 correction applied as MI355X_MICROARCH.md prescribes) -- per launch
+    traffic, traffic_src = None, None
+    try:
+        pmc_path = os.path.join(ROOT, "profiles", "r03_bench_pmc_tcc.json")
+        pmc = json.load(open(pmc_path))
+        for kn, kv in pmc["kernels"].items():
+            if "ivfpq_qscan_kernel<8, 1>" in kn and quantised and args.config == "c2":
+                traffic = kv["hbm_bytes_per_launch"]
+                traffic_src = ("profiles/r03_bench_pmc_tcc.json: 2 x FETCH_SIZE + WRITE_SIZE per launch of " + kn +
+                               " (rocprofv3 --pmc passes of `bench.py --steps 5 --no-cpu-baseline`, not collected in this run)")
+    except Exception:
+        pass
+    guide_lds_peak = LDS_B64_CONFLICT_FREE_PER_CLK_CU * 256 * 2.4e9      # lane-gathers/s: ds_read_b64, 256 B/clk/CU, 256 CUs, 2.4 GHz
+    c4 = args.config == "c4"
     result = {
-        "metric": "QPS @ recall@10 (SIFT-1M IVF_PQ nlist=256 M=16) + index-build sec",
+        "metric": ("QPS @ recall@10 (SIFT-1M IVF_PQ nlist=256 M=16) + index-build sec" if not c4 else
+                   "QPS @ recall@10 (synthetic f16 x128, IVF_PQ nlist=4096 M=16; BASELINE config 4 shape) + index-build sec"),
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
@@ -296,9 +331,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not c4 else "f16 rows, f32 arithmetic",
         "data": "synthetic",
-        "config": {"workload": "SIFT-1M-like 1Mx128 f32, IVF_PQ nlist=256 M=16 nbits=8, build+search on MI355X",
+        "config": {"workload": ("SIFT-1M-like 1Mx128 f32, IVF_PQ nlist=256 M=16 nbits=8, build+search on MI355X" if not c4 else
+                                f"C4 shape: {args.n} x 128 f16 rows, IVF_PQ nlist=4096 M=16 nbits=8, build+search on MI355X"),
                    "n": args.n, "d": d, "nlist": nlist, "m": m, "queries_per_step_per_gpu": args.nq, "k": args.k,
                    "nprobes": args.nprobes, "refine_factor": args.refine,
                    "parallelism": (f"build: rows sharded over {world} ranks, RCCL all-reduce per Lloyd iteration; search: replica x{world} "
@@ -308,11 +344,20 @@ def main():
         "streams": nstreams,
         "host_buffers_qps_pcie_inclusive": pcie_qps,
         "build_sec": build_sec,
+        # N > 1: the two numbers that say something about scaling (the replica `value` is linear by construction): the SAME
+        # query batches answered jointly by list shards (strong scaling), and the row-sharded build with one all-reduce per
+        # Lloyd iteration.  null at N = 1.  No multi-GPU hardware record exists for them before the driver's SCALE run.
+        "strong_scaling_list_sharded_qps": mg.get("list_sharded_qps_strong_scaling") if mg else None,
+        "build_sec_rows_sharded_allreduce": mg.get("build_sec_ivf_sharded_allreduce") if mg else None,
         "multi_gpu": mg or None,
         "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
         "kernel_ms_per_step": {k_: round(v[0] / max(v[1], 1), 4) for k_, v in kt.items()},
         "roofline": {"kernel": kernel_name, "bound": "lds", "achieved": gather_rate / 1e9, "peak": ceiling / 1e9,
-                     "unit": "G lane-gathers/s", "frac": gather_rate / ceiling if ceiling else None, "traffic": None,
+                     "unit": "G lane-gathers/s", "frac": gather_rate / ceiling if ceiling else None,
+                     "frac_of_guide_lds_peak": gather_rate / guide_lds_peak,
+                     "guide_lds_peak_G_per_s": guide_lds_peak / 1e9,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                     "traffic_vs_algorithmic_code_bytes": (traffic / avg_bytes) if (traffic and avg_bytes) else None,
                      "peak_source": f"lance_hip_ubench({ceil_key}): random ds_read_b64 gathers of a [16][256] table, measured in this run",
                      "queries_per_gather": queries_per_gather,
                      "lut_values_per_s": lut_values / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0,

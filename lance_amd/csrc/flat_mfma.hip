@@ -11,6 +11,15 @@
 // E = 2^-12 (|x|^2 + |q|^2), and only the pairs that pass (a fraction ~ k / rows seen) are recomputed with dist_exact_rt
 // and appended under the exact (key, rowid) test -- so the pools, and the answers, are the exact kernel's.
 // Operand roles as in mfma_assign.hip: B = 32 data rows per wave in registers for the whole query sweep, A = query tiles.
+//
+// Round 3 (profiles/r02_mfma_flat_pmc.json: 8.5 VALU instructions per MFMA, matrix cores busy 14 % of the time): the epilogue
+// no longer evaluates passing pairs inline.  (i) Fast reject: s = fma(-2, x.q, xk - tq) for two pairs per packed instruction,
+// folded into one running minimum (v_min3) -- 1.5 VALU per pair instead of ~6, and no branch unless the minimum is <= 0;
+// (ii) the pairs that pass (about k * rows_in_epoch / rows_seen per query, a wave meets one in half of its tiles) are only
+// APPENDED, as row numbers, to a per-query queue; flat_mfma_eval_kernel then gives every query a workgroup that recomputes its
+// queued rows exactly (one lane per row, all lanes busy) and appends to the pool under the exact (key, rowid) test -- the inline
+// version ran a 128-dimension exact distance with two dependent global loads on one active lane while the wave's MFMA stream
+// stood still.  A queue that overflows raises the pool-overflow flag: the caller's repair loop rescans with the exact kernels.
 #include <algorithm>
 #include <cstdlib>
 
@@ -55,7 +64,11 @@ struct FmArgs {
   FlatPool p;
   const uint16_t *qhi, *qlo;   // [nq][d] bf16 planes of this query chunk
   const float *qn;             // [nq] |q|^2
+  uint32_t *scnt;              // [nq] queued rows of this epoch
+  uint32_t *squeue;            // [nq][FM_SQ_CAP] row numbers whose surrogate distance passed
 };
+
+constexpr int FM_SQ_CAP = 2048;
 
 template <int KS, int METRIC, typename TX>
 __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
@@ -97,7 +110,6 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
   __syncthreads();
   const int64_t row = row0 + wave * 32 + j;
   const bool rvalid = row < p.r1;
-  const uint64_t rid = rvalid ? (p.row_ids ? p.row_ids[row] : (uint64_t)row) : ~0ull;
   // per-lane constant of the test  s - E <= T  <=>  (|q|^2 (1 - 2^-12) + T)'s partner: xk = |x|^2 (1 - 2^-12)
   const float xk = METRIC == METRIC_DOT ? -0.000244140625f * xn2 : xn2 - 0.000244140625f * xn2;
 
@@ -173,29 +185,46 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
     }
     const int q0 = t * FM_QT;
     const float *tqb = tqs + buf * FM_QT;
+    // fast reject: minimum over the lane's 32 pairs of  s = xk - 2 x.q - tq'  (dot: xk + 1 - x.q - tq'), two pairs per packed op.
+    // A NaN s is ignored by the minimum and fails `<=` in the slow path alike (as `sp <= tq` did).
+    const f2 mul2 = METRIC == METRIC_DOT ? f2{-1.0f, -1.0f} : f2{-2.0f, -2.0f};
+    const float xk1 = METRIC == METRIC_DOT ? 1.0f + xk : xk;
+    const f2 xk2 = {xk1, xk1};
+    float mn = INFINITY;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
       for (int vq = 0; vq < 4; ++vq) {
         const int ib = blk * 32 + 8 * vq + 4 * g;
         const f4 tq4 = *reinterpret_cast<const f4 *>(tqb + ib);
+        const f2 d01 = blk ? f2{acc1[vq * 4 + 0], acc1[vq * 4 + 1]} : f2{acc0[vq * 4 + 0], acc0[vq * 4 + 1]};
+        const f2 d23 = blk ? f2{acc1[vq * 4 + 2], acc1[vq * 4 + 3]} : f2{acc0[vq * 4 + 2], acc0[vq * 4 + 3]};
+        const f2 s01 = __builtin_elementwise_fma(mul2, d01, xk2 - f2{tq4.x, tq4.y});
+        const f2 s23 = __builtin_elementwise_fma(mul2, d23, xk2 - f2{tq4.z, tq4.w});
+        mn = __builtin_fminf(mn, __builtin_fminf(s01.x, s01.y));
+        mn = __builtin_fminf(mn, __builtin_fminf(s23.x, s23.y));
+      }
+    }
+    // Every pair the round-2 test `fma(-2, x.q, xk) <= tq` passed still passes: for finite operands the two forms differ by
+    // 2^-24 |xk - tq|, and a pair near the boundary has |xk - tq| ~ 2 |x.q| <= |x|^2 + |q|^2, far inside the 3 * 2^-14 (|x|^2 +
+    // |q|^2) the margin has to spare; tq = +inf gives s = -inf; a row whose |x|^2 overflowed (xk not finite: inf - inf = NaN,
+    // which the minimum ignores) takes the slow path with the permissive comparison below.
+    const bool odd = !(__builtin_fabsf(xk1) < INFINITY);
+    if ((mn <= 0.0f || odd) && rvalid) {   // rare per lane (~1 % of lane-tiles): find the pairs, queue the row for each of their queries
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float dot = blk ? acc1[vq * 4 + e] : acc0[vq * 4 + e];
-          // L2: |x|^2(1-eps) - 2 x.q <= T - |q|^2(1-eps)      dot: 1 - x.q - eps|x|^2 <= T + eps|q|^2
-          const float sp = METRIC == METRIC_DOT ? (1.0f - dot) + xk : __builtin_fmaf(-2.0f, dot, xk);
-          if (sp <= tq4[e] && rvalid) {
-            const int qi = q0 + ib + e;   // < nq: padded queries carry ptq = -inf
-            // (q - x)^2 == (x - q)^2 and q*x == x*q bit for bit: the query is the f32 operand, the row is widened per element
-            const float v = finish_metric<METRIC>(dist_exact_rt<METRIC, TX>(p.q + (int64_t)qi * D, static_cast<const TX *>(p.x_native) + row * D, D));
-            const uint32_t key = order_key(v);
-            const uint32_t tk = p.tkey[qi];
-            if (key < tk || (key == tk && rid <= p.trid[qi])) {
-              const uint32_t pos = atomicAdd(&p.cnt[qi], 1u);
-              if (pos < (uint32_t)p.cap) {
-                p.pkeys[(int64_t)qi * p.cap + pos] = key;
-                p.prids[(int64_t)qi * p.cap + pos] = rid;
-              }
+      for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq) {
+          const int ib = blk * 32 + 8 * vq + 4 * g;
+          const f4 tq4 = *reinterpret_cast<const f4 *>(tqb + ib);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dot = blk ? acc1[vq * 4 + e] : acc0[vq * 4 + e];
+            const float sv = __builtin_fmaf(mul2.x, dot, xk1 - tq4[e]);
+            if (odd ? !(sv > 0.0f) : (sv <= 0.0f)) {
+              const int qi = q0 + ib + e;   // < nq: padded queries carry tq' = -inf
+              const uint32_t pos = atomicAdd(&a.scnt[qi], 1u);
+              if (pos < (uint32_t)FM_SQ_CAP) a.squeue[(int64_t)qi * FM_SQ_CAP + pos] = (uint32_t)(row - p.r0);
             }
           }
         }
@@ -203,6 +232,34 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
     }
     if (tn < ntiles) store(buf ^ 1);
     __syncthreads();
+  }
+}
+
+// exact evaluation of the queued (query, row) pairs: one workgroup per query, one lane per queued row
+template <int METRIC, typename TX>
+__global__ __launch_bounds__(256) void flat_mfma_eval_kernel(FmArgs a, int d) {
+  const FlatPool &p = a.p;
+  const int qi = blockIdx.x;
+  const uint32_t raw = a.scnt[qi];
+  if (raw == 0) return;
+  if (raw > (uint32_t)FM_SQ_CAP && threadIdx.x == 0) atomicOr(p.overflow, 1u);   // rows were lost: the caller's repair loop rescans
+  const int c = (int)min(raw, (uint32_t)FM_SQ_CAP);
+  const uint32_t tk = p.tkey[qi];
+  const uint64_t tr = p.trid[qi];
+  const float *qv = p.q + (int64_t)qi * d;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    const int64_t row = p.r0 + (int64_t)a.squeue[(int64_t)qi * FM_SQ_CAP + i];
+    const uint64_t rid = p.row_ids ? p.row_ids[row] : (uint64_t)row;
+    // (q - x)^2 == (x - q)^2 and q*x == x*q bit for bit: the query is the f32 operand, the row is widened per element
+    const float v = finish_metric<METRIC>(dist_exact_rt<METRIC, TX>(qv, static_cast<const TX *>(p.x_native) + row * d, d));
+    const uint32_t key = order_key(v);
+    if (key < tk || (key == tk && rid <= tr)) {
+      const uint32_t pos = atomicAdd(&p.cnt[qi], 1u);
+      if (pos < (uint32_t)p.cap) {
+        p.pkeys[(int64_t)qi * p.cap + pos] = key;
+        p.prids[(int64_t)qi * p.cap + pos] = rid;
+      }
+    }
   }
 }
 
@@ -236,12 +293,28 @@ static void fm_launch_ks(lance_hip_ctx *ctx, const FmArgs &a, int metric, dim3 g
   else go(float());
 }
 
+static void fm_launch_eval(lance_hip_ctx *ctx, const FmArgs &a, int metric, int d) {
+  auto go = [&](auto tag) {
+    using TX = decltype(tag);
+    if (metric == METRIC_DOT) hipLaunchKernelGGL((flat_mfma_eval_kernel<METRIC_DOT, TX>), dim3(a.p.nq), dim3(256), 0, ctx->stream, a, d);
+    else hipLaunchKernelGGL((flat_mfma_eval_kernel<METRIC_L2, TX>), dim3(a.p.nq), dim3(256), 0, ctx->stream, a, d);
+  };
+  if (a.p.x_dtype == LANCE_HIP_F16) go(__half());
+  else if (a.p.x_dtype == LANCE_HIP_I8) go(int8_t());
+  else go(float());
+}
+
 // one epoch of flat.hip's v2 scan (rows [r0, r1) against the chunk's queries) -- every threshold must already be set
 int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int metric, const uint16_t *qhi, const uint16_t *qlo, const float *qn) {
   FmArgs a;
   a.p = e; a.qhi = qhi; a.qlo = qlo; a.qn = qn;
   const int64_t rows = e.r1 - e.r0;
   if (rows <= 0) return LANCE_HIP_OK;
+  LH_REQUIRE(rows < (1ll << 32), "flat scan: an epoch of %lld rows does not fit the 32-bit row queue", (long long)rows);
+  a.scnt = ctx->scratch_t<uint32_t>("fm.scnt", (size_t)e.nq);
+  a.squeue = ctx->scratch_t<uint32_t>("fm.squeue", (size_t)e.nq * FM_SQ_CAP);
+  if (!a.scnt || !a.squeue) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemsetAsync(a.scnt, 0, (size_t)e.nq * 4, ctx->stream));
   const unsigned rblocks = (unsigned)cdiv(rows, FM_ROWS);
   const int qtiles = (e.nq + FM_QT - 1) / FM_QT;
   int z = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(2ll * ctx->num_cus, rblocks)));
@@ -256,6 +329,7 @@ int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int me
     case 7: fm_launch_ks<7>(ctx, a, metric, grid); break;
     default: fm_launch_ks<8>(ctx, a, metric, grid); break;
   }
+  fm_launch_eval(ctx, a, metric, d);
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

@@ -442,56 +442,68 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
   // chunk loads: 128 rows x 32 elements = 512 16-byte pieces per plane; thread -> (row = idx >> 2, piece = idx & 3), 2 per plane
   const int lr0 = threadIdx.x >> 2, lc = threadIdx.x & 3;
-  for (int c0 = 0; c0 < p.k; c0 += MW_CT) {
-    f32x16 acc[4];
+  const int nchunks = dp / MW_KC, ntiles = (p.k + MW_CT - 1) / MW_CT;
+  const int total = nchunks * ntiles;
+  uint4 ga[2][2], gb[2][2];
+  float gcn = 0.0f, gbias = 0.0f;
+  // software pipeline: the global loads of step it + 1 are issued before the MFMAs of step it and land while they run
+  auto fetch = [&](int it) {
+    const int c0 = (it / nchunks) * MW_CT, k0 = (it % nchunks) * MW_KC;
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[b][v] = 0.0f;
-    for (int k0 = 0; k0 < dp; k0 += MW_KC) {
-      uint4 ga[2][2], gb[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int r = lr0 + 64 * u;
-        ga[0][u] = ga[1][u] = gb[0][u] = gb[1][u] = make_uint4(0, 0, 0, 0);
-        if (c0 + r < p.k) {
-          ga[0][u] = *reinterpret_cast<const uint4 *>(p.chi + (int64_t)(c0 + r) * dp + k0 + lc * 8);
-          ga[1][u] = *reinterpret_cast<const uint4 *>(p.clo + (int64_t)(c0 + r) * dp + k0 + lc * 8);
-        }
-        if (row0 + r < p.n) {
-          gb[0][u] = *reinterpret_cast<const uint4 *>(p.xhi + (row0 + r) * dp + k0 + lc * 8);
-          gb[1][u] = *reinterpret_cast<const uint4 *>(p.xlo + (row0 + r) * dp + k0 + lc * 8);
-        }
+    for (int u = 0; u < 2; ++u) {
+      const int r = lr0 + 64 * u;
+      ga[0][u] = ga[1][u] = gb[0][u] = gb[1][u] = make_uint4(0, 0, 0, 0);
+      if (c0 + r < p.k) {
+        ga[0][u] = *reinterpret_cast<const uint4 *>(p.chi + (int64_t)(c0 + r) * dp + k0 + lc * 8);
+        ga[1][u] = *reinterpret_cast<const uint4 *>(p.clo + (int64_t)(c0 + r) * dp + k0 + lc * 8);
       }
-      __syncthreads();          // the previous chunk's fragments have been read
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int r = lr0 + 64 * u;
-        *reinterpret_cast<uint4 *>(&abuf[0][r][lc * 8]) = ga[0][u];
-        *reinterpret_cast<uint4 *>(&abuf[1][r][lc * 8]) = ga[1][u];
-        *reinterpret_cast<uint4 *>(&bbuf[0][r][lc * 8]) = gb[0][u];
-        *reinterpret_cast<uint4 *>(&bbuf[1][r][lc * 8]) = gb[1][u];
-      }
-      if (k0 == 0 && threadIdx.x < MW_CT) {
-        const int c = c0 + threadIdx.x;
-        cns[0][threadIdx.x] = c < p.k ? p.cn[c] : 0.0f;
-        cns[1][threadIdx.x] = (c < p.k && p.bias) ? p.bias[c] : 0.0f;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int s = 0; s < MW_KC / 16; ++s) {
-        const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(&bbuf[0][wave * 32 + j][s * 16 + g * 8]);
-        const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(&bbuf[1][wave * 32 + j][s * 16 + g * 8]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&abuf[0][b * 32 + j][s * 16 + g * 8]);
-          const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&abuf[1][b * 32 + j][s * 16 + g * 8]);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[b], 0, 0, 0);
-        }
+      if (row0 + r < p.n) {
+        gb[0][u] = *reinterpret_cast<const uint4 *>(p.xhi + (row0 + r) * dp + k0 + lc * 8);
+        gb[1][u] = *reinterpret_cast<const uint4 *>(p.xlo + (row0 + r) * dp + k0 + lc * 8);
       }
     }
+    if (k0 == 0 && threadIdx.x < MW_CT) {
+      const int c = c0 + threadIdx.x;
+      gcn = c < p.k ? p.cn[c] : 0.0f;
+      gbias = (c < p.k && p.bias) ? p.bias[c] : 0.0f;
+    }
+  };
+  f32x16 acc[4];
+  fetch(0);
+  for (int it = 0; it < total; ++it) {
+    const int c0 = (it / nchunks) * MW_CT, kc = it % nchunks;
+    if (kc == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[b][v] = 0.0f;
+    }
+    __syncthreads();          // the previous step's fragments (and, at a tile boundary, its cns) have been read
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = lr0 + 64 * u;
+      *reinterpret_cast<uint4 *>(&abuf[0][r][lc * 8]) = ga[0][u];
+      *reinterpret_cast<uint4 *>(&abuf[1][r][lc * 8]) = ga[1][u];
+      *reinterpret_cast<uint4 *>(&bbuf[0][r][lc * 8]) = gb[0][u];
+      *reinterpret_cast<uint4 *>(&bbuf[1][r][lc * 8]) = gb[1][u];
+    }
+    if (kc == 0 && threadIdx.x < MW_CT) { cns[0][threadIdx.x] = gcn; cns[1][threadIdx.x] = gbias; }
+    __syncthreads();
+    if (it + 1 < total) fetch(it + 1);
+#pragma unroll
+    for (int s = 0; s < MW_KC / 16; ++s) {
+      const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(&bbuf[0][wave * 32 + j][s * 16 + g * 8]);
+      const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(&bbuf[1][wave * 32 + j][s * 16 + g * 8]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&abuf[0][b * 32 + j][s * 16 + g * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&abuf[1][b * 32 + j][s * 16 + g * 8]);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[b], 0, 0, 0);
+      }
+    }
+    if (kc != nchunks - 1) continue;
     // D[centroid i][row j]: lane (j, g) holds centroids i = (v & 3) + 8 (v >> 2) + 4 g of each 32-block (as in ma_top3_kernel)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -518,7 +530,6 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
           for (int e = 0; e < 4; ++e) top4_insert(tp, sv[vq * 4 + e], (uint32_t)(c0 + b * 32 + 8 * vq + 4 * g + e));
       }
     }
-    // (the next super-tile's first __syncthreads orders these cns reads before its cns writes)
   }
   {
     const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
@@ -541,16 +552,20 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   }
 }
 
-// exact re-check for wide rows: one wave per row, the row staged in LDS, lane t < 3 takes candidate t (reference arithmetic,
-// run-time dimension); lane 0 applies argmin_value_float's rule -- strictly smallest biased value, smallest index on ties,
-// NaN never selected (kernels.rs:79-111).  Undecided rows go to ma_recompute_kernel's list.
+// exact re-check for wide rows: one wave per row, the row staged in LDS, one 16-lane group per candidate.  Lane i of a group IS
+// lane accumulator i of the reference's l2_scalar / dot_scalar (sums[i] over the 16-chunks in order), the d % 16 remainder is
+// summed first in element order, and the 16 partial sums are folded in lane order through shuffles -- dist_exact_rt's result,
+// with the candidate's centroid read as 64-byte segments.  Lane 0 applies argmin_value_float's rule -- strictly smallest biased
+// value, smallest index on ties, NaN never selected (kernels.rs:79-111).  Undecided rows go to ma_recompute_kernel's list.
 template <int METRIC, typename TX, int LANES>
 __global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
+  static_assert(LANES == 16, "16 lane accumulators: one per lane of a candidate's group");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.active && !p.active[0]) return;
   float *wrow = reinterpret_cast<float *>(smem) + (threadIdx.x >> 6) * p.d;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, grp = lane >> 4, i = lane & 15;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int d = p.d, full = d / 16 * 16;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.n; row += nwaves) {
     const uint8_t cl = p.cls[row];
     if (cl == 3) {       // wave-uniform
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
       continue;
     }
     bool fin = true;
-    for (int e = lane; e < p.d; e += 64) {
+    for (int e = lane; e < d; e += 64) {
       const float v = ld_elem(static_cast<const TX *>(p.x) + row * p.ldx, e);
       wrow[e] = v;
       fin &= isfinite(v);
@@ -566,20 +581,46 @@ __global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
     const bool finite = !p.check_finite || __all(fin);
     __builtin_amdgcn_wave_barrier();
     uint32_t c = LANCE_HIP_NONE;
-    float v = INFINITY, vb = INFINITY;
-    if (lane <= (int)cl) {
-      c = lane == 0 ? p.id1[row] : (lane == 1 ? p.id2[row] : p.id3[row]);
-      if (c != LANCE_HIP_NONE) {
-        v = finish_metric<METRIC>(dist_exact_rt<METRIC, float, LANES>(wrow, p.cent + (int64_t)c * p.d, p.d));
-        vb = p.bias ? v + p.bias[c] : v;
+    if (grp <= (int)cl && grp < 3) c = grp == 0 ? p.id1[row] : (grp == 1 ? p.id2[row] : p.id3[row]);
+    float s = 0.0f, acc = 0.0f;
+    if (c != LANCE_HIP_NONE) {
+      const float *y = p.cent + (int64_t)c * d;
+      if (full != d) {       // remainder first, in element order (every lane of the group computes the same value)
+        float r = 0.0f;
+        for (int e = full; e < d; ++e) {
+          if constexpr (METRIC == METRIC_DOT) {
+            r = r + wrow[e] * y[e];
+          } else {
+            const float diff = wrow[e] - y[e];
+            r = r + diff * diff;
+          }
+        }
+        s = r;
       }
+      for (int ch = 0; ch < full; ch += 16) {
+        const float xv = wrow[ch + i], yv = y[ch + i];
+        if constexpr (METRIC == METRIC_DOT) {
+          acc = acc + xv * yv;
+        } else {
+          const float diff = xv - yv;
+          acc = acc + diff * diff;
+        }
+      }
+    }
+    float tot = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) tot = tot + __shfl(acc, (lane & 48) + t, 64);     // ((0 + a0) + a1) + ... + a15
+    float v = INFINITY, vb = INFINITY;
+    if (c != LANCE_HIP_NONE) {
+      v = finish_metric<METRIC>(s + tot);
+      vb = p.bias ? v + p.bias[c] : v;
     }
     uint32_t best = LANCE_HIP_NONE;
     float bestv = INFINITY, bestb = INFINITY;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const uint32_t ct = __shfl(c, t, 64);
-      const float vt = __shfl(v, t, 64), vbt = __shfl(vb, t, 64);
+      const uint32_t ct = __shfl(c, 16 * t, 64);
+      const float vt = __shfl(v, 16 * t, 64), vbt = __shfl(vb, 16 * t, 64);
       if (t <= (int)cl && ct != LANCE_HIP_NONE) {
         if (vbt < bestb || (vbt == bestb && best != LANCE_HIP_NONE && ct < best)) { bestb = vbt; bestv = vt; best = ct; }
       }

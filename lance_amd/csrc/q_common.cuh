@@ -41,6 +41,7 @@ struct QscanArgs {
   uint32_t *seg_pos;            // [nq * nprobes][Q_CAP] storage positions
   uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
   const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
+  unsigned long long *prof = nullptr;   // -DLH_QT_PROF builds only (tiled kernel): [0] build clocks [1] scan [2] emit [3] items
 };
 
 

@@ -701,11 +701,26 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   const size_t lds = qscan_lds_bytes(d, m);
   const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;
+#ifdef LH_QT_PROF
+  static const bool qt_prof = getenv("LANCE_HIP_QT_PROF") != nullptr;
+  if (qt_prof && qscan_tiled_shape(m, sd)) {
+    a.prof = ctx->scratch_t<unsigned long long>("qt.prof", 8);
+    if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
+  }
+#endif
   if (qscan_tiled_shape(m, sd)) ok = qscan_tiled_launch(ctx, a, m, sd, grid);
   else if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
   else if (sd == 16) ok = launch_qscan_sd<16>(ctx, a, m, grid, lds);
   LH_REQUIRE(ok, "quantised scan: unsupported shape (m=%d, sd=%d)", m, sd);
+#ifdef LH_QT_PROF
+  if (a.prof) {
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (h[3]) fprintf(stderr, "[qt prof] items=%llu  100 MHz clocks per item: table build %.0f | row scan %.0f\n", h[3], (double)h[0] / h[3], (double)h[1] / h[3]);
+  }
+#endif
   return LANCE_HIP_OK;
 }
 

@@ -84,6 +84,14 @@ __device__ __forceinline__ void qt_row_tile(const uint2 *lutq, const uint8_t *__
   }
 }
 
+#ifdef LH_QT_PROF
+#define QT_PROF_MARK(v) const long long v = wall_clock64()
+#define QT_PROF_ADD(slot, dv) do { if (threadIdx.x == 0 && p.prof) atomicAdd(&p.prof[slot], (unsigned long long)(dv)); } while (0)
+#else
+#define QT_PROF_MARK(v) do { } while (0)
+#define QT_PROF_ADD(slot, dv) do { } while (0)
+#endif
+
 template <int SD, int MU, int NT>
 __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
   const f4 s4 = *reinterpret_cast<const f4 *>(sc);
   const f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
   const uint8_t *pcodes = p.codes + (int64_t)off * M;
+  QT_PROF_ADD(3, 1);
   for (int row0 = 0; row0 < np; row0 += QT_BS * QT_R) {
     uint32_t acc[QT_R][4];
 #pragma unroll
@@ -132,13 +141,18 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
 #pragma unroll 1
     for (int tile = 0; tile < NT; ++tile) {
       if (tile > 0 || row0 > 0) __syncthreads();   // every lane is done with the previous tile's table
+      QT_PROF_MARK(t0);
       qt_build_tile<SD, MT>(lutq, rq4, p.codebook, tile, c, part, s01, s23);
       __syncthreads();
+      QT_PROF_MARK(t1);
 #pragma unroll
       for (int r = 0; r < QT_R; ++r) {
         const int row = row0 + r * QT_BS + (int)threadIdx.x;
         if (row < np) qt_row_tile<MT>(lutq, pcodes + (int64_t)row * M + tile * MT, acc[r]);
       }
+      QT_PROF_ADD(0, t1 - t0);
+      QT_PROF_MARK(t2);
+      QT_PROF_ADD(1, t2 - t1);
     }
 #pragma unroll
     for (int r = 0; r < QT_R; ++r) {

@@ -5,7 +5,7 @@ digests of the large arrays (trained centroids, codebook, partition ids, PQ code
 
 Cases = BASELINE.json configs 3 and 5 at their real index parameters on a row count the oracle can build in minutes:
   c3: 100,000 x 1536 f32 unit-norm, cosine, IVF_PQ nlist 1024 (hierarchical k-means), M 96 (sub-dimension 16)
-  c5: 300,000 x 128 int8, L2, nlist 65,536 (one flat Lloyd iteration from the reference's random-row init), M 32 (sub-dim 4)
+  c5: 300,000 x 128 int8, L2, nlist 65,536 (centroids = the reference's random-row k-means initialisation: the trainers stop at 4096 per call), M 32 (sub-dim 4)
 """
 import hashlib
 

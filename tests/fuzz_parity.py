@@ -1,6 +1,6 @@
 """Randomised differential run: HIP path vs CPU oracle on random shapes (not collected by pytest; GPU only).
 
-    python tests/fuzz_parity.py [seconds] [seed] [--dry] [--log FILE] [--case N] [--first N]
+    python tests/fuzz_parity.py [seconds] [seed] [--dry] [--log FILE] [--case N] [--first N] [--debug]
 
 --dry replaces the device classes with the oracle-backed stand-ins of tests/oracle_engine.py (CPU): it checks this harness
 itself -- argument order, dtypes, the expectations -- where no GPU exists.
@@ -93,8 +93,36 @@ def make_data(rng, c):
     if c["f16"]:
         if not c["integer"]:
             x = x / 3; q = q / 3                                # keep the f16 M-step sums well inside the f16 range
+        elif metric == "cosine":
+            # normalize_fsl::<Float16Type> sums the squares in half precision: a row whose |x|^2 passes 65504 becomes all zeros and
+            # its cosine distance 0 / 0, whose sign -- hence the order under f32::total_cmp -- is platform-dependent in the reference
+            # itself (tests/test_zz_gpu_zz_ivfflat_ties.py pins the shape of that answer).  Keep the integer rows inside the range.
+            hi = max(2.0, np.floor(np.sqrt(40000.0 / d)))
+            x = np.clip(np.rint(x * (hi / 30.0)), 0, hi) + 1.0; q = np.clip(np.rint(q * (hi / 30.0)), 0, hi) + 1.0
         x = x.astype(np.float16); q = q.astype(np.float16)     # the oracle calls below take the f16 arrays (dtype-aware arms)
     return x, q
+
+
+DEBUG = False
+
+
+def explain(eng, g, qg, q, k, nprobes, rf, gi, gd, oi, od):
+    """--debug: what differs, and whether the same queries in small batches (other kernels: query-major, nsplit > 1) agree"""
+    gi_h, gd_h = gi.cpu().numpy().view(np.uint64), gd.cpu().numpy()
+    bad = np.nonzero((gi_h != oi).any(axis=1))[0]
+    print(f"  [debug] k={k} nprobes={nprobes} rf={rf}: {bad.size} of {gi_h.shape[0]} queries differ, first {bad[:8].tolist()}; exact replays {eng.search_stats()}", flush=True)
+    b = int(bad[0])
+    col = np.nonzero(gi_h[b] != oi[b])[0]
+    print(f"  [debug] query {b}: first differing rank {int(col[0])} of {k}; gpu ids {gi_h[b][max(0, col[0] - 2):col[0] + 4].tolist()} dists {gd_h[b][max(0, col[0] - 2):col[0] + 4].tolist()}", flush=True)
+    print(f"  [debug]            oracle ids {oi[b][max(0, col[0] - 2):col[0] + 4].tolist()} dists {od[b][max(0, col[0] - 2):col[0] + 4].tolist()}", flush=True)
+    same_set = sorted(gi_h[b].tolist()) == sorted(oi[b].tolist())
+    print(f"  [debug]            same id set in another order: {same_set}; distances bit-equal: {bool((gd_h[b].view(np.uint32) == od[b].view(np.uint32)).all())}", flush=True)
+    for chunk in (1, 40, 300):
+        sel = bad[:chunk]
+        qq = qg[sel] if not hasattr(qg, "index_select") else qg[sel.tolist()]
+        si, _ = g.search(qq, k, nprobes, rf)
+        ok = (si.cpu().numpy().view(np.uint64) == oi[sel]).all(axis=1)
+        print(f"  [debug] the first {sel.size} differing queries as one batch of {sel.size}: {int(ok.sum())} now agree; exact replays {eng.search_stats()}", flush=True)
 
 
 def run_case(rng, c, ncase, eng, classes, torch, oracle):
@@ -130,6 +158,8 @@ def run_case(rng, c, ncase, eng, classes, torch, oracle):
                 rf = 0
             gi, gd = g.search(qg, k, nprobes, rf)
             oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x.astype(f32) if rf else None)
+            if DEBUG and not (gi.cpu().numpy().view(np.uint64) == oi).all():
+                explain(eng, g, qg, q, k, nprobes, rf, gi, gd, oi, od)
             assert (gi.cpu().numpy().view(np.uint64) == oi).all(), f"search ids k={k} nprobes={nprobes} rf={rf}"
             assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"search dists k={k} nprobes={nprobes} rf={rf}"
         # distance range (no refine) and, for 8-bit codes, a row-id prefilter -- against the oracle's restatements
@@ -196,6 +226,10 @@ def main():
     dry = "--dry" in sys.argv
     args = [a for a in sys.argv[1:] if a != "--dry"]
     opts = {}
+    global DEBUG
+    if "--debug" in args:
+        DEBUG = True
+        args.remove("--debug")
     for name in ("--log", "--case", "--first"):
         if name in args:
             i = args.index(name)

@@ -54,9 +54,10 @@ def make_c5(out):
     x, q = xi.astype(f32), qi.astype(f32)
     t = time.time()
     init_rows = oracle.kmeans_init_indices(c["n"], c["nlist"], c["seed"])
-    init = x[init_rows.astype(np.int64)]
-    oc, loss, its, _ = oracle.kmeans_train(x, c["nlist"], max_iters=1, init=init, seed=c["seed"])
-    t = tick(t, "c5 one Lloyd iteration against 65,536 centroids")
+    # the trainers (reference and engine alike) stop at 4096 centroids per call; the C5 coarse quantiser here is the reference's
+    # k-means INITIALISATION -- 65,536 distinct random rows (kmeans_random_init, kmeans.rs:149-170) -- which exercises
+    # assign / encode / find_partitions / search at nlist = 65,536 all the same (duplicate rows give exactly tied centroids)
+    oc = np.ascontiguousarray(x[init_rows.astype(np.int64)])
     part, _ = oracle.assign(x, oc)
     res = oracle.residual(x, oc, np.where(part == oracle.NONE, 0, part))
     ocb, pits = oracle.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=c["seed"] + 1)
@@ -64,7 +65,7 @@ def make_c5(out):
     oidx = oracle.build_index(x, oc, ocb, "l2")
     t = tick(t, "c5 build_index")
     out["c5_init_rows"] = init_rows.astype(np.uint64)
-    out["c5_centroids"] = digest(oc); out["c5_loss"] = np.float64(loss); out["c5_codebook"] = digest(ocb)
+    out["c5_centroids"] = digest(oc); out["c5_codebook"] = digest(ocb)
     out["c5_pq_iters"] = pits.astype(np.uint32)
     out["c5_part_ids"] = digest(oidx.part_ids); out["c5_codes"] = digest(oidx.codes_rowmajor)
     out["c5_part_offsets_digest"] = digest(oidx.part_offsets.astype(np.uint32))

@@ -119,3 +119,57 @@ def test_native_index_io_glue_under_sanitizers(tmp_path):
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
     assert "largest chunk 1000 bytes" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c99_program_drives_the_device_entry_points(tmp_path, oracle):
+    """tests/c/device_pipeline.c: a plain-C99 program (no torch, no HIP headers) trains, encodes, builds the storage layout on
+    the host, creates the index from it and searches -- through lance_hip_malloc / memcpy_h2d / the entry points in the call
+    order of integration/rust/lance-linalg/src/hip.rs.  Everything it writes out is compared with the oracle bit for bit."""
+    import subprocess
+    import numpy as np
+    from lance_amd.testing import sift_like
+    f32 = np.float32
+    n, d, nlist, m, nq, k, nprobes, refine, ivf_iters, pq_iters, seed = 30000, 64, 32, 16, 500, 10, 9, 5, 8, 6, 17
+    x = sift_like(n, d, seed=5)
+    q = sift_like(nq, d, seed=6)
+    allow = (np.random.default_rng(3).random(n) < 0.3).astype(np.uint8)
+    inp, outp, exe = tmp_path / "in.bin", tmp_path / "out.bin", tmp_path / "device_pipeline"
+    with open(inp, "wb") as fh:
+        np.array([n, d, nlist, m, nq, k, nprobes, refine, ivf_iters, pq_iters, seed, 0], np.uint32).tofile(fh)
+        x.tofile(fh); q.tofile(fh); allow.tofile(fh)
+    libdir = os.path.join(ROOT, "lance_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "device_pipeline.c"),
+                        "-o", str(exe), "-L", libdir, "-l:liblance_hip.so", "-Wl,-rpath," + libdir], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe), str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+    raw = np.fromfile(outp, np.uint8)
+    pos = 0
+
+    def take(count, dt):
+        nonlocal pos
+        a = raw[pos:pos + count * np.dtype(dt).itemsize].view(dt)
+        pos += count * np.dtype(dt).itemsize
+        return a
+    cent = take(nlist * d, f32).reshape(nlist, d)
+    cb = take(256 * d, f32).reshape(m, 256, d // m)
+    part = take(n, np.uint32)
+    codes = take(n * m, np.uint8).reshape(n, m)
+    probes = take(nq * nprobes, np.uint32).reshape(nq, nprobes)
+    res = [(take(nq * k, np.uint64).reshape(nq, k), take(nq * k, f32).reshape(nq, k)) for _ in range(3)]
+    assert pos == raw.size
+    samp = x[: nlist * 256]
+    oc, _, _, _ = oracle.kmeans_train(samp, nlist, max_iters=ivf_iters, balance_factor=f32(1.0) / f32(samp.shape[0]), seed=seed)
+    assert (cent.view(np.uint32) == oc.view(np.uint32)).all(), "IVF centroids"
+    opart, _ = oracle.assign(x, oc)
+    ores = oracle.residual(x[:65536], oc, opart[:65536])
+    ocb, _ = oracle.pq_train(ores, m, max_iters=pq_iters, seed=seed + 1)
+    assert (cb.view(np.uint32) == ocb.view(np.uint32)).all(), "PQ codebook"
+    oidx = oracle.build_index(x, oc, ocb, "l2")
+    assert (part == oidx.part_ids).all() and (codes == oidx.codes_rowmajor).all()
+    pi, _ = oracle.find_partitions(q, oc, nprobes)
+    assert (probes == pi).all()
+    for (gi, gd), kw in zip(res, (dict(), dict(refine=refine, raw=x), dict(prefilter=allow.astype(bool)))):
+        oi, od = oidx.search(q, k, nprobes, **kw)
+        assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), kw.keys()
