@@ -333,6 +333,15 @@ int lance_hip_index_save(lance_hip_ctx *ctx, const lance_hip_index *idx, const c
 int lance_hip_file_read_column(const char *path, const char *column, void *dst, uint64_t dst_bytes, uint64_t *rows,
                                uint32_t *row_bytes);
 
+/* Shuffle buffers -- the artefact the reference's `precomputed_shuffle_buffers` hand-off carries: rows of (row_id u64,
+ * __ivf_part_id u32, __pq_code FSL<u8>[code_bytes]), un-transposed (python/lance/vector.py:659-665; read back by
+ * IvfIndexBuilder::shuffle_dataset, lance/src/index/vector/builder.rs:509-546).  One Lance v2.0 FILE, written with the same
+ * page encodings the reference's FileWriter uses; rows with part id LANCE_HIP_NONE are dropped; row_ids NULL = row numbers.
+ * HOST pointers.  (Wrapping the file in a dataset directory -- manifest, version files -- stays with the caller's pylance:
+ * the storage engine is outside this library's scope.)                                                           */
+int lance_hip_shuffle_buffer_write(const char *path, const uint64_t *row_ids, const uint32_t *part_ids, const uint8_t *codes,
+                                   uint64_t n, uint32_t code_bytes, uint64_t *rows_written);
+
 /* ---- multi-GPU: merge of per-shard candidate lists (list-sharded search) -------------------------------- */
 /* SortExec([_distance asc, _rowid asc]).with_fetch(k) (lance scanner.rs:3440-3468) over `c` candidates per query gathered
  * from the list shards: ids [nq][c] (int64, -1 = none), dists [nq][c].  With exact_dists != NULL (refine, scanner.rs:2884-

@@ -34,6 +34,7 @@ SYMBOLS = [
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
     "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
     "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench", "lance_hip_merge_topk",
+    "lance_hip_shuffle_buffer_write",
 ]
 
 
@@ -133,6 +134,7 @@ def load():
         "lance_hip_timing_query": (i32, [vp, C.c_char_p, C.POINTER(f64), C.POINTER(u64)]),
         "lance_hip_ubench": (i32, [vp, i32, C.POINTER(f64)]),
         "lance_hip_merge_topk": (i32, [vp, vp, vp, vp, u32, u32, u32, u32, vp, vp]),
+        "lance_hip_shuffle_buffer_write": (i32, [C.c_char_p, vp, vp, vp, u64, u32, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

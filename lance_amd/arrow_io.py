@@ -12,9 +12,13 @@ and pre-assigned rows to the Rust builder, which then skips its own training and
                       codes row-major / un-transposed (python/python/lance/vector.py:659-665; consumed by
                       lance/src/index/vector/builder.rs:509-546).  Rows without a partition are dropped.
 
-Everything here is host-side pyarrow; no GPU is involved.  Writing the buffers as legacy-format Lance files is one
-`lance.file` call on a machine that has pylance; this image does not, so the tests stop at Arrow.
+Everything here is host-side; no GPU is involved.  The shuffle buffers can be written as Arrow IPC (pyarrow) or, round 3, as
+a Lance v2.0 FILE by the library's own writer (write_shuffle_buffers_lance -> lance_hip_shuffle_buffer_write) with the three
+columns above; wrapping that file into the dataset directory the reference opens (manifest, version files) is one
+`lance.write_dataset` call on a machine that has pylance -- this image does not.
 """
+import os
+
 import numpy as np
 import pyarrow as pa
 
@@ -72,6 +76,44 @@ def write_shuffle_buffers_ipc(path, row_ids, part_ids, codes, batch_size=10240):
             w.write_batch(b)
             n += b.num_rows
     return n
+
+
+def write_shuffle_buffers_lance(path, row_ids, part_ids, codes):
+    """The same rows as ONE Lance v2.0 file written by the native writer (lance_hip_shuffle_buffer_write): columns row_id u64,
+    __ivf_part_id u32, __pq_code fixed_size_list<u8>[M] -- the schema IvfIndexBuilder::shuffle_dataset reads back
+    (lance/src/index/vector/builder.rs:509-546; python/lance/vector.py:659-665).  Rows without a partition are dropped.
+    -> rows written.  A pylance host wraps the file into the dataset directory `precomputed_shuffle_buffers` points at
+    (lance.write_dataset(lance.file.LanceFileReader(path).read_all().to_table(), uri, data_storage_version="legacy")); the
+    manifest / version files of a dataset belong to the storage engine, which this package does not rebuild."""
+    import ctypes as C
+    from . import _lib
+    part = np.ascontiguousarray(part_ids).view(np.uint32) if np.asarray(part_ids).dtype == np.int32 else np.ascontiguousarray(part_ids, np.uint32)
+    codes = np.ascontiguousarray(codes, np.uint8)
+    rid = None if row_ids is None else np.ascontiguousarray(row_ids, np.uint64)
+    if codes.ndim != 2 or codes.shape[0] != part.shape[0] or (rid is not None and rid.shape[0] != part.shape[0]):
+        raise ValueError("row ids, partition ids and codes must have the same number of rows")
+    written = C.c_uint64(0)
+    _lib.check(_lib.load().lance_hip_shuffle_buffer_write(os.fsencode(path), None if rid is None else rid.ctypes.data_as(C.c_void_p),
+                                                         part.ctypes.data_as(C.c_void_p), codes.ctypes.data_as(C.c_void_p),
+                                                         part.shape[0], codes.shape[1], C.byref(written)))
+    return int(written.value)
+
+
+def read_shuffle_buffers_lance(path):
+    """-> (row_ids u64 [n], part_ids u32 [n], codes u8 [n, M]) from a file written by write_shuffle_buffers_lance (or by the
+    reference's FileWriter with the same three fixed-width columns), through the native reader."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    out = []
+    for col, dt in (("row_id", np.uint64), ("__ivf_part_id", np.uint32), ("__pq_code", np.uint8)):
+        rows, rb = C.c_uint64(0), C.c_uint32(0)
+        _lib.check(lib.lance_hip_file_read_column(os.fsencode(path), col.encode(), None, 0, C.byref(rows), C.byref(rb)))
+        buf = np.empty(rows.value * rb.value, np.uint8)
+        _lib.check(lib.lance_hip_file_read_column(os.fsencode(path), col.encode(), buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(rows), C.byref(rb)))
+        a = buf.view(dt)
+        out.append(a.reshape(rows.value, -1) if col == "__pq_code" else a)
+    return tuple(out)
 
 
 def centroids_from_batch(batch):

@@ -549,6 +549,41 @@ extern "C" int lance_hip_file_read_column(const char *path, const char *column, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// shuffle buffers: the (row_id, __ivf_part_id, __pq_code) rows an accelerator hands to the reference's index builder
+// (python/lance/vector.py:659-665 output_schema; consumed by IvfIndexBuilder::shuffle_dataset, builder.rs:509-546, which
+// renames row_id -> _rowid).  Written as one Lance v2.0 file with the generic FileWriter (the encodings the reference's own
+// FileWriter emits for u64 / u32 / FSL<u8>); rows whose partition id is LANCE_HIP_NONE are dropped, as the reference's
+// transform drops non-finite vectors before the shuffle.  Host pointers.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int lance_hip_shuffle_buffer_write(const char *path, const uint64_t *row_ids, const uint32_t *part_ids, const uint8_t *codes,
+                                              uint64_t n, uint32_t code_bytes, uint64_t *rows_written) {
+  LH_REQUIRE(path && part_ids && codes && code_bytes > 0, "shuffle_buffer_write: NULL / empty argument");
+  std::vector<uint64_t> rid;
+  std::vector<uint32_t> part;
+  std::vector<uint8_t> cd;
+  rid.reserve(n); part.reserve(n); cd.reserve((size_t)n * code_bytes);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (part_ids[i] == LANCE_HIP_NONE) continue;
+    rid.push_back(row_ids ? row_ids[i] : i);
+    part.push_back(part_ids[i]);
+    cd.insert(cd.end(), codes + (size_t)i * code_bytes, codes + (size_t)(i + 1) * code_bytes);
+  }
+  std::vector<Field> fields(3);
+  fields[0].name = "row_id"; fields[0].id = 0; fields[0].logical_type = "uint64";
+  fields[1].name = "__ivf_part_id"; fields[1].id = 1; fields[1].logical_type = "uint32";
+  fields[2].name = "__pq_code"; fields[2].id = 2; fields[2].logical_type = "fixed_size_list:uint8:" + std::to_string(code_bytes);
+  std::string err;
+  auto w = FileWriter::create(path, fields, &err);
+  if (!w) IO_FAIL(LANCE_HIP_EIO, "shuffle_buffer_write: %s", err.c_str());
+  w->set_column(0, rid.data(), rid.size(), 64, 1);
+  w->set_column(1, part.data(), part.size(), 32, 1);
+  w->set_column(2, cd.data(), rid.size(), 8, code_bytes);
+  if (!w->finish(&err)) IO_FAIL(LANCE_HIP_EIO, "shuffle_buffer_write: %s", err.c_str());
+  if (rows_written) *rows_written = rid.size();
+  return LANCE_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // files <-> HBM
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {

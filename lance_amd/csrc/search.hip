@@ -358,7 +358,13 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
 
     const uint8_t *pcodes = p.codes + (int64_t)off * m;
     for (int base = 0; base < ((p.ablate & 4) ? 0 : np); base += SCAN_ROUND) {
-      if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);  // uniform: misc[0] stable after the barrier
+      // The decision must be the same in every lane, and a lane that runs ahead appends (atomicAdd on misc[0]) as soon as it is
+      // past this point: read the count, THEN a barrier, then decide.  (Round 1-2 read it without the barrier: a wave that saw
+      // the count just over the limit entered tighten()'s barriers while the others were in the scan round -- rows lost or
+      // distances from a half-written state for ~1 query in 1000 of a large batch; found by tests/fuzz_parity.py in round 3.)
+      const bool need_tighten = (int)s.misc[0] > SCAN_CAP - SCAN_ROUND;
+      __syncthreads();
+      if (need_tighten) tighten(s, p.keff);
       const uint32_t T = s.misc[1];
 #pragma unroll
       for (int u = 0; u < SCAN_ROUND / 256; ++u) {
@@ -535,7 +541,9 @@ __global__ __launch_bounds__(256) void ivfpq_scan4_kernel(ScanArgs p) {
     const uint8_t *pcodes = p.codes + (int64_t)off * mb;
     if (!p.allow) pq4_prelude<METRIC, 256>(s.lut, m, pcodes, np, p.keff, q4);   // uniform branch
     for (int base = 0; base < np; base += SCAN_ROUND) {
-      if ((int)s.misc[0] > SCAN_CAP - SCAN_ROUND) tighten(s, p.keff);
+      const bool need_tighten = (int)s.misc[0] > SCAN_CAP - SCAN_ROUND;   // read, barrier, decide (see ivfpq_scan_kernel)
+      __syncthreads();
+      if (need_tighten) tighten(s, p.keff);
       const uint32_t T = s.misc[1];
       for (int u = 0; u < SCAN_ROUND / 256; ++u) {
         const int row = base + u * 256 + threadIdx.x;

@@ -342,9 +342,16 @@ __device__ __forceinline__ void pm_scan_item(const PmArgs &p, const uint32_t ite
   };
   for (int base = 0; base < np; base += ROUND) {
     constexpr int LIMIT = RP == 1 ? CAP - PM_BS : CAP / 2;
-    if ((int)misc[0] > LIMIT) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
-    if ((int)misc[2] > LIMIT) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
-    const uint32_t cnt0_before = misc[0], cnt1_before = misc[2];
+    // counts are read by every lane BEFORE a barrier: lanes past it append to them at once (read, barrier, decide -- the
+    // unguarded read let a fast wave's appends change a slow wave's decision: divergent barriers, see search.hip)
+    uint32_t cnt0_before = misc[0], cnt1_before = misc[2];
+    __syncthreads();
+    if ((int)cnt0_before > LIMIT || (int)cnt1_before > LIMIT) {   // uniform
+      if ((int)cnt0_before > LIMIT) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
+      if ((int)cnt1_before > LIMIT) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
+      cnt0_before = misc[0]; cnt1_before = misc[2];
+      __syncthreads();
+    }
     const uint32_t T0 = misc[1], T1 = misc[3];
     uint4 cwc[RP][MU];
 #pragma unroll
@@ -372,8 +379,10 @@ __device__ __forceinline__ void pm_scan_item(const PmArgs &p, const uint32_t ite
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < RP; ++u) {
-          if ((int)misc[0] > CAP - PM_BS) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
-          if ((int)misc[2] > CAP - PM_BS) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
+          const uint32_t r0 = misc[0], r1 = misc[2];
+          __syncthreads();
+          if ((int)r0 > CAP - PM_BS) tighten_bs<PM_BS, CAP>(b0, p.keff, sorted, &misc[4]);
+          if ((int)r1 > CAP - PM_BS) tighten_bs<PM_BS, CAP>(b1, p.keff, sorted, &misc[4]);
           scan_rows(base, u, cwc[u], misc[1], misc[3]);
           __syncthreads();
         }
@@ -496,7 +505,9 @@ __global__ __launch_bounds__(256) void ivfpq_merge_pm_kernel(const uint32_t *__r
   CandBuf b{ckey, cpos, &misc[0], &misc[1]};
   const uint32_t *pk = pool_key + (int64_t)q * pool_cap, *pp = pool_pos + (int64_t)q * pool_cap;
   for (int base = 0; base < n; base += 512) {
-    if ((int)misc[0] > PMM_CAP - 512) tighten_bs<256, PMM_CAP>(b, o.keff, sorted, &misc[2]);
+    const bool need_tighten = (int)misc[0] > PMM_CAP - 512;   // read, barrier, decide
+    __syncthreads();
+    if (need_tighten) tighten_bs<256, PMM_CAP>(b, o.keff, sorted, &misc[2]);
     const uint32_t T = misc[1];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {

@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
     const uint32_t off = o.part_offsets[part];
     const int np = (int)(o.part_offsets[part + 1] - off);
     for (int base = 0; base < np; base += 256) {
-      if ((int)misc[0] > CAP - 256) tighten_bs<256, CAP>(b, o.keff, sorted, &misc[2]);
+      const bool need_tighten = (int)misc[0] > CAP - 256;   // read, barrier, decide (lanes past this point append at once)
+      __syncthreads();
+      if (need_tighten) tighten_bs<256, CAP>(b, o.keff, sorted, &misc[2]);
       const uint32_t T = misc[1];
       const int row = base + threadIdx.x;
       if (row < np) {
@@ -524,7 +526,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
     const int n = min((int)a.pool_cnt[q], a.pool_cap);
     const uint32_t *pk = a.pool_key + (int64_t)q * a.pool_cap, *pp = a.pool_pos + (int64_t)q * a.pool_cap;
     for (int base = 0; base < n; base += BS) {
-      if ((int)misc[0] > CAP - BS) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+      const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
+      __syncthreads();
+      if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
       const uint32_t T = misc[1];
       const int i = base + threadIdx.x;
       if (i < n) {
@@ -565,7 +569,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
       __syncthreads();
       const int total = (int)s_pre[QM_G];
       for (int base = 0; base < total; base += BS) {
-        if ((int)misc[0] > CAP - BS) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+        const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
+        __syncthreads();
+        if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
         const uint32_t T = misc[1];
         const int t = base + threadIdx.x;
         if (t < total) {

@@ -104,6 +104,7 @@ def make_data(rng, c):
 
 
 DEBUG = False
+METRIC_OF = {}
 
 
 def explain(eng, g, qg, q, k, nprobes, rf, gi, gd, oi, od):
@@ -117,6 +118,22 @@ def explain(eng, g, qg, q, k, nprobes, rf, gi, gd, oi, od):
     print(f"  [debug]            oracle ids {oi[b][max(0, col[0] - 2):col[0] + 4].tolist()} dists {od[b][max(0, col[0] - 2):col[0] + 4].tolist()}", flush=True)
     same_set = sorted(gi_h[b].tolist()) == sorted(oi[b].tolist())
     print(f"  [debug]            same id set in another order: {same_set}; distances bit-equal: {bool((gd_h[b].view(np.uint32) == od[b].view(np.uint32)).all())}", flush=True)
+    # is it the query or its position in the batch?  the whole batch again (three times), then in reverse order
+    for rep in range(3):
+        si, _ = g.search(qg, k, nprobes, rf)
+        bb = np.nonzero((si.cpu().numpy().view(np.uint64) != oi).any(axis=1))[0]
+        print(f"  [debug] whole batch again: {bb.size} differ {bb[:12].tolist()}", flush=True)
+    rev = np.arange(gi_h.shape[0])[::-1].copy()
+    qr = qg[rev] if not hasattr(qg, "index_select") else qg[rev.tolist()]
+    si, _ = g.search(qr, k, nprobes, rf)
+    bb = np.nonzero((si.cpu().numpy().view(np.uint64) != oi[rev]).any(axis=1))[0]
+    print(f"  [debug] batch in reverse order: {bb.size} differ at POSITIONS {bb[:12].tolist()} = queries {rev[bb[:12]].tolist()}", flush=True)
+    try:      # was the missing row's partition probed?
+        missing = [int(v) for v in oi[b] if v not in set(gi_h[b].tolist())]
+        pi, _ = eng.find_partitions(qg[b:b + 1] if not hasattr(qg, "index_select") else qg[b:b + 1], g.centroids, nprobes, METRIC_OF[id(g)])
+        print(f"  [debug] query {b}: rows missing on the gpu {missing[:4]}; gpu probe list {np.asarray(pi.cpu()).reshape(-1)[:40].tolist()}", flush=True)
+    except Exception as e:
+        print("  [debug] probe check failed:", repr(e), flush=True)
     for chunk in (1, 40, 300):
         sel = bad[:chunk]
         qq = qg[sel] if not hasattr(qg, "index_select") else qg[sel.tolist()]
@@ -145,6 +162,7 @@ def run_case(rng, c, ncase, eng, classes, torch, oracle):
         assert (gcodes.cpu().numpy() == oidx.codes_rowmajor).all(), "codes"
         g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=xg, dtype="int8" if int8 else None)
         held.append(g)
+        METRIC_OF[id(g)] = "l2" if metric == "cosine" else metric
         offs, codes_t, rid = g.export()
         assert (offs == oidx.part_offsets).all() and (rid == oidx.row_ids).all() and (codes_t == oidx.codes_t).all(), "layout"
         big = nq > 100

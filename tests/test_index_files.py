@@ -462,3 +462,29 @@ def test_write_validates_arguments(tmp_path):
     c.part_offsets[-1] -= 1
     with pytest.raises(_lib.LanceHipError, match="offsets"):
         IF.write_index_files(tmp_path / "x", c)
+
+
+def test_shuffle_buffers_as_a_lance_file_roundtrip(tmp_path):
+    """lance_hip_shuffle_buffer_write: (row_id, __ivf_part_id, __pq_code) rows as a Lance v2.0 file (python/lance/vector.py:659-665
+    schema), read back column by column with the native reader; rows without a partition are dropped, un-transposed codes."""
+    from lance_amd import arrow_io
+    rng = np.random.default_rng(3)
+    n, m = 70000, 16          # > one 32 MiB page? no: 70000 x 16 B -- several reads of the same page; big enough for two u64 pages? one
+    part = rng.integers(0, 256, n).astype(np.uint32)
+    part[rng.random(n) < 0.01] = 0xFFFFFFFF
+    codes = rng.integers(0, 256, (n, m)).astype(np.uint8)
+    rid = rng.permutation(n).astype(np.uint64) + 5
+    path = str(tmp_path / "shuffle_0.lance")
+    written = arrow_io.write_shuffle_buffers_lance(path, rid, part, codes)
+    keep = part != 0xFFFFFFFF
+    assert written == int(keep.sum())
+    r, p, c = arrow_io.read_shuffle_buffers_lance(path)
+    assert (r == rid[keep]).all() and (p == part[keep]).all() and (c == codes[keep]).all()
+    # the Arrow route yields the same rows
+    got = [b for b in arrow_io.shuffle_buffer_batches(rid, part, codes, batch_size=9000)]
+    assert sum(b.num_rows for b in got) == written
+    assert (np.concatenate([b.column(0).to_numpy() for b in got]) == r).all()
+    # int32 partition ids (what the device returns), implicit row ids
+    written2 = arrow_io.write_shuffle_buffers_lance(str(tmp_path / "s2.lance"), None, part.view(np.int32), codes)
+    r2, _, _ = arrow_io.read_shuffle_buffers_lance(str(tmp_path / "s2.lance"))
+    assert written2 == written and (r2 == np.nonzero(keep)[0].astype(np.uint64)).all()
