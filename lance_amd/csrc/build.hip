@@ -352,7 +352,9 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   pa.lanes32 = f16 && metric == LANCE_HIP_DOT && d > 16;   // coarse quantiser of an f16 column under dot: dot_scalar::<f16, f32, 32>
   // Native route (L2 / dot): the MFMA assign kernels and the fused residual + encode kernel read the rows in the column's own
   // element type -- no f32 copy of the column, no residual array.  Cosine normalises first and takes the staged route.
-  const bool native = metric != LANCE_HIP_COSINE && encode_fused_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf);
+  // (round 3: the sub-quantiser argmin of the fused encode runs on the matrix cores when the shape allows -- pq_mfma.hip)
+  const bool mfma_enc = metric != LANCE_HIP_COSINE && pq_mfma_encode_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf, (int64_t)n);
+  const bool native = metric != LANCE_HIP_COSINE && (mfma_enc || encode_fused_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf));
   bool assign_native = false;
   if (native) {
     pa.x_native = x; pa.x_dtype = dtype;
@@ -371,7 +373,8 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   }
   LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
   if (native) {
-    LH_TRY(launch_encode_fused(ctx, dtype, x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, cbf, (int)m, codes));
+    if (mfma_enc) LH_TRY(launch_pq_mfma_encode(ctx, dtype, x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, cbf, (int)m, codes));
+    else LH_TRY(launch_encode_fused(ctx, dtype, x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, cbf, (int)m, codes));
   } else {
     const float *enc_in = xs;
     if (scan_metric == LANCE_HIP_L2) {

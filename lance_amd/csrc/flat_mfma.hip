@@ -34,6 +34,9 @@ namespace lh {
 typedef short fm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float fm_f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef LH_FM_WAVES
+#define LH_FM_WAVES 2
+#endif
 constexpr int FM_ROWS = 128;
 constexpr int FM_QT = 64;
 
@@ -71,7 +74,7 @@ struct FmArgs {
 constexpr int FM_SQ_CAP = 2048;
 
 template <int KS, int METRIC, typename TX>
-__global__ __launch_bounds__(256, 2) void flat_filter_mfma_kernel(FmArgs a) {
+__global__ __launch_bounds__(256, LH_FM_WAVES) void flat_filter_mfma_kernel(FmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const FlatPool &p = a.p;
   constexpr int D = KS * 16;

@@ -39,6 +39,13 @@ struct PairwiseArgs {
   uint32_t *part_idx = nullptr;
 };
 
+// PQ sub-quantiser argmin (k = 256, sub-dimension 4 / 8 / 16, L2) on the matrix cores with exact re-check (pq_mfma.hip)
+bool pq_mfma_supported(const PairwiseArgs &p, int d, int metric, int batches);
+int launch_pq_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int batches);
+bool pq_mfma_encode_supported(int dtype, int d, int m, int nbits, const void *x, const float *cent, const float *codebook, int64_t n);
+int launch_pq_mfma_encode(lance_hip_ctx *ctx, int dtype, const void *x, int64_t n, int d, const float *cent, const uint32_t *part_ids,
+                          int residual, const float *codebook, int m, uint8_t *codes);
+
 // flat scan v2: per-query candidate pools + threshold pairs (flat.hip)
 struct FlatPool {
   const float *x;       // rows as f32 (NULL when the fixed-dimension kernels read the column in its own element type)

@@ -214,26 +214,41 @@ __global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t i
   atomicAdd(&s_sq, sq);
   if (empty) s_empty = 1;
   __syncthreads();
+  // compute_cluster_sizes: the running-max rule picks, among the clusters of maximal size, the one whose last member comes
+  // first in row order (and cluster 0 when every cluster is empty).  That is an order-free selection -- largest size, then
+  // smallest last row (distinct for non-empty clusters), then smallest id -- so all lanes take part: a single lane walking k
+  // LDS words with a dependent compare each was two thirds of this kernel's 30 us (98 launches per index build).
+  __shared__ uint32_t s_bsz[4], s_blast[4], s_bid[4];
+  {
+    uint32_t bsz = 0, blast = 0xFFFFFFFFu, bid = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < k; i += 256) {
+      const uint32_t v = sz[i], lr = lasts[i];
+      if (v > bsz || (v == bsz && ((v > 0 && lr < blast) || (v == 0 && (uint32_t)i < bid)))) { bsz = v; blast = lr; bid = (uint32_t)i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t osz = __shfl_xor(bsz, o, 64), olast = __shfl_xor(blast, o, 64), oid = __shfl_xor(bid, o, 64);
+      if (osz > bsz || (osz == bsz && ((osz > 0 && olast < blast) || (osz == 0 && oid < bid)))) { bsz = osz; blast = olast; bid = oid; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_bsz[threadIdx.x >> 6] = bsz; s_blast[threadIdx.x >> 6] = blast; s_bid[threadIdx.x >> 6] = bid; }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     KmState &s = c.state[b];
     const double *lb = lbs;
     const float *rb = c.radius + (int64_t)b * k;
-    const uint32_t *lastr = lasts;
     s.iters = it;
-    // compute_cluster_sizes: the running-max rule picks, among the clusters of maximal size, the one whose last member
-    // comes first in row order
-    uint64_t max_size = 0;
-    int max_id = 0;
-    uint32_t max_last = 0xFFFFFFFFu;
-    for (int i = 0; i < k; ++i) {
-      const uint64_t v = sz[i];
-      const uint32_t lr = lastr[i];
-      if (v > max_size || (v == max_size && max_size > 0 && lr < max_last)) { max_size = v; max_id = i; max_last = lr; }
+    uint32_t bsz = s_bsz[0], blast = s_blast[0], bid = s_bid[0];
+    for (int w = 1; w < 4; ++w) {
+      const uint32_t osz = s_bsz[w], olast = s_blast[w], oid = s_bid[w];
+      if (osz > bsz || (osz == bsz && ((osz > 0 && olast < blast) || (osz == 0 && oid < bid)))) { bsz = osz; blast = olast; bid = oid; }
     }
+    const int max_id = bid == 0xFFFFFFFFu ? 0 : (int)bid;
     s.adjusted = (rb[max_id] - (float)lb[max_id] / (float)sz[max_id]) / (float)c.n;
     const float size_loss = (float)(uint64_t)s_sq;
     const float balance_loss = s.bf_used * (size_loss - (float)((uint64_t)c.n * (uint64_t)c.n) / (float)k);
-    double lsum = 0.0;
+    double lsum = 0.0;     // f64 chain in cluster order (the reference's order): unrolled so that the LDS loads run ahead of the adds
+#pragma unroll 8
     for (int i = 0; i < k; ++i) lsum = lsum + lb[i];
     s.last_loss = lsum + (double)balance_loss;
     if (s_empty) {

@@ -39,6 +39,8 @@ struct QscanArgs {
   const uint32_t *tbound;       // [nq] bound key per query (class A: 0 < T < inf)
   uint32_t *seg_cnt;            // [nq * nprobes] survivors of (query, probe) -- zeroed before the launch
   uint32_t *seg_pos;            // [nq * nprobes][Q_CAP] storage positions
+  uint16_t *seg_sum;            // [nq * nprobes][Q_CAP] the survivors' integer sums (<= LIM < 65536): the merge kernel derives a tighter
+                                // cut from them before it re-evaluates anything exactly
   uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
   const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
   unsigned long long *prof = nullptr;   // -DLH_QT_PROF builds only (tiled kernel): [0] build clocks [1] scan [2] emit [3] items

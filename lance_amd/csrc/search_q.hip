@@ -146,6 +146,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
   uint32_t *cand = reinterpret_cast<uint32_t *>(smem);                // [4][Q_CAP]
   uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
   float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T / 65535 (1e30: no such query in this item)
+  uint16_t *csum = reinterpret_cast<uint16_t *>(sc + 4);              // [4][Q_CAP] the survivors' integer sums
 
   // one item per workgroup and no loop: nothing is stored to global memory before the residual loads, so the compiler may
   // (and does) turn them into scalar loads
@@ -224,10 +225,10 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
           const bool p0 = (a0 & 0xFFFFu) <= LIM, p1 = (a0 >> 16) <= LIM, p2 = (a1 & 0xFFFFu) <= LIM, p3 = (a1 >> 16) <= LIM;
           if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
             const uint32_t pos = off + (uint32_t)row;
-            if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) cand[0 * Q_CAP + slot] = pos; }
-            if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) cand[1 * Q_CAP + slot] = pos; }
-            if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) cand[2 * Q_CAP + slot] = pos; }
-            if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) cand[3 * Q_CAP + slot] = pos; }
+            if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) { cand[0 * Q_CAP + slot] = pos; csum[0 * Q_CAP + slot] = (uint16_t)(a0 & 0xFFFFu); } }
+            if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) { cand[1 * Q_CAP + slot] = pos; csum[1 * Q_CAP + slot] = (uint16_t)(a0 >> 16); } }
+            if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) { cand[2 * Q_CAP + slot] = pos; csum[2 * Q_CAP + slot] = (uint16_t)(a1 & 0xFFFFu); } }
+            if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) { cand[3 * Q_CAP + slot] = pos; csum[3 * Q_CAP + slot] = (uint16_t)(a1 >> 16); } }
           }
         }
       }
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
           p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
           if (raw > (uint32_t)Q_CAP) p.qovf[qj[j]] = 1u;
         }
-        for (uint32_t i = threadIdx.x; i < n; i += Q_BS) p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
+        for (uint32_t i = threadIdx.x; i < n; i += Q_BS) {
+          p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
+          p.seg_sum[seg * Q_CAP + i] = csum[j * Q_CAP + i];
+        }
       }
     }
   }
@@ -395,6 +399,10 @@ struct QmergeArgs {
   const uint64_t *row_ids;
   int d, nprobes, round_f16;
   int qm_g;                      // probes whose residuals are staged together (<= QM_G; fewer for long rows: LDS = occupancy)
+  int vec4;                      // d % 4 == 0 and 16-byte aligned query / centroid rows: staged with float4 loads
+  const uint16_t *seg_sum;       // [nq * nprobes][Q_CAP] integer sums of the survivors (scan kernels)
+  int cut_shift;                 // histogram bin = sum >> cut_shift (512 bins cover 0 .. LIM)
+  uint32_t cut_slack;            // a survivor whose sum exceeds (upper edge of the keff-th bin) + cut_slack cannot reach the top keff
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
   uint32_t *tglobal;             // class B: running bound of the exact pair kernel
   const uint32_t *seg_cnt, *seg_pos;
@@ -513,6 +521,14 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   uint32_t *spos = skey + SCAN_LCAP;                                     // [SCAN_LCAP]
   __shared__ uint32_t s_cnt[QM_G + 1], s_pre[QM_G + 1];
   __shared__ int s_amb;
+  // Round 3: the survivors arrive with their integer sums S.  For one query all sums share one scale s, and
+  // S - lo <= dist * s <= S + hi (lo, hi = the rounding slacks of the table encoding), so once keff survivors have S <= B every
+  // survivor with S > B + hi + lo is farther than keff others and cannot be in the answer: a 512-bin histogram of the sums
+  // gives B, and only the survivors under the cut (about 1.1 x keff of the ~2.5 x keff) are re-evaluated exactly -- compacted
+  // first, so that the lanes of a round are all busy.
+  constexpr int QM_LC = 512;                       // compacted survivors per chunk
+  __shared__ uint32_t s_hist[512], l_pos[QM_LC], s_cut, l_cnt;
+  __shared__ uint8_t l_rr[QM_LC];
   const SelectOut &o = a.o;
   const int q = blockIdx.x;
   if (o.flags[q] & FLAG_OVERFLOW) return;   // the exact kernel recomputes this query
@@ -545,6 +561,65 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
     const int dpad = (a.d + 3) & ~3;
     float *r = reinterpret_cast<float *>(smem);   // [QM_G][dpad]
     const float *qv = a.q + (int64_t)q * a.d;
+    // ---- pass A: histogram of the survivors' sums -> cut   (cut_shift < 0: LANCE_HIP_NO_QCUT, every survivor is re-evaluated)
+    for (int i = threadIdx.x; i < 512; i += BS) s_hist[i] = 0u;
+    if (threadIdx.x == 0) s_cut = 0xFFFFFFFFu;
+    for (int g0 = 0; a.cut_shift >= 0 && g0 < a.nprobes; g0 += QM_G) {
+      const int ng = min(QM_G, a.nprobes - g0);
+      __syncthreads();
+      if ((int)threadIdx.x < ng) {
+        const uint32_t c = a.seg_cnt[(int64_t)q * a.nprobes + g0 + threadIdx.x];
+        s_cnt[threadIdx.x] = c > (uint32_t)Q_CAP ? 0u : c;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < QM_G; ++i) { s_pre[i] = run; run += i < ng ? s_cnt[i] : 0u; }
+        s_pre[QM_G] = run;
+      }
+      __syncthreads();
+      const int total = (int)s_pre[QM_G];
+      for (int t = threadIdx.x; t < total; t += BS) {
+        int rr = 0, st = 0;
+#pragma unroll
+        for (int i = 1; i < QM_G; ++i) {
+          const int pi = (int)s_pre[i];
+          if (t >= pi) { rr = i; st = pi; }
+        }
+        const uint32_t sv = a.seg_sum[((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st)];
+        atomicAdd(&s_hist[min(511u, sv >> a.cut_shift)], 1u);
+      }
+    }
+    __syncthreads();
+    if (a.cut_shift >= 0 && threadIdx.x < 64) {   // first bin where the cumulative count reaches keff
+      const int lane = threadIdx.x;
+      uint32_t loc[8], tot = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { loc[i] = s_hist[lane * 8 + i]; tot += loc[i]; }
+      uint32_t incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t tt = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += tt;
+      }
+      uint32_t run = incl - tot;
+      int found = -1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        run += loc[i];
+        if (found < 0 && run >= (uint32_t)o.keff) found = lane * 8 + i;
+      }
+      const uint64_t mask = __ballot(found >= 0);
+      if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        const int bin = __shfl(found, leader, 64);
+        // bin 511 also holds the sums beyond the histogram's range: no upper edge there -> no cut
+        if (lane == 0 && bin < 511) s_cut = (((uint32_t)bin + 1u) << a.cut_shift) - 1u + a.cut_slack;
+      }
+    }
+    __syncthreads();
+    const uint32_t cut = s_cut;
+    // ---- pass B: exact re-evaluation of the survivors under the cut, probe group by probe group
     for (int g0 = 0; g0 < a.nprobes; g0 += a.qm_g) {
       const int ng = min(a.qm_g, a.nprobes - g0);
       __syncthreads();
@@ -552,12 +627,31 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         const uint32_t c = a.seg_cnt[(int64_t)q * a.nprobes + g0 + threadIdx.x];
         s_cnt[threadIdx.x] = c > (uint32_t)Q_CAP ? 0u : c;    // an overflowed segment comes through the pool (rescan kernel)
       }
-      for (int t = threadIdx.x; t < ng * a.d; t += BS) {
-        const int rr = t / a.d, e = t - rr * a.d;
-        const uint32_t part = a.probes[(int64_t)q * a.nprobes + g0 + rr];
-        float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
-        if (a.round_f16) v = __half2float(__float2half_rn(v));
-        r[rr * dpad + e] = v;
+      if (a.vec4) {
+        // long rows (C3: 5 probes x 1536 elements per group): 16-byte loads, four independent ones in flight per lane -- the
+        // element-at-a-time loop below was a chain of 60 dependent L2 round trips per group at d = 1536
+        const int d4 = a.d >> 2, tot4 = ng * d4;
+#pragma unroll 4
+        for (int t = threadIdx.x; t < tot4; t += BS) {
+          const int rr = t / d4, e4 = t - rr * d4;
+          const uint32_t part = a.probes[(int64_t)q * a.nprobes + g0 + rr];
+          const f4 qq = reinterpret_cast<const f4 *>(qv)[e4];
+          const f4 cc = reinterpret_cast<const f4 *>(a.centroids + (int64_t)part * a.d)[e4];
+          f4 v = qq - cc;      // element-wise IEEE subtraction: the same values as the scalar loop
+          if (a.round_f16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __half2float(__float2half_rn(v[e]));
+          }
+          *reinterpret_cast<f4 *>(&r[rr * dpad + 4 * e4]) = v;
+        }
+      } else {
+        for (int t = threadIdx.x; t < ng * a.d; t += BS) {
+          const int rr = t / a.d, e = t - rr * a.d;
+          const uint32_t part = a.probes[(int64_t)q * a.nprobes + g0 + rr];
+          float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
+          if (a.round_f16) v = __half2float(__float2half_rn(v));
+          r[rr * dpad + e] = v;
+        }
       }
       __syncthreads();
       // prefix of the segment sizes, kept in LDS (17 registers less per lane: occupancy is what this kernel lives on)
@@ -568,56 +662,72 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
       }
       __syncthreads();
       const int total = (int)s_pre[QM_G];
-      for (int base = 0; base < total; base += BS) {
-        const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
+      for (int chunk0 = 0; chunk0 < total; chunk0 += QM_LC) {
         __syncthreads();
-        if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
-        const uint32_t T = misc[1];
-        const int t = base + threadIdx.x;
-        if (t < total) {
+        if (threadIdx.x == 0) l_cnt = 0u;
+        __syncthreads();
+        const int cend = min(total, chunk0 + QM_LC);
+        for (int t = chunk0 + threadIdx.x; t < cend; t += BS) {
           int rr = 0, st = 0;
 #pragma unroll
           for (int i = 1; i < QM_G; ++i) {
             const int pi = (int)s_pre[i];
             if (t >= pi) { rr = i; st = pi; }   // s_pre[] is non-decreasing and t < s_pre[QM_G]: the last hit is the segment
           }
-          const uint32_t pos = a.seg_pos[((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st)];
-          const uint8_t *rc = a.codes + (int64_t)pos * M;
-          const float *rres = r + rr * dpad;
-          float dist = 0.0f;   // pq/distance.rs:128-141: += table[code] for m = 0..M-1 -- the table entry is recomputed here
-#pragma unroll
-          for (int w = 0; w < MU; ++w) {
-            const uint4 cw = *reinterpret_cast<const uint4 *>(rc + w * 16);
-            const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-            for (int hh = 0; hh < 16 / Q_MPF; ++hh) {
-              // the codebook entries of Q_MPF sub-quantisers are requested together (one L2 round trip for all of them)
-              f4 cbv[Q_MPF][QV];
-#pragma unroll
-              for (int t8 = 0; t8 < Q_MPF; ++t8) {
-                const int mi = hh * Q_MPF + t8, mm = w * 16 + mi;
-                const uint32_t code = (cws[mi >> 2] >> (8 * (mi & 3))) & 255u;
-                const f4 *src = reinterpret_cast<const f4 *>(a.codebook + ((int64_t)mm * 256 + code) * SD);
-#pragma unroll
-                for (int u = 0; u < QV; ++u) cbv[t8][u] = src[u];
-              }
-#pragma unroll
-              for (int t8 = 0; t8 < Q_MPF; ++t8) {
-                const int mm = w * 16 + hh * Q_MPF + t8;
-                RegVec<SD> av;
-#pragma unroll
-                for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&rres[mm * SD + 4 * u]);
-                dist += finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
-              }
-            }
-          }
-          const uint32_t kk = order_key(dist);
-          if (kk <= T) {
-            const uint32_t slot = atomicAdd(&misc[0], 1u);
-            if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = pos; } else misc[3] = 1u;   // an entry was lost (ties at the bound)
+          const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
+          if ((uint32_t)a.seg_sum[e] <= cut) {
+            const uint32_t slot = atomicAdd(&l_cnt, 1u);
+            l_pos[slot] = a.seg_pos[e]; l_rr[slot] = (uint8_t)rr;
           }
         }
         __syncthreads();
+        const int nl = (int)l_cnt;
+        for (int base = 0; base < nl; base += BS) {
+          const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
+          __syncthreads();
+          if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+          const uint32_t T = misc[1];
+          const int t = base + threadIdx.x;
+          if (t < nl) {
+            const uint32_t pos = l_pos[t];
+            const int rr = (int)l_rr[t];
+            const uint8_t *rc = a.codes + (int64_t)pos * M;
+            const float *rres = r + rr * dpad;
+            float dist = 0.0f;   // pq/distance.rs:128-141: += table[code] for m = 0..M-1 -- the table entry is recomputed here
+#pragma unroll
+            for (int w = 0; w < MU; ++w) {
+              const uint4 cw = *reinterpret_cast<const uint4 *>(rc + w * 16);
+              const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+              for (int hh = 0; hh < 16 / Q_MPF; ++hh) {
+                // the codebook entries of Q_MPF sub-quantisers are requested together (one L2 round trip for all of them)
+                f4 cbv[Q_MPF][QV];
+#pragma unroll
+                for (int t8 = 0; t8 < Q_MPF; ++t8) {
+                  const int mi = hh * Q_MPF + t8, mm = w * 16 + mi;
+                  const uint32_t code = (cws[mi >> 2] >> (8 * (mi & 3))) & 255u;
+                  const f4 *src = reinterpret_cast<const f4 *>(a.codebook + ((int64_t)mm * 256 + code) * SD);
+#pragma unroll
+                  for (int u = 0; u < QV; ++u) cbv[t8][u] = src[u];
+                }
+#pragma unroll
+                for (int t8 = 0; t8 < Q_MPF; ++t8) {
+                  const int mm = w * 16 + hh * Q_MPF + t8;
+                  RegVec<SD> av;
+#pragma unroll
+                  for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&rres[mm * SD + 4 * u]);
+                  dist += finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
+                }
+              }
+            }
+            const uint32_t kk = order_key(dist);
+            if (kk <= T) {
+              const uint32_t slot = atomicAdd(&misc[0], 1u);
+              if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = pos; } else misc[3] = 1u;   // an entry was lost (ties at the bound)
+            }
+          }
+          __syncthreads();
+        }
       }
     }
     __syncthreads();
@@ -657,7 +767,7 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
 
 size_t qscan_lds_bytes(int d, int m) {   // dynamic part (the quantised LUT is static LDS)
   (void)d; (void)m;
-  return (size_t)4 * Q_CAP * 4 + 8 * 4;
+  return (size_t)4 * Q_CAP * 4 + 8 * 4 + (size_t)4 * Q_CAP * 2;   // positions, counters + scales, sums
 }
 
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
@@ -704,6 +814,8 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
+  a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);   // the merge launcher asks for the same slot
+  if (!a.seg_sum) return LANCE_HIP_ENOMEM;
   const size_t lds = qscan_lds_bytes(d, m);
   const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;
@@ -788,6 +900,20 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   {   // staged residuals: at most 32 KiB per workgroup (d = 1536: 5 probes at a time)
     const int dpad = (d + 3) & ~3;
     a.qm_g = std::max(1, std::min(QM_G, 32768 / (dpad * 4)));
+    a.vec4 = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(qs) | reinterpret_cast<uintptr_t>(ix->centroids)) & 15) == 0;
+  }
+  {
+    // the survivors' sums (written by the scan launcher into the same scratch slot) and the cut's parameters.  Encodings:
+    //   M = 16 / 32 (search_q.hip):    |e - L s| <= 1 per entry, +2 for the f32 terms: S - (M + 2) <= dist * s <= S + (M + 2);
+    //                                  LIM = SE + M + 2 with SE ~ 65535 / M: 3986 / 2018 -> bins of 8 / 4
+    //   M = 48 / 64 / 96 (search_qt.hip): floor-like entries over the full u16 range: S - 4 <= dist * s <= S + 1.5 M + 4;
+    //                                  LIM = 61444 -> bins of 128
+    static const bool no_cut = getenv("LANCE_HIP_NO_QCUT") != nullptr;
+    a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);
+    if (!a.seg_sum) return LANCE_HIP_ENOMEM;
+    const bool tiled = qscan_tiled_shape(m, sd);
+    a.cut_shift = no_cut ? -1 : (tiled ? 7 : (m == 16 ? 3 : 2));
+    a.cut_slack = tiled ? (uint32_t)(2 * m + 8) : (uint32_t)(2 * m + 4);
   }
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
   bool ok = true;

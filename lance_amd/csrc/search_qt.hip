@@ -62,7 +62,18 @@ __device__ __forceinline__ void qt_build_tile(uint2 *lutq, cf4_ptr rq4, const fl
   for (int i = 0; i < MTP; ++i) {
     const int ml = part * MTP + i, mm = tile * MT + ml;
     f2 acc01, acc23;
+#if LH_QT_ABLATE == 1      // perf experiment: no arithmetic -- one codeword load and one residual load per entry stay
+    { const f4 cv = *reinterpret_cast<const f4 *>(codebook + ((int64_t)mm * 256 + c) * SD); const f4 rv = rq4[mm * SD];
+      acc01 = f2{cv.x + rv.x, cv.y + rv.y}; acc23 = f2{cv.z + rv.z, cv.w + rv.w}; }
+#elif LH_QT_ABLATE == 2    // perf experiment: no codeword loads (the lane's own index stands in for the codeword)
+    { float fake[SD]; for (int u = 0; u < SD; ++u) fake[u] = (float)(c + u + mm); q_entry_acc<SD>(rq4 + mm * SD, fake, acc01, acc23); }
+#elif LH_QT_ABLATE == 3    // perf experiment: no residual loads (constants instead): codeword loads + arithmetic
+    { acc01 = f2{0.f, 0.f}; acc23 = f2{0.f, 0.f}; const float *cbp = codebook + ((int64_t)mm * 256 + c) * SD;
+      for (int u = 0; u < SD; ++u) { const float cv = cbp[u]; const f2 cc = {cv, cv}; const f2 d01 = f2{1.0f + u, 2.0f} + cc, d23 = f2{3.0f, 4.0f + mm} + cc;
+        acc01 = __builtin_elementwise_fma(d01, d01, acc01); acc23 = __builtin_elementwise_fma(d23, d23, acc23); } }
+#else
     q_entry_acc<SD>(rq4 + mm * SD, codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
+#endif
     lutq[ml * 256 + c] = q_entry_quantise_floor(acc01, acc23, s01, s23);
   }
 }
@@ -84,6 +95,9 @@ __device__ __forceinline__ void qt_row_tile(const uint2 *lutq, const uint8_t *__
   }
 }
 
+#ifndef LH_QT_ABLATE
+#define LH_QT_ABLATE 0
+#endif
 #ifdef LH_QT_PROF
 #define QT_PROF_MARK(v) const long long v = wall_clock64()
 #define QT_PROF_ADD(slot, dv) do { if (threadIdx.x == 0 && p.prof) atomicAdd(&p.prof[slot], (unsigned long long)(dv)); } while (0)
@@ -102,6 +116,7 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
   uint32_t *cand = reinterpret_cast<uint32_t *>(smem);                // [4][Q_CAP]
   uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
   float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T / 65535 (1e30: no such query in this item)
+  uint16_t *csum = reinterpret_cast<uint16_t *>(sc + 4);              // [4][Q_CAP] the survivors' integer sums (<= QT_LIM < 65536)
   const uint32_t item = blockIdx.x;
   if (item >= p.item_start[p.nlist]) return;
   const int4 dsc = p.desc[item];
@@ -161,10 +176,10 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
         const bool p0 = acc[r][0] <= QT_LIM, p1 = acc[r][1] <= QT_LIM, p2 = acc[r][2] <= QT_LIM, p3 = acc[r][3] <= QT_LIM;
         if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
           const uint32_t pos = off + (uint32_t)row;
-          if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) cand[0 * Q_CAP + slot] = pos; }
-          if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) cand[1 * Q_CAP + slot] = pos; }
-          if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) cand[2 * Q_CAP + slot] = pos; }
-          if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) cand[3 * Q_CAP + slot] = pos; }
+          if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) { cand[0 * Q_CAP + slot] = pos; csum[0 * Q_CAP + slot] = (uint16_t)acc[r][0]; } }
+          if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) { cand[1 * Q_CAP + slot] = pos; csum[1 * Q_CAP + slot] = (uint16_t)acc[r][1]; } }
+          if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) { cand[2 * Q_CAP + slot] = pos; csum[2 * Q_CAP + slot] = (uint16_t)acc[r][2]; } }
+          if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) { cand[3 * Q_CAP + slot] = pos; csum[3 * Q_CAP + slot] = (uint16_t)acc[r][3]; } }
         }
       }
     }
@@ -180,7 +195,10 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
         p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
         if (raw > (uint32_t)Q_CAP) p.qovf[qj[j]] = 1u;
       }
-      for (uint32_t i = threadIdx.x; i < n; i += QT_BS) p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
+      for (uint32_t i = threadIdx.x; i < n; i += QT_BS) {
+        p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
+        p.seg_sum[seg * Q_CAP + i] = csum[j * Q_CAP + i];
+      }
     }
   }
 }
@@ -323,7 +341,7 @@ bool qscan_tiled_shape(int m, int sd) {
 
 template <int SD, int MU, int NT>
 static void launch_qscan_tiled(lance_hip_ctx *ctx, const QscanArgs &a, unsigned grid) {
-  const size_t lds = (size_t)4 * Q_CAP * 4 + 8 * 4;
+  const size_t lds = (size_t)4 * Q_CAP * 4 + 8 * 4 + (size_t)4 * Q_CAP * 2;
   hipLaunchKernelGGL((ivfpq_qscan_tiled_kernel<SD, MU, NT>), dim3(grid), dim3(QT_BS), lds, ctx->stream, a);
 }
 

@@ -63,6 +63,19 @@ def main():
             dt = timed(lambda: eng.flat_topk(x, qs, 10), reps=2 if nq >= 1000 else 5)
             flat[str(nq)] = {"ms": dt * 1e3, "qps": nq / dt, "algorithmic_GBps_per_batch": x.numel() * 4 / dt / 1e9,
                              "algorithmic_TFLOPs": 3 * x.shape[0] * d * nq / dt / 1e12}
+        # roofline objects in bench.py's schema (flat scan = N*d*s bytes per batch, 2*N*d flops per query)
+        t1, t10k = flat["1"]["ms"] * 1e-3, flat["10000"]["ms"] * 1e-3
+        out["c1_roofline_single_query"] = {
+            "kernel": "flat_filter_kernel<128,L2> + flat_select_kernel (one query: every row read once)", "bound": "hbm",
+            "achieved": x.numel() * 4 / t1 / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": x.numel() * 4 / t1 / 1e9 / 8000.0, "traffic": None,
+            "note": "latency-bound at one query: 3 epochs + select kernels; algorithmic bytes = N*d*4"}
+        out["c1_roofline_batch_10k"] = {
+            "kernel": "flat_filter_mfma_kernel<KS=8,L2,f32> (+ flat_mfma_eval_kernel, flat_select_kernel)", "bound": "mfma",
+            "achieved": 2.0 * x.shape[0] * d * 10_000 / t10k / 1e12, "peak": 2500.0, "unit": "TFLOP/s (algorithmic 2*N*d per query; dense bf16 peak)",
+            "frac": 2.0 * x.shape[0] * d * 10_000 / t10k / 1e12 / 2500.0,
+            "executed_bf16_TFLOPs": 3 * 2.0 * x.shape[0] * d * 10_000 / t10k / 1e12,
+            "frac_executed": 3 * 2.0 * x.shape[0] * d * 10_000 / t10k / 1e12 / 2500.0, "traffic": None,
+            "note": "three bf16 products per pair (hi*hi, hi*lo, lo*hi) stand in for one f32 product; wall time of the whole call"}
         out["c1_flat"] = {"n": 1_000_000, "d": d, "k": 10, "by_batch_size": flat,
                           "note": "bytes = N*d*4 once per batch (SURVEY 8d); flops counted as 3 per element (sub, mul, add: no FMA by contract)"}
         gt, _ = eng.flat_topk(x, q[:1000], 10)
@@ -140,6 +153,24 @@ def main():
             grid.append({"nprobes": nprobes, "refine_factor": rf, "recall_at_10": recall_of(ids, gt), "nq": 1000,
                          "ms_per_batch": dt * 1e3, "qps": 1000 / dt, "exact_replays": eng.search_stats()})
         c3["grid"] = grid
+        # roofline of the dominant search kernel at (nprobes 10, refine 10): the tiled filter scan (search_qt.hip).  Its time is the
+        # 4-query table build -- SURVEY 8d: 2 * 256 * d flops per (query, probe) -- on the packed-f32 VALU (157 TFLOP/s vector peak)
+        eng.timing(True)
+        b0 = eng.timing_query("ivfpq_scan_c1")
+        for _ in range(5):
+            idx.search_device(q, 10, 10, 10)
+        eng.synchronize()
+        b1 = eng.timing_query("ivfpq_scan_c1")
+        eng.timing(False)
+        if b1[1] > b0[1]:
+            t_scan = (b1[0] - b0[0]) / (b1[1] - b0[1]) * 1e-3
+            flops = 1000 * 10 * 2.0 * 256 * d
+            c3["roofline"] = {"kernel": "ivfpq_qscan_tiled_kernel<SD=16,MU=6,NT=2> (4-query u16 table build tiled over m + row scan)",
+                              "bound": "valu", "achieved": flops / t_scan / 1e12, "peak": 157.3, "unit": "TFLOP/s (f32 vector)",
+                              "frac": flops / t_scan / 1e12 / 157.3, "traffic": None, "avg_launch_ms": t_scan * 1e3,
+                              "algorithmic_flops_per_launch": flops,
+                              "note": "LUT build 2*256*d flops per (query, probe), SURVEY 8(d); executed as sub + FMA (2 packed VALU per 2 "
+                                      "MACs), so the executed rate is twice the algorithmic one"}
         out["c3"] = c3
     print(json.dumps(out, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else str(o)))
 

@@ -1,6 +1,6 @@
 """Randomised differential run: HIP path vs CPU oracle on random shapes (not collected by pytest; GPU only).
 
-    python tests/fuzz_parity.py [seconds] [seed] [--dry] [--log FILE] [--case N] [--first N] [--debug]
+    python tests/fuzz_parity.py [seconds] [seed] [--dry] [--log FILE] [--case N] [--first N] [--debug] [--watchdog SECONDS]
 
 --dry replaces the device classes with the oracle-backed stand-ins of tests/oracle_engine.py (CPU): it checks this harness
 itself -- argument order, dtypes, the expectations -- where no GPU exists.
@@ -248,7 +248,7 @@ def main():
     if "--debug" in args:
         DEBUG = True
         args.remove("--debug")
-    for name in ("--log", "--case", "--first"):
+    for name in ("--log", "--case", "--first", "--watchdog"):
         if name in args:
             i = args.index(name)
             opts[name] = args[i + 1]
@@ -286,6 +286,11 @@ def main():
     while time.time() < t_end and len(failures) < 25:
         rng = np.random.default_rng([seed, ncase])
         c = draw_config(rng)
+        if "--watchdog" in opts:      # a case that hangs: dump where (Python stack) every N seconds
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+            print(f"[watchdog] case {ncase}: {c}", file=sys.stderr, flush=True)
+            faulthandler.dump_traceback_later(float(opts["--watchdog"]), repeat=True, file=sys.stderr)
         if c is not None:
             cfg = dict(seed=seed, case=ncase, **c)
             try:
