@@ -86,10 +86,12 @@ def main():
         out = torch.empty((count, d), dtype=torch.float16, device=dev)
         for a in range(0, count, 4_000_000):
             b = min(count, a + 4_000_000)
-            out[a:b] = sift_like(b - a, d, seed=seed + 31 * (a // 4_000_000), device=dev, n_clusters=4096).to(torch.float16)
+            # / 256: the reference accumulates the k-means M-step in the column's element type (kmeans.rs:380-406), so Float16 rows
+            # must keep their cluster sums far from 65504 (scripts/scale_probe.py uses the same scaling)
+            out[a:b] = (sift_like(b - a, d, seed=seed + 31 * (a // 4_000_000), device=dev, n_clusters=4096) / 256.0).to(torch.float16)
         return out
     # 4 different query batches per rank, cycled over the steps
-    qbatches = [(sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev, n_clusters=4096).to(torch.float16) if half else
+    qbatches = [((sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev, n_clusters=4096) / 256.0).to(torch.float16) if half else
                  sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev)) for i in range(4)]
     mg = {}            # multi-GPU extras of the bench line
 
@@ -148,7 +150,7 @@ def main():
         # strong-scaling line: the IVF lists sharded over the ranks (list p -> rank p % N, rows moved by all_to_all), every
         # rank answers the SAME query batches with its lists, one all-gather + device (dist, rowid) merge per batch
         shard, l2g = ld.list_shard_index(bld, x_local)
-        common = [(sift_like(args.nq, d, seed=9000 + i, device=dev, n_clusters=4096).to(torch.float16) if half else
+        common = [((sift_like(args.nq, d, seed=9000 + i, device=dev, n_clusters=4096) / 256.0).to(torch.float16) if half else
                    sift_like(args.nq, d, seed=9000 + i, device=dev)) for i in range(2)]
 
         def lstep(i):

@@ -337,7 +337,7 @@ bool pq_mfma_encode_supported(int dtype, int d, int m, int nbits, const void *x,
   if (off || nbits != 8 || m <= 0 || d % m != 0) return false;
   const int sd = d / m;
   if (sd != 4 && sd != 8 && sd != 16) return false;
-  if (n < 2048 || (uint64_t)n >= (1ull << 32)) return false;
+  if (n < 2048) return false;
   const size_t es = dtype == LANCE_HIP_F16 ? 2 : (dtype == LANCE_HIP_I8 ? 1 : 4);
   if (reinterpret_cast<uintptr_t>(x) % (4 * es) || (d % 4)) return false;
   if ((cent && (reinterpret_cast<uintptr_t>(cent) & 15)) || (reinterpret_cast<uintptr_t>(codebook) & 15)) return false;
@@ -362,22 +362,29 @@ int launch_pq_mfma_encode(lance_hip_ctx *ctx, int dtype, const void *x, int64_t 
                           int residual, const float *codebook, int m, uint8_t *codes) {
   if (n == 0) return LANCE_HIP_OK;
   const int sd = d / m;
-  PqmArgs a;
-  a.p.n = n; a.p.ldx = d; a.p.x_batch_off = sd;
-  a.p.cent = codebook; a.p.k = 256; a.p.cent_batch_stride = (int64_t)256 * sd;
-  a.p.codes = codes; a.p.codes_ld = m;
-  a.xn = x; a.rcent = residual ? cent : nullptr; a.rpart = part_ids; a.round_f16 = dtype == LANCE_HIP_F16 ? 1 : 0;
-  a.batches = m;
-  a.fb_cnt = ctx->scratch_t<uint32_t>("pqm.fb_cnt", (size_t)m);
-  a.fb_items = ctx->scratch_t<uint32_t>("pqm.fb_items", (size_t)n * m);
-  if (!a.fb_cnt || !a.fb_items) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(a.fb_cnt, 0, (size_t)m * 4, ctx->stream));
-  const dim3 grid((unsigned)cdiv((uint64_t)n, PQM_WG_ROWS), (unsigned)m);
-  const dim3 fix_grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)n, 256)), 64), (unsigned)m);
+  // rows go through in chunks: the undecided-row lists are [m][chunk] words of scratch (256 MB at most), whatever n is
+  const int64_t chunk = std::max<int64_t>(PQM_WG_ROWS, std::min<int64_t>(n, ((int64_t)64 << 20) / m / PQM_WG_ROWS * PQM_WG_ROWS));
+  uint32_t *fb_cnt = ctx->scratch_t<uint32_t>("pqm.fb_cnt", (size_t)m);
+  uint32_t *fb_items = ctx->scratch_t<uint32_t>("pqm.fb_items", (size_t)chunk * m);
+  if (!fb_cnt || !fb_items) return LANCE_HIP_ENOMEM;
+  const size_t es = dtype == LANCE_HIP_F16 ? 2 : (dtype == LANCE_HIP_I8 ? 1 : 4);
   ScopedTimer t(ctx, "encode_fused");
-  if (sd == 4) launch_pqm_encode_sd<4>(ctx, dtype, a, grid, fix_grid);
-  else if (sd == 8) launch_pqm_encode_sd<8>(ctx, dtype, a, grid, fix_grid);
-  else launch_pqm_encode_sd<16>(ctx, dtype, a, grid, fix_grid);
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t rows = std::min<int64_t>(chunk, n - r0);
+    PqmArgs a;
+    a.p.n = rows; a.p.ldx = d; a.p.x_batch_off = sd;
+    a.p.cent = codebook; a.p.k = 256; a.p.cent_batch_stride = (int64_t)256 * sd;
+    a.p.codes = codes + r0 * m; a.p.codes_ld = m;
+    a.xn = static_cast<const char *>(x) + (size_t)r0 * d * es;
+    a.rcent = residual ? cent : nullptr; a.rpart = part_ids ? part_ids + r0 : nullptr; a.round_f16 = dtype == LANCE_HIP_F16 ? 1 : 0;
+    a.batches = m; a.fb_cnt = fb_cnt; a.fb_items = fb_items;
+    LH_CHECK_HIP(hipMemsetAsync(fb_cnt, 0, (size_t)m * 4, ctx->stream));
+    const dim3 grid((unsigned)cdiv((uint64_t)rows, PQM_WG_ROWS), (unsigned)m);
+    const dim3 fix_grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)rows, 256)), 64), (unsigned)m);
+    if (sd == 4) launch_pqm_encode_sd<4>(ctx, dtype, a, grid, fix_grid);
+    else if (sd == 8) launch_pqm_encode_sd<8>(ctx, dtype, a, grid, fix_grid);
+    else launch_pqm_encode_sd<16>(ctx, dtype, a, grid, fix_grid);
+  }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
