@@ -252,6 +252,7 @@ lance_hip_index::~lance_hip_index() {
   (void)hipSetDevice(device);
   if (centroids) (void)hipFree(centroids);
   if (codebook) (void)hipFree(codebook);
+  if (cb_mean) (void)hipFree(cb_mean);
   if (part_offsets) (void)hipFree(part_offsets);
   if (codes) (void)hipFree(codes);
   if (row_ids) (void)hipFree(row_ids);
@@ -426,6 +427,7 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
   const size_t cb_elems = (size_t)m * ((size_t)1 << nbits) * (d / m);
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, cb_elems * 4, reinterpret_cast<void **>(&ix->codebook));
   if (r == LANCE_HIP_OK) r = widen_into(ctx, model_dtype(dtype), codebook, cb_elems, ix->codebook);
+  if (r == LANCE_HIP_OK && m != 0 && nbits == 8) r = qscan_index_constants(ctx, ix);
   if (r == LANCE_HIP_OK) r = dev_dup(ctx, nullptr, (size_t)(nlist + 1) * 4, reinterpret_cast<void **>(&ix->part_offsets));
   if (r != LANCE_HIP_OK) { delete ix; return r; }
   *out = ix;

@@ -13,6 +13,7 @@ struct lance_hip_index {
   uint64_t n = 0;                 // rows stored (rows with part id NONE are dropped)
   float *centroids = nullptr;     // [nlist][d]
   float *codebook = nullptr;      // [m][256][d/m]
+  float *cb_mean = nullptr;       // 8-bit PQ: [d] mean codeword of every sub-quantiser, then [1] sum over m of the mean |c|^2 (bound pass scale)
   uint32_t *part_offsets = nullptr;  // [nlist+1] device
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition

@@ -386,8 +386,14 @@ static bool ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dt
   if (dtype == LANCE_HIP_F32) {
     if (metric == METRIC_DOT) ma_launch_one<KS, METRIC_DOT, float>(ctx, a); else ma_launch_one<KS, METRIC_L2, float>(ctx, a);
   } else if (dtype == LANCE_HIP_F16) {
-    if (metric == METRIC_DOT) return false;   // f16 rows with a dot metric always arrive with lanes32 (d > 16) or as their f32 copy
-    ma_launch_one<KS, METRIC_L2, __half>(ctx, a);
+    if (metric == METRIC_DOT) {
+      // f16 rows under dot arrive with lanes32 when d > 16; at d = 16 the 32-lane and the 16-lane orders are the same sequence
+      // of additions (dot.rs:91-102), so the 16-lane instantiation serves (refused until the round-3 fuzz drew d = 16, f16, dot)
+      if constexpr (KS == 1) ma_launch_one<1, METRIC_DOT, __half>(ctx, a);
+      else return false;
+    } else {
+      ma_launch_one<KS, METRIC_L2, __half>(ctx, a);
+    }
   } else {
     if (metric == METRIC_DOT) ma_launch_one<KS, METRIC_DOT, int8_t>(ctx, a); else ma_launch_one<KS, METRIC_L2, int8_t>(ctx, a);
   }

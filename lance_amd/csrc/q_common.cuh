@@ -42,6 +42,7 @@ struct QscanArgs {
   uint16_t *seg_sum;            // [nq * nprobes][Q_CAP] the survivors' integer sums (<= LIM < 65536): the merge kernel derives a tighter
                                 // cut from them before it re-evaluates anything exactly
   uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
+  uint32_t *ovf;                // [1 + nq * nprobes] count (zeroed before the launch) + the overflowed segments: the rescan kernel's work list
   const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
   unsigned long long *prof = nullptr;   // -DLH_QT_PROF builds only (tiled kernel): [0] build clocks [1] scan [2] emit [3] items
 };
@@ -88,6 +89,28 @@ __device__ __forceinline__ uint2 q_entry_quantise(f2 acc01, f2 acc23, f2 s01, f2
   return make_uint2(__builtin_bit_cast(uint32_t, e01), __builtin_bit_cast(uint32_t, e23));
 }
 
+// Bound pass scale: the sum over m of the MEAN table entry (the expected distance of a random code) without building the table:
+//   sum_m mean_c |r_m - c|^2 = |r|^2 - 2 r . mu + nu,   mu = the mean codeword of every sub-quantiser (d values), nu = sum_m mean_c |c|^2
+// -- constants of the index (lance_hip_index::cb_mean).  rq holds the NEGATED residuals: |r|^2 + 2 (-r) . mu.  Any scale is sound
+// (it only sets how tight T comes out), so the f32 rounding of this form against the summed table is immaterial.
+// Leaves the four queries' sums in sums[0..3] (LDS, zeroed by the caller before a barrier); the caller adds cb_mean[d].
+template <int BS>
+__device__ __forceinline__ void q_mean_entry_sums(const f4 *__restrict__ rq_item, const float *__restrict__ cb_mean, int d, float *sums) {
+  f4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int e = threadIdx.x; e < d; e += BS) {
+    const f4 r4 = rq_item[e];
+    const float mu2 = 2.0f * cb_mean[e];
+    t += r4 * (r4 + f4{mu2, mu2, mu2, mu2});
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = t[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && (int)(threadIdx.x & ~63u) < d) atomicAdd(&sums[j], v);
+  }
+}
+
 constexpr int QB_BINS = 512;      // histogram bins per query
 constexpr int QB_SHIFT = 3;       // bin width 8: sums 0 .. 4095
 struct QboundArgs {
@@ -96,6 +119,7 @@ struct QboundArgs {
   const uint32_t *item_start;   // [nlist+1], groups of 4
   const int4 *desc;
   const float *centroids, *codebook;
+  const float *cb_mean;         // [d] mean codeword per sub-quantiser dimension, [d] = sum over m of the mean |c|^2 (lance_hip_index::cb_mean)
   const uint32_t *part_offsets;
   const uint8_t *codes;
   int d, nlist, keff, round_f16;

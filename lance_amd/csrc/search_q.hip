@@ -242,7 +242,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
         const int64_t seg = (int64_t)qj[j] * p.nprobes + rk[j];
         if (threadIdx.x == 0) {
           p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
-          if (raw > (uint32_t)Q_CAP) p.qovf[qj[j]] = 1u;
+          if (raw > (uint32_t)Q_CAP) { p.qovf[qj[j]] = 1u; p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = (uint32_t)seg; }
         }
         for (uint32_t i = threadIdx.x; i < n; i += Q_BS) {
           p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
@@ -291,27 +291,10 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? 6 : 4)) void ivfpq_qbound_kernel(Q
     __syncthreads();
     const int c = threadIdx.x & 255, half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     constexpr int MH = M / 2;
-    {
-      f2 t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
-#pragma unroll 1
-      for (int i = 0; i < MH; ++i) {
-        const int mm = half * MH + i;
-        f2 acc01, acc23;
-        q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
-        t01 += acc01; t23 += acc23;
-      }
-      const float tot[4] = {t01.x, t01.y, t23.x, t23.y};
-#pragma unroll
-      for (int j = 0; j < Q_G; ++j) {
-        float t = tot[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        if (lane == 0) atomicAdd(&sums[j], t);
-      }
-    }
+    q_mean_entry_sums<Q_BS>(p.rq + (int64_t)item * p.d, p.cb_mean, p.d, sums);   // round 3: was a full table build
     __syncthreads();
     if (threadIdx.x < Q_G) {
-      const float mean = sums[threadIdx.x] * (1.0f / 256.0f);   // sum over m of the mean entry: distance of a random code
+      const float mean = sums[threadIdx.x] + p.cb_mean[p.d];     // sum over m of the mean entry: distance of a random code
       float s = 1e30f;                                           // absent query / degenerate mean: everything saturates
       if ((int)threadIdx.x < cnt && mean > 0.0f && mean < INFINITY) s = fminf((float)SE / mean, 1e30f);
       sc[threadIdx.x] = s;
@@ -409,42 +392,50 @@ struct QmergeArgs {
   uint32_t *pool_key, *pool_pos, *pool_cnt;
   int pool_cap;
   const uint32_t *qovf;          // [nq] != 0: some segment of the query overflowed (its rows come through the pool)
+  const uint32_t *ovf;           // [1 + nq * nprobes] count, then the overflowed segments (query * nprobes + rank): the rescan kernel's work list
   const uint32_t *allow;         // prefilter bitmap (rescan)
   SelectOut o;
 };
 
 // Segments that lost survivors (more than Q_CAP rows under the bound: it was loose for this query) are rescanned with the
-// exact f32 table, one workgroup per affected query; what stays under the (tightened) threshold goes to the query's pool,
-// which the merge kernel reads besides the segments.  Rare (a few queries per 10,000), so it has its own small kernel
-// instead of 16-32 KiB of LDS in every merge workgroup.
-template <int SD, int MU>
-__global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
+// exact f32 table; what stays under the (tightened) threshold is appended to the query's pool, which the merge kernel reads
+// besides the segments.  Rare for M = 16 / 32 (a few queries per 10,000); the tiled shapes (M >= 48) see it for 1-2 % of the
+// segments -- small partitions give loose bounds, and a query with a loose bound overflows in MOST of its probes.
+// Round 3: one workgroup per overflowed SEGMENT, taken from a device-side list the scan kernels fill (ovf[0] = count, then the
+// segment indices), by a fixed grid of looping workgroups.  The earlier one-workgroup-per-query form walked such a query's
+// 10-50 partitions one after the other (table build + scan each): 0.2-0.4 ms of single-workgroup latency in front of every
+// merge at C3, whatever the workgroup size (256 lanes: 0.25 ms, 1024 lanes: 0.22 ms).
+// BS: 256 lanes where the table is small (M = 16 / 32); 1024 for the tiled shapes (48-96 KiB of exact table per workgroup).
+template <int SD, int MU, int BS>
+__global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
   constexpr int QV = SD / 4;
-  constexpr int CAP = 1024;
-  const int q = blockIdx.x;
-  if (!a.qovf[q]) return;
-  __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[256], misc[8];
+  constexpr int CAP = BS > 256 ? 2 * BS : 1024;
+  __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
   const SelectOut &o = a.o;
   const int dpad = (a.d + 3) & ~3;
   float *r = reinterpret_cast<float *>(smem);   // [dpad]
   float *lutx = r + dpad;                       // [M][256] exact table
-  const float *qv = a.q + (int64_t)q * a.d;
-  if (threadIdx.x == 0) { misc[0] = 0; misc[1] = a.tbound[q]; misc[3] = 0; }
-  __syncthreads();
   CandBuf b{ckey, cpos, &misc[0], &misc[1]};
-  for (int rank = 0; rank < a.nprobes; ++rank) {
-    if (a.seg_cnt[(int64_t)q * a.nprobes + rank] <= (uint32_t)Q_CAP) continue;   // uniform
-    const uint32_t part = a.probes[(int64_t)q * a.nprobes + rank];
-    __syncthreads();
-    for (int e = threadIdx.x; e < a.d; e += 256) {
+  const uint32_t nseg = a.ovf[0];
+  for (uint32_t it = blockIdx.x; it < nseg; it += gridDim.x) {
+    const uint32_t seg = a.ovf[1 + it];
+    const int q = (int)(seg / (uint32_t)a.nprobes);
+    const uint32_t part = a.probes[seg];
+    const float *qv = a.q + (int64_t)q * a.d;
+    __syncthreads();   // the previous segment's buffers are done with
+    // any value of tglobal is an upper bound of the query's final keff-th distance (the filter's bound, lowered by whoever
+    // finished a segment of this query first)
+    const uint32_t t_start = min(a.tbound[q], __hip_atomic_load(&a.tglobal[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (threadIdx.x == 0) { misc[0] = 0; misc[1] = t_start; misc[3] = 0; }
+    for (int e = threadIdx.x; e < a.d; e += BS) {
       float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
       if (a.round_f16) v = __half2float(__float2half_rn(v));
       r[e] = v;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < M * 256; idx += 256) {
+    for (int idx = threadIdx.x; idx < M * 256; idx += BS) {
       const int mm = idx >> 8;
       RegVec<SD> av;
 #pragma unroll
@@ -454,10 +445,10 @@ __global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
     __syncthreads();
     const uint32_t off = o.part_offsets[part];
     const int np = (int)(o.part_offsets[part + 1] - off);
-    for (int base = 0; base < np; base += 256) {
-      const bool need_tighten = (int)misc[0] > CAP - 256;   // read, barrier, decide (lanes past this point append at once)
+    for (int base = 0; base < np; base += BS) {
+      const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide (lanes past this point append at once)
       __syncthreads();
-      if (need_tighten) tighten_bs<256, CAP>(b, o.keff, sorted, &misc[2]);
+      if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
       const uint32_t T = misc[1];
       const int row = base + threadIdx.x;
       if (row < np) {
@@ -480,19 +471,34 @@ __global__ __launch_bounds__(256) void ivfpq_qrescan_kernel(QmergeArgs a) {
       }
       __syncthreads();
     }
+    // publish: about keff rows per segment (<= BS entries left -> one per lane -> the bound is the exact keff-th smallest)
+    for (int iter = 0; iter < 3; ++iter) {
+      const bool more = (int)misc[0] > o.keff + 28;   // read, barrier (inside tighten_bs), decide
+      __syncthreads();
+      if (!more) break;
+      tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+    }
+    __syncthreads();
+    const int c = min((int)misc[0], CAP);
+    if (threadIdx.x == 0) {
+      uint32_t basep = 0xFFFFFFFFu;
+      if (!misc[3] && c > 0) {
+        if (misc[1] < t_start) atomicMin(&a.tglobal[q], misc[1]);
+        basep = atomicAdd(&a.pool_cnt[q], (uint32_t)c);
+      }
+      // more rows tied under the bound than the pool holds (or an entry lost above): the exact kernel replays the query
+      if (misc[3] || (c > 0 && basep + (uint32_t)c > (uint32_t)a.pool_cap)) { atomicOr(&o.flags[q], FLAG_OVERFLOW); basep = 0xFFFFFFFFu; }
+      misc[4] = basep;
+    }
+    __syncthreads();
+    const uint32_t basep = misc[4];
+    if (basep != 0xFFFFFFFFu) {
+      for (int i = threadIdx.x; i < c; i += BS) {
+        a.pool_key[(int64_t)q * a.pool_cap + basep + i] = ckey[i];
+        a.pool_pos[(int64_t)q * a.pool_cap + basep + i] = cpos[i];
+      }
+    }
   }
-  for (int iter = 0; iter < 8 && (int)misc[0] > a.pool_cap; ++iter) tighten_bs<256, CAP>(b, o.keff, sorted, &misc[2]);
-  __syncthreads();
-  const int c = min((int)misc[0], CAP);
-  if (c > a.pool_cap || misc[3]) {   // more rows tied under the bound than the buffers hold: the exact kernel replays the query
-    if (threadIdx.x == 0) atomicOr(&o.flags[q], FLAG_OVERFLOW);
-    return;
-  }
-  for (int i = threadIdx.x; i < c; i += 256) {
-    a.pool_key[(int64_t)q * a.pool_cap + i] = ckey[i];
-    a.pool_pos[(int64_t)q * a.pool_cap + i] = cpos[i];
-  }
-  if (threadIdx.x == 0) { a.pool_cnt[q] = (uint32_t)c; atomicMin(&a.tglobal[q], misc[1]); }
 }
 
 // One workgroup of BS lanes per query.  The kernel is latency-bound (dependent position -> code -> codebook loads, selection
@@ -815,7 +821,9 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
   a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);   // the merge launcher asks for the same slot
-  if (!a.seg_sum) return LANCE_HIP_ENOMEM;
+  a.ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)nq * nprobes + 1);                // likewise (and the class-B conversion)
+  if (!a.seg_sum || !a.ovf) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemsetAsync(a.ovf, 0, 4, ctx->stream));
   const size_t lds = qscan_lds_bytes(d, m);
   const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;
@@ -849,6 +857,36 @@ static bool launch_qbound_sd(lance_hip_ctx *ctx, const QboundArgs &a, int m, uns
   return false;
 }
 
+// lance_hip_index::cb_mean -- one workgroup per sub-quantiser, one lane per codeword
+__global__ __launch_bounds__(256) void q_codebook_mean_kernel(const float *__restrict__ codebook, int sd, int d, float *__restrict__ out) {
+  __shared__ float part[4];
+  const int mm = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+  const float *cw = codebook + ((int64_t)mm * 256 + c) * sd;
+  float sq = 0.0f;
+  for (int e = 0; e <= sd; ++e) {
+    float v;
+    if (e < sd) { v = cw[e]; sq += v * v; } else v = sq;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    if (c == 0) {
+      const float tot = (part[0] + part[1] + part[2] + part[3]) * (1.0f / 256.0f);
+      if (e < sd) out[mm * sd + e] = tot; else atomicAdd(&out[d], tot);
+    }
+  }
+}
+
+int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {
+  const int d = (int)ix->d, m = (int)ix->m;
+  if (!ix->cb_mean) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_mean), (size_t)(d + 1) * 4));
+  LH_CHECK_HIP(hipMemsetAsync(ix->cb_mean, 0, (size_t)(d + 1) * 4, ctx->stream));
+  hipLaunchKernelGGL(q_codebook_mean_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ix->codebook, d / m, d, ix->cb_mean);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 // bound pass on the integer table: pair_starts0 / pair_idx0 = the nq (query, nearest partition) pairs grouped by partition
 int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow) {
@@ -865,6 +903,8 @@ int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tglobal = tglobal; a.allow = allow;
+  LH_REQUIRE(ix->cb_mean, "integer bound pass: the index carries no codebook means (8-bit PQ only)");
+  a.cb_mean = ix->cb_mean;
   const size_t lds = (size_t)4 * QB_BINS * 4 + 8 * 4;
   bool ok = false;
   if (qscan_tiled_shape(m, sd)) ok = qbound_tiled_launch(ctx, a, m, sd, max_items);
@@ -880,7 +920,9 @@ template <int SD, int MU>
 static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned nq, int bs) {
   const int dpad = (a.d + 3) & ~3;
   const size_t lds_rescan = (size_t)dpad * 4 + (size_t)MU * 16 * 256 * 4;
-  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU>), dim3(nq), dim3(256), lds_rescan, ctx->stream, a);
+  constexpr int RBS = MU >= 3 ? 1024 : 256;
+  const unsigned rgrid = (unsigned)std::min<uint64_t>((uint64_t)nq * a.nprobes, (uint64_t)ctx->num_cus * (MU >= 3 ? 1 : 4));
+  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, RBS>), dim3(rgrid), dim3(RBS), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
   const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
   if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
@@ -910,7 +952,8 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     //                                  LIM = 61444 -> bins of 128
     static const bool no_cut = getenv("LANCE_HIP_NO_QCUT") != nullptr;
     a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);
-    if (!a.seg_sum) return LANCE_HIP_ENOMEM;
+    a.ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)nq * nprobes + 1);
+    if (!a.seg_sum || !a.ovf) return LANCE_HIP_ENOMEM;
     const bool tiled = qscan_tiled_shape(m, sd);
     a.cut_shift = no_cut ? -1 : (tiled ? 7 : (m == 16 ? 3 : 2));
     a.cut_slack = tiled ? (uint32_t)(2 * m + 8) : (uint32_t)(2 * m + 4);

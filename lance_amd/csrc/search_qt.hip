@@ -35,8 +35,23 @@
 
 namespace lh {
 
-constexpr int QT_BS = 1024;    // lanes per workgroup: the table tile leaves room for one workgroup per CU -> 4 waves per SIMD
-constexpr int QT_R = 2;        // rows per lane between table rebuilds (2048 rows per block; C3's partitions average 977)
+#ifndef LH_QT_BS
+#define LH_QT_BS 512
+#endif
+#ifndef LH_QT_R
+#define LH_QT_R 4
+#endif
+#ifndef LH_QT_NT96
+#define LH_QT_NT96 3          // tiles at M = 96 (2 x 48 sub-quantisers = 96 KiB; 3 x 32 = 64 KiB; 6 x 16 = 32 KiB) -- A/B builds
+#endif
+#ifndef LH_QT_NT64
+#define LH_QT_NT64 2
+#endif
+// Shape measured on the C3 probe (profiles/r03_c3_tile_shapes.txt): 512 lanes x 4 rows, three 64 KiB tiles at M = 96 -> two
+// workgroups per CU, one building its table while the other gathers: scan 0.378 ms against 0.56 ms for 1024 lanes x 2 rows x
+// two 96 KiB tiles (one workgroup per CU, build and gather phases strictly alternating).
+constexpr int QT_BS = LH_QT_BS;    // lanes per workgroup
+constexpr int QT_R = LH_QT_R;      // rows per lane between table rebuilds (2048 rows per block; C3's partitions average 977)
 constexpr int QT_PARTS = QT_BS / 256;
 constexpr uint32_t QT_SE = 61440u;          // the bound T maps to SE; entries saturate at 65535 (L > 1.067 T: such a row is out anyway)
 constexpr uint32_t QT_LIM = QT_SE + 4u;
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_kernel(QscanArgs p) {
       const int64_t seg = (int64_t)qj[j] * p.nprobes + rk[j];
       if (threadIdx.x == 0) {
         p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
-        if (raw > (uint32_t)Q_CAP) p.qovf[qj[j]] = 1u;
+        if (raw > (uint32_t)Q_CAP) { p.qovf[qj[j]] = 1u; p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = (uint32_t)seg; }
       }
       for (uint32_t i = threadIdx.x; i < n; i += QT_BS) {
         p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
@@ -233,28 +248,10 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qbound_tiled_kernel(QboundArgs p)
   if (threadIdx.x < 4) sums[threadIdx.x] = 0.0f;
   __syncthreads();
   const int c = threadIdx.x & 255, part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-  {
-    constexpr int MP = M / QT_PARTS;
-    f2 t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
-#pragma unroll 1
-    for (int i = 0; i < MP; ++i) {
-      const int mm = part * MP + i;
-      f2 acc01, acc23;
-      q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
-      t01 += acc01; t23 += acc23;
-    }
-    const float tot[4] = {t01.x, t01.y, t23.x, t23.y};
-#pragma unroll
-    for (int j = 0; j < Q_G; ++j) {
-      float t = tot[j];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-      if (lane == 0) atomicAdd(&sums[j], t);
-    }
-  }
+  q_mean_entry_sums<QT_BS>(p.rq + (int64_t)item * p.d, p.cb_mean, p.d, sums);   // the scale without a table build (q_common.cuh)
   __syncthreads();
   if (threadIdx.x < Q_G) {
-    const float mean = sums[threadIdx.x] * (1.0f / 256.0f);   // sum over m of the mean entry: distance of a random code
+    const float mean = sums[threadIdx.x] + p.cb_mean[p.d];     // sum over m of the mean entry: distance of a random code
     float s = 1e30f;                                           // absent query / degenerate mean: everything saturates
     if ((int)threadIdx.x < cnt && mean > 0.0f && mean < INFINITY) s = fminf((float)QT_SEB / mean, 1e30f);
     sc[threadIdx.x] = s;
@@ -325,12 +322,14 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qbound_tiled_kernel(QboundArgs p)
 
 // class B at these sizes: every segment of a query without a bound is handed to the rescan kernel
 __global__ __launch_bounds__(256) void q_classb_to_rescan_kernel(const uint32_t *__restrict__ tbound, int64_t npairs, int nprobes,
-                                                                  uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ qovf) {
+                                                                  uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ qovf,
+                                                                  uint32_t *__restrict__ ovf) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= npairs) return;
   const int64_t q = i / nprobes;
   if (tbound[q] != 0xFFFFFFFFu) return;
-  seg_cnt[i] = 0xFFFFFFFFu;
+  seg_cnt[i] = 0xFFFFFFFFu;      // class-B pairs were never scanned: they cannot be on the list already
+  ovf[1u + atomicAdd(&ovf[0], 1u)] = (uint32_t)i;
   if (i % nprobes == 0) qovf[q] = 1u;
 }
 
@@ -348,8 +347,8 @@ static void launch_qscan_tiled(lance_hip_ctx *ctx, const QscanArgs &a, unsigned 
 template <int SD>
 static bool launch_qscan_tiled_sd(lance_hip_ctx *ctx, const QscanArgs &a, int m, unsigned grid) {
   if (m == 48) { launch_qscan_tiled<SD, 3, 1>(ctx, a, grid); return true; }
-  if (m == 64) { launch_qscan_tiled<SD, 4, 2>(ctx, a, grid); return true; }
-  if (m == 96) { launch_qscan_tiled<SD, 6, 2>(ctx, a, grid); return true; }
+  if (m == 64) { launch_qscan_tiled<SD, 4, LH_QT_NT64>(ctx, a, grid); return true; }
+  if (m == 96) { launch_qscan_tiled<SD, 6, LH_QT_NT96>(ctx, a, grid); return true; }
   return false;
 }
 
@@ -369,8 +368,8 @@ static void launch_qbound_tiled(lance_hip_ctx *ctx, const QboundArgs &a, unsigne
 template <int SD>
 static bool launch_qbound_tiled_sd(lance_hip_ctx *ctx, const QboundArgs &a, int m, unsigned grid) {
   if (m == 48) { launch_qbound_tiled<SD, 3, 1>(ctx, a, grid); return true; }
-  if (m == 64) { launch_qbound_tiled<SD, 4, 2>(ctx, a, grid); return true; }
-  if (m == 96) { launch_qbound_tiled<SD, 6, 2>(ctx, a, grid); return true; }
+  if (m == 64) { launch_qbound_tiled<SD, 4, LH_QT_NT64>(ctx, a, grid); return true; }
+  if (m == 96) { launch_qbound_tiled<SD, 6, LH_QT_NT96>(ctx, a, grid); return true; }
   return false;
 }
 
@@ -383,8 +382,10 @@ bool qbound_tiled_launch(lance_hip_ctx *ctx, const QboundArgs &a, int m, int sd,
 
 int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t nq, uint32_t nprobes, uint32_t *seg_cnt, uint32_t *qovf) {
   const int64_t npairs = (int64_t)nq * nprobes;
+  uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)npairs + 1);   // the slot qscan_launch zeroed and the scan kernels filled
+  if (!ovf) return LANCE_HIP_ENOMEM;
   hipLaunchKernelGGL(q_classb_to_rescan_kernel, dim3((unsigned)cdiv((uint64_t)npairs, 256)), dim3(256), 0, ctx->stream, tbound, npairs, (int)nprobes,
-                     seg_cnt, qovf);
+                     seg_cnt, qovf, ovf);
   return LANCE_HIP_OK;
 }
 

@@ -107,6 +107,10 @@ DEBUG = False
 METRIC_OF = {}
 
 
+class SkipCase(Exception):
+    pass
+
+
 def explain(eng, g, qg, q, k, nprobes, rf, gi, gd, oi, od):
     """--debug: what differs, and whether the same queries in small batches (other kernels: query-major, nsplit > 1) agree"""
     gi_h, gd_h = gi.cpu().numpy().view(np.uint64), gd.cpu().numpy()
@@ -156,6 +160,11 @@ def run_case(rng, c, ncase, eng, classes, torch, oracle):
         part, _ = oracle.assign(xs, cent, km)
         res = oracle.residual(xs, cent, np.where(part == oracle.NONE, 0, part)) if km == "l2" else xs
         cb, _ = oracle.pq_train(res[: 256 * 8], m, nbits=nbits, max_iters=4, seed=ncase + 1)
+        if not (np.isfinite(np.asarray(cent, dtype=f32)).all() and np.isfinite(np.asarray(cb, dtype=f32)).all()):
+            # an f16 model whose M-step sums left the half range (dot k-means collapses onto one centroid: thousands of rows summed in
+            # f16, kmeans.rs:259-275) holds inf; every distance against it is inf - inf = NaN, whose SIGN -- hence its place under
+            # f32::total_cmp -- is a property of the platform's FPU, not of the reference.  Outside the domain; see profiles/r03_fuzz.txt.
+            raise SkipCase("f16 model not finite")
         oidx = oracle.build_index(x, cent, cb, metric, nbits=nbits)
         gpart, gcodes, _ = eng.ivfpq_encode(xg, cent, cb, metric)
         assert (gpart.cpu().numpy().view(np.uint32) == oidx.part_ids).all(), "part ids"
@@ -282,7 +291,7 @@ def main():
     first = int(opts.get("--first", 0))
     only = int(opts["--case"]) if "--case" in opts else None
     ncase = first if only is None else only
-    done, failures, fams = 0, [], {}
+    done, failures, fams, skipped = 0, [], {}, 0
     while time.time() < t_end and len(failures) < 25:
         rng = np.random.default_rng([seed, ncase])
         c = draw_config(rng)
@@ -297,6 +306,9 @@ def main():
                 run_case(rng, c, ncase, eng, classes, torch, oracle)
                 fams[c["fam"]] = fams.get(c["fam"], 0) + 1
                 done += 1
+            except SkipCase as e:
+                say("SKIP", e, cfg)
+                skipped += 1
             except AssertionError as e:
                 say("MISMATCH", e, cfg)
                 failures.append(cfg)
@@ -306,7 +318,7 @@ def main():
         ncase += 1
         if only is not None:
             break
-    say(f"fuzz {'ok' if not failures else 'FAILED'}: {done} configurations passed ({fams}), {len(failures)} failed, seed {seed}, "
+    say(f"fuzz {'ok' if not failures else 'FAILED'}: {done} configurations passed ({fams}), {len(failures)} failed, {skipped} skipped, seed {seed}, "
         f"cases {first if only is None else only}..{ncase - 1}, {time.time() - t0:.0f} s" + (" [dry]" if dry else ""))
     sys.exit(1 if failures else 0)
 

@@ -5,6 +5,8 @@
    a barrier while lanes that were already past it appended to it -- two waves could decide differently and meet different
    barriers.  The partition-major merge / rescan / exact pair kernels had the same pattern.  Fixed by read -> barrier -> decide.
    Seeds 11/4, 11/39, 11/59, 13/4, 13/46, 13/49, 13/63, 13/77, 13/86 of the first widened run.
+2. "assign: element type 1 with metric 2 is not on the MFMA path": Float16 column, dot metric, d = 16 -- the one-K-step shape had no
+   f16 + dot instantiation in mfma_assign.hip (seeds 41/21, 43/53 of the closing run).
 Sorted last: newest device code last."""
 import numpy as np
 import pytest
@@ -50,3 +52,18 @@ def test_large_batch_on_the_query_major_kernels(eng, oracle, nbits, nlist, n, d,
             assert bad.size == 0, f"run {rep}: {bad.size} queries differ (first {bad[:6].tolist()}) at k={k} nprobes={nprobes}"
             assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
     g.close()
+
+
+@pytest.mark.parametrize("d", [16, 32, 48])
+@pytest.mark.parametrize("metric", ["dot", "l2"])
+def test_f16_assign_short_rows(eng, oracle, d, metric):
+    """Float16 rows and centroids at one / two / three K steps of the MFMA assign, both metrics: partition ids and distances are
+    the oracle's (half::f16 arms: pairs widened to f32, the reference's lane order)."""
+    rng = np.random.default_rng(4100 + d)
+    n, k = 6000, 37
+    x = rng.integers(-6, 7, (n, d)).astype(np.float16)
+    cent = (rng.standard_normal((k, d)) * 3).astype(np.float16)
+    gp, gd = eng.assign(x, cent, metric)
+    op, od = oracle.assign(x, cent, metric)
+    assert (_np(gp).view(np.uint32) == op.view(np.uint32)).all()
+    assert (_np(gd).view(np.uint32) == np.asarray(od, dtype=f32).view(np.uint32)).all()
