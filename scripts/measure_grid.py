@@ -165,7 +165,7 @@ def main():
         if b1[1] > b0[1]:
             t_scan = (b1[0] - b0[0]) / (b1[1] - b0[1]) * 1e-3
             flops = 1000 * 10 * 2.0 * 256 * d
-            c3["roofline"] = {"kernel": "ivfpq_qscan_tiled_kernel<SD=16,MU=6,NT=2> (4-query u16 table build tiled over m + row scan)",
+            c3["roofline"] = {"kernel": "ivfpq_qscan_tiled_kernel<SD=16,MU=6,NT=3> (4-query u16 table build tiled over m + row scan)",
                               "bound": "valu", "achieved": flops / t_scan / 1e12, "peak": 157.3, "unit": "TFLOP/s (f32 vector)",
                               "frac": flops / t_scan / 1e12 / 157.3, "traffic": None, "avg_launch_ms": t_scan * 1e3,
                               "algorithmic_flops_per_launch": flops,

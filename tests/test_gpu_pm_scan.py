@@ -381,3 +381,29 @@ def test_pm_scan_tiled_table_prefilter_and_class_b(eng, oracle):
     gidx2 = DeviceIndex.create(eng, "l2", cent2, cb2, gpart2, gcodes2, None, raw=x)
     _check(eng, oracle, gidx2, oidx2, q, q, x, [(10, 12, 10), (100, 9, 0), (10, 40, 0)])
     gidx2.close()
+
+
+@pytest.mark.parametrize("d,m", [(64, 16), (128, 32), (96 * 8, 96)])
+def test_pm_scan_loose_bounds_overflow_segments_are_rescanned(eng, oracle, d, m):
+    """A query whose nearest partition holds barely k * refine rows gets a LOOSE bound; in the dominant cluster's partitions
+    (thousands of rows) more than 256 rows then pass the integer filter -> the segment overflows -> ivfpq_qrescan_kernel
+    redoes that (query, probe) with the exact table, one workgroup per overflowed segment, several segments of one query
+    appending to its pool concurrently (round 3).  LANCE_HIP_Q_STATS=1 prints the overflow counts (scripts/gpu/r03v.sh)."""
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(700 + d + m)
+    n, nlist, nq = 24000, 30, 700
+    ncl = 16
+    centers = rng.standard_normal((ncl, d)).astype(f32) * 0.4
+    w = np.array([60.0] + [1.0] * (ncl - 1)); w /= w.sum()      # ~80 % of the rows in one TIGHT cluster, the others ~300 loose rows each
+    cl = rng.choice(ncl, n, p=w)
+    x = (centers[cl] + rng.standard_normal((n, d)).astype(f32) * np.where(cl == 0, 0.35, 0.8)[:, None].astype(f32)).astype(f32)
+    wq = np.array([1.0] + [4.0] * (ncl - 1)); wq /= wq.sum()    # most queries near the loose clusters: their k * refine-th neighbour
+    q = (centers[rng.choice(ncl, nq, p=wq)] + rng.standard_normal((nq, d)).astype(f32) * 0.8).astype(f32)   # is farther than the whole tight cluster
+    cent, cb = _models(oracle, x, nlist, m, "l2", seed=d)
+    oidx = oracle.build_index(x, cent, cb, "l2")
+    sizes = np.diff(oidx.part_offsets.astype(np.int64))
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "l2")
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    _check(eng, oracle, gidx, oidx, q, q, x, [(10, 8, 10), (10, 12, 0), (25, 30, 4), (100, 8, 0)])
+    assert sizes.max() > 1500, sizes
+    gidx.close()
