@@ -121,9 +121,11 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
 bool qscan_tiled_shape(int m, int sd);
 int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t nq, uint32_t nprobes, uint32_t *seg_cnt, uint32_t *qovf);
 int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys);
+// G = queries per work item of the main pass: 4, or 8 when qscan8_enabled(m, sd) (search_q8.hip)
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
-                uint32_t max_items4);
+                uint32_t max_items4, int G = 4);
+bool qscan8_enabled(int m, int sd);   // search_q8.hip: eight queries per gather with 8-bit entries (M = 16; LANCE_HIP_Q8=1)
 int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,

@@ -27,8 +27,16 @@ constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); mor
 #endif
 constexpr int Q_MPF = LH_Q_MPF;        // merge kernel: codebook entries fetched together per candidate row (registers vs round trips)
 
+// search_q8.hip: eight queries per gather, 8-bit entries
+constexpr int Q8_G = 8;
+constexpr uint32_t Q8_CAP_E = 63u;     // largest entry: four of them add up inside a byte
+#ifndef LH_Q8_SE
+#define LH_Q8_SE 378
+#endif
+constexpr uint32_t Q8_SE = LH_Q8_SE;   // the bound T maps to SE8 (6 x the cap: scripts/sim/q8_selectivity.py)
+
 struct QscanArgs {
-  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel)
+  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel); q8: [items][d][2] (q_residual8_kernel)
   const uint32_t *pair_idx;     // grouped pair indices (pair = q * nprobes + rank)
   const uint32_t *item_start;   // [nlist+1]: items of class A
   const int4 *desc;
@@ -127,6 +135,12 @@ struct QboundArgs {
   const uint32_t *allow;
 };
 
+
+// search_q8.hip
+size_t qscan8_lds_bytes();
+int qscan8_residual(lance_hip_ctx *ctx, const float *qs, const uint32_t *pair_idx, const uint32_t *item_start, const int4 *desc,
+                    const float *centroids, int d, int nlist, int nprobes, int round_f16, uint32_t max_items, f4 *rq);
+bool qscan8_launch(lance_hip_ctx *ctx, const QscanArgs &a, int sd, unsigned grid);
 
 // search_qt.hip
 bool qscan_tiled_launch(lance_hip_ctx *ctx, const QscanArgs &a, int m, int sd, unsigned grid);

@@ -384,6 +384,7 @@ struct QmergeArgs {
   int qm_g;                      // probes whose residuals are staged together (<= QM_G; fewer for long rows: LDS = occupancy)
   int vec4;                      // d % 4 == 0 and 16-byte aligned query / centroid rows: staged with float4 loads
   const uint16_t *seg_sum;       // [nq * nprobes][Q_CAP] integer sums of the survivors (scan kernels)
+  int cut_mode;                  // 0: sums bound the distance from both sides (u16 tables); 1: lower bounds only (8-bit entries): two-phase cut
   int cut_shift;                 // histogram bin = sum >> cut_shift (512 bins cover 0 .. LIM)
   uint32_t cut_slack;            // a survivor whose sum exceeds (upper edge of the keff-th bin) + cut_slack cannot reach the top keff
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
@@ -512,7 +513,11 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
 #else
 #define LH_QM_BOUNDS(BS) __launch_bounds__(BS)
 #endif
-template <int SD, int MU, int BS>
+// CUTM = 1 (search_q8.hip's 8-bit sums, which are only LOWER bounds -- an entry can saturate below the filter's limit): the cut is
+// taken in two phases.  Phase 0 re-evaluates the survivors up to the histogram bin where the count reaches keff (no slack);
+// the keff-th smallest EXACT distance T' among them bounds the answer from above, and a row with distance <= T' has a sum
+// <= T' * s (+ rounding), so phase 1 re-evaluates the survivors between the two limits and nothing else can matter.
+template <int SD, int MU, int BS, int CUTM = 0>
 __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
@@ -625,6 +630,23 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
     }
     __syncthreads();
     const uint32_t cut = s_cut;
+    uint32_t range_lo = 0u, range_hi = cut;     // survivors with range_lo <= sum <= range_hi are re-evaluated in this phase
+    for (int phase = 0; phase < (CUTM ? 2 : 1); ++phase) {
+    if constexpr (CUTM != 0) {
+      if (phase == 1) {
+        if (cut == 0xFFFFFFFFu) break;          // uniform: phase 0 had no cut
+        __syncthreads();
+        const bool enough = (int)misc[0] >= o.keff;   // read, barrier, decide
+        __syncthreads();
+        if (enough) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);   // T <- upper bound of the keff-th smallest exact key so far
+        __syncthreads();
+        const float sq = fminf((float)Q8_SE / key_to_float(tb), 1e30f);   // the scan kernel's scale for this query
+        const float lim = key_to_float(misc[1]) * sq * 1.00001f + 1.0f;
+        const uint32_t cut2 = lim < 65535.0f ? (uint32_t)lim : 0xFFFFu;
+        if (cut2 <= cut) break;                 // uniform
+        range_lo = cut + 1u; range_hi = cut2;
+      }
+    }
     // ---- pass B: exact re-evaluation of the survivors under the cut, probe group by probe group
     for (int g0 = 0; g0 < a.nprobes; g0 += a.qm_g) {
       const int ng = min(a.qm_g, a.nprobes - g0);
@@ -681,7 +703,8 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
             if (t >= pi) { rr = i; st = pi; }   // s_pre[] is non-decreasing and t < s_pre[QM_G]: the last hit is the segment
           }
           const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
-          if ((uint32_t)a.seg_sum[e] <= cut) {
+          const uint32_t sv = (uint32_t)a.seg_sum[e];
+          if (sv >= range_lo && sv <= range_hi) {
             const uint32_t slot = atomicAdd(&l_cnt, 1u);
             l_pos[slot] = a.seg_pos[e]; l_rr[slot] = (uint8_t)rr;
           }
@@ -736,6 +759,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         }
       }
     }
+    }   // phase
     __syncthreads();
   }
   for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
@@ -778,13 +802,13 @@ size_t qscan_lds_bytes(int d, int m) {   // dynamic part (the quantised LUT is s
 
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
-                uint32_t max_items4) {
+                uint32_t max_items4, int G) {
   const size_t npairs = (size_t)nq * nprobes;
   hipLaunchKernelGGL(q_tclass_keys_kernel, dim3((unsigned)cdiv(npairs, 256)), dim3(256), 0, ctx->stream, probes, (int64_t)npairs, (int)nprobes,
                      nlist, tglobal, keys, tbound);
   LH_TRY(stable_group(ctx, keys, (int64_t)npairs, (int64_t)npairs, 2 * nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
-  hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, Q_G, item_start4);
-  hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items4, 256)), dim3(256), 0, ctx->stream, item_start4, pair_starts, nlist, Q_G,
+  hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, G, item_start4);
+  hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items4, 256)), dim3(256), 0, ctx->stream, item_start4, pair_starts, nlist, G,
                      max_items4, desc4);
   return LANCE_HIP_OK;
 }
@@ -805,10 +829,16 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
                  uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
-  f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", (size_t)max_items4 * d * 4));
+  const bool q8 = qscan8_enabled(m, sd);   // items hold 8 queries (qscan_group was called with G = 8): at most npairs / 8 + nlist + 2 of them
+  const uint32_t max_items8 = (uint32_t)((uint64_t)nq * nprobes / 8 + ix->nlist + 2);
+  f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", q8 ? (size_t)max_items8 * d * 8 : (size_t)max_items4 * d * 4));
   if (!rq) return LANCE_HIP_ENOMEM;
   {
     ScopedTimer t(ctx, "q_residual");
+    if (q8)
+      LH_TRY(qscan8_residual(ctx, qs, pair_idx, item_start4, desc4, ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0,
+                             max_items8, rq));
+    else
     hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4,
                        ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
     LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
@@ -835,6 +865,7 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   }
 #endif
   if (qscan_tiled_shape(m, sd)) ok = qscan_tiled_launch(ctx, a, m, sd, grid);
+  else if (q8) ok = qscan8_launch(ctx, a, sd, max_items8);
   else if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
   else if (sd == 16) ok = launch_qscan_sd<16>(ctx, a, m, grid, lds);
@@ -925,6 +956,12 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
   hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, RBS>), dim3(rgrid), dim3(RBS), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
   const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
+  if constexpr (MU == 1) {
+    if (a.cut_mode == 1) {   // search_q8.hip's sums
+      hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128, 1>), dim3(nq), dim3(128), lds, ctx->stream, a);
+      return;
+    }
+  }
   if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
   else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
 }
@@ -957,6 +994,10 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     const bool tiled = qscan_tiled_shape(m, sd);
     a.cut_shift = no_cut ? -1 : (tiled ? 7 : (m == 16 ? 3 : 2));
     a.cut_slack = tiled ? (uint32_t)(2 * m + 8) : (uint32_t)(2 * m + 4);
+    a.cut_mode = 0;
+    if (qscan8_enabled(m, sd)) {   // sums 0 .. 379: one bin per value, no slack -- the second phase takes its limit from exact distances
+      a.cut_mode = 1; a.cut_shift = no_cut ? -1 : 0; a.cut_slack = 0;
+    }
   }
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
   bool ok = true;
