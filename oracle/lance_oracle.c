@@ -885,6 +885,69 @@ void orc_build_lut_f32(int metric, const float *q, size_t d, const float *codebo
       lut[m * kc + c] = orc_dist(metric, q + m * sd, codebook + (m * kc + c) * sd, sd);
 }
 
+/* The same table, SIMD lanes across CODEWORDS (8-bit codes, L2 / dot): every entry goes through exactly the operation sequence of
+ * orc_l2_f32 / orc_dot_f32 above (tail elements first, 16 lane accumulators, lanes added in order, tail + total) -- only sixteen
+ * entries advance together, so the values are bit-identical to orc_build_lut_f32 (tests/test_oracle_golden.py pins that).
+ * The search restatement builds one table per (query, probed partition): this is where a fuzz case's oracle time went.
+ * cbT = the codebook transposed to [M][sd][256] (orc_transpose_codebook_f32, once per search call).                          */
+void orc_transpose_codebook_f32(const float *codebook, size_t d, size_t m_count, float *cbT) {
+  const size_t sd = d / m_count, kc = 256;
+  for (size_t m = 0; m < m_count; m++)
+    for (size_t c = 0; c < kc; c++)
+      for (size_t i = 0; i < sd; i++) cbT[(m * sd + i) * kc + c] = codebook[(m * kc + c) * sd + i];
+}
+
+void orc_build_lut_T_f32(int metric, const float *q, size_t d, const float *cbT, size_t m_count, float *lut) {
+  enum { VW = 16, LANES = 16 };
+  const size_t sd = d / m_count, kc = 256, full = sd / LANES * LANES;
+  const int is_dot = metric == ORC_DOT;
+  for (size_t m = 0; m < m_count; m++) {
+    const float *qm = q + m * sd, *T = cbT + m * sd * kc;
+    for (size_t c0 = 0; c0 < kc; c0 += VW) {
+      float s[VW], tot[VW], sums[LANES][VW];
+      for (int v = 0; v < VW; v++) s[v] = 0.0f;
+      if (full != sd) {
+        float acc[VW];
+        for (int v = 0; v < VW; v++) acc[v] = 0.0f;
+        for (size_t i = full; i < sd; i++) {
+          const float xi = qm[i];
+          const float *row = T + i * kc + c0;
+          if (is_dot) {
+#pragma omp simd
+            for (int v = 0; v < VW; v++) acc[v] = acc[v] + xi * row[v];
+          } else {
+#pragma omp simd
+            for (int v = 0; v < VW; v++) { const float diff = xi - row[v]; acc[v] = acc[v] + diff * diff; }
+          }
+        }
+        for (int v = 0; v < VW; v++) s[v] = acc[v];
+      }
+      for (int i = 0; i < LANES; i++)
+        for (int v = 0; v < VW; v++) sums[i][v] = 0.0f;
+      for (size_t c = 0; c < full; c += LANES)
+        for (int i = 0; i < LANES; i++) {
+          const float xi = qm[c + i];
+          const float *row = T + (c + i) * kc + c0;
+          if (is_dot) {
+#pragma omp simd
+            for (int v = 0; v < VW; v++) sums[i][v] += xi * row[v];
+          } else {
+#pragma omp simd
+            for (int v = 0; v < VW; v++) { const float diff = xi - row[v]; sums[i][v] += diff * diff; }
+          }
+        }
+      for (int v = 0; v < VW; v++) tot[v] = 0.0f;
+      for (int i = 0; i < LANES; i++) {
+#pragma omp simd
+        for (int v = 0; v < VW; v++) tot[v] = tot[v] + sums[i][v];
+      }
+      float *out = lut + m * kc + c0;
+      if (is_dot) { for (int v = 0; v < VW; v++) out[v] = 1.0f - (s[v] + tot[v]); }
+      else { for (int v = 0; v < VW; v++) out[v] = s[v] + tot[v]; }
+    }
+  }
+}
+
 /* a17: compute_pq_distance (8-bit)  pq/distance.rs:109-144 over TRANSPOSED codes;
  * dist[j] = ((0 + LUT[0][c0j]) + LUT[1][c1j]) + ... ; dot post-bias -(M-1)
  * pq/storage.rs:949-957.                                                        */
@@ -1224,6 +1287,12 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
     size_t np_ = part_offsets[p + 1] - part_offsets[p];
     if (np_ > max_np) max_np = np_;
   }
+  /* 8-bit codes under L2 / dot: tables built sixteen codewords at a time from a transposed codebook (bit-identical values) */
+  float *cbT = NULL;
+  if (nbits == 8 && (scan_metric == ORC_L2 || scan_metric == ORC_DOT)) {
+    cbT = (float *)malloc(m_count * 256 * (d / m_count) * sizeof(float));
+    if (cbT) orc_transpose_codebook_f32(codebook, d, m_count, cbT);
+  }
 #pragma omp parallel for schedule(dynamic, 1)
   for (size_t i = 0; i < nq; i++) {
     float *q = (float *)malloc(d * sizeof(float));
@@ -1258,7 +1327,8 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
       } else {
         memcpy(qr, q, d * sizeof(float));
       }
-      orc_build_lut_f32(scan_metric, qr, d, codebook, m_count, nbits, lut);
+      if (cbT) orc_build_lut_T_f32(scan_metric, qr, d, cbT, m_count, lut);
+      else orc_build_lut_f32(scan_metric, qr, d, codebook, m_count, nbits, lut);
       if (allow) {
         /* prefilter branch: only selected rows, in storage order, each through distance(id); the heap sees the same
          * (row id, distance) sequence as FlatIndex::search's loop */
@@ -1303,6 +1373,7 @@ static void orc_ivfpq_search_impl(int metric, const float *centroids, size_t nli
     }
     free(q); free(qr); free(lut); free(pd); free(pid); free(parts); free(cand_ids); free(cand_d);
   }
+  free(cbT);
 }
 
 void orc_ivfpq_search_x2(int metric, const float *centroids, size_t nlist, size_t d,

@@ -796,3 +796,32 @@ def test_distance_range_search_semantics(oracle):
         assert np.array_equal(ri[i][got], want_i) and np.array_equal(rd[i][got].view(np.uint32), want_d.view(np.uint32))
     ei, _ = idx.search(q, 5, 4, lower=hi, upper=hi)          # empty interval
     assert (ei == none).all()
+
+
+@pytest.mark.parametrize("metric", [0, 2])     # ORC_L2, ORC_DOT
+def test_lut_built_sixteen_codewords_at_a_time_is_bit_identical(oracle, metric):
+    """orc_build_lut_T_f32 (SIMD lanes across codewords, transposed codebook: what the search restatement uses for 8-bit codes
+    since round 3, 3x faster) against orc_build_lut_f32 (one entry at a time through orc_l2_f32 / orc_dot_f32, which the golden
+    vectors above pin): every sub-dimension 1..40 and a few beyond (tail only / 16-lane part only / both), NaN and inf entries."""
+    import ctypes as C
+    lib = oracle.lib()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    st = C.c_size_t
+    rng = np.random.default_rng(11 + metric)
+    for sd in list(range(1, 41)) + [48, 64, 100]:
+        for m in (1, 3, 16):
+            d = sd * m
+            q = (rng.standard_normal(d) * 3).astype(np.float32)
+            cb = (rng.standard_normal((m, 256, sd)) * 3).astype(np.float32)
+            if sd % 7 == 0:
+                cb[0, 5, 0] = np.nan
+                cb[0, 6, sd - 1] = np.inf
+                if sd % 14 == 0:
+                    q[0] = -np.inf
+            a = np.empty((m, 256), np.float32)
+            b = np.empty((m, 256), np.float32)
+            cbt = np.empty((m, sd, 256), np.float32)
+            lib.orc_build_lut_f32(C.c_int(metric), P(q), st(d), P(cb), st(m), C.c_uint32(8), P(a))
+            lib.orc_transpose_codebook_f32(P(cb), st(d), st(m), P(cbt))
+            lib.orc_build_lut_T_f32(C.c_int(metric), P(q), st(d), P(cbt), st(m), P(b))
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), (metric, sd, m)
