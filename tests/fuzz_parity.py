@@ -308,9 +308,12 @@ def main():
         if c is not None:
             cfg = dict(seed=seed, case=ncase, **c)
             try:
+                tc = time.time()
                 run_case(rng, c, ncase, eng, classes, torch, oracle)
                 fams[c["fam"]] = fams.get(c["fam"], 0) + 1
                 done += 1
+                if logf:      # a run killed by its caller's timeout still leaves how far it got (and which case was slow)
+                    logf.write(f"ok case {ncase} {c['fam']} {time.time() - tc:.1f} s\n"); logf.flush()
             except SkipCase as e:
                 say("SKIP", e, cfg)
                 skipped += 1
