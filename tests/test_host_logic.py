@@ -345,3 +345,31 @@ def test_range_with_refine_selection_logic(oracle):
                              upper=np.finfo(f32).max if b is None else b)
         assert np.array_equal(gi.numpy().view(np.uint64), oi), (k, nprobes, rf)
         assert np.array_equal(gd.numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The bench line recorded on the MI355X for the final tree of the round (profiles/) carries every key the driver and the
+    judge read: the contract keys, `roofline` with bound / achieved / peak / frac / traffic, `cpu_baseline` with value / cores /
+    kind / sample -- and the numbers are self-consistent (value = queries per step / ms per step, frac = achieved / peak)."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r0*_bench_n1*.json")))
+    if not files:
+        pytest.skip("no recorded bench line")
+    j = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None and "workload" in j["config"]
+    per_step = j["config"]["queries_per_step_per_gpu"]
+    assert abs(j["value"] - per_step / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    r = j["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None and r["traffic"] > 0
+    c = j["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c.get("ids_equal_gpu") is True
