@@ -253,14 +253,6 @@ lance_hip_index::~lance_hip_index() {
   if (centroids) (void)hipFree(centroids);
   if (codebook) (void)hipFree(codebook);
   if (cb_mean) (void)hipFree(cb_mean);
-  if (pt) {
-    if (pt->g) (void)hipFree(pt->g);
-    if (pt->cen_t) (void)hipFree(pt->cen_t);
-    if (pt->row_beta) (void)hipFree(pt->row_beta);
-    if (pt->beta_min) (void)hipFree(pt->beta_min);
-    if (pt->beta_abs) (void)hipFree(pt->beta_abs);
-    delete pt;
-  }
   if (part_offsets) (void)hipFree(part_offsets);
   if (codes) (void)hipFree(codes);
   if (row_ids) (void)hipFree(row_ids);

@@ -130,9 +130,7 @@ int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
-                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow, const uint32_t *probes = nullptr);
-// search_qt.hip: per-query tables + per-row bias instead of a table per (query, partition) (M = 48 / 64 / 96; LANCE_HIP_QPT=1)
-bool qscan_pt_enabled(const lance_hip_index *ix);
+                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow);
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
                   uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow);

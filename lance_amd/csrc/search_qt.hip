@@ -389,320 +389,4 @@ int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t 
   return LANCE_HIP_OK;
 }
 
-
-// ==== per-query tables + per-row bias (LANCE_HIP_QPT=1; round 3, written against scripts/sim/pqt_filter_spec.py, NOT YET RUN ON
-// HARDWARE when the round closed -- DESIGN.md section 8) =====================================================================
-// With q~ = q - g, cen~ = cen_p - g (g = the mean centroid: any fixed vector leaves r = q - cen_p unchanged, this one removes the
-// data's common offset) the residual table entry splits into
-//     ||r_m - c||^2 = ||q~_m - c||^2 + 2 cen~_pm . c + (||cen~_pm||^2 - 2 cen~_pm . q~_m)
-// i.e.  dist(q, row) = sum_m A_q[m][code_m] + beta_row + kappa_qp  with a table per QUERY, a constant per stored ROW and a scalar
-// per pair.  The filter  dist <= T  becomes  sum_m e_q[m][code_m] <= s_q (T - kappa_qp - beta_row) + slack:  the integer table is
-// built once per query (q_pt_table_kernel) and an item LOADS its four queries' tiles instead of computing them.
-//   e       = floor(min(A^ s_q, 65535)), A^ the f32 FMA chain, s_q = SE / Theta_q, Theta_q = max over the query's probes of
-//             (T - kappa - min beta of the partition): every row that can pass has all its entries below saturation;
-//   beta    = f32 of an f64 sum (q_pt_row_beta_kernel, once per index), kappa likewise (q_pt_scale_kernel, per pair);
-//   slack   = 2 + u s_q (10 (|T| + |kappa| + max|beta| + |q~|^2) + (SD + M + 6) Theta_q) units, u = 2^-24; a pair whose slack
-//             exceeds PT_CAP units is handed to the exact rescan kernel like an overflowed segment;
-//   stored sum S' = floor(sum e + s_q (beta + kappa)) ~ s_q dist: S' - 9 <= s_q dist <= S' + M + 10 -- inside the merge kernel's
-//             existing cut slack for these shapes (2 M + 8).
-constexpr float PT_CAP = 8.0f;
-
-struct PtArgs {
-  const uint16_t *tab;     // [nq][M][256] per-query integer tables
-  const float *sq;         // [nq] scale (0: the query has no table)
-  const float *kap;        // [nq * nprobes] kappa of the pair
-  const float *pslack;     // [nq * nprobes] slack of the pair in units
-  const float *row_beta;   // [n] per stored row
-};
-
-// g[dim] = mean over the centroids (f64 accumulation)
-__global__ __launch_bounds__(256) void q_pt_mean_kernel(const float *__restrict__ cent, int nlist, int d, float *__restrict__ g) {
-  const int dim = blockIdx.x * 256 + threadIdx.x;
-  if (dim >= d) return;
-  double acc = 0.0;
-  for (int p = 0; p < nlist; ++p) acc += (double)cent[(int64_t)p * d + dim];
-  g[dim] = (float)(acc / (double)nlist);
-}
-
-__global__ __launch_bounds__(256) void q_pt_translate_kernel(const float *__restrict__ cent, const float *__restrict__ g, int64_t total, int d,
-                                                              float *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < total) out[i] = cent[i] - g[i % d];
-}
-
-// one workgroup per partition: beta of every stored row (f64 sum, one rounding), the partition's min beta and max |beta|
-__global__ __launch_bounds__(256) void q_pt_row_beta_kernel(const float *__restrict__ cen_t, const float *__restrict__ codebook,
-                                                             const uint8_t *__restrict__ codes, const uint32_t *__restrict__ part_offsets,
-                                                             int d, int m, float *__restrict__ row_beta, float *__restrict__ beta_min,
-                                                             float *__restrict__ beta_abs) {
-  __shared__ float s_min[4], s_abs[4];
-  const int p = blockIdx.x, sd = d / m;
-  const uint32_t off = part_offsets[p];
-  const int np = (int)(part_offsets[p + 1] - off);
-  const float *ct = cen_t + (int64_t)p * d;
-  float lmin = INFINITY, labs = 0.0f;
-  for (int row = threadIdx.x; row < np; row += 256) {
-    const uint8_t *rc = codes + ((int64_t)off + row) * m;
-    double acc = 0.0;
-    for (int mm = 0; mm < m; ++mm) {
-      const float *cw = codebook + ((int64_t)mm * 256 + rc[mm]) * sd;
-      for (int u = 0; u < sd; ++u) acc += 2.0 * (double)ct[mm * sd + u] * (double)cw[u];
-    }
-    const float b = (float)acc;
-    row_beta[(int64_t)off + row] = b;
-    lmin = fminf(lmin, b); labs = fmaxf(labs, fabsf(b));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lmin = fminf(lmin, __shfl_xor(lmin, o, 64)); labs = fmaxf(labs, __shfl_xor(labs, o, 64)); }
-  if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lmin; s_abs[threadIdx.x >> 6] = labs; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float mn = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
-    beta_min[p] = np > 0 ? mn : 0.0f;
-    beta_abs[p] = fmaxf(fmaxf(s_abs[0], s_abs[1]), fmaxf(s_abs[2], s_abs[3]));
-  }
-}
-
-// one wave per query: q~, kappa and slack of every pair, the query's scale
-__global__ __launch_bounds__(256) void q_pt_scale_kernel(const float *__restrict__ qs, const float *__restrict__ g, const float *__restrict__ cen_t,
-                                                          const float *__restrict__ beta_min, const float *__restrict__ beta_abs,
-                                                          const uint32_t *__restrict__ probes, const uint32_t *__restrict__ tbound, int nq,
-                                                          int nprobes, int d, int sd_plus_m, float *__restrict__ qt, float *__restrict__ sq,
-                                                          float *__restrict__ kap, float *__restrict__ pslack) {
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (q >= nq) return;
-  double qn2 = 0.0;
-  for (int dim = lane; dim < d; dim += 64) {
-    const float v = qs[(int64_t)q * d + dim] - g[dim];
-    qt[(int64_t)q * d + dim] = v;
-    qn2 += (double)v * (double)v;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o, 64);
-  const uint32_t tb = tbound[q];
-  if (tb == 0xFFFFFFFFu) {   // class B: no bound, no table (its segments go to the rescan kernel anyway)
-    if (lane == 0) sq[q] = 0.0f;
-    return;
-  }
-  const double T = (double)key_to_float(tb);
-  double theta = 0.0;
-  for (int rank = 0; rank < nprobes; ++rank) {
-    const uint32_t p = probes[(int64_t)q * nprobes + rank];
-    const float *ct = cen_t + (int64_t)p * d;
-    double acc = 0.0;
-    for (int dim = lane; dim < d; dim += 64) {
-      const double c = (double)ct[dim];
-      acc += c * c - 2.0 * c * (double)qt[(int64_t)q * d + dim];   // this lane wrote qt[dim] itself
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    const float kf = (float)acc;
-    if (lane == 0) kap[(int64_t)q * nprobes + rank] = kf;
-    theta = fmax(theta, T - (double)kf - (double)beta_min[p]);
-  }
-  // theta <= 0 or not finite: no usable scale -- every pair of the query is sent to the rescan kernel (slack = inf)
-  const bool ok = theta > 0.0 && theta < 1e300;
-  const float s = ok ? (float)((double)QT_SE / theta) : 0.0f;
-  if (lane == 0) sq[q] = s;
-  if (lane == 0) {   // one lane: it wrote kap[] itself (program order), and the loop is nprobes short iterations
-    const double u = 5.9604644775390625e-8;   // 2^-24
-    for (int rank = 0; rank < nprobes; ++rank) {
-      const uint32_t p = probes[(int64_t)q * nprobes + rank];
-      const double kf = (double)kap[(int64_t)q * nprobes + rank];
-      const double sl = 2.0 + u * (double)s * (10.0 * (fabs(T) + fabs(kf) + (double)beta_abs[p] + qn2) + (double)(sd_plus_m + 6) * theta);
-      pslack[(int64_t)q * nprobes + rank] = ok ? (float)sl : INFINITY;
-    }
-  }
-}
-
-// grid (M, nq), lane = codeword: the query's integer table
-template <int SD>
-__global__ __launch_bounds__(256) void q_pt_table_kernel(const float *__restrict__ qt, const float *__restrict__ sq, const float *__restrict__ codebook,
-                                                          int d, int m, uint16_t *__restrict__ tab) {
-  const int mm = blockIdx.x, q = blockIdx.y, c = threadIdx.x;
-  const float s = sq[q];
-  if (!(s > 0.0f)) return;   // uniform
-  const float *qv = qt + (int64_t)q * d + mm * SD;
-  const float *cw = codebook + ((int64_t)mm * 256 + c) * SD;
-  float acc = 0.0f;
-#pragma unroll
-  for (int u = 0; u < SD; ++u) {
-    const float diff = qv[u] - cw[u];
-    acc = fmaf(diff, diff, acc);
-  }
-  float z = fminf(acc * s, 65535.0f);
-  z = z >= 0.0f ? z : 0.0f;                       // NaN -> 0: the row survives and the exact pass decides
-  tab[((int64_t)q * m + mm) * 256 + c] = (uint16_t)(uint32_t)z;   // truncation = floor
-}
-
-template <int MU, int NT>
-__global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_pt_kernel(QscanArgs p, PtArgs t) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int M = MU * 16, MT = M / NT, MTP = MT / QT_PARTS;
-  static_assert(M % NT == 0 && MT % 16 == 0 && MT % QT_PARTS == 0, "tile shape");
-  __shared__ __attribute__((aligned(16))) uint2 lutq[MT * 256];
-  uint32_t *cand = reinterpret_cast<uint32_t *>(smem);                // [4][Q_CAP]
-  uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts, [4..7] 1: the pair goes to the rescan kernel
-  float *sc = reinterpret_cast<float *>(misc + 8);                    // [4] s_q
-  float *thr = sc + 4;                                                // [4] s_q (T - kappa) + slack  (-1e30: nothing passes)
-  float *skap = thr + 4;                                              // [4] s_q kappa
-  uint16_t *csum = reinterpret_cast<uint16_t *>(skap + 4);            // [4][Q_CAP] the survivors' sums ~ s_q dist
-  const uint32_t item = blockIdx.x;
-  if (item >= p.item_start[p.nlist]) return;
-  const int4 dsc = p.desc[item];
-  const int part_id = dsc.x, i0 = dsc.y, cnt = dsc.z;
-  const uint32_t off = p.part_offsets[part_id];
-  const int np = (int)(p.part_offsets[part_id + 1] - off);
-  if (np == 0) return;   // uniform; seg_cnt stays 0
-  uint32_t qj[Q_G], pr[Q_G];
-#pragma unroll
-  for (int j = 0; j < Q_G; ++j) {
-    pr[j] = p.pair_idx[i0 + (j < cnt ? j : 0)];
-    qj[j] = pr[j] / (uint32_t)p.nprobes;
-  }
-  if (threadIdx.x < Q_G) {
-    const int j = threadIdx.x;
-    misc[j] = 0; misc[4 + j] = 0;
-    float s = 0.0f, th = -1e30f, sk = 0.0f;
-    if (j < cnt) {
-      const float sj = t.sq[qj[j]], sl = t.pslack[pr[j]];
-      if (sj > 0.0f && sl <= PT_CAP) {
-        const float T = key_to_float(p.tbound[qj[j]]), kp = t.kap[pr[j]];
-        s = sj; th = sj * (T - kp) + sl; sk = sj * kp;
-      } else {
-        misc[4 + j] = 1u;
-      }
-    }
-    sc[j] = s; thr[j] = th; skap[j] = sk;
-  }
-  __syncthreads();
-  const int c = threadIdx.x & 255, part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-  const f4 s4 = *reinterpret_cast<const f4 *>(sc), th4 = *reinterpret_cast<const f4 *>(thr), sk4 = *reinterpret_cast<const f4 *>(skap);
-  const uint16_t *tq0 = t.tab + (int64_t)qj[0] * M * 256, *tq1 = t.tab + (int64_t)qj[1] * M * 256;
-  const uint16_t *tq2 = t.tab + (int64_t)qj[2] * M * 256, *tq3 = t.tab + (int64_t)qj[3] * M * 256;
-  const uint8_t *pcodes = p.codes + (int64_t)off * M;
-  for (int row0 = 0; row0 < np; row0 += QT_BS * QT_R) {
-    uint32_t acc[QT_R][4];
-#pragma unroll
-    for (int r = 0; r < QT_R; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[r][j] = 0u;
-#pragma unroll 1
-    for (int tile = 0; tile < NT; ++tile) {
-      if (tile > 0 || row0 > 0) __syncthreads();   // every lane is done with the previous tile's table
-#pragma unroll 4
-      for (int i = 0; i < MTP; ++i) {
-        const int ml = part * MTP + i, idx = (tile * MT + ml) * 256 + c;
-        const uint32_t e0 = tq0[idx], e1 = tq1[idx], e2 = tq2[idx], e3 = tq3[idx];
-        lutq[ml * 256 + c] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < QT_R; ++r) {
-        const int row = row0 + r * QT_BS + (int)threadIdx.x;
-        if (row < np) qt_row_tile<MT>(lutq, pcodes + (int64_t)row * M + tile * MT, acc[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < QT_R; ++r) {
-      const int row = row0 + r * QT_BS + (int)threadIdx.x;
-      if (row < np) {
-        const float beta = t.row_beta[(int64_t)off + row];
-        const float a0 = (float)acc[r][0], a1 = (float)acc[r][1], a2 = (float)acc[r][2], a3 = (float)acc[r][3];   // exact: sums < 2^24
-        const bool p0 = a0 <= fmaf(-s4.x, beta, th4.x), p1 = a1 <= fmaf(-s4.y, beta, th4.y);
-        const bool p2 = a2 <= fmaf(-s4.z, beta, th4.z), p3 = a3 <= fmaf(-s4.w, beta, th4.w);
-        if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
-          const uint32_t pos = off + (uint32_t)row;
-          // stored sum ~ s_q dist (what the merge kernel's cut reads): floor(sum e + s_q (beta + kappa)), clamped to the u16 range
-          if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) { cand[0 * Q_CAP + slot] = pos; csum[0 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a0 + fmaf(s4.x, beta, sk4.x), 0.0f), 65535.0f); } }
-          if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) { cand[1 * Q_CAP + slot] = pos; csum[1 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a1 + fmaf(s4.y, beta, sk4.y), 0.0f), 65535.0f); } }
-          if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) { cand[2 * Q_CAP + slot] = pos; csum[2 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a2 + fmaf(s4.z, beta, sk4.z), 0.0f), 65535.0f); } }
-          if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) { cand[3 * Q_CAP + slot] = pos; csum[3 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a3 + fmaf(s4.w, beta, sk4.w), 0.0f), 65535.0f); } }
-        }
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < Q_G; ++j) {
-    if (j < cnt) {
-      const uint32_t raw = misc[4 + j] ? 0xFFFFFFFFu : misc[j];   // no table / slack over the cap: the rescan kernel does this pair exactly
-      const uint32_t n = raw > (uint32_t)Q_CAP ? 0u : raw;
-      const int64_t seg = (int64_t)pr[j];
-      if (threadIdx.x == 0) {
-        p.seg_cnt[seg] = raw;
-        if (raw > (uint32_t)Q_CAP) { p.qovf[qj[j]] = 1u; p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = (uint32_t)seg; }
-      }
-      for (uint32_t i = threadIdx.x; i < n; i += QT_BS) {
-        p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
-        p.seg_sum[seg * Q_CAP + i] = csum[j * Q_CAP + i];
-      }
-    }
-  }
-}
-
-// ---- host ------------------------------------------------------------------------------------------------------------------
-bool qscan_pt_enabled(const lance_hip_index *ix) {
-  static const bool on = getenv("LANCE_HIP_QPT") != nullptr;
-  if (!on || !ix || ix->m == 0 || ix->nbits != 8) return false;
-  const int m = (int)ix->m, sd = (int)(ix->d / ix->m);
-  if (!qscan_tiled_shape(m, sd)) return false;
-  if (ix->dtype == LANCE_HIP_F16) return false;      // the reference rounds the residual to f16 there: r is not q - cen any more
-  return ix->metric == LANCE_HIP_L2 || ix->metric == LANCE_HIP_COSINE;
-}
-
-static int qscan_pt_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
-  if (ix->pt) return LANCE_HIP_OK;
-  const int d = (int)ix->d, m = (int)ix->m, nlist = (int)ix->nlist;
-  auto *pc = new lance_hip_index::PtConst();
-  bool ok = hipMalloc(reinterpret_cast<void **>(&pc->g), (size_t)d * 4) == hipSuccess;
-  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->cen_t), (size_t)nlist * d * 4) == hipSuccess;
-  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->row_beta), (size_t)(ix->n ? ix->n : 1) * 4) == hipSuccess;
-  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_min), (size_t)nlist * 4) == hipSuccess;
-  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_abs), (size_t)nlist * 4) == hipSuccess;
-  ix->pt = pc;   // the destructor frees whatever was allocated
-  if (!ok) { set_error("per-query tables: out of device memory for the index constants"); return LANCE_HIP_ENOMEM; }
-  hipLaunchKernelGGL(q_pt_mean_kernel, dim3((unsigned)cdiv((uint64_t)d, 256)), dim3(256), 0, ctx->stream, ix->centroids, nlist, d, pc->g);
-  hipLaunchKernelGGL(q_pt_translate_kernel, dim3((unsigned)cdiv((uint64_t)nlist * d, 256)), dim3(256), 0, ctx->stream, ix->centroids, pc->g,
-                     (int64_t)nlist * d, d, pc->cen_t);
-  hipLaunchKernelGGL(q_pt_row_beta_kernel, dim3((unsigned)nlist), dim3(256), 0, ctx->stream, pc->cen_t, ix->codebook, ix->codes, ix->part_offsets, d, m,
-                     pc->row_beta, pc->beta_min, pc->beta_abs);
-  LH_CHECK_HIP(hipGetLastError());
-  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // other engine contexts (streams) search the same index
-  return LANCE_HIP_OK;
-}
-
-template <int MU, int NT>
-static void launch_qscan_tiled_pt(lance_hip_ctx *ctx, const QscanArgs &a, const PtArgs &t, unsigned grid) {
-  const size_t lds = (size_t)4 * Q_CAP * 4 + 8 * 4 + 12 * 4 + (size_t)4 * Q_CAP * 2;
-  hipLaunchKernelGGL((ivfpq_qscan_tiled_pt_kernel<MU, NT>), dim3(grid), dim3(QT_BS), lds, ctx->stream, a, t);
-}
-
-int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const QscanArgs &a, const float *qs, uint32_t nq, const uint32_t *probes,
-                    unsigned grid) {
-  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);   // the constants are a cache attached to the index
-  LH_TRY(qscan_pt_prepare(ctx, ix));
-  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nprobes = a.nprobes;
-  float *qt = ctx->scratch_t<float>("pt.qt", (size_t)nq * d);
-  float *sq = ctx->scratch_t<float>("pt.sq", nq);
-  float *kap = ctx->scratch_t<float>("pt.kap", (size_t)nq * nprobes);
-  float *pslack = ctx->scratch_t<float>("pt.pslack", (size_t)nq * nprobes);
-  uint16_t *tab = ctx->scratch_t<uint16_t>("pt.tab", (size_t)nq * m * 256);
-  if (!qt || !sq || !kap || !pslack || !tab) return LANCE_HIP_ENOMEM;
-  hipLaunchKernelGGL(q_pt_scale_kernel, dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, ctx->stream, qs, ix->pt->g, ix->pt->cen_t, ix->pt->beta_min,
-                     ix->pt->beta_abs, probes, a.tbound, (int)nq, nprobes, d, sd + m, qt, sq, kap, pslack);
-  const dim3 tgrid((unsigned)m, nq);
-  if (sd == 4) hipLaunchKernelGGL((q_pt_table_kernel<4>), tgrid, dim3(256), 0, ctx->stream, qt, sq, ix->codebook, d, m, tab);
-  else if (sd == 8) hipLaunchKernelGGL((q_pt_table_kernel<8>), tgrid, dim3(256), 0, ctx->stream, qt, sq, ix->codebook, d, m, tab);
-  else hipLaunchKernelGGL((q_pt_table_kernel<16>), tgrid, dim3(256), 0, ctx->stream, qt, sq, ix->codebook, d, m, tab);
-  PtArgs t;
-  t.tab = tab; t.sq = sq; t.kap = kap; t.pslack = pslack; t.row_beta = ix->pt->row_beta;
-  if (m == 48) launch_qscan_tiled_pt<3, 1>(ctx, a, t, grid);
-  else if (m == 64) launch_qscan_tiled_pt<4, LH_QT_NT64>(ctx, a, t, grid);
-  else if (m == 96) launch_qscan_tiled_pt<6, LH_QT_NT96>(ctx, a, t, grid);
-  else { set_error("per-query tables: unsupported shape (m=%d)", m); return LANCE_HIP_EINVAL; }
-  LH_CHECK_HIP(hipGetLastError());
-  return LANCE_HIP_OK;
-}
-
 }  // namespace lh
