@@ -430,16 +430,93 @@ static inline int orc_argmin_row(int metric, const float *v, const float *cent, 
   return found;
 }
 
-/* a6/a9: compute_membership_and_dist  kmeans.rs:317-369 ; compute_partition :1350 */
+/* Distances of ONE vector to kp vectors stored transposed ([d][kp], kp a multiple of 16), SIMD lanes across the kp vectors: every
+ * distance goes through exactly the operation sequence of orc_l2_f32 / orc_dot_f32 (tail elements first, 16 lane accumulators,
+ * lanes added in order, tail + total; dot: 1 - that) -- sixteen of them advance together, the values are bit-identical to the
+ * one-at-a-time functions (tests/test_oracle_golden.py pins that).  Used where the restatement's time goes: one table per
+ * (query, probed partition) in the search, the E-step / assign of the builds.                                                  */
+static void orc_dist_many_T(int is_dot, const float *x, size_t d, const float *T, size_t kp, float *out) {
+  enum { VW = 16, LANES = 16 };
+  const size_t full = d / LANES * LANES;
+  for (size_t c0 = 0; c0 < kp; c0 += VW) {
+    float s[VW], tot[VW], sums[LANES][VW];
+    for (int v = 0; v < VW; v++) s[v] = 0.0f;
+    if (full != d) {
+      float acc[VW];
+      for (int v = 0; v < VW; v++) acc[v] = 0.0f;
+      for (size_t i = full; i < d; i++) {
+        const float xi = x[i];
+        const float *row = T + i * kp + c0;
+        if (is_dot) {
+#pragma omp simd
+          for (int v = 0; v < VW; v++) acc[v] = acc[v] + xi * row[v];
+        } else {
+#pragma omp simd
+          for (int v = 0; v < VW; v++) { const float diff = xi - row[v]; acc[v] = acc[v] + diff * diff; }
+        }
+      }
+      for (int v = 0; v < VW; v++) s[v] = acc[v];
+    }
+    for (int i = 0; i < LANES; i++)
+      for (int v = 0; v < VW; v++) sums[i][v] = 0.0f;
+    for (size_t c = 0; c < full; c += LANES)
+      for (int i = 0; i < LANES; i++) {
+        const float xi = x[c + i];
+        const float *row = T + (c + i) * kp + c0;
+        if (is_dot) {
+#pragma omp simd
+          for (int v = 0; v < VW; v++) sums[i][v] += xi * row[v];
+        } else {
+#pragma omp simd
+          for (int v = 0; v < VW; v++) { const float diff = xi - row[v]; sums[i][v] += diff * diff; }
+        }
+      }
+    for (int v = 0; v < VW; v++) tot[v] = 0.0f;
+    for (int i = 0; i < LANES; i++) {
+#pragma omp simd
+      for (int v = 0; v < VW; v++) tot[v] = tot[v] + sums[i][v];
+    }
+    if (is_dot) { for (int v = 0; v < VW; v++) out[c0 + v] = 1.0f - (s[v] + tot[v]); }
+    else { for (int v = 0; v < VW; v++) out[c0 + v] = s[v] + tot[v]; }
+  }
+}
+
+/* a6/a9: compute_membership_and_dist  kmeans.rs:317-369 ; compute_partition :1350
+ * L2 / dot with enough work: the centroids transposed once ([d][k rounded up to 16], zero padding), every row's k distances from
+ * orc_dist_many_T, then the same strict-'<' argmin over them (with the bias, if any) as orc_argmin_row.                          */
 void orc_assign_f32(int metric, const float *x, size_t n, size_t d, const float *cent, size_t k,
                     const float *bias, uint32_t *ids, float *dists) {
-#pragma omp parallel for schedule(static)
-  for (size_t r = 0; r < n; r++) {
-    uint32_t id; float dist;
-    orc_argmin_row(metric, x + r * d, cent, k, d, bias, &id, &dist);
-    ids[r] = id;
-    if (dists) dists[r] = dist;
+  float *cT = NULL;
+  const size_t kp = (k + 15) / 16 * 16;
+  if ((metric == ORC_L2 || metric == ORC_DOT) && k >= 16 && n * k * d >= (size_t)1 << 20) {
+    cT = (float *)calloc(d * kp, sizeof(float));
+    if (cT)
+      for (size_t c = 0; c < k; c++)
+        for (size_t i = 0; i < d; i++) cT[i * kp + c] = cent[c * d + i];
   }
+#pragma omp parallel
+  {
+    float *dv = cT ? (float *)malloc(kp * sizeof(float)) : NULL;
+#pragma omp for schedule(static)
+    for (size_t r = 0; r < n; r++) {
+      uint32_t id; float dist;
+      if (dv) {
+        orc_dist_many_T(metric == ORC_DOT, x + r * d, d, cT, kp, dv);
+        int found = 0; uint32_t min_idx = 0; float min_value = INFINITY, min_orig = INFINITY;
+        for (size_t c = 0; c < k; c++) {
+          const float value = dv[c], vb = bias ? value + bias[c] : value;
+          if (vb < min_value) { min_value = vb; min_orig = value; min_idx = (uint32_t)c; found = 1; }
+        }
+        id = found ? min_idx : ORC_NONE; dist = min_orig;
+      } else {
+        orc_argmin_row(metric, x + r * d, cent, k, d, bias, &id, &dist);
+      }
+      ids[r] = id;
+      if (dists) dists[r] = dist;
+    }
+    free(dv);
+  }
+  free(cT);
 }
 
 /* f16 data + f16 centroids (KMeansAlgoFloat<Float16Type>) */
@@ -898,54 +975,8 @@ void orc_transpose_codebook_f32(const float *codebook, size_t d, size_t m_count,
 }
 
 void orc_build_lut_T_f32(int metric, const float *q, size_t d, const float *cbT, size_t m_count, float *lut) {
-  enum { VW = 16, LANES = 16 };
-  const size_t sd = d / m_count, kc = 256, full = sd / LANES * LANES;
-  const int is_dot = metric == ORC_DOT;
-  for (size_t m = 0; m < m_count; m++) {
-    const float *qm = q + m * sd, *T = cbT + m * sd * kc;
-    for (size_t c0 = 0; c0 < kc; c0 += VW) {
-      float s[VW], tot[VW], sums[LANES][VW];
-      for (int v = 0; v < VW; v++) s[v] = 0.0f;
-      if (full != sd) {
-        float acc[VW];
-        for (int v = 0; v < VW; v++) acc[v] = 0.0f;
-        for (size_t i = full; i < sd; i++) {
-          const float xi = qm[i];
-          const float *row = T + i * kc + c0;
-          if (is_dot) {
-#pragma omp simd
-            for (int v = 0; v < VW; v++) acc[v] = acc[v] + xi * row[v];
-          } else {
-#pragma omp simd
-            for (int v = 0; v < VW; v++) { const float diff = xi - row[v]; acc[v] = acc[v] + diff * diff; }
-          }
-        }
-        for (int v = 0; v < VW; v++) s[v] = acc[v];
-      }
-      for (int i = 0; i < LANES; i++)
-        for (int v = 0; v < VW; v++) sums[i][v] = 0.0f;
-      for (size_t c = 0; c < full; c += LANES)
-        for (int i = 0; i < LANES; i++) {
-          const float xi = qm[c + i];
-          const float *row = T + (c + i) * kc + c0;
-          if (is_dot) {
-#pragma omp simd
-            for (int v = 0; v < VW; v++) sums[i][v] += xi * row[v];
-          } else {
-#pragma omp simd
-            for (int v = 0; v < VW; v++) { const float diff = xi - row[v]; sums[i][v] += diff * diff; }
-          }
-        }
-      for (int v = 0; v < VW; v++) tot[v] = 0.0f;
-      for (int i = 0; i < LANES; i++) {
-#pragma omp simd
-        for (int v = 0; v < VW; v++) tot[v] = tot[v] + sums[i][v];
-      }
-      float *out = lut + m * kc + c0;
-      if (is_dot) { for (int v = 0; v < VW; v++) out[v] = 1.0f - (s[v] + tot[v]); }
-      else { for (int v = 0; v < VW; v++) out[v] = s[v] + tot[v]; }
-    }
-  }
+  const size_t sd = d / m_count, kc = 256;
+  for (size_t m = 0; m < m_count; m++) orc_dist_many_T(metric == ORC_DOT, q + m * sd, sd, cbT + m * sd * kc, kc, lut + m * kc);
 }
 
 /* a17: compute_pq_distance (8-bit)  pq/distance.rs:109-144 over TRANSPOSED codes;

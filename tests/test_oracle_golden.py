@@ -825,3 +825,23 @@ def test_lut_built_sixteen_codewords_at_a_time_is_bit_identical(oracle, metric):
             lib.orc_transpose_codebook_f32(P(cb), st(d), st(m), P(cbt))
             lib.orc_build_lut_T_f32(C.c_int(metric), P(q), st(d), P(cbt), st(m), P(b))
             assert (a.view(np.uint32) == b.view(np.uint32)).all(), (metric, sd, m)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_assign_sixteen_centroids_at_a_time_is_bit_identical(oracle, metric):
+    """orc_assign_f32 takes the SIMD-across-centroids route (orc_dist_many_T) for batches with enough work and the one-pair-at-a-time
+    route (orc_argmin_row, pinned by the golden vectors) for small ones: the same rows in one big call and in small slices give the
+    same ids and the same distance bits -- dimensions with and without a 16-lane part, k not a multiple of 16, a bias, NaN / inf."""
+    rng = np.random.default_rng(5)
+    for d, k in ((8, 256), (20, 37), (128, 300), (100, 17)):
+        n = max(64, (1 << 21) // (k * d))
+        x = (rng.standard_normal((n, d)) * 2).astype(np.float32)
+        cent = (rng.standard_normal((k, d)) * 2).astype(np.float32)
+        x[3, 0] = np.nan
+        cent[5, d - 1] = np.inf
+        big_ids, big_d = oracle.assign(x, cent, metric)
+        step = max(1, ((1 << 20) - 1) // (k * d))          # n * k * d < 2^20: the scalar route
+        for lo in range(0, min(n, 6 * step), step):
+            ids, dist = oracle.assign(x[lo:lo + step], cent, metric)
+            assert (ids == big_ids[lo:lo + step]).all(), (d, k, lo)
+            assert (np.asarray(dist).view(np.uint32) == np.asarray(big_d[lo:lo + step]).view(np.uint32)).all(), (d, k, lo)
