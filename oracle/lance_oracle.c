@@ -916,19 +916,36 @@ void orc_pq_train_x(const float *resid, size_t n, size_t d, size_t m_count, uint
   free(sub);
 }
 
+void orc_transpose_codebook_f32(const float *codebook, size_t d, size_t m_count, float *cbT);
 /* a12: ProductQuantizer::transform_impl<8>  pq.rs:116-191: per sub-vector argmin
  * (compute_partition, no bias), unwrap_or(0).  codes row-major [n][M].        */
 void orc_pq_encode_f32(int metric, const float *x, size_t n, size_t d, const float *codebook,
                        size_t m_count, uint32_t nbits, uint8_t *codes) {
   size_t sd = d / m_count, kc = (size_t)1 << nbits;
+  /* 8-bit codes under L2 / dot: the 256 distances of a sub-vector from orc_dist_many_T (bit-identical), same strict-'<' argmin */
+  float *cbT = NULL;
+  if (nbits == 8 && (metric == ORC_L2 || metric == ORC_DOT) && n * d >= (size_t)1 << 12) {
+    cbT = (float *)malloc(m_count * 256 * sd * sizeof(float));
+    if (cbT) orc_transpose_codebook_f32(codebook, d, m_count, cbT);
+  }
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < n; r++) {
+    float dv[256];
     for (size_t m = 0; m < m_count; m++) {
+      if (cbT) {
+        orc_dist_many_T(metric == ORC_DOT, x + r * d + m * sd, sd, cbT + m * sd * 256, 256, dv);
+        int found = 0; uint32_t mi = 0; float mv = INFINITY;
+        for (size_t c = 0; c < 256; c++)
+          if (dv[c] < mv) { mv = dv[c]; mi = (uint32_t)c; found = 1; }
+        codes[r * m_count + m] = found ? (uint8_t)mi : 0;
+        continue;
+      }
       uint32_t id; float dist;
       int found = orc_argmin_row(metric, x + r * d + m * sd, codebook + m * kc * sd, kc, sd, NULL, &id, &dist);
       codes[r * m_count + m] = found ? (uint8_t)id : 0;
     }
   }
+  free(cbT);
 }
 
 /* 4-bit packing  pq.rs:168-172: (v[1] << 4) | v[0] */

@@ -845,3 +845,20 @@ def test_assign_sixteen_centroids_at_a_time_is_bit_identical(oracle, metric):
             ids, dist = oracle.assign(x[lo:lo + step], cent, metric)
             assert (ids == big_ids[lo:lo + step]).all(), (d, k, lo)
             assert (np.asarray(dist).view(np.uint32) == np.asarray(big_d[lo:lo + step]).view(np.uint32)).all(), (d, k, lo)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_pq_encode_sixteen_codewords_at_a_time_is_bit_identical(oracle, metric):
+    """orc_pq_encode_f32's SIMD route (batches of >= 4096 elements) against its one-codeword-at-a-time route (smaller calls): the same
+    rows give the same code bytes, incl. rows with NaN (no codeword selected -> 0, pq.rs:150-160)."""
+    rng = np.random.default_rng(9)
+    for d, m in ((128, 16), (40, 8), (96, 6)):
+        sd = d // m
+        x = (rng.standard_normal((300, d)) * 2).astype(np.float32)
+        x[7, :sd] = np.nan
+        cb = (rng.standard_normal((m, 256, sd)) * 2).astype(np.float32)
+        big = oracle.pq_encode(x, cb, metric=metric)
+        step = max(1, 4095 // d)
+        for lo in range(0, 300, step):
+            part = oracle.pq_encode(x[lo:lo + step], cb, metric=metric)
+            assert (part == big[lo:lo + step]).all(), (d, m, lo)
