@@ -522,6 +522,20 @@ void orc_assign_f32(int metric, const float *x, size_t n, size_t d, const float 
 /* f16 data + f16 centroids (KMeansAlgoFloat<Float16Type>) */
 void orc_assign_f16(int metric, const uint16_t *x, size_t n, size_t d, const uint16_t *cent,
                     size_t k, uint32_t *ids, float *dists) {
+  /* L2: orc_l2_f16 is orc_l2_f32 on the widened elements (same 16 lanes, same order) -- widen once and take the f32 route, whose
+   * SIMD-across-centroids form is bit-identical to the one-pair-at-a-time form (tests/test_oracle_golden.py) */
+  if (!orc_is_dot(metric) && !orc_is_cos(metric) && k >= 16 && n * k * d >= (size_t)1 << 20) {
+    float *xf = (float *)malloc(n * d * sizeof(float)), *cf = (float *)malloc(k * d * sizeof(float));
+    if (xf && cf) {
+#pragma omp parallel for schedule(static)
+      for (size_t i = 0; i < n * d; i++) xf[i] = orc_h2f(x[i]);
+      for (size_t i = 0; i < k * d; i++) cf[i] = orc_h2f(cent[i]);
+      orc_assign_f32(ORC_L2, xf, n, d, cf, k, NULL, ids, dists);
+      free(xf); free(cf);
+      return;
+    }
+    free(xf); free(cf);
+  }
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < n; r++) {
     int found = 0; uint32_t mi = 0; float mv = INFINITY;

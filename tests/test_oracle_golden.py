@@ -862,3 +862,19 @@ def test_pq_encode_sixteen_codewords_at_a_time_is_bit_identical(oracle, metric):
         for lo in range(0, 300, step):
             part = oracle.pq_encode(x[lo:lo + step], cb, metric=metric)
             assert (part == big[lo:lo + step]).all(), (d, m, lo)
+
+
+def test_f16_assign_widened_route_is_bit_identical(oracle):
+    """orc_assign_f16 under L2 widens once and takes orc_assign_f32's SIMD route for big batches; small calls stay on
+    orc_l2_f16 pair by pair: same ids, same distance bits."""
+    rng = np.random.default_rng(13)
+    for d, k in ((16, 64), (128, 100), (40, 33)):
+        n = max(64, (1 << 21) // (k * d))
+        x = (rng.standard_normal((n, d)) * 2).astype(np.float16)
+        cent = (rng.standard_normal((k, d)) * 2).astype(np.float16)
+        big_ids, big_d = oracle.assign(x, cent, "l2")
+        step = max(1, ((1 << 20) - 1) // (k * d))
+        for lo in range(0, min(n, 4 * step), step):
+            ids, dist = oracle.assign(x[lo:lo + step], cent, "l2")
+            assert (ids == big_ids[lo:lo + step]).all(), (d, k, lo)
+            assert (np.asarray(dist).view(np.uint32) == np.asarray(big_d[lo:lo + step]).view(np.uint32)).all(), (d, k, lo)
