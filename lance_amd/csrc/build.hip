@@ -253,6 +253,14 @@ lance_hip_index::~lance_hip_index() {
   if (centroids) (void)hipFree(centroids);
   if (codebook) (void)hipFree(codebook);
   if (cb_mean) (void)hipFree(cb_mean);
+  if (pt) {
+    if (pt->g) (void)hipFree(pt->g);
+    if (pt->cen_t) (void)hipFree(pt->cen_t);
+    if (pt->row_beta) (void)hipFree(pt->row_beta);
+    if (pt->beta_min) (void)hipFree(pt->beta_min);
+    if (pt->beta_abs) (void)hipFree(pt->beta_abs);
+    delete pt;
+  }
   if (part_offsets) (void)hipFree(part_offsets);
   if (codes) (void)hipFree(codes);
   if (row_ids) (void)hipFree(row_ids);
@@ -263,6 +271,7 @@ lance_hip_index::~lance_hip_index() {
 extern "C" {
 
 int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, void *out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && out, "normalize: NULL argument");
   LH_REQUIRE(dtype == LANCE_HIP_F32 || dtype == LANCE_HIP_F16, "normalize: f32 and f16 columns (normalize_fsl accepts float arrays only, kernels.rs:170-186)");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -283,6 +292,7 @@ int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n
 
 int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, const void *centroids,
                        const uint32_t *part_ids, void *out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && centroids && part_ids && out, "residual: NULL argument");
   LH_TRY(check_dtype(dtype, "residual"));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -314,6 +324,7 @@ int lance_hip_residual(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n,
 
 int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                         const void *codebook, uint32_t m, uint32_t nbits, uint8_t *codes) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && codebook && codes, "pq_encode: NULL argument");
   LH_TRY(check_dtype(dtype, "pq_encode"));
   LH_TRY(check_pq_params(d, m, nbits));
@@ -332,6 +343,7 @@ int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x
 int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                            const void *centroids, uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
                            uint32_t *part_ids, uint8_t *codes, double *loss_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && centroids && codebook && part_ids && codes, "ivfpq_encode: NULL argument");
   LH_TRY(check_dtype(dtype, "ivfpq_encode"));
   LH_TRY(check_pq_params(d, m, nbits));
@@ -447,6 +459,7 @@ static int index_finish_offsets(lance_hip_ctx *ctx, lance_hip_index *ix) {
 int lance_hip_index_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,
                            const void *codebook, uint32_t m, uint32_t nbits, const uint32_t *part_ids,
                            const uint8_t *codes, const uint64_t *row_ids, uint64_t n, lance_hip_index **out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(part_ids && codes, "index_create: NULL argument");
   LH_REQUIRE(n < (1ull << 32), "index_create: n too large for this version");
   lance_hip_index *ix = nullptr;
@@ -477,6 +490,7 @@ int lance_hip_index_from_storage(lance_hip_ctx *ctx, int dtype, int metric, uint
                                  uint32_t nlist, const void *codebook, uint32_t m, uint32_t nbits,
                                  const uint32_t *part_offsets_host, const uint8_t *codes, int transposed,
                                  const uint64_t *row_ids, uint64_t n, lance_hip_index **out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(part_offsets_host && (n == 0 || (codes && row_ids)), "index_from_storage: NULL argument");
   LH_REQUIRE(part_offsets_host[0] == 0 && part_offsets_host[nlist] == n, "index_from_storage: offsets do not cover n rows");
   lance_hip_index *ix = nullptr;
@@ -519,6 +533,7 @@ int lance_hip_index_info(const lance_hip_index *idx, uint64_t *n_rows, uint32_t 
 
 int lance_hip_index_export(lance_hip_ctx *ctx, const lance_hip_index *idx, uint32_t *part_offsets_host,
                            uint8_t *codes_transposed_host, uint64_t *row_ids_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && idx, "index_export: NULL argument");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (part_offsets_host) memcpy(part_offsets_host, idx->part_offsets_h.data(), (size_t)(idx->nlist + 1) * 4);

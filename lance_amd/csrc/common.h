@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,11 @@ struct lance_hip_ctx {
   bool timing = false;
   const uint32_t *last_replay_counter = nullptr;  // device word written by the exact kernel of the last search
   std::map<std::string, lh::KernelTimer> timers;
+  // Every extern "C" entry point holds this for its duration (lh::CtxLock): two host threads may share a context -- their
+  // calls serialise, the work of each is ordered on the context's stream -- and threads that want to overlap use a context
+  // each (the reference calls this path from many rayon / tokio threads at once, v2.rs:232-306).  Recursive: entry points
+  // call each other.
+  std::recursive_mutex mu;
 
   // returns nullptr on failure (error set)
   void *scratch(const char *name, size_t bytes);
@@ -76,6 +82,13 @@ struct ScopedTimer {
   lance_hip_ctx *c; const char *k;
   ScopedTimer(lance_hip_ctx *c_, const char *k_) : c(c_), k(k_) { if (c->timing) c->time_begin(k); }
   ~ScopedTimer() { if (c->timing) c->time_end(k); }
+};
+struct CtxLock {
+  lance_hip_ctx *c;
+  explicit CtxLock(lance_hip_ctx *c_) : c(c_) { if (c) c->mu.lock(); }
+  ~CtxLock() { if (c) c->mu.unlock(); }
+  CtxLock(const CtxLock &) = delete;
+  CtxLock &operator=(const CtxLock &) = delete;
 };
 inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 }  // namespace lh

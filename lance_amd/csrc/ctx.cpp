@@ -107,12 +107,14 @@ void lance_hip_ctx_destroy(lance_hip_ctx *ctx) {
 }
 
 int lance_hip_synchronize(lance_hip_ctx *ctx) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx, "ctx is NULL");
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
 
 int lance_hip_malloc(lance_hip_ctx *ctx, size_t bytes, void **out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && out, "malloc: NULL argument");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   hipError_t e = hipMalloc(out, bytes ? bytes : 16);
@@ -123,11 +125,13 @@ int lance_hip_malloc(lance_hip_ctx *ctx, size_t bytes, void **out) {
   return LANCE_HIP_OK;
 }
 int lance_hip_free(lance_hip_ctx *ctx, void *ptr) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx, "ctx is NULL");
   if (ptr) LH_CHECK_HIP(hipFree(ptr));
   return LANCE_HIP_OK;
 }
 int lance_hip_memcpy_h2d(lance_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && (bytes == 0 || (dst && src_host)), "memcpy_h2d: NULL argument");
   if (bytes == 0) return LANCE_HIP_OK;
   LH_CHECK_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -135,6 +139,7 @@ int lance_hip_memcpy_h2d(lance_hip_ctx *ctx, void *dst, const void *src_host, si
   return LANCE_HIP_OK;
 }
 int lance_hip_memcpy_d2h(lance_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && (bytes == 0 || (dst_host && src)), "memcpy_d2h: NULL argument");
   if (bytes == 0) return LANCE_HIP_OK;
   LH_CHECK_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -143,12 +148,14 @@ int lance_hip_memcpy_d2h(lance_hip_ctx *ctx, void *dst_host, const void *src, si
 }
 
 int lance_hip_timing_enable(lance_hip_ctx *ctx, int on) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx, "ctx is NULL");
   ctx->timing = on != 0;
   return LANCE_HIP_OK;
 }
 
 int lance_hip_timing_query(lance_hip_ctx *ctx, const char *kernel, double *ms_total, uint64_t *launches) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && kernel, "timing_query: NULL argument");
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   auto &t = ctx->timers[kernel];

@@ -1,6 +1,7 @@
 // index.h -- device-resident IVF_PQ index (see build.hip for the layout rationale).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 struct int2_host { int x, y; };
@@ -14,6 +15,15 @@ struct lance_hip_index {
   float *centroids = nullptr;     // [nlist][d]
   float *codebook = nullptr;      // [m][256][d/m]
   float *cb_mean = nullptr;       // 8-bit PQ: [d] mean codeword of every sub-quantiser, then [1] sum over m of the mean |c|^2 (bound pass scale)
+  // LANCE_HIP_QPT=1 (search_qt.hip, per-query tables): constants of that filter, created by the first such search
+  struct PtConst {
+    float *g = nullptr;           // [d] mean centroid (the translation that keeps the table's resolution)
+    float *cen_t = nullptr;       // [nlist][d] centroids - g
+    float *row_beta = nullptr;    // [n] sum over m of 2 cen_t[p][m] . codeword[m][code] for every stored row
+    float *beta_min = nullptr;    // [nlist] smallest row_beta of the partition
+    float *beta_abs = nullptr;    // [nlist] largest |row_beta| of the partition
+  } *pt = nullptr;
+  std::mutex lazy_mu;             // guards the creation of `pt` (several contexts / host threads may search one index)
   uint32_t *part_offsets = nullptr;  // [nlist+1] device
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition

@@ -110,6 +110,10 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow);
 int find_partitions_f32(lance_hip_ctx *ctx, int metric, const float *qf, uint32_t nq, uint32_t d, const float *cf, uint32_t nlist,
                         uint32_t nprobes, uint32_t *part_ids, float *dists, bool lanes32);   // search.hip
+// mfma_assign.hip: the coarse quantiser at query time on the matrix cores (surrogate matrix + exact re-check of the candidates)
+bool coarse_mfma_supported(int metric, int d, uint32_t nq, uint32_t nlist, uint32_t nprobes, bool lanes32, const float *q, const float *cent);
+int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t nprobes,
+                         float *matrix, uint32_t *part_ids, float *dists);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16);   // f16: half-precision arithmetic on f32 containers
 
 // quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
@@ -130,7 +134,9 @@ int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
-                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow);
+                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow, const uint32_t *probes = nullptr);
+// search_qt.hip: per-query tables + per-row bias instead of a table per (query, partition) (M = 48 / 64 / 96; LANCE_HIP_QPT=1)
+bool qscan_pt_enabled(const lance_hip_index *ix);
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
                   uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow);

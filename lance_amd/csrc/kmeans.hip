@@ -568,6 +568,7 @@ extern "C" {
 
 int lance_hip_assign(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                      const void *centroids, uint32_t k, const float *bias, uint32_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && centroids && ids, "assign: NULL argument");
   LH_TRY(check_dtype(dtype, "assign"));
   LH_REQUIRE(d > 0 && k > 0, "assign: d and k must be > 0");
@@ -611,6 +612,7 @@ int lance_hip_kmeans_train_ex(lance_hip_ctx *ctx, int dtype, int metric, const v
                               uint32_t max_iters, double tol, float balance_factor, uint32_t hierarchical_k,
                               const void *init_centroids, uint64_t seed, void *centroids_out, double *loss_out_host,
                               uint32_t *iters_out_host, uint32_t *k_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && centroids_out, "kmeans_train: NULL argument");
   LH_TRY(check_dtype(dtype, "kmeans_train"));
   LH_REQUIRE(d > 0 && k > 0 && n > 0, "kmeans_train: empty problem");
@@ -651,6 +653,7 @@ int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void
                            uint32_t k, uint32_t max_iters, double tol, float balance_factor,
                            const void *init_centroids, uint64_t seed, void *centroids_out,
                            double *loss_out_host, uint32_t *iters_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
   // KMeansParams default hierarchical_k = 16 (kmeans.rs:92-103)
   return lance_hip_kmeans_train_ex(ctx, dtype, metric, x, n, d, k, max_iters, tol, balance_factor, 16, init_centroids, seed,
                                    centroids_out, loss_out_host, iters_out_host, nullptr);
@@ -659,6 +662,7 @@ int lance_hip_kmeans_train(lance_hip_ctx *ctx, int dtype, int metric, const void
 int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d,
                                    const void *centroids, uint32_t k, const float *bias, float *buf, double *losses,
                                    float *radius, double *loss_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && x && centroids && buf, "kmeans_estep_partial: NULL argument");
   LH_REQUIRE(dtype == LANCE_HIP_F32, "kmeans_estep_partial: only f32 is implemented in this version");
   LH_REQUIRE(n < (1ull << 32) && k <= 4096, "kmeans_estep_partial: n or k too large for this version");
@@ -808,6 +812,7 @@ int lance_hip_kmeans_init_indices(uint64_t n, uint32_t k, uint64_t seed, uint64_
 }
 
 int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_factor_scaled, uint64_t seed, void *state, float *bias) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && state && bias, "kmeans_shard_begin: NULL argument");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(kmeans_shard_init_kernel, dim3(4), dim3(256), 0, ctx->stream, static_cast<KmShardState *>(state), bias, (int)k,
@@ -818,6 +823,7 @@ int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_f
 
 int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
                                  const float *bias, const void *state, float *buf, double *losses, float *radius) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && centroids && buf && losses && radius && state && (n == 0 || x), "kmeans_shard_estep: NULL argument");
   LH_REQUIRE(n < (1ull << 32) && k <= 4096, "kmeans_shard_estep: n or k too large for this version");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -849,6 +855,7 @@ int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x,
 int lance_hip_kmeans_shard_update(lance_hip_ctx *ctx, void *state, const float *buf, const double *losses, const float *radius,
                                   float *centroids, float *bias, uint32_t k, uint32_t d, uint64_t n_total, float balance_factor_scaled,
                                   double tol, uint32_t it) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && state && buf && losses && radius && centroids && bias, "kmeans_shard_update: NULL argument");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(kmeans_shard_update_kernel, dim3(1), dim3(256), (size_t)k * 12 + 8, ctx->stream, static_cast<KmShardState *>(state), buf,
@@ -858,6 +865,7 @@ int lance_hip_kmeans_shard_update(lance_hip_ctx *ctx, void *state, const float *
 }
 
 int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *loss_host, uint32_t *iters_host, int *active_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && state, "kmeans_shard_end: NULL argument");
   KmShardState h;
   LH_CHECK_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -869,6 +877,7 @@ int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *lo
 }
 
 int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, uint32_t k, uint32_t d, void *centroids_out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && buf && centroids_out, "kmeans_finalize: NULL argument");
   LH_REQUIRE(dtype == LANCE_HIP_F32, "kmeans_finalize: only f32 is implemented in this version");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -882,6 +891,7 @@ int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, u
 int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uint64_t n, uint32_t d, uint32_t m,
                        uint32_t nbits, uint32_t max_iters, uint32_t sample_rate, uint64_t seed, void *codebook_out,
                        uint32_t *iters_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && residuals && codebook_out, "pq_train: NULL argument");
   LH_TRY(check_dtype(dtype, "pq_train"));
   LH_REQUIRE(m > 0 && d % m == 0, "num_sub_vectors must divide vector dimension %u, but got %u", d, m);

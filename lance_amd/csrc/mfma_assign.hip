@@ -87,6 +87,11 @@ struct MaArgs {
   const uint16_t *xhi = nullptr, *xlo = nullptr;
   const float *xn2 = nullptr;
   int dp = 0;
+  // SUR = true instantiations (coarse_mfma.hip: find_partitions at query time): the surrogates go to a matrix instead of a running
+  // top-4, the centroid tiles are split over blockIdx.y (small query batches would otherwise leave most CUs idle)
+  float *sur = nullptr;        // [n][k] surrogate values
+  float *e2 = nullptr;         // [n] 2E of the row (the select kernel's candidate margin)
+  int tiles_per_block = 0;     // centroid tiles (narrow: MA_CT, wide: MW_CT centroids) per blockIdx.y slice
 };
 
 // running four smallest (values m1 <= m2 <= m3 <= m4, centroid ids of the first three)
@@ -112,7 +117,7 @@ __device__ __forceinline__ void top4_insert(Top4 &t, float v, uint32_t i) {
 }
 
 // KS = d / 16 MFMA k-steps (d <= 128).  DOT: surrogate = -x.c + bias.
-template <int KS, int METRIC, typename TX>
+template <int KS, int METRIC, typename TX, bool SUR = false>
 __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.active && !p.active[0]) return;
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
   xn2 += __shfl_xor(xn2, 32, 64);
   __syncthreads();   // xs is dead: the same LDS now holds centroid tiles
 
-  const int ntiles = (p.k + MA_CT - 1) / MA_CT;
+  int ntiles = (p.k + MA_CT - 1) / MA_CT, t_first = 0;
+  if constexpr (SUR) { t_first = (int)blockIdx.y * p.tiles_per_block; ntiles = min(ntiles, t_first + p.tiles_per_block); }
   constexpr int NCH = MA_CT * D / 8;          // 16-byte chunks per plane
   constexpr int CH = (NCH + 255) / 256;       // per thread (4 at D = 128)
   uint4 ph[CH], pl[CH];
@@ -191,10 +197,10 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
     if (threadIdx.x < MA_CT) { cns[(buf * 2 + 0) * MA_CT + threadIdx.x] = pcn; cns[(buf * 2 + 1) * MA_CT + threadIdx.x] = pbias; }
   };
   Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
-  tile_fetch(0);
-  tile_store(0);
+  tile_fetch(t_first);
+  tile_store(t_first & 1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_first; t < ntiles; ++t) {
     const int buf = t & 1;
     if (t + 1 < ntiles) tile_fetch(t + 1);
     const uint16_t *hi = cbuf + (size_t)(buf * 2 + 0) * MA_CT * CS, *lo = cbuf + (size_t)(buf * 2 + 1) * MA_CT * CS;
@@ -235,17 +241,31 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
           if (c0 + ib + e >= p.k) v = INFINITY;
           sv[vq * 4 + e] = v;
           bm = fminf(bm, v);
+          if constexpr (SUR) {
+            const int64_t srow = row0 + wave * 32 + j;
+            if (srow < p.n && c0 + ib + e < p.k) p.sur[srow * p.k + c0 + ib + e] = v;
+          }
         }
       }
+      if constexpr (!SUR) {
       if (bm < tp.m4) {
 #pragma unroll
         for (int vq = 0; vq < 4; ++vq)
 #pragma unroll
           for (int e = 0; e < 4; ++e) top4_insert(tp, sv[vq * 4 + e], (uint32_t)(c0 + blk * 32 + 8 * vq + 4 * g + e));
       }
+      }
     }
     if (t + 1 < ntiles) tile_store(buf ^ 1);
     __syncthreads();
+  }
+  if constexpr (SUR) {
+    const int64_t srow = row0 + wave * 32 + j;
+    if (g == 0 && srow < p.n && blockIdx.y == 0) {
+      const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
+      p.e2[srow] = 2.0f * 0.0001220703125f * (xn2 + cmax2 + bmax);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
+    }
+    return;
   }
   // the two lanes of a row hold disjoint centroid subsets: merge the partner's four
   {
@@ -435,7 +455,7 @@ __global__ __launch_bounds__(256) void ma_split_rows_kernel(const TX *__restrict
   if (lane == 0) xn2[row] = s;
 }
 
-template <int METRIC>
+template <int METRIC, bool SUR = false>
 __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   __shared__ __attribute__((aligned(16))) uint16_t abuf[2][MW_CT][MW_LS];     // centroid chunk: hi / lo planes   20 KB
   __shared__ __attribute__((aligned(16))) uint16_t bbuf[2][MW_ROWS][MW_LS];   // row chunk: hi / lo planes        20 KB
@@ -448,8 +468,10 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
   // chunk loads: 128 rows x 32 elements = 512 16-byte pieces per plane; thread -> (row = idx >> 2, piece = idx & 3), 2 per plane
   const int lr0 = threadIdx.x >> 2, lc = threadIdx.x & 3;
-  const int nchunks = dp / MW_KC, ntiles = (p.k + MW_CT - 1) / MW_CT;
-  const int total = nchunks * ntiles;
+  const int nchunks = dp / MW_KC;
+  int ntiles = (p.k + MW_CT - 1) / MW_CT, t_first = 0;
+  if constexpr (SUR) { t_first = (int)blockIdx.y * p.tiles_per_block; ntiles = min(ntiles, t_first + p.tiles_per_block); }
+  const int total = nchunks * ntiles, it_first = nchunks * t_first;
   uint4 ga[2][2], gb[2][2];
   float gcn = 0.0f, gbias = 0.0f;
   // software pipeline: the global loads of step it + 1 are issued before the MFMAs of step it and land while they run
@@ -475,8 +497,8 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
     }
   };
   f32x16 acc[4];
-  fetch(0);
-  for (int it = 0; it < total; ++it) {
+  if (it_first < total) fetch(it_first);
+  for (int it = it_first; it < total; ++it) {
     const int c0 = (it / nchunks) * MW_CT, kc = it % nchunks;
     if (kc == 0) {
 #pragma unroll
@@ -527,15 +549,29 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
           if (c0 + ib + e >= p.k) v = INFINITY;
           sv[vq * 4 + e] = v;
           bm = fminf(bm, v);
+          if constexpr (SUR) {
+            const int64_t srow = row0 + wave * 32 + j;
+            if (srow < p.n && c0 + ib + e < p.k) p.sur[srow * p.k + c0 + ib + e] = v;
+          }
         }
       }
+      if constexpr (!SUR) {
       if (bm < tp.m4) {
 #pragma unroll
         for (int vq = 0; vq < 4; ++vq)
 #pragma unroll
           for (int e = 0; e < 4; ++e) top4_insert(tp, sv[vq * 4 + e], (uint32_t)(c0 + b * 32 + 8 * vq + 4 * g + e));
       }
+      }
     }
+  }
+  if constexpr (SUR) {
+    const int64_t srow = row0 + wave * 32 + j;
+    if (g == 0 && srow < p.n && blockIdx.y == 0) {
+      const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
+      p.e2[srow] = 2.0f * 0.000244140625f * (p.xn2[srow] + cmax2 + bmax);   // 2E, E = 2^-12 (|x|^2 + max|c|^2 + max|bias|)
+    }
+    return;
   }
   {
     const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
@@ -723,6 +759,255 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
     default: return LANCE_HIP_EINVAL;
   }
   LH_REQUIRE(ok, "assign: element type %d with metric %d is not on the MFMA path", dtype, metric);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+// =====================================================================================================================
+// find_partitions at query time on the matrix cores  (ivf/storage.rs:107-119 -> kmeans_find_partitions kmeans.rs:1134-1158)
+//
+// The reference computes every query's distance to all nlist centroids and keeps the nprobes smallest, ascending by
+// (distance, index).  Here the [nq][nlist] matrix is the bf16x3 SURROGATE of the kernels above (SUR = true: s(c) = |c|^2 - 2 q.c,
+// dot: -q.c; |s(c) + const_q - dist_ref(c)| <= E with E as in the assign path), and one wave per query turns it into the exact
+// answer:
+//   T0   = the nprobes-th smallest of the 64 lane minima of the row -- at least nprobes centroids have s <= T0;
+//   cand = { c : s(c) <= T0 + 2E } -- every centroid of the reference's answer is in it (its dist_ref is <= the nprobes-th
+//          smallest dist_ref <= T0 + const_q + E, hence s <= T0 + 2E); usually nprobes + 1..3 centroids;
+//   the candidates' distances are recomputed in the reference's order (16 lane accumulators = the 16 lanes of a group,
+//   remainder first, lane-ordered fold: dist_exact_rt's value), sorted by (total_cmp key, index), the first nprobes emitted.
+// A row with a NaN / overflowed bound, or with more candidates than the list holds (ties: duplicate centroids), is answered by
+// the same wave from exact distances to ALL centroids -- rare, slow, and still the reference's result.
+constexpr int CS_CAP = 128;     // candidates per query (two per lane in the final sort)
+
+template <int METRIC>
+__device__ __forceinline__ float cs_group_distance(const float *wrow, const float *__restrict__ y, int d, int lane) {
+  // the 16 lanes of a group: lane i = lane accumulator i of l2_scalar / dot_scalar (see ma_finalize_wide_kernel)
+  const int i = lane & 15, full = d / 16 * 16;
+  float s = 0.0f, acc = 0.0f;
+  if (full != d) {
+    float r = 0.0f;
+    for (int e = full; e < d; ++e) {
+      if constexpr (METRIC == METRIC_DOT) r = r + wrow[e] * y[e];
+      else { const float diff = wrow[e] - y[e]; r = r + diff * diff; }
+    }
+    s = r;
+  }
+  for (int ch = 0; ch < full; ch += 16) {
+    const float xv = wrow[ch + i], yv = y[ch + i];
+    if constexpr (METRIC == METRIC_DOT) acc = acc + xv * yv;
+    else { const float diff = xv - yv; acc = acc + diff * diff; }
+  }
+  float tot = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) tot = tot + __shfl(acc, (lane & 48) + t, 64);     // ((0 + a0) + a1) + ... + a15
+  return finish_metric<METRIC>(s + tot);
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ sur, const float *__restrict__ e2, const float *__restrict__ q,
+                                                            const float *__restrict__ cent, int nq, int nlist, int d, int nprobes,
+                                                            uint32_t *__restrict__ part_ids, float *__restrict__ dists,
+                                                            uint32_t *__restrict__ n_exact_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= nq) return;                       // no workgroup-level barrier below: waves are independent
+  const int dpad = (d + 3) & ~3;
+  float *wrow = reinterpret_cast<float *>(smem) + (size_t)wave * dpad;
+  unsigned long long *ck = reinterpret_cast<unsigned long long *>(smem + (size_t)4 * dpad * 4) + (size_t)wave * CS_CAP;   // (key << 32) | centroid
+  uint32_t *cl = reinterpret_cast<uint32_t *>(smem + (size_t)4 * dpad * 4 + (size_t)4 * CS_CAP * 8) + (size_t)wave * CS_CAP;
+  const float *qv = q + (int64_t)qi * d;
+  for (int e = lane; e < d; e += 64) wrow[e] = qv[e];
+  float *row = sur + (int64_t)qi * nlist;
+  const float E2 = e2[qi];
+  // pass 1: lane minima (a NaN anywhere sends the row to the exact path)
+  float mn = INFINITY;
+  bool bad = !(E2 < INFINITY);
+  for (int i = lane; i < nlist; i += 64) {
+    const float v = row[i];
+    bad |= v != v;
+    mn = fminf(mn, v);
+  }
+  bad = __any(bad);
+  float sv = mn;
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int jj = k2 >> 1; jj > 0; jj >>= 1) {
+      const float o = __shfl_xor(sv, jj, 64);
+      const bool up = (lane & k2) == 0, lower = (lane & jj) == 0;
+      sv = (lower == up) ? fminf(sv, o) : fmaxf(sv, o);
+    }
+  }
+  const float thr = __shfl(sv, nprobes - 1, 64) + E2;     // nprobes <= 64 (host); +inf when fewer than nprobes lanes hold a value
+  uint32_t cnt = 0;
+  if (!bad) {
+    for (int base = 0; base < nlist; base += 64) {
+      const int i = base + lane;
+      const bool take = i < nlist && row[i] <= thr;
+      const unsigned long long mask = __ballot(take);
+      if (take) {
+        const uint32_t pos = cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < (uint32_t)CS_CAP) cl[pos] = (uint32_t)i;
+      }
+      cnt += (uint32_t)__popcll(mask);
+    }
+    if (cnt > (uint32_t)CS_CAP || cnt < (uint32_t)nprobes) bad = true;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (bad) {
+    // exact distances to every centroid, written over the row; then the nprobes smallest (key, index) one after the other
+    if (lane == 0 && n_exact_rows) atomicAdd(n_exact_rows, 1u);
+    for (int c0 = 0; c0 < nlist; c0 += 4) {
+      const int c = c0 + grp;
+      float v = 0.0f;
+      if (c < nlist) v = cs_group_distance<METRIC>(wrow, cent + (int64_t)c * d, d, lane);
+      else (void)cs_group_distance<METRIC>(wrow, cent, d, lane);          // keep the shuffles wave-uniform
+      if (c < nlist && (lane & 15) == 0) row[c] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    unsigned long long last = 0ull;
+    bool have_last = false;
+    for (int r = 0; r < nprobes; ++r) {
+      unsigned long long best = ~0ull;
+      for (int i = lane; i < nlist; i += 64) {
+        const unsigned long long kk = ((unsigned long long)order_key(row[i]) << 32) | (uint32_t)i;
+        if ((!have_last || kk > last) && kk < best) best = kk;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o, 64); best = ob < best ? ob : best; }
+      if (lane == 0) {
+        part_ids[(int64_t)qi * nprobes + r] = (uint32_t)best;
+        if (dists) dists[(int64_t)qi * nprobes + r] = key_to_float((uint32_t)(best >> 32));
+      }
+      last = best; have_last = true;
+    }
+    return;
+  }
+  // exact distances of the candidates, four per round
+  for (uint32_t c0 = 0; c0 < cnt; c0 += 4) {
+    const uint32_t ci = c0 + (uint32_t)grp;
+    const uint32_t c = ci < cnt ? cl[ci] : cl[0];
+    const float v = cs_group_distance<METRIC>(wrow, cent + (int64_t)c * d, d, lane);
+    if (ci < cnt && (lane & 15) == 0) ck[ci] = ((unsigned long long)order_key(v) << 32) | c;
+  }
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long v2[2];
+#pragma unroll
+  for (int jr = 0; jr < 2; ++jr) {
+    const uint32_t e = (uint32_t)(jr * 64 + lane);
+    v2[jr] = e < cnt ? ck[e] : ~0ull;
+  }
+  // bitonic network over 128 elements: element e = register e / 64 of lane e % 64
+#pragma unroll
+  for (int k2 = 2; k2 <= 128; k2 <<= 1) {
+#pragma unroll
+    for (int dd = k2 >> 1; dd > 0; dd >>= 1) {
+      if (dd >= 64) {
+        const bool up = true;       // k2 = 128: one ascending sequence
+        const unsigned long long a = v2[0], b = v2[1];
+        if ((a > b) == up) { v2[0] = b; v2[1] = a; }
+      } else {
+#pragma unroll
+        for (int jr = 0; jr < 2; ++jr) {
+          const int e = jr * 64 + lane;
+          const unsigned long long o = __shfl_xor(v2[jr], dd, 64);
+          const bool up = (e & k2) == 0, lower = (lane & dd) == 0;
+          v2[jr] = (lower == up) ? (v2[jr] < o ? v2[jr] : o) : (v2[jr] > o ? v2[jr] : o);
+        }
+      }
+    }
+  }
+  if (lane < nprobes) {       // nprobes <= 64: the answer sits in register 0
+    part_ids[(int64_t)qi * nprobes + lane] = (uint32_t)v2[0];
+    if (dists) dists[(int64_t)qi * nprobes + lane] = key_to_float((uint32_t)(v2[0] >> 32));
+  }
+}
+
+bool coarse_mfma_supported(int metric, int d, uint32_t nq, uint32_t nlist, uint32_t nprobes, bool lanes32, const float *q, const float *cent) {
+  static const char *env = getenv("LANCE_HIP_MFMA_COARSE");      // "0": off, "1": on for every shape the kernels take
+  static const bool off = env && env[0] == '0', force = env && env[0] == '1';
+  if (off || lanes32 || (metric != METRIC_L2 && metric != METRIC_DOT)) return false;
+  if (nprobes == 0 || nprobes > 64 || nprobes > nlist) return false;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cent)) & 15) return false;
+  if (d <= 128) { if (d % 16 != 0 || d < 16 || nlist < 32) return false; }
+  else if (d > 4096 || nlist < 64 || d % 4 != 0) return false;
+  if (force) return true;
+  // below this the exact kernel's matrix is cheaper than the split / prep launches
+  return (uint64_t)nq * nlist * (uint64_t)d >= (1ull << 27);
+}
+
+template <int KS>
+static void coarse_launch_narrow(lance_hip_ctx *ctx, const MaArgs &a, int metric, dim3 grid) {
+  constexpr int D = KS * 16;
+  const size_t lds_x = (size_t)MA_ROWS * (D + 4) * 4;
+  const size_t lds_c = (size_t)2 * 2 * MA_CT * (D + 8) * 2 + (size_t)2 * 2 * MA_CT * 4;
+  const size_t lds = std::max(lds_x, lds_c);
+  if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_DOT, float, true>), grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_L2, float, true>), grid, dim3(256), lds, ctx->stream, a);
+}
+
+// part_ids [nq][nprobes], dists [nq][nprobes] or NULL; matrix: [nq][nlist] scratch of the caller.  Enqueues only.
+int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t nprobes,
+                         float *matrix, uint32_t *part_ids, float *dists) {
+  const bool wide = d > 128;
+  const int dp = wide ? (d + MW_KC - 1) / MW_KC * MW_KC : d;
+  const size_t kd = (size_t)nlist * dp;
+  uint16_t *chi = ctx->scratch_t<uint16_t>("cq.chi", kd), *clo = ctx->scratch_t<uint16_t>("cq.clo", kd);
+  float *cn = ctx->scratch_t<float>("cq.cn", (size_t)nlist);
+  uint32_t *maxbits = ctx->scratch_t<uint32_t>("cq.maxbits", 4);   // [0] max |c|^2, [1] unused (no bias), [2] rows answered by the exact path
+  float *e2 = ctx->scratch_t<float>("cq.e2", (size_t)nq);
+  if (!chi || !clo || !cn || !maxbits || !e2) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemsetAsync(maxbits, 0, 16, ctx->stream));
+  {
+    ScopedTimer t(ctx, "dist_matrix");
+    hipLaunchKernelGGL(ma_prep_kernel, dim3(nlist), dim3(64), 0, ctx->stream, cent, (int)nlist, d, dp, nullptr, chi, clo, cn, maxbits, nullptr);
+    MaArgs a;
+    a.x = q; a.n = nq; a.ldx = d; a.d = d; a.k = (int)nlist;
+    a.chi = chi; a.clo = clo; a.cn = cn; a.bias = nullptr; a.maxbits = maxbits; a.cent = cent;
+    a.sur = matrix; a.e2 = e2; a.active = nullptr;
+    const unsigned rblocks = (unsigned)cdiv(nq, wide ? MW_ROWS : MA_ROWS);
+    const int ntiles = (int)cdiv(nlist, wide ? MW_CT : MA_CT);
+    // enough slices to put about two workgroups on every CU
+    int slices = (int)std::min<uint64_t>((uint64_t)ntiles, std::max<uint64_t>(1, cdiv((uint64_t)2 * ctx->num_cus, rblocks)));
+    a.tiles_per_block = (int)cdiv((uint64_t)ntiles, (uint64_t)slices);
+    slices = (int)cdiv((uint64_t)ntiles, (uint64_t)a.tiles_per_block);
+    const dim3 grid(rblocks, (unsigned)slices);
+    if (wide) {
+      uint16_t *xhi = ctx->scratch_t<uint16_t>("cq.xhi", (size_t)nq * dp), *xlo = ctx->scratch_t<uint16_t>("cq.xlo", (size_t)nq * dp);
+      float *xn2 = ctx->scratch_t<float>("cq.xn2", (size_t)nq);
+      if (!xhi || !xlo || !xn2) return LANCE_HIP_ENOMEM;
+      a.xhi = xhi; a.xlo = xlo; a.xn2 = xn2; a.dp = dp;
+      hipLaunchKernelGGL((ma_split_rows_kernel<float>), dim3((unsigned)cdiv(nq, 4)), dim3(256), 0, ctx->stream, q, (int64_t)nq, (int64_t)d, d, dp, xhi, xlo,
+                         xn2, nullptr);
+      if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_top3_wide_kernel<METRIC_DOT, true>), grid, dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((ma_top3_wide_kernel<METRIC_L2, true>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+      switch (d / 16) {
+        case 1: coarse_launch_narrow<1>(ctx, a, metric, grid); break;
+        case 2: coarse_launch_narrow<2>(ctx, a, metric, grid); break;
+        case 3: coarse_launch_narrow<3>(ctx, a, metric, grid); break;
+        case 4: coarse_launch_narrow<4>(ctx, a, metric, grid); break;
+        case 5: coarse_launch_narrow<5>(ctx, a, metric, grid); break;
+        case 6: coarse_launch_narrow<6>(ctx, a, metric, grid); break;
+        case 7: coarse_launch_narrow<7>(ctx, a, metric, grid); break;
+        case 8: coarse_launch_narrow<8>(ctx, a, metric, grid); break;
+        default: return LANCE_HIP_EINVAL;
+      }
+    }
+  }
+  {
+    ScopedTimer t(ctx, "select_probes");
+    const int dpad = (d + 3) & ~3;
+    const size_t lds = (size_t)4 * dpad * 4 + (size_t)4 * CS_CAP * 8 + (size_t)4 * CS_CAP * 4;
+    if (metric == METRIC_DOT)
+      hipLaunchKernelGGL((coarse_select_kernel<METRIC_DOT>), dim3((unsigned)cdiv(nq, 4)), dim3(256), lds, ctx->stream, matrix, e2, q, cent, (int)nq, (int)nlist,
+                         d, (int)nprobes, part_ids, dists, maxbits + 2);
+    else
+      hipLaunchKernelGGL((coarse_select_kernel<METRIC_L2>), dim3((unsigned)cdiv(nq, 4)), dim3(256), lds, ctx->stream, matrix, e2, q, cent, (int)nq, (int)nlist,
+                         d, (int)nprobes, part_ids, dists, maxbits + 2);
+  }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

@@ -143,6 +143,8 @@ int qscan8_residual(lance_hip_ctx *ctx, const float *qs, const uint32_t *pair_id
 bool qscan8_launch(lance_hip_ctx *ctx, const QscanArgs &a, int sd, unsigned grid);
 
 // search_qt.hip
+int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const QscanArgs &a, const float *qs, uint32_t nq, const uint32_t *probes,
+                    unsigned grid);
 bool qscan_tiled_launch(lance_hip_ctx *ctx, const QscanArgs &a, int m, int sd, unsigned grid);
 bool qbound_tiled_launch(lance_hip_ctx *ctx, const QboundArgs &a, int m, int sd, unsigned grid);
 

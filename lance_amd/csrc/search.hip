@@ -991,10 +991,14 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
   uint32_t *probes = ctx->scratch_t<uint32_t>("search.probes", (size_t)nq * nprobes);
   if (!matrix || !probes) return LANCE_HIP_ENOMEM;
-  {
+  const bool coarse_l32 = ix->dtype == LANCE_HIP_F16 && scan_metric == LANCE_HIP_DOT && d > 16;
+  if (coarse_mfma_supported(scan_metric, d, nq, (uint32_t)nlist, nprobes, coarse_l32, qs, ix->centroids)) {
+    // kmeans.rs:1134-1158 on the matrix cores: bf16x3 surrogate matrix, exact re-check of the nprobes + few candidates
+    LH_TRY(find_partitions_mfma(ctx, scan_metric, qs, nq, d, ix->centroids, (uint32_t)nlist, nprobes, matrix, probes, nullptr));
+  } else {
     PairwiseArgs pa;
     pa.x = qs; pa.n = nq; pa.ldx = d; pa.cent = ix->centroids; pa.k = nlist; pa.matrix = matrix;
-    pa.lanes32 = ix->dtype == LANCE_HIP_F16 && scan_metric == LANCE_HIP_DOT && d > 16;
+    pa.lanes32 = coarse_l32;
     LH_TRY(launch_dist_matrix(ctx, pa, d, scan_metric, 1));
     ScopedTimer t(ctx, "select_probes");
     launch_select_probes(ctx, matrix, nlist, (int)nprobes, (int)nq, probes, nullptr);
@@ -1140,12 +1144,17 @@ int find_partitions_f32(lance_hip_ctx *ctx, int metric, const float *qf, uint32_
   if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
   float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
   if (!matrix) return LANCE_HIP_ENOMEM;
-  PairwiseArgs pa;
-  pa.x = qf; pa.n = nq; pa.ldx = d;
-  pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
-  pa.lanes32 = lanes32;
-  LH_TRY(launch_dist_matrix(ctx, pa, (int)d, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, 1));
-  launch_select_probes(ctx, matrix, (int)nlist, (int)nprobes, (int)nq, part_ids, dists);
+  const int km = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
+  if (coarse_mfma_supported(km, (int)d, nq, nlist, nprobes, lanes32, qf, cf)) {
+    LH_TRY(find_partitions_mfma(ctx, km, qf, nq, (int)d, cf, nlist, nprobes, matrix, part_ids, dists));
+  } else {
+    PairwiseArgs pa;
+    pa.x = qf; pa.n = nq; pa.ldx = d;
+    pa.cent = cf; pa.k = (int)nlist; pa.matrix = matrix;
+    pa.lanes32 = lanes32;
+    LH_TRY(launch_dist_matrix(ctx, pa, (int)d, km, 1));
+    launch_select_probes(ctx, matrix, (int)nlist, (int)nprobes, (int)nq, part_ids, dists);
+  }
   LH_CHECK_HIP(hipGetLastError());
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
@@ -1177,6 +1186,7 @@ extern "C" {
 
 int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const void *q, uint32_t nq, uint32_t d,
                               const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && q && centroids && part_ids, "find_partitions: NULL argument");
   LH_TRY(check_dtype(dtype, "find_partitions"));
   LH_REQUIRE(nlist > 0 && nlist <= 65536, "find_partitions: nlist=%u not supported in this version (1..65536)", nlist);
@@ -1190,6 +1200,7 @@ int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const v
 
 int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                  uint32_t nprobes, uint32_t refine_factor, uint64_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search: NULL argument");
   LH_REQUIRE(ctx->device == idx->device, "search: context and index live on different devices");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -1200,6 +1211,7 @@ int lance_hip_ivfpq_search_async(lance_hip_ctx *ctx, const lance_hip_index *idx,
 
 int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                            uint32_t nprobes, uint32_t refine_factor, uint64_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search: NULL argument");
   LH_REQUIRE(ctx->device == idx->device, "search: context and index live on different devices");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -1212,6 +1224,7 @@ int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const
 
 int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                  uint32_t nprobes, uint32_t refine_factor, float lower, float upper, uint64_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "search_range: NULL argument");
   LH_REQUIRE(ctx->device == idx->device, "search_range: context and index live on different devices");
   LH_REQUIRE(idx->m != 0, "search_range: not an IVF_PQ index");
@@ -1274,17 +1287,20 @@ static int search_filtered_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, 
 int lance_hip_ivfpq_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                     uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
                                     uint64_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   return search_filtered_impl(ctx, idx, q, nq, k, nprobes, refine_factor, allow_by_rowid, n_allow, 0, 0.f, 0.f, ids, dists);
 }
 
 int lance_hip_ivfpq_search_filtered_range(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                           uint32_t nprobes, uint32_t refine_factor, const uint8_t *allow_by_rowid, uint64_t n_allow,
                                           float lower, float upper, uint64_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(!(lower > upper), "search_filtered_range: lower bound %g is above the upper bound %g", (double)lower, (double)upper);
   return search_filtered_impl(ctx, idx, q, nq, k, nprobes, refine_factor, allow_by_rowid, n_allow, 1, lower, upper, ids, dists);
 }
 
 int lance_hip_search_stats(lance_hip_ctx *ctx, uint32_t *n_exact_replays_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && n_exact_replays_host, "search_stats: NULL argument");
   *n_exact_replays_host = 0;
   if (!ctx->last_replay_counter) return LANCE_HIP_OK;
@@ -1297,6 +1313,7 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
                            const void *codebook, uint32_t m, uint32_t nbits, const uint8_t *codes_transposed,
                            const uint64_t *row_ids, uint64_t n_p, uint32_t k, int has_range, float lower, float upper,
                            uint64_t *out_ids, float *out_dists, uint32_t *out_n_host) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && q_residual && codebook && out_ids && out_dists, "pq_scan_topk: NULL argument");
   LH_TRY(check_dtype(dtype, "pq_scan_topk"));
   LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && m != 0 && d / m > 16), "pq_scan_topk: f16 dot with sub-vectors longer than 16 is not supported");

@@ -672,7 +672,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
                        2 * nlist, nlist, (int)nprobes, max_items2, desc);
   }
   // timers inside: "q_residual" (memsets + residual pre-pass) and "ivfpq_scan_c1" (the filter scan kernel alone)
-  LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow));
+  LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow, probes));
   static const bool q_stats = getenv("LANCE_HIP_Q_STATS") != nullptr;
   if (q_stats) {   // diagnosis: how many rows survive the integer filter
     std::vector<uint32_t> sc(npairs), tb(nq);

@@ -827,15 +827,17 @@ static bool launch_qscan_sd(lance_hip_ctx *ctx, const QscanArgs &a, int m, unsig
 
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
                  const uint32_t *item_start4, const int4 *desc4, uint32_t max_items4, const uint32_t *tbound, uint32_t *seg_cnt,
-                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow) {
+                 uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow, const uint32_t *probes) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
+  const bool pt = probes != nullptr && qscan_pt_enabled(ix);   // per-query tables: no residual pre-pass, no table build in the scan
   const bool q8 = qscan8_enabled(m, sd);   // items hold 8 queries (qscan_group was called with G = 8): at most npairs / 8 + nlist + 2 of them
   const uint32_t max_items8 = (uint32_t)((uint64_t)nq * nprobes / 8 + ix->nlist + 2);
   f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", q8 ? (size_t)max_items8 * d * 8 : (size_t)max_items4 * d * 4));
   if (!rq) return LANCE_HIP_ENOMEM;
   {
     ScopedTimer t(ctx, "q_residual");
-    if (q8)
+    if (pt) {
+    } else if (q8)
       LH_TRY(qscan8_residual(ctx, qs, pair_idx, item_start4, desc4, ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0,
                              max_items8, rq));
     else
@@ -864,7 +866,8 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
     if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
   }
 #endif
-  if (qscan_tiled_shape(m, sd)) ok = qscan_tiled_launch(ctx, a, m, sd, grid);
+  if (pt) { LH_TRY(qscan_pt_launch(ctx, ix, a, qs, nq, probes, grid)); ok = true; }
+  else if (qscan_tiled_shape(m, sd)) ok = qscan_tiled_launch(ctx, a, m, sd, grid);
   else if (q8) ok = qscan8_launch(ctx, a, sd, max_items8);
   else if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);

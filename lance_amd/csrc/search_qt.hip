@@ -389,4 +389,346 @@ int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t 
   return LANCE_HIP_OK;
 }
 
+
+// ==== per-query tables + per-row bias (LANCE_HIP_QPT=1; round 3, written against scripts/sim/pqt_filter_spec.py, NOT YET RUN ON
+// HARDWARE when the round closed -- DESIGN.md section 8) =====================================================================
+// With q~ = q - g, cen~ = cen_p - g (g = the mean centroid: any fixed vector leaves r = q - cen_p unchanged, this one removes the
+// data's common offset) the residual table entry splits into
+//     ||r_m - c||^2 = ||q~_m - c||^2 + 2 cen~_pm . c + (||cen~_pm||^2 - 2 cen~_pm . q~_m)
+// i.e.  dist(q, row) = sum_m A_q[m][code_m] + beta_row + kappa_qp  with a table per QUERY, a constant per stored ROW and a scalar
+// per pair.  The filter  dist <= T  becomes  sum_m e_q[m][code_m] <= s_q (T - kappa_qp - beta_row) + slack:  the integer table is
+// built once per query (q_pt_table_kernel) and an item LOADS its four queries' tiles instead of computing them.
+//   e       = floor(min(A^ s_q, 65535)), A^ the f32 FMA chain, s_q = SE / Theta_q, Theta_q = max over the query's probes of
+//             (T - kappa - min beta of the partition): every row that can pass has all its entries below saturation;
+//   beta    = f32 of an f64 sum (q_pt_row_beta_kernel, once per index), kappa likewise (q_pt_scale_kernel, per pair);
+//   slack   = 2 + u s_q (10 (|T| + |kappa| + max|beta| + |q~|^2) + (SD + M + 6) Theta_q) units, u = 2^-24; a pair whose slack
+//             exceeds PT_CAP units is handed to the exact rescan kernel like an overflowed segment;
+//   stored sum S' = floor(sum e + s_q (beta + kappa)) ~ s_q dist: S' - 9 <= s_q dist <= S' + M + 10 -- inside the merge kernel's
+//             existing cut slack for these shapes (2 M + 8).
+constexpr float PT_CAP = 8.0f;
+
+struct PtArgs {
+  const uint16_t *tab;     // [nq][M][256] per-query integer tables
+  const float *sq;         // [nq] scale (0: the query has no table)
+  const float *kap;        // [nq * nprobes] kappa of the pair
+  const float *pslack;     // [nq * nprobes] slack of the pair in units
+  const float *row_beta;   // [n] per stored row
+};
+
+// g[dim] = mean over the centroids (f64 accumulation)
+__global__ __launch_bounds__(256) void q_pt_mean_kernel(const float *__restrict__ cent, int nlist, int d, float *__restrict__ g) {
+  const int dim = blockIdx.x * 256 + threadIdx.x;
+  if (dim >= d) return;
+  double acc = 0.0;
+  for (int p = 0; p < nlist; ++p) acc += (double)cent[(int64_t)p * d + dim];
+  g[dim] = (float)(acc / (double)nlist);
+}
+
+__global__ __launch_bounds__(256) void q_pt_translate_kernel(const float *__restrict__ cent, const float *__restrict__ g, int64_t total, int d,
+                                                              float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) out[i] = cent[i] - g[i % d];
+}
+
+// one workgroup per partition: beta of every stored row (f64 sum, one rounding), the partition's min beta and max |beta|
+__global__ __launch_bounds__(256) void q_pt_row_beta_kernel(const float *__restrict__ cen_t, const float *__restrict__ codebook,
+                                                             const uint8_t *__restrict__ codes, const uint32_t *__restrict__ part_offsets,
+                                                             int d, int m, float *__restrict__ row_beta, float *__restrict__ beta_min,
+                                                             float *__restrict__ beta_abs) {
+  __shared__ float s_min[4], s_abs[4];
+  const int p = blockIdx.x, sd = d / m;
+  const uint32_t off = part_offsets[p];
+  const int np = (int)(part_offsets[p + 1] - off);
+  const float *ct = cen_t + (int64_t)p * d;
+  float lmin = INFINITY, labs = 0.0f;
+  for (int row = threadIdx.x; row < np; row += 256) {
+    const uint8_t *rc = codes + ((int64_t)off + row) * m;
+    double acc = 0.0;
+    for (int mm = 0; mm < m; ++mm) {
+      const float *cw = codebook + ((int64_t)mm * 256 + rc[mm]) * sd;
+      for (int u = 0; u < sd; ++u) acc += 2.0 * (double)ct[mm * sd + u] * (double)cw[u];
+    }
+    const float b = (float)acc;
+    row_beta[(int64_t)off + row] = b;
+    lmin = fminf(lmin, b); labs = fmaxf(labs, fabsf(b));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lmin = fminf(lmin, __shfl_xor(lmin, o, 64)); labs = fmaxf(labs, __shfl_xor(labs, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lmin; s_abs[threadIdx.x >> 6] = labs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mn = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    beta_min[p] = np > 0 ? mn : 0.0f;
+    beta_abs[p] = fmaxf(fmaxf(s_abs[0], s_abs[1]), fmaxf(s_abs[2], s_abs[3]));
+  }
+}
+
+// one wave per (query, probe) pair: kappa = |cen~_p|^2 - 2 cen~_p . q~ (f64 sum, one rounding); the pair of rank 0 also leaves |q~|^2
+__global__ __launch_bounds__(256) void q_pt_kappa_kernel(const float *__restrict__ qs, const float *__restrict__ g, const float *__restrict__ cen_t,
+                                                          const uint32_t *__restrict__ probes, int64_t npairs, int nprobes, int d,
+                                                          float *__restrict__ kap, double *__restrict__ qn2_out) {
+  const int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pr >= npairs) return;
+  const int64_t q = pr / nprobes;
+  const float *ct = cen_t + (int64_t)probes[pr] * d, *qv = qs + q * d;
+  double acc = 0.0, qn2 = 0.0;
+  for (int dim = lane; dim < d; dim += 64) {
+    const float v = qv[dim] - g[dim];          // q~ (the same f32 subtraction as the table kernel's)
+    const double c = (double)ct[dim];
+    acc += c * c - 2.0 * c * (double)v;
+    qn2 += (double)v * (double)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); qn2 += __shfl_xor(qn2, o, 64); }
+  if (lane == 0) {
+    kap[pr] = (float)acc;
+    if (pr % nprobes == 0) qn2_out[q] = qn2;
+  }
+}
+
+// one lane per query: the scale from Theta = max over the probes of (T - kappa - min beta of the partition), the slack of every pair
+__global__ __launch_bounds__(256) void q_pt_scale_kernel(const float *__restrict__ beta_min, const float *__restrict__ beta_abs,
+                                                          const uint32_t *__restrict__ probes, const uint32_t *__restrict__ tbound, int nq,
+                                                          int nprobes, int sd_plus_m, const float *__restrict__ kap, const double *__restrict__ qn2_in,
+                                                          float *__restrict__ sq, float *__restrict__ pslack) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const uint32_t tb = tbound[q];
+  if (tb == 0xFFFFFFFFu) {   // class B: no bound, no table (its segments go to the rescan kernel anyway)
+    sq[q] = 0.0f;
+    return;
+  }
+  const double T = (double)key_to_float(tb), qn2 = qn2_in[q];
+  double theta = 0.0;
+  for (int rank = 0; rank < nprobes; ++rank) {
+    const uint32_t p = probes[(int64_t)q * nprobes + rank];
+    theta = fmax(theta, T - (double)kap[(int64_t)q * nprobes + rank] - (double)beta_min[p]);
+  }
+  // theta <= 0 or not finite: no usable scale -- every pair of the query is sent to the rescan kernel (slack = inf)
+  const bool ok = theta > 0.0 && theta < 1e300;
+  const float s = ok ? (float)((double)QT_SE / theta) : 0.0f;
+  sq[q] = s;
+  const double u = 5.9604644775390625e-8;   // 2^-24
+  for (int rank = 0; rank < nprobes; ++rank) {
+    const uint32_t p = probes[(int64_t)q * nprobes + rank];
+    const double kf = (double)kap[(int64_t)q * nprobes + rank];
+    const double sl = 2.0 + u * (double)s * (10.0 * (fabs(T) + fabs(kf) + (double)beta_abs[p] + qn2) + (double)(sd_plus_m + 6) * theta);
+    pslack[(int64_t)q * nprobes + rank] = ok ? (float)sl : INFINITY;
+  }
+}
+
+// grid (M, nq), lane = codeword: the query's integer table
+template <int SD>
+__global__ __launch_bounds__(256) void q_pt_table_kernel(const float *__restrict__ qs, const float *__restrict__ g, const float *__restrict__ sq,
+                                                          const float *__restrict__ codebook, int d, int m, uint16_t *__restrict__ tab) {
+  const int mm = blockIdx.x, q = blockIdx.y, c = threadIdx.x;
+  const float s = sq[q];
+  if (!(s > 0.0f)) return;   // uniform
+  const float *qv = qs + (int64_t)q * d + mm * SD, *gv = g + mm * SD;
+  const float *cw = codebook + ((int64_t)mm * 256 + c) * SD;
+  float acc = 0.0f;
+#pragma unroll
+  for (int u = 0; u < SD; ++u) {
+    const float diff = (qv[u] - gv[u]) - cw[u];      // q~ = q - g rounded once, as in q_pt_kappa_kernel
+    acc = fmaf(diff, diff, acc);
+  }
+  float z = fminf(acc * s, 65535.0f);
+  z = z >= 0.0f ? z : 0.0f;                       // NaN -> 0: the row survives and the exact pass decides
+  tab[((int64_t)q * m + mm) * 256 + c] = (uint16_t)(uint32_t)z;   // truncation = floor
+}
+
+template <int MU, int NT>
+__global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_pt_kernel(QscanArgs p, PtArgs t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16, MT = M / NT;
+  static_assert(M % NT == 0 && MT % 16 == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) uint2 lutq[MT * 256];
+  uint32_t *cand = reinterpret_cast<uint32_t *>(smem);                // [4][Q_CAP]
+  uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts, [4..7] 1: the pair goes to the rescan kernel
+  float *sc = reinterpret_cast<float *>(misc + 8);                    // [4] s_q
+  float *thr = sc + 4;                                                // [4] s_q (T - kappa) + slack  (-1e30: nothing passes)
+  float *skap = thr + 4;                                              // [4] s_q kappa
+  uint16_t *csum = reinterpret_cast<uint16_t *>(skap + 4);            // [4][Q_CAP] the survivors' sums ~ s_q dist
+  const uint32_t item = blockIdx.x;
+  if (item >= p.item_start[p.nlist]) return;
+  const int4 dsc = p.desc[item];
+  const int part_id = dsc.x, i0 = dsc.y, cnt = dsc.z;
+  const uint32_t off = p.part_offsets[part_id];
+  const int np = (int)(p.part_offsets[part_id + 1] - off);
+  if (np == 0) return;   // uniform; seg_cnt stays 0
+  uint32_t qj[Q_G], pr[Q_G];
+#pragma unroll
+  for (int j = 0; j < Q_G; ++j) {
+    pr[j] = p.pair_idx[i0 + (j < cnt ? j : 0)];
+    qj[j] = pr[j] / (uint32_t)p.nprobes;
+  }
+  if (threadIdx.x < Q_G) {
+    const int j = threadIdx.x;
+    misc[j] = 0; misc[4 + j] = 0;
+    float s = 0.0f, th = -1e30f, sk = 0.0f;
+    if (j < cnt) {
+      const float sj = t.sq[qj[j]], sl = t.pslack[pr[j]];
+      if (sj > 0.0f && sl <= PT_CAP) {
+        const float T = key_to_float(p.tbound[qj[j]]), kp = t.kap[pr[j]];
+        s = sj; th = sj * (T - kp) + sl; sk = sj * kp;
+      } else {
+        misc[4 + j] = 1u;
+      }
+    }
+    sc[j] = s; thr[j] = th; skap[j] = sk;
+  }
+  __syncthreads();
+  const f4 s4 = *reinterpret_cast<const f4 *>(sc), th4 = *reinterpret_cast<const f4 *>(thr), sk4 = *reinterpret_cast<const f4 *>(skap);
+  const uint16_t *tq0 = t.tab + (int64_t)qj[0] * M * 256, *tq1 = t.tab + (int64_t)qj[1] * M * 256;
+  const uint16_t *tq2 = t.tab + (int64_t)qj[2] * M * 256, *tq3 = t.tab + (int64_t)qj[3] * M * 256;
+  const uint8_t *pcodes = p.codes + (int64_t)off * M;
+  for (int row0 = 0; row0 < np; row0 += QT_BS * QT_R) {
+    uint32_t acc[QT_R][4];
+#pragma unroll
+    for (int r = 0; r < QT_R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[r][j] = 0u;
+#pragma unroll 1
+    for (int tile = 0; tile < NT; ++tile) {
+      if (tile > 0 || row0 > 0) __syncthreads();   // every lane is done with the previous tile's table
+      // four consecutive codewords of one sub-quantiser per step: one 8-byte load from each query's table (a wave reads 512
+      // contiguous bytes per query), a 4 x 4 transpose of the u16 entries in registers (v_perm_b32), two 16-byte LDS stores.
+      // (The first version moved one u16 per load: 192 load instructions per lane and row block, and ran no faster than the
+      // table build it replaced -- gpurun r04a.)
+      constexpr int GROUPS = MT * 64;
+#pragma unroll 2
+      for (int gi = (int)threadIdx.x; gi < GROUPS; gi += QT_BS) {
+        const int ml = gi >> 6, c4 = (gi & 63) * 4, idx = (tile * MT + ml) * 256 + c4;
+        const uint2 a0 = *reinterpret_cast<const uint2 *>(tq0 + idx), a1 = *reinterpret_cast<const uint2 *>(tq1 + idx);
+        const uint2 a2 = *reinterpret_cast<const uint2 *>(tq2 + idx), a3 = *reinterpret_cast<const uint2 *>(tq3 + idx);
+        constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;   // low / high halves of (second operand, first operand)
+        uint4 o01, o23;
+        o01.x = __builtin_amdgcn_perm(a1.x, a0.x, LO); o01.y = __builtin_amdgcn_perm(a3.x, a2.x, LO);
+        o01.z = __builtin_amdgcn_perm(a1.x, a0.x, HI); o01.w = __builtin_amdgcn_perm(a3.x, a2.x, HI);
+        o23.x = __builtin_amdgcn_perm(a1.y, a0.y, LO); o23.y = __builtin_amdgcn_perm(a3.y, a2.y, LO);
+        o23.z = __builtin_amdgcn_perm(a1.y, a0.y, HI); o23.w = __builtin_amdgcn_perm(a3.y, a2.y, HI);
+        *reinterpret_cast<uint4 *>(&lutq[ml * 256 + c4]) = o01;
+        *reinterpret_cast<uint4 *>(&lutq[ml * 256 + c4 + 2]) = o23;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < QT_R; ++r) {
+        const int row = row0 + r * QT_BS + (int)threadIdx.x;
+        if (row < np) qt_row_tile<MT>(lutq, pcodes + (int64_t)row * M + tile * MT, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < QT_R; ++r) {
+      const int row = row0 + r * QT_BS + (int)threadIdx.x;
+      if (row < np) {
+        const float beta = t.row_beta[(int64_t)off + row];
+        const float a0 = (float)acc[r][0], a1 = (float)acc[r][1], a2 = (float)acc[r][2], a3 = (float)acc[r][3];   // exact: sums < 2^24
+        const bool p0 = a0 <= fmaf(-s4.x, beta, th4.x), p1 = a1 <= fmaf(-s4.y, beta, th4.y);
+        const bool p2 = a2 <= fmaf(-s4.z, beta, th4.z), p3 = a3 <= fmaf(-s4.w, beta, th4.w);
+        if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
+          const uint32_t pos = off + (uint32_t)row;
+          // stored sum ~ s_q dist (what the merge kernel's cut reads): floor(sum e + s_q (beta + kappa)), clamped to the u16 range
+          if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) { cand[0 * Q_CAP + slot] = pos; csum[0 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a0 + fmaf(s4.x, beta, sk4.x), 0.0f), 65535.0f); } }
+          if (p1) { const uint32_t slot = atomicAdd(&misc[1], 1u); if (slot < (uint32_t)Q_CAP) { cand[1 * Q_CAP + slot] = pos; csum[1 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a1 + fmaf(s4.y, beta, sk4.y), 0.0f), 65535.0f); } }
+          if (p2) { const uint32_t slot = atomicAdd(&misc[2], 1u); if (slot < (uint32_t)Q_CAP) { cand[2 * Q_CAP + slot] = pos; csum[2 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a2 + fmaf(s4.z, beta, sk4.z), 0.0f), 65535.0f); } }
+          if (p3) { const uint32_t slot = atomicAdd(&misc[3], 1u); if (slot < (uint32_t)Q_CAP) { cand[3 * Q_CAP + slot] = pos; csum[3 * Q_CAP + slot] = (uint16_t)(uint32_t)fminf(fmaxf(a3 + fmaf(s4.w, beta, sk4.w), 0.0f), 65535.0f); } }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < Q_G; ++j) {
+    if (j < cnt) {
+      const uint32_t raw = misc[4 + j] ? 0xFFFFFFFFu : misc[j];   // no table / slack over the cap: the rescan kernel does this pair exactly
+      const uint32_t n = raw > (uint32_t)Q_CAP ? 0u : raw;
+      const int64_t seg = (int64_t)pr[j];
+      if (threadIdx.x == 0) {
+        p.seg_cnt[seg] = raw;
+        if (raw > (uint32_t)Q_CAP) { p.qovf[qj[j]] = 1u; p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = (uint32_t)seg; }
+      }
+      for (uint32_t i = threadIdx.x; i < n; i += QT_BS) {
+        p.seg_pos[seg * Q_CAP + i] = cand[j * Q_CAP + i];
+        p.seg_sum[seg * Q_CAP + i] = csum[j * Q_CAP + i];
+      }
+    }
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------
+bool qscan_pt_enabled(const lance_hip_index *ix) {
+  static const bool on = getenv("LANCE_HIP_QPT") != nullptr;
+  if (!on || !ix || ix->m == 0 || ix->nbits != 8) return false;
+  const int m = (int)ix->m, sd = (int)(ix->d / ix->m);
+  if (!qscan_tiled_shape(m, sd)) return false;
+  if (ix->dtype == LANCE_HIP_F16) return false;      // the reference rounds the residual to f16 there: r is not q - cen any more
+  return ix->metric == LANCE_HIP_L2 || ix->metric == LANCE_HIP_COSINE;
+}
+
+static int qscan_pt_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
+  std::lock_guard<std::mutex> lk(ix->lazy_mu);   // the first search of any context builds the constants, the others wait for it
+  if (ix->pt) return LANCE_HIP_OK;
+  const int d = (int)ix->d, m = (int)ix->m, nlist = (int)ix->nlist;
+  auto *pc = new lance_hip_index::PtConst();
+  bool ok = hipMalloc(reinterpret_cast<void **>(&pc->g), (size_t)d * 4) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->cen_t), (size_t)nlist * d * 4) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->row_beta), (size_t)(ix->n ? ix->n : 1) * 4) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_min), (size_t)nlist * 4) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_abs), (size_t)nlist * 4) == hipSuccess;
+  auto drop = [&]() {
+    (void)hipFree(pc->g); (void)hipFree(pc->cen_t); (void)hipFree(pc->row_beta); (void)hipFree(pc->beta_min); (void)hipFree(pc->beta_abs);
+    delete pc;
+  };
+  if (!ok) { drop(); set_error("per-query tables: out of device memory for the index constants"); return LANCE_HIP_ENOMEM; }
+  hipLaunchKernelGGL(q_pt_mean_kernel, dim3((unsigned)cdiv((uint64_t)d, 256)), dim3(256), 0, ctx->stream, ix->centroids, nlist, d, pc->g);
+  hipLaunchKernelGGL(q_pt_translate_kernel, dim3((unsigned)cdiv((uint64_t)nlist * d, 256)), dim3(256), 0, ctx->stream, ix->centroids, pc->g,
+                     (int64_t)nlist * d, d, pc->cen_t);
+  hipLaunchKernelGGL(q_pt_row_beta_kernel, dim3((unsigned)nlist), dim3(256), 0, ctx->stream, pc->cen_t, ix->codebook, ix->codes, ix->part_offsets, d, m,
+                     pc->row_beta, pc->beta_min, pc->beta_abs);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {   // other contexts (streams) search the same index
+    drop();
+    set_error("per-query tables: building the index constants failed");
+    return LANCE_HIP_ERUNTIME;
+  }
+  ix->pt = pc;   // published complete; lance_hip_index's destructor frees it
+  return LANCE_HIP_OK;
+}
+
+template <int MU, int NT>
+static void launch_qscan_tiled_pt(lance_hip_ctx *ctx, const QscanArgs &a, const PtArgs &t, unsigned grid) {
+  const size_t lds = (size_t)4 * Q_CAP * 4 + 8 * 4 + 12 * 4 + (size_t)4 * Q_CAP * 2;
+  hipLaunchKernelGGL((ivfpq_qscan_tiled_pt_kernel<MU, NT>), dim3(grid), dim3(QT_BS), lds, ctx->stream, a, t);
+}
+
+int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const QscanArgs &a, const float *qs, uint32_t nq, const uint32_t *probes,
+                    unsigned grid) {
+  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);   // the constants are a cache attached to the index
+  LH_TRY(qscan_pt_prepare(ctx, ix));
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nprobes = a.nprobes;
+  double *qn2 = ctx->scratch_t<double>("pt.qn2", nq);
+  float *sq = ctx->scratch_t<float>("pt.sq", nq);
+  float *kap = ctx->scratch_t<float>("pt.kap", (size_t)nq * nprobes);
+  float *pslack = ctx->scratch_t<float>("pt.pslack", (size_t)nq * nprobes);
+  uint16_t *tab = ctx->scratch_t<uint16_t>("pt.tab", (size_t)nq * m * 256);
+  if (!qn2 || !sq || !kap || !pslack || !tab) return LANCE_HIP_ENOMEM;
+  const int64_t npairs = (int64_t)nq * nprobes;
+  hipLaunchKernelGGL(q_pt_kappa_kernel, dim3((unsigned)cdiv((uint64_t)npairs, 4)), dim3(256), 0, ctx->stream, qs, ix->pt->g, ix->pt->cen_t, probes,
+                     npairs, nprobes, d, kap, qn2);
+  hipLaunchKernelGGL(q_pt_scale_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, ix->pt->beta_min, ix->pt->beta_abs, probes, a.tbound,
+                     (int)nq, nprobes, sd + m, kap, qn2, sq, pslack);
+  const dim3 tgrid((unsigned)m, nq);
+  if (sd == 4) hipLaunchKernelGGL((q_pt_table_kernel<4>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, tab);
+  else if (sd == 8) hipLaunchKernelGGL((q_pt_table_kernel<8>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, tab);
+  else hipLaunchKernelGGL((q_pt_table_kernel<16>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, tab);
+  PtArgs t;
+  t.tab = tab; t.sq = sq; t.kap = kap; t.pslack = pslack; t.row_beta = ix->pt->row_beta;
+  if (m == 48) launch_qscan_tiled_pt<3, 1>(ctx, a, t, grid);
+  else if (m == 64) launch_qscan_tiled_pt<4, LH_QT_NT64>(ctx, a, t, grid);
+  else if (m == 96) launch_qscan_tiled_pt<6, LH_QT_NT96>(ctx, a, t, grid);
+  else { set_error("per-query tables: unsupported shape (m=%d)", m); return LANCE_HIP_EINVAL; }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 }  // namespace lh

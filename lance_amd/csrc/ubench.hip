@@ -173,6 +173,7 @@ extern "C" {
 //       v_pk_add_f32, 64 lanes each); 6 / 7 = code-major m-staggered u16x4 table, M = 16 / 32 (lane-gathers per second, all
 //       address work included); 8 = today's [m][code] u16x4 table with the same integer accumulate; 9 = conflict-free ds_read_b64
 int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && result, "ubench: NULL argument");
   LH_REQUIRE(what >= 0 && what <= 9, "ubench: unknown measurement %d", what);
   LH_CHECK_HIP(hipSetDevice(ctx->device));

@@ -373,3 +373,23 @@ def test_committed_bench_line_keeps_the_driver_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c.get("ids_equal_gpu") is True
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no external launcher) re-executes itself under torch.distributed.run with two ranks; on a box
+    without two GPUs the RANK code refuses -- not the launcher, and not a silent single-GPU run.  Under an external launcher a
+    --gpus that disagrees with WORLD_SIZE is an error."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""        # also on a GPU box: no device for the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "needs 2 MI355X GPUs (rank 0 sees" in out and "needs 2 MI355X GPUs (rank 1 sees" in out, out[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
