@@ -16,9 +16,15 @@
  *   - Return 0 on success, a negative LANCE_HIP_E* code on failure; the message is
  *     available from lance_hip_last_error() (thread-local).  Never throws or aborts.
  *   - Work is issued on the context's stream; calls return after the stream has been
- *     synchronised unless stated otherwise.  A context may be used by one thread at a
- *     time; create one per thread for concurrent callers (the reference calls these
- *     paths from rayon / tokio worker threads).
+ *     synchronised unless stated otherwise.
+ *   - Threads (the reference calls these paths from rayon / tokio worker threads,
+ *     rust/lance/src/index/vector/ivf/v2.rs:232-306): every entry point is re-entrant.  A
+ *     context is a stream + scratch arena; its entry points hold a per-context lock, so
+ *     threads sharing one context take turns, and threads with a context each overlap on
+ *     the device.  An index is read-only during searches and may be searched through any
+ *     number of contexts at once (tests/test_zz_gpu_threads.py); building / destroying it
+ *     while it is being searched is the caller's error.  lance_hip_last_error() is
+ *     thread-local.
  *   - "No partition" (all-NaN row; kmeans.rs:1447-1486) is id 0xFFFFFFFF.
  *   - Results are bit-identical to the reference CPU path for ids / codes / distances
  *     (see DESIGN.md for the exact statement and the two documented tie rules).

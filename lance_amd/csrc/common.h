@@ -40,6 +40,14 @@ void set_error(const char *fmt, ...);
     if (_r != LANCE_HIP_OK) return _r; \
   } while (0)
 
+// a captured search (search.hip: ivfpq_search_enqueue): the ~25 launches of one batch replayed as one hipGraphLaunch
+struct GraphEntry {
+  hipGraphExec_t exec = nullptr;
+  uint32_t seen = 0;                 // calls with this key so far (the first one runs uncaptured: it sizes the scratch arena)
+  uint32_t *flags = nullptr;         // what the captured call handed back through flags_out
+  const uint32_t *replay = nullptr;  // ... and left in last_replay_counter
+};
+
 struct KernelTimer {
   double ms = 0.0;
   uint64_t launches = 0;
@@ -65,6 +73,11 @@ struct lance_hip_ctx {
   // each (the reference calls this path from many rayon / tokio threads at once, v2.rs:232-306).  Recursive: entry points
   // call each other.
   std::recursive_mutex mu;
+  // captured searches, keyed by the packed arguments of the call.  Every node holds scratch-arena pointers, so the cache is
+  // dropped whenever a slot is reallocated; growth DURING a capture is refused (the uncaptured first call has sized the arena).
+  std::map<std::string, lh::GraphEntry> graphs;
+  bool capturing = false;
+  void drop_graphs();
 
   // returns nullptr on failure (error set)
   void *scratch(const char *name, size_t bytes);

@@ -15,7 +15,12 @@ void *lance_hip_ctx::scratch(const char *name, size_t bytes) {
   if (bytes == 0) bytes = 16;
   auto it = slots.find(name);
   if (it != slots.end() && it->second.second >= bytes) return it->second.first;
+  if (capturing) {
+    lh::set_error("scratch '%s' would have to grow to %zu bytes while a search graph is being captured", name, bytes);
+    return nullptr;
+  }
   if (it != slots.end()) {
+    drop_graphs();   // captured searches hold the old block's address
     // make sure nothing in flight still uses the old block
     (void)hipStreamSynchronize(stream);
     (void)hipFree(it->second.first);
@@ -31,6 +36,14 @@ void *lance_hip_ctx::scratch(const char *name, size_t bytes) {
   }
   slots[name] = {p, cap};
   return p;
+}
+
+void lance_hip_ctx::drop_graphs() {
+  if (graphs.empty()) return;
+  (void)hipStreamSynchronize(stream);
+  for (auto &kv : graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  graphs.clear();
 }
 
 void *lance_hip_ctx::host_staging(size_t bytes) {
@@ -98,6 +111,7 @@ void lance_hip_ctx_destroy(lance_hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  ctx->drop_graphs();
   for (auto &kv : ctx->slots) (void)hipFree(kv.second.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto &kv : ctx->timers)

@@ -1,12 +1,19 @@
 // index.h -- device-resident IVF_PQ index (see build.hip for the layout rationale).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <vector>
 
 struct int2_host { int x, y; };
 
+inline uint64_t lance_hip_next_index_serial() {
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1, std::memory_order_relaxed);
+}
+
 struct lance_hip_index {
+  uint64_t serial = lance_hip_next_index_serial();   // distinguishes indices that reuse an address (captured search graphs are keyed on it)
   int device = 0;
   int metric = 0;
   int dtype = 0;                  // element type of queries / raw vectors (model is kept widened to f32)

@@ -24,6 +24,7 @@
 // k rows tied at the boundary distance -- is detected and flagged.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -955,9 +956,77 @@ static void launch_scan(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t 
 }
 
 // The whole query pipeline, enqueued on ctx->stream.  flags_out: device [nq] (zeroed here).
+static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
+                                     uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
+                                     uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow);
+
+// A batch is ~25 small launches (coarse quantiser, two groupings, bound pass, residuals, filter scan, rescan, merge, exact
+// replay, refine) and a handful of memsets: at C3 a third of a 1000-query batch's wall time was the gaps between them
+// (profiles/r03_c3_search_breakdown.json).  LANCE_HIP_GRAPH=1: the second call with the same arguments (index, buffers,
+// shape) is captured into a HIP graph, later ones replay it with one hipGraphLaunch.  The first call always runs uncaptured: it
+// sizes the scratch arena (growth would need hipMalloc + a stream sync, neither of which a capture allows) and builds the
+// index's lazy constants.  Timing runs (HIP events per kernel) and the diagnostic switches that synchronise mid-pipeline stay
+// on the plain path.
 int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
                          uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
                          uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow) {
+  static const bool on = [] {
+    const char *e = getenv("LANCE_HIP_GRAPH");
+    return e && e[0] == '1' && !getenv("LANCE_HIP_Q_STATS") && !getenv("LANCE_HIP_PM_PROF") && !getenv("LANCE_HIP_QT_PROF");
+  }();
+  if (!on || ctx->timing || nq == 0)
+    return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+  struct Key {
+    const void *ix; uint64_t serial; const void *raw; uint64_t n_raw; const void *q, *ids, *dists, *allow;
+    uint32_t nq, k, nprobes, rf; int has_range; float lo, hi;
+  } key;
+  memset(&key, 0, sizeof(key));
+  key.ix = ix; key.serial = ix->serial; key.raw = ix->raw; key.n_raw = ix->n_raw; key.q = q; key.ids = ids; key.dists = dists; key.allow = allow;
+  key.nq = nq; key.k = k; key.nprobes = nprobes; key.rf = refine_factor; key.has_range = has_range; key.lo = lower; key.hi = upper;
+  const std::string ks(reinterpret_cast<const char *>(&key), sizeof(key));
+  if (ctx->graphs.size() > 64 && !ctx->graphs.count(ks)) ctx->drop_graphs();      // bounded: callers that never repeat a call
+  {
+    GraphEntry &e = ctx->graphs[ks];
+    if (e.exec) {
+      LH_CHECK_HIP(hipGraphLaunch(e.exec, ctx->stream));
+      ctx->last_replay_counter = e.replay;
+      if (flags_out) *flags_out = e.flags;
+      return LANCE_HIP_OK;
+    }
+    if (e.seen != 1) {      // 0: first call, runs uncaptured; > 1: a capture failed before -- stay on the plain path
+      if (e.seen == 0) e.seen = 1;
+      return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+    }
+    e.seen = 2;
+  }
+  uint32_t *fl = nullptr;
+  hipGraph_t g = nullptr;
+  if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+  }
+  ctx->capturing = true;
+  const int rc = ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, &fl, allow);
+  ctx->capturing = false;
+  const hipError_t ee = hipStreamEndCapture(ctx->stream, &g);
+  hipGraphExec_t ex = nullptr;
+  if (rc == LANCE_HIP_OK && ee == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex) {
+    (void)hipGraphDestroy(g);
+    GraphEntry &e = ctx->graphs[ks];
+    e.exec = ex; e.flags = fl; e.replay = ctx->last_replay_counter; e.seen = 2;
+    LH_CHECK_HIP(hipGraphLaunch(ex, ctx->stream));
+    if (flags_out) *flags_out = fl;
+    return LANCE_HIP_OK;
+  }
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  // nothing was executed (the launches went into the discarded graph): run the batch on the plain path
+  return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+}
+
+static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
+                                     uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
+                                     uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow) {
   LH_REQUIRE(k > 0, "search: k must be > 0");
   if (nprobes > ix->nlist) nprobes = ix->nlist;
   LH_REQUIRE(ix->nlist <= 8192 || nprobes <= 256, "search: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);

@@ -98,6 +98,7 @@ def lib():
         _lib.orc_round_f16.restype = C.c_float
         _lib.orc_round_f16.argtypes = [C.c_float]
         _lib.orc_kmeans_train_hierarchical_f32.restype = C.c_size_t
+        _lib.orc_kmeans_train_hierarchical_x.restype = C.c_size_t
         _lib.orc_set_threads(min(int(_lib.orc_num_threads()), usable_cpus()))
     return _lib
 
@@ -248,14 +249,16 @@ def kmeans_train(x, k, max_iters=50, tol=1e-4, balance_factor=0.0, init=None, se
 
 
 def kmeans_train_hierarchical(x, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, hierarchical_k=16, seed=0, metric="l2"):
-    """train_hierarchical_kmeans (kmeans.rs:746-1003) -> centroids [n_clusters, d]"""
+    """train_hierarchical_kmeans (kmeans.rs:746-1003) -> centroids [n_clusters, d].  float16 input -> the Float16Type
+    instantiation (f16 M-step in every inner k-means), centroids returned as float16."""
+    f16 = np.asarray(x).dtype == np.float16
     x = _f32(x)
     n, d = x.shape
     cent = np.zeros((k, d), np.float32)
-    got = lib().orc_kmeans_train_hierarchical_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(k), C.c_uint32(max_iters),
-                                                  C.c_double(tol), C.c_float(balance_factor_scaled), C.c_size_t(hierarchical_k),
-                                                  C.c_uint64(seed), _p(cent))
-    return cent[:got]
+    got = lib().orc_kmeans_train_hierarchical_x(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), C.c_size_t(k), C.c_uint32(max_iters),
+                                                C.c_double(tol), C.c_float(balance_factor_scaled), C.c_size_t(hierarchical_k),
+                                                C.c_uint64(seed), _p(cent), C.c_int(int(f16)))
+    return cent[:got].astype(np.float16) if f16 else cent[:got]
 
 
 def residual(x, centroids, part_ids):

@@ -787,23 +787,39 @@ static orc_cluster orc_cheap_pop(orc_cheap *h) {
 }
 
 static int orc_kmeans_capped(int metric, const float *x, size_t n, size_t d, size_t k, uint32_t max_iters, double tol,
-                             float bf, uint64_t seed, float *cent) {
+                             float bf, uint64_t seed, float *cent, int f16) {
   size_t rows = n >= k * 512 ? k * 512 : n;
   double loss;
-  return orc_kmeans_train_f32(metric, x, rows, d, k, max_iters, tol, bf, NULL, seed, cent, &loss, NULL);
+  return orc_kmeans_train_x(metric, x, rows, d, k, max_iters, tol, bf, NULL, seed, cent, &loss, NULL, f16);
+}
+static int orc_cluster_by_id(const void *a, const void *b) {
+  size_t ia = ((const orc_cluster *)a)->id, ib = ((const orc_cluster *)b)->id;
+  return ia < ib ? -1 : (ia > ib ? 1 : 0);
 }
 
 /* returns the number of clusters produced (== target_k unless splitting stalls) */
+/* f16 != 0: train_hierarchical_kmeans::<Float16Type, KMeansAlgoFloat<Float16Type>> (kmeans.rs:1030-1033): every inner k-means
+ * runs the f16 M-step, the membership pass is compute_partitions on the f16 values (widened per element; dot: 32 lanes)       */
+size_t orc_kmeans_train_hierarchical_x(int metric, const float *x, size_t n, size_t d, size_t target_k,
+                                       uint32_t max_iters, double tol, float balance_factor_scaled,
+                                       size_t hierarchical_k, uint64_t seed, float *centroids_out, int f16);
 size_t orc_kmeans_train_hierarchical_f32(int metric, const float *x, size_t n, size_t d, size_t target_k,
                                          uint32_t max_iters, double tol, float balance_factor_scaled,
                                          size_t hierarchical_k, uint64_t seed, float *centroids_out) {
+  return orc_kmeans_train_hierarchical_x(metric, x, n, d, target_k, max_iters, tol, balance_factor_scaled, hierarchical_k, seed,
+                                         centroids_out, 0);
+}
+size_t orc_kmeans_train_hierarchical_x(int metric, const float *x, size_t n, size_t d, size_t target_k,
+                                       uint32_t max_iters, double tol, float balance_factor_scaled,
+                                       size_t hierarchical_k, uint64_t seed, float *centroids_out, int f16) {
+  const int amet = orc_metric_h(metric, f16);
   uint64_t run = 0;
   size_t initial_k = hierarchical_k < target_k ? hierarchical_k : target_k;
   if (initial_k > n) initial_k = n;
   float *c0 = (float *)malloc(initial_k * d * sizeof(float));
-  orc_kmeans_capped(metric, x, n, d, initial_k, max_iters, tol, balance_factor_scaled, seed + run++, c0);
+  orc_kmeans_capped(metric, x, n, d, initial_k, max_iters, tol, balance_factor_scaled, seed + run++, c0, f16);
   uint32_t *mem = (uint32_t *)malloc(n * sizeof(uint32_t));
-  orc_assign_f32(metric, x, n, d, c0, initial_k, NULL, mem, NULL);
+  orc_assign_f32(amet, x, n, d, c0, initial_k, NULL, mem, NULL);
   orc_cheap heap; heap.d = (orc_cluster *)malloc((target_k + hierarchical_k + 2) * sizeof(orc_cluster)); heap.len = 0;
   size_t next_id = 0;
   for (size_t i = 0; i < initial_k; i++) {
@@ -836,9 +852,9 @@ size_t orc_kmeans_train_hierarchical_f32(int metric, const float *x, size_t n, s
     float *sub = (float *)malloc(big.n * d * sizeof(float));
     for (size_t r = 0; r < big.n; r++) memcpy(sub + r * d, x + (size_t)big.idx[r] * d, d * sizeof(float));
     float *sc = (float *)malloc(cluster_k * d * sizeof(float));
-    orc_kmeans_capped(metric, sub, big.n, d, cluster_k, max_iters, tol, balance_factor_scaled, seed + run++, sc);
+    orc_kmeans_capped(metric, sub, big.n, d, cluster_k, max_iters, tol, balance_factor_scaled, seed + run++, sc, f16);
     uint32_t *sm = (uint32_t *)malloc(big.n * sizeof(uint32_t));
-    orc_assign_f32(metric, sub, big.n, d, sc, cluster_k, NULL, sm, NULL);
+    orc_assign_f32(amet, sub, big.n, d, sc, cluster_k, NULL, sm, NULL);
     int all_same = 1, have_first = 0; uint32_t first = 0;
     for (size_t r = 0; r < big.n; r++) {
       if (sm[r] == ORC_NONE) continue;
@@ -866,9 +882,7 @@ size_t orc_kmeans_train_hierarchical_f32(int metric, const float *x, size_t n, s
   }
   /* sort by id, emit */
   size_t outn = heap.len;
-  for (size_t i = 0; i < outn; i++)
-    for (size_t j = i + 1; j < outn; j++)
-      if (heap.d[j].id < heap.d[i].id) { orc_cluster t = heap.d[i]; heap.d[i] = heap.d[j]; heap.d[j] = t; }
+  qsort(heap.d, outn, sizeof(orc_cluster), orc_cluster_by_id);     /* ids are distinct: any sort gives the same order */
   for (size_t i = 0; i < outn; i++) {
     memcpy(centroids_out + i * d, heap.d[i].centroid, d * sizeof(float));
     free(heap.d[i].idx); free(heap.d[i].centroid);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle  # noqa: E402
-from fullconfig_spec import C3, C5, c3_data, c5_data, digest, f32  # noqa: E402
+from fullconfig_spec import C3, C4, C5, C5T, c3_data, c4_data, c5_data, digest, f32  # noqa: E402
 
 OUT = os.path.join(HERE, "fullconfig.npz")
 
@@ -77,6 +77,49 @@ def make_c5(out):
     tick(t, "c5 searches")
 
 
+def make_c4(out):
+    c = C4
+    x, q = c4_data()                      # float16
+    t = time.time()
+    oc = oracle.kmeans_train_hierarchical(x, c["nlist"], max_iters=c["ivf_iters"], balance_factor_scaled=f32(1.0) / f32(c["n"]), seed=c["seed"])
+    t = tick(t, "c4 hierarchical IVF training (f16 M-step)")
+    assert oc.shape[0] == c["nlist"] and oc.dtype == np.float16
+    part, _ = oracle.assign(x, oc)
+    res = oracle.residual(x, oc, part)
+    ocb, its = oracle.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=c["seed"] + 1)
+    t = tick(t, "c4 assign + residual + PQ training")
+    oidx = oracle.build_index(x, oc, ocb, "l2")
+    t = tick(t, "c4 build_index")
+    out["c4_centroids"] = digest(oc); out["c4_codebook"] = digest(ocb); out["c4_pq_iters"] = its.astype(np.uint32)
+    out["c4_part_ids"] = digest(oidx.part_ids); out["c4_codes"] = digest(oidx.codes_rowmajor)
+    out["c4_part_offsets"] = oidx.part_offsets.astype(np.uint32)
+    for (k, nprobes, rf) in c["searches"]:
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        out[f"c4_ids_{k}_{nprobes}_{rf}"] = oi; out[f"c4_dists_{k}_{nprobes}_{rf}"] = od
+    tick(t, "c4 searches")
+
+
+def make_c5t(out):
+    c, ct = C5, C5T
+    xi, qi = c5_data()
+    x, q = xi.astype(f32), qi.astype(f32)
+    t = time.time()
+    oc = oracle.kmeans_train_hierarchical(x, ct["nlist"], max_iters=ct["ivf_iters"], balance_factor_scaled=f32(1.0) / f32(c["n"]), seed=ct["seed"])
+    t = tick(t, f"c5t hierarchical IVF training to {oc.shape[0]} centroids")
+    out["c5t_ncent"] = np.array([oc.shape[0]], np.uint32)
+    out["c5t_centroids"] = digest(oc)
+    part, _ = oracle.assign(x, oc)
+    res = oracle.residual(x, oc, np.where(part == oracle.NONE, 0, part))
+    ocb, pits = oracle.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=ct["seed"] + 1)
+    oidx = oracle.build_index(x, oc, ocb, "l2")
+    t = tick(t, "c5t assign + PQ + build_index")
+    out["c5t_codebook"] = digest(ocb); out["c5t_part_ids"] = digest(oidx.part_ids); out["c5t_codes"] = digest(oidx.codes_rowmajor)
+    for (k, nprobes, rf) in ct["searches"]:
+        oi, od = oidx.search(q, k, nprobes, refine=rf, raw=x if rf else None)
+        out[f"c5t_ids_{k}_{nprobes}_{rf}"] = oi; out[f"c5t_dists_{k}_{nprobes}_{rf}"] = od
+    tick(t, "c5t searches")
+
+
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:]] or ["c3", "c5"]
     out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
@@ -84,5 +127,9 @@ if __name__ == "__main__":
         make_c3(out)
     if "c5" in which:
         make_c5(out)
+    if "c4" in which:
+        make_c4(out)
+    if "c5t" in which:
+        make_c5t(out)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

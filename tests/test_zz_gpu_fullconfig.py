@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from fullconfig_spec import C3, C5, c3_data, c5_data, digest, f32
+from fullconfig_spec import C3, C4, C5, C5T, c3_data, c4_data, c5_data, digest, f32
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullconfig.npz")
@@ -93,4 +93,70 @@ def test_c5_bigann_parameters_nlist_65536_int8(eng, gold):
         gi, gd = g.search(qt, k, nprobes, rf)
         assert (_np(gi).view(np.uint64) == gold[f"c5_ids_{k}_{nprobes}_{rf}"]).all(), (k, nprobes, rf)
         assert (_np(gd).view(np.uint32) == gold[f"c5_dists_{k}_{nprobes}_{rf}"].view(np.uint32)).all(), (k, nprobes, rf)
+    g.close()
+
+
+def test_c4_f16_rows_hierarchical_nlist_4096_one_million_rows(eng, gold):
+    """BASELINE config 4 at its real index parameters on 1/100 of its rows: Float16 column, the hierarchical trainer in its
+    Float16Type instantiation up to nlist 4096, M 16; searches at 1 / 10 / 50 probes and the exhaustive probe (nprobes = nlist)."""
+    import torch
+    from lance_amd.engine import DeviceIndex
+    if "c4_centroids" not in gold:
+        pytest.fail("tests/golden/fullconfig.npz carries no c4 record (python tests/golden/make_fullconfig_golden.py c4)")
+    c = C4
+    x, q = c4_data()
+    xt = torch.from_numpy(x)
+    cent, _, _ = eng.kmeans_train(xt, c["nlist"], max_iters=c["ivf_iters"], balance_factor=1.0, seed=c["seed"])
+    assert cent.shape[0] == c["nlist"]
+    cent_h = _np(cent).astype(np.float16)
+    assert same(cent_h, gold["c4_centroids"]), "f16 hierarchical IVF centroids differ from the oracle's"
+    part, _ = eng.assign(xt, cent_h, "l2")
+    res = eng.residual(xt, cent_h, part)
+    cb, its = eng.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=c["seed"] + 1)
+    assert (_np(its).astype(np.uint32) == gold["c4_pq_iters"]).all()
+    cb_h = _np(cb).astype(np.float16)
+    assert same(cb_h, gold["c4_codebook"]), "PQ codebook differs from the oracle's"
+    gpart, gcodes, _ = eng.ivfpq_encode(xt, cent_h, cb_h, "l2")
+    assert same(_np(gpart).view(np.uint32), gold["c4_part_ids"]) and same(_np(gcodes), gold["c4_codes"])
+    g = DeviceIndex.create(eng, "l2", cent_h, cb_h, gpart, gcodes, None, raw=xt, dtype="float16")
+    offs, _, _ = g.export()
+    assert (offs == gold["c4_part_offsets"]).all()
+    for (k, nprobes, rf) in c["searches"]:
+        gi, gd = g.search(q, k, nprobes, rf)
+        assert (_np(gi).view(np.uint64) == gold[f"c4_ids_{k}_{nprobes}_{rf}"]).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == gold[f"c4_dists_{k}_{nprobes}_{rf}"].view(np.uint32)).all(), (k, nprobes, rf)
+    # the partition-major path (nq * nprobes >= 4096): the same queries tiled
+    qq = np.tile(q, (3, 1))
+    gi, gd = g.search(qq, 10, 10, 10)
+    assert (_np(gi).view(np.uint64) == np.tile(gold["c4_ids_10_10_10"], (3, 1))).all()
+    assert (_np(gd).view(np.uint32) == np.tile(gold["c4_dists_10_10_10"], (3, 1)).view(np.uint32)).all()
+    g.close()
+
+
+def test_c5_coarse_quantiser_trained_to_65536_by_the_engine(eng, gold):
+    """Config 5's nlist built for real: the hierarchical trainer (the reference's route for k > 256, kmeans.rs:746-1003) run
+    to 65,536 centroids on the device -- ~4,400 cluster splits, the last levels with a handful of rows per cluster -- equal to
+    the oracle's run centroid for centroid, then the index and its searches."""
+    import torch
+    from lance_amd.engine import DeviceIndex
+    if "c5t_centroids" not in gold:
+        pytest.fail("tests/golden/fullconfig.npz carries no c5t record (python tests/golden/make_fullconfig_golden.py c5t)")
+    c, ct = C5, C5T
+    xi, qi = c5_data()
+    xt, qt = torch.from_numpy(xi), torch.from_numpy(qi)
+    cent, _, _ = eng.kmeans_train(xt, ct["nlist"], max_iters=ct["ivf_iters"], balance_factor=1.0, seed=ct["seed"])
+    cent = _np(cent).astype(f32)
+    assert cent.shape[0] == int(gold["c5t_ncent"][0])
+    assert same(cent, gold["c5t_centroids"]), "hierarchical centroids (target 65,536) differ from the oracle's"
+    part, _ = eng.assign(xt, cent, "l2")
+    res = eng.residual(xi.astype(f32), cent, part)
+    cb, _ = eng.pq_train(res[:65536], c["m"], max_iters=c["pq_iters"], seed=ct["seed"] + 1)
+    assert same(_np(cb).astype(f32), gold["c5t_codebook"])
+    gpart, gcodes, _ = eng.ivfpq_encode(xt, cent, cb, "l2")
+    assert same(_np(gpart).view(np.uint32), gold["c5t_part_ids"]) and same(_np(gcodes), gold["c5t_codes"])
+    g = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=xt, dtype="int8")
+    for (k, nprobes, rf) in ct["searches"]:
+        gi, gd = g.search(qt, k, nprobes, rf)
+        assert (_np(gi).view(np.uint64) == gold[f"c5t_ids_{k}_{nprobes}_{rf}"]).all(), (k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == gold[f"c5t_dists_{k}_{nprobes}_{rf}"].view(np.uint32)).all(), (k, nprobes, rf)
     g.close()

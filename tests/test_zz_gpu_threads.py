@@ -1,0 +1,69 @@
+"""Host threads against one index (round 4): the reference calls this path from many rayon / tokio threads at once
+(rust/lance/src/index/vector/ivf/v2.rs:232-306, `buffered(n_cpus)` over partitions / queries).  The C ABI's contract
+(include/lance_hip.h): an index is read-only during searches and may be searched through any number of contexts at the same
+time; a context is a stream + scratch arena whose entry points serialise on a per-context lock, so (a) two threads with a
+context each overlap on the device, (b) two threads sharing one context are safe and simply take turns.  ctypes releases the GIL
+for the duration of every call, so the threads below really are inside the library together."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _sift_like(n, d, seed, ncl=64):
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(0, 128, (ncl, d))
+    x = centers[rng.integers(0, ncl, n)] + rng.normal(0, 24, (n, d))
+    return np.clip(np.rint(x), 0, 218).astype(f32)
+
+
+@pytest.mark.parametrize("shape", ["m16", "m96"])
+def test_two_threads_two_contexts_one_index(engine, shape):
+    import lance_amd
+    from lance_amd.engine import Engine
+    if shape == "m16":
+        n, d, nlist, m = 120_000, 128, 64, 16
+    else:
+        n, d, nlist, m = 30_000, 384, 32, 96       # tiled-table kernels (and the per-query-table filter's lazy index constants)
+    x = _sift_like(n, d, 5)
+    idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=nlist, num_sub_vectors=m, max_iters=6)
+    dev = torch.device("cuda", 0)
+    # thread 0: large batches (partition-major quantised flow), thread 1: small ones (query-major kernels) and a refine
+    work = [dict(q=torch.from_numpy(_sift_like(1500, d, 11)).to(dev), k=10, nprobes=8, rf=5),
+            dict(q=torch.from_numpy(_sift_like(40, d, 12)).to(dev), k=7, nprobes=nlist, rf=0)]
+    expect = []
+    for w in work:
+        i, dd = idx.search_device(w["q"], w["k"], w["nprobes"], w["rf"])
+        expect.append((i.clone(), dd.clone()))
+    torch.cuda.synchronize()
+
+    def run(engines, reps):
+        errors = []
+
+        def body(t):
+            try:
+                w = work[t]
+                for _ in range(reps):
+                    i, dd = idx.search_device(w["q"], w["k"], w["nprobes"], w["rf"], engine=engines[t])
+                    if not (torch.equal(i, expect[t][0]) and torch.equal(dd.view(torch.int32), expect[t][1].view(torch.int32))):
+                        errors.append(f"thread {t}: result differs from the single-threaded answer")
+                        return
+            except Exception as e:      # noqa: BLE001 -- reported to the asserting thread
+                errors.append(f"thread {t}: {e!r}")
+
+        ts = [threading.Thread(target=body, args=(t,)) for t in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ts), "a search thread did not finish"
+        assert not errors, errors
+
+    e1, e2 = Engine(), Engine()
+    run([e1, e2], 25)            # a context each: the calls overlap
+    run([e1, e1], 25)            # one shared context: the calls take turns on its lock
+    e1.close(); e2.close()
