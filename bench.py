@@ -397,6 +397,40 @@ def main():
                 traffic_recorded = {"hbm_bytes_per_launch": kv["hbm_bytes_per_launch"], "source": "profiles/r03_bench_pmc_tcc.json (round 3 tree; not this run)"}
     except Exception:
         pass
+    # ---- the build half of the metric against ITS rooflines (world 1): (i) the transform pass (assign + residual + encode of every
+    # row, one streaming read of the column) against HBM; (ii) one IVF E-step of the training sample (65,536 x nlist x d) against the
+    # dense bf16 MFMA peak -- executed flop = 3 x algorithmic (two-term bf16 split: hi.hi + lo.hi + hi.lo)
+    roofline_build = None
+    if world == 1 and not multi:
+        es = 2 if half else 4
+        tr_bytes = float(args.n) * d * es + float(args.n) * (4 + m)
+        tr_sec = idx.stats.seconds.get("transform") if idx.stats else None
+        ns = min(args.n, nlist * 256)
+        xs_ = x[:ns]
+        cent_ = idx._ix.centroids
+        for _ in range(3):
+            eng.assign(xs_, cent_, "l2")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps_e = 20
+        for _ in range(reps_e):
+            eng.assign(xs_, cent_, "l2")
+        torch.cuda.synchronize()
+        e_sec = (time.perf_counter() - t1) / reps_e
+        e_flop = 2.0 * ns * nlist * d
+        MFMA_BF16_PEAK = 2500.0      # TFLOP/s dense bf16, MI355X_MICROARCH.md
+        roofline_build = {
+            "transform": {"bound": "hbm", "algorithmic_bytes": tr_bytes, "seconds": tr_sec,
+                          "achieved": (tr_bytes / tr_sec / 1e9) if tr_sec else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": (tr_bytes / tr_sec / 1e9 / HBM_PEAK_GBS) if tr_sec else None,
+                          "what": "lance_hip_ivfpq_encode over all rows: MFMA assign + exact re-check + fused residual / PQ encode; bytes = N*d*s read + N*(4+M) written"},
+            "estep_ivf": {"bound": "mfma", "rows": ns, "centroids": nlist, "d": d, "seconds": e_sec,
+                          "achieved": e_flop / e_sec / 1e12, "achieved_executed": 3.0 * e_flop / e_sec / 1e12, "peak": MFMA_BF16_PEAK,
+                          "unit": "TFLOP/s", "frac": e_flop / e_sec / 1e12 / MFMA_BF16_PEAK, "frac_executed": 3.0 * e_flop / e_sec / 1e12 / MFMA_BF16_PEAK,
+                          "what": "lance_hip_assign of the training sample against the trained centroids (prep + MFMA sweep + exact re-check), "
+                                  "host-timed over 20 calls incl. launch gaps; algorithmic flop = 2*n*k*d"},
+            "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
+        }
     guide_lds_peak = LDS_B64_CONFLICT_FREE_PER_CLK_CU * 256 * 2.4e9      # lane-gathers/s: ds_read_b64, 256 B/clk/CU, 256 CUs, 2.4 GHz
     c4 = args.config == "c4"
     result = {
@@ -436,6 +470,7 @@ def main():
         # = 32 lanes/clk/CU, x 256 CUs x 2.4 GHz); the same rate against the random-gather microbenchmark of this run is kept as
         # frac_of_measured_gather (that kernel shares the scan's bank-conflict pathology: it is a floor for "what this table shape
         # can deliver", not a roofline)
+        "roofline_build": roofline_build,
         "roofline": {"kernel": kernel_name, "bound": "lds", "achieved": gather_rate / 1e9, "peak": guide_lds_peak / 1e9,
                      "unit": "G lane-gathers/s", "frac": gather_rate / guide_lds_peak,
                      "peak_source": "MI355X_MICROARCH.md, LDS: ds_read_b64 conflict-free = 32 lanes/clk/CU x 256 CUs x 2.4 GHz",

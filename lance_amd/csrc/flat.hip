@@ -1089,6 +1089,13 @@ extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, co
   // f16 columns under dot / cosine: half::f16's own distance functions (32-lane dot_scalar / norm_l2_impl, scalar cosine;
   // dot.rs:91-102, norm_l2.rs:60-85, cosine.rs:171-179) -- the run-time-dimension kernel below carries those orders
   const bool h32 = dtype == LANCE_HIP_F16 && metric != LANCE_HIP_L2;
+  if (flat_small_supported(metric, dtype, d, nq, k, n)) {      // one to four queries: a single streaming pass (flat_small.hip)
+    const float *qs2;
+    LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qs2));
+    bool done = false;
+    LH_TRY(flat_topk_small(ctx, metric, dtype, x, row_ids, n, d, qs2, nq, k, ids, dists, &done));
+    if (done) return LANCE_HIP_OK;
+  }
   if (!h32 && flat_v2_supported(metric, d, k) && !getenv("LANCE_HIP_FLAT_V1")) {
     const float *xf2 = nullptr, *qf2;
     LH_TRY(as_f32(ctx, dtype, q, (size_t)nq * d, "f16.q", &qf2));

@@ -110,6 +110,10 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow);
 int find_partitions_f32(lance_hip_ctx *ctx, int metric, const float *qf, uint32_t nq, uint32_t d, const float *cf, uint32_t nlist,
                         uint32_t nprobes, uint32_t *part_ids, float *dists, bool lanes32);   // search.hip
+// flat_small.hip: exhaustive KNN for one to four queries in a single streaming pass (*done = false: mass ties, take the batch path)
+bool flat_small_supported(int metric, int dtype, uint32_t d, uint32_t nq, uint32_t k, uint64_t n);
+int flat_topk_small(lance_hip_ctx *ctx, int metric, int dtype, const void *x, const uint64_t *row_ids, uint64_t n, uint32_t d, const float *q,
+                    uint32_t nq, uint32_t k, uint64_t *ids, float *dists, bool *done);
 // mfma_assign.hip: the coarse quantiser at query time on the matrix cores (surrogate matrix + exact re-check of the candidates)
 bool coarse_mfma_supported(int metric, int d, uint32_t nq, uint32_t nlist, uint32_t nprobes, bool lanes32, const float *q, const float *cent);
 int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t nprobes,

@@ -792,7 +792,19 @@ __device__ __forceinline__ float cs_group_distance(const float *wrow, const floa
     }
     s = r;
   }
-  for (int ch = 0; ch < full; ch += 16) {
+  int ch = 0;
+  for (; ch + 128 <= full; ch += 128) {      // eight chunks' loads in flight; the adds stay in chunk order
+    float yv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) yv[u] = y[ch + 16 * u + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float xv = wrow[ch + 16 * u + i];
+      if constexpr (METRIC == METRIC_DOT) acc = acc + xv * yv[u];
+      else { const float diff = xv - yv[u]; acc = acc + diff * diff; }
+    }
+  }
+  for (; ch < full; ch += 16) {
     const float xv = wrow[ch + i], yv = y[ch + i];
     if constexpr (METRIC == METRIC_DOT) acc = acc + xv * yv;
     else { const float diff = xv - yv; acc = acc + diff * diff; }
@@ -820,26 +832,54 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ 
   for (int e = lane; e < d; e += 64) wrow[e] = qv[e];
   float *row = sur + (int64_t)qi * nlist;
   const float E2 = e2[qi];
-  // pass 1: lane minima (a NaN anywhere sends the row to the exact path)
-  float mn = INFINITY;
+  // pass 1: the four smallest values of every lane (a NaN anywhere sends the row to the exact path).  The nprobes-th smallest
+  // of these 256 values bounds the nprobes-th smallest of the row from above (they are distinct elements), and unlike the
+  // nprobes-th smallest of 64 lane MINIMA it stays close to it when nprobes approaches 64 (r04b: at nprobes = 50 the minima
+  // gave ~90 candidates per query, most rows overflowed the list and took the exact path: 4.3 ms per 1000 queries).
+  float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
   bool bad = !(E2 < INFINITY);
   for (int i = lane; i < nlist; i += 64) {
     const float v = row[i];
     bad |= v != v;
-    mn = fminf(mn, v);
-  }
-  bad = __any(bad);
-  float sv = mn;
-#pragma unroll
-  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-    for (int jj = k2 >> 1; jj > 0; jj >>= 1) {
-      const float o = __shfl_xor(sv, jj, 64);
-      const bool up = (lane & k2) == 0, lower = (lane & jj) == 0;
-      sv = (lower == up) ? fminf(sv, o) : fmaxf(sv, o);
+    if (v < m3) {
+      if (v < m2) {
+        m3 = m2;
+        if (v < m1) {
+          m2 = m1;
+          if (v < m0) { m1 = m0; m0 = v; } else m1 = v;
+        } else m2 = v;
+      } else m3 = v;
     }
   }
-  const float thr = __shfl(sv, nprobes - 1, 64) + E2;     // nprobes <= 64 (host); +inf when fewer than nprobes lanes hold a value
+  bad = __any(bad);
+  // bitonic network over the 256 values: element e = register e / 64 of lane e % 64 (as select_probes_wave_kernel)
+  float sv4[4] = {m0, m1, m2, m3};
+#pragma unroll
+  for (int k2 = 2; k2 <= 256; k2 <<= 1) {
+#pragma unroll
+    for (int dd = k2 >> 1; dd > 0; dd >>= 1) {
+      if (dd >= 64) {
+        const int jd = dd >> 6;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+          if ((jr & jd) == 0) {
+            const bool up = ((jr * 64) & k2) == 0;
+            const float lo = fminf(sv4[jr], sv4[jr | jd]), hi = fmaxf(sv4[jr], sv4[jr | jd]);
+            sv4[jr] = up ? lo : hi; sv4[jr | jd] = up ? hi : lo;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+          const int e = jr * 64 + lane;
+          const float o = __shfl_xor(sv4[jr], dd, 64);
+          const bool up = (e & k2) == 0, lower = (lane & dd) == 0;
+          sv4[jr] = (lower == up) ? fminf(sv4[jr], o) : fmaxf(sv4[jr], o);
+        }
+      }
+    }
+  }
+  const float thr = __shfl(sv4[0], nprobes - 1, 64) + E2;     // nprobes <= 64 (host); +inf when the row has fewer than nprobes values
   uint32_t cnt = 0;
   if (!bad) {
     for (int base = 0; base < nlist; base += 64) {
@@ -934,7 +974,10 @@ bool coarse_mfma_supported(int metric, int d, uint32_t nq, uint32_t nlist, uint3
   if (d <= 128) { if (d % 16 != 0 || d < 16 || nlist < 32) return false; }
   else if (d > 4096 || nlist < 64 || d % 4 != 0) return false;
   if (force) return true;
-  // below this the exact kernel's matrix is cheaper than the split / prep launches
+  // below this the exact kernel's matrix is cheaper than the split / prep launches.  Long rows (K-tiled kernel): its workgroups
+  // walk the dimension in 32-element steps, 48 dependent steps at d = 1536, and a 1000-query batch fills a quarter of the CUs --
+  // measured slower than the exact kernels at C3 (r04b: 0.19 vs 0.155 ms per 1000 queries), so it waits for more work per launch
+  if (d > 128) return (uint64_t)nq * nlist >= (1ull << 23);
   return (uint64_t)nq * nlist * (uint64_t)d >= (1ull << 27);
 }
 

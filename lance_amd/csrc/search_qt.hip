@@ -658,7 +658,7 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_pt_kernel(QscanArgs p
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
 bool qscan_pt_enabled(const lance_hip_index *ix) {
-  static const bool on = getenv("LANCE_HIP_QPT") != nullptr;
+  static const bool on = [] { const char *e = getenv("LANCE_HIP_QPT"); return e ? e[0] != '0' : false; }();   // unset: off (for now)
   if (!on || !ix || ix->m == 0 || ix->nbits != 8) return false;
   const int m = (int)ix->m, sd = (int)(ix->d / ix->m);
   if (!qscan_tiled_shape(m, sd)) return false;
@@ -713,6 +713,8 @@ int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const Qscan
   uint16_t *tab = ctx->scratch_t<uint16_t>("pt.tab", (size_t)nq * m * 256);
   if (!qn2 || !sq || !kap || !pslack || !tab) return LANCE_HIP_ENOMEM;
   const int64_t npairs = (int64_t)nq * nprobes;
+  {
+  ScopedTimer tprep(ctx, "q_pt_tables");      // (inside the caller's "ivfpq_scan_c1" timer)
   hipLaunchKernelGGL(q_pt_kappa_kernel, dim3((unsigned)cdiv((uint64_t)npairs, 4)), dim3(256), 0, ctx->stream, qs, ix->pt->g, ix->pt->cen_t, probes,
                      npairs, nprobes, d, kap, qn2);
   hipLaunchKernelGGL(q_pt_scale_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, ix->pt->beta_min, ix->pt->beta_abs, probes, a.tbound,
@@ -721,6 +723,7 @@ int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const Qscan
   if (sd == 4) hipLaunchKernelGGL((q_pt_table_kernel<4>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, tab);
   else if (sd == 8) hipLaunchKernelGGL((q_pt_table_kernel<8>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, tab);
   else hipLaunchKernelGGL((q_pt_table_kernel<16>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, tab);
+  }
   PtArgs t;
   t.tab = tab; t.sq = sq; t.kap = kap; t.pslack = pslack; t.row_beta = ix->pt->row_beta;
   if (m == 48) launch_qscan_tiled_pt<3, 1>(ctx, a, t, grid);
