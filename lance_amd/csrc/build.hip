@@ -449,7 +449,10 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
 static int index_finish_offsets(lance_hip_ctx *ctx, lance_hip_index *ix) {
   ix->part_offsets_h.resize(ix->nlist + 1);
   LH_CHECK_HIP(hipMemcpyAsync(ix->part_offsets_h.data(), ix->part_offsets, (size_t)(ix->nlist + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t nonfinite = 0;
+  if (ix->cb_mean) LH_CHECK_HIP(hipMemcpyAsync(&nonfinite, ix->cb_mean + ix->d + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  ix->model_finite = nonfinite == 0;
   ix->max_part = 0;
   for (uint32_t p = 0; p < ix->nlist; ++p)
     ix->max_part = std::max(ix->max_part, ix->part_offsets_h[p + 1] - ix->part_offsets_h[p]);

@@ -864,6 +864,7 @@ using namespace lh;
 extern "C" int lance_hip_ivfflat_create(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,
                                         const void *x, const uint32_t *part_ids, const uint64_t *row_ids, uint64_t n,
                                         lance_hip_index **out) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && centroids && out && (n == 0 || (x && part_ids)), "ivfflat_create: NULL argument");
   LH_TRY(check_dtype(dtype, "ivfflat_create"));
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "ivfflat_create: bad metric %d", metric);
@@ -923,11 +924,19 @@ __global__ __launch_bounds__(256) void ivfflat_flag_overfull_kernel(FlatPool p, 
   if (q < nq) flags[q] = p.cnt[q] > (uint32_t)p.cap ? 1u : 0u;
 }
 
+__global__ __launch_bounds__(256) void ivfflat_flag_all_kernel(int nq, uint32_t *__restrict__ flags) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q < nq) flags[q] = 1u;
+}
+
 static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k, uint32_t nprobes,
                                const uint32_t *allow, uint64_t *ids, float *dists) {
   LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && dists)), "ivfflat_search: NULL argument");
   LH_REQUIRE(idx->m == 0 && idx->vectors, "ivfflat_search: not an IVF_FLAT index");
-  LH_REQUIRE(k > 0 && k <= 128, "ivfflat_search: k=%u not supported (1..128)", k);
+  // FlatIndex::search takes any k (flat/index.rs:82-177).  The threshold machinery of the fast kernels selects among one value per
+  // lane (k <= 128); beyond that every query goes through the heap-emulating exact kernel, whose heap lives in LDS (k <= 4096)
+  LH_REQUIRE(k > 0 && k <= 4096, "ivfflat_search: k=%u not supported (1..4096)", k);
+  const bool big_k = k > 128;
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (nq == 0) return LANCE_HIP_OK;
   if (nprobes > idx->nlist) nprobes = idx->nlist;
@@ -971,6 +980,7 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
   const bool fixed = !cosine && !h32 && flat_fixed_dim(idx->d);
   const size_t sel_lds = (size_t)IVFFLAT_CAP * 16;
   const size_t ex_lds = (size_t)(((d + 3) & ~3) + 2) * 4 + (size_t)k * 12 + (size_t)(k + 1) * 8 + 64 * 4 + 64;
+  LH_REQUIRE(ex_lds <= 160 * 1024, "ivfflat_search: k=%u with %d-dimensional vectors does not fit the exact kernel's LDS", k, d);
   auto finish = [&](int nqc, uint64_t *oid, float *od, bool select = true) {
     if (select) hipLaunchKernelGGL(ivfflat_select_kernel, dim3(nqc), dim3(256), sel_lds, ctx->stream, a, oid, od);
     ScopedTimer t(ctx, "ivfflat_exact");
@@ -1037,6 +1047,11 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
     float *od = dists + (int64_t)qc0 * k;
     hipLaunchKernelGGL(flat_pool_reset_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, pl, 1);
     grouped = false;
+    if (big_k) {     // every query flagged: the exact kernel answers all of them
+      hipLaunchKernelGGL(ivfflat_flag_all_kernel, dim3(cdiv(nqc, 256)), dim3(256), 0, ctx->stream, nqc, a.flags);
+      finish(nqc, oid, od, false);
+      continue;
+    }
     scan(1, nqc);
     scan(0, nqc);
     finish(nqc, oid, od);
@@ -1063,12 +1078,14 @@ static int ivfflat_search_impl(lance_hip_ctx *ctx, const lance_hip_index *idx, c
 
 extern "C" int lance_hip_ivfflat_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                         uint32_t nprobes, uint64_t *ids, float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   return ivfflat_search_impl(ctx, idx, q, nq, k, nprobes, nullptr, ids, dists);
 }
 
 extern "C" int lance_hip_ivfflat_search_filtered(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t k,
                                                  uint32_t nprobes, const uint8_t *allow_by_rowid, uint64_t n_allow, uint64_t *ids,
                                                  float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && idx && (allow_by_rowid || n_allow == 0), "ivfflat_search_filtered: NULL argument");
   LH_REQUIRE(idx->m == 0 && idx->vectors, "ivfflat_search_filtered: not an IVF_FLAT index");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
@@ -1080,6 +1097,7 @@ extern "C" int lance_hip_ivfflat_search_filtered(lance_hip_ctx *ctx, const lance
 extern "C" int lance_hip_flat_topk(lance_hip_ctx *ctx, int dtype, int metric, const void *x, const uint64_t *row_ids,
                                    uint64_t n, uint32_t d, const void *q, uint32_t nq, uint32_t k, uint64_t *ids,
                                    float *dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && (n == 0 || x) && (nq == 0 || (q && ids && dists)), "flat_topk: NULL argument");
   LH_TRY(check_dtype(dtype, "flat_topk"));
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "flat_topk: bad metric %d", metric);

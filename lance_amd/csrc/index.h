@@ -21,6 +21,10 @@ struct lance_hip_index {
   uint64_t n = 0;                 // rows stored (rows with part id NONE are dropped)
   float *centroids = nullptr;     // [nlist][d]
   float *codebook = nullptr;      // [m][256][d/m]
+  // cb_mean is followed by one flag word (cb_mean[d + 1], as bits): != 0 when a centroid or codeword is NaN / infinite
+  // (an overflowed f16 model).  model_finite mirrors it on the host; the integer filter scans -- whose NaN entries quantise to 0
+  // and would enter the merge kernel's sum cut as small sums -- are only taken for finite models
+  bool model_finite = true;
   float *cb_mean = nullptr;       // 8-bit PQ: [d] mean codeword of every sub-quantiser, then [1] sum over m of the mean |c|^2 (bound pass scale)
   // LANCE_HIP_QPT=1 (search_qt.hip, per-query tables): constants of that filter, created by the first such search
   struct PtConst {

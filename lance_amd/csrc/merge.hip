@@ -54,6 +54,7 @@ using namespace lh;
 
 extern "C" int lance_hip_merge_topk(lance_hip_ctx *ctx, const int64_t *ids, const float *dists, const float *exact_dists, uint32_t nq,
                                     uint32_t c, uint32_t keff, uint32_t k, int64_t *out_ids, float *out_dists) {
+  lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && (nq == 0 || (ids && dists && out_ids && out_dists)), "merge_topk: NULL argument");
   LH_REQUIRE(c > 0 && c <= 4096, "merge_topk: %u candidates per query not supported (1..4096)", c);
   LH_REQUIRE(k > 0, "merge_topk: k must be > 0");

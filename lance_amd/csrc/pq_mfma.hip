@@ -299,6 +299,9 @@ bool pq_mfma_supported(const PairwiseArgs &p, int d, int metric, int batches) {
   if (p.k != 256 || p.n < 2048 || batches < 1) return false;
   if (!p.x || !p.x_aligned || !p.cent_aligned) return false;
   if ((uint64_t)p.n >= (1ull << 32)) return false;                          // row numbers in 32 bits
+  // the undecided-row list is n * batches words of persistent scratch and this launcher does not chunk the rows (the encode
+  // launcher does): beyond 256 MB the exact kernels take the call (an IVF assign of 10^8 short rows against 256 centroids)
+  if ((uint64_t)p.n * (uint64_t)batches * 4 > (256ull << 20)) return false;
   return true;
 }
 

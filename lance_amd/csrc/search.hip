@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void select_probes_big_kernel(const float *__r
   lmin[threadIdx.x] = mn;
   __syncthreads();
   bitonic_sort_u64(lmin, 256);
-  uint64_t T = lmin[min(nprobes, 256) - 1];
+  // more probes than lanes: no bound from the lane minima -- the first round collects the first 4096 keys it meets and takes
+  // its bound from those (each later round drops at least 4096 - nprobes keys: nprobes <= 2048 converges within the 64 rounds)
+  uint64_t T = nprobes <= 256 ? lmin[nprobes - 1] : ~0ull;
   for (int round = 0; round < 64; ++round) {
     __syncthreads();
     if (threadIdx.x == 0) s_cnt = 0;
@@ -1029,11 +1031,12 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
                                      uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow) {
   LH_REQUIRE(k > 0, "search: k must be > 0");
   if (nprobes > ix->nlist) nprobes = ix->nlist;
-  LH_REQUIRE(ix->nlist <= 8192 || nprobes <= 256, "search: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
+  LH_REQUIRE(ix->nlist <= 8192 || nprobes <= 2048, "search: nprobes=%u > 2048 with more than 8192 partitions is not supported", nprobes);
   LH_REQUIRE(nprobes > 0, "search: nprobes must be > 0");
   const uint32_t rf = refine_factor == 0 ? 1 : refine_factor;
   const uint64_t keff64 = (uint64_t)k * rf;
-  LH_REQUIRE(keff64 <= 2048, "search: k * refine_factor = %llu > 2048 is not supported in this version", (unsigned long long)keff64);
+  // the reference has no limit on k * refine_factor; here the exact kernel's heap and the refine sort live in LDS (8192 entries)
+  LH_REQUIRE(keff64 <= 8192, "search: k * refine_factor = %llu > 8192 is not supported", (unsigned long long)keff64);
   const uint32_t keff = (uint32_t)keff64;
   const bool fast = keff <= (uint32_t)SCAN_MAX_KEFF;  // larger k: every query takes the exact (slow) kernel
   const bool do_refine = refine_factor >= 1;  // Some(rf): re-rank even when rf == 1 (scanner.rs:2884)
@@ -1209,7 +1212,7 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
 int find_partitions_f32(lance_hip_ctx *ctx, int metric, const float *qf, uint32_t nq, uint32_t d, const float *cf, uint32_t nlist,
                         uint32_t nprobes, uint32_t *part_ids, float *dists, bool lanes32) {
   if (nprobes > nlist) nprobes = nlist;
-  LH_REQUIRE(nlist <= 8192 || nprobes <= 256, "find_partitions: nprobes=%u > 256 with more than 8192 partitions is not supported", nprobes);
+  LH_REQUIRE(nlist <= 8192 || nprobes <= 2048, "find_partitions: nprobes=%u > 2048 with more than 8192 partitions is not supported", nprobes);
   if (nq == 0 || nprobes == 0) return LANCE_HIP_OK;
   float *matrix = ctx->scratch_t<float>("search.matrix", (size_t)nq * nlist);
   if (!matrix) return LANCE_HIP_ENOMEM;

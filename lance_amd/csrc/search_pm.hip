@@ -618,7 +618,12 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   uint32_t *tglobal = ctx->scratch_t<uint32_t>("pm.tglobal", (size_t)nq * 4);
   uint32_t *seg_cnt = ctx->scratch_t<uint32_t>("q.seg_cnt", npairs);
   uint32_t *seg_pos = ctx->scratch_t<uint32_t>("q.seg_pos", npairs * QSCAN_SEG_CAP);
-  int pool_cap = (int)std::min<uint64_t>(8192, std::max<uint64_t>(512, (uint64_t)nprobes * (keff + 28)));
+  // tiled shapes (M >= 48) have no exact pair kernel: EVERY segment of a query without a bound goes through the rescan kernel and
+  // publishes ~keff rows to the pool, so the pool follows nprobes there (nprobes = 100 with refine 10 overflowed the
+  // 8192-entry pool of every such query and sent it to the query-major replay), within 1 GiB of scratch
+  uint64_t pool_max = qscan_tiled_shape(m, sd) ? 65536 : 8192;
+  while (pool_max > 8192 && (uint64_t)nq * pool_max * 8 > (1ull << 30)) pool_max /= 2;
+  int pool_cap = (int)std::min<uint64_t>(pool_max, std::max<uint64_t>(512, (uint64_t)nprobes * (keff + 28)));
   pool_cap = (pool_cap + 255) & ~255;
   uint32_t *pool_key = ctx->scratch_t<uint32_t>("pm.pool_key", (size_t)nq * pool_cap);
   uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * pool_cap);

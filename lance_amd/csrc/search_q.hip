@@ -783,7 +783,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
 // ---- host -------------------------------------------------------------------------------------------------------
 bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   static const bool off = getenv("LANCE_HIP_NO_QSCAN") != nullptr;
-  if (off) return false;
+  if (off || !ix->model_finite) return false;      // NaN / infinite centroids or codewords: the exact kernels decide (index.h)
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
   if (scan_metric != LANCE_HIP_L2) return false;                    // entries must be >= 0 (squared L2)
   {
@@ -912,11 +912,23 @@ __global__ __launch_bounds__(256) void q_codebook_mean_kernel(const float *__res
   }
 }
 
+__global__ __launch_bounds__(256) void q_model_finite_kernel(const float *__restrict__ a, int64_t na, const float *__restrict__ b, int64_t nb,
+                                                             uint32_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (i < na) bad = !isfinite(a[i]);
+  else if (i < na + nb) bad = !isfinite(b[i - na]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {
   const int d = (int)ix->d, m = (int)ix->m;
-  if (!ix->cb_mean) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_mean), (size_t)(d + 1) * 4));
-  LH_CHECK_HIP(hipMemsetAsync(ix->cb_mean, 0, (size_t)(d + 1) * 4, ctx->stream));
+  if (!ix->cb_mean) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_mean), (size_t)(d + 2) * 4));
+  LH_CHECK_HIP(hipMemsetAsync(ix->cb_mean, 0, (size_t)(d + 2) * 4, ctx->stream));
   hipLaunchKernelGGL(q_codebook_mean_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ix->codebook, d / m, d, ix->cb_mean);
+  const int64_t nc = (int64_t)ix->nlist * d, ncb = (int64_t)m * 256 * (d / m);
+  hipLaunchKernelGGL(q_model_finite_kernel, dim3((unsigned)cdiv((uint64_t)(nc + ncb), 256)), dim3(256), 0, ctx->stream, ix->centroids, nc, ix->codebook,
+                     ncb, reinterpret_cast<uint32_t *>(ix->cb_mean + d + 1));
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
