@@ -145,6 +145,27 @@ int lance_hip_kmeans_shard_update(lance_hip_ctx *ctx, void *state, const float *
                                   double tol, uint32_t it);
 int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *loss_host, uint32_t *iters_host, int *active_host);
 
+/* ---- the same loop with its collectives behind the ABI (RCCL over xGMI) ----------------------------------------
+ * For hosts without torch.distributed.  One process per GPU; rank 0 draws an id (lance_hip_comm_unique_id, 128 bytes = an
+ * ncclUniqueId), ships it to the other ranks by whatever channel the host has, every rank calls lance_hip_comm_create on its own
+ * context -- or lance_hip_comm_adopt wraps an ncclComm_t the host already owns (it stays the host's to destroy).
+ * lance_hip_kmeans_train_sharded runs KMeans::train_kmeans (kmeans.rs:610-719) over rows sharded across the ranks: per Lloyd
+ * iteration a local E-step + partial sums, ONE ncclAllReduce(sum) of the fused f32 buffer [k*d sums | k counts] (129 KiB at
+ * nlist 256, d 128), one of the k f64 losses and one max-reduce of the k radii, then the update kernel -- all enqueued on the
+ * context's stream; the host reads the state every 8 iterations.  `centroids` holds the initial centroids (identical on every
+ * rank: e.g. rank 0's kmeans_random_init rows, broadcast by the host) and receives the trained ones (identical on every rank).
+ * comm == NULL: single process, no collective.  balance_factor is the unscaled parameter (divided by n_total as train_kmeans does).
+ * Sums arrive in rank order rather than row order: against the single-GPU trainer the centroids agree to f32 round-off for more
+ * than one rank and bit for bit for one.  librccl.so is loaded on first use (dlopen).                                        */
+typedef struct lance_hip_comm lance_hip_comm;
+int lance_hip_comm_unique_id(char *id_out_host /* 128 bytes */);
+int lance_hip_comm_create(lance_hip_ctx *ctx, const char *id_host /* 128 bytes */, int nranks, int rank, lance_hip_comm **out);
+int lance_hip_comm_adopt(void *nccl_comm, int nranks, int rank, lance_hip_comm **out);
+void lance_hip_comm_destroy(lance_hip_comm *comm);
+int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int metric, const float *x_local, uint64_t n_local, uint32_t d,
+                                   uint32_t k, uint64_t n_total, uint32_t max_iters, double tol, float balance_factor, uint64_t seed,
+                                   float *centroids, double *loss_out_host, uint32_t *iters_out_host);
+
 /* ---- a11: PQBuildParams::build_from_fsl (pq/builder.rs:89-157) ------------------- */
 /* M independent k-means (k = 2^nbits, L2, no balance) over the sub-vector columns of
  * `residuals`; sub-quantiser m uses seed + m.  codebook_out: [m][2^nbits][d/m].      */

@@ -1,0 +1,156 @@
+// comm.cpp -- the collectives of the row-sharded index build behind the C ABI.
+//
+// A Python host orders its RCCL calls through torch.distributed (lance_amd/dist.py).  A host without torch -- the Rust side of the
+// reference -- needs the same loop behind plain C: a communicator handle (created here from an ncclUniqueId the host ships to its
+// ranks, or adopted from an ncclComm_t the host already owns) and `lance_hip_kmeans_train_sharded`, which runs the whole Lloyd
+// loop on the context's stream: local E-step + partial sums (kmeans.hip) -> ncclAllReduce SUM of the fused f32 buffer
+// [k*d sums | k counts] and of the f64 per-cluster losses, ncclAllReduce MAX of the radii -> the update kernel (centroids, loss,
+// balance factor, convergence, shared-seed split, next bias).  The host looks at the state every 8 iterations.
+//   KMeans::train_kmeans   rust/lance-index/src/vector/kmeans.rs:610-719 (one exchange per iteration replaces the rayon reduction)
+// librccl is resolved with dlopen at first use: liblance_hip.so itself has no load-time dependency on it, and inside a torch
+// process the already-loaded RCCL is the one that answers.
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef struct { char internal[128]; } rccl_unique_id;      // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef void *rccl_comm_t;
+enum { RCCL_SUM = 0, RCCL_MAX = 2 };                          // ncclRedOp_t
+enum { RCCL_F32 = 7, RCCL_F64 = 8 };                          // ncclDataType_t
+
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(rccl_unique_id *) = nullptr;
+  int (*CommInitRank)(rccl_comm_t *, int, rccl_unique_id, int) = nullptr;
+  int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+
+RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
+  });
+  return api;
+}
+
+int rccl_fail(const char *what, int rc) {
+  RcclApi &a = rccl();
+  lh::set_error("%s failed: %s (RCCL result %d)", what, a.GetErrorString ? a.GetErrorString(rc) : "?", rc);
+  return LANCE_HIP_ERUNTIME;
+}
+
+}  // namespace
+
+struct lance_hip_comm {
+  rccl_comm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  bool owned = false;
+};
+
+extern "C" {
+
+int lance_hip_comm_unique_id(char *id_out_host) {
+  LH_REQUIRE(id_out_host, "comm_unique_id: NULL argument");
+  RcclApi &a = rccl();
+  LH_REQUIRE(a.ok, "RCCL is not available (librccl.so could not be loaded)");
+  rccl_unique_id id;
+  const int rc = a.GetUniqueId(&id);
+  if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(id_out_host, id.internal, sizeof(id.internal));
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_comm_create(lance_hip_ctx *ctx, const char *id_host, int nranks, int rank, lance_hip_comm **out) {
+  lh::CtxLock _ctx_lock(ctx);
+  LH_REQUIRE(ctx && id_host && out, "comm_create: NULL argument");
+  LH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_create: rank %d of %d", rank, nranks);
+  RcclApi &a = rccl();
+  LH_REQUIRE(a.ok, "RCCL is not available (librccl.so could not be loaded)");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  rccl_unique_id id;
+  memcpy(id.internal, id_host, sizeof(id.internal));
+  rccl_comm_t c = nullptr;
+  const int rc = a.CommInitRank(&c, nranks, id, rank);
+  if (rc != 0) return rccl_fail("ncclCommInitRank", rc);
+  auto *h = new lance_hip_comm();
+  h->comm = c; h->nranks = nranks; h->rank = rank; h->owned = true;
+  *out = h;
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_comm_adopt(void *nccl_comm, int nranks, int rank, lance_hip_comm **out) {
+  LH_REQUIRE(nccl_comm && out, "comm_adopt: NULL argument");
+  LH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_adopt: rank %d of %d", rank, nranks);
+  LH_REQUIRE(rccl().ok, "RCCL is not available (librccl.so could not be loaded)");
+  auto *h = new lance_hip_comm();
+  h->comm = nccl_comm; h->nranks = nranks; h->rank = rank; h->owned = false;
+  *out = h;
+  return LANCE_HIP_OK;
+}
+
+void lance_hip_comm_destroy(lance_hip_comm *comm) {
+  if (!comm) return;
+  if (comm->owned && comm->comm && rccl().ok) (void)rccl().CommDestroy(comm->comm);
+  delete comm;
+}
+
+int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int metric, const float *x_local, uint64_t n_local, uint32_t d,
+                                   uint32_t k, uint64_t n_total, uint32_t max_iters, double tol, float balance_factor, uint64_t seed,
+                                   float *centroids, double *loss_out_host, uint32_t *iters_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
+  LH_REQUIRE(ctx && centroids && (n_local == 0 || x_local), "kmeans_train_sharded: NULL argument");
+  LH_REQUIRE(d > 0 && k > 0 && n_total >= k && n_total >= n_local, "kmeans_train_sharded: need n_total >= k and n_total >= n_local");
+  LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "kmeans_train_sharded: bad metric %d", metric);
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  void *state = ctx->scratch("shard.state", 256);
+  float *bias = ctx->scratch_t<float>("shard.bias", k);
+  float *buf = ctx->scratch_t<float>("shard.buf", (size_t)k * d + k);
+  double *losses = ctx->scratch_t<double>("shard.losses", k);
+  float *radius = ctx->scratch_t<float>("shard.radius", k);
+  if (!state || !bias || !buf || !losses || !radius) return LANCE_HIP_ENOMEM;
+  const float bf_scaled = balance_factor / (float)n_total;      // train_kmeans :1344: params.balance_factor /= data.len()
+  LH_TRY(lance_hip_kmeans_shard_begin(ctx, k, bf_scaled, seed, state, bias));
+  double loss = 0.0;
+  uint32_t iters = 0;
+  int active = 1;
+  for (uint32_t it = 1; it <= max_iters; ++it) {
+    LH_TRY(lance_hip_kmeans_shard_estep(ctx, metric, x_local, n_local, d, centroids, k, bias, state, buf, losses, radius));
+    if (comm) {
+      RcclApi &a = rccl();
+      int rc = a.AllReduce(buf, buf, (size_t)k * d + k, RCCL_F32, RCCL_SUM, comm->comm, ctx->stream);
+      if (rc == 0) rc = a.AllReduce(losses, losses, k, RCCL_F64, RCCL_SUM, comm->comm, ctx->stream);
+      if (rc == 0) rc = a.AllReduce(radius, radius, k, RCCL_F32, RCCL_MAX, comm->comm, ctx->stream);
+      if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+    }
+    LH_TRY(lance_hip_kmeans_shard_update(ctx, state, buf, losses, radius, centroids, bias, k, d, n_total, bf_scaled, tol, it));
+    if (it % 8 == 0 || it == max_iters) {
+      LH_TRY(lance_hip_kmeans_shard_end(ctx, state, &loss, &iters, &active));
+      if (!active) break;
+    }
+  }
+  if (iters == 0) LH_TRY(lance_hip_kmeans_shard_end(ctx, state, &loss, &iters, &active));
+  if (loss_out_host) *loss_out_host = loss;
+  if (iters_out_host) *iters_out_host = iters;
+  return LANCE_HIP_OK;
+}
+
+}  // extern "C"

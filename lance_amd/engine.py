@@ -206,6 +206,35 @@ class Engine:
         check(self.lib.lance_hip_kmeans_shard_end(self.h, _ptr(st["state"]), C.byref(loss), C.byref(iters), C.byref(active)))
         return loss.value, iters.value, bool(active.value)
 
+    # ---- the sharded Lloyd loop with its collectives behind the C ABI (comm.cpp): for hosts without torch.distributed ----
+    def comm_unique_id(self):
+        """ncclGetUniqueId through the library: 128 bytes rank 0 ships to the other ranks"""
+        buf = C.create_string_buffer(128)
+        check(self.lib.lance_hip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_create(self, unique_id, nranks, rank):
+        """ncclCommInitRank on this engine's device -> opaque communicator handle (comm_destroy releases it)"""
+        h = C.c_void_p()
+        check(self.lib.lance_hip_comm_create(self.h, C.create_string_buffer(bytes(unique_id), 128), nranks, rank, C.byref(h)))
+        return h
+
+    def comm_destroy(self, comm):
+        self.lib.lance_hip_comm_destroy(comm)
+
+    def kmeans_train_sharded(self, comm, x_local, init_centroids, n_total, max_iters=50, tol=1e-4, balance_factor=0.0, seed=0, metric="l2"):
+        """lance_hip_kmeans_train_sharded: rows sharded over the ranks of `comm` (None: single process), one fused all-reduce per
+        Lloyd iteration inside the library.  init_centroids: identical on every rank.  -> (centroids, loss, iterations)"""
+        x = to_device(x_local, torch.float32)
+        cent = to_device(init_centroids, torch.float32).clone().contiguous()
+        n, d = x.shape
+        k = cent.shape[0]
+        loss = C.c_double(0); iters = C.c_uint32(0)
+        torch.cuda.synchronize()
+        check(self.lib.lance_hip_kmeans_train_sharded(self.h, comm, METRICS[metric], _ptr(x), n, d, k, int(n_total), max_iters, tol, balance_factor,
+                                                      seed, _ptr(cent), C.byref(loss), C.byref(iters)))
+        return cent, loss.value, iters.value
+
     def pq_train(self, residuals, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
         r, dt = _vec(residuals)
         n, d = r.shape

@@ -9,6 +9,7 @@
 typedef int hipError_t;
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
+typedef void *hipGraphExec_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipHostMallocDefault 0

@@ -24,6 +24,7 @@ void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(
 extern "C" const char *lance_hip_last_error(void) { return lh::g_err; }
 
 void *lance_hip_ctx::scratch(const char *, size_t) { return nullptr; }
+void lance_hip_ctx::drop_graphs() {}
 void lance_hip_ctx::time_begin(const char *) {}
 void lance_hip_ctx::time_end(const char *) {}
 static size_t g_max_stage = 0, g_stage_calls = 0;
