@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void pack_nibbles_kernel(const uint8_t *__rest
 }
 
 int pq_encode_launch(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, const float *codebook, int m,
-                     uint8_t *codes, int nbits) {
+                     uint8_t *codes, int nbits, bool lanes32) {
   const int kc = 1 << nbits;
   uint8_t *dst = codes;
   if (nbits == 4) {
@@ -236,6 +236,7 @@ int pq_encode_launch(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, 
   pa.x = x; pa.n = n; pa.ldx = d; pa.x_batch_off = d / m;
   pa.cent = codebook; pa.k = kc; pa.cent_batch_stride = (int64_t)kc * (d / m);
   pa.codes = dst; pa.codes_ld = m;
+  pa.lanes32 = lanes32;      // f16 sub-vectors of more than 16 elements under dot: dot_scalar::<f16, f32, 32> (dot.rs:91-102)
   LH_TRY(launch_assign(ctx, pa, d / m, metric, m));
   if (nbits == 4 && n > 0) {
     hipLaunchKernelGGL(pack_nibbles_kernel, dim3((unsigned)cdiv((uint64_t)n * (m / 2), 256)), dim3(256), 0, ctx->stream, dst, n, m, codes);
@@ -331,11 +332,11 @@ int lance_hip_pq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void *x
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   // f16 columns: L2 takes l2_scalar::<f16, f32, 16> (as f32 does); dot products of f16 sub-vectors are dot_scalar::<f16, f32, 32>
   // (dot.rs:91-102), which for sub-vectors of up to 16 elements is the same sequence of additions as the 16-lane form
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d / m > 16), "pq_encode: f16 dot with sub-vectors longer than 16 is not supported");
   const float *xf, *cbf;
   LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
   LH_TRY(as_f32(ctx, model_dtype(dtype), codebook, ((size_t)1 << nbits) * d, "f16.codebook", &cbf));
-  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, xf, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits));
+  LH_TRY(pq_encode_launch(ctx, metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric, xf, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits,
+                          dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d / m > 16));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;
 }
@@ -398,7 +399,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
     }
     // the quantizer is built with DistanceType::L2 whatever the index metric (lance/src/index/vector/builder.rs:456) and
     // ProductQuantizer::transform encodes with the quantizer's distance type (pq.rs:143,165): L2-nearest codeword, dot too
-    LH_TRY(pq_encode_launch(ctx, LANCE_HIP_L2, enc_in, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits));
+    LH_TRY(pq_encode_launch(ctx, LANCE_HIP_L2, enc_in, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits, false));
   }
   LH_CHECK_HIP(hipGetLastError());
   if (loss_out_host) {
@@ -424,8 +425,8 @@ static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_
   LH_REQUIRE(ctx && centroids && codebook && out, "index: NULL argument");
   LH_TRY(check_dtype(dtype, "index"));
   // f16 columns under dot: the table entries are dot products of f16 sub-vectors (32-lane dot_scalar, dot.rs:91-102) -- identical
-  // to the 16-lane form up to 16 elements, which is what the table kernels implement
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && m != 0 && d / m > 16), "index: f16 dot with sub-vectors longer than 16 is not supported");
+  // to the 16-lane form up to 16 elements (the partition-major kernels' sub-dimensions); longer sub-vectors take the query-major
+  // kernels, whose table build switches to the 32-lane order (search.hip: lut_entry_rt)
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_COSINE || metric == LANCE_HIP_DOT, "index: bad metric %d", metric);
   LH_REQUIRE(nlist > 0 && nlist <= 65536, "index: nlist=%u not supported in this version (1..65536)", nlist);
   LH_TRY(check_pq_params(d, m, nbits));

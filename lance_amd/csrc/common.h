@@ -96,6 +96,10 @@ struct ScopedTimer {
   ScopedTimer(lance_hip_ctx *c_, const char *k_) : c(c_), k(k_) { if (c->timing) c->time_begin(k); }
   ~ScopedTimer() { if (c->timing) c->time_end(k); }
 };
+// hipMemsetAsync as a plain kernel launch (dtype.hip).  Same cost as the runtime's own fill kernel, but a KERNEL node when a
+// search is captured into a HIP graph: replays of graphs holding memset nodes returned empty results on ROCm 7.2 (gpurun r04c,
+// tests/test_zz_gpu_graph.py) while the first launch of the same graph was right.
+hipError_t memset_async(void *ptr, int value, size_t bytes, hipStream_t stream);
 struct CtxLock {
   lance_hip_ctx *c;
   explicit CtxLock(lance_hip_ctx *c_) : c(c_) { if (c) c->mu.lock(); }

@@ -74,4 +74,25 @@ int from_f32(lance_hip_ctx *ctx, int dtype, const float *src, void *dst, size_t 
   return LANCE_HIP_OK;
 }
 
+__global__ __launch_bounds__(256) void fill_words_kernel(uint32_t *__restrict__ p, uint32_t v, size_t words) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < words) p[i] = v;
+}
+__global__ __launch_bounds__(256) void fill_bytes_kernel(uint8_t *__restrict__ p, uint8_t v, size_t bytes) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < bytes) p[i] = v;
+}
+
+hipError_t memset_async(void *ptr, int value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  const uint32_t b = (uint32_t)value & 255u;
+  if ((reinterpret_cast<uintptr_t>(ptr) & 3) == 0 && (bytes & 3) == 0) {
+    const size_t words = bytes / 4;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, static_cast<uint32_t *>(ptr), b * 0x01010101u, words);
+  } else {
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, stream, static_cast<uint8_t *>(ptr), (uint8_t)b, bytes);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace lh

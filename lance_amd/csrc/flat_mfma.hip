@@ -317,7 +317,7 @@ int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int me
   a.scnt = ctx->scratch_t<uint32_t>("fm.scnt", (size_t)e.nq);
   a.squeue = ctx->scratch_t<uint32_t>("fm.squeue", (size_t)e.nq * FM_SQ_CAP);
   if (!a.scnt || !a.squeue) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(a.scnt, 0, (size_t)e.nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(a.scnt, 0, (size_t)e.nq * 4, ctx->stream));
   const unsigned rblocks = (unsigned)cdiv(rows, FM_ROWS);
   const int qtiles = (e.nq + FM_QT - 1) / FM_QT;
   int z = (int)std::min<int64_t>(qtiles, std::max<int64_t>(1, cdiv(2ll * ctx->num_cus, rblocks)));

@@ -35,7 +35,7 @@ namespace lh {
 constexpr int FS_BS = 256;       // 16 row groups of 16 lanes
 constexpr int FS_CAP = 1024;     // list entries per query and workgroup
 constexpr int FS_RPI = 8;        // rows per group between two capacity checks
-constexpr int FS_MAXQ = 4;
+constexpr int FS_MAXQ = 4;       // instantiated; flat_small_supported() decides how many queries take this path
 
 struct FsArgs {
   const void *x;                 // [n][d] rows in the column's element type
@@ -113,11 +113,18 @@ __global__ __launch_bounds__(FS_BS) void flat_small_scan_kernel(FsArgs a) {
       }
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
-        float tot = 0.0f;
+        // ((0 + a0) + a1) + ... + a15 as a running sum handed from lane to lane inside the 16-lane DPP row (row_shr:1; lane 0 of a
+        // row receives +0.0): after step j lanes 0..j hold their prefix, recomputing a settled lane gives the same value, so after
+        // 15 steps lane 15 holds the reference's total.  (The first version fetched the 16 partial sums with 16 ds_bpermute per row
+        // and query: r04c, 135 us per 512 MB for one query and 2.4 x that per further query -- the fold, not HBM, set the pace.)
+        float run = 0.0f + acc[qi];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) tot = tot + __shfl(acc[qi], (lane & 48) + t, 64);     // ((0 + a0) + a1) + ... + a15
-        const uint32_t key = order_key(finish_metric<METRIC>(s[qi] + tot));
-        if (valid && gi == 0 && key <= T[qi]) {
+        for (int t = 1; t < 16; ++t) {
+          const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, run), 0x111, 0xF, 0xF, false));
+          run = prev + acc[qi];
+        }
+        const uint32_t key = order_key(finish_metric<METRIC>(s[qi] + run));
+        if (valid && gi == 15 && key <= T[qi]) {
           const uint32_t slot = atomicAdd(&misc[qi * 4], 1u);
           if (slot < (uint32_t)FS_CAP) { ckey[qi * FS_CAP + slot] = key; cpos[qi * FS_CAP + slot] = (uint32_t)(row - r_begin); }
           else misc[qi * 4 + 3] = 1u;
@@ -216,7 +223,10 @@ __global__ __launch_bounds__(FS_BS) void flat_small_merge_kernel(FsArgs a, uint6
 
 bool flat_small_supported(int metric, int dtype, uint32_t d, uint32_t nq, uint32_t k, uint64_t n) {
   static const bool off = getenv("LANCE_HIP_NO_FLAT_SMALL") != nullptr;
-  if (off || nq == 0 || nq > (uint32_t)FS_MAXQ || k > 128 || d == 0 || d > 2048) return false;
+  // r04c, C1 (1M x 128 f32): one query 0.135 ms here against 0.25 ms on the batch path (wall 0.177 / 0.247); with two or more
+  // queries the batch path's lanes-own-rows kernel wins (0.13-0.15 ms of kernels for 2-4 queries) -- LANCE_HIP_FLAT_SMALL_MAXQ overrides
+  static const uint32_t maxq = getenv("LANCE_HIP_FLAT_SMALL_MAXQ") ? (uint32_t)atoi(getenv("LANCE_HIP_FLAT_SMALL_MAXQ")) : 1u;
+  if (off || nq == 0 || nq > std::min<uint32_t>(maxq, (uint32_t)FS_MAXQ) || k > 128 || d == 0 || d > 2048) return false;
   if (metric != LANCE_HIP_L2 && metric != LANCE_HIP_DOT) return false;      // cosine_fast has its own arithmetic (flat.hip)
   if (dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d > 16) return false;   // 32 lane accumulators (dot.rs:91-102): batch path
   return n >= 4096;     // tiny tables: the batch path's single epoch is as good
@@ -248,7 +258,7 @@ int flat_topk_small(lance_hip_ctx *ctx, int metric, int dtype, const void *x, co
   a.lrids = ctx->scratch_t<uint64_t>("fs.lrids", (size_t)nq * G * k);
   a.overflow = ctx->scratch_t<uint32_t>("fs.ovf", 1);
   if (!a.lkeys || !a.lrids || !a.overflow) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(a.overflow, 0, 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(a.overflow, 0, 4, ctx->stream));
   const size_t lds_fixed = (size_t)FS_CAP * 8 + (size_t)FS_BS * 4 + (size_t)FS_MAXQ * 16;
   {
     ScopedTimer t(ctx, "flat_scan");

@@ -182,7 +182,7 @@ static int stable_group_wide(lance_hip_ctx *ctx, const uint32_t *ids, int64_t n,
   hipLaunchKernelGGL(group_digit_hi_kernel, dim3(grid), dim3(256), 0, ctx->stream, ids, p1, st1 + 256, n, khi);
   LH_TRY(stable_group(ctx, khi, n, n, k2, 1, st2, p2, n, nullptr));
   hipLaunchKernelGGL(group_compose_kernel, dim3(grid), dim3(256), 0, ctx->stream, p1, p2, st1 + 256, n, sorted_rows);
-  LH_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)k * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(counts, 0, (size_t)k * 4, ctx->stream));
   hipLaunchKernelGGL(group_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, ids, n, k, counts);
   hipLaunchKernelGGL(group_scan_totals_kernel, dim3(1), dim3(256), 0, ctx->stream, counts, k, starts, (const uint8_t *)nullptr);
   LH_CHECK_HIP(hipGetLastError());

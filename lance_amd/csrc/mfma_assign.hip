@@ -727,7 +727,7 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
   uint32_t *fb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)p.n);
   if (!chi || !clo || !cn || !maxbits || !id1 || !id2 || !id3 || !cls || !fb_rows) return LANCE_HIP_ENOMEM;
   LH_REQUIRE(p.n < (1ll << 32), "assign: more than 2^32 rows per call");
-  LH_CHECK_HIP(hipMemsetAsync(maxbits, 0, 12, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(maxbits, 0, 12, ctx->stream));
   hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, dp, p.bias, chi, clo, cn, maxbits, p.active);
   MaArgs a;
   a.x = p.x_native ? p.x_native : static_cast<const void *>(p.x); a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
@@ -809,9 +809,15 @@ __device__ __forceinline__ float cs_group_distance(const float *wrow, const floa
     if constexpr (METRIC == METRIC_DOT) acc = acc + xv * yv;
     else { const float diff = xv - yv; acc = acc + diff * diff; }
   }
-  float tot = 0.0f;
+  // ((0 + a0) + a1) + ... + a15: a running sum handed down the 16-lane DPP row (row_shr:1, lane 0 receives +0.0); after step j
+  // lanes 0..j hold their prefix and recomputing a settled lane changes nothing, so lane 15 ends with the reference's total
+  float run = 0.0f + acc;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) tot = tot + __shfl(acc, (lane & 48) + t, 64);     // ((0 + a0) + a1) + ... + a15
+  for (int t = 1; t < 16; ++t) {
+    const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, run), 0x111, 0xF, 0xF, false));
+    run = prev + acc;
+  }
+  const float tot = __shfl(run, (lane & 48) + 15, 64);     // every lane of the group gets the total
   return finish_metric<METRIC>(s + tot);
 }
 
@@ -1002,7 +1008,7 @@ int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_
   uint32_t *maxbits = ctx->scratch_t<uint32_t>("cq.maxbits", 4);   // [0] max |c|^2, [1] unused (no bias), [2] rows answered by the exact path
   float *e2 = ctx->scratch_t<float>("cq.e2", (size_t)nq);
   if (!chi || !clo || !cn || !maxbits || !e2) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(maxbits, 0, 16, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(maxbits, 0, 16, ctx->stream));
   {
     ScopedTimer t(ctx, "dist_matrix");
     hipLaunchKernelGGL(ma_prep_kernel, dim3(nlist), dim3(64), 0, ctx->stream, cent, (int)nlist, d, dp, nullptr, chi, clo, cn, maxbits, nullptr);

@@ -311,7 +311,7 @@ int launch_pq_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int batches
   a.fb_cnt = ctx->scratch_t<uint32_t>("pqm.fb_cnt", (size_t)batches);
   a.fb_items = ctx->scratch_t<uint32_t>("pqm.fb_items", (size_t)p.n * batches);
   if (!a.fb_cnt || !a.fb_items) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(a.fb_cnt, 0, (size_t)batches * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(a.fb_cnt, 0, (size_t)batches * 4, ctx->stream));
   const dim3 grid((unsigned)cdiv((uint64_t)p.n, PQM_WG_ROWS), (unsigned)batches);
   // fix kernel: grid (blocks, batches); a workgroup whose first wave has no item returns before staging the codebook
   const dim3 fix_grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)p.n, 256)), 64), (unsigned)batches);
@@ -381,7 +381,7 @@ int launch_pq_mfma_encode(lance_hip_ctx *ctx, int dtype, const void *x, int64_t 
     a.xn = static_cast<const char *>(x) + (size_t)r0 * d * es;
     a.rcent = residual ? cent : nullptr; a.rpart = part_ids ? part_ids + r0 : nullptr; a.round_f16 = dtype == LANCE_HIP_F16 ? 1 : 0;
     a.batches = m; a.fb_cnt = fb_cnt; a.fb_items = fb_items;
-    LH_CHECK_HIP(hipMemsetAsync(fb_cnt, 0, (size_t)m * 4, ctx->stream));
+    LH_CHECK_HIP(lh::memset_async(fb_cnt, 0, (size_t)m * 4, ctx->stream));
     const dim3 grid((unsigned)cdiv((uint64_t)rows, PQM_WG_ROWS), (unsigned)m);
     const dim3 fix_grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)rows, 256)), 64), (unsigned)m);
     if (sd == 4) launch_pqm_encode_sd<4>(ctx, dtype, a, grid, fix_grid);

@@ -216,7 +216,19 @@ struct ScanArgs {
   int round_f16;      // index element type is f16: the residual query is an f16 subtraction (v2.rs:326)
   int ablate;         // perf experiments only (LANCE_HIP_ABLATE): 1 = LUT once per query, 2 = no candidate appends, 4 = skip scan
   const uint32_t *allow;   // prefilter bitmap over storage positions or NULL
+  int lanes32 = 0;         // f16 column under dot with sub-vectors of more than 16 elements: 32-lane table entries (lut_entry_rt)
 };
+
+// one LUT entry at a run-time sub-dimension.  lanes32: an f16 column under dot -- the table entries are dot products of f16
+// sub-vectors, dot_scalar::<f16, f32, 32> (dot.rs:91-102,138-161): 32 lane accumulators, which differs from the 16-lane form once
+// a sub-vector has more than 16 elements
+template <int METRIC>
+__device__ __forceinline__ float lut_entry_rt(const float *__restrict__ r, const float *__restrict__ cw, int sd, int lanes32) {
+  if constexpr (METRIC == METRIC_DOT) {
+    if (lanes32) return finish_metric<METRIC>(dist_exact_rt<METRIC, float, 32>(r, cw, sd));
+  }
+  return finish_metric<METRIC>(dist_exact_rt<METRIC>(r, cw, sd));
+}
 
 struct ScanShared {
   float *r;
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
       } else {
         for (int idx = threadIdx.x; idx < m * 256; idx += 256) {
           const int mm = idx >> 8;
-          s.lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&s.r[mm * sd], p.codebook + (int64_t)idx * sd, sd));
+          s.lut[idx] = lut_entry_rt<METRIC>(&s.r[mm * sd], p.codebook + (int64_t)idx * sd, sd, p.lanes32);
         }
       }
     }
@@ -539,7 +551,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan4_kernel(ScanArgs p) {
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < m * 16; idx += 256)
-      s.lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&s.r[(idx >> 4) * sd], p.codebook + (int64_t)idx * sd, sd));
+      s.lut[idx] = lut_entry_rt<METRIC>(&s.r[(idx >> 4) * sd], p.codebook + (int64_t)idx * sd, sd, p.lanes32);
     __syncthreads();
     const uint8_t *pcodes = p.codes + (int64_t)off * mb;
     if (!p.allow) pq4_prelude<METRIC, 256>(s.lut, m, pcodes, np, p.keff, q4);   // uniform branch
@@ -837,7 +849,7 @@ __global__ __launch_bounds__(64) void ivfpq_exact_kernel(ExactArgs a) {
     }
     __syncthreads();
     for (int idx = lane; idx < m * KC; idx += 64)
-      lut[idx] = finish_metric<METRIC>(dist_exact_rt<METRIC>(&r[(idx / KC) * sd], p.codebook + (int64_t)idx * sd, sd));
+      lut[idx] = lut_entry_rt<METRIC>(&r[(idx / KC) * sd], p.codebook + (int64_t)idx * sd, sd, p.lanes32);
     if (lane == 0) s_hlen = 0;
     __syncthreads();
     const uint8_t *pcodes = p.codes + (int64_t)off * (NBITS == 4 ? m / 2 : m);
@@ -1046,7 +1058,7 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
 
   uint32_t *flags = ctx->scratch_t<uint32_t>("search.flags", (size_t)nq + 1);
   if (!flags) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)nq + 1) * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(flags, 0, ((size_t)nq + 1) * 4, ctx->stream));
   uint32_t *n_fallback = flags + nq;
   ctx->last_replay_counter = n_fallback;
   if (flags_out) *flags_out = flags;
@@ -1109,6 +1121,7 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
     a.nbits = (int)ix->nbits;
     a.residual = scan_metric == LANCE_HIP_L2 ? 1 : 0;
     a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
+    a.lanes32 = (ix->dtype == LANCE_HIP_F16 && scan_metric == LANCE_HIP_DOT && sd > 16) ? 1 : 0;
     a.has_range = has_range;
     a.allow = allow;
     a.lo_key = 0; a.hi_key = 0xFFFFFFFFu;
@@ -1388,7 +1401,6 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
   lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && q_residual && codebook && out_ids && out_dists, "pq_scan_topk: NULL argument");
   LH_TRY(check_dtype(dtype, "pq_scan_topk"));
-  LH_REQUIRE(!(dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && m != 0 && d / m > 16), "pq_scan_topk: f16 dot with sub-vectors longer than 16 is not supported");
   LH_REQUIRE(n_p == 0 || (codes_transposed && row_ids), "pq_scan_topk: NULL codes");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   // a single-partition index whose centroid is 0: q_residual - 0 == q_residual exactly

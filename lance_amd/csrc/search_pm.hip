@@ -631,8 +631,8 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
       !desc4 || !tglobal || !seg_cnt || !seg_pos || !pool_key || !pool_pos)
     return LANCE_HIP_ENOMEM;
   uint32_t *pool_cnt = tglobal + nq, *tbound = tglobal + 2 * (size_t)nq, *qovf = tglobal + 3 * (size_t)nq;
-  LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
-  LH_CHECK_HIP(hipMemsetAsync(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
   PmArgs a;
   a.q = qs; a.probes = probes;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
@@ -734,8 +734,8 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * pool_cap);
   if (!pair_starts || !pair_idx || !item_start || !tglobal || !pool_key || !pool_pos) return LANCE_HIP_ENOMEM;
   uint32_t *pool_cnt = tglobal + nq;
-  LH_CHECK_HIP(hipMemsetAsync(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
-  LH_CHECK_HIP(hipMemsetAsync(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
   uint32_t *keys = ctx->scratch_t<uint32_t>("pm.keys", npairs);
   const uint32_t max_items = (uint32_t)(npairs / 2 + 2 * nlist + 2);   // >= sum over virtual partitions of ceil(c / 2)
   int4 *desc = ctx->scratch_t<int4>("pm.desc", max_items);
@@ -761,7 +761,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   static const bool pm_prof = getenv("LANCE_HIP_PM_PROF") != nullptr;
   if (pm_prof) {
     a.prof = ctx->scratch_t<unsigned long long>("pm.prof", 8);
-    if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
+    if (a.prof) (void)lh::memset_async(a.prof, 0, 64, ctx->stream);
   }
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   const size_t lds_base = pm_lds_base(d, m);
@@ -795,7 +795,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
         (void)hipStreamSynchronize(ctx->stream);
         if (h[5]) fprintf(stderr, "[pm prof] items=%llu clocks/item: desc %.0f | q,centroid,residual %.0f | LUT %.0f | scan %.0f | publish %.0f\n", h[5],
                           (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
-        (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
+        (void)lh::memset_async(a.prof, 0, 64, ctx->stream);
       }
     }
   }

@@ -843,8 +843,8 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
     else
     hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4,
                        ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
-    LH_CHECK_HIP(hipMemsetAsync(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
-    LH_CHECK_HIP(hipMemsetAsync(qovf, 0, (size_t)nq * 4, ctx->stream));
+    LH_CHECK_HIP(lh::memset_async(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
+    LH_CHECK_HIP(lh::memset_async(qovf, 0, (size_t)nq * 4, ctx->stream));
   }
   ScopedTimer t(ctx, "ivfpq_scan_c1");
   QscanArgs a;
@@ -855,7 +855,7 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);   // the merge launcher asks for the same slot
   a.ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)nq * nprobes + 1);                // likewise (and the class-B conversion)
   if (!a.seg_sum || !a.ovf) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(hipMemsetAsync(a.ovf, 0, 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(a.ovf, 0, 4, ctx->stream));
   const size_t lds = qscan_lds_bytes(d, m);
   const unsigned grid = max_items4;   // one workgroup per item (persistent workgroups looping over items measured no faster)
   bool ok = false;
@@ -863,7 +863,7 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   static const bool qt_prof = getenv("LANCE_HIP_QT_PROF") != nullptr;
   if (qt_prof && qscan_tiled_shape(m, sd)) {
     a.prof = ctx->scratch_t<unsigned long long>("qt.prof", 8);
-    if (a.prof) (void)hipMemsetAsync(a.prof, 0, 64, ctx->stream);
+    if (a.prof) (void)lh::memset_async(a.prof, 0, 64, ctx->stream);
   }
 #endif
   if (pt) { LH_TRY(qscan_pt_launch(ctx, ix, a, qs, nq, probes, grid)); ok = true; }
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void q_model_finite_kernel(const float *__rest
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {
   const int d = (int)ix->d, m = (int)ix->m;
   if (!ix->cb_mean) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_mean), (size_t)(d + 2) * 4));
-  LH_CHECK_HIP(hipMemsetAsync(ix->cb_mean, 0, (size_t)(d + 2) * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_async(ix->cb_mean, 0, (size_t)(d + 2) * 4, ctx->stream));
   hipLaunchKernelGGL(q_codebook_mean_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ix->codebook, d / m, d, ix->cb_mean);
   const int64_t nc = (int64_t)ix->nlist * d, ncb = (int64_t)m * 256 * (d / m);
   hipLaunchKernelGGL(q_model_finite_kernel, dim3((unsigned)cdiv((uint64_t)(nc + ncb), 256)), dim3(256), 0, ctx->stream, ix->centroids, nc, ix->codebook,

@@ -59,9 +59,9 @@ def _cases():
     q[6] = np.inf
     q[8] = 1e30                                    # squares overflow: inf distances
     # dot: inf x 0 is a NaN whose SIGN is the platform's (x86: the negative "real indefinite", which total_cmp sorts first; gfx950:
-    # the positive default NaN, sorted last) -- the reference itself answers differently on x86 and ARM there, so the infinite
-    # query stays an L2 case
-    qd = q.copy(); qd[6] = q[7]
+    # the positive default NaN, sorted last), and 1 - NaN keeps the NaN's sign on x86 while the GPU's subtract-as-negated-add may
+    # flip it -- the reference itself answers differently on x86 and ARM there, so the NaN / infinite queries stay L2 cases
+    qd = q.copy(); qd[6] = q[7]; qd[5] = q[4]
     for nprobes in (1, 10, 50, 64):
         _eq(eng, oracle, q, cent, nprobes, "l2", ("ties", nprobes)); n_cases += 1
         _eq(eng, oracle, qd, cent, nprobes, "dot", ("ties-dot", nprobes)); n_cases += 1

@@ -70,3 +70,19 @@ def test_row_ids_nan_rows_and_mass_duplicates(eng, oracle):
     _check(eng, oracle, x, q2, 128, "l2", row_ids=rid, tag="mass duplicates, row ids")
     # fewer rows than k in the table's tail slices, and k larger than the table's distinct distances
     _check(eng, oracle, x[:4100], q, 128, "l2", tag="short table")
+
+
+def test_two_to_four_queries_on_the_single_pass_kernel():
+    """By default only single queries take flat_small.hip (the batch path is faster from two queries on); LANCE_HIP_FLAT_SMALL_MAXQ=4
+    (read once per process) sends two to four there as well: the cases above again in a child process with the switch set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("LANCE_HIP_FLAT_SMALL_MAXQ"):
+        pytest.skip("already inside the child run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "small_batches or native or row_ids"], cwd=root, env=dict(os.environ, LANCE_HIP_FLAT_SMALL_MAXQ="4"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
