@@ -280,6 +280,15 @@ def main():
         for e in engines:
             e.synchronize()
 
+    # Untimed priming: a search is captured into a HIP graph on its second call with the same arguments (context, query batch,
+    # output buffers) and replayed from the third -- every (context, batch) pair of the cycle below is taken through that once, so
+    # that the warm-up and the timed region measure the steady state a serving loop runs in (LANCE_HIP_GRAPH=0: no capture, no priming)
+    graph_priming = 0
+    if os.environ.get("LANCE_HIP_GRAPH", "1") != "0" and os.environ.get("LANCE_BENCH_PMC_CHILD") != "1":
+        graph_priming = 2 * 4 * nstreams
+        for i in range(graph_priming):
+            step(i)
+        sync_all()
     for i in range(max(args.warmup, nstreams)):
         step(i)
     sync_all()
@@ -456,6 +465,7 @@ def main():
         "recall_at_10": recall,
         "exact_replays_last_step": exact_replays,
         "streams": nstreams,
+        "graph_priming_calls": graph_priming,
         "host_buffers_qps_pcie_inclusive": pcie_qps,
         "build_sec": build_sec,
         # N > 1: the two numbers that say something about scaling (the replica `value` is linear by construction): the SAME

@@ -976,8 +976,8 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
 
 // A batch is ~25 small launches (coarse quantiser, two groupings, bound pass, residuals, filter scan, rescan, merge, exact
 // replay, refine) and a handful of memsets: at C3 a third of a 1000-query batch's wall time was the gaps between them
-// (profiles/r03_c3_search_breakdown.json).  LANCE_HIP_GRAPH=1: the second call with the same arguments (index, buffers,
-// shape) is captured into a HIP graph, later ones replay it with one hipGraphLaunch.  The first call always runs uncaptured: it
+// (profiles/r03_c3_search_breakdown.json).  The second call with the same arguments (index, buffers, shape) is captured into
+// a HIP graph, later ones replay it with one hipGraphLaunch (LANCE_HIP_GRAPH=0 keeps every call on the plain path).  The first call always runs uncaptured: it
 // sizes the scratch arena (growth would need hipMalloc + a stream sync, neither of which a capture allows) and builds the
 // index's lazy constants.  Timing runs (HIP events per kernel) and the diagnostic switches that synchronise mid-pipeline stay
 // on the plain path.
@@ -985,8 +985,8 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
                          uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
                          uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow) {
   static const bool on = [] {
-    const char *e = getenv("LANCE_HIP_GRAPH");
-    return e && e[0] == '1' && !getenv("LANCE_HIP_Q_STATS") && !getenv("LANCE_HIP_PM_PROF") && !getenv("LANCE_HIP_QT_PROF");
+    const char *e = getenv("LANCE_HIP_GRAPH");     // default on (r04d: +8 % on the C2 bench line); "0" switches it off
+    return !(e && e[0] == '0') && !getenv("LANCE_HIP_Q_STATS") && !getenv("LANCE_HIP_PM_PROF") && !getenv("LANCE_HIP_QT_PROF");
   }();
   if (!on || ctx->timing || nq == 0)
     return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);

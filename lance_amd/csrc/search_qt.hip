@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256) void q_pt_kappa_kernel(const float *__restrict
   const int64_t q = pr / nprobes;
   const float *ct = cen_t + (int64_t)probes[pr] * d, *qv = qs + q * d;
   double acc = 0.0, qn2 = 0.0;
+#pragma unroll 4
   for (int dim = lane; dim < d; dim += 64) {
     const float v = qv[dim] - g[dim];          // q~ (the same f32 subtraction as the table kernel's)
     const double c = (double)ct[dim];
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void q_pt_table_kernel(const float *__restrict
   const float s = sq[q];
   if (!(s > 0.0f)) return;   // uniform
   const int m0 = blockIdx.y * mper, m1 = min(m, m0 + mper);
-#pragma unroll 2
+#pragma unroll 4
   for (int mm = m0; mm < m1; ++mm) {
     const float *qv = qs + (int64_t)q * d + mm * SD, *gv = g + mm * SD;
     const float *cw = codebook + ((int64_t)mm * 256 + c) * SD;
@@ -728,8 +729,9 @@ int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const Qscan
                      npairs, nprobes, d, kap, qn2);
   hipLaunchKernelGGL(q_pt_scale_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, ix->pt->beta_min, ix->pt->beta_abs, probes, a.tbound,
                      (int)nq, nprobes, sd + m, kap, qn2, sq, pslack);
-  // enough slices of the sub-quantisers to put about four workgroups on every CU
-  int msplit = (int)std::min<uint64_t>((uint64_t)m, std::max<uint64_t>(1, cdiv((uint64_t)4 * ctx->num_cus, nq)));
+  ScopedTimer ttab(ctx, "q_pt_table_only");
+  // enough slices of the sub-quantisers to put about sixteen workgroups on every CU (the kernel is a chain of L2 round trips)
+  int msplit = (int)std::min<uint64_t>((uint64_t)m, std::max<uint64_t>(1, cdiv((uint64_t)16 * ctx->num_cus, nq)));
   const int mper = (int)cdiv((uint64_t)m, (uint64_t)msplit);
   msplit = (int)cdiv((uint64_t)m, (uint64_t)mper);
   const dim3 tgrid(nq, (unsigned)msplit);

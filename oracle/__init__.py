@@ -291,15 +291,16 @@ def pq_train(resid, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
 
 
 def pq_encode(x, codebook, metric="l2", nbits=8):
+    metric = _mh(metric, _is_f16(x))       # Float16 sub-vectors under dot: dot_scalar::<f16, f32, 32> (pq.rs:143,165 -> dot.rs:91-102)
     x = _f32(x); codebook = _f32(codebook)
     n, d = x.shape
     m = codebook.shape[0]
     if nbits == 4:
         codes = np.empty((n, m // 2), np.uint8)
-        lib().orc_pq_encode4_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(codebook), C.c_size_t(m), _p(codes))
+        lib().orc_pq_encode4_f32(C.c_int(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(codebook), C.c_size_t(m), _p(codes))
         return codes
     codes = np.empty((n, m), np.uint8)
-    lib().orc_pq_encode_f32(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(codebook), C.c_size_t(m),
+    lib().orc_pq_encode_f32(C.c_int(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(codebook), C.c_size_t(m),
                             C.c_uint32(nbits), _p(codes))
     return codes
 

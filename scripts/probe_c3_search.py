@@ -20,7 +20,7 @@ x = torch.nn.functional.normalize(sift_like(n, d, seed=77, device=dev, n_cluster
 q = torch.nn.functional.normalize(sift_like(1000, d, seed=78, device=dev, n_clusters=1024, latent=48, model_seed=77) - 64.0, dim=1).contiguous()
 idx = lance_amd.create_index(x, "IVF_PQ", metric="cosine", num_partitions=nlist, num_sub_vectors=m)
 torch.cuda.synchronize()
-names = ("dist_matrix", "select_probes", "pm_group", "ivfpq_scan", "ivfpq_scan_c0", "q_residual", "ivfpq_scan_c1", "q_pt_tables", "ivfpq_scan_cb",
+names = ("dist_matrix", "select_probes", "pm_group", "ivfpq_scan", "ivfpq_scan_c0", "q_residual", "ivfpq_scan_c1", "q_pt_tables", "q_pt_table_only", "ivfpq_scan_cb",
          "ivfpq_merge", "ivfpq_exact", "refine")
 out = {"n": n, "build_stages_ms": {k: round(v * 1e3, 2) for k, v in idx.stats.seconds.items()}}
 CFGS = ((10, 0), (10, 10), (50, 10))

@@ -65,8 +65,10 @@ def _cases():
     for nprobes in (1, 10, 50, 64):
         _eq(eng, oracle, q, cent, nprobes, "l2", ("ties", nprobes)); n_cases += 1
         _eq(eng, oracle, qd, cent, nprobes, "dot", ("ties-dot", nprobes)); n_cases += 1
-    cent2 = cent.copy(); cent2[11, 0] = np.nan
-    _eq(eng, oracle, q, cent2, 10, "l2", "nan-centroid"); n_cases += 1
+    # a non-finite centroid: every surrogate row carries a NaN (inf - inf in the bf16 split) -> every query takes the exact path.
+    # (+inf, not NaN: x - NaN keeps the NaN's sign on x86 while the GPU's subtract may flip it, and total_cmp sorts -NaN first)
+    cent2 = cent.copy(); cent2[11, 0] = np.inf
+    _eq(eng, oracle, q, cent2, 10, "l2", "inf-centroid"); n_cases += 1
     eng.close()
     print(f"coarse mfma cases ok: {n_cases}")
 

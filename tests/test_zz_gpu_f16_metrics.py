@@ -138,3 +138,32 @@ def test_f16_python_api(eng, oracle, metric):
         oi, od = oidx.search(q, 10, nprobes, refine=rf or 0, raw=x.astype(f32) if rf else None)
         assert (gi.view(np.uint64) == oi).all(), (metric, nprobes, rf)
         assert (gd.view(np.uint32) == od.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("d,m", [(96, 4), (128, 4), (80, 2)])
+def test_f16_dot_index_with_sub_vectors_longer_than_16(eng, oracle, d, m):
+    """Round 4: an f16 dot index whose PQ sub-vectors have more than 16 elements (24 / 32 / 40 here).  The table entries are
+    dot_scalar::<f16, f32, 32> products (dot.rs:91-102,138-161) -- a different addition order from the 16-lane form beyond 16
+    elements -- built by the query-major kernels' run-time-dimension table code (search.hip: lut_entry_rt); lance_hip_pq_encode
+    under dot takes the 32-lane argmin as well."""
+    from lance_amd.engine import DeviceIndex
+    n, nlist = 12000, 16
+    x = f16_data(n, d, 71 + d)
+    q = f16_data(120, d, 72 + d)
+    cent, _, _, _ = oracle.kmeans_train(x[:4096], nlist, max_iters=6, seed=1, metric="dot")
+    cb, _ = oracle.pq_train(x[:4096], m, max_iters=5, seed=2)
+    oidx = oracle.build_index(x, cent, cb, "dot")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "dot")
+    assert (_np(gpart).view(np.uint32) == oidx.part_ids).all()
+    assert (_np(gcodes) == oidx.codes_rowmajor).all()
+    gidx = DeviceIndex.create(eng, "dot", cent, cb, gpart, gcodes, None, raw=x)
+    xf = x.astype(f32)
+    for nq, k, nprobes, rf in ((120, 10, nlist, 0), (120, 10, 4, 0), (120, 5, 4, 8)):
+        gi, gd = gidx.search(q[:nq], k, nprobes, rf)
+        oi, od = oidx.search(q[:nq], k, nprobes, refine=rf, raw=xf)
+        assert (_np(gi).view(np.uint64) == oi).all(), (d, m, nq, k, nprobes, rf)
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all(), (d, m, nq, k, nprobes, rf)
+    # the stand-alone encoder under dot: nearest codeword by dot distance of f16 sub-vectors
+    gc = eng.pq_encode(x[:3000], cb, "dot")
+    oc = oracle.pq_encode(x[:3000], cb, "dot")
+    assert (_np(gc) == oc).all()

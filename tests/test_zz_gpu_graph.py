@@ -1,5 +1,5 @@
-"""LANCE_HIP_GRAPH=1 (search.hip: ivfpq_search_enqueue): the second call with the same arguments is captured into a HIP graph and
-later ones replay it.  A replay must give what the plain path gives -- the oracle's answer, bit for bit -- also after another
+"""Captured searches (search.hip: ivfpq_search_enqueue; on by default, LANCE_HIP_GRAPH=0 switches it off): the second call with
+the same arguments is captured into a HIP graph and later ones replay it.  A replay must give what the plain path gives -- the oracle's answer, bit for bit -- also after another
 call has grown the scratch arena (which drops every captured graph), through a second context, and with the per-query-table
 filter on.  The switch is read once per process: the cases run in a child process."""
 import os
