@@ -121,7 +121,8 @@ int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16);   // f16: half-precision arithmetic on f32 containers
 
 // quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
-int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix);   // search_q.hip: lance_hip_index::cb_mean (8-bit PQ)
+int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix);
+bool qscan_mfma_table(const lance_hip_index *ix);   // search_q.hip: the filter scan builds its table on the matrix cores (sub-dimension 8)   // search_q.hip: lance_hip_index::cb_mean (8-bit PQ)
 constexpr int QSCAN_SEG_CAP = 256;   // survivors kept per (query, probe)
 struct SelectOut;
 bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);

@@ -18,6 +18,7 @@ constexpr int Q_G = 4;         // queries per work item (4 x u16 = one ds_read_b
 #define LH_Q_WAVES 8
 #endif
 constexpr int Q_WAVES = LH_Q_WAVES;   // launch-bounds hint for M = 16, sub-dimension <= 8: waves per SIMD (8 = FOUR 512-lane workgroups per CU, <= 64 VGPRs: fits without spills once the table build is not unrolled -- main pass 0.52 -> 0.42 ms; with the build unrolled by 2 it spilled and lost 25 %)
+constexpr float Q_MB_SLACK_CAP = 16.0f;   // MFMA table build: largest per-query slack (units) the filter takes; beyond it the pair is rescanned exactly
 constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); more -> that partition is rescanned exactly for the query
 #ifndef LH_Q_LUT_UNROLL
 #define LH_Q_LUT_UNROLL 1
@@ -52,6 +53,9 @@ struct QscanArgs {
   uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
   uint32_t *ovf;                // [1 + nq * nprobes] count (zeroed before the launch) + the overflowed segments: the rescan kernel's work list
   const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
+  // MFMA table build (search_q.hip, sub-dimension 8): bf16 hi / lo planes of the codebook [m][256][8] and the codewords' squared norms
+  const uint16_t *cb_hi = nullptr, *cb_lo = nullptr;
+  const float *cb_n2 = nullptr;
   unsigned long long *prof = nullptr;   // -DLH_QT_PROF builds only (tiled kernel): [0] build clocks [1] scan [2] emit [3] items
 };
 

@@ -133,10 +133,30 @@ __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict
   }
 }
 
-template <int SD, int MU>
+// MB = true (sub-dimension 8): the table is built on the MATRIX CORES.  (c + nr)^2 = |c|^2 + 2 c.nr + |nr|^2 per sub-quantiser; the
+// 256 x 4 dot products of one sub-quantiser against the four queries' (negated) residuals are an [256 x 8] x [8 x 4] product, and four
+// sub-quantisers fill one v_mfma_f32_16x16x32_bf16: A = 16 rows (sub-quantiser m', query j) x K = 32 (4 sub-quantisers x 8
+// dimensions, block diagonal: row (m', j) is non-zero only in k-group m'), B = K x 16 codewords (k-group g = codeword c of
+// sub-quantiser g), so D[(m', j)][c] puts, in lane l, the four queries' dot products of codeword (l & 15) of sub-quantiser (l >> 4)
+// -- exactly one uint2 table entry.  bf16 hi / lo split of both operands, three MFMAs (hi.hi + lo.hi + hi.lo): |error| <= 2^-14
+// |c||nr| per dot product, i.e. at most 2^-13.9 (|c|^2 + |nr|^2) per entry with the f32 rounding of the norms; summed over a
+// row's entries and scaled: delta_j = 2^-13.9 s_j (3 |r_j|^2 + 2 T_j) units for every row that can pass (|c_row| <= |r| + sqrt(T)).
+// The per-query limit carries ceil(delta_j); a pair whose delta exceeds Q_MB_SLACK_CAP is handed to the exact rescan.  The table is
+// a bound, not a result: survivors are re-evaluated in the reference's arithmetic by the merge kernel as before.  VALU per table
+// entry (4 queries): ~12 (norm adds, 2 x pk_fma, quantisation) instead of 44.
+typedef short q_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float q_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t q_bf16_rne(float x) {
+  const uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int SD, int MU, bool MB = false>
 __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
+  static_assert(!MB || SD == 8, "the MFMA table build is written for sub-dimension 8");
   constexpr uint32_t CAPE = 65535u / M;        // largest entry: M of them cannot overflow a u16 field
   constexpr uint32_t SE = CAPE - CAPE / 32;     // the bound T maps to SE; ~3 % head-room below CAPE
   constexpr uint32_t LIM = SE + M + 2;          // one unit per entry for the conversion's rounding; +2 covers the f32 rounding terms (see header)
@@ -147,6 +167,8 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
   uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
   float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T / 65535 (1e30: no such query in this item)
   uint16_t *csum = reinterpret_cast<uint16_t *>(sc + 4);              // [4][Q_CAP] the survivors' integer sums
+  __shared__ float mb_r2[Q_G];          // MB: |r_j|^2 of the item's four queries
+  __shared__ uint32_t mb_lim[Q_G];      // MB: per-query limit (0: the pair goes to the exact rescan)
 
   // one item per workgroup and no loop: nothing is stored to global memory before the residual loads, so the compiler may
   // (and does) turn them into scalar loads
@@ -176,6 +198,72 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
     }
     __syncthreads();
     const f4 *rq4 = p.rq + (int64_t)item * p.d;
+    uint32_t lim4[Q_G] = {LIM, LIM, LIM, LIM};
+    if constexpr (MB) {
+      // |r_j|^2 -> the per-query slack of the surrogate table (header)
+      if (threadIdx.x < Q_G) mb_r2[threadIdx.x] = 0.0f;
+      __syncthreads();
+      if ((int)threadIdx.x < p.d) {
+        const f4 v = rq4[threadIdx.x];
+        f4 sq = v * v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sq.x += __shfl_xor(sq.x, o, 64); sq.y += __shfl_xor(sq.y, o, 64); sq.z += __shfl_xor(sq.z, o, 64); sq.w += __shfl_xor(sq.w, o, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&mb_r2[0], sq.x); atomicAdd(&mb_r2[1], sq.y); atomicAdd(&mb_r2[2], sq.z); atomicAdd(&mb_r2[3], sq.w); }
+      }
+      __syncthreads();
+      if (threadIdx.x < Q_G) {
+        uint32_t lim = LIM;
+        if ((int)threadIdx.x < cnt) {
+          const float T = key_to_float(p.tbound[qj[threadIdx.x]]);
+          const float sj = fminf((float)SE / T, 1e30f);
+          const float delta = 6.5e-5f * sj * (3.0f * mb_r2[threadIdx.x] + 2.0f * T) * 1.01f;     // 2^-13.9 = 6.5e-5
+          lim = (delta <= Q_MB_SLACK_CAP) ? LIM + (uint32_t)ceilf(delta) : 0u;                    // NaN delta -> 0: rescan
+        }
+        mb_lim[threadIdx.x] = lim;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < Q_G; ++j) lim4[j] = mb_lim[j];
+      // ---- table on the matrix cores: wave w owns one quad of sub-quantisers and TPW blocks of 16 codewords
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      constexpr int TPW = M / 2;                        // (M / 4 quads) x 16 codeword blocks / 8 waves
+      const int quad = (wave * TPW) >> 4, cb0 = (wave * TPW) & 15;
+      const int g = lane >> 4, r = lane & 15, mrow = r >> 2, jrow = r & 3;
+      q_bf16x8 ah, al;
+      {
+        const int mm = quad * 4 + mrow;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const f4 rv = rq4[mm * 8 + u];
+          const float v = g == mrow ? rv[jrow] : 0.0f;
+          const uint32_t hb = q_bf16_rne(v);
+          ah[u] = (short)hb;
+          al[u] = (short)q_bf16_rne(v - __uint_as_float(hb << 16));
+        }
+      }
+      const int mE = quad * 4 + g;                      // this lane's sub-quantiser in every tile's result
+      f4 rn2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const f4 rv = rq4[mE * 8 + u]; rn2 += rv * rv; }
+      const f4 s4 = *reinterpret_cast<const f4 *>(sc);
+      const f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
+      const f2 two = {2.0f, 2.0f};
+#pragma unroll 2
+      for (int i = 0; i < TPW; ++i) {
+        const int c = (cb0 + i) * 16 + r;
+        const int64_t e = (int64_t)mE * 256 + c;
+        const q_bf16x8 bh = *reinterpret_cast<const q_bf16x8 *>(p.cb_hi + e * 8);
+        const q_bf16x8 bl = *reinterpret_cast<const q_bf16x8 *>(p.cb_lo + e * 8);
+        const float cn = p.cb_n2[e];
+        q_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+        const f2 l01 = __builtin_elementwise_fma(two, f2{acc[0], acc[1]}, f2{cn + rn2.x, cn + rn2.y});
+        const f2 l23 = __builtin_elementwise_fma(two, f2{acc[2], acc[3]}, f2{cn + rn2.z, cn + rn2.w});
+        lutq[mE * 256 + c] = q_entry_quantise<CAPE>(l01, l23, s01, s23);
+      }
+    } else {
     // quantised LUT: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half * M/2, (half+1) * M/2).  A bound, not a
     // result (q_entry_acc / q_entry_quantise above).
     {
@@ -190,6 +278,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
         q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
         lutq[mm * 256 + c] = q_entry_quantise<CAPE>(acc01, acc23, s01, s23);
       }
+    }
     }
     __syncthreads();
     // scan: no barrier inside; survivors go to the per-query LDS lists
@@ -222,7 +311,9 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
                 a0 += v.x; a1 += v.y;
               }
           }
-          const bool p0 = (a0 & 0xFFFFu) <= LIM, p1 = (a0 >> 16) <= LIM, p2 = (a1 & 0xFFFFu) <= LIM, p3 = (a1 >> 16) <= LIM;
+          // (MB: a limit of 0 = the pair is rescanned exactly -- nothing of it passes here unless its sum is 0, which the final
+          // count below overrides)
+          const bool p0 = (a0 & 0xFFFFu) <= lim4[0], p1 = (a0 >> 16) <= lim4[1], p2 = (a1 & 0xFFFFu) <= lim4[2], p3 = (a1 >> 16) <= lim4[3];
           if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
             const uint32_t pos = off + (uint32_t)row;
             if (p0) { const uint32_t slot = atomicAdd(&misc[0], 1u); if (slot < (uint32_t)Q_CAP) { cand[0 * Q_CAP + slot] = pos; csum[0 * Q_CAP + slot] = (uint16_t)(a0 & 0xFFFFu); } }
@@ -237,8 +328,9 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
 #pragma unroll
     for (int j = 0; j < Q_G; ++j) {
       if (j < cnt) {
-        const uint32_t raw = misc[j];
-        const uint32_t n = min(raw, (uint32_t)Q_CAP);
+        uint32_t raw = misc[j];
+        if constexpr (MB) { if (lim4[j] == 0u) raw = 0xFFFFFFFFu; }   // slack over the cap: the rescan kernel does this pair exactly
+        const uint32_t n = raw > (uint32_t)Q_CAP ? (MB && lim4[j] == 0u ? 0u : (uint32_t)Q_CAP) : raw;
         const int64_t seg = (int64_t)qj[j] * p.nprobes + rk[j];
         if (threadIdx.x == 0) {
           p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
@@ -820,6 +912,12 @@ int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, 
 
 template <int SD>
 static bool launch_qscan_sd(lance_hip_ctx *ctx, const QscanArgs &a, int m, unsigned grid, size_t lds) {
+  if constexpr (SD == 8) {
+    if (a.cb_hi) {      // the table on the matrix cores (qscan_mfma_table)
+      if (m == 16) { hipLaunchKernelGGL((ivfpq_qscan_kernel<8, 1, true>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
+      if (m == 32) { hipLaunchKernelGGL((ivfpq_qscan_kernel<8, 2, true>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
+    }
+  }
   if (m == 16) { hipLaunchKernelGGL((ivfpq_qscan_kernel<SD, 1>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
   if (m == 32) { hipLaunchKernelGGL((ivfpq_qscan_kernel<SD, 2>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
   return false;
@@ -852,6 +950,7 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
+  if (!pt && !q8 && qscan_mfma_table(ix)) { a.cb_hi = ix->cb_hi; a.cb_lo = ix->cb_lo; a.cb_n2 = ix->cb_n2; }
   a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);   // the merge launcher asks for the same slot
   a.ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)nq * nprobes + 1);                // likewise (and the class-B conversion)
   if (!a.seg_sum || !a.ovf) return LANCE_HIP_ENOMEM;
@@ -921,8 +1020,38 @@ __global__ __launch_bounds__(256) void q_model_finite_kernel(const float *__rest
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// MFMA table build (sub-dimension 8): bf16 hi / lo planes of the codebook and the codewords' squared norms
+__global__ __launch_bounds__(256) void q_codebook_planes_kernel(const float *__restrict__ codebook, int64_t nwords, uint16_t *__restrict__ hi,
+                                                                uint16_t *__restrict__ lo, float *__restrict__ n2) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;      // codeword (m, c)
+  if (w >= nwords) return;
+  float s = 0.0f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const float v = codebook[w * 8 + u];
+    const uint32_t hb = q_bf16_rne(v);
+    hi[w * 8 + u] = (uint16_t)hb;
+    lo[w * 8 + u] = (uint16_t)q_bf16_rne(v - __uint_as_float(hb << 16));
+    s += v * v;
+  }
+  n2[w] = s;
+}
+
+bool qscan_mfma_table(const lance_hip_index *ix) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA_TABLE") != nullptr;
+  return !off && ix->cb_hi != nullptr && ix->m != 0 && ix->d / ix->m == 8 && (ix->m == 16 || ix->m == 32);
+}
+
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {
   const int d = (int)ix->d, m = (int)ix->m;
+  if (d / m == 8 && (m == 16 || m == 32)) {
+    const int64_t nwords = (int64_t)m * 256;
+    if (!ix->cb_hi) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_hi), (size_t)nwords * 8 * 2));
+    if (!ix->cb_lo) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_lo), (size_t)nwords * 8 * 2));
+    if (!ix->cb_n2) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_n2), (size_t)nwords * 4));
+    hipLaunchKernelGGL(q_codebook_planes_kernel, dim3((unsigned)cdiv((uint64_t)nwords, 256)), dim3(256), 0, ctx->stream, ix->codebook, nwords, ix->cb_hi,
+                       ix->cb_lo, ix->cb_n2);
+  }
   if (!ix->cb_mean) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_mean), (size_t)(d + 2) * 4));
   LH_CHECK_HIP(lh::memset_async(ix->cb_mean, 0, (size_t)(d + 2) * 4, ctx->stream));
   hipLaunchKernelGGL(q_codebook_mean_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ix->codebook, d / m, d, ix->cb_mean);
@@ -1009,6 +1138,8 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     const bool tiled = qscan_tiled_shape(m, sd);
     a.cut_shift = no_cut ? -1 : (tiled ? 7 : (m == 16 ? 3 : 2));
     a.cut_slack = tiled ? (uint32_t)(2 * m + 8) : (uint32_t)(2 * m + 4);
+    // the MFMA-built table's entries carry up to Q_MB_SLACK_CAP more units per row on either side (ivfpq_qscan_kernel<.., true>)
+    if (!tiled && !qscan8_enabled(m, sd) && qscan_mfma_table(ix)) a.cut_slack += 2u * (uint32_t)Q_MB_SLACK_CAP;
     a.cut_mode = 0;
     if (qscan8_enabled(m, sd)) {   // sums 0 .. 379: one bin per value, no slack -- the second phase takes its limit from exact distances
       a.cut_mode = 1; a.cut_shift = no_cut ? -1 : 0; a.cut_slack = 0;
