@@ -263,6 +263,7 @@ lance_hip_index::~lance_hip_index() {
     if (pt->row_beta) (void)hipFree(pt->row_beta);
     if (pt->beta_min) (void)hipFree(pt->beta_min);
     if (pt->beta_abs) (void)hipFree(pt->beta_abs);
+    if (pt->beta_mean) (void)hipFree(pt->beta_mean);
     delete pt;
   }
   if (part_offsets) (void)hipFree(part_offsets);

@@ -37,6 +37,7 @@ struct lance_hip_index {
     float *row_beta = nullptr;    // [n] sum over m of 2 cen_t[p][m] . codeword[m][code] for every stored row
     float *beta_min = nullptr;    // [nlist] smallest row_beta of the partition
     float *beta_abs = nullptr;    // [nlist] largest |row_beta| of the partition
+    float *beta_mean = nullptr;   // [nlist] 2 cen_t[p] . mu (mu = the mean codeword of every sub-quantiser): row_beta of an average code
   } *pt = nullptr;
   std::mutex lazy_mu;             // guards the creation of `pt` (several contexts / host threads may search one index)
   uint32_t *part_offsets = nullptr;  // [nlist+1] device

@@ -130,6 +130,7 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
 bool qscan_tiled_shape(int m, int sd);
 int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t nq, uint32_t nprobes, uint32_t *seg_cnt, uint32_t *qovf);
 int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys);
+int qscan_item_tables(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nlist, int G, uint32_t *item_start, int4 *desc, uint32_t max_items);
 // G = queries per work item of the main pass: 4, or 8 when qscan8_enabled(m, sd) (search_q8.hip)
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
@@ -142,6 +143,10 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
                  uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow, const uint32_t *probes = nullptr);
 // search_qt.hip: per-query tables + per-row bias instead of a table per (query, partition) (M = 48 / 64 / 96; LANCE_HIP_QPT=1)
 bool qscan_pt_enabled(const lance_hip_index *ix);
+int qscan_pt_mode(const lance_hip_index *ix);      // 0 off, 1 tables after the bound pass, 2 tables before it (shared by both passes)
+int qbound_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, uint32_t keff,
+                     const uint32_t *probes, const uint32_t *pair_starts0, const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc,
+                     uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
                   uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow);

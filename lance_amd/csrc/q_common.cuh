@@ -56,6 +56,7 @@ struct QscanArgs {
   // MFMA table build (search_q.hip, sub-dimension 8): bf16 hi / lo planes of the codebook [m][256][8] and the codewords' squared norms
   const uint16_t *cb_hi = nullptr, *cb_lo = nullptr;
   const float *cb_n2 = nullptr;
+  const f4 *rq_n2 = nullptr;    // [items] |r_j|^2 of the item's four queries (q_residual_kernel)
   unsigned long long *prof = nullptr;   // -DLH_QT_PROF builds only (tiled kernel): [0] build clocks [1] scan [2] emit [3] items
 };
 

@@ -663,6 +663,10 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     const size_t lds = pm_lds_base(d, m) + (size_t)PM_CAP_BOUND * 16;
     const bool ok = launch_pm_sd<METRIC_L2>(ctx, a, sd, (unsigned)(nq / 2 + nlist + 1), lds);
     LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
+  } else if (qscan_pt_mode(ix) == 2) {   // per-query tables built before the bound pass and shared with the main pass (search_qt.hip)
+    ScopedTimer t(ctx, "ivfpq_scan_c0");
+    LH_TRY(qbound_pt_launch(ctx, ix, qs, nq, nprobes, keff, probes, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal,
+                            allow));
   } else {             // integer histogram bound, four queries per gather (search_q.hip)
     ScopedTimer t(ctx, "ivfpq_scan_c0");
     LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void q_item_desc_kernel(const uint32_t *__rest
 __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict__ q, const uint32_t *__restrict__ pair_idx,
                                                          const uint32_t *__restrict__ item_start, const int4 *__restrict__ desc,
                                                          const float *__restrict__ centroids, int d, int nlist, int pdiv, int round_f16,
-                                                         f4 *__restrict__ rq) {
+                                                         f4 *__restrict__ rq, f4 *__restrict__ rq_n2 = nullptr) {
   const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (item >= item_start[nlist]) return;
   const int lane = threadIdx.x & 63;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict
   uint32_t qj[Q_G];
 #pragma unroll
   for (int j = 0; j < Q_G; ++j) qj[j] = pair_idx[i0 + (j < cnt ? j : 0)] / (uint32_t)pdiv;
+  f4 n2 = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int dim = lane; dim < d; dim += 64) {
     const float cen = centroids[(int64_t)part * d + dim];
     f4 r4;
@@ -130,6 +131,12 @@ __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict
       r4[j] = -v;   // NEGATED: (r - c)^2 is evaluated as (c + (-r))^2 so that the add packs (v_pk_add_f32)
     }
     rq[(int64_t)item * d + dim] = r4;
+    n2 += r4 * r4;
+  }
+  if (rq_n2) {      // |r_j|^2 of the item's four queries (the MFMA table build's slack; any summation order serves a bound)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n2.x += __shfl_xor(n2.x, o, 64); n2.y += __shfl_xor(n2.y, o, 64); n2.z += __shfl_xor(n2.z, o, 64); n2.w += __shfl_xor(n2.w, o, 64); }
+    if (lane == 0) rq_n2[item] = n2;
   }
 }
 
@@ -153,7 +160,7 @@ __device__ __forceinline__ uint32_t q_bf16_rne(float x) {
 }
 
 template <int SD, int MU, bool MB = false>
-__global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
+__global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
   static_assert(!MB || SD == 8, "the MFMA table build is written for sub-dimension 8");
@@ -167,7 +174,6 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
   uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
   float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T / 65535 (1e30: no such query in this item)
   uint16_t *csum = reinterpret_cast<uint16_t *>(sc + 4);              // [4][Q_CAP] the survivors' integer sums
-  __shared__ float mb_r2[Q_G];          // MB: |r_j|^2 of the item's four queries
   __shared__ uint32_t mb_lim[Q_G];      // MB: per-query limit (0: the pair goes to the exact rescan)
 
   // one item per workgroup and no loop: nothing is stored to global memory before the residual loads, so the compiler may
@@ -200,24 +206,15 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
     const f4 *rq4 = p.rq + (int64_t)item * p.d;
     uint32_t lim4[Q_G] = {LIM, LIM, LIM, LIM};
     if constexpr (MB) {
-      // |r_j|^2 -> the per-query slack of the surrogate table (header)
-      if (threadIdx.x < Q_G) mb_r2[threadIdx.x] = 0.0f;
-      __syncthreads();
-      if ((int)threadIdx.x < p.d) {
-        const f4 v = rq4[threadIdx.x];
-        f4 sq = v * v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { sq.x += __shfl_xor(sq.x, o, 64); sq.y += __shfl_xor(sq.y, o, 64); sq.z += __shfl_xor(sq.z, o, 64); sq.w += __shfl_xor(sq.w, o, 64); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&mb_r2[0], sq.x); atomicAdd(&mb_r2[1], sq.y); atomicAdd(&mb_r2[2], sq.z); atomicAdd(&mb_r2[3], sq.w); }
-      }
-      __syncthreads();
+      // the per-query slack of the surrogate table (header) from |r_j|^2, which the residual pre-pass left beside the residuals
       if (threadIdx.x < Q_G) {
         uint32_t lim = LIM;
         if ((int)threadIdx.x < cnt) {
           const float T = key_to_float(p.tbound[qj[threadIdx.x]]);
           const float sj = fminf((float)SE / T, 1e30f);
-          const float delta = 6.5e-5f * sj * (3.0f * mb_r2[threadIdx.x] + 2.0f * T) * 1.01f;     // 2^-13.9 = 6.5e-5
-          lim = (delta <= Q_MB_SLACK_CAP) ? LIM + (uint32_t)ceilf(delta) : 0u;                    // NaN delta -> 0: rescan
+          const float r2 = p.rq_n2[item][threadIdx.x];
+          const float delta = 6.5e-5f * sj * (3.0f * r2 + 2.0f * T) * 1.01f;     // 2^-13.9 = 6.5e-5
+          lim = (delta <= Q_MB_SLACK_CAP) ? LIM + (uint32_t)ceilf(delta) : 0u;    // NaN delta -> 0: rescan
         }
         mb_lim[threadIdx.x] = lim;
       }
@@ -248,7 +245,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void
       const f4 s4 = *reinterpret_cast<const f4 *>(sc);
       const f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
       const f2 two = {2.0f, 2.0f};
-#pragma unroll 2
+#pragma unroll 4
       for (int i = 0; i < TPW; ++i) {
         const int c = (cb0 + i) * 16 + r;
         const int64_t e = (int64_t)mE * 256 + c;
@@ -905,6 +902,13 @@ int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_
   return LANCE_HIP_OK;
 }
 
+// item_start / desc of the (partition, G queries) items of a grouping (used by the bound passes)
+int qscan_item_tables(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nlist, int G, uint32_t *item_start, int4 *desc, uint32_t max_items) {
+  hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, G, item_start);
+  hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, nlist, G, max_items, desc);
+  return LANCE_HIP_OK;
+}
+
 int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys) {
   hipLaunchKernelGGL(q_nearest_keys_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, probes, (int)nq, (int)nprobes, keys);
   return LANCE_HIP_OK;
@@ -932,15 +936,22 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   const uint32_t max_items8 = (uint32_t)((uint64_t)nq * nprobes / 8 + ix->nlist + 2);
   f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", q8 ? (size_t)max_items8 * d * 8 : (size_t)max_items4 * d * 4));
   if (!rq) return LANCE_HIP_ENOMEM;
+  const bool mbt = !pt && !q8 && qscan_mfma_table(ix);
+  f4 *rq_n2 = nullptr;
   {
     ScopedTimer t(ctx, "q_residual");
     if (pt) {
     } else if (q8)
       LH_TRY(qscan8_residual(ctx, qs, pair_idx, item_start4, desc4, ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0,
                              max_items8, rq));
-    else
+    else {
+    if (mbt) {
+      rq_n2 = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq_n2", (size_t)max_items4 * 4));
+      if (!rq_n2) return LANCE_HIP_ENOMEM;
+    }
     hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4,
-                       ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
+                       ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq, rq_n2);
+    }
     LH_CHECK_HIP(lh::memset_async(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
     LH_CHECK_HIP(lh::memset_async(qovf, 0, (size_t)nq * 4, ctx->stream));
   }
@@ -950,7 +961,7 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
-  if (!pt && !q8 && qscan_mfma_table(ix)) { a.cb_hi = ix->cb_hi; a.cb_lo = ix->cb_lo; a.cb_n2 = ix->cb_n2; }
+  if (mbt) { a.cb_hi = ix->cb_hi; a.cb_lo = ix->cb_lo; a.cb_n2 = ix->cb_n2; a.rq_n2 = rq_n2; }
   a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);   // the merge launcher asks for the same slot
   a.ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)nq * nprobes + 1);                // likewise (and the class-B conversion)
   if (!a.seg_sum || !a.ovf) return LANCE_HIP_ENOMEM;
@@ -1038,8 +1049,10 @@ __global__ __launch_bounds__(256) void q_codebook_planes_kernel(const float *__r
 }
 
 bool qscan_mfma_table(const lance_hip_index *ix) {
-  static const bool off = getenv("LANCE_HIP_NO_MFMA_TABLE") != nullptr;
-  return !off && ix->cb_hi != nullptr && ix->m != 0 && ix->d / ix->m == 8 && (ix->m == 16 || ix->m == 32);
+  // opt-in: parity-green on its first run (gpurun r04e: pm-scan suite, 136 fuzz cases) but SLOWER than the packed-VALU build at
+  // C2 (scan 0.405 vs 0.347 ms per 10k-query batch): eight tiles per wave are a chain of L2 round trips the 44-VALU build does not have
+  static const bool on = getenv("LANCE_HIP_MFMA_TABLE") != nullptr && getenv("LANCE_HIP_MFMA_TABLE")[0] == '1';
+  return on && ix->cb_hi != nullptr && ix->m != 0 && ix->d / ix->m == 8 && (ix->m == 16 || ix->m == 32);
 }
 
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {

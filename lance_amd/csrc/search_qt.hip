@@ -463,28 +463,42 @@ __global__ __launch_bounds__(256) void q_pt_row_beta_kernel(const float *__restr
   }
 }
 
+// beta of an average code: 2 cen~_p . mu per partition (LANCE_HIP_QPT=2: the pre-scale of the shared tables)
+__global__ __launch_bounds__(256) void q_pt_beta_mean_kernel(const float *__restrict__ cen_t, const float *__restrict__ mu, int nlist, int d,
+                                                              float *__restrict__ beta_mean) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= nlist) return;
+  double acc = 0.0;
+  for (int dim = lane; dim < d; dim += 64) acc += 2.0 * (double)cen_t[(int64_t)p * d + dim] * (double)mu[dim];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) beta_mean[p] = (float)acc;
+}
+
 // one wave per (query, probe) pair: kappa = |cen~_p|^2 - 2 cen~_p . q~ (f64 sum, one rounding); the pair of rank 0 also leaves |q~|^2
 __global__ __launch_bounds__(256) void q_pt_kappa_kernel(const float *__restrict__ qs, const float *__restrict__ g, const float *__restrict__ cen_t,
                                                           const uint32_t *__restrict__ probes, int64_t npairs, int nprobes, int d,
-                                                          float *__restrict__ kap, double *__restrict__ qn2_out) {
+                                                          float *__restrict__ kap, double *__restrict__ qn2_out,
+                                                          const float *__restrict__ mu = nullptr, double *__restrict__ qmu_out = nullptr) {
   const int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pr >= npairs) return;
   const int64_t q = pr / nprobes;
   const float *ct = cen_t + (int64_t)probes[pr] * d, *qv = qs + q * d;
-  double acc = 0.0, qn2 = 0.0;
+  double acc = 0.0, qn2 = 0.0, qmu = 0.0;
 #pragma unroll 4
   for (int dim = lane; dim < d; dim += 64) {
     const float v = qv[dim] - g[dim];          // q~ (the same f32 subtraction as the table kernel's)
     const double c = (double)ct[dim];
     acc += c * c - 2.0 * c * (double)v;
     qn2 += (double)v * (double)v;
+    if (mu) qmu += (double)v * (double)mu[dim];
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); qn2 += __shfl_xor(qn2, o, 64); }
+  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); qn2 += __shfl_xor(qn2, o, 64); qmu += __shfl_xor(qmu, o, 64); }
   if (lane == 0) {
     kap[pr] = (float)acc;
-    if (pr % nprobes == 0) qn2_out[q] = qn2;
+    if (pr % nprobes == 0) { qn2_out[q] = qn2; if (qmu_out) qmu_out[q] = qmu; }
   }
 }
 
@@ -667,8 +681,15 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_pt_kernel(QscanArgs p
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
+// 0: off; 1: tables after the bound pass (scale from T); 2: tables before the bound pass, shared by both passes
+static int qscan_pt_env() {
+  static const int mode = [] { const char *e = getenv("LANCE_HIP_QPT"); return e ? (e[0] == '2' ? 2 : (e[0] != '0' ? 1 : 0)) : 0; }();   // unset: off (for now)
+  return mode;
+}
+int qscan_pt_mode(const lance_hip_index *ix) { return qscan_pt_enabled(ix) ? qscan_pt_env() : 0; }
+
 bool qscan_pt_enabled(const lance_hip_index *ix) {
-  static const bool on = [] { const char *e = getenv("LANCE_HIP_QPT"); return e ? e[0] != '0' : false; }();   // unset: off (for now)
+  const bool on = qscan_pt_env() != 0;
   if (!on || !ix || ix->m == 0 || ix->nbits != 8) return false;
   const int m = (int)ix->m, sd = (int)(ix->d / ix->m);
   if (!qscan_tiled_shape(m, sd)) return false;
@@ -686,8 +707,10 @@ static int qscan_pt_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->row_beta), (size_t)(ix->n ? ix->n : 1) * 4) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_min), (size_t)nlist * 4) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_abs), (size_t)nlist * 4) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&pc->beta_mean), (size_t)nlist * 4) == hipSuccess;
   auto drop = [&]() {
     (void)hipFree(pc->g); (void)hipFree(pc->cen_t); (void)hipFree(pc->row_beta); (void)hipFree(pc->beta_min); (void)hipFree(pc->beta_abs);
+    (void)hipFree(pc->beta_mean);
     delete pc;
   };
   if (!ok) { drop(); set_error("per-query tables: out of device memory for the index constants"); return LANCE_HIP_ENOMEM; }
@@ -696,6 +719,8 @@ static int qscan_pt_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
                      (int64_t)nlist * d, d, pc->cen_t);
   hipLaunchKernelGGL(q_pt_row_beta_kernel, dim3((unsigned)nlist), dim3(256), 0, ctx->stream, pc->cen_t, ix->codebook, ix->codes, ix->part_offsets, d, m,
                      pc->row_beta, pc->beta_min, pc->beta_abs);
+  if (ix->cb_mean)
+    hipLaunchKernelGGL(q_pt_beta_mean_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, pc->cen_t, ix->cb_mean, nlist, d, pc->beta_mean);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {   // other contexts (streams) search the same index
     drop();
     set_error("per-query tables: building the index constants failed");
@@ -705,10 +730,233 @@ static int qscan_pt_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   return LANCE_HIP_OK;
 }
 
+
+// ==== LANCE_HIP_QPT=2: the per-query tables are built BEFORE the bound pass and serve both passes ==============================
+// The bound pass spent a table build per (query, nearest partition) item -- about one per query at C3 (1000 queries over 1024
+// partitions), as much arithmetic as the per-query tables of the main pass.  Any scale is sound for the filter (it only sets how
+// tight it is), so the scale is fixed before T is known: T_pre = twice the distance of an AVERAGE code of the nearest partition,
+//   mean dist = (|q~|^2 - 2 q~.mu + nu) + 2 cen~_p0.mu + kappa_{q,p0}      (mu, nu: the codebook means of the index, cb_mean),
+// Theta_pre = max over the probes of (T_pre - kappa - min beta), s_q = SE / Theta_pre.  The bound kernel loads the item's four
+// tables, scans the first QT_BS * QT_R rows of the nearest partition and histograms S' = sum e + s (beta + kappa) ~ s dist of the
+// rows without a saturated entry (sum e < 65535); with keff rows at or below a bin's upper edge B the keff-th smallest ADC
+// distance is at most (B + M + 10 + slack) / s (the same two-sided relation the merge kernel's cut uses).  After the bound pass a
+// per-pair kernel computes the slack with the actual T and checks that no passing row can hold a saturated entry
+// (s (T - kappa - min beta) <= SE); a pair that fails goes to the exact rescan, as in mode 1.
+__global__ __launch_bounds__(256) void q_pt_prescale_kernel(const float *__restrict__ beta_min, const float *__restrict__ beta_abs,
+                                                             const float *__restrict__ beta_mean, const uint32_t *__restrict__ probes, int nq,
+                                                             int nprobes, int sd_plus_m, const float *__restrict__ nu_ptr, const float *__restrict__ kap,
+                                                             const double *__restrict__ qn2_in, const double *__restrict__ qmu_in,
+                                                             float *__restrict__ sq, float *__restrict__ theta_out, float *__restrict__ bslack) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const uint32_t p0 = probes[(int64_t)q * nprobes];
+  const double k0 = (double)kap[(int64_t)q * nprobes], qn2 = qn2_in[q];
+  const double abar = qn2 - 2.0 * qmu_in[q] + (double)nu_ptr[0];
+  const double tpre = 2.0 * (abar + k0 + (double)beta_mean[p0]);
+  double theta = 0.0;
+  for (int rank = 0; rank < nprobes; ++rank) {
+    const uint32_t p = probes[(int64_t)q * nprobes + rank];
+    theta = fmax(theta, tpre - (double)kap[(int64_t)q * nprobes + rank] - (double)beta_min[p]);
+  }
+  const bool ok = tpre > 0.0 && theta > 0.0 && theta < 1e300;
+  const float s = ok ? (float)((double)QT_SE / theta) : 0.0f;
+  sq[q] = s;
+  theta_out[q] = ok ? (float)theta : 0.0f;
+  const double u = 5.9604644775390625e-8;   // 2^-24
+  bslack[q] = ok ? (float)(2.0 + u * (double)s * (10.0 * (tpre + fabs(k0) + (double)beta_abs[p0] + qn2) + (double)(sd_plus_m + 6) * theta)) : INFINITY;
+}
+
+__global__ __launch_bounds__(256) void q_pt_slack_kernel(const float *__restrict__ beta_min, const float *__restrict__ beta_abs,
+                                                          const uint32_t *__restrict__ probes, const uint32_t *__restrict__ tbound, int64_t npairs,
+                                                          int nprobes, int sd_plus_m, const float *__restrict__ kap, const double *__restrict__ qn2_in,
+                                                          const float *__restrict__ sq, const float *__restrict__ theta_in, float *__restrict__ pslack) {
+  const int64_t pr = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pr >= npairs) return;
+  const int64_t q = pr / nprobes;
+  const uint32_t tb = tbound[q];
+  const float s = sq[q];
+  float out = INFINITY;
+  if (tb != 0xFFFFFFFFu && s > 0.0f) {
+    const double T = (double)key_to_float(tb), kf = (double)kap[pr], theta = (double)theta_in[q];
+    const uint32_t p = probes[pr];
+    const double u = 5.9604644775390625e-8;
+    const double sl = 2.0 + u * (double)s * (10.0 * (fabs(T) + fabs(kf) + (double)beta_abs[p] + qn2_in[q]) + (double)(sd_plus_m + 6) * theta);
+    // every row that can pass must have all its entries below saturation: s (T - kappa - min beta) <= SE
+    const double thmax = (double)s * (T - kf - (double)beta_min[p]);
+    if (thmax <= (double)QT_SE * 1.000001 && sl < 1e30) out = (float)sl;
+  }
+  pslack[pr] = out;
+}
+
+struct PtBoundArgs {
+  const uint16_t *tab;
+  const float *sq, *kap, *bslack, *row_beta;
+  int nprobes;
+};
+
+template <int MU, int NT>
+__global__ __launch_bounds__(QT_BS) void ivfpq_qbound_tiled_pt_kernel(QboundArgs p, PtBoundArgs t) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16, MT = M / NT;
+  __shared__ __attribute__((aligned(16))) uint2 lutq[MT * 256];
+  uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                   // [4][QB_BINS]
+  float *sc = reinterpret_cast<float *>(hist + 4 * QB_BINS);              // [4] s_j (0: no table)
+  float *skap = sc + 4;                                                   // [4] s_j kappa_j
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t item = blockIdx.x;
+  if (item >= p.item_start[p.nlist]) return;
+  const int4 dsc = p.desc[item];
+  const int part_id = dsc.x, i0 = dsc.y, cnt = dsc.z;
+  const uint32_t off = p.part_offsets[part_id];
+  const int np = (int)(p.part_offsets[part_id + 1] - off);
+  if (np < p.keff) return;   // uniform: fewer rows than k*refine -> no bound from this partition
+  uint32_t qj[Q_G];
+#pragma unroll
+  for (int j = 0; j < Q_G; ++j) qj[j] = p.pair_idx[i0 + (j < cnt ? j : 0)];
+  for (int i = threadIdx.x; i < 4 * QB_BINS; i += QT_BS) hist[i] = 0u;
+  if (threadIdx.x < Q_G) {
+    const int j = threadIdx.x;
+    const float s = j < cnt ? t.sq[qj[j]] : 0.0f;
+    sc[j] = s;
+    skap[j] = s * t.kap[(int64_t)qj[j] * t.nprobes];      // the nearest partition is probe rank 0
+  }
+  __syncthreads();
+  const f4 s4 = *reinterpret_cast<const f4 *>(sc), sk4 = *reinterpret_cast<const f4 *>(skap);
+  const uint16_t *tq0 = t.tab + (int64_t)qj[0] * M * 256, *tq1 = t.tab + (int64_t)qj[1] * M * 256;
+  const uint16_t *tq2 = t.tab + (int64_t)qj[2] * M * 256, *tq3 = t.tab + (int64_t)qj[3] * M * 256;
+  const uint8_t *pcodes = p.codes + (int64_t)off * M;
+  const int nrows = min(np, QT_BS * QT_R);
+  uint32_t acc[QT_R][4];
+#pragma unroll
+  for (int r = 0; r < QT_R; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[r][j] = 0u;
+#pragma unroll 1
+  for (int tile = 0; tile < NT; ++tile) {
+    if (tile > 0) __syncthreads();
+    constexpr int GROUPS = MT * 64;
+#pragma unroll 2
+    for (int gi = (int)threadIdx.x; gi < GROUPS; gi += QT_BS) {
+      const int ml = gi >> 6, c4 = (gi & 63) * 4, idx = (tile * MT + ml) * 256 + c4;
+      const uint2 a0 = *reinterpret_cast<const uint2 *>(tq0 + idx), a1 = *reinterpret_cast<const uint2 *>(tq1 + idx);
+      const uint2 a2 = *reinterpret_cast<const uint2 *>(tq2 + idx), a3 = *reinterpret_cast<const uint2 *>(tq3 + idx);
+      constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;
+      uint4 o01, o23;
+      o01.x = __builtin_amdgcn_perm(a1.x, a0.x, LO); o01.y = __builtin_amdgcn_perm(a3.x, a2.x, LO);
+      o01.z = __builtin_amdgcn_perm(a1.x, a0.x, HI); o01.w = __builtin_amdgcn_perm(a3.x, a2.x, HI);
+      o23.x = __builtin_amdgcn_perm(a1.y, a0.y, LO); o23.y = __builtin_amdgcn_perm(a3.y, a2.y, LO);
+      o23.z = __builtin_amdgcn_perm(a1.y, a0.y, HI); o23.w = __builtin_amdgcn_perm(a3.y, a2.y, HI);
+      *reinterpret_cast<uint4 *>(&lutq[ml * 256 + c4]) = o01;
+      *reinterpret_cast<uint4 *>(&lutq[ml * 256 + c4 + 2]) = o23;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < QT_R; ++r) {
+      const int row = r * QT_BS + (int)threadIdx.x;
+      if (row < nrows) qt_row_tile<MT>(lutq, pcodes + (int64_t)row * M + tile * MT, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < QT_R; ++r) {
+    const int row = r * QT_BS + (int)threadIdx.x;
+    if (row < nrows && row_allowed(p.allow, off + (uint32_t)row)) {
+      const float beta = t.row_beta[(int64_t)off + row];
+#pragma unroll
+      for (int j = 0; j < Q_G; ++j) {
+        if (j < cnt && s4[j] > 0.0f && acc[r][j] < 65535u) {      // sum e < 65535: no entry of the row saturated
+          const float S = (float)acc[r][j] + fmaf(s4[j], beta, sk4[j]);
+          if (S < 65536.0f) atomicAdd(&hist[j * QB_BINS + (S > 0.0f ? ((uint32_t)S >> QT_BSHIFT) : 0u)], 1u);   // a NaN S is not counted
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < cnt && sc[wave] > 0.0f) {
+    const uint32_t *h = hist + wave * QB_BINS;
+    constexpr int PER = QB_BINS / 64;
+    uint32_t loc[PER], tot = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { loc[i] = h[lane * PER + i]; tot += loc[i]; }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t tt = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += tt;
+    }
+    uint32_t run = incl - tot;
+    int found = -1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      run += loc[i];
+      if (found < 0 && run >= (uint32_t)p.keff) found = lane * PER + i;
+    }
+    const uint64_t mask = __ballot(found >= 0);
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      const int bin = __shfl(found, leader, 64);
+      if (lane == 0) {
+        const float B = (float)(((uint32_t)bin + 1u) << QT_BSHIFT);             // every counted row has S' < B
+        const float T = (B + (float)(M + 18) + t.bslack[qj[wave]]) / sc[wave] * 1.00001f;     // s dist <= S' + M + 10 (+ the f32 slack, + margin)
+        if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[qj[wave]], order_key(T));
+      }
+    }
+  }
+}
+
 template <int MU, int NT>
 static void launch_qscan_tiled_pt(lance_hip_ctx *ctx, const QscanArgs &a, const PtArgs &t, unsigned grid) {
   const size_t lds = (size_t)4 * Q_CAP * 4 + 8 * 4 + 12 * 4 + (size_t)4 * Q_CAP * 2;
   hipLaunchKernelGGL((ivfpq_qscan_tiled_pt_kernel<MU, NT>), dim3(grid), dim3(QT_BS), lds, ctx->stream, a, t);
+}
+
+static void pt_launch_tables(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const float *sq, uint16_t *tab) {
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
+  // enough slices of the sub-quantisers to put about sixteen workgroups on every CU (the kernel is a chain of L2 round trips)
+  int msplit = (int)std::min<uint64_t>((uint64_t)m, std::max<uint64_t>(1, cdiv((uint64_t)16 * ctx->num_cus, nq)));
+  const int mper = (int)cdiv((uint64_t)m, (uint64_t)msplit);
+  msplit = (int)cdiv((uint64_t)m, (uint64_t)mper);
+  const dim3 tgrid(nq, (unsigned)msplit);
+  if (sd == 4) hipLaunchKernelGGL((q_pt_table_kernel<4>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, mper, tab);
+  else if (sd == 8) hipLaunchKernelGGL((q_pt_table_kernel<8>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, mper, tab);
+  else hipLaunchKernelGGL((q_pt_table_kernel<16>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, mper, tab);
+}
+
+// LANCE_HIP_QPT=2: kappa, pre-scale and tables, then the bound pass on those tables (pair_starts0 / pair_idx0 = the queries grouped by
+// their nearest partition, as qbound_launch takes them)
+int qbound_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *qs, uint32_t nq, uint32_t nprobes, uint32_t keff,
+                     const uint32_t *probes, const uint32_t *pair_starts0, const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc,
+                     uint32_t max_items, uint32_t *tglobal, const uint32_t *allow) {
+  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
+  LH_TRY(qscan_pt_prepare(ctx, ix));
+  LH_REQUIRE(ix->cb_mean, "per-query tables: the index carries no codebook means");
+  const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
+  double *qn2 = ctx->scratch_t<double>("pt.qn2", nq), *qmu = ctx->scratch_t<double>("pt.qmu", nq);
+  float *sq = ctx->scratch_t<float>("pt.sq", nq), *theta = ctx->scratch_t<float>("pt.theta", nq), *bslack = ctx->scratch_t<float>("pt.bslack", nq);
+  float *kap = ctx->scratch_t<float>("pt.kap", (size_t)nq * nprobes);
+  float *nu_h = nullptr; (void)nu_h;
+  uint16_t *tab = ctx->scratch_t<uint16_t>("pt.tab", (size_t)nq * m * 256);
+  if (!qn2 || !qmu || !sq || !theta || !bslack || !kap || !tab) return LANCE_HIP_ENOMEM;
+  const int64_t npairs = (int64_t)nq * nprobes;
+  hipLaunchKernelGGL(q_pt_kappa_kernel, dim3((unsigned)cdiv((uint64_t)npairs, 4)), dim3(256), 0, ctx->stream, qs, ix->pt->g, ix->pt->cen_t, probes,
+                     npairs, (int)nprobes, d, kap, qn2, ix->cb_mean, qmu);
+  hipLaunchKernelGGL(q_pt_prescale_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, ix->pt->beta_min, ix->pt->beta_abs, ix->pt->beta_mean,
+                     probes, (int)nq, (int)nprobes, sd + m, ix->cb_mean + d, kap, qn2, qmu, sq, theta, bslack);
+  pt_launch_tables(ctx, ix, qs, nq, sq, tab);
+  LH_TRY(qscan_item_tables(ctx, pair_starts0, nlist, Q_G, item_start, desc, max_items));
+  QboundArgs a;
+  a.rq = nullptr; a.pair_idx = pair_idx0; a.item_start = item_start; a.desc = desc;
+  a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
+  a.d = d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = 0;
+  a.tglobal = tglobal; a.allow = allow; a.cb_mean = ix->cb_mean;
+  PtBoundArgs t;
+  t.tab = tab; t.sq = sq; t.kap = kap; t.bslack = bslack; t.row_beta = ix->pt->row_beta; t.nprobes = (int)nprobes;
+  const size_t lds = (size_t)4 * QB_BINS * 4 + 8 * 4;
+  if (m == 48) hipLaunchKernelGGL((ivfpq_qbound_tiled_pt_kernel<3, 1>), dim3(max_items), dim3(QT_BS), lds, ctx->stream, a, t);
+  else if (m == 64) hipLaunchKernelGGL((ivfpq_qbound_tiled_pt_kernel<4, LH_QT_NT64>), dim3(max_items), dim3(QT_BS), lds, ctx->stream, a, t);
+  else if (m == 96) hipLaunchKernelGGL((ivfpq_qbound_tiled_pt_kernel<6, LH_QT_NT96>), dim3(max_items), dim3(QT_BS), lds, ctx->stream, a, t);
+  else { set_error("per-query tables: unsupported shape (m=%d)", m); return LANCE_HIP_EINVAL; }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
 }
 
 int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const QscanArgs &a, const float *qs, uint32_t nq, const uint32_t *probes,
@@ -723,21 +971,20 @@ int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const Qscan
   uint16_t *tab = ctx->scratch_t<uint16_t>("pt.tab", (size_t)nq * m * 256);
   if (!qn2 || !sq || !kap || !pslack || !tab) return LANCE_HIP_ENOMEM;
   const int64_t npairs = (int64_t)nq * nprobes;
-  {
+  if (qscan_pt_mode(ix) == 2) {
+    // the tables exist since the bound pass (qbound_pt_launch): only the per-pair slack with the actual T is left
+    float *theta = ctx->scratch_t<float>("pt.theta", nq);
+    if (!theta) return LANCE_HIP_ENOMEM;
+    hipLaunchKernelGGL(q_pt_slack_kernel, dim3((unsigned)cdiv((uint64_t)npairs, 256)), dim3(256), 0, ctx->stream, ix->pt->beta_min, ix->pt->beta_abs,
+                       probes, a.tbound, npairs, nprobes, sd + m, kap, qn2, sq, theta, pslack);
+  } else {
   ScopedTimer tprep(ctx, "q_pt_tables");      // (inside the caller's "ivfpq_scan_c1" timer)
   hipLaunchKernelGGL(q_pt_kappa_kernel, dim3((unsigned)cdiv((uint64_t)npairs, 4)), dim3(256), 0, ctx->stream, qs, ix->pt->g, ix->pt->cen_t, probes,
                      npairs, nprobes, d, kap, qn2);
   hipLaunchKernelGGL(q_pt_scale_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, ix->pt->beta_min, ix->pt->beta_abs, probes, a.tbound,
                      (int)nq, nprobes, sd + m, kap, qn2, sq, pslack);
   ScopedTimer ttab(ctx, "q_pt_table_only");
-  // enough slices of the sub-quantisers to put about sixteen workgroups on every CU (the kernel is a chain of L2 round trips)
-  int msplit = (int)std::min<uint64_t>((uint64_t)m, std::max<uint64_t>(1, cdiv((uint64_t)16 * ctx->num_cus, nq)));
-  const int mper = (int)cdiv((uint64_t)m, (uint64_t)msplit);
-  msplit = (int)cdiv((uint64_t)m, (uint64_t)mper);
-  const dim3 tgrid(nq, (unsigned)msplit);
-  if (sd == 4) hipLaunchKernelGGL((q_pt_table_kernel<4>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, mper, tab);
-  else if (sd == 8) hipLaunchKernelGGL((q_pt_table_kernel<8>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, mper, tab);
-  else hipLaunchKernelGGL((q_pt_table_kernel<16>), tgrid, dim3(256), 0, ctx->stream, qs, ix->pt->g, sq, ix->codebook, d, m, mper, tab);
+  pt_launch_tables(ctx, ix, qs, nq, sq, tab);
   }
   PtArgs t;
   t.tab = tab; t.sq = sq; t.kap = kap; t.pslack = pslack; t.row_beta = ix->pt->row_beta;

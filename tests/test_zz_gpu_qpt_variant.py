@@ -1,10 +1,10 @@
-"""The per-query-table filter (lance_amd/csrc/search_qt.hip, LANCE_HIP_QPT=1) was written at the end of round 3
-against its CPU specification (scripts/sim/pqt_filter_spec.py) after the round's GPU budget was spent: it compiles, it has
-never run.  This test is the first thing to run on hardware next round; until then it only runs when asked to
-(LANCE_TEST_UNVALIDATED=1), so that an unvalidated experimental path cannot turn the suite red.
-
-What it does: the tiled-table parity cases (M = 48 / 64 / 96) again in a child process with the switch on -- bit-equal to the
-oracle like the default path, since the variant only changes the FILTER."""
+"""The per-query-table filter for the tiled PQ shapes (lance_amd/csrc/search_qt.hip): with r = q - cen_p the table entry
+splits into a per-QUERY table, a constant per stored ROW and a scalar per (query, partition) pair, so the integer table is built once
+per query and a work item loads its four queries' tables instead of computing them.  LANCE_HIP_QPT (read once per process):
+  1 -- tables after the bound pass, scale from the bound T (first run on hardware: round 4, gpurun r04a: parity test + 176 fuzz cases);
+  2 -- tables BEFORE the bound pass, scale from the distance of an average code, shared by the bound pass and the main pass.
+The variant only changes the FILTER; survivors are re-evaluated in the reference's arithmetic, so the tiled-table parity cases
+(M = 48 / 64 / 96) and the C3 full-configuration case must stay bit-equal to the oracle.  They run again in a child process per mode."""
 import os
 import subprocess
 import sys
@@ -14,10 +14,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(os.environ.get("LANCE_TEST_UNVALIDATED") != "1", reason="experimental path, not yet run on hardware (set LANCE_TEST_UNVALIDATED=1)")
-def test_tiled_cases_with_per_query_tables():
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_tiled_cases_with_per_query_tables(mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LANCE_HIP_QPT="1")
+    env = dict(os.environ, LANCE_HIP_QPT=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_pm_scan.py"), os.path.join(root, "tests", "test_zz_gpu_fullconfig.py"),
                         "-m", "gpu", "-q", "-x", "-k", "tiled or loose_bounds or c3", "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
