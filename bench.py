@@ -391,7 +391,7 @@ def main():
     # HBM traffic of the dominant kernel: measured IN THIS RUN by two rocprofv3 --pmc child passes (collect_pmc_traffic); the figure
     # recorded under profiles/ in an earlier round is kept beside it under its own key, never as `traffic`
     traffic, traffic_src, traffic_detail = None, None, None
-    pmc_kernel = "ivfpq_qscan_kernel<8, 1>" if (quantised and args.config == "c2") else None
+    pmc_kernel = "ivfpq_qscan_kernel<8, 1" if (quantised and args.config == "c2") else None
     if pmc_kernel and not args.no_pmc and world == 1:
         child = ["--steps", "3", "--warmup", "1", "--streams", "1", "--no-cpu-baseline", "--no-pmc", "--config", args.config, "--n", str(args.n),
                  "--nq", str(args.nq), "--nprobes", str(args.nprobes), "--refine", str(args.refine), "--k", str(args.k)]

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(QT_BS) void ivfpq_qscan_tiled_pt_kernel(QscanArgs p
 // ---- host ------------------------------------------------------------------------------------------------------------------
 // 0: off; 1: tables after the bound pass (scale from T); 2: tables before the bound pass, shared by both passes
 static int qscan_pt_env() {
-  static const int mode = [] { const char *e = getenv("LANCE_HIP_QPT"); return e ? (e[0] == '2' ? 2 : (e[0] != '0' ? 1 : 0)) : 0; }();   // unset: off (for now)
+  static const int mode = [] { const char *e = getenv("LANCE_HIP_QPT"); return e ? (e[0] == '2' ? 2 : (e[0] != '0' ? 1 : 0)) : 2; }();   // unset: mode 2 (r04g: C3 716 k -> 788 k q/s at nprobes 10, 348 k -> 508 k at 50)
   return mode;
 }
 int qscan_pt_mode(const lance_hip_index *ix) { return qscan_pt_enabled(ix) ? qscan_pt_env() : 0; }
