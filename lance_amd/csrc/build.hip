@@ -266,6 +266,12 @@ lance_hip_index::~lance_hip_index() {
     if (pt->beta_mean) (void)hipFree(pt->beta_mean);
     delete pt;
   }
+  if (ms) {
+    if (ms->cbh) (void)hipFree(ms->cbh);
+    if (ms->cbn2) (void)hipFree(ms->cbn2);
+    if (ms->row_cn2) (void)hipFree(ms->row_cn2);
+    delete ms;
+  }
   if (part_offsets) (void)hipFree(part_offsets);
   if (codes) (void)hipFree(codes);
   if (row_ids) (void)hipFree(row_ids);

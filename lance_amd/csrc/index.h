@@ -39,7 +39,16 @@ struct lance_hip_index {
     float *beta_abs = nullptr;    // [nlist] largest |row_beta| of the partition
     float *beta_mean = nullptr;   // [nlist] 2 cen_t[p] . mu (mu = the mean codeword of every sub-quantiser): row_beta of an average code
   } *pt = nullptr;
-  std::mutex lazy_mu;             // guards the creation of `pt` (several contexts / host threads may search one index)
+  // search_ms.hip (the filter scan on the matrix cores): constants of that filter, created by the first such search
+  struct MsConst {
+    bool usable = false;          // false: nothing to scale by (all-zero codebook) -- the integer scan serves the index
+    float sigma = 1.0f;           // power of two: the largest |2 sigma c| sits in [2^13, 2^14)
+    void *cbh = nullptr;          // [m][256][d/m] binary16: -2 sigma c
+    float *cbn2 = nullptr;        // [m][256] |c|^2
+    float *row_cn2 = nullptr;     // [n] sigma^2 |reconstruction of the stored row|^2
+    uint32_t max_units = 0;       // sum over the partitions of ceil(rows / 256): the scan's grid
+  } *ms = nullptr;
+  std::mutex lazy_mu;             // guards the creation of `pt` / `ms` (several contexts / host threads may search one index)
   uint32_t *part_offsets = nullptr;  // [nlist+1] device
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition

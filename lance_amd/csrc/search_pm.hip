@@ -681,7 +681,16 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
                        2 * nlist, nlist, (int)nprobes, max_items2, desc);
   }
   // timers inside: "q_residual" (memsets + residual pre-pass) and "ivfpq_scan_c1" (the filter scan kernel alone)
-  LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow, probes));
+  // search_ms.hip: the filter as a matrix product per partition (its own pre-pass; same segment outputs + a per-query slack for the merge cut)
+  uint32_t *qslack = nullptr;
+  int ms_rc = -1;
+  if (mscan_supported(ix, nq, nprobes))
+    ms_rc = mscan_launch(ctx, ix, qs, nq, nprobes, probes, pair_starts, pair_idx, tbound, seg_cnt, seg_pos, qovf, allow, &qslack);
+  if (ms_rc > 0) return ms_rc;
+  if (ms_rc < 0) {
+    qslack = nullptr;
+    LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow, probes));
+  }
   static const bool q_stats = getenv("LANCE_HIP_Q_STATS") != nullptr;
   if (q_stats) {   // diagnosis: how many rows survive the integer filter
     std::vector<uint32_t> sc(npairs), tb(nq);
@@ -712,7 +721,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     o.out_ids = ids; o.out_dists = dists; o.cand_rid = cand_rid; o.cand_cnt = cand_cnt; o.flags = flags;
     o.part_offsets = ix->part_offsets; o.nlist = nlist;
     ScopedTimer t(ctx, "ivfpq_merge");
-    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o, allow));
+    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o, allow, qslack));
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;

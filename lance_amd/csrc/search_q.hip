@@ -476,6 +476,7 @@ struct QmergeArgs {
   int cut_mode;                  // 0: sums bound the distance from both sides (u16 tables); 1: lower bounds only (8-bit entries): two-phase cut
   int cut_shift;                 // histogram bin = sum >> cut_shift (512 bins cover 0 .. LIM)
   uint32_t cut_slack;            // a survivor whose sum exceeds (upper edge of the keff-th bin) + cut_slack cannot reach the top keff
+  const uint32_t *qslack;        // search_ms.hip: [nq] per-query bound of |sum - dist * s| (units); the cut carries twice that on top of cut_slack
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
   uint32_t *tglobal;             // class B: running bound of the exact pair kernel
   const uint32_t *seg_cnt, *seg_pos;
@@ -518,7 +519,12 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
     // any value of tglobal is an upper bound of the query's final keff-th distance (the filter's bound, lowered by whoever
     // finished a segment of this query first)
     const uint32_t t_start = min(a.tbound[q], __hip_atomic_load(&a.tglobal[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (threadIdx.x == 0) { misc[0] = 0; misc[1] = t_start; misc[3] = 0; }
+    if (threadIdx.x == 0) {
+      misc[0] = 0; misc[1] = t_start; misc[3] = 0;
+      // every listed segment's rows come through the pool: the merge kernel reads it for queries flagged here (the scan kernels set the
+      // flag themselves; search_ms.hip's burst path only lists the segment)
+      const_cast<uint32_t *>(a.qovf)[q] = 1u;
+    }
     for (int e = threadIdx.x; e < a.d; e += BS) {
       float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
       if (a.round_f16) v = __half2float(__float2half_rn(v));
@@ -714,7 +720,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         const int leader = __ffsll((long long)mask) - 1;
         const int bin = __shfl(found, leader, 64);
         // bin 511 also holds the sums beyond the histogram's range: no upper edge there -> no cut
-        if (lane == 0 && bin < 511) s_cut = (((uint32_t)bin + 1u) << a.cut_shift) - 1u + a.cut_slack;
+        if (lane == 0 && bin < 511) s_cut = (((uint32_t)bin + 1u) << a.cut_shift) - 1u + a.cut_slack + (a.qslack ? 2u * a.qslack[q] : 0u);
       }
     }
     __syncthreads();
@@ -1125,9 +1131,11 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
 
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
-                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow) {
+                  uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow,
+                  const uint32_t *qslack) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
+  a.qslack = qslack;
   a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
   a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
@@ -1156,6 +1164,11 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     a.cut_mode = 0;
     if (qscan8_enabled(m, sd)) {   // sums 0 .. 379: one bin per value, no slack -- the second phase takes its limit from exact distances
       a.cut_mode = 1; a.cut_shift = no_cut ? -1 : 0; a.cut_slack = 0;
+    }
+    if (qslack) {   // search_ms.hip's sums: rint(dist~ * s) with |dist~ - dist| s <= qslack[q]; LIM ~ 30000 + slack -> bins of 64
+      int sh = 0; uint32_t sl = 0;
+      mscan_cut_params(&sh, &sl);
+      a.cut_mode = 0; a.cut_shift = no_cut ? -1 : sh; a.cut_slack = sl;
     }
   }
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
