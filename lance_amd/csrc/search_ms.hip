@@ -137,6 +137,7 @@ struct MsPrepArgs {
   uint32_t *qslack;             // [nq] max over the query's pairs of ceil(E s) (zeroed before the launch)
   uint32_t *seg_cnt, *qovf, *ovf;
   uint32_t nan_slot;            // index into prm of the NaN-limit record (written here, loaded by the scan for padded pair slots)
+  f2 *prm2;                     // [nq * nprobes] by PAIR: {s / sigma^2, |r|^2 s} -- what turns an accumulator value into the survivor's integer sum
 };
 
 constexpr int MS_PPW = 4;      // pairs per wave of the pre-pass: their loads are in flight together (one pair per wave was 100k waves of
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
   f4 o;
   if (ok) {
     o.x = lim * sig2; o.y = s / sig2; o.z = n2l * s;
+    p.prm2[pairl] = f2{o.y, o.z};
     atomicMax(&p.qslack[q], (uint32_t)ceilf(eu));
   } else {
     // this (query, partition) pair goes to the exact rescan (ivfpq_qrescan_kernel), as an overflowed segment does.  The limit is a
@@ -226,6 +228,8 @@ struct MscanArgs {
   const _Float16 *rh;           // [pairs][d]
   const f4 *prm;                // [pairs]
   const MsUnit *units;          // [units] (pipelined kernel)
+  const f2 *prm2;               // [nq * nprobes] by pair (pipelined kernel's flush)
+  unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1: [0] prologue [1] barrier waits [2] flush + DMA issue [3] tiles [4] tail [5] waves [6] super-blocks
   uint32_t nan_slot;
   int nlist, nprobes, m;
   uint32_t *seg_cnt, *seg_pos;
@@ -233,137 +237,6 @@ struct MscanArgs {
   uint32_t *qovf, *ovf;
   const uint32_t *allow;
 };
-
-template <int SD, int KS>
-__global__ __launch_bounds__(256, 2) void ivfpq_mscan_kernel(MscanArgs p) {
-  constexpr int D = KS * 16;
-  constexpr int RS = D + 8;                 // f16 row stride of a staged B tile: 16-byte skew, conflict-free ds_read_b128
-  constexpr int M = D / SD;
-  __shared__ __attribute__((aligned(16))) _Float16 sB[MS_SBP * RS];
-  __shared__ __attribute__((aligned(16))) f4 sP[MS_SBP];
-  __shared__ __attribute__((aligned(8))) uint2 sQ[4][MS_QCAP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, g = lane >> 5;
-  // consecutive units (the row chunks of one partition share the partition's B tiles) stay on one XCD: blockIdx round-robins the 8 XCDs
-  const uint32_t per_xcd = (gridDim.x + 7u) >> 3;
-  const uint32_t unit = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (unit >= p.unit_start[p.nlist]) return;
-  int part = (int)find_partition_dev(p.unit_start, p.nlist, unit);
-  while (p.unit_start[part + 1] <= unit) ++part;      // empty ranges share their successor's start
-  const uint32_t off = p.part_offsets[part];
-  const int np = (int)(p.part_offsets[part + 1] - off);
-  const int row0 = (int)(unit - p.unit_start[part]) * MS_RW;
-  const uint32_t gs = p.pair_starts[part];
-  const int Qp = (int)(p.pair_starts[part + 1] - gs);
-
-  // A: the f16 reconstruction of this wave's 64 rows, in MFMA operand layout (lane (j, g): row j of the 32-block, k-slice g)
-  ms_h8 a[2][KS];
-  ms_f16v cinit[2];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
-    const int rowl = wave * 64 + rb * 32 + j;
-    const int rowc = min(row0 + rowl, np - 1);
-    const uint8_t *rc = p.codes + ((int64_t)off + rowc) * M;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if constexpr (SD == 8) {
-        const int mm = 2 * s + g;
-        a[rb][s] = *reinterpret_cast<const ms_h8 *>(p.cbh + ((int64_t)mm * 256 + rc[mm]) * 8);
-      } else if constexpr (SD == 4) {
-        const int mm = 4 * s + 2 * g;
-        const ms_h4 lo = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)mm * 256 + rc[mm]) * 4);
-        const ms_h4 hi = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)(mm + 1) * 256 + rc[mm + 1]) * 4);
-        a[rb][s] = ms_h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      } else {
-        static_assert(SD == 16, "sub-dimension 4 / 8 / 16");
-        a[rb][s] = *reinterpret_cast<const ms_h8 *>(p.cbh + ((int64_t)s * 256 + rc[s]) * 16 + g * 8);
-      }
-    }
-    // D[row i][query j]: lane (j, g) holds rows i = (v & 3) + 8 (v >> 2) + 4 g of the 32-block (layout as in mfma_assign.hip)
-#pragma unroll
-    for (int vq = 0; vq < 4; ++vq)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = row0 + wave * 64 + rb * 32 + 8 * vq + 4 * g + e;
-        cinit[rb][vq * 4 + e] = r < np ? p.row_cn2[(int64_t)off + r] : INFINITY;      // a padded row never passes
-      }
-  }
-
-  uint2 *myq = sQ[wave];
-  uint32_t qn = 0;      // wave-uniform
-  auto flush = [&]() {
-    for (uint32_t e = (uint32_t)lane; e < qn; e += 64u) {
-      const uint2 ent = myq[e];
-      const uint32_t slot = ent.x >> 8, rowl = ent.x & 255u;
-      const f4 P = sP[slot];
-      const uint32_t pair = __float_as_uint(P.w);
-      const float S = fminf(fmaxf(rintf(__builtin_fmaf(__uint_as_float(ent.y), P.y, P.z)), 0.0f), 65535.0f);
-      const uint32_t pos = off + (uint32_t)row0 + rowl;
-      if (row_allowed(p.allow, pos)) {
-        const uint32_t k = atomicAdd(&p.seg_cnt[pair], 1u);
-        if (k < (uint32_t)Q_CAP) {
-          p.seg_pos[(int64_t)pair * Q_CAP + k] = pos;
-          p.seg_sum[(int64_t)pair * Q_CAP + k] = (uint16_t)S;
-        } else if (k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
-          p.qovf[pair / (uint32_t)p.nprobes] = 1u;
-          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;
-        }
-      }
-    }
-    qn = 0;
-  };
-
-  for (int sb0 = 0; sb0 < Qp; sb0 += MS_SBP) {
-    const int nsb = min(MS_SBP, Qp - sb0);
-    const int nblk = (nsb + 31) >> 5;
-    __syncthreads();      // the previous super-block's tiles and parameters are done with (queues flushed)
-    {
-      constexpr int CPR = D / 8;      // 16-byte chunks per pair row
-      const _Float16 *src = p.rh + ((int64_t)gs + sb0) * D;
-      for (int idx = threadIdx.x; idx < nblk * 32 * CPR; idx += 256) {
-        const int slot = idx / CPR, c = idx - slot * CPR;
-        const uint4 v = *reinterpret_cast<const uint4 *>(src + (int64_t)slot * D + c * 8);      // (rh is padded by 32 rows)
-        *reinterpret_cast<uint4 *>(&sB[slot * RS + c * 8]) = v;
-      }
-      for (int slot = threadIdx.x; slot < nblk * 32; slot += 256) {
-        f4 P = {__uint_as_float(0x7FC00000u), 0.0f, 0.0f, 0.0f};      // padding slots read whatever follows in rh: NaN limit, never passes
-        if (slot < nsb) P = p.prm[(int64_t)gs + sb0 + slot];
-        sP[slot] = P;
-      }
-    }
-    __syncthreads();
-    for (int jb = 0; jb < nblk; ++jb) {
-      ms_h8 b[KS];
-      const _Float16 *br = &sB[(jb * 32 + j) * RS + g * 8];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const ms_h8 *>(br + s * 16);
-      const float lim = sP[jb * 32 + j].x;
-      if (qn + 128u > (uint32_t)MS_QCAP) flush();      // room for this tile's worst plausible burst; checked again per append
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        ms_f16v acc = cinit[rb];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][s], b[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const bool pass = acc[v] <= lim;
-          const uint64_t mask = __ballot(pass);
-          if (mask) {
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            if (qn + cnt > (uint32_t)MS_QCAP) flush();
-            if (pass) {
-              const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-              const uint32_t rowl = (uint32_t)(wave * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * g);
-              myq[idx] = make_uint2(((uint32_t)(jb * 32 + j) << 8) | rowl, __float_as_uint(acc[v]));
-            }
-            qn += cnt;
-          }
-        }
-      }
-    }
-    flush();      // before the parameters of this super-block are overwritten
-  }
-}
 
 // ---- the scan, pipelined (the default) -----------------------------------------------------------------------------------------------
 // First hardware run of the kernel above (gpurun r04h): parity green (62 tests, 209 fuzz cases), 0.343 ms per 10k-query batch at C2 --
@@ -382,7 +255,7 @@ typedef __attribute__((address_space(3))) void *ms_lptr;
 constexpr int MS2_SBP = 128;        // pairs per LDS super-block (4 tiles of 32), double buffered
 constexpr int MS2_QCAP = 128;       // survivor queue entries per wave (2 per lane pending in registers)
 
-template <int SD, int KS>
+template <int SD, int KS, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
   constexpr int D = KS * 16;
   constexpr int M = D / SD;
@@ -393,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
   constexpr int PE = MS2_QCAP / 64;
   __shared__ __attribute__((aligned(16))) char sB[2][MS2_SBP * RB];
   __shared__ __attribute__((aligned(16))) f4 sP[2][MS2_SBP];
-  __shared__ __attribute__((aligned(8))) uint2 sQ[4][MS2_QCAP];
+  __shared__ __attribute__((aligned(8))) uint2 sQ[4][MS2_QCAP + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
   const uint32_t per_xcd = (gridDim.x + 7u) >> 3;
@@ -426,6 +299,8 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
     }
   };
   const int nsbk = (Qp + MS2_SBP - 1) / MS2_SBP;
+  long long pc0 = 0, pc_wait = 0, pc_flush = 0, pc_comp = 0, pct = 0;      // PROF: s_memtime stamps (100 MHz)
+  if constexpr (PROF) pc0 = clock64();
   stage(0, 0);
 
   // A: the f16 reconstruction of this wave's 64 rows, in MFMA operand layout (lane (j, g): row j of the 32-block, k-slice g)
@@ -470,21 +345,23 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
 
   uint2 *myq = sQ[wave];
   uint32_t qn = 0;      // wave-uniform: queue entries
-  // pending flush: entries whose segment slot has been requested (atomicAdd issued) but not yet used
-  uint32_t pd_pair[PE], pd_pos[PE], pd_k[PE], pd_s[PE];
+  // pending flush: entries whose segment slot has been requested (atomicAdd issued, sum scale requested) but not yet used
+  uint32_t pd_pair[PE], pd_pos[PE], pd_k[PE];
+  float pd_a[PE];
+  f2 pd_yz[PE];
 #pragma unroll
-  for (int i = 0; i < PE; ++i) { pd_pair[i] = 0xFFFFFFFFu; pd_pos[i] = 0u; pd_k[i] = 0u; pd_s[i] = 0u; }
+  for (int i = 0; i < PE; ++i) { pd_pair[i] = 0xFFFFFFFFu; pd_pos[i] = 0u; pd_k[i] = 0u; pd_a[i] = 0.0f; pd_yz[i] = f2{0.0f, 0.0f}; }
   auto flush_end = [&]() {
 #pragma unroll
     for (int i = 0; i < PE; ++i) {
       if (pd_pair[i] != 0xFFFFFFFFu) {
         const uint32_t k = pd_k[i], pair = pd_pair[i];
         if (k < (uint32_t)Q_CAP) {
+          const float S = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(pd_a[i], pd_yz[i].x, pd_yz[i].y)), 0.0f, 65535.0f);
           p.seg_pos[(int64_t)pair * Q_CAP + k] = pd_pos[i];
-          p.seg_sum[(int64_t)pair * Q_CAP + k] = (uint16_t)pd_s[i];
+          p.seg_sum[(int64_t)pair * Q_CAP + k] = (uint16_t)S;
         } else if (k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
-          p.qovf[pair / (uint32_t)p.nprobes] = 1u;
-          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;
+          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
         }
         pd_pair[i] = 0xFFFFFFFFu;
       }
@@ -498,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
         const uint2 ent = myq[e];
         const uint32_t pair = ent.x >> 8, pos = off + (uint32_t)row0 + (ent.x & 255u);
         if (row_allowed(p.allow, pos)) {
-          pd_pair[i] = pair; pd_pos[i] = pos; pd_s[i] = ent.y;
+          pd_pair[i] = pair; pd_pos[i] = pos; pd_a[i] = __uint_as_float(ent.y);
+          pd_yz[i] = p.prm2[pair];
           pd_k[i] = atomicAdd(&p.seg_cnt[pair], 1u);
         }
       }
@@ -508,10 +386,17 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
 
   for (int sb = 0; sb < nsbk; ++sb) {
     const int buf = sb & 1;
-    __syncthreads();      // vmcnt(0) + barrier: super-block sb has landed for every wave; the other buffer's readers are done
+    if constexpr (PROF) { pct = clock64(); if (sb == 0) pc0 = pct - pc0; }
+    // The DMA is ordered for the readers only by the ISSUING wave's vmcnt(0) followed by the barrier -- and hipcc does not put that
+    // wait in front of this barrier by itself (gpurun r04j: the loop header was a bare s_barrier; two queries of 700 read a
+    // super-block that had not landed): stated here.  It also retires the flush's atomics, loads and stores, as intended.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // super-block sb has landed for every wave; the other buffer's readers are done
+    if constexpr (PROF) { const long long t = clock64(); pc_wait += t - pct; pct = t; }
     flush_end();          // stores behind the atomics issued one super-block ago
     flush_begin();        // atomics for the survivors of the previous super-block
     if (sb + 1 < nsbk) stage(sb + 1, buf ^ 1);
+    if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; }
     const int nsb = min(MS2_SBP, Qp - sb * MS2_SBP);
     const int nblk = (nsb + 31) >> 5;
     for (int jb = 0; jb < nblk; ++jb) {
@@ -522,41 +407,339 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
       const f4 P = sP[buf][slot];
+      const float lim = P.x;
       const uint32_t pair8 = __float_as_uint(P.w) << 8;
-      // room for a tile's usual yield (13 survivors at C2); a burst beyond the queue hands its pairs to the exact rescan below
+      // room for a tile's usual yield (13 survivors at C2); a burst beyond the queue is handled after the tile
       if (qn > (uint32_t)(MS2_QCAP - 48)) { flush_end(); flush_begin(); }
+      uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         ms_f16v acc = cinit[rb];
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][s], b[s], acc, 0, 0, 0);
+        // Sixteen compares back to back into sixteen lane masks, THEN the (scalar) tests: the first version branched on each compare's
+        // result as it came -- 32 VALU -> SALU dependency stalls per tile, and ~20 wave instructions per survivor behind them
+        uint64_t mk[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= lim);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const bool pass = acc[v] <= P.x;
-          const uint64_t mask = __ballot(pass);
-          if (mask) {
-            if (pass) {
-              const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-              if (idx < (uint32_t)MS2_QCAP) {
-                const uint32_t rowl = (uint32_t)(wave * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * g);
-                const float S = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(acc[v], P.y, P.z)), 0.0f, 65535.0f);
-                myq[idx] = make_uint2(pair8 | rowl, (uint32_t)S);
-              } else {
-                // more than a queue's worth of survivors in one tile (>= 4 % of its cells pass: this pair's segment would overflow
-                // anyway): the pair is handed to the exact rescan -- the count jumps past Q_CAP, and whoever crosses it lists the pair
-                const uint32_t pair = pair8 >> 8;
-                const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
-                if (k <= (uint32_t)Q_CAP) p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
-              }
+          if (mk[v]) {
+            const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
+                                     (uint32_t)MS2_QCAP);      // entry MS2_QCAP: the bin of a burst
+            if (acc[v] <= lim) {      // (the same compare: the compiler reuses its lane mask as the exec mask)
+              const uint32_t rowl = (uint32_t)(wave * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * g);
+              myq[idx] = make_uint2(pair8 | rowl, __float_as_uint(acc[v]));
             }
-            qn = min(qn + (uint32_t)__popcll(mask), (uint32_t)MS2_QCAP);
+            qraw += (uint32_t)__popcll(mk[v]);
           }
         }
       }
+      qn = min(qraw, (uint32_t)MS2_QCAP);
+      if (qraw > (uint32_t)MS2_QCAP) {
+        // more than a queue's worth of survivors in one tile (>= 4 % of its cells pass -- these pairs' segments would overflow anyway):
+        // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
+        // crosses it lists the pair
+        if (g == 0 && slot < nsb) {
+          const uint32_t pair = pair8 >> 8;
+          const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
+          if (k <= (uint32_t)Q_CAP) p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
+        }
+      }
     }
+    if constexpr (PROF) { const long long t = clock64(); pc_comp += t - pct; pct = t; }
   }
   flush_end();
   flush_begin();
+  flush_end();
+  if constexpr (PROF) {
+    if (lane == 0) {
+      atomicAdd(&p.prof[0], (unsigned long long)pc0);       // start -> first barrier (unit record, A gather, |c^|^2, first DMA)
+      atomicAdd(&p.prof[1], (unsigned long long)pc_wait);   // vmcnt(0) + barrier
+      atomicAdd(&p.prof[2], (unsigned long long)pc_flush);  // flush_end + flush_begin + DMA issue
+      atomicAdd(&p.prof[3], (unsigned long long)pc_comp);   // tiles: LDS reads, MFMA, compares, queue
+      atomicAdd(&p.prof[4], (unsigned long long)(clock64() - pct));      // final flushes
+      atomicAdd(&p.prof[5], 1ull);
+      atomicAdd(&p.prof[6], (unsigned long long)nsbk);
+    }
+  }
+}
+
+// ---- the scan, resident pair block + independent waves (the default) ------------------------------------------------------------------
+// Phase stamps and SQ counters of the pipelined kernel above (gpurun r04k, profiles/r04k_*): a wave spent 29 % of its life in the tiles
+// (LDS reads, MFMA, compares, queue), 27 % before its first barrier (unit record -> codes, |c^|^2 -> codeword gathers: three dependent
+// round trips), 23 % issuing flush traffic and DMA, 15 % in the synchronous tail flush, 6 % at barriers; VALU busy 23 %, MFMA busy 15 %
+// of the kernel's cycles -- two workgroups per CU marching in lockstep through a few microseconds of work per unit cannot hide any of it.
+// Here the PAIR BLOCK is the resident operand: one persistent 512-lane workgroup per CU takes a slice = (partition, <= 512 of its pairs,
+// <= MS3_RS of its rows) from a device-side counter, brings the block's f16 residuals into LDS once (128 KiB, LDS-DMA, swizzled as above),
+// and then its eight waves work INDEPENDENTLY: each takes 64-row chunks from an LDS counter, gathers the chunk's reconstruction into
+// registers, runs it against every tile of the block, queues survivors, and issues the flush's atomics at the chunk's end -- their
+// dependent stores go out a chunk later.  No barrier inside a slice: while one wave of a SIMD waits for its gathers the other computes.
+constexpr int MS3_PB = 512;         // pairs resident in LDS (128 KiB at d = 128)
+constexpr int MS3_RS = 1024;        // rows per slice: 16 chunks of 64 for the workgroup's 8 waves
+constexpr int MS3_QCAP = 128;
+struct MsSlice { uint32_t off, np, row_begin, row_count, gs, qp, pad0, pad1; };
+
+// slice_start[p] = exclusive scan of (pair blocks of partition p) x (row slices of partition p)
+__global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__restrict__ pair_starts, const uint32_t *__restrict__ part_offsets, int nlist,
+                                                             uint32_t *__restrict__ slice_start, uint32_t *__restrict__ slice_ctr) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { carry_s = 0; slice_ctr[0] = 0u; }
+  __syncthreads();
+  for (int base = 0; base < nlist; base += 256) {
+    const int i = base + threadIdx.x;
+    uint32_t v = 0;
+    if (i < nlist) {
+      const uint32_t qp = pair_starts[i + 1] - pair_starts[i], np = part_offsets[i + 1] - part_offsets[i];
+      v = ((qp + MS3_PB - 1) / MS3_PB) * ((np + MS3_RS - 1) / MS3_RS);
+    }
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const uint32_t carry = carry_s;
+    if (i < nlist) slice_start[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) slice_start[nlist] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__restrict__ slice_start, const uint32_t *__restrict__ pair_starts,
+                                                            const uint32_t *__restrict__ part_offsets, int nlist, MsSlice *__restrict__ slices) {
+  const int part = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (part >= nlist) return;
+  const uint32_t s0 = slice_start[part], s1 = slice_start[part + 1];
+  if (s1 == s0) return;
+  const uint32_t off = part_offsets[part], np = part_offsets[part + 1] - off;
+  const uint32_t gs = pair_starts[part], qp = pair_starts[part + 1] - gs;
+  const uint32_t npb = (qp + MS3_PB - 1) / MS3_PB;
+  const uint32_t blk = (((qp + npb - 1) / npb) + 31u) & ~31u;      // equal pair blocks, whole tiles of 32 (<= MS3_PB)
+  // row slices vary fastest: the slices of one pair block are taken by different CUs at about the same time (its residuals come from L2)
+  const uint32_t nrs = (np + MS3_RS - 1) / MS3_RS;
+  for (uint32_t t = (uint32_t)lane; t < s1 - s0; t += 64u) {
+    const uint32_t pb = t / nrs, rs = t - pb * nrs;
+    MsSlice u;
+    u.off = off; u.np = np; u.row_begin = rs * (uint32_t)MS3_RS; u.row_count = min((uint32_t)MS3_RS, np - u.row_begin);
+    u.gs = gs + pb * blk; u.qp = min(blk, qp - pb * blk); u.pad0 = u.pad1 = 0u;
+    slices[s0 + t] = u;
+  }
+}
+
+struct Mscan3Args {
+  const MsSlice *slices;
+  const uint32_t *slice_start;  // [nlist + 1]: slice_start[nlist] = number of slices
+  uint32_t *slice_ctr;          // [1] next slice (zeroed by ms_slice_table_kernel)
+  const uint8_t *codes;
+  const _Float16 *cbh;          // [m][256][sd] = f16(-2 sigma c)
+  const float *row_cn2;         // [n] sigma^2 |c^_row|^2
+  const _Float16 *rh;           // [pairs][d]
+  const f4 *prm;                // [pairs] grouped order: {limit sigma^2, -, -, pair}
+  const f2 *prm2;               // [nq * nprobes] by pair: {s / sigma^2, |r|^2 s}
+  uint32_t nan_slot;
+  int nlist, nprobes;
+  uint32_t *seg_cnt, *seg_pos;
+  uint16_t *seg_sum;
+  uint32_t *ovf;
+  const uint32_t *allow;
+};
+
+template <int SD, int KS>
+__global__ __launch_bounds__(512, 2) void ivfpq_mscan3_kernel(Mscan3Args p) {
+  constexpr int D = KS * 16;
+  constexpr int M = D / SD;
+  constexpr int RB = D * 2;                 // bytes of a pair's f16 residual
+  constexpr int CPR = RB / 16;              // 16-byte chunks per pair row (16 / 8)
+  constexpr int RPK = 256 / RB;             // pair rows per 256 bytes (1 / 2): the swizzle key is (row / RPK) & (CPR - 1)
+  constexpr int SPI = 8192 / RB;            // pair slots one 512-lane DMA pass covers (32 / 64)
+  constexpr int PE = MS3_QCAP / 64;
+  __shared__ __attribute__((aligned(16))) char sB[MS3_PB * RB];
+  __shared__ __attribute__((aligned(16))) f4 sP[MS3_PB];
+  __shared__ __attribute__((aligned(8))) uint2 sQ[8][MS3_QCAP + 1];
+  __shared__ uint32_t s_slice, s_chunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const uint32_t nslices = p.slice_start[p.nlist];
+
+  uint2 *myq = sQ[wave];
+  uint32_t qn = 0;      // wave-uniform: queue entries
+  // pending flush: entries whose segment slot has been requested (atomicAdd issued, sum scale requested) but not yet used
+  uint32_t pd_pair[PE], pd_pos[PE], pd_k[PE];
+  float pd_a[PE];
+  f2 pd_yz[PE];
+#pragma unroll
+  for (int i = 0; i < PE; ++i) { pd_pair[i] = 0xFFFFFFFFu; pd_pos[i] = 0u; pd_k[i] = 0u; pd_a[i] = 0.0f; pd_yz[i] = f2{0.0f, 0.0f}; }
+  auto flush_end = [&]() {
+#pragma unroll
+    for (int i = 0; i < PE; ++i) {
+      if (pd_pair[i] != 0xFFFFFFFFu) {
+        const uint32_t k = pd_k[i], pair = pd_pair[i];
+        if (k < (uint32_t)Q_CAP) {
+          const float S = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(pd_a[i], pd_yz[i].x, pd_yz[i].y)), 0.0f, 65535.0f);
+          p.seg_pos[(int64_t)pair * Q_CAP + k] = pd_pos[i];
+          p.seg_sum[(int64_t)pair * Q_CAP + k] = (uint16_t)S;
+        } else if (k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
+          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
+        }
+        pd_pair[i] = 0xFFFFFFFFu;
+      }
+    }
+  };
+  auto flush_begin = [&](uint32_t pos_base) {
+#pragma unroll
+    for (int i = 0; i < PE; ++i) {
+      const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
+      if (e < qn) {
+        const uint2 ent = myq[e];
+        const uint32_t pair = ent.x >> 8, pos = pos_base + (ent.x & 255u);
+        if (row_allowed(p.allow, pos)) {
+          pd_pair[i] = pair; pd_pos[i] = pos; pd_a[i] = __uint_as_float(ent.y);
+          pd_yz[i] = p.prm2[pair];
+          pd_k[i] = atomicAdd(&p.seg_cnt[pair], 1u);
+        }
+      }
+    }
+    qn = 0;
+  };
+
+  for (;;) {
+    __syncthreads();      // every wave is done with the previous slice's block (and with s_slice / s_chunk)
+    if (threadIdx.x == 0) { s_slice = atomicAdd(p.slice_ctr, 1u); s_chunk = 0u; }
+    __syncthreads();
+    const uint32_t slice = s_slice;
+    if (slice >= nslices) break;
+    const MsSlice U = p.slices[slice];
+    const int Qp = (int)U.qp;
+    const int nslots = ((Qp + 31) >> 5) << 5;
+    {
+      // LDS-DMA of the pair block: lane-linear destination, swizzled source; padded slots keep whatever was there (their limit is a NaN)
+      const char *src = reinterpret_cast<const char *>(p.rh + (int64_t)U.gs * D);
+#pragma unroll 4
+      for (int it = 0; it < MS3_PB / SPI; ++it) {
+        const int slot = it * SPI + wave * (SPI / 8) + lane / CPR, k = lane % CPR;
+        if (it * SPI < nslots && slot < Qp)
+          __builtin_amdgcn_global_load_lds((ms_gptr)(src + (int64_t)slot * RB + ((k ^ ((slot / RPK) & (CPR - 1))) << 4)),
+                                           (ms_lptr)(&sB[(it * SPI + wave * (SPI / 8)) * RB]), 16, 0, 0);
+      }
+      const int slot = wave * 64 + lane;
+      if (slot < nslots) {
+        const f4 *ps = slot < Qp ? p.prm + (int64_t)U.gs + slot : p.prm + p.nan_slot;
+        __builtin_amdgcn_global_load_lds((ms_gptr)ps, (ms_lptr)(&sP[wave * 64]), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is ordered for the readers by the issuer's vmcnt(0) + the barrier
+    __syncthreads();
+    const uint32_t nchunks = (U.row_count + 63u) >> 6;
+    const int nblk = nslots >> 5;
+    const int row_end = (int)(U.row_begin + U.row_count);      // <= np
+
+    for (;;) {
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(&s_chunk, 1u);
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      if (c >= nchunks) break;
+      const int row0 = (int)(U.row_begin + c * 64u);
+
+      // A: the f16 reconstruction of this wave's 64 rows, in MFMA operand layout (lane (j, g): row j of the 32-block, k-slice g)
+      ms_h8 a[2][KS];
+      ms_f16v cinit[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int rowc = min(row0 + rb * 32 + j, row_end - 1);
+        uint32_t cw[M / 4];
+        {
+          const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)U.off + rowc) * M);      // rows of 16 / 32 bytes, 16-byte aligned
+#pragma unroll
+          for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
+        }
+        auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if constexpr (SD == 8) {
+            const uint32_t c0 = code(2 * s), c1 = code(2 * s + 1);
+            const int mm = 2 * s + g;
+            a[rb][s] = *reinterpret_cast<const ms_h8 *>(p.cbh + ((int64_t)mm * 256 + (g ? c1 : c0)) * 8);
+          } else {
+            static_assert(SD == 4, "sub-dimension 4 / 8");
+            const uint32_t c0 = g ? code(4 * s + 2) : code(4 * s), c1 = g ? code(4 * s + 3) : code(4 * s + 1);
+            const int mm = 4 * s + 2 * g;
+            const ms_h4 lo = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)mm * 256 + c0) * 4);
+            const ms_h4 hi = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)(mm + 1) * 256 + c1) * 4);
+            a[rb][s] = ms_h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+        // D[row i][query j]: lane (j, g) holds rows i = (v & 3) + 8 (v >> 2) + 4 g of the 32-block (layout as in mfma_assign.hip)
+#pragma unroll
+        for (int vq = 0; vq < 4; ++vq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = row0 + rb * 32 + 8 * vq + 4 * g + e;
+            cinit[rb][vq * 4 + e] = r < row_end ? p.row_cn2[(int64_t)U.off + r] : INFINITY;      // a padded row never passes
+          }
+      }
+      const uint32_t pos_base = U.off + (uint32_t)row0;
+
+      for (int jb = 0; jb < nblk; ++jb) {
+        const int slot = jb * 32 + j;
+        ms_h8 b[KS];
+        const char *br = &sB[slot * RB];
+        const int key = (slot / RPK) & (CPR - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
+        const f4 P = sP[slot];
+        const float lim = P.x;
+        const uint32_t pair8 = __float_as_uint(P.w) << 8;
+        // room for a tile's usual yield (13 survivors at C2); a burst beyond the queue is handled after the tile
+        if (qn > (uint32_t)(MS3_QCAP - 48)) { flush_end(); flush_begin(pos_base); }
+        uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          ms_f16v acc = cinit[rb];
+#pragma unroll
+          for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][s], b[s], acc, 0, 0, 0);
+          uint64_t mk[16];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= lim);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            if (mk[v]) {
+              const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
+                                       (uint32_t)MS3_QCAP);      // entry MS3_QCAP: the bin of a burst
+              if (acc[v] <= lim) {      // (the same compare: the compiler reuses its lane mask as the exec mask)
+                const uint32_t rowl = (uint32_t)(rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * g);
+                myq[idx] = make_uint2(pair8 | rowl, __float_as_uint(acc[v]));
+              }
+              qraw += (uint32_t)__popcll(mk[v]);
+            }
+          }
+        }
+        qn = min(qraw, (uint32_t)MS3_QCAP);
+        if (qraw > (uint32_t)MS3_QCAP) {
+          // more than a queue's worth of survivors in one tile (>= 4 % of its cells pass -- these pairs' segments would overflow anyway):
+          // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
+          // crosses it lists the pair
+          if (g == 0 && slot < Qp) {
+            const uint32_t pair = pair8 >> 8;
+            const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
+            if (k <= (uint32_t)Q_CAP) p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
+          }
+        }
+      }
+      flush_end();              // stores behind the atomics issued a chunk (or a mid-chunk flush) ago
+      flush_begin(pos_base);    // atomics for this chunk's survivors; their stores go out at the next chunk's end
+    }
+  }
   flush_end();
 }
 
@@ -613,6 +796,10 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   uint64_t units = 0;
   for (uint32_t pid = 0; pid < ix->nlist; ++pid) units += cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), MS_RW);
   mc->max_units = (uint32_t)std::min<uint64_t>(units, 0x7FFFFFF0u);
+  for (uint32_t pid = 0; pid < ix->nlist; ++pid) {
+    const uint32_t rs = (uint32_t)cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), MS3_RS);
+    mc->sum_rs += rs; mc->max_rs = std::max(mc->max_rs, rs);
+  }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {   // other contexts (streams) search the same index
     drop();
     set_error("matrix-core scan: building the index constants failed");
@@ -633,6 +820,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   if (!ms_shape(ix, &sd, &ks)) return -1;
   LH_TRY(mscan_prepare(ctx, ix));
   if (!ix->ms->usable || ix->ms->max_units == 0) return -1;
+  static const bool v2 = getenv("LANCE_HIP_MS_V2") != nullptr || getenv("LANCE_HIP_MS_PROF") != nullptr;      // the pipelined kernel, kept for A/B
   const int d = (int)ix->d, nlist = (int)ix->nlist;
   const size_t npairs = (size_t)nq * nprobes;
   _Float16 *rh = reinterpret_cast<_Float16 *>(ctx->scratch("ms.rh", (npairs + 32) * (size_t)d * 2));
@@ -641,9 +829,10 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   uint32_t *unit_start = ctx->scratch_t<uint32_t>("ms.unit_start", (size_t)nlist + 1);
   MsUnit *units = reinterpret_cast<MsUnit *>(ctx->scratch("ms.units", ((size_t)ix->ms->max_units + 8) * sizeof(MsUnit)));
   const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
+  f2 *prm2 = reinterpret_cast<f2 *>(ctx->scratch("ms.prm2", npairs * 8));
   uint16_t *seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", npairs * Q_CAP);   // the merge launcher asks for the same slot
   uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // likewise
-  if (!rh || !prm || !qslack || !unit_start || !units || !seg_sum || !ovf) return LANCE_HIP_ENOMEM;
+  if (!rh || !prm || !qslack || !unit_start || !units || !prm2 || !seg_sum || !ovf) return LANCE_HIP_ENOMEM;
   {
     ScopedTimer t(ctx, "q_residual");
     LH_CHECK_HIP(lh::memset_async(seg_cnt, 0, npairs * 4, ctx->stream));
@@ -654,27 +843,68 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.q = qs; pa.centroids = ix->centroids; pa.pair_idx = pair_idx; pa.pair_starts = pair_starts; pa.probes = probes; pa.tbound = tbound;
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     pa.sigma = ix->ms->sigma; pa.rh = rh; pa.prm = prm; pa.qslack = qslack; pa.seg_cnt = seg_cnt; pa.qovf = qovf; pa.ovf = ovf;
-    pa.nan_slot = nan_slot;
+    pa.nan_slot = nan_slot; pa.prm2 = prm2;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
-    hipLaunchKernelGGL(ms_unit_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, unit_start);
-    hipLaunchKernelGGL(ms_unit_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, unit_start, pair_starts, ix->part_offsets,
-                       nlist, units);
+    if (v2) {
+      hipLaunchKernelGGL(ms_unit_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, unit_start);
+      hipLaunchKernelGGL(ms_unit_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, unit_start, pair_starts, ix->part_offsets,
+                         nlist, units);
+    }
+  }
+  if (!v2) {
+    // slices: at most sum over the partitions of (row slices) x (pair blocks), pair blocks <= pairs / MS3_PB + 1 per partition
+    const uint64_t cap = (uint64_t)ix->ms->sum_rs + (uint64_t)ix->ms->max_rs * cdiv(npairs, MS3_PB) + 8;
+    uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2);      // [nlist + 1], then the work counter
+    MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
+    if (!slice_start || !slices) return LANCE_HIP_ENOMEM;
+    uint32_t *slice_ctr = slice_start + nlist + 1;
+    {
+      ScopedTimer tq(ctx, "q_residual");
+      hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, slice_start, slice_ctr);
+      hipLaunchKernelGGL(ms_slice_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, slice_start, pair_starts, ix->part_offsets,
+                         nlist, slices);
+    }
+    ScopedTimer t(ctx, "ivfpq_scan_c1");
+    ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
+    Mscan3Args a3;
+    a3.slices = slices; a3.slice_start = slice_start; a3.slice_ctr = slice_ctr; a3.codes = ix->codes;
+    a3.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a3.row_cn2 = ix->ms->row_cn2; a3.rh = rh; a3.prm = prm; a3.prm2 = prm2;
+    a3.nan_slot = nan_slot; a3.nlist = nlist; a3.nprobes = (int)nprobes;
+    a3.seg_cnt = seg_cnt; a3.seg_pos = seg_pos; a3.seg_sum = seg_sum; a3.ovf = ovf; a3.allow = allow;
+    const unsigned grid3 = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus, cap);
+    if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<8, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
+    else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<4, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
+    else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan3_kernel<4, 4>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
+    else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
+    LH_CHECK_HIP(hipGetLastError());
+    if (qslack_out) *qslack_out = qslack;
+    return LANCE_HIP_OK;
   }
   ScopedTimer t(ctx, "ivfpq_scan_c1");
   MscanArgs a;
   a.unit_start = unit_start; a.pair_starts = pair_starts; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm;
-  a.nlist = nlist; a.nprobes = (int)nprobes; a.m = (int)ix->m; a.units = units; a.nan_slot = nan_slot;
+  a.nlist = nlist; a.nprobes = (int)nprobes; a.m = (int)ix->m; a.units = units; a.nan_slot = nan_slot; a.prm2 = prm2;
   a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_sum = seg_sum; a.qovf = qovf; a.ovf = ovf; a.allow = allow;
   const unsigned grid = (ix->ms->max_units + 7u) & ~7u;
   ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
-  static const bool v1 = getenv("LANCE_HIP_MS_V1") != nullptr;      // the unpipelined first version, kept for A/B
-  if (!v1 && sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<8, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (!v1 && sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (!v1 && sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan_kernel<8, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan_kernel<4, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan_kernel<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, a);
+  static const bool prof = getenv("LANCE_HIP_MS_PROF") != nullptr;  // s_memtime phase stamps of the pipelined kernel (printed per launch)
+  if (prof) {
+    a.prof = ctx->scratch_t<unsigned long long>("ms.prof", 8);
+    if (!a.prof) return LANCE_HIP_ENOMEM;
+    LH_CHECK_HIP(lh::memset_async(a.prof, 0, 64, ctx->stream));
+    if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<8, 8, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 8, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 4, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    unsigned long long h[8];
+    LH_CHECK_HIP(hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (h[5])
+      fprintf(stderr, "[ms prof] waves=%llu super-blocks/wave %.2f | 100 MHz clocks per wave: prologue %.0f | barrier waits %.0f | flush + DMA issue %.0f | tiles %.0f | tail %.0f\n",
+              h[5], (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
+  } else if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<8, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
+  else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
+  else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, a);
   else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
   LH_CHECK_HIP(hipGetLastError());
   if (qslack_out) *qslack_out = qslack;
