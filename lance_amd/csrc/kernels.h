@@ -150,12 +150,12 @@ int qbound_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float 
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
                   uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow,
-                  const uint32_t *qslack = nullptr);
+                  const uint32_t *qslack = nullptr, const float *seg_val = nullptr, const float *seg_scale = nullptr);
 // search_ms.hip: the filter scan as a [rows x d] x [d x queries] product per partition on the matrix cores (8-bit PQ, d = 64 / 128, M = 16 / 32)
 bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
 int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *probes,
                  const uint32_t *pair_starts, const uint32_t *pair_idx, const uint32_t *tbound, uint32_t *seg_cnt, uint32_t *seg_pos,
-                 uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out);
+                 uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out);
 void mscan_cut_params(int *cut_shift, uint32_t *cut_slack);
 
 }  // namespace lh

@@ -138,6 +138,7 @@ struct MsPrepArgs {
   uint32_t *seg_cnt, *qovf, *ovf;
   uint32_t nan_slot;            // index into prm of the NaN-limit record (written here, loaded by the scan for padded pair slots)
   f2 *prm2;                     // [nq * nprobes] by PAIR: {s / sigma^2, |r|^2 s} -- what turns an accumulator value into the survivor's integer sum
+  int rel_limit;                // rows-on-lanes kernel: the accumulator starts at |c^|^2 - limit, prm2.y carries the limit's share of the sum
 };
 
 constexpr int MS_PPW = 4;      // pairs per wave of the pre-pass: their loads are in flight together (one pair per wave was 100k waves of
@@ -203,7 +204,9 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
   f4 o;
   if (ok) {
     o.x = lim * sig2; o.y = s / sig2; o.z = n2l * s;
-    p.prm2[pairl] = f2{o.y, o.z};
+    // by pair, for the flush: sum = (accumulator value relative to the limit) * y + (T (1 + 2^-17) + E) s; the pipelined / queries-on-lanes
+    // kernels queue the accumulator itself and read .z' = |r|^2 s through rel == 0
+    p.prm2[pairl] = p.rel_limit ? f2{o.y, ((T * 1.0000077f + E)) * s} : f2{o.y, o.z};
     atomicMax(&p.qslack[q], (uint32_t)ceilf(eu));
   } else {
     // this (query, partition) pair goes to the exact rescan (ivfpq_qrescan_kernel), as an overflowed segment does.  The limit is a
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
 // registers, runs it against every tile of the block, queues survivors, and issues the flush's atomics at the chunk's end -- their
 // dependent stores go out a chunk later.  No barrier inside a slice: while one wave of a SIMD waits for its gathers the other computes.
 constexpr int MS3_PB = 512;         // pairs resident in LDS (128 KiB at d = 128)
-constexpr int MS3_RS = 1024;        // rows per slice: 16 chunks of 64 for the workgroup's 8 waves
+constexpr int MS3_RS = 2048;        // rows per slice (64 chunks of 32 for sixteen waves): the block's DMA + two barriers + the wait for the slowest wave are paid per slice
 constexpr int MS3_QCAP = 128;
 struct MsSlice { uint32_t off, np, row_begin, row_count, gs, qp, pad0, pad1; };
 
@@ -550,8 +553,11 @@ struct Mscan3Args {
   int nlist, nprobes;
   uint32_t *seg_cnt, *seg_pos;
   uint16_t *seg_sum;
+  float *seg_val = nullptr;     // rows-on-lanes kernel: [nq * nprobes][Q_CAP] the survivors' accumulator values (the merge kernel scales them)
   uint32_t *ovf;
   const uint32_t *allow;
+  int dbg = 0;                          // LANCE_HIP_MS_DBG (timing experiments, results WRONG): 1 = the flush drops its entries, 2 = every limit a NaN (nothing passes)
+  unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1 (rows-on-lanes kernel): [0] stage [1] gather [2] tiles [3] flush [4] life [5] waves [6] chunks [7] longest life
 };
 
 template <int SD, int KS>
@@ -743,6 +749,221 @@ __global__ __launch_bounds__(512, 2) void ivfpq_mscan3_kernel(Mscan3Args p) {
   flush_end();
 }
 
+// ---- the scan, rows on the lanes (the default) -------------------------------------------------------------------------------------------
+// SQ counters of the kernel above (gpurun r04l): 0.242 ms, VALU busy 23 %, MFMA busy 17 %, waves waiting 47 % of their cycles -- with two
+// waves per SIMD (244 VGPRs) each wave's ~290 instructions per tile run at ~16 cycles apiece (LDS round trip in front of the MFMA chain,
+// the chain itself, scalar branches on sixteen masks) and one sibling wave cannot fill that.  Same slices, same block in LDS, but the
+// operands of the MFMA trade places: D = Q x R^T, queries down the accumulator registers, ROWS across the lanes.  The accumulator then
+// starts at one value per lane (|c^|^2 of the lane's row: 1 VGPR instead of 32), a wave carries ONE 32-row block (32 VGPRs of
+// reconstruction instead of 64), and the kernel fits in 128 VGPRs: sixteen waves per CU, four per SIMD.  Limits come per query = per
+// accumulator register (four broadcast ds_read_b128 per tile); a queue entry names the pair's LDS slot, resolved at flush time.
+constexpr int MS4_QH = 64;          // entries per queue half (one per lane)
+template <int SD, int KS, bool PROF = false>
+__global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
+  constexpr int D = KS * 16;
+  constexpr int M = D / SD;
+  constexpr int RB = D * 2;                 // bytes of a pair's f16 residual
+  constexpr int CPR = RB / 16;              // 16-byte chunks per pair row (16 / 8)
+  constexpr int RPK = 256 / RB;             // pair rows per 256 bytes (1 / 2): the swizzle key is (row / RPK) & (CPR - 1)
+  constexpr int SPI = 16384 / RB;           // pair slots one 1024-lane DMA pass covers (64 / 128)
+  __shared__ __attribute__((aligned(16))) char sB[MS3_PB * RB];
+  __shared__ __attribute__((aligned(16))) float sLim[MS3_PB];
+  __shared__ __attribute__((aligned(16))) uint32_t sPair[MS3_PB];
+  __shared__ __attribute__((aligned(8))) uint2 sQ[16][2][MS4_QH + 1];      // per wave: two halves (fill one while the other's atomics are in flight)
+  __shared__ uint32_t s_slice, s_chunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const uint32_t nslices = p.slice_start[p.nlist];
+
+  uint2 *const qw = &sQ[wave][0][0];
+  uint32_t cur = 0;     // wave-uniform: offset (entries) of the half being filled; the other half's segment slots have been requested
+  uint32_t qn = 0;      // wave-uniform: entries in the half being filled
+  uint32_t pd_n = 0, pd_base = 0;      // wave-uniform: entries of the other half in flight (this lane's slot in pd_k), their chunk's first position
+  uint32_t pd_k = 0;
+  long long pc_t0 = 0, pc_stage = 0, pc_gather = 0, pc_tiles = 0, pc_flush = 0, pct = 0, pc_nchunk = 0;      // PROF: s_memtime stamps
+  if constexpr (PROF) { pc_t0 = clock64(); pct = pc_t0; }
+  // Flush in two steps, one queue half apart: flush_begin requests a segment slot per entry of the full half (atomicAdd, nothing waits)
+  // and the halves trade places; flush_end -- called before the NEXT flush_begin, several tiles later -- writes position and value behind
+  // the slots.  One register of pending state per lane (the first rows-on-lanes build kept pair / position / value / scale there and
+  // spilled; a synchronous flush measured 33 % of a wave's life, gpurun r04n).  A queue entry names the pair's LDS slot, so both steps
+  // run while the slice's block is resident.
+  auto flush_end = [&]() {
+    if (pd_n) {
+      if ((uint32_t)lane < pd_n && pd_k != 0xFFFFFFFFu) {
+        const uint2 ent = qw[((uint32_t)(MS4_QH + 1) - cur) + (uint32_t)lane];
+        const uint32_t pair = sPair[ent.x >> 8];
+        if (pd_k < (uint32_t)Q_CAP) {
+          p.seg_pos[(int64_t)pair * Q_CAP + pd_k] = pd_base + (ent.x & 255u);
+          p.seg_val[(int64_t)pair * Q_CAP + pd_k] = __uint_as_float(ent.y);
+        } else if (pd_k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
+          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
+        }
+      }
+      pd_n = 0;
+    }
+  };
+  auto flush_begin = [&](uint32_t pos_base) {      // (after flush_end)
+    pd_k = 0xFFFFFFFFu;
+    if ((uint32_t)lane < qn && !(p.dbg & 1)) {
+      const uint2 ent = qw[cur + (uint32_t)lane];
+      if (row_allowed(p.allow, pos_base + (ent.x & 255u))) pd_k = atomicAdd(&p.seg_cnt[sPair[ent.x >> 8]], 1u);
+    }
+    pd_n = qn; pd_base = pos_base; qn = 0;
+    cur = (uint32_t)(MS4_QH + 1) - cur;
+  };
+
+  for (;;) {
+    __syncthreads();      // every wave is done with the previous slice's block (and with s_slice / s_chunk)
+    if (threadIdx.x == 0) { s_slice = atomicAdd(p.slice_ctr, 1u); s_chunk = 0u; }
+    __syncthreads();
+    const uint32_t slice = s_slice;
+    if (slice >= nslices) break;
+    const MsSlice U = p.slices[slice];
+    const int Qp = (int)U.qp;
+    const int nslots = ((Qp + 31) >> 5) << 5;
+    {
+      // LDS-DMA of the pair block: lane-linear destination, swizzled source; padded slots keep whatever was there (their limit is a NaN)
+      const char *src = reinterpret_cast<const char *>(p.rh + (int64_t)U.gs * D);
+#pragma unroll 4
+      for (int it = 0; it < MS3_PB / SPI; ++it) {
+        const int slot = it * SPI + wave * (SPI / 16) + lane / CPR, k = lane % CPR;
+        if (it * SPI < nslots && slot < Qp)
+          __builtin_amdgcn_global_load_lds((ms_gptr)(src + (int64_t)slot * RB + ((k ^ ((slot / RPK) & (CPR - 1))) << 4)),
+                                           (ms_lptr)(&sB[(it * SPI + wave * (SPI / 16)) * RB]), 16, 0, 0);
+      }
+      // limits (waves 0-7) and pair ids (waves 8-15): one dword per slot out of the {limit, -, -, pair} records
+      const int slot = (wave & 7) * 64 + lane;
+      if (slot < nslots) {
+        const float *ps = reinterpret_cast<const float *>(slot < Qp && !(p.dbg & 2) ? p.prm + (int64_t)U.gs + slot : p.prm + p.nan_slot);
+        if (wave < 8) __builtin_amdgcn_global_load_lds((ms_gptr)ps, (ms_lptr)(&sLim[(wave & 7) * 64]), 4, 0, 0);
+        else __builtin_amdgcn_global_load_lds((ms_gptr)(ps + 3), (ms_lptr)(&sPair[(wave & 7) * 64]), 4, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is ordered for the readers by the issuer's vmcnt(0) + the barrier
+    __syncthreads();
+    if constexpr (PROF) { const long long t = clock64(); pc_stage += t - pct; pct = t; }
+    const uint32_t nchunks = (U.row_count + 31u) >> 5;
+    const int nblk = nslots >> 5;
+    const int row_end = (int)(U.row_begin + U.row_count);      // <= np
+
+    for (;;) {
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(&s_chunk, 1u);
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      if (c >= nchunks) break;
+      const int row0 = (int)(U.row_begin + c * 32u);
+
+      // the f16 reconstruction of the wave's 32 rows as the MFMA's B operand (lane (j, g): row j, k-slice g), |c^|^2 of row j
+      ms_h8 rw[KS];
+      float cn2v;
+      {
+        const int rowc = min(row0 + j, row_end - 1);
+        uint32_t cw[M / 4];
+        {
+          const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)U.off + rowc) * M);      // rows of 16 / 32 bytes, 16-byte aligned
+#pragma unroll
+          for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
+        }
+        cn2v = row0 + j < row_end ? p.row_cn2[(int64_t)U.off + rowc] : INFINITY;      // a padded row never passes
+        auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if constexpr (SD == 8) {
+            const uint32_t c0 = code(2 * s), c1 = code(2 * s + 1);
+            const int mm = 2 * s + g;
+            rw[s] = *reinterpret_cast<const ms_h8 *>(reinterpret_cast<const char *>(p.cbh) + (uint32_t)(((uint32_t)mm * 256u + (g ? c1 : c0)) * 16u));
+          } else {
+            static_assert(SD == 4, "sub-dimension 4 / 8");
+            const uint32_t c0 = g ? code(4 * s + 2) : code(4 * s), c1 = g ? code(4 * s + 3) : code(4 * s + 1);
+            const int mm = 4 * s + 2 * g;
+            const ms_h4 lo = *reinterpret_cast<const ms_h4 *>(reinterpret_cast<const char *>(p.cbh) + (uint32_t)(((uint32_t)mm * 256u + c0) * 8u));
+            const ms_h4 hi = *reinterpret_cast<const ms_h4 *>(reinterpret_cast<const char *>(p.cbh) + (uint32_t)(((uint32_t)(mm + 1) * 256u + c1) * 8u));
+            rw[s] = ms_h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        }
+      }
+      const uint32_t pos_base = U.off + (uint32_t)row0;
+      if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gathers have landed: what follows is the tiles' own time
+        const long long t = clock64(); pc_gather += t - pct; pct = t;
+      }
+
+      for (int jb = 0; jb < nblk; ++jb) {
+        // A: the tile's 32 queries (lane (i, g): query i, k-slice g); D[query i][row j]: lane (j, g) holds queries i = (v & 3) + 8 (v >> 2) + 4 g
+        const int slot = jb * 32 + j;
+        ms_h8 qa[KS];
+        const char *br = &sB[slot * RB];
+        const int key = (slot / RPK) & (CPR - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qa[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
+        // the accumulator starts at |c^|^2 - limit (row's constant minus the query's limit): the test is a compare with zero and neither
+        // sixteen limits nor a sixteen-register splat of |c^|^2 stay live across the tile (128 VGPRs = four waves per SIMD)
+        ms_f16v acc;
+        {
+          const f4 *lp = reinterpret_cast<const f4 *>(&sLim[jb * 32 + 4 * g]);
+#pragma unroll
+          for (int vq = 0; vq < 4; ++vq) {
+            const f4 t = lp[2 * vq];
+            acc[4 * vq] = cn2v - t.x; acc[4 * vq + 1] = cn2v - t.y; acc[4 * vq + 2] = cn2v - t.z; acc[4 * vq + 3] = cn2v - t.w;
+          }
+        }
+        const uint32_t ebase = ((uint32_t)(jb * 32 + 4 * g) << 8) | (uint32_t)j;
+        // room for a tile's usual yield; a burst beyond the queue is handled after the tile
+        if (qn > (uint32_t)(MS4_QH - 32)) {      // room for a tile's usual yield (6-7 survivors at C2); a burst beyond the half is handled after the tile
+          if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; }
+          flush_end(); flush_begin(pos_base);
+          if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; }
+        }
+        uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s], rw[s], acc, 0, 0, 0);
+        uint64_t mk[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= 0.0f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          if (mk[v]) {
+            const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
+                                     (uint32_t)MS4_QH);      // entry MS4_QH: the bin of a burst
+            if (acc[v] <= 0.0f)      // (the same compare: the compiler reuses its lane mask as the exec mask)
+              qw[cur + idx] = make_uint2(ebase + ((uint32_t)((v & 3) + 8 * (v >> 2)) << 8), __float_as_uint(acc[v]));
+            qraw += (uint32_t)__popcll(mk[v]);
+          }
+        }
+        qn = min(qraw, (uint32_t)MS4_QH);
+        if (qraw > (uint32_t)MS4_QH) {
+          // more than the half's room in one tile (>= 2 % of its cells pass -- these pairs' segments would overflow anyway):
+          // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
+          // crosses it lists the pair
+          if (g == 0 && slot < Qp) {
+            const uint32_t pair = sPair[slot];
+            const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
+            if (k <= (uint32_t)Q_CAP) p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
+          }
+        }
+      }
+      if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; }
+      flush_end(); flush_begin(pos_base);      // (positions are relative to the chunk: a half never spans two chunks)
+      if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; ++pc_nchunk; }
+    }
+    flush_end();      // before the block (and its pair ids) leaves LDS
+  }
+  if constexpr (PROF) {
+    if (lane == 0) {
+      const long long t1 = clock64();
+      atomicAdd(&p.prof[0], (unsigned long long)pc_stage);    // slice counter, DMA of the block, barriers, waiting for the slowest wave
+      atomicAdd(&p.prof[1], (unsigned long long)pc_gather);   // codes -> codeword gathers, |c^|^2
+      atomicAdd(&p.prof[2], (unsigned long long)pc_tiles);    // LDS reads, MFMA, compares, queue
+      atomicAdd(&p.prof[3], (unsigned long long)pc_flush);    // queue -> atomics -> stores
+      atomicAdd(&p.prof[4], (unsigned long long)(t1 - pc_t0));
+      atomicAdd(&p.prof[5], 1ull);
+      atomicAdd(&p.prof[6], (unsigned long long)pc_nchunk);
+      atomicMax(&p.prof[7], (unsigned long long)(t1 - pc_t0));
+    }
+  }
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------------
 static bool ms_shape(const lance_hip_index *ix, int *sd_out, int *ks_out) {
   if (!ix || ix->m == 0 || ix->nbits != 8 || ix->d % ix->m != 0) return false;
@@ -814,13 +1035,14 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
 // Replaces qscan_launch: same outputs (seg_cnt / seg_pos / seg_sum / qovf / ovf), plus qslack for the merge kernel's cut.
 int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *probes,
                  const uint32_t *pair_starts, const uint32_t *pair_idx, const uint32_t *tbound, uint32_t *seg_cnt, uint32_t *seg_pos,
-                 uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out) {
+                 uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out) {
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);   // the constants are a cache attached to the index
   int sd = 0, ks = 0;
   if (!ms_shape(ix, &sd, &ks)) return -1;
   LH_TRY(mscan_prepare(ctx, ix));
   if (!ix->ms->usable || ix->ms->max_units == 0) return -1;
-  static const bool v2 = getenv("LANCE_HIP_MS_V2") != nullptr || getenv("LANCE_HIP_MS_PROF") != nullptr;      // the pipelined kernel, kept for A/B
+  static const bool v2 = getenv("LANCE_HIP_MS_V2") != nullptr || (getenv("LANCE_HIP_MS_PROF") != nullptr && getenv("LANCE_HIP_MS_PROF4") == nullptr);      // the pipelined kernel, kept for A/B
+  static const bool v3 = getenv("LANCE_HIP_MS_V3") != nullptr;      // queries on the lanes, 8 waves per CU: kept for A/B
   const int d = (int)ix->d, nlist = (int)ix->nlist;
   const size_t npairs = (size_t)nq * nprobes;
   _Float16 *rh = reinterpret_cast<_Float16 *>(ctx->scratch("ms.rh", (npairs + 32) * (size_t)d * 2));
@@ -843,7 +1065,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.q = qs; pa.centroids = ix->centroids; pa.pair_idx = pair_idx; pa.pair_starts = pair_starts; pa.probes = probes; pa.tbound = tbound;
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     pa.sigma = ix->ms->sigma; pa.rh = rh; pa.prm = prm; pa.qslack = qslack; pa.seg_cnt = seg_cnt; pa.qovf = qovf; pa.ovf = ovf;
-    pa.nan_slot = nan_slot; pa.prm2 = prm2;
+    pa.nan_slot = nan_slot; pa.prm2 = prm2; pa.rel_limit = (!v2 && !v3) ? 1 : 0;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
     if (v2) {
       hipLaunchKernelGGL(ms_unit_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, unit_start);
@@ -871,13 +1093,36 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     a3.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a3.row_cn2 = ix->ms->row_cn2; a3.rh = rh; a3.prm = prm; a3.prm2 = prm2;
     a3.nan_slot = nan_slot; a3.nlist = nlist; a3.nprobes = (int)nprobes;
     a3.seg_cnt = seg_cnt; a3.seg_pos = seg_pos; a3.seg_sum = seg_sum; a3.ovf = ovf; a3.allow = allow;
+    if (!v3) {
+      a3.seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
+      if (!a3.seg_val) return LANCE_HIP_ENOMEM;
+    }
     const unsigned grid3 = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus, cap);
-    if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<8, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
+    static const int dbg = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
+    a3.dbg = dbg;
+    static const bool prof4 = getenv("LANCE_HIP_MS_PROF4") != nullptr;      // s_memtime phase stamps of the rows-on-lanes kernel (d = 128, M = 16)
+    if (prof4 && !v3 && sd == 8 && ks == 8) {
+      a3.prof = ctx->scratch_t<unsigned long long>("ms.prof", 8);
+      if (!a3.prof) return LANCE_HIP_ENOMEM;
+      LH_CHECK_HIP(lh::memset_async(a3.prof, 0, 64, ctx->stream));
+      hipLaunchKernelGGL((ivfpq_mscan4_kernel<8, 8, true>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
+      unsigned long long h[8];
+      LH_CHECK_HIP(hipMemcpyAsync(h, a3.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
+      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (h[5])
+        fprintf(stderr, "[ms4 prof] waves=%llu chunks/wave %.2f | s_memtime ticks per wave: stage+barriers %.0f | gather %.0f | tiles %.0f | flush %.0f | life %.0f (longest %llu)\n",
+                h[5], (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[7]);
+    } else
+    if (!v3 && sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan4_kernel<8, 8>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
+    else if (!v3 && sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan4_kernel<4, 8>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
+    else if (!v3 && sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan4_kernel<4, 4>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
+    else if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<8, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
     else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<4, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
     else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan3_kernel<4, 4>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
     else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
     LH_CHECK_HIP(hipGetLastError());
     if (qslack_out) *qslack_out = qslack;
+    if (!v3) { *seg_val_out = a3.seg_val; *seg_scale_out = reinterpret_cast<float *>(prm2); }
     return LANCE_HIP_OK;
   }
   ScopedTimer t(ctx, "ivfpq_scan_c1");

@@ -683,12 +683,13 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   // timers inside: "q_residual" (memsets + residual pre-pass) and "ivfpq_scan_c1" (the filter scan kernel alone)
   // search_ms.hip: the filter as a matrix product per partition (its own pre-pass; same segment outputs + a per-query slack for the merge cut)
   uint32_t *qslack = nullptr;
+  float *seg_val = nullptr, *seg_scale = nullptr;      // rows-on-lanes kernel: the survivors' accumulator values + the per-pair scale of their sums
   int ms_rc = -1;
   if (mscan_supported(ix, nq, nprobes))
-    ms_rc = mscan_launch(ctx, ix, qs, nq, nprobes, probes, pair_starts, pair_idx, tbound, seg_cnt, seg_pos, qovf, allow, &qslack);
+    ms_rc = mscan_launch(ctx, ix, qs, nq, nprobes, probes, pair_starts, pair_idx, tbound, seg_cnt, seg_pos, qovf, allow, &qslack, &seg_val, &seg_scale);
   if (ms_rc > 0) return ms_rc;
   if (ms_rc < 0) {
-    qslack = nullptr;
+    qslack = nullptr; seg_val = nullptr; seg_scale = nullptr;
     LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow, probes));
   }
   static const bool q_stats = getenv("LANCE_HIP_Q_STATS") != nullptr;
@@ -721,7 +722,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     o.out_ids = ids; o.out_dists = dists; o.cand_rid = cand_rid; o.cand_cnt = cand_cnt; o.flags = flags;
     o.part_offsets = ix->part_offsets; o.nlist = nlist;
     ScopedTimer t(ctx, "ivfpq_merge");
-    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o, allow, qslack));
+    LH_TRY(qmerge_launch(ctx, ix, qs, nq, probes, nprobes, tbound, tglobal, seg_cnt, seg_pos, qovf, pool_key, pool_pos, pool_cnt, pool_cap, o, allow, qslack, seg_val, seg_scale));
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;

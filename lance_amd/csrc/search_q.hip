@@ -477,6 +477,8 @@ struct QmergeArgs {
   int cut_shift;                 // histogram bin = sum >> cut_shift (512 bins cover 0 .. LIM)
   uint32_t cut_slack;            // a survivor whose sum exceeds (upper edge of the keff-th bin) + cut_slack cannot reach the top keff
   const uint32_t *qslack;        // search_ms.hip: [nq] per-query bound of |sum - dist * s| (units); the cut carries twice that on top of cut_slack
+  const float *seg_val;          // search_ms.hip (rows-on-lanes kernel): [nq * nprobes][Q_CAP] the survivors' accumulator values instead of seg_sum;
+  const f2 *seg_scale;           //   sum = rint(val * seg_scale[pair].x + seg_scale[pair].y), clamped to 0 .. 65535
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
   uint32_t *tglobal;             // class B: running bound of the exact pair kernel
   const uint32_t *seg_cnt, *seg_pos;
@@ -626,6 +628,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   uint32_t *skey = reinterpret_cast<uint32_t *>(rid + SCAN_LCAP);        // [SCAN_LCAP]
   uint32_t *spos = skey + SCAN_LCAP;                                     // [SCAN_LCAP]
   __shared__ uint32_t s_cnt[QM_G + 1], s_pre[QM_G + 1];
+  __shared__ f2 s_yz[QM_G];
   __shared__ int s_amb;
   // Round 3: the survivors arrive with their integer sums S.  For one query all sums share one scale s, and
   // S - lo <= dist * s <= S + hi (lo, hi = the rounding slacks of the table encoding), so once keff survivors have S <= B every
@@ -676,6 +679,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
       if ((int)threadIdx.x < ng) {
         const uint32_t c = a.seg_cnt[(int64_t)q * a.nprobes + g0 + threadIdx.x];
         s_cnt[threadIdx.x] = c > (uint32_t)Q_CAP ? 0u : c;
+        if (a.seg_val) s_yz[threadIdx.x] = a.seg_scale[(int64_t)q * a.nprobes + g0 + threadIdx.x];
       }
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -692,7 +696,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
           const int pi = (int)s_pre[i];
           if (t >= pi) { rr = i; st = pi; }
         }
-        const uint32_t sv = a.seg_sum[((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st)];
+        const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
+        const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a.seg_val[e], s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
+                                      : (uint32_t)a.seg_sum[e];
         atomicAdd(&s_hist[min(511u, sv >> a.cut_shift)], 1u);
       }
     }
@@ -749,6 +755,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
       if ((int)threadIdx.x < ng) {
         const uint32_t c = a.seg_cnt[(int64_t)q * a.nprobes + g0 + threadIdx.x];
         s_cnt[threadIdx.x] = c > (uint32_t)Q_CAP ? 0u : c;    // an overflowed segment comes through the pool (rescan kernel)
+        if (a.seg_val) s_yz[threadIdx.x] = a.seg_scale[(int64_t)q * a.nprobes + g0 + threadIdx.x];
       }
       if (a.vec4) {
         // long rows (C3: 5 probes x 1536 elements per group): 16-byte loads, four independent ones in flight per lane -- the
@@ -798,7 +805,8 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
             if (t >= pi) { rr = i; st = pi; }   // s_pre[] is non-decreasing and t < s_pre[QM_G]: the last hit is the segment
           }
           const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
-          const uint32_t sv = (uint32_t)a.seg_sum[e];
+          const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a.seg_val[e], s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
+                                        : (uint32_t)a.seg_sum[e];
           if (sv >= range_lo && sv <= range_hi) {
             const uint32_t slot = atomicAdd(&l_cnt, 1u);
             l_pos[slot] = a.seg_pos[e]; l_rr[slot] = (uint8_t)rr;
@@ -1132,10 +1140,10 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
                   uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow,
-                  const uint32_t *qslack) {
+                  const uint32_t *qslack, const float *seg_val, const float *seg_scale) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
-  a.qslack = qslack;
+  a.qslack = qslack; a.seg_val = seg_val; a.seg_scale = reinterpret_cast<const f2 *>(seg_scale);
   a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
   a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
