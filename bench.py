@@ -316,6 +316,7 @@ def main():
     exact_replays = eng.search_stats()
     kt = {kname: eng.timing_query(kname) for kname in ("dist_matrix", "select_probes", "pm_group", "ivfpq_scan", "ivfpq_scan_c0",
                                                        "q_residual", "ivfpq_scan_c1", "ivfpq_merge", "ivfpq_exact", "refine")}
+    mscan = eng.timing_query("ivfpq_mscan")[1] > 0      # the main pass ran as the matrix-core filter scan (search_ms.hip)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -391,7 +392,7 @@ def main():
     # HBM traffic of the dominant kernel: measured IN THIS RUN by two rocprofv3 --pmc child passes (collect_pmc_traffic); the figure
     # recorded under profiles/ in an earlier round is kept beside it under its own key, never as `traffic`
     traffic, traffic_src, traffic_detail = None, None, None
-    pmc_kernel = "ivfpq_qscan_kernel<8, 1" if (quantised and args.config == "c2") else None
+    pmc_kernel = ("ivfpq_mscan4_kernel<8, 8" if mscan else "ivfpq_qscan_kernel<8, 1") if (quantised and args.config == "c2") else None
     if pmc_kernel and not args.no_pmc and world == 1:
         child = ["--steps", "3", "--warmup", "1", "--streams", "1", "--no-cpu-baseline", "--no-pmc", "--config", args.config, "--n", str(args.n),
                  "--nq", str(args.nq), "--nprobes", str(args.nprobes), "--refine", str(args.refine), "--k", str(args.k)]
@@ -481,23 +482,41 @@ def main():
         # frac_of_measured_gather (that kernel shares the scan's bank-conflict pathology: it is a floor for "what this table shape
         # can deliver", not a roofline)
         "roofline_build": roofline_build,
-        "roofline": {"kernel": kernel_name, "bound": "lds", "achieved": gather_rate / 1e9, "peak": guide_lds_peak / 1e9,
-                     "unit": "G lane-gathers/s", "frac": gather_rate / guide_lds_peak,
-                     "peak_source": "MI355X_MICROARCH.md, LDS: ds_read_b64 conflict-free = 32 lanes/clk/CU x 256 CUs x 2.4 GHz",
-                     "frac_of_measured_gather": gather_rate / ceiling if ceiling else None,
-                     "measured_gather_G_per_s": ceiling / 1e9,
-                     "measured_gather_source": f"lance_hip_ubench({ceil_key}): random ds_read_b64 gathers of a [16][256] table, measured in this run",
-                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "traffic_detail": traffic_detail, "traffic_recorded": traffic_recorded,
-                     "traffic_vs_algorithmic_code_bytes": (traffic / avg_bytes) if (traffic and avg_bytes) else None,
-                     "queries_per_gather": queries_per_gather,
-                     "lut_values_per_s": lut_values / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0,
-                     "algorithmic_gathers_per_launch": gathers, "avg_launch_ms": avg_scan_ms,
-                     "survey_8d_code_bytes_per_launch": avg_bytes, "survey_8d_byte_rate_GBps": hbm_equiv,
-                     "hbm_peak_GBps": HBM_PEAK_GBS, "device_copy_GBps_measured": copy_bw / 1e9,
-                     "note": "HBM is not the bound (code table is L2-resident); PMC evidence (LDS busy, VALU issue, bank "
-                             "conflicts, FETCH/WRITE) is under profiles/"},
+        "roofline": None,
     }
+    common = {"traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src, "traffic_detail": traffic_detail,
+              "traffic_recorded": traffic_recorded, "traffic_vs_algorithmic_code_bytes": (traffic / avg_bytes) if (traffic and avg_bytes) else None,
+              "avg_launch_ms": avg_scan_ms, "survey_8d_code_bytes_per_launch": avg_bytes, "survey_8d_byte_rate_GBps": hbm_equiv,
+              "hbm_peak_GBps": HBM_PEAK_GBS, "device_copy_GBps_measured": copy_bw / 1e9}
+    if mscan:
+        # The main pass is the matrix-core filter scan: per partition a [queries x d] x [d x rows] f16 product (v_mfma_f32_32x32x16_f16)
+        # whose accumulator starts at |c^|^2 - limit, one compare per (row, query).  Algorithmic flop per launch = 2 d x the number of
+        # (row, query) cells = 2 d x sum over (query, probe) pairs of n_p (avg_bytes / M); peak = the dense f16 MFMA rate of the guide.
+        cells = avg_bytes / m
+        flop = 2.0 * d * cells
+        MFMA_F16_PEAK = 2500.0      # TFLOP/s dense f16 / bf16, MI355X_MICROARCH.md
+        ach = flop / (avg_scan_ms * 1e-3) / 1e12 if avg_scan_ms > 0 else 0.0
+        result["roofline"] = dict(common, kernel="ivfpq_mscan4_kernel<SD=8,KS=8> (main pass: matrix-core filter scan of all nprobes partitions, "
+                                  "32 rows x 32 queries per v_mfma_f32_32x32x16_f16 chain)",
+                                  bound="mfma", achieved=ach, peak=MFMA_F16_PEAK, unit="TFLOP/s", frac=ach / MFMA_F16_PEAK,
+                                  peak_source="MI355X_MICROARCH.md: dense f16 MFMA ~2.5 PFLOP/s",
+                                  algorithmic_flop_per_launch=flop, row_query_cells_per_launch=cells,
+                                  cells_per_s=cells / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0,
+                                  note="survivors of the filter (~250 per query) are re-evaluated in the reference's arithmetic by the merge kernel; "
+                                       "HBM is not the bound (codes, codebook and residual blocks are L2-resident); SQ counters and phase stamps "
+                                       "under profiles/r04*_mscan*")
+    else:
+        result["roofline"] = dict(common, kernel=kernel_name, bound="lds", achieved=gather_rate / 1e9, peak=guide_lds_peak / 1e9,
+                                  unit="G lane-gathers/s", frac=gather_rate / guide_lds_peak,
+                                  peak_source="MI355X_MICROARCH.md, LDS: ds_read_b64 conflict-free = 32 lanes/clk/CU x 256 CUs x 2.4 GHz",
+                                  frac_of_measured_gather=gather_rate / ceiling if ceiling else None,
+                                  measured_gather_G_per_s=ceiling / 1e9,
+                                  measured_gather_source=f"lance_hip_ubench({ceil_key}): random ds_read_b64 gathers of a [16][256] table, measured in this run",
+                                  queries_per_gather=queries_per_gather,
+                                  lut_values_per_s=lut_values / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0,
+                                  algorithmic_gathers_per_launch=gathers,
+                                  note="HBM is not the bound (code table is L2-resident); PMC evidence (LDS busy, VALU issue, bank "
+                                       "conflicts, FETCH/WRITE) is under profiles/")
 
     if not args.no_cpu_baseline and world == 1:
         import oracle as orc

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void kmeans_state_init_kernel(KmCtl c, const ui
 
 __device__ __forceinline__ float km_round(float v, int f16) { return f16 ? __half2float(__float2half_rn(v)) : v; }
 
-__global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t it) {
+__global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c) {
   extern __shared__ __attribute__((aligned(8))) char km_smem[];
   // per-cluster inputs staged in LDS by all lanes, so that lane 0's sequential chains read LDS, not one global word at a time
   double *lbs = reinterpret_cast<double *>(km_smem);            // [k] per-cluster losses
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void kmeans_control_kernel(KmCtl c, uint32_t i
     KmState &s = c.state[b];
     const double *lb = lbs;
     const float *rb = c.radius + (int64_t)b * k;
-    s.iters = it;
+    s.iters += 1u;      // (counted on the device: the launch takes no per-iteration argument, so a block of iterations can be a HIP graph)
     uint32_t bsz = s_bsz[0], blast = s_blast[0], bid = s_bid[0];
     for (int w = 1; w < 4; ++w) {
       const uint32_t osz = s_bsz[w], olast = s_blast[w], oid = s_bid[w];
@@ -351,7 +351,7 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
   // looks at the flags only every few iterations to stop enqueueing once every problem has converged.
   static const uint32_t check_every = getenv("LANCE_HIP_KMEANS_CHECK") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_KMEANS_CHECK"))) : 8;
   std::vector<uint8_t> active(B, 1);
-  for (uint32_t it = 1; it <= max_iters; ++it) {
+  auto enqueue_iteration = [&]() -> int {
     PairwiseArgs pa;
     pa.x = x; pa.n = n; pa.ldx = ldx; pa.x_batch_off = x_batch_off;
     pa.cent = cent; pa.k = k; pa.cent_batch_stride = (int64_t)k * d;
@@ -367,17 +367,67 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
                          sorted_rows, n, starts, losses_d, radius_d, last_d, active_d);
       hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), B), dim3(256), 0, ctx->stream,
                          x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1, f16_arith ? 1 : 0);
-      hipLaunchKernelGGL(kmeans_control_kernel, dim3(B), dim3(256), (size_t)k * 16, ctx->stream, ctl, it);
+      hipLaunchKernelGGL(kmeans_control_kernel, dim3(B), dim3(256), (size_t)k * 16, ctx->stream, ctl);
     }
     LH_CHECK_HIP(hipGetLastError());
-    if (it % check_every == 0 && it < max_iters) {
-      LH_CHECK_HIP(hipMemcpyAsync(active.data(), active_d, B, hipMemcpyDeviceToHost, ctx->stream));
-      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-      bool any = false;
-      for (int b = 0; b < B; ++b) any |= active[b] != 0;
-      if (!any) break;
+    return LANCE_HIP_OK;
+  };
+  auto all_converged = [&]() -> int {      // 1: every problem has turned itself off; 0: not yet; < 0: error
+    if (hipMemcpyAsync(active.data(), active_d, B, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      set_error("kmeans_train: reading the convergence flags failed");
+      return -1;
+    }
+    for (int b = 0; b < B; ++b) if (active[b]) return 0;
+    return 1;
+  };
+  // An iteration is ~10 small launches (assign: prep + MFMA sweep + re-check, four grouping kernels, stats, accumulate, control) whose
+  // arguments never change: the build was launch-latency bound (profiles/r03: train_pq 14 ms = 50 iterations x ~280 us of which ~160 us
+  // are kernels).  The first block of `check_every` iterations runs on the plain path (it sizes the scratch arena); the second is captured
+  // into a HIP graph and every further block is one hipGraphLaunch.  LANCE_HIP_KMEANS_GRAPH=0 keeps every block on the plain path.
+  static const bool graph_on = !(getenv("LANCE_HIP_KMEANS_GRAPH") && getenv("LANCE_HIP_KMEANS_GRAPH")[0] == '0');
+  hipGraphExec_t gexec = nullptr;
+  bool graph_failed = !graph_on || ctx->timing || ctx->capturing;
+  uint32_t it = 0;
+  int rc_loop = LANCE_HIP_OK;
+  while (it < max_iters) {
+    const uint32_t blk = std::min<uint32_t>(check_every, max_iters - it);
+    bool done_block = false;
+    if (blk == check_every && it >= check_every && !graph_failed) {
+      if (!gexec) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          ctx->capturing = true;
+          int rc = LANCE_HIP_OK;
+          for (uint32_t t = 0; t < blk && rc == LANCE_HIP_OK; ++t) rc = enqueue_iteration();
+          ctx->capturing = false;
+          const hipError_t ee = hipStreamEndCapture(ctx->stream, &g);
+          if (!(rc == LANCE_HIP_OK && ee == hipSuccess && g && hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0) == hipSuccess && gexec)) {
+            gexec = nullptr; graph_failed = true;      // nothing was executed: this block runs on the plain path below
+          }
+          if (g) (void)hipGraphDestroy(g);
+          (void)hipGetLastError();
+        } else {
+          (void)hipGetLastError();
+          graph_failed = true;
+        }
+      }
+      if (gexec) {
+        if (hipGraphLaunch(gexec, ctx->stream) != hipSuccess) { set_error("kmeans_train: hipGraphLaunch failed"); rc_loop = LANCE_HIP_ERUNTIME; break; }
+        done_block = true;
+      }
+    }
+    if (!done_block)
+      for (uint32_t t = 0; t < blk; ++t) { rc_loop = enqueue_iteration(); if (rc_loop != LANCE_HIP_OK) break; }
+    if (rc_loop != LANCE_HIP_OK) break;
+    it += blk;
+    if (it < max_iters) {
+      const int c = all_converged();
+      if (c < 0) { rc_loop = LANCE_HIP_ERUNTIME; break; }
+      if (c) break;
     }
   }
+  if (gexec) { (void)hipStreamSynchronize(ctx->stream); (void)hipGraphExecDestroy(gexec); }
+  if (rc_loop != LANCE_HIP_OK) return rc_loop;
   std::vector<KmState> st_h(B);
   LH_CHECK_HIP(hipMemcpyAsync(st_h.data(), state_d, (size_t)B * sizeof(KmState), hipMemcpyDeviceToHost, ctx->stream));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -747,7 +797,7 @@ __global__ __launch_bounds__(256) void kmeans_shard_update_kernel(KmShardState *
   __syncthreads();
   if (threadIdx.x == 0) {
     KmState &s = st->s;
-    s.iters = it;
+    s.iters += 1u;      // (counted on the device: the launch takes no per-iteration argument, so a block of iterations can be a HIP graph)
     uint64_t max_size = 0;
     int max_id = 0;
     for (int i = 0; i < k; ++i) if (sz[i] > max_size) { max_size = sz[i]; max_id = i; }   // first maximal cluster
