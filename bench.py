@@ -392,7 +392,7 @@ def main():
     # HBM traffic of the dominant kernel: measured IN THIS RUN by two rocprofv3 --pmc child passes (collect_pmc_traffic); the figure
     # recorded under profiles/ in an earlier round is kept beside it under its own key, never as `traffic`
     traffic, traffic_src, traffic_detail = None, None, None
-    pmc_kernel = ("ivfpq_mscan4_kernel<8, 8" if mscan else "ivfpq_qscan_kernel<8, 1") if (quantised and args.config == "c2") else None
+    pmc_kernel = ("ivfpq_mscan_kernel<8, 8" if mscan else "ivfpq_qscan_kernel<8, 1") if (quantised and args.config == "c2") else None
     if pmc_kernel and not args.no_pmc and world == 1:
         child = ["--steps", "3", "--warmup", "1", "--streams", "1", "--no-cpu-baseline", "--no-pmc", "--config", args.config, "--n", str(args.n),
                  "--nq", str(args.nq), "--nprobes", str(args.nprobes), "--refine", str(args.refine), "--k", str(args.k)]
@@ -496,7 +496,7 @@ def main():
         flop = 2.0 * d * cells
         MFMA_F16_PEAK = 2500.0      # TFLOP/s dense f16 / bf16, MI355X_MICROARCH.md
         ach = flop / (avg_scan_ms * 1e-3) / 1e12 if avg_scan_ms > 0 else 0.0
-        result["roofline"] = dict(common, kernel="ivfpq_mscan4_kernel<SD=8,KS=8> (main pass: matrix-core filter scan of all nprobes partitions, "
+        result["roofline"] = dict(common, kernel="ivfpq_mscan_kernel<SD=8,KS=8> (main pass: matrix-core filter scan of all nprobes partitions, "
                                   "32 rows x 32 queries per v_mfma_f32_32x32x16_f16 chain)",
                                   bound="mfma", achieved=ach, peak=MFMA_F16_PEAK, unit="TFLOP/s", frac=ach / MFMA_F16_PEAK,
                                   peak_source="MI355X_MICROARCH.md: dense f16 MFMA ~2.5 PFLOP/s",

@@ -46,8 +46,7 @@ struct lance_hip_index {
     void *cbh = nullptr;          // [m][256][d/m] binary16: -2 sigma c
     float *cbn2 = nullptr;        // [m][256] |c|^2
     float *row_cn2 = nullptr;     // [n] sigma^2 |reconstruction of the stored row|^2
-    uint32_t max_units = 0;       // sum over the partitions of ceil(rows / 256): the pipelined scan's grid
-    uint32_t sum_rs = 0, max_rs = 0;   // row slices (of 1024 rows) summed over the partitions / of the largest partition: bound the slice table
+    uint32_t sum_rs = 0, max_rs = 0;   // row slices (of 2048 rows) summed over the partitions / of the largest partition: bound the slice table
   } *ms = nullptr;
   std::mutex lazy_mu;             // guards the creation of `pt` / `ms` (several contexts / host threads may search one index)
   uint32_t *part_offsets = nullptr;  // [nlist+1] device

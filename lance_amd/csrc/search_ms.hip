@@ -1,33 +1,45 @@
 // search_ms.hip -- the ADC filter scan on the matrix cores (8-bit PQ, L2 / cosine, d = 64 / 128; M = 16 / 32).
 //
-// Why (round 4, gpurun r04g): the 4-query integer scan (search_q.hip) is the dominant kernel of the C2 step (0.354 of 0.84 ms)
-// and sits under two ceilings at once -- random LDS gathers (61 % of its LDS cycles are bank conflicts) and VALU issue (158 M
-// wave instructions per launch, 40 % of them the table build per (query, partition) item).  Both come from evaluating
+// Why: the 4-query integer scan (search_q.hip) was the dominant kernel of the C2 step (0.354 of 0.84 ms, gpurun r04g) and sat under two
+// ceilings at once -- random LDS gathers (61 % of its LDS cycles are bank conflicts) and VALU issue (158 M wave instructions per launch,
+// 40 % of them the table build per (query, partition) item).  Both come from evaluating
 //     dist(q, row) = sum_m |r_m - c_m(code_m)|^2                 (pq/distance.rs:109-144, v2.rs:316-332: r = q - centroid_p)
 // one table lookup per (row, sub-quantiser) per group of four queries.  The same number is |r - c^_row|^2 with c^_row the row's
 // reconstruction (the concatenated codewords), i.e.
 //     dist = |c^_row|^2 - 2 r . c^_row + |r|^2 :
-// |c^_row|^2 is a constant of the stored row (4 bytes, computed once per index), |r|^2 a scalar per (query, partition) pair, and
-// the cross term is a [rows x d] x [d x queries] product per partition -- matrix-core work.  A workgroup owns 256 rows of one
-// partition: each wave gathers the f16 reconstruction of its 64 rows ONCE (one 16-byte codeword fetch per (row, k-slice), i.e. n_p M
-// gathers per partition instead of n_p M per four queries) and keeps it in registers as the A operand of
-// v_mfma_f32_32x32x16_f16; the partition's queries stream through LDS as B tiles of 32; the accumulator starts at |c^_row|^2 (the
-// MFMA's C operand), so D = |c^|^2 - 2 r.c^ comes out of the matrix pipe and the epilogue is ONE compare per (row, query) against
-// lim = T + E - |r|^2.
+// |c^_row|^2 is a constant of the stored row (4 bytes, computed once per index), |r|^2 a scalar per (query, partition) pair, and the
+// cross term is a [queries x d] x [d x rows] product per partition -- matrix-core work (v_mfma_f32_32x32x16_f16).  The accumulator starts
+// at |c^|^2 - limit, so the epilogue is ONE compare with zero per (row, query).
 //
-// It is a FILTER, exactly like the integer scan it replaces: survivors go to the same per-(query, probe) segments, with an integer
-// sum S ~ dist * s for the merge kernel's cut, and ivfpq_qmerge_kernel re-evaluates them in the reference's arithmetic -- ids and
-// distances stay bit-equal to the oracle.  Soundness (no row with reference distance <= T is dropped): with u = 2^-11 (binary16),
+// It is a FILTER, exactly like the integer scan it replaces: survivors go to the same per-(query, probe) segments, with the accumulator
+// value the merge kernel turns into an integer sum S ~ dist * s for its cut, and ivfpq_qmerge_kernel re-evaluates them in the reference's
+// arithmetic -- ids and distances stay bit-equal to the oracle.  Soundness (no row with reference distance <= T is dropped): with
+// u = 2^-11 (binary16),
 //   |fl16(a) fl16(b) - a b| <= |a b| (2u + u^2)  ->  |2 r~.c~ - 2 r.c^| <= 2^-9 (1 + 2^-12) |r| |c^|      (Cauchy-Schwarz),
 // the f32 accumulation of K <= 128 exact products adds <= K 2^-23 * 2 |r| |c^| (whatever the matrix pipe's internal rounding),
-// the f32 evaluations of |c^|^2, |r|^2 and of the reference's own table / sequential sum <= (d + M + 4) 2^-24 of their values
-// (together < 2^-13 (|r|^2 + T) with |c^|^2 <= 2 |r|^2 + 2.1 T), and a row that can pass has |c^| <= |r| + sqrt(T)
+// the f32 evaluations of |c^|^2, |r|^2, of |c^|^2 - limit and of the reference's own table / sequential sum <= (d + M + 4) 2^-24 of their
+// values (together < 2^-13 (|r|^2 + T) with |c^|^2 <= 2 |r|^2 + 2.1 T), and a row that can pass has |c^| <= |r| + sqrt(T)
 // (triangle inequality); every SURVIVOR of the test has |c^| <= 1.01 (|r| + sqrt(T + E)) as well, so the same E bounds the error of
 // every sum the merge kernel's histogram counts.  ms_prep_kernel evaluates
 //   E = 1.05 [2^-9 1.02 |r| (|r| + sqrt T) + 2^-13 (|r|^2 + T)] + E_abs        (E_abs: f16 subnormals flushed, per element 2^-14 / sigma)
 // per pair; sigma is a power of two per index that puts the largest codeword component near 2^13 (products and scales by powers
 // of two are exact).  A pair whose residual overflows binary16, whose E exceeds 5 % of T, or with anything non-finite is handed
 // to the exact rescan (the integer scan's overflow route); so is a segment with more than Q_CAP survivors.
+//
+// How the kernel got its shape (all on hardware, parity green at every step: tests/test_zz_gpu_mscan.py, tests/test_gpu_pm_scan.py, fuzz):
+//   v1  256 rows x all pairs per workgroup, pairs staged global -> register -> LDS per super-block, flush with dependent atomics:
+//       0.343 ms per 10k-query batch at C2 (no faster than the integer scan): a unit spent 43 us on ~4 us of arithmetic.
+//   v2  LDS-DMA double buffer (global_load_lds_dwordx4, XOR-swizzled source + read), one 32-byte unit record, deferred segment stores,
+//       sixteen compares hoisted in front of sixteen scalar tests: 0.267 ms.  Phase stamps (profiles/r04k_*): 29 % of a wave's life in
+//       the tiles, 27 % before its first barrier, 23 % flush + DMA issue, 15 % tail flush, 6 % barriers; VALU busy 23 %, MFMA 15 %.
+//       (hipcc does NOT put the vmcnt(0) an LDS-DMA needs in front of a loop-header barrier: two queries of 700 read a super-block
+//       that had not landed until the wait was written out -- kept below.)
+//   v3  the PAIR BLOCK resident in LDS (<= 512 pairs, 128 KiB), one persistent 512-lane workgroup per CU taking slices from a device
+//       counter, eight waves working independently on 64-row chunks, no barrier inside a slice: 0.242 ms.
+//   v4  (this file) the MFMA's operands trade places -- queries down the accumulator registers, ROWS across the lanes: the accumulator
+//       starts from one value per lane, a wave carries one 32-row block, 128 VGPRs, sixteen waves per CU: 0.206 ms; slices taken
+//       largest-first: 0.188 ms.  Timing experiments (profiles/r04n_*): without any survivor 0.139 ms, MFMA floor 0.041 ms -- a
+//       32 x 32 block costs a wave ~2,600 cycles of mostly serial latency and four waves per SIMD are what the register file holds.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -47,12 +59,11 @@ typedef _Float16 ms_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ms_h4 __attribute__((ext_vector_type(4)));
 typedef float ms_f16v __attribute__((ext_vector_type(16)));
 
-constexpr int MS_RW = 256;          // rows per workgroup (4 waves x 64)
-constexpr int MS_SBP = 192;         // pairs per LDS super-block (6 tiles of 32)
-constexpr int MS_QCAP = 256;        // survivor queue entries per wave
 constexpr float MS_SE = 30000.0f;   // the bound T maps to MS_SE units of the integer sums
 constexpr float MS_SLACK_CAP = 1500.0f;   // largest E * s (units) the filter takes: 5 % of T
 constexpr int MS_CUT_SHIFT = 6;     // merge histogram: 512 bins of 64 units
+typedef __attribute__((address_space(1))) const void *ms_gptr;
+typedef __attribute__((address_space(3))) void *ms_lptr;
 
 // ---- index constants ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ms_codebook_kernel(const float *__restrict__ cb, int64_t nwords, int sd, float scale, _Float16 *__restrict__ cbh,
@@ -78,51 +89,6 @@ __global__ __launch_bounds__(256) void ms_row_norm_kernel(const uint8_t *__restr
   row_cn2[r] = s * sigma2;
 }
 
-// unit_start[p] = exclusive scan of (partition p has class-A pairs ? ceil(n_p / MS_RW) : 0)
-__global__ __launch_bounds__(256) void ms_unit_table_kernel(const uint32_t *__restrict__ pair_starts, const uint32_t *__restrict__ part_offsets, int nlist,
-                                                            uint32_t *__restrict__ unit_start) {
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t carry_s;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < nlist; base += 256) {
-    const int i = base + threadIdx.x;
-    uint32_t v = 0;
-    if (i < nlist && pair_starts[i + 1] > pair_starts[i]) v = (part_offsets[i + 1] - part_offsets[i] + MS_RW - 1) / MS_RW;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    const uint32_t carry = carry_s;
-    if (i < nlist) unit_start[i] = carry + woff + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry_s = carry + woff + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) unit_start[nlist] = carry_s;
-}
-
-// unit -> everything the scan needs to start, in one 32-byte record (the first version searched unit_start by bisection and then
-// chased part_offsets / pair_starts: eleven dependent L2 round trips, 6-7 us, in front of ~4 us of arithmetic per unit)
-struct MsUnit { uint32_t part, row0, off, np, gs, qp, pad0, pad1; };
-__global__ __launch_bounds__(256) void ms_unit_desc_kernel(const uint32_t *__restrict__ unit_start, const uint32_t *__restrict__ pair_starts,
-                                                           const uint32_t *__restrict__ part_offsets, int nlist, MsUnit *__restrict__ units) {
-  const int part = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (part >= nlist) return;
-  const uint32_t u0 = unit_start[part], u1 = unit_start[part + 1];
-  MsUnit u;
-  u.part = (uint32_t)part; u.off = part_offsets[part]; u.np = part_offsets[part + 1] - u.off;
-  u.gs = pair_starts[part]; u.qp = pair_starts[part + 1] - u.gs; u.pad0 = u.pad1 = 0u;
-  for (uint32_t c = (uint32_t)lane; c < u1 - u0; c += 64u) { u.row0 = c * (uint32_t)MS_RW; units[u0 + c] = u; }
-}
-
 // ---- per-pair pre-pass: f16 residual (scaled by sigma), limit, integer-sum scale --------------------------------------------------
 struct MsPrepArgs {
   const float *q, *centroids;
@@ -137,8 +103,7 @@ struct MsPrepArgs {
   uint32_t *qslack;             // [nq] max over the query's pairs of ceil(E s) (zeroed before the launch)
   uint32_t *seg_cnt, *qovf, *ovf;
   uint32_t nan_slot;            // index into prm of the NaN-limit record (written here, loaded by the scan for padded pair slots)
-  f2 *prm2;                     // [nq * nprobes] by PAIR: {s / sigma^2, |r|^2 s} -- what turns an accumulator value into the survivor's integer sum
-  int rel_limit;                // rows-on-lanes kernel: the accumulator starts at |c^|^2 - limit, prm2.y carries the limit's share of the sum
+  f2 *prm2;                     // [nq * nprobes] by PAIR: {s / sigma^2, (T' + E) s} -- what turns a survivor's accumulator value into its integer sum
 };
 
 constexpr int MS_PPW = 4;      // pairs per wave of the pre-pass: their loads are in flight together (one pair per wave was 100k waves of
@@ -204,9 +169,8 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
   f4 o;
   if (ok) {
     o.x = lim * sig2; o.y = s / sig2; o.z = n2l * s;
-    // by pair, for the flush: sum = (accumulator value relative to the limit) * y + (T (1 + 2^-17) + E) s; the pipelined / queries-on-lanes
-    // kernels queue the accumulator itself and read .z' = |r|^2 s through rel == 0
-    p.prm2[pairl] = p.rel_limit ? f2{o.y, ((T * 1.0000077f + E)) * s} : f2{o.y, o.z};
+    // by pair, for the merge kernel: sum = (accumulator value, which is relative to the limit) * y + (T (1 + 2^-17) + E) s
+    p.prm2[pairl] = f2{o.y, (T * 1.0000077f + E) * s};
     atomicMax(&p.qslack[q], (uint32_t)ceilf(eu));
   } else {
     // this (query, partition) pair goes to the exact rescan (ivfpq_qrescan_kernel), as an overflowed segment does.  The limit is a
@@ -220,273 +184,18 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
   p.prm[g0 + (uint32_t)lane] = o;
 }
 
-// ---- the scan ------------------------------------------------------------------------------------------------------------------
-struct MscanArgs {
-  const uint32_t *unit_start;   // [nlist+1]
-  const uint32_t *pair_starts;  // [nlist+1] (class A)
-  const uint32_t *part_offsets;
-  const uint8_t *codes;
-  const _Float16 *cbh;          // [m][256][sd] = f16(-2 sigma c)
-  const float *row_cn2;         // [n] sigma^2 |c^_row|^2
-  const _Float16 *rh;           // [pairs][d]
-  const f4 *prm;                // [pairs]
-  const MsUnit *units;          // [units] (pipelined kernel)
-  const f2 *prm2;               // [nq * nprobes] by pair (pipelined kernel's flush)
-  unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1: [0] prologue [1] barrier waits [2] flush + DMA issue [3] tiles [4] tail [5] waves [6] super-blocks
-  uint32_t nan_slot;
-  int nlist, nprobes, m;
-  uint32_t *seg_cnt, *seg_pos;
-  uint16_t *seg_sum;
-  uint32_t *qovf, *ovf;
-  const uint32_t *allow;
-};
-
-// ---- the scan, pipelined (the default) -----------------------------------------------------------------------------------------------
-// First hardware run of the kernel above (gpurun r04h): parity green (62 tests, 209 fuzz cases), 0.343 ms per 10k-query batch at C2 --
-// no faster than the integer scan -- because a unit spent 43 us on ~4 us of arithmetic: bisection + pointer chasing in front, then
-// per super-block {global -> register -> LDS staging, barrier, MFMAs, flush with two to four DEPENDENT device-scope atomic round trips},
-// nothing overlapped, two workgroups per CU.  This version keeps the arithmetic and takes the waiting out:
-//   * one 32-byte unit record instead of the search;
-//   * the pairs' f16 residuals and parameters arrive by LDS-DMA (global_load_lds_dwordx4) into the OTHER half of a double buffer while
-//     the current super-block is computed; the bank-conflict padding of the first version becomes an XOR swizzle of the 16-byte chunk
-//     index, applied to the per-lane SOURCE address (the DMA writes lane-linear) and to the ds_read_b128 address alike;
-//   * survivors are queued with their integer sum already computed (the parameters are in registers at that point), so the flush
-//     needs nothing from LDS but the queue; its atomics are issued right AFTER the super-block's barrier and their dependent stores
-//     one super-block later -- both have a whole compute phase to complete before the next barrier's vmcnt(0).
-typedef __attribute__((address_space(1))) const void *ms_gptr;
-typedef __attribute__((address_space(3))) void *ms_lptr;
-constexpr int MS2_SBP = 128;        // pairs per LDS super-block (4 tiles of 32), double buffered
-constexpr int MS2_QCAP = 128;       // survivor queue entries per wave (2 per lane pending in registers)
-
-template <int SD, int KS, bool PROF = false>
-__global__ __launch_bounds__(256, 2) void ivfpq_mscan2_kernel(MscanArgs p) {
-  constexpr int D = KS * 16;
-  constexpr int M = D / SD;
-  constexpr int RB = D * 2;                 // bytes of a pair's f16 residual
-  constexpr int CPR = RB / 16;              // 16-byte chunks per pair row (16 / 8)
-  constexpr int RPK = 256 / RB;             // pair rows per 256 bytes (1 / 2): the swizzle key is (row / RPK) & (CPR - 1)
-  constexpr int SPI = 4096 / RB;            // pair slots one 256-lane DMA pass covers (16 / 32)
-  constexpr int PE = MS2_QCAP / 64;
-  __shared__ __attribute__((aligned(16))) char sB[2][MS2_SBP * RB];
-  __shared__ __attribute__((aligned(16))) f4 sP[2][MS2_SBP];
-  __shared__ __attribute__((aligned(8))) uint2 sQ[4][MS2_QCAP + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, g = lane >> 5;
-  const uint32_t per_xcd = (gridDim.x + 7u) >> 3;
-  const uint32_t unit = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (unit >= p.unit_start[p.nlist]) return;
-  const MsUnit U = p.units[unit];
-  const uint32_t off = U.off;
-  const int np = (int)U.np, row0 = (int)U.row0, Qp = (int)U.qp;
-  const uint32_t gs = U.gs;
-
-  // LDS-DMA of super-block `sb` into buffer `buf` (lane-linear destination, swizzled source)
-  auto stage = [&](int sb, int buf) {
-    const int sb0 = sb * MS2_SBP;
-    const int nsb = min(MS2_SBP, Qp - sb0);
-    const int nslots = ((nsb + 31) >> 5) << 5;
-    const char *src = reinterpret_cast<const char *>(p.rh + ((int64_t)gs + sb0) * D);
-#pragma unroll
-    for (int it = 0; it < MS2_SBP / SPI; ++it) {
-      const int slot = it * SPI + wave * (SPI / 4) + lane / CPR, k = lane % CPR;
-      if (it * SPI < nslots && slot < nsb)      // padded slots keep whatever the buffer held: their limit is a NaN
-        __builtin_amdgcn_global_load_lds((ms_gptr)(src + (int64_t)slot * RB + ((k ^ ((slot / RPK) & (CPR - 1))) << 4)),
-                                         (ms_lptr)(&sB[buf][(it * SPI + wave * (SPI / 4)) * RB]), 16, 0, 0);
-    }
-    if (wave < MS2_SBP / 64) {
-      const int slot = wave * 64 + lane;
-      if (slot < nslots) {
-        const f4 *ps = slot < nsb ? p.prm + (int64_t)gs + sb0 + slot : p.prm + p.nan_slot;
-        __builtin_amdgcn_global_load_lds((ms_gptr)ps, (ms_lptr)(&sP[buf][wave * 64]), 16, 0, 0);
-      }
-    }
-  };
-  const int nsbk = (Qp + MS2_SBP - 1) / MS2_SBP;
-  long long pc0 = 0, pc_wait = 0, pc_flush = 0, pc_comp = 0, pct = 0;      // PROF: s_memtime stamps (100 MHz)
-  if constexpr (PROF) pc0 = clock64();
-  stage(0, 0);
-
-  // A: the f16 reconstruction of this wave's 64 rows, in MFMA operand layout (lane (j, g): row j of the 32-block, k-slice g)
-  ms_h8 a[2][KS];
-  ms_f16v cinit[2];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb) {
-    const int rowl = wave * 64 + rb * 32 + j;
-    const int rowc = min(row0 + rowl, np - 1);
-    uint32_t cw[M / 4];
-    {
-      const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)off + rowc) * M);      // rows of 16 / 32 bytes, 16-byte aligned
-#pragma unroll
-      for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
-    }
-    auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if constexpr (SD == 8) {
-        // sub-quantiser 2 s + g: both candidates extracted with static shifts, one select
-        const uint32_t c0 = code(2 * s), c1 = code(2 * s + 1);
-        const int mm = 2 * s + g;
-        a[rb][s] = *reinterpret_cast<const ms_h8 *>(p.cbh + ((int64_t)mm * 256 + (g ? c1 : c0)) * 8);
-      } else {
-        static_assert(SD == 4, "sub-dimension 4 / 8");
-        const uint32_t c0 = g ? code(4 * s + 2) : code(4 * s), c1 = g ? code(4 * s + 3) : code(4 * s + 1);
-        const int mm = 4 * s + 2 * g;
-        const ms_h4 lo = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)mm * 256 + c0) * 4);
-        const ms_h4 hi = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)(mm + 1) * 256 + c1) * 4);
-        a[rb][s] = ms_h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-    }
-    // D[row i][query j]: lane (j, g) holds rows i = (v & 3) + 8 (v >> 2) + 4 g of the 32-block (layout as in mfma_assign.hip)
-#pragma unroll
-    for (int vq = 0; vq < 4; ++vq)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = row0 + wave * 64 + rb * 32 + 8 * vq + 4 * g + e;
-        cinit[rb][vq * 4 + e] = r < np ? p.row_cn2[(int64_t)off + r] : INFINITY;      // a padded row never passes
-      }
-  }
-
-  uint2 *myq = sQ[wave];
-  uint32_t qn = 0;      // wave-uniform: queue entries
-  // pending flush: entries whose segment slot has been requested (atomicAdd issued, sum scale requested) but not yet used
-  uint32_t pd_pair[PE], pd_pos[PE], pd_k[PE];
-  float pd_a[PE];
-  f2 pd_yz[PE];
-#pragma unroll
-  for (int i = 0; i < PE; ++i) { pd_pair[i] = 0xFFFFFFFFu; pd_pos[i] = 0u; pd_k[i] = 0u; pd_a[i] = 0.0f; pd_yz[i] = f2{0.0f, 0.0f}; }
-  auto flush_end = [&]() {
-#pragma unroll
-    for (int i = 0; i < PE; ++i) {
-      if (pd_pair[i] != 0xFFFFFFFFu) {
-        const uint32_t k = pd_k[i], pair = pd_pair[i];
-        if (k < (uint32_t)Q_CAP) {
-          const float S = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(pd_a[i], pd_yz[i].x, pd_yz[i].y)), 0.0f, 65535.0f);
-          p.seg_pos[(int64_t)pair * Q_CAP + k] = pd_pos[i];
-          p.seg_sum[(int64_t)pair * Q_CAP + k] = (uint16_t)S;
-        } else if (k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
-          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
-        }
-        pd_pair[i] = 0xFFFFFFFFu;
-      }
-    }
-  };
-  auto flush_begin = [&]() {
-#pragma unroll
-    for (int i = 0; i < PE; ++i) {
-      const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
-      if (e < qn) {
-        const uint2 ent = myq[e];
-        const uint32_t pair = ent.x >> 8, pos = off + (uint32_t)row0 + (ent.x & 255u);
-        if (row_allowed(p.allow, pos)) {
-          pd_pair[i] = pair; pd_pos[i] = pos; pd_a[i] = __uint_as_float(ent.y);
-          pd_yz[i] = p.prm2[pair];
-          pd_k[i] = atomicAdd(&p.seg_cnt[pair], 1u);
-        }
-      }
-    }
-    qn = 0;
-  };
-
-  for (int sb = 0; sb < nsbk; ++sb) {
-    const int buf = sb & 1;
-    if constexpr (PROF) { pct = clock64(); if (sb == 0) pc0 = pct - pc0; }
-    // The DMA is ordered for the readers only by the ISSUING wave's vmcnt(0) followed by the barrier -- and hipcc does not put that
-    // wait in front of this barrier by itself (gpurun r04j: the loop header was a bare s_barrier; two queries of 700 read a
-    // super-block that had not landed): stated here.  It also retires the flush's atomics, loads and stores, as intended.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();      // super-block sb has landed for every wave; the other buffer's readers are done
-    if constexpr (PROF) { const long long t = clock64(); pc_wait += t - pct; pct = t; }
-    flush_end();          // stores behind the atomics issued one super-block ago
-    flush_begin();        // atomics for the survivors of the previous super-block
-    if (sb + 1 < nsbk) stage(sb + 1, buf ^ 1);
-    if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; }
-    const int nsb = min(MS2_SBP, Qp - sb * MS2_SBP);
-    const int nblk = (nsb + 31) >> 5;
-    for (int jb = 0; jb < nblk; ++jb) {
-      const int slot = jb * 32 + j;
-      ms_h8 b[KS];
-      const char *br = &sB[buf][slot * RB];
-      const int key = (slot / RPK) & (CPR - 1);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
-      const f4 P = sP[buf][slot];
-      const float lim = P.x;
-      const uint32_t pair8 = __float_as_uint(P.w) << 8;
-      // room for a tile's usual yield (13 survivors at C2); a burst beyond the queue is handled after the tile
-      if (qn > (uint32_t)(MS2_QCAP - 48)) { flush_end(); flush_begin(); }
-      uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        ms_f16v acc = cinit[rb];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][s], b[s], acc, 0, 0, 0);
-        // Sixteen compares back to back into sixteen lane masks, THEN the (scalar) tests: the first version branched on each compare's
-        // result as it came -- 32 VALU -> SALU dependency stalls per tile, and ~20 wave instructions per survivor behind them
-        uint64_t mk[16];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= lim);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          if (mk[v]) {
-            const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
-                                     (uint32_t)MS2_QCAP);      // entry MS2_QCAP: the bin of a burst
-            if (acc[v] <= lim) {      // (the same compare: the compiler reuses its lane mask as the exec mask)
-              const uint32_t rowl = (uint32_t)(wave * 64 + rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * g);
-              myq[idx] = make_uint2(pair8 | rowl, __float_as_uint(acc[v]));
-            }
-            qraw += (uint32_t)__popcll(mk[v]);
-          }
-        }
-      }
-      qn = min(qraw, (uint32_t)MS2_QCAP);
-      if (qraw > (uint32_t)MS2_QCAP) {
-        // more than a queue's worth of survivors in one tile (>= 4 % of its cells pass -- these pairs' segments would overflow anyway):
-        // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
-        // crosses it lists the pair
-        if (g == 0 && slot < nsb) {
-          const uint32_t pair = pair8 >> 8;
-          const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
-          if (k <= (uint32_t)Q_CAP) p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
-        }
-      }
-    }
-    if constexpr (PROF) { const long long t = clock64(); pc_comp += t - pct; pct = t; }
-  }
-  flush_end();
-  flush_begin();
-  flush_end();
-  if constexpr (PROF) {
-    if (lane == 0) {
-      atomicAdd(&p.prof[0], (unsigned long long)pc0);       // start -> first barrier (unit record, A gather, |c^|^2, first DMA)
-      atomicAdd(&p.prof[1], (unsigned long long)pc_wait);   // vmcnt(0) + barrier
-      atomicAdd(&p.prof[2], (unsigned long long)pc_flush);  // flush_end + flush_begin + DMA issue
-      atomicAdd(&p.prof[3], (unsigned long long)pc_comp);   // tiles: LDS reads, MFMA, compares, queue
-      atomicAdd(&p.prof[4], (unsigned long long)(clock64() - pct));      // final flushes
-      atomicAdd(&p.prof[5], 1ull);
-      atomicAdd(&p.prof[6], (unsigned long long)nsbk);
-    }
-  }
-}
-
-// ---- the scan, resident pair block + independent waves (the default) ------------------------------------------------------------------
-// Phase stamps and SQ counters of the pipelined kernel above (gpurun r04k, profiles/r04k_*): a wave spent 29 % of its life in the tiles
-// (LDS reads, MFMA, compares, queue), 27 % before its first barrier (unit record -> codes, |c^|^2 -> codeword gathers: three dependent
-// round trips), 23 % issuing flush traffic and DMA, 15 % in the synchronous tail flush, 6 % at barriers; VALU busy 23 %, MFMA busy 15 %
-// of the kernel's cycles -- two workgroups per CU marching in lockstep through a few microseconds of work per unit cannot hide any of it.
-// Here the PAIR BLOCK is the resident operand: one persistent 512-lane workgroup per CU takes a slice = (partition, <= 512 of its pairs,
-// <= MS3_RS of its rows) from a device-side counter, brings the block's f16 residuals into LDS once (128 KiB, LDS-DMA, swizzled as above),
-// and then its eight waves work INDEPENDENTLY: each takes 64-row chunks from an LDS counter, gathers the chunk's reconstruction into
-// registers, runs it against every tile of the block, queues survivors, and issues the flush's atomics at the chunk's end -- their
-// dependent stores go out a chunk later.  No barrier inside a slice: while one wave of a SIMD waits for its gathers the other computes.
+// ---- slices: (partition, <= MS3_PB of its pairs, <= rows-per-slice of its rows) -----------------------------------------------------------
 constexpr int MS3_PB = 512;         // pairs resident in LDS (128 KiB at d = 128)
 constexpr int MS3_RS = 2048;        // rows per slice (64 chunks of 32 for sixteen waves): the block's DMA + two barriers + the wait for the slowest wave are paid per slice
-constexpr int MS3_QCAP = 128;
+static int ms_rows_per_slice() {    // LANCE_HIP_MS_RS: A/B of the slice height (multiple of 64)
+  static const int v = [] { const char *e = getenv("LANCE_HIP_MS_RS"); const int x = e ? atoi(e) : MS3_RS; return x >= 64 ? (x / 64) * 64 : MS3_RS; }();
+  return v;
+}
 struct MsSlice { uint32_t off, np, row_begin, row_count, gs, qp, pad0, pad1; };
 
 // slice_start[p] = exclusive scan of (pair blocks of partition p) x (row slices of partition p)
 __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__restrict__ pair_starts, const uint32_t *__restrict__ part_offsets, int nlist,
-                                                             uint32_t *__restrict__ slice_start, uint32_t *__restrict__ slice_ctr) {
+                                                             uint32_t rs_rows, uint32_t *__restrict__ slice_start, uint32_t *__restrict__ slice_ctr) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -497,7 +206,7 @@ __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__r
     uint32_t v = 0;
     if (i < nlist) {
       const uint32_t qp = pair_starts[i + 1] - pair_starts[i], np = part_offsets[i + 1] - part_offsets[i];
-      v = ((qp + MS3_PB - 1) / MS3_PB) * ((np + MS3_RS - 1) / MS3_RS);
+      v = ((qp + MS3_PB - 1) / MS3_PB) * ((np + rs_rows - 1) / rs_rows);
     }
     uint32_t incl = v;
 #pragma unroll
@@ -519,7 +228,8 @@ __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__r
 }
 
 __global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__restrict__ slice_start, const uint32_t *__restrict__ pair_starts,
-                                                            const uint32_t *__restrict__ part_offsets, int nlist, MsSlice *__restrict__ slices) {
+                                                            const uint32_t *__restrict__ part_offsets, int nlist, uint32_t rs_rows,
+                                                            MsSlice *__restrict__ slices) {
   const int part = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (part >= nlist) return;
   const uint32_t s0 = slice_start[part], s1 = slice_start[part + 1];
@@ -529,17 +239,39 @@ __global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__re
   const uint32_t npb = (qp + MS3_PB - 1) / MS3_PB;
   const uint32_t blk = (((qp + npb - 1) / npb) + 31u) & ~31u;      // equal pair blocks, whole tiles of 32 (<= MS3_PB)
   // row slices vary fastest: the slices of one pair block are taken by different CUs at about the same time (its residuals come from L2)
-  const uint32_t nrs = (np + MS3_RS - 1) / MS3_RS;
+  const uint32_t nrs = (np + rs_rows - 1) / rs_rows;
   for (uint32_t t = (uint32_t)lane; t < s1 - s0; t += 64u) {
     const uint32_t pb = t / nrs, rs = t - pb * nrs;
     MsSlice u;
-    u.off = off; u.np = np; u.row_begin = rs * (uint32_t)MS3_RS; u.row_count = min((uint32_t)MS3_RS, np - u.row_begin);
+    u.off = off; u.np = np; u.row_begin = rs * rs_rows; u.row_count = min(rs_rows, np - u.row_begin);
     u.gs = gs + pb * blk; u.qp = min(blk, qp - pb * blk); u.pad0 = u.pad1 = 0u;
     slices[s0 + t] = u;
   }
 }
 
-struct Mscan3Args {
+// order[i] = the slices by decreasing work (rows x pairs), in 32 classes: the persistent workgroups take them from a counter, and a large
+// slice taken last would be the kernel's tail (simulation on the bench's partition sizes and probe counts: makespan / mean 1.37 in
+// index order, 1.15 largest-first at 722 slices on 256 CUs).  One workgroup: class histogram, scan, scatter (the order inside a class is
+// whatever the atomics give -- only the schedule depends on it).
+__global__ __launch_bounds__(1024) void ms_slice_order_kernel(const MsSlice *__restrict__ slices, const uint32_t *__restrict__ slice_start, int nlist,
+                                                              uint32_t rs_rows, uint32_t *__restrict__ order) {
+  __shared__ uint32_t hist[32], base[32];
+  const uint32_t n = slice_start[nlist];
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0u;
+  __syncthreads();
+  auto cls = [&](uint32_t i) -> uint32_t {
+    const uint64_t w = (uint64_t)slices[i].row_count * slices[i].qp;      // <= rs_rows * MS3_PB
+    return 31u - (uint32_t)min<uint64_t>(31u, w * 32u / ((uint64_t)rs_rows * MS3_PB));
+  };
+  for (uint32_t i = threadIdx.x; i < n; i += 1024u) atomicAdd(&hist[cls(i)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t run = 0; for (int b = 0; b < 32; ++b) { base[b] = run; run += hist[b]; } }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += 1024u) order[atomicAdd(&base[cls(i)], 1u)] = i;
+}
+
+struct MscanArgs {
+  const uint32_t *order;        // [slices] by decreasing work
   const MsSlice *slices;
   const uint32_t *slice_start;  // [nlist + 1]: slice_start[nlist] = number of slices
   uint32_t *slice_ctr;          // [1] next slice (zeroed by ms_slice_table_kernel)
@@ -548,218 +280,28 @@ struct Mscan3Args {
   const float *row_cn2;         // [n] sigma^2 |c^_row|^2
   const _Float16 *rh;           // [pairs][d]
   const f4 *prm;                // [pairs] grouped order: {limit sigma^2, -, -, pair}
-  const f2 *prm2;               // [nq * nprobes] by pair: {s / sigma^2, |r|^2 s}
+  const f2 *prm2;               // [nq * nprobes] by pair (read by the merge kernel; here only passed along)
   uint32_t nan_slot;
   int nlist, nprobes;
   uint32_t *seg_cnt, *seg_pos;
-  uint16_t *seg_sum;
-  float *seg_val = nullptr;     // rows-on-lanes kernel: [nq * nprobes][Q_CAP] the survivors' accumulator values (the merge kernel scales them)
+  float *seg_val = nullptr;     // [nq * nprobes][Q_CAP] the survivors' accumulator values (the merge kernel scales them into integer sums)
   uint32_t *ovf;
   const uint32_t *allow;
   int dbg = 0;                          // LANCE_HIP_MS_DBG (timing experiments, results WRONG): 1 = the flush drops its entries, 2 = every limit a NaN (nothing passes)
-  unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1 (rows-on-lanes kernel): [0] stage [1] gather [2] tiles [3] flush [4] life [5] waves [6] chunks [7] longest life
+  unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1: [0] stage [1] gather [2] tiles [3] flush [4] life [5] waves [6] chunks [7] longest life
 };
 
-template <int SD, int KS>
-__global__ __launch_bounds__(512, 2) void ivfpq_mscan3_kernel(Mscan3Args p) {
-  constexpr int D = KS * 16;
-  constexpr int M = D / SD;
-  constexpr int RB = D * 2;                 // bytes of a pair's f16 residual
-  constexpr int CPR = RB / 16;              // 16-byte chunks per pair row (16 / 8)
-  constexpr int RPK = 256 / RB;             // pair rows per 256 bytes (1 / 2): the swizzle key is (row / RPK) & (CPR - 1)
-  constexpr int SPI = 8192 / RB;            // pair slots one 512-lane DMA pass covers (32 / 64)
-  constexpr int PE = MS3_QCAP / 64;
-  __shared__ __attribute__((aligned(16))) char sB[MS3_PB * RB];
-  __shared__ __attribute__((aligned(16))) f4 sP[MS3_PB];
-  __shared__ __attribute__((aligned(8))) uint2 sQ[8][MS3_QCAP + 1];
-  __shared__ uint32_t s_slice, s_chunk;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, g = lane >> 5;
-  const uint32_t nslices = p.slice_start[p.nlist];
-
-  uint2 *myq = sQ[wave];
-  uint32_t qn = 0;      // wave-uniform: queue entries
-  // pending flush: entries whose segment slot has been requested (atomicAdd issued, sum scale requested) but not yet used
-  uint32_t pd_pair[PE], pd_pos[PE], pd_k[PE];
-  float pd_a[PE];
-  f2 pd_yz[PE];
-#pragma unroll
-  for (int i = 0; i < PE; ++i) { pd_pair[i] = 0xFFFFFFFFu; pd_pos[i] = 0u; pd_k[i] = 0u; pd_a[i] = 0.0f; pd_yz[i] = f2{0.0f, 0.0f}; }
-  auto flush_end = [&]() {
-#pragma unroll
-    for (int i = 0; i < PE; ++i) {
-      if (pd_pair[i] != 0xFFFFFFFFu) {
-        const uint32_t k = pd_k[i], pair = pd_pair[i];
-        if (k < (uint32_t)Q_CAP) {
-          const float S = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(pd_a[i], pd_yz[i].x, pd_yz[i].y)), 0.0f, 65535.0f);
-          p.seg_pos[(int64_t)pair * Q_CAP + k] = pd_pos[i];
-          p.seg_sum[(int64_t)pair * Q_CAP + k] = (uint16_t)S;
-        } else if (k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
-          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
-        }
-        pd_pair[i] = 0xFFFFFFFFu;
-      }
-    }
-  };
-  auto flush_begin = [&](uint32_t pos_base) {
-#pragma unroll
-    for (int i = 0; i < PE; ++i) {
-      const uint32_t e = (uint32_t)lane + 64u * (uint32_t)i;
-      if (e < qn) {
-        const uint2 ent = myq[e];
-        const uint32_t pair = ent.x >> 8, pos = pos_base + (ent.x & 255u);
-        if (row_allowed(p.allow, pos)) {
-          pd_pair[i] = pair; pd_pos[i] = pos; pd_a[i] = __uint_as_float(ent.y);
-          pd_yz[i] = p.prm2[pair];
-          pd_k[i] = atomicAdd(&p.seg_cnt[pair], 1u);
-        }
-      }
-    }
-    qn = 0;
-  };
-
-  for (;;) {
-    __syncthreads();      // every wave is done with the previous slice's block (and with s_slice / s_chunk)
-    if (threadIdx.x == 0) { s_slice = atomicAdd(p.slice_ctr, 1u); s_chunk = 0u; }
-    __syncthreads();
-    const uint32_t slice = s_slice;
-    if (slice >= nslices) break;
-    const MsSlice U = p.slices[slice];
-    const int Qp = (int)U.qp;
-    const int nslots = ((Qp + 31) >> 5) << 5;
-    {
-      // LDS-DMA of the pair block: lane-linear destination, swizzled source; padded slots keep whatever was there (their limit is a NaN)
-      const char *src = reinterpret_cast<const char *>(p.rh + (int64_t)U.gs * D);
-#pragma unroll 4
-      for (int it = 0; it < MS3_PB / SPI; ++it) {
-        const int slot = it * SPI + wave * (SPI / 8) + lane / CPR, k = lane % CPR;
-        if (it * SPI < nslots && slot < Qp)
-          __builtin_amdgcn_global_load_lds((ms_gptr)(src + (int64_t)slot * RB + ((k ^ ((slot / RPK) & (CPR - 1))) << 4)),
-                                           (ms_lptr)(&sB[(it * SPI + wave * (SPI / 8)) * RB]), 16, 0, 0);
-      }
-      const int slot = wave * 64 + lane;
-      if (slot < nslots) {
-        const f4 *ps = slot < Qp ? p.prm + (int64_t)U.gs + slot : p.prm + p.nan_slot;
-        __builtin_amdgcn_global_load_lds((ms_gptr)ps, (ms_lptr)(&sP[wave * 64]), 16, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is ordered for the readers by the issuer's vmcnt(0) + the barrier
-    __syncthreads();
-    const uint32_t nchunks = (U.row_count + 63u) >> 6;
-    const int nblk = nslots >> 5;
-    const int row_end = (int)(U.row_begin + U.row_count);      // <= np
-
-    for (;;) {
-      uint32_t c = 0;
-      if (lane == 0) c = atomicAdd(&s_chunk, 1u);
-      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-      if (c >= nchunks) break;
-      const int row0 = (int)(U.row_begin + c * 64u);
-
-      // A: the f16 reconstruction of this wave's 64 rows, in MFMA operand layout (lane (j, g): row j of the 32-block, k-slice g)
-      ms_h8 a[2][KS];
-      ms_f16v cinit[2];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const int rowc = min(row0 + rb * 32 + j, row_end - 1);
-        uint32_t cw[M / 4];
-        {
-          const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)U.off + rowc) * M);      // rows of 16 / 32 bytes, 16-byte aligned
-#pragma unroll
-          for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
-        }
-        auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          if constexpr (SD == 8) {
-            const uint32_t c0 = code(2 * s), c1 = code(2 * s + 1);
-            const int mm = 2 * s + g;
-            a[rb][s] = *reinterpret_cast<const ms_h8 *>(p.cbh + ((int64_t)mm * 256 + (g ? c1 : c0)) * 8);
-          } else {
-            static_assert(SD == 4, "sub-dimension 4 / 8");
-            const uint32_t c0 = g ? code(4 * s + 2) : code(4 * s), c1 = g ? code(4 * s + 3) : code(4 * s + 1);
-            const int mm = 4 * s + 2 * g;
-            const ms_h4 lo = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)mm * 256 + c0) * 4);
-            const ms_h4 hi = *reinterpret_cast<const ms_h4 *>(p.cbh + ((int64_t)(mm + 1) * 256 + c1) * 4);
-            a[rb][s] = ms_h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
-        }
-        // D[row i][query j]: lane (j, g) holds rows i = (v & 3) + 8 (v >> 2) + 4 g of the 32-block (layout as in mfma_assign.hip)
-#pragma unroll
-        for (int vq = 0; vq < 4; ++vq)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = row0 + rb * 32 + 8 * vq + 4 * g + e;
-            cinit[rb][vq * 4 + e] = r < row_end ? p.row_cn2[(int64_t)U.off + r] : INFINITY;      // a padded row never passes
-          }
-      }
-      const uint32_t pos_base = U.off + (uint32_t)row0;
-
-      for (int jb = 0; jb < nblk; ++jb) {
-        const int slot = jb * 32 + j;
-        ms_h8 b[KS];
-        const char *br = &sB[slot * RB];
-        const int key = (slot / RPK) & (CPR - 1);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) b[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
-        const f4 P = sP[slot];
-        const float lim = P.x;
-        const uint32_t pair8 = __float_as_uint(P.w) << 8;
-        // room for a tile's usual yield (13 survivors at C2); a burst beyond the queue is handled after the tile
-        if (qn > (uint32_t)(MS3_QCAP - 48)) { flush_end(); flush_begin(pos_base); }
-        uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          ms_f16v acc = cinit[rb];
-#pragma unroll
-          for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][s], b[s], acc, 0, 0, 0);
-          uint64_t mk[16];
-#pragma unroll
-          for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= lim);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            if (mk[v]) {
-              const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
-                                       (uint32_t)MS3_QCAP);      // entry MS3_QCAP: the bin of a burst
-              if (acc[v] <= lim) {      // (the same compare: the compiler reuses its lane mask as the exec mask)
-                const uint32_t rowl = (uint32_t)(rb * 32 + (v & 3) + 8 * (v >> 2) + 4 * g);
-                myq[idx] = make_uint2(pair8 | rowl, __float_as_uint(acc[v]));
-              }
-              qraw += (uint32_t)__popcll(mk[v]);
-            }
-          }
-        }
-        qn = min(qraw, (uint32_t)MS3_QCAP);
-        if (qraw > (uint32_t)MS3_QCAP) {
-          // more than a queue's worth of survivors in one tile (>= 4 % of its cells pass -- these pairs' segments would overflow anyway):
-          // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
-          // crosses it lists the pair
-          if (g == 0 && slot < Qp) {
-            const uint32_t pair = pair8 >> 8;
-            const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
-            if (k <= (uint32_t)Q_CAP) p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
-          }
-        }
-      }
-      flush_end();              // stores behind the atomics issued a chunk (or a mid-chunk flush) ago
-      flush_begin(pos_base);    // atomics for this chunk's survivors; their stores go out at the next chunk's end
-    }
-  }
-  flush_end();
-}
-
-// ---- the scan, rows on the lanes (the default) -------------------------------------------------------------------------------------------
-// SQ counters of the kernel above (gpurun r04l): 0.242 ms, VALU busy 23 %, MFMA busy 17 %, waves waiting 47 % of their cycles -- with two
-// waves per SIMD (244 VGPRs) each wave's ~290 instructions per tile run at ~16 cycles apiece (LDS round trip in front of the MFMA chain,
-// the chain itself, scalar branches on sixteen masks) and one sibling wave cannot fill that.  Same slices, same block in LDS, but the
-// operands of the MFMA trade places: D = Q x R^T, queries down the accumulator registers, ROWS across the lanes.  The accumulator then
-// starts at one value per lane (|c^|^2 of the lane's row: 1 VGPR instead of 32), a wave carries ONE 32-row block (32 VGPRs of
-// reconstruction instead of 64), and the kernel fits in 128 VGPRs: sixteen waves per CU, four per SIMD.  Limits come per query = per
-// accumulator register (four broadcast ds_read_b128 per tile); a queue entry names the pair's LDS slot, resolved at flush time.
-constexpr int MS4_QH = 64;          // entries per queue half (one per lane)
+// ---- the scan -------------------------------------------------------------------------------------------------------------------------
+// One persistent 1024-lane workgroup per CU.  It takes a slice from the device counter (largest first), brings the block's f16 residuals
+// into LDS once (LDS-DMA, lane-linear destination, XOR-swizzled SOURCE address and the same swizzle on the ds_read_b128 address), limits
+// and pair ids beside them, and then its sixteen waves work independently: a wave takes 32-row chunks from an LDS counter, gathers the
+// chunk's reconstruction into registers (the MFMA's B operand: lane (j, g) = row j, k-slice g) and runs it against every 32-query tile
+// of the block: D = Q x R^T, queries down the accumulator registers, rows across the lanes, accumulator started at |c^|^2 - limit.
+// Sixteen compares with zero -> sixteen lane masks -> scalar tests; a survivor is queued (pair slot, row, accumulator value); a full
+// queue half requests its segment slots (atomicAdd, nothing waits) while the other half fills, and writes behind them a few tiles later.
+constexpr int MS_QH = 64;          // entries per queue half (one per lane)
 template <int SD, int KS, bool PROF = false>
-__global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
+__global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   constexpr int D = KS * 16;
   constexpr int M = D / SD;
   constexpr int RB = D * 2;                 // bytes of a pair's f16 residual
@@ -769,7 +311,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
   __shared__ __attribute__((aligned(16))) char sB[MS3_PB * RB];
   __shared__ __attribute__((aligned(16))) float sLim[MS3_PB];
   __shared__ __attribute__((aligned(16))) uint32_t sPair[MS3_PB];
-  __shared__ __attribute__((aligned(8))) uint2 sQ[16][2][MS4_QH + 1];      // per wave: two halves (fill one while the other's atomics are in flight)
+  __shared__ __attribute__((aligned(8))) uint2 sQ[16][2][MS_QH + 1];      // per wave: two halves (fill one while the other's atomics are in flight)
   __shared__ uint32_t s_slice, s_chunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
@@ -790,7 +332,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
   auto flush_end = [&]() {
     if (pd_n) {
       if ((uint32_t)lane < pd_n && pd_k != 0xFFFFFFFFu) {
-        const uint2 ent = qw[((uint32_t)(MS4_QH + 1) - cur) + (uint32_t)lane];
+        const uint2 ent = qw[((uint32_t)(MS_QH + 1) - cur) + (uint32_t)lane];
         const uint32_t pair = sPair[ent.x >> 8];
         if (pd_k < (uint32_t)Q_CAP) {
           p.seg_pos[(int64_t)pair * Q_CAP + pd_k] = pd_base + (ent.x & 255u);
@@ -809,7 +351,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
       if (row_allowed(p.allow, pos_base + (ent.x & 255u))) pd_k = atomicAdd(&p.seg_cnt[sPair[ent.x >> 8]], 1u);
     }
     pd_n = qn; pd_base = pos_base; qn = 0;
-    cur = (uint32_t)(MS4_QH + 1) - cur;
+    cur = (uint32_t)(MS_QH + 1) - cur;
   };
 
   for (;;) {
@@ -818,7 +360,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
     __syncthreads();
     const uint32_t slice = s_slice;
     if (slice >= nslices) break;
-    const MsSlice U = p.slices[slice];
+    const MsSlice U = p.slices[p.order[slice]];
     const int Qp = (int)U.qp;
     const int nslots = ((Qp + 31) >> 5) << 5;
     {
@@ -888,14 +430,20 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
         const long long t = clock64(); pc_gather += t - pct; pct = t;
       }
 
-      for (int jb = 0; jb < nblk; ++jb) {
-        // A: the tile's 32 queries (lane (i, g): query i, k-slice g); D[query i][row j]: lane (j, g) holds queries i = (v & 3) + 8 (v >> 2) + 4 g
-        const int slot = jb * 32 + j;
-        ms_h8 qa[KS];
-        const char *br = &sB[slot * RB];
-        const int key = (slot / RPK) & (CPR - 1);
+      // A: a tile's 32 queries (lane (i, g): query i, k-slice g); D[query i][row j]: lane (j, g) holds queries i = (v & 3) + 8 (v >> 2) + 4 g.
+      // The loop is rotated: tile jb + 1's operand is requested right behind tile jb's MFMAs (into the same registers -- the chain has
+      // read them by then), so its LDS round trip runs under the compare / queue work instead of in front of the next chain.
+      ms_h8 qa[KS];
+      auto load_qa = [&](int jbx) {
+        const int sl = jbx * 32 + j;
+        const char *br = &sB[sl * RB];
+        const int key = (sl / RPK) & (CPR - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) qa[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
+      };
+      load_qa(0);
+      for (int jb = 0; jb < nblk; ++jb) {
+        const int slot = jb * 32 + j;
         // the accumulator starts at |c^|^2 - limit (row's constant minus the query's limit): the test is a compare with zero and neither
         // sixteen limits nor a sixteen-register splat of |c^|^2 stay live across the tile (128 VGPRs = four waves per SIMD)
         ms_f16v acc;
@@ -909,7 +457,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
         }
         const uint32_t ebase = ((uint32_t)(jb * 32 + 4 * g) << 8) | (uint32_t)j;
         // room for a tile's usual yield; a burst beyond the queue is handled after the tile
-        if (qn > (uint32_t)(MS4_QH - 32)) {      // room for a tile's usual yield (6-7 survivors at C2); a burst beyond the half is handled after the tile
+        if (qn > (uint32_t)(MS_QH - 32)) {      // room for a tile's usual yield (6-7 survivors at C2); a burst beyond the half is handled after the tile
           if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; }
           flush_end(); flush_begin(pos_base);
           if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; }
@@ -917,6 +465,9 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
         uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s], rw[s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_qa(min(jb + 1, nblk - 1));      // (the last tile re-reads itself: harmless)
+        __builtin_amdgcn_sched_barrier(0);
         uint64_t mk[16];
 #pragma unroll
         for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= 0.0f);
@@ -925,14 +476,14 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan4_kernel(Mscan3Args p) {
         for (int v = 0; v < 16; ++v) {
           if (mk[v]) {
             const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
-                                     (uint32_t)MS4_QH);      // entry MS4_QH: the bin of a burst
+                                     (uint32_t)MS_QH);      // entry MS_QH: the bin of a burst
             if (acc[v] <= 0.0f)      // (the same compare: the compiler reuses its lane mask as the exec mask)
               qw[cur + idx] = make_uint2(ebase + ((uint32_t)((v & 3) + 8 * (v >> 2)) << 8), __float_as_uint(acc[v]));
             qraw += (uint32_t)__popcll(mk[v]);
           }
         }
-        qn = min(qraw, (uint32_t)MS4_QH);
-        if (qraw > (uint32_t)MS4_QH) {
+        qn = min(qraw, (uint32_t)MS_QH);
+        if (qraw > (uint32_t)MS_QH) {
           // more than the half's room in one tile (>= 2 % of its cells pass -- these pairs' segments would overflow anyway):
           // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
           // crosses it lists the pair
@@ -996,7 +547,7 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   float cbmax = 0.0f;
   for (float v : cb) cbmax = std::max(cbmax, std::fabs(v));
   auto *mc = new lance_hip_index::MsConst();
-  if (!(cbmax > 0.0f) || !std::isfinite(cbmax)) {      // an all-zero codebook: nothing to scale by -- the integer scan serves this index
+  if (!(cbmax > 0.0f) || !std::isfinite(cbmax) || ix->n == 0) {      // an all-zero codebook: nothing to scale by -- the integer scan serves this index
     mc->usable = false;
     ix->ms = mc;
     return LANCE_HIP_OK;
@@ -1006,19 +557,15 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   mc->sigma = std::ldexp(1.0f, 13 - e);      // 2 sigma cbmax in [2^13, 2^14)
   bool ok = hipMalloc(reinterpret_cast<void **>(&mc->cbh), (size_t)nwords * sd * 2) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void **>(&mc->cbn2), (size_t)nwords * 4) == hipSuccess;
-  ok = ok && hipMalloc(reinterpret_cast<void **>(&mc->row_cn2), (size_t)(ix->n ? ix->n : 1) * 4) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&mc->row_cn2), (size_t)ix->n * 4) == hipSuccess;
   auto drop = [&]() { (void)hipFree(mc->cbh); (void)hipFree(mc->cbn2); (void)hipFree(mc->row_cn2); delete mc; };
   if (!ok) { drop(); set_error("matrix-core scan: out of device memory for the index constants"); return LANCE_HIP_ENOMEM; }
   hipLaunchKernelGGL(ms_codebook_kernel, dim3((unsigned)cdiv((uint64_t)nwords, 256)), dim3(256), 0, ctx->stream, ix->codebook, nwords, sd,
                      -2.0f * mc->sigma, reinterpret_cast<_Float16 *>(mc->cbh), mc->cbn2);
-  if (ix->n)
-    hipLaunchKernelGGL(ms_row_norm_kernel, dim3((unsigned)cdiv(ix->n, 256)), dim3(256), 0, ctx->stream, ix->codes, (int64_t)ix->n, m, mc->cbn2,
-                       mc->sigma * mc->sigma, mc->row_cn2);
-  uint64_t units = 0;
-  for (uint32_t pid = 0; pid < ix->nlist; ++pid) units += cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), MS_RW);
-  mc->max_units = (uint32_t)std::min<uint64_t>(units, 0x7FFFFFF0u);
+  hipLaunchKernelGGL(ms_row_norm_kernel, dim3((unsigned)cdiv(ix->n, 256)), dim3(256), 0, ctx->stream, ix->codes, (int64_t)ix->n, m, mc->cbn2,
+                     mc->sigma * mc->sigma, mc->row_cn2);
   for (uint32_t pid = 0; pid < ix->nlist; ++pid) {
-    const uint32_t rs = (uint32_t)cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), MS3_RS);
+    const uint32_t rs = (uint32_t)cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), (uint64_t)ms_rows_per_slice());
     mc->sum_rs += rs; mc->max_rs = std::max(mc->max_rs, rs);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {   // other contexts (streams) search the same index
@@ -1032,7 +579,8 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
 }
 
 // -1: this index cannot take the matrix-core scan (the caller falls back to the integer scan); otherwise a status code.
-// Replaces qscan_launch: same outputs (seg_cnt / seg_pos / seg_sum / qovf / ovf), plus qslack for the merge kernel's cut.
+// Replaces qscan_launch: same segment outputs (seg_cnt / seg_pos / qovf / ovf) with the survivors' accumulator values (seg_val) and the
+// per-pair scale that turns them into integer sums (seg_scale), plus qslack for the merge kernel's cut.
 int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *probes,
                  const uint32_t *pair_starts, const uint32_t *pair_idx, const uint32_t *tbound, uint32_t *seg_cnt, uint32_t *seg_pos,
                  uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out) {
@@ -1040,21 +588,23 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   int sd = 0, ks = 0;
   if (!ms_shape(ix, &sd, &ks)) return -1;
   LH_TRY(mscan_prepare(ctx, ix));
-  if (!ix->ms->usable || ix->ms->max_units == 0) return -1;
-  static const bool v2 = getenv("LANCE_HIP_MS_V2") != nullptr || (getenv("LANCE_HIP_MS_PROF") != nullptr && getenv("LANCE_HIP_MS_PROF4") == nullptr);      // the pipelined kernel, kept for A/B
-  static const bool v3 = getenv("LANCE_HIP_MS_V3") != nullptr;      // queries on the lanes, 8 waves per CU: kept for A/B
+  if (!ix->ms->usable) return -1;
   const int d = (int)ix->d, nlist = (int)ix->nlist;
   const size_t npairs = (size_t)nq * nprobes;
+  // slices: at most sum over the partitions of (row slices) x (pair blocks), pair blocks <= pairs / MS3_PB + 1 per partition
+  const uint64_t cap = (uint64_t)ix->ms->sum_rs + (uint64_t)ix->ms->max_rs * cdiv(npairs, MS3_PB) + 8;
   _Float16 *rh = reinterpret_cast<_Float16 *>(ctx->scratch("ms.rh", (npairs + 32) * (size_t)d * 2));
   f4 *prm = reinterpret_cast<f4 *>(ctx->scratch("ms.prm", (npairs + 32) * 16));
-  uint32_t *qslack = ctx->scratch_t<uint32_t>("ms.qslack", nq);
-  uint32_t *unit_start = ctx->scratch_t<uint32_t>("ms.unit_start", (size_t)nlist + 1);
-  MsUnit *units = reinterpret_cast<MsUnit *>(ctx->scratch("ms.units", ((size_t)ix->ms->max_units + 8) * sizeof(MsUnit)));
-  const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
   f2 *prm2 = reinterpret_cast<f2 *>(ctx->scratch("ms.prm2", npairs * 8));
-  uint16_t *seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", npairs * Q_CAP);   // the merge launcher asks for the same slot
-  uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // likewise
-  if (!rh || !prm || !qslack || !unit_start || !units || !prm2 || !seg_sum || !ovf) return LANCE_HIP_ENOMEM;
+  uint32_t *qslack = ctx->scratch_t<uint32_t>("ms.qslack", nq);
+  uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2);      // [nlist + 1], then the work counter
+  MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
+  uint32_t *order = ctx->scratch_t<uint32_t>("ms.order", cap);
+  float *seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
+  uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // the merge launcher asks for the same slot
+  if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !seg_val || !ovf) return LANCE_HIP_ENOMEM;
+  uint32_t *slice_ctr = slice_start + nlist + 1;
+  const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
   {
     ScopedTimer t(ctx, "q_residual");
     LH_CHECK_HIP(lh::memset_async(seg_cnt, 0, npairs * 4, ctx->stream));
@@ -1065,94 +615,43 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.q = qs; pa.centroids = ix->centroids; pa.pair_idx = pair_idx; pa.pair_starts = pair_starts; pa.probes = probes; pa.tbound = tbound;
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     pa.sigma = ix->ms->sigma; pa.rh = rh; pa.prm = prm; pa.qslack = qslack; pa.seg_cnt = seg_cnt; pa.qovf = qovf; pa.ovf = ovf;
-    pa.nan_slot = nan_slot; pa.prm2 = prm2; pa.rel_limit = (!v2 && !v3) ? 1 : 0;
+    pa.nan_slot = nan_slot; pa.prm2 = prm2;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
-    if (v2) {
-      hipLaunchKernelGGL(ms_unit_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, unit_start);
-      hipLaunchKernelGGL(ms_unit_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, unit_start, pair_starts, ix->part_offsets,
-                         nlist, units);
-    }
-  }
-  if (!v2) {
-    // slices: at most sum over the partitions of (row slices) x (pair blocks), pair blocks <= pairs / MS3_PB + 1 per partition
-    const uint64_t cap = (uint64_t)ix->ms->sum_rs + (uint64_t)ix->ms->max_rs * cdiv(npairs, MS3_PB) + 8;
-    uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2);      // [nlist + 1], then the work counter
-    MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
-    if (!slice_start || !slices) return LANCE_HIP_ENOMEM;
-    uint32_t *slice_ctr = slice_start + nlist + 1;
-    {
-      ScopedTimer tq(ctx, "q_residual");
-      hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, slice_start, slice_ctr);
-      hipLaunchKernelGGL(ms_slice_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, slice_start, pair_starts, ix->part_offsets,
-                         nlist, slices);
-    }
-    ScopedTimer t(ctx, "ivfpq_scan_c1");
-    ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
-    Mscan3Args a3;
-    a3.slices = slices; a3.slice_start = slice_start; a3.slice_ctr = slice_ctr; a3.codes = ix->codes;
-    a3.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a3.row_cn2 = ix->ms->row_cn2; a3.rh = rh; a3.prm = prm; a3.prm2 = prm2;
-    a3.nan_slot = nan_slot; a3.nlist = nlist; a3.nprobes = (int)nprobes;
-    a3.seg_cnt = seg_cnt; a3.seg_pos = seg_pos; a3.seg_sum = seg_sum; a3.ovf = ovf; a3.allow = allow;
-    if (!v3) {
-      a3.seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
-      if (!a3.seg_val) return LANCE_HIP_ENOMEM;
-    }
-    const unsigned grid3 = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus, cap);
-    static const int dbg = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
-    a3.dbg = dbg;
-    static const bool prof4 = getenv("LANCE_HIP_MS_PROF4") != nullptr;      // s_memtime phase stamps of the rows-on-lanes kernel (d = 128, M = 16)
-    if (prof4 && !v3 && sd == 8 && ks == 8) {
-      a3.prof = ctx->scratch_t<unsigned long long>("ms.prof", 8);
-      if (!a3.prof) return LANCE_HIP_ENOMEM;
-      LH_CHECK_HIP(lh::memset_async(a3.prof, 0, 64, ctx->stream));
-      hipLaunchKernelGGL((ivfpq_mscan4_kernel<8, 8, true>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
-      unsigned long long h[8];
-      LH_CHECK_HIP(hipMemcpyAsync(h, a3.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
-      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-      if (h[5])
-        fprintf(stderr, "[ms4 prof] waves=%llu chunks/wave %.2f | s_memtime ticks per wave: stage+barriers %.0f | gather %.0f | tiles %.0f | flush %.0f | life %.0f (longest %llu)\n",
-                h[5], (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[7]);
-    } else
-    if (!v3 && sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan4_kernel<8, 8>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
-    else if (!v3 && sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan4_kernel<4, 8>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
-    else if (!v3 && sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan4_kernel<4, 4>), dim3(grid3), dim3(1024), 0, ctx->stream, a3);
-    else if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<8, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
-    else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan3_kernel<4, 8>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
-    else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan3_kernel<4, 4>), dim3(grid3), dim3(512), 0, ctx->stream, a3);
-    else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
-    LH_CHECK_HIP(hipGetLastError());
-    if (qslack_out) *qslack_out = qslack;
-    if (!v3) { *seg_val_out = a3.seg_val; *seg_scale_out = reinterpret_cast<float *>(prm2); }
-    return LANCE_HIP_OK;
+    const uint32_t rs_rows = (uint32_t)ms_rows_per_slice();
+    hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, rs_rows, slice_start, slice_ctr);
+    hipLaunchKernelGGL(ms_slice_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, slice_start, pair_starts, ix->part_offsets,
+                       nlist, rs_rows, slices);
+    static const bool no_order = getenv("LANCE_HIP_MS_NOORDER") != nullptr;      // A/B: one work class = slices in (roughly) index order
+    hipLaunchKernelGGL(ms_slice_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, slices, slice_start, nlist, no_order ? 0x40000000u : rs_rows, order);
   }
   ScopedTimer t(ctx, "ivfpq_scan_c1");
-  MscanArgs a;
-  a.unit_start = unit_start; a.pair_starts = pair_starts; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
-  a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm;
-  a.nlist = nlist; a.nprobes = (int)nprobes; a.m = (int)ix->m; a.units = units; a.nan_slot = nan_slot; a.prm2 = prm2;
-  a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_sum = seg_sum; a.qovf = qovf; a.ovf = ovf; a.allow = allow;
-  const unsigned grid = (ix->ms->max_units + 7u) & ~7u;
   ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
-  static const bool prof = getenv("LANCE_HIP_MS_PROF") != nullptr;  // s_memtime phase stamps of the pipelined kernel (printed per launch)
-  if (prof) {
+  MscanArgs a;
+  a.order = order; a.slices = slices; a.slice_start = slice_start; a.slice_ctr = slice_ctr; a.codes = ix->codes;
+  a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm; a.prm2 = prm2;
+  a.nan_slot = nan_slot; a.nlist = nlist; a.nprobes = (int)nprobes;
+  a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
+  static const int dbg = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
+  a.dbg = dbg;
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus, cap);      // persistent: one workgroup per CU (151 KiB of LDS each)
+  static const bool prof = getenv("LANCE_HIP_MS_PROF") != nullptr;      // s_memtime phase stamps (d = 128, M = 16), printed per launch; plain path only
+  if (prof && sd == 8 && ks == 8 && !ctx->capturing) {
     a.prof = ctx->scratch_t<unsigned long long>("ms.prof", 8);
     if (!a.prof) return LANCE_HIP_ENOMEM;
     LH_CHECK_HIP(lh::memset_async(a.prof, 0, 64, ctx->stream));
-    if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<8, 8, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 8, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 4, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((ivfpq_mscan_kernel<8, 8, true>), dim3(grid), dim3(1024), 0, ctx->stream, a);
     unsigned long long h[8];
     LH_CHECK_HIP(hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
     LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if (h[5])
-      fprintf(stderr, "[ms prof] waves=%llu super-blocks/wave %.2f | 100 MHz clocks per wave: prologue %.0f | barrier waits %.0f | flush + DMA issue %.0f | tiles %.0f | tail %.0f\n",
-              h[5], (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5]);
-  } else if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<8, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 8>), dim3(grid), dim3(256), 0, ctx->stream, a);
-  else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan2_kernel<4, 4>), dim3(grid), dim3(256), 0, ctx->stream, a);
+      fprintf(stderr, "[ms prof] waves=%llu chunks/wave %.2f | s_memtime ticks per wave: stage+barriers %.0f | gather %.0f | tiles %.0f | flush %.0f | life %.0f (longest %llu)\n",
+              h[5], (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[7]);
+  } else if (sd == 8 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan_kernel<8, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
+  else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
+  else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan_kernel<4, 4>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
   LH_CHECK_HIP(hipGetLastError());
-  if (qslack_out) *qslack_out = qslack;
+  *qslack_out = qslack; *seg_val_out = seg_val; *seg_scale_out = reinterpret_cast<float *>(prm2);
   return LANCE_HIP_OK;
 }
 
