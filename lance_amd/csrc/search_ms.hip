@@ -193,20 +193,47 @@ static int ms_rows_per_slice() {    // LANCE_HIP_MS_RS: A/B of the slice height 
 }
 struct MsSlice { uint32_t off, np, row_begin, row_count, gs, qp, pad0, pad1; };
 
-// slice_start[p] = exclusive scan of (pair blocks of partition p) x (row slices of partition p)
+// slice_start[p] = exclusive scan of (pair blocks of partition p) x (row slices of partition p); cls_cursor[c] = first position, in the
+// largest-first order, of work class c (rows x pairs in 32 classes, class 0 the largest).  The persistent workgroups take slices from a
+// counter, and a large slice taken last would be the kernel's tail (simulation on the bench's partition sizes and probe counts:
+// makespan / mean 1.37 in index order, 1.15 largest-first at 722 slices on 256 CUs; measured: scan 0.211 -> 0.188 ms).
+__device__ __forceinline__ uint32_t ms_work_class(uint32_t rows, uint32_t pairs, uint32_t rs_rows) {
+  const uint64_t w = (uint64_t)rows * pairs;      // <= rs_rows * MS3_PB
+  return 31u - (uint32_t)min<uint64_t>(31u, w * 32u / ((uint64_t)rs_rows * MS3_PB));
+}
+struct MsSplit { uint32_t npb, blk, nrs; };
+__device__ __forceinline__ MsSplit ms_split(uint32_t qp, uint32_t np, uint32_t rs_rows) {
+  MsSplit r;
+  r.npb = (qp + MS3_PB - 1) / MS3_PB;
+  r.blk = r.npb ? ((((qp + r.npb - 1) / r.npb) + 31u) & ~31u) : 0u;      // equal pair blocks, whole tiles of 32 (<= MS3_PB)
+  r.nrs = (np + rs_rows - 1) / rs_rows;
+  return r;
+}
+
 __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__restrict__ pair_starts, const uint32_t *__restrict__ part_offsets, int nlist,
-                                                             uint32_t rs_rows, uint32_t *__restrict__ slice_start, uint32_t *__restrict__ slice_ctr) {
+                                                             uint32_t rs_rows, uint32_t cls_rows, uint32_t *__restrict__ slice_start,
+                                                             uint32_t *__restrict__ slice_ctr, uint32_t *__restrict__ cls_cursor) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry_s;
+  __shared__ uint32_t hist[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { carry_s = 0; slice_ctr[0] = 0u; }
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0u;
   __syncthreads();
   for (int base = 0; base < nlist; base += 256) {
     const int i = base + threadIdx.x;
     uint32_t v = 0;
     if (i < nlist) {
       const uint32_t qp = pair_starts[i + 1] - pair_starts[i], np = part_offsets[i + 1] - part_offsets[i];
-      v = ((qp + MS3_PB - 1) / MS3_PB) * ((np + rs_rows - 1) / rs_rows);
+      const MsSplit sp = ms_split(qp, np, rs_rows);
+      v = sp.npb * sp.nrs;
+      // at most four distinct (rows, pairs) shapes per partition: full / last row slice x full / last pair block
+      for (uint32_t pb = 0; pb < sp.npb; pb += max(1u, sp.npb - 1u)) {
+        const uint32_t pairs = min(sp.blk, qp - pb * sp.blk), npb_same = (pb + 1 == sp.npb) ? 1u : sp.npb - 1u;
+        if (sp.nrs > 1) atomicAdd(&hist[ms_work_class(rs_rows, pairs, cls_rows)], npb_same * (sp.nrs - 1u));
+        if (sp.nrs > 0) atomicAdd(&hist[ms_work_class(np - (sp.nrs - 1u) * rs_rows, pairs, cls_rows)], npb_same);
+        if (sp.npb == 1) break;
+      }
     }
     uint32_t incl = v;
 #pragma unroll
@@ -224,50 +251,33 @@ __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__r
     if (threadIdx.x == 255) carry_s = carry + woff + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) slice_start[nlist] = carry_s;
+  if (threadIdx.x == 0) {
+    slice_start[nlist] = carry_s;
+    uint32_t run = 0;
+    for (int c = 0; c < 32; ++c) { cls_cursor[c] = run; run += hist[c]; }
+  }
 }
 
 __global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__restrict__ slice_start, const uint32_t *__restrict__ pair_starts,
-                                                            const uint32_t *__restrict__ part_offsets, int nlist, uint32_t rs_rows,
-                                                            MsSlice *__restrict__ slices) {
+                                                            const uint32_t *__restrict__ part_offsets, int nlist, uint32_t rs_rows, uint32_t cls_rows,
+                                                            MsSlice *__restrict__ slices, uint32_t *__restrict__ cls_cursor, uint32_t *__restrict__ order) {
   const int part = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (part >= nlist) return;
   const uint32_t s0 = slice_start[part], s1 = slice_start[part + 1];
   if (s1 == s0) return;
   const uint32_t off = part_offsets[part], np = part_offsets[part + 1] - off;
   const uint32_t gs = pair_starts[part], qp = pair_starts[part + 1] - gs;
-  const uint32_t npb = (qp + MS3_PB - 1) / MS3_PB;
-  const uint32_t blk = (((qp + npb - 1) / npb) + 31u) & ~31u;      // equal pair blocks, whole tiles of 32 (<= MS3_PB)
+  const MsSplit sp = ms_split(qp, np, rs_rows);
   // row slices vary fastest: the slices of one pair block are taken by different CUs at about the same time (its residuals come from L2)
-  const uint32_t nrs = (np + rs_rows - 1) / rs_rows;
   for (uint32_t t = (uint32_t)lane; t < s1 - s0; t += 64u) {
-    const uint32_t pb = t / nrs, rs = t - pb * nrs;
+    const uint32_t pb = t / sp.nrs, rs = t - pb * sp.nrs;
     MsSlice u;
     u.off = off; u.np = np; u.row_begin = rs * rs_rows; u.row_count = min(rs_rows, np - u.row_begin);
-    u.gs = gs + pb * blk; u.qp = min(blk, qp - pb * blk); u.pad0 = u.pad1 = 0u;
+    u.gs = gs + pb * sp.blk; u.qp = min(sp.blk, qp - pb * sp.blk); u.pad0 = u.pad1 = 0u;
     slices[s0 + t] = u;
+    // the slice's place in the largest-first order (inside a class: whatever the atomics give -- only the schedule depends on it)
+    order[atomicAdd(&cls_cursor[ms_work_class(u.row_count, u.qp, cls_rows)], 1u)] = s0 + t;
   }
-}
-
-// order[i] = the slices by decreasing work (rows x pairs), in 32 classes: the persistent workgroups take them from a counter, and a large
-// slice taken last would be the kernel's tail (simulation on the bench's partition sizes and probe counts: makespan / mean 1.37 in
-// index order, 1.15 largest-first at 722 slices on 256 CUs).  One workgroup: class histogram, scan, scatter (the order inside a class is
-// whatever the atomics give -- only the schedule depends on it).
-__global__ __launch_bounds__(1024) void ms_slice_order_kernel(const MsSlice *__restrict__ slices, const uint32_t *__restrict__ slice_start, int nlist,
-                                                              uint32_t rs_rows, uint32_t *__restrict__ order) {
-  __shared__ uint32_t hist[32], base[32];
-  const uint32_t n = slice_start[nlist];
-  if (threadIdx.x < 32) hist[threadIdx.x] = 0u;
-  __syncthreads();
-  auto cls = [&](uint32_t i) -> uint32_t {
-    const uint64_t w = (uint64_t)slices[i].row_count * slices[i].qp;      // <= rs_rows * MS3_PB
-    return 31u - (uint32_t)min<uint64_t>(31u, w * 32u / ((uint64_t)rs_rows * MS3_PB));
-  };
-  for (uint32_t i = threadIdx.x; i < n; i += 1024u) atomicAdd(&hist[cls(i)], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t run = 0; for (int b = 0; b < 32; ++b) { base[b] = run; run += hist[b]; } }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += 1024u) order[atomicAdd(&base[cls(i)], 1u)] = i;
 }
 
 struct MscanArgs {
@@ -597,13 +607,13 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   f4 *prm = reinterpret_cast<f4 *>(ctx->scratch("ms.prm", (npairs + 32) * 16));
   f2 *prm2 = reinterpret_cast<f2 *>(ctx->scratch("ms.prm2", npairs * 8));
   uint32_t *qslack = ctx->scratch_t<uint32_t>("ms.qslack", nq);
-  uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2);      // [nlist + 1], then the work counter
+  uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2 + 32);      // [nlist + 1], the work counter, 32 class cursors
   MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
   uint32_t *order = ctx->scratch_t<uint32_t>("ms.order", cap);
   float *seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
   uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // the merge launcher asks for the same slot
   if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !seg_val || !ovf) return LANCE_HIP_ENOMEM;
-  uint32_t *slice_ctr = slice_start + nlist + 1;
+  uint32_t *slice_ctr = slice_start + nlist + 1, *cls_cursor = slice_ctr + 1;
   const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
   {
     ScopedTimer t(ctx, "q_residual");
@@ -618,11 +628,12 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.nan_slot = nan_slot; pa.prm2 = prm2;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
     const uint32_t rs_rows = (uint32_t)ms_rows_per_slice();
-    hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, rs_rows, slice_start, slice_ctr);
-    hipLaunchKernelGGL(ms_slice_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, slice_start, pair_starts, ix->part_offsets,
-                       nlist, rs_rows, slices);
     static const bool no_order = getenv("LANCE_HIP_MS_NOORDER") != nullptr;      // A/B: one work class = slices in (roughly) index order
-    hipLaunchKernelGGL(ms_slice_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, slices, slice_start, nlist, no_order ? 0x40000000u : rs_rows, order);
+    const uint32_t cls_rows = no_order ? 0x40000000u : rs_rows;
+    hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, rs_rows, cls_rows, slice_start,
+                       slice_ctr, cls_cursor);
+    hipLaunchKernelGGL(ms_slice_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, slice_start, pair_starts, ix->part_offsets,
+                       nlist, rs_rows, cls_rows, slices, cls_cursor, order);
   }
   ScopedTimer t(ctx, "ivfpq_scan_c1");
   ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
