@@ -153,6 +153,7 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
                   const uint32_t *qslack = nullptr, const float *seg_val = nullptr, const float *seg_scale = nullptr);
 // search_ms.hip: the filter scan as a [rows x d] x [d x queries] product per partition on the matrix cores (8-bit PQ, d = 64 / 128, M = 16 / 32)
 bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
+bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);   // shape + batch-size part of mscan_supported
 int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *probes,
                  const uint32_t *pair_starts, const uint32_t *pair_idx, const uint32_t *tbound, uint32_t *seg_cnt, uint32_t *seg_pos,
                  uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out);

@@ -537,13 +537,21 @@ static bool ms_shape(const lance_hip_index *ix, int *sd_out, int *ks_out) {
   return true;
 }
 
-bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
+// The matrix-core scan pays once a partition sees a few tiles' worth of queries: a wave's 32-row chunk costs a gather (codes -> 8
+// codewords -> |c^|^2) worth ~4 tiles before its first MFMA.  Measured (gpurun r04v): 390 pairs per partition (C2) 0.188 + 0.047 ms
+// against 0.354 + 0.021 for the integer scan; 24 pairs per partition (C4 shape, nlist 4096, 10k x 10) 0.463 + 0.110 against
+// 0.324 + 0.023 -- slower.  Per (row, query) cell the model (G + t C) / (1024 t) crosses the integer scan's cost near t = 3 tiles.
+bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   static const bool off = getenv("LANCE_HIP_NO_MSCAN") != nullptr;
-  static const uint32_t minq = getenv("LANCE_HIP_MSCAN_MINQ") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_MSCAN_MINQ"))) : 16u;
-  if (off || !ms_shape(ix, nullptr, nullptr) || !qscan_supported(ix, nq, nprobes)) return false;
+  static const uint32_t minq = getenv("LANCE_HIP_MSCAN_MINQ") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_MSCAN_MINQ"))) : 96u;
+  if (off || !ms_shape(ix, nullptr, nullptr)) return false;
+  if (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_COSINE) return false;
   if (qscan8_enabled((int)ix->m, (int)(ix->d / ix->m))) return false;
-  // a tile is 32 queries of one partition: worth it once the partitions see a couple of tiles' worth of queries on average
   return (uint64_t)nq * nprobes >= (uint64_t)minq * ix->nlist;
+}
+
+bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
+  return mscan_batch_shape(ix, nq, nprobes) && qscan_supported(ix, nq, nprobes);
 }
 
 static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {

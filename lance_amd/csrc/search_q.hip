@@ -894,7 +894,11 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
     if (!((m == 16 || m == 32) && (sd == 4 || sd == 8 || sd == 16)) && !qscan_tiled_shape(m, sd)) return false;
   }
   if ((uint64_t)nq * nprobes * Q_CAP * 4 > (2ull << 30)) return false;   // survivor segments: at most 2 GiB of scratch
-  if (((uint64_t)nq * nprobes / Q_G + ix->nlist + 1) * ix->d * 16 > (2ull << 30)) return false;   // item residuals likewise
+  // item residuals likewise -- where the main pass reads them: neither the per-query-table filter (search_qt.hip) nor the matrix-core
+  // scan (search_ms.hip) does.  (This check used to apply to both: a 10,000-query batch at nprobes = 50 on the C3 shape fell back to the
+  // query-major kernel, 62 ms instead of ~6: gpurun r04v.)
+  const bool needs_rq = !qscan_pt_enabled(ix) && !mscan_batch_shape(ix, nq, nprobes);
+  if (needs_rq && ((uint64_t)nq * nprobes / Q_G + ix->nlist + 1) * ix->d * 16 > (2ull << 30)) return false;
   return true;
 }
 
@@ -948,8 +952,8 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   const bool pt = probes != nullptr && qscan_pt_enabled(ix);   // per-query tables: no residual pre-pass, no table build in the scan
   const bool q8 = qscan8_enabled(m, sd);   // items hold 8 queries (qscan_group was called with G = 8): at most npairs / 8 + nlist + 2 of them
   const uint32_t max_items8 = (uint32_t)((uint64_t)nq * nprobes / 8 + ix->nlist + 2);
-  f4 *rq = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", q8 ? (size_t)max_items8 * d * 8 : (size_t)max_items4 * d * 4));
-  if (!rq) return LANCE_HIP_ENOMEM;
+  f4 *rq = pt ? nullptr : reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", q8 ? (size_t)max_items8 * d * 8 : (size_t)max_items4 * d * 4));
+  if (!pt && !rq) return LANCE_HIP_ENOMEM;
   const bool mbt = !pt && !q8 && qscan_mfma_table(ix);
   f4 *rq_n2 = nullptr;
   {

@@ -1,6 +1,6 @@
 """C3-shaped search (1M x 1536 f32 cosine, IVF_PQ nlist 1024, M 96) with the per-kernel HIP-event timers on: where a 1000-query
 batch spends its time at (nprobes, refine) = (10, 0) / (10, 10) / (50, 10).  LANCE_HIP_Q_STATS=1 adds the filter's survivor counts.
-GPU only.  Usage: python scripts/probe_c3_search.py [n_rows]"""
+GPU only.  Usage: python scripts/probe_c3_search.py [n_rows] [queries_per_batch]"""
 import json
 import os
 import sys
@@ -13,16 +13,17 @@ import lance_amd
 from lance_amd.testing import sift_like
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 d, nlist, m = 1536, 1024, 96
 dev = torch.device("cuda", 0)
 eng = lance_amd.default_engine()
 x = torch.nn.functional.normalize(sift_like(n, d, seed=77, device=dev, n_clusters=1024, latent=48, model_seed=77) - 64.0, dim=1).contiguous()
-q = torch.nn.functional.normalize(sift_like(1000, d, seed=78, device=dev, n_clusters=1024, latent=48, model_seed=77) - 64.0, dim=1).contiguous()
+q = torch.nn.functional.normalize(sift_like(nq, d, seed=78, device=dev, n_clusters=1024, latent=48, model_seed=77) - 64.0, dim=1).contiguous()
 idx = lance_amd.create_index(x, "IVF_PQ", metric="cosine", num_partitions=nlist, num_sub_vectors=m)
 torch.cuda.synchronize()
 names = ("dist_matrix", "select_probes", "pm_group", "ivfpq_scan", "ivfpq_scan_c0", "q_residual", "ivfpq_scan_c1", "q_pt_tables", "q_pt_table_only", "ivfpq_scan_cb",
          "ivfpq_merge", "ivfpq_exact", "refine")
-out = {"n": n, "build_stages_ms": {k: round(v * 1e3, 2) for k, v in idx.stats.seconds.items()}}
+out = {"n": n, "queries_per_batch": nq, "build_stages_ms": {k: round(v * 1e3, 2) for k, v in idx.stats.seconds.items()}}
 CFGS = ((10, 0), (10, 10), (50, 10))
 wall = {}
 outb = (torch.empty((q.shape[0], 10), dtype=torch.int64, device=dev), torch.empty((q.shape[0], 10), dtype=torch.float32, device=dev))

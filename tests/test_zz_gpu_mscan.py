@@ -1,9 +1,9 @@
 """The ADC filter scan on the matrix cores (lance_amd/csrc/search_ms.hip): dist = |c^|^2 - 2 r.c^ + |r|^2 with c^ the row's
-reconstruction, evaluated per partition as a [rows x d] x [d x queries] f16 product (v_mfma_f32_32x32x16_f16) whose accumulator starts
-at |c^|^2; one compare per (row, query) against T + E - |r|^2.  It only FILTERS -- the survivors are re-evaluated in the reference's
+reconstruction, evaluated per partition as a [queries x d] x [d x rows] f16 product (v_mfma_f32_32x32x16_f16) whose accumulator starts
+at |c^|^2 - limit (limit = T + E - |r|^2); one compare with zero per (row, query).  It only FILTERS -- the survivors are re-evaluated in the reference's
 arithmetic (pq/distance.rs:109-144, sequential-m sum) by the merge kernel -- so ids and distances must stay bit-equal to the oracle.
 
-Taken for 8-bit PQ, L2 / cosine, d = 64 (M 16) / 128 (M 16 / 32) once `nq * nprobes >= 16 * nlist`; every case below is sized for it
+Taken for 8-bit PQ, L2 / cosine, d = 64 (M 16) / 128 (M 16 / 32) once `nq * nprobes >= 96 * nlist` (a partition sees three tiles of queries on average); every case below is sized for it
 and ASSERTS it ran (the `ivfpq_mscan` timer).  The integer scan it replaces for these shapes (search_q.hip) keeps its coverage through
 a child process with LANCE_HIP_NO_MSCAN=1.
 """
@@ -66,14 +66,14 @@ def test_mscan_every_instantiation(eng, oracle, d, m, metric):
     oidx = oracle.build_index(x, cent, cb, metric)
     gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
     gidx = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
-    # nprobes = nlist: 700 pairs per partition = four LDS super-blocks of 192; k = 100: class B appears in the small partitions
+    # nprobes = nlist: 700 pairs per partition = two resident pair blocks of 352; k = 100: class B appears in the small partitions
     _check(eng, gidx, oidx, q, q, x, [(10, 8, 0), (10, 8, 10), (10, nlist, 0), (100, 7, 0), (1, 7, 1), (37, 9, 3), (128, 6, 0)])
     gidx.close()
 
 
 def test_mscan_non_integer_data_and_tiny_partitions(eng, oracle):
     """Gaussian rows of small magnitude (sigma = 2^13 / max codeword far from 1), unit-scale residuals, partitions of 1 .. 300 rows
-    (row padding inside the last 256-row unit, units of a single row), queries far from every centroid (large |r|^2 / T: pairs whose
+    (row padding inside a 32-row chunk, slices of a single row), queries far from every centroid (large |r|^2 / T: pairs whose
     slack exceeds the cap go to the exact rescan)."""
     from lance_amd.engine import DeviceIndex
     rng = np.random.default_rng(77)
@@ -143,7 +143,7 @@ def test_mscan_not_taken_for_small_batches_or_dot(eng, oracle):
     oidx = oracle.build_index(x, cent, cb)
     gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb)
     gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
-    with _ms_used(eng, expect=False):                  # 600 x 8 = 4800 pairs < 16 x 512: the integer scan serves it
+    with _ms_used(eng, expect=False):                  # 600 x 8 = 4800 pairs < 96 x 512: the integer scan serves it
         gi, gd = gidx.search(q, 10, 8, 0)
     oi, od = oidx.search(q, 10, 8)
     assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
