@@ -652,7 +652,10 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
   static const int dbg = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
   a.dbg = dbg;
-  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus, cap);      // persistent: one workgroup per CU (151 KiB of LDS each)
+  // persistent: one workgroup per CU (151 KiB of LDS each).  LANCE_HIP_MS_GRID: fewer workgroups leave CUs to the latency-bound kernels of
+  // other engine contexts (merge, refine, bound pass) while this one runs -- an A/B knob
+  static const int grid_env = getenv("LANCE_HIP_MS_GRID") ? atoi(getenv("LANCE_HIP_MS_GRID")) : 0;
+  const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)(grid_env > 0 ? std::min(grid_env, ctx->num_cus) : ctx->num_cus), cap);
   static const bool prof = getenv("LANCE_HIP_MS_PROF") != nullptr;      // s_memtime phase stamps (d = 128, M = 16), printed per launch; plain path only
   if (prof && sd == 8 && ks == 8 && !ctx->capturing) {
     a.prof = ctx->scratch_t<unsigned long long>("ms.prof", 8);

@@ -479,6 +479,8 @@ struct QmergeArgs {
   const uint32_t *qslack;        // search_ms.hip: [nq] per-query bound of |sum - dist * s| (units); the cut carries twice that on top of cut_slack
   const float *seg_val;          // search_ms.hip (rows-on-lanes kernel): [nq * nprobes][Q_CAP] the survivors' accumulator values instead of seg_sum;
   const f2 *seg_scale;           //   sum = rint(val * seg_scale[pair].x + seg_scale[pair].y), clamped to 0 .. 65535
+  int dbg;                       // LANCE_HIP_QM_DBG (timing experiments, results WRONG): the kernel returns after 1: the cut, 2: staging the residuals,
+                                 // 3: compaction, 4: exact re-evaluation, 5: the sort
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
   uint32_t *tglobal;             // class B: running bound of the exact pair kernel
   const uint32_t *seg_cnt, *seg_pos;
@@ -730,6 +732,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
       }
     }
     __syncthreads();
+    if (a.dbg == 1) return;
     const uint32_t cut = s_cut;
     uint32_t range_lo = 0u, range_hi = cut;     // survivors with range_lo <= sum <= range_hi are re-evaluated in this phase
     for (int phase = 0; phase < (CUTM ? 2 : 1); ++phase) {
@@ -784,6 +787,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         }
       }
       __syncthreads();
+      if (a.dbg == 2) return;
       // prefix of the segment sizes, kept in LDS (17 registers less per lane: occupancy is what this kernel lives on)
       if (threadIdx.x == 0) {
         uint32_t run = 0;
@@ -813,6 +817,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
           }
         }
         __syncthreads();
+        if (a.dbg == 3) return;
         const int nl = (int)l_cnt;
         for (int base = 0; base < nl; base += BS) {
           const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
@@ -865,6 +870,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
     }   // phase
     __syncthreads();
   }
+  if (a.dbg == 4) return;
   for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
   __syncthreads();   // also: every lane is done with the staged residuals, the region is reused below
   int c = min((int)misc[0], CAP);
@@ -880,6 +886,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   int Pq = 64;
   while (Pq < c) Pq <<= 1;
   bitonic_sort_kr<BS>(skey, rid, spos, Pq);
+  if (a.dbg == 5) return;
   select_and_emit<BS>(o, q, skey, rid, spos, c, &s_amb);
 }
 
@@ -1126,9 +1133,10 @@ template <int SD, int MU>
 static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned nq, int bs) {
   const int dpad = (a.d + 3) & ~3;
   const size_t lds_rescan = (size_t)dpad * 4 + (size_t)MU * 16 * 256 * 4;
-  constexpr int RBS = MU >= 3 ? 1024 : 256;
-  const unsigned rgrid = (unsigned)std::min<uint64_t>((uint64_t)nq * a.nprobes, (uint64_t)ctx->num_cus * (MU >= 3 ? 1 : 4));
-  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, RBS>), dim3(rgrid), dim3(RBS), lds_rescan, ctx->stream, a);
+  // 1024 lanes per overflowed segment for every shape (round 4; M = 16 / 32 had 256: 0.1666 -> 0.1628 ms for rescan + merge at C2 -- the few
+  // segments a batch lists, ~5 per 10,000 queries there, are single-workgroup latency in front of the merge)
+  const unsigned rgrid = (unsigned)std::min<uint64_t>((uint64_t)nq * a.nprobes, (uint64_t)ctx->num_cus);
+  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, 1024>), dim3(rgrid), dim3(1024), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
   const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
   if constexpr (MU == 1) {
@@ -1148,6 +1156,7 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
   a.qslack = qslack; a.seg_val = seg_val; a.seg_scale = reinterpret_cast<const f2 *>(seg_scale);
+  { static const int dbg = getenv("LANCE_HIP_QM_DBG") ? atoi(getenv("LANCE_HIP_QM_DBG")) : 0; a.dbg = dbg; }
   a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
   a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
