@@ -650,7 +650,11 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm; a.prm2 = prm2;
   a.nan_slot = nan_slot; a.nlist = nlist; a.nprobes = (int)nprobes;
   a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
-  static const int dbg = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
+  static const int dbg = [] {
+    const int v = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
+    if (v) fprintf(stderr, "lance_hip: LANCE_HIP_MS_DBG=%d -- timing experiment, search RESULTS ARE WRONG\n", v);
+    return v;
+  }();
   a.dbg = dbg;
   // persistent: one workgroup per CU (151 KiB of LDS each).  LANCE_HIP_MS_GRID: fewer workgroups leave CUs to the latency-bound kernels of
   // other engine contexts (merge, refine, bound pass) while this one runs -- an A/B knob

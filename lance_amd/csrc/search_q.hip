@@ -1156,7 +1156,14 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
   a.qslack = qslack; a.seg_val = seg_val; a.seg_scale = reinterpret_cast<const f2 *>(seg_scale);
-  { static const int dbg = getenv("LANCE_HIP_QM_DBG") ? atoi(getenv("LANCE_HIP_QM_DBG")) : 0; a.dbg = dbg; }
+  {
+    static const int dbg = [] {
+      const int v = getenv("LANCE_HIP_QM_DBG") ? atoi(getenv("LANCE_HIP_QM_DBG")) : 0;
+      if (v) fprintf(stderr, "lance_hip: LANCE_HIP_QM_DBG=%d -- timing experiment, search RESULTS ARE WRONG\n", v);
+      return v;
+    }();
+    a.dbg = dbg;
+  }
   a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
   a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
