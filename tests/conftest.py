@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a test that hangs (a rendezvous that never completes, a wedged child process) must fail, not stall the whole run:
+    # pytest-timeout, when installed and no --timeout was given, limits every test to ten minutes
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
 
 
 def has_gpu():
