@@ -1,0 +1,203 @@
+"""Executable specification (numpy, binary16 / f32-faithful) of the matrix-core ADC filter (lance_amd/csrc/search_ms.hip), with the slack
+its header derives checked against the reference arithmetic.  Runs on the CPU; `tests/test_mscan_spec.py` runs a small instance.
+
+For a (query, probed partition) pair with residual r = q - centroid (v2.rs:316-332) and a stored row with reconstruction c^ (its M
+codewords concatenated):
+
+    dist_ref      = the reference's f32 ADC distance: table entries (orc_build_lut_f32: l2_scalar per sub-vector), summed
+                    sequentially over m (pq/distance.rs:109-144)
+    sigma         = power of two with the largest |2 sigma c| in [2^13, 2^14)                      (per index)
+    cbh           = binary16(-2 sigma c)                  rh  = binary16(sigma r)                  (per index / per pair)
+    cn2           = f32(sigma^2 * sum_m |c_m(code_m)|^2)  (sequential f32 sum of per-codeword f32 norms, as ms_row_norm_kernel)
+    lim           = f32((T (1 + 2^-17) + E) - |r|^2) * sigma^2                                     (ms_prep_kernel)
+    acc           = f32(cn2 - lim) + sum_k binary16 x binary16 products accumulated in f32        (the MFMA; any accumulation order)
+    pass         <=>  acc <= 0
+    E             = 1.05 [2^-9 1.02 |r| (|r| + sqrt T) + 2^-13 (|r|^2 + T)] + E_abs               (the header's slack)
+    S             = clamp(rint(acc * (s / sigma^2) + (T (1 + 2^-17) + E) s), 0, 65535),  s = 30000 / T    (the merge kernel's sum)
+
+Checked: (i) SOUNDNESS -- every row with dist_ref <= T passes; (ii) the sum of every passing row satisfies |S - dist_ref * s| <= the
+per-pair slack units ceil(E s 1.1 + 3) the merge kernel's cut carries; (iii) selectivity -- survivors per row with dist_ref <= T.
+Pairs the pre-pass hands to the exact rescan (residual beyond binary16, slack above 5 % of T) are counted, not filtered.
+The accumulation is done in two orders (ascending k, and pairwise tree) -- the bound must hold for any.
+
+    python scripts/sim/ms_filter_spec.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import oracle  # noqa: E402
+
+f16, f32, f64 = np.float16, np.float32, np.float64
+MS_SE = f32(30000.0)
+MS_SLACK_CAP = f32(1500.0)
+lib = oracle.lib()
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ref_lut(rq, cb, m, d):
+    lut = np.empty((m, 256), f32)
+    lib.orc_build_lut_f32(C.c_int(0), P(rq), C.c_size_t(d), P(cb), C.c_size_t(m), C.c_uint32(8), P(lut))
+    return lut
+
+
+def ref_adc(lut, codes):
+    """sequential-m f32 sum of table entries (pq/distance.rs:128-141)"""
+    acc = np.zeros(codes.shape[0], f32)
+    for mm in range(lut.shape[0]):
+        acc = (acc + lut[mm, codes[:, mm]]).astype(f32)
+    return acc
+
+
+def prep(r, T, sigma, d):
+    """ms_prep_kernel, lane-0 arithmetic in f32: returns (ok, lim * sigma^2, y, z', slack units, rh)"""
+    r = r.astype(f32)
+    n2 = f32(0.0)
+    # lane-strided partial sums then a xor-shuffle tree: any order serves a bound; here: 64 strided partials, pairwise tree
+    part = np.zeros(64, f32)
+    for e in range(d):
+        part[e % 64] = f32(part[e % 64] + f32(r[e] * r[e]))
+    w = part.copy()
+    o = 32
+    while o > 0:
+        w = (w + np.roll(w, -o)).astype(f32)      # every lane ends with the full sum (xor butterfly == this for the sum)
+        o //= 2
+    n2 = f32(w[0])
+    vmax = f32(np.max(np.abs(r)))
+    s = f32(MS_SE / T)
+    rn = f32(np.sqrt(n2, dtype=f32) * f32(1.000001))
+    st = f32(np.sqrt(T, dtype=f32) * f32(1.000001))
+    sqd = f32(np.sqrt(f32(d), dtype=f32) + f32(1.0))
+    e_abs = f32(f32(6.1035156e-5) * sqd * (f32(3.0) * rn + f32(2.0) * st) / sigma + f32(d) * f32(3.7252903e-9) / (sigma * sigma))
+    E = f32(f32(1.05) * (f32(1.9921875e-3) * rn * (rn + st) + f32(1.2207031e-4) * (n2 + T)) + e_abs)
+    eu = f32(E * s * f32(1.1) + f32(3.0))
+    lim = f32(f32(T * f32(1.0000077) + E) - n2)
+    sig2 = f32(sigma * sigma)
+    ok = bool(T > 0 and np.isfinite(T) and s > 0 and np.isfinite(s) and np.isfinite(n2) and vmax * sigma < 60000.0 and eu <= MS_SLACK_CAP
+              and np.isfinite(lim * sig2) and n2 * s < 1e30)
+    rh = (r * sigma).astype(f32).astype(f16)
+    return ok, f32(lim * sig2), f32(s / sig2), f32(f32(T * f32(1.0000077) + E) * s), int(np.ceil(eu)), rh, E
+
+
+def mfma_acc(init, rows_h, q_h, order):
+    """acc[row] = f32 init + sum_k f16 x f16 products (exact in f32), accumulated in f32 in the given order"""
+    prod = rows_h.astype(f32) * q_h.astype(f32)[None, :]      # exact: 11-bit x 11-bit significands
+    if order == "seq":
+        acc = init.astype(f32).copy()
+        for k in range(prod.shape[1]):
+            acc = (acc + prod[:, k]).astype(f32)
+        return acc
+    # pairwise tree over k, then one add to the start value
+    p = prod
+    while p.shape[1] > 1:
+        if p.shape[1] % 2:
+            p = np.concatenate([p, np.zeros((p.shape[0], 1), f32)], axis=1)
+        p = (p[:, 0::2] + p[:, 1::2]).astype(f32)
+    return (init.astype(f32) + p[:, 0]).astype(f32)
+
+
+def run(name, x, q, m, nlist, keff=100, nprobes=4, max_pairs=200, seed=0, verbose=True):
+    n, d = x.shape
+    sd = d // m
+    cent, _, _, _ = oracle.kmeans_train(x[: min(n, nlist * 256)], nlist, max_iters=6, seed=1)
+    part, _ = oracle.assign(x, cent)
+    res = oracle.residual(x, cent, part)
+    cb, _ = oracle.pq_train(res[: min(n, 65536)], m, max_iters=5, seed=2)
+    cb = np.ascontiguousarray(np.asarray(cb, f32).reshape(m, 256, sd))
+    codes = np.asarray(oracle.pq_encode(res, cb, "l2")).reshape(n, m)
+    # index constants (mscan_prepare / ms_codebook_kernel / ms_row_norm_kernel)
+    cbmax = float(np.max(np.abs(cb)))
+    e = int(np.frexp(cbmax)[1])
+    sigma = f32(np.ldexp(1.0, 13 - e))
+    cbh = (cb * f32(-2.0) * sigma).astype(f32).astype(f16)      # [m][256][sd]
+    cbn2 = np.zeros((m, 256), f32)
+    for u in range(sd):
+        cbn2 = (cbn2 + (cb[:, :, u] * cb[:, :, u]).astype(f32)).astype(f32)
+    row_cn2 = np.zeros(n, f32)
+    for mm in range(m):
+        row_cn2 = (row_cn2 + cbn2[mm, codes[:, mm]]).astype(f32)
+    row_cn2 = (row_cn2 * f32(sigma * sigma)).astype(f32)
+    rows_h = cbh[np.arange(m)[None, :], codes].reshape(n, d)      # the gathered reconstruction, binary16
+
+    probes, _ = oracle.find_partitions(q, cent, nprobes)
+    rng = np.random.default_rng(seed)
+    tot = dict(pairs=0, handed=0, must=0, violations=0, survivors=0, sum_violations=0, worst_sum_err=0.0, worst_margin=np.inf)
+    qsel = rng.permutation(len(q))
+    for qi in qsel:
+        if tot["pairs"] >= max_pairs:
+            break
+        # the bound T: keff-th smallest reference distance in the NEAREST partition (what the bound pass upper-bounds)
+        p0 = int(probes[qi, 0])
+        rows0 = np.nonzero(part == p0)[0]
+        if len(rows0) < keff:
+            continue
+        r0 = (q[qi] - cent[p0]).astype(f32)
+        d0 = ref_adc(ref_lut(r0, cb, m, d), codes[rows0])
+        T = f32(np.partition(d0, keff - 1)[keff - 1] * f32(1.0 + 1e-3))      # any upper bound of it is legal
+        for pr in probes[qi]:
+            rows = np.nonzero(part == int(pr))[0]
+            if len(rows) == 0:
+                continue
+            r = (q[qi] - cent[int(pr)]).astype(f32)
+            tot["pairs"] += 1
+            ok, lim_s, y, zp, units, rh, E = prep(r, T, sigma, d)
+            if not ok:
+                tot["handed"] += 1
+                continue
+            dref = ref_adc(ref_lut(r, cb, m, d), codes[rows])
+            init = (row_cn2[rows] - lim_s).astype(f32)
+            for order in ("seq", "tree"):
+                acc = mfma_acc(init, rows_h[rows], rh, order)
+                passed = acc <= 0
+                must = dref <= T
+                tot["violations"] += int(np.sum(must & ~passed))
+                if order == "seq":
+                    tot["must"] += int(must.sum())
+                    tot["survivors"] += int(passed.sum())
+                    if must.any():
+                        tot["worst_margin"] = min(tot["worst_margin"], float(np.min(-acc[must]) / (float(sigma) ** 2) / max(float(E), 1e-30)))
+                S = np.clip(np.rint((acc[passed].astype(f64) * f64(y) + f64(zp)).astype(f32)), 0, 65535)
+                s = f64(MS_SE) / f64(T)
+                err = np.abs(S.astype(f64) - dref[passed].astype(f64) * s)
+                if err.size:
+                    tot["worst_sum_err"] = max(tot["worst_sum_err"], float(np.max(err / units)))
+                    tot["sum_violations"] += int(np.sum(err > units))
+    if verbose:
+        print(f"{name}: d={d} M={m} sigma=2^{int(np.log2(sigma))} pairs={tot['pairs']} handed_to_rescan={tot['handed']} rows_with_dist<=T={tot['must']} "
+              f"violations={tot['violations']} survivors={tot['survivors']} ({tot['survivors'] / max(tot['must'], 1):.2f} x) "
+              f"smallest (limit - acc) / E among must-pass rows={tot['worst_margin']:.3f} "
+              f"largest |S - dist s| / slack units={tot['worst_sum_err']:.3f} sum_violations={tot['sum_violations']}")
+    return tot
+
+
+def sift_like(n, d, seed):
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(0, 128, (64, d))
+    x = centers[rng.integers(0, 64, n)] + rng.normal(0, 22, (n, d))
+    return np.clip(np.rint(x), 0, 218).astype(f32)
+
+
+def main():
+    x = sift_like(40000, 128, 1)
+    q = sift_like(300, 128, 2)
+    run("sift-like integer rows", x, q, 16, 16)
+    run("sift-like, M=32 (sub-dimension 4)", x, q, 32, 16)
+    rng = np.random.default_rng(3)
+    xu = rng.standard_normal((40000, 128)).astype(f32)
+    xu /= np.linalg.norm(xu, axis=1, keepdims=True)
+    qu = rng.standard_normal((300, 128)).astype(f32)
+    qu /= np.linalg.norm(qu, axis=1, keepdims=True)
+    run("unit vectors (sigma = 2^14)", xu.astype(f32), qu.astype(f32), 16, 16)
+    run("rows far from the origin (|r|^2 >> T for far probes)", x + f32(3000.0), q + f32(3000.0), 16, 16)
+    x64 = sift_like(30000, 64, 5)
+    run("d=64 M=16", x64, sift_like(200, 64, 6), 16, 12)
+
+
+if __name__ == "__main__":
+    main()
