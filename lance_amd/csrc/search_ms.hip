@@ -298,6 +298,7 @@ struct MscanArgs {
   uint32_t *ovf;
   const uint32_t *allow;
   int dbg = 0;                          // LANCE_HIP_MS_DBG (timing experiments, results WRONG): 1 = the flush drops its entries, 2 = every limit a NaN (nothing passes)
+  unsigned long long *prof_slices = nullptr;   // LANCE_HIP_MS_PROF=1: [slices] ticks a workgroup spent on the slice (taken order)
   unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1: [0] stage [1] gather [2] tiles [3] flush [4] life [5] waves [6] chunks [7] longest life
 };
 
@@ -370,6 +371,8 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
     __syncthreads();
     const uint32_t slice = s_slice;
     if (slice >= nslices) break;
+    long long pc_slice0 = 0;
+    if constexpr (PROF) pc_slice0 = clock64();
     const MsSlice U = p.slices[p.order[slice]];
     const int Qp = (int)U.qp;
     const int nslots = ((Qp + 31) >> 5) << 5;
@@ -509,6 +512,10 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
       if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; ++pc_nchunk; }
     }
     flush_end();      // before the block (and its pair ids) leaves LDS
+    if constexpr (PROF) {
+      __syncthreads();
+      if (threadIdx.x == 0 && p.prof_slices) p.prof_slices[slice] = (unsigned long long)(clock64() - pc_slice0);
+    }
   }
   if constexpr (PROF) {
     if (lane == 0) {
@@ -665,10 +672,38 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     a.prof = ctx->scratch_t<unsigned long long>("ms.prof", 8);
     if (!a.prof) return LANCE_HIP_ENOMEM;
     LH_CHECK_HIP(lh::memset_async(a.prof, 0, 64, ctx->stream));
+    a.prof_slices = ctx->scratch_t<unsigned long long>("ms.prof_slices", cap);
+    if (!a.prof_slices) return LANCE_HIP_ENOMEM;
+    LH_CHECK_HIP(lh::memset_async(a.prof_slices, 0, cap * 8, ctx->stream));
     hipLaunchKernelGGL((ivfpq_mscan_kernel<8, 8, true>), dim3(grid), dim3(1024), 0, ctx->stream, a);
     unsigned long long h[8];
     LH_CHECK_HIP(hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
     LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    {   // per-slice durations in taken order, with the slice's shape: which slices make the tail
+      std::vector<unsigned long long> st(cap);
+      std::vector<MsSlice> sl(cap);
+      std::vector<uint32_t> ord(cap), ss((size_t)nlist + 1);
+      (void)hipMemcpy(st.data(), a.prof_slices, cap * 8, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(sl.data(), slices, cap * sizeof(MsSlice), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(ord.data(), order, cap * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(ss.data(), slice_start, ((size_t)nlist + 1) * 4, hipMemcpyDeviceToHost);
+      const uint32_t ns = ss[nlist];
+      std::vector<uint32_t> idx(ns);
+      for (uint32_t i = 0; i < ns; ++i) idx[i] = i;
+      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return st[x] > st[y]; });
+      double tot = 0, totw = 0;
+      for (uint32_t i = 0; i < ns; ++i) { tot += (double)st[i]; totw += (double)sl[ord[i]].row_count * sl[ord[i]].qp; }
+      fprintf(stderr, "[ms prof] %u slices, mean %.0f ticks, mean ticks per 1000 cells %.2f; slowest (taken#, ticks, rows, pairs, ticks per 1000 cells):", ns, tot / ns, tot / totw * 1e3);
+      for (uint32_t t = 0; t < std::min<uint32_t>(ns, 12); ++t) {
+        const uint32_t i = idx[t];
+        fprintf(stderr, " (%u, %llu, %u, %u, %.2f)", i, st[i], sl[ord[i]].row_count, sl[ord[i]].qp, (double)st[i] / ((double)sl[ord[i]].row_count * sl[ord[i]].qp) * 1e3);
+      }
+      // and the last 12 taken
+      fprintf(stderr, " | last taken:");
+      for (uint32_t i = ns > 12 ? ns - 12 : 0; i < ns; ++i)
+        fprintf(stderr, " (%u, %llu, %u, %u)", i, st[i], sl[ord[i]].row_count, sl[ord[i]].qp);
+      fprintf(stderr, "\n");
+    }
     if (h[5])
       fprintf(stderr, "[ms prof] waves=%llu chunks/wave %.2f | s_memtime ticks per wave: stage+barriers %.0f | gather %.0f | tiles %.0f | flush %.0f | life %.0f (longest %llu)\n",
               h[5], (double)h[6] / h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[7]);
