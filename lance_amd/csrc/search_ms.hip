@@ -280,9 +280,6 @@ __global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__re
   }
 }
 
-constexpr int MS_BLK = 256;         // survivor records per block (left once fewer than 64 slots remain: >= 75 % used)
-struct MsRec { uint32_t g, pos; float val; uint32_t pad; };      // grouped pair index (-> prm[g].w = pair), storage position, accumulator value
-
 struct MscanArgs {
   const uint32_t *order;        // [slices] by decreasing work
   const MsSlice *slices;
@@ -300,11 +297,6 @@ struct MscanArgs {
   float *seg_val = nullptr;     // [nq * nprobes][Q_CAP] the survivors' accumulator values (the merge kernel scales them into integer sums)
   uint32_t *ovf;
   const uint32_t *allow;
-  // survivor records: the scan appends them to blocks of MS_BLK it reserves ahead from `rec_cursor`; ms_scatter_kernel turns them into segments
-  MsRec *recs = nullptr;        // [rec_cap]
-  uint32_t *rec_cursor = nullptr;   // [1] records reserved so far (zeroed per launch), followed by
-  uint32_t *blk_count = nullptr;    // [rec_cap / MS_BLK] records actually written to each block (zeroed per launch)
-  uint32_t rec_cap = 0;
   int dbg = 0;                          // LANCE_HIP_MS_DBG (timing experiments, results WRONG): 1 = the flush drops its entries, 2 = every limit a NaN (nothing passes)
   unsigned long long *prof_slices = nullptr;   // LANCE_HIP_MS_PROF=1: [slices] ticks a workgroup spent on the slice (taken order)
   unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1: [0] stage [1] gather [2] tiles [3] flush [4] life [5] waves [6] chunks [7] longest life
@@ -318,6 +310,7 @@ struct MscanArgs {
 // of the block: D = Q x R^T, queries down the accumulator registers, rows across the lanes, accumulator started at |c^|^2 - limit.
 // Sixteen compares with zero -> sixteen lane masks -> scalar tests; a survivor is queued (pair slot, row, accumulator value); a full
 // queue half requests its segment slots (atomicAdd, nothing waits) while the other half fills, and writes behind them a few tiles later.
+constexpr int MS_QH = 64;          // entries per queue half (one per lane)
 template <int SD, int KS, bool PROF = false>
 __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   constexpr int D = KS * 16;
@@ -329,31 +322,47 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   __shared__ __attribute__((aligned(16))) char sB[MS3_PB * RB];
   __shared__ __attribute__((aligned(16))) float sLim[MS3_PB];
   __shared__ __attribute__((aligned(16))) uint32_t sPair[MS3_PB];
+  __shared__ __attribute__((aligned(8))) uint2 sQ[16][2][MS_QH + 1];      // per wave: two halves (fill one while the other's atomics are in flight)
   __shared__ uint32_t s_slice, s_chunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
   const uint32_t nslices = p.slice_start[p.nlist];
 
-  // Survivors leave the scan as RECORDS (grouped pair index, position, accumulator value) appended with plain stores to a block of
-  // MS_BLK the wave reserved ahead of time; the segment insertion (one atomicAdd per survivor + two scattered stores) happens in
-  // ms_scatter_kernel, one lane per record, at full occupancy.  Per-slice stamps of the queue-and-flush form (gpurun r04zh) showed why:
-  // a 64-entry queue half filled faster than one device-scope atomic round trip in survivor-dense slices, every flush waited for the
-  // previous half's slots, and those slices ran 5-7 x slower per cell than the mean -- the kernel's tail.
-  uint32_t wbase, wused = 0;      // wave-uniform: first record of the block being filled, records in it
-  uint32_t nbase_v;               // lane 0: the block reserved for later (its atomicAdd was issued one block ago)
-  {
-    uint32_t b0 = 0, b1 = 0;
-    if (lane == 0) { b0 = atomicAdd(p.rec_cursor, (uint32_t)MS_BLK); b1 = atomicAdd(p.rec_cursor, (uint32_t)MS_BLK); }
-    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-    nbase_v = b1;
-  }
+  uint2 *const qw = &sQ[wave][0][0];
+  uint32_t cur = 0;     // wave-uniform: offset (entries) of the half being filled; the other half's segment slots have been requested
+  uint32_t qn = 0;      // wave-uniform: entries in the half being filled
+  uint32_t pd_n = 0, pd_base = 0;      // wave-uniform: entries of the other half in flight (this lane's slot in pd_k), their chunk's first position
+  uint32_t pd_k = 0;
   long long pc_t0 = 0, pc_stage = 0, pc_gather = 0, pc_tiles = 0, pc_flush = 0, pct = 0, pc_nchunk = 0;      // PROF: s_memtime stamps
   if constexpr (PROF) { pc_t0 = clock64(); pct = pc_t0; }
-  auto next_block = [&]() {      // leave the current block (its count goes to blk_count), take the reserved one, reserve another
-    if (lane == 0 && wbase < p.rec_cap) p.blk_count[wbase / (uint32_t)MS_BLK] = wused;
-    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nbase_v);
-    wused = 0;
-    if (lane == 0) nbase_v = atomicAdd(p.rec_cursor, (uint32_t)MS_BLK);
+  // Flush in two steps, one queue half apart: flush_begin requests a segment slot per entry of the full half (atomicAdd, nothing waits)
+  // and the halves trade places; flush_end -- called before the NEXT flush_begin, several tiles later -- writes position and value behind
+  // the slots.  One register of pending state per lane (the first rows-on-lanes build kept pair / position / value / scale there and
+  // spilled; a synchronous flush measured 33 % of a wave's life, gpurun r04n).  A queue entry names the pair's LDS slot, so both steps
+  // run while the slice's block is resident.
+  auto flush_end = [&]() {
+    if (pd_n) {
+      if ((uint32_t)lane < pd_n && pd_k != 0xFFFFFFFFu) {
+        const uint2 ent = qw[((uint32_t)(MS_QH + 1) - cur) + (uint32_t)lane];
+        const uint32_t pair = sPair[ent.x >> 8];
+        if (pd_k < (uint32_t)Q_CAP) {
+          p.seg_pos[(int64_t)pair * Q_CAP + pd_k] = pd_base + (ent.x & 255u);
+          p.seg_val[(int64_t)pair * Q_CAP + pd_k] = __uint_as_float(ent.y);
+        } else if (pd_k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
+          p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
+        }
+      }
+      pd_n = 0;
+    }
+  };
+  auto flush_begin = [&](uint32_t pos_base) {      // (after flush_end)
+    pd_k = 0xFFFFFFFFu;
+    if ((uint32_t)lane < qn && !(p.dbg & 1)) {
+      const uint2 ent = qw[cur + (uint32_t)lane];
+      if (row_allowed(p.allow, pos_base + (ent.x & 255u))) pd_k = atomicAdd(&p.seg_cnt[sPair[ent.x >> 8]], 1u);
+    }
+    pd_n = qn; pd_base = pos_base; qn = 0;
+    cur = (uint32_t)(MS_QH + 1) - cur;
   };
 
   for (;;) {
@@ -459,10 +468,14 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
             acc[4 * vq] = cn2v - t.x; acc[4 * vq + 1] = cn2v - t.y; acc[4 * vq + 2] = cn2v - t.z; acc[4 * vq + 3] = cn2v - t.w;
           }
         }
-        const uint32_t gbase = U.gs + (uint32_t)(jb * 32 + 4 * g);      // grouped pair index of this lane's query 0 of the tile
-        if (wused > (uint32_t)(MS_BLK - 64)) next_block();      // room for 64 survivors per tile (usual yield: 6-7); a burst beyond it is handled after the tile
-        const uint32_t room = wbase < p.rec_cap ? (uint32_t)MS_BLK - wused : 0u;      // (no space left in the record list: every survivor is a burst)
-        uint32_t qraw = 0;      // wave-uniform: survivors of this tile
+        const uint32_t ebase = ((uint32_t)(jb * 32 + 4 * g) << 8) | (uint32_t)j;
+        // room for a tile's usual yield; a burst beyond the queue is handled after the tile
+        if (qn > (uint32_t)(MS_QH - 32)) {      // room for a tile's usual yield (6-7 survivors at C2); a burst beyond the half is handled after the tile
+          if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; }
+          flush_end(); flush_begin(pos_base);
+          if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; }
+        }
+        uint32_t qraw = qn;      // wave-uniform: entries the tile wanted (qn stays clamped to the queue)
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s], rw[s], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -472,24 +485,21 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= 0.0f);
         __builtin_amdgcn_sched_barrier(0);
-        MsRec *const wrec = p.recs + wbase + wused;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           if (mk[v]) {
-            const uint32_t idx = qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u));
-            if (acc[v] <= 0.0f && idx < room) {      // (the same compare: the compiler reuses its lane mask as the exec mask)
-              MsRec r;
-              r.g = gbase + (uint32_t)((v & 3) + 8 * (v >> 2)); r.pos = pos_base + (uint32_t)j; r.val = acc[v]; r.pad = 0u;
-              wrec[idx] = r;
-            }
+            const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
+                                     (uint32_t)MS_QH);      // entry MS_QH: the bin of a burst
+            if (acc[v] <= 0.0f)      // (the same compare: the compiler reuses its lane mask as the exec mask)
+              qw[cur + idx] = make_uint2(ebase + ((uint32_t)((v & 3) + 8 * (v >> 2)) << 8), __float_as_uint(acc[v]));
             qraw += (uint32_t)__popcll(mk[v]);
           }
         }
-        wused += min(qraw, room);
-        if (qraw > room) {
-          // more survivors in one tile than the block had room for (>= 6 % of its cells pass -- these pairs' segments would overflow
-          // anyway -- or the record list is full): survivors were dropped, so every pair of the tile is handed to the exact rescan: the
-          // count jumps past Q_CAP, and whoever crosses it lists the pair
+        qn = min(qraw, (uint32_t)MS_QH);
+        if (qraw > (uint32_t)MS_QH) {
+          // more than the half's room in one tile (>= 2 % of its cells pass -- these pairs' segments would overflow anyway):
+          // survivors were dropped, so every pair of the tile is handed to the exact rescan: the count jumps past Q_CAP, and whoever
+          // crosses it lists the pair
           if (g == 0 && slot < Qp) {
             const uint32_t pair = sPair[slot];
             const uint32_t k = atomicAdd(&p.seg_cnt[pair], (uint32_t)Q_CAP + 1u);
@@ -497,14 +507,16 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
           }
         }
       }
-      if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; ++pc_nchunk; }
+      if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; }
+      flush_end(); flush_begin(pos_base);      // (positions are relative to the chunk: a half never spans two chunks)
+      if constexpr (PROF) { const long long t = clock64(); pc_flush += t - pct; pct = t; ++pc_nchunk; }
     }
+    flush_end();      // before the block (and its pair ids) leaves LDS
     if constexpr (PROF) {
       __syncthreads();
       if (threadIdx.x == 0 && p.prof_slices) p.prof_slices[slice] = (unsigned long long)(clock64() - pc_slice0);
     }
   }
-  if (lane == 0 && wbase < p.rec_cap) p.blk_count[wbase / (uint32_t)MS_BLK] = wused;      // (the block reserved for later stays at count 0)
   if constexpr (PROF) {
     if (lane == 0) {
       const long long t1 = clock64();
@@ -517,35 +529,6 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
       atomicAdd(&p.prof[6], (unsigned long long)pc_nchunk);
       atomicMax(&p.prof[7], (unsigned long long)(t1 - pc_t0));
     }
-  }
-}
-
-// ---- survivor records -> per-(query, probe) segments ---------------------------------------------------------------------------------------
-// One lane per record of every block the scan reserved (blk_count says how many it wrote): the pair's segment slot by atomicAdd, position and
-// value behind it; the lane that takes slot Q_CAP lists the segment for the exact rescan.  ~2.5 M records per 10k-query batch at C2.
-struct MsScatterArgs {
-  const MsRec *recs;
-  const uint32_t *rec_cursor, *blk_count;
-  uint32_t rec_cap;
-  const f4 *prm;
-  uint32_t *seg_cnt, *seg_pos;
-  float *seg_val;
-  uint32_t *ovf;
-  const uint32_t *allow;
-};
-__global__ __launch_bounds__(MS_BLK) void ms_scatter_kernel(MsScatterArgs a) {
-  const uint32_t blk = blockIdx.x;
-  if (blk * (uint32_t)MS_BLK >= min(a.rec_cursor[0], a.rec_cap)) return;
-  if (threadIdx.x >= a.blk_count[blk]) return;
-  const MsRec r = a.recs[(size_t)blk * MS_BLK + threadIdx.x];
-  if (!row_allowed(a.allow, r.pos)) return;
-  const uint32_t pair = __float_as_uint(a.prm[r.g].w);
-  const uint32_t k = atomicAdd(&a.seg_cnt[pair], 1u);
-  if (k < (uint32_t)Q_CAP) {
-    a.seg_pos[(int64_t)pair * Q_CAP + k] = r.pos;
-    a.seg_val[(int64_t)pair * Q_CAP + k] = r.val;
-  } else if (k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
-    a.ovf[1u + atomicAdd(&a.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
   }
 }
 
@@ -643,13 +626,8 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
   uint32_t *order = ctx->scratch_t<uint32_t>("ms.order", cap);
   float *seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
-  // survivor records: ~25 per pair at C2 (r04zi: 48 per pair with blocks of 128 left half full ran out -- late waves handed their tiles to the rescan); beyond the list's capacity the scan hands pairs to the exact rescan instead of recording them
-  const uint32_t rec_cap = (uint32_t)std::min<uint64_t>(
-      (std::max<uint64_t>((uint64_t)npairs * 96, (uint64_t)ctx->num_cus * 16 * 4 * MS_BLK) + MS_BLK - 1) / MS_BLK * MS_BLK, 0x7FFFFF00u);
-  MsRec *recs = reinterpret_cast<MsRec *>(ctx->scratch("ms.recs", (size_t)rec_cap * sizeof(MsRec)));
-  uint32_t *rec_cursor = ctx->scratch_t<uint32_t>("ms.rec_cursor", (size_t)rec_cap / MS_BLK + 1);      // [0] cursor, then the block counts
   uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // the merge launcher asks for the same slot
-  if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !seg_val || !ovf || !recs || !rec_cursor) return LANCE_HIP_ENOMEM;
+  if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !seg_val || !ovf) return LANCE_HIP_ENOMEM;
   uint32_t *slice_ctr = slice_start + nlist + 1, *cls_cursor = slice_ctr + 1;
   const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
   {
@@ -658,7 +636,6 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     LH_CHECK_HIP(lh::memset_async(qovf, 0, (size_t)nq * 4, ctx->stream));
     LH_CHECK_HIP(lh::memset_async(qslack, 0, (size_t)nq * 4, ctx->stream));
     LH_CHECK_HIP(lh::memset_async(ovf, 0, 4, ctx->stream));
-    LH_CHECK_HIP(lh::memset_async(rec_cursor, 0, ((size_t)rec_cap / MS_BLK + 1) * 4, ctx->stream));
     MsPrepArgs pa;
     pa.q = qs; pa.centroids = ix->centroids; pa.pair_idx = pair_idx; pa.pair_starts = pair_starts; pa.probes = probes; pa.tbound = tbound;
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
@@ -680,7 +657,6 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm; a.prm2 = prm2;
   a.nan_slot = nan_slot; a.nlist = nlist; a.nprobes = (int)nprobes;
   a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
-  a.recs = recs; a.rec_cursor = rec_cursor; a.blk_count = rec_cursor + 1; a.rec_cap = rec_cap;
   static const int dbg = [] {
     const int v = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
     if (v) fprintf(stderr, "lance_hip: LANCE_HIP_MS_DBG=%d -- timing experiment, search RESULTS ARE WRONG\n", v);
@@ -735,12 +711,6 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ivfpq_mscan_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ivfpq_mscan_kernel<4, 4>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
-  if (!(a.dbg & 1)) {      // (LANCE_HIP_MS_DBG=1: the records are dropped -- timing experiment)
-    MsScatterArgs sa;
-    sa.recs = recs; sa.rec_cursor = rec_cursor; sa.blk_count = rec_cursor + 1; sa.rec_cap = rec_cap; sa.prm = prm;
-    sa.seg_cnt = seg_cnt; sa.seg_pos = seg_pos; sa.seg_val = seg_val; sa.ovf = ovf; sa.allow = allow;
-    hipLaunchKernelGGL(ms_scatter_kernel, dim3(rec_cap / MS_BLK), dim3(MS_BLK), 0, ctx->stream, sa);
-  }
   LH_CHECK_HIP(hipGetLastError());
   *qslack_out = qslack; *seg_val_out = seg_val; *seg_scale_out = reinterpret_cast<float *>(prm2);
   return LANCE_HIP_OK;
