@@ -537,6 +537,8 @@ class DeviceIndex:
                                                      codes.ctypes.data_as(C.c_void_p), rid.ctypes.data_as(C.c_void_p)))
         return offs, codes, rid
 
+    MAX_PAIRS_PER_CALL = 1_500_000      # (query, probe) pairs per library call of a synchronous search (256 survivor slots x 8 B each)
+
     def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True, engine=None):
         """engine: another Engine (own stream + scratch arena) on the same GPU to run this batch on -- the index is read-only
         during searches, so batches enqueued through different engines overlap on the device (sync=False)."""
@@ -551,6 +553,15 @@ class DeviceIndex:
             ids, dists = out
         eng = engine if engine is not None else self.engine
         fn = eng.lib.lance_hip_ivfpq_search if sync else eng.lib.lance_hip_ivfpq_search_async
+        if sync and nq > 1 and nq * max(1, nprobes) > self.MAX_PAIRS_PER_CALL:
+            # a batch whose survivor segments would not fit the library's 2 GiB scratch limit leaves the batched kernels for the
+            # query-major ones (correct, many times slower): queries are independent, so the batch goes through in slices
+            step = max(1, self.MAX_PAIRS_PER_CALL // max(1, nprobes))
+            torch.cuda.synchronize()
+            for a in range(0, nq, step):
+                b = min(nq, a + step)
+                check(fn(eng.h, self.h, _ptr(q[a:b]), b - a, k, nprobes, refine_factor, _ptr(ids[a:b]), _ptr(dists[a:b])))
+            return ids, dists
         if sync:
             torch.cuda.synchronize()
         elif not eng.use_torch_stream and (q.data_ptr() != t.data_ptr() or out is None):

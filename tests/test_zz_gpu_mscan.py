@@ -150,6 +150,22 @@ def test_mscan_not_taken_for_small_batches_or_dot(eng, oracle):
     gidx.close()
 
 
+def test_large_batches_go_through_in_slices(eng, oracle, monkeypatch):
+    """DeviceIndex.search splits a synchronous batch whose (query, probe) pairs exceed MAX_PAIRS_PER_CALL into slices of queries (the
+    library's batched kernels refuse batches whose survivor segments pass 2 GiB of scratch): same answers, every slice on the batched path."""
+    from lance_amd.engine import DeviceIndex
+    n, d, m, nlist, nq = 12000, 128, 16, 12, 1500
+    x = clustered(n, d, 71)
+    q = clustered(nq, d, 72)
+    cent, cb = _models(oracle, x, nlist, m, "l2", seed=9)
+    oidx = oracle.build_index(x, cent, cb, "l2")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "l2")
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=x)
+    monkeypatch.setattr(DeviceIndex, "MAX_PAIRS_PER_CALL", 4800)      # 1500 x 8 = 12,000 pairs -> three slices of 600 queries
+    _check(eng, gidx, oidx, q, q, x, [(10, 8, 0), (10, 8, 5)])
+    gidx.close()
+
+
 def test_integer_scan_keeps_its_coverage_without_mscan():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LANCE_HIP_NO_MSCAN="1")
