@@ -389,7 +389,9 @@ def test_bench_gpus_flag_starts_that_many_ranks():
                        capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode != 0
-    assert "needs 2 MI355X GPUs (rank 0 sees" in out and "needs 2 MI355X GPUs (rank 1 sees" in out, out[-2000:]
+    # (torch.distributed.run tears the other workers down as soon as one fails, so the second rank's line may never be printed:
+    # one refusal from rank code is the statement -- asserting both was an intermittent failure)
+    assert "needs 2 MI355X GPUs (rank " in out and " sees 0 HIP devices" in out, out[-2000:]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
