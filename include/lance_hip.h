@@ -156,11 +156,21 @@ int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *lo
  * rank: e.g. rank 0's kmeans_random_init rows, broadcast by the host) and receives the trained ones (identical on every rank).
  * comm == NULL: single process, no collective.  balance_factor is the unscaled parameter (divided by n_total as train_kmeans does).
  * Sums arrive in rank order rather than row order: against the single-GPU trainer the centroids agree to f32 round-off for more
- * than one rank and bit for bit for one.  librccl.so is loaded on first use (dlopen).                                        */
+ * than one rank and bit for bit for one.  An RCCL the process already maps answers; otherwise librccl.so.1 is loaded on first use.
+ * A failure of the first E-step on one rank (its scratch allocation) is exchanged before the first all-reduce: every rank returns. */
 typedef struct lance_hip_comm lance_hip_comm;
 int lance_hip_comm_unique_id(char *id_out_host /* 128 bytes */);
 int lance_hip_comm_create(lance_hip_ctx *ctx, const char *id_host /* 128 bytes */, int nranks, int rank, lance_hip_comm **out);
 int lance_hip_comm_adopt(void *nccl_comm, int nranks, int rank, lance_hip_comm **out);
+/* A host with its own transport (MPI, gloo, ...) hands over an in-place all-reduce instead of an RCCL communicator: `buf` is a DEVICE
+ * pointer holding `count` elements (LANCE_HIP_COMM_F32 / _F64), `op` LANCE_HIP_COMM_SUM / _MAX, `stream` the hipStream_t the producing
+ * kernels were enqueued on and the consuming ones will be (the callback must order itself against it -- e.g. synchronise it, reduce
+ * through host memory, copy back -- and return 0, or non-zero to abort the training on this rank).  lance_hip_kmeans_train_sharded
+ * issues the same exchanges through it as through RCCL (rust/lance-index/src/vector/kmeans.rs:610-719: the rayon reduction's place). */
+enum { LANCE_HIP_COMM_F32 = 0, LANCE_HIP_COMM_F64 = 1 };
+enum { LANCE_HIP_COMM_SUM = 0, LANCE_HIP_COMM_MAX = 1 };
+typedef int (*lance_hip_allreduce_fn)(void *user, void *buf, uint64_t count, int dtype, int op, void *stream);
+int lance_hip_comm_from_callback(lance_hip_allreduce_fn fn, void *user, int nranks, int rank, lance_hip_comm **out);
 void lance_hip_comm_destroy(lance_hip_comm *comm);
 int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int metric, const float *x_local, uint64_t n_local, uint32_t d,
                                    uint32_t k, uint64_t n_total, uint32_t max_iters, double tol, float balance_factor, uint64_t seed,

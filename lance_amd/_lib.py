@@ -35,8 +35,12 @@ SYMBOLS = [
     "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
     "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench", "lance_hip_merge_topk",
     "lance_hip_shuffle_buffer_write",
-    "lance_hip_comm_unique_id", "lance_hip_comm_create", "lance_hip_comm_adopt", "lance_hip_comm_destroy", "lance_hip_kmeans_train_sharded",
+    "lance_hip_comm_unique_id", "lance_hip_comm_create", "lance_hip_comm_adopt", "lance_hip_comm_from_callback", "lance_hip_comm_destroy", "lance_hip_kmeans_train_sharded",
 ]
+
+
+# lance_hip_allreduce_fn (include/lance_hip.h): int fn(void *user, void *buf, uint64_t count, int dtype, int op, void *stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p)
 
 
 class IndexFileView(C.Structure):
@@ -139,6 +143,7 @@ def load():
         "lance_hip_comm_unique_id": (i32, [C.c_char_p]),
         "lance_hip_comm_create": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(vp)]),
         "lance_hip_comm_adopt": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "lance_hip_comm_from_callback": (i32, [ALLREDUCE_FN, vp, i32, i32, C.POINTER(vp)]),
         "lance_hip_comm_destroy": (None, [vp]),
         "lance_hip_kmeans_train_sharded": (i32, [vp, vp, i32, vp, u64, u32, u32, u64, u32, f64, f32, u64, vp, C.POINTER(f64), C.POINTER(u32)]),
     }

@@ -7,8 +7,12 @@
 // [k*d sums | k counts] and of the f64 per-cluster losses, ncclAllReduce MAX of the radii -> the update kernel (centroids, loss,
 // balance factor, convergence, shared-seed split, next bias).  The host looks at the state every 8 iterations.
 //   KMeans::train_kmeans   rust/lance-index/src/vector/kmeans.rs:610-719 (one exchange per iteration replaces the rayon reduction)
-// librccl is resolved with dlopen at first use: liblance_hip.so itself has no load-time dependency on it, and inside a torch
-// process the already-loaded RCCL is the one that answers.
+// librccl is resolved at first use: liblance_hip.so itself has no load-time dependency on it.  Inside a process that already maps an
+// RCCL (torch bundles its own, soname librccl.so.1) THAT library must answer -- an adopted ncclComm_t is only meaningful to the
+// library that made it -- so the lookup goes: symbols already visible (RTLD_DEFAULT), then the soname / file name with RTLD_NOLOAD
+// (finds a library mapped RTLD_LOCAL, as Python's loader does), and only then a fresh load by name.
+// A host that brings its own transport (MPI, gloo, a test harness running two ranks on one GPU) passes an all-reduce callback instead
+// (lance_hip_comm_from_callback): the loop below is then the same code with the three exchanges routed through it.
 #include <dlfcn.h>
 
 #include <mutex>
@@ -37,10 +41,17 @@ RcclApi &rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (api.lib) break;
-    }
+    if (dlsym(RTLD_DEFAULT, "ncclAllReduce") && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) api.lib = RTLD_DEFAULT;
+    if (!api.lib)
+      for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (api.lib) break;
+      }
+    if (!api.lib)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+      }
     if (!api.lib) return;
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
@@ -64,7 +75,24 @@ struct lance_hip_comm {
   rccl_comm_t comm = nullptr;
   int nranks = 1, rank = 0;
   bool owned = false;
+  lance_hip_allreduce_fn fn = nullptr;      // host transport (lance_hip_comm_from_callback) instead of RCCL
+  void *user = nullptr;
 };
+
+namespace {
+// one exchange of the Lloyd loop: in place, on the context's stream (RCCL) or through the host's callback
+int comm_allreduce(lance_hip_ctx *ctx, lance_hip_comm *comm, void *buf, size_t count, int dtype, int op) {
+  if (comm->fn) {
+    const int rc = comm->fn(comm->user, buf, (uint64_t)count, dtype, op, ctx->stream);
+    if (rc != 0) { lh::set_error("all-reduce callback failed with %d", rc); return LANCE_HIP_ERUNTIME; }
+    return LANCE_HIP_OK;
+  }
+  const int rc = rccl().AllReduce(buf, buf, count, dtype == LANCE_HIP_COMM_F64 ? RCCL_F64 : RCCL_F32, op == LANCE_HIP_COMM_MAX ? RCCL_MAX : RCCL_SUM,
+                                  comm->comm, ctx->stream);
+  if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+  return LANCE_HIP_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -107,6 +135,15 @@ int lance_hip_comm_adopt(void *nccl_comm, int nranks, int rank, lance_hip_comm *
   return LANCE_HIP_OK;
 }
 
+int lance_hip_comm_from_callback(lance_hip_allreduce_fn fn, void *user, int nranks, int rank, lance_hip_comm **out) {
+  LH_REQUIRE(fn && out, "comm_from_callback: NULL argument");
+  LH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_from_callback: rank %d of %d", rank, nranks);
+  auto *h = new lance_hip_comm();
+  h->fn = fn; h->user = user; h->nranks = nranks; h->rank = rank;
+  *out = h;
+  return LANCE_HIP_OK;
+}
+
 void lance_hip_comm_destroy(lance_hip_comm *comm) {
   if (!comm) return;
   if (comm->owned && comm->comm && rccl().ok) (void)rccl().CommDestroy(comm->comm);
@@ -120,26 +157,47 @@ int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int
   LH_REQUIRE(ctx && centroids && (n_local == 0 || x_local), "kmeans_train_sharded: NULL argument");
   LH_REQUIRE(d > 0 && k > 0 && n_total >= k && n_total >= n_local, "kmeans_train_sharded: need n_total >= k and n_total >= n_local");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "kmeans_train_sharded: bad metric %d", metric);
+  // Everything that can fail on ONE rank only is checked before the first collective: a rank that returned early would leave its
+  // peers waiting in the all-reduce for ever.  The limits are those of lance_hip_kmeans_shard_estep / _update.
+  LH_REQUIRE(k <= 4096, "kmeans_train_sharded: k=%u > 4096 is not supported by the sharded E-step (train hierarchically per rank)", k);
+  LH_REQUIRE(n_local < (1ull << 32), "kmeans_train_sharded: %llu rows on one rank (limit 2^32 - 1)", (unsigned long long)n_local);
+  LH_REQUIRE(!comm || comm->fn || rccl().ok, "RCCL is not available (librccl.so could not be loaded)");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   void *state = ctx->scratch("shard.state", 256);
   float *bias = ctx->scratch_t<float>("shard.bias", k);
   float *buf = ctx->scratch_t<float>("shard.buf", (size_t)k * d + k);
   double *losses = ctx->scratch_t<double>("shard.losses", k);
   float *radius = ctx->scratch_t<float>("shard.radius", k);
-  if (!state || !bias || !buf || !losses || !radius) return LANCE_HIP_ENOMEM;
+  float *status = ctx->scratch_t<float>("shard.status", 4);
+  if (!state || !bias || !buf || !losses || !radius || !status) return LANCE_HIP_ENOMEM;
   const float bf_scaled = balance_factor / (float)n_total;      // train_kmeans :1344: params.balance_factor /= data.len()
   LH_TRY(lance_hip_kmeans_shard_begin(ctx, k, bf_scaled, seed, state, bias));
   double loss = 0.0;
   uint32_t iters = 0;
   int active = 1;
   for (uint32_t it = 1; it <= max_iters; ++it) {
-    LH_TRY(lance_hip_kmeans_shard_estep(ctx, metric, x_local, n_local, d, centroids, k, bias, state, buf, losses, radius));
+    const int erc = lance_hip_kmeans_shard_estep(ctx, metric, x_local, n_local, d, centroids, k, bias, state, buf, losses, radius);
+    if (comm && it == 1) {
+      // The first E-step sizes this rank's scratch arena (row-count sized slots): the only place where ONE rank can fail while its
+      // peers go on.  Before anybody enters the iteration's all-reduces the ranks exchange one word -- max over "my E-step failed" --
+      // and all of them leave together (later iterations allocate nothing: same sizes).
+      char saved[1024];
+      snprintf(saved, sizeof(saved), "%s", lance_hip_last_error());
+      const float mine = erc != LANCE_HIP_OK ? 1.0f : 0.0f;
+      float any = 1.0f;
+      LH_CHECK_HIP(hipMemcpyAsync(status, &mine, 4, hipMemcpyHostToDevice, ctx->stream));
+      LH_TRY(comm_allreduce(ctx, comm, status, 1, LANCE_HIP_COMM_F32, LANCE_HIP_COMM_MAX));
+      LH_CHECK_HIP(hipMemcpyAsync(&any, status, 4, hipMemcpyDeviceToHost, ctx->stream));
+      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (erc != LANCE_HIP_OK) { lh::set_error("%s", saved); return erc; }
+      if (any != 0.0f) { lh::set_error("kmeans_train_sharded: the first E-step failed on another rank (this rank stops with it)"); return LANCE_HIP_ERUNTIME; }
+    } else if (erc != LANCE_HIP_OK) {
+      return erc;
+    }
     if (comm) {
-      RcclApi &a = rccl();
-      int rc = a.AllReduce(buf, buf, (size_t)k * d + k, RCCL_F32, RCCL_SUM, comm->comm, ctx->stream);
-      if (rc == 0) rc = a.AllReduce(losses, losses, k, RCCL_F64, RCCL_SUM, comm->comm, ctx->stream);
-      if (rc == 0) rc = a.AllReduce(radius, radius, k, RCCL_F32, RCCL_MAX, comm->comm, ctx->stream);
-      if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+      LH_TRY(comm_allreduce(ctx, comm, buf, (size_t)k * d + k, LANCE_HIP_COMM_F32, LANCE_HIP_COMM_SUM));
+      LH_TRY(comm_allreduce(ctx, comm, losses, k, LANCE_HIP_COMM_F64, LANCE_HIP_COMM_SUM));
+      LH_TRY(comm_allreduce(ctx, comm, radius, k, LANCE_HIP_COMM_F32, LANCE_HIP_COMM_MAX));
     }
     LH_TRY(lance_hip_kmeans_shard_update(ctx, state, buf, losses, radius, centroids, bias, k, d, n_total, bf_scaled, tol, it));
     if (it % 8 == 0 || it == max_iters) {

@@ -43,9 +43,11 @@ void set_error(const char *fmt, ...);
 // a captured search (search.hip: ivfpq_search_enqueue): the ~25 launches of one batch replayed as one hipGraphLaunch
 struct GraphEntry {
   hipGraphExec_t exec = nullptr;
-  uint32_t seen = 0;                 // calls with this key so far (the first one runs uncaptured: it sizes the scratch arena)
+  bool failed = false;               // a capture of this key failed before: it stays on the plain path
   uint32_t *flags = nullptr;         // what the captured call handed back through flags_out
   const uint32_t *replay = nullptr;  // ... and left in last_replay_counter
+  uint64_t last_use = 0;             // ctx->graph_tick of the last capture / replay (eviction: least recently used)
+  std::vector<const char *> paths;   // the named pipeline stages the captured call went through (ScopedTimer names): a replay counts them
 };
 
 struct KernelTimer {
@@ -76,8 +78,22 @@ struct lance_hip_ctx {
   // captured searches, keyed by the packed arguments of the call.  Every node holds scratch-arena pointers, so the cache is
   // dropped whenever a slot is reallocated; growth DURING a capture is refused (the uncaptured first call has sized the arena).
   std::map<std::string, lh::GraphEntry> graphs;
+  // keys seen exactly once (their first call ran uncaptured and sized the scratch arena): a bounded FIFO, so that callers that never
+  // repeat a call -- fresh output buffers every time -- cost a string each and never touch the graphs above
+  std::vector<std::string> graph_seen_once;
+  size_t graph_seen_next = 0;
+  uint64_t graph_tick = 0;
   bool capturing = false;
+  std::vector<const char *> *capture_paths = nullptr;   // while capturing: the stage names of the call being captured
   void drop_graphs();
+  // How often each named pipeline stage was ENQUEUED on this context -- plain launches, captures and graph replays alike (HIP-event
+  // timing, by contrast, forces the plain path).  Read through lance_hip_timing_query("count:<stage>"): tests assert which kernels
+  // served a call that went through a replayed graph.
+  std::map<std::string, uint64_t> stage_counts;
+  void count_stage(const char *name) {
+    ++stage_counts[name];
+    if (capture_paths) capture_paths->push_back(name);
+  }
 
   // returns nullptr on failure (error set)
   void *scratch(const char *name, size_t bytes);
@@ -93,7 +109,7 @@ struct lance_hip_ctx {
 namespace lh {
 struct ScopedTimer {
   lance_hip_ctx *c; const char *k;
-  ScopedTimer(lance_hip_ctx *c_, const char *k_) : c(c_), k(k_) { if (c->timing) c->time_begin(k); }
+  ScopedTimer(lance_hip_ctx *c_, const char *k_) : c(c_), k(k_) { c->count_stage(k); if (c->timing) c->time_begin(k); }
   ~ScopedTimer() { if (c->timing) c->time_end(k); }
 };
 // hipMemsetAsync as a plain kernel launch (dtype.hip).  Same cost as the runtime's own fill kernel, but a KERNEL node when a

@@ -39,6 +39,8 @@ void *lance_hip_ctx::scratch(const char *name, size_t bytes) {
 }
 
 void lance_hip_ctx::drop_graphs() {
+  graph_seen_once.clear();      // a key seen once must size the (reallocated) arena again before it is captured
+  graph_seen_next = 0;
   if (graphs.empty()) return;
   (void)hipStreamSynchronize(stream);
   for (auto &kv : graphs)
@@ -172,6 +174,12 @@ int lance_hip_timing_query(lance_hip_ctx *ctx, const char *kernel, double *ms_to
   lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && kernel, "timing_query: NULL argument");
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (strncmp(kernel, "count:", 6) == 0) {      // enqueue counter of a pipeline stage (common.h: stage_counts); not reset by the query
+    auto it = ctx->stage_counts.find(kernel + 6);
+    if (ms_total) *ms_total = 0.0;
+    if (launches) *launches = it == ctx->stage_counts.end() ? 0 : it->second;
+    return LANCE_HIP_OK;
+  }
   auto &t = ctx->timers[kernel];
   for (auto &ev : t.pending) {
     float ms = 0.f;

@@ -14,6 +14,7 @@ inline uint64_t lance_hip_next_index_serial() {
 
 struct lance_hip_index {
   uint64_t serial = lance_hip_next_index_serial();   // distinguishes indices that reuse an address (captured search graphs are keyed on it)
+  bool ephemeral = false;         // built for one call (lance_hip_pq_scan_topk): its searches are never captured into graphs
   int device = 0;
   int metric = 0;
   int dtype = 0;                  // element type of queries / raw vectors (model is kept widened to f32)

@@ -383,8 +383,10 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
   // An iteration is ~10 small launches (assign: prep + MFMA sweep + re-check, four grouping kernels, stats, accumulate, control) whose
   // arguments never change: the build was launch-latency bound (profiles/r03: train_pq 14 ms = 50 iterations x ~280 us of which ~160 us
   // are kernels).  The first block of `check_every` iterations runs on the plain path (it sizes the scratch arena); the second is captured
-  // into a HIP graph and every further block is one hipGraphLaunch.  LANCE_HIP_KMEANS_GRAPH=0 keeps every block on the plain path.
-  static const bool graph_on = !(getenv("LANCE_HIP_KMEANS_GRAPH") && getenv("LANCE_HIP_KMEANS_GRAPH")[0] == '0');
+  // into a HIP graph and every further block is one hipGraphLaunch.  OPT-IN (LANCE_HIP_KMEANS_GRAPH=1): measured no gain (24.4 vs 25.0 ms at
+  // C2, gpurun r04p -- the cost is the kernel boundaries, not the launches) while every training call, and every sub-problem of a
+  // hierarchical one, paid a capture + instantiate.
+  static const bool graph_on = getenv("LANCE_HIP_KMEANS_GRAPH") && getenv("LANCE_HIP_KMEANS_GRAPH")[0] == '1';
   hipGraphExec_t gexec = nullptr;
   bool graph_failed = !graph_on || ctx->timing || ctx->capturing;
   uint32_t it = 0;

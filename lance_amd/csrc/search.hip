@@ -988,7 +988,7 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
     const char *e = getenv("LANCE_HIP_GRAPH");     // default on (r04d: +8 % on the C2 bench line); "0" switches it off
     return !(e && e[0] == '0') && !getenv("LANCE_HIP_Q_STATS") && !getenv("LANCE_HIP_PM_PROF") && !getenv("LANCE_HIP_QT_PROF");
   }();
-  if (!on || ctx->timing || nq == 0)
+  if (!on || ctx->timing || nq == 0 || ix->ephemeral)      // ephemeral: the one-call index of lance_hip_pq_scan_topk
     return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
   struct Key {
     const void *ix; uint64_t serial; const void *raw; uint64_t n_raw; const void *q, *ids, *dists, *allow;
@@ -998,44 +998,80 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   key.ix = ix; key.serial = ix->serial; key.raw = ix->raw; key.n_raw = ix->n_raw; key.q = q; key.ids = ids; key.dists = dists; key.allow = allow;
   key.nq = nq; key.k = k; key.nprobes = nprobes; key.rf = refine_factor; key.has_range = has_range; key.lo = lower; key.hi = upper;
   const std::string ks(reinterpret_cast<const char *>(&key), sizeof(key));
-  if (ctx->graphs.size() > 64 && !ctx->graphs.count(ks)) ctx->drop_graphs();      // bounded: callers that never repeat a call
+  auto plain = [&]() { return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow); };
+  // Life of a key: first call -> plain path, remembered in the bounded `graph_seen_once` FIFO (it sized the scratch arena and built the
+  // index's lazy constants); second call -> captured, instantiated, launched; later calls -> replayed.  A caller that never repeats a
+  // call (fresh output buffers every time) therefore never creates a graph entry, and a full cache evicts ONE entry -- a failed one
+  // first (no exec: nothing to wait for), else the least recently used -- instead of dropping every valid graph.
+  constexpr size_t GRAPH_CACHE_MAX = 64, SEEN_ONCE_MAX = 128;
+  auto it = ctx->graphs.find(ks);
+  if (it != ctx->graphs.end()) {
+    GraphEntry &e = it->second;
+    if (!e.exec) return plain();      // a capture of this key failed before
+    e.last_use = ++ctx->graph_tick;
+    LH_CHECK_HIP(hipGraphLaunch(e.exec, ctx->stream));
+    ctx->count_stage("graph_replay");
+    for (const char *nm : e.paths) ++ctx->stage_counts[nm];
+    ctx->last_replay_counter = e.replay;
+    if (flags_out) *flags_out = e.flags;
+    return LANCE_HIP_OK;
+  }
   {
-    GraphEntry &e = ctx->graphs[ks];
-    if (e.exec) {
-      LH_CHECK_HIP(hipGraphLaunch(e.exec, ctx->stream));
-      ctx->last_replay_counter = e.replay;
-      if (flags_out) *flags_out = e.flags;
-      return LANCE_HIP_OK;
+    auto so = std::find(ctx->graph_seen_once.begin(), ctx->graph_seen_once.end(), ks);
+    if (so == ctx->graph_seen_once.end()) {
+      if (ctx->graph_seen_once.size() < SEEN_ONCE_MAX) ctx->graph_seen_once.push_back(ks);
+      else { ctx->graph_seen_once[ctx->graph_seen_next] = ks; ctx->graph_seen_next = (ctx->graph_seen_next + 1) % SEEN_ONCE_MAX; }
+      return plain();
     }
-    if (e.seen != 1) {      // 0: first call, runs uncaptured; > 1: a capture failed before -- stay on the plain path
-      if (e.seen == 0) e.seen = 1;
-      return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+    so->clear();      // promoted: the slot is reused by the FIFO in its own time
+  }
+  if (ctx->graphs.size() >= GRAPH_CACHE_MAX) {
+    auto victim = ctx->graphs.end();
+    for (auto g = ctx->graphs.begin(); g != ctx->graphs.end(); ++g) {
+      if (!g->second.exec) { victim = g; break; }
+      if (victim == ctx->graphs.end() || g->second.last_use < victim->second.last_use) victim = g;
     }
-    e.seen = 2;
+    if (victim != ctx->graphs.end()) {
+      if (victim->second.exec) {      // its last replay may still be in flight on this stream
+        LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipGraphExecDestroy(victim->second.exec);
+      }
+      ctx->graphs.erase(victim);
+    }
   }
   uint32_t *fl = nullptr;
   hipGraph_t g = nullptr;
   if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
-    return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+    ctx->graphs[ks].failed = true;
+    return plain();
   }
+  std::vector<const char *> paths;
   ctx->capturing = true;
+  ctx->capture_paths = &paths;
   const int rc = ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, &fl, allow);
   ctx->capturing = false;
+  ctx->capture_paths = nullptr;
   const hipError_t ee = hipStreamEndCapture(ctx->stream, &g);
   hipGraphExec_t ex = nullptr;
   if (rc == LANCE_HIP_OK && ee == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex) {
     (void)hipGraphDestroy(g);
     GraphEntry &e = ctx->graphs[ks];
-    e.exec = ex; e.flags = fl; e.replay = ctx->last_replay_counter; e.seen = 2;
+    e.exec = ex; e.flags = fl; e.replay = ctx->last_replay_counter; e.last_use = ++ctx->graph_tick; e.paths = std::move(paths);
     LH_CHECK_HIP(hipGraphLaunch(ex, ctx->stream));
+    ctx->count_stage("graph_capture");
     if (flags_out) *flags_out = fl;
     return LANCE_HIP_OK;
   }
   if (g) (void)hipGraphDestroy(g);
   (void)hipGetLastError();
-  // nothing was executed (the launches went into the discarded graph): run the batch on the plain path
-  return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
+  ctx->graphs[ks].failed = true;
+  // nothing was executed (the launches went into the discarded graph) and the stage counters counted a call that never ran: undo them,
+  // then run the batch on the plain path.  The failed capture may have left its reason in the thread's error string (a scratch slot that
+  // would have had to grow): the plain run below succeeds or sets its own.
+  for (const char *nm : paths) --ctx->stage_counts[nm];
+  set_error("");
+  return plain();
 }
 
 static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
@@ -1413,6 +1449,7 @@ int lance_hip_pq_scan_topk(lance_hip_ctx *ctx, int dtype, int metric, const void
   lance_hip_index *ix = nullptr;
   const int scan_metric = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   LH_TRY(lance_hip_index_from_storage(ctx, dtype, scan_metric, d, zc, 1, codebook, m, nbits, offs, codes_transposed, 1, row_ids, n_p, &ix));
+  ix->ephemeral = true;
   uint32_t *flags = nullptr;
   const float *qf = nullptr;
   int r = as_f32(ctx, model_dtype(dtype), q_residual, d, "f16.q", &qf);

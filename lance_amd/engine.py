@@ -219,6 +219,16 @@ class Engine:
         check(self.lib.lance_hip_comm_create(self.h, C.create_string_buffer(bytes(unique_id), 128), nranks, rank, C.byref(h)))
         return h
 
+    def comm_from_callback(self, fn, nranks, rank):
+        """lance_hip_comm_from_callback: the sharded trainer's exchanges through a host transport.  fn(buf_ptr, count, dtype, op,
+        stream_ptr) -> 0 reduces `count` elements (dtype 0 = f32, 1 = f64; op 0 = sum, 1 = max) at DEVICE address buf_ptr in place
+        across the ranks.  The ctypes thunk is kept alive on the returned handle's engine."""
+        thunk = _lib.ALLREDUCE_FN(lambda user, buf, count, dtype, op, stream: int(fn(buf, count, dtype, op, stream)))
+        h = C.c_void_p()
+        check(self.lib.lance_hip_comm_from_callback(thunk, None, nranks, rank, C.byref(h)))
+        self._comm_thunks = getattr(self, "_comm_thunks", []) + [thunk]
+        return h
+
     def comm_destroy(self, comm):
         self.lib.lance_hip_comm_destroy(comm)
 
@@ -572,23 +582,27 @@ class DeviceIndex:
         check(fn(eng.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(ids), _ptr(dists)))
         return ids, dists
 
-    def search_filtered(self, q, k, nprobes, allow, refine_factor=0):
+    def search_filtered(self, q, k, nprobes, allow, refine_factor=0, out=None):
         """Search under a row-id prefilter (lance_hip_ivfpq_search_filtered): `allow` = boolean array indexed by row id.  The
-        mask is tested inside the scan kernels; no filtered copy of the index is built."""
+        mask is tested inside the scan kernels; no filtered copy of the index is built.  out = (ids, dists) device tensors to
+        write into (a caller that keeps its query / output buffers gets the captured-graph path from its second call)."""
         d = self.centroids.shape[1]
         t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
         q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
         a = allow if isinstance(allow, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(allow, dtype=bool))
         a = a.to(torch.uint8).to(_dev()).contiguous()
         nq = q.shape[0]
-        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        if out is None:
+            ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        else:
+            ids, dists = out
         torch.cuda.synchronize()
         check(self.engine.lib.lance_hip_ivfpq_search_filtered(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(a),
                                                               a.numel(), _ptr(ids), _ptr(dists)))
         return ids, dists
 
-    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0, allow=None):
+    def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0, allow=None, out=None):
         """Distance-range query: only rows with lower <= d < upper (ADC distance) enter the per-partition heaps.  With a
         refine factor the reference also filters the exact distances before the final fetch (scanner.rs:3334-3377): all
         k * refine_factor candidates come back re-ranked from the device and the range is applied to them here.
@@ -614,8 +628,11 @@ class DeviceIndex:
         t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
         q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
         nq = q.shape[0]
-        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        if out is None:
+            ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        else:
+            ids, dists = out
         lo = float(np.finfo(np.float32).min) if lower is None else float(np.float32(lower))
         hi = float(np.finfo(np.float32).max) if upper is None else float(np.float32(upper))
         if allow is not None:

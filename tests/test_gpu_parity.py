@@ -332,6 +332,32 @@ def test_full_size_properties_sift1m(engine, oracle):
         oi, od = oidx.search(qh, 10, nprobes, refine=rf, raw=xh)
         assert (gi.cpu().numpy().view(np.uint64) == oi).all()
         assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all()
+    # The HEADLINE kernel on the headline index: the slices above stay under the matrix-core scan's batch threshold
+    # (96 pairs per partition: 2000 x 10 and 64 x 256 pairs both fall short of 96 x 256), so they ran the integer scan.  128 queries x
+    # every partition (v2.rs:1354-1381: nprobes = nlist, un-refined and refined) and one bench-sized 10,000 x 10 batch go through
+    # ivfpq_mscan_kernel -- asserted on the context's stage counter, which also counts replayed graphs -- and must equal the oracle.
+    eng = lance_amd.default_engine()
+    ms_runs = lambda: eng.timing_query("count:ivfpq_mscan")[1]
+    q128 = latent_sift(128, 128, 987, device="cuda"); q128h = q128.cpu().numpy()
+    for nprobes, rf in ((256, 0), (256, 10)):
+        before = ms_runs()
+        gi, gd = idx.search_device(q128, 10, nprobes, rf)
+        assert ms_runs() > before, "128 x 256 pairs did not take the matrix-core scan"
+        oi, od = oidx.search(q128h, 10, nprobes, refine=rf, raw=xh)
+        bad = np.nonzero((gi.cpu().numpy().view(np.uint64) != oi).any(axis=1))[0]
+        assert bad.size == 0, (nprobes, rf, bad[:8])
+        assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all()
+    q10k = latent_sift(10_000, 128, 4321 + 7, device="cuda"); q10kh = q10k.cpu().numpy()
+    oi, od = oidx.search(q10kh, 10, 10, refine=10, raw=xh)
+    out = (torch.empty((10_000, 10), dtype=torch.int64, device="cuda"), torch.empty((10_000, 10), dtype=torch.float32, device="cuda"))
+    for rep in range(3):                                    # plain call, captured call, replayed graph: the serving pattern
+        out[0].fill_(-7); out[1].fill_(-7.0)
+        before = ms_runs()
+        idx.search_device(q10k, 10, 10, 10, out=out)
+        assert ms_runs() > before, f"10,000 x 10 pairs did not take the matrix-core scan (rep {rep})"
+        bad = np.nonzero((out[0].cpu().numpy().view(np.uint64) != oi).any(axis=1))[0]
+        assert bad.size == 0, (rep, bad.size, bad[:8])
+        assert (out[1].cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), rep
     # flat ground truth at full size equals the oracle for a few queries
     gi, gd = lance_amd.flat_knn(x, q[:8], 10)
     oi, od = oracle.flat_knn(xh, qh[:8], 10)

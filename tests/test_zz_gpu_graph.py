@@ -21,6 +21,95 @@ def _sift_like(n, d, seed, ncl=64):
     return np.clip(np.rint(x), 0, 218).astype(f32)
 
 
+def _changed_contents(idx, oidx, x, d, dev, graphs_on):
+    """The serving pattern (bench.py: `host_step`): ONE device query buffer and ONE pair of output buffers, overwritten in place with a
+    different batch before every call -- the captured graph is keyed on the pointers, so from the third call on every batch is answered
+    by a replay that must read the NEW contents.  Outputs are filled with a sentinel before each call; every answer is compared with
+    the oracle's for the batch that is in the buffer.  The same for a prefiltered search (the allow bitmap is rebuilt outside the graph,
+    its scratch pointer is inside) and a distance-range search."""
+    import torch
+    import lance_amd
+    eng = lance_amd.default_engine()
+    n = x.shape[0]
+    nq, k, nprobes, rf = 1500, 10, 8, 5
+    batches = [_sift_like(nq, d, 100 + i) for i in range(3)]
+    hq = [torch.from_numpy(b).pin_memory() for b in batches]
+    qbuf = torch.empty((nq, d), dtype=torch.float32, device=dev)
+    out = (torch.empty((nq, k), dtype=torch.int64, device=dev), torch.empty((nq, k), dtype=torch.float32, device=dev))
+    h_ids = torch.empty((nq, k), dtype=torch.int64).pin_memory(); h_d = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+    want = [oidx.search(b, k, nprobes, refine=rf, raw=x) for b in batches]
+    replays = lambda: eng.timing_query("count:graph_replay")[1]
+    r0 = replays()
+    done = 0
+    for rep in range(7):                     # plain, capture, then replays -- the batch in the buffer changes every time
+        b = rep % 3
+        qbuf.copy_(hq[b], non_blocking=True)
+        out[0].fill_(-7); out[1].fill_(float("nan"))
+        torch.cuda.current_stream().synchronize()
+        idx.search_device(qbuf, k, nprobes, rf, out=out, sync=False)
+        eng.synchronize()
+        h_ids.copy_(out[0], non_blocking=True); h_d.copy_(out[1], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        oi, od = want[b]
+        bad = np.argwhere((h_ids.numpy().view(np.uint64) != oi).any(axis=1)).reshape(-1)
+        assert bad.size == 0, ("changed contents", rep, b, f"{bad.size} of {nq} queries differ, first {bad[:5]}")
+        assert (h_d.numpy().view(np.uint32) == od.view(np.uint32)).all(), ("changed contents", rep, b)
+        done += 1
+    if graphs_on:
+        assert replays() - r0 >= 5, f"expected the calls from the third on to be graph replays, counted {replays() - r0}"
+    else:
+        assert replays() == r0
+    # prefilter: two different masks through the same buffers (the bitmap is rebuilt per call, the graph only holds its address)
+    rng = np.random.default_rng(3)
+    masks = [rng.random(n) < 0.5, rng.random(n) < 0.2]
+    r0 = replays()
+    for rep in range(6):
+        b, mk = rep % 3, masks[rep % 2]
+        qbuf.copy_(hq[b]); out[0].fill_(-7); out[1].fill_(float("nan"))
+        torch.cuda.synchronize()
+        gi, gd = idx._ix.search_filtered(qbuf, k, nprobes, mk, refine_factor=0, out=out)
+        oi, od = oidx.search(batches[b], k, nprobes, prefilter=mk)
+        assert (gi.cpu().numpy().view(np.uint64) == oi).all(), ("filtered", rep)
+        assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), ("filtered", rep)
+        done += 1
+    if graphs_on:
+        assert replays() - r0 >= 4, f"filtered searches: {replays() - r0} replays"
+    # distance range through the same buffers
+    lo, hi = 0.0, float(np.median(want[0][1][:, -1]))
+    r0 = replays()
+    for rep in range(5):
+        b = rep % 3
+        qbuf.copy_(hq[b]); out[0].fill_(-7); out[1].fill_(float("nan"))
+        torch.cuda.synchronize()
+        gi, gd = idx._ix.search_range(qbuf, k, nprobes, lower=lo, upper=hi, out=out)
+        oi, od = oidx.search(batches[b], k, nprobes, lower=lo, upper=hi)
+        assert (gi.cpu().numpy().view(np.uint64) == oi).all(), ("range", rep)
+        assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), ("range", rep)
+        done += 1
+    if graphs_on:
+        assert replays() - r0 >= 3, f"range searches: {replays() - r0} replays"
+    # A caller that never repeats a call (fresh output buffers, kept alive so that the allocator cannot hand an address out twice) must
+    # neither create graph entries nor push the steady-state graph out of the cache (ADVICE r04: the cache used to be dropped wholesale).
+    captures = lambda: eng.timing_query("count:graph_capture")[1]
+    qbuf.copy_(hq[0]); torch.cuda.synchronize()
+    idx.search_device(qbuf, k, nprobes, rf, out=out)      # the steady-state key: replayed since the first loop above
+    c0, r0 = captures(), replays()
+    keep_alive = []
+    qsmall = qbuf[:40]
+    for i in range(150):
+        keep_alive.append(idx.search_device(qsmall, 5, 4, 0))
+    assert captures() == c0, "calls that never repeat were captured"
+    out[0].fill_(-7); torch.cuda.synchronize()
+    idx.search_device(qbuf, k, nprobes, rf, out=out)
+    if graphs_on:
+        assert replays() == r0 + 1, "the steady-state graph was evicted by calls that never repeat"
+    assert (out[0].cpu().numpy().view(np.uint64) == want[0][0]).all()
+    gi, _ = keep_alive[-1]
+    oi, _ = oidx.search(batches[0][:40], 5, 4)
+    assert (gi.cpu().numpy().view(np.uint64) == oi).all()
+    return done + 2
+
+
 def _cases():
     sys.path.insert(0, ROOT)
     import torch
@@ -29,6 +118,7 @@ def _cases():
     from lance_amd.engine import Engine
     dev = torch.device("cuda", 0)
     checked = 0
+    graphs_on = os.environ.get("LANCE_HIP_GRAPH", "1") != "0"
     for (n, d, nlist, m) in ((60_000, 128, 64, 16), (30_000, 384, 32, 96)):
         x = _sift_like(n, d, 5)
         idx = lance_amd.create_index(x, "IVF_PQ", metric="l2", num_partitions=nlist, num_sub_vectors=m, max_iters=6)
@@ -44,6 +134,9 @@ def _cases():
         def check(name, engine=None, out=None, tag=""):
             nonlocal checked
             k, nprobes, rf, oi, od = want[name]
+            if out is not None:      # a replay that did nothing must not pass on the previous repetition's answer
+                out[0].fill_(-7); out[1].fill_(float("nan"))
+                torch.cuda.synchronize()
             gi, gd = idx.search_device(qs[name], k, nprobes, rf, out=out, engine=engine)
             gi = gi.cpu().numpy().view(np.uint64); gd = gd.cpu().numpy()
             bad = np.argwhere((gi != oi).any(axis=1)).reshape(-1)
@@ -67,6 +160,7 @@ def _cases():
         e2.synchronize()
         assert (outs["big"][0].cpu().numpy().view(np.uint64) == oi).all()
         e2.close()
+        checked += _changed_contents(idx, oidx, x, d, dev, graphs_on)
     print(f"graph cases ok: {checked}")
 
 
