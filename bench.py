@@ -128,7 +128,15 @@ def main():
         # only rank 0 reports; keep the other ranks' stdout (RCCL prints a version banner through C stdio) out of the
         # launcher's combined output so that the JSON line stays the only thing on it
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+    # First-contact insurance for the N-rank path on a box with ONE GPU (tests/test_zz_gpu_two_ranks.py): LANCE_BENCH_ONE_GPU=1 puts every
+    # rank on device 0 and LANCE_BENCH_BACKEND=gloo carries the collectives through host memory (RCCL refuses two ranks on one device) --
+    # every kernel, buffer layout and exchange of the multi-GPU build / search runs for real; only the transport differs.  Never a
+    # measurement: the line says so in `multi_gpu.transport`.
+    one_gpu = os.environ.get("LANCE_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("LANCE_BENCH_BACKEND", "nccl")
+    if one_gpu:
+        local_rank = 0
+    if not torch.cuda.is_available() or (not one_gpu and torch.cuda.device_count() < world):
         raise SystemExit(f"bench.py --gpus {world} needs {world} MI355X GPUs (rank {rank} sees {torch.cuda.device_count() if torch.cuda.is_available() else 0} "
                          f"HIP devices); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -137,7 +145,10 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import lance_amd
     from lance_amd.testing import sift_like
@@ -215,7 +226,8 @@ def main():
         x, _ = ld.all_gather_var(x_local)             # refine on a replica needs every raw vector on every rank (512 MB over xGMI)
         idx._ix.set_raw(x)
         torch.cuda.synchronize()
-        mg = {"rccl_ranks": world, "rows_per_rank": hi - lo, "build_sec_ivf_sharded_allreduce": secs["sharded"],
+        mg = {"rccl_ranks": world, "transport": "rccl" if backend == "nccl" else f"{backend} through host memory" + (", all ranks on one GPU" if one_gpu else ""),
+              "rows_per_rank": hi - lo, "build_sec_ivf_sharded_allreduce": secs["sharded"],
               "build_sec_ivf_replicated": secs["replicated"], "raw_vectors_allgather_sec": time.perf_counter() - t0,
               "build_stages_ms_sharded": {k_: round(v * 1e3, 3) for k_, v in bld.stats.seconds.items()}}
         # strong-scaling line: the IVF lists sharded over the ranks (list p -> rank p % N, rows moved by all_to_all), every
@@ -318,12 +330,13 @@ def main():
                                                        "q_residual", "ivfpq_scan_c1", "ivfpq_merge", "ivfpq_exact", "refine")}
     mscan = eng.timing_query("ivfpq_mscan")[1] > 0      # the main pass ran as the matrix-core filter scan (search_ms.hip)
     if world > 1:
+        from lance_amd import dist as ld
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ld._all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
         if "list_sharded_qps_strong_scaling" in mg:
             tl = torch.tensor([mg["list_sharded_qps_strong_scaling"]], dtype=torch.float64, device=dev)
-            dist.all_reduce(tl, op=dist.ReduceOp.MIN)
+            ld._all_reduce(tl, op=dist.ReduceOp.MIN)
             mg["list_sharded_qps_strong_scaling"] = tl.item()
 
     if rank != 0:

@@ -254,9 +254,6 @@ lance_hip_index::~lance_hip_index() {
   if (centroids) (void)hipFree(centroids);
   if (codebook) (void)hipFree(codebook);
   if (cb_mean) (void)hipFree(cb_mean);
-  if (cb_hi) (void)hipFree(cb_hi);
-  if (cb_lo) (void)hipFree(cb_lo);
-  if (cb_n2) (void)hipFree(cb_n2);
   if (pt) {
     if (pt->g) (void)hipFree(pt->g);
     if (pt->cen_t) (void)hipFree(pt->cen_t);

@@ -26,10 +26,6 @@ struct lance_hip_index {
   // (an overflowed f16 model).  model_finite mirrors it on the host; the integer filter scans -- whose NaN entries quantise to 0
   // and would enter the merge kernel's sum cut as small sums -- are only taken for finite models
   bool model_finite = true;
-  // 8-bit PQ with sub-dimension 8 (search_q.hip, MFMA table build): the codebook as bf16 hi / lo planes [m][256][8] and the
-  // squared norms of the codewords [m][256]
-  uint16_t *cb_hi = nullptr, *cb_lo = nullptr;
-  float *cb_n2 = nullptr;
   float *cb_mean = nullptr;       // 8-bit PQ: [d] mean codeword of every sub-quantiser, then [1] sum over m of the mean |c|^2 (bound pass scale)
   // LANCE_HIP_QPT=1 (search_qt.hip, per-query tables): constants of that filter, created by the first such search
   struct PtConst {

@@ -122,7 +122,6 @@ int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float
 
 // quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix);
-bool qscan_mfma_table(const lance_hip_index *ix);   // search_q.hip: the filter scan builds its table on the matrix cores (sub-dimension 8)   // search_q.hip: lance_hip_index::cb_mean (8-bit PQ)
 constexpr int QSCAN_SEG_CAP = 256;   // survivors kept per (query, probe)
 struct SelectOut;
 bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
@@ -131,11 +130,10 @@ bool qscan_tiled_shape(int m, int sd);
 int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t nq, uint32_t nprobes, uint32_t *seg_cnt, uint32_t *qovf);
 int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys);
 int qscan_item_tables(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nlist, int G, uint32_t *item_start, int4 *desc, uint32_t max_items);
-// G = queries per work item of the main pass: 4, or 8 when qscan8_enabled(m, sd) (search_q8.hip)
+// G = queries per work item of the main pass
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
                 uint32_t max_items4, int G = 4);
-bool qscan8_enabled(int m, int sd);   // search_q8.hip: eight queries per gather with 8-bit entries (M = 16; LANCE_HIP_Q8=1)
 int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,

@@ -18,7 +18,6 @@ constexpr int Q_G = 4;         // queries per work item (4 x u16 = one ds_read_b
 #define LH_Q_WAVES 8
 #endif
 constexpr int Q_WAVES = LH_Q_WAVES;   // launch-bounds hint for M = 16, sub-dimension <= 8: waves per SIMD (8 = FOUR 512-lane workgroups per CU, <= 64 VGPRs: fits without spills once the table build is not unrolled -- main pass 0.52 -> 0.42 ms; with the build unrolled by 2 it spilled and lost 25 %)
-constexpr float Q_MB_SLACK_CAP = 16.0f;   // MFMA table build: largest per-query slack (units) the filter takes; beyond it the pair is rescanned exactly
 constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); more -> that partition is rescanned exactly for the query
 #ifndef LH_Q_LUT_UNROLL
 #define LH_Q_LUT_UNROLL 1
@@ -28,16 +27,8 @@ constexpr int Q_CAP = QSCAN_SEG_CAP;   // survivors kept per (query, probe); mor
 #endif
 constexpr int Q_MPF = LH_Q_MPF;        // merge kernel: codebook entries fetched together per candidate row (registers vs round trips)
 
-// search_q8.hip: eight queries per gather, 8-bit entries
-constexpr int Q8_G = 8;
-constexpr uint32_t Q8_CAP_E = 63u;     // largest entry: four of them add up inside a byte
-#ifndef LH_Q8_SE
-#define LH_Q8_SE 378
-#endif
-constexpr uint32_t Q8_SE = LH_Q8_SE;   // the bound T maps to SE8 (6 x the cap: scripts/sim/q8_selectivity.py)
-
 struct QscanArgs {
-  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel); q8: [items][d][2] (q_residual8_kernel)
+  const f4 *rq;                 // [items][d] x 4 queries: negated residuals (q_residual_kernel)
   const uint32_t *pair_idx;     // grouped pair indices (pair = q * nprobes + rank)
   const uint32_t *item_start;   // [nlist+1]: items of class A
   const int4 *desc;
@@ -53,10 +44,6 @@ struct QscanArgs {
   uint32_t *qovf;               // [nq] set when a segment of the query overflowed -- zeroed before the launch
   uint32_t *ovf;                // [1 + nq * nprobes] count (zeroed before the launch) + the overflowed segments: the rescan kernel's work list
   const uint32_t *allow;        // prefilter bitmap over storage positions or NULL
-  // MFMA table build (search_q.hip, sub-dimension 8): bf16 hi / lo planes of the codebook [m][256][8] and the codewords' squared norms
-  const uint16_t *cb_hi = nullptr, *cb_lo = nullptr;
-  const float *cb_n2 = nullptr;
-  const f4 *rq_n2 = nullptr;    // [items] |r_j|^2 of the item's four queries (q_residual_kernel)
   unsigned long long *prof = nullptr;   // -DLH_QT_PROF builds only (tiled kernel): [0] build clocks [1] scan [2] emit [3] items
 };
 
@@ -140,12 +127,6 @@ struct QboundArgs {
   const uint32_t *allow;
 };
 
-
-// search_q8.hip
-size_t qscan8_lds_bytes();
-int qscan8_residual(lance_hip_ctx *ctx, const float *qs, const uint32_t *pair_idx, const uint32_t *item_start, const int4 *desc,
-                    const float *centroids, int d, int nlist, int nprobes, int round_f16, uint32_t max_items, f4 *rq);
-bool qscan8_launch(lance_hip_ctx *ctx, const QscanArgs &a, int sd, unsigned grid);
 
 // search_qt.hip
 int qscan_pt_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const QscanArgs &a, const float *qs, uint32_t nq, const uint32_t *probes,

@@ -214,7 +214,12 @@ struct ScanArgs {
   uint32_t *out_cnt;  // [nq*nsplit]
   uint32_t *flags;    // [nq]
   int round_f16;      // index element type is f16: the residual query is an f16 subtraction (v2.rs:326)
-  int ablate;         // perf experiments only (LANCE_HIP_ABLATE): 1 = LUT once per query, 2 = no candidate appends, 4 = skip scan
+#ifdef LH_TIMING_EXPERIMENTS      // builds with -DLH_TIMING_EXPERIMENTS only (scripts/build_variant.sh): results WRONG, timing only
+  int ablate;         // LANCE_HIP_ABLATE: 1 = LUT once per query, 2 = no candidate appends, 4 = skip scan
+#define SCAN_ABLATE(p) ((p).ablate)
+#else
+#define SCAN_ABLATE(p) 0
+#endif
   const uint32_t *allow;   // prefilter bitmap over storage positions or NULL
   int lanes32 = 0;         // f16 column under dot with sub-vectors of more than 16 elements: 32-lane table entries (lut_entry_rt)
 };
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
     }
     __syncthreads();
     // pq/distance.rs:24-92: LUT[mm][c] = dist(q_sub[mm], codebook[mm][c]) in l2_scalar / dot_scalar order
-    if (!((p.ablate & 1) && pi > sp)) {
+    if (!((SCAN_ABLATE(p) & 1) && pi > sp)) {
       if constexpr (SD > 0 && SD % 4 == 0) {
         // 4 entries per step: all codebook loads of the step are issued before the arithmetic,
         // so one L2 round trip covers 4 entries (the codebook is 128 KiB, L2-resident).
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
     __syncthreads();
 
     const uint8_t *pcodes = p.codes + (int64_t)off * m;
-    for (int base = 0; base < ((p.ablate & 4) ? 0 : np); base += SCAN_ROUND) {
+    for (int base = 0; base < ((SCAN_ABLATE(p) & 4) ? 0 : np); base += SCAN_ROUND) {
       // The decision must be the same in every lane, and a lane that runs ahead appends (atomicAdd on misc[0]) as soon as it is
       // past this point: read the count, THEN a barrier, then decide.  (Round 1-2 read it without the barrier: a wave that saw
       // the count just over the limit entered tighten()'s barriers while the others were in the scan round -- rows lost or
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(ScanArgs p) {
           if constexpr (METRIC == METRIC_DOT) dist = dist - ((float)m - 1.0f);  // pq/storage.rs:949-957
           const uint32_t key = order_key(dist);
           const bool in_range = !p.has_range || (key >= p.lo_key && key < p.hi_key);  // flat/index.rs:98-105
-          if (in_range && key <= T && !((p.ablate & 2) && base > 0) && row_allowed(p.allow, off + (uint32_t)row)) {
+          if (in_range && key <= T && !((SCAN_ABLATE(p) & 2) && base > 0) && row_allowed(p.allow, off + (uint32_t)row)) {
             const uint32_t slot = atomicAdd(&s.misc[0], 1u);
             if (slot < SCAN_CAP) { s.ckey[slot] = key; s.cpos[slot] = off + (uint32_t)row; }
             else s.misc[3] = FLAG_OVERFLOW;
@@ -1168,7 +1173,9 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
       a.hi_key = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
     }
     a.out_keys = ckeys; a.out_pos = cpos; a.out_cnt = ccnt; a.flags = flags;
+#ifdef LH_TIMING_EXPERIMENTS
     { static const int ablate = getenv("LANCE_HIP_ABLATE") ? atoi(getenv("LANCE_HIP_ABLATE")) : 0; a.ablate = ablate; }
+#endif
     const int dpad = (d + 3) & ~3;
     const size_t lds = (size_t)dpad * 4 + (size_t)m * 256 * 4 + (size_t)SCAN_CAP * 8 + 256 * 4 + 8 * 4;
     LH_REQUIRE(lds <= 160 * 1024, "search: LUT of %d sub-vectors does not fit in LDS", m);

@@ -297,10 +297,20 @@ struct MscanArgs {
   float *seg_val = nullptr;     // [nq * nprobes][Q_CAP] the survivors' accumulator values (the merge kernel scales them into integer sums)
   uint32_t *ovf;
   const uint32_t *allow;
+#ifdef LH_TIMING_EXPERIMENTS
   int dbg = 0;                          // LANCE_HIP_MS_DBG (timing experiments, results WRONG): 1 = the flush drops its entries, 2 = every limit a NaN (nothing passes)
+#endif
   unsigned long long *prof_slices = nullptr;   // LANCE_HIP_MS_PROF=1: [slices] ticks a workgroup spent on the slice (taken order)
   unsigned long long *prof = nullptr;   // LANCE_HIP_MS_PROF=1: [0] stage [1] gather [2] tiles [3] flush [4] life [5] waves [6] chunks [7] longest life
 };
+
+// Timing experiments that make the results WRONG (LANCE_HIP_MS_DBG) exist only in builds with -DLH_TIMING_EXPERIMENTS
+// (scripts/build_variant.sh NAME search_ms.hip -- -DLH_TIMING_EXPERIMENTS): the product library cannot be switched into them.
+#ifdef LH_TIMING_EXPERIMENTS
+#define MS_DBG(p) ((p).dbg)
+#else
+#define MS_DBG(p) 0
+#endif
 
 // ---- the scan -------------------------------------------------------------------------------------------------------------------------
 // One persistent 1024-lane workgroup per CU.  It takes a slice from the device counter (largest first), brings the block's f16 residuals
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   };
   auto flush_begin = [&](uint32_t pos_base) {      // (after flush_end)
     pd_k = 0xFFFFFFFFu;
-    if ((uint32_t)lane < qn && !(p.dbg & 1)) {
+    if ((uint32_t)lane < qn && !(MS_DBG(p) & 1)) {
       const uint2 ent = qw[cur + (uint32_t)lane];
       if (row_allowed(p.allow, pos_base + (ent.x & 255u))) pd_k = atomicAdd(&p.seg_cnt[sPair[ent.x >> 8]], 1u);
     }
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
       // limits (waves 0-7) and pair ids (waves 8-15): one dword per slot out of the {limit, -, -, pair} records
       const int slot = (wave & 7) * 64 + lane;
       if (slot < nslots) {
-        const float *ps = reinterpret_cast<const float *>(slot < Qp && !(p.dbg & 2) ? p.prm + (int64_t)U.gs + slot : p.prm + p.nan_slot);
+        const float *ps = reinterpret_cast<const float *>(slot < Qp && !(MS_DBG(p) & 2) ? p.prm + (int64_t)U.gs + slot : p.prm + p.nan_slot);
         if (wave < 8) __builtin_amdgcn_global_load_lds((ms_gptr)ps, (ms_lptr)(&sLim[(wave & 7) * 64]), 4, 0, 0);
         else __builtin_amdgcn_global_load_lds((ms_gptr)(ps + 3), (ms_lptr)(&sPair[(wave & 7) * 64]), 4, 0, 0);
       }
@@ -553,7 +563,6 @@ bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes)
   static const uint32_t minq = getenv("LANCE_HIP_MSCAN_MINQ") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_MSCAN_MINQ"))) : 96u;
   if (off || !ms_shape(ix, nullptr, nullptr)) return false;
   if (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_COSINE) return false;
-  if (qscan8_enabled((int)ix->m, (int)(ix->d / ix->m))) return false;
   return (uint64_t)nq * nprobes >= (uint64_t)minq * ix->nlist;
 }
 
@@ -657,12 +666,14 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm; a.prm2 = prm2;
   a.nan_slot = nan_slot; a.nlist = nlist; a.nprobes = (int)nprobes;
   a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
+#ifdef LH_TIMING_EXPERIMENTS
   static const int dbg = [] {
     const int v = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
     if (v) fprintf(stderr, "lance_hip: LANCE_HIP_MS_DBG=%d -- timing experiment, search RESULTS ARE WRONG\n", v);
     return v;
   }();
   a.dbg = dbg;
+#endif
   // persistent: one workgroup per CU (151 KiB of LDS each).  LANCE_HIP_MS_GRID: fewer workgroups leave CUs to the latency-bound kernels of
   // other engine contexts (merge, refine, bound pass) while this one runs -- an A/B knob
   static const int grid_env = getenv("LANCE_HIP_MS_GRID") ? atoi(getenv("LANCE_HIP_MS_GRID")) : 0;

@@ -674,8 +674,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   {
     // main pass grouping: class A (bounded) pairs by partition for the filter scan, class B for the exact pair kernel
     ScopedTimer t(ctx, "pm_group");
-    LH_TRY(qscan_group(ctx, probes, nq, nprobes, nlist, tglobal, keys, tbound, pair_starts, pair_idx, item_start4, desc4, max_items4,
-                       qscan8_enabled(m, sd) ? 8 : 4));
+    LH_TRY(qscan_group(ctx, probes, nq, nprobes, nlist, tglobal, keys, tbound, pair_starts, pair_idx, item_start4, desc4, max_items4, 4));      // four queries per work item (q_common.cuh: Q_G)
     hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, 2 * nlist, item_start);
     hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items2, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, pair_idx,
                        2 * nlist, nlist, (int)nprobes, max_items2, desc);

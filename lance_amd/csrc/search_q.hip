@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void q_item_desc_kernel(const uint32_t *__rest
 __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict__ q, const uint32_t *__restrict__ pair_idx,
                                                          const uint32_t *__restrict__ item_start, const int4 *__restrict__ desc,
                                                          const float *__restrict__ centroids, int d, int nlist, int pdiv, int round_f16,
-                                                         f4 *__restrict__ rq, f4 *__restrict__ rq_n2 = nullptr) {
+                                                         f4 *__restrict__ rq) {
   const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (item >= item_start[nlist]) return;
   const int lane = threadIdx.x & 63;
@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict
   uint32_t qj[Q_G];
 #pragma unroll
   for (int j = 0; j < Q_G; ++j) qj[j] = pair_idx[i0 + (j < cnt ? j : 0)] / (uint32_t)pdiv;
-  f4 n2 = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int dim = lane; dim < d; dim += 64) {
     const float cen = centroids[(int64_t)part * d + dim];
     f4 r4;
@@ -131,39 +130,17 @@ __global__ __launch_bounds__(256) void q_residual_kernel(const float *__restrict
       r4[j] = -v;   // NEGATED: (r - c)^2 is evaluated as (c + (-r))^2 so that the add packs (v_pk_add_f32)
     }
     rq[(int64_t)item * d + dim] = r4;
-    n2 += r4 * r4;
-  }
-  if (rq_n2) {      // |r_j|^2 of the item's four queries (the MFMA table build's slack; any summation order serves a bound)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { n2.x += __shfl_xor(n2.x, o, 64); n2.y += __shfl_xor(n2.y, o, 64); n2.z += __shfl_xor(n2.z, o, 64); n2.w += __shfl_xor(n2.w, o, 64); }
-    if (lane == 0) rq_n2[item] = n2;
   }
 }
 
-// MB = true (sub-dimension 8): the table is built on the MATRIX CORES.  (c + nr)^2 = |c|^2 + 2 c.nr + |nr|^2 per sub-quantiser; the
-// 256 x 4 dot products of one sub-quantiser against the four queries' (negated) residuals are an [256 x 8] x [8 x 4] product, and four
-// sub-quantisers fill one v_mfma_f32_16x16x32_bf16: A = 16 rows (sub-quantiser m', query j) x K = 32 (4 sub-quantisers x 8
-// dimensions, block diagonal: row (m', j) is non-zero only in k-group m'), B = K x 16 codewords (k-group g = codeword c of
-// sub-quantiser g), so D[(m', j)][c] puts, in lane l, the four queries' dot products of codeword (l & 15) of sub-quantiser (l >> 4)
-// -- exactly one uint2 table entry.  bf16 hi / lo split of both operands, three MFMAs (hi.hi + lo.hi + hi.lo): |error| <= 2^-14
-// |c||nr| per dot product, i.e. at most 2^-13.9 (|c|^2 + |nr|^2) per entry with the f32 rounding of the norms; summed over a
-// row's entries and scaled: delta_j = 2^-13.9 s_j (3 |r_j|^2 + 2 T_j) units for every row that can pass (|c_row| <= |r| + sqrt(T)).
-// The per-query limit carries ceil(delta_j); a pair whose delta exceeds Q_MB_SLACK_CAP is handed to the exact rescan.  The table is
-// a bound, not a result: survivors are re-evaluated in the reference's arithmetic by the merge kernel as before.  VALU per table
-// entry (4 queries): ~12 (norm adds, 2 x pk_fma, quantisation) instead of 44.
-typedef short q_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float q_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t q_bf16_rne(float x) {
-  const uint32_t u = __float_as_uint(x);
-  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
-template <int SD, int MU, bool MB = false>
-__global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
+// (An MFMA-built table -- [256 x 8] x [8 x 4] per sub-quantiser on v_mfma_f32_16x16x32_bf16, bf16 hi / lo split -- was parity-green in
+// round 4 and SLOWER than the packed-VALU build below (scan 0.405 vs 0.347 ms per 10k-query batch at C2, gpurun r04e: eight tiles per
+// wave are a chain of L2 round trips the 44-VALU build does not have); so was an 8-queries-per-gather variant with 8-bit entries
+// (round 3, profiles/r03_q8_variant.txt).  Both were removed in round 5; the matrix-core scan of search_ms.hip took their place.)
+template <int SD, int MU>
+__global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 ? Q_WAVES : 6) : 4)) void ivfpq_qscan_kernel(QscanArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
-  static_assert(!MB || SD == 8, "the MFMA table build is written for sub-dimension 8");
   constexpr uint32_t CAPE = 65535u / M;        // largest entry: M of them cannot overflow a u16 field
   constexpr uint32_t SE = CAPE - CAPE / 32;     // the bound T maps to SE; ~3 % head-room below CAPE
   constexpr uint32_t LIM = SE + M + 2;          // one unit per entry for the conversion's rounding; +2 covers the f32 rounding terms (see header)
@@ -174,7 +151,6 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4
   uint32_t *misc = cand + 4 * Q_CAP;                                  // [0..3] survivor counts
   float *sc = reinterpret_cast<float *>(misc + 4);                    // [4] SE / T / 65535 (1e30: no such query in this item)
   uint16_t *csum = reinterpret_cast<uint16_t *>(sc + 4);              // [4][Q_CAP] the survivors' integer sums
-  __shared__ uint32_t mb_lim[Q_G];      // MB: per-query limit (0: the pair goes to the exact rescan)
 
   // one item per workgroup and no loop: nothing is stored to global memory before the residual loads, so the compiler may
   // (and does) turn them into scalar loads
@@ -204,63 +180,7 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4
     }
     __syncthreads();
     const f4 *rq4 = p.rq + (int64_t)item * p.d;
-    uint32_t lim4[Q_G] = {LIM, LIM, LIM, LIM};
-    if constexpr (MB) {
-      // the per-query slack of the surrogate table (header) from |r_j|^2, which the residual pre-pass left beside the residuals
-      if (threadIdx.x < Q_G) {
-        uint32_t lim = LIM;
-        if ((int)threadIdx.x < cnt) {
-          const float T = key_to_float(p.tbound[qj[threadIdx.x]]);
-          const float sj = fminf((float)SE / T, 1e30f);
-          const float r2 = p.rq_n2[item][threadIdx.x];
-          const float delta = 6.5e-5f * sj * (3.0f * r2 + 2.0f * T) * 1.01f;     // 2^-13.9 = 6.5e-5
-          lim = (delta <= Q_MB_SLACK_CAP) ? LIM + (uint32_t)ceilf(delta) : 0u;    // NaN delta -> 0: rescan
-        }
-        mb_lim[threadIdx.x] = lim;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < Q_G; ++j) lim4[j] = mb_lim[j];
-      // ---- table on the matrix cores: wave w owns one quad of sub-quantisers and TPW blocks of 16 codewords
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      constexpr int TPW = M / 2;                        // (M / 4 quads) x 16 codeword blocks / 8 waves
-      const int quad = (wave * TPW) >> 4, cb0 = (wave * TPW) & 15;
-      const int g = lane >> 4, r = lane & 15, mrow = r >> 2, jrow = r & 3;
-      q_bf16x8 ah, al;
-      {
-        const int mm = quad * 4 + mrow;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const f4 rv = rq4[mm * 8 + u];
-          const float v = g == mrow ? rv[jrow] : 0.0f;
-          const uint32_t hb = q_bf16_rne(v);
-          ah[u] = (short)hb;
-          al[u] = (short)q_bf16_rne(v - __uint_as_float(hb << 16));
-        }
-      }
-      const int mE = quad * 4 + g;                      // this lane's sub-quantiser in every tile's result
-      f4 rn2 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const f4 rv = rq4[mE * 8 + u]; rn2 += rv * rv; }
-      const f4 s4 = *reinterpret_cast<const f4 *>(sc);
-      const f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
-      const f2 two = {2.0f, 2.0f};
-#pragma unroll 4
-      for (int i = 0; i < TPW; ++i) {
-        const int c = (cb0 + i) * 16 + r;
-        const int64_t e = (int64_t)mE * 256 + c;
-        const q_bf16x8 bh = *reinterpret_cast<const q_bf16x8 *>(p.cb_hi + e * 8);
-        const q_bf16x8 bl = *reinterpret_cast<const q_bf16x8 *>(p.cb_lo + e * 8);
-        const float cn = p.cb_n2[e];
-        q_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
-        const f2 l01 = __builtin_elementwise_fma(two, f2{acc[0], acc[1]}, f2{cn + rn2.x, cn + rn2.y});
-        const f2 l23 = __builtin_elementwise_fma(two, f2{acc[2], acc[3]}, f2{cn + rn2.z, cn + rn2.w});
-        lutq[mE * 256 + c] = q_entry_quantise<CAPE>(l01, l23, s01, s23);
-      }
-    } else {
+    const uint32_t lim4[Q_G] = {LIM, LIM, LIM, LIM};
     // quantised LUT: lane (c = tid & 255, half = tid >> 8) fills sub-quantisers [half * M/2, (half+1) * M/2).  A bound, not a
     // result (q_entry_acc / q_entry_quantise above).
     {
@@ -275,7 +195,6 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4
         q_entry_acc<SD>(rq4 + mm * SD, p.codebook + ((int64_t)mm * 256 + c) * SD, acc01, acc23);
         lutq[mm * 256 + c] = q_entry_quantise<CAPE>(acc01, acc23, s01, s23);
       }
-    }
     }
     __syncthreads();
     // scan: no barrier inside; survivors go to the per-query LDS lists
@@ -308,8 +227,6 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4
                 a0 += v.x; a1 += v.y;
               }
           }
-          // (MB: a limit of 0 = the pair is rescanned exactly -- nothing of it passes here unless its sum is 0, which the final
-          // count below overrides)
           const bool p0 = (a0 & 0xFFFFu) <= lim4[0], p1 = (a0 >> 16) <= lim4[1], p2 = (a1 & 0xFFFFu) <= lim4[2], p3 = (a1 >> 16) <= lim4[3];
           if ((p0 | p1 | p2 | p3) && row_allowed(p.allow, off + (uint32_t)row)) {
             const uint32_t pos = off + (uint32_t)row;
@@ -325,9 +242,8 @@ __global__ __launch_bounds__(Q_BS, (MU == 1 ? (SD <= 8 && !MB ? Q_WAVES : 6) : 4
 #pragma unroll
     for (int j = 0; j < Q_G; ++j) {
       if (j < cnt) {
-        uint32_t raw = misc[j];
-        if constexpr (MB) { if (lim4[j] == 0u) raw = 0xFFFFFFFFu; }   // slack over the cap: the rescan kernel does this pair exactly
-        const uint32_t n = raw > (uint32_t)Q_CAP ? (MB && lim4[j] == 0u ? 0u : (uint32_t)Q_CAP) : raw;
+        const uint32_t raw = misc[j];
+        const uint32_t n = raw > (uint32_t)Q_CAP ? (uint32_t)Q_CAP : raw;
         const int64_t seg = (int64_t)qj[j] * p.nprobes + rk[j];
         if (threadIdx.x == 0) {
           p.seg_cnt[seg] = raw;   // raw > Q_CAP: survivors were lost -> the rescan kernel redoes this (query, probe) exactly
@@ -473,14 +389,18 @@ struct QmergeArgs {
   int qm_g;                      // probes whose residuals are staged together (<= QM_G; fewer for long rows: LDS = occupancy)
   int vec4;                      // d % 4 == 0 and 16-byte aligned query / centroid rows: staged with float4 loads
   const uint16_t *seg_sum;       // [nq * nprobes][Q_CAP] integer sums of the survivors (scan kernels)
-  int cut_mode;                  // 0: sums bound the distance from both sides (u16 tables); 1: lower bounds only (8-bit entries): two-phase cut
   int cut_shift;                 // histogram bin = sum >> cut_shift (512 bins cover 0 .. LIM)
   uint32_t cut_slack;            // a survivor whose sum exceeds (upper edge of the keff-th bin) + cut_slack cannot reach the top keff
   const uint32_t *qslack;        // search_ms.hip: [nq] per-query bound of |sum - dist * s| (units); the cut carries twice that on top of cut_slack
   const float *seg_val;          // search_ms.hip (rows-on-lanes kernel): [nq * nprobes][Q_CAP] the survivors' accumulator values instead of seg_sum;
   const f2 *seg_scale;           //   sum = rint(val * seg_scale[pair].x + seg_scale[pair].y), clamped to 0 .. 65535
+#ifdef LH_TIMING_EXPERIMENTS      // builds with -DLH_TIMING_EXPERIMENTS only (scripts/build_variant.sh): the product library has no such switch
   int dbg;                       // LANCE_HIP_QM_DBG (timing experiments, results WRONG): the kernel returns after 1: the cut, 2: staging the residuals,
                                  // 3: compaction, 4: exact re-evaluation, 5: the sort
+#define QM_DBG_RETURN(a, n) do { if ((a).dbg == (n)) return; } while (0)
+#else
+#define QM_DBG_RETURN(a, n) do { } while (0)
+#endif
   const uint32_t *tbound;        // class per query (0xFFFFFFFF: class B -> pool)
   uint32_t *tglobal;             // class B: running bound of the exact pair kernel
   const uint32_t *seg_cnt, *seg_pos;
@@ -612,11 +532,7 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
 #else
 #define LH_QM_BOUNDS(BS) __launch_bounds__(BS)
 #endif
-// CUTM = 1 (search_q8.hip's 8-bit sums, which are only LOWER bounds -- an entry can saturate below the filter's limit): the cut is
-// taken in two phases.  Phase 0 re-evaluates the survivors up to the histogram bin where the count reaches keff (no slack);
-// the keff-th smallest EXACT distance T' among them bounds the answer from above, and a row with distance <= T' has a sum
-// <= T' * s (+ rounding), so phase 1 re-evaluates the survivors between the two limits and nothing else can matter.
-template <int SD, int MU, int BS, int CUTM = 0>
+template <int SD, int MU, int BS>
 __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
@@ -732,25 +648,8 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
       }
     }
     __syncthreads();
-    if (a.dbg == 1) return;
+    QM_DBG_RETURN(a, 1);
     const uint32_t cut = s_cut;
-    uint32_t range_lo = 0u, range_hi = cut;     // survivors with range_lo <= sum <= range_hi are re-evaluated in this phase
-    for (int phase = 0; phase < (CUTM ? 2 : 1); ++phase) {
-    if constexpr (CUTM != 0) {
-      if (phase == 1) {
-        if (cut == 0xFFFFFFFFu) break;          // uniform: phase 0 had no cut
-        __syncthreads();
-        const bool enough = (int)misc[0] >= o.keff;   // read, barrier, decide
-        __syncthreads();
-        if (enough) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);   // T <- upper bound of the keff-th smallest exact key so far
-        __syncthreads();
-        const float sq = fminf((float)Q8_SE / key_to_float(tb), 1e30f);   // the scan kernel's scale for this query
-        const float lim = key_to_float(misc[1]) * sq * 1.00001f + 1.0f;
-        const uint32_t cut2 = lim < 65535.0f ? (uint32_t)lim : 0xFFFFu;
-        if (cut2 <= cut) break;                 // uniform
-        range_lo = cut + 1u; range_hi = cut2;
-      }
-    }
     // ---- pass B: exact re-evaluation of the survivors under the cut, probe group by probe group
     for (int g0 = 0; g0 < a.nprobes; g0 += a.qm_g) {
       const int ng = min(a.qm_g, a.nprobes - g0);
@@ -787,7 +686,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         }
       }
       __syncthreads();
-      if (a.dbg == 2) return;
+      QM_DBG_RETURN(a, 2);
       // prefix of the segment sizes, kept in LDS (17 registers less per lane: occupancy is what this kernel lives on)
       if (threadIdx.x == 0) {
         uint32_t run = 0;
@@ -811,13 +710,13 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
           const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
           const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a.seg_val[e], s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
                                         : (uint32_t)a.seg_sum[e];
-          if (sv >= range_lo && sv <= range_hi) {
+          if (sv <= cut) {
             const uint32_t slot = atomicAdd(&l_cnt, 1u);
             l_pos[slot] = a.seg_pos[e]; l_rr[slot] = (uint8_t)rr;
           }
         }
         __syncthreads();
-        if (a.dbg == 3) return;
+        QM_DBG_RETURN(a, 3);
         const int nl = (int)l_cnt;
         for (int base = 0; base < nl; base += BS) {
           const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
@@ -867,10 +766,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         }
       }
     }
-    }   // phase
     __syncthreads();
   }
-  if (a.dbg == 4) return;
+  QM_DBG_RETURN(a, 4);
   for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
   __syncthreads();   // also: every lane is done with the staged residuals, the region is reused below
   int c = min((int)misc[0], CAP);
@@ -886,7 +784,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   int Pq = 64;
   while (Pq < c) Pq <<= 1;
   bitonic_sort_kr<BS>(skey, rid, spos, Pq);
-  if (a.dbg == 5) return;
+  QM_DBG_RETURN(a, 5);
   select_and_emit<BS>(o, q, skey, rid, spos, c, &s_amb);
 }
 
@@ -941,12 +839,6 @@ int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, 
 
 template <int SD>
 static bool launch_qscan_sd(lance_hip_ctx *ctx, const QscanArgs &a, int m, unsigned grid, size_t lds) {
-  if constexpr (SD == 8) {
-    if (a.cb_hi) {      // the table on the matrix cores (qscan_mfma_table)
-      if (m == 16) { hipLaunchKernelGGL((ivfpq_qscan_kernel<8, 1, true>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
-      if (m == 32) { hipLaunchKernelGGL((ivfpq_qscan_kernel<8, 2, true>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
-    }
-  }
   if (m == 16) { hipLaunchKernelGGL((ivfpq_qscan_kernel<SD, 1>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
   if (m == 32) { hipLaunchKernelGGL((ivfpq_qscan_kernel<SD, 2>), dim3(grid), dim3(Q_BS), lds, ctx->stream, a); return true; }
   return false;
@@ -957,26 +849,13 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
                  uint32_t *seg_pos, uint32_t *qovf, const uint32_t *allow, const uint32_t *probes) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   const bool pt = probes != nullptr && qscan_pt_enabled(ix);   // per-query tables: no residual pre-pass, no table build in the scan
-  const bool q8 = qscan8_enabled(m, sd);   // items hold 8 queries (qscan_group was called with G = 8): at most npairs / 8 + nlist + 2 of them
-  const uint32_t max_items8 = (uint32_t)((uint64_t)nq * nprobes / 8 + ix->nlist + 2);
-  f4 *rq = pt ? nullptr : reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", q8 ? (size_t)max_items8 * d * 8 : (size_t)max_items4 * d * 4));
+  f4 *rq = pt ? nullptr : reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq", (size_t)max_items4 * d * 4));
   if (!pt && !rq) return LANCE_HIP_ENOMEM;
-  const bool mbt = !pt && !q8 && qscan_mfma_table(ix);
-  f4 *rq_n2 = nullptr;
   {
     ScopedTimer t(ctx, "q_residual");
-    if (pt) {
-    } else if (q8)
-      LH_TRY(qscan8_residual(ctx, qs, pair_idx, item_start4, desc4, ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0,
-                             max_items8, rq));
-    else {
-    if (mbt) {
-      rq_n2 = reinterpret_cast<f4 *>(ctx->scratch_t<float>("qscan.rq_n2", (size_t)max_items4 * 4));
-      if (!rq_n2) return LANCE_HIP_ENOMEM;
-    }
-    hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4,
-                       ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq, rq_n2);
-    }
+    if (!pt)
+      hipLaunchKernelGGL(q_residual_kernel, dim3((unsigned)cdiv(max_items4, 4)), dim3(256), 0, ctx->stream, qs, pair_idx, item_start4, desc4,
+                         ix->centroids, d, (int)ix->nlist, (int)nprobes, ix->dtype == LANCE_HIP_F16 ? 1 : 0, rq);
     LH_CHECK_HIP(lh::memset_async(seg_cnt, 0, (size_t)nq * nprobes * 4, ctx->stream));
     LH_CHECK_HIP(lh::memset_async(qovf, 0, (size_t)nq * 4, ctx->stream));
   }
@@ -986,7 +865,6 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.nprobes = (int)nprobes; a.nlist = (int)ix->nlist; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf; a.allow = allow;
-  if (mbt) { a.cb_hi = ix->cb_hi; a.cb_lo = ix->cb_lo; a.cb_n2 = ix->cb_n2; a.rq_n2 = rq_n2; }
   a.seg_sum = ctx->scratch_t<uint16_t>("q.seg_sum", (size_t)nq * nprobes * Q_CAP);   // the merge launcher asks for the same slot
   a.ovf = ctx->scratch_t<uint32_t>("q.ovf", (size_t)nq * nprobes + 1);                // likewise (and the class-B conversion)
   if (!a.seg_sum || !a.ovf) return LANCE_HIP_ENOMEM;
@@ -1003,7 +881,6 @@ int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
 #endif
   if (pt) { LH_TRY(qscan_pt_launch(ctx, ix, a, qs, nq, probes, grid)); ok = true; }
   else if (qscan_tiled_shape(m, sd)) ok = qscan_tiled_launch(ctx, a, m, sd, grid);
-  else if (q8) ok = qscan8_launch(ctx, a, sd, max_items8);
   else if (sd == 4) ok = launch_qscan_sd<4>(ctx, a, m, grid, lds);
   else if (sd == 8) ok = launch_qscan_sd<8>(ctx, a, m, grid, lds);
   else if (sd == 16) ok = launch_qscan_sd<16>(ctx, a, m, grid, lds);
@@ -1056,40 +933,8 @@ __global__ __launch_bounds__(256) void q_model_finite_kernel(const float *__rest
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
-// MFMA table build (sub-dimension 8): bf16 hi / lo planes of the codebook and the codewords' squared norms
-__global__ __launch_bounds__(256) void q_codebook_planes_kernel(const float *__restrict__ codebook, int64_t nwords, uint16_t *__restrict__ hi,
-                                                                uint16_t *__restrict__ lo, float *__restrict__ n2) {
-  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;      // codeword (m, c)
-  if (w >= nwords) return;
-  float s = 0.0f;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const float v = codebook[w * 8 + u];
-    const uint32_t hb = q_bf16_rne(v);
-    hi[w * 8 + u] = (uint16_t)hb;
-    lo[w * 8 + u] = (uint16_t)q_bf16_rne(v - __uint_as_float(hb << 16));
-    s += v * v;
-  }
-  n2[w] = s;
-}
-
-bool qscan_mfma_table(const lance_hip_index *ix) {
-  // opt-in: parity-green on its first run (gpurun r04e: pm-scan suite, 136 fuzz cases) but SLOWER than the packed-VALU build at
-  // C2 (scan 0.405 vs 0.347 ms per 10k-query batch): eight tiles per wave are a chain of L2 round trips the 44-VALU build does not have
-  static const bool on = getenv("LANCE_HIP_MFMA_TABLE") != nullptr && getenv("LANCE_HIP_MFMA_TABLE")[0] == '1';
-  return on && ix->cb_hi != nullptr && ix->m != 0 && ix->d / ix->m == 8 && (ix->m == 16 || ix->m == 32);
-}
-
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {
   const int d = (int)ix->d, m = (int)ix->m;
-  if (d / m == 8 && (m == 16 || m == 32)) {
-    const int64_t nwords = (int64_t)m * 256;
-    if (!ix->cb_hi) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_hi), (size_t)nwords * 8 * 2));
-    if (!ix->cb_lo) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_lo), (size_t)nwords * 8 * 2));
-    if (!ix->cb_n2) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_n2), (size_t)nwords * 4));
-    hipLaunchKernelGGL(q_codebook_planes_kernel, dim3((unsigned)cdiv((uint64_t)nwords, 256)), dim3(256), 0, ctx->stream, ix->codebook, nwords, ix->cb_hi,
-                       ix->cb_lo, ix->cb_n2);
-  }
   if (!ix->cb_mean) LH_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&ix->cb_mean), (size_t)(d + 2) * 4));
   LH_CHECK_HIP(lh::memset_async(ix->cb_mean, 0, (size_t)(d + 2) * 4, ctx->stream));
   hipLaunchKernelGGL(q_codebook_mean_kernel, dim3((unsigned)m), dim3(256), 0, ctx->stream, ix->codebook, d / m, d, ix->cb_mean);
@@ -1139,12 +984,6 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
   hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, 1024>), dim3(rgrid), dim3(1024), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
   const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
-  if constexpr (MU == 1) {
-    if (a.cut_mode == 1) {   // search_q8.hip's sums
-      hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128, 1>), dim3(nq), dim3(128), lds, ctx->stream, a);
-      return;
-    }
-  }
   if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
   else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
 }
@@ -1156,6 +995,7 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
   a.qslack = qslack; a.seg_val = seg_val; a.seg_scale = reinterpret_cast<const f2 *>(seg_scale);
+#ifdef LH_TIMING_EXPERIMENTS
   {
     static const int dbg = [] {
       const int v = getenv("LANCE_HIP_QM_DBG") ? atoi(getenv("LANCE_HIP_QM_DBG")) : 0;
@@ -1164,6 +1004,7 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     }();
     a.dbg = dbg;
   }
+#endif
   a.q = qs; a.probes = probes; a.centroids = ix->centroids; a.codebook = ix->codebook; a.codes = ix->codes; a.row_ids = ix->row_ids;
   a.d = d; a.nprobes = (int)nprobes; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.tbound = tbound; a.tglobal = tglobal; a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.qovf = qovf;
@@ -1187,16 +1028,10 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
     const bool tiled = qscan_tiled_shape(m, sd);
     a.cut_shift = no_cut ? -1 : (tiled ? 7 : (m == 16 ? 3 : 2));
     a.cut_slack = tiled ? (uint32_t)(2 * m + 8) : (uint32_t)(2 * m + 4);
-    // the MFMA-built table's entries carry up to Q_MB_SLACK_CAP more units per row on either side (ivfpq_qscan_kernel<.., true>)
-    if (!tiled && !qscan8_enabled(m, sd) && qscan_mfma_table(ix)) a.cut_slack += 2u * (uint32_t)Q_MB_SLACK_CAP;
-    a.cut_mode = 0;
-    if (qscan8_enabled(m, sd)) {   // sums 0 .. 379: one bin per value, no slack -- the second phase takes its limit from exact distances
-      a.cut_mode = 1; a.cut_shift = no_cut ? -1 : 0; a.cut_slack = 0;
-    }
     if (qslack) {   // search_ms.hip's sums: rint(dist~ * s) with |dist~ - dist| s <= qslack[q]; LIM ~ 30000 + slack -> bins of 64
       int sh = 0; uint32_t sl = 0;
       mscan_cut_params(&sh, &sl);
-      a.cut_mode = 0; a.cut_shift = no_cut ? -1 : sh; a.cut_slack = sl;
+      a.cut_shift = no_cut ? -1 : sh; a.cut_slack = sl;
     }
   }
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;

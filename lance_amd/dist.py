@@ -31,6 +31,62 @@ from ._rng import Rng, kmeans_init_indices
 FLT_MAX = float(np.finfo(np.float32).max)
 
 
+# ---- collectives ------------------------------------------------------------------------------------------------------------
+# Production: backend "nccl" (= RCCL over xGMI), device tensors, everything ordered on the current stream.  The same host logic must be
+# exercisable where RCCL cannot run -- two ranks sharing ONE GPU (RCCL refuses a duplicate device), or a CPU box: under the gloo backend
+# a device tensor takes the round trip through host memory here (synchronous with the current stream), so every code path above the
+# transport -- sharding, fused buffers, update kernels, list exchange, device merge -- runs on the real kernels at world size > 1
+# (tests/test_zz_gpu_two_ranks.py; `LANCE_BENCH_BACKEND=gloo LANCE_BENCH_ONE_GPU=1 python bench.py --gpus 2`).
+def _host_transport(t, group=None):
+    return isinstance(t, torch.Tensor) and t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, op, group=None):
+    if _host_transport(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return
+    dist.all_reduce(t, op=op, group=group)
+
+
+def _broadcast(t, src, group=None):
+    if _host_transport(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
+def _all_gather(outs, t, group=None):
+    if _host_transport(t, group):
+        hs = [o.cpu() for o in outs]
+        dist.all_gather(hs, t.cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+        return
+    dist.all_gather(outs, t, group=group)
+
+
+def _all_gather_into_tensor(out, t, group=None):
+    if _host_transport(t, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, t.cpu(), group=group)
+        out.copy_(h)
+        return
+    dist.all_gather_into_tensor(out, t, group=group)
+
+
+def _all_to_all_single(out, t, output_split_sizes=None, input_split_sizes=None, group=None):
+    if _host_transport(t, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h, t.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+        out.copy_(h)
+        return
+    dist.all_to_all_single(out, t, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+
+
 def _split_clusters(n, cnts, centroids, rng):
     """split_clusters (kmeans.rs:174-207) on host numpy arrays (f32), shared-seed RNG."""
     f32 = np.float32
@@ -71,7 +127,7 @@ def train_kmeans_sharded(engine, x_local, k, n_total, max_iters=50, tol=1e-4, ba
                 else torch.from_numpy(np.asarray(x_local)[idx.astype(np.int64)])
             cent.copy_(rows)
         if world > 1:
-            dist.broadcast(cent, src=0, group=group)
+            _broadcast(cent, src=0, group=group)
     else:
         cent = torch.as_tensor(init, dtype=torch.float32).to(dev).clone()
     bf_param = f32(balance_factor) / f32(n_total)          # train_kmeans :1344
@@ -91,9 +147,9 @@ def train_kmeans_sharded(engine, x_local, k, n_total, max_iters=50, tol=1e-4, ba
             bias = torch.from_numpy((f32(bf) * sizes.astype(f32)).astype(f32)).to(dev)
         buf, losses, radius = engine.kmeans_estep_partial(x_local, cent, metric, bias)
         if world > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(radius, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(losses, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(radius, op=dist.ReduceOp.MAX, group=group)
         cent = engine.kmeans_finalize(buf, k, d)
         counts = buf[k * d:].cpu().numpy().astype(np.int64)
         lh = losses.cpu().numpy()
@@ -143,9 +199,9 @@ def _train_kmeans_sharded_device(engine, x_local, cent, k, n_total, max_iters, t
         for it in range(1, max_iters + 1):
             twin.kmeans_shard_estep(st, x_local, cent, metric)
             if world > 1:
-                dist.all_reduce(st["buf"], op=dist.ReduceOp.SUM, group=group)
-                dist.all_reduce(st["losses"], op=dist.ReduceOp.SUM, group=group)
-                dist.all_reduce(st["radius"], op=dist.ReduceOp.MAX, group=group)
+                _all_reduce(st["buf"], op=dist.ReduceOp.SUM, group=group)
+                _all_reduce(st["losses"], op=dist.ReduceOp.SUM, group=group)
+                _all_reduce(st["radius"], op=dist.ReduceOp.MAX, group=group)
             twin.kmeans_shard_update(st, cent, n_total, tol, it)
             if it % 8 == 0 or it == max_iters:
                 loss, iters, active = twin.kmeans_shard_end(st)
@@ -173,7 +229,7 @@ def all_gather_blocks(local, total, group=None):
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: hi - lo] = local
     out = torch.empty((per * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    _all_gather_into_tensor(out, pad.contiguous(), group=group)
     if per * world == total:
         return out
     keep = torch.cat([torch.arange(r * per, r * per + (b - a), device=local.device) for r, (a, b) in enumerate(ranges)])
@@ -294,13 +350,13 @@ def all_gather_var(local, group=None):
     world = dist.get_world_size(group)
     nloc = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(nloc) for _ in range(world)]
-    dist.all_gather(counts, nloc, group=group)
+    _all_gather(counts, nloc, group=group)
     counts = [int(c.item()) for c in counts]
     per = max(counts) if counts else 0
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((per * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    _all_gather_into_tensor(out, pad.contiguous(), group=group)
     return torch.cat([out[r * per: r * per + c] for r, c in enumerate(counts)]).contiguous(), counts
 
 
@@ -313,13 +369,13 @@ def exchange_by_owner(owner, tensors, group=None):
     sel = torch.nonzero(keep).reshape(-1)[order]
     send_counts = torch.bincount(owner[keep], minlength=world).to(torch.int64)
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    _all_to_all_single(recv_counts, send_counts, group=group)
     sc, rc = [int(v) for v in send_counts.tolist()], [int(v) for v in recv_counts.tolist()]
     out = []
     for t in tensors:
         src = t[sel].contiguous()
         dst = torch.empty((sum(rc),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        _all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=sc, group=group)
         out.append(dst)
     return out
 
@@ -360,7 +416,7 @@ def create_index_rowsharded(x_local, metric="l2", num_partitions=256, num_sub_ve
     dev = x_local.device
     nl = torch.tensor([n_local], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(nl) for _ in range(world)]
-    dist.all_gather(counts, nl, group=group)
+    _all_gather(counts, nl, group=group)
     counts = [int(c.item()) for c in counts]
     n_total, row0 = sum(counts), sum(counts[:rank])
     stats = lv.BuildStats()
@@ -393,7 +449,7 @@ def create_index_rowsharded(x_local, metric="l2", num_partitions=256, num_sub_ve
             full, _ = all_gather_var(samp, group)
             return eng.kmeans_train(full, num_partitions, max_iters=max_iters, balance_factor=1.0, seed=seed, metric=kmetric)
         nt = torch.tensor([samp.shape[0]], dtype=torch.int64, device=dev)
-        dist.all_reduce(nt, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(nt, op=dist.ReduceOp.SUM, group=group)
         return train_kmeans_sharded(eng, samp, num_partitions, int(nt.item()), max_iters, 1e-4, 1.0, None, seed, kmetric, group)
 
     cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", train_ivf)
@@ -578,7 +634,7 @@ def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group
     gathered = []
     for t in payload:
         buf = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(buf, t, group=group)
+        _all_gather(buf, t, group=group)
         gathered.append(torch.cat(buf, dim=1))
     if engine is not None and gathered[0].shape[1] <= 4096:
         return engine.merge_topk(gathered[0], gathered[1], k, exact=gathered[2] if refine_factor else None, keff=keff)
