@@ -98,7 +98,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--streams", type=int, default=3, help="engine contexts (HIP streams) the query batches alternate on")
-    args = ap.parse_args()
+    # ranks started by this script's own launcher take their arguments from the environment: torchrun's argument parser refuses
+    # `--n` after the script name (an abbreviation of several of ITS options: gpurun r05a)
+    args = ap.parse_args(json.loads(os.environ["LANCE_BENCH_ARGV"])) if "LANCE_BENCH_ARGV" in os.environ else ap.parse_args()
 
     # `python bench.py --gpus N` on its own starts the N ranks itself (one process per GPU under torch.distributed.run, rendezvous
     # on 127.0.0.1); under an external launcher (WORLD_SIZE already set: the driver's own command form) the flag is checked
@@ -111,7 +113,8 @@ def main():
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-port", str(port), os.path.abspath(__file__)]
+        os.environ["LANCE_BENCH_ARGV"] = json.dumps(sys.argv[1:])
         sys.stdout.flush()
         os.execv(sys.executable, cmd)
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:

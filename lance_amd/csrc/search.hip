@@ -1024,9 +1024,14 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   {
     auto so = std::find(ctx->graph_seen_once.begin(), ctx->graph_seen_once.end(), ks);
     if (so == ctx->graph_seen_once.end()) {
-      if (ctx->graph_seen_once.size() < SEEN_ONCE_MAX) ctx->graph_seen_once.push_back(ks);
-      else { ctx->graph_seen_once[ctx->graph_seen_next] = ks; ctx->graph_seen_next = (ctx->graph_seen_next + 1) % SEEN_ONCE_MAX; }
-      return plain();
+      // remembered AFTER the call: a scratch slot that grows during it drops the cache and this FIFO with it -- the call that sized the
+      // arena is the one that counts as "seen once"
+      const int prc = plain();
+      if (prc == LANCE_HIP_OK) {
+        if (ctx->graph_seen_once.size() < SEEN_ONCE_MAX) ctx->graph_seen_once.push_back(ks);
+        else { ctx->graph_seen_once[ctx->graph_seen_next] = ks; ctx->graph_seen_next = (ctx->graph_seen_next + 1) % SEEN_ONCE_MAX; }
+      }
+      return prc;
     }
     so->clear();      // promoted: the slot is reused by the FIFO in its own time
   }

@@ -788,6 +788,279 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   select_and_emit<BS>(o, q, skey, rid, spos, c, &s_amb);
 }
 
+// ---- merge, one residual group (nprobes <= qm_g): fewer dependent memory round trips -------------------------------------------------
+// The kernel above is bound by the number of queries in flight x the length of a query's DEPENDENT chain of memory round trips
+// (gpurun r04zb: 0.166 ms for 10,000 queries at C2, ~40 us per workgroup; the arithmetic is a few thousand lane-operations).  Its chain:
+// flags / bounds -> segment counts -> survivors' sums (histogram) -> [cut] -> counts again -> probes -> centroids (staging) -> sums AND
+// positions again (compaction) -> codes -> 4 x codebook -> row ids: thirteen trips.  Here everything that does not depend on the cut is
+// requested TOGETHER after the one trip that yields the segment counts and the probed partitions: each lane takes its survivors' (value,
+// position) pairs into registers -- four per lane cover 512 survivors, a query has ~250 -- and its share of the residual staging loads
+// right behind them; the histogram, the cut and the compaction then run out of registers and LDS.  Chain: counts / probes -> survivors +
+// residual rows -> codes -> 4 x codebook -> row ids: eight trips.  More than 512 survivors: further chunks are re-read (rare).
+// Same arithmetic, same selection machinery, same outputs as the kernel above (which keeps the batches with more probes than one
+// staging holds).
+template <int SD, int MU, int BS>
+__global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = MU * 16;
+  constexpr int QV = SD / 4;
+  constexpr int CAP = BS == 128 ? 512 : 1024;   // (key, pos) entries under selection
+  static_assert(BS >= SCAN_MAX_KEFF, "tighten_bs selects among one value per lane");
+  __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
+  uint64_t *rid = reinterpret_cast<uint64_t *>(smem);                    // [SCAN_LCAP]  (the dynamic region holds the staged residuals first)
+  uint32_t *skey = reinterpret_cast<uint32_t *>(rid + SCAN_LCAP);        // [SCAN_LCAP]
+  uint32_t *spos = skey + SCAN_LCAP;                                     // [SCAN_LCAP]
+  constexpr int QM_LC = 512;                       // survivors per chunk
+  constexpr int SPL = QM_LC / BS;                  // survivors per lane per chunk (registers)
+  __shared__ uint32_t s_cnt[QM_G], s_part[QM_G];
+  __shared__ f2 s_yz[QM_G];
+  __shared__ int s_amb;
+  __shared__ uint32_t s_hist[512], l_pos[QM_LC], s_cut, l_cnt;
+  __shared__ uint8_t l_rr[QM_LC];
+  const SelectOut &o = a.o;
+  const int q = blockIdx.x;
+  const int np = a.nprobes;                        // <= a.qm_g <= QM_G (launcher)
+  // ---- trip 1: everything a lane can ask for knowing only the query's number
+  const uint32_t qflags = o.flags[q];
+  const uint32_t tb = a.tbound[q];
+  uint32_t c_l = 0, part_l = 0;
+  f2 yz_l = {0.0f, 0.0f};
+  if ((int)threadIdx.x < np) {
+    c_l = a.seg_cnt[(int64_t)q * np + threadIdx.x];
+    part_l = a.probes[(int64_t)q * np + threadIdx.x];
+    if (a.seg_val) yz_l = a.seg_scale[(int64_t)q * np + threadIdx.x];
+  }
+  const uint32_t qov = a.qovf[q];
+  uint32_t tg0 = 0;
+  if (threadIdx.x == 0) tg0 = a.tglobal[q];
+  if (qflags & FLAG_OVERFLOW) return;   // the exact kernel recomputes this query
+  const bool class_a = tb != 0xFFFFFFFFu;
+  if (threadIdx.x == 0) { misc[0] = 0; misc[1] = tg0; misc[3] = 0; s_amb = 0; s_cut = 0xFFFFFFFFu; l_cnt = 0u; }   // class A: the bound (lowered by a rescan, if any)
+  for (int i = threadIdx.x; i < 512; i += BS) s_hist[i] = 0u;
+  if ((int)threadIdx.x < QM_G) {
+    s_cnt[threadIdx.x] = ((int)threadIdx.x < np && c_l <= (uint32_t)Q_CAP) ? c_l : 0u;    // an overflowed segment comes through the pool (rescan kernel)
+    s_part[threadIdx.x] = part_l;
+    s_yz[threadIdx.x] = yz_l;
+  }
+  __syncthreads();
+  CandBuf b{ckey, cpos, &misc[0], &misc[1]};
+  // rows with exact keys already: class B's pool (exact pair kernel) or the rescan of overflowed segments
+  if (!class_a || qov) {
+    const int n = min((int)a.pool_cnt[q], a.pool_cap);
+    const uint32_t *pk = a.pool_key + (int64_t)q * a.pool_cap, *pp = a.pool_pos + (int64_t)q * a.pool_cap;
+    for (int base = 0; base < n; base += BS) {
+      const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
+      __syncthreads();
+      if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+      const uint32_t T = misc[1];
+      const int i = base + threadIdx.x;
+      if (i < n) {
+        const uint32_t kk = pk[i];
+        if (kk <= T) {
+          const uint32_t slot = atomicAdd(&misc[0], 1u);
+          if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = pp[i]; } else misc[3] = 1u;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (class_a) {
+    const int dpad = (a.d + 3) & ~3;
+    float *r = reinterpret_cast<float *>(smem);   // [np][dpad]
+    const float *qv = a.q + (int64_t)q * a.d;
+    // prefix of the segment sizes: every lane folds the <= 16 counts itself (LDS broadcast reads; no barrier, no serial lane)
+    uint32_t total = 0;
+    for (int i = 0; i < np; ++i) total += s_cnt[i];
+    const int nchunks = ((int)total + QM_LC - 1) / QM_LC;
+    uint32_t sv_pos[SPL], sv_sum[SPL];      // this lane's survivors of the chunk in registers: position, integer sum (0xFFFFFFFF: none)
+    uint32_t sv_rr[SPL];
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        const int t = ch * QM_LC + j * BS + (int)threadIdx.x;
+        sv_sum[j] = 0xFFFFFFFFu; sv_pos[j] = 0u; sv_rr[j] = 0u;
+        if (t < (int)total) {
+          int rr = 0, st = 0, run = 0;
+          for (int i = 0; i < np; ++i) {      // s_cnt[] >= 0 and t < total: the last segment whose start is <= t
+            if (t >= run) { rr = i; st = run; }
+            run += (int)s_cnt[i];
+          }
+          const int64_t e = ((int64_t)q * np + rr) * Q_CAP + (t - st);
+          sv_pos[j] = a.seg_pos[e];
+          sv_rr[j] = (uint32_t)rr;
+          sv_sum[j] = a.seg_val ? __float_as_uint(a.seg_val[e]) : (uint32_t)a.seg_sum[e];      // (the value's conversion waits until it is used)
+        }
+      }
+    };
+    // ---- trip 2: the first chunk of survivors and the residual rows, requested together
+    bool have[SPL];
+    auto mark = [&](int ch) {
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) have[j] = ch * QM_LC + j * BS + (int)threadIdx.x < (int)total;
+    };
+    if (nchunks > 0) load_chunk(0);
+    mark(0);
+    if (a.vec4) {
+      const int d4 = a.d >> 2, tot4 = np * d4;
+#pragma unroll 4
+      for (int t = threadIdx.x; t < tot4; t += BS) {
+        const int rr = t / d4, e4 = t - rr * d4;
+        const uint32_t part = s_part[rr];
+        const f4 qq = reinterpret_cast<const f4 *>(qv)[e4];
+        const f4 cc = reinterpret_cast<const f4 *>(a.centroids + (int64_t)part * a.d)[e4];
+        f4 v = qq - cc;      // element-wise IEEE subtraction (v2.rs:316-332)
+        if (a.round_f16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __half2float(__float2half_rn(v[e]));
+        }
+        *reinterpret_cast<f4 *>(&r[rr * dpad + 4 * e4]) = v;
+      }
+    } else {
+      for (int t = threadIdx.x; t < np * a.d; t += BS) {
+        const int rr = t / a.d, e = t - rr * a.d;
+        float v = qv[e] - a.centroids[(int64_t)s_part[rr] * a.d + e];
+        if (a.round_f16) v = __half2float(__float2half_rn(v));
+        r[rr * dpad + e] = v;
+      }
+    }
+    auto to_sums = [&]() {
+      if (a.seg_val) {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+          if (have[j]) {
+            const f2 yz = s_yz[sv_rr[j]];
+            sv_sum[j] = (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(__uint_as_float(sv_sum[j]), yz.x, yz.y)), 0.0f, 65535.0f);
+          }
+      }
+    };
+    // ---- pass A: histogram of the survivors' sums -> cut   (cut_shift < 0: LANCE_HIP_NO_QCUT, every survivor is re-evaluated)
+    if (a.cut_shift >= 0) {
+      for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch > 0) { load_chunk(ch); mark(ch); }
+        to_sums();
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+          if (have[j]) atomicAdd(&s_hist[min(511u, sv_sum[j] >> a.cut_shift)], 1u);
+      }
+    } else if (nchunks > 0) {
+      to_sums();
+    }
+    __syncthreads();      // histogram complete; residuals staged
+    if (a.cut_shift >= 0 && threadIdx.x < 64) {   // first bin where the cumulative count reaches keff
+      const int lane = threadIdx.x;
+      uint32_t loc[8], tot = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { loc[i] = s_hist[lane * 8 + i]; tot += loc[i]; }
+      uint32_t incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t tt = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += tt;
+      }
+      uint32_t run = incl - tot;
+      int found = -1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        run += loc[i];
+        if (found < 0 && run >= (uint32_t)o.keff) found = lane * 8 + i;
+      }
+      const uint64_t mask = __ballot(found >= 0);
+      if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        const int bin = __shfl(found, leader, 64);
+        // bin 511 also holds the sums beyond the histogram's range: no upper edge there -> no cut
+        if (lane == 0 && bin < 511) s_cut = (((uint32_t)bin + 1u) << a.cut_shift) - 1u + a.cut_slack + (a.qslack ? 2u * a.qslack[q] : 0u);
+      }
+    }
+    __syncthreads();
+    QM_DBG_RETURN(a, 1);
+    const uint32_t cut = s_cut;
+    // ---- pass B: compaction under the cut (registers -> LDS), exact re-evaluation
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (nchunks > 1) {      // (one chunk: the registers still hold it)
+        __syncthreads();
+        if (threadIdx.x == 0) l_cnt = 0u;
+        __syncthreads();
+        load_chunk(ch); mark(ch); to_sums();
+      }
+#pragma unroll
+      for (int j = 0; j < SPL; ++j)
+        if (have[j] && sv_sum[j] <= cut) {
+          const uint32_t slot = atomicAdd(&l_cnt, 1u);
+          l_pos[slot] = sv_pos[j]; l_rr[slot] = (uint8_t)sv_rr[j];
+        }
+      __syncthreads();
+      QM_DBG_RETURN(a, 3);
+      const int nl = (int)l_cnt;
+      for (int base = 0; base < nl; base += BS) {
+        const bool need_tighten = (int)misc[0] > CAP - BS;   // read, barrier, decide
+        __syncthreads();
+        if (need_tighten) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+        const uint32_t T = misc[1];
+        const int t = base + threadIdx.x;
+        if (t < nl) {
+          const uint32_t pos = l_pos[t];
+          const int rr = (int)l_rr[t];
+          const uint8_t *rc = a.codes + (int64_t)pos * M;
+          const float *rres = r + rr * dpad;
+          float dist = 0.0f;   // pq/distance.rs:128-141: += table[code] for m = 0..M-1 -- the table entry is recomputed here
+#pragma unroll
+          for (int w = 0; w < MU; ++w) {
+            const uint4 cw = *reinterpret_cast<const uint4 *>(rc + w * 16);
+            const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int hh = 0; hh < 16 / Q_MPF; ++hh) {
+              // the codebook entries of Q_MPF sub-quantisers are requested together (one L2 round trip for all of them)
+              f4 cbv[Q_MPF][QV];
+#pragma unroll
+              for (int t8 = 0; t8 < Q_MPF; ++t8) {
+                const int mi = hh * Q_MPF + t8, mm = w * 16 + mi;
+                const uint32_t code = (cws[mi >> 2] >> (8 * (mi & 3))) & 255u;
+                const f4 *src = reinterpret_cast<const f4 *>(a.codebook + ((int64_t)mm * 256 + code) * SD);
+#pragma unroll
+                for (int u = 0; u < QV; ++u) cbv[t8][u] = src[u];
+              }
+#pragma unroll
+              for (int t8 = 0; t8 < Q_MPF; ++t8) {
+                const int mm = w * 16 + hh * Q_MPF + t8;
+                RegVec<SD> av;
+#pragma unroll
+                for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&rres[mm * SD + 4 * u]);
+                dist += finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
+              }
+            }
+          }
+          const uint32_t kk = order_key(dist);
+          if (kk <= T) {
+            const uint32_t slot = atomicAdd(&misc[0], 1u);
+            if (slot < (uint32_t)CAP) { ckey[slot] = kk; cpos[slot] = pos; } else misc[3] = 1u;   // an entry was lost (ties at the bound)
+          }
+        }
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  QM_DBG_RETURN(a, 4);
+  for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+  __syncthreads();   // also: every lane is done with the staged residuals, the region is reused below
+  int c = min((int)misc[0], CAP);
+  if (c > SCAN_LCAP || misc[3]) {
+    if (threadIdx.x == 0) atomicOr(&o.flags[q], FLAG_OVERFLOW);
+    c = min(c, SCAN_LCAP);
+  }
+  for (int i = threadIdx.x; i < SCAN_LCAP; i += BS) {
+    if (i < c) { skey[i] = ckey[i]; spos[i] = cpos[i]; rid[i] = a.row_ids[cpos[i]]; }
+    else { skey[i] = 0xFFFFFFFFu; spos[i] = 0; rid[i] = ~0ull; }
+  }
+  __syncthreads();
+  int Pq = 64;
+  while (Pq < c) Pq <<= 1;
+  bitonic_sort_kr<BS>(skey, rid, spos, Pq);
+  QM_DBG_RETURN(a, 5);
+  select_and_emit<BS>(o, q, skey, rid, spos, c, &s_amb);
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------
 bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   static const bool off = getenv("LANCE_HIP_NO_QSCAN") != nullptr;
@@ -984,6 +1257,13 @@ static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned n
   hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, 1024>), dim3(rgrid), dim3(1024), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
   const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
+  // one residual group (nprobes <= qm_g <= 16): the kernel with the short dependent chain; LANCE_HIP_QMERGE_V1=1 keeps the general one (A/B)
+  static const bool v1 = getenv("LANCE_HIP_QMERGE_V1") != nullptr;
+  if (!v1 && a.nprobes <= a.qm_g) {
+    if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge1g_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((ivfpq_qmerge1g_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
+    return;
+  }
   if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
   else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
 }

@@ -385,7 +385,9 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["HIP_VISIBLE_DEVICES"] = ""        # also on a GPU box: no device for the ranks
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+    # (`--n`: torchrun's own parser rejects it after the script name as an ambiguous abbreviation -- the ranks take their arguments
+    # from LANCE_BENCH_ARGV; gpurun r05a)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "50000"], env=env,
                        capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode != 0
