@@ -99,7 +99,7 @@ struct MsPrepArgs {
   int d, nprobes, nlist, round_f16;
   float sigma;
   _Float16 *rh;                 // [npairs + 32][d]
-  f4 *prm;                      // [npairs + 32]: {lim sigma^2, s / sigma^2, |r|^2 s, pair (bits)}
+  f4 *prm;                      // [npairs + 32]: {-lim sigma^2, s / sigma^2, |r|^2 s, pair (bits)}
   uint32_t *qslack;             // [nq] max over the query's pairs of ceil(E s) (zeroed before the launch)
   uint32_t *seg_cnt, *qovf, *ovf;
   uint32_t nan_slot;            // index into prm of the NaN-limit record (written here, loaded by the scan for padded pair slots)
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
                   eu <= MS_SLACK_CAP && fabsf(lim * sig2) < INFINITY && n2l * s < 1e30f;
   f4 o;
   if (ok) {
-    o.x = lim * sig2; o.y = s / sig2; o.z = n2l * s;
+    o.x = -(lim * sig2); o.y = s / sig2; o.z = n2l * s;      // MINUS the limit: the scan's accumulator starts from it
     // by pair, for the merge kernel: sum = (accumulator value, which is relative to the limit) * y + (T (1 + 2^-17) + E) s
     p.prm2[pairl] = f2{o.y, (T * 1.0000077f + E) * s};
     atomicMax(&p.qslack[q], (uint32_t)ceilf(eu));
@@ -289,7 +289,7 @@ struct MscanArgs {
   const _Float16 *cbh;          // [m][256][sd] = f16(-2 sigma c)
   const float *row_cn2;         // [n] sigma^2 |c^_row|^2
   const _Float16 *rh;           // [pairs][d]
-  const f4 *prm;                // [pairs] grouped order: {limit sigma^2, -, -, pair}
+  const f4 *prm;                // [pairs] grouped order: {-limit sigma^2, -, -, pair}
   const f2 *prm2;               // [nq * nprobes] by pair (read by the merge kernel; here only passed along)
   uint32_t nan_slot;
   int nlist, nprobes;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
 
       // the f16 reconstruction of the wave's 32 rows as the MFMA's B operand (lane (j, g): row j, k-slice g), |c^|^2 of row j
       ms_h8 rw[KS];
-      float cn2v;
+      float ncn2v;
       {
         const int rowc = min(row0 + j, row_end - 1);
         uint32_t cw[M / 4];
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
 #pragma unroll
           for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
         }
-        cn2v = row0 + j < row_end ? p.row_cn2[(int64_t)U.off + rowc] : INFINITY;      // a padded row never passes
+        ncn2v = row0 + j < row_end ? -p.row_cn2[(int64_t)U.off + rowc] : -INFINITY;      // minus |c^|^2; a padded row never passes (nothing is <= -inf)
         auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -448,8 +448,16 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
         }
       }
       const uint32_t pos_base = U.off + (uint32_t)row0;
+      // The gathers must have landed before the first MFMA anyway: wait for them HERE, once, and hand the registers to the tile loop
+      // through empty asm statements -- which makes them VALU-defined values for the compiler's wait-count pass.  Without this it put
+      // `s_waitcnt vmcnt(8) .. vmcnt(1)` in front of the eight MFMAs of EVERY tile (it cannot prove, inside the loop, that the chunk's
+      // loads are done), and since the counter is in-order those waits also drained the flush's atomics and stores that were meant to
+      // stay in flight across the following tiles (round 5: read off the gfx950 assembly; the r04 stamps had the time in "tiles").
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(rw[s]));
+      asm volatile("" : "+v"(ncn2v));
       if constexpr (PROF) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the gathers have landed: what follows is the tiles' own time
         const long long t = clock64(); pc_gather += t - pct; pct = t;
       }
 
@@ -467,18 +475,24 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
       load_qa(0);
       for (int jb = 0; jb < nblk; ++jb) {
         const int slot = jb * 32 + j;
-        // the accumulator starts at |c^|^2 - limit (row's constant minus the query's limit): the test is a compare with zero and neither
-        // sixteen limits nor a sixteen-register splat of |c^|^2 stay live across the tile (128 VGPRs = four waves per SIMD)
+        // The accumulator starts at MINUS the query's limit, read straight from LDS into the accumulator registers (the pre-pass stores
+        // the limits negated), and the row's |c^|^2 enters at the compare: acc <= -|c^|^2.  Round 4 started it at |c^|^2 - limit and
+        // compared with zero: sixteen v_sub per tile in front of the MFMA chain and, in the generated code, a sixteen-register splat of
+        // |c^|^2 held across the tile loop (the spills).  Same test up to one f32 rounding fewer (the compare itself is exact); the
+        // survivor's value is acc + |c^|^2, formed in the survivor branch.
         ms_f16v acc;
         {
           const f4 *lp = reinterpret_cast<const f4 *>(&sLim[jb * 32 + 4 * g]);
 #pragma unroll
           for (int vq = 0; vq < 4; ++vq) {
             const f4 t = lp[2 * vq];
-            acc[4 * vq] = cn2v - t.x; acc[4 * vq + 1] = cn2v - t.y; acc[4 * vq + 2] = cn2v - t.z; acc[4 * vq + 3] = cn2v - t.w;
+            acc[4 * vq] = t.x; acc[4 * vq + 1] = t.y; acc[4 * vq + 2] = t.z; acc[4 * vq + 3] = t.w;
           }
         }
-        const uint32_t ebase = ((uint32_t)(jb * 32 + 4 * g) << 8) | (uint32_t)j;
+        // (the queue entry's slot / row bits are put together inside the survivor branch from the loop counter and the lane number:
+        // kept in a register across the tile loop the compiler turned them into an induction variable it SPILLED, and the reload -- a
+        // scratch load -- put an `s_waitcnt vmcnt(0)` into every survivor branch, i.e. each first survivor after a flush waited for
+        // the flush's atomics to come back)
         // room for a tile's usual yield; a burst beyond the queue is handled after the tile
         if (qn > (uint32_t)(MS_QH - 32)) {      // room for a tile's usual yield (6-7 survivors at C2); a burst beyond the half is handled after the tile
           if constexpr (PROF) { const long long t = clock64(); pc_tiles += t - pct; pct = t; }
@@ -493,15 +507,19 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         uint64_t mk[16];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= 0.0f);
+        for (int v = 0; v < 16; ++v) mk[v] = __ballot(acc[v] <= ncn2v);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           if (mk[v]) {
             const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
                                      (uint32_t)MS_QH);      // entry MS_QH: the bin of a burst
-            if (acc[v] <= 0.0f)      // (the same compare: the compiler reuses its lane mask as the exec mask)
-              qw[cur + idx] = make_uint2(ebase + ((uint32_t)((v & 3) + 8 * (v >> 2)) << 8), __float_as_uint(acc[v]));
+            if (acc[v] <= ncn2v) {     // (the same compare: the compiler reuses its lane mask as the exec mask)
+              uint32_t ln;            // lane number, recomputed here (two VALU operations, no register held across the loop)
+              asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+              const uint32_t ebase = ((uint32_t)jb << 13) + (((ln >> 5) << 10) | (ln & 31u));      // ((jb * 32 + 4 g) << 8) | j
+              qw[cur + idx] = make_uint2(ebase + ((uint32_t)((v & 3) + 8 * (v >> 2)) << 8), __float_as_uint(acc[v] - ncn2v));
+            }
             qraw += (uint32_t)__popcll(mk[v]);
           }
         }

@@ -10,10 +10,11 @@ codewords concatenated):
     cbh           = binary16(-2 sigma c)                  rh  = binary16(sigma r)                  (per index / per pair)
     cn2           = f32(sigma^2 * sum_m |c_m(code_m)|^2)  (sequential f32 sum of per-codeword f32 norms, as ms_row_norm_kernel)
     lim           = f32((T (1 + 2^-17) + E) - |r|^2) * sigma^2                                     (ms_prep_kernel)
-    acc           = f32(cn2 - lim) + sum_k binary16 x binary16 products accumulated in f32        (the MFMA; any accumulation order)
-    pass         <=>  acc <= 0
+    acc           = f32(-lim) + sum_k binary16 x binary16 products accumulated in f32              (the MFMA; any accumulation order)
+    pass         <=>  acc <= -cn2        (round 5; round 4 started the accumulator at f32(cn2 - lim) and compared with zero)
+    val           = f32(acc + cn2)       (the survivor's value: relative to the limit)
     E             = 1.05 [2^-9 1.02 |r| (|r| + sqrt T) + 2^-13 (|r|^2 + T)] + E_abs               (the header's slack)
-    S             = clamp(rint(acc * (s / sigma^2) + (T (1 + 2^-17) + E) s), 0, 65535),  s = 30000 / T    (the merge kernel's sum)
+    S             = clamp(rint(val * (s / sigma^2) + (T (1 + 2^-17) + E) s), 0, 65535),  s = 30000 / T    (the merge kernel's sum)
 
 Checked: (i) SOUNDNESS -- every row with dist_ref <= T passes; (ii) the sum of every passing row satisfies |S - dist_ref * s| <= the
 per-pair slack units ceil(E s 1.1 + 3) the merge kernel's cut carries; (iii) selectivity -- survivors per row with dist_ref <= T.
@@ -151,10 +152,11 @@ def run(name, x, q, m, nlist, keff=100, nprobes=4, max_pairs=200, seed=0, verbos
                 tot["handed"] += 1
                 continue
             dref = ref_adc(ref_lut(r, cb, m, d), codes[rows])
-            init = (row_cn2[rows] - lim_s).astype(f32)
+            init = np.full(len(rows), -lim_s, f32)
             for order in ("seq", "tree"):
-                acc = mfma_acc(init, rows_h[rows], rh, order)
-                passed = acc <= 0
+                acc0 = mfma_acc(init, rows_h[rows], rh, order)
+                passed = acc0 <= -row_cn2[rows]
+                acc = (acc0 + row_cn2[rows]).astype(f32)      # the survivor's value (and, for the margin statistic, the distance to the limit)
                 must = dref <= T
                 tot["violations"] += int(np.sum(must & ~passed))
                 if order == "seq":
