@@ -795,6 +795,93 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
   }
 }
 
+// refine, f32 rows of d % 16 == 0 elements under L2 / dot: TWO lanes per candidate, the whole row in flight.
+// The kernel above walks a row with one lane in a ROLLED loop of 16-element chunks: eight dependent memory round trips of 64 bytes per
+// candidate at d = 128 (read off the gfx950 assembly: `global_load_dwordx4 x4 -> s_waitcnt vmcnt(3..0) -> loop`), i.e. the kernel was bound
+// by HBM LATENCY x workgroups in flight (0.114 ms per 10,000 x 100 candidates = 512 MB at C2), not by bandwidth.  Here lane h of a pair owns
+// the lane accumulators 8h .. 8h+7 of l2_scalar / dot_scalar (l2.rs:57-91, dot.rs:52-89: accumulator i takes the elements = i mod 16), i.e.
+// the two 16-byte halves [8h, 8h+8) of every 64-byte chunk, and requests all of them -- up to 8 chunks = 16 loads per lane -- before it
+// consumes any: one round trip per 128 elements, 32 bytes contiguous per lane, 64 per pair.  Same arithmetic: per accumulator the chunks
+// arrive in ascending order (mul, then add: -ffp-contract=off), the final fold is the reference's ((0 + s0) + s1) + ... + s15, done by lane 0
+// of the pair after one xor-shuffle per accumulator; d % 16 == 0, so the scalar tail is the +0.0 the reference adds too.
+template <int METRIC>
+__global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restrict__ q, int d, const float *__restrict__ raw, uint64_t n_raw,
+                                                          const uint64_t *__restrict__ cand_rid, const uint32_t *__restrict__ cand_cnt, int keff,
+                                                          int k, int P, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
+                                                          uint32_t *__restrict__ flags) {
+  static_assert(METRIC == METRIC_L2 || METRIC == METRIC_DOT, "squared L2 / dot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
+  uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
+  uint32_t *pos = key + P;
+  f4 *qs4 = reinterpret_cast<f4 *>(pos + P);      // [d / 4] the query
+  const int qi = blockIdx.x;
+  const int c = (int)cand_cnt[qi];
+  const f4 *qv4 = reinterpret_cast<const f4 *>(q + (int64_t)qi * d);
+  for (int e = threadIdx.x; e < d / 4; e += 256) qs4[e] = qv4[e];
+  __syncthreads();
+  const int h = threadIdx.x & 1, slot = threadIdx.x >> 1;   // 128 candidates per round
+  const int nchunk = d >> 4;
+  for (int i0 = 0; i0 < P; i0 += 128) {
+    const int i = i0 + slot;
+    uint64_t r = ~0ull;
+    if (i < c) {
+      r = cand_rid[(int64_t)qi * keff + i];
+      if (r >= n_raw && h == 0) atomicOr(&flags[qi], FLAG_BADROW);   // stored row id beyond the raw vectors handed to set_raw: reported, not ranked
+    }
+    const bool ok = i < c && r < n_raw;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    if (ok) {
+      const f4 *yp = reinterpret_cast<const f4 *>(raw + r * d) + 2 * h;
+      const f4 *xp = qs4 + 2 * h;
+      for (int c0 = 0; c0 < nchunk; c0 += 8) {
+        f4 y[8][2];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < nchunk) { y[cc][0] = yp[(c0 + cc) * 4]; y[cc][1] = yp[(c0 + cc) * 4 + 1]; }
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < nchunk) {
+            const f4 x0 = xp[(c0 + cc) * 4], x1 = xp[(c0 + cc) * 4 + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (METRIC == METRIC_DOT) {
+                acc[e] += x0[e] * y[cc][0][e];
+                acc[4 + e] += x1[e] * y[cc][1][e];
+              } else {
+                const float d0 = x0[e] - y[cc][0][e], d1 = x1[e] - y[cc][1][e];
+                acc[e] += d0 * d0;
+                acc[4 + e] += d1 * d1;
+              }
+            }
+          }
+      }
+    }
+    float oth[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oth[e] = __shfl_xor(acc[e], 1, 64);
+    if (h == 0 && i < P) {
+      float tot = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tot = tot + acc[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tot = tot + oth[e];
+      tot = 0.0f + tot;      // `s + tot` of dist_exact_rt with an empty scalar tail
+      key[i] = ok ? order_key(finish_metric<METRIC>(tot)) : 0xFFFFFFFFu;
+      rid[i] = r; pos[i] = 0;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_kr(key, rid, pos, P);
+  const int got = min(c, k);
+  for (int i = threadIdx.x; i < k; i += 256) {
+    out_ids[(int64_t)qi * k + i] = i < got ? rid[i] : ~0ull;
+    out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(key[i]) : INFINITY;
+  }
+}
+
 
 // ------------------------------------------------------------------------------------
 // Exact fallback: one wave per FLAGGED query re-runs the query the way the reference
@@ -1257,12 +1344,24 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
       hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256),
                          (size_t)P * 16 + (refine_wide_rows(d) ? (size_t)d * 4 : 0), ctx->stream, q, d, rawf, ix->n_raw,
                          cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->metric == LANCE_HIP_DOT)
-      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else
-      hipLaunchKernelGGL((refine_kernel<METRIC_L2, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+    else {
+      // f32 rows of whole 16-element chunks, 16-byte aligned: two lanes per candidate with the row in flight (LANCE_HIP_REFINE_V1=1: A/B)
+      static const bool v1 = getenv("LANCE_HIP_REFINE_V1") != nullptr;
+      const bool pair = !v1 && (d & 15) == 0 && ((reinterpret_cast<uintptr_t>(rawf) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+      const size_t lds_pair = (size_t)P * 16 + (size_t)d * 4;
+      if (pair && ix->metric == LANCE_HIP_DOT)
+        hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
+                           (int)keff, (int)k, P, ids, dists, flags);
+      else if (pair)
+        hipLaunchKernelGGL((refine_pair_kernel<METRIC_L2>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
+                           (int)keff, (int)k, P, ids, dists, flags);
+      else if (ix->metric == LANCE_HIP_DOT)
+        hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
+                           cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+      else
+        hipLaunchKernelGGL((refine_kernel<METRIC_L2, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
+                           cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+    }
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;

@@ -87,12 +87,13 @@ def _changed_contents(idx, oidx, x, d, dev, graphs_on):
         assert (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), ("range", rep)
         done += 1
     if graphs_on:
-        assert replays() - r0 >= 3, f"range searches: {replays() - r0} replays"
+        assert replays() - r0 >= 2, f"range searches: {replays() - r0} replays"
     # A caller that never repeats a call (fresh output buffers, kept alive so that the allocator cannot hand an address out twice) must
     # neither create graph entries nor push the steady-state graph out of the cache (the cache used to be dropped wholesale).
     captures = lambda: eng.timing_query("count:graph_capture")[1]
     qbuf.copy_(hq[0]); torch.cuda.synchronize()
-    idx.search_device(qbuf, k, nprobes, rf, out=out)      # the steady-state key: replayed since the first loop above
+    for _ in range(3):      # the steady-state key (the filtered / range loops above may have grown a scratch slot, which drops every graph:
+        idx.search_device(qbuf, k, nprobes, rf, out=out)      # plain, capture, replay bring it back)
     c0, r0 = captures(), replays()
     keep_alive = []
     qsmall = qbuf[:40]
