@@ -1042,6 +1042,34 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
     __syncthreads();
   }
   QM_DBG_RETURN(a, 4);
+  if (o.refine) {
+    // Refine follows: it ranks the candidates by their exact distances, so all it needs from here is the SET of the keff best by
+    // (key, row id), in any order.  Once at most one entry per lane is left, tighten_bs returns the exact keff-th smallest key and keeps
+    // key <= it: if exactly keff entries remain (no tie across the boundary) they ARE that set -- no (key, rowid) sort of up to 256
+    // entries through LDS (36 barrier-separated passes: 0.034 of this kernel's 0.117 ms at C2, gpurun r04zb), no tie check.  A tie across
+    // the boundary, a lost entry, or more entries than lanes after the tightening rounds take the sort below as before.
+    for (int iter = 0; iter < 8; ++iter) {
+      __syncthreads();
+      const bool more = (int)misc[0] > BS;      // read, barrier (inside tighten_bs), decide
+      if (!more) break;      // uniform
+      tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
+    }
+    __syncthreads();
+    int c1 = (int)misc[0];
+    const bool lost = misc[3] != 0u;
+    __syncthreads();
+    if (!lost && c1 <= BS) {
+      if (c1 >= o.keff) {
+        tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);      // c1 <= BS: exact threshold, entries with key <= it kept (compacted)
+        c1 = (int)misc[0];
+      }
+      if (c1 <= o.keff) {      // uniform
+        for (int i = threadIdx.x; i < o.keff; i += BS) o.cand_rid[(int64_t)q * o.keff + i] = i < c1 ? a.row_ids[cpos[i]] : ~0ull;
+        if (threadIdx.x == 0) o.cand_cnt[q] = (uint32_t)c1;
+        return;
+      }
+    }
+  }
   for (int iter = 0; iter < 8 && (int)misc[0] > SCAN_LCAP; ++iter) tighten_bs<BS, CAP>(b, o.keff, sorted, &misc[2]);
   __syncthreads();   // also: every lane is done with the staged residuals, the region is reused below
   int c = min((int)misc[0], CAP);
