@@ -383,7 +383,11 @@ static void ma_launch_one(lance_hip_ctx *ctx, const MaArgs &a) {
   const size_t lds_x = (size_t)MA_ROWS * (D + 4) * 4;
   const size_t lds_c = (size_t)2 * 2 * MA_CT * (D + 8) * 2 + (size_t)2 * 2 * MA_CT * 4;
   const size_t lds = std::max(lds_x, lds_c);
-  hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC, TX>), dim3((unsigned)cdiv(a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+  {
+    ScopedTimer t(ctx, "ma_sweep");      // the MFMA sweep alone (bench.py: roofline_build.estep_ivf is this kernel's time, by HIP events)
+    hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC, TX>), dim3((unsigned)cdiv(a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+  }
+  ScopedTimer t2(ctx, "ma_recheck");       // exact re-check of the candidates inside the margin + rows recomputed against all centroids
   hipLaunchKernelGGL((ma_finalize_kernel<D, METRIC, TX, LANES>), dim3((unsigned)cdiv(a.n, 256)), dim3(256), 0, ctx->stream, a);
   hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX, LANES>), dim3(512), dim3(256), (size_t)4 * D * 4, ctx->stream, a);
 }

@@ -285,8 +285,6 @@ struct MscanArgs {
   const MsSlice *slices;
   const uint32_t *slice_start;  // [nlist + 1]: slice_start[nlist] = number of slices
   uint32_t *slice_ctr;          // [1] next slice (zeroed by ms_slice_table_kernel)
-  uint32_t *chunk_ctr;          // [slices, taken order] next 32-row chunk of the slice (zeroed per launch): the slice's owner AND helpers draw from it
-  int help_min;                 // a workgroup without a slice of its own joins the slice with the most chunks left, from this many (0: never)
   const uint8_t *codes;
   const _Float16 *cbh;          // [m][256][sd] = f16(-2 sigma c)
   const float *row_cn2;         // [n] sigma^2 |c^_row|^2
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   __shared__ __attribute__((aligned(16))) float sLim[MS3_PB];
   __shared__ __attribute__((aligned(16))) uint32_t sPair[MS3_PB];
   __shared__ __attribute__((aligned(8))) uint2 sQ[16][2][MS_QH + 1];      // per wave: two halves (fill one while the other's atomics are in flight)
-  __shared__ uint32_t s_slice, s_best_rem, s_best_idx;
+  __shared__ uint32_t s_slice, s_chunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
   const uint32_t nslices = p.slice_start[p.nlist];
@@ -378,39 +376,11 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   };
 
   for (;;) {
-    __syncthreads();      // every wave is done with the previous slice's block (and with s_slice)
-    if (threadIdx.x == 0) { s_slice = atomicAdd(p.slice_ctr, 1u); s_best_rem = 0u; s_best_idx = 0xFFFFFFFFu; }
+    __syncthreads();      // every wave is done with the previous slice's block (and with s_slice / s_chunk)
+    if (threadIdx.x == 0) { s_slice = atomicAdd(p.slice_ctr, 1u); s_chunk = 0u; }
     __syncthreads();
-    uint32_t slice = s_slice;
-    if (slice >= nslices) {
-      // No slice of its own left: HELP.  Slice durations are far from proportional to rows x pairs (survivor-dense slices run 5-7 x
-      // longer per cell, gpurun r04zh) and there are only ~3 slices per workgroup, so largest-first still left a wave's mean life at
-      // 0.56 of the longest -- 44 % of the kernel was workgroups waiting for the last slices.  The chunks of a slice are drawn from a
-      // counter in global memory; a workgroup that has run out of slices takes the slice with the most chunks left, stages its pair block
-      // like an owner (one DMA: the price of joining) and draws chunks beside it.  Survivors go through the global segment atomics as
-      // always, so nothing else is shared.  Every lane looks at one slice's counter; the workgroup leaves when no slice has `help_min`
-      // chunks left.
-      if (p.help_min <= 0) break;
-      uint32_t my_rem = 0;
-      for (uint32_t t = threadIdx.x; t < nslices; t += 1024u) {
-        const uint32_t nch = (p.slices[p.order[t]].row_count + 31u) >> 5;
-        const uint32_t done = __hip_atomic_load(&p.chunk_ctr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t rem = done < nch ? nch - done : 0u;
-        if (rem >= (uint32_t)p.help_min && rem > my_rem) my_rem = rem;
-      }
-      if (my_rem) atomicMax(&s_best_rem, my_rem);
-      __syncthreads();
-      const uint32_t best = s_best_rem;
-      if (best == 0u) break;      // uniform
-      for (uint32_t t = threadIdx.x; t < nslices; t += 1024u) {      // (the counters have moved on: any slice that still has `best` or more will do)
-        const uint32_t nch = (p.slices[p.order[t]].row_count + 31u) >> 5;
-        const uint32_t done = __hip_atomic_load(&p.chunk_ctr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done < nch && nch - done >= (uint32_t)p.help_min && nch - done + 1u >= best) atomicMin(&s_best_idx, t);
-      }
-      __syncthreads();
-      slice = s_best_idx;
-      if (slice >= nslices) continue;      // uniform: drained in the meantime -- look again (the loop's barrier protects the LDS words)
-    }
+    const uint32_t slice = s_slice;
+    if (slice >= nslices) break;
     long long pc_slice0 = 0;
     if constexpr (PROF) pc_slice0 = clock64();
     const MsSlice U = p.slices[p.order[slice]];
@@ -441,14 +411,11 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
     const int nblk = nslots >> 5;
     const int row_end = (int)(U.row_begin + U.row_count);      // <= np
 
-    // chunks are drawn from the slice's global counter, one draw AHEAD: the atomic's round trip (~1-2 us device scope) runs under the
-    // previous chunk's tiles.  (Every wave over-draws once at the end: the counter may pass nchunks, which only means "none left".)
-    uint32_t c_ahead = 0;
-    if (lane == 0) c_ahead = atomicAdd(&p.chunk_ctr[slice], 1u);
     for (;;) {
-      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_ahead);
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(&s_chunk, 1u);
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
       if (c >= nchunks) break;
-      if (lane == 0) c_ahead = atomicAdd(&p.chunk_ctr[slice], 1u);
       const int row0 = (int)(U.row_begin + c * 32u);
 
       // the f16 reconstruction of the wave's 32 rows as the MFMA's B operand (lane (j, g): row j, k-slice g), |c^|^2 of row j
@@ -685,10 +652,9 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2 + 32);      // [nlist + 1], the work counter, 32 class cursors
   MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
   uint32_t *order = ctx->scratch_t<uint32_t>("ms.order", cap);
-  uint32_t *chunk_ctr = ctx->scratch_t<uint32_t>("ms.chunk_ctr", cap);
   float *seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
   uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // the merge launcher asks for the same slot
-  if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !chunk_ctr || !seg_val || !ovf) return LANCE_HIP_ENOMEM;
+  if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !seg_val || !ovf) return LANCE_HIP_ENOMEM;
   uint32_t *slice_ctr = slice_start + nlist + 1, *cls_cursor = slice_ctr + 1;
   const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
   {
@@ -697,7 +663,6 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     LH_CHECK_HIP(lh::memset_async(qovf, 0, (size_t)nq * 4, ctx->stream));
     LH_CHECK_HIP(lh::memset_async(qslack, 0, (size_t)nq * 4, ctx->stream));
     LH_CHECK_HIP(lh::memset_async(ovf, 0, 4, ctx->stream));
-    LH_CHECK_HIP(lh::memset_async(chunk_ctr, 0, (size_t)cap * 4, ctx->stream));
     MsPrepArgs pa;
     pa.q = qs; pa.centroids = ix->centroids; pa.pair_idx = pair_idx; pa.pair_starts = pair_starts; pa.probes = probes; pa.tbound = tbound;
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
@@ -715,10 +680,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   ScopedTimer t(ctx, "ivfpq_scan_c1");
   ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
   MscanArgs a;
-  a.order = order; a.slices = slices; a.slice_start = slice_start; a.slice_ctr = slice_ctr; a.chunk_ctr = chunk_ctr; a.codes = ix->codes;
-  // LANCE_HIP_MS_HELP: chunks a slice must have left for an idle workgroup to join it (default 8 = half a chunk per wave; 0: nobody helps)
-  static const int help_min = getenv("LANCE_HIP_MS_HELP") ? std::max(0, atoi(getenv("LANCE_HIP_MS_HELP"))) : 8;
-  a.help_min = help_min;
+  a.order = order; a.slices = slices; a.slice_start = slice_start; a.slice_ctr = slice_ctr; a.codes = ix->codes;
   a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm; a.prm2 = prm2;
   a.nan_slot = nan_slot; a.nlist = nlist; a.nprobes = (int)nprobes;
   a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
