@@ -597,14 +597,18 @@ def main():
         ms_, n_ = kt[name]
         return ms_ / max(n_, 1)
     keff_b = args.k * max(args.refine, 1)
-    refine_bytes = float(args.nq) * keff_b * d * (2 if half else 4)
+    refine_u8 = eng.timing_query("count:refine_u8")[1] > 0      # the index kept a lossless u8 copy of the integer-valued f32 column (index.h raw_u8)
+    refine_bytes = float(args.nq) * keff_b * d * (1 if refine_u8 else 2 if half else 4)
+    result["refine_source"] = ("lossless u8 copy of the f32 raw column (every element is an integer in [0, 255], checked on the bits when the index was "
+                               "built; same f32 values after widening, same arithmetic): 1 byte per element" if refine_u8 else
+                               "the caller's raw column, " + ("2" if half else "4") + " bytes per element")
     near_bytes = float(np.mean([scan_bytes[i % 4] - scan_bytes_c1[i % 4] for i in range(args.steps)]))      # n_p * M over the (query, nearest partition) pairs
     rt = {}
     if per_launch("refine") > 0:
         r_ms = per_launch("refine")
         rt["refine_kernel"] = {"bound": "hbm", "algorithmic_bytes": refine_bytes, "avg_launch_ms": r_ms, "achieved": refine_bytes / (r_ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": refine_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "what": f"{args.nq} x {keff_b} candidate rows of {d} elements read at random from the raw column (two lanes per row, whole row in flight)"}
+                               "what": f"{args.nq} x {keff_b} candidate rows of {d} elements read at random from the refine source (two lanes per row, whole row in flight)"}
     if per_launch("ivfpq_scan_c0") > 0:
         b_ms = per_launch("ivfpq_scan_c0")
         g_ = near_bytes / 4.0

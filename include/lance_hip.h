@@ -223,6 +223,11 @@ void lance_hip_index_destroy(lance_hip_index *idx);
 /* Optional raw vectors for refine (scanner.rs:2884-2904 `take` + flat_knn): x[n_raw][d],
  * indexed by row id (row id r -> x[r]); borrowed, must outlive the index.             */
 int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw);
+/* Index::prewarm (rust/lance/src/index/vector/ivf/v2.rs:349-352, python dataset.py:2991 prewarm_index): builds NOW, on ctx's
+ * stream, the per-index search constants the first search would otherwise build (the matrix-core scan's f16 codebook and row norms;
+ * the lossless u8 refine copy of an integer-valued f32 raw column).  Optional: results never depend on it, only the first search's
+ * latency does.  Synchronises the stream.                                                                                        */
+int lance_hip_index_prewarm(lance_hip_ctx *ctx, lance_hip_index *idx);
 int lance_hip_index_info(const lance_hip_index *idx, uint64_t *n_rows, uint32_t *nlist, uint32_t *m, uint32_t *d);
 /* Copies out the storage layout (host pointers, any may be NULL): part_offsets[nlist+1],
  * codes transposed per partition (the reference layout), row ids in partition order. */

@@ -27,7 +27,7 @@ SYMBOLS = [
     "lance_hip_kmeans_shard_end", "lance_hip_kmeans_init_indices",
     "lance_hip_kmeans_finalize", "lance_hip_pq_train", "lance_hip_residual", "lance_hip_pq_encode",
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
-    "lance_hip_index_set_raw", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
+    "lance_hip_index_set_raw", "lance_hip_index_prewarm", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
     "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_ivfpq_search_range",
     "lance_hip_search_stats", "lance_hip_ivfpq_search_filtered", "lance_hip_ivfpq_search_filtered_range",
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search", "lance_hip_ivfflat_search_filtered",
@@ -112,6 +112,7 @@ def load():
                                                C.POINTER(vp)]),
         "lance_hip_index_destroy": (None, [vp]),
         "lance_hip_index_set_raw": (i32, [vp, vp, u64]),
+        "lance_hip_index_prewarm": (i32, [vp, vp]),
         "lance_hip_index_info": (i32, [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "lance_hip_index_export": (i32, [vp, vp, vp, vp, vp]),
         "lance_hip_find_partitions": (i32, [vp, i32, i32, vp, u32, u32, vp, u32, u32, vp, vp]),

@@ -274,6 +274,7 @@ lance_hip_index::~lance_hip_index() {
   if (row_ids) (void)hipFree(row_ids);
   if (vectors) (void)hipFree(vectors);
   if (flat_items) (void)hipFree(flat_items);
+  if (raw_u8) (void)hipFree(raw_u8);
 }
 
 extern "C" {
@@ -528,8 +529,15 @@ void lance_hip_index_destroy(lance_hip_index *idx) { delete idx; }
 
 int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw) {
   LH_REQUIRE(idx, "index is NULL");
+  std::lock_guard<std::mutex> lk(idx->lazy_mu);
   idx->raw = x;   // element type = the index's dtype
   idx->n_raw = n_raw;
+  if (idx->raw_u8) {   // the compact refine copy belonged to the previous column (searches of this index must have finished: the caller swaps its data)
+    (void)hipSetDevice(idx->device);
+    (void)hipFree(idx->raw_u8);
+    idx->raw_u8 = nullptr;
+  }
+  idx->raw_compact_state = 0;
   return LANCE_HIP_OK;
 }
 

@@ -55,6 +55,12 @@ struct lance_hip_index {
   float *vectors = nullptr;       // IVF_FLAT only (m == 0): [n][d] f32 vectors in the same order (flat/storage.rs FlatFloatStorage)
   const void *raw = nullptr;      // borrowed raw vectors (dtype elements) for refine, indexed by row id
   uint64_t n_raw = 0;
+  // Refine source (search.hip, raw_compact_prepare): when EVERY element of an f32 raw column is an integer in [0, 255] (SIFT descriptors
+  // are: u8 values stored as f32) the engine keeps a lossless u8 copy [n_raw][d] and the refine kernel reads that -- a quarter of the
+  // bytes of the random row reads that bound it, the same f32 values after widening, hence the same bits out.  Created by the first
+  // refining search of the index or by lance_hip_index_prewarm; dropped by lance_hip_index_set_raw.  Guarded by lazy_mu.
+  uint8_t *raw_u8 = nullptr;
+  int raw_compact_state = 0;      // 0: not tried yet; 1: raw_u8 holds the column; -1: the column is not representable (or no memory for the copy)
   uint32_t max_part = 0;
   uint32_t code_bytes() const { return nbits == 4 ? m / 2 : m; }   // bytes of PQ code per row
   ~lance_hip_index();

@@ -804,8 +804,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
 // consumes any: one round trip per 128 elements, 32 bytes contiguous per lane, 64 per pair.  Same arithmetic: per accumulator the chunks
 // arrive in ascending order (mul, then add: -ffp-contract=off), the final fold is the reference's ((0 + s0) + s1) + ... + s15, done by lane 0
 // of the pair after one xor-shuffle per accumulator; d % 16 == 0, so the scalar tail is the +0.0 the reference adds too.
-template <int METRIC>
-__global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restrict__ q, int d, const float *__restrict__ raw, uint64_t n_raw,
+// TR = uint8_t: the index's lossless u8 copy of an integer-valued f32 column (index.h raw_u8): lane h reads the 8 bytes [8h, 8h+8) of every
+// 16-byte chunk, widens them (v_cvt_f32_ubyte*: exact) and runs the SAME arithmetic on the same f32 values -- a quarter of the row bytes.
+template <int METRIC, typename TR = float>
+__global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw, uint64_t n_raw,
                                                           const uint64_t *__restrict__ cand_rid, const uint32_t *__restrict__ cand_cnt, int keff,
                                                           int k, int P, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
                                                           uint32_t *__restrict__ flags) {
@@ -834,13 +836,30 @@ __global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
     if (ok) {
-      const f4 *yp = reinterpret_cast<const f4 *>(raw + r * d) + 2 * h;
       const f4 *xp = qs4 + 2 * h;
       for (int c0 = 0; c0 < nchunk; c0 += 8) {
         f4 y[8][2];
+        if constexpr (sizeof(TR) == 1) {
+          const uint2 *yp = reinterpret_cast<const uint2 *>(raw + r * d) + h;
+          uint2 yb[8];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-          if (c0 + cc < nchunk) { y[cc][0] = yp[(c0 + cc) * 4]; y[cc][1] = yp[(c0 + cc) * 4 + 1]; }
+          for (int cc = 0; cc < 8; ++cc)
+            if (c0 + cc < nchunk) yb[cc] = yp[(c0 + cc) * 2];
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc)
+            if (c0 + cc < nchunk) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                y[cc][0][e] = (float)((yb[cc].x >> (8 * e)) & 255u);
+                y[cc][1][e] = (float)((yb[cc].y >> (8 * e)) & 255u);
+              }
+            }
+        } else {
+          const f4 *yp = reinterpret_cast<const f4 *>(raw + r * d) + 2 * h;
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc)
+            if (c0 + cc < nchunk) { y[cc][0] = yp[(c0 + cc) * 4]; y[cc][1] = yp[(c0 + cc) * 4 + 1]; }
+        }
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc)
           if (c0 + cc < nchunk) {
@@ -880,6 +899,72 @@ __global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restric
     out_ids[(int64_t)qi * k + i] = i < got ? rid[i] : ~0ull;
     out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(key[i]) : INFINITY;
   }
+}
+
+// ---- the lossless u8 refine source (index.h: raw_u8) ---------------------------------------------------------------------------------
+// One pass over the f32 column: 16 elements per lane -> 16 bytes, and a flag if ANY element is not bit-for-bit the widening of its byte
+// (a fraction, a value outside [0, 255], -0.0, NaN).  The flag decides whether the copy is kept: the test is on the bits, so "lossless"
+// means the refine kernel sees exactly the f32 values of the caller's column.
+__global__ __launch_bounds__(256) void raw_to_u8_kernel(const f4 *__restrict__ x, int64_t n16, uint4 *__restrict__ out, uint32_t *__restrict__ bad) {
+  bool ok = true;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    uint32_t w[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const f4 v = x[i * 4 + p];
+      uint32_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t b = (v[e] >= 0.0f && v[e] < 256.0f) ? (uint32_t)v[e] : 0u;
+        ok = ok && __float_as_uint((float)b) == __float_as_uint(v[e]);
+        pk |= b << (8 * e);
+      }
+      w[p] = pk;
+    }
+    out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  if (__any(!ok) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// Called by a refining search (not while its stream is being captured) and by lance_hip_index_prewarm.  Synchronises the stream once per
+// index; afterwards one mutex-protected read.  Returns the u8 column or nullptr (f32 path).
+static bool raw_compact_enabled() {
+  static const bool off = getenv("LANCE_HIP_NO_RAW_COMPACT") != nullptr;      // A/B switch: always refine from the caller's column
+  return !off;
+}
+const uint8_t *raw_compact_prepare(lance_hip_ctx *ctx, const lance_hip_index *ix_c) {
+  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);      // a cache attached to the index, like the scan constants
+  if (!raw_compact_enabled() || ix->dtype != LANCE_HIP_F32 || !ix->raw || ix->n_raw == 0 || (ix->d & 15) != 0 ||
+      (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_DOT) || (reinterpret_cast<uintptr_t>(ix->raw) & 15) != 0)
+    return nullptr;
+  std::lock_guard<std::mutex> lk(ix->lazy_mu);
+  if (ix->raw_compact_state != 0) return ix->raw_compact_state > 0 ? ix->raw_u8 : nullptr;
+  if (ctx->capturing) return nullptr;      // this capture keeps the f32 kernel; a later plain call builds the copy
+  const uint64_t bytes = ix->n_raw * (uint64_t)ix->d;
+  uint8_t *buf = nullptr;
+  uint32_t *bad = ctx->scratch_t<uint32_t>("raw.compact_flag", 1);
+  if (!bad || hipMalloc(reinterpret_cast<void **>(&buf), bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    ix->raw_compact_state = -1;
+    return nullptr;
+  }
+  uint32_t bad_h = 1;
+  bool ran = lh::memset_async(bad, 0, 4, ctx->stream) == hipSuccess;
+  if (ran) {
+    const int64_t n16 = (int64_t)(bytes / 16);
+    hipLaunchKernelGGL(raw_to_u8_kernel, dim3((unsigned)std::min<uint64_t>(cdiv((uint64_t)n16, 256), 1u << 20)), dim3(256), 0, ctx->stream,
+                       static_cast<const f4 *>(ix->raw), n16, reinterpret_cast<uint4 *>(buf), bad);
+    ran = hipGetLastError() == hipSuccess && hipMemcpyAsync(&bad_h, bad, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+          hipStreamSynchronize(ctx->stream) == hipSuccess;
+  }
+  if (!ran || bad_h != 0) {
+    (void)hipFree(buf);
+    ix->raw_compact_state = -1;
+    return nullptr;
+  }
+  ix->raw_u8 = buf;
+  ix->raw_compact_state = 1;
+  return buf;
 }
 
 
@@ -1349,7 +1434,16 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
       static const bool v1 = getenv("LANCE_HIP_REFINE_V1") != nullptr;
       const bool pair = !v1 && (d & 15) == 0 && ((reinterpret_cast<uintptr_t>(rawf) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
       const size_t lds_pair = (size_t)P * 16 + (size_t)d * 4;
-      if (pair && ix->metric == LANCE_HIP_DOT)
+      const uint8_t *raw8 = pair ? raw_compact_prepare(ctx, ix) : nullptr;      // integer-valued column: its lossless u8 copy (index.h)
+      if (raw8) {
+        ScopedTimer t8(ctx, "refine_u8");      // the same launch under its own name: tests assert which source the refine read
+        if (ix->metric == LANCE_HIP_DOT)
+          hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT, uint8_t>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
+                             cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+        else
+          hipLaunchKernelGGL((refine_pair_kernel<METRIC_L2, uint8_t>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
+                             cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
+      } else if (pair && ix->metric == LANCE_HIP_DOT)
         hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
                            (int)keff, (int)k, P, ids, dists, flags);
       else if (pair)
@@ -1415,6 +1509,16 @@ static int check_flags(lance_hip_ctx *ctx, const uint32_t *flags, uint32_t nq) {
 using namespace lh;
 
 extern "C" {
+
+int lance_hip_index_prewarm(lance_hip_ctx *ctx, lance_hip_index *idx) {
+  lh::CtxLock _ctx_lock(ctx);
+  LH_REQUIRE(ctx && idx, "index_prewarm: NULL argument");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (idx->m > 0 && idx->nbits == 8) LH_TRY(mscan_prewarm(ctx, idx));
+  (void)raw_compact_prepare(ctx, idx);      // nullptr = the column stays f32 (not integer-valued, or not an f32 L2 / dot index): not an error
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
 
 int lance_hip_find_partitions(lance_hip_ctx *ctx, int dtype, int metric, const void *q, uint32_t nq, uint32_t d,
                               const void *centroids, uint32_t nlist, uint32_t nprobes, uint32_t *part_ids, float *dists) {

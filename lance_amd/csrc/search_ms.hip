@@ -745,6 +745,13 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   return LANCE_HIP_OK;
 }
 
+int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix_c) {
+  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
+  static const bool off = getenv("LANCE_HIP_NO_MSCAN") != nullptr;
+  if (off || !ms_shape(ix, nullptr, nullptr) || (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_COSINE) || !ix->model_finite) return LANCE_HIP_OK;
+  return mscan_prepare(ctx, ix);
+}
+
 void mscan_cut_params(int *cut_shift, uint32_t *cut_slack) { *cut_shift = MS_CUT_SHIFT; *cut_slack = 2u; }
 
 }  // namespace lh

@@ -531,6 +531,10 @@ class DeviceIndex:
         self._raw = t.to(self.data_dtype).to(_dev()).contiguous()
         check(self.engine.lib.lance_hip_index_set_raw(self.h, _ptr(self._raw), self._raw.shape[0]))
 
+    def prewarm(self):
+        """Index::prewarm (ivf/v2.rs:349-352, dataset.py prewarm_index): build the per-index search constants now."""
+        check(self.engine.lib.lance_hip_index_prewarm(self.engine.h, self.h))
+
     def info(self):
         n = C.c_uint64(); nlist = C.c_uint32(); m = C.c_uint32(); d = C.c_uint32()
         check(self.engine.lib.lance_hip_index_info(self.h, C.byref(n), C.byref(nlist), C.byref(m), C.byref(d)))

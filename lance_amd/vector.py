@@ -470,6 +470,9 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
     ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
                                                               raw=x if keep_raw else None,
                                                               dtype="int8" if x.dtype == torch.int8 else None))
+    # Index::prewarm (ivf/v2.rs:349-352): the search-side constants (matrix-core scan tables, the lossless u8 refine copy of an
+    # integer-valued f32 column) are built here, inside the build's clock, instead of inside the first search
+    timed("prewarm", ix.prewarm)
     return IvfPqIndex(ix, params, stats, part, codes)
 
 

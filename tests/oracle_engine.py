@@ -167,6 +167,9 @@ class OracleDeviceIndex:
     def close(self):
         pass
 
+    def prewarm(self):
+        pass
+
     def info(self):
         return {"n": int(self.o.row_ids.size), "nlist": int(self.o.centroids.shape[0]), "m": int(self.o.codebook.shape[0]),
                 "d": int(self.o.centroids.shape[1])}
