@@ -156,7 +156,10 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
                  const uint32_t *pair_starts, const uint32_t *pair_idx, const uint32_t *tbound, uint32_t *seg_cnt, uint32_t *seg_pos,
                  uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out);
 void mscan_cut_params(int *cut_shift, uint32_t *cut_slack);
-int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix);      // builds the scan's index constants now (lance_hip_index_prewarm)
+int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix);
+int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
+                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);   // search_ms.hip: -1 = not taken
+int qscan_items(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nvp, int G, uint32_t *item_start, int4 *desc, uint32_t max_items);   // search_q.hip: work items of G grouped pairs      // builds the scan's index constants now (lance_hip_index_prewarm)
 const uint8_t *raw_compact_prepare(lance_hip_ctx *ctx, const lance_hip_index *ix);   // search.hip: lossless u8 refine copy (index.h), or nullptr
 
 }  // namespace lh

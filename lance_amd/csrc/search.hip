@@ -671,6 +671,43 @@ __global__ __launch_bounds__(256) void ivfpq_merge_kernel(MergeArgs p) {
 // (dist, rowid) order, fetch k  (scanner.rs:2884-2904 take + flat_knn :3336-3412)
 // H32: the column is f16 -- its dot products and norms are the 32-lane dot_scalar / norm_l2_impl (dot.rs:91-102, norm_l2.rs:60-85)
 // and its cosine distance is the trait default cosine_scalar (cosine.rs:171-179), not f32's cosine_fast.
+// Final selection of the refine kernels: key / rid [0, P) hold the candidates' (exact distance key, row id), invalid slots (key
+// 0xFFFFFFFF).  The reference sorts by (dist, rowid) and takes k; only the k best are needed, so up to 256 slots are RANKED instead
+// of sorted: slot t counts the slots that precede it in (key, rid, slot) order -- P broadcast LDS reads, one barrier, against the 28
+// barrier-separated passes of a 128-entry bitonic sort (a third of the kernel's life once the row reads stopped being its bound) --
+// and writes itself to out[rank] when rank < min(c, k).  Same order as the sort (the slot index only separates identical pairs, which
+// are interchangeable).  More than 256 slots: the sort.
+__device__ __forceinline__ void refine_emit_topk(uint32_t *key, uint64_t *rid, uint32_t *pos, int P, int c, int k, int qi,
+                                                 uint64_t *__restrict__ out_ids, float *__restrict__ out_dists) {
+  const int got = min(c, k);
+  if (P <= 256) {
+    const int t = threadIdx.x;
+    if (t < P) {
+      const uint32_t mk = key[t];
+      const uint64_t mr = rid[t];
+      int rank = 0;
+      for (int j0 = 0; j0 < P; j0 += 4) {
+        const uint4 kj = *reinterpret_cast<const uint4 *>(&key[j0]);
+        const uint32_t kk[4] = {kj.x, kj.y, kj.z, kj.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          bool before = kk[u] < mk;
+          if (kk[u] == mk) { const uint64_t rj = rid[j0 + u]; before = rj < mr || (rj == mr && j0 + u < t); }
+          rank += before ? 1 : 0;
+        }
+      }
+      if (rank < got) { out_ids[(int64_t)qi * k + rank] = mr; out_dists[(int64_t)qi * k + rank] = key_to_float(mk); }
+    }
+    for (int i = got + (int)threadIdx.x; i < k; i += 256) { out_ids[(int64_t)qi * k + i] = ~0ull; out_dists[(int64_t)qi * k + i] = INFINITY; }
+    return;
+  }
+  bitonic_sort_kr(key, rid, pos, P);
+  for (int i = threadIdx.x; i < k; i += 256) {
+    out_ids[(int64_t)qi * k + i] = i < got ? rid[i] : ~0ull;
+    out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(key[i]) : INFINITY;
+  }
+}
+
 // rows long enough for the four-lanes-per-candidate cosine path (no f32x8 / scalar tail: d % 16 == 0; 16-byte aligned rows)
 __host__ __device__ __forceinline__ bool refine_wide_rows(int d) { return d >= 256 && (d & 15) == 0; }
 
@@ -787,12 +824,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
     }
   }
   __syncthreads();
-  bitonic_sort_kr(key, rid, pos, P);
-  const int got = min(c, k);
-  for (int i = threadIdx.x; i < k; i += 256) {
-    out_ids[(int64_t)qi * k + i] = i < got ? rid[i] : ~0ull;
-    out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(key[i]) : INFINITY;
-  }
+  refine_emit_topk(key, rid, pos, P, c, k, qi, out_ids, out_dists);
 }
 
 // refine, f32 rows of d % 16 == 0 elements under L2 / dot: TWO lanes per candidate, the whole row in flight.
@@ -804,10 +836,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
 // consumes any: one round trip per 128 elements, 32 bytes contiguous per lane, 64 per pair.  Same arithmetic: per accumulator the chunks
 // arrive in ascending order (mul, then add: -ffp-contract=off), the final fold is the reference's ((0 + s0) + s1) + ... + s15, done by lane 0
 // of the pair after one xor-shuffle per accumulator; d % 16 == 0, so the scalar tail is the +0.0 the reference adds too.
-// TR = uint8_t: the index's lossless u8 copy of an integer-valued f32 column (index.h raw_u8): lane h reads the 8 bytes [8h, 8h+8) of every
-// 16-byte chunk, widens them (v_cvt_f32_ubyte*: exact) and runs the SAME arithmetic on the same f32 values -- a quarter of the row bytes.
-template <int METRIC, typename TR = float>
-__global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw, uint64_t n_raw,
+template <int METRIC>
+__global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restrict__ q, int d, const float *__restrict__ raw, uint64_t n_raw,
                                                           const uint64_t *__restrict__ cand_rid, const uint32_t *__restrict__ cand_cnt, int keff,
                                                           int k, int P, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
                                                           uint32_t *__restrict__ flags) {
@@ -836,30 +866,13 @@ __global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
     if (ok) {
+      const f4 *yp = reinterpret_cast<const f4 *>(raw + r * d) + 2 * h;
       const f4 *xp = qs4 + 2 * h;
       for (int c0 = 0; c0 < nchunk; c0 += 8) {
         f4 y[8][2];
-        if constexpr (sizeof(TR) == 1) {
-          const uint2 *yp = reinterpret_cast<const uint2 *>(raw + r * d) + h;
-          uint2 yb[8];
 #pragma unroll
-          for (int cc = 0; cc < 8; ++cc)
-            if (c0 + cc < nchunk) yb[cc] = yp[(c0 + cc) * 2];
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc)
-            if (c0 + cc < nchunk) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                y[cc][0][e] = (float)((yb[cc].x >> (8 * e)) & 255u);
-                y[cc][1][e] = (float)((yb[cc].y >> (8 * e)) & 255u);
-              }
-            }
-        } else {
-          const f4 *yp = reinterpret_cast<const f4 *>(raw + r * d) + 2 * h;
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc)
-            if (c0 + cc < nchunk) { y[cc][0] = yp[(c0 + cc) * 4]; y[cc][1] = yp[(c0 + cc) * 4 + 1]; }
-        }
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < nchunk) { y[cc][0] = yp[(c0 + cc) * 4]; y[cc][1] = yp[(c0 + cc) * 4 + 1]; }
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc)
           if (c0 + cc < nchunk) {
@@ -893,18 +906,97 @@ __global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restric
     }
   }
   __syncthreads();
-  bitonic_sort_kr(key, rid, pos, P);
-  const int got = min(c, k);
-  for (int i = threadIdx.x; i < k; i += 256) {
-    out_ids[(int64_t)qi * k + i] = i < got ? rid[i] : ~0ull;
-    out_dists[(int64_t)qi * k + i] = i < got ? key_to_float(key[i]) : INFINITY;
+  refine_emit_topk(key, rid, pos, P, c, k, qi, out_ids, out_dists);
+}
+
+// The same refine from the index's lossless u8 copy of an integer-valued f32 column (index.h raw_u8): lane h of a pair reads the 8 bytes
+// [8h, 8h+8) of every 16-element chunk -- a quarter of the row bytes --, widens them (v_cvt_f32_ubyte0..3: exact) as they are consumed
+// and runs the SAME arithmetic on the same f32 values: per accumulator the chunks in ascending order, mul then add, the reference's
+// fold.  The candidate ids are requested together with the count (the list is [nq][keff]; slots beyond the count are masked after the
+// loads come back), so the kernel's dependent chain is ids -> rows -> rank.
+template <int METRIC>
+__global__ __launch_bounds__(256) void refine_u8_kernel(const float *__restrict__ q, int d, const uint8_t *__restrict__ raw, uint64_t n_raw,
+                                                        const uint64_t *__restrict__ cand_rid, const uint32_t *__restrict__ cand_cnt, int keff,
+                                                        int k, int P, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
+                                                        uint32_t *__restrict__ flags) {
+  static_assert(METRIC == METRIC_L2 || METRIC == METRIC_DOT, "squared L2 / dot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
+  uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
+  uint32_t *pos = key + P;
+  f4 *qs4 = reinterpret_cast<f4 *>(pos + P);      // [d / 4] the query
+  const int qi = blockIdx.x;
+  const int h = threadIdx.x & 1, slot = threadIdx.x >> 1;   // 128 candidates per round
+  uint64_t r0 = ~0ull;
+  if (slot < keff) r0 = cand_rid[(int64_t)qi * keff + slot];      // first round's ids: in flight with the count and the query
+  const int c = (int)cand_cnt[qi];
+  const f4 *qv4 = reinterpret_cast<const f4 *>(q + (int64_t)qi * d);
+  for (int e = threadIdx.x; e < d / 4; e += 256) qs4[e] = qv4[e];
+  __syncthreads();
+  const int nchunk = d >> 4;
+  for (int i0 = 0; i0 < P; i0 += 128) {
+    const int i = i0 + slot;
+    uint64_t r = ~0ull;
+    if (i < c) {
+      r = i0 == 0 ? r0 : cand_rid[(int64_t)qi * keff + i];
+      if (r >= n_raw && h == 0) atomicOr(&flags[qi], FLAG_BADROW);   // stored row id beyond the raw vectors handed to set_raw: reported, not ranked
+    }
+    const bool ok = i < c && r < n_raw;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    if (ok) {
+      const uint2 *yp = reinterpret_cast<const uint2 *>(raw + r * d) + h;
+      const f4 *xp = qs4 + 2 * h;
+      for (int c0 = 0; c0 < nchunk; c0 += 8) {
+        uint2 yb[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < nchunk) yb[cc] = yp[(c0 + cc) * 2];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (c0 + cc < nchunk) {
+            const f4 x0 = xp[(c0 + cc) * 4], x1 = xp[(c0 + cc) * 4 + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y0 = (float)((yb[cc].x >> (8 * e)) & 255u), y1 = (float)((yb[cc].y >> (8 * e)) & 255u);
+              if constexpr (METRIC == METRIC_DOT) {
+                acc[e] += x0[e] * y0;
+                acc[4 + e] += x1[e] * y1;
+              } else {
+                const float d0 = x0[e] - y0, d1 = x1[e] - y1;
+                acc[e] += d0 * d0;
+                acc[4 + e] += d1 * d1;
+              }
+            }
+          }
+      }
+    }
+    float oth[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oth[e] = __shfl_xor(acc[e], 1, 64);
+    if (h == 0 && i < P) {
+      float tot = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tot = tot + acc[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tot = tot + oth[e];
+      tot = 0.0f + tot;      // `s + tot` of dist_exact_rt with an empty scalar tail
+      key[i] = ok ? order_key(finish_metric<METRIC>(tot)) : 0xFFFFFFFFu;
+      rid[i] = r; pos[i] = 0;
+    }
   }
+  __syncthreads();
+  refine_emit_topk(key, rid, pos, P, c, k, qi, out_ids, out_dists);
 }
 
 // ---- the lossless u8 refine source (index.h: raw_u8) ---------------------------------------------------------------------------------
-// One pass over the f32 column: 16 elements per lane -> 16 bytes, and a flag if ANY element is not bit-for-bit the widening of its byte
-// (a fraction, a value outside [0, 255], -0.0, NaN).  The flag decides whether the copy is kept: the test is on the bits, so "lossless"
-// means the refine kernel sees exactly the f32 values of the caller's column.
+// One pass over the f32 column: 16 elements per lane -> 16 bytes, and a flag if ANY element is not the widening of its byte (a fraction,
+// a value outside [0, 255], NaN).  The flag decides whether the copy is kept.  -0.0 is accepted as the byte 0 (numpy's rint / clip
+// pipelines leave it behind): the refine kernel then sees +0.0 where the column holds -0.0, and neither metric can tell -- squared L2
+// forms d = x - y, and x - (-0.0) and x - (+0.0) differ at most in the sign of a zero that is squared next; dot forms x * y = -+0.0 and
+// adds it to an accumulator that starts at +0.0 and therefore is never -0.0 (+0.0 + -0.0 = +0.0 in round-to-nearest), so the sum's
+// bits do not depend on the sign of a zero addend.
 __global__ __launch_bounds__(256) void raw_to_u8_kernel(const f4 *__restrict__ x, int64_t n16, uint4 *__restrict__ out, uint32_t *__restrict__ bad) {
   bool ok = true;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
@@ -916,7 +1008,7 @@ __global__ __launch_bounds__(256) void raw_to_u8_kernel(const f4 *__restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t b = (v[e] >= 0.0f && v[e] < 256.0f) ? (uint32_t)v[e] : 0u;
-        ok = ok && __float_as_uint((float)b) == __float_as_uint(v[e]);
+        ok = ok && (float)b == v[e];
         pk |= b << (8 * e);
       }
       w[p] = pk;
@@ -1438,10 +1530,10 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
       if (raw8) {
         ScopedTimer t8(ctx, "refine_u8");      // the same launch under its own name: tests assert which source the refine read
         if (ix->metric == LANCE_HIP_DOT)
-          hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT, uint8_t>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
+          hipLaunchKernelGGL((refine_u8_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
                              cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
         else
-          hipLaunchKernelGGL((refine_pair_kernel<METRIC_L2, uint8_t>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
+          hipLaunchKernelGGL((refine_u8_kernel<METRIC_L2>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
                              cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
       } else if (pair && ix->metric == LANCE_HIP_DOT)
         hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,

@@ -560,6 +560,229 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   }
 }
 
+// ---- the bound pass on the matrix cores -----------------------------------------------------------------------------------------------
+// Every query needs an upper bound T of its final k*refine-th ADC distance before the filter (search_q.hip, "integer bound pass": a
+// 512-bin histogram of the nearest partition's sums, four queries per LDS gather, a 16 x 256 table built per item: 0.080 ms per 10,000
+// queries at C2 alone on the device, 0.128 ms when it shares the device with the other engine contexts' kernels -- as much as the
+// refine).  The same histogram from the matrix product of the scan above: one workgroup per (partition, block of <= 64 of the queries
+// whose nearest partition it is), the block's f16 residuals AND the whole f16 codebook (64 KiB) resident in LDS -- so a chunk's
+// reconstruction gather is eight ds_read_b128 instead of a dependent global round trip --, sixteen waves taking 32-row chunks: per
+// 32-query tile 8 x v_mfma_f32_32x32x16_f16 from a zero accumulator, then per (row, query) cell
+//     bin = floor(((acc + sigma^2 |c^|^2) / sigma^2 + |r|^2) * sb) = floor(dist~ * sb),     sb = 496 / (mean distance of a random code),
+// one FMA, one compare, one LDS atomic on a histogram of 512 u16 bins per query (two bins per word; partitions of >= 65,536 rows keep
+// the integer pass).  If at least k*refine allowed rows have dist~ < (b + 1) / sb =: Ta then -- by the error bound of the header
+// (every row that passes a test with threshold Ta has |c^| <= 1.01 (|r| + sqrt(Ta + E)), so |dist~ - dist_reference| <= E(Ta)) --
+// at least k*refine reference distances are <= Ta + E(Ta):   T = (Ta + 1.1 E(Ta)) (1 + 2^-16)   is a valid bound.  The epilogue's
+// own three f32 roundings (the add of |c^|^2, the FMA) are ~2^-19 (|r|^2 + T) and sit inside E's 2^-13 term.  A query whose residual
+// overflows binary16, with a non-finite value anywhere, or with fewer than k*refine countable rows gets no bound here (class B: the
+// exact pair kernel), exactly as in the integer pass.  T only has to be AN upper bound: ids and distances do not depend on which pass
+// produced it (tests/test_zz_gpu_msbound.py compares both against the oracle).
+constexpr int MSB_BQ = 64;           // queries per workgroup (two tiles)
+constexpr int MSB_BINS = 512;        // bins per query, two per LDS word
+constexpr float MSB_MEAN_BIN = 496.0f;   // the mean distance of a random code lands here (the integer pass: SE / 8)
+struct MsBoundArgs {
+  const float *q, *centroids, *cb_mean;      // cb_mean: [d] mean codeword of every sub-quantiser, [d] = sum over m of the mean |c|^2
+  const uint32_t *pair_idx0;    // [nq] query indices grouped by nearest partition
+  const uint32_t *item_start;   // [nlist + 1] blocks of MSB_BQ queries
+  const int4 *desc;             // {partition, first grouped query, queries (1 .. MSB_BQ), -}
+  const uint32_t *part_offsets;
+  const uint8_t *codes;
+  const _Float16 *cbh;          // [m][256][sd] f16(-2 sigma c)
+  const float *row_cn2;         // [n] sigma^2 |c^_row|^2
+  int d, nlist, keff, round_f16;
+  float sigma;
+  uint32_t *tglobal;            // [nq] bound key (atomicMin)
+  const uint32_t *allow;
+};
+
+template <int SD, int KS>
+__global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
+  constexpr int D = KS * 16;
+  constexpr int M = D / SD;
+  constexpr int RB = D * 2;
+  constexpr int CPR = RB / 16;
+  constexpr int RPK = 256 / RB;
+  constexpr int CBB = 256 * D * 2;          // bytes of the f16 codebook
+  __shared__ __attribute__((aligned(16))) char sCB[CBB];
+  __shared__ __attribute__((aligned(16))) char sB[MSB_BQ * RB];
+  __shared__ __attribute__((aligned(16))) uint32_t sH[MSB_BQ * (MSB_BINS / 2)];
+  __shared__ __attribute__((aligned(16))) float sPa[MSB_BQ];      // sb / sigma^2 (NaN: the query takes no bound from this pass)
+  __shared__ __attribute__((aligned(16))) float sPb[MSB_BQ];      // |r|^2 sb
+  __shared__ float sN2[MSB_BQ], sSb[MSB_BQ];
+  __shared__ uint32_t s_chunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const uint32_t item = blockIdx.x;
+  if (item >= p.item_start[p.nlist]) return;
+  const int4 dsc = p.desc[item];
+  const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
+  const uint32_t off = p.part_offsets[part];
+  const int np = (int)(p.part_offsets[part + 1] - off);
+  if (np < p.keff) return;      // uniform: fewer rows than k*refine -> no bound from this partition
+  const int nslots = ((cnt + 31) >> 5) << 5;
+
+  // the codebook: 16 bytes per lane and pass
+  for (int b = (int)threadIdx.x * 16; b < CBB; b += 1024 * 16)
+    *reinterpret_cast<uint4 *>(&sCB[b]) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(p.cbh) + b);
+  for (int i = threadIdx.x; i < MSB_BQ * (MSB_BINS / 2); i += 1024) sH[i] = 0u;
+  if (threadIdx.x == 0) s_chunk = 0u;
+  // residuals: wave w stages slots w, w + 16, ..; a lane owns two neighbouring elements
+  for (int sl = wave; sl < nslots; sl += 16) {
+    const int key = (sl / RPK) & (CPR - 1);
+    const int e = 2 * lane;
+    float n2 = 0.0f, vmax = 0.0f, rmu = 0.0f;
+    bool bad = false;
+    uint32_t packed = 0u;
+    uint32_t qi = 0u;
+    if (sl < cnt) {
+      qi = p.pair_idx0[i0 + sl];
+      if (e < D) {
+        const f2 qv = *reinterpret_cast<const f2 *>(p.q + (int64_t)qi * D + e);
+        const f2 cv = *reinterpret_cast<const f2 *>(p.centroids + (int64_t)part * D + e);
+        const f2 mu = *reinterpret_cast<const f2 *>(p.cb_mean + e);
+        float v0 = qv.x - cv.x, v1 = qv.y - cv.y;      // v2.rs:316-332, the subtraction of the exact path
+        if (p.round_f16) { v0 = __half2float(__float2half_rn(v0)); v1 = __half2float(__float2half_rn(v1)); }
+        n2 = v0 * v0 + v1 * v1;
+        vmax = fmaxf(fabsf(v0), fabsf(v1));
+        rmu = v0 * mu.x + v1 * mu.y;
+        bad = !(fabsf(v0) < INFINITY) || !(fabsf(v1) < INFINITY);
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 hv = {(_Float16)(v0 * p.sigma), (_Float16)(v1 * p.sigma)};
+        packed = __builtin_bit_cast(uint32_t, hv);
+      }
+    }
+    if (e < D) *reinterpret_cast<uint32_t *>(&sB[sl * RB + ((((e >> 3) ^ key)) << 4) + ((e & 7) << 1)]) = packed;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      n2 += __shfl_xor(n2, o, 64); rmu += __shfl_xor(rmu, o, 64); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    }
+    bad = __any(bad);
+    if (lane == 0) {
+      float a = __uint_as_float(0x7FC00000u), b = 0.0f, sb = 0.0f;
+      if (sl < cnt) {
+        const float mean = n2 - 2.0f * rmu + p.cb_mean[D];      // sum over m of the mean table entry: the distance of a random code
+        sb = MSB_MEAN_BIN / mean;
+        const float sig2 = p.sigma * p.sigma;
+        const bool ok = !bad && n2 < INFINITY && vmax * p.sigma < 60000.0f && mean > 0.0f && mean < INFINITY && sb > 0.0f && sb < INFINITY &&
+                        n2 * sb < 1e30f && sb / sig2 > 0.0f && sb / sig2 < INFINITY;
+        if (ok) { a = sb / sig2; b = n2 * sb; }
+      }
+      sPa[sl] = a; sPb[sl] = b; sN2[sl] = n2; sSb[sl] = sb;
+    }
+  }
+  for (int sl = nslots + (int)threadIdx.x; sl < MSB_BQ; sl += 1024) { sPa[sl] = __uint_as_float(0x7FC00000u); sPb[sl] = 0.0f; }
+  __syncthreads();
+
+  const uint32_t nchunks = ((uint32_t)np + 31u) >> 5;
+  const int nblk = nslots >> 5;
+  for (;;) {
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(&s_chunk, 1u);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    if (c >= nchunks) break;
+    const int row0 = (int)(c * 32u);
+    ms_h8 rw[KS];
+    float cn2v;
+    {
+      const int rowc = min(row0 + j, np - 1);
+      uint32_t cw[M / 4];
+      {
+        const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)off + rowc) * M);
+#pragma unroll
+        for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
+      }
+      const bool live = row0 + j < np && row_allowed(p.allow, off + (uint32_t)rowc);
+      cn2v = live ? p.row_cn2[(int64_t)off + rowc] : INFINITY;      // a padded / filtered row lands in no bin
+      auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if constexpr (SD == 8) {
+          const uint32_t c0 = code(2 * s), c1 = code(2 * s + 1);
+          const int mm = 2 * s + g;
+          rw[s] = *reinterpret_cast<const ms_h8 *>(&sCB[((uint32_t)mm * 256u + (g ? c1 : c0)) * 16u]);
+        } else {
+          static_assert(SD == 4, "sub-dimension 4 / 8");
+          const uint32_t c0 = g ? code(4 * s + 2) : code(4 * s), c1 = g ? code(4 * s + 3) : code(4 * s + 1);
+          const int mm = 4 * s + 2 * g;
+          const ms_h4 lo = *reinterpret_cast<const ms_h4 *>(&sCB[((uint32_t)mm * 256u + c0) * 8u]);
+          const ms_h4 hi = *reinterpret_cast<const ms_h4 *>(&sCB[((uint32_t)(mm + 1) * 256u + c1) * 8u]);
+          rw[s] = ms_h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+    }
+    for (int jb = 0; jb < nblk; ++jb) {
+      ms_h8 qa[KS];
+      {
+        const int sl = jb * 32 + j;
+        const char *br = &sB[sl * RB];
+        const int key = (sl / RPK) & (CPR - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qa[s] = *reinterpret_cast<const ms_h8 *>(br + (((2 * s + g) ^ key) << 4));
+      }
+      ms_f16v acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[s], rw[s], acc, 0, 0, 0);
+      // lane (j, g) holds row j against the queries (v & 3) + 8 (v >> 2) + 4 g of the tile
+      const f4 *pa = reinterpret_cast<const f4 *>(&sPa[jb * 32 + 4 * g]);
+      const f4 *pb = reinterpret_cast<const f4 *>(&sPb[jb * 32 + 4 * g]);
+#pragma unroll
+      for (int vq = 0; vq < 4; ++vq) {
+        const f4 a4 = pa[2 * vq], b4 = pb[2 * vq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = __builtin_fmaf(acc[4 * vq + e] + cn2v, a4[e], b4[e]);
+          if (t < (float)MSB_BINS) {      // (false for a NaN scale and for padded rows)
+            const int bin = max((int)t, 0);
+            const int slot = jb * 32 + 8 * vq + 4 * g + e;
+            atomicAdd(&sH[slot * (MSB_BINS / 2) + (bin >> 1)], 1u << (16 * (bin & 1)));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // wave w: queries w, w + 16, ..: the first bin where the cumulative count reaches k*refine
+  for (int sl = wave; sl < cnt; sl += 16) {
+    const float a = sPa[sl];
+    if (!(a > 0.0f)) continue;      // uniform: no bound for this query
+    const uint4 hw = *reinterpret_cast<const uint4 *>(&sH[sl * (MSB_BINS / 2) + lane * 4]);      // bins 8 lane .. 8 lane + 7
+    const uint32_t loc[8] = {hw.x & 0xFFFFu, hw.x >> 16, hw.y & 0xFFFFu, hw.y >> 16, hw.z & 0xFFFFu, hw.z >> 16, hw.w & 0xFFFFu, hw.w >> 16};
+    uint32_t tot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += loc[i];
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    uint32_t run = incl - tot;
+    int found = -1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      run += loc[i];
+      if (found < 0 && run >= (uint32_t)p.keff) found = lane * 8 + i;
+    }
+    const uint64_t mask = __ballot(found >= 0);
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      const int bin = __shfl(found, leader, 64);
+      if (lane == 0) {
+        const float n2 = sN2[sl], sb = sSb[sl];
+        const float Ta = (float)(bin + 1) / sb * 1.000001f;      // every counted row has dist~ < (bin + 1) / sb
+        const float rn = sqrtf(n2) * 1.000001f, st = sqrtf(Ta) * 1.000001f;
+        const float sqd = sqrtf((float)D) + 1.0f;
+        const float e_abs = 6.1035156e-5f * sqd * (3.0f * rn + 2.0f * st) / p.sigma + (float)D * 3.7252903e-9f / (p.sigma * p.sigma);
+        const float E = 1.05f * (1.9921875e-3f * rn * (rn + st) + 1.2207031e-4f * (n2 + Ta)) + e_abs;      // ms_prep_kernel's E at T = Ta
+        const float T = (Ta + 1.1f * E) * 1.0000153f;
+        if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl]], order_key(T));
+      }
+    }
+  }
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------------
 static bool ms_shape(const lance_hip_index *ix, int *sd_out, int *ks_out) {
   if (!ix || ix->m == 0 || ix->nbits != 8 || ix->d % ix->m != 0) return false;
@@ -742,6 +965,34 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   else { set_error("matrix-core scan: unsupported shape (d=%d, sd=%d)", d, sd); return LANCE_HIP_EINVAL; }
   LH_CHECK_HIP(hipGetLastError());
   *qslack_out = qslack; *seg_val_out = seg_val; *seg_scale_out = reinterpret_cast<float *>(prm2);
+  return LANCE_HIP_OK;
+}
+
+// The bound pass of a batch the matrix-core scan serves (search_pm.hip).  pair_starts0 / pair_idx0: the nq (query, nearest partition) pairs
+// grouped by partition.  -1: not taken (the caller runs the integer pass); otherwise a status code.
+int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
+                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow) {
+  static const bool off = getenv("LANCE_HIP_NO_MSBOUND") != nullptr;      // A/B switch: the integer histogram pass (search_q.hip)
+  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
+  int sd = 0, ks = 0;
+  if (off || !ms_shape(ix, &sd, &ks) || !ix->cb_mean || ix->max_part >= 65536u) return -1;      // u16 bins: a bin never holds more rows than the partition has
+  if (((reinterpret_cast<uintptr_t>(qs) | reinterpret_cast<uintptr_t>(ix->centroids)) & 7) != 0) return -1;
+  LH_TRY(mscan_prepare(ctx, ix));
+  if (!ix->ms->usable) return -1;
+  const int nlist = (int)ix->nlist;
+  LH_TRY(qscan_items(ctx, pair_starts0, nlist, MSB_BQ, item_start, desc, max_items));
+  ScopedTimer t(ctx, "ivfpq_msbound");      // the launch under its own name: tests assert which bound pass ran
+  MsBoundArgs a;
+  a.q = qs; a.centroids = ix->centroids; a.cb_mean = ix->cb_mean; a.pair_idx0 = pair_idx0; a.item_start = item_start; a.desc = desc;
+  a.part_offsets = ix->part_offsets; a.codes = ix->codes; a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2;
+  a.d = (int)ix->d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0; a.sigma = ix->ms->sigma;
+  a.tglobal = tglobal; a.allow = allow;
+  const unsigned grid = (unsigned)std::min<uint64_t>(max_items, (uint64_t)nq / MSB_BQ + (uint64_t)nlist + 1);      // sum over partitions of ceil(queries / MSB_BQ)
+  if (sd == 8 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<8, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
+  else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
+  else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ms_bound_kernel<4, 4>), dim3(grid), dim3(1024), 0, ctx->stream, a);
+  else return -1;
+  LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
 

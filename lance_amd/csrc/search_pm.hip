@@ -667,9 +667,15 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     ScopedTimer t(ctx, "ivfpq_scan_c0");
     LH_TRY(qbound_pt_launch(ctx, ix, qs, nq, nprobes, keff, probes, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal,
                             allow));
-  } else {             // integer histogram bound, four queries per gather (search_q.hip)
+  } else {
     ScopedTimer t(ctx, "ivfpq_scan_c0");
-    LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));
+    // a batch the matrix-core scan serves gets its bounds from the same matrix product (search_ms.hip: ms_bound_kernel) ...
+    int mb_rc = -1;
+    if (mscan_supported(ix, nq, nprobes))
+      mb_rc = msbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow);
+    if (mb_rc > 0) return mb_rc;
+    // ... every other one from the integer histogram, four queries per gather (search_q.hip)
+    if (mb_rc < 0) LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));
   }
   {
     // main pass grouping: class A (bounded) pairs by partition for the filter scan, class B for the exact pair kernel

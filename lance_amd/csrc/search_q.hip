@@ -1246,6 +1246,14 @@ int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix) {
   return LANCE_HIP_OK;
 }
 
+// item_start[vp] = exclusive scan of ceil(pairs of vp / G), desc[item] = {virtual partition, first grouped pair, pairs (1..G), 0}
+int qscan_items(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nvp, int G, uint32_t *item_start, int4 *desc, uint32_t max_items) {
+  hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nvp, G, item_start);
+  hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, nvp, G, max_items, desc);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 // bound pass on the integer table: pair_starts0 / pair_idx0 = the nq (query, nearest partition) pairs grouped by partition
 int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow) {
