@@ -399,6 +399,12 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
       default: launch_flat_filter<128>(ctx, e, metric); break;
     }
   };
+  // long rows (no fixed-dimension kernel): query batches run the epochs after the first on the matrix cores (flat_mfma_wide.hip);
+  // the rows' bf16 plane and norms are made once per call
+  const bool wide_mfma = !fixed && flat_mfma_wide_supported(metric, d, std::min(nq, qch), n, x, q);
+  const uint16_t *wxb = nullptr;
+  const float *wxn2 = nullptr;
+  if (wide_mfma) LH_TRY(flat_mfma_wide_prepare_rows(ctx, x, n, d, &wxb, &wxn2));
   const size_t sel_lds = (size_t)FLAT_CAP * 12;
   for (int qc0 = 0; qc0 < nq; qc0 += qch) {
     a.q = q + (int64_t)qc0 * d;
@@ -412,6 +418,10 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
     const uint16_t *qhi = nullptr, *qlo = nullptr;
     const float *qn2 = nullptr;
     if (use_mfma) LH_TRY(flat_mfma_prepare(ctx, a.q, a.nq, d, &qhi, &qlo, &qn2));
+    const bool use_wide = wide_mfma && flat_mfma_wide_supported(metric, d, a.nq, n, x, a.q);      // (a short last chunk takes the exact kernel)
+    const uint16_t *wqb = nullptr;
+    const float *wqn2 = nullptr;
+    if (use_wide) LH_TRY(flat_mfma_wide_prepare_queries(ctx, a.q, a.nq, d, &wqb, &wqn2));
     int64_t seen = 0;
     if (n == 0) {
       a.r0 = a.r1 = 0;
@@ -425,6 +435,7 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
       {
         ScopedTimer t(ctx, "flat_scan");
         if (use_mfma && seen > 0 && seen >= k) LH_TRY(launch_flat_filter_mfma(ctx, a, d, metric, qhi, qlo, qn2));
+        else if (use_wide && seen > 0 && seen >= k) LH_TRY(launch_flat_filter_mfma_wide(ctx, a, d, metric, wxb, wxn2, wqb, wqn2));
         else filter(a);
       }
       seen = a.r1;

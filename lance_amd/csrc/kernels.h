@@ -72,6 +72,12 @@ int build_allow_bits(lance_hip_ctx *ctx, const uint64_t *row_ids, uint64_t n, co
 bool flat_mfma_supported(int metric, int d, int nq, const void *x, const float *q);
 int flat_mfma_prepare(lance_hip_ctx *ctx, const float *q, int nq, int d, const uint16_t **qhi, const uint16_t **qlo, const float **qn);
 int launch_flat_filter_mfma(lance_hip_ctx *ctx, const FlatPool &e, int d, int metric, const uint16_t *qhi, const uint16_t *qlo, const float *qn);
+// K-tiled bf16 MFMA surrogate + exact re-check for query batches against LONG f32 rows, L2 / dot / cosine (flat_mfma_wide.hip)
+bool flat_mfma_wide_supported(int metric, int d, int nq, int64_t n, const float *x, const float *q);
+int flat_mfma_wide_prepare_rows(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const uint16_t **xb, const float **xn2);
+int flat_mfma_wide_prepare_queries(lance_hip_ctx *ctx, const float *q, int nq, int d, const uint16_t **qb, const float **qn2);
+int launch_flat_filter_mfma_wide(lance_hip_ctx *ctx, const FlatPool &e, int d, int metric, const uint16_t *xb, const float *xn2, const uint16_t *qb,
+                                 const float *qn2);
 
 int launch_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric, int batches);
 bool assign_reads_native(PairwiseArgs p, int d, int batches);

@@ -626,21 +626,33 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
     *reinterpret_cast<uint4 *>(&sCB[b]) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(p.cbh) + b);
   for (int i = threadIdx.x; i < MSB_BQ * (MSB_BINS / 2); i += 1024) sH[i] = 0u;
   if (threadIdx.x == 0) s_chunk = 0u;
-  // residuals: wave w stages slots w, w + 16, ..; a lane owns two neighbouring elements
-  for (int sl = wave; sl < nslots; sl += 16) {
-    const int key = (sl / RPK) & (CPR - 1);
+  // residuals: wave w stages slots w, w + 16, w + 32, w + 48 -- their loads in flight together; a lane owns two neighbouring elements
+  {
+    constexpr int SPW = MSB_BQ / 16;
     const int e = 2 * lane;
-    float n2 = 0.0f, vmax = 0.0f, rmu = 0.0f;
-    bool bad = false;
-    uint32_t packed = 0u;
-    uint32_t qi = 0u;
-    if (sl < cnt) {
-      qi = p.pair_idx0[i0 + sl];
-      if (e < D) {
-        const f2 qv = *reinterpret_cast<const f2 *>(p.q + (int64_t)qi * D + e);
-        const f2 cv = *reinterpret_cast<const f2 *>(p.centroids + (int64_t)part * D + e);
-        const f2 mu = *reinterpret_cast<const f2 *>(p.cb_mean + e);
-        float v0 = qv.x - cv.x, v1 = qv.y - cv.y;      // v2.rs:316-332, the subtraction of the exact path
+    uint32_t qi[SPW];
+#pragma unroll
+    for (int t = 0; t < SPW; ++t) { const int sl = wave + 16 * t; qi[t] = sl < cnt ? p.pair_idx0[i0 + sl] : 0u; }
+    f2 qv[SPW], cv = {0.0f, 0.0f}, mu = {0.0f, 0.0f};
+    if (e < D) {
+      cv = *reinterpret_cast<const f2 *>(p.centroids + (int64_t)part * D + e);
+      mu = *reinterpret_cast<const f2 *>(p.cb_mean + e);
+    }
+#pragma unroll
+    for (int t = 0; t < SPW; ++t) {
+      qv[t] = f2{0.0f, 0.0f};
+      if (wave + 16 * t < cnt && e < D) qv[t] = *reinterpret_cast<const f2 *>(p.q + (int64_t)qi[t] * D + e);
+    }
+#pragma unroll
+    for (int t = 0; t < SPW; ++t) {
+      const int sl = wave + 16 * t;
+      if (sl >= nslots) break;      // uniform
+      const int key = (sl / RPK) & (CPR - 1);
+      float n2 = 0.0f, vmax = 0.0f, rmu = 0.0f;
+      bool bad = false;
+      uint32_t packed = 0u;
+      if (sl < cnt && e < D) {
+        float v0 = qv[t].x - cv.x, v1 = qv[t].y - cv.y;      // v2.rs:316-332, the subtraction of the exact path
         if (p.round_f16) { v0 = __half2float(__float2half_rn(v0)); v1 = __half2float(__float2half_rn(v1)); }
         n2 = v0 * v0 + v1 * v1;
         vmax = fmaxf(fabsf(v0), fabsf(v1));
@@ -650,24 +662,24 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
         const h2 hv = {(_Float16)(v0 * p.sigma), (_Float16)(v1 * p.sigma)};
         packed = __builtin_bit_cast(uint32_t, hv);
       }
-    }
-    if (e < D) *reinterpret_cast<uint32_t *>(&sB[sl * RB + ((((e >> 3) ^ key)) << 4) + ((e & 7) << 1)]) = packed;
+      if (e < D) *reinterpret_cast<uint32_t *>(&sB[sl * RB + ((((e >> 3) ^ key)) << 4) + ((e & 7) << 1)]) = packed;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      n2 += __shfl_xor(n2, o, 64); rmu += __shfl_xor(rmu, o, 64); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    }
-    bad = __any(bad);
-    if (lane == 0) {
-      float a = __uint_as_float(0x7FC00000u), b = 0.0f, sb = 0.0f;
-      if (sl < cnt) {
-        const float mean = n2 - 2.0f * rmu + p.cb_mean[D];      // sum over m of the mean table entry: the distance of a random code
-        sb = MSB_MEAN_BIN / mean;
-        const float sig2 = p.sigma * p.sigma;
-        const bool ok = !bad && n2 < INFINITY && vmax * p.sigma < 60000.0f && mean > 0.0f && mean < INFINITY && sb > 0.0f && sb < INFINITY &&
-                        n2 * sb < 1e30f && sb / sig2 > 0.0f && sb / sig2 < INFINITY;
-        if (ok) { a = sb / sig2; b = n2 * sb; }
+      for (int o = 32; o > 0; o >>= 1) {
+        n2 += __shfl_xor(n2, o, 64); rmu += __shfl_xor(rmu, o, 64); vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
       }
-      sPa[sl] = a; sPb[sl] = b; sN2[sl] = n2; sSb[sl] = sb;
+      bad = __any(bad);
+      if (lane == 0) {
+        float a = __uint_as_float(0x7FC00000u), b = 0.0f, sb = 0.0f;
+        if (sl < cnt) {
+          const float mean = n2 - 2.0f * rmu + p.cb_mean[D];      // sum over m of the mean table entry: the distance of a random code
+          sb = MSB_MEAN_BIN / mean;
+          const float sig2 = p.sigma * p.sigma;
+          const bool ok = !bad && n2 < INFINITY && vmax * p.sigma < 60000.0f && mean > 0.0f && mean < INFINITY && sb > 0.0f && sb < INFINITY &&
+                          n2 * sb < 1e30f && sb / sig2 > 0.0f && sb / sig2 < INFINITY;
+          if (ok) { a = sb / sig2; b = n2 * sb; }
+        }
+        sPa[sl] = a; sPb[sl] = b; sN2[sl] = n2; sSb[sl] = sb;
+      }
     }
   }
   for (int sl = nslots + (int)threadIdx.x; sl < MSB_BQ; sl += 1024) { sPa[sl] = __uint_as_float(0x7FC00000u); sPb[sl] = 0.0f; }
@@ -675,24 +687,37 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
 
   const uint32_t nchunks = ((uint32_t)np + 31u) >> 5;
   const int nblk = nslots >> 5;
-  for (;;) {
+  // a chunk's codes and |c^|^2 are requested one chunk ahead (the codeword gather itself is LDS)
+  auto take = [&]() -> uint32_t {
     uint32_t c = 0;
     if (lane == 0) c = atomicAdd(&s_chunk, 1u);
-    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-    if (c >= nchunks) break;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+  };
+  uint32_t cwn[M / 4];
+  float cn2n = INFINITY;
+  auto request = [&](uint32_t c) {
     const int row0 = (int)(c * 32u);
-    ms_h8 rw[KS];
-    float cn2v;
-    {
-      const int rowc = min(row0 + j, np - 1);
-      uint32_t cw[M / 4];
-      {
-        const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)off + rowc) * M);
+    const int rowc = min(row0 + j, np - 1);
+    const uint4 *rc4 = reinterpret_cast<const uint4 *>(p.codes + ((int64_t)off + rowc) * M);
 #pragma unroll
-        for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cw[4 * w] = t.x; cw[4 * w + 1] = t.y; cw[4 * w + 2] = t.z; cw[4 * w + 3] = t.w; }
-      }
-      const bool live = row0 + j < np && row_allowed(p.allow, off + (uint32_t)rowc);
-      cn2v = live ? p.row_cn2[(int64_t)off + rowc] : INFINITY;      // a padded / filtered row lands in no bin
+    for (int w = 0; w < M / 16; ++w) { const uint4 t = rc4[w]; cwn[4 * w] = t.x; cwn[4 * w + 1] = t.y; cwn[4 * w + 2] = t.z; cwn[4 * w + 3] = t.w; }
+    const bool live = row0 + j < np && row_allowed(p.allow, off + (uint32_t)rowc);
+    cn2n = live ? p.row_cn2[(int64_t)off + rowc] : INFINITY;      // a padded / filtered row lands in no bin
+  };
+  uint32_t c = take();
+  if (c < nchunks) request(c);
+  while (c < nchunks) {
+    const uint32_t cnext = take();
+    uint32_t cw[M / 4];
+#pragma unroll
+    for (int w = 0; w < M / 4; ++w) cw[w] = cwn[w];
+    const float cn2v = cn2n;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int w = 0; w < M / 4; ++w) asm volatile("" : "+v"(cw[w]));
+    if (cnext < nchunks) request(cnext);
+    ms_h8 rw[KS];
+    {
       auto code = [&](int mm) -> uint32_t { return (cw[mm >> 2] >> (8 * (mm & 3))) & 255u; };
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
@@ -741,6 +766,7 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
         }
       }
     }
+    c = cnext;
   }
   __syncthreads();
   // wave w: queries w, w + 16, ..: the first bin where the cumulative count reaches k*refine

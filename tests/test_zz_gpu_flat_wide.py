@@ -1,0 +1,109 @@
+"""Batched flat KNN over LONG f32 rows on the matrix cores (lance_amd/csrc/flat_mfma_wide.hip): a K-tiled bf16 product filters the
+(query, row) pairs, the pairs that can beat a query's threshold are recomputed in the reference's arithmetic (l2.rs:57-91 / dot.rs:52-89
+16-lane order, cosine.rs:143-175 cosine_fast) -- so row ids and distances must equal the oracle's flat_knn bit for bit
+(KNNVectorDistanceExec + SortExec, knn.rs:218-246, scanner.rs:3386-3406), for L2, dot and cosine, any d % 16 == 0.
+
+Every case asserts whether the matrix-core filter ran (`flat_mfma_wide` stage counter); its error margin is wide by design
+(one bf16 product: 0.45 % of |x||q|), so the cases put many rows close to each query's k-th distance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def eng(engine):
+    from lance_amd.engine import Engine
+    e = Engine()
+    yield e
+    e.close()
+
+
+def _ran(eng):
+    return eng.timing_query("count:flat_mfma_wide")[1]
+
+
+def _check(eng, oracle, x, q, k, metric, row_ids=None, tag=None, expect=True):
+    before = _ran(eng)
+    gi, gd = eng.flat_topk(x, q, k, metric, row_ids=row_ids)
+    assert (_ran(eng) > before) == expect, (tag, "matrix-core filter " + ("not taken" if expect else "taken unexpectedly"))
+    oi, od = oracle.flat_knn(x, q, k, metric, row_ids=row_ids)
+    gi = gi.cpu().numpy().view(np.uint64); gd = gd.cpu().numpy()
+    bad = np.nonzero((gi != oi).any(axis=1))[0]
+    assert bad.size == 0, (tag, f"ids differ for {bad.size} of {q.shape[0]} queries, first {bad[:5]}")
+    assert (gd.view(np.uint32) == od.view(np.uint32)).all(), (tag, "distance bits differ")
+
+
+def _data(rng, n, nq, d, unit=False, integer=False):
+    centers = rng.normal(0, 1.0, (24, d))
+    x = centers[rng.integers(0, 24, n)] + rng.normal(0, 0.35, (n, d))
+    q = centers[rng.integers(0, 24, nq)] + rng.normal(0, 0.35, (nq, d))
+    if integer:
+        x, q = np.rint(x * 20), np.rint(q * 20)
+    if unit:
+        x /= np.linalg.norm(x, axis=1, keepdims=True); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return x.astype(f32), q.astype(f32)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
+@pytest.mark.parametrize("d,n", [(256, 40_000), (1536, 24_000), (144, 30_000), (960, 16_000)])
+def test_long_rows_match_the_oracle(eng, oracle, d, n, metric):
+    rng = np.random.default_rng(1000 + d)
+    x, q = _data(rng, n, 300, d, unit=(metric == "cosine" and d == 1536))
+    x[100] = x[7]; x[5000] = x[7]; q[0] = x[7]              # exact ties: the smaller row id first
+    for k in (10, 1, 100):
+        _check(eng, oracle, x, q, k, metric, tag=(d, metric, k))
+
+
+def test_integer_rows_mass_ties_and_row_ids(eng, oracle):
+    """Integer-valued rows: many exactly equal distances around every threshold; 3000 copies of one row; row ids unrelated to the storage order."""
+    rng = np.random.default_rng(7)
+    n, d = 30_000, 256
+    x, q = _data(rng, n, 200, d, integer=True)
+    x[10_000:13_000] = x[9]
+    q[:20] = x[9] + rng.integers(0, 2, (20, d))
+    rid = rng.permutation(n).astype(np.uint64) * 3 + 5
+    for metric in ("l2", "dot", "cosine"):
+        _check(eng, oracle, x, q, 10, metric, row_ids=rid, tag=("ties", metric))
+    _check(eng, oracle, x, q, 128, "l2", tag="ties k=128")
+
+
+def test_degenerate_rows(eng, oracle):
+    """Zero rows under cosine (0 / 0), a row of huge components under L2 (|x|^2 overflows f32), a row scaled by 1e-20 (its norm
+    underflows): the filter must hand them to the exact arithmetic, whatever it decides."""
+    rng = np.random.default_rng(9)
+    n, d = 20_000, 256
+    x, q = _data(rng, n, 160, d)
+    x[17] = 0.0; x[9000] = 0.0
+    x[31] = 3e19                                   # |x|^2 = inf
+    x[32] *= f32(1e-20)
+    for metric in ("cosine", "l2", "dot"):
+        _check(eng, oracle, x, q, 10, metric, tag=("degenerate rows", metric))
+
+
+def test_degenerate_queries(eng, oracle):
+    """A zero query and a query scaled by 1e-20 under cosine / L2 / dot: every row is a candidate of the zero query (cosine: 0 / 0), the
+    queue overflows and the repair loop of flat.hip decides with the exact kernel."""
+    rng = np.random.default_rng(10)
+    n, d = 12_000, 256
+    x, q = _data(rng, n, 160, d)
+    q[5] = 0.0
+    q[6] *= f32(1e-20)
+    for metric in ("cosine", "l2", "dot"):
+        _check(eng, oracle, x, q, 10, metric, tag=("degenerate queries", metric))
+
+
+def test_small_batches_and_short_rows_keep_their_kernels(eng, oracle):
+    rng = np.random.default_rng(11)
+    x, q = _data(rng, 20_000, 100, 256)
+    _check(eng, oracle, x, q, 10, "l2", tag="nq < 128", expect=False)
+    x, q = _data(rng, 20_000, 300, 128)
+    _check(eng, oracle, x, q, 10, "l2", tag="d = 128: the register-resident filter", expect=False)
+
+
+def test_many_query_chunks(eng, oracle):
+    """More queries than one pass takes (2048): the rows' bf16 plane is made once, the last chunk is short."""
+    rng = np.random.default_rng(13)
+    x, q = _data(rng, 12_000, 2048 + 200, 192)
+    _check(eng, oracle, x, q, 10, "cosine", tag="chunks")
