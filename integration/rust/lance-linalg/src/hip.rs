@@ -77,6 +77,8 @@ extern "C" {
         transposed: i32, row_ids: *const u64, n: u64, out: *mut *mut LanceHipIndex) -> i32;
     pub fn lance_hip_index_load(ctx: *mut LanceHipCtx, dir: *const c_char, dtype: i32, out: *mut *mut LanceHipIndex) -> i32;
     pub fn lance_hip_index_set_raw(idx: *mut LanceHipIndex, x: *const c_void, n_raw: u64) -> i32;
+    /// Index::prewarm (lance/src/index/vector/ivf/v2.rs:349): build the per-index search constants now.
+    pub fn lance_hip_index_prewarm(ctx: *mut LanceHipCtx, idx: *mut LanceHipIndex) -> i32;
     pub fn lance_hip_index_destroy(idx: *mut LanceHipIndex);
     pub fn lance_hip_ivfpq_search(ctx: *mut LanceHipCtx, idx: *const LanceHipIndex, q: *const c_void, nq: u32, k: u32,
         nprobes: u32, refine_factor: u32, ids: *mut u64, dists: *mut f32) -> i32;

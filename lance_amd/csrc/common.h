@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -116,6 +117,8 @@ struct ScopedTimer {
 // search is captured into a HIP graph: replays of graphs holding memset nodes returned empty results on ROCm 7.2 (gpurun r04c,
 // tests/test_zz_gpu_graph.py) while the first launch of the same graph was right.
 hipError_t memset_async(void *ptr, int value, size_t bytes, hipStream_t stream);
+struct FillSpec { void *ptr; int value; size_t bytes; };
+hipError_t memset_multi(hipStream_t stream, std::initializer_list<FillSpec> fills);      // up to six word-aligned fills in one launch (dtype.hip)
 struct CtxLock {
   lance_hip_ctx *c;
   explicit CtxLock(lance_hip_ctx *c_) : c(c_) { if (c) c->mu.lock(); }

@@ -908,10 +908,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   const uint32_t nan_slot = (uint32_t)npairs + 1u;      // inside prm's 32 records of padding
   {
     ScopedTimer t(ctx, "q_residual");
-    LH_CHECK_HIP(lh::memset_async(seg_cnt, 0, npairs * 4, ctx->stream));
-    LH_CHECK_HIP(lh::memset_async(qovf, 0, (size_t)nq * 4, ctx->stream));
-    LH_CHECK_HIP(lh::memset_async(qslack, 0, (size_t)nq * 4, ctx->stream));
-    LH_CHECK_HIP(lh::memset_async(ovf, 0, 4, ctx->stream));
+    LH_CHECK_HIP(lh::memset_multi(ctx->stream, {{seg_cnt, 0, npairs * 4}, {qovf, 0, (size_t)nq * 4}, {qslack, 0, (size_t)nq * 4}, {ovf, 0, 4}}));
     MsPrepArgs pa;
     pa.q = qs; pa.centroids = ix->centroids; pa.pair_idx = pair_idx; pa.pair_starts = pair_starts; pa.probes = probes; pa.tbound = tbound;
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;

@@ -631,8 +631,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
       !desc4 || !tglobal || !seg_cnt || !seg_pos || !pool_key || !pool_pos)
     return LANCE_HIP_ENOMEM;
   uint32_t *pool_cnt = tglobal + nq, *tbound = tglobal + 2 * (size_t)nq, *qovf = tglobal + 3 * (size_t)nq;
-  LH_CHECK_HIP(lh::memset_async(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
-  LH_CHECK_HIP(lh::memset_async(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_multi(ctx->stream, {{tglobal, 0xFF, (size_t)nq * 4}, {pool_cnt, 0, (size_t)nq * 4}}));
   PmArgs a;
   a.q = qs; a.probes = probes;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
@@ -753,8 +752,7 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
   uint32_t *pool_pos = ctx->scratch_t<uint32_t>("pm.pool_pos", (size_t)nq * pool_cap);
   if (!pair_starts || !pair_idx || !item_start || !tglobal || !pool_key || !pool_pos) return LANCE_HIP_ENOMEM;
   uint32_t *pool_cnt = tglobal + nq;
-  LH_CHECK_HIP(lh::memset_async(tglobal, 0xFF, (size_t)nq * 4, ctx->stream));
-  LH_CHECK_HIP(lh::memset_async(pool_cnt, 0, (size_t)nq * 4, ctx->stream));
+  LH_CHECK_HIP(lh::memset_multi(ctx->stream, {{tglobal, 0xFF, (size_t)nq * 4}, {pool_cnt, 0, (size_t)nq * 4}}));
   uint32_t *keys = ctx->scratch_t<uint32_t>("pm.keys", npairs);
   const uint32_t max_items = (uint32_t)(npairs / 2 + 2 * nlist + 2);   // >= sum over virtual partitions of ceil(c / 2)
   int4 *desc = ctx->scratch_t<int4>("pm.desc", max_items);
