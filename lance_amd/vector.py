@@ -364,15 +364,29 @@ def train_ivf_centroids(x, params: IvfPqParams, engine=None, init=None):
                             seed=params.seed, metric=kmetric)
 
 
-def train_pq_codebook(x, centroids, params: IvfPqParams, engine=None):
+def pq_sample_indices(n, params: IvfPqParams):
+    """The rows the PQ codebook is trained on (maybe_sample_training_data, rust/lance/src/index/vector/utils.rs:173): a pure function of
+    (n, params) -- create_index draws it on a host thread WHILE the IVF k-means runs on the device (2.7 ms of numpy at n = 1M that used to
+    sit inside train_pq with the GPU idle)."""
+    rng = np.random.default_rng(params.seed + 1)
+    return _sample_rows(n, params.sample_rate * (1 << params.num_bits), rng)
+
+
+_UNSET = object()
+
+
+def train_pq_codebook(x, centroids, params: IvfPqParams, engine=None, sample_idx=_UNSET):
     """load_or_build_quantizer (rust/lance/src/index/vector/builder.rs:399-466): sample
     sample_rate * 2^nbits rows, normalise (cosine), drop non-finite, residual vs the IVF centroids
-    (L2/cosine), then PQBuildParams::build (L2 k-means per sub-vector)."""
+    (L2/cosine), then PQBuildParams::build (L2 k-means per sub-vector).  sample_idx: the result of pq_sample_indices when the
+    caller already has it (None = all rows), or a concurrent.futures.Future of it."""
     eng = engine or default_engine()
     metric = _normalize_metric_type(params.metric)
     x = to_device(x)
-    rng = np.random.default_rng(params.seed + 1)
-    idx = _sample_rows(x.shape[0], params.sample_rate * (1 << params.num_bits), rng)
+    if sample_idx is _UNSET:
+        idx = pq_sample_indices(x.shape[0], params)
+    else:
+        idx = sample_idx.result() if hasattr(sample_idx, "result") else sample_idx
     sample = x if idx is None else x[torch.from_numpy(idx).to(x.device)]
     if metric == "cosine":
         sample = eng.normalize(sample)
@@ -439,12 +453,24 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
         stats.seconds[name] = time.perf_counter() - t
         return out
 
+    pq_idx = _UNSET
+    pq_pool = None
+    if itype == "IVF_PQ" and pq_codebook is None and ivf_centroids is None:
+        # the PQ training sample depends on (n, params) only: drawn on a host thread while the IVF k-means occupies the device
+        from concurrent.futures import ThreadPoolExecutor
+        pq_pool = ThreadPoolExecutor(max_workers=1)
+        pq_idx = pq_pool.submit(pq_sample_indices, n, params)
     if ivf_centroids is not None:
         cent = to_device(np.asarray(ivf_centroids, np.float32))
         if cent.shape != (num_partitions, d):
             raise ValueError(f"IVF centroids length mismatch: {tuple(cent.shape)} != {(num_partitions, d)}")
     else:
-        cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
+        try:
+            cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: train_ivf_centroids(x, params, eng))
+        except BaseException:
+            if pq_pool is not None:
+                pq_pool.shutdown(wait=True)
+            raise
     if itype == "IVF_FLAT":
         if params.metric == "cosine":
             # IvfTransformer::new_flat (rust/lance-index/src/vector/ivf.rs:147-175): rows are normalised, assigned with L2 and
@@ -465,7 +491,11 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
     if pq_codebook is not None:
         cb = to_device(np.asarray(pq_codebook, np.float32).reshape(num_sub_vectors, 1 << num_bits, d // num_sub_vectors))
     else:
-        cb, stats.pq_iters = timed("train_pq", lambda: train_pq_codebook(x, cent, params, eng))
+        try:
+            cb, stats.pq_iters = timed("train_pq", lambda: train_pq_codebook(x, cent, params, eng, sample_idx=pq_idx))
+        finally:
+            if pq_pool is not None:
+                pq_pool.shutdown(wait=True)
     part, codes, _ = timed("transform", lambda: eng.ivfpq_encode(x, cent, cb, params.metric))
     ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
                                                               raw=x if keep_raw else None,

@@ -29,5 +29,5 @@ for o in "$ROOT"/build/obj/*.o; do
     OBJS="$OBJS $o"
   fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build/variants/liblance_hip_$NAME.so" $OBJS
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/build/variants/liblance_hip_$NAME.so" $OBJS -ldl -pthread
 echo "built build/variants/liblance_hip_$NAME.so"
