@@ -306,13 +306,26 @@ __global__ void flat_pool_reset_kernel(FlatPool p, int reset_t) {
 
 // cosine_fast's y-side norm for every row, d % 16 == 0: 16 FMA lane accumulators -> f32x8 tree (cosine.rs:143-175).
 // One 16-lane group per row (coalesced 64-byte reads), the tree via shuffles.  out = sqrt(y_norm).
-__global__ __launch_bounds__(256) void cosine_rownorm_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
+// xb != NULL: the same pass also writes the rows' bf16 plane (round-to-nearest-even) for the long-row matrix-core filter
+// (flat_mfma_wide.hip) -- the f32 column is read once, not twice.
+__device__ __forceinline__ uint16_t cr_bf16_rne(float x) {
+  const uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ __launch_bounds__(256) void cosine_rownorm_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out,
+                                                             uint16_t *__restrict__ xb) {
   const int lane = threadIdx.x & 63, i = lane & 15;
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   float a = 0.0f;
   if (row < n) {
     const float *src = x + row * d;
-    for (int c = 0; c < d; c += 16) { const float v = src[c + i]; a = __fmaf_rn(v, v, a); }
+    if (xb) {
+      uint16_t *dst = xb + row * d;
+      for (int c = 0; c < d; c += 16) { const float v = src[c + i]; a = __fmaf_rn(v, v, a); dst[c + i] = cr_bf16_rne(v); }
+    } else {
+      for (int c = 0; c < d; c += 16) { const float v = src[c + i]; a = __fmaf_rn(v, v, a); }
+    }
   }
   const float t = a + __shfl(a, lane + 8);        // i < 8: t_i = a_i + a_{i+8}
   const float s = t + __shfl(t, lane + 4);        // i < 4: s_i = t_i + t_{i+4}
@@ -379,13 +392,22 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
   const bool fixed = metric != LANCE_HIP_COSINE && flat_fixed_dim((uint32_t)d) &&
                      (((reinterpret_cast<uintptr_t>(a.x_native) | reinterpret_cast<uintptr_t>(q)) & 15) == 0);
   LH_REQUIRE(x || fixed, "flat_topk: internal: native rows need the fixed-dimension kernels");
+  // long rows (no fixed-dimension kernel): query batches run the epochs after the first on the matrix cores (flat_mfma_wide.hip);
+  // the rows' bf16 plane and norms are made once per call (cosine: by the row-norm pass below, which reads the column anyway)
+  const bool wide_mfma = !fixed && flat_mfma_wide_supported(metric, d, std::min(nq, qch), n, x, q);
+  const uint16_t *wxb = nullptr;
+  const float *wxn2 = nullptr;
   if (metric == LANCE_HIP_COSINE) {
     float *sy = ctx->scratch_t<float>("flat2.row_sy", (size_t)std::max<int64_t>(n, 1));
     float *qn = ctx->scratch_t<float>("flat2.q_norm", (size_t)nq);
-    if (!sy || !qn) return LANCE_HIP_ENOMEM;
-    if (n > 0) hipLaunchKernelGGL(cosine_rownorm_kernel, dim3((unsigned)cdiv((uint64_t)n * 16, 256)), dim3(256), 0, ctx->stream, x, n, d, sy);
+    uint16_t *xb = wide_mfma ? ctx->scratch_t<uint16_t>("fw.xb", (size_t)std::max<int64_t>(n, 1) * d) : nullptr;
+    if (!sy || !qn || (wide_mfma && !xb)) return LANCE_HIP_ENOMEM;
+    if (n > 0) hipLaunchKernelGGL(cosine_rownorm_kernel, dim3((unsigned)cdiv((uint64_t)n * 16, 256)), dim3(256), 0, ctx->stream, x, n, d, sy, xb);
     hipLaunchKernelGGL(query_norm_kernel, dim3(cdiv(nq, 64)), dim3(64), 0, ctx->stream, q, nq, d, qn);
     a.row_sy = sy;
+    wxb = xb; wxn2 = sy;      // (the cosine filter reads row_sy, not |x|^2)
+  } else if (wide_mfma) {
+    LH_TRY(flat_mfma_wide_prepare_rows(ctx, x, n, d, &wxb, &wxn2));
   }
   const float *qn_all = metric == LANCE_HIP_COSINE ? ctx->scratch_t<float>("flat2.q_norm", (size_t)nq) : nullptr;
   auto filter = [&](const FlatPool &e) {
@@ -399,12 +421,6 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
       default: launch_flat_filter<128>(ctx, e, metric); break;
     }
   };
-  // long rows (no fixed-dimension kernel): query batches run the epochs after the first on the matrix cores (flat_mfma_wide.hip);
-  // the rows' bf16 plane and norms are made once per call
-  const bool wide_mfma = !fixed && flat_mfma_wide_supported(metric, d, std::min(nq, qch), n, x, q);
-  const uint16_t *wxb = nullptr;
-  const float *wxn2 = nullptr;
-  if (wide_mfma) LH_TRY(flat_mfma_wide_prepare_rows(ctx, x, n, d, &wxb, &wxn2));
   const size_t sel_lds = (size_t)FLAT_CAP * 12;
   for (int qc0 = 0; qc0 < nq; qc0 += qch) {
     a.q = q + (int64_t)qc0 * d;

@@ -33,7 +33,10 @@ typedef short pq_bf16x4 __attribute__((ext_vector_type(4)));
 typedef short pq_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float pq_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PQM_RG = 4;                 // 32-row groups per wave: a workgroup covers 4 waves x 4 x 32 = 512 rows
+#ifndef LH_PQM_RG
+#define LH_PQM_RG 8
+#endif
+constexpr int PQM_RG = LH_PQM_RG;         // 32-row groups per wave: a workgroup covers 4 waves x 8 x 32 = 1024 rows (the codebook's LDS set-up is paid per workgroup: 4 -> 8 groups took 0.28 ms off the C2 build, gpurun r05l)
 constexpr int PQM_WG_ROWS = 4 * PQM_RG * 32;
 
 __device__ __forceinline__ uint32_t pqm_bf16_rne(float x) {

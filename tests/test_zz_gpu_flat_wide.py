@@ -56,6 +56,15 @@ def test_long_rows_match_the_oracle(eng, oracle, d, n, metric):
         _check(eng, oracle, x, q, k, metric, tag=(d, metric, k))
 
 
+def test_cosine_takes_it_at_every_dimension(eng, oracle):
+    """Cosine has no fixed-dimension kernel (cosine_fast's own lane layout), so its query batches take the K-tiled filter for short rows
+    too; the rows' bf16 plane comes out of the row-norm pass."""
+    rng = np.random.default_rng(21)
+    for d in (32, 64, 128):
+        x, q = _data(rng, 30_000, 256, d)
+        _check(eng, oracle, x, q, 10, "cosine", tag=("cosine", d))
+
+
 def test_integer_rows_mass_ties_and_row_ids(eng, oracle):
     """Integer-valued rows: many exactly equal distances around every threshold; 3000 copies of one row; row ids unrelated to the storage order."""
     rng = np.random.default_rng(7)
