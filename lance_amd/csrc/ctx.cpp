@@ -38,6 +38,13 @@ void *lance_hip_ctx::scratch(const char *name, size_t bytes) {
   return p;
 }
 
+void lance_hip_ctx::scratch_release(const char *name) {
+  auto it = slots.find(name);
+  if (it == slots.end()) return;
+  (void)hipFree(it->second.first);
+  slots.erase(it);
+}
+
 void lance_hip_ctx::drop_graphs() {
   graph_seen_once.clear();      // a key seen once must size the (reallocated) arena again before it is captured
   graph_seen_next = 0;

@@ -471,6 +471,12 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
     }
   }
   LH_CHECK_HIP(hipGetLastError());
+  // the rows' bf16 plane is as large as half the column: not something to keep in the arena between calls (the repair loop above
+  // synchronised the stream after the last chunk's kernels were enqueued ... except its final select: wait for that one too)
+  if (wide_mfma && (uint64_t)n * (uint64_t)d * 2 > (4ull << 30)) {      // (up to 4 GiB it stays: a repeated call does not pay the allocation)
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->scratch_release("fw.xb");
+  }
   return LANCE_HIP_OK;
 }
 
