@@ -955,6 +955,26 @@ int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, u
   return LANCE_HIP_OK;
 }
 
+}  // extern "C"
+
+namespace lh {
+// [rows][d] -> [m][rows][sd]: every sub-quantiser's training matrix contiguous.  The batched Lloyd kernels address problem b's row r as
+// x + b * x_batch_off + r * ldx, so the sliced layout is just (ldx = sd, x_batch_off = rows * sd) to them -- but the E-step's row loads
+// become 32 rows x 32 contiguous bytes instead of 32 rows 512 bytes apart, each sub-quantiser's 2 MB stays in the L2 of the XCDs that work
+// on it (the 32 MB row-major matrix was re-fetched by the workgroups of all sixteen column slices: 50 iterations x 16 x 32 MB through the
+// fabric), and the M-step's row gathers hit a compact matrix.  Same values, same row order: the trained codebook is bit-identical.
+__global__ __launch_bounds__(256) void pq_slice_transpose_kernel(const f4 *__restrict__ x, int64_t rows, int d4, int sd4, f4 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * d4) return;
+  const int64_t row = i / d4;
+  const int c4 = (int)(i - row * d4);
+  const int b = c4 / sd4, e4 = c4 - b * sd4;
+  out[((int64_t)b * rows + row) * sd4 + e4] = x[i];
+}
+}  // namespace lh
+
+extern "C" {
+
 int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uint64_t n, uint32_t d, uint32_t m,
                        uint32_t nbits, uint32_t max_iters, uint32_t sample_rate, uint64_t seed, void *codebook_out,
                        uint32_t *iters_out_host) {
@@ -981,7 +1001,19 @@ int lance_hip_pq_train(lance_hip_ctx *ctx, int dtype, const void *residuals, uin
     if (!cb) return LANCE_HIP_ENOMEM;
   }
   // balance factor 0 (KMeansParams::new, pq/builder.rs:113-128); L2 always (builder.rs:455)
-  LH_TRY(kmeans_train_batched(ctx, LANCE_HIP_L2, rf, (int64_t)rows, d, (int)(d / m), (int)(d / m), (int)kc, (int)m, max_iters, 1e-4, 0.0f,
+  const uint32_t sd = d / m;
+  static const bool no_slices = getenv("LANCE_HIP_PQ_NO_SLICES") != nullptr;      // A/B: train on the row-major matrix
+  int64_t ldx = d;
+  int xoff = (int)sd;
+  if (!no_slices && m > 1 && sd % 4 == 0 && (reinterpret_cast<uintptr_t>(rf) & 15) == 0 && (uint64_t)rows * sd < (1ull << 31)) {
+    float *xt = ctx->scratch_t<float>("pq.slices", (size_t)rows * d);
+    if (!xt) return LANCE_HIP_ENOMEM;
+    hipLaunchKernelGGL(lh::pq_slice_transpose_kernel, dim3((unsigned)cdiv(rows * (uint64_t)(d / 4), 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const f4 *>(rf), (int64_t)rows, (int)(d / 4), (int)(sd / 4), reinterpret_cast<f4 *>(xt));
+    LH_CHECK_HIP(hipGetLastError());
+    rf = xt; ldx = sd; xoff = (int)(rows * sd);
+  }
+  LH_TRY(kmeans_train_batched(ctx, LANCE_HIP_L2, rf, (int64_t)rows, ldx, xoff, (int)sd, (int)kc, (int)m, max_iters, 1e-4, 0.0f,
                               false, seeds.data(), cb, loss.data(), iters_out_host, f16));
   if (f16) {
     LH_TRY(from_f32(ctx, model_dtype(dtype), cb, codebook_out, (size_t)m * kc * (d / m)));

@@ -13,7 +13,8 @@ flat scan and IVF_FLAT, bit for bit.  Three case families:
   batch  -- 600..3000 queries so that nq * nprobes >= 4096: the partition-major path with its surrogates (integer bound pass,
             u16 filter scan, exact re-evaluation; M in {16, 32, 96}, sub-dimension 4 / 8 / 16, f32 / f16 / int8 columns),
             the MFMA flat filter (batched flat scan) and the MFMA assign;
-  wide   -- rows of more than 128 elements (up to 1536 = the dbpedia shape): K-tiled MFMA assign, any-dimension kernels.
+  wide   -- rows of more than 128 elements (up to 1536 = the dbpedia shape): K-tiled MFMA assign, any-dimension kernels, and (700-query
+            cases) the K-tiled MFMA flat filter of flat_mfma_wide.hip.
 A mismatch does not stop the run: the failing configuration is printed (and appended to FILE), the case's device objects are
 released and the next case starts; the exit status is 1 if any case failed (at most 25 are collected).
 """
@@ -225,7 +226,7 @@ def run_case(rng, c, ncase, eng, classes, torch, oracle):
                 a = g.search(qg, k, nprobes); b = g2.search(qg, k, nprobes)
                 assert (a[0] == b[0]).all() and (a[1].cpu().numpy().view(np.uint32) == b[1].cpu().numpy().view(np.uint32)).all(), "save/load"
         k = int(rng.integers(1, 40))
-        nqf = nq if (big and d <= 128) else min(nq, 40)          # batches go through the MFMA flat filter (d <= 128)
+        nqf = nq if big else min(nq, 40)          # batches go through the MFMA flat filters (d <= 128: register-resident rows; longer f32 rows and cosine: K-tiled)
         gi, gd = eng.flat_topk(xg, qg[:nqf], k, metric)
         oi, od = oracle.flat_knn(x, q[:nqf], k, metric)
         assert (gi.cpu().numpy().view(np.uint64) == oi).all() and (gd.cpu().numpy().view(np.uint32) == od.view(np.uint32)).all(), f"flat k={k} nq={nqf}"
