@@ -31,6 +31,7 @@
 // overflows raises the pool-overflow flag and the caller's repair loop rescans with the exact kernel).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "exact.cuh"
@@ -43,8 +44,7 @@ namespace lh {
 typedef short fw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float fw_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FW_TM = 128;            // rows per workgroup tile
-constexpr int FW_TN = 128;            // queries per workgroup tile
+constexpr int FW_TN = 128;            // queries per workgroup tile (rows per tile: 64 x BR, BR = 32-row blocks per wave: template parameter)
 constexpr int FW_KT = 64;             // elements of d per stage
 constexpr int FW_LS = FW_KT + 8;      // LDS row stride (bf16 elements): 144 bytes
 constexpr int FW_SQ_CAP = 2048;       // queued rows per query and epoch
@@ -98,11 +98,14 @@ struct FwArgs {
   uint32_t *scnt;              // [nq] queued rows of this epoch
   uint32_t *squeue;            // [nq][FW_SQ_CAP] rows (relative to p.r0) whose surrogate distance passed
   int d;
-  uint32_t nqt;                // query tiles (the grid is one-dimensional: block = row tile * nqt + query tile)
+  uint32_t nqt, nrt;           // query tiles, row tiles (one-dimensional grid, XCD-aware order: see the kernel)
 };
 
-template <int METRIC>
+// BR = 32-row blocks per wave (2: 128-row tiles, 64 accumulator registers; 4: 256-row tiles, 128 accumulator registers -- six operand reads
+// per eight MFMAs instead of four per four, and twice the matrix work behind every stage's global loads)
+template <int METRIC, int BR>
 __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a) {
+  constexpr int FW_TM = 64 * BR;
   __shared__ __attribute__((aligned(16))) uint16_t Xs[FW_TM * FW_LS];
   __shared__ __attribute__((aligned(16))) uint16_t Qs[FW_TN * FW_LS];
   __shared__ __attribute__((aligned(16))) float tqs[FW_TN];
@@ -111,8 +114,17 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
   const int wr = wave >> 1, wq = wave & 1;
-  const int q0 = (int)(blockIdx.x % a.nqt) * FW_TN;        // query tiles vary fastest: the workgroups that share a row tile run together
-  const int64_t row0 = p.r0 + (int64_t)(blockIdx.x / a.nqt) * FW_TM;
+  // XCD-aware tile order.  Workgroups are dealt to the eight XCDs round-robin (block b -> XCD b % 8), each XCD with its own L2: in plain
+  // row-major order the nqt workgroups that share a row tile land on nqt DIFFERENT XCDs and every one of them pulls the same 128 x d rows
+  // through the fabric (nqt = 8 at 1000 queries: 24 GB per epoch of a 3 GB plane -- the first version's bound: 8.3 ms whatever the tile
+  // shape, gpurun r05n).  Here block b = 8 i + x takes row tile 8 (i / nqt) + x and query tile i % nqt: the workgroups of a row tile are
+  // consecutive on ONE XCD, the tile comes from HBM once and the other query tiles hit that XCD's L2; the query plane (nq x d bf16, 3 MB)
+  // is small enough to live in every L2.
+  const uint32_t xi = blockIdx.x >> 3, xc = blockIdx.x & 7u;
+  const uint32_t rt = (xi / a.nqt) * 8u + xc;
+  if (rt >= a.nrt) return;      // (the grid is padded to whole groups of eight row tiles)
+  const int q0 = (int)(xi % a.nqt) * FW_TN;
+  const int64_t row0 = p.r0 + (int64_t)rt * (64 * BR);
 
   // per-query threshold term
   if (threadIdx.x < FW_TN) {
@@ -136,31 +148,35 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     tqs[threadIdx.x] = t;
   }
 
-  // staging: thread (r, h) moves 32 elements (64 bytes) of row r / query r per stage
+  // staging: thread (r, h) moves 32 elements (64 bytes) of query r and of the rows r, r + 128, .. per stage
   const int sr = threadIdx.x >> 1, sh = threadIdx.x & 1;
-  const bool xrow_ok = row0 + sr < p.r1, qrow_ok = q0 + sr < p.nq;
+  constexpr int XR = FW_TM / 128;      // rows per thread and stage
+  const bool qrow_ok = q0 + sr < p.nq;
   const uint16_t *xsrc = a.xb + (row0 + sr) * (int64_t)d + sh * 32;
   const uint16_t *qsrc = a.qb + (int64_t)(q0 + sr) * d + sh * 32;
-  uint4 px[4], pq[4];
+  uint4 px[XR][4], pq[4];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const bool in = k0 + sh * 32 + u * 8 < d;      // d % 8 == 0: a 16-byte piece is inside or outside
-      px[u] = (xrow_ok && in) ? *reinterpret_cast<const uint4 *>(xsrc + k0 + u * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int xr = 0; xr < XR; ++xr)
+        px[xr][u] = (row0 + sr + 128 * xr < p.r1 && in) ? *reinterpret_cast<const uint4 *>(xsrc + (int64_t)(128 * xr) * d + k0 + u * 8) : make_uint4(0, 0, 0, 0);
       pq[u] = (qrow_ok && in) ? *reinterpret_cast<const uint4 *>(qsrc + k0 + u * 8) : make_uint4(0, 0, 0, 0);
     }
   };
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      *reinterpret_cast<uint4 *>(&Xs[sr * FW_LS + sh * 32 + u * 8]) = px[u];
+#pragma unroll
+      for (int xr = 0; xr < XR; ++xr) *reinterpret_cast<uint4 *>(&Xs[(sr + 128 * xr) * FW_LS + sh * 32 + u * 8]) = px[xr][u];
       *reinterpret_cast<uint4 *>(&Qs[sr * FW_LS + sh * 32 + u * 8]) = pq[u];
     }
   };
 
-  fw_f32x16 acc[2][2];
+  fw_f32x16 acc[BR][2];
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < BR; ++bi)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
@@ -174,14 +190,13 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     if (more) fetch(k0 + FW_KT);
 #pragma unroll
     for (int s = 0; s < FW_KT / 16; ++s) {
-      fw_bf16x8 aq[2], bx[2];
+      fw_bf16x8 aq[2], bx[BR];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        aq[b] = *reinterpret_cast<const fw_bf16x8 *>(&Qs[(wq * 64 + b * 32 + j) * FW_LS + s * 16 + g * 8]);
-        bx[b] = *reinterpret_cast<const fw_bf16x8 *>(&Xs[(wr * 64 + b * 32 + j) * FW_LS + s * 16 + g * 8]);
-      }
+      for (int b = 0; b < 2; ++b) aq[b] = *reinterpret_cast<const fw_bf16x8 *>(&Qs[(wq * 64 + b * 32 + j) * FW_LS + s * 16 + g * 8]);
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
+      for (int b = 0; b < BR; ++b) bx[b] = *reinterpret_cast<const fw_bf16x8 *>(&Xs[(wr * 32 * BR + b * 32 + j) * FW_LS + s * 16 + g * 8]);
+#pragma unroll
+      for (int bi = 0; bi < BR; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[bj], bx[bi], acc[bi][bj], 0, 0, 0);
     }
@@ -192,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
 
   // epilogue: lane (j, g) of block (bi, bj) holds row j of the row block against the queries (v & 3) + 8 (v >> 2) + 4 g of the query block
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
-    const int64_t row = row0 + wr * 64 + bi * 32 + j;
+  for (int bi = 0; bi < BR; ++bi) {
+    const int64_t row = row0 + wr * 32 * BR + bi * 32 + j;
     const bool rvalid = row < p.r1;
     float xk = 0.0f;        // per-row constant of the test
     bool odd = false;       // row whose norm is not usable: permissive comparison
@@ -325,22 +340,30 @@ int launch_flat_filter_mfma_wide(lance_hip_ctx *ctx, const FlatPool &e, int d, i
   a.squeue = ctx->scratch_t<uint32_t>("fw.squeue", (size_t)e.nq * FW_SQ_CAP);
   if (!a.scnt || !a.squeue) return LANCE_HIP_ENOMEM;
   LH_CHECK_HIP(lh::memset_async(a.scnt, 0, (size_t)e.nq * 4, ctx->stream));
-  const uint64_t rblocks = cdiv((uint64_t)rows, FW_TM);
+  static const int br_env = getenv("LANCE_HIP_FW_BR") ? atoi(getenv("LANCE_HIP_FW_BR")) : 0;      // A/B: 32-row blocks per wave (2 / 4)
+  const int br = br_env == 2 || br_env == 4 ? br_env : 2;      // (4 measured no faster, gpurun r05n: the operand traffic was not the bound)
+  const uint64_t rblocks = cdiv((uint64_t)rows, (uint64_t)(64 * br));
   a.nqt = (uint32_t)cdiv((uint64_t)e.nq, FW_TN);
-  LH_REQUIRE(rblocks * a.nqt < (1ull << 31), "flat scan: an epoch of %lld rows x %d queries exceeds the grid of the long-row matrix-core filter",
+  a.nrt = (uint32_t)rblocks;
+  const uint64_t nblocks = cdiv(rblocks, 8) * 8 * a.nqt;
+  LH_REQUIRE(nblocks < (1ull << 31), "flat scan: an epoch of %lld rows x %d queries exceeds the grid of the long-row matrix-core filter",
              (long long)rows, e.nq);
-  const dim3 grid((unsigned)(rblocks * a.nqt), 1, 1);
+  const dim3 grid((unsigned)nblocks, 1, 1);
   ScopedTimer t(ctx, "flat_mfma_wide");
-  if (metric == METRIC_COSINE) {
-    hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_COSINE>), grid, dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_COSINE>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
-  } else if (metric == METRIC_DOT) {
-    hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_DOT>), grid, dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_DOT>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
-  } else {
-    hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_L2>), grid, dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_L2>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
-  }
+  auto go = [&](auto br_tag) {
+    constexpr int BR = decltype(br_tag)::value;
+    if (metric == METRIC_COSINE) {
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_COSINE, BR>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_COSINE>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
+    } else if (metric == METRIC_DOT) {
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_DOT, BR>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_DOT>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
+    } else {
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_L2, BR>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_L2>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
+    }
+  };
+  if (br == 4) go(std::integral_constant<int, 4>()); else go(std::integral_constant<int, 2>());
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
