@@ -45,8 +45,7 @@ typedef short fw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float fw_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int FW_TN = 128;            // queries per workgroup tile (rows per tile: 64 x BR, BR = 32-row blocks per wave: template parameter)
-constexpr int FW_KT = 64;             // elements of d per stage
-constexpr int FW_LS = FW_KT + 8;      // LDS row stride (bf16 elements): 144 bytes
+// elements of d per stage: template parameter KT (64 / 128); LDS row stride KT + 8 bf16 elements (144 / 272 bytes: conflict-free ds_read_b128)
 constexpr int FW_SQ_CAP = 2048;       // queued rows per query and epoch
 constexpr float FW_EW = 0.0045f;
 constexpr float FW_EWC = 0.0046f;
@@ -103,8 +102,13 @@ struct FwArgs {
 
 // BR = 32-row blocks per wave (2: 128-row tiles, 64 accumulator registers; 4: 256-row tiles, 128 accumulator registers -- six operand reads
 // per eight MFMAs instead of four per four, and twice the matrix work behind every stage's global loads)
-template <int METRIC, int BR>
+// KT = elements of d per stage.  The next stage's global loads are issued when a stage starts and waited for when its MFMAs are done: one
+// stage of matrix work is all that covers their latency, and the SQ counters show the waves stalled or parked 83 % of the time
+// (profiles/r05q_*).  KT = 128 -- twice the work behind every load, half the barriers per MFMA, but 176 VGPRs = two waves per SIMD and 70 KB
+// of LDS -- measured 1.9 x SLOWER than KT = 64 (gpurun r05r: 14.3 vs 7.6 ms at C3's shape): occupancy is what hides the latency here.
+template <int METRIC, int BR, int KT>
 __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a) {
+  constexpr int FW_KT = KT, FW_LS = KT + 8, HK = KT / 2, NU = KT / 16;      // a staging thread moves HK elements = NU 16-byte pieces of a row
   constexpr int FW_TM = 64 * BR;
   __shared__ __attribute__((aligned(16))) uint16_t Xs[FW_TM * FW_LS];
   __shared__ __attribute__((aligned(16))) uint16_t Qs[FW_TN * FW_LS];
@@ -148,17 +152,17 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     tqs[threadIdx.x] = t;
   }
 
-  // staging: thread (r, h) moves 32 elements (64 bytes) of query r and of the rows r, r + 128, .. per stage
+  // staging: thread (r, h) moves half a stage (HK elements) of query r and of the rows r, r + 128, .. per stage
   const int sr = threadIdx.x >> 1, sh = threadIdx.x & 1;
   constexpr int XR = FW_TM / 128;      // rows per thread and stage
   const bool qrow_ok = q0 + sr < p.nq;
-  const uint16_t *xsrc = a.xb + (row0 + sr) * (int64_t)d + sh * 32;
-  const uint16_t *qsrc = a.qb + (int64_t)(q0 + sr) * d + sh * 32;
-  uint4 px[XR][4], pq[4];
+  const uint16_t *xsrc = a.xb + (row0 + sr) * (int64_t)d + sh * HK;
+  const uint16_t *qsrc = a.qb + (int64_t)(q0 + sr) * d + sh * HK;
+  uint4 px[XR][NU], pq[NU];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool in = k0 + sh * 32 + u * 8 < d;      // d % 8 == 0: a 16-byte piece is inside or outside
+    for (int u = 0; u < NU; ++u) {
+      const bool in = k0 + sh * HK + u * 8 < d;      // d % 8 == 0: a 16-byte piece is inside or outside
 #pragma unroll
       for (int xr = 0; xr < XR; ++xr)
         px[xr][u] = (row0 + sr + 128 * xr < p.r1 && in) ? *reinterpret_cast<const uint4 *>(xsrc + (int64_t)(128 * xr) * d + k0 + u * 8) : make_uint4(0, 0, 0, 0);
@@ -167,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
   };
   auto store = [&]() {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
 #pragma unroll
-      for (int xr = 0; xr < XR; ++xr) *reinterpret_cast<uint4 *>(&Xs[(sr + 128 * xr) * FW_LS + sh * 32 + u * 8]) = px[xr][u];
-      *reinterpret_cast<uint4 *>(&Qs[sr * FW_LS + sh * 32 + u * 8]) = pq[u];
+      for (int xr = 0; xr < XR; ++xr) *reinterpret_cast<uint4 *>(&Xs[(sr + 128 * xr) * FW_LS + sh * HK + u * 8]) = px[xr][u];
+      *reinterpret_cast<uint4 *>(&Qs[sr * FW_LS + sh * HK + u * 8]) = pq[u];
     }
   };
 
@@ -350,20 +354,23 @@ int launch_flat_filter_mfma_wide(lance_hip_ctx *ctx, const FlatPool &e, int d, i
              (long long)rows, e.nq);
   const dim3 grid((unsigned)nblocks, 1, 1);
   ScopedTimer t(ctx, "flat_mfma_wide");
-  auto go = [&](auto br_tag) {
-    constexpr int BR = decltype(br_tag)::value;
+  auto go = [&](auto br_tag, auto kt_tag) {
+    constexpr int BR = decltype(br_tag)::value, KT = decltype(kt_tag)::value;
     if (metric == METRIC_COSINE) {
-      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_COSINE, BR>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_COSINE, BR, KT>), grid, dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_COSINE>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
     } else if (metric == METRIC_DOT) {
-      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_DOT, BR>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_DOT, BR, KT>), grid, dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_DOT>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
     } else {
-      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_L2, BR>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_L2, BR, KT>), grid, dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_L2>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
     }
   };
-  if (br == 4) go(std::integral_constant<int, 4>()); else go(std::integral_constant<int, 2>());
+  typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4;
+  typedef std::integral_constant<int, 64> K64;
+  if (br == 4) go(I4(), K64());
+  else go(I2(), K64());
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
