@@ -44,7 +44,7 @@ namespace lh {
 typedef short fw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float fw_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FW_TN = 128;            // queries per workgroup tile (rows per tile: 64 x BR, BR = 32-row blocks per wave: template parameter)
+// workgroup tile: 64 x BR rows by 64 x BQ queries (BR / BQ = 32-row / 32-query blocks per wave: template parameters; four waves, 2 x 2)
 // elements of d per stage: template parameter KT (64 / 128); LDS row stride KT + 8 bf16 elements (144 / 272 bytes: conflict-free ds_read_b128)
 constexpr int FW_SQ_CAP = 2048;       // queued rows per query and epoch
 constexpr float FW_EW = 0.0045f;
@@ -106,10 +106,10 @@ struct FwArgs {
 // stage of matrix work is all that covers their latency, and the SQ counters show the waves stalled or parked 83 % of the time
 // (profiles/r05q_*).  KT = 128 -- twice the work behind every load, half the barriers per MFMA, but 176 VGPRs = two waves per SIMD and 70 KB
 // of LDS -- measured 1.9 x SLOWER than KT = 64 (gpurun r05r: 14.3 vs 7.6 ms at C3's shape): occupancy is what hides the latency here.
-template <int METRIC, int BR, int KT>
+template <int METRIC, int BR, int KT, int BQ = 2>
 __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a) {
   constexpr int FW_KT = KT, FW_LS = KT + 8, HK = KT / 2, NU = KT / 16;      // a staging thread moves HK elements = NU 16-byte pieces of a row
-  constexpr int FW_TM = 64 * BR;
+  constexpr int FW_TM = 64 * BR, FW_TN = 64 * BQ;
   __shared__ __attribute__((aligned(16))) uint16_t Xs[FW_TM * FW_LS];
   __shared__ __attribute__((aligned(16))) uint16_t Qs[FW_TN * FW_LS];
   __shared__ __attribute__((aligned(16))) float tqs[FW_TN];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
   // staging: thread (r, h) moves half a stage (HK elements) of query r and of the rows r, r + 128, .. per stage
   const int sr = threadIdx.x >> 1, sh = threadIdx.x & 1;
   constexpr int XR = FW_TM / 128;      // rows per thread and stage
-  const bool qrow_ok = q0 + sr < p.nq;
+  const bool qrow_ok = sr < FW_TN && q0 + sr < p.nq;
   const uint16_t *xsrc = a.xb + (row0 + sr) * (int64_t)d + sh * HK;
   const uint16_t *qsrc = a.qb + (int64_t)(q0 + sr) * d + sh * HK;
   uint4 px[XR][NU], pq[NU];
@@ -174,15 +174,15 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
       for (int xr = 0; xr < XR; ++xr) *reinterpret_cast<uint4 *>(&Xs[(sr + 128 * xr) * FW_LS + sh * HK + u * 8]) = px[xr][u];
-      *reinterpret_cast<uint4 *>(&Qs[sr * FW_LS + sh * HK + u * 8]) = pq[u];
+      if (sr < FW_TN) *reinterpret_cast<uint4 *>(&Qs[sr * FW_LS + sh * HK + u * 8]) = pq[u];
     }
   };
 
-  fw_f32x16 acc[BR][2];
+  fw_f32x16 acc[BR][BQ];
 #pragma unroll
   for (int bi = 0; bi < BR; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
+    for (int bj = 0; bj < BQ; ++bj)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[bi][bj][v] = 0.0f;
 
@@ -194,15 +194,15 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     if (more) fetch(k0 + FW_KT);
 #pragma unroll
     for (int s = 0; s < FW_KT / 16; ++s) {
-      fw_bf16x8 aq[2], bx[BR];
+      fw_bf16x8 aq[BQ], bx[BR];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) aq[b] = *reinterpret_cast<const fw_bf16x8 *>(&Qs[(wq * 64 + b * 32 + j) * FW_LS + s * 16 + g * 8]);
+      for (int b = 0; b < BQ; ++b) aq[b] = *reinterpret_cast<const fw_bf16x8 *>(&Qs[(wq * 32 * BQ + b * 32 + j) * FW_LS + s * 16 + g * 8]);
 #pragma unroll
       for (int b = 0; b < BR; ++b) bx[b] = *reinterpret_cast<const fw_bf16x8 *>(&Xs[(wr * 32 * BR + b * 32 + j) * FW_LS + s * 16 + g * 8]);
 #pragma unroll
       for (int bi = 0; bi < BR; ++bi)
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[bj], bx[bi], acc[bi][bj], 0, 0, 0);
+        for (int bj = 0; bj < BQ; ++bj) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[bj], bx[bi], acc[bi][bj], 0, 0, 0);
     }
     __syncthreads();      // every wave has read this stage
     if (more) store();
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     }
     float mn = INFINITY;
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const float *tqb = tqs + wq * 64 + bj * 32 + 4 * g;
+    for (int bj = 0; bj < BQ; ++bj) {
+      const float *tqb = tqs + wq * 32 * BQ + bj * 32 + 4 * g;
 #pragma unroll
       for (int vq = 0; vq < 4; ++vq) {
         const f4 t4 = *reinterpret_cast<const f4 *>(tqb + 8 * vq);
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
     }
     if ((mn <= 0.0f || odd) && rvalid) {      // rare per lane: find the pairs, queue the row for each of their queries
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
-        const float *tqb = tqs + wq * 64 + bj * 32 + 4 * g;
+      for (int bj = 0; bj < BQ; ++bj) {
+        const float *tqb = tqs + wq * 32 * BQ + bj * 32 + 4 * g;
 #pragma unroll
         for (int vq = 0; vq < 4; ++vq) {
           const f4 t4 = *reinterpret_cast<const f4 *>(tqb + 8 * vq);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
             if constexpr (METRIC == METRIC_COSINE) sv = __builtin_fmaf(t4[e], xk, -dot);
             else if constexpr (METRIC == METRIC_DOT) sv = (xk - t4[e]) - dot;
             else sv = __builtin_fmaf(-2.0f, dot, xk - t4[e]);
-            const int qi = q0 + wq * 64 + bj * 32 + 8 * vq + 4 * g + e;
+            const int qi = q0 + wq * 32 * BQ + bj * 32 + 8 * vq + 4 * g + e;
             if (qi < p.nq && (odd ? !(sv > 0.0f) : (sv <= 0.0f))) {
               const uint32_t pos = atomicAdd(&a.scnt[qi], 1u);
               if (pos < (uint32_t)FW_SQ_CAP) a.squeue[(int64_t)qi * FW_SQ_CAP + pos] = (uint32_t)(row - p.r0);
@@ -345,32 +345,34 @@ int launch_flat_filter_mfma_wide(lance_hip_ctx *ctx, const FlatPool &e, int d, i
   if (!a.scnt || !a.squeue) return LANCE_HIP_ENOMEM;
   LH_CHECK_HIP(lh::memset_async(a.scnt, 0, (size_t)e.nq * 4, ctx->stream));
   static const int br_env = getenv("LANCE_HIP_FW_BR") ? atoi(getenv("LANCE_HIP_FW_BR")) : 0;      // A/B: 32-row blocks per wave (2 / 4)
+  static const int bq_env = getenv("LANCE_HIP_FW_BQ") ? atoi(getenv("LANCE_HIP_FW_BQ")) : 0;      // A/B: 32-query blocks per wave (1 / 2)
   const int br = br_env == 2 || br_env == 4 ? br_env : 2;      // (4 measured no faster, gpurun r05n: the operand traffic was not the bound)
+  const int bq = (bq_env == 1 || bq_env == 2) && br == 2 ? bq_env : 2;
   const uint64_t rblocks = cdiv((uint64_t)rows, (uint64_t)(64 * br));
-  a.nqt = (uint32_t)cdiv((uint64_t)e.nq, FW_TN);
+  a.nqt = (uint32_t)cdiv((uint64_t)e.nq, (uint64_t)(64 * bq));
   a.nrt = (uint32_t)rblocks;
   const uint64_t nblocks = cdiv(rblocks, 8) * 8 * a.nqt;
   LH_REQUIRE(nblocks < (1ull << 31), "flat scan: an epoch of %lld rows x %d queries exceeds the grid of the long-row matrix-core filter",
              (long long)rows, e.nq);
   const dim3 grid((unsigned)nblocks, 1, 1);
   ScopedTimer t(ctx, "flat_mfma_wide");
-  auto go = [&](auto br_tag, auto kt_tag) {
-    constexpr int BR = decltype(br_tag)::value, KT = decltype(kt_tag)::value;
+  auto go = [&](auto br_tag, auto bq_tag) {
+    constexpr int BR = decltype(br_tag)::value, BQ = decltype(bq_tag)::value;
     if (metric == METRIC_COSINE) {
-      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_COSINE, BR, KT>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_COSINE, BR, 64, BQ>), grid, dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_COSINE>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
     } else if (metric == METRIC_DOT) {
-      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_DOT, BR, KT>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_DOT, BR, 64, BQ>), grid, dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_DOT>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
     } else {
-      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_L2, BR, KT>), grid, dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL((flat_filter_mfma_wide_kernel<METRIC_L2, BR, 64, BQ>), grid, dim3(256), 0, ctx->stream, a);
       hipLaunchKernelGGL((flat_wide_eval_kernel<METRIC_L2>), dim3(e.nq), dim3(256), 0, ctx->stream, a);
     }
   };
-  typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4;
-  typedef std::integral_constant<int, 64> K64;
-  if (br == 4) go(I4(), K64());
-  else go(I2(), K64());
+  typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4;
+  if (br == 4) go(I4(), I2());
+  else if (bq == 1) go(I2(), I1());
+  else go(I2(), I2());
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
