@@ -44,7 +44,9 @@ namespace lh {
 typedef short fw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float fw_f32x16 __attribute__((ext_vector_type(16)));
 
-// workgroup tile: 64 x BR rows by 64 x BQ queries (BR / BQ = 32-row / 32-query blocks per wave: template parameters; four waves, 2 x 2)
+// workgroup tile: 64 x BR rows by 64 x BQ queries (BR / BQ = 32-row / 32-query blocks per wave: template parameters; four waves, 2 x 2).
+// Measured at C3's shape (1000 queries x 1M x 1536, filter ms per call; gpurun r05n / r05r / r05t): BR x BQ = 2 x 2 (144 VGPRs, three waves
+// per SIMD) 7.7; 4 x 2 (236 VGPRs, two waves) 7.7; 2 x 1 (104 VGPRs, four waves) 9.3; 2 x 2 with 128-element stages (176 VGPRs, two waves) 14.3.
 // elements of d per stage: template parameter KT (64 / 128); LDS row stride KT + 8 bf16 elements (144 / 272 bytes: conflict-free ds_read_b128)
 constexpr int FW_SQ_CAP = 2048;       // queued rows per query and epoch
 constexpr float FW_EW = 0.0045f;
