@@ -34,14 +34,14 @@
 namespace lh {
 
 // one lane per (centroid, dim): sequential row-order sum, then *= 1/count (kmeans.rs:388-418)
-__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__restrict__ x, int64_t ldx, int x_batch_off,
-                                                                int d, int k, const uint32_t *__restrict__ sorted_rows,
-                                                                int64_t rows_stride, const uint32_t *__restrict__ starts,
-                                                                float *__restrict__ cent, int64_t cent_batch_stride,
-                                                                const uint8_t *__restrict__ active, int scale, int f16) {
+__device__ __forceinline__ void kmeans_accumulate_body(int bx, const float *__restrict__ x, int64_t ldx, int x_batch_off,
+                                                       int d, int k, const uint32_t *__restrict__ sorted_rows,
+                                                       int64_t rows_stride, const uint32_t *__restrict__ starts,
+                                                       float *__restrict__ cent, int64_t cent_batch_stride,
+                                                       const uint8_t *__restrict__ active, int scale, int f16) {
   const int b = blockIdx.y;
   if (active && !active[b]) return;
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t g = (int64_t)bx * 256 + threadIdx.x;
   if (g >= (int64_t)k * d) return;
   const int c = (int)(g / d), dim = (int)(g % d);
   const uint32_t *st = starts + (int64_t)b * (k + 1);
@@ -83,20 +83,26 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
   }
   cent[(int64_t)b * cent_batch_stride + (int64_t)c * d + dim] = acc;
 }
+__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__restrict__ x, int64_t ldx, int x_batch_off,
+                                                                int d, int k, const uint32_t *__restrict__ sorted_rows,
+                                                                int64_t rows_stride, const uint32_t *__restrict__ starts,
+                                                                float *__restrict__ cent, int64_t cent_batch_stride,
+                                                                const uint8_t *__restrict__ active, int scale, int f16) {
+  kmeans_accumulate_body((int)blockIdx.x, x, ldx, x_batch_off, d, k, sorted_rows, rows_stride, starts, cent, cent_batch_stride, active, scale, f16);
+}
 
 // one WAVE per centroid: the 64 lanes fetch 64 member distances at a time (two dependent loads, but 64 wide),
 // lane 0 then adds them in row order -- the f64 chain of kmeans.rs:274-277 is kept, only its operands are
 // fetched in parallel.  (One lane per centroid spent 70 us per iteration on 2 x 32 serial memory round trips.)
-__global__ __launch_bounds__(256) void kmeans_stats_kernel(const float *__restrict__ dists, int64_t dist_stride, int k,
-                                                           const uint32_t *__restrict__ sorted_rows, int64_t rows_stride,
-                                                           const uint32_t *__restrict__ starts, double *__restrict__ losses,
-                                                           float *__restrict__ radius, uint32_t *__restrict__ last_row,
-                                                           const uint8_t *__restrict__ active) {
-  __shared__ __attribute__((aligned(16))) float buf[4][2][64];
+__device__ __forceinline__ void kmeans_stats_body(int bx, float (*buf)[2][64], const float *__restrict__ dists, int64_t dist_stride, int k,
+                                                  const uint32_t *__restrict__ sorted_rows, int64_t rows_stride,
+                                                  const uint32_t *__restrict__ starts, double *__restrict__ losses,
+                                                  float *__restrict__ radius, uint32_t *__restrict__ last_row,
+                                                  const uint8_t *__restrict__ active) {
   const int b = blockIdx.y;
   if (active && !active[b]) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 4 + wave;
+  const int c = bx * 4 + wave;
   if (c >= k) return;
   const uint32_t *st = starts + (int64_t)b * (k + 1);
   const uint32_t *rows = sorted_rows + (int64_t)b * rows_stride;
@@ -133,6 +139,33 @@ __global__ __launch_bounds__(256) void kmeans_stats_kernel(const float *__restri
     radius[(int64_t)b * k + c] = rad;
     last_row[(int64_t)b * k + c] = e > s ? rows[e - 1] : 0xFFFFFFFFu;
   }
+}
+__global__ __launch_bounds__(256) void kmeans_stats_kernel(const float *__restrict__ dists, int64_t dist_stride, int k,
+                                                           const uint32_t *__restrict__ sorted_rows, int64_t rows_stride,
+                                                           const uint32_t *__restrict__ starts, double *__restrict__ losses,
+                                                           float *__restrict__ radius, uint32_t *__restrict__ last_row,
+                                                           const uint8_t *__restrict__ active) {
+  __shared__ __attribute__((aligned(16))) float buf[4][2][64];
+  kmeans_stats_body((int)blockIdx.x, buf, dists, dist_stride, k, sorted_rows, rows_stride, starts, losses, radius, last_row, active);
+}
+
+// The trainer's M-step in ONE launch: blocks [0, acc_blocks) are kmeans_accumulate_kernel's, the rest kmeans_stats_kernel's (they read the
+// same member lists and are independent of each other; a launch less per Lloyd iteration: the build is bound by its kernel boundaries).
+struct KmMstepArgs {
+  const float *x; int64_t ldx; int x_batch_off, d, k;
+  const uint32_t *sorted_rows; int64_t rows_stride; const uint32_t *starts;
+  float *cent; int64_t cent_batch_stride; const uint8_t *active; int scale, f16;
+  const float *dists; int64_t dist_stride; double *losses; float *radius; uint32_t *last_row;
+  int acc_blocks;
+};
+__global__ __launch_bounds__(256) void kmeans_mstep_kernel(KmMstepArgs a) {
+  __shared__ __attribute__((aligned(16))) float buf[4][2][64];
+  if ((int)blockIdx.x < a.acc_blocks)
+    kmeans_accumulate_body((int)blockIdx.x, a.x, a.ldx, a.x_batch_off, a.d, a.k, a.sorted_rows, a.rows_stride, a.starts, a.cent, a.cent_batch_stride, a.active,
+                           a.scale, a.f16);
+  else
+    kmeans_stats_body((int)blockIdx.x - a.acc_blocks, buf, a.dists, a.dist_stride, a.k, a.sorted_rows, a.rows_stride, a.starts, a.losses, a.radius,
+                      a.last_row, a.active);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, int64_t ldx, int x_batch_off, int d,
@@ -378,10 +411,12 @@ int kmeans_train_batched(lance_hip_ctx *ctx, int metric, const float *x, int64_t
     LH_TRY(stable_group(ctx, ids, n, n, k, B, starts, sorted_rows, n, active_d));
     {
       ScopedTimer t(ctx, "kmeans_mstep");
-      hipLaunchKernelGGL(kmeans_stats_kernel, dim3((unsigned)cdiv(k, 4), B), dim3(256), 0, ctx->stream, dists, n, k,
-                         sorted_rows, n, starts, losses_d, radius_d, last_d, active_d);
-      hipLaunchKernelGGL(kmeans_accumulate_kernel, dim3((unsigned)cdiv((uint64_t)k * d, 256), B), dim3(256), 0, ctx->stream,
-                         x, ldx, x_batch_off, d, k, sorted_rows, n, starts, cent, (int64_t)k * d, active_d, 1, f16_arith ? 1 : 0);
+      KmMstepArgs ma;
+      ma.x = x; ma.ldx = ldx; ma.x_batch_off = x_batch_off; ma.d = d; ma.k = k; ma.sorted_rows = sorted_rows; ma.rows_stride = n; ma.starts = starts;
+      ma.cent = cent; ma.cent_batch_stride = (int64_t)k * d; ma.active = active_d; ma.scale = 1; ma.f16 = f16_arith ? 1 : 0;
+      ma.dists = dists; ma.dist_stride = n; ma.losses = losses_d; ma.radius = radius_d; ma.last_row = last_d;
+      ma.acc_blocks = (int)cdiv((uint64_t)k * d, 256);
+      hipLaunchKernelGGL(kmeans_mstep_kernel, dim3((unsigned)(ma.acc_blocks + (int)cdiv(k, 4)), B), dim3(256), 0, ctx->stream, ma);
       hipLaunchKernelGGL(kmeans_control_kernel, dim3(B), dim3(256), (size_t)k * 16, ctx->stream, ctl);
     }
     LH_CHECK_HIP(hipGetLastError());
