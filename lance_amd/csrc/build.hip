@@ -538,6 +538,7 @@ int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw)
     idx->raw_u8 = nullptr;
   }
   idx->raw_compact_state = 0;
+  ++idx->raw_gen;      // a captured search of the previous attachment must not be replayed (same pointer, new contents; the freed u8 copy)
   return LANCE_HIP_OK;
 }
 

@@ -60,6 +60,7 @@ struct lance_hip_index {
   // bytes of the random row reads that bound it, the same f32 values after widening, hence the same bits out.  Created by the first
   // refining search of the index or by lance_hip_index_prewarm; dropped by lance_hip_index_set_raw.  Guarded by lazy_mu.
   uint8_t *raw_u8 = nullptr;
+  uint64_t raw_gen = 0;           // bumped by every lance_hip_index_set_raw: captured search graphs are keyed on it (they hold raw / raw_u8 pointers)
   int raw_compact_state = 0;      // 0: not tried yet; 1: raw_u8 holds the column; -1: the column is not representable (or no memory for the copy)
   uint32_t max_part = 0;
   uint32_t code_bytes() const { return nbits == 4 ? m / 2 : m; }   // bytes of PQ code per row

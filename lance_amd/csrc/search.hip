@@ -1260,11 +1260,11 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   if (!on || ctx->timing || nq == 0 || ix->ephemeral)      // ephemeral: the one-call index of lance_hip_pq_scan_topk
     return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow);
   struct Key {
-    const void *ix; uint64_t serial; const void *raw; uint64_t n_raw; const void *q, *ids, *dists, *allow;
+    const void *ix; uint64_t serial; const void *raw; uint64_t n_raw, raw_gen; const void *q, *ids, *dists, *allow;
     uint32_t nq, k, nprobes, rf; int has_range; float lo, hi;
   } key;
   memset(&key, 0, sizeof(key));
-  key.ix = ix; key.serial = ix->serial; key.raw = ix->raw; key.n_raw = ix->n_raw; key.q = q; key.ids = ids; key.dists = dists; key.allow = allow;
+  key.ix = ix; key.serial = ix->serial; key.raw = ix->raw; key.n_raw = ix->n_raw; key.raw_gen = ix->raw_gen; key.q = q; key.ids = ids; key.dists = dists; key.allow = allow;
   key.nq = nq; key.k = k; key.nprobes = nprobes; key.rf = refine_factor; key.has_range = has_range; key.lo = lower; key.hi = upper;
   const std::string ks(reinterpret_cast<const char *>(&key), sizeof(key));
   auto plain = [&]() { return ivfpq_search_enqueue_impl(ctx, ix, q, nq, k, nprobes, refine_factor, has_range, lower, upper, ids, dists, flags_out, allow); };

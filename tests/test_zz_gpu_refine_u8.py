@@ -166,3 +166,33 @@ def test_u8_refine_through_captured_graphs(eng, oracle):
         _equal(gi, gd, oi, od, f"rep {rep}")
     assert replays() - r0 >= 3, "the repeated call was not replayed as a graph"
     gidx.close()
+
+
+def test_set_raw_with_the_same_pointer_invalidates_captured_graphs(eng, oracle):
+    """A caller re-attaches the SAME device buffer after changing its contents: the captured searches of the first attachment hold the
+    address of a u8 copy that set_raw has freed -- they must not be replayed (the graph key carries the attachment's generation)."""
+    import torch
+    from lance_amd.engine import DeviceIndex
+    n, d, m, nlist, nq = 8000, 128, 16, 8, 256
+    x = clustered(n, d, 51)
+    cent, cb = _models(oracle, x, nlist, m, "l2", seed=12)
+    oidx = oracle.build_index(x, cent, cb, "l2")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "l2")
+    xt = torch.from_numpy(x).cuda()
+    gidx = DeviceIndex.create(eng, "l2", cent, cb, gpart, gcodes, None, raw=xt)
+    q = clustered(nq, d, 52)
+    qbuf = torch.from_numpy(q).cuda()
+    out = (torch.empty((nq, 10), dtype=torch.int64, device="cuda"), torch.empty((nq, 10), dtype=torch.float32, device="cuda"))
+    replays = lambda: eng.timing_query("count:graph_replay")[1]
+    for contents in (x, np.clip(x + f32(2.0), 0, 255).astype(f32), x + f32(0.5)):      # u8, u8 (other values), not representable
+        xt.copy_(torch.from_numpy(contents))
+        gidx.set_raw(xt)                                       # the same tensor, hence the same pointer
+        oi, od = oidx.search(q, 10, 4, refine=10, raw=contents)
+        r0 = replays()
+        for rep in range(4):
+            out[0].fill_(-7); out[1].fill_(-7.0)
+            gi, gd = gidx.search(qbuf, 10, 4, 10, out=out)
+            torch.cuda.synchronize()
+            _equal(gi, gd, oi, od, f"rep {rep}")
+        assert replays() - r0 >= 2, "the repeated call was not replayed as a graph"
+    gidx.close()
