@@ -397,3 +397,18 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+def test_pq_training_sample_is_a_pure_function_of_n_and_params():
+    """create_index draws the PQ training sample on a host thread while the IVF k-means runs on the device (vector.py:
+    pq_sample_indices): the rows must be exactly the ones train_pq_codebook would draw itself -- same generator, same call."""
+    from concurrent.futures import ThreadPoolExecutor
+    from lance_amd import vector as lv
+    p = lv.IvfPqParams(8, 4, 8, "l2", 5, 256, 7)
+    want = lv._sample_rows(200_000, 256 * 256, np.random.default_rng(p.seed + 1))
+    got = lv.pq_sample_indices(200_000, p)
+    assert got.dtype == want.dtype and (got == want).all() and (np.diff(got) > 0).all()
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        fut = pool.submit(lv.pq_sample_indices, 200_000, p)
+        assert (fut.result() == want).all()
+    assert lv.pq_sample_indices(1000, p) is None            # a table smaller than the sample: all rows
