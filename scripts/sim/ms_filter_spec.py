@@ -21,6 +21,9 @@ per-pair slack units ceil(E s 1.1 + 3) the merge kernel's cut carries; (iii) sel
 Pairs the pre-pass hands to the exact rescan (residual beyond binary16, slack above 5 % of T) are counted, not filtered.
 The accumulation is done in two orders (ascending k, and pairwise tree) -- the bound must hold for any.
 
+Round 5: `run_bound` does the same for the bound pass on the matrix cores (ms_bound_kernel): histogram of dist~ over the query's nearest
+partition, T = (upper edge of the keff-th bin) + 1.1 E -- checked: T is never below the keff-th smallest reference distance.
+
     python scripts/sim/ms_filter_spec.py
 """
 import ctypes as C
@@ -178,6 +181,101 @@ def run(name, x, q, m, nlist, keff=100, nprobes=4, max_pairs=200, seed=0, verbos
     return tot
 
 
+def bound_T(r, rows_h, cn2_rows, sigma, cb_mean, nu, d, keff, order="seq"):
+    """ms_bound_kernel for one (query, nearest partition): returns (T, Ta, E) or None when the pass gives the query no bound.
+    r: f32 residual; rows_h: [rows][d] binary16 reconstruction operand (-2 sigma c); cn2_rows: f32 sigma^2 |c^|^2 per row;
+    cb_mean: [d] mean codeword of every sub-quantiser dimension; nu: sum over m of the mean |c|^2 (lance_hip_index::cb_mean)."""
+    r = r.astype(f32)
+    n2 = f32(0.0)
+    rmu = f32(0.0)
+    for e in range(d):      # (the kernel sums lane pairs then a xor tree: any order serves -- the scale only sets tightness, n2 enters E through its own slack)
+        n2 = f32(n2 + f32(r[e] * r[e]))
+        rmu = f32(rmu + f32(r[e] * cb_mean[e]))
+    vmax = f32(np.max(np.abs(r)))
+    mean = f32(f32(n2 - f32(2.0) * rmu) + nu)
+    if not (np.isfinite(n2) and vmax * sigma < 60000.0 and mean > 0 and np.isfinite(mean)):
+        return None
+    sb = f32(f32(496.0) / mean)
+    sig2 = f32(sigma * sigma)
+    a = f32(sb / sig2)
+    b = f32(n2 * sb)
+    if not (sb > 0 and np.isfinite(sb) and a > 0 and np.isfinite(a) and n2 * sb < 1e30):
+        return None
+    rh = (r * sigma).astype(f32).astype(f16)
+    acc = mfma_acc(np.zeros(rows_h.shape[0], f32), rows_h, rh, order)
+    t = ((acc + cn2_rows).astype(f32).astype(f64) * f64(a) + f64(b)).astype(f32)      # one FMA: a single rounding of the exact product-sum
+    inb = t < f32(512.0)
+    bins = np.maximum(t[inb].astype(np.int64), 0)      # (int) truncation; negative values land in bin 0
+    hist = np.bincount(bins, minlength=512)
+    cum = np.cumsum(hist)
+    hit = np.nonzero(cum >= keff)[0]
+    if hit.size == 0:
+        return None
+    binb = int(hit[0])
+    Ta = f32(f32(f32(binb + 1) / sb) * f32(1.000001))
+    rn = f32(np.sqrt(n2, dtype=f32) * f32(1.000001))
+    st = f32(np.sqrt(Ta, dtype=f32) * f32(1.000001))
+    sqd = f32(np.sqrt(f32(d), dtype=f32) + f32(1.0))
+    e_abs = f32(f32(6.1035156e-5) * sqd * (f32(3.0) * rn + f32(2.0) * st) / sigma + f32(d) * f32(3.7252903e-9) / (sigma * sigma))
+    E = f32(f32(1.05) * (f32(1.9921875e-3) * rn * (rn + st) + f32(1.2207031e-4) * (n2 + Ta)) + e_abs)
+    T = f32(f32(Ta + f32(1.1) * E) * f32(1.0000153))
+    return T, Ta, E
+
+
+def run_bound(name, x, q, m, nlist, keff=100, max_queries=150, seed=0, verbose=True):
+    """The bound pass on the matrix cores (ms_bound_kernel): T must be >= the keff-th smallest REFERENCE distance of the query's nearest
+    partition (then it bounds the final keff-th distance over all probed partitions too); reports how loose it is."""
+    n, d = x.shape
+    sd = d // m
+    cent, _, _, _ = oracle.kmeans_train(x[: min(n, nlist * 256)], nlist, max_iters=6, seed=1)
+    part, _ = oracle.assign(x, cent)
+    res = oracle.residual(x, cent, part)
+    cb, _ = oracle.pq_train(res[: min(n, 65536)], m, max_iters=5, seed=2)
+    cb = np.ascontiguousarray(np.asarray(cb, f32).reshape(m, 256, sd))
+    codes = np.asarray(oracle.pq_encode(res, cb, "l2")).reshape(n, m)
+    cbmax = float(np.max(np.abs(cb)))
+    sigma = f32(np.ldexp(1.0, 13 - int(np.frexp(cbmax)[1])))
+    cbh = (cb * f32(-2.0) * sigma).astype(f32).astype(f16)
+    cbn2 = np.zeros((m, 256), f32)
+    for u in range(sd):
+        cbn2 = (cbn2 + (cb[:, :, u] * cb[:, :, u]).astype(f32)).astype(f32)
+    row_cn2 = np.zeros(n, f32)
+    for mm in range(m):
+        row_cn2 = (row_cn2 + cbn2[mm, codes[:, mm]]).astype(f32)
+    row_cn2 = (row_cn2 * f32(sigma * sigma)).astype(f32)
+    rows_h = cbh[np.arange(m)[None, :], codes].reshape(n, d)
+    cb_mean = cb.mean(axis=1).astype(f32).reshape(d)                    # q_codebook_mean_kernel: mean codeword per sub-quantiser dimension
+    nu = f32(np.sum((cb.astype(f64) ** 2).sum(axis=2).mean(axis=1)))   # sum over m of the mean |c|^2
+    probes, _ = oracle.find_partitions(q, cent, 1)
+    rng = np.random.default_rng(seed)
+    tot = dict(queries=0, no_bound=0, violations=0, worst_ratio=0.0, mean_ratio=0.0)
+    for qi in rng.permutation(len(q))[:max_queries]:
+        p0 = int(probes[qi, 0])
+        rows = np.nonzero(part == p0)[0]
+        if len(rows) < keff:
+            continue
+        r = (q[qi] - cent[p0]).astype(f32)
+        dref = ref_adc(ref_lut(r, cb, m, d), codes[rows])
+        true_k = float(np.partition(dref, keff - 1)[keff - 1])
+        tot["queries"] += 1
+        for order in ("seq", "tree"):
+            out = bound_T(r, rows_h[rows], row_cn2[rows], sigma, cb_mean, nu, d, keff, order)
+            if out is None:
+                tot["no_bound"] += order == "seq"
+                continue
+            T = float(out[0])
+            tot["violations"] += int(not (T >= true_k))
+            if order == "seq" and true_k > 0:
+                tot["worst_ratio"] = max(tot["worst_ratio"], T / true_k)
+                tot["mean_ratio"] += T / true_k
+    if tot["queries"] > tot["no_bound"]:
+        tot["mean_ratio"] /= (tot["queries"] - tot["no_bound"])
+    if verbose:
+        print(f"{name} [bound pass]: queries={tot['queries']} without a bound={tot['no_bound']} T below the true keff-th distance={tot['violations']} "
+              f"T / true: mean {tot['mean_ratio']:.4f} worst {tot['worst_ratio']:.4f}")
+    return tot
+
+
 def sift_like(n, d, seed):
     rng = np.random.default_rng(seed)
     centers = rng.uniform(0, 128, (64, d))
@@ -199,6 +297,11 @@ def main():
     run("rows far from the origin (|r|^2 >> T for far probes)", x + f32(3000.0), q + f32(3000.0), 16, 16)
     x64 = sift_like(30000, 64, 5)
     run("d=64 M=16", x64, sift_like(200, 64, 6), 16, 12)
+    run_bound("sift-like integer rows", x, q, 16, 16)
+    run_bound("sift-like, M=32", x, q, 32, 16)
+    run_bound("unit vectors", xu.astype(f32), qu.astype(f32), 16, 16)
+    run_bound("rows far from the origin", x + f32(3000.0), q + f32(3000.0), 16, 16)
+    run_bound("d=64 M=16", x64, sift_like(200, 64, 6), 16, 12, keff=10)
 
 
 if __name__ == "__main__":

@@ -49,3 +49,24 @@ def test_unit_vectors_and_far_queries(spec):
         t = spec.run("far", xi, qf, 16, 8, keff=60, nprobes=3, max_pairs=45, seed=2, verbose=False)
     assert t["violations"] == 0 and t["sum_violations"] == 0
     assert t["handed"] > 0 and t["must"] > 500
+
+
+@pytest.mark.parametrize("d,m,keff", [(128, 16, 100), (128, 32, 60), (64, 16, 10)])
+def test_bound_pass_never_undershoots_the_keff_th_distance(spec, d, m, keff):
+    """ms_bound_kernel (round 5): T = (upper edge of the histogram bin where the count of dist~ reaches keff) + 1.1 E must be >= the keff-th
+    smallest REFERENCE distance of the query's nearest partition, for either accumulation order of the f16 products -- and stay a bound
+    worth having (within 2 % of it)."""
+    x = spec.sift_like(12000, d, 31 + d + m)
+    q = spec.sift_like(150, d, 32 + d + m)
+    t = spec.run_bound(f"d={d} M={m}", x, q, m, 8, keff=keff, max_queries=60, seed=d + m, verbose=False)
+    assert t["queries"] >= 50 and t["no_bound"] == 0
+    assert t["violations"] == 0
+    assert 1.0 <= t["mean_ratio"] <= 1.02 and t["worst_ratio"] <= 1.03
+
+
+def test_bound_pass_gives_no_bound_to_residuals_beyond_binary16(spec):
+    xi = spec.sift_like(12000, 128, 41)
+    qf = spec.sift_like(60, 128, 42) * f32(8.0)      # sigma |r| leaves binary16: the kernel must decline (class B: exact pair kernel), not guess
+    with np.errstate(over="ignore"):
+        t = spec.run_bound("far", xi, qf, 16, 8, keff=60, max_queries=40, seed=3, verbose=False)
+    assert t["queries"] >= 30 and t["violations"] == 0 and t["no_bound"] == t["queries"]
