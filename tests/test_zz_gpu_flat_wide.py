@@ -138,3 +138,28 @@ def test_many_query_chunks(eng, oracle):
     rng = np.random.default_rng(13)
     x, q = _data(rng, 12_000, 2048 + 200, 192)
     _check(eng, oracle, x, q, 10, "cosine", tag="chunks")
+
+
+def test_aligned_rounding_errors_do_not_drop_neighbours(eng, oracle):
+    """The filter's worst case (tests/test_flat_wide_spec.py): every element half an ulp below a bfloat16 rounding boundary, all positive,
+    rows nearly parallel to their query -- each product errs by -2^-7 of itself and nothing cancels, so x~.q~ is 0.78 % short of x.q.  The
+    near neighbours arrive in LATER epochs than a first set that already gave the query a tight threshold: a margin of one operand's
+    roundoff (0.45 %, the kernel's first version) drops them; the margin of the product's roundoff (0.84 %) must not."""
+    rng = np.random.default_rng(17)
+    d, nq = 1024, 128
+    base = 1.0 + (2.0 ** -8) * (1 - 2.0 ** -10)
+
+    def variant(v, m):
+        x = v.copy()
+        x[rng.choice(d, m, replace=False)] *= 2.0
+        return x
+
+    qs = [base * rng.choice([1.0, 2.0], d) for _ in range(nq)]
+    first = [variant(qv, int(rng.integers(6, 9))) for qv in qs for _ in range(12)]                # 1536 rows: the first epoch's threshold
+    near = [variant(qv, int(rng.integers(1, 6))) for qv in qs for _ in range(12)]                 # arrive in the second / third epoch
+    filler = [base * rng.choice([1.0, 2.0], d) for _ in range(30_000)]
+    x = np.asarray(first + filler[:600] + filler[600:20_000] + near + filler[20_000:], f32)
+    q = np.asarray(qs, f32)
+    assert (x[:2048].shape[0] == 2048) and len(first) == 1536
+    for metric in ("cosine", "l2", "dot"):
+        _check(eng, oracle, x, q, 10, metric, tag=("aligned roundoff", metric))
