@@ -4,7 +4,7 @@
 (KNNVectorDistanceExec + SortExec, knn.rs:218-246, scanner.rs:3386-3406), for L2, dot and cosine, any d % 16 == 0.
 
 Every case asserts whether the matrix-core filter ran (`flat_mfma_wide` stage counter); its error margin is wide by design
-(one bf16 product: 0.45 % of |x||q|), so the cases put many rows close to each query's k-th distance."""
+(one bf16 product: 0.84 % of |x||q|), so the cases put many rows close to each query's k-th distance."""
 import numpy as np
 import pytest
 
