@@ -221,7 +221,11 @@ int lance_hip_index_from_storage(lance_hip_ctx *ctx, int dtype, int metric, uint
                                  const uint64_t *row_ids, uint64_t n, lance_hip_index **out);
 void lance_hip_index_destroy(lance_hip_index *idx);
 /* Optional raw vectors for refine (scanner.rs:2884-2904 `take` + flat_knn): x[n_raw][d],
- * indexed by row id (row id r -> x[r]); borrowed, must outlive the index.             */
+ * indexed by row id (row id r -> x[r]); borrowed, must outlive the index and must not
+ * change while attached: the engine may keep a lossless compact copy of it (an f32 column
+ * whose every element is an integer in [0, 255] is read as bytes by the refine kernel) and
+ * captured searches hold its address.  After changing the contents call set_raw again
+ * (same pointer allowed): it drops the copy and invalidates the captured searches.       */
 int lance_hip_index_set_raw(lance_hip_index *idx, const void *x, uint64_t n_raw);
 /* Index::prewarm (rust/lance/src/index/vector/ivf/v2.rs:349-352, python dataset.py:2991 prewarm_index): builds NOW, on ctx's
  * stream, the per-index search constants the first search would otherwise build (the matrix-core scan's f16 codebook and row norms;
