@@ -277,6 +277,27 @@ lance_hip_index::~lance_hip_index() {
   if (raw_u8) (void)hipFree(raw_u8);
 }
 
+// tail of lance_hip_ivfpq_encode: the optional loss and the synchronisation
+static int encode_finish(lance_hip_ctx *ctx, uint64_t n, uint32_t nlist, const float *dists, const uint32_t *part_ids, double *loss_out_host) {
+  LH_CHECK_HIP(hipGetLastError());
+  if (loss_out_host) {
+    // sum of the assignment distances (compute_partitions, kmeans.rs:1276-1290): f64, host side
+    std::vector<float> dh(n);
+    std::vector<uint32_t> ph(n);
+    LH_CHECK_HIP(hipMemcpyAsync(dh.data(), dists, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipMemcpyAsync(ph.data(), part_ids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<double> losses(nlist, 0.0);
+    for (uint64_t r = 0; r < n; ++r)
+      if (ph[r] != LANCE_HIP_NONE) losses[ph[r]] += (double)dh[r];
+    double tot = 0.0;
+    for (uint32_t c = 0; c < nlist; ++c) tot = tot + losses[c];
+    *loss_out_host = tot;
+  }
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return LANCE_HIP_OK;
+}
+
 extern "C" {
 
 int lance_hip_normalize(lance_hip_ctx *ctx, int dtype, const void *x, uint64_t n, uint32_t d, void *out) {
@@ -375,6 +396,14 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   // Native route (L2 / dot): the MFMA assign kernels and the fused residual + encode kernel read the rows in the column's own
   // element type -- no f32 copy of the column, no residual array.  Cosine normalises first and takes the staged route.
   // (round 3: the sub-quantiser argmin of the fused encode runs on the matrix cores when the shape allows -- pq_mfma.hip)
+  // Round 6: the shapes of the north-star configurations (d <= 128, sub-dimension 4 / 8, 8-bit codes) take ONE kernel for the whole chain
+  // (xform_fused.hip): the rows are read once, in their own element type.  Cosine normalises into an f32 copy first and runs the same
+  // kernel on that (L2 on unit vectors, residual rounded to binary16 for f16 columns).
+  if (metric != LANCE_HIP_COSINE &&
+      xform_fused_supported(dtype, scan_metric, (int)d, (int)m, (int)nbits, (int64_t)n, (int)nlist, x, centf, cbf, codes, pa.lanes32)) {
+    LH_TRY(launch_xform_fused(ctx, dtype, scan_metric, x, (int64_t)n, (int)d, centf, (int)nlist, cbf, (int)m, part_ids, dists, codes, f16));
+    return encode_finish(ctx, n, nlist, dists, part_ids, loss_out_host);
+  }
   const bool mfma_enc = metric != LANCE_HIP_COSINE && pq_mfma_encode_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf, (int64_t)n);
   const bool native = metric != LANCE_HIP_COSINE && (mfma_enc || encode_fused_supported(dtype, (int)d, (int)m, (int)nbits, x, centf, cbf));
   bool assign_native = false;
@@ -392,6 +421,10 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
     if (!xn) return LANCE_HIP_ENOMEM;
     LH_TRY(launch_normalize(ctx, xs, (int64_t)n, (int)d, xn, f16));
     xs = xn; pa.x = xs;
+    if (xform_fused_supported(LANCE_HIP_F32, LANCE_HIP_L2, (int)d, (int)m, (int)nbits, (int64_t)n, (int)nlist, xn, centf, cbf, codes, false)) {
+      LH_TRY(launch_xform_fused(ctx, LANCE_HIP_F32, LANCE_HIP_L2, xn, (int64_t)n, (int)d, centf, (int)nlist, cbf, (int)m, part_ids, dists, codes, f16));
+      return encode_finish(ctx, n, nlist, dists, part_ids, loss_out_host);
+    }
   }
   LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
   if (native) {
@@ -409,23 +442,7 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
     // ProductQuantizer::transform encodes with the quantizer's distance type (pq.rs:143,165): L2-nearest codeword, dot too
     LH_TRY(pq_encode_launch(ctx, LANCE_HIP_L2, enc_in, (int64_t)n, (int)d, cbf, (int)m, codes, (int)nbits, false));
   }
-  LH_CHECK_HIP(hipGetLastError());
-  if (loss_out_host) {
-    // sum of the assignment distances (compute_partitions, kmeans.rs:1276-1290): f64, host side
-    std::vector<float> dh(n);
-    std::vector<uint32_t> ph(n);
-    LH_CHECK_HIP(hipMemcpyAsync(dh.data(), dists, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    LH_CHECK_HIP(hipMemcpyAsync(ph.data(), part_ids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<double> losses(nlist, 0.0);
-    for (uint64_t r = 0; r < n; ++r)
-      if (ph[r] != LANCE_HIP_NONE) losses[ph[r]] += (double)dh[r];
-    double tot = 0.0;
-    for (uint32_t c = 0; c < nlist; ++c) tot = tot + losses[c];
-    *loss_out_host = tot;
-  }
-  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  return LANCE_HIP_OK;
+  return encode_finish(ctx, n, nlist, dists, part_ids, loss_out_host);
 }
 
 static int index_alloc_common(lance_hip_ctx *ctx, int dtype, int metric, uint32_t d, const void *centroids, uint32_t nlist,

@@ -40,6 +40,20 @@ struct PairwiseArgs {
 };
 
 // PQ sub-quantiser argmin (k = 256, sub-dimension 4 / 8 / 16, L2) on the matrix cores with exact re-check (pq_mfma.hip)
+// its argument block
+struct PqmArgs {
+  PairwiseArgs p;
+  // encode mode (fused residual + PQ encode, encode_fused.hip's contract): rows are read from `xn` in the column's own element
+  // type (row stride p.ldx elements), row r's operand is xn[r] - rcent[rpart[r]] (rounded to f16 for Float16 columns,
+  // residual.rs:96); rows without a partition encode the zero vector.  rcent == NULL: no residual (dot metric).
+  const void *xn = nullptr;
+  const float *rcent = nullptr;
+  const uint32_t *rpart = nullptr;
+  int round_f16 = 0;
+  uint32_t *fb_cnt;      // [batches] undecided rows per sub-quantiser
+  uint32_t *fb_items;    // [batches][n] their row numbers
+  int batches;
+};
 bool pq_mfma_supported(const PairwiseArgs &p, int d, int metric, int batches);
 int launch_pq_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int batches);
 bool pq_mfma_encode_supported(int dtype, int d, int m, int nbits, const void *x, const float *cent, const float *codebook, int64_t n);
@@ -85,6 +99,11 @@ bool assign_reads_native(PairwiseArgs p, int d, int batches);
 bool encode_fused_supported(int dtype, int d, int m, int nbits, const void *x, const float *cent, const float *codebook);
 int launch_encode_fused(lance_hip_ctx *ctx, int dtype, const void *x, int64_t n, int d, const float *cent, const uint32_t *part_ids,
                         int residual, const float *codebook, int m, uint8_t *codes);
+// the whole transform in one pass over the rows: coarse assign + exact re-check + residual + PQ encode (xform_fused.hip)
+bool xform_fused_supported(int dtype, int metric, int d, int m, int nbits, int64_t n, int nlist, const void *x, const float *cent,
+                           const float *codebook, uint8_t *codes, bool lanes32);
+int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x, int64_t n, int d, const float *cent, int nlist,
+                       const float *codebook, int m, uint32_t *part_ids, float *dists, uint8_t *codes, bool round_f16);
 // bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);
@@ -155,6 +174,9 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
                   const uint32_t *tbound, uint32_t *tglobal, const uint32_t *seg_cnt, const uint32_t *seg_pos, const uint32_t *qovf,
                   uint32_t *pool_key, uint32_t *pool_pos, uint32_t *pool_cnt, int pool_cap, const SelectOut &o, const uint32_t *allow,
                   const uint32_t *qslack = nullptr, const float *seg_val = nullptr, const float *seg_scale = nullptr);
+// "this launcher does not serve the call, take the other route": POSITIVE, because every LANCE_HIP_E* error code is negative (ADVICE r05:
+// -1 doubled as EINVAL and a failure inside the launcher fell back silently)
+constexpr int LH_NOT_TAKEN = 1;
 // search_ms.hip: the filter scan as a [rows x d] x [d x queries] product per partition on the matrix cores (8-bit PQ, d = 64 / 128, M = 16 / 32)
 bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
 bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);   // shape + batch-size part of mscan_supported
@@ -164,7 +186,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
 void mscan_cut_params(int *cut_shift, uint32_t *cut_slack);
 int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix);
 int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
-                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);   // search_ms.hip: -1 = not taken
+                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);   // search_ms.hip: LH_NOT_TAKEN = the integer bound pass serves the batch
 int qscan_items(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nvp, int G, uint32_t *item_start, int4 *desc, uint32_t max_items);   // search_q.hip: work items of G grouped pairs      // builds the scan's index constants now (lance_hip_index_prewarm)
 const uint8_t *raw_compact_prepare(lance_hip_ctx *ctx, const lance_hip_index *ix);   // search.hip: lossless u8 refine copy (index.h), or nullptr
 

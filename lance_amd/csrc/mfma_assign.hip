@@ -23,23 +23,11 @@
 #include "common.h"
 #include "exact.cuh"
 #include "kernels.h"
+#include "ma_common.cuh"
 
 #pragma clang fp contract(off)
 
 namespace lh {
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int MA_ROWS = 128;   // data rows per workgroup (4 waves x 32)
-constexpr int MA_CT = 64;      // centroids per LDS tile (2 MFMA row blocks)
-
-__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {   // round-to-nearest-even bf16, NaN kept
-  const uint32_t u = __float_as_uint(x);
-  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
 
 // ---- centroid preparation: hi / lo bf16 planes, squared norms, maxima for the error bound ------------------------
 // dp = row stride of the planes (d, or d rounded up to the K-chunk of the wide kernel: the padding is zero-filled)
@@ -64,55 +52,6 @@ __global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ c
     cn[c] = s;
     if (s == s) atomicMax(&maxbits[0], __float_as_uint(fabsf(s)));
     if (bias) { const float b = fabsf(bias[c]); if (b == b) atomicMax(&maxbits[1], __float_as_uint(b)); }
-  }
-}
-
-struct MaArgs {
-  const void *x;         // [n][ldx] elements of the column's type (f32 / f16 / int8)
-  int64_t n, ldx;
-  int d, k;
-  const uint16_t *chi, *clo;   // [k][d] bf16 planes
-  const float *cn;             // [k] |c|^2
-  const float *bias;           // [k] or NULL
-  const uint32_t *maxbits;
-  const float *cent;           // [k][d] f32 (exact re-check)
-  uint32_t *id1, *id2, *id3;   // [n] three nearest by surrogate
-  uint8_t *cls;                // [n] 0 certain, 1 / 2: two / three candidates, 3 recompute
-  uint32_t *ids;               // outputs of the finalize kernel
-  float *dists;
-  int check_finite;
-  uint32_t *fb_cnt, *fb_rows;  // rows left to ma_recompute_kernel
-  const uint8_t *active;       // k-means: the (single) problem has converged -> every kernel returns at once
-  // wide rows (d > 128, ma_top3_wide_kernel): the rows pre-split into bf16 planes of stride dp, and their squared norms
-  const uint16_t *xhi = nullptr, *xlo = nullptr;
-  const float *xn2 = nullptr;
-  int dp = 0;
-  // SUR = true instantiations (coarse_mfma.hip: find_partitions at query time): the surrogates go to a matrix instead of a running
-  // top-4, the centroid tiles are split over blockIdx.y (small query batches would otherwise leave most CUs idle)
-  float *sur = nullptr;        // [n][k] surrogate values
-  float *e2 = nullptr;         // [n] 2E of the row (the select kernel's candidate margin)
-  int tiles_per_block = 0;     // centroid tiles (narrow: MA_CT, wide: MW_CT centroids) per blockIdx.y slice
-};
-
-// running four smallest (values m1 <= m2 <= m3 <= m4, centroid ids of the first three)
-struct Top4 {
-  float m1, m2, m3, m4;
-  uint32_t i1, i2, i3;
-};
-__device__ __forceinline__ void top4_insert(Top4 &t, float v, uint32_t i) {
-  if (v < t.m4) {
-    if (v < t.m3) {
-      t.m4 = t.m3;
-      if (v < t.m2) {
-        t.m3 = t.m2; t.i3 = t.i2;
-        if (v < t.m1) { t.m2 = t.m1; t.i2 = t.i1; t.m1 = v; t.i1 = i; }
-        else { t.m2 = v; t.i2 = i; }
-      } else {
-        t.m3 = v; t.i3 = i;
-      }
-    } else {
-      t.m4 = v;
-    }
   }
 }
 
@@ -284,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
     if (tp.m2 - tp.m1 > E2) cl = 0;
     else if (tp.m3 - tp.m1 > E2) cl = 1;
     else if (tp.m4 - tp.m1 > E2) cl = 2;
-    if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY)) cl = 3;   // NaN / overflow anywhere: recompute exactly
+    if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY) || !(E2 > 7.888609052210118e-31f)) cl = 3;   // (E2 <= 2^-100: products underflow, the relative bound does not hold)   // NaN / overflow anywhere: recompute exactly
     p.id1[row] = tp.i1; p.id2[row] = tp.i2; p.id3[row] = tp.i3; p.cls[row] = cl;
   }
 }
@@ -593,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
     if (tp.m2 - tp.m1 > E2) cl = 0;
     else if (tp.m3 - tp.m1 > E2) cl = 1;
     else if (tp.m4 - tp.m1 > E2) cl = 2;
-    if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY)) cl = 3;
+    if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY) || !(E2 > 7.888609052210118e-31f)) cl = 3;   // (E2 <= 2^-100: products underflow, the relative bound does not hold)
     p.id1[row] = tp.i1; p.id2[row] = tp.i2; p.id3[row] = tp.i3; p.cls[row] = cl;
   }
 }
@@ -717,22 +656,51 @@ bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches) {
   return true;
 }
 
+int ma_prepare_centroids(lance_hip_ctx *ctx, const float *cent, int k, int d, int dp, const float *bias, const uint8_t *active, uint16_t **chi_out,
+                         uint16_t **clo_out, float **cn_out, uint32_t **maxbits_out) {
+  const size_t kd = (size_t)k * dp;
+  uint16_t *chi = ctx->scratch_t<uint16_t>("ma.chi", kd), *clo = ctx->scratch_t<uint16_t>("ma.clo", kd);
+  float *cn = ctx->scratch_t<float>("ma.cn", (size_t)k);
+  uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);
+  if (!chi || !clo || !cn || !maxbits) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(lh::memset_async(maxbits, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)k), dim3(64), 0, ctx->stream, cent, k, d, dp, bias, chi, clo, cn, maxbits, active);
+  LH_CHECK_HIP(hipGetLastError());
+  *chi_out = chi; *clo_out = clo; *cn_out = cn; *maxbits_out = maxbits;
+  return LANCE_HIP_OK;
+}
+
+int ma_recompute_launch(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dtype) {
+  const size_t lds = (size_t)4 * a.d * 4;
+  const dim3 grid(512), block(256);
+  if (dtype == LANCE_HIP_F16) {
+    if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_recompute_kernel<METRIC_DOT, __half, 16>), grid, block, lds, ctx->stream, a);
+    else hipLaunchKernelGGL((ma_recompute_kernel<METRIC_L2, __half, 16>), grid, block, lds, ctx->stream, a);
+  } else if (dtype == LANCE_HIP_I8) {
+    if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_recompute_kernel<METRIC_DOT, int8_t, 16>), grid, block, lds, ctx->stream, a);
+    else hipLaunchKernelGGL((ma_recompute_kernel<METRIC_L2, int8_t, 16>), grid, block, lds, ctx->stream, a);
+  } else {
+    if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_recompute_kernel<METRIC_DOT, float, 16>), grid, block, lds, ctx->stream, a);
+    else hipLaunchKernelGGL((ma_recompute_kernel<METRIC_L2, float, 16>), grid, block, lds, ctx->stream, a);
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 // ids / dists of PairwiseArgs are filled exactly as launch_assign's exact kernels fill them.
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric) {
   const bool wide = d > 128;
   const int dp = wide ? (d + MW_KC - 1) / MW_KC * MW_KC : d;
-  const size_t kd = (size_t)p.k * dp;
-  uint16_t *chi = ctx->scratch_t<uint16_t>("ma.chi", kd), *clo = ctx->scratch_t<uint16_t>("ma.clo", kd);
-  float *cn = ctx->scratch_t<float>("ma.cn", (size_t)p.k);
-  uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);   // [0] max |c|^2, [1] max |bias|, [2] rows left to the recompute kernel
+  uint16_t *chi, *clo;
+  float *cn;
+  uint32_t *maxbits;   // [0] max |c|^2, [1] max |bias|, [2] rows left to the recompute kernel
+  LH_REQUIRE(p.n < (1ll << 32), "assign: more than 2^32 rows per call");
+  LH_TRY(ma_prepare_centroids(ctx, p.cent, p.k, d, dp, p.bias, p.active, &chi, &clo, &cn, &maxbits));
   uint32_t *id1 = ctx->scratch_t<uint32_t>("ma.id1", (size_t)p.n), *id2 = ctx->scratch_t<uint32_t>("ma.id2", (size_t)p.n);
   uint32_t *id3 = ctx->scratch_t<uint32_t>("ma.id3", (size_t)p.n);
   uint8_t *cls = ctx->scratch_t<uint8_t>("ma.cls", (size_t)p.n);
   uint32_t *fb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)p.n);
-  if (!chi || !clo || !cn || !maxbits || !id1 || !id2 || !id3 || !cls || !fb_rows) return LANCE_HIP_ENOMEM;
-  LH_REQUIRE(p.n < (1ll << 32), "assign: more than 2^32 rows per call");
-  LH_CHECK_HIP(lh::memset_async(maxbits, 0, 12, ctx->stream));
-  hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, dp, p.bias, chi, clo, cn, maxbits, p.active);
+  if (!id1 || !id2 || !id3 || !cls || !fb_rows) return LANCE_HIP_ENOMEM;
   MaArgs a;
   a.x = p.x_native ? p.x_native : static_cast<const void *>(p.x); a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
   const int dtype = p.x_native ? p.x_dtype : LANCE_HIP_F32;
@@ -847,7 +815,7 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ 
   // nprobes-th smallest of 64 lane MINIMA it stays close to it when nprobes approaches 64 (r04b: at nprobes = 50 the minima
   // gave ~90 candidates per query, most rows overflowed the list and took the exact path: 4.3 ms per 1000 queries).
   float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
-  bool bad = !(E2 < INFINITY);
+  bool bad = !(E2 < INFINITY) || !(E2 > 7.888609052210118e-31f);      // (2 * 2^-100 scale: products in the denormal range -> exact path)
   for (int i = lane; i < nlist; i += 64) {
     const float v = row[i];
     bad |= v != v;

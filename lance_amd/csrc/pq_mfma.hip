@@ -51,20 +51,6 @@ __device__ __forceinline__ uint32_t pqm_med3(uint32_t x, uint32_t y, uint32_t z)
   return r;
 }
 
-struct PqmArgs {
-  PairwiseArgs p;
-  // encode mode (fused residual + PQ encode, encode_fused.hip's contract): rows are read from `xn` in the column's own element
-  // type (row stride p.ldx elements), row r's operand is xn[r] - rcent[rpart[r]] (rounded to f16 for Float16 columns,
-  // residual.rs:96); rows without a partition encode the zero vector.  rcent == NULL: no residual (dot metric).
-  const void *xn = nullptr;
-  const float *rcent = nullptr;
-  const uint32_t *rpart = nullptr;
-  int round_f16 = 0;
-  uint32_t *fb_cnt;      // [batches] undecided rows per sub-quantiser
-  uint32_t *fb_items;    // [batches][n] their row numbers
-  int batches;
-};
-
 __device__ __forceinline__ f4 pqm_load4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ f4 pqm_load4(const __half *p) {
   const uint2 u = *reinterpret_cast<const uint2 *>(p);
@@ -226,7 +212,7 @@ __global__ __launch_bounds__(256) void pq_mfma_estep_kernel(PqmArgs a) {
     }
     if (g == 0 && valid) {
       const float s1 = __uint_as_float(m1 & 0xFFFFFF00u), s2 = __uint_as_float(m2 & 0xFFFFFF00u);
-      const bool decided = (margin < INFINITY) && (s2 - s1 > margin);     // NaN anywhere: false
+      const bool decided = (margin < INFINITY) && (margin > 7.888609052210118e-31f) && (s2 - s1 > margin);     // NaN anywhere: false; margin <= 2^-100: products / cleared key bits in the denormal range
       if (decided) {
         const uint32_t c = m1 & 0xFFu;
         const float v = dist_exact<SD, METRIC_L2>(rv, &cbf[c * SD]);

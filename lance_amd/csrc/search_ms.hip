@@ -887,9 +887,9 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
                  uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out) {
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);   // the constants are a cache attached to the index
   int sd = 0, ks = 0;
-  if (!ms_shape(ix, &sd, &ks)) return -1;
+  if (!ms_shape(ix, &sd, &ks)) return LH_NOT_TAKEN;
   LH_TRY(mscan_prepare(ctx, ix));
-  if (!ix->ms->usable) return -1;
+  if (!ix->ms->usable) return LH_NOT_TAKEN;
   const int d = (int)ix->d, nlist = (int)ix->nlist;
   const size_t npairs = (size_t)nq * nprobes;
   // slices: at most sum over the partitions of (row slices) x (pair blocks), pair blocks <= pairs / MS3_PB + 1 per partition
@@ -998,12 +998,13 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
   static const bool off = getenv("LANCE_HIP_NO_MSBOUND") != nullptr;      // A/B switch: the integer histogram pass (search_q.hip)
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
   int sd = 0, ks = 0;
-  if (off || !ms_shape(ix, &sd, &ks) || !ix->cb_mean || ix->max_part >= 65536u) return -1;      // u16 bins: a bin never holds more rows than the partition has
-  if (((reinterpret_cast<uintptr_t>(qs) | reinterpret_cast<uintptr_t>(ix->centroids)) & 7) != 0) return -1;
+  if (off || !ms_shape(ix, &sd, &ks) || !ix->cb_mean || ix->max_part >= 65536u) return LH_NOT_TAKEN;      // u16 bins: a bin never holds more rows than the partition has
+  if (((reinterpret_cast<uintptr_t>(qs) | reinterpret_cast<uintptr_t>(ix->centroids)) & 7) != 0) return LH_NOT_TAKEN;
   LH_TRY(mscan_prepare(ctx, ix));
-  if (!ix->ms->usable) return -1;
+  if (!ix->ms->usable) return LH_NOT_TAKEN;
   const int nlist = (int)ix->nlist;
   LH_TRY(qscan_items(ctx, pair_starts0, nlist, MSB_BQ, item_start, desc, max_items));
+  if (!((sd == 8 && ks == 8) || (sd == 4 && (ks == 8 || ks == 4)))) return LH_NOT_TAKEN;      // before the stage is counted
   ScopedTimer t(ctx, "ivfpq_msbound");      // the launch under its own name: tests assert which bound pass ran
   MsBoundArgs a;
   a.q = qs; a.centroids = ix->centroids; a.cb_mean = ix->cb_mean; a.pair_idx0 = pair_idx0; a.item_start = item_start; a.desc = desc;
@@ -1013,8 +1014,7 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
   const unsigned grid = (unsigned)std::min<uint64_t>(max_items, (uint64_t)nq / MSB_BQ + (uint64_t)nlist + 1);      // sum over partitions of ceil(queries / MSB_BQ)
   if (sd == 8 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<8, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
-  else if (sd == 4 && ks == 4) hipLaunchKernelGGL((ms_bound_kernel<4, 4>), dim3(grid), dim3(1024), 0, ctx->stream, a);
-  else return -1;
+  else hipLaunchKernelGGL((ms_bound_kernel<4, 4>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

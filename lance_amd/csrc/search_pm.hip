@@ -669,12 +669,12 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   } else {
     ScopedTimer t(ctx, "ivfpq_scan_c0");
     // a batch the matrix-core scan serves gets its bounds from the same matrix product (search_ms.hip: ms_bound_kernel) ...
-    int mb_rc = -1;
+    int mb_rc = LH_NOT_TAKEN;
     if (mscan_supported(ix, nq, nprobes))
       mb_rc = msbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow);
-    if (mb_rc > 0) return mb_rc;
+    if (mb_rc < 0) return mb_rc;          // a real failure (every LANCE_HIP_E* code is negative): never a silent fall-back
     // ... every other one from the integer histogram, four queries per gather (search_q.hip)
-    if (mb_rc < 0) LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));
+    if (mb_rc == LH_NOT_TAKEN) LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));
   }
   {
     // main pass grouping: class A (bounded) pairs by partition for the filter scan, class B for the exact pair kernel
@@ -688,11 +688,11 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   // search_ms.hip: the filter as a matrix product per partition (its own pre-pass; same segment outputs + a per-query slack for the merge cut)
   uint32_t *qslack = nullptr;
   float *seg_val = nullptr, *seg_scale = nullptr;      // rows-on-lanes kernel: the survivors' accumulator values + the per-pair scale of their sums
-  int ms_rc = -1;
+  int ms_rc = LH_NOT_TAKEN;
   if (mscan_supported(ix, nq, nprobes))
     ms_rc = mscan_launch(ctx, ix, qs, nq, nprobes, probes, pair_starts, pair_idx, tbound, seg_cnt, seg_pos, qovf, allow, &qslack, &seg_val, &seg_scale);
-  if (ms_rc > 0) return ms_rc;
-  if (ms_rc < 0) {
+  if (ms_rc < 0) return ms_rc;
+  if (ms_rc == LH_NOT_TAKEN) {
     qslack = nullptr; seg_val = nullptr; seg_scale = nullptr;
     LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow, probes));
   }

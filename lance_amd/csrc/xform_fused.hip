@@ -1,0 +1,797 @@
+// xform_fused.hip -- the IVF-PQ transform as ONE pass over the rows: coarse assign -> exact re-check -> residual -> PQ encode.
+//
+//   IvfTransformer chain         ivf.rs:188-236      (PartitionTransformer -> ResidualTransform -> PQTransformer)
+//   compute_partitions           kmeans.rs:1187-1246 (argmin over the centroids, KeepFiniteVectors folded in: ivf/transform.rs:75-137)
+//   do_compute_residual          residual.rs:58-102  (x - centroid[part], in the column's element type: f16 rounds)
+//   ProductQuantizer::transform  pq.rs:116-191       (per sub-vector the L2-nearest codeword, unwrap_or(0))
+//   precedent for fusing them    python/python/lance/vector.py:693-714 (one torch pass: assign, residual, encode)
+//
+// Round 5 ran this as ma_top3_kernel -> ma_finalize_kernel -> pq_mfma_estep_kernel: the rows crossed HBM three times (the third
+// time sixteen times over in 32-byte pieces, one per sub-quantiser) and the PQ half spent 4-5 VALU per (row, codeword) pair on
+// top of three half-empty K = 8 MFMAs: 2.66 ms per million 128-d rows, 0.025 of the HBM roofline.  Here a
+// 256-lane workgroup owns 128 rows and keeps them on chip from the first load to the code bytes:
+//
+//   1. rows: HBM -> LDS (coalesced, the column's own element type) -> registers: wave w owns rows 32 w .. 32 w + 31, a lane
+//      pair (j, g) holds row j as f32 (exact re-check, residual) and as bf16 hi / lo MFMA fragments.  int8 rows are exact in
+//      bf16: their lo fragments and the MFMAs that would multiply them do not exist ("terms that are zero").
+//   2. coarse sweep, as mfma_assign.hip: centroid planes stream through LDS (double buffered), s(c) = |c|^2 - 2 x.c from
+//      v_mfma_f32_32x32x16_bf16 (xh.ch + xl.ch + xh.cl), running four smallest per row, classification against
+//      2E = 2^-12 (|x|^2 + max|c|^2): one, two or three candidates, or "recompute" (>= 4 inside the margin, NaN).
+//   3. exact re-check IN the kernel: the lane pair evaluates l2_scalar / dot_scalar of its row against each candidate in the
+//      reference's order -- lane (j, g) owns lane accumulators 8 g .. 8 g + 7 of the 16 (sums[i] += over the 16-chunks in
+//      order), the fold ((0 + s0) + s1) + ... + s15 runs through lane g = 0 and is handed to g = 1 by one shuffle.  Partition id
+//      and distance are therefore bit-equal to the exact kernels (argmin_value_float: strictly smaller, then smaller index;
+//      non-finite rows: None).  Rows left undecided go to ma_recompute_kernel's list as before.
+//   4. residual r = x - c[part] in f32 (f16 columns: rounded to binary16, residual.rs:96), split into bf16 hi / lo planes in
+//      LDS (the centroid staging area, dead by now; 16-byte chunks rotated by the row number: conflict-free reads), with an upper
+//      bound of every sub-vector's squared norm (bf16, rounded up).
+//   5. PQ encode with the roles swapped: wave w now owns sub-quantisers w, w + 4, ... for ALL 128 rows; its 256 codewords sit
+//      in registers as MFMA A fragments prepared once per call (xf_pq_prep_kernel), the rows stream from LDS as B.  The
+//      whole surrogate comes out of the matrix pipe -- for sub-dimension 8 two K = 16 products per 32 x 32 tile,
+//           A1 = [-2 ch | -2 cl]   B1 = [xh | xh]        A2 = [-2 ch | n1 n2 n3 0 ..]   B2 = [xl | 1 1 1 0 ..]
+//      (|c|^2 = n1 + n2 + n3 as three bf16 terms), accumulator started at |r_m|^2 + margin: s'' = |r_m - c|^2 + margin >= 0 with
+//      no VALU arithmetic at all, and no K slot multiplies zeros (sub-dimension 4: one product, [xh xh | xl 1 1 1 0]).
+//      Epilogue = 3 VALU per (row, codeword): key = (bits & ~63) | slot (v_and_or_b32, slot an inline constant), second
+//      smallest by v_med3_u32, smallest by v_min_u32 -- two trackers of 64 slots so the slot number stays an inline constant.
+//      margin = 2^-12 (|r_m|^2 + max|c|^2) as in pq_mfma.hip (split error <= 2^-14 |r||c|, the |c|^2 terms and the f32
+//      accumulation of 16 + 16 slots < 2^-17 (|r|^2 + |c|^2), cleared mantissa bits < 2^-15 relative, the norm bound's excess is
+//      a constant of the row and cancels in every comparison).  Second key farther than the margin -> the first is the
+//      reference's argmin; otherwise the (row, sub-quantiser) item goes to pq_mfma_fix_kernel's list (exact distances to all
+//      256 codewords).  Codes are gathered in LDS and leave as one coalesced store per workgroup.
+//
+// HBM traffic: the row once, plus M + 8 bytes per row out.  Everything else (centroid planes 2 x 2 B x nlist x d, codeword
+// fragments 16 KiB per sub-quantiser, f32 centroids of the candidates) is re-read from L2 by every workgroup.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "exact.cuh"
+#include "kernels.h"
+#include "ma_common.cuh"
+
+#pragma clang fp contract(off)
+
+namespace lh {
+
+struct XfArgs {
+  const void *x;                 // [n][ldx] rows in the column's element type
+  int64_t n, ldx;
+  int k;                         // coarse centroids
+  const uint16_t *cpl;           // [k rounded up to 64][2 d + 16] bf16 centroid planes (xf_cent_prep_kernel)
+  const uint32_t *maxbits;       // [0] max |c|^2
+  const float *cent;             // [k][d] f32
+  int residual, round_f16, check_finite;
+  const uint4 *pqa;              // [m][8 tiles][NMF][64 lanes] codeword fragments (xf_pq_prep_kernel)
+  const float *pq_cmax2;         // [m] max |codeword|^2
+  uint32_t *part_ids;            // [n]
+  float *dists;                  // [n]
+  uint8_t *codes;                // [n][m]
+  uint32_t *afb_cnt, *afb_rows;  // rows for ma_recompute_kernel
+  uint32_t *fb_cnt, *fb_items;   // [1], [n m]: undecided (row, sub-quantiser) items for xf_fix_kernel, item = m << 27 | row
+  unsigned long long *prof = nullptr;   // LANCE_HIP_XF_PROF=1: s_memtime ticks summed over the waves: [0] rows->registers [1] sweep [2] merge + exact re-check
+                                        // [3] residual + barrier [4] PQ encode [5] codes out [6] waves [7] undecided PQ items
+};
+
+__device__ __forceinline__ uint32_t xf_med3(uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+
+// bf16 >= v for v >= 0 (NaN stays NaN): the sub-vector norm kept in 16 bits
+__device__ __forceinline__ uint32_t xf_bf16_up(float v) {
+  const uint32_t u = __float_as_uint(v);
+  if ((u & 0x7FFFFFFFu) >= 0x7F800000u) return u >> 16 | ((u & 0xFFFFu) ? 0x40u : 0u);
+  return (u + 0xFFFFu) >> 16;
+}
+
+// ---- codeword fragments: one workgroup per sub-quantiser, thread = codeword -------------------------------------------
+// SD = 8: per 32-codeword tile two A operands (see the header); SD = 4: one.  Lane (j, g) of the MFMA reads 16 bytes.
+template <int SD>
+__global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict__ codebook, uint4 *__restrict__ pqa, float *__restrict__ cmax2) {
+  constexpr int NMF = SD == 8 ? 2 : 1;
+  __shared__ uint32_t s_max;
+  const int m = blockIdx.x, c = threadIdx.x;
+  if (c == 0) s_max = 0u;
+  __syncthreads();
+  const float *cw = codebook + ((int64_t)m * 256 + c) * SD;
+  uint32_t hi[SD], lo[SD];
+  float s = 0.0f;
+#pragma unroll
+  for (int e = 0; e < SD; ++e) {
+    const float v = cw[e];
+    s += v * v;
+    const float w = -2.0f * v;
+    const uint32_t hb = bf16_rne_bits(w);
+    hi[e] = hb & 0xFFFFu;
+    lo[e] = bf16_rne_bits(w - bf16_bits_to_float(hb)) & 0xFFFFu;
+  }
+  const uint32_t n1 = bf16_rne_bits(s) & 0xFFFFu;
+  const float r1 = s - bf16_bits_to_float(n1);
+  const uint32_t n2 = bf16_rne_bits(r1) & 0xFFFFu;
+  const uint32_t n3 = bf16_rne_bits(r1 - bf16_bits_to_float(n2)) & 0xFFFFu;
+  if (s == s) atomicMax(&s_max, __float_as_uint(fabsf(s)));
+  const int t = c >> 5, j = c & 31;
+  uint4 *dst = pqa + ((int64_t)(m * 8 + t) * NMF) * 64;
+  if constexpr (SD == 8) {
+    const uint4 h = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, hi[4] | hi[5] << 16, hi[6] | hi[7] << 16);
+    const uint4 l = make_uint4(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, lo[4] | lo[5] << 16, lo[6] | lo[7] << 16);
+    dst[j] = h;                                  // A1, g = 0: -2 ch
+    dst[32 + j] = l;                             // A1, g = 1: -2 cl
+    dst[64 + j] = h;                             // A2, g = 0: -2 ch
+    dst[96 + j] = make_uint4(n1 | n2 << 16, n3, 0u, 0u);   // A2, g = 1: |c|^2 in three terms
+  } else {
+    dst[j] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);       // g = 0: [-2 ch | -2 cl]
+    dst[32 + j] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, n1 | n2 << 16, n3);                         // g = 1: [-2 ch | n1 n2 n3 0]
+  }
+  __syncthreads();
+  if (c == 0) cmax2[m] = __uint_as_float(s_max);
+}
+
+// ---- coarse centroid planes: per centroid [ -2 c hi (D) | n1 n2 n3 1 0.. (16) | -2 c lo (D) ] bf16 (dot: -c, no norm terms) -------------------
+// The extra K = 16 step carries |c|^2 (three bf16 terms) and a 1 that multiplies the row's offset R, so the surrogate leaves the
+// matrix pipe complete: s'(c) = R + |c|^2 - 2 x.c.  Rows c >= k (padding to whole 64-centroid tiles) get |c|^2 = +inf: never selected.
+template <int METRIC>
+__global__ __launch_bounds__(64) void xf_cent_prep_kernel(const float *__restrict__ cent, int k, int d, uint16_t *__restrict__ cpl,
+                                                          uint32_t *__restrict__ maxbits) {
+  const int c = blockIdx.x, w = 2 * d + 16;
+  uint16_t *row = cpl + (int64_t)c * w;
+  const float scale = METRIC == METRIC_DOT ? -1.0f : -2.0f;
+  float s = 0.0f;
+  for (int e = threadIdx.x; e < d; e += 64) {
+    const float v = c < k ? cent[(int64_t)c * d + e] : 0.0f;
+    const float t = scale * v;
+    const uint32_t hb = bf16_rne_bits(t);
+    row[e] = (uint16_t)hb;
+    row[d + 16 + e] = (uint16_t)bf16_rne_bits(t - bf16_bits_to_float(hb));
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x < 16) {
+    uint32_t v = 0u;
+    if (threadIdx.x == 3) v = 0x3F80u;                        // 1.0: multiplies the row's offset R
+    if (METRIC != METRIC_DOT || c >= k) {
+      const float n = c < k ? s : INFINITY;
+      const uint32_t n1 = bf16_rne_bits(n) & 0xFFFFu;
+      const float r1 = c < k ? n - bf16_bits_to_float(n1) : 0.0f;
+      const uint32_t n2 = bf16_rne_bits(r1) & 0xFFFFu;
+      const uint32_t n3 = bf16_rne_bits(r1 - bf16_bits_to_float(n2)) & 0xFFFFu;
+      if (threadIdx.x == 0) v = n1;
+      if (threadIdx.x == 1) v = n2;
+      if (threadIdx.x == 2) v = n3;
+    }
+    row[d + threadIdx.x] = (uint16_t)v;
+  }
+  if (threadIdx.x == 0 && c < k && s == s) atomicMax(&maxbits[0], __float_as_uint(fabsf(s)));
+}
+
+// LDS (bytes) of one workgroup: the centroid tiles of the sweep and the residual planes of the encode alias each other; the
+// workgroup's queue of undecided items (a counter + XF_QCAP 16-bit entries, m << 7 | row) sits behind both
+constexpr int XF_QCAP = 1024;
+template <int KS, int SD>
+constexpr size_t xf_lds_main() {
+  constexpr int D = KS * 16, M = D / SD;
+  constexpr size_t b = (size_t)2 * MA_CT * (2 * D + 24) * 2;                                     // two centroid tiles
+  constexpr size_t c = (size_t)2 * MA_ROWS * D * 2 + (size_t)MA_ROWS * M * 2 + (size_t)MA_ROWS * ((M + 3) / 4) * 4 + MA_ROWS;   // residual planes, norms, codes, flags
+  return ((b > c ? b : c) + 15) / 16 * 16;
+}
+template <int KS, int SD>
+constexpr size_t xf_lds_bytes() { return xf_lds_main<KS, SD>() + 16 + (size_t)XF_QCAP * 2; }
+
+typedef __bf16 xf_bf2 __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN)
+__device__ __forceinline__ uint32_t xf_cvt2(float a, float b) {
+  const f2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xf_bf2));
+}
+// eight floats -> bf16 hi / lo fragments (x = hi + lo to 2^-17 |x|: the remainder v - hi is exact in f32)
+template <bool LO>
+__device__ __forceinline__ void xf_split8(const float (&v)[8], uint4 &hi, uint4 &lo) {
+  uint32_t h[4], l[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = xf_cvt2(v[2 * q], v[2 * q + 1]);
+    if constexpr (LO) l[q] = xf_cvt2(v[2 * q] - __uint_as_float(h[q] << 16), v[2 * q + 1] - __uint_as_float(h[q] & 0xFFFF0000u));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// exact distance of the pair's row to centroid row `y` in the reference's summation order; every lane gets the value
+template <int KS, int METRIC>
+__device__ __forceinline__ float xf_exact(const float (&xf)[KS][8], const float *__restrict__ y, int j, int g) {
+  float sums[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sums[e] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const f4 c0 = *reinterpret_cast<const f4 *>(y + s * 16 + g * 8), c1 = *reinterpret_cast<const f4 *>(y + s * 16 + g * 8 + 4);
+    const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if constexpr (METRIC == METRIC_DOT) {
+        sums[e] = sums[e] + xf[s][e] * cv[e];
+      } else {
+        const float diff = xf[s][e] - cv[e];
+        sums[e] = sums[e] + diff * diff;
+      }
+    }
+  }
+  float t = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t = t + sums[e];           // g = 0: ((0 + s0) + s1) + ... + s7
+  const float t0 = __shfl(t, j, 64);
+  float u = t0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) u = u + sums[e];           // g = 1 continues with s8 .. s15
+  const float tot = __shfl(u, 32 + j, 64);
+  return finish_metric<METRIC>(0.0f + tot);
+}
+
+// an undecided (row, sub-quantiser) item: into the workgroup's LDS queue (flushed with one global atomic at the end), or -- queue full:
+// rows full of ties -- straight to the global list
+__device__ __forceinline__ void xf_queue_item(const XfArgs &p, uint32_t *q_cnt, uint16_t *q_items, uint32_t m, uint32_t lrow, int64_t row0) {
+  const uint32_t slot = atomicAdd(&q_cnt[0], 1u);
+  if (slot < (uint32_t)XF_QCAP) {
+    q_items[slot] = (uint16_t)((m << 7) | lrow);
+  } else {
+    const uint32_t s2 = atomicAdd(p.fb_cnt, 1u);
+    p.fb_items[s2] = (m << 27) | (uint32_t)(row0 + lrow);
+  }
+}
+
+// Undecided items: one wave each, exact distances of the (residual) sub-vector to the sub-quantiser's 256 codewords in the reference's
+// order (l2_scalar, kmeans.rs:1350-1369), argmin_value_float semantics (first strictly smallest, NaN / +inf never selected, none ->
+// code 0: pq.rs:165 unwrap_or(0)) -- pq_mfma_fix_kernel's arithmetic on a flat list (the codewords come from L2: items are ~1 % of the work)
+struct XfFixArgs {
+  const void *x; int64_t ldx;
+  const float *cent; const uint32_t *part_ids; int residual, round_f16;
+  const float *codebook; int m;
+  const uint32_t *cnt, *items;
+  uint8_t *codes;
+};
+template <int SD, typename TX>
+__global__ __launch_bounds__(256) void xf_fix_kernel(XfFixArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t cnt = *a.cnt, nwaves = gridDim.x * 4;
+  for (uint32_t it = blockIdx.x * 4 + (threadIdx.x >> 6); it < cnt; it += nwaves) {
+    const uint32_t item = a.items[it], m = item >> 27;
+    const int64_t row = item & 0x7FFFFFFu;
+    RegVec<SD> rv;
+#pragma unroll
+    for (int i = 0; i < SD / 4; ++i) rv.q[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t part = a.residual ? a.part_ids[row] : 0u;
+    if (!(a.residual && part == LANCE_HIP_NONE)) {       // no partition: the zero vector
+      const TX *src = static_cast<const TX *>(a.x) + row * a.ldx + (int64_t)m * SD;
+#pragma unroll
+      for (int i = 0; i < SD / 4; ++i) {
+        f4 v = load4(src + 4 * i);
+        if (a.residual) {
+          v = v - *reinterpret_cast<const f4 *>(a.cent + (int64_t)part * a.ldx + (int64_t)m * SD + 4 * i);
+          if (a.round_f16) {
+            v.x = __half2float(__float2half_rn(v.x)); v.y = __half2float(__float2half_rn(v.y));
+            v.z = __half2float(__float2half_rn(v.z)); v.w = __half2float(__float2half_rn(v.w));
+          }
+        }
+        rv.q[i] = v;
+      }
+    }
+    const float *cb = a.codebook + (int64_t)m * 256 * SD;
+    float best = INFINITY;
+    uint32_t bi = LANCE_HIP_NONE;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t c = (uint32_t)(u * 64 + lane);
+      const float v = dist_exact<SD, METRIC_L2>(rv, cb + c * SD);
+      if (v < best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const uint32_t oi = __shfl_xor(bi, o, 64);
+      if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) a.codes[row * a.m + m] = bi == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)bi;
+  }
+}
+
+template <int KS, int SD, int METRIC, typename TX, bool PROF = false>
+__global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
+  long long pt[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t pc_und = 0;
+  if constexpr (PROF) pt[0] = clock64();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = KS * 16, M = D / SD;
+  constexpr int CW = 2 * D + 16;     // bf16 elements per centroid in global memory: hi (D) | norm step (16) | lo (D)
+  constexpr int CS = CW + 8;         // ... and per LDS row (16-byte skew: conflict-free ds_read_b128)
+  constexpr int NCH = D / 8;         // 16-byte chunks per residual row
+  constexpr int NMF = SD == 8 ? 2 : 1;
+  constexpr int MW = (M + 3) / 4;    // sub-quantisers per wave
+  constexpr bool XL = !std::is_same<TX, int8_t>::value;       // int8 rows are exact in bf16
+  static_assert(SD == 4 || SD == 8, "sub-dimension 4 or 8");
+  uint16_t *cbuf = reinterpret_cast<uint16_t *>(smem);               // phase 2: [2][MA_CT][CS]
+  uint16_t *rh = reinterpret_cast<uint16_t *>(smem);                 // phase 3: [128][D] hi, [128][D] lo (chunks rotated by the row)
+  uint16_t *rl = rh + (size_t)MA_ROWS * D;
+  uint16_t *xn2s = rl + (size_t)MA_ROWS * D;                         // [128][M] bf16 upper bounds of |r_m|^2
+  // codes: [wave][MW][128] -- a byte is written by the wave that owns the sub-quantiser, its dword neighbours are the adjacent rows
+  // of the SAME store instruction (round 6, first version: [row][m] put four waves' bytes into one dword, and about one byte in two
+  // million came out stale: concurrent sub-dword LDS stores of different waves to one dword are not safe)
+  uint8_t *codes_s = reinterpret_cast<uint8_t *>(xn2s + (size_t)MA_ROWS * M);
+  uint8_t *rskip = codes_s + (size_t)4 * MW * MA_ROWS;               // [128] 1: the row's items were queued (or the row does not exist)
+  uint32_t *q_cnt = reinterpret_cast<uint32_t *>(smem + xf_lds_main<KS, SD>());      // undecided items of the workgroup: count, base in the global list
+  uint16_t *q_items = reinterpret_cast<uint16_t *>(smem + xf_lds_main<KS, SD>() + 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * MA_ROWS;
+
+  // ---- 1. rows -> registers ---------------------------------------------------------------------------------------------
+  // Lane (j, g) reads its own 8-element pieces of row j straight from HBM: all of a wave's loads are in flight together (one
+  // round trip; the LDS-staged copy of round 5 paid sixteen dependent ones), and the 128-byte lines a load touches are finished
+  // by the next three loads of the same wave (they hit in the CU's L1).
+  if (threadIdx.x == 0) { q_cnt[0] = 0u; q_cnt[1] = 0u; }
+  const int64_t row = row0 + wave * 32 + j;
+  const bool valid = row < p.n;
+  float xf[KS][8];
+  bf16x8 xh[KS], xl[KS];
+  float xn2 = 0.0f;
+  {
+    const TX *xr = static_cast<const TX *>(p.x) + (valid ? row : 0) * p.ldx + g * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f4 a = load4(xr + s * 16), b = load4(xr + s * 16 + 4);
+      xf[s][0] = a.x; xf[s][1] = a.y; xf[s][2] = a.z; xf[s][3] = a.w; xf[s][4] = b.x; xf[s][5] = b.y; xf[s][6] = b.z; xf[s][7] = b.w;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (!valid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[s][e] = 0.0f;
+      }
+      uint4 h4, l4;
+      xf_split8<XL>(xf[s], h4, l4);
+      xh[s] = __builtin_bit_cast(bf16x8, h4);
+      if constexpr (XL) xl[s] = __builtin_bit_cast(bf16x8, l4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xn2 = __builtin_fmaf(xf[s][e], xf[s][e], xn2);
+    }
+  }
+  xn2 += __shfl_xor(xn2, 32, 64);          // (a non-finite element makes this inf / NaN: the row is then recomputed exactly, below)
+  const float cmax2c = __uint_as_float(p.maxbits[0]);
+  const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2c);   // 2E, E = 2^-13 (|x|^2 + max|c|^2)
+  // the row's offset R (one bf16, rounded up): L2  s' = R + |c|^2 - 2 x.c = |x - c|^2 + (R - |x|^2) >= 0;  dot  s' = R - x.c >= 0
+  bf16x8 bx = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (g == 0) {
+    const float R = METRIC == METRIC_DOT ? 0.5f * (xn2 + cmax2c) + E2 : xn2 + E2;
+    bx[0] = (short)0x3F80; bx[1] = (short)0x3F80; bx[2] = (short)0x3F80; bx[3] = (short)xf_bf16_up(R);
+  }
+  if constexpr (PROF) pt[1] = clock64();
+
+  // ---- 2. coarse sweep -------------------------------------------------------------------------------------------------
+  const int ntiles = (p.k + MA_CT - 1) / MA_CT;
+  constexpr int NCHK = MA_CT * CW / 8;        // 16-byte chunks per tile (contiguous in global memory)
+  constexpr int CH = (NCHK + 255) / 256;      // per thread (9 at D = 128)
+  uint4 pf[CH];
+  auto tile_fetch = [&](int t) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.cpl) + (int64_t)t * NCHK;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int ch = threadIdx.x + 256 * u;
+      pf[u] = make_uint4(0, 0, 0, 0);
+      if (ch < NCHK) pf[u] = src[ch];
+    }
+  };
+  auto tile_store = [&](int buf) {
+    uint16_t *dst = cbuf + (size_t)buf * MA_CT * CS;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int ch = threadIdx.x + 256 * u;
+      const int cr = ch / (CW / 8), cc = ch - cr * (CW / 8);
+      if (ch < NCHK) *reinterpret_cast<uint4 *>(dst + cr * CS + cc * 8) = pf[u];
+    }
+  };
+  Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
+  tile_fetch(0);
+  tile_store(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) tile_fetch(t + 1);
+    const uint16_t *tl = cbuf + (size_t)buf * MA_CT * CS;
+    const uint16_t *r0 = tl + j * CS + g * 8, *r1 = tl + (32 + j) * CS + g * 8;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the norm / offset step first: its C operand is the inline constant 0
+    f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(r0 + D), bx, zero, 0, 0, 0);
+    f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(r1 + D), bx, zero, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(r0 + s * 16);
+      const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(r0 + D + 16 + s * 16);
+      const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(r1 + s * 16);
+      const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(r1 + D + 16 + s * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xh[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xh[s], acc1, 0, 0, 0);
+      if constexpr (XL) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xl[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xl[s], acc1, 0, 0, 0);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, xh[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, xh[s], acc1, 0, 0, 0);
+    }
+    // D[centroid i][row j]: lane (j, g) holds centroids i = (v & 3) + 8 (v >> 2) + 4 g of each 32-block.  Surrogates are >= 0 (or
+    // NaN), so their bit patterns order like the values: the tile's minimum by v_min3_u32, and only when it undercuts the row's
+    // running fourth-smallest (with k = 4096 about one tile in twenty) the tile's own four smallest -- value bits with the
+    // register number in the five lowest mantissa bits (2^-18 relative, inside E), one v_and_or_b32 + three v_med3_u32 + one
+    // v_min_u32 per centroid -- are folded into the running four.
+    uint32_t bm = min(__float_as_uint(acc0[0]), __float_as_uint(acc1[0]));
+#pragma unroll
+    for (int v = 1; v < 16; ++v) bm = min(bm, min(__float_as_uint(acc0[v]), __float_as_uint(acc1[v])));
+    if (bm < __float_as_uint(tp.m4)) {
+      uint32_t t1 = 0xFFFFFFFFu, t2 = 0xFFFFFFFFu, t3 = 0xFFFFFFFFu, t4 = 0xFFFFFFFFu;
+#pragma unroll
+      for (int li = 0; li < 32; ++li) {
+        const uint32_t key = (__float_as_uint(li < 16 ? acc0[li] : acc1[li - 16]) & 0xFFFFFFE0u) | (uint32_t)li;
+        t4 = xf_med3(t3, t4, key);
+        t3 = xf_med3(t2, t3, key);
+        t2 = xf_med3(t1, t2, key);
+        t1 = min(t1, key);
+      }
+      const uint32_t c0 = (uint32_t)(t * MA_CT + 4 * g);
+      auto fold = [&](uint32_t key) {
+        const uint32_t li = key & 31u, v = li & 15u;
+        top4_insert(tp, __uint_as_float(key & 0xFFFFFFE0u), c0 + (li >> 4) * 32u + 8u * (v >> 2) + (v & 3u));
+      };
+      fold(t1); fold(t2); fold(t3); fold(t4);
+    }
+    if (t + 1 < ntiles) tile_store(buf ^ 1);
+    __syncthreads();
+  }
+  if constexpr (PROF) pt[2] = clock64();
+  // the two lanes of a row hold disjoint centroid subsets: merge the partner's four
+  {
+    const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
+    const uint32_t pi1 = __shfl_xor(tp.i1, 32, 64), pi2 = __shfl_xor(tp.i2, 32, 64), pi3 = __shfl_xor(tp.i3, 32, 64);
+    top4_insert(tp, pm1, pi1);
+    top4_insert(tp, pm2, pi2);
+    top4_insert(tp, pm3, pi3);
+    top4_insert(tp, pm4, LANCE_HIP_NONE);   // >= the three just inserted: can only land in the fourth (index-free) slot
+  }
+  int cl = 3;                             // number of exact candidates - 1; 3 = recompute against every centroid
+  if (tp.m2 - tp.m1 > E2) cl = 0;
+  else if (tp.m3 - tp.m1 > E2) cl = 1;
+  else if (tp.m4 - tp.m1 > E2) cl = 2;
+  // NaN / overflow anywhere, a padding centroid among the candidates (fewer than four real ones in reach: never with k >= 32 finite
+  // centroids, but +inf surrogates must not reach the exact step), products in the denormal range (E2 <= 2^-100): recompute exactly
+  if (tp.i1 == LANCE_HIP_NONE || !(E2 < INFINITY) || !(E2 > 7.888609052210118e-31f) || !(tp.m1 < INFINITY)) cl = 3;
+  // lane g = 0 decides for the pair (equal surrogates may sit in a different order in the partner's registers)
+  cl = __shfl(cl, j, 64);
+  const uint32_t cand[3] = {(uint32_t)__shfl((int)tp.i1, j, 64), (uint32_t)__shfl((int)tp.i2, j, 64), (uint32_t)__shfl((int)tp.i3, j, 64)};
+
+  // ---- 3. exact re-check (argmin_value_float over the candidates) ------------------------------------------------------
+  uint32_t best = LANCE_HIP_NONE;
+  float bestv = INFINITY;
+  {
+    float bestb = INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bool need = valid && cl < 3 && t <= cl && cand[t] != LANCE_HIP_NONE && cand[t] < (uint32_t)p.k;
+      if (!__any(need)) continue;                                   // wave-uniform: rounds 2 and 3 are rare
+      const uint32_t c = need ? cand[t] : 0u;
+      const float v = xf_exact<KS, METRIC>(xf, p.cent + (int64_t)c * D, j, g);
+      if (need && (v < bestb || (v == bestb && best != LANCE_HIP_NONE && c < best))) { bestb = v; bestv = v; best = c; }
+    }
+  }
+  const bool queued = valid && cl == 3;        // ma_recompute_kernel answers the row; its PQ items go to the fix lists
+  if (best == LANCE_HIP_NONE) bestv = INFINITY;
+  if (g == 0 && valid) {
+    if (queued) {
+      const uint32_t slot = atomicAdd(p.afb_cnt, 1u);
+      p.afb_rows[slot] = (uint32_t)row;
+      for (int m = 0; m < M; ++m) xf_queue_item(p, q_cnt, q_items, (uint32_t)m, (uint32_t)(wave * 32 + j), row0);
+    } else {
+      p.part_ids[row] = best;
+      p.dists[row] = bestv;
+    }
+  }
+
+  if constexpr (PROF) pt[3] = clock64();
+  // ---- 4. residual -> bf16 planes in LDS (the centroid tiles are dead: the sweep's last barrier is behind every wave) ----
+  {
+    const int lrow = wave * 32 + j;
+    const bool sub = p.residual && best != LANCE_HIP_NONE;
+    const bool zero = !valid || (p.residual && best == LANCE_HIP_NONE);     // rows without a partition encode the zero vector
+    const float *cb = p.cent + (int64_t)(sub ? best : 0u) * D;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float r[8];
+      if (sub) {
+        const f4 c0 = *reinterpret_cast<const f4 *>(cb + s * 16 + g * 8), c1 = *reinterpret_cast<const f4 *>(cb + s * 16 + g * 8 + 4);
+        const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          r[e] = xf[s][e] - cv[e];
+          if (p.round_f16) r[e] = __half2float(__float2half_rn(r[e]));      // `*v - *cent` in half::f16 (residual.rs:96)
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = zero ? 0.0f : xf[s][e];
+      }
+      uint4 h4, l4;
+      xf_split8<true>(r, h4, l4);
+      const int chunk = 2 * s + g, slot = (chunk + lrow) % NCH;
+      *reinterpret_cast<uint4 *>(rh + (size_t)lrow * D + slot * 8) = h4;
+      *reinterpret_cast<uint4 *>(rl + (size_t)lrow * D + slot * 8) = l4;
+      if constexpr (SD == 8) {
+        float q = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q = __builtin_fmaf(r[e], r[e], q);
+        xn2s[lrow * M + chunk] = (uint16_t)xf_bf16_up(q * 1.0000005f);          // (the fused sum may sit an ulp under the true norm)
+      } else {
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q0 = __builtin_fmaf(r[e], r[e], q0); q1 = __builtin_fmaf(r[4 + e], r[4 + e], q1); }
+        *reinterpret_cast<uint32_t *>(xn2s + lrow * M + 2 * chunk) = (xf_bf16_up(q0 * 1.0000005f) & 0xFFFFu) | (xf_bf16_up(q1 * 1.0000005f) << 16);
+      }
+    }
+    if (g == 0) rskip[lrow] = (uint8_t)((!valid || queued) ? 1 : 0);
+  }
+  __syncthreads();
+  if constexpr (PROF) pt[4] = clock64();
+
+  // ---- 5. PQ encode: this wave's sub-quantisers against all 128 rows ---------------------------------------------------
+  const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, 0, 0, 0, 0, 0};
+#pragma unroll 1
+  for (int m = wave, mi = 0; m < M; m += 4, ++mi) {
+    bf16x8 af[8][NMF];
+    {
+      const uint4 *src = p.pqa + (int64_t)m * 8 * NMF * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int f = 0; f < NMF; ++f) af[t][f] = __builtin_bit_cast(bf16x8, src[(t * NMF + f) * 64]);
+    }
+    const float cmax2 = p.pq_cmax2[m];
+#pragma unroll 1
+    for (int rg = 0; rg < MA_ROWS / 32; ++rg) {
+      const int lrow = rg * 32 + j;
+      bf16x8 b1, b2;
+      if constexpr (SD == 8) {
+        const int slot = (m + lrow) % NCH;
+        b1 = *reinterpret_cast<const bf16x8 *>(rh + (size_t)lrow * D + slot * 8);
+        const bf16x8 lo8 = *reinterpret_cast<const bf16x8 *>(rl + (size_t)lrow * D + slot * 8);
+        b2 = g == 0 ? lo8 : ones;
+      } else {
+        const int slot = ((m >> 1) + lrow) % NCH;
+        const uint2 h4 = *reinterpret_cast<const uint2 *>(rh + (size_t)lrow * D + slot * 8 + (m & 1) * 4);
+        const uint2 l4 = *reinterpret_cast<const uint2 *>(rl + (size_t)lrow * D + slot * 8 + (m & 1) * 4);
+        const uint4 bb = g == 0 ? make_uint4(h4.x, h4.y, h4.x, h4.y) : make_uint4(l4.x, l4.y, 0x3F803F80u, 0x00003F80u);
+        b1 = __builtin_bit_cast(bf16x8, bb);
+        b2 = b1;
+      }
+      const float xq = __uint_as_float((uint32_t)xn2s[lrow * M + m] << 16);
+      const float margin = 0.000244140625f * (xq + cmax2);       // 2^-12 (|r_m|^2 + max|c|^2)
+      const float rowc = xq + margin;                             // keeps every surrogate >= 0: float order == unsigned order of the bits
+      f32x16 c0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) c0[v] = rowc;
+      uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b1, c0, 0, 0, 0);
+        if constexpr (NMF == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], b2, acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const uint32_t key = (__float_as_uint(acc[v]) & 0xFFFFFFC0u) | (uint32_t)((t & 3) * 16 + v);
+          if (t < 4) { a2 = xf_med3(a1, a2, key); a1 = min(a1, key); }
+          else { q2 = xf_med3(q1, q2, key); q1 = min(q1, key); }
+        }
+      }
+      // slot -> codeword: tile (slot >> 4) (+ 4 for the second tracker), register v = slot & 15 holds codeword 8 (v >> 2) + 4 g + (v & 3)
+      auto widen = [&](uint32_t key, uint32_t half) {
+        const uint32_t sl = key & 63u, v = sl & 15u;
+        const uint32_t cw = ((sl >> 4) + 4u * half) * 32u + 8u * (v >> 2) + 4u * (uint32_t)g + (v & 3u);
+        return (key & 0xFFFFFF00u) | cw;
+      };
+      const uint32_t ka1 = widen(a1, 0), ka2 = widen(a2, 0), kb1 = widen(q1, 1), kb2 = widen(q2, 1);
+      uint32_t m1 = min(ka1, kb1), m2 = min(max(ka1, kb1), min(ka2, kb2));
+      {   // the partner lane holds the other 128 codewords of the row
+        const uint32_t p1 = __shfl_xor(m1, 32, 64), p2 = __shfl_xor(m2, 32, 64);
+        const uint32_t lo = min(m1, p1), hi2 = max(m1, p1);
+        m2 = min(hi2, min(m2, p2));
+        m1 = lo;
+      }
+      if (g == 0) {
+        const float s1 = __uint_as_float(m1 & 0xFFFFFF00u), s2 = __uint_as_float(m2 & 0xFFFFFF00u);
+        // margin > 2^-100: the relative bounds above assume no product, sum or cleared mantissa bit sits in the denormal range
+        // (16 + 16 slots x 2^-126, 255 ulps of a denormal key); columns scaled like 1e-20 take the exact kernel (NaN anywhere: false)
+        const bool decided = (margin < INFINITY) && (margin > 7.888609052210118e-31f) && (s2 - s1 > margin);
+        codes_s[(wave * MW + mi) * MA_ROWS + lrow] = (uint8_t)(m1 & 0xFFu);      // (an undecided item's byte is rewritten by the fix kernel)
+        if (!decided && !rskip[lrow]) {
+          if constexpr (PROF) ++pc_und;
+          xf_queue_item(p, q_cnt, q_items, (uint32_t)m, (uint32_t)lrow, row0);
+        }
+      }
+    }
+  }
+  if constexpr (PROF) pt[5] = clock64();
+  __syncthreads();
+  // ---- the workgroup's undecided items: one atomic on the global list ----
+  {
+    const uint32_t nq = min(q_cnt[0], (uint32_t)XF_QCAP);
+    if (nq) {
+      if (threadIdx.x == 0) q_cnt[1] = atomicAdd(p.fb_cnt, nq);
+      __syncthreads();
+      const uint32_t base = q_cnt[1];
+      for (uint32_t i = threadIdx.x; i < nq; i += 256) {
+        const uint32_t it = q_items[i];
+        p.fb_items[base + i] = ((it >> 7) << 27) | (uint32_t)(row0 + (it & 127u));
+      }
+    }
+  }
+  // ---- codes: [wave][mi][row] in LDS -> [row][m] in HBM, one coalesced store per workgroup ----
+  {
+    const int64_t nrows = p.n - row0 < MA_ROWS ? p.n - row0 : MA_ROWS;
+    const int nbytes = (int)nrows * M;
+    uint8_t *dst = p.codes + row0 * M;
+    const int nw = nbytes / 4;
+    for (int i = threadIdx.x; i < nw; i += 256) {
+      uint32_t w = 0u;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int o = 4 * i + b, r = o / M, m = o - r * M;
+        w |= (uint32_t)codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r] << (8 * b);
+      }
+      reinterpret_cast<uint32_t *>(dst)[i] = w;
+    }
+    for (int o = nw * 4 + threadIdx.x; o < nbytes; o += 256) {
+      const int r = o / M, m = o - r * M;
+      dst[o] = codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r];
+    }
+  }
+  if constexpr (PROF) {
+    pt[6] = clock64();
+    uint32_t und = pc_und;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) und += __shfl_xor(und, o, 64);
+    if (lane == 0 && p.prof) {
+      for (int i = 0; i < 6; ++i) atomicAdd(&p.prof[i], (unsigned long long)(pt[i + 1] - pt[i]));
+      atomicAdd(&p.prof[6], 1ull);
+      atomicAdd(&p.prof[7], (unsigned long long)und);
+    }
+  }
+}
+
+bool xform_fused_supported(int dtype, int metric, int d, int m, int nbits, int64_t n, int nlist, const void *x, const float *cent,
+                           const float *codebook, uint8_t *codes, bool lanes32) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr || getenv("LANCE_HIP_NO_XFORM_FUSED") != nullptr ||
+                          getenv("LANCE_HIP_NO_MFMA_PQ") != nullptr || getenv("LANCE_HIP_NO_MFMA_ENCODE") != nullptr;
+  if (off || lanes32 || nbits != 8 || m <= 0 || d % m != 0) return false;
+  if (metric != METRIC_L2 && metric != METRIC_DOT) return false;
+  if (d % 16 != 0 || d < 16 || d > 128) return false;
+  const int sd = d / m;
+  if (sd != 4 && sd != 8) return false;
+  if (n < 2048 || nlist < 32) return false;
+  const size_t es = dtype == LANCE_HIP_F16 ? 2 : (dtype == LANCE_HIP_I8 ? 1 : 4);
+  if (reinterpret_cast<uintptr_t>(x) % (4 * es)) return false;
+  if ((reinterpret_cast<uintptr_t>(cent) & 15) || (reinterpret_cast<uintptr_t>(codebook) & 15) || (reinterpret_cast<uintptr_t>(codes) & 3)) return false;
+  return true;
+}
+
+template <int KS, int SD, int METRIC, typename TX>
+static void xf_launch_one(lance_hip_ctx *ctx, const XfArgs &a) {
+  constexpr size_t lds = xf_lds_bytes<KS, SD>();
+  hipLaunchKernelGGL((xf_kernel<KS, SD, METRIC, TX>), dim3((unsigned)cdiv((uint64_t)a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+}
+template <int KS, int SD>
+static void xf_launch_ks(lance_hip_ctx *ctx, const XfArgs &a, int metric, int dtype) {
+  if (metric == METRIC_DOT) {
+    if (dtype == LANCE_HIP_F16) xf_launch_one<KS, SD, METRIC_DOT, __half>(ctx, a);
+    else if (dtype == LANCE_HIP_I8) xf_launch_one<KS, SD, METRIC_DOT, int8_t>(ctx, a);
+    else xf_launch_one<KS, SD, METRIC_DOT, float>(ctx, a);
+  } else {
+    if (dtype == LANCE_HIP_F16) xf_launch_one<KS, SD, METRIC_L2, __half>(ctx, a);
+    else if (dtype == LANCE_HIP_I8) xf_launch_one<KS, SD, METRIC_L2, int8_t>(ctx, a);
+    else xf_launch_one<KS, SD, METRIC_L2, float>(ctx, a);
+  }
+}
+template <int SD>
+static int xf_launch_sd(lance_hip_ctx *ctx, const XfArgs &a, int d, int metric, int dtype) {
+  switch (d / 16) {
+    case 1: xf_launch_ks<1, SD>(ctx, a, metric, dtype); break;
+    case 2: xf_launch_ks<2, SD>(ctx, a, metric, dtype); break;
+    case 3: xf_launch_ks<3, SD>(ctx, a, metric, dtype); break;
+    case 4: xf_launch_ks<4, SD>(ctx, a, metric, dtype); break;
+    case 5: xf_launch_ks<5, SD>(ctx, a, metric, dtype); break;
+    case 6: xf_launch_ks<6, SD>(ctx, a, metric, dtype); break;
+    case 7: xf_launch_ks<7, SD>(ctx, a, metric, dtype); break;
+    case 8: xf_launch_ks<8, SD>(ctx, a, metric, dtype); break;
+    default: return LANCE_HIP_EINVAL;
+  }
+  return LANCE_HIP_OK;
+}
+
+// x: [n][d] rows in the column's element type; metric: METRIC_L2 (residual encoded) or METRIC_DOT (the row itself encoded);
+// round_f16: the residual is rounded to binary16 (f16 columns, also when they arrive as a normalised f32 copy: cosine);
+// part_ids / dists [n] and codes [n][m] are filled exactly as launch_assign + the fused encode fill them.
+int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x, int64_t n, int d, const float *cent, int nlist,
+                       const float *codebook, int m, uint32_t *part_ids, float *dists, uint8_t *codes, bool round_f16) {
+  if (n == 0) return LANCE_HIP_OK;
+  const int sd = d / m, nmf = sd == 8 ? 2 : 1;
+  const int kpad = (nlist + MA_CT - 1) / MA_CT * MA_CT;
+  uint16_t *cpl = ctx->scratch_t<uint16_t>("xf.cpl", (size_t)kpad * (2 * d + 16));
+  uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);      // [0] max |c|^2, [2] rows left to the recompute kernel
+  if (!cpl || !maxbits) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(lh::memset_async(maxbits, 0, 16, ctx->stream));
+  if (metric == METRIC_DOT) hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_DOT>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, nlist, d, cpl, maxbits);
+  else hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_L2>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, nlist, d, cpl, maxbits);
+  uint4 *pqa = ctx->scratch_t<uint4>("xf.pqa", (size_t)m * 8 * nmf * 64);
+  float *cmax2 = ctx->scratch_t<float>("xf.cmax2", (size_t)m);
+  // rows go through in chunks: the undecided-item list is [chunk * m] words of scratch (256 MB at most), whatever n is; row numbers take 27 bits
+  const int64_t chunk = std::max<int64_t>(MA_ROWS, std::min<int64_t>(n, ((int64_t)64 << 20) / m / MA_ROWS * MA_ROWS));
+  uint32_t *fb_cnt = ctx->scratch_t<uint32_t>("xf.fb_cnt", 4);
+  uint32_t *fb_items = ctx->scratch_t<uint32_t>("xf.fb_items", (size_t)chunk * m);
+  uint32_t *afb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)chunk);
+  if (!pqa || !cmax2 || !fb_cnt || !fb_items || !afb_rows) return LANCE_HIP_ENOMEM;
+  ScopedTimer t(ctx, "xform_fused");
+  if (sd == 8) hipLaunchKernelGGL(xf_pq_prep_kernel<8>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+  else hipLaunchKernelGGL(xf_pq_prep_kernel<4>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+  const size_t es = dtype == LANCE_HIP_F16 ? 2 : (dtype == LANCE_HIP_I8 ? 1 : 4);
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t rows = std::min<int64_t>(chunk, n - r0);
+    XfArgs a;
+    a.x = static_cast<const char *>(x) + (size_t)r0 * d * es; a.n = rows; a.ldx = d; a.k = nlist;
+    a.cpl = cpl; a.maxbits = maxbits; a.cent = cent;
+    a.residual = metric == METRIC_L2 ? 1 : 0; a.round_f16 = round_f16 ? 1 : 0; a.check_finite = 1;
+    a.pqa = pqa; a.pq_cmax2 = cmax2;
+    a.part_ids = part_ids + r0; a.dists = dists + r0; a.codes = codes + r0 * m;
+    a.afb_cnt = maxbits + 2; a.afb_rows = afb_rows; a.fb_cnt = fb_cnt; a.fb_items = fb_items;
+    LH_CHECK_HIP(lh::memset_multi(ctx->stream, {{fb_cnt, 0, 16}, {maxbits + 2, 0, 4}}));
+    {
+      ScopedTimer t1(ctx, "xf_main");
+      static const bool prof = getenv("LANCE_HIP_XF_PROF") != nullptr;      // s_memtime phase stamps (d = 128, sub-dimension 8, f32, L2), printed per launch
+      if (prof && sd == 8 && d == 128 && metric == METRIC_L2 && dtype == LANCE_HIP_F32) {
+        a.prof = ctx->scratch_t<unsigned long long>("xf.prof", 8);
+        if (!a.prof) return LANCE_HIP_ENOMEM;
+        LH_CHECK_HIP(lh::memset_async(a.prof, 0, 64, ctx->stream));
+        constexpr size_t lds = xf_lds_bytes<8, 8>();
+        hipLaunchKernelGGL((xf_kernel<8, 8, METRIC_L2, float, true>), dim3((unsigned)cdiv((uint64_t)a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+        unsigned long long h[8];
+        LH_CHECK_HIP(hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
+        LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (h[6])
+          fprintf(stderr, "[xf prof] waves=%llu | s_memtime ticks per wave: rows->regs %.0f | sweep %.0f | merge+exact %.0f | residual+barrier %.0f | pq %.0f | codes out %.0f | "
+                  "undecided pq items %llu\n", h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6],
+                  (double)h[5] / h[6], h[7]);
+      } else if (sd == 8) LH_TRY(xf_launch_sd<8>(ctx, a, d, metric, dtype));
+      else LH_TRY(xf_launch_sd<4>(ctx, a, d, metric, dtype));
+    }
+    ScopedTimer t2(ctx, "xf_fix");          // the two exact clean-up kernels
+    // rows the coarse surrogate left undecided: exact distances to every centroid (writes part_ids / dists) ...
+    MaArgs ma{};
+    ma.x = a.x; ma.n = rows; ma.ldx = d; ma.d = d; ma.k = nlist; ma.cent = cent; ma.bias = nullptr;
+    ma.ids = a.part_ids; ma.dists = a.dists; ma.check_finite = 1; ma.fb_cnt = a.afb_cnt; ma.fb_rows = afb_rows; ma.active = nullptr;
+    LH_TRY(ma_recompute_launch(ctx, ma, metric, dtype));
+    // ... then the undecided (row, sub-quantiser) items, which read the partition ids
+    XfFixArgs fa;
+    fa.x = a.x; fa.ldx = d; fa.cent = cent; fa.part_ids = a.part_ids; fa.residual = a.residual; fa.round_f16 = a.round_f16;
+    fa.codebook = codebook; fa.m = m; fa.cnt = fb_cnt; fa.items = fb_items; fa.codes = a.codes;
+    const dim3 fgrid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)rows, 64)), 2048));
+    if (sd == 8) {
+      if (dtype == LANCE_HIP_F16) hipLaunchKernelGGL((xf_fix_kernel<8, __half>), fgrid, dim3(256), 0, ctx->stream, fa);
+      else if (dtype == LANCE_HIP_I8) hipLaunchKernelGGL((xf_fix_kernel<8, int8_t>), fgrid, dim3(256), 0, ctx->stream, fa);
+      else hipLaunchKernelGGL((xf_fix_kernel<8, float>), fgrid, dim3(256), 0, ctx->stream, fa);
+    } else {
+      if (dtype == LANCE_HIP_F16) hipLaunchKernelGGL((xf_fix_kernel<4, __half>), fgrid, dim3(256), 0, ctx->stream, fa);
+      else if (dtype == LANCE_HIP_I8) hipLaunchKernelGGL((xf_fix_kernel<4, int8_t>), fgrid, dim3(256), 0, ctx->stream, fa);
+      else hipLaunchKernelGGL((xf_fix_kernel<4, float>), fgrid, dim3(256), 0, ctx->stream, fa);
+    }
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+}  // namespace lh
