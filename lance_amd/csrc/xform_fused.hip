@@ -28,9 +28,9 @@
 //   5. PQ encode with the roles swapped: wave w now owns sub-quantisers w, w + 4, ... for ALL 128 rows; its 256 codewords sit
 //      in registers as MFMA A fragments prepared once per call (xf_pq_prep_kernel), the rows stream from LDS as B.  The
 //      whole surrogate comes out of the matrix pipe -- for sub-dimension 8 two K = 16 products per 32 x 32 tile,
-//           A1 = [-2 ch | -2 cl]   B1 = [xh | xh]        A2 = [-2 ch | n1 n2 n3 0 ..]   B2 = [xl | 1 1 1 0 ..]
-//      (|c|^2 = n1 + n2 + n3 as three bf16 terms), accumulator started at |r_m|^2 + margin: s'' = |r_m - c|^2 + margin >= 0 with
-//      no VALU arithmetic at all, and no K slot multiplies zeros (sub-dimension 4: one product, [xh xh | xl 1 1 1 0]).
+//           A1 = [-2 ch | -2 cl]   B1 = [xh | xh]        A2 = [-2 ch | n1 n2 n3 1 0 ..]   B2 = [xl | 1 1 1 R 0 ..]
+//      (|c|^2 = n1 + n2 + n3 as three bf16 terms, R = one bf16 >= |r_m|^2 + margin): s'' = |r_m - c|^2 + (R - |r_m|^2) >= 0 with
+//      no VALU arithmetic at all, and no K slot multiplies zeros (sub-dimension 4: one product, [xh xh | xl 1 1 1 R]).
 //      Epilogue = 3 VALU per (row, codeword): key = (bits & ~63) | slot (v_and_or_b32, slot an inline constant), second
 //      smallest by v_med3_u32, smallest by v_min_u32 -- two trackers of 64 slots so the slot number stays an inline constant.
 //      margin = 2^-12 (|r_m|^2 + max|c|^2) as in pq_mfma.hip (split error <= 2^-14 |r||c|, the |c|^2 terms and the f32
@@ -123,10 +123,10 @@ __global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict
     dst[j] = h;                                  // A1, g = 0: -2 ch
     dst[32 + j] = l;                             // A1, g = 1: -2 cl
     dst[64 + j] = h;                             // A2, g = 0: -2 ch
-    dst[96 + j] = make_uint4(n1 | n2 << 16, n3, 0u, 0u);   // A2, g = 1: |c|^2 in three terms
+    dst[96 + j] = make_uint4(n1 | n2 << 16, n3 | 0x3F80u << 16, 0u, 0u);   // A2, g = 1: |c|^2 in three terms, and a 1 for the row's offset
   } else {
     dst[j] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, lo[0] | lo[1] << 16, lo[2] | lo[3] << 16);       // g = 0: [-2 ch | -2 cl]
-    dst[32 + j] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, n1 | n2 << 16, n3);                         // g = 1: [-2 ch | n1 n2 n3 0]
+    dst[32 + j] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, n1 | n2 << 16, n3 | 0x3F80u << 16);          // g = 1: [-2 ch | n1 n2 n3 1]
   }
   __syncthreads();
   if (c == 0) cmax2[m] = __uint_as_float(s_max);
@@ -176,7 +176,9 @@ constexpr int XF_QCAP = 1024;
 template <int KS, int SD>
 constexpr size_t xf_lds_main() {
   constexpr int D = KS * 16, M = D / SD;
-  constexpr size_t b = (size_t)2 * MA_CT * (2 * D + 24) * 2;                                     // two centroid tiles
+  constexpr size_t a = (size_t)MA_ROWS * (D + 4) * 4;                                            // rows, f32
+  constexpr size_t b0 = (size_t)2 * MA_CT * (2 * D + 24) * 2;                                    // two centroid tiles
+  constexpr size_t b = a > b0 ? a : b0;
   constexpr size_t c = (size_t)2 * MA_ROWS * D * 2 + (size_t)MA_ROWS * M * 2 + (size_t)MA_ROWS * ((M + 3) / 4) * 4 + MA_ROWS;   // residual planes, norms, codes, flags
   return ((b > c ? b : c) + 15) / 16 * 16;
 }
@@ -302,11 +304,15 @@ __global__ __launch_bounds__(256) void xf_fix_kernel(XfFixArgs a) {
 
 template <int KS, int SD, int METRIC, typename TX, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
-  long long pt[7] = {0, 0, 0, 0, 0, 0, 0};
+  long long pa[6] = {0, 0, 0, 0, 0, 0}, pprev = 0;      // PROF: s_memtime ticks per phase, summed over this workgroup's row tiles
   uint32_t pc_und = 0;
-  if constexpr (PROF) pt[0] = clock64();
+  if constexpr (PROF) pprev = clock64();
+  auto mark = [&](int i) {
+    if constexpr (PROF) { const long long t = clock64(); pa[i] += t - pprev; pprev = t; }
+  };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = KS * 16, M = D / SD;
+  constexpr int XS = D + 4;          // f32 row stride of the x staging tile
   constexpr int CW = 2 * D + 16;     // bf16 elements per centroid in global memory: hi (D) | norm step (16) | lo (D)
   constexpr int CS = CW + 8;         // ... and per LDS row (16-byte skew: conflict-free ds_read_b128)
   constexpr int NCH = D / 8;         // 16-byte chunks per residual row
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   constexpr int MW = (M + 3) / 4;    // sub-quantisers per wave
   constexpr bool XL = !std::is_same<TX, int8_t>::value;       // int8 rows are exact in bf16
   static_assert(SD == 4 || SD == 8, "sub-dimension 4 or 8");
+  float *xs = reinterpret_cast<float *>(smem);                       // phase 1: [128][XS] f32
   uint16_t *cbuf = reinterpret_cast<uint16_t *>(smem);               // phase 2: [2][MA_CT][CS]
   uint16_t *rh = reinterpret_cast<uint16_t *>(smem);                 // phase 3: [128][D] hi, [128][D] lo (chunks rotated by the row)
   uint16_t *rl = rh + (size_t)MA_ROWS * D;
@@ -329,29 +336,39 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   const int j = lane & 31, g = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * MA_ROWS;
 
-  // ---- 1. rows -> registers ---------------------------------------------------------------------------------------------
-  // Lane (j, g) reads its own 8-element pieces of row j straight from HBM: all of a wave's loads are in flight together (one
-  // round trip; the LDS-staged copy of round 5 paid sixteen dependent ones), and the 128-byte lines a load touches are finished
-  // by the next three loads of the same wave (they hit in the CU's L1).
+  // ---- 1. rows -> LDS -> registers --------------------------------------------------------------------------------------
+  // Coalesced 16-byte loads, ALL of a thread's loads in flight before the first LDS store (one HBM round trip: the loop form of
+  // round 5 -- load, LDS store, next load -- paid sixteen dependent ones, 110k of a wave's 335k cycles; lanes fetching their own
+  // 16-byte pieces straight from HBM measured 54k: four times the line requests).  (Persistent workgroups that request the next
+  // tile's rows before the PQ phase were tried -- gpurun r06i: the 64 staging registers spill, 1.03 -> 1.36 ms.)
   if (threadIdx.x == 0) { q_cnt[0] = 0u; q_cnt[1] = 0u; }
   const int64_t row = row0 + wave * 32 + j;
   const bool valid = row < p.n;
+  constexpr int NLD = MA_ROWS * (D / 4) / 256;        // 4-element pieces per thread (16 at D = 128)
+  {
+    f4 stage[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / (D / 4), c4 = idx - r * (D / 4);
+      stage[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (row0 + r < p.n) stage[u] = load4(static_cast<const TX *>(p.x) + (row0 + r) * p.ldx + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / (D / 4), c4 = idx - r * (D / 4);
+      *reinterpret_cast<f4 *>(&xs[r * XS + 4 * c4]) = stage[u];
+    }
+  }
+  __syncthreads();
   float xf[KS][8];
   bf16x8 xh[KS], xl[KS];
   float xn2 = 0.0f;
   {
-    const TX *xr = static_cast<const TX *>(p.x) + (valid ? row : 0) * p.ldx + g * 8;
+    const float *xr = xs + (wave * 32 + j) * XS + g * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const f4 a = load4(xr + s * 16), b = load4(xr + s * 16 + 4);
+      const f4 a = *reinterpret_cast<const f4 *>(xr + s * 16), b = *reinterpret_cast<const f4 *>(xr + s * 16 + 4);
       xf[s][0] = a.x; xf[s][1] = a.y; xf[s][2] = a.z; xf[s][3] = a.w; xf[s][4] = b.x; xf[s][5] = b.y; xf[s][6] = b.z; xf[s][7] = b.w;
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (!valid) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xf[s][e] = 0.0f;
-      }
       uint4 h4, l4;
       xf_split8<XL>(xf[s], h4, l4);
       xh[s] = __builtin_bit_cast(bf16x8, h4);
@@ -369,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     const float R = METRIC == METRIC_DOT ? 0.5f * (xn2 + cmax2c) + E2 : xn2 + E2;
     bx[0] = (short)0x3F80; bx[1] = (short)0x3F80; bx[2] = (short)0x3F80; bx[3] = (short)xf_bf16_up(R);
   }
-  if constexpr (PROF) pt[1] = clock64();
+  __syncthreads();   // xs is dead: the same LDS now holds centroid tiles
+  mark(0);
 
   // ---- 2. coarse sweep -------------------------------------------------------------------------------------------------
   const int ntiles = (p.k + MA_CT - 1) / MA_CT;
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     if (t + 1 < ntiles) tile_store(buf ^ 1);
     __syncthreads();
   }
-  if constexpr (PROF) pt[2] = clock64();
+  mark(1);
   // the two lanes of a row hold disjoint centroid subsets: merge the partner's four
   {
     const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
@@ -498,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     }
   }
 
-  if constexpr (PROF) pt[3] = clock64();
+  mark(2);
   // ---- 4. residual -> bf16 planes in LDS (the centroid tiles are dead: the sweep's last barrier is behind every wave) ----
   {
     const int lrow = wave * 32 + j;
@@ -540,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     if (g == 0) rskip[lrow] = (uint8_t)((!valid || queued) ? 1 : 0);
   }
   __syncthreads();
-  if constexpr (PROF) pt[4] = clock64();
+  mark(3);
 
   // ---- 5. PQ encode: this wave's sub-quantisers against all 128 rows ---------------------------------------------------
   const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, 0, 0, 0, 0, 0};
@@ -574,10 +592,15 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
       }
       const float xq = __uint_as_float((uint32_t)xn2s[lrow * M + m] << 16);
       const float margin = 0.000244140625f * (xq + cmax2);       // 2^-12 (|r_m|^2 + max|c|^2)
-      const float rowc = xq + margin;                             // keeps every surrogate >= 0: float order == unsigned order of the bits
-      f32x16 c0;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) c0[v] = rowc;
+      // the row's offset R = bf16 >= |r_m|^2 + margin rides in the fourth slot of the "ones" vector (the codeword side holds a 1 there):
+      // every surrogate is >= 0 (float order == unsigned order of the bits) and the accumulator starts from the inline constant 0
+      const uint32_t rb = xf_bf16_up(xq + margin);
+      if constexpr (SD == 8) {
+        if (g == 1) b2[3] = (short)rb;
+      } else {
+        if (g == 1) { b1[7] = (short)rb; b2 = b1; }
+      }
+      const f32x16 c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -617,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
       }
     }
   }
-  if constexpr (PROF) pt[5] = clock64();
+  mark(4);
   __syncthreads();
   // ---- the workgroup's undecided items: one atomic on the global list ----
   {
@@ -652,13 +675,13 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
       dst[o] = codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r];
     }
   }
+  mark(5);
   if constexpr (PROF) {
-    pt[6] = clock64();
     uint32_t und = pc_und;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) und += __shfl_xor(und, o, 64);
     if (lane == 0 && p.prof) {
-      for (int i = 0; i < 6; ++i) atomicAdd(&p.prof[i], (unsigned long long)(pt[i + 1] - pt[i]));
+      for (int i = 0; i < 6; ++i) atomicAdd(&p.prof[i], (unsigned long long)pa[i]);
       atomicAdd(&p.prof[6], 1ull);
       atomicAdd(&p.prof[7], (unsigned long long)und);
     }
@@ -681,10 +704,12 @@ bool xform_fused_supported(int dtype, int metric, int d, int m, int nbits, int64
   return true;
 }
 
+static unsigned xf_grid(lance_hip_ctx *, int64_t n) { return (unsigned)cdiv((uint64_t)n, MA_ROWS); }      // one workgroup per 128 rows
+
 template <int KS, int SD, int METRIC, typename TX>
 static void xf_launch_one(lance_hip_ctx *ctx, const XfArgs &a) {
   constexpr size_t lds = xf_lds_bytes<KS, SD>();
-  hipLaunchKernelGGL((xf_kernel<KS, SD, METRIC, TX>), dim3((unsigned)cdiv((uint64_t)a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+  hipLaunchKernelGGL((xf_kernel<KS, SD, METRIC, TX>), dim3(xf_grid(ctx, a.n)), dim3(256), lds, ctx->stream, a);
 }
 template <int KS, int SD>
 static void xf_launch_ks(lance_hip_ctx *ctx, const XfArgs &a, int metric, int dtype) {
@@ -758,7 +783,7 @@ int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x,
         if (!a.prof) return LANCE_HIP_ENOMEM;
         LH_CHECK_HIP(lh::memset_async(a.prof, 0, 64, ctx->stream));
         constexpr size_t lds = xf_lds_bytes<8, 8>();
-        hipLaunchKernelGGL((xf_kernel<8, 8, METRIC_L2, float, true>), dim3((unsigned)cdiv((uint64_t)a.n, MA_ROWS)), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL((xf_kernel<8, 8, METRIC_L2, float, true>), dim3(xf_grid(ctx, a.n)), dim3(256), lds, ctx->stream, a);
         unsigned long long h[8];
         LH_CHECK_HIP(hipMemcpyAsync(h, a.prof, 64, hipMemcpyDeviceToHost, ctx->stream));
         LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));

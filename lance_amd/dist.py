@@ -332,7 +332,7 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
         _, ranges = block_ranges(n, world)
         lo, hi = ranges[rank]
         if hi > lo:
-            part_l, codes_l, _ = eng.ivfpq_encode(x[lo:hi], cent, cb, params.metric)
+            part_l, codes_l, _ = eng.ivfpq_encode(x[lo:hi], cent, cb, params.metric, want_loss=False)
         else:
             part_l = torch.empty(0, dtype=torch.int32, device=x.device)
             codes_l = torch.empty((0, num_sub_vectors if num_bits == 8 else num_sub_vectors // 2), dtype=torch.uint8, device=x.device)
@@ -479,7 +479,7 @@ def create_index_rowsharded(x_local, metric="l2", num_partitions=256, num_sub_ve
         if n_local == 0:
             return (torch.empty(0, dtype=torch.int32, device=dev),
                     torch.empty((0, num_sub_vectors if num_bits == 8 else num_sub_vectors // 2), dtype=torch.uint8, device=dev))
-        p, c, _ = eng.ivfpq_encode(x_local, cent, cb, params.metric)
+        p, c, _ = eng.ivfpq_encode(x_local, cent, cb, params.metric, want_loss=False)
         return p, c
 
     part_l, codes_l = timed("transform", transform)

@@ -273,7 +273,9 @@ class Engine:
         check(self.lib.lance_hip_pq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(codebook), m, nb, _ptr(codes)))
         return codes
 
-    def ivfpq_encode(self, x, centroids, codebook, metric="l2"):
+    def ivfpq_encode(self, x, centroids, codebook, metric="l2", want_loss=True):
+        """-> (partition ids, PQ codes, loss).  want_loss=False passes NULL for `loss_out_host`: the C side then skips copying the n
+        assignment distances to the host and summing them there (0.5 ms per million rows; the index build does not use the figure)."""
         x, dt = _vec(x); centroids = _model(centroids, x)
         codebook = _model(codebook, x)
         n, d = x.shape
@@ -284,8 +286,9 @@ class Engine:
         loss = C.c_double(0)
         torch.cuda.synchronize()
         check(self.lib.lance_hip_ivfpq_encode(self.h, dt, METRICS[metric], _ptr(x), n, d, _ptr(centroids),
-                                              centroids.shape[0], _ptr(codebook), m, nb, _ptr(part), _ptr(codes), C.byref(loss)))
-        return part, codes, loss.value
+                                              centroids.shape[0], _ptr(codebook), m, nb, _ptr(part), _ptr(codes),
+                                              C.byref(loss) if want_loss else None))
+        return part, codes, (loss.value if want_loss else None)
 
     def find_partitions(self, q, centroids, nprobes, metric="l2"):
         centroids, dt = _vec(centroids)

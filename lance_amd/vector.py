@@ -496,7 +496,7 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
         finally:
             if pq_pool is not None:
                 pq_pool.shutdown(wait=True)
-    part, codes, _ = timed("transform", lambda: eng.ivfpq_encode(x, cent, cb, params.metric))
+    part, codes, _ = timed("transform", lambda: eng.ivfpq_encode(x, cent, cb, params.metric, want_loss=False))
     ix = timed("build_partitions", lambda: DeviceIndex.create(eng, params.metric, cent, cb, part, codes, None,
                                                               raw=x if keep_raw else None,
                                                               dtype="int8" if x.dtype == torch.int8 else None))
