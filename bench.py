@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--streams", type=int, default=3, help="engine contexts (HIP streams) the query batches alternate on")
     ap.add_argument("--no-grid", action="store_true", help="skip the small-batch latencies and the SURVEY 8(d) recall grid (a few seconds)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the child run on the f32 refine source and the PCIe-inclusive build (round 6 additions to the line)")
     # ranks started by this script's own launcher take their arguments from the environment: torchrun's argument parser refuses
     # `--n` after the script name (an abbreviation of several of ITS options: gpurun r05a)
     args = ap.parse_args(json.loads(os.environ["LANCE_BENCH_ARGV"])) if "LANCE_BENCH_ARGV" in os.environ else ap.parse_args()
@@ -197,7 +198,24 @@ def main():
             idx, bs = build_once()
             build_secs.append(bs)
         build_sec = min(build_secs)
+        # informational (never `build_sec`): the same build when the boundary hands over a HOST buffer -- the column crosses PCIe first
+        build_sec_pcie = None
+        if not args.no_extras and os.environ.get("LANCE_BENCH_CHILD") != "1":
+            hx = x.cpu().pin_memory()
+            xd = torch.empty_like(x)
+            bt = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                xd.copy_(hx, non_blocking=True)
+                ixp = lance_amd.create_index(xd, "IVF_PQ", metric="l2", num_partitions=nlist, num_sub_vectors=m)
+                torch.cuda.synchronize()
+                bt.append(time.perf_counter() - t0)
+                del ixp
+            build_sec_pcie = min(bt)
+            del hx, xd
     else:
+        build_sec_pcie = None
         # One node, N ranks: every rank generates and keeps ONLY its block of the 1M rows (same mixture, own draws); the
         # vectors never leave their GPU during the build.  IVF k-means = Lloyd iterations with one RCCL all-reduce of the
         # fused [k*d sums | k counts] buffer per iteration ("sharded"; the replicated-training time is reported beside it),
@@ -493,10 +511,15 @@ def main():
             "transform": {"bound": "hbm", "algorithmic_bytes": tr_bytes, "seconds": tr_sec,
                           "achieved": (tr_bytes / tr_sec / 1e9) if tr_sec else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (tr_bytes / tr_sec / 1e9 / HBM_PEAK_GBS) if tr_sec else None,
-                          "what": "lance_hip_ivfpq_encode over all rows: MFMA assign + exact re-check + fused residual / PQ encode; bytes = N*d*s read + N*(4+M) written"},
+                          "what": "lance_hip_ivfpq_encode over all rows as create_index calls it (host wall clock of the call): ONE kernel (xf_kernel, xform_fused.hip) "
+                                  "reads every row once -- MFMA coarse assign, exact re-check, residual, MFMA PQ encode -- plus two clean-up kernels for the ~1 % undecided "
+                                  "items; bytes = N*d*s read + N*(4+M) written.  The kernel is VALU-issue bound, not HBM bound: 3 VALU per (row, codeword) pair "
+                                  "(profiles/r06_xform_fused_notes.txt)"},
             "estep_ivf": {"bound": "mfma", "rows": ns, "centroids": nlist, "d": d, "seconds": e_sec,
                           "achieved": e_flop / e_sec / 1e12, "achieved_executed": 3.0 * e_flop / e_sec / 1e12, "peak": MFMA_BF16_PEAK,
                           "unit": "TFLOP/s", "frac": e_flop / e_sec / 1e12 / MFMA_BF16_PEAK, "frac_executed": 3.0 * e_flop / e_sec / 1e12 / MFMA_BF16_PEAK,
+                          "peak_measured": eng.ubench("mfma_bf16") / 1e12,
+                          "peak_measured_source": "lance_hip_ubench(mfma_bf16): v_mfma_f32_32x32x16_bf16 register loop, measured in this run",
                           "exact_recheck_seconds": e_recheck, "call_wall_seconds": e_wall,
                           "what": "the MFMA sweep kernel (ma_top3_kernel: bf16x3 products, four smallest kept) of lance_hip_assign over the training "
                                   "sample against the trained centroids, mean of 20 launches by HIP events on the engine's stream; the exact re-check "
@@ -531,6 +554,8 @@ def main():
         "graph_priming_calls": graph_priming,
         "host_buffers_qps_pcie_inclusive": pcie_qps,
         "build_sec": build_sec,
+        "build_sec_pcie_inclusive": build_sec_pcie,
+        "qps_f32_refine_source": None,
         # N > 1: the two numbers that say something about scaling (the replica `value` is linear by construction): the SAME
         # query batches answered jointly by list shards (strong scaling), and the row-sharded build with one all-reduce per
         # Lloyd iteration.  null at N = 1.  No multi-GPU hardware record exists for them before the driver's SCALE run.
@@ -559,11 +584,21 @@ def main():
         cells = avg_bytes / m
         flop = 2.0 * d * cells
         MFMA_F16_PEAK = 2500.0      # TFLOP/s dense f16 / bf16, MI355X_MICROARCH.md
+        mfma_meas = eng.ubench("mfma_f16") / 1e12      # the same instruction in a plain register loop on THIS box (lance_hip_ubench 10)
         ach = flop / (avg_scan_ms * 1e-3) / 1e12 if avg_scan_ms > 0 else 0.0
+        la_rate = avg_bytes / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0
         result["roofline"] = dict(common, kernel="ivfpq_mscan_kernel<SD=8,KS=8> (main pass: matrix-core filter scan of all nprobes partitions, "
                                   "32 rows x 32 queries per v_mfma_f32_32x32x16_f16 chain)",
                                   bound="mfma", achieved=ach, peak=MFMA_F16_PEAK, unit="TFLOP/s", frac=ach / MFMA_F16_PEAK,
                                   peak_source="MI355X_MICROARCH.md: dense f16 MFMA ~2.5 PFLOP/s",
+                                  peak_measured=mfma_meas, frac_of_peak_measured=(ach / mfma_meas) if mfma_meas else None,
+                                  peak_measured_source="lance_hip_ubench(mfma_f16): v_mfma_f32_32x32x16_f16, four independent accumulator chains per wave, "
+                                                       "two waves per SIMD, operands in registers, measured in this run",
+                                  # SURVEY 8(d)'s unit against the same peak: the LUT formulation of the reference needs M lookup-adds per (row, query)
+                                  # cell; counting each as ONE flop, the fraction of the MFMA peak's flop rate this kernel delivers them at
+                                  frac_algorithmic=(la_rate / 1e12 / MFMA_F16_PEAK),
+                                  frac_algorithmic_what="SURVEY 8(d) lookup-adds per second (M per (row, query) cell, one flop each) / dense f16 MFMA flop per second; "
+                                                        "the executed-flop `frac` is 2 d / M = 16 x this",
                                   executed_flop_per_launch=flop, row_query_cells_per_launch=cells,
                                   cells_per_s=cells / (avg_scan_ms * 1e-3) if avg_scan_ms > 0 else 0.0,
                                   # SURVEY 8(d)'s own unit beside it: the LUT formulation needs M lookup-adds per (row, query) cell; the rate this
@@ -609,10 +644,21 @@ def main():
         rt["refine_kernel"] = {"bound": "hbm", "algorithmic_bytes": refine_bytes, "avg_launch_ms": r_ms, "achieved": refine_bytes / (r_ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": refine_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "what": f"{args.nq} x {keff_b} candidate rows of {d} elements read at random from the refine source (two lanes per row, whole row in flight)"}
-    if per_launch("ivfpq_scan_c0") > 0:
+    msbound = eng.timing_query("count:ivfpq_msbound")[1] > 0      # the bound pass ran on the matrix cores (search_ms.hip: ms_bound_kernel)
+    if per_launch("ivfpq_scan_c0") > 0 and msbound:
+        b_ms = per_launch("ivfpq_scan_c0")
+        cells_b = near_bytes / m
+        fl_b = 2.0 * d * cells_b
+        rt["bound_pass"] = {"kernel": "ms_bound_kernel<SD=8,KS=8> (+ its two item-table kernels: the stage's HIP-event time)", "bound": "mfma",
+                            "row_query_cells": cells_b, "executed_flop": fl_b, "avg_launch_ms": b_ms, "achieved": fl_b / (b_ms * 1e-3) / 1e12,
+                            "peak": 2500.0, "unit": "TFLOP/s", "frac": fl_b / (b_ms * 1e-3) / 1e12 / 2500.0,
+                            "what": "512-bin histogram of |c^|^2 - 2 r.c^ + |r|^2 over every query's NEAREST partition from the f16 product on "
+                                    "v_mfma_f32_32x32x16_f16 (2 d flop per (row, query) cell, one FMA + one compare + one LDS atomic per cell behind it); "
+                                    "a tenth of the main scan's cells, latency and LDS-atomic bound rather than MFMA bound -- the fraction says how far"}
+    elif per_launch("ivfpq_scan_c0") > 0:
         b_ms = per_launch("ivfpq_scan_c0")
         g_ = near_bytes / 4.0
-        rt["bound_pass"] = {"bound": "lds", "algorithmic_gathers": g_, "avg_launch_ms": b_ms, "achieved": g_ / (b_ms * 1e-3) / 1e9, "peak": guide_lds_peak / 1e9,
+        rt["bound_pass"] = {"kernel": "ivfpq_qbound_kernel (integer tables)", "bound": "lds", "algorithmic_gathers": g_, "avg_launch_ms": b_ms, "achieved": g_ / (b_ms * 1e-3) / 1e9, "peak": guide_lds_peak / 1e9,
                             "unit": "G lane-gathers/s", "frac": g_ / (b_ms * 1e-3) / guide_lds_peak,
                             "what": "integer-table histogram over every query's nearest partition, four queries per 8-byte LDS gather (item tables + residual "
                                     "pre-pass + ivfpq_qbound_kernel)"}
@@ -624,6 +670,24 @@ def main():
                                "survivors + residual rows -> codes -> 4 x codebook -> row ids) around a few thousand lane-operations; bound by latency x "
                                "workgroups in flight (10 per CU by LDS), not by a throughput roofline"}
     result["roofline_tail"] = rt or None
+
+    # the headline refine reads the lossless u8 copy that an integer-valued f32 column admits; the same steps with the refine kernel on the
+    # caller's f32 rows (what a general f32 column gets), from a child run of this script with LANCE_HIP_NO_RAW_COMPACT=1
+    if world == 1 and not multi and not args.no_extras and refine_u8 and os.environ.get("LANCE_BENCH_CHILD") != "1":
+        import subprocess
+        env = dict(os.environ, LANCE_HIP_NO_RAW_COMPACT="1", LANCE_BENCH_CHILD="1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--streams", str(args.streams),
+               "--no-pmc", "--no-cpu-baseline", "--no-grid", "--no-extras", "--config", args.config, "--n", str(args.n), "--nq", str(args.nq),
+               "--nprobes", str(args.nprobes), "--refine", str(args.refine), "--k", str(args.k)]
+        try:
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            cj = json.loads(cp.stdout.strip().splitlines()[-1])
+            result["qps_f32_refine_source"] = {"value": cj["value"], "ms_per_step": cj["ms_per_step"], "recall_at_10": cj["recall_at_10"],
+                                               "refine_kernel_ms": cj["kernel_ms_per_step"].get("refine"),
+                                               "what": "child run of this script with LANCE_HIP_NO_RAW_COMPACT=1: same index, same batches, the refine kernel "
+                                                       "reads the caller's f32 rows (4 bytes per element)"}
+        except Exception as e:      # the extra is informational: never fail the line over it
+            result["qps_f32_refine_source"] = {"error": str(e)[:200]}
 
     if not args.no_cpu_baseline and world == 1:
         import oracle as orc

@@ -403,7 +403,8 @@ int lance_hip_timing_query(lance_hip_ctx *ctx, const char *kernel, double *ms_to
 /* Ceilings measured in-process for bench.py's roofline denominators (no reference counterpart; SURVEY 8(d) asks for
  * peaks "re-measured on the box").  what: 0 / 1 / 2 = random LDS gathers of 4 / 8 / 16-byte PQ-LUT entries, result in
  * lane-gathers per second; 3 = device copy, bytes (read + written) per second; 4 / 5 = v_add_f32 / v_pk_add_f32
- * wave-instructions per second.                                                                                    */
+ * wave-instructions per second; 6-9 = LDS table-layout variants (lane-gathers per second); 10 / 11 = dense
+ * v_mfma_f32_32x32x16_f16 / _bf16 issue rate in flop per second (round 6: the MFMA roofline's measured peak).          */
 int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result);
 
 #ifdef __cplusplus

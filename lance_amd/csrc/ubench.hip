@@ -162,6 +162,41 @@ __global__ __launch_bounds__(256) void ub_valu_kernel(float *__restrict__ out, i
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// dense MFMA issue rate: four independent 32x32x16 accumulator chains per wave, operands in registers (bench.py: roofline peak_measured)
+typedef _Float16 ub_f16x8 __attribute__((ext_vector_type(8)));
+typedef short ub_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ub_f32x16 __attribute__((ext_vector_type(16)));
+template <int BF16>
+__global__ __launch_bounds__(256) void ub_mfma_kernel(float *__restrict__ out, int iters, float seed) {
+  ub_f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[c][v] = 0.0f;
+  ub_f16x8 ah, bh;
+  ub_bf16x8 ab, bb;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ah[e] = (_Float16)(seed * 0.001f * (float)((threadIdx.x + e) & 7)); bh[e] = (_Float16)(seed * 0.002f * (float)((threadIdx.x * 3 + e) & 7));
+    ab[e] = (short)(0x3C00 + ((threadIdx.x + e) & 7)); bb[e] = (short)(0x3B80 + ((threadIdx.x * 3 + e) & 7));
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (BF16) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, acc[c], 0, 0, 0);
+        else acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[c], 0, 0, 0);
+      }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s += acc[c][v];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace lh
 
 using namespace lh;
@@ -171,11 +206,12 @@ extern "C" {
 // what: 0..2 = LDS random gather of 4 / 8 / 16-byte entries (result: gathers per second, one gather = one lane's read);
 //       3 = device copy (bytes read + written per second); 4 / 5 = f32 VALU wave-instructions per second (v_add_f32 /
 //       v_pk_add_f32, 64 lanes each); 6 / 7 = code-major m-staggered u16x4 table, M = 16 / 32 (lane-gathers per second, all
-//       address work included); 8 = today's [m][code] u16x4 table with the same integer accumulate; 9 = conflict-free ds_read_b64
+//       address work included); 8 = today's [m][code] u16x4 table with the same integer accumulate; 9 = conflict-free ds_read_b64;
+//       10 / 11 = dense v_mfma_f32_32x32x16_f16 / _bf16 rate, flop per second (the roofline's measured MFMA peak)
 int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result) {
   lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && result, "ubench: NULL argument");
-  LH_REQUIRE(what >= 0 && what <= 9, "ubench: unknown measurement %d", what);
+  LH_REQUIRE(what >= 0 && what <= 11, "ubench: unknown measurement %d", what);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   hipEvent_t e0, e1;
   LH_CHECK_HIP(hipEventCreate(&e0));
@@ -207,7 +243,7 @@ int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result) {
       if (rep) best = std::min(best, ms);
     }
     work = (double)blocks * 512 * iters * 64;
-  } else if (what >= 6) {
+  } else if (what >= 6 && what <= 9) {
     // 6 / 7: staggered code-major table, M = 16 / 32; 8: today's layout with the integer accumulate; 9: conflict-free ds_read_b64
     const int blocks = ctx->num_cus * 12, iters = 100;
     const size_t nbytes = (size_t)blocks * 512 * 64;
@@ -232,6 +268,22 @@ int lance_hip_ubench(lance_hip_ctx *ctx, int what, double *result) {
       if (rep) best = std::min(best, ms);
     }
     work = (double)blocks * 512 * iters * 64;   // lane-gathers: 64 per lane per iteration in every variant
+  } else if (what >= 10) {
+    // 10 / 11: v_mfma_f32_32x32x16_f16 / _bf16, flop per second (2 x 32 x 32 x 16 per instruction), two waves per SIMD
+    const int blocks = ctx->num_cus * 2, iters = 4000;
+    float *out = ctx->scratch_t<float>("ubench.out", (size_t)blocks * 512);
+    if (!out) return LANCE_HIP_ENOMEM;
+    for (int rep = 0; rep < 4; ++rep) {
+      LH_CHECK_HIP(hipEventRecord(e0, ctx->stream));
+      if (what == 10) hipLaunchKernelGGL(ub_mfma_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, out, iters, 1.0f);
+      else hipLaunchKernelGGL(ub_mfma_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, out, iters, 1.0f);
+      LH_CHECK_HIP(hipEventRecord(e1, ctx->stream));
+      LH_CHECK_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      LH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) best = std::min(best, ms);
+    }
+    work = (double)blocks * 4 * iters * 16 * 32768.0;   // 4 waves x 16 MFMAs per iteration x 2 * 32 * 32 * 16 flop
   } else if (what == 3) {
     const size_t n4 = (size_t)64 << 20;   // 1 GiB each way
     f4u *src = ctx->scratch_t<f4u>("ubench.src", n4);

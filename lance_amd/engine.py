@@ -375,7 +375,9 @@ class Engine:
         codes = {"lds4": 0, "lds8": 1, "lds16": 2, "copy": 3, "valu": 4, "valu_pk": 5,
                  # round 3: code-major m-staggered u16x4 table (M = 16 / 32), today's layout with the integer accumulate, and the
                  # conflict-free ds_read_b64 stream (the LDS pipe's own ceiling)
-                 "lds8_stagger16": 6, "lds8_stagger32": 7, "lds8_u16x4": 8, "lds8_linear": 9}
+                 "lds8_stagger16": 6, "lds8_stagger32": 7, "lds8_u16x4": 8, "lds8_linear": 9,
+                 # round 6: dense 32x32x16 MFMA rate (flop per second), f16 / bf16 operands
+                 "mfma_f16": 10, "mfma_bf16": 11}
         check(self.lib.lance_hip_ubench(self.h, codes[what], C.byref(r)))
         return r.value
 
