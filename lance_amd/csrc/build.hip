@@ -427,6 +427,13 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
     }
   }
   LH_TRY(launch_assign(ctx, pa, (int)d, scan_metric, 1));
+  // long rows (d > 128) that exist as f32 -- an f32 column, or the f32 copy the steps above made: residual + encode in one kernel per
+  // 128-column block (xform_fused.hip: xf_tail_kernel), no residual array (round 6)
+  const float *tail_x = xs ? xs : (dtype == LANCE_HIP_F32 ? static_cast<const float *>(x) : nullptr);
+  if (tail_x && xform_tail_supported((int)d, (int)m, (int)nbits, (int64_t)n, tail_x, centf, cbf)) {
+    LH_TRY(launch_xform_tail(ctx, tail_x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, f16, cbf, (int)m, codes));
+    return encode_finish(ctx, n, nlist, dists, part_ids, loss_out_host);
+  }
   if (native) {
     if (mfma_enc) LH_TRY(launch_pq_mfma_encode(ctx, dtype, x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, cbf, (int)m, codes));
     else LH_TRY(launch_encode_fused(ctx, dtype, x, (int64_t)n, (int)d, centf, part_ids, scan_metric == LANCE_HIP_L2 ? 1 : 0, cbf, (int)m, codes));

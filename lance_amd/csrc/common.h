@@ -98,6 +98,7 @@ struct lance_hip_ctx {
 
   // returns nullptr on failure (error set)
   void *scratch(const char *name, size_t bytes);
+  void *scratch_exact(const char *name, size_t bytes);   // no headroom; nullptr (no error set) when the device cannot give it
   void scratch_release(const char *name);      // gives a slot back (large one-call buffers); the caller has synchronised the stream
   void *host_staging(size_t bytes);
   template <typename T>

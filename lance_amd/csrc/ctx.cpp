@@ -38,6 +38,29 @@ void *lance_hip_ctx::scratch(const char *name, size_t bytes) {
   return p;
 }
 
+// One-call buffers as large as a column (the long-row flat filter's bf16 plane): exactly `bytes` (no growth headroom), and a failed
+// allocation is an answer, not an error -- the caller takes its route without the buffer.
+void *lance_hip_ctx::scratch_exact(const char *name, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  auto it = slots.find(name);
+  if (it != slots.end() && it->second.second >= bytes) return it->second.first;
+  if (capturing) return nullptr;
+  if (it != slots.end()) {
+    drop_graphs();
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(it->second.first);
+    slots.erase(it);
+  }
+  const size_t cap = (bytes + 255) & ~(size_t)255;
+  void *p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    (void)hipGetLastError();      // clear the sticky error: the caller goes on without the buffer
+    return nullptr;
+  }
+  slots[name] = {p, cap};
+  return p;
+}
+
 void lance_hip_ctx::scratch_release(const char *name) {
   auto it = slots.find(name);
   if (it == slots.end()) return;

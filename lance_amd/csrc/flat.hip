@@ -394,20 +394,34 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
   LH_REQUIRE(x || fixed, "flat_topk: internal: native rows need the fixed-dimension kernels");
   // long rows (no fixed-dimension kernel): query batches run the epochs after the first on the matrix cores (flat_mfma_wide.hip);
   // the rows' bf16 plane and norms are made once per call (cosine: by the row-norm pass below, which reads the column anyway)
-  const bool wide_mfma = !fixed && flat_mfma_wide_supported(metric, d, std::min(nq, qch), n, x, q);
+  bool wide_mfma = !fixed && flat_mfma_wide_supported(metric, d, std::min(nq, qch), n, x, q);
   const uint16_t *wxb = nullptr;
   const float *wxn2 = nullptr;
+  // The plane is as large as half the column (exact size, no arena headroom).  If the device cannot give it the scan runs on the exact
+  // kernel, as before the matrix-core route existed (the call used to fail with ENOMEM on columns near device capacity);
+  // a plane above 4 GiB goes back on EVERY way out of this function, error paths included (up to 4 GiB it stays: a repeated call does
+  // not pay the allocation).
+  struct PlaneGuard {
+    lance_hip_ctx *c; bool armed;
+    ~PlaneGuard() { if (armed) { (void)hipStreamSynchronize(c->stream); c->scratch_release("fw.xb"); } }
+  } plane_guard{ctx, false};
+  const bool big_plane = (uint64_t)n * (uint64_t)d * 2 > (4ull << 30);
   if (metric == LANCE_HIP_COSINE) {
     float *sy = ctx->scratch_t<float>("flat2.row_sy", (size_t)std::max<int64_t>(n, 1));
     float *qn = ctx->scratch_t<float>("flat2.q_norm", (size_t)nq);
-    uint16_t *xb = wide_mfma ? ctx->scratch_t<uint16_t>("fw.xb", (size_t)std::max<int64_t>(n, 1) * d) : nullptr;
-    if (!sy || !qn || (wide_mfma && !xb)) return LANCE_HIP_ENOMEM;
+    uint16_t *xb = wide_mfma ? static_cast<uint16_t *>(ctx->scratch_exact("fw.xb", (size_t)std::max<int64_t>(n, 1) * d * 2)) : nullptr;
+    if (wide_mfma && !xb) wide_mfma = false;
+    plane_guard.armed = wide_mfma && big_plane;
+    if (!sy || !qn) return LANCE_HIP_ENOMEM;
     if (n > 0) hipLaunchKernelGGL(cosine_rownorm_kernel, dim3((unsigned)cdiv((uint64_t)n * 16, 256)), dim3(256), 0, ctx->stream, x, n, d, sy, xb);
     hipLaunchKernelGGL(query_norm_kernel, dim3(cdiv(nq, 64)), dim3(64), 0, ctx->stream, q, nq, d, qn);
     a.row_sy = sy;
     wxb = xb; wxn2 = sy;      // (the cosine filter reads row_sy, not |x|^2)
   } else if (wide_mfma) {
-    LH_TRY(flat_mfma_wide_prepare_rows(ctx, x, n, d, &wxb, &wxn2));
+    const int prc = flat_mfma_wide_prepare_rows(ctx, x, n, d, &wxb, &wxn2);
+    if (prc == LH_NOT_TAKEN) wide_mfma = false;
+    else if (prc != LANCE_HIP_OK) return prc;
+    plane_guard.armed = wide_mfma && big_plane;
   }
   const float *qn_all = metric == LANCE_HIP_COSINE ? ctx->scratch_t<float>("flat2.q_norm", (size_t)nq) : nullptr;
   auto filter = [&](const FlatPool &e) {
@@ -471,13 +485,7 @@ static int flat_topk_v2(lance_hip_ctx *ctx, int metric, const float *x, const vo
     }
   }
   LH_CHECK_HIP(hipGetLastError());
-  // the rows' bf16 plane is as large as half the column: not something to keep in the arena between calls (the repair loop above
-  // synchronised the stream after the last chunk's kernels were enqueued ... except its final select: wait for that one too)
-  if (wide_mfma && (uint64_t)n * (uint64_t)d * 2 > (4ull << 30)) {      // (up to 4 GiB it stays: a repeated call does not pay the allocation)
-    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->scratch_release("fw.xb");
-  }
-  return LANCE_HIP_OK;
+  return LANCE_HIP_OK;      // (plane_guard gives a > 4 GiB plane back after waiting for the stream)
 }
 
 template <int D>

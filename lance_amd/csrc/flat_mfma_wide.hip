@@ -318,9 +318,11 @@ bool flat_mfma_wide_supported(int metric, int d, int nq, int64_t n, const float 
 
 // once per flat_topk call: the bf16 plane and the norms of ALL rows
 int flat_mfma_wide_prepare_rows(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const uint16_t **xb_out, const float **xn2_out) {
-  uint16_t *xb = ctx->scratch_t<uint16_t>("fw.xb", (size_t)std::max<int64_t>(n, 1) * d);
+  // the plane is half the column: exact size, and "no room" is reported as LH_NOT_TAKEN -- flat_topk then scans on the exact kernel
+  uint16_t *xb = static_cast<uint16_t *>(ctx->scratch_exact("fw.xb", (size_t)std::max<int64_t>(n, 1) * d * 2));
+  if (!xb) return LH_NOT_TAKEN;
   float *xn2 = ctx->scratch_t<float>("fw.xn2", (size_t)std::max<int64_t>(n, 1));
-  if (!xb || !xn2) return LANCE_HIP_ENOMEM;
+  if (!xn2) return LANCE_HIP_ENOMEM;
   if (n > 0) hipLaunchKernelGGL(fw_rows_prep_kernel, dim3((unsigned)cdiv((uint64_t)n, 4)), dim3(256), 0, ctx->stream, x, n, d, xb, xn2);
   *xb_out = xb; *xn2_out = xn2;
   return LANCE_HIP_OK;

@@ -104,6 +104,10 @@ bool xform_fused_supported(int dtype, int metric, int d, int m, int nbits, int64
                            const float *codebook, uint8_t *codes, bool lanes32);
 int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x, int64_t n, int d, const float *cent, int nlist,
                        const float *codebook, int m, uint32_t *part_ids, float *dists, uint8_t *codes, bool round_f16);
+// long rows (d > 128): residual + PQ encode of 128-column blocks on the same machinery, after the K-tiled coarse quantiser (xform_fused.hip)
+bool xform_tail_supported(int d, int m, int nbits, int64_t n, const float *x, const float *cent, const float *codebook);
+int launch_xform_tail(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, int residual, bool round_f16,
+                      const float *codebook, int m, uint8_t *codes);
 // bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);

@@ -33,11 +33,17 @@
 //      no VALU arithmetic at all, and no K slot multiplies zeros (sub-dimension 4: one product, [xh xh | xl 1 1 1 R]).
 //      Epilogue = 3 VALU per (row, codeword): key = (bits & ~63) | slot (v_and_or_b32, slot an inline constant), second
 //      smallest by v_med3_u32, smallest by v_min_u32 -- two trackers of 64 slots so the slot number stays an inline constant.
-//      margin = 2^-12 (|r_m|^2 + max|c|^2) as in pq_mfma.hip (split error <= 2^-14 |r||c|, the |c|^2 terms and the f32
-//      accumulation of 16 + 16 slots < 2^-17 (|r|^2 + |c|^2), cleared mantissa bits < 2^-15 relative, the norm bound's excess is
-//      a constant of the row and cancels in every comparison).  Second key farther than the margin -> the first is the
-//      reference's argmin; otherwise the (row, sub-quantiser) item goes to pq_mfma_fix_kernel's list (exact distances to all
-//      256 codewords).  Codes are gathered in LDS and leave as one coalesced store per workgroup.
+//      The bound.  Per element the three products miss xh.ec + xl.cl + er.c with |ec| <= 2^-18 |c|, |er| <= 2^-18 |r|, |xl| <= 2^-9 |r|,
+//      |cl| <= 2^-9 |c| (two round-to-nearest bf16 terms each): 3.01 x 2^-18 |r_k||c_k|, summed (Cauchy-Schwarz) and doubled
+//      2^-15.4 |r||c| <= 2^-16.4 (|r|^2 + |c|^2); |c|^2 as computed in f32 and split in three terms 2^-20 |c|^2; the matrix pipe's f32
+//      accumulation of at most four K = 16 steps 2^-19 (|r|^2 + |c|^2): every surrogate is within E = 2^-15 (|r_m|^2 + max|c|^2) of
+//      |r - c|^2 + (R - |r|^2) -- with a factor two to spare -- and the reference's own f32 distance within 2^-20 of that.  A key sits
+//      at most 2^-15 of its value under its surrogate (8 cleared mantissa bits after the codeword number is widened in).  Hence:
+//      second key - first key > 2 E + 2^-14 first key  ==>  the first is the reference's argmin (the offset R, one bf16 >= |r_m|^2 +
+//      2 E, is a constant of the row and cancels).  Otherwise the (row, sub-quantiser) item goes to the fix kernel's list (exact
+//      distances to all 256 codewords).  (pq_mfma.hip's margin, 2^-12, is four times this: at C3's shape -- 16-dimensional sub-vectors,
+//      distances concentrate -- it left 4.7 % of the items undecided, gpurun r06n.)  Codes are gathered in LDS and leave as one
+//      coalesced store per workgroup.
 //
 // HBM traffic: the row once, plus M + 8 bytes per row out.  Everything else (centroid planes 2 x 2 B x nlist x d, codeword
 // fragments 16 KiB per sub-quantiser, f32 centroids of the candidates) is re-read from L2 by every workgroup.
@@ -45,6 +51,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include <hip/hip_fp16.h>
 
@@ -71,7 +78,10 @@ struct XfArgs {
   float *dists;                  // [n]
   uint8_t *codes;                // [n][m]
   uint32_t *afb_cnt, *afb_rows;  // rows for ma_recompute_kernel
-  uint32_t *fb_cnt, *fb_items;   // [1], [n m]: undecided (row, sub-quantiser) items for xf_fix_kernel, item = m << 27 | row
+  uint32_t *fb_cnt, *fb_items;   // [m_total], [m_total][n]: undecided rows per sub-quantiser, for xf_fix_kernel
+  int m_total = 0;               // sub-quantisers of the whole index (row stride of `codes`)
+  int64_t d_total = 0;           // elements per centroid row (xf_tail_kernel: a workgroup sees a 128-column block of it)
+  int col_base = 0;              // xf_tail_kernel: first column of this launch's blocks
   unsigned long long *prof = nullptr;   // LANCE_HIP_XF_PROF=1: s_memtime ticks summed over the waves: [0] rows->registers [1] sweep [2] merge + exact re-check
                                         // [3] residual + barrier [4] PQ encode [5] codes out [6] waves [7] undecided PQ items
 };
@@ -91,9 +101,16 @@ __device__ __forceinline__ uint32_t xf_bf16_up(float v) {
 
 // ---- codeword fragments: one workgroup per sub-quantiser, thread = codeword -------------------------------------------
 // SD = 8: per 32-codeword tile two A operands (see the header); SD = 4: one.  Lane (j, g) of the MFMA reads 16 bytes.
+// SD = 16: three A operands per tile -- AH = -2 ch (lane half g: dimensions 8 g .. 8 g + 7), AL = -2 cl, AN = [n1 n2 n3 1 0 .. | 0 ..]; the
+// kernel runs AH.BH + AL.BH + AH.BL + AN.BN with BH / BL the residual's hi / lo halves and BN = [1 1 1 R 0 .. | 0 ..].
+template <int SD> struct XfSd;
+template <> struct XfSd<4> { static constexpr int NA = 1; };
+template <> struct XfSd<8> { static constexpr int NA = 2; };
+template <> struct XfSd<16> { static constexpr int NA = 3; };
+
 template <int SD>
 __global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict__ codebook, uint4 *__restrict__ pqa, float *__restrict__ cmax2) {
-  constexpr int NMF = SD == 8 ? 2 : 1;
+  constexpr int NMF = XfSd<SD>::NA;
   __shared__ uint32_t s_max;
   const int m = blockIdx.x, c = threadIdx.x;
   if (c == 0) s_max = 0u;
@@ -117,7 +134,14 @@ __global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict
   if (s == s) atomicMax(&s_max, __float_as_uint(fabsf(s)));
   const int t = c >> 5, j = c & 31;
   uint4 *dst = pqa + ((int64_t)(m * 8 + t) * NMF) * 64;
-  if constexpr (SD == 8) {
+  if constexpr (SD == 16) {
+    dst[j] = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, hi[4] | hi[5] << 16, hi[6] | hi[7] << 16);
+    dst[32 + j] = make_uint4(hi[8] | hi[9] << 16, hi[10] | hi[11] << 16, hi[12] | hi[13] << 16, hi[14] | hi[15] << 16);
+    dst[64 + j] = make_uint4(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, lo[4] | lo[5] << 16, lo[6] | lo[7] << 16);
+    dst[96 + j] = make_uint4(lo[8] | lo[9] << 16, lo[10] | lo[11] << 16, lo[12] | lo[13] << 16, lo[14] | lo[15] << 16);
+    dst[128 + j] = make_uint4(n1 | n2 << 16, n3 | 0x3F80u << 16, 0u, 0u);
+    dst[160 + j] = make_uint4(0u, 0u, 0u, 0u);
+  } else if constexpr (SD == 8) {
     const uint4 h = make_uint4(hi[0] | hi[1] << 16, hi[2] | hi[3] << 16, hi[4] | hi[5] << 16, hi[6] | hi[7] << 16);
     const uint4 l = make_uint4(lo[0] | lo[1] << 16, lo[2] | lo[3] << 16, lo[4] | lo[5] << 16, lo[6] | lo[7] << 16);
     dst[j] = h;                                  // A1, g = 0: -2 ch
@@ -171,8 +195,9 @@ __global__ __launch_bounds__(64) void xf_cent_prep_kernel(const float *__restric
 }
 
 // LDS (bytes) of one workgroup: the centroid tiles of the sweep and the residual planes of the encode alias each other; the
-// workgroup's queue of undecided items (a counter + XF_QCAP 16-bit entries, m << 7 | row) sits behind both
-constexpr int XF_QCAP = 1024;
+// workgroup's queues of undecided items -- per sub-quantiser of the block a counter, a base in the global list and XF_QBYTES / M one-byte
+// row numbers -- sit behind both
+constexpr int XF_QBYTES = 2048;
 template <int KS, int SD>
 constexpr size_t xf_lds_main() {
   constexpr int D = KS * 16, M = D / SD;
@@ -183,7 +208,7 @@ constexpr size_t xf_lds_main() {
   return ((b > c ? b : c) + 15) / 16 * 16;
 }
 template <int KS, int SD>
-constexpr size_t xf_lds_bytes() { return xf_lds_main<KS, SD>() + 16 + (size_t)XF_QCAP * 2; }
+constexpr size_t xf_lds_bytes() { return xf_lds_main<KS, SD>() + 256 + (size_t)XF_QBYTES; }
 
 typedef __bf16 xf_bf2 __attribute__((ext_vector_type(2)));
 // two floats -> packed bf16 (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN)
@@ -235,15 +260,18 @@ __device__ __forceinline__ float xf_exact(const float (&xf)[KS][8], const float 
   return finish_metric<METRIC>(0.0f + tot);
 }
 
-// an undecided (row, sub-quantiser) item: into the workgroup's LDS queue (flushed with one global atomic at the end), or -- queue full:
-// rows full of ties -- straight to the global list
-__device__ __forceinline__ void xf_queue_item(const XfArgs &p, uint32_t *q_cnt, uint16_t *q_items, uint32_t m, uint32_t lrow, int64_t row0) {
-  const uint32_t slot = atomicAdd(&q_cnt[0], 1u);
-  if (slot < (uint32_t)XF_QCAP) {
-    q_items[slot] = (uint16_t)((m << 7) | lrow);
+// An undecided (row, sub-quantiser) item goes into the workgroup's LDS queue of that sub-quantiser (written by the ONE wave that owns it in
+// the PQ phase: no sub-dword stores of different waves into one dword), flushed with one global atomic per (workgroup, sub-quantiser);
+// a full queue (rows full of ties) or a caller outside the PQ phase (direct = true) appends to the global list itself.
+template <int QC>
+__device__ __forceinline__ void xf_queue_item(const XfArgs &p, uint32_t *q_cnt, uint8_t *q_rows, int m_local, int m_global, uint32_t lrow, int64_t row0, bool direct) {
+  uint32_t slot = (uint32_t)QC;
+  if (!direct) slot = atomicAdd(&q_cnt[m_local], 1u);
+  if (slot < (uint32_t)QC) {
+    q_rows[m_local * QC + slot] = (uint8_t)lrow;
   } else {
-    const uint32_t s2 = atomicAdd(p.fb_cnt, 1u);
-    p.fb_items[s2] = (m << 27) | (uint32_t)(row0 + lrow);
+    const uint32_t s2 = atomicAdd(&p.fb_cnt[m_global], 1u);
+    p.fb_items[(int64_t)m_global * p.n + s2] = (uint32_t)(row0 + lrow);
   }
 }
 
@@ -251,19 +279,25 @@ __device__ __forceinline__ void xf_queue_item(const XfArgs &p, uint32_t *q_cnt, 
 // order (l2_scalar, kmeans.rs:1350-1369), argmin_value_float semantics (first strictly smallest, NaN / +inf never selected, none ->
 // code 0: pq.rs:165 unwrap_or(0)) -- pq_mfma_fix_kernel's arithmetic on a flat list (the codewords come from L2: items are ~1 % of the work)
 struct XfFixArgs {
-  const void *x; int64_t ldx;
+  const void *x; int64_t ldx, n;
   const float *cent; const uint32_t *part_ids; int residual, round_f16;
   const float *codebook; int m;
-  const uint32_t *cnt, *items;
+  const uint32_t *cnt, *items;        // [m], [m][n]
   uint8_t *codes;
 };
 template <int SD, typename TX>
 __global__ __launch_bounds__(256) void xf_fix_kernel(XfFixArgs a) {
+  __shared__ __attribute__((aligned(16))) float cbf[256 * SD];      // the sub-quantiser's codebook
+  const int m = blockIdx.y;
+  const uint32_t cnt = a.cnt[m];
+  if (blockIdx.x * 4u >= cnt) return;    // uniform: nothing left for this workgroup
+  const float *cb = a.codebook + (int64_t)m * 256 * SD;
+  for (int i = threadIdx.x; i < 256 * SD / 4; i += 256) reinterpret_cast<f4 *>(cbf)[i] = reinterpret_cast<const f4 *>(cb)[i];
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const uint32_t cnt = *a.cnt, nwaves = gridDim.x * 4;
+  const uint32_t nwaves = gridDim.x * 4;
   for (uint32_t it = blockIdx.x * 4 + (threadIdx.x >> 6); it < cnt; it += nwaves) {
-    const uint32_t item = a.items[it], m = item >> 27;
-    const int64_t row = item & 0x7FFFFFFu;
+    const int64_t row = a.items[(int64_t)m * a.n + it];
     RegVec<SD> rv;
 #pragma unroll
     for (int i = 0; i < SD / 4; ++i) rv.q[i] = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -283,13 +317,12 @@ __global__ __launch_bounds__(256) void xf_fix_kernel(XfFixArgs a) {
         rv.q[i] = v;
       }
     }
-    const float *cb = a.codebook + (int64_t)m * 256 * SD;
     float best = INFINITY;
     uint32_t bi = LANCE_HIP_NONE;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t c = (uint32_t)(u * 64 + lane);
-      const float v = dist_exact<SD, METRIC_L2>(rv, cb + c * SD);
+      const float v = dist_exact<SD, METRIC_L2>(rv, &cbf[c * SD]);
       if (v < best) { best = v; bi = c; }
     }
 #pragma unroll
@@ -300,6 +333,276 @@ __global__ __launch_bounds__(256) void xf_fix_kernel(XfFixArgs a) {
     }
     if (lane == 0) a.codes[row * a.m + m] = bi == LANCE_HIP_NONE ? (uint8_t)0 : (uint8_t)bi;
   }
+}
+
+// LDS of the encode half (phases 4 and 5), shared by xf_kernel and xf_tail_kernel
+template <int KS, int SD>
+struct XfLds {
+  static constexpr int D = KS * 16, M = D / SD, MW = (M + 3) / 4;
+  __device__ static uint16_t *rh(char *smem) { return reinterpret_cast<uint16_t *>(smem); }                    // [128][D] hi (16-byte chunks rotated by the row)
+  __device__ static uint16_t *rl(char *smem) { return rh(smem) + (size_t)MA_ROWS * D; }                        // [128][D] lo
+  __device__ static uint16_t *xn2s(char *smem) { return rl(smem) + (size_t)MA_ROWS * D; }                      // [128][M] bf16 upper bounds of |r_m|^2
+  // codes: [wave][MW][128] -- a byte is written by the wave that owns the sub-quantiser, its dword neighbours are the adjacent rows
+  // of the SAME store instruction (round 6, first version: [row][m] put four waves' bytes into one dword, and about one byte in two
+  // million came out stale: concurrent sub-dword LDS stores of different waves to one dword are not safe)
+  __device__ static uint8_t *codes(char *smem) { return reinterpret_cast<uint8_t *>(xn2s(smem) + (size_t)MA_ROWS * M); }
+  __device__ static uint8_t *rskip(char *smem) { return codes(smem) + (size_t)4 * MW * MA_ROWS; }               // [128] 1: no items of this row from the PQ phase
+  static constexpr int QC = XF_QBYTES / M >= 128 ? 128 : XF_QBYTES / M / 4 * 4;           // queue entries per sub-quantiser (dword-aligned lists)
+  __device__ static uint32_t *q_cnt(char *smem) { return reinterpret_cast<uint32_t *>(smem + xf_lds_main<KS, SD>()); }            // [M] counts
+  __device__ static uint32_t *q_base(char *smem) { return reinterpret_cast<uint32_t *>(smem + xf_lds_main<KS, SD>() + 128); }      // [M] bases in the global lists
+  __device__ static uint8_t *q_rows(char *smem) { return reinterpret_cast<uint8_t *>(smem + xf_lds_main<KS, SD>() + 256); }        // [M][QC]
+};
+
+// phase 4: this lane's pieces of the row (xf: dimensions 16 s + 8 g .. + 7 of the block) minus the centroid's -> hi / lo planes + norms
+template <int KS, int SD>
+__device__ __forceinline__ void xf_residual_to_lds(const float (&xf)[KS][8], const float *__restrict__ cb, bool sub, bool zero, int round_f16, char *smem,
+                                                   int lrow, int g, bool skip) {
+  constexpr int D = KS * 16, M = D / SD, NCH = D / 8;
+  uint16_t *rh = XfLds<KS, SD>::rh(smem), *rl = XfLds<KS, SD>::rl(smem), *xn2s = XfLds<KS, SD>::xn2s(smem);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    float r[8];
+    if (sub) {
+      const f4 c0 = *reinterpret_cast<const f4 *>(cb + s * 16 + g * 8), c1 = *reinterpret_cast<const f4 *>(cb + s * 16 + g * 8 + 4);
+      const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        r[e] = xf[s][e] - cv[e];
+        if (round_f16) r[e] = __half2float(__float2half_rn(r[e]));      // `*v - *cent` in half::f16 (residual.rs:96)
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = zero ? 0.0f : xf[s][e];
+    }
+    uint4 h4, l4;
+    xf_split8<true>(r, h4, l4);
+    const int chunk = 2 * s + g, slot = (chunk + lrow) % NCH;
+    *reinterpret_cast<uint4 *>(rh + (size_t)lrow * D + slot * 8) = h4;
+    *reinterpret_cast<uint4 *>(rl + (size_t)lrow * D + slot * 8) = l4;
+    // (q * 1.0000005: the fused sum may sit an ulp under the true norm)
+    if constexpr (SD == 16) {
+      float q = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q = __builtin_fmaf(r[e], r[e], q);
+      q += __shfl_xor(q, 32, 64);
+      if (g == 0) xn2s[lrow * M + s] = (uint16_t)xf_bf16_up(q * 1.0000005f);
+    } else if constexpr (SD == 8) {
+      float q = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q = __builtin_fmaf(r[e], r[e], q);
+      xn2s[lrow * M + chunk] = (uint16_t)xf_bf16_up(q * 1.0000005f);
+    } else {
+      float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { q0 = __builtin_fmaf(r[e], r[e], q0); q1 = __builtin_fmaf(r[4 + e], r[4 + e], q1); }
+      *reinterpret_cast<uint32_t *>(xn2s + lrow * M + 2 * chunk) = (xf_bf16_up(q0 * 1.0000005f) & 0xFFFFu) | (xf_bf16_up(q1 * 1.0000005f) << 16);
+    }
+  }
+  if (g == 0) XfLds<KS, SD>::rskip(smem)[lrow] = (uint8_t)(skip ? 1 : 0);
+}
+
+// phase 5 (+ the undecided items and the code bytes on their way out).  m0: the block's first sub-quantiser in the whole index.
+template <int KS, int SD, bool PROF>
+__device__ __forceinline__ void xf_pq_phase(const XfArgs &p, char *smem, int m0, int64_t row0, uint32_t &pc_und, long long &prof_pq, long long &pprev) {
+  constexpr int D = KS * 16, M = D / SD, NCH = D / 8, NA = XfSd<SD>::NA, MW = (M + 3) / 4;
+  uint16_t *rh = XfLds<KS, SD>::rh(smem), *rl = XfLds<KS, SD>::rl(smem), *xn2s = XfLds<KS, SD>::xn2s(smem);
+  uint8_t *codes_s = XfLds<KS, SD>::codes(smem), *rskip = XfLds<KS, SD>::rskip(smem);
+  constexpr int QC = XfLds<KS, SD>::QC;
+  uint32_t *q_cnt = XfLds<KS, SD>::q_cnt(smem), *q_base = XfLds<KS, SD>::q_base(smem);
+  uint8_t *q_rows = XfLds<KS, SD>::q_rows(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, 0, 0, 0, 0, 0};
+  const bf16x8 zeros8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+  for (int m = wave, mi = 0; m < M; m += 4, ++mi) {
+    bf16x8 af[8][NA];
+    {
+      const uint4 *src = p.pqa + (int64_t)(m0 + m) * 8 * NA * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int f = 0; f < NA; ++f) af[t][f] = __builtin_bit_cast(bf16x8, src[(t * NA + f) * 64]);
+    }
+    const float cmax2 = p.pq_cmax2[m0 + m];
+#pragma unroll 1
+    for (int rg = 0; rg < MA_ROWS / 32; ++rg) {
+      const int lrow = rg * 32 + j;
+      bf16x8 b1, b2, b3 = zeros8;
+      if constexpr (SD == 16) {
+        const int slot = (2 * m + g + lrow) % NCH;
+        b1 = *reinterpret_cast<const bf16x8 *>(rh + (size_t)lrow * D + slot * 8);       // BH: dimensions 8 g .. 8 g + 7 of the sub-vector
+        b2 = *reinterpret_cast<const bf16x8 *>(rl + (size_t)lrow * D + slot * 8);       // BL
+        b3 = g == 0 ? ones : zeros8;                                                    // BN (+ R below)
+      } else if constexpr (SD == 8) {
+        const int slot = (m + lrow) % NCH;
+        b1 = *reinterpret_cast<const bf16x8 *>(rh + (size_t)lrow * D + slot * 8);
+        const bf16x8 lo8 = *reinterpret_cast<const bf16x8 *>(rl + (size_t)lrow * D + slot * 8);
+        b2 = g == 0 ? lo8 : ones;
+      } else {
+        const int slot = ((m >> 1) + lrow) % NCH;
+        const uint2 h4 = *reinterpret_cast<const uint2 *>(rh + (size_t)lrow * D + slot * 8 + (m & 1) * 4);
+        const uint2 l4 = *reinterpret_cast<const uint2 *>(rl + (size_t)lrow * D + slot * 8 + (m & 1) * 4);
+        const uint4 bb = g == 0 ? make_uint4(h4.x, h4.y, h4.x, h4.y) : make_uint4(l4.x, l4.y, 0x3F803F80u, 0x00003F80u);
+        b1 = __builtin_bit_cast(bf16x8, bb);
+        b2 = b1;
+      }
+      const float xq = __uint_as_float((uint32_t)xn2s[lrow * M + m] << 16);
+      const float margin = 0.00006103515625f * (xq + cmax2);     // 2 E, E = 2^-15 (|r_m|^2 + max|c|^2): see the bound in the header
+      // the row's offset R = bf16 >= |r_m|^2 + margin rides in the fourth slot of the "ones" vector (the codeword side holds a 1 there):
+      // every surrogate is >= 0 (float order == unsigned order of the bits) and the accumulator starts from the inline constant 0
+      const uint32_t rb = xf_bf16_up(xq + margin);
+      if constexpr (SD == 16) {
+        if (g == 0) b3[3] = (short)rb;
+      } else if constexpr (SD == 8) {
+        if (g == 1) b2[3] = (short)rb;
+      } else {
+        if (g == 1) { b1[7] = (short)rb; b2 = b1; }
+      }
+      const f32x16 c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b1, c0, 0, 0, 0);
+        if constexpr (SD == 8) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], b2, acc, 0, 0, 0);
+        if constexpr (SD == 16) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], b1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][2], b3, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const uint32_t key = (__float_as_uint(acc[v]) & 0xFFFFFFC0u) | (uint32_t)((t & 3) * 16 + v);
+          if (t < 4) { a2 = xf_med3(a1, a2, key); a1 = min(a1, key); }
+          else { q2 = xf_med3(q1, q2, key); q1 = min(q1, key); }
+        }
+      }
+      // slot -> codeword: tile (slot >> 4) (+ 4 for the second tracker), register v = slot & 15 holds codeword 8 (v >> 2) + 4 g + (v & 3)
+      auto widen = [&](uint32_t key, uint32_t half) {
+        const uint32_t sl = key & 63u, v = sl & 15u;
+        const uint32_t cw = ((sl >> 4) + 4u * half) * 32u + 8u * (v >> 2) + 4u * (uint32_t)g + (v & 3u);
+        return (key & 0xFFFFFF00u) | cw;
+      };
+      const uint32_t ka1 = widen(a1, 0), ka2 = widen(a2, 0), kb1 = widen(q1, 1), kb2 = widen(q2, 1);
+      uint32_t m1 = min(ka1, kb1), m2 = min(max(ka1, kb1), min(ka2, kb2));
+      {   // the partner lane holds the other 128 codewords of the row
+        const uint32_t p1 = __shfl_xor(m1, 32, 64), p2 = __shfl_xor(m2, 32, 64);
+        const uint32_t lo = min(m1, p1), hi2 = max(m1, p1);
+        m2 = min(hi2, min(m2, p2));
+        m1 = lo;
+      }
+      if (g == 0) {
+        const float s1 = __uint_as_float(m1 & 0xFFFFFF00u), s2 = __uint_as_float(m2 & 0xFFFFFF00u);
+        // margin > 2^-100: the relative bounds above assume no product, sum or cleared mantissa bit sits in the denormal range
+        // (16 + 16 slots x 2^-126, 255 ulps of a denormal key); columns scaled like 1e-20 take the exact kernel (NaN anywhere: false)
+        // + 2^-14 s1: the winner's key sits up to 2^-15 of its value under its surrogate (8 cleared mantissa bits)
+        const bool decided = (margin < INFINITY) && (margin > 7.888609052210118e-31f) && (s2 - s1 > margin + 0.00006103515625f * s1);
+        codes_s[(wave * MW + mi) * MA_ROWS + lrow] = (uint8_t)(m1 & 0xFFu);      // (an undecided item's byte is rewritten by the fix kernel)
+        if (!decided && !rskip[lrow]) {
+          if constexpr (PROF) ++pc_und;
+          xf_queue_item<QC>(p, q_cnt, q_rows, m, m0 + m, (uint32_t)lrow, row0, false);
+        }
+      }
+    }
+  }
+  if constexpr (PROF) { const long long t = clock64(); prof_pq += t - pprev; pprev = t; }
+  __syncthreads();
+  // ---- the workgroup's undecided items: one atomic per sub-quantiser that has any ----
+  {
+    if (threadIdx.x < M) {
+      const uint32_t c = min(q_cnt[threadIdx.x], (uint32_t)QC);
+      q_base[threadIdx.x] = c ? atomicAdd(&p.fb_cnt[m0 + threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * QC; i += 256) {
+      const int m = i / QC, e = i - m * QC;
+      if ((uint32_t)e < min(q_cnt[m], (uint32_t)QC)) p.fb_items[(int64_t)(m0 + m) * p.n + q_base[m] + e] = (uint32_t)(row0 + q_rows[i]);
+    }
+  }
+  // ---- codes: [wave][mi][row] in LDS -> [row][m0 + m] in HBM ----
+  {
+    const int64_t nrows = p.n - row0 < MA_ROWS ? p.n - row0 : MA_ROWS;
+    if (p.m_total == M) {      // the block is the whole code row: one coalesced store per workgroup
+      const int nbytes = (int)nrows * M;
+      uint8_t *dst = p.codes + row0 * M;
+      const int nw = nbytes / 4;
+      for (int i = threadIdx.x; i < nw; i += 256) {
+        uint32_t w = 0u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int o = 4 * i + b, r = o / M, m = o - r * M;
+          w |= (uint32_t)codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r] << (8 * b);
+        }
+        reinterpret_cast<uint32_t *>(dst)[i] = w;
+      }
+      for (int o = nw * 4 + threadIdx.x; o < nbytes; o += 256) {
+        const int r = o / M, m = o - r * M;
+        dst[o] = codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r];
+      }
+    } else {                   // a column block of a long row: M bytes at [row][m0 ..]
+      for (int o = threadIdx.x; o < (int)nrows * M; o += 256) {
+        const int r = o / M, m = o - r * M;
+        p.codes[(row0 + r) * p.m_total + m0 + m] = codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r];
+      }
+    }
+  }
+}
+
+// ---- long rows (d > 128: C3's 1536-dimensional embeddings): residual + PQ encode of one 128-column block per workgroup ------------------
+// The coarse quantiser of such rows is the K-tiled matrix-core kernel of mfma_assign.hip; this kernel is the second half of the
+// transform.  Round 5 ran it as residual_kernel (6 GB read, 6 GB written at C3) + the exact pairwise kernel over 96 sub-quantisers
+// (24.7 ms of the 56 ms transform, profiles/r06k_c3_xform_kernel_stats.csv): the undecided-row lists of pq_mfma.hip did not fit its
+// 256 MB budget at M = 96.  Here a workgroup takes 128 rows x 128 columns (8 sub-quantisers of 16): the piece of the row and of its
+// centroid are read once, the residual never exists in HBM, and phases 4 / 5 of xf_kernel do the rest.
+template <int KS, int SD>
+__global__ __launch_bounds__(256, 2) void xf_tail_kernel(XfArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = KS * 16, XS = D + 4;
+  float *xs = reinterpret_cast<float *>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * MA_ROWS;
+  const int col0 = p.col_base + (int)blockIdx.y * D;
+  uint32_t *q_cnt = XfLds<KS, SD>::q_cnt(smem);
+  if (threadIdx.x < XfLds<KS, SD>::M) q_cnt[threadIdx.x] = 0u;
+  const int64_t row = row0 + wave * 32 + j;
+  const bool valid = row < p.n;
+  constexpr int NLD = MA_ROWS * (D / 4) / 256;
+  {
+    f4 stage[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / (D / 4), c4 = idx - r * (D / 4);
+      stage[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (row0 + r < p.n) stage[u] = *reinterpret_cast<const f4 *>(static_cast<const float *>(p.x) + (row0 + r) * p.ldx + col0 + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + 256 * u, r = idx / (D / 4), c4 = idx - r * (D / 4);
+      *reinterpret_cast<f4 *>(&xs[r * XS + 4 * c4]) = stage[u];
+    }
+  }
+  const uint32_t best = valid ? p.part_ids[row] : LANCE_HIP_NONE;
+  __syncthreads();
+  float xf[KS][8];
+  {
+    const float *xr = xs + (wave * 32 + j) * XS + g * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f4 a = *reinterpret_cast<const f4 *>(xr + s * 16), b = *reinterpret_cast<const f4 *>(xr + s * 16 + 4);
+      xf[s][0] = a.x; xf[s][1] = a.y; xf[s][2] = a.z; xf[s][3] = a.w; xf[s][4] = b.x; xf[s][5] = b.y; xf[s][6] = b.z; xf[s][7] = b.w;
+    }
+  }
+  __syncthreads();      // xs is dead: the residual planes take its place
+  {
+    const bool sub = p.residual && best != LANCE_HIP_NONE;
+    const bool zero = !valid || (p.residual && best == LANCE_HIP_NONE);
+    xf_residual_to_lds<KS, SD>(xf, p.cent + (int64_t)(sub ? best : 0u) * p.d_total + col0, sub, zero, p.round_f16, smem, wave * 32 + j, g, !valid);
+  }
+  __syncthreads();
+  uint32_t und = 0;
+  long long t0 = 0, t1 = 0;
+  xf_pq_phase<KS, SD, false>(p, smem, col0 / SD, row0, und, t0, t1);
 }
 
 template <int KS, int SD, int METRIC, typename TX, bool PROF = false>
@@ -315,23 +618,12 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   constexpr int XS = D + 4;          // f32 row stride of the x staging tile
   constexpr int CW = 2 * D + 16;     // bf16 elements per centroid in global memory: hi (D) | norm step (16) | lo (D)
   constexpr int CS = CW + 8;         // ... and per LDS row (16-byte skew: conflict-free ds_read_b128)
-  constexpr int NCH = D / 8;         // 16-byte chunks per residual row
-  constexpr int NMF = SD == 8 ? 2 : 1;
-  constexpr int MW = (M + 3) / 4;    // sub-quantisers per wave
   constexpr bool XL = !std::is_same<TX, int8_t>::value;       // int8 rows are exact in bf16
-  static_assert(SD == 4 || SD == 8, "sub-dimension 4 or 8");
+  static_assert(SD == 4 || SD == 8 || SD == 16, "sub-dimension 4, 8 or 16");
   float *xs = reinterpret_cast<float *>(smem);                       // phase 1: [128][XS] f32
-  uint16_t *cbuf = reinterpret_cast<uint16_t *>(smem);               // phase 2: [2][MA_CT][CS]
-  uint16_t *rh = reinterpret_cast<uint16_t *>(smem);                 // phase 3: [128][D] hi, [128][D] lo (chunks rotated by the row)
-  uint16_t *rl = rh + (size_t)MA_ROWS * D;
-  uint16_t *xn2s = rl + (size_t)MA_ROWS * D;                         // [128][M] bf16 upper bounds of |r_m|^2
-  // codes: [wave][MW][128] -- a byte is written by the wave that owns the sub-quantiser, its dword neighbours are the adjacent rows
-  // of the SAME store instruction (round 6, first version: [row][m] put four waves' bytes into one dword, and about one byte in two
-  // million came out stale: concurrent sub-dword LDS stores of different waves to one dword are not safe)
-  uint8_t *codes_s = reinterpret_cast<uint8_t *>(xn2s + (size_t)MA_ROWS * M);
-  uint8_t *rskip = codes_s + (size_t)4 * MW * MA_ROWS;               // [128] 1: the row's items were queued (or the row does not exist)
-  uint32_t *q_cnt = reinterpret_cast<uint32_t *>(smem + xf_lds_main<KS, SD>());      // undecided items of the workgroup: count, base in the global list
-  uint16_t *q_items = reinterpret_cast<uint16_t *>(smem + xf_lds_main<KS, SD>() + 16);
+  uint16_t *cbuf = reinterpret_cast<uint16_t *>(smem);               // phase 2: [2][MA_CT][CS]; phases 4 / 5: XfLds
+  uint32_t *q_cnt = XfLds<KS, SD>::q_cnt(smem);                      // undecided items of the workgroup, per sub-quantiser
+  uint8_t *q_rows = XfLds<KS, SD>::q_rows(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * MA_ROWS;
@@ -341,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   // round 5 -- load, LDS store, next load -- paid sixteen dependent ones, 110k of a wave's 335k cycles; lanes fetching their own
   // 16-byte pieces straight from HBM measured 54k: four times the line requests).  (Persistent workgroups that request the next
   // tile's rows before the PQ phase were tried -- gpurun r06i: the 64 staging registers spill, 1.03 -> 1.36 ms.)
-  if (threadIdx.x == 0) { q_cnt[0] = 0u; q_cnt[1] = 0u; }
+  if (threadIdx.x < M) q_cnt[threadIdx.x] = 0u;
   const int64_t row = row0 + wave * 32 + j;
   const bool valid = row < p.n;
   constexpr int NLD = MA_ROWS * (D / 4) / 256;        // 4-element pieces per thread (16 at D = 128)
@@ -509,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     if (queued) {
       const uint32_t slot = atomicAdd(p.afb_cnt, 1u);
       p.afb_rows[slot] = (uint32_t)row;
-      for (int m = 0; m < M; ++m) xf_queue_item(p, q_cnt, q_items, (uint32_t)m, (uint32_t)(wave * 32 + j), row0);
+      for (int m = 0; m < M; ++m) xf_queue_item<XfLds<KS, SD>::QC>(p, q_cnt, q_rows, m, m, (uint32_t)(wave * 32 + j), row0, true);      // (rare: straight to the global lists)
     } else {
       p.part_ids[row] = best;
       p.dists[row] = bestv;
@@ -519,162 +811,14 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   mark(2);
   // ---- 4. residual -> bf16 planes in LDS (the centroid tiles are dead: the sweep's last barrier is behind every wave) ----
   {
-    const int lrow = wave * 32 + j;
     const bool sub = p.residual && best != LANCE_HIP_NONE;
     const bool zero = !valid || (p.residual && best == LANCE_HIP_NONE);     // rows without a partition encode the zero vector
-    const float *cb = p.cent + (int64_t)(sub ? best : 0u) * D;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      float r[8];
-      if (sub) {
-        const f4 c0 = *reinterpret_cast<const f4 *>(cb + s * 16 + g * 8), c1 = *reinterpret_cast<const f4 *>(cb + s * 16 + g * 8 + 4);
-        const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          r[e] = xf[s][e] - cv[e];
-          if (p.round_f16) r[e] = __half2float(__float2half_rn(r[e]));      // `*v - *cent` in half::f16 (residual.rs:96)
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = zero ? 0.0f : xf[s][e];
-      }
-      uint4 h4, l4;
-      xf_split8<true>(r, h4, l4);
-      const int chunk = 2 * s + g, slot = (chunk + lrow) % NCH;
-      *reinterpret_cast<uint4 *>(rh + (size_t)lrow * D + slot * 8) = h4;
-      *reinterpret_cast<uint4 *>(rl + (size_t)lrow * D + slot * 8) = l4;
-      if constexpr (SD == 8) {
-        float q = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q = __builtin_fmaf(r[e], r[e], q);
-        xn2s[lrow * M + chunk] = (uint16_t)xf_bf16_up(q * 1.0000005f);          // (the fused sum may sit an ulp under the true norm)
-      } else {
-        float q0 = 0.0f, q1 = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { q0 = __builtin_fmaf(r[e], r[e], q0); q1 = __builtin_fmaf(r[4 + e], r[4 + e], q1); }
-        *reinterpret_cast<uint32_t *>(xn2s + lrow * M + 2 * chunk) = (xf_bf16_up(q0 * 1.0000005f) & 0xFFFFu) | (xf_bf16_up(q1 * 1.0000005f) << 16);
-      }
-    }
-    if (g == 0) rskip[lrow] = (uint8_t)((!valid || queued) ? 1 : 0);
+    xf_residual_to_lds<KS, SD>(xf, p.cent + (int64_t)(sub ? best : 0u) * D, sub, zero, p.round_f16, smem, wave * 32 + j, g, !valid || queued);
   }
   __syncthreads();
   mark(3);
-
-  // ---- 5. PQ encode: this wave's sub-quantisers against all 128 rows ---------------------------------------------------
-  const bf16x8 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, 0, 0, 0, 0, 0};
-#pragma unroll 1
-  for (int m = wave, mi = 0; m < M; m += 4, ++mi) {
-    bf16x8 af[8][NMF];
-    {
-      const uint4 *src = p.pqa + (int64_t)m * 8 * NMF * 64 + lane;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int f = 0; f < NMF; ++f) af[t][f] = __builtin_bit_cast(bf16x8, src[(t * NMF + f) * 64]);
-    }
-    const float cmax2 = p.pq_cmax2[m];
-#pragma unroll 1
-    for (int rg = 0; rg < MA_ROWS / 32; ++rg) {
-      const int lrow = rg * 32 + j;
-      bf16x8 b1, b2;
-      if constexpr (SD == 8) {
-        const int slot = (m + lrow) % NCH;
-        b1 = *reinterpret_cast<const bf16x8 *>(rh + (size_t)lrow * D + slot * 8);
-        const bf16x8 lo8 = *reinterpret_cast<const bf16x8 *>(rl + (size_t)lrow * D + slot * 8);
-        b2 = g == 0 ? lo8 : ones;
-      } else {
-        const int slot = ((m >> 1) + lrow) % NCH;
-        const uint2 h4 = *reinterpret_cast<const uint2 *>(rh + (size_t)lrow * D + slot * 8 + (m & 1) * 4);
-        const uint2 l4 = *reinterpret_cast<const uint2 *>(rl + (size_t)lrow * D + slot * 8 + (m & 1) * 4);
-        const uint4 bb = g == 0 ? make_uint4(h4.x, h4.y, h4.x, h4.y) : make_uint4(l4.x, l4.y, 0x3F803F80u, 0x00003F80u);
-        b1 = __builtin_bit_cast(bf16x8, bb);
-        b2 = b1;
-      }
-      const float xq = __uint_as_float((uint32_t)xn2s[lrow * M + m] << 16);
-      const float margin = 0.000244140625f * (xq + cmax2);       // 2^-12 (|r_m|^2 + max|c|^2)
-      // the row's offset R = bf16 >= |r_m|^2 + margin rides in the fourth slot of the "ones" vector (the codeword side holds a 1 there):
-      // every surrogate is >= 0 (float order == unsigned order of the bits) and the accumulator starts from the inline constant 0
-      const uint32_t rb = xf_bf16_up(xq + margin);
-      if constexpr (SD == 8) {
-        if (g == 1) b2[3] = (short)rb;
-      } else {
-        if (g == 1) { b1[7] = (short)rb; b2 = b1; }
-      }
-      const f32x16 c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, q1 = 0xFFFFFFFFu, q2 = 0xFFFFFFFFu;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][0], b1, c0, 0, 0, 0);
-        if constexpr (NMF == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][1], b2, acc, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const uint32_t key = (__float_as_uint(acc[v]) & 0xFFFFFFC0u) | (uint32_t)((t & 3) * 16 + v);
-          if (t < 4) { a2 = xf_med3(a1, a2, key); a1 = min(a1, key); }
-          else { q2 = xf_med3(q1, q2, key); q1 = min(q1, key); }
-        }
-      }
-      // slot -> codeword: tile (slot >> 4) (+ 4 for the second tracker), register v = slot & 15 holds codeword 8 (v >> 2) + 4 g + (v & 3)
-      auto widen = [&](uint32_t key, uint32_t half) {
-        const uint32_t sl = key & 63u, v = sl & 15u;
-        const uint32_t cw = ((sl >> 4) + 4u * half) * 32u + 8u * (v >> 2) + 4u * (uint32_t)g + (v & 3u);
-        return (key & 0xFFFFFF00u) | cw;
-      };
-      const uint32_t ka1 = widen(a1, 0), ka2 = widen(a2, 0), kb1 = widen(q1, 1), kb2 = widen(q2, 1);
-      uint32_t m1 = min(ka1, kb1), m2 = min(max(ka1, kb1), min(ka2, kb2));
-      {   // the partner lane holds the other 128 codewords of the row
-        const uint32_t p1 = __shfl_xor(m1, 32, 64), p2 = __shfl_xor(m2, 32, 64);
-        const uint32_t lo = min(m1, p1), hi2 = max(m1, p1);
-        m2 = min(hi2, min(m2, p2));
-        m1 = lo;
-      }
-      if (g == 0) {
-        const float s1 = __uint_as_float(m1 & 0xFFFFFF00u), s2 = __uint_as_float(m2 & 0xFFFFFF00u);
-        // margin > 2^-100: the relative bounds above assume no product, sum or cleared mantissa bit sits in the denormal range
-        // (16 + 16 slots x 2^-126, 255 ulps of a denormal key); columns scaled like 1e-20 take the exact kernel (NaN anywhere: false)
-        const bool decided = (margin < INFINITY) && (margin > 7.888609052210118e-31f) && (s2 - s1 > margin);
-        codes_s[(wave * MW + mi) * MA_ROWS + lrow] = (uint8_t)(m1 & 0xFFu);      // (an undecided item's byte is rewritten by the fix kernel)
-        if (!decided && !rskip[lrow]) {
-          if constexpr (PROF) ++pc_und;
-          xf_queue_item(p, q_cnt, q_items, (uint32_t)m, (uint32_t)lrow, row0);
-        }
-      }
-    }
-  }
-  mark(4);
-  __syncthreads();
-  // ---- the workgroup's undecided items: one atomic on the global list ----
-  {
-    const uint32_t nq = min(q_cnt[0], (uint32_t)XF_QCAP);
-    if (nq) {
-      if (threadIdx.x == 0) q_cnt[1] = atomicAdd(p.fb_cnt, nq);
-      __syncthreads();
-      const uint32_t base = q_cnt[1];
-      for (uint32_t i = threadIdx.x; i < nq; i += 256) {
-        const uint32_t it = q_items[i];
-        p.fb_items[base + i] = ((it >> 7) << 27) | (uint32_t)(row0 + (it & 127u));
-      }
-    }
-  }
-  // ---- codes: [wave][mi][row] in LDS -> [row][m] in HBM, one coalesced store per workgroup ----
-  {
-    const int64_t nrows = p.n - row0 < MA_ROWS ? p.n - row0 : MA_ROWS;
-    const int nbytes = (int)nrows * M;
-    uint8_t *dst = p.codes + row0 * M;
-    const int nw = nbytes / 4;
-    for (int i = threadIdx.x; i < nw; i += 256) {
-      uint32_t w = 0u;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int o = 4 * i + b, r = o / M, m = o - r * M;
-        w |= (uint32_t)codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r] << (8 * b);
-      }
-      reinterpret_cast<uint32_t *>(dst)[i] = w;
-    }
-    for (int o = nw * 4 + threadIdx.x; o < nbytes; o += 256) {
-      const int r = o / M, m = o - r * M;
-      dst[o] = codes_s[((m & 3) * MW + (m >> 2)) * MA_ROWS + r];
-    }
-  }
+  // ---- 5. PQ encode: this wave's sub-quantisers against all 128 rows; undecided items; codes out ----
+  xf_pq_phase<KS, SD, PROF>(p, smem, 0, row0, pc_und, pa[4], pprev);
   mark(5);
   if constexpr (PROF) {
     uint32_t und = pc_und;
@@ -696,7 +840,7 @@ bool xform_fused_supported(int dtype, int metric, int d, int m, int nbits, int64
   if (metric != METRIC_L2 && metric != METRIC_DOT) return false;
   if (d % 16 != 0 || d < 16 || d > 128) return false;
   const int sd = d / m;
-  if (sd != 4 && sd != 8) return false;
+  if (sd != 4 && sd != 8 && sd != 16) return false;
   if (n < 2048 || nlist < 32) return false;
   const size_t es = dtype == LANCE_HIP_F16 ? 2 : (dtype == LANCE_HIP_I8 ? 1 : 4);
   if (reinterpret_cast<uintptr_t>(x) % (4 * es)) return false;
@@ -739,13 +883,33 @@ static int xf_launch_sd(lance_hip_ctx *ctx, const XfArgs &a, int d, int metric, 
   return LANCE_HIP_OK;
 }
 
+static void xf_pq_prep_launch(lance_hip_ctx *ctx, int sd, int m, const float *codebook, uint4 *pqa, float *cmax2) {
+  if (sd == 16) hipLaunchKernelGGL(xf_pq_prep_kernel<16>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+  else if (sd == 8) hipLaunchKernelGGL(xf_pq_prep_kernel<8>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+  else hipLaunchKernelGGL(xf_pq_prep_kernel<4>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+}
+
+template <int SD>
+static void xf_fix_launch_sd(lance_hip_ctx *ctx, int dtype, dim3 fgrid, const XfFixArgs &fa) {
+  if (dtype == LANCE_HIP_F16) hipLaunchKernelGGL((xf_fix_kernel<SD, __half>), fgrid, dim3(256), 0, ctx->stream, fa);
+  else if (dtype == LANCE_HIP_I8) hipLaunchKernelGGL((xf_fix_kernel<SD, int8_t>), fgrid, dim3(256), 0, ctx->stream, fa);
+  else hipLaunchKernelGGL((xf_fix_kernel<SD, float>), fgrid, dim3(256), 0, ctx->stream, fa);
+}
+static void xf_fix_launch(lance_hip_ctx *ctx, int sd, int dtype, int64_t rows, const XfFixArgs &fa) {
+  // grid (blocks, sub-quantisers); a workgroup whose first wave has no item returns before staging the codebook
+  const dim3 fgrid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)rows, 256)), 64), (unsigned)fa.m);
+  if (sd == 16) xf_fix_launch_sd<16>(ctx, dtype, fgrid, fa);
+  else if (sd == 8) xf_fix_launch_sd<8>(ctx, dtype, fgrid, fa);
+  else xf_fix_launch_sd<4>(ctx, dtype, fgrid, fa);
+}
+
 // x: [n][d] rows in the column's element type; metric: METRIC_L2 (residual encoded) or METRIC_DOT (the row itself encoded);
 // round_f16: the residual is rounded to binary16 (f16 columns, also when they arrive as a normalised f32 copy: cosine);
 // part_ids / dists [n] and codes [n][m] are filled exactly as launch_assign + the fused encode fill them.
 int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x, int64_t n, int d, const float *cent, int nlist,
                        const float *codebook, int m, uint32_t *part_ids, float *dists, uint8_t *codes, bool round_f16) {
   if (n == 0) return LANCE_HIP_OK;
-  const int sd = d / m, nmf = sd == 8 ? 2 : 1;
+  const int sd = d / m, nmf = sd == 16 ? 3 : (sd == 8 ? 2 : 1);
   const int kpad = (nlist + MA_CT - 1) / MA_CT * MA_CT;
   uint16_t *cpl = ctx->scratch_t<uint16_t>("xf.cpl", (size_t)kpad * (2 * d + 16));
   uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);      // [0] max |c|^2, [2] rows left to the recompute kernel
@@ -755,15 +919,14 @@ int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x,
   else hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_L2>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, nlist, d, cpl, maxbits);
   uint4 *pqa = ctx->scratch_t<uint4>("xf.pqa", (size_t)m * 8 * nmf * 64);
   float *cmax2 = ctx->scratch_t<float>("xf.cmax2", (size_t)m);
-  // rows go through in chunks: the undecided-item list is [chunk * m] words of scratch (256 MB at most), whatever n is; row numbers take 27 bits
-  const int64_t chunk = std::max<int64_t>(MA_ROWS, std::min<int64_t>(n, ((int64_t)64 << 20) / m / MA_ROWS * MA_ROWS));
-  uint32_t *fb_cnt = ctx->scratch_t<uint32_t>("xf.fb_cnt", 4);
+  // rows go through in chunks: the undecided-item list is [chunk * m] words of scratch (256 MB at most), whatever n is; row numbers take 25 bits
+  const int64_t chunk = std::max<int64_t>(MA_ROWS, std::min<int64_t>(std::min<int64_t>(n, (int64_t)1 << 24), ((int64_t)64 << 20) / m / MA_ROWS * MA_ROWS));
+  uint32_t *fb_cnt = ctx->scratch_t<uint32_t>("xf.fb_cnt", (size_t)m);
   uint32_t *fb_items = ctx->scratch_t<uint32_t>("xf.fb_items", (size_t)chunk * m);
   uint32_t *afb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)chunk);
   if (!pqa || !cmax2 || !fb_cnt || !fb_items || !afb_rows) return LANCE_HIP_ENOMEM;
   ScopedTimer t(ctx, "xform_fused");
-  if (sd == 8) hipLaunchKernelGGL(xf_pq_prep_kernel<8>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
-  else hipLaunchKernelGGL(xf_pq_prep_kernel<4>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+  xf_pq_prep_launch(ctx, sd, m, codebook, pqa, cmax2);
   const size_t es = dtype == LANCE_HIP_F16 ? 2 : (dtype == LANCE_HIP_I8 ? 1 : 4);
   for (int64_t r0 = 0; r0 < n; r0 += chunk) {
     const int64_t rows = std::min<int64_t>(chunk, n - r0);
@@ -772,9 +935,9 @@ int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x,
     a.cpl = cpl; a.maxbits = maxbits; a.cent = cent;
     a.residual = metric == METRIC_L2 ? 1 : 0; a.round_f16 = round_f16 ? 1 : 0; a.check_finite = 1;
     a.pqa = pqa; a.pq_cmax2 = cmax2;
-    a.part_ids = part_ids + r0; a.dists = dists + r0; a.codes = codes + r0 * m;
+    a.part_ids = part_ids + r0; a.dists = dists + r0; a.codes = codes + r0 * m; a.m_total = m; a.d_total = d;
     a.afb_cnt = maxbits + 2; a.afb_rows = afb_rows; a.fb_cnt = fb_cnt; a.fb_items = fb_items;
-    LH_CHECK_HIP(lh::memset_multi(ctx->stream, {{fb_cnt, 0, 16}, {maxbits + 2, 0, 4}}));
+    LH_CHECK_HIP(lh::memset_multi(ctx->stream, {{fb_cnt, 0, (size_t)m * 4}, {maxbits + 2, 0, 4}}));
     {
       ScopedTimer t1(ctx, "xf_main");
       static const bool prof = getenv("LANCE_HIP_XF_PROF") != nullptr;      // s_memtime phase stamps (d = 128, sub-dimension 8, f32, L2), printed per launch
@@ -791,7 +954,8 @@ int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x,
           fprintf(stderr, "[xf prof] waves=%llu | s_memtime ticks per wave: rows->regs %.0f | sweep %.0f | merge+exact %.0f | residual+barrier %.0f | pq %.0f | codes out %.0f | "
                   "undecided pq items %llu\n", h[6], (double)h[0] / h[6], (double)h[1] / h[6], (double)h[2] / h[6], (double)h[3] / h[6], (double)h[4] / h[6],
                   (double)h[5] / h[6], h[7]);
-      } else if (sd == 8) LH_TRY(xf_launch_sd<8>(ctx, a, d, metric, dtype));
+      } else if (sd == 16) LH_TRY(xf_launch_sd<16>(ctx, a, d, metric, dtype));
+      else if (sd == 8) LH_TRY(xf_launch_sd<8>(ctx, a, d, metric, dtype));
       else LH_TRY(xf_launch_sd<4>(ctx, a, d, metric, dtype));
     }
     ScopedTimer t2(ctx, "xf_fix");          // the two exact clean-up kernels
@@ -802,17 +966,85 @@ int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x,
     LH_TRY(ma_recompute_launch(ctx, ma, metric, dtype));
     // ... then the undecided (row, sub-quantiser) items, which read the partition ids
     XfFixArgs fa;
-    fa.x = a.x; fa.ldx = d; fa.cent = cent; fa.part_ids = a.part_ids; fa.residual = a.residual; fa.round_f16 = a.round_f16;
+    fa.x = a.x; fa.ldx = d; fa.n = rows; fa.cent = cent; fa.part_ids = a.part_ids; fa.residual = a.residual; fa.round_f16 = a.round_f16;
     fa.codebook = codebook; fa.m = m; fa.cnt = fb_cnt; fa.items = fb_items; fa.codes = a.codes;
-    const dim3 fgrid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)rows, 64)), 2048));
-    if (sd == 8) {
-      if (dtype == LANCE_HIP_F16) hipLaunchKernelGGL((xf_fix_kernel<8, __half>), fgrid, dim3(256), 0, ctx->stream, fa);
-      else if (dtype == LANCE_HIP_I8) hipLaunchKernelGGL((xf_fix_kernel<8, int8_t>), fgrid, dim3(256), 0, ctx->stream, fa);
-      else hipLaunchKernelGGL((xf_fix_kernel<8, float>), fgrid, dim3(256), 0, ctx->stream, fa);
-    } else {
-      if (dtype == LANCE_HIP_F16) hipLaunchKernelGGL((xf_fix_kernel<4, __half>), fgrid, dim3(256), 0, ctx->stream, fa);
-      else if (dtype == LANCE_HIP_I8) hipLaunchKernelGGL((xf_fix_kernel<4, int8_t>), fgrid, dim3(256), 0, ctx->stream, fa);
-      else hipLaunchKernelGGL((xf_fix_kernel<4, float>), fgrid, dim3(256), 0, ctx->stream, fa);
+    xf_fix_launch(ctx, sd, dtype, rows, fa);
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+// ---- long rows: the second half of the transform (residual + PQ encode) after the K-tiled coarse quantiser -------------------------------
+bool xform_tail_supported(int d, int m, int nbits, int64_t n, const float *x, const float *cent, const float *codebook) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr || getenv("LANCE_HIP_NO_XFORM_FUSED") != nullptr ||
+                          getenv("LANCE_HIP_NO_MFMA_PQ") != nullptr || getenv("LANCE_HIP_NO_MFMA_ENCODE") != nullptr;
+  if (off || nbits != 8 || m <= 0 || m > 127 || d % m != 0 || d <= 128 || n < 2048) return false;
+  const int sd = d / m;
+  if (sd != 4 && sd != 8 && sd != 16) return false;
+  if (d % 16 != 0 || (d % 128 != 0 && sd != 16)) return false;      // a last block of fewer than 128 columns is instantiated for sub-dimension 16 only
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(cent) | reinterpret_cast<uintptr_t>(codebook)) & 15) return false;
+  return true;
+}
+
+template <int KS, int SD>
+static void xf_tail_launch_one(lance_hip_ctx *ctx, const XfArgs &a, unsigned blocks_y) {
+  constexpr size_t lds = xf_lds_bytes<KS, SD>();
+  hipLaunchKernelGGL((xf_tail_kernel<KS, SD>), dim3((unsigned)cdiv((uint64_t)a.n, MA_ROWS), blocks_y), dim3(256), lds, ctx->stream, a);
+}
+
+// x: [n][d] f32 rows (already normalised for cosine); part_ids: their partitions (LANCE_HIP_NONE: the zero vector is encoded when `residual`)
+int launch_xform_tail(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, int residual, bool round_f16,
+                      const float *codebook, int m, uint8_t *codes) {
+  if (n == 0) return LANCE_HIP_OK;
+  const int sd = d / m, na = sd == 16 ? 3 : (sd == 8 ? 2 : 1);
+  uint4 *pqa = ctx->scratch_t<uint4>("xf.pqa", (size_t)m * 8 * na * 64);
+  float *cmax2 = ctx->scratch_t<float>("xf.cmax2", (size_t)m);
+  const int64_t chunk = std::max<int64_t>(MA_ROWS, std::min<int64_t>(std::min<int64_t>(n, (int64_t)1 << 24), ((int64_t)64 << 20) / m / MA_ROWS * MA_ROWS));
+  uint32_t *fb_cnt = ctx->scratch_t<uint32_t>("xf.fb_cnt", (size_t)m);
+  uint32_t *fb_items = ctx->scratch_t<uint32_t>("xf.fb_items", (size_t)chunk * m);
+  if (!pqa || !cmax2 || !fb_cnt || !fb_items) return LANCE_HIP_ENOMEM;
+  ScopedTimer t(ctx, "xform_tail");
+  xf_pq_prep_launch(ctx, sd, m, codebook, pqa, cmax2);
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t rows = std::min<int64_t>(chunk, n - r0);
+    XfArgs a{};
+    a.x = x + (size_t)r0 * d; a.n = rows; a.ldx = d; a.cent = cent; a.d_total = d;
+    a.residual = residual; a.round_f16 = round_f16 ? 1 : 0;
+    a.pqa = pqa; a.pq_cmax2 = cmax2; a.part_ids = const_cast<uint32_t *>(part_ids) + r0; a.codes = codes + r0 * m; a.m_total = m;
+    a.fb_cnt = fb_cnt; a.fb_items = fb_items;
+    LH_CHECK_HIP(lh::memset_async(fb_cnt, 0, (size_t)m * 4, ctx->stream));
+    const int full = d / 128, rem = d % 128;
+    if (full) {
+      a.col_base = 0;
+      if (sd == 16) xf_tail_launch_one<8, 16>(ctx, a, (unsigned)full);
+      else if (sd == 8) xf_tail_launch_one<8, 8>(ctx, a, (unsigned)full);
+      else xf_tail_launch_one<8, 4>(ctx, a, (unsigned)full);
+    }
+    if (rem) {      // (sub-dimension 16 only: xform_tail_supported)
+      a.col_base = full * 128;
+      switch (rem / 16) {
+        case 1: xf_tail_launch_one<1, 16>(ctx, a, 1); break;
+        case 2: xf_tail_launch_one<2, 16>(ctx, a, 1); break;
+        case 3: xf_tail_launch_one<3, 16>(ctx, a, 1); break;
+        case 4: xf_tail_launch_one<4, 16>(ctx, a, 1); break;
+        case 5: xf_tail_launch_one<5, 16>(ctx, a, 1); break;
+        case 6: xf_tail_launch_one<6, 16>(ctx, a, 1); break;
+        default: xf_tail_launch_one<7, 16>(ctx, a, 1); break;
+      }
+    }
+    XfFixArgs fa;
+    fa.x = a.x; fa.ldx = d; fa.n = rows; fa.cent = cent; fa.part_ids = a.part_ids; fa.residual = residual; fa.round_f16 = a.round_f16;
+    fa.codebook = codebook; fa.m = m; fa.cnt = fb_cnt; fa.items = fb_items; fa.codes = a.codes;
+    xf_fix_launch(ctx, sd, LANCE_HIP_F32, rows, fa);
+    static const bool prof = getenv("LANCE_HIP_XF_PROF") != nullptr;      // how many (row, sub-quantiser) items the surrogate left undecided
+    if (prof) {
+      std::vector<uint32_t> h((size_t)m);
+      LH_CHECK_HIP(hipMemcpyAsync(h.data(), fb_cnt, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+      LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      uint64_t tot = 0, mx = 0;
+      for (uint32_t v : h) { tot += v; mx = std::max<uint64_t>(mx, v); }
+      fprintf(stderr, "[xf tail prof] rows %lld x %d sub-quantisers: %llu undecided items (%.2f %%), largest list %llu\n", (long long)rows, m,
+              (unsigned long long)tot, 100.0 * (double)tot / ((double)rows * m), (unsigned long long)mx);
     }
   }
   LH_CHECK_HIP(hipGetLastError());

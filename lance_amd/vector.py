@@ -246,8 +246,10 @@ class IvfPqIndex:
         per distinct filter; queries sharing a filter should share the returned index."""
         from .engine import DeviceIndex
         if self.params.num_bits == 4:
-            raise NotImplementedError("prefilter on a 4-bit PQ index: the reference scores filtered rows with the unquantised "
-                                      "table (pq/storage.rs:897-908), which this engine's 4-bit scan does not implement yet")
+            # 4-bit PQ: the reference scores FILTERED rows with the unquantised f32 table (pq/storage.rs:893-921), a different arithmetic
+            # from its unfiltered fast-scan -- a compacted copy would be searched with the wrong one.  The masked kernels implement it
+            # (lance_hip_ivfpq_search_filtered, search.hip pq4_masked_row): hand back a view that carries the mask into every search.
+            return _MaskedIndexView(self, allow)
         part, codes, rid = self._storage_rows()
         allow_t = to_device(np.ascontiguousarray(allow, dtype=bool)) if not isinstance(allow, torch.Tensor) else allow.to(part.device)
         ids = torch.arange(part.numel(), device=part.device) if rid is None else rid
@@ -504,6 +506,17 @@ def create_index(x, index_type="IVF_PQ", metric="l2", num_partitions=256, num_su
     # integer-valued f32 column) are built here, inside the build's clock, instead of inside the first search
     timed("prewarm", ix.prewarm)
     return IvfPqIndex(ix, params, stats, part, codes)
+
+
+class _MaskedIndexView:
+    """`IvfPqIndex.prefiltered(allow)` of a 4-bit index: the same index, every search under the row-id mask (no copy)."""
+
+    def __init__(self, index, allow):
+        self._index, self._allow = index, allow
+        self.params, self.stats = index.params, index.stats
+
+    def nearest(self, q, k=10, nprobes=1, refine_factor=None, distance_range=None, **kw):
+        return self._index.nearest(q, k=k, nprobes=nprobes, refine_factor=refine_factor, prefilter=self._allow, distance_range=distance_range, **kw)
 
 
 def validate_vector_index(index, vectors, refine_factor=5, sample_size=None, pass_threshold=1.0, seed=0):

@@ -56,11 +56,11 @@ def oracle_chain(oracle, x, cent, cb, metric):
     return part, codes, float(tot)
 
 
-def run_case(eng, oracle, x, cent, cb, metric):
-    before = eng.timing_query("count:xform_fused")[1]
+def run_case(eng, oracle, x, cent, cb, metric, stage="xform_fused"):
+    before = eng.timing_query("count:" + stage)[1]
     part, codes, loss = eng.ivfpq_encode(x, cent, cb, metric)
     import os
-    assert os.environ.get("XF_ALLOW_OLD") or eng.timing_query("count:xform_fused")[1] == before + 1, "the fused transform kernel did not serve this call"
+    assert os.environ.get("XF_ALLOW_OLD") or eng.timing_query("count:" + stage)[1] == before + 1, f"the {stage} kernel did not serve this call"
     part = _np(part).view(np.uint32); codes = _np(codes)
     opart, ocodes, oloss = oracle_chain(oracle, x, cent, cb, metric)
     bad = np.nonzero(part != opart)[0]
@@ -91,14 +91,15 @@ def dup_centroids(cent):
 
 def dup_codewords(cb):
     cb = cb.copy()
-    cb[1, 7] = cb[1, 100]
+    cb[min(1, cb.shape[0] - 1), 7] = cb[min(1, cb.shape[0] - 1), 100]
     cb[-1, 255] = cb[-1, 0]
     return cb
 
 
 @pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
 @pytest.mark.parametrize("d,m,nlist,n", [(128, 16, 256, 5037), (64, 8, 40, 3000), (128, 32, 100, 2177), (48, 6, 33, 2100), (16, 2, 32, 2048),
-                                         (80, 20, 64, 2300), (112, 14, 70, 2600), (32, 8, 1000, 4100)])
+                                         (80, 20, 64, 2300), (112, 14, 70, 2600), (32, 8, 1000, 4100),
+                                         (128, 8, 64, 2500), (48, 3, 40, 2200), (16, 1, 32, 2100)])      # sub-dimension 16
 def test_f32_rows(eng, oracle, metric, d, m, nlist, n):
     x = spoil(clustered(n, d, 7 + d + m).astype(f32))
     if metric == "cosine":
@@ -166,3 +167,34 @@ def test_large_values_and_tiny_values(eng, oracle):
         cb = np.stack([x[rng.choice(n, 256, replace=False)][:, i * 8:(i + 1) * 8] for i in range(m)]).astype(f32)
         print("scale", scale)
         run_case(eng, oracle, x, cent, cb, "l2")
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
+@pytest.mark.parametrize("d,m,nlist,n", [(256, 16, 64, 2300), (1536, 96, 100, 2177), (192, 12, 40, 2100), (144, 9, 33, 2050), (256, 32, 64, 2400),
+                                         (384, 96, 48, 2060)])
+def test_long_rows_take_the_tail_kernel(eng, oracle, metric, d, m, nlist, n):
+    """d > 128: the K-tiled coarse quantiser (mfma_assign.hip), then ONE kernel per 128-column block for residual + PQ encode
+    (xf_tail_kernel): sub-dimension 16 (C3's shape: 1536 / 96), a last block of fewer than 128 columns (192, 144), sub-dimension 8 and 4"""
+    x = spoil(clustered(n, d, 17 + d + m, scale=6.0, noise=2.5, integer=False).astype(f32))
+    if metric == "cosine":
+        x[100] = 1.0
+    rng = np.random.default_rng(d + 5 * m)
+    xs = oracle.normalize(x) if metric == "cosine" else x
+    fin = oracle.is_finite(xs)
+    cent = dup_centroids(np.ascontiguousarray(xs[fin][rng.choice(int(fin.sum()), nlist, replace=False)]))
+    part, _ = oracle.assign(np.ascontiguousarray(xs[fin]), cent, "l2" if metric == "cosine" else metric)
+    res = oracle.residual(np.ascontiguousarray(xs[fin]), cent, np.where(part == oracle.NONE, 0, part)) if metric != "dot" else xs[fin]
+    sd = d // m
+    cb = np.stack([res[rng.choice(res.shape[0], 256, replace=False)][:, i * sd:(i + 1) * sd] for i in range(m)]).astype(f32)
+    run_case(eng, oracle, x, cent, dup_codewords(cb), metric, stage="xform_tail")
+
+
+def test_long_f16_rows_take_the_tail_kernel(eng, oracle):
+    n, d, m, nlist = 2300, 256, 16, 48
+    x = spoil((clustered(n, d, 3, scale=1.5, noise=0.6, integer=False)).astype(np.float16))
+    rng = np.random.default_rng(9)
+    cent = dup_centroids(np.ascontiguousarray(x[200:200 + nlist]))
+    part, _ = oracle.assign(np.ascontiguousarray(x[200:]), cent, "l2")
+    res = oracle.residual(np.ascontiguousarray(x[200:]), cent, np.where(part == oracle.NONE, 0, part))
+    cb = np.stack([res[rng.choice(res.shape[0], 256, replace=False)][:, i * 16:(i + 1) * 16] for i in range(m)]).astype(np.float16)
+    run_case(eng, oracle, x, cent, dup_codewords(cb), "l2", stage="xform_tail")
