@@ -86,11 +86,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # a step is 0.5 ms: 200 of them time 0.1 s (20 steps = 10 ms moved the line by 5 % run to run)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
                     help="c2 (default, the contract workload): SIFT-1M-like f32, IVF_PQ(256, 16).  c4: BASELINE config 4's shape -- "
                          "f16 rows, IVF_PQ(4096, 16), 12.5M rows PER RANK (100M on 8 GPUs): the configuration where the E-step "
                          "outweighs the per-iteration all-reduce of the sharded k-means")
-    ap.add_argument("--n", type=int, default=None, help="total rows (default: 1,000,000 for c2; 12,500,000 x ranks for c4)")
+    ap.add_argument("--n", type=int, default=None, help="total rows (default: 1,000,000 for c2; 12,500,000 x ranks for c4 / c5).  c5: BASELINE config 5's "
+                    "shape -- int8 rows x 128, IVF_PQ(65536, 32), hierarchical k-means")
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--nprobes", type=int, default=10)
     ap.add_argument("--refine", type=int, default=10)
@@ -160,14 +161,21 @@ def main():
     from lance_amd import vector as lv
 
     eng = lance_amd.default_engine()
-    d, nlist, m = (128, 256, 16) if args.config == "c2" else (128, 4096, 16)
+    d, nlist, m = {"c2": (128, 256, 16), "c4": (128, 4096, 16), "c5": (128, 65536, 32)}[args.config]
     half = args.config == "c4"                      # Float16 column (C4)
+    int8c = args.config == "c5"                     # Int8 column (C5: BigANN-shaped)
     if args.n is None:
         args.n = 1_000_000 if args.config == "c2" else 12_500_000 * world
     multi = world > 1 or force_dist
 
     def gen_rows(count, seed):
         # c4: 100M rows do not fit through one f32 staging tensor comfortably -- generate in 4M-row pieces, keep f16
+        if int8c:      # descriptors as signed bytes, 16,384 clusters, generated in 4M-row pieces
+            out = torch.empty((count, d), dtype=torch.int8, device=dev)
+            for a in range(0, count, 4_000_000):
+                b = min(count, a + 4_000_000)
+                out[a:b] = (sift_like(b - a, d, seed=seed + 31 * (a // 4_000_000), device=dev, n_clusters=16384) - 100.0).clamp_(-128, 127).to(torch.int8)
+            return out
         if not half:
             return sift_like(count, d, seed=seed, device=dev)
         out = torch.empty((count, d), dtype=torch.float16, device=dev)
@@ -179,6 +187,7 @@ def main():
         return out
     # 4 different query batches per rank, cycled over the steps
     qbatches = [((sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev, n_clusters=4096) / 256.0).to(torch.float16) if half else
+                 (sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev, n_clusters=16384) - 100.0).clamp_(-128, 127).to(torch.int8) if int8c else
                  sift_like(args.nq, d, seed=4321 + 100 * rank + i, device=dev)) for i in range(4)]
     mg = {}            # multi-GPU extras of the bench line
 
@@ -260,7 +269,7 @@ def main():
 
         def lstep(i):
             return ld.search_list_sharded(lambda qq, kk, npb, rf: shard.search(qq, kk, npb, rf), l2g, common[i % 2], args.k, args.nprobes,
-                                          args.refine, engine=eng)
+                                          args.refine, engine=eng, local_candidates=lambda qq, ke, npb: shard.search_candidates(qq, ke, npb))
 
         li, _ = lstep(0)
         ri, _ = idx.search_device(common[0], args.k, args.nprobes, args.refine)
@@ -305,7 +314,7 @@ def main():
                            "single-query latencies (BASELINE.md: 1.24-8.67 ms, IVF512, unnamed hardware)")
         recall_grid = []
         o_g = (torch.empty((1000, args.k), dtype=torch.int64, device=dev), torch.empty((1000, args.k), dtype=torch.float32, device=dev))
-        for npb in (1, 10, 25, 50, nlist):
+        for npb in (1, 10, 25, 50, min(nlist, 256)):      # (c4 / c5: 256 probes stand in for the exhaustive column)
             for rf in (0, 10):
                 for _ in range(3):
                     idx.search_device(qs, args.k, npb, rf, out=o_g)
@@ -483,7 +492,7 @@ def main():
     # dense bf16 MFMA peak -- executed flop = 3 x algorithmic (two-term bf16 split: hi.hi + lo.hi + hi.lo)
     roofline_build = None
     if world == 1 and not multi:
-        es = 2 if half else 4
+        es = 2 if half else 1 if int8c else 4
         tr_bytes = float(args.n) * d * es + float(args.n) * (4 + m)
         tr_sec = idx.stats.seconds.get("transform") if idx.stats else None
         ns = min(args.n, nlist * 256)
@@ -492,7 +501,7 @@ def main():
         for _ in range(3):
             eng.assign(xs_, cent_, "l2")
         torch.cuda.synchronize()
-        reps_e = 20
+        reps_e = 20 if nlist <= 4096 else 2
         eng.timing(True)          # HIP events around the MFMA sweep kernel itself (a host clock over an 85 us call measured the launch gaps)
         eng.timing_query("ma_sweep"); eng.timing_query("ma_recheck")
         t1 = time.perf_counter()
@@ -529,8 +538,9 @@ def main():
     guide_lds_peak = LDS_B64_CONFLICT_FREE_PER_CLK_CU * 256 * 2.4e9      # lane-gathers/s: ds_read_b64, 256 B/clk/CU, 256 CUs, 2.4 GHz
     c4 = args.config == "c4"
     result = {
-        "metric": ("QPS @ recall@10 (SIFT-1M IVF_PQ nlist=256 M=16) + index-build sec" if not c4 else
-                   "QPS @ recall@10 (synthetic f16 x128, IVF_PQ nlist=4096 M=16; BASELINE config 4 shape) + index-build sec"),
+        "metric": ("QPS @ recall@10 (SIFT-1M IVF_PQ nlist=256 M=16) + index-build sec" if args.config == "c2" else
+                   "QPS @ recall@10 (synthetic f16 x128, IVF_PQ nlist=4096 M=16; BASELINE config 4 shape) + index-build sec" if c4 else
+                   "QPS @ recall@10 (synthetic int8 x128, IVF_PQ nlist=65536 M=32, hierarchical k-means; BASELINE config 5 shape) + index-build sec"),
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
@@ -540,10 +550,11 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if not c4 else "f16 rows, f32 arithmetic",
+        "dtype": "f32" if args.config == "c2" else "f16 rows, f32 arithmetic" if c4 else "int8 rows, f32 arithmetic",
         "data": "synthetic",
-        "config": {"workload": ("SIFT-1M-like 1Mx128 f32, IVF_PQ nlist=256 M=16 nbits=8, build+search on MI355X" if not c4 else
-                                f"C4 shape: {args.n} x 128 f16 rows, IVF_PQ nlist=4096 M=16 nbits=8, build+search on MI355X"),
+        "config": {"workload": ("SIFT-1M-like 1Mx128 f32, IVF_PQ nlist=256 M=16 nbits=8, build+search on MI355X" if args.config == "c2" else
+                                f"C4 shape: {args.n} x 128 f16 rows, IVF_PQ nlist=4096 M=16 nbits=8, build+search on MI355X" if c4 else
+                                f"C5 shape: {args.n} x 128 int8 rows, IVF_PQ nlist=65536 M=32 nbits=8 (hierarchical k-means), build+search on MI355X"),
                    "n": args.n, "d": d, "nlist": nlist, "m": m, "queries_per_step_per_gpu": args.nq, "k": args.k,
                    "nprobes": args.nprobes, "refine_factor": args.refine,
                    "parallelism": (f"build: rows sharded over {world} ranks, RCCL all-reduce per Lloyd iteration; search: replica x{world} "
@@ -633,7 +644,7 @@ def main():
         return ms_ / max(n_, 1)
     keff_b = args.k * max(args.refine, 1)
     refine_u8 = eng.timing_query("count:refine_u8")[1] > 0      # the index kept a lossless u8 copy of the integer-valued f32 column (index.h raw_u8)
-    refine_bytes = float(args.nq) * keff_b * d * (1 if refine_u8 else 2 if half else 4)
+    refine_bytes = float(args.nq) * keff_b * d * (1 if (refine_u8 or int8c) else 2 if half else 4)
     result["refine_source"] = ("lossless u8 copy of the f32 raw column (every element is an integer in [0, 255], checked on the bits when the index was "
                                "built; same f32 values after widening, same arithmetic): 1 byte per element" if refine_u8 else
                                "the caller's raw column, " + ("2" if half else "4") + " bytes per element")

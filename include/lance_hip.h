@@ -282,6 +282,16 @@ int lance_hip_ivfpq_search_range(lance_hip_ctx *ctx, const lance_hip_index *idx,
                                  uint32_t nprobes, uint32_t refine_factor, float lower, float upper, uint64_t *ids,
                                  float *dists);
 
+/* One scan, two distances per candidate -- the local half of a LIST-SHARDED multi-GPU search with refine (search is
+ * embarrassingly parallel over IVF lists; scanner.rs:2884-2904 re-ranks the k * refine_factor best by PQ distance with exact
+ * distances): ids / pq_dists [nq][keff] = the keff nearest rows of this index by PQ distance in (dist, rowid) order (~0 / +inf
+ * beyond the found ones), exactly lance_hip_ivfpq_search(k = keff, refine_factor = 0); exact_dists [nq][keff] (may be NULL) = each
+ * candidate's exact distance to the query in the index's metric, the refine kernels' arithmetic, in the SAME order.  The ranks
+ * all-gather the three arrays and lance_hip_merge_topk picks the global keff by PQ distance and orders them by the exact one.
+ * (Round 5 obtained the exact distances from a second scan with refine_factor = 1 and aligned the two lists with sorts.)          */
+int lance_hip_ivfpq_search_candidates(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t keff,
+                                      uint32_t nprobes, uint64_t *ids, float *pq_dists, float *exact_dists);
+
 /* The same search under a row-id prefilter (`nearest=..., filter=..., prefilter=True`: scanner.rs -> DatasetPreFilter ->
  * FlatIndex::search's RowIdMask branch, flat/index.rs:129-165).  allow_by_rowid[r] != 0 <=> row id r may be returned; rows
  * whose id is >= n_allow are filtered out.  The mask is applied INSIDE the scan kernels (one bit per stored row, tested

@@ -29,6 +29,7 @@ SYMBOLS = [
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
     "lance_hip_index_set_raw", "lance_hip_index_prewarm", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
     "lance_hip_pq_scan_topk", "lance_hip_ivfpq_search", "lance_hip_ivfpq_search_async", "lance_hip_ivfpq_search_range",
+    "lance_hip_ivfpq_search_candidates",
     "lance_hip_search_stats", "lance_hip_ivfpq_search_filtered", "lance_hip_ivfpq_search_filtered_range",
     "lance_hip_flat_topk", "lance_hip_ivfflat_create", "lance_hip_ivfflat_search", "lance_hip_ivfflat_search_filtered",
     "lance_hip_index_file_open", "lance_hip_index_file_get", "lance_hip_index_file_close", "lance_hip_index_file_write",
@@ -121,6 +122,7 @@ def load():
         "lance_hip_ivfpq_search": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
         "lance_hip_ivfpq_search_async": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, vp]),
         "lance_hip_ivfpq_search_range": (i32, [vp, vp, vp, u32, u32, u32, u32, f32, f32, vp, vp]),
+        "lance_hip_ivfpq_search_candidates": (i32, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
         "lance_hip_search_stats": (i32, [vp, C.POINTER(u32)]),
         "lance_hip_ivfpq_search_filtered": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, u64, vp, vp]),
         "lance_hip_ivfpq_search_filtered_range": (i32, [vp, vp, vp, u32, u32, u32, u32, vp, u64, f32, f32, vp, vp]),

@@ -708,6 +708,14 @@ __device__ __forceinline__ void refine_emit_topk(uint32_t *key, uint64_t *rid, u
   }
 }
 
+// lance_hip_ivfpq_search_candidates: the exact distance of every candidate IN THE CANDIDATE LIST'S ORDER (the list-sharded multi-GPU search
+// gathers PQ-ordered candidates and their exact distances from one scan; +inf for an empty slot)
+__device__ __forceinline__ void refine_write_cand_exact(float *__restrict__ cand_exact, const uint32_t *key, int keff, int c, int qi) {
+  if (!cand_exact) return;      // uniform
+  for (int i = threadIdx.x; i < keff; i += 256) cand_exact[(int64_t)qi * keff + i] = (i < c && key[i] != 0xFFFFFFFFu) ? key_to_float(key[i]) : INFINITY;
+  __syncthreads();              // the selection below may sort `key` in place
+}
+
 // rows long enough for the four-lanes-per-candidate cosine path (no f32x8 / scalar tail: d % 16 == 0; 16-byte aligned rows)
 __host__ __device__ __forceinline__ bool refine_wide_rows(int d) { return d >= 256 && (d & 15) == 0; }
 
@@ -715,7 +723,8 @@ template <int METRIC, typename TR, bool H32 = false>
 __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q, int d, const TR *__restrict__ raw,
                                                      uint64_t n_raw, const uint64_t *__restrict__ cand_rid,
                                                      const uint32_t *__restrict__ cand_cnt, int keff, int k, int P,
-                                                     uint64_t *__restrict__ out_ids, float *__restrict__ out_dists, uint32_t *__restrict__ flags) {
+                                                     uint64_t *__restrict__ out_ids, float *__restrict__ out_dists, uint32_t *__restrict__ flags,
+                                                     float *__restrict__ cand_exact = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
   uint32_t *key = reinterpret_cast<uint32_t *>(rid + P);
@@ -824,6 +833,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ q
     }
   }
   __syncthreads();
+  refine_write_cand_exact(cand_exact, key, keff, c, qi);
   refine_emit_topk(key, rid, pos, P, c, k, qi, out_ids, out_dists);
 }
 
@@ -840,7 +850,7 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restrict__ q, int d, const float *__restrict__ raw, uint64_t n_raw,
                                                           const uint64_t *__restrict__ cand_rid, const uint32_t *__restrict__ cand_cnt, int keff,
                                                           int k, int P, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
-                                                          uint32_t *__restrict__ flags) {
+                                                          uint32_t *__restrict__ flags, float *__restrict__ cand_exact = nullptr) {
   static_assert(METRIC == METRIC_L2 || METRIC == METRIC_DOT, "squared L2 / dot");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
@@ -906,6 +916,7 @@ __global__ __launch_bounds__(256) void refine_pair_kernel(const float *__restric
     }
   }
   __syncthreads();
+  refine_write_cand_exact(cand_exact, key, keff, c, qi);
   refine_emit_topk(key, rid, pos, P, c, k, qi, out_ids, out_dists);
 }
 
@@ -918,7 +929,7 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void refine_u8_kernel(const float *__restrict__ q, int d, const uint8_t *__restrict__ raw, uint64_t n_raw,
                                                         const uint64_t *__restrict__ cand_rid, const uint32_t *__restrict__ cand_cnt, int keff,
                                                         int k, int P, uint64_t *__restrict__ out_ids, float *__restrict__ out_dists,
-                                                        uint32_t *__restrict__ flags) {
+                                                        uint32_t *__restrict__ flags, float *__restrict__ cand_exact = nullptr) {
   static_assert(METRIC == METRIC_L2 || METRIC == METRIC_DOT, "squared L2 / dot");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t *rid = reinterpret_cast<uint64_t *>(smem);
@@ -987,6 +998,7 @@ __global__ __launch_bounds__(256) void refine_u8_kernel(const float *__restrict_
     }
   }
   __syncthreads();
+  refine_write_cand_exact(cand_exact, key, keff, c, qi);
   refine_emit_topk(key, rid, pos, P, c, k, qi, out_ids, out_dists);
 }
 
@@ -1239,6 +1251,80 @@ static void launch_scan(lance_hip_ctx *ctx, const ScanArgs &a, int grid, size_t 
 }
 
 // The whole query pipeline, enqueued on ctx->stream.  flags_out: device [nq] (zeroed here).
+// valid ids of a search result row are a prefix (empty slots hold ~0): their count, for the refine kernels
+__global__ __launch_bounds__(256) void cand_count_kernel(const uint64_t *__restrict__ ids, uint32_t nq, uint32_t keff, uint32_t *__restrict__ cnt) {
+  const uint32_t qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= nq) return;
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < keff; ++i) c += ids[(uint64_t)qi * keff + i] != ~0ull ? 1u : 0u;
+  cnt[qi] = c;
+}
+
+// refine of cand_rid [nq][keff] (cand_cnt [nq] valid entries each): exact distances in the index's metric against the raw column, then
+// (dist, rowid) order, fetch k; cand_exact (optional): every candidate's exact distance in the list's order
+static int launch_refine(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, int d, const uint64_t *cand_rid, const uint32_t *cand_cnt,
+                         uint32_t keff, uint32_t k, uint64_t *ids, float *dists, uint32_t *flags, float *cand_exact) {
+  {
+    const int P = next_pow2(std::max((int)keff, 64));
+    ScopedTimer t(ctx, "refine");
+    const float *rawf = static_cast<const float *>(ix->raw);
+    const __half *rawh = static_cast<const __half *>(ix->raw);
+    // flat_knn on the taken rows uses the index's metric with the ORIGINAL query (q_orig = widened q for f16)
+    const int8_t *rawi = static_cast<const int8_t *>(ix->raw);
+    if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_COSINE)
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_DOT)
+      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else if (ix->dtype == LANCE_HIP_I8)
+      hipLaunchKernelGGL((refine_kernel<METRIC_L2, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else if (ix->dtype == LANCE_HIP_F16 && ix->metric == LANCE_HIP_COSINE)
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, __half, true>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else if (ix->dtype == LANCE_HIP_F16 && ix->metric == LANCE_HIP_DOT)
+      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, __half, true>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else if (ix->dtype == LANCE_HIP_F16)
+      hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else if (ix->metric == LANCE_HIP_COSINE)
+      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256),
+                         (size_t)P * 16 + (refine_wide_rows(d) ? (size_t)d * 4 : 0), ctx->stream, q, d, rawf, ix->n_raw,
+                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    else {
+      // f32 rows of whole 16-element chunks, 16-byte aligned: two lanes per candidate with the row in flight (LANCE_HIP_REFINE_V1=1: A/B)
+      static const bool v1 = getenv("LANCE_HIP_REFINE_V1") != nullptr;
+      const bool pair = !v1 && (d & 15) == 0 && ((reinterpret_cast<uintptr_t>(rawf) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+      const size_t lds_pair = (size_t)P * 16 + (size_t)d * 4;
+      const uint8_t *raw8 = pair ? raw_compact_prepare(ctx, ix) : nullptr;      // integer-valued column: its lossless u8 copy (index.h)
+      if (raw8) {
+        ScopedTimer t8(ctx, "refine_u8");      // the same launch under its own name: tests assert which source the refine read
+        if (ix->metric == LANCE_HIP_DOT)
+          hipLaunchKernelGGL((refine_u8_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
+                             cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+        else
+          hipLaunchKernelGGL((refine_u8_kernel<METRIC_L2>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
+                             cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+      } else if (pair && ix->metric == LANCE_HIP_DOT)
+        hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
+                           (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+      else if (pair)
+        hipLaunchKernelGGL((refine_pair_kernel<METRIC_L2>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
+                           (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+      else if (ix->metric == LANCE_HIP_DOT)
+        hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
+                           cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+      else
+        hipLaunchKernelGGL((refine_kernel<METRIC_L2, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
+                           cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags, cand_exact);
+    }
+  }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
 static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
                                      uint32_t nprobes, uint32_t refine_factor, int has_range, float lower, float upper,
                                      uint64_t *ids, float *dists, uint32_t **flags_out, const uint32_t *allow);
@@ -1492,63 +1578,7 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
       else hipLaunchKernelGGL((ivfpq_exact_kernel<METRIC_L2, 8>), dim3(nq), dim3(64), lds, ctx->stream, ea);
     }
   }
-  if (do_refine) {
-    const int P = next_pow2(std::max((int)keff, 64));
-    ScopedTimer t(ctx, "refine");
-    const float *rawf = static_cast<const float *>(ix->raw);
-    const __half *rawh = static_cast<const __half *>(ix->raw);
-    // flat_knn on the taken rows uses the index's metric with the ORIGINAL query (q_orig = widened q for f16)
-    const int8_t *rawi = static_cast<const int8_t *>(ix->raw);
-    if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_COSINE)
-      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->dtype == LANCE_HIP_I8 && ix->metric == LANCE_HIP_DOT)
-      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->dtype == LANCE_HIP_I8)
-      hipLaunchKernelGGL((refine_kernel<METRIC_L2, int8_t>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawi, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->dtype == LANCE_HIP_F16 && ix->metric == LANCE_HIP_COSINE)
-      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, __half, true>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->dtype == LANCE_HIP_F16 && ix->metric == LANCE_HIP_DOT)
-      hipLaunchKernelGGL((refine_kernel<METRIC_DOT, __half, true>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->dtype == LANCE_HIP_F16)
-      hipLaunchKernelGGL((refine_kernel<METRIC_L2, __half>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawh, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else if (ix->metric == LANCE_HIP_COSINE)
-      hipLaunchKernelGGL((refine_kernel<METRIC_COSINE, float>), dim3(nq), dim3(256),
-                         (size_t)P * 16 + (refine_wide_rows(d) ? (size_t)d * 4 : 0), ctx->stream, q, d, rawf, ix->n_raw,
-                         cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    else {
-      // f32 rows of whole 16-element chunks, 16-byte aligned: two lanes per candidate with the row in flight (LANCE_HIP_REFINE_V1=1: A/B)
-      static const bool v1 = getenv("LANCE_HIP_REFINE_V1") != nullptr;
-      const bool pair = !v1 && (d & 15) == 0 && ((reinterpret_cast<uintptr_t>(rawf) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
-      const size_t lds_pair = (size_t)P * 16 + (size_t)d * 4;
-      const uint8_t *raw8 = pair ? raw_compact_prepare(ctx, ix) : nullptr;      // integer-valued column: its lossless u8 copy (index.h)
-      if (raw8) {
-        ScopedTimer t8(ctx, "refine_u8");      // the same launch under its own name: tests assert which source the refine read
-        if (ix->metric == LANCE_HIP_DOT)
-          hipLaunchKernelGGL((refine_u8_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
-                             cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-        else
-          hipLaunchKernelGGL((refine_u8_kernel<METRIC_L2>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, raw8, ix->n_raw, cand_rid,
-                             cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-      } else if (pair && ix->metric == LANCE_HIP_DOT)
-        hipLaunchKernelGGL((refine_pair_kernel<METRIC_DOT>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
-                           (int)keff, (int)k, P, ids, dists, flags);
-      else if (pair)
-        hipLaunchKernelGGL((refine_pair_kernel<METRIC_L2>), dim3(nq), dim3(256), lds_pair, ctx->stream, q, d, rawf, ix->n_raw, cand_rid, cand_cnt,
-                           (int)keff, (int)k, P, ids, dists, flags);
-      else if (ix->metric == LANCE_HIP_DOT)
-        hipLaunchKernelGGL((refine_kernel<METRIC_DOT, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                           cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-      else
-        hipLaunchKernelGGL((refine_kernel<METRIC_L2, float>), dim3(nq), dim3(256), (size_t)P * 16, ctx->stream, q, d, rawf, ix->n_raw,
-                           cand_rid, cand_cnt, (int)keff, (int)k, P, ids, dists, flags);
-    }
-  }
+  if (do_refine) LH_TRY(launch_refine(ctx, ix, q, nq, d, cand_rid, cand_cnt, keff, k, ids, dists, flags, nullptr));
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }
@@ -1647,6 +1677,32 @@ int lance_hip_ivfpq_search(lance_hip_ctx *ctx, const lance_hip_index *idx, const
   const float *qf;
   LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
   LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, k, nprobes, refine_factor, 0, 0.f, 0.f, ids, dists, &flags, nullptr));
+  return check_flags(ctx, flags, nq);
+}
+
+int lance_hip_ivfpq_search_candidates(lance_hip_ctx *ctx, const lance_hip_index *idx, const void *q, uint32_t nq, uint32_t keff, uint32_t nprobes,
+                                      uint64_t *ids, float *pq_dists, float *exact_dists) {
+  lh::CtxLock _ctx_lock(ctx);
+  LH_REQUIRE(ctx && idx && (nq == 0 || (q && ids && pq_dists)), "search_candidates: NULL argument");
+  LH_REQUIRE(ctx->device == idx->device, "search_candidates: context and index live on different devices");
+  LH_REQUIRE(idx->m != 0, "search_candidates: not an IVF_PQ index");
+  LH_REQUIRE(!exact_dists || idx->raw != nullptr, "search_candidates: exact distances need raw vectors (lance_hip_index_set_raw)");
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  if (nq == 0) return LANCE_HIP_OK;
+  uint32_t *flags = nullptr;
+  const float *qf;
+  LH_TRY(as_f32(ctx, idx->dtype, q, (size_t)nq * idx->d, "f16.q", &qf));
+  // ONE scan: the keff best by PQ distance, (dist, rowid) order ...
+  LH_TRY(ivfpq_search_enqueue(ctx, idx, qf, nq, keff, nprobes, 0, 0, 0.f, 0.f, ids, pq_dists, &flags, nullptr));
+  if (exact_dists) {
+    // ... and the exact distance of each, in that order (the refine kernels' arithmetic, their selection output discarded)
+    uint32_t *cnt = ctx->scratch_t<uint32_t>("search.cx_cnt", nq);
+    uint64_t *oi = ctx->scratch_t<uint64_t>("search.cx_ids", (size_t)nq * keff);
+    float *od = ctx->scratch_t<float>("search.cx_dists", (size_t)nq * keff);
+    if (!cnt || !oi || !od) return LANCE_HIP_ENOMEM;
+    hipLaunchKernelGGL(cand_count_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, ids, nq, keff, cnt);
+    LH_TRY(launch_refine(ctx, idx, qf, nq, (int)idx->d, ids, cnt, keff, keff, oi, od, flags, exact_dists));
+  }
   return check_flags(ctx, flags, nq);
 }
 

@@ -609,18 +609,27 @@ def load_list_shard(engine, index_dir, raw=None, dtype=None, group=None):
     return ix, torch.empty(0, dtype=torch.int64)
 
 
-def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group=None, engine=None):
+def search_list_sharded(local_search, l2g, q, k, nprobes, refine_factor=0, group=None, engine=None, local_candidates=None):
     """local_search(q, kk, nprobes, refine_factor) -> (local ids int64 [-1 = none], dists) over this rank's lists.
     Every rank passes the SAME query batch and gets the same (ids [nq,k] int64 global, dists [nq,k]).
-    engine: merge the gathered candidates with the device kernel (lance_hip_merge_topk) instead of torch sorts."""
+    engine: merge the gathered candidates with the device kernel (lance_hip_merge_topk) instead of torch sorts.
+    local_candidates(q, keff, nprobes) -> (ids, PQ dists, exact dists) from ONE scan (DeviceIndex.search_candidates =
+    lance_hip_ivfpq_search_candidates): with a refine factor the local half is then a single C-ABI call -- no second scan with
+    refine_factor = 1, no sorts to align the two candidate lists (the strong-scaling path paid 2 x scan + torch glue)."""
     world = dist.get_world_size(group)
     keff = k * refine_factor if refine_factor else k
-    li, ld = local_search(q, keff, nprobes, 0)
+    ex = None
+    if refine_factor and local_candidates is not None:
+        li, ld, ex = local_candidates(q, keff, nprobes)
+    else:
+        li, ld = local_search(q, keff, nprobes, 0)
     li = torch.as_tensor(li).to(torch.int64); ld = torch.as_tensor(ld).to(torch.float32)
     l2g = torch.as_tensor(l2g).to(li.device)
     gi = torch.where(li < 0, li, l2g[li.clamp(min=0)]) if l2g.numel() else li
     payload = [gi.contiguous(), ld.contiguous()]
-    if refine_factor:
+    if ex is not None:
+        payload.append(torch.as_tensor(ex).to(torch.float32).contiguous())
+    elif refine_factor:
         # exact distances of the same keff local candidates (k = keff, refine_factor = 1 re-ranks without dropping any)
         ri, rd = local_search(q, keff, nprobes, 1)
         ri = torch.as_tensor(ri).to(torch.int64); rd = torch.as_tensor(rd).to(torch.float32)

@@ -611,6 +611,23 @@ class DeviceIndex:
                                                               a.numel(), _ptr(ids), _ptr(dists)))
         return ids, dists
 
+    def search_candidates(self, q, keff, nprobes, exact=True, engine=None):
+        """ONE scan -> (ids [nq, keff] int64 (-1 = none), PQ distances, exact distances or None): the keff nearest rows by PQ distance in
+        (dist, rowid) order and, aligned with them, each one's exact distance to the query (lance_hip_ivfpq_search_candidates) -- the
+        local half of a list-sharded search with refine (lance_amd/dist.py: search_list_sharded)."""
+        eng = engine or self.engine
+        d = self.centroids.shape[1]
+        t = q if isinstance(q, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(q))
+        q = t.to(self.data_dtype).to(_dev()).contiguous().reshape(-1, d)
+        nq = q.shape[0]
+        ids = torch.empty((nq, keff), dtype=torch.int64, device=q.device)
+        pq = torch.empty((nq, keff), dtype=torch.float32, device=q.device)
+        ex = torch.empty((nq, keff), dtype=torch.float32, device=q.device) if exact else None
+        torch.cuda.synchronize()
+        check(eng.lib.lance_hip_ivfpq_search_candidates(eng.h, self.h, _ptr(q), nq, keff, min(nprobes, self.centroids.shape[0]), _ptr(ids), _ptr(pq),
+                                                        _ptr(ex) if exact else None))
+        return ids, pq, ex
+
     def search_range(self, q, k, nprobes, lower=None, upper=None, refine_factor=0, allow=None, out=None):
         """Distance-range query: only rows with lower <= d < upper (ADC distance) enter the per-partition heaps.  With a
         refine factor the reference also filters the exact distances before the final fetch (scanner.rs:3334-3377): all

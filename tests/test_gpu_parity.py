@@ -1105,6 +1105,22 @@ def test_rowsharded_build_and_list_shards_world1(eng, oracle):
                 ti, td = ld.search_list_sharded(fn, l2g, torch.from_numpy(qh).cuda(), k, nprobes, rf)                 # torch-sort merge
                 assert (_np(li).view(np.uint64) == oi).all() and (_np(ldist).view(np.uint32) == od.view(np.uint32)).all(), (mode, "lists", k, nprobes, rf)
                 assert torch.equal(li, ti) and torch.equal(ldist, td)
+                # round 6: the local half as ONE scan (lance_hip_ivfpq_search_candidates: PQ order + exact distances, aligned)
+                scans = eng.timing_query("count:refine")[1]
+                ci, cdist = ld.search_list_sharded(fn, l2g, torch.from_numpy(qh).cuda(), k, nprobes, rf, engine=eng,
+                                                   local_candidates=lambda qq, ke, npb: shard.search_candidates(qq, ke, npb))
+                assert torch.equal(ci, li) and torch.equal(cdist, ldist), (mode, "one-scan candidates", k, nprobes, rf)
+                if rf:
+                    assert eng.timing_query("count:refine")[1] == scans + 1      # one pass of the refine kernels, no second search
+                    # the candidate call itself: ids / PQ distances = search(k = keff, no refine); exact = the oracle's re-ranked distances
+                    i3, p3, e3 = shard.search_candidates(qh, k * rf, nprobes)
+                    i0, p0 = shard.search(qh, k * rf, nprobes, 0)
+                    assert torch.equal(i3, i0) and torch.equal(p3, p0)
+                    oi2, od2 = oidx.search(qh, k * rf, nprobes, refine=1, raw=xh)       # same candidate set, exact distances, re-ranked
+                    gl = torch.where(i3 < 0, i3, l2g.to(i3.device)[i3.clamp(min=0)]) if l2g.numel() else i3
+                    got = {(int(a), int(b)) for a, b in zip(_np(gl)[0], _np(e3)[0].view(np.uint32)) if a >= 0}
+                    want = {(int(a), int(b)) for a, b in zip(oi2[0].astype(np.int64), od2[0].view(np.uint32)) if a != np.iinfo(np.uint64).max}
+                    assert got == want
             shard.close()
         # the sharded loop on one rank adds the rows in the single-GPU order: same centroids as the single-GPU trainer
         samp = x[:16384]
