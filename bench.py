@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--streams", type=int, default=3, help="engine contexts (HIP streams) the query batches alternate on")
     ap.add_argument("--no-grid", action="store_true", help="skip the small-batch latencies and the SURVEY 8(d) recall grid (a few seconds)")
+    ap.add_argument("--nlist", type=int, default=None, help="override the configuration's number of IVF lists (tests: a count the ranks do not divide)")
     ap.add_argument("--no-extras", action="store_true", help="skip the child run on the f32 refine source and the PCIe-inclusive build (round 6 additions to the line)")
     # ranks started by this script's own launcher take their arguments from the environment: torchrun's argument parser refuses
     # `--n` after the script name (an abbreviation of several of ITS options: gpurun r05a)
@@ -162,6 +163,8 @@ def main():
 
     eng = lance_amd.default_engine()
     d, nlist, m = {"c2": (128, 256, 16), "c4": (128, 4096, 16), "c5": (128, 65536, 32)}[args.config]
+    if args.nlist:
+        nlist = args.nlist
     half = args.config == "c4"                      # Float16 column (C4)
     int8c = args.config == "c5"                     # Int8 column (C5: BigANN-shaped)
     if args.n is None:
@@ -260,7 +263,13 @@ def main():
         mg = {"rccl_ranks": world, "transport": "rccl" if backend == "nccl" else f"{backend} through host memory" + (", all ranks on one GPU" if one_gpu else ""),
               "rows_per_rank": hi - lo, "build_sec_ivf_sharded_allreduce": secs["sharded"],
               "build_sec_ivf_replicated": secs["replicated"], "raw_vectors_allgather_sec": time.perf_counter() - t0,
-              "build_stages_ms_sharded": {k_: round(v * 1e3, 3) for k_, v in bld.stats.seconds.items()}}
+              "build_stages_ms_sharded": {k_: round(v * 1e3, 3) for k_, v in bld.stats.seconds.items()},
+              # what "sharded" IVF training means at this nlist, and what it can be checked against
+              "ivf_training_sharded_is": ("hierarchical k-means (nlist > 256, kmeans.rs:1027) with its splits spread over the ranks: bit-identical to the "
+                                          "single-GPU trainer and to the CPU oracle (tests/test_dist_gloo.py)" if nlist > 256 else
+                                          "row-sharded Lloyd loop, one all-reduce per iteration: the sums arrive in rank order, not row order -- equal to the "
+                                          "single-GPU trainer to f32 round-off only (no oracle equality; one rank: identical)"),
+              "ivf_hierarchical_rounds": getattr(bld.stats, "ivf_hierarchical", None)}
         # strong-scaling line: the IVF lists sharded over the ranks (list p -> rank p % N, rows moved by all_to_all), every
         # rank answers the SAME query batches with its lists, one all-gather + device (dist, rowid) merge per batch
         shard, l2g = ld.list_shard_index(bld, x_local)

@@ -123,6 +123,19 @@ int lance_hip_kmeans_estep_partial(lance_hip_ctx *ctx, int dtype, int metric, co
 int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, uint32_t k, uint32_t d,
                               void *centroids_out);
 
+/* One split of the hierarchical trainer -- train_hierarchical_kmeans, kmeans.rs:746-1003: k-means with k centroids over the rows
+ * `rows_host` (n_rows indices into x, ascending; NULL = all rows: the first level) of the training sample x [n][d] (device, f32 or f16:
+ * an f16 sample trains in half-precision M-step arithmetic, as the single-GPU trainer), then the membership of those rows
+ * (kmeans.rs:866-905).  balance_factor_scaled is the factor ALREADY divided by the sample size (train_kmeans :1344 divides once, by the
+ * whole sample, and every split inherits it); seed = the run's seed (the trainer uses seed + number of k-means runs so far).  Outputs on
+ * the host: centroids [k][d] f32, membership [n_rows] (LANCE_HIP_NONE: no centroid).
+ * This is the unit of work of the multi-GPU hierarchical trainer (lance_amd/dist.py train_kmeans_hierarchical_sharded, SURVEY 8(e);
+ * BASELINE config 5: nlist 65,536): every rank holds the sample, the splits of the largest clusters are computed on different ranks at
+ * the same time and applied in the reference's order -- the result is the single-GPU trainer's bit for bit.                         */
+int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, const uint32_t *rows_host,
+                           uint64_t n_rows, uint32_t k, uint32_t max_iters, double tol, float balance_factor_scaled, uint64_t seed,
+                           float *centroids_out_host, uint32_t *membership_out_host);
+
 /* Row-sharded Lloyd iteration WITHOUT host round trips (multi-GPU build).  Per iteration the caller enqueues, on
  * the stream the context was created on (e.g. torch's current stream, so that RCCL collectives are ordered with it):
  *   shard_estep  -- local E-step + local partials: buf = [k*d sums | k counts] (f32), losses [k] (f64), radius [k] (f32);

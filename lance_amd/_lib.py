@@ -24,7 +24,7 @@ SYMBOLS = [
     "lance_hip_synchronize", "lance_hip_malloc", "lance_hip_free", "lance_hip_memcpy_h2d", "lance_hip_memcpy_d2h",
     "lance_hip_normalize", "lance_hip_assign", "lance_hip_kmeans_train", "lance_hip_kmeans_train_ex",
     "lance_hip_kmeans_estep_partial", "lance_hip_kmeans_shard_begin", "lance_hip_kmeans_shard_estep", "lance_hip_kmeans_shard_update",
-    "lance_hip_kmeans_shard_end", "lance_hip_kmeans_init_indices",
+    "lance_hip_kmeans_shard_end", "lance_hip_kmeans_init_indices", "lance_hip_kmeans_split",
     "lance_hip_kmeans_finalize", "lance_hip_pq_train", "lance_hip_residual", "lance_hip_pq_encode",
     "lance_hip_ivfpq_encode", "lance_hip_index_create", "lance_hip_index_from_storage", "lance_hip_index_destroy",
     "lance_hip_index_set_raw", "lance_hip_index_prewarm", "lance_hip_index_info", "lance_hip_index_export", "lance_hip_find_partitions",
@@ -104,6 +104,7 @@ def load():
         "lance_hip_kmeans_shard_update": (i32, [vp, vp, vp, vp, vp, vp, vp, u32, u32, u64, f32, f64, u32]),
         "lance_hip_kmeans_shard_end": (i32, [vp, vp, C.POINTER(f64), C.POINTER(u32), C.POINTER(i32)]),
         "lance_hip_kmeans_init_indices": (i32, [u64, u32, u64, vp]),
+        "lance_hip_kmeans_split": (i32, [vp, i32, i32, vp, u64, u32, vp, u64, u32, u32, f64, f32, u64, vp, vp]),
         "lance_hip_pq_train": (i32, [vp, i32, vp, u64, u32, u32, u32, u32, u32, u64, vp, vp]),
         "lance_hip_residual": (i32, [vp, i32, vp, u64, u32, vp, vp, vp]),
         "lance_hip_pq_encode": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, u32, vp]),

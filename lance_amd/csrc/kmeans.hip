@@ -579,6 +579,23 @@ static int hier_assign_host(lance_hip_ctx *ctx, int metric, const float *x, int6
   return LANCE_HIP_OK;
 }
 
+// One split of train_hierarchical_kmeans (kmeans.rs:866-905): k-means with `cluster_k` centroids over the rows `idx` of x, then the
+// membership of those rows.  cdev: [cluster_k][d] device centroids; mem: host membership (LANCE_HIP_NONE: no centroid).
+static int hier_split(lance_hip_ctx *ctx, int metric, const float *x, int d, const uint32_t *idx_host, size_t cluster_size, int cluster_k,
+                      uint32_t max_iters, double tol, float bf_scaled, uint64_t seed, bool f16_arith, float *cdev, std::vector<uint32_t> &mem) {
+  uint32_t *didx = ctx->scratch_t<uint32_t>("hier.idx", cluster_size);
+  float *sub = ctx->scratch_t<float>("hier.sub", cluster_size * d);
+  if (!didx || !sub) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(hipMemcpyAsync(didx, idx_host, cluster_size * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(gather_rows_u32_kernel, dim3((unsigned)cdiv(cluster_size * d, 256)), dim3(256), 0, ctx->stream, x, d, didx,
+                     (int64_t)cluster_size, sub);
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  uint64_t sd = seed;
+  LH_TRY(kmeans_train_batched(ctx, metric, sub, (int64_t)cluster_size, d, 0, d, cluster_k, 1, max_iters, tol, bf_scaled, false, &sd, cdev, nullptr,
+                              nullptr, f16_arith));
+  return hier_assign_host(ctx, metric, sub, (int64_t)cluster_size, d, cdev, cluster_k, mem, f16_arith);
+}
+
 int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, int64_t n, int d, int target_k, uint32_t max_iters,
                               double tol, float bf_scaled, int hierarchical_k, uint64_t seed, float *cent_out, uint32_t *n_out,
                               bool f16_arith) {
@@ -617,17 +634,8 @@ int kmeans_train_hierarchical(lance_hip_ctx *ctx, int metric, const float *x, in
     } else {
       cluster_k = std::max<size_t>(std::min<size_t>(std::min<size_t>(cluster_size / hierarchical_k, remaining_k), hierarchical_k), 2);
     }
-    uint32_t *didx = ctx->scratch_t<uint32_t>("hier.idx", cluster_size);
-    float *sub = ctx->scratch_t<float>("hier.sub", cluster_size * d);
-    if (!didx || !sub) return LANCE_HIP_ENOMEM;
-    LH_CHECK_HIP(hipMemcpyAsync(didx, big.idx.data(), cluster_size * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(gather_rows_u32_kernel, dim3((unsigned)cdiv(cluster_size * d, 256)), dim3(256), 0, ctx->stream, x, d, didx,
-                       (int64_t)cluster_size, sub);
-    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     sd = seed + run++;
-    LH_TRY(kmeans_train_batched(ctx, metric, sub, (int64_t)cluster_size, d, 0, d, (int)cluster_k, 1, max_iters, tol, bf_scaled, false, &sd,
-                                cdev, nullptr, nullptr, f16_arith));
-    LH_TRY(hier_assign_host(ctx, metric, sub, (int64_t)cluster_size, d, cdev, (int)cluster_k, mem, f16_arith));
+    LH_TRY(hier_split(ctx, metric, x, d, big.idx.data(), cluster_size, (int)cluster_k, max_iters, tol, bf_scaled, sd, f16_arith, cdev, mem));
     bool all_same = true, have_first = false;
     uint32_t first = 0;
     for (size_t r = 0; r < cluster_size; ++r) {
@@ -975,6 +983,29 @@ int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *lo
   if (loss_host) *loss_host = h.s.last_loss;
   if (iters_host) *iters_host = h.s.iters;
   if (active_host) *active_host = (int)h.active;
+  return LANCE_HIP_OK;
+}
+
+int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, const uint32_t *rows_host,
+                           uint64_t n_rows, uint32_t k, uint32_t max_iters, double tol, float balance_factor_scaled, uint64_t seed,
+                           float *centroids_out_host, uint32_t *membership_out_host) {
+  lh::CtxLock _ctx_lock(ctx);
+  LH_REQUIRE(ctx && x && centroids_out_host && membership_out_host && (rows_host || n_rows == n), "kmeans_split: NULL argument");
+  LH_REQUIRE(dtype == LANCE_HIP_F32 || dtype == LANCE_HIP_F16, "kmeans_split: f32 and f16 samples (Int8 columns train on their f32 copy)");
+  LH_REQUIRE(n_rows > 0 && n_rows <= n && n < (1ull << 32) && k > 0 && k <= n_rows, "kmeans_split: %llu rows of %llu, k = %u", (unsigned long long)n_rows,
+             (unsigned long long)n, k);
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  const float *xf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  const int km = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
+  float *cdev = ctx->scratch_t<float>("hier.cent", (size_t)std::max<uint32_t>(k, 16) * d);
+  if (!cdev) return LANCE_HIP_ENOMEM;
+  std::vector<uint32_t> all, mem;
+  if (!rows_host) { all.resize(n_rows); for (uint64_t i = 0; i < n_rows; ++i) all[i] = (uint32_t)i; rows_host = all.data(); }
+  LH_TRY(hier_split(ctx, km, xf, (int)d, rows_host, (size_t)n_rows, (int)k, max_iters, tol, balance_factor_scaled, seed, dtype == LANCE_HIP_F16, cdev, mem));
+  LH_CHECK_HIP(hipMemcpyAsync(centroids_out_host, cdev, (size_t)k * d * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(membership_out_host, mem.data(), (size_t)n_rows * 4);
   return LANCE_HIP_OK;
 }
 

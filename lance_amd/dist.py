@@ -213,6 +213,190 @@ def _train_kmeans_sharded_device(engine, x_local, cent, k, n_total, max_iters, t
     return cent, loss, iters
 
 
+# ---- hierarchical k-means (k > 256: BASELINE configs 4 / 5) with its splits spread over the ranks ------------------------------------
+class _HCluster:
+    __slots__ = ("id", "idx", "centroid", "finalized")
+
+    def __init__(self, cid, idx, centroid):
+        self.id, self.idx, self.centroid, self.finalized = cid, idx, centroid, False
+
+
+def _hc_le(a, b):
+    """Ord of the reference's Cluster (kmeans.rs:769-790): unfinalized before finalized, then by size -- the `<=` a max-heap sift uses"""
+    ka, kb = (0 if a.finalized else 1), (0 if b.finalized else 1)
+    if ka != kb:
+        return ka < kb
+    return len(a.idx) <= len(b.idx)
+
+
+class _HHeap:
+    """std::collections::BinaryHeap restated (push = sift_up; pop = swap_remove(0) + sift_down_to_bottom + sift_up): the ORDER in which equal-sized
+    clusters are popped depends on it, and the run counter that seeds every split follows the pop order (lance_amd/csrc/kmeans.hip HHeap
+    is the same restatement)."""
+
+    def __init__(self, d=None):
+        self.d = [] if d is None else d
+
+    def _sift_up(self, start, pos):
+        e = self.d[pos]
+        while pos > start:
+            parent = (pos - 1) // 2
+            if _hc_le(e, self.d[parent]):
+                break
+            self.d[pos] = self.d[parent]
+            pos = parent
+        self.d[pos] = e
+
+    def push(self, c):
+        self.d.append(c)
+        self._sift_up(0, len(self.d) - 1)
+
+    def pop(self):
+        item = self.d.pop()
+        if self.d:
+            item, self.d[0] = self.d[0], item
+            end = len(self.d)
+            pos, child = 0, 1
+            e = self.d[0]
+            while end >= 2 and child <= end - 2:
+                if _hc_le(self.d[child], self.d[child + 1]):
+                    child += 1
+                self.d[pos] = self.d[child]
+                pos = child
+                child = 2 * pos + 1
+            if child == end - 1:
+                self.d[pos] = self.d[child]
+                pos = child
+            self.d[pos] = e
+            self._sift_up(0, pos)
+        return item
+
+    def shadow(self):
+        return _HHeap(list(self.d))          # same structure, same objects: pops on the copy replay the original's next pops
+
+
+def _hier_cluster_k(size, remaining_k, hk):
+    if size <= hk:
+        return min(2, remaining_k, size)
+    return max(min(size // hk, remaining_k, hk), 2)
+
+
+def train_kmeans_hierarchical_sharded(engine, sample, k, max_iters=50, tol=1e-4, balance_factor=1.0, hierarchical_k=16, seed=0, metric="l2",
+                                      group=None, window=None, stats=None):
+    """train_hierarchical_kmeans (rust/lance-index/src/vector/kmeans.rs:746-1003) with the splits of the largest clusters computed on
+    DIFFERENT ranks at the same time.  `sample` is the whole training sample, identical on every rank (at C5: 16.7M x 128 f32 = 8.6 GB per
+    GPU; the caller all-gathers it once).  The reference pops the largest cluster, runs a k-means over its rows (seeded by the number of
+    runs so far), pushes the children, and repeats until k clusters exist: a sequential recurrence -- but the next pops are almost always
+    the next-largest clusters already in the heap, whatever the split in progress produces.  So every round SPECULATES the next
+    `window` pops on a copy of the heap, rank r runs the speculated splits j = r (mod world) (engine.kmeans_split = one C-ABI call each),
+    the results are exchanged, and the reference's loop is then replayed on the real heap: a speculated split is applied only if the
+    cluster the real heap pops next is the one it was computed for, with the same k and therefore the same seed; the first mismatch
+    (a child outgrew a waiting cluster, or the remaining budget changed k) throws the rest of the round away.  The result is the
+    single-GPU trainer's BIT FOR BIT (same sub-problems, same seeds, same order) -- unlike the row-sharded Lloyd loop it has an oracle to
+    be equal to.  -> centroids [<= k, d] float32 tensor on the sample's device.
+    stats (optional dict): rounds, splits applied, splits thrown away."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n, d = sample.shape
+    hk = int(hierarchical_k)
+    bfs = float(np.float32(balance_factor) / np.float32(n))        # train_kmeans :1344 divides once, by the whole sample
+    window = int(window) if window else max(1, 2 * world)
+    run = 0
+    initial_k = min(hk, k, n)
+    # first level: one k-means over the whole sample -- computed on every rank (a single problem: nothing to spread)
+    c0, mem0 = engine.kmeans_split(sample, None, initial_k, max_iters=max_iters, tol=tol, balance_factor_scaled=bfs, seed=seed + run, metric=metric)
+    run += 1
+    heap = _HHeap()
+    next_id = 0
+    allrows = np.arange(n, dtype=np.uint32)
+    for i in range(initial_k):
+        idx = allrows[mem0 == i]
+        if idx.size == 0:
+            continue
+        heap.push(_HCluster(next_id, idx, c0[i].copy()))
+        next_id += 1
+
+    def next_job(h):
+        """the head of the reference's loop on heap h: -> (cluster, cluster_k) with the cluster popped, or None when the loop ends"""
+        if len(h.d) >= k or not h.d:
+            return None
+        big = h.pop()
+        if big.finalized or len(big.idx) <= 1:
+            h.push(big)
+            return None
+        return big, _hier_cluster_k(len(big.idx), k - len(h.d), hk)
+
+    n_rounds = n_applied = n_wasted = 0
+    pending = None
+    while True:
+        first = pending if pending is not None else next_job(heap)
+        pending = None
+        if first is None:
+            break
+        # speculate the pops after `first` on a copy: children are assumed non-empty (each split adds cluster_k - 1 clusters) and small
+        jobs = [first]
+        sh = heap.shadow()
+        virt = len(heap.d) + first[1]
+        while len(jobs) < window and virt < k and sh.d:
+            c = sh.pop()
+            if c.finalized or len(c.idx) <= 1:
+                break
+            ck = _hier_cluster_k(len(c.idx), k - (virt - 1), hk)     # the reference computes remaining_k after the pop
+            jobs.append((c, ck))
+            virt += ck - 1
+        mine = {}
+        for j in range(rank, len(jobs), world):
+            c, ck = jobs[j]
+            mine[j] = engine.kmeans_split(sample, c.idx, ck, max_iters=max_iters, tol=tol, balance_factor_scaled=bfs, seed=seed + run + j, metric=metric)
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine, group=group)
+            results = {}
+            for g in gathered:
+                results.update(g)
+        else:
+            results = mine
+        n_rounds += 1
+        # replay the reference's loop on the real heap
+        for j, (c, ck) in enumerate(jobs):
+            if j > 0:
+                nj = next_job(heap)
+                if nj is None:
+                    n_wasted += len(jobs) - j
+                    pending = None
+                    jobs = jobs[:j]
+                    first = None
+                    break
+                if nj[0] is not c or nj[1] != ck:
+                    n_wasted += len(jobs) - j
+                    pending = nj
+                    break
+            cent, mem = results[j]
+            run += 1
+            n_applied += 1
+            valid = mem[mem != 0xFFFFFFFF]
+            if valid.size == 0 or (valid == valid[0]).all():      # every row in one child: the cluster cannot be split further
+                c.finalized = True
+                heap.push(c)
+                continue
+            for i in range(ck):
+                idx = c.idx[mem == i]
+                if idx.size == 0:
+                    continue
+                heap.push(_HCluster(next_id, idx, cent[i].copy()))
+                next_id += 1
+        else:
+            continue
+        if first is None and pending is None:
+            break
+    out = sorted(heap.d, key=lambda c: c.id)
+    if stats is not None:
+        stats.update(rounds=n_rounds, splits_applied=n_applied, splits_thrown_away=n_wasted, window=window, world=world)
+    cent = np.stack([c.centroid for c in out]).astype(np.float32) if out else np.zeros((0, d), np.float32)
+    t = torch.from_numpy(cent)
+    return t.to(sample.device) if isinstance(sample, torch.Tensor) else t
+
+
 def block_ranges(total, world):
     """contiguous blocks of ceil(total / world) items per rank (the last ranks may be short or empty)"""
     per = (total + world - 1) // world
@@ -245,9 +429,10 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
         65,536-row sample takes 0.17 ms, less than one all-reduce round trip), or
       * "sharded": rows split over the ranks, one all-reduce per Lloyd iteration (train_kmeans_sharded) -- for
         training sets large enough that the E-step dominates (C4 and up).
-    "auto" picks by the E-step size and keeps nlist > 256 replicated (the reference's hierarchical trainer is a chain
-    of small sub-problems; "sharded" always means the flat Lloyd loop).  With replicated training the whole index is bit-identical to the
-    single-GPU build (same sample, same seeds, independent sub-quantisers, per-row encode).
+      * "hierarchical" (nlist > 256, where the reference trains hierarchically): the splits of the largest clusters are computed on
+        different ranks and applied in the reference's order (train_kmeans_hierarchical_sharded) -- bit-identical to one GPU.
+    "auto" picks by the E-step size; nlist > 256 goes hierarchical on more than one rank.  With replicated or hierarchical training the
+    whole index is bit-identical to the single-GPU build (same sample, same seeds, independent sub-quantisers, per-row encode).
     `index_factory` (default DeviceIndex.create) exists so that the collective logic can be driven on CPU by the
     world_size > 1 gloo tests with a stand-in engine."""
     import time
@@ -290,9 +475,17 @@ def create_index_sharded(x, metric="l2", num_partitions=256, num_sub_vectors=16,
     sample = prep(x if idx is None else x[torch.from_numpy(idx).to(x.device)])
     n_total = sample.shape[0]
     if ivf_training == "auto":
-        ivf_training = "replicated" if n_total * num_partitions * d <= (1 << 36) or num_partitions > 256 else "sharded"
+        # nlist > 256: the reference trains hierarchically (kmeans.rs:1027) -- its splits are spread over the ranks, result bit-identical to
+        # the single-GPU trainer (round 6; round 5 kept such builds replicated: every rank trained the same 65,536 clusters)
+        ivf_training = ("hierarchical" if num_partitions > 256 and world > 1 else
+                        "replicated" if n_total * num_partitions * d <= (1 << 36) or num_partitions > 256 else "sharded")
     stats.ivf_training = ivf_training
-    if ivf_training == "replicated":
+    if ivf_training == "hierarchical":
+        hst = {}
+        cent = timed("train_ivf", lambda: train_kmeans_hierarchical_sharded(eng, sample, num_partitions, max_iters=max_iters, balance_factor=1.0,
+                                                                            seed=seed, metric=kmetric, group=group, stats=hst))
+        stats.ivf_loss, stats.ivf_iters, stats.ivf_hierarchical = 0.0, 0, hst      # "Loss is not meaningful for hierarchical clustering" (:1001)
+    elif ivf_training == "replicated":
         cent, stats.ivf_loss, stats.ivf_iters = timed("train_ivf", lambda: eng.kmeans_train(
             sample, num_partitions, max_iters=max_iters, balance_factor=1.0, seed=seed, metric=kmetric))
     else:
@@ -445,6 +638,15 @@ def create_index_rowsharded(x_local, metric="l2", num_partitions=256, num_sub_ve
 
     def train_ivf():
         samp = local_sample(num_partitions * sample_rate, 0)
+        if ivf_training == "hierarchical" or (ivf_training == "sharded" and num_partitions > 256):
+            # nlist > 256 is a hierarchical training in the reference (kmeans.rs:1027): the sample (16.7M x 128 at C5) is all-gathered once,
+            # the splits are computed on different ranks side by side and applied in the reference's order (bit-identical to one GPU)
+            full, _ = all_gather_var(samp, group)
+            hst = {}
+            c = train_kmeans_hierarchical_sharded(eng, full, num_partitions, max_iters=max_iters, balance_factor=1.0, seed=seed, metric=kmetric,
+                                                  group=group, stats=hst)
+            stats.ivf_hierarchical = hst
+            return c, 0.0, 0
         if ivf_training == "replicated":
             full, _ = all_gather_var(samp, group)
             return eng.kmeans_train(full, num_partitions, max_iters=max_iters, balance_factor=1.0, seed=seed, metric=kmetric)

@@ -117,7 +117,8 @@ class BuildStats:
     ivf_iters: int = 0
     pq_iters: Optional[np.ndarray] = None
     ivf_loss: float = 0.0
-    ivf_training: str = "single"      # multi-GPU builds: "replicated" | "sharded" (lance_amd/dist.py)
+    ivf_training: str = "single"      # multi-GPU builds: "replicated" | "sharded" | "hierarchical" (lance_amd/dist.py)
+    ivf_hierarchical: Optional[dict] = None      # hierarchical training spread over ranks: rounds, splits applied / thrown away
 
     @property
     def total(self):

@@ -261,6 +261,21 @@ def kmeans_train_hierarchical(x, k, max_iters=50, tol=1e-4, balance_factor_scale
     return cent[:got].astype(np.float16) if f16 else cent[:got]
 
 
+def kmeans_split(x, rows, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, seed=0, metric="l2"):
+    """One split of the hierarchical trainer (orc_kmeans_split_x): k-means with k centroids over x[rows] (rows None: all), then the
+    membership of those rows.  float16 x -> the Float16Type instantiation.  -> (centroids [k, d] f32, membership u32 [len(rows)])"""
+    f16 = np.asarray(x).dtype == np.float16
+    x = _f32(x)
+    n, d = x.shape
+    r = None if rows is None else np.ascontiguousarray(rows, np.uint32)
+    nr = n if r is None else len(r)
+    cent = np.empty((k, d), np.float32)
+    mem = np.empty(nr, np.uint32)
+    lib().orc_kmeans_split_x(_m(metric), _p(x), C.c_size_t(n), C.c_size_t(d), _p(r), C.c_size_t(nr), C.c_size_t(k), C.c_uint32(max_iters),
+                             C.c_double(tol), C.c_float(balance_factor_scaled), C.c_uint64(seed), _p(cent), _p(mem), C.c_int(int(f16)))
+    return cent, mem
+
+
 def residual(x, centroids, part_ids):
     f16 = np.asarray(x).dtype == np.float16
     x = _f32(x); centroids = _f32(centroids)

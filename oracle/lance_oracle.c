@@ -797,6 +797,26 @@ static int orc_cluster_by_id(const void *a, const void *b) {
   return ia < ib ? -1 : (ia > ib ? 1 : 0);
 }
 
+/* One split of the hierarchical trainer on its own (kmeans.rs:866-905: the k-means over a cluster's rows, then compute_partitions of
+ * those rows) -- the unit of work the multi-GPU trainer hands to a rank (lance_amd/dist.py train_kmeans_hierarchical_sharded); the same
+ * two calls as inside orc_kmeans_train_hierarchical_x below.  rows == NULL: all n rows (the first level).  TEST INFRASTRUCTURE. */
+void orc_kmeans_split_x(int metric, const float *x, size_t n, size_t d, const uint32_t *rows, size_t n_rows, size_t k, uint32_t max_iters,
+                        double tol, float balance_factor_scaled, uint64_t seed, float *cent_out, uint32_t *mem_out, int f16) {
+  const int amet = orc_metric_h(metric, f16);
+  const float *sub = x;
+  float *tmp = NULL;
+  if (rows) {
+    tmp = (float *)malloc(n_rows * d * sizeof(float));
+    for (size_t r = 0; r < n_rows; r++) memcpy(tmp + r * d, x + (size_t)rows[r] * d, d * sizeof(float));
+    sub = tmp;
+  } else {
+    n_rows = n;
+  }
+  orc_kmeans_capped(metric, sub, n_rows, d, k, max_iters, tol, balance_factor_scaled, seed, cent_out, f16);
+  orc_assign_f32(amet, sub, n_rows, d, cent_out, k, NULL, mem_out, NULL);
+  free(tmp);
+}
+
 /* returns the number of clusters produced (== target_k unless splitting stalls) */
 /* f16 != 0: train_hierarchical_kmeans::<Float16Type, KMeansAlgoFloat<Float16Type>> (kmeans.rs:1030-1033): every inner k-means
  * runs the f16 M-step, the membership pass is compute_partitions on the f16 values (widened per element; dot: 32 lanes)       */

@@ -55,6 +55,10 @@ class OracleEngine:
                                                 seed=seed, metric=metric)
         return torch.from_numpy(c), loss, iters
 
+    def kmeans_split(self, x, rows, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, seed=0, metric="l2"):
+        return oracle.kmeans_split(np.ascontiguousarray(_np(x)), rows, k, max_iters=max_iters, tol=tol, balance_factor_scaled=balance_factor_scaled,
+                                   seed=seed, metric=metric)
+
     def residual(self, x, cent, part):
         return torch.from_numpy(oracle.residual(_np(x), _np(cent), np.ascontiguousarray(_np(part)).view(np.uint32)))
 
@@ -66,7 +70,7 @@ class OracleEngine:
         cbn = _np(cb)
         return torch.from_numpy(oracle.pq_encode(np.ascontiguousarray(_np(x)), cbn, metric, nbits=4 if cbn.shape[1] == 16 else 8))
 
-    def ivfpq_encode(self, x, cent, cb, metric="l2"):
+    def ivfpq_encode(self, x, cent, cb, metric="l2", want_loss=True):
         xn = np.ascontiguousarray(_np(x))
         cbn = _np(cb)
         oi = oracle.build_index(xn, _np(cent), cbn, metric, nbits=4 if cbn.shape[1] == 16 else 8)

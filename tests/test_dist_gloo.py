@@ -39,6 +39,12 @@ class OracleEngine:
         buf = torch.from_numpy(np.concatenate([sums.ravel(), counts]))
         return buf, torch.from_numpy(losses), torch.from_numpy(radius)
 
+    def kmeans_split(self, x, rows, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, seed=0, metric="l2"):
+        import oracle
+        xn = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        return oracle.kmeans_split(np.ascontiguousarray(xn), rows, k, max_iters=max_iters, tol=tol, balance_factor_scaled=balance_factor_scaled,
+                                   seed=seed, metric=metric)
+
     def kmeans_finalize(self, buf, k, d):
         b = buf.numpy()
         sums = b[: k * d].reshape(k, d).copy(); counts = b[k * d:]
@@ -253,7 +259,7 @@ class OracleBuildEngine:
         cb, it = oracle.pq_train(np.ascontiguousarray(self._np(r)), m, nbits=nbits, max_iters=max_iters, sample_rate=sample_rate, seed=seed)
         return torch.from_numpy(cb), it.astype(np.uint32)
 
-    def ivfpq_encode(self, x, cent, cb, metric="l2"):
+    def ivfpq_encode(self, x, cent, cb, metric="l2", want_loss=True):
         import oracle
         xn = np.ascontiguousarray(self._np(x))
         nb = 4 if cb.shape[1] == 16 else 8
@@ -432,3 +438,57 @@ def test_rowsharded_build_replica_and_list_shards(world, mode):
     for r in range(1, world):
         assert (got[r]["cent"].view(np.uint32) == got[0]["cent"].view(np.uint32)).all()
         assert (got[r]["cb"].view(np.uint32) == got[0]["cb"].view(np.uint32)).all()
+
+
+# ---- hierarchical k-means with its splits spread over the ranks (lance_amd/dist.py: train_kmeans_hierarchical_sharded) ----------------
+def _hier_data(f16=False):
+    rng = np.random.default_rng(23)
+    c = rng.standard_normal((40, 8)) * 4
+    x = (c[rng.integers(0, 40, 9000)] + rng.standard_normal((9000, 8))).astype(f32)
+    x[100:140] = x[100]                     # forty identical rows: a cluster that cannot be split (the `finalized` arm)
+    return x.astype(np.float16) if f16 else x
+
+
+def _hier_worker(rank, world, port, f16, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    try:
+        from lance_amd import dist as ld
+        x = _hier_data(f16)
+        st = {}
+        c = ld.train_kmeans_hierarchical_sharded(OracleEngine(), torch.from_numpy(x), 700, max_iters=12, balance_factor=1.0, seed=5, stats=st)
+        out[rank] = (c.numpy().copy(), st)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_hierarchical_kmeans_spread_over_ranks_is_the_single_trainer_bit_for_bit(f16):
+    """k = 700 > 256: the reference trains hierarchically (kmeans.rs:746-1003).  The multi-GPU trainer computes the splits of the largest
+    clusters on different ranks and applies them in the reference's order: centroids equal to the oracle's single-process trainer bit
+    for bit -- one process with speculation windows 1 (the plain loop), 4 and 9, and gloo worlds of 2 and 3 (sharded
+    training for nlist > 4096 / north_star config 5; a row-sharded Lloyd loop would only agree to round-off)."""
+    import oracle
+    sys.path.insert(0, ROOT)
+    from lance_amd import dist as ld
+    x = _hier_data(f16)
+    want = oracle.kmeans_train_hierarchical(x, 700, max_iters=12, balance_factor_scaled=f32(1.0) / f32(x.shape[0]), seed=5)
+    assert want.shape[0] > 600
+    wasted = 0
+    for window in (1, 4, 9):
+        st = {}
+        got = ld.train_kmeans_hierarchical_sharded(OracleEngine(), torch.from_numpy(x), 700, max_iters=12, balance_factor=1.0, seed=5, window=window,
+                                                   stats=st).numpy()
+        assert got.shape == want.shape and (got.view(np.uint32) == np.ascontiguousarray(want, f32).view(np.uint32)).all(), window
+        assert st["splits_thrown_away"] == 0 if window == 1 else True
+        wasted += st["splits_thrown_away"]
+        assert st["rounds"] <= st["splits_applied"]
+    for world in (2, 3):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_hier_worker, args=(world, 29640 + world + (10 if f16 else 0), f16, out), nprocs=world, join=True)
+        for r in range(world):
+            c, st = out[r]
+            assert c.shape == want.shape and (c.view(np.uint32) == np.ascontiguousarray(want, f32).view(np.uint32)).all(), (world, r)
+            assert st["world"] == world and st["rounds"] < st["splits_applied"]      # several splits per round: the ranks did work side by side

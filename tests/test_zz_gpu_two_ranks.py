@@ -136,3 +136,46 @@ def test_bench_two_ranks_on_one_gpu_end_to_end():
     assert mg["list_sharded_qps_strong_scaling"] > 0 and j["strong_scaling_list_sharded_qps"] == mg["list_sharded_qps_strong_scaling"]
     assert mg["rows_per_rank"] == 100000
     assert j["recall_at_10"] > 0.85
+
+
+def test_bench_eight_ranks_on_one_gpu_uneven_blocks_and_lists():
+    """`python bench.py --gpus 8` -- the driver's scaling command -- with all eight ranks on the one GPU (gloo through host memory): 200,003
+    rows (blocks of 25,001 and a short last one), 250 IVF lists (250 % 8 = 2: the list -> rank map is uneven).  The line's contract, and
+    the list-sharded search -- its local half now ONE scan per rank (lance_hip_ivfpq_search_candidates) -- equal to the replica's."""
+    env = dict(os.environ, LANCE_BENCH_ONE_GPU="1", LANCE_BENCH_BACKEND="gloo", MASTER_PORT=str(_free_port()))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--n", "200003", "--nlist", "250",
+                        "--nq", "2000", "--no-pmc", "--no-cpu-baseline", "--no-grid"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["nlist"] == 250
+    mg = j["multi_gpu"]
+    assert mg["rccl_ranks"] == 8 and mg["rows_per_rank"] == 25001
+    assert mg["list_sharded_equals_replica"] is True
+    assert mg["list_sharded_qps_strong_scaling"] > 0
+    assert "round-off" in mg["ivf_training_sharded_is"]
+    assert j["recall_at_10"] > 0.8
+
+
+def test_hierarchical_training_spread_over_ranks_equals_the_single_gpu_trainer(engine, oracle):
+    """lance_hip_kmeans_split as the unit of work of lance_amd.dist.train_kmeans_hierarchical_sharded (one process here: windows of 1 and
+    6 speculated splits): centroids equal to lance_hip_kmeans_train's hierarchical path and to the oracle's, bit for bit -- f32, f16
+    (half-precision M-step) and int8 samples."""
+    import torch
+    from lance_amd import dist as ld
+    eng = engine.default_engine()
+    rng = np.random.default_rng(41)
+    c = rng.standard_normal((60, 32)) * 30
+    base = np.clip(np.rint(c[rng.integers(0, 60, 30000)] + rng.standard_normal((30000, 32)) * 9), -127, 127)
+    for x in (base.astype(f32), (base / 64).astype(np.float16), base.astype(np.int8)):
+        xt = torch.from_numpy(x).cuda()
+        single, _, _ = eng.kmeans_train(xt, 600, max_iters=10, balance_factor=1.0, seed=3)
+        xo = x.astype(f32) if x.dtype == np.int8 else x
+        want = oracle.kmeans_train_hierarchical(xo, 600, max_iters=10, balance_factor_scaled=f32(1.0) / f32(x.shape[0]), seed=3)
+        assert (single.float().cpu().numpy().view(np.uint32) == np.ascontiguousarray(want, f32).view(np.uint32)).all()
+        for window in (1, 6):
+            st = {}
+            got = ld.train_kmeans_hierarchical_sharded(eng, xt, 600, max_iters=10, balance_factor=1.0, seed=3, window=window, stats=st)
+            assert got.shape[0] == want.shape[0]
+            assert (got.cpu().numpy().view(np.uint32) == np.ascontiguousarray(want, f32).view(np.uint32)).all(), (x.dtype, window, st)
