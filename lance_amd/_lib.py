@@ -36,7 +36,8 @@ SYMBOLS = [
     "lance_hip_index_load", "lance_hip_index_load_lists", "lance_hip_index_save", "lance_hip_file_read_column",
     "lance_hip_timing_enable", "lance_hip_timing_query", "lance_hip_ubench", "lance_hip_merge_topk",
     "lance_hip_shuffle_buffer_write",
-    "lance_hip_comm_unique_id", "lance_hip_comm_create", "lance_hip_comm_adopt", "lance_hip_comm_from_callback", "lance_hip_comm_destroy", "lance_hip_kmeans_train_sharded",
+    "lance_hip_comm_unique_id", "lance_hip_comm_create", "lance_hip_comm_adopt", "lance_hip_comm_from_callback", "lance_hip_comm_destroy", "lance_hip_kmeans_train_sharded", "lance_hip_kmeans_train_sharded_x",
+    "lance_hip_kmeans_shard_estep_x",
 ]
 
 
@@ -101,6 +102,7 @@ def load():
         "lance_hip_kmeans_finalize": (i32, [vp, i32, vp, u32, u32, vp]),
         "lance_hip_kmeans_shard_begin": (i32, [vp, u32, f32, u64, vp, vp]),
         "lance_hip_kmeans_shard_estep": (i32, [vp, i32, vp, u64, u32, vp, u32, vp, vp, vp, vp, vp]),
+        "lance_hip_kmeans_shard_estep_x": (i32, [vp, i32, i32, vp, u64, u32, vp, u32, vp, vp, vp, vp, vp]),
         "lance_hip_kmeans_shard_update": (i32, [vp, vp, vp, vp, vp, vp, vp, u32, u32, u64, f32, f64, u32]),
         "lance_hip_kmeans_shard_end": (i32, [vp, vp, C.POINTER(f64), C.POINTER(u32), C.POINTER(i32)]),
         "lance_hip_kmeans_init_indices": (i32, [u64, u32, u64, vp]),
@@ -150,6 +152,7 @@ def load():
         "lance_hip_comm_from_callback": (i32, [ALLREDUCE_FN, vp, i32, i32, C.POINTER(vp)]),
         "lance_hip_comm_destroy": (None, [vp]),
         "lance_hip_kmeans_train_sharded": (i32, [vp, vp, i32, vp, u64, u32, u32, u64, u32, f64, f32, u64, vp, C.POINTER(f64), C.POINTER(u32)]),
+        "lance_hip_kmeans_train_sharded_x": (i32, [vp, vp, i32, i32, vp, u64, u32, u32, u64, u32, f64, f32, u64, vp, C.POINTER(f64), C.POINTER(u32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

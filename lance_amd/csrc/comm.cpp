@@ -29,6 +29,7 @@ enum { RCCL_F32 = 7, RCCL_F64 = 8 };                          // ncclDataType_t
 
 struct RcclApi {
   void *lib = nullptr;
+  bool resident = false;      // the process already maps an RCCL (torch's): its symbols are resolved through RTLD_DEFAULT
   int (*GetUniqueId)(rccl_unique_id *) = nullptr;
   int (*CommInitRank)(rccl_comm_t *, int, rccl_unique_id, int) = nullptr;
   int (*CommDestroy)(rccl_comm_t) = nullptr;
@@ -41,23 +42,27 @@ RcclApi &rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    if (dlsym(RTLD_DEFAULT, "ncclAllReduce") && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) api.lib = RTLD_DEFAULT;
-    if (!api.lib)
+    // An RCCL the process already exposes must answer (an adopted ncclComm_t belongs to THAT library, whatever its file is called or
+    // however it was linked in).  RTLD_DEFAULT is a null pointer on glibc: the hit is kept in its own flag, not in `lib`.
+    api.resident = dlsym(RTLD_DEFAULT, "ncclAllReduce") && dlsym(RTLD_DEFAULT, "ncclCommInitRank");
+    if (!api.resident) {
       for (const char *name : {"librccl.so.1", "librccl.so"}) {
         api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         if (api.lib) break;
       }
-    if (!api.lib)
-      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (api.lib) break;
-      }
-    if (!api.lib) return;
-    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
-    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
-    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
-    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
-    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      if (!api.lib)
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+          api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+          if (api.lib) break;
+        }
+      if (!api.lib) return;
+    }
+    void *from = api.resident ? RTLD_DEFAULT : api.lib;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(from, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(from, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(from, "ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(from, "ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(from, "ncclGetErrorString"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
   });
   return api;
@@ -150,37 +155,52 @@ void lance_hip_comm_destroy(lance_hip_comm *comm) {
   delete comm;
 }
 
-int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int metric, const float *x_local, uint64_t n_local, uint32_t d,
-                                   uint32_t k, uint64_t n_total, uint32_t max_iters, double tol, float balance_factor, uint64_t seed,
-                                   float *centroids, double *loss_out_host, uint32_t *iters_out_host) {
+int lance_hip_kmeans_train_sharded_x(lance_hip_ctx *ctx, lance_hip_comm *comm, int dtype, int metric, const void *x_local, uint64_t n_local, uint32_t d,
+                                     uint32_t k, uint64_t n_total, uint32_t max_iters, double tol, float balance_factor, uint64_t seed,
+                                     float *centroids, double *loss_out_host, uint32_t *iters_out_host) {
   lh::CtxLock _ctx_lock(ctx);
+  // Argument errors that every rank sees alike may return at once ...
   LH_REQUIRE(ctx && centroids && (n_local == 0 || x_local), "kmeans_train_sharded: NULL argument");
   LH_REQUIRE(d > 0 && k > 0 && n_total >= k && n_total >= n_local, "kmeans_train_sharded: need n_total >= k and n_total >= n_local");
   LH_REQUIRE(metric == LANCE_HIP_L2 || metric == LANCE_HIP_DOT || metric == LANCE_HIP_COSINE, "kmeans_train_sharded: bad metric %d", metric);
-  // Everything that can fail on ONE rank only is checked before the first collective: a rank that returned early would leave its
-  // peers waiting in the all-reduce for ever.  The limits are those of lance_hip_kmeans_shard_estep / _update.
-  LH_REQUIRE(k <= 4096, "kmeans_train_sharded: k=%u > 4096 is not supported by the sharded E-step (train hierarchically per rank)", k);
-  LH_REQUIRE(n_local < (1ull << 32), "kmeans_train_sharded: %llu rows on one rank (limit 2^32 - 1)", (unsigned long long)n_local);
+  LH_REQUIRE(k <= 4096, "kmeans_train_sharded: k=%u > 4096 is not a flat Lloyd problem (the reference trains k > 256 hierarchically: "
+             "lance_hip_kmeans_split is the unit of work of the multi-GPU hierarchical trainer)", k);
   LH_REQUIRE(!comm || comm->fn || rccl().ok, "RCCL is not available (librccl.so could not be loaded)");
+  LH_TRY(lh::check_dtype(dtype, "kmeans_train_sharded"));
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  void *state = ctx->scratch("shard.state", 256);
-  float *bias = ctx->scratch_t<float>("shard.bias", k);
-  float *buf = ctx->scratch_t<float>("shard.buf", (size_t)k * d + k);
-  double *losses = ctx->scratch_t<double>("shard.losses", k);
-  float *radius = ctx->scratch_t<float>("shard.radius", k);
+  // ... everything that can fail on ONE rank only -- its row count, its scratch, the f32 copy of an f16 / int8 shard, its first E-step --
+  // is folded into one status word that the ranks exchange BEFORE the first all-reduce of the loop: a rank that returned early would
+  // leave its peers waiting in that all-reduce for ever.  The status slot itself is the one allocation that cannot be.
   float *status = ctx->scratch_t<float>("shard.status", 4);
-  if (!state || !bias || !buf || !losses || !radius || !status) return LANCE_HIP_ENOMEM;
+  if (!status) return LANCE_HIP_ENOMEM;
+  int pre = LANCE_HIP_OK;
+  void *state = nullptr;
+  float *bias = nullptr, *buf = nullptr, *radius = nullptr;
+  double *losses = nullptr;
+  const float *xf = nullptr;
   const float bf_scaled = balance_factor / (float)n_total;      // train_kmeans :1344: params.balance_factor /= data.len()
-  LH_TRY(lance_hip_kmeans_shard_begin(ctx, k, bf_scaled, seed, state, bias));
+  if (n_local >= (1ull << 32)) {
+    lh::set_error("kmeans_train_sharded: %llu rows on one rank (limit 2^32 - 1)", (unsigned long long)n_local);
+    pre = LANCE_HIP_EINVAL;
+  }
+  if (pre == LANCE_HIP_OK) {
+    state = ctx->scratch("shard.state", 256);
+    bias = ctx->scratch_t<float>("shard.bias", k);
+    buf = ctx->scratch_t<float>("shard.buf", (size_t)k * d + k);
+    losses = ctx->scratch_t<double>("shard.losses", k);
+    radius = ctx->scratch_t<float>("shard.radius", k);
+    if (!state || !bias || !buf || !losses || !radius) pre = LANCE_HIP_ENOMEM;
+  }
+  // f16 / int8 shards: widened once, here (exact; the flat sharded loop accumulates in f32 -- the M-step of an f16 column on ONE GPU
+  // rounds like half::f16, one more reason the two agree to round-off only)
+  if (pre == LANCE_HIP_OK) pre = lh::as_f32(ctx, dtype, x_local, (size_t)n_local * d, "shard.x", &xf);
+  if (pre == LANCE_HIP_OK) pre = lance_hip_kmeans_shard_begin(ctx, k, bf_scaled, seed, state, bias);
   double loss = 0.0;
   uint32_t iters = 0;
   int active = 1;
   for (uint32_t it = 1; it <= max_iters; ++it) {
-    const int erc = lance_hip_kmeans_shard_estep(ctx, metric, x_local, n_local, d, centroids, k, bias, state, buf, losses, radius);
+    const int erc = pre != LANCE_HIP_OK ? pre : lance_hip_kmeans_shard_estep(ctx, metric, xf, n_local, d, centroids, k, bias, state, buf, losses, radius);
     if (comm && it == 1) {
-      // The first E-step sizes this rank's scratch arena (row-count sized slots): the only place where ONE rank can fail while its
-      // peers go on.  Before anybody enters the iteration's all-reduces the ranks exchange one word -- max over "my E-step failed" --
-      // and all of them leave together (later iterations allocate nothing: same sizes).
       char saved[1024];
       snprintf(saved, sizeof(saved), "%s", lance_hip_last_error());
       const float mine = erc != LANCE_HIP_OK ? 1.0f : 0.0f;
@@ -190,7 +210,7 @@ int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int
       LH_CHECK_HIP(hipMemcpyAsync(&any, status, 4, hipMemcpyDeviceToHost, ctx->stream));
       LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
       if (erc != LANCE_HIP_OK) { lh::set_error("%s", saved); return erc; }
-      if (any != 0.0f) { lh::set_error("kmeans_train_sharded: the first E-step failed on another rank (this rank stops with it)"); return LANCE_HIP_ERUNTIME; }
+      if (any != 0.0f) { lh::set_error("kmeans_train_sharded: set-up or the first E-step failed on another rank (this rank stops with it)"); return LANCE_HIP_ERUNTIME; }
     } else if (erc != LANCE_HIP_OK) {
       return erc;
     }
@@ -209,6 +229,13 @@ int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int
   if (loss_out_host) *loss_out_host = loss;
   if (iters_out_host) *iters_out_host = iters;
   return LANCE_HIP_OK;
+}
+
+int lance_hip_kmeans_train_sharded(lance_hip_ctx *ctx, lance_hip_comm *comm, int metric, const float *x_local, uint64_t n_local, uint32_t d,
+                                   uint32_t k, uint64_t n_total, uint32_t max_iters, double tol, float balance_factor, uint64_t seed,
+                                   float *centroids, double *loss_out_host, uint32_t *iters_out_host) {
+  return lance_hip_kmeans_train_sharded_x(ctx, comm, LANCE_HIP_F32, metric, x_local, n_local, d, k, n_total, max_iters, tol, balance_factor, seed, centroids,
+                                          loss_out_host, iters_out_host);
 }
 
 }  // extern "C"

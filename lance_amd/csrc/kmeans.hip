@@ -932,6 +932,21 @@ int lance_hip_kmeans_shard_begin(lance_hip_ctx *ctx, uint32_t k, float balance_f
 }
 
 int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
+                                 const float *bias, const void *state, float *buf, double *losses, float *radius);
+// the shard in the column's own element type: f16 / int8 rows are widened (exactly) into the context's scratch on every call -- a caller
+// that iterates keeps its own f32 copy and uses the f32 entry point (lance_hip_kmeans_train_sharded_x widens once for the whole loop)
+int lance_hip_kmeans_shard_estep_x(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
+                                   const float *bias, const void *state, float *buf, double *losses, float *radius) {
+  lh::CtxLock _ctx_lock(ctx);
+  LH_REQUIRE(ctx && (n == 0 || x), "kmeans_shard_estep: NULL argument");
+  LH_TRY(check_dtype(dtype, "kmeans_shard_estep"));
+  LH_CHECK_HIP(hipSetDevice(ctx->device));
+  const float *xf;
+  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "shard.x", &xf));
+  return lance_hip_kmeans_shard_estep(ctx, metric, xf, n, d, centroids, k, bias, state, buf, losses, radius);
+}
+
+int lance_hip_kmeans_shard_estep(lance_hip_ctx *ctx, int metric, const float *x, uint64_t n, uint32_t d, const float *centroids, uint32_t k,
                                  const float *bias, const void *state, float *buf, double *losses, float *radius) {
   lh::CtxLock _ctx_lock(ctx);
   LH_REQUIRE(ctx && centroids && buf && losses && radius && state && (n == 0 || x), "kmeans_shard_estep: NULL argument");

@@ -241,26 +241,38 @@ class Engine:
         """lance_hip_comm_from_callback: the sharded trainer's exchanges through a host transport.  fn(buf_ptr, count, dtype, op,
         stream_ptr) -> 0 reduces `count` elements (dtype 0 = f32, 1 = f64; op 0 = sum, 1 = max) at DEVICE address buf_ptr in place
         across the ranks.  The ctypes thunk is kept alive on the returned handle's engine."""
-        thunk = _lib.ALLREDUCE_FN(lambda user, buf, count, dtype, op, stream: int(fn(buf, count, dtype, op, stream)))
+        def guarded(user, buf, count, dtype, op, stream):
+            # an exception must reach the trainer as a failed exchange: ctypes would print the traceback and hand 0 ("reduced") to C,
+            # and the ranks would go on with unreduced buffers (ADVICE r05)
+            try:
+                return int(fn(buf, count, dtype, op, stream))
+            except BaseException:
+                import traceback
+                traceback.print_exc()
+                return 1
+        thunk = _lib.ALLREDUCE_FN(guarded)
         h = C.c_void_p()
         check(self.lib.lance_hip_comm_from_callback(thunk, None, nranks, rank, C.byref(h)))
-        self._comm_thunks = getattr(self, "_comm_thunks", []) + [thunk]
+        if not hasattr(self, "_comm_thunks"):
+            self._comm_thunks = {}
+        self._comm_thunks[h.value] = thunk       # alive exactly as long as the communicator
         return h
 
     def comm_destroy(self, comm):
         self.lib.lance_hip_comm_destroy(comm)
+        getattr(self, "_comm_thunks", {}).pop(getattr(comm, "value", comm), None)
 
     def kmeans_train_sharded(self, comm, x_local, init_centroids, n_total, max_iters=50, tol=1e-4, balance_factor=0.0, seed=0, metric="l2"):
         """lance_hip_kmeans_train_sharded: rows sharded over the ranks of `comm` (None: single process), one fused all-reduce per
         Lloyd iteration inside the library.  init_centroids: identical on every rank.  -> (centroids, loss, iterations)"""
-        x = to_device(x_local, torch.float32)
+        x, dt = _vec(x_local)                # the shard in the column's own element type (f16 / int8 are widened inside the library, once)
         cent = to_device(init_centroids, torch.float32).clone().contiguous()
         n, d = x.shape
         k = cent.shape[0]
         loss = C.c_double(0); iters = C.c_uint32(0)
         torch.cuda.synchronize()
-        check(self.lib.lance_hip_kmeans_train_sharded(self.h, comm, METRICS[metric], _ptr(x), n, d, k, int(n_total), max_iters, tol, balance_factor,
-                                                      seed, _ptr(cent), C.byref(loss), C.byref(iters)))
+        check(self.lib.lance_hip_kmeans_train_sharded_x(self.h, comm, dt, METRICS[metric], _ptr(x), n, d, k, int(n_total), max_iters, tol, balance_factor,
+                                                        seed, _ptr(cent), C.byref(loss), C.byref(iters)))
         return cent, loss.value, iters.value
 
     def pq_train(self, residuals, m, nbits=8, max_iters=50, sample_rate=256, seed=0):
