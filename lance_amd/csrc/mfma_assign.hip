@@ -373,6 +373,7 @@ static bool ma_launch_ks(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dt
 // exact re-check (reference arithmetic, ma_finalize_wide_kernel / ma_recompute_kernel) are unchanged, so ids and distances
 // stay bit-equal to the exact kernels.  E = 2^-12 (|x|^2 + max|c|^2 + max|bias|): the split error is as above, the f32
 // accumulation over up to 4096 / 16 x 3 MFMA steps adds < 2^-15 |x||c|.
+typedef _Float16 ma_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int MW_ROWS = 128, MW_CT = 128, MW_KC = 32, MW_LS = MW_KC + 8;   // LDS row stride in bf16 elements (80 bytes)
 
 template <typename TX>
@@ -398,7 +399,14 @@ __global__ __launch_bounds__(256) void ma_split_rows_kernel(const TX *__restrict
   if (lane == 0) xn2[row] = s;
 }
 
-template <int METRIC, bool SUR = false>
+// F16 (round 6; unit-length rows: cosine indices): ONE binary16 plane per operand, scaled by 2^14 (rows) / 2^14 (centroids, |c_i| <= 2 checked by
+// the launcher), ONE v_mfma_f32_32x32x16_f16 per fragment pair instead of three bf16 products.  Error of the surrogate: both roundings
+// <= 2^-11 relative per element (binary16 subnormals -- |x_i| < 2^-28 -- are an absolute 2^-39 each), so |fl(x).fl(c) - x.c| <= 2^-10 (1 + 2^-12)
+// |x||c| (Cauchy-Schwarz), the f32 accumulation of d <= 4096 exact products <= d 2^-24 |x||c| (2^-13.4 at d = 1536): s = |c|^2 - 2 x.c is
+// within 2 (2^-10 + 2^-12) |x||c| <= 2^-9.7 (|x|^2 + |c|^2) / 2 ... E = 2^-9.5 (|x|^2 + max|c|^2) covers it with the f32 error of |c|^2
+// and of the reference's own distance (<= 2^-12 of their values).  5.7 x the margin of the bf16 x 3 route, a third of its matrix work:
+// more rows take the two- / three-candidate exact check (cheap), more take the recompute list (not cheap: measured per data set).
+template <int METRIC, bool SUR = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   __shared__ __attribute__((aligned(16))) uint16_t abuf[2][MW_CT][MW_LS];     // centroid chunk: hi / lo planes   20 KB
   __shared__ __attribute__((aligned(16))) uint16_t bbuf[2][MW_ROWS][MW_LS];   // row chunk: hi / lo planes        20 KB
@@ -426,11 +434,11 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
       ga[0][u] = ga[1][u] = gb[0][u] = gb[1][u] = make_uint4(0, 0, 0, 0);
       if (c0 + r < p.k) {
         ga[0][u] = *reinterpret_cast<const uint4 *>(p.chi + (int64_t)(c0 + r) * dp + k0 + lc * 8);
-        ga[1][u] = *reinterpret_cast<const uint4 *>(p.clo + (int64_t)(c0 + r) * dp + k0 + lc * 8);
+        if constexpr (!F16) ga[1][u] = *reinterpret_cast<const uint4 *>(p.clo + (int64_t)(c0 + r) * dp + k0 + lc * 8);
       }
       if (row0 + r < p.n) {
         gb[0][u] = *reinterpret_cast<const uint4 *>(p.xhi + (row0 + r) * dp + k0 + lc * 8);
-        gb[1][u] = *reinterpret_cast<const uint4 *>(p.xlo + (row0 + r) * dp + k0 + lc * 8);
+        if constexpr (!F16) gb[1][u] = *reinterpret_cast<const uint4 *>(p.xlo + (row0 + r) * dp + k0 + lc * 8);
       }
     }
     if (k0 == 0 && threadIdx.x < MW_CT) {
@@ -454,15 +462,25 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
     for (int u = 0; u < 2; ++u) {
       const int r = lr0 + 64 * u;
       *reinterpret_cast<uint4 *>(&abuf[0][r][lc * 8]) = ga[0][u];
-      *reinterpret_cast<uint4 *>(&abuf[1][r][lc * 8]) = ga[1][u];
       *reinterpret_cast<uint4 *>(&bbuf[0][r][lc * 8]) = gb[0][u];
-      *reinterpret_cast<uint4 *>(&bbuf[1][r][lc * 8]) = gb[1][u];
+      if constexpr (!F16) {
+        *reinterpret_cast<uint4 *>(&abuf[1][r][lc * 8]) = ga[1][u];
+        *reinterpret_cast<uint4 *>(&bbuf[1][r][lc * 8]) = gb[1][u];
+      }
     }
     if (kc == 0 && threadIdx.x < MW_CT) { cns[0][threadIdx.x] = gcn; cns[1][threadIdx.x] = gbias; }
     __syncthreads();
     if (it + 1 < total) fetch(it + 1);
 #pragma unroll
     for (int s = 0; s < MW_KC / 16; ++s) {
+      if constexpr (F16) {
+        const ma_f16x8 xh = *reinterpret_cast<const ma_f16x8 *>(&bbuf[0][wave * 32 + j][s * 16 + g * 8]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const ma_f16x8 ah = *reinterpret_cast<const ma_f16x8 *>(&abuf[0][b * 32 + j][s * 16 + g * 8]);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[b], 0, 0, 0);
+        }
+      } else {
       const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(&bbuf[0][wave * 32 + j][s * 16 + g * 8]);
       const bf16x8 xl = *reinterpret_cast<const bf16x8 *>(&bbuf[1][wave * 32 + j][s * 16 + g * 8]);
 #pragma unroll
@@ -472,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[b], 0, 0, 0);
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[b], 0, 0, 0);
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[b], 0, 0, 0);
+      }
       }
     }
     if (kc != nchunks - 1) continue;
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
         const f4 cn4 = *reinterpret_cast<const f4 *>(&cns[0][ib]), bi4 = *reinterpret_cast<const f4 *>(&cns[1][ib]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float dot = acc[b][vq * 4 + e];
+          const float dot = F16 ? acc[b][vq * 4 + e] * 3.7252902984619140625e-9f : acc[b][vq * 4 + e];      // F16: both planes carry 2^14
           float v = METRIC == METRIC_DOT ? -dot : __builtin_fmaf(-2.0f, dot, cn4[e]);
           v += bi4[e];
           if (c0 + ib + e >= p.k) v = INFINITY;
@@ -512,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
     const int64_t srow = row0 + wave * 32 + j;
     if (g == 0 && srow < p.n && blockIdx.y == 0) {
       const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
-      p.e2[srow] = 2.0f * 0.000244140625f * (p.xn2[srow] + cmax2 + bmax);   // 2E, E = 2^-12 (|x|^2 + max|c|^2 + max|bias|)
+      p.e2[srow] = 2.0f * (F16 ? 0.001381067932f : 0.000244140625f) * (p.xn2[srow] + cmax2 + bmax);   // 2E, E = 2^-12 (F16: 2^-9.5) (|x|^2 + max|c|^2 + max|bias|)
     }
     return;
   }
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   const int64_t row = row0 + wave * 32 + j;
   if (g == 0 && row < p.n) {
     const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
-    const float E2 = 2.0f * 0.000244140625f * (p.xn2[row] + cmax2 + bmax);   // 2E, E = 2^-12 (|x|^2 + max|c|^2 + max|bias|)
+    const float E2 = 2.0f * (F16 ? 0.001381067932f : 0.000244140625f) * (p.xn2[row] + cmax2 + bmax);   // 2E, E = 2^-12 (F16: 2^-9.5) (|x|^2 + max|c|^2 + max|bias|)
     uint8_t cl = 3;
     if (tp.m2 - tp.m1 > E2) cl = 0;
     else if (tp.m3 - tp.m1 > E2) cl = 1;

@@ -586,6 +586,13 @@ class DeviceIndex:
                                                      codes.ctypes.data_as(C.c_void_p), rid.ctypes.data_as(C.c_void_p)))
         return offs, codes, rid
 
+    def part_offsets(self):
+        """-> part_offsets u32[nlist+1] alone (no copy of the codes or row ids to the host: at a billion rows those are 40 GB)"""
+        inf = self.info()
+        offs = np.empty(inf["nlist"] + 1, np.uint32)
+        check(self.engine.lib.lance_hip_index_export(self.engine.h, self.h, offs.ctypes.data_as(C.c_void_p), None, None))
+        return offs
+
     MAX_PAIRS_PER_CALL = 1_500_000      # (query, probe) pairs per library call of a synchronous search (256 survivor slots x 8 B each)
 
     def search(self, q, k, nprobes, refine_factor=0, out=None, sync=True, engine=None):
