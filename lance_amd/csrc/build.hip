@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict_
 // reading its own row (normalize_kernel) every load instruction touches 64 cache lines: 44 ms per 1M x 1536 against the
 // 18 GB / 4 TB/s = 4.5 ms this layout moves.
 template <bool F16>
-__global__ __launch_bounds__(256) void normalize_tiled_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void normalize_tiled_kernel(const float *__restrict__ x, int64_t n, int d, float *__restrict__ out,
+                                                              uint16_t *__restrict__ plane16 = nullptr, int dp = 0, float *__restrict__ n2 = nullptr) {
   __shared__ float tile[64][65];
   __shared__ float norms[64];
   const int64_t row0 = (int64_t)blockIdx.x * 64;
@@ -98,9 +99,28 @@ __global__ __launch_bounds__(256) void normalize_tiled_kernel(const float *__res
         float qv = x[(row0 + r) * d + c0 + col] / norms[r];
         if (F16) qv = __half2float(__float2half_rn(qv));
         out[(row0 + r) * d + c0 + col] = qv;
+        // |qv| <= 1 (+ an ulp): x 2^14 is a normal binary16 down to |qv| = 2^-28
+        if (plane16) plane16[(row0 + r) * dp + c0 + col] = __half_as_ushort(__float2half_rn(qv * 16384.0f));
       }
     }
   }
+  if (plane16) {
+    for (int i = tid; i < 64 * (dp - d); i += 256) {      // the plane's padding columns
+      const int r = i / (dp - d), c = d + i % (dp - d);
+      if (row0 + r < n) plane16[(row0 + r) * dp + c] = 0;
+    }
+    // a unit vector's squared norm, as an upper bound for the coarse quantiser's margin; a row without a direction (zero / non-finite) has NaN
+    if (tid < 64 && row0 + tid < n) n2[row0 + tid] = (norms[tid] > 0.0f && norms[tid] < INFINITY) ? 1.0001f : __uint_as_float(0x7FC00000u);
+  }
+}
+
+int launch_normalize_planes(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16, uint16_t *plane16, int dp, float *n2) {
+  if (n <= 0) return LANCE_HIP_OK;
+  LH_REQUIRE(d >= 64 && dp >= d && plane16 && n2, "normalize: the plane-writing form needs d >= 64");
+  if (f16) hipLaunchKernelGGL(normalize_tiled_kernel<true>, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, ctx->stream, x, n, d, out, plane16, dp, n2);
+  else hipLaunchKernelGGL(normalize_tiled_kernel<false>, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, ctx->stream, x, n, d, out, plane16, dp, n2);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
 }
 
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16) {
@@ -419,7 +439,23 @@ int lance_hip_ivfpq_encode(lance_hip_ctx *ctx, int dtype, int metric, const void
   if (metric == LANCE_HIP_COSINE) {
     float *xn = ctx->scratch_t<float>("encode.norm", (size_t)n * d);
     if (!xn) return LANCE_HIP_ENOMEM;
-    LH_TRY(launch_normalize(ctx, xs, (int64_t)n, (int)d, xn, f16));
+    // long rows: the normalise kernel also leaves the unit rows as a binary16 plane for the K-tiled coarse quantiser (one f16 matrix product
+    // instead of three bf16 ones + a separate pass that splits the rows: mfma_assign.hip)
+    static const bool no_f16 = getenv("LANCE_HIP_NO_MFMA_F16") != nullptr;
+    const int dp16 = ((int)d + 31) / 32 * 32;
+    uint16_t *plane16 = nullptr;
+    float *plane_n2 = nullptr;
+    if (!no_f16 && d > 128 && d <= 4096 && n >= 2048 && nlist >= 64 && (uint64_t)n * dp16 * 2 <= (16ull << 30)) {
+      plane16 = static_cast<uint16_t *>(ctx->scratch_exact("encode.plane16", (size_t)n * dp16 * 2));
+      plane_n2 = plane16 ? ctx->scratch_t<float>("encode.plane_n2", (size_t)n) : nullptr;
+      if (!plane_n2) plane16 = nullptr;
+    }
+    if (plane16) {
+      LH_TRY(launch_normalize_planes(ctx, xs, (int64_t)n, (int)d, xn, f16, plane16, dp16, plane_n2));
+      pa.x_plane16 = plane16; pa.x_plane_n2 = plane_n2; pa.x_plane_dp = dp16;
+    } else {
+      LH_TRY(launch_normalize(ctx, xs, (int64_t)n, (int)d, xn, f16));
+    }
     xs = xn; pa.x = xs;
     if (xform_fused_supported(LANCE_HIP_F32, LANCE_HIP_L2, (int)d, (int)m, (int)nbits, (int64_t)n, (int)nlist, xn, centf, cbf, codes, false)) {
       LH_TRY(launch_xform_fused(ctx, LANCE_HIP_F32, LANCE_HIP_L2, xn, (int64_t)n, (int)d, centf, (int)nlist, cbf, (int)m, part_ids, dists, codes, f16));

@@ -34,6 +34,12 @@ struct PairwiseArgs {
   bool x_aligned = false;
   bool cent_aligned = false;
   bool check_finite = false;  // MODE 0: rows with a non-finite element get id NONE
+  // long UNIT-LENGTH rows (cosine indices: the normalise kernel writes them): the rows once more as a binary16 plane scaled by 2^14, row stride
+  // x_plane_dp (d rounded up to 32, zero padded), and an upper bound of their squared norms (NaN for a row that has none) -- the K-tiled
+  // coarse quantiser then runs one f16 product instead of three bf16 ones (mfma_assign.hip: ma_top3_wide_kernel<.., F16>)
+  const uint16_t *x_plane16 = nullptr;
+  const float *x_plane_n2 = nullptr;
+  int x_plane_dp = 0;
   float *part_vb = nullptr;   // k-split partials (set by the launcher)
   float *part_v = nullptr;
   uint32_t *part_idx = nullptr;
@@ -148,6 +154,8 @@ bool coarse_mfma_supported(int metric, int d, uint32_t nq, uint32_t nlist, uint3
 int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t nprobes,
                          float *matrix, uint32_t *part_ids, float *dists);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16);   // f16: half-precision arithmetic on f32 containers
+// the same, and the normalised rows once more as a binary16 plane x 2^14 (stride dp = d rounded up to 32) + the squared-norm bound per row
+int launch_normalize_planes(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16, uint16_t *plane16, int dp, float *n2);
 
 // quantised 4-query filter scan + exact re-evaluation (search_q.hip), driven by ivfpq_scan_merge_pm
 int qscan_index_constants(lance_hip_ctx *ctx, lance_hip_index *ix);

@@ -47,6 +47,9 @@ struct MaArgs {
   float *sur = nullptr;        // [n][k] surrogate values
   float *e2 = nullptr;         // [n] 2E of the row (the select kernel's candidate margin)
   int tiles_per_block = 0;     // centroid tiles (narrow: MA_CT, wide: MW_CT centroids) per blockIdx.y slice
+  // second stage of the f16 route: the kernels work on a COMPACTED subset -- planes, id1..3 / cls indexed 0..n-1, row i being row row_map[i] of
+  // x / ids / dists (and of the recompute list)
+  const uint32_t *row_map = nullptr;
 };
 
 // running four smallest (values m1 <= m2 <= m3 <= m4, centroid ids of the first three)

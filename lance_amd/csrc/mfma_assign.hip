@@ -17,6 +17,7 @@
 // D[centroid][row] puts one data row per lane (two lanes per row), so the running top-4 is a per-lane register update.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include <hip/hip_fp16.h>
 
@@ -379,15 +380,16 @@ constexpr int MW_ROWS = 128, MW_CT = 128, MW_KC = 32, MW_LS = MW_KC + 8;   // LD
 template <typename TX>
 __global__ __launch_bounds__(256) void ma_split_rows_kernel(const TX *__restrict__ x, int64_t n, int64_t ldx, int d, int dp,
                                                             uint16_t *__restrict__ xhi, uint16_t *__restrict__ xlo, float *__restrict__ xn2,
-                                                            const uint8_t *__restrict__ active) {
+                                                            const uint8_t *__restrict__ active, const uint32_t *__restrict__ row_map = nullptr) {
   if (active && !active[0]) return;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
+  const int64_t src = row_map ? (int64_t)row_map[row] : row;      // (planes are written at the compact index)
   float s = 0.0f;
   for (int e = 2 * lane; e < dp; e += 128) {     // two elements per lane: one 4-byte store per plane
-    const float v0 = e < d ? ld_elem(x + row * ldx, e) : 0.0f;
-    const float v1 = e + 1 < d ? ld_elem(x + row * ldx, e + 1) : 0.0f;
+    const float v0 = e < d ? ld_elem(x + src * ldx, e) : 0.0f;
+    const float v1 = e + 1 < d ? ld_elem(x + src * ldx, e + 1) : 0.0f;
     const uint32_t h0 = bf16_rne_bits(v0), h1 = bf16_rne_bits(v1);
     const uint32_t l0 = bf16_rne_bits(v0 - bf16_bits_to_float(h0)), l1 = bf16_rne_bits(v1 - bf16_bits_to_float(h1));
     *reinterpret_cast<uint32_t *>(xhi + row * dp + e) = (h0 & 0xFFFFu) | (h1 << 16);
@@ -570,22 +572,31 @@ __global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, i = lane & 15;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int d = p.d, full = d / 16 * 16;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.n; row += nwaves) {
-    const uint8_t cl = p.cls[row];
+  for (int64_t crow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); crow < p.n; crow += nwaves) {
+    const uint8_t cl = p.cls[crow];
+    const int64_t row = p.row_map ? (int64_t)p.row_map[crow] : crow;      // the row of x / ids / dists this (compact) slot stands for
     if (cl == 3) {       // wave-uniform
       if (lane == 0) { const uint32_t slot = atomicAdd(p.fb_cnt, 1u); p.fb_rows[slot] = (uint32_t)row; }
       continue;
     }
     bool fin = true;
-    for (int e = lane; e < d; e += 64) {
-      const float v = ld_elem(static_cast<const TX *>(p.x) + row * p.ldx, e);
-      wrow[e] = v;
-      fin &= isfinite(v);
+    for (int e0 = 0; e0 < d; e0 += 512) {      // eight loads of the row in flight per lane
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u + lane;
+        v[u] = e < d ? ld_elem(static_cast<const TX *>(p.x) + row * p.ldx, e) : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u + lane;
+        if (e < d) { wrow[e] = v[u]; fin &= isfinite(v[u]); }
+      }
     }
     const bool finite = !p.check_finite || __all(fin);
     __builtin_amdgcn_wave_barrier();
     uint32_t c = LANCE_HIP_NONE;
-    if (grp <= (int)cl && grp < 3) c = grp == 0 ? p.id1[row] : (grp == 1 ? p.id2[row] : p.id3[row]);
+    if (grp <= (int)cl && grp < 3) c = grp == 0 ? p.id1[crow] : (grp == 1 ? p.id2[crow] : p.id3[crow]);
     float s = 0.0f, acc = 0.0f;
     if (c != LANCE_HIP_NONE) {
       const float *y = p.cent + (int64_t)c * d;
@@ -601,7 +612,23 @@ __global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
         }
         s = r;
       }
-      for (int ch = 0; ch < full; ch += 16) {
+      int ch = 0;
+      for (; ch + 256 <= full; ch += 256) {      // sixteen chunks' centroid loads in flight (one dependent L2 round trip per chunk made this kernel
+        float yv[16];                            // 5.5 ms per million 1536-d rows: gpurun r06u); the adds stay in chunk order
+#pragma unroll
+        for (int u = 0; u < 16; ++u) yv[u] = y[ch + 16 * u + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float xv = wrow[ch + 16 * u + i];
+          if constexpr (METRIC == METRIC_DOT) {
+            acc = acc + xv * yv[u];
+          } else {
+            const float diff = xv - yv[u];
+            acc = acc + diff * diff;
+          }
+        }
+      }
+      for (; ch < full; ch += 16) {
         const float xv = wrow[ch + i], yv = y[ch + i];
         if constexpr (METRIC == METRIC_DOT) {
           acc = acc + xv * yv;
@@ -637,6 +664,68 @@ __global__ __launch_bounds__(256) void ma_finalize_wide_kernel(MaArgs p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// centroids as one binary16 plane x 2^14 (F16 route), |c|^2, and the maxima incl. [3] = max |c_i| (the route needs it <= 2)
+__global__ __launch_bounds__(64) void ma_prep_f16_kernel(const float *__restrict__ cent, int k, int d, int dp, const float *__restrict__ bias,
+                                                         uint16_t *__restrict__ ch16, float *__restrict__ cn, uint32_t *__restrict__ maxbits) {
+  const int c = blockIdx.x;
+  float s = 0.0f, am = 0.0f;
+  bool bad = false;
+  for (int e = threadIdx.x; e < dp; e += 64) {
+    const float v = e < d ? cent[(int64_t)c * d + e] : 0.0f;
+    ch16[(int64_t)c * dp + e] = __half_as_ushort(__float2half_rn(v * 16384.0f));
+    s += v * v;
+    am = fmaxf(am, fabsf(v));
+    bad |= !(fabsf(v) < INFINITY);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); am = fmaxf(am, __shfl_xor(am, o, 64)); }
+  bad = __any(bad);
+  if (threadIdx.x == 0) {
+    cn[c] = s;
+    if (s == s) atomicMax(&maxbits[0], __float_as_uint(fabsf(s)));
+    atomicMax(&maxbits[3], bad ? 0x7F800000u : __float_as_uint(am));
+    if (bias) { const float b = fabsf(bias[c]); if (b == b) atomicMax(&maxbits[1], __float_as_uint(b)); }
+  }
+}
+
+// Unit-length long rows, two stages.  (1) The single-f16-product sweep + exact check of up to three candidates.  Its margin is 5.7 x the
+// three-term bf16 sweep's, and distances between high-dimensional unit vectors concentrate: on the C3-shaped probe a sixth of the rows
+// had four or more centroids inside it, and sending those to the all-centroids recompute kernel cost more than the sweep saved (gpurun
+// r06u: recompute 10.6 ms per million rows against 0.7).  (2) So the undecided rows are COMPACTED (their list is the row map) and go through
+// the accurate sweep -- planes split on the fly, bf16 x 3, margin 2^-12 -- and its exact check; what even that leaves undecided (true ties:
+// duplicated centroids) is recomputed against every centroid as before.  `b` = the stage-2 arguments (planes / lists sized for the subset).
+template <int METRIC, typename TX>
+static int ma_launch_wide_f16(lance_hip_ctx *ctx, const MaArgs &a, MaArgs b, uint16_t *chi, uint16_t *clo, float *cn, uint32_t *maxbits2) {
+  hipLaunchKernelGGL((ma_top3_wide_kernel<METRIC, false, true>), dim3((unsigned)cdiv(a.n, MW_ROWS)), dim3(256), 0, ctx->stream, a);
+  const unsigned fgrid = (unsigned)std::min<int64_t>(cdiv(a.n, 4), 16384);
+  hipLaunchKernelGGL((ma_finalize_wide_kernel<METRIC, TX, 16>), dim3(fgrid), dim3(256), (size_t)4 * a.d * 4, ctx->stream, a);
+  uint32_t nf = 0;
+  LH_CHECK_HIP(hipMemcpyAsync(&nf, a.fb_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (nf == 0) return LANCE_HIP_OK;
+  if (nf < 256) {      // a handful: straight to the exact kernel
+    hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX, 16>), dim3(512), dim3(256), (size_t)4 * a.d * 4, ctx->stream, a);
+    return LANCE_HIP_OK;
+  }
+  const size_t pl = (size_t)nf * a.dp;
+  uint16_t *xhi = ctx->scratch_t<uint16_t>("ma.xhi", pl), *xlo = ctx->scratch_t<uint16_t>("ma.xlo", pl);
+  float *xn2 = ctx->scratch_t<float>("ma.xn2", (size_t)nf);
+  if (!xhi || !xlo || !xn2) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(lh::memset_async(maxbits2, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(ma_prep_kernel, dim3((unsigned)a.k), dim3(64), 0, ctx->stream, a.cent, a.k, a.d, a.dp, (const float *)nullptr, chi, clo, cn, maxbits2,
+                     (const uint8_t *)nullptr);
+  hipLaunchKernelGGL((ma_split_rows_kernel<TX>), dim3((unsigned)cdiv(nf, 4)), dim3(256), 0, ctx->stream, static_cast<const TX *>(a.x), (int64_t)nf, a.ldx, a.d,
+                     a.dp, xhi, xlo, xn2, (const uint8_t *)nullptr, a.fb_rows);
+  b.n = nf; b.row_map = a.fb_rows; b.xhi = xhi; b.xlo = xlo; b.xn2 = xn2; b.chi = chi; b.clo = clo; b.cn = cn; b.maxbits = maxbits2;
+  b.fb_cnt = maxbits2 + 2;
+  hipLaunchKernelGGL((ma_top3_wide_kernel<METRIC, false, false>), dim3((unsigned)cdiv(nf, MW_ROWS)), dim3(256), 0, ctx->stream, b);
+  hipLaunchKernelGGL((ma_finalize_wide_kernel<METRIC, TX, 16>), dim3((unsigned)std::min<int64_t>(cdiv(nf, 4), 16384)), dim3(256), (size_t)4 * a.d * 4, ctx->stream, b);
+  MaArgs r = b;         // the rows the accurate sweep left undecided: by their global numbers
+  r.n = a.n; r.row_map = nullptr;
+  hipLaunchKernelGGL((ma_recompute_kernel<METRIC, TX, 16>), dim3(512), dim3(256), (size_t)4 * a.d * 4, ctx->stream, r);
+  return LANCE_HIP_OK;
 }
 
 template <int METRIC, typename TX>
@@ -710,6 +799,49 @@ int ma_recompute_launch(lance_hip_ctx *ctx, const MaArgs &a, int metric, int dty
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric) {
   const bool wide = d > 128;
   const int dp = wide ? (d + MW_KC - 1) / MW_KC * MW_KC : d;
+  // unit-length long rows that come with their binary16 plane (cosine transform: build.hip): one f16 product per fragment pair, if the
+  // centroids fit the plane's scale (|c_i| <= 2: centroids of unit vectors are inside the unit ball; anything else takes the bf16 route)
+  if (wide && p.x_plane16 && p.x_plane_n2 && p.x_plane_dp == dp && metric == METRIC_L2 && !p.bias && !p.active && p.x) {
+    uint16_t *ch16 = ctx->scratch_t<uint16_t>("ma.ch16", (size_t)p.k * dp);
+    float *cn16 = ctx->scratch_t<float>("ma.cn", (size_t)p.k);
+    uint32_t *mb = ctx->scratch_t<uint32_t>("ma.maxbits", 4);
+    uint32_t *id1 = ctx->scratch_t<uint32_t>("ma.id1", (size_t)p.n), *id2 = ctx->scratch_t<uint32_t>("ma.id2", (size_t)p.n);
+    uint32_t *id3 = ctx->scratch_t<uint32_t>("ma.id3", (size_t)p.n);
+    uint8_t *cls = ctx->scratch_t<uint8_t>("ma.cls", (size_t)p.n);
+    uint32_t *fb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)p.n);
+    if (!ch16 || !cn16 || !mb || !id1 || !id2 || !id3 || !cls || !fb_rows) return LANCE_HIP_ENOMEM;
+    LH_REQUIRE(p.n < (1ll << 32), "assign: more than 2^32 rows per call");
+    LH_CHECK_HIP(lh::memset_async(mb, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(ma_prep_f16_kernel, dim3((unsigned)p.k), dim3(64), 0, ctx->stream, p.cent, p.k, d, dp, p.bias, ch16, cn16, mb);
+    uint32_t h[4];
+    LH_CHECK_HIP(hipMemcpyAsync(h, mb, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    float cmax_el;
+    memcpy(&cmax_el, &h[3], 4);
+    if (cmax_el <= 2.0f) {
+      MaArgs a{};
+      a.x = p.x; a.n = p.n; a.ldx = p.ldx; a.d = d; a.k = p.k;
+      a.chi = ch16; a.clo = nullptr; a.cn = cn16; a.bias = nullptr; a.maxbits = mb; a.cent = p.cent;
+      a.fb_cnt = mb + 2; a.fb_rows = fb_rows; a.active = nullptr;
+      a.id1 = id1; a.id2 = id2; a.id3 = id3; a.cls = cls; a.ids = p.ids; a.dists = p.dists; a.check_finite = p.check_finite ? 1 : 0;
+      a.xhi = p.x_plane16; a.xlo = nullptr; a.xn2 = p.x_plane_n2; a.dp = dp;
+      // stage 2 (the rows stage 1 leaves undecided, compacted): its own candidate arrays and recompute list -- stage 1's list is its row map
+      uint16_t *chi2 = ctx->scratch_t<uint16_t>("ma.chi", (size_t)p.k * dp), *clo2 = ctx->scratch_t<uint16_t>("ma.clo", (size_t)p.k * dp);
+      float *cn2 = ctx->scratch_t<float>("ma.cn2", (size_t)p.k);
+      uint32_t *mb2 = ctx->scratch_t<uint32_t>("ma.maxbits2", 4);
+      uint32_t *fb2 = ctx->scratch_t<uint32_t>("ma.fb_rows2", (size_t)p.n);
+      uint32_t *jd1 = ctx->scratch_t<uint32_t>("ma.id1b", (size_t)p.n), *jd2 = ctx->scratch_t<uint32_t>("ma.id2b", (size_t)p.n);
+      uint32_t *jd3 = ctx->scratch_t<uint32_t>("ma.id3b", (size_t)p.n);
+      uint8_t *cls2 = ctx->scratch_t<uint8_t>("ma.clsb", (size_t)p.n);
+      if (!chi2 || !clo2 || !cn2 || !mb2 || !fb2 || !jd1 || !jd2 || !jd3 || !cls2) return LANCE_HIP_ENOMEM;
+      MaArgs b2 = a;
+      b2.id1 = jd1; b2.id2 = jd2; b2.id3 = jd3; b2.cls = cls2; b2.fb_rows = fb2;
+      ScopedTimer t(ctx, "ma_wide_f16");
+      LH_TRY((ma_launch_wide_f16<METRIC_L2, float>(ctx, a, b2, chi2, clo2, cn2, mb2)));
+      LH_CHECK_HIP(hipGetLastError());
+      return LANCE_HIP_OK;
+    }
+  }
   uint16_t *chi, *clo;
   float *cn;
   uint32_t *maxbits;   // [0] max |c|^2, [1] max |bias|, [2] rows left to the recompute kernel

@@ -198,3 +198,30 @@ def test_long_f16_rows_take_the_tail_kernel(eng, oracle):
     res = oracle.residual(np.ascontiguousarray(x[200:]), cent, np.where(part == oracle.NONE, 0, part))
     cb = np.stack([res[rng.choice(res.shape[0], 256, replace=False)][:, i * 16:(i + 1) * 16] for i in range(m)]).astype(np.float16)
     run_case(eng, oracle, x, cent, dup_codewords(cb), "l2", stage="xform_tail")
+
+
+def test_unit_rows_take_the_single_f16_product_in_the_coarse_quantiser(eng, oracle):
+    """cosine, d > 128: the normalise kernel leaves the unit rows as a binary16 plane and the K-tiled coarse quantiser multiplies it by
+    a binary16 centroid plane -- one v_mfma_f32_32x32x16_f16 instead of three bf16 products, margin E = 2^-9.5 (|x|^2 + max|c|^2)
+    (mfma_assign.hip: ma_top3_wide_kernel<.., F16>).  Partition ids, codes and the loss stay the oracle's bit for bit, with duplicated
+    centroids (two / three / five of a kind), near-duplicates inside the wider margin, zero rows (no direction: dropped) and a caller's
+    centroids that do NOT fit the plane's scale (the bf16 route takes those)."""
+    n, d, m, nlist = 3000, 384, 24, 96
+    x = spoil(clustered(n, d, 77, scale=6.0, noise=2.5, integer=False).astype(f32))
+    x[100] = 1.0
+    x[101] = 0.0
+    rng = np.random.default_rng(5)
+    xs = oracle.normalize(x)
+    fin = oracle.is_finite(xs)
+    cent = dup_centroids(np.ascontiguousarray(xs[fin][rng.choice(int(fin.sum()), nlist, replace=False)]))
+    cent[40] = cent[41] * f32(1.0005)                 # inside the f16 margin, outside the bf16 x 3 one: exact check decides
+    cent[50] = cent[51] + f32(1e-4)
+    part, _ = oracle.assign(np.ascontiguousarray(xs[fin]), cent, "l2")
+    res = oracle.residual(np.ascontiguousarray(xs[fin]), cent, np.where(part == oracle.NONE, 0, part))
+    cb = np.stack([res[rng.choice(res.shape[0], 256, replace=False)][:, i * 16:(i + 1) * 16] for i in range(m)]).astype(f32)
+    before = eng.timing_query("count:ma_wide_f16")[1]
+    run_case(eng, oracle, x, cent, dup_codewords(cb), "cosine", stage="xform_tail")
+    assert eng.timing_query("count:ma_wide_f16")[1] == before + 1, "the f16 coarse sweep did not serve the call"
+    big = cent * f32(60.0)                            # components beyond 2: outside the plane's scale -> the three-term bf16 sweep
+    run_case(eng, oracle, x, big, dup_codewords(cb), "cosine", stage="xform_tail")
+    assert eng.timing_query("count:ma_wide_f16")[1] == before + 1
