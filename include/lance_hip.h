@@ -124,15 +124,16 @@ int lance_hip_kmeans_finalize(lance_hip_ctx *ctx, int dtype, const float *buf, u
                               void *centroids_out);
 
 /* One split of the hierarchical trainer -- train_hierarchical_kmeans, kmeans.rs:746-1003: k-means with k centroids over the rows
- * `rows_host` (n_rows indices into x, ascending; NULL = all rows: the first level) of the training sample x [n][d] (device, f32 or f16:
- * an f16 sample trains in half-precision M-step arithmetic, as the single-GPU trainer), then the membership of those rows
+ * `rows_host` (n_rows indices into x, ascending; NULL = all rows: the first level) of the training sample x [n][d] (device, f32 values;
+ * dtype = the COLUMN's type: LANCE_HIP_F16 says the values are binary16-representable -- widened once by the caller -- and the M-step
+ * rounds like half::f16, as the single-GPU trainer of an f16 column does), then the membership of those rows
  * (kmeans.rs:866-905).  balance_factor_scaled is the factor ALREADY divided by the sample size (train_kmeans :1344 divides once, by the
  * whole sample, and every split inherits it); seed = the run's seed (the trainer uses seed + number of k-means runs so far).  Outputs on
  * the host: centroids [k][d] f32, membership [n_rows] (LANCE_HIP_NONE: no centroid).
  * This is the unit of work of the multi-GPU hierarchical trainer (lance_amd/dist.py train_kmeans_hierarchical_sharded, SURVEY 8(e);
  * BASELINE config 5: nlist 65,536): every rank holds the sample, the splits of the largest clusters are computed on different ranks at
  * the same time and applied in the reference's order -- the result is the single-GPU trainer's bit for bit.                         */
-int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, const uint32_t *rows_host,
+int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const float *x, uint64_t n, uint32_t d, const uint32_t *rows_host,
                            uint64_t n_rows, uint32_t k, uint32_t max_iters, double tol, float balance_factor_scaled, uint64_t seed,
                            float *centroids_out_host, uint32_t *membership_out_host);
 

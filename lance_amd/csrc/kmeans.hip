@@ -1001,7 +1001,7 @@ int lance_hip_kmeans_shard_end(lance_hip_ctx *ctx, const void *state, double *lo
   return LANCE_HIP_OK;
 }
 
-int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const void *x, uint64_t n, uint32_t d, const uint32_t *rows_host,
+int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const float *x, uint64_t n, uint32_t d, const uint32_t *rows_host,
                            uint64_t n_rows, uint32_t k, uint32_t max_iters, double tol, float balance_factor_scaled, uint64_t seed,
                            float *centroids_out_host, uint32_t *membership_out_host) {
   lh::CtxLock _ctx_lock(ctx);
@@ -1010,8 +1010,7 @@ int lance_hip_kmeans_split(lance_hip_ctx *ctx, int dtype, int metric, const void
   LH_REQUIRE(n_rows > 0 && n_rows <= n && n < (1ull << 32) && k > 0 && k <= n_rows, "kmeans_split: %llu rows of %llu, k = %u", (unsigned long long)n_rows,
              (unsigned long long)n, k);
   LH_CHECK_HIP(hipSetDevice(ctx->device));
-  const float *xf;
-  LH_TRY(as_f32(ctx, dtype, x, (size_t)n * d, "f16.x", &xf));
+  const float *xf = x;      // the sample as f32 (an f16 column's sample widened ONCE by the caller: thousands of splits read it)
   const int km = metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : metric;
   float *cdev = ctx->scratch_t<float>("hier.cent", (size_t)std::max<uint32_t>(k, 16) * d);
   if (!cdev) return LANCE_HIP_ENOMEM;

@@ -282,7 +282,7 @@ def _hier_cluster_k(size, remaining_k, hk):
 
 
 def train_kmeans_hierarchical_sharded(engine, sample, k, max_iters=50, tol=1e-4, balance_factor=1.0, hierarchical_k=16, seed=0, metric="l2",
-                                      group=None, window=None, stats=None):
+                                      group=None, window=None, stats=None, engines=None):
     """train_hierarchical_kmeans (rust/lance-index/src/vector/kmeans.rs:746-1003) with the splits of the largest clusters computed on
     DIFFERENT ranks at the same time.  `sample` is the whole training sample, identical on every rank (at C5: 16.7M x 128 f32 = 8.6 GB per
     GPU; the caller all-gathers it once).  The reference pops the largest cluster, runs a k-means over its rows (seeded by the number of
@@ -294,17 +294,30 @@ def train_kmeans_hierarchical_sharded(engine, sample, k, max_iters=50, tol=1e-4,
     (a child outgrew a waiting cluster, or the remaining budget changed k) throws the rest of the round away.  The result is the
     single-GPU trainer's BIT FOR BIT (same sub-problems, same seeds, same order) -- unlike the row-sharded Lloyd loop it has an oracle to
     be equal to.  -> centroids [<= k, d] float32 tensor on the sample's device.
-    stats (optional dict): rounds, splits applied, splits thrown away."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    stats (optional dict): rounds, splits applied, splits thrown away.
+    engines (optional list): further engine contexts on THIS GPU -- the rank's share of a round then runs on host threads, one context
+    (own stream + scratch) each: thousands of the splits are a few thousand rows against sixteen centroids and do not fill a GPU one
+    at a time (C5, one GPU: 4,369 splits, 10 s one after the other)."""
+    world = dist.get_world_size(group) if (dist.is_initialized() and group is not False) else 1
+    rank = dist.get_rank(group) if (dist.is_initialized() and group is not False) else 0
+    pool = list(engines) if engines else [engine]
     n, d = sample.shape
     hk = int(hierarchical_k)
+    f16 = (isinstance(sample, torch.Tensor) and sample.dtype == torch.float16) or (isinstance(sample, np.ndarray) and sample.dtype == np.float16)
+    out_dev = sample.device if isinstance(sample, torch.Tensor) else None
+    if isinstance(sample, torch.Tensor) and sample.is_cuda and sample.dtype != torch.float32:
+        sample = sample.float().contiguous()      # f16 / int8 samples: widened (exactly) ONCE -- thousands of splits read the sample
+    if isinstance(sample, torch.Tensor) and sample.is_cuda:
+        if not sample.is_contiguous():
+            sample = sample.contiguous()
+        torch.cuda.synchronize()                  # the engine contexts run on their own streams: the sample must be complete before the first split
+    kw = {"f16_arith": True} if (f16 and isinstance(sample, torch.Tensor) and sample.is_cuda) else {}
     bfs = float(np.float32(balance_factor) / np.float32(n))        # train_kmeans :1344 divides once, by the whole sample
-    window = int(window) if window else max(1, 2 * world)
+    window = int(window) if window else max(1, 2 * world * len(pool))
     run = 0
     initial_k = min(hk, k, n)
     # first level: one k-means over the whole sample -- computed on every rank (a single problem: nothing to spread)
-    c0, mem0 = engine.kmeans_split(sample, None, initial_k, max_iters=max_iters, tol=tol, balance_factor_scaled=bfs, seed=seed + run, metric=metric)
+    c0, mem0 = engine.kmeans_split(sample, None, initial_k, max_iters=max_iters, tol=tol, balance_factor_scaled=bfs, seed=seed + run, metric=metric, **kw)
     run += 1
     heap = _HHeap()
     next_id = 0
@@ -328,6 +341,7 @@ def train_kmeans_hierarchical_sharded(engine, sample, k, max_iters=50, tol=1e-4,
 
     n_rounds = n_applied = n_wasted = 0
     pending = None
+    tpool = None
     while True:
         first = pending if pending is not None else next_job(heap)
         pending = None
@@ -345,9 +359,23 @@ def train_kmeans_hierarchical_sharded(engine, sample, k, max_iters=50, tol=1e-4,
             jobs.append((c, ck))
             virt += ck - 1
         mine = {}
-        for j in range(rank, len(jobs), world):
+        my_jobs = list(range(rank, len(jobs), world))
+
+        def run_job(t):
+            slot, j = t
             c, ck = jobs[j]
-            mine[j] = engine.kmeans_split(sample, c.idx, ck, max_iters=max_iters, tol=tol, balance_factor_scaled=bfs, seed=seed + run + j, metric=metric)
+            return j, pool[slot % len(pool)].kmeans_split(sample, c.idx, ck, max_iters=max_iters, tol=tol, balance_factor_scaled=bfs,
+                                                          seed=seed + run + j, metric=metric, **kw)
+        if len(pool) > 1 and len(my_jobs) > 1:
+            if tpool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                tpool = ThreadPoolExecutor(max_workers=len(pool))
+            for j, res in tpool.map(run_job, list(enumerate(my_jobs))):
+                mine[j] = res
+        else:
+            for t in enumerate(my_jobs):
+                j, res = run_job(t)
+                mine[j] = res
         if world > 1:
             gathered = [None] * world
             dist.all_gather_object(gathered, mine, group=group)
@@ -389,12 +417,14 @@ def train_kmeans_hierarchical_sharded(engine, sample, k, max_iters=50, tol=1e-4,
             continue
         if first is None and pending is None:
             break
+    if tpool is not None:
+        tpool.shutdown(wait=True)
     out = sorted(heap.d, key=lambda c: c.id)
     if stats is not None:
         stats.update(rounds=n_rounds, splits_applied=n_applied, splits_thrown_away=n_wasted, window=window, world=world)
     cent = np.stack([c.centroid for c in out]).astype(np.float32) if out else np.zeros((0, d), np.float32)
     t = torch.from_numpy(cent)
-    return t.to(sample.device) if isinstance(sample, torch.Tensor) else t
+    return t.to(out_dev) if out_dev is not None else t
 
 
 def block_ranges(total, world):

@@ -161,19 +161,22 @@ class Engine:
                                                  C.byref(iters), C.byref(kout)))
         return cent[: kout.value], loss.value, iters.value
 
-    def kmeans_split(self, x, rows, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, seed=0, metric="l2"):
+    def kmeans_split(self, x, rows, k, max_iters=50, tol=1e-4, balance_factor_scaled=0.0, seed=0, metric="l2", f16_arith=False):
         """One split of the hierarchical trainer (lance_hip_kmeans_split): k-means with k centroids over the rows `rows` (ascending u32
-        indices, None: all) of the device sample x (f32 / f16; int8 samples train on their f32 copy), then their membership.
+        indices, None: all) of the device sample x (f32; an f16 / int8 sample is widened -- f16_arith: the values are binary16 and the
+        M-step rounds like half::f16), then their membership.  No device-wide synchronisation: host threads run splits side by side.
         -> (centroids np.float32 [k, d], membership np.uint32 [len(rows)])"""
-        x, dt = _vec(x)
-        if x.dtype == torch.int8:
-            x = x.float(); dt = _lib.F32
+        f16 = bool(f16_arith)
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+            x, dt0 = _vec(x)
+            f16 = f16 or x.dtype == torch.float16
+            x = x.float().contiguous()          # (callers that split many times widen once themselves and pass f16_arith)
+        dt = _lib.F16 if f16 else _lib.F32
         n, d = x.shape
         r = None if rows is None else np.ascontiguousarray(rows, np.uint32)
         nr = n if r is None else len(r)
         cent = np.empty((k, d), np.float32)
         mem = np.empty(nr, np.uint32)
-        torch.cuda.synchronize()
         check(self.lib.lance_hip_kmeans_split(self.h, dt, METRICS[metric], _ptr(x), n, d, None if r is None else r.ctypes.data_as(C.c_void_p), nr, k,
                                               max_iters, tol, float(balance_factor_scaled), seed, cent.ctypes.data_as(C.c_void_p),
                                               mem.ctypes.data_as(C.c_void_p)))

@@ -363,8 +363,35 @@ def train_ivf_centroids(x, params: IvfPqParams, engine=None, init=None):
         sample = eng.normalize(sample)
     sample = sample[torch.isfinite(sample).all(dim=1)]
     kmetric = "l2" if metric == "cosine" else metric
+    pool = _hier_engine_pool(eng) if (params.num_partitions > 256 and isinstance(sample, torch.Tensor) and sample.is_cuda) else None
+    if pool and len(pool) > 1:
+        # k > 256: the reference trains hierarchically (kmeans.rs:1027) -- thousands of small k-means, one after the other.  The splits the
+        # reference is about to pop are computed side by side on several engine contexts of this GPU and applied in its order (the
+        # multi-GPU trainer of lance_amd/dist.py on one rank): same centroids bit for bit, a fraction of the wall time.
+        from . import dist as _ld
+        f16 = sample.dtype == torch.float16
+        cent = _ld.train_kmeans_hierarchical_sharded(eng, sample, params.num_partitions, max_iters=params.max_iters, balance_factor=1.0,
+                                                     seed=params.seed, metric=kmetric, group=False, engines=pool)
+        return (cent.to(torch.float16) if f16 else cent), 0.0, 0      # "Loss is not meaningful for hierarchical clustering" (kmeans.rs:1001)
     return eng.kmeans_train(sample, params.num_partitions, max_iters=params.max_iters, balance_factor=1.0, init=init,
                             seed=params.seed, metric=kmetric)
+
+
+_HIER_POOLS = {}
+
+
+def _hier_engine_pool(eng):
+    """engine contexts (own HIP stream + scratch arena each) the hierarchical trainer's splits run on side by side; LANCE_HIP_HIER_CONTEXTS
+    sets the count (default 8; 1 = the library's own sequential loop)"""
+    import os
+    want = int(os.environ.get("LANCE_HIP_HIER_CONTEXTS", "8"))
+    if want <= 1 or not hasattr(eng, "device"):
+        return None
+    key = id(eng)
+    if key not in _HIER_POOLS:
+        from .engine import Engine
+        _HIER_POOLS[key] = [eng] + [Engine(device=eng.device) for _ in range(want - 1)]
+    return _HIER_POOLS[key]
 
 
 def pq_sample_indices(n, params: IvfPqParams):
