@@ -545,9 +545,10 @@ def main():
                           "peak_measured": eng.ubench("mfma_bf16") / 1e12,
                           "peak_measured_source": "lance_hip_ubench(mfma_bf16): v_mfma_f32_32x32x16_bf16 register loop, measured in this run",
                           "exact_recheck_seconds": e_recheck, "call_wall_seconds": e_wall,
-                          "what": "the MFMA sweep kernel (ma_top3_kernel: bf16x3 products, four smallest kept) of lance_hip_assign over the training "
-                                  "sample against the trained centroids, mean of 20 launches by HIP events on the engine's stream; the exact re-check "
-                                  "kernels and the whole call's wall time beside it; algorithmic flop = 2*n*k*d"},
+                          "what": "the E-step kernel of lance_hip_assign over the training sample against the trained centroids (f32 rows, d <= 128: xf_kernel<.., ASSIGN>, "
+                                  "xform_fused.hip -- rows -> bf16x3 MFMA sweep, four smallest kept -> exact re-check of the candidates, ONE kernel; other "
+                                  "shapes: ma_top3_kernel), mean of 20 launches by HIP events on the engine's stream; the recompute-list kernel and the "
+                                  "whole call's wall time beside it; algorithmic flop = 2*n*k*d"},
             "build_stages_ms": {k_: round(v * 1e3, 3) for k_, v in (idx.stats.seconds.items() if idx.stats else [])},
         }
     guide_lds_peak = LDS_B64_CONFLICT_FREE_PER_CLK_CU * 256 * 2.4e9      # lane-gathers/s: ds_read_b64, 256 B/clk/CU, 256 CUs, 2.4 GHz

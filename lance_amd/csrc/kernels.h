@@ -114,6 +114,12 @@ int launch_xform_fused(lance_hip_ctx *ctx, int dtype, int metric, const void *x,
 bool xform_tail_supported(int d, int m, int nbits, int64_t n, const float *x, const float *cent, const float *codebook);
 int launch_xform_tail(lance_hip_ctx *ctx, const float *x, int64_t n, int d, const float *cent, const uint32_t *part_ids, int residual, bool round_f16,
                       const float *codebook, int m, uint8_t *codes);
+// the codebook training's E-step (all sub-quantisers, one launch) on the transform's PQ phase (xform_fused.hip); the undecided items go to pq_mfma_fix_kernel
+bool xform_pqtrain_supported(const PairwiseArgs &p, int sd, int batches);
+int launch_xform_pqtrain(lance_hip_ctx *ctx, const PairwiseArgs &p, int sd, int batches, uint32_t *fb_cnt, uint32_t *fb_items);
+// f32 rows of d <= 128: sweep + exact re-check in one kernel (phases 1-3 of the transform kernel, with the k-means bias); same outputs as launch_assign
+bool xform_assign_supported(const PairwiseArgs &p, int d, int metric, int batches);
+int launch_xform_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);
 // bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);

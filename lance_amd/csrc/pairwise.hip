@@ -214,6 +214,7 @@ static int launch_pairwise(lance_hip_ctx *ctx, PairwiseArgs p, int d, int metric
     if (d <= 16) p.lanes32 = false;   // up to 16 elements both orders are the same sequence of additions
   }
   if (MODE == 0 && pq_mfma_supported(p, d, metric, batches)) return launch_pq_mfma(ctx, p, d, batches);
+  if (MODE == 0 && xform_assign_supported(p, d, metric, batches)) return launch_xform_assign(ctx, p, d, metric);
   if (MODE == 0 && mfma_assign_supported(p, d, batches)) return launch_assign_mfma(ctx, p, d, metric);
   LH_REQUIRE(p.x != nullptr, "internal: the exact assign kernels need the f32 view of the rows");
   bool fixed_ok = p.cent_aligned;  // LDS tile float4 reads in dist_exact need 16B-aligned rows

@@ -300,11 +300,21 @@ int launch_pq_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int batches
   a.fb_cnt = ctx->scratch_t<uint32_t>("pqm.fb_cnt", (size_t)batches);
   a.fb_items = ctx->scratch_t<uint32_t>("pqm.fb_items", (size_t)p.n * batches);
   if (!a.fb_cnt || !a.fb_items) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(lh::memset_async(a.fb_cnt, 0, (size_t)batches * 4, ctx->stream));
   const dim3 grid((unsigned)cdiv((uint64_t)p.n, PQM_WG_ROWS), (unsigned)batches);
   // fix kernel: grid (blocks, batches); a workgroup whose first wave has no item returns before staging the codebook
   const dim3 fix_grid((unsigned)std::min<uint64_t>(std::max<uint64_t>(1, cdiv((uint64_t)p.n, 256)), 64), (unsigned)batches);
   ScopedTimer t(ctx, "pq_mfma_estep");
+  if (xform_pqtrain_supported(p, d, batches)) {
+    // round 6: the transform's PQ phase picks the codewords (xf_pqtrain_kernel: two full K = 16 products per tile, 3 VALU per pair, codeword
+    // fragments prepared once per iteration -- which also zeroes the lists' counters); the undecided items come here as before
+    LH_TRY(launch_xform_pqtrain(ctx, p, d, batches, a.fb_cnt, a.fb_items));
+    if (d == 4) hipLaunchKernelGGL(pq_mfma_fix_kernel<4>, fix_grid, dim3(256), 0, ctx->stream, a);
+    else if (d == 8) hipLaunchKernelGGL(pq_mfma_fix_kernel<8>, fix_grid, dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(pq_mfma_fix_kernel<16>, fix_grid, dim3(256), 0, ctx->stream, a);
+    LH_CHECK_HIP(hipGetLastError());
+    return LANCE_HIP_OK;
+  }
+  LH_CHECK_HIP(lh::memset_async(a.fb_cnt, 0, (size_t)batches * 4, ctx->stream));
   switch (d) {
     case 4:
       hipLaunchKernelGGL(pq_mfma_estep_kernel<4>, grid, dim3(256), 0, ctx->stream, a);

@@ -82,6 +82,13 @@ struct XfArgs {
   int m_total = 0;               // sub-quantisers of the whole index (row stride of `codes`)
   int64_t d_total = 0;           // elements per centroid row (xf_tail_kernel: a workgroup sees a 128-column block of it)
   int col_base = 0;              // xf_tail_kernel: first column of this launch's blocks
+  // xf_pqtrain_kernel (codebook training E-step): sub-quantiser b's sub-vector of row r at tr_x + b * tr_boff + r * tr_ldx; ids / dists [b][tr_stride]
+  const uint8_t *active = nullptr;      // [m_total] 0: the sub-quantiser's problem has converged, nothing of it is touched (ASSIGN: [1], the one problem)
+  const float *bias = nullptr;          // ASSIGN (k-means E-step with a balance factor): argmin over dist + bias[c] (kmeans.rs:317-369); maxbits[1] = max |bias|
+  const float *tr_x = nullptr, *tr_cb = nullptr;
+  int64_t tr_ldx = 0, tr_boff = 0, tr_stride = 0;
+  uint32_t *tr_ids = nullptr;
+  float *tr_dists = nullptr;
   unsigned long long *prof = nullptr;   // LANCE_HIP_XF_PROF=1: s_memtime ticks summed over the waves: [0] rows->registers [1] sweep [2] merge + exact re-check
                                         // [3] residual + barrier [4] PQ encode [5] codes out [6] waves [7] undecided PQ items
 };
@@ -109,11 +116,12 @@ template <> struct XfSd<8> { static constexpr int NA = 2; };
 template <> struct XfSd<16> { static constexpr int NA = 3; };
 
 template <int SD>
-__global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict__ codebook, uint4 *__restrict__ pqa, float *__restrict__ cmax2) {
+__global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict__ codebook, uint4 *__restrict__ pqa, float *__restrict__ cmax2,
+                                                         uint32_t *__restrict__ zero_cnt) {
   constexpr int NMF = XfSd<SD>::NA;
   __shared__ uint32_t s_max;
   const int m = blockIdx.x, c = threadIdx.x;
-  if (c == 0) s_max = 0u;
+  if (c == 0) { s_max = 0u; if (zero_cnt) zero_cnt[m] = 0u; }      // (the training E-step: one launch fewer per Lloyd iteration)
   __syncthreads();
   const float *cw = codebook + ((int64_t)m * 256 + c) * SD;
   uint32_t hi[SD], lo[SD];
@@ -161,7 +169,9 @@ __global__ __launch_bounds__(256) void xf_pq_prep_kernel(const float *__restrict
 // matrix pipe complete: s'(c) = R + |c|^2 - 2 x.c.  Rows c >= k (padding to whole 64-centroid tiles) get |c|^2 = +inf: never selected.
 template <int METRIC>
 __global__ __launch_bounds__(64) void xf_cent_prep_kernel(const float *__restrict__ cent, int k, int d, uint16_t *__restrict__ cpl,
-                                                          uint32_t *__restrict__ maxbits) {
+                                                          uint32_t *__restrict__ maxbits, const float *__restrict__ bias = nullptr,
+                                                          const uint8_t *__restrict__ active = nullptr) {
+  if (active && !active[0]) return;
   const int c = blockIdx.x, w = 2 * d + 16;
   uint16_t *row = cpl + (int64_t)c * w;
   const float scale = METRIC == METRIC_DOT ? -1.0f : -2.0f;
@@ -179,8 +189,9 @@ __global__ __launch_bounds__(64) void xf_cent_prep_kernel(const float *__restric
   if (threadIdx.x < 16) {
     uint32_t v = 0u;
     if (threadIdx.x == 3) v = 0x3F80u;                        // 1.0: multiplies the row's offset R
-    if (METRIC != METRIC_DOT || c >= k) {
-      const float n = c < k ? s : INFINITY;
+    if (METRIC != METRIC_DOT || c >= k || bias) {
+      // (with a bias the norm slot carries |c|^2 + bias[c] -- dot: bias[c] -- so the surrogate still leaves the matrix pipe complete)
+      const float n = c < k ? ((METRIC != METRIC_DOT ? s : 0.0f) + (bias ? bias[c] : 0.0f)) : INFINITY;
       const uint32_t n1 = bf16_rne_bits(n) & 0xFFFFu;
       const float r1 = c < k ? n - bf16_bits_to_float(n1) : 0.0f;
       const uint32_t n2 = bf16_rne_bits(r1) & 0xFFFFu;
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(64) void xf_cent_prep_kernel(const float *__restric
     row[d + threadIdx.x] = (uint16_t)v;
   }
   if (threadIdx.x == 0 && c < k && s == s) atomicMax(&maxbits[0], __float_as_uint(fabsf(s)));
+  if (threadIdx.x == 0 && c < k && bias) atomicMax(&maxbits[1], __float_as_uint(fabsf(bias[c])));      // (a NaN bias: a huge bound, every row recomputed exactly)
 }
 
 // LDS (bytes) of one workgroup: the centroid tiles of the sweep and the residual planes of the encode alias each other; the
@@ -416,6 +428,7 @@ __device__ __forceinline__ void xf_pq_phase(const XfArgs &p, char *smem, int m0,
   const bf16x8 zeros8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
   for (int m = wave, mi = 0; m < M; m += 4, ++mi) {
+    if (p.active && !p.active[m0 + m]) continue;      // (training: a converged problem; wave-uniform)
     bf16x8 af[8][NA];
     {
       const uint4 *src = p.pqa + (int64_t)(m0 + m) * 8 * NA * 64 + lane;
@@ -496,7 +509,8 @@ __device__ __forceinline__ void xf_pq_phase(const XfArgs &p, char *smem, int m0,
         // margin > 2^-100: the relative bounds above assume no product, sum or cleared mantissa bit sits in the denormal range
         // (16 + 16 slots x 2^-126, 255 ulps of a denormal key); columns scaled like 1e-20 take the exact kernel (NaN anywhere: false)
         // + 2^-14 s1: the winner's key sits up to 2^-15 of its value under its surrogate (8 cleared mantissa bits)
-        const bool decided = (margin < INFINITY) && (margin > 7.888609052210118e-31f) && (s2 - s1 > margin + 0.00006103515625f * s1);
+        // s1 < 2^120: the winner's exact distance (<= s1 + E) is then finite -- the training E-step writes it without a second look
+        const bool decided = (margin < INFINITY) && (margin > 7.888609052210118e-31f) && (s2 - s1 > margin + 0.00006103515625f * s1) && (s1 < 1.329228e36f);
         codes_s[(wave * MW + mi) * MA_ROWS + lrow] = (uint8_t)(m1 & 0xFFu);      // (an undecided item's byte is rewritten by the fix kernel)
         if (!decided && !rskip[lrow]) {
           if constexpr (PROF) ++pc_und;
@@ -520,7 +534,7 @@ __device__ __forceinline__ void xf_pq_phase(const XfArgs &p, char *smem, int m0,
     }
   }
   // ---- codes: [wave][mi][row] in LDS -> [row][m0 + m] in HBM ----
-  {
+  if (p.codes) {
     const int64_t nrows = p.n - row0 < MA_ROWS ? p.n - row0 : MA_ROWS;
     if (p.m_total == M) {      // the block is the whole code row: one coalesced store per workgroup
       const int nbytes = (int)nrows * M;
@@ -605,8 +619,80 @@ __global__ __launch_bounds__(256, 2) void xf_tail_kernel(XfArgs p) {
   xf_pq_phase<KS, SD, false>(p, smem, col0 / SD, row0, und, t0, t1);
 }
 
-template <int KS, int SD, int METRIC, typename TX, bool PROF = false>
+// ---- the codebook training's E-step (pq/builder.rs:89-157 -> kmeans.rs:317-369 per sub-quantiser) on the same machinery --------------------
+// Round 5's pq_mfma_estep_kernel (pq_mfma.hip) is the encode half of the round-5 transform: software bf16 splits, three half-empty K = 8
+// products and 4-5 VALU per (row, codeword) pair -- 73 us per Lloyd iteration at C2 (16 x 65,536 x 256 x 8), fifty times per build.  Here a
+// workgroup takes 128 rows x 128 columns of the residual matrix (the sub-quantisers' slices [b][rows][sd] or the row-major matrix: any
+// (row stride, problem offset)), phases 4 / 5 of xf_kernel pick every item's codeword, and the epilogue evaluates the winner's distance
+// exactly (l2_scalar order: the loss is a sum of these) -- ids and distances bit-equal to pairwise_kernel's.  Undecided items go to the
+// lists of pq_mfma_fix_kernel, which overwrites what the epilogue wrote for them.
+template <int SD>
+__global__ __launch_bounds__(256, 2) void xf_pqtrain_kernel(XfArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = 8, D = KS * 16, XS = D + 4, M = D / SD, MW = (M + 3) / 4, PPS = MA_ROWS * (SD / 4);      // 16-byte pieces per sub-quantiser slice of the tile
+  float *xs = reinterpret_cast<float *>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * MA_ROWS;
+  const int m0 = (int)blockIdx.y * M;
+  uint32_t *q_cnt = XfLds<KS, SD>::q_cnt(smem);
+  if (threadIdx.x < M) q_cnt[threadIdx.x] = 0u;
+  const bool valid = row0 + wave * 32 + j < p.n;
+  constexpr int NLD = MA_ROWS * (D / 4) / 256;
+  {
+    f4 stage[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + 256 * u, mm = idx / PPS, rem = idx - mm * PPS, r = rem / (SD / 4), e4 = rem - r * (SD / 4);
+      stage[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (row0 + r < p.n) stage[u] = *reinterpret_cast<const f4 *>(p.tr_x + (int64_t)(m0 + mm) * p.tr_boff + (row0 + r) * p.tr_ldx + 4 * e4);
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = threadIdx.x + 256 * u, mm = idx / PPS, rem = idx - mm * PPS, r = rem / (SD / 4), e4 = rem - r * (SD / 4);
+      *reinterpret_cast<f4 *>(&xs[r * XS + mm * SD + 4 * e4]) = stage[u];
+    }
+  }
+  __syncthreads();
+  float xf[KS][8];
+  {
+    const float *xr = xs + (wave * 32 + j) * XS + g * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f4 a = *reinterpret_cast<const f4 *>(xr + s * 16), b = *reinterpret_cast<const f4 *>(xr + s * 16 + 4);
+      xf[s][0] = a.x; xf[s][1] = a.y; xf[s][2] = a.z; xf[s][3] = a.w; xf[s][4] = b.x; xf[s][5] = b.y; xf[s][6] = b.z; xf[s][7] = b.w;
+    }
+  }
+  __syncthreads();      // xs is dead: the bf16 planes take its place
+  xf_residual_to_lds<KS, SD>(xf, nullptr, false, !valid, 0, smem, wave * 32 + j, g, !valid);
+  __syncthreads();
+  uint32_t und = 0;
+  long long t0 = 0, t1 = 0;
+  xf_pq_phase<KS, SD, false>(p, smem, m0, row0, und, t0, t1);
+  // ---- the winners' exact distances: consecutive threads = consecutive rows of one sub-quantiser ----
+  const uint8_t *codes_s = XfLds<KS, SD>::codes(smem);
+  const int nrows = (int)(p.n - row0 < MA_ROWS ? p.n - row0 : MA_ROWS);
+#pragma unroll 2
+  for (int i = threadIdx.x; i < MA_ROWS * M; i += 256) {
+    const int mm = i / MA_ROWS, r = i - mm * MA_ROWS, mg = m0 + mm;
+    if (r >= nrows || (p.active && !p.active[mg])) continue;
+    const uint32_t c = codes_s[((mm & 3) * MW + (mm >> 2)) * MA_ROWS + r];
+    const float *src = p.tr_x + (int64_t)mg * p.tr_boff + (row0 + r) * p.tr_ldx;
+    RegVec<SD> rv;
+#pragma unroll
+    for (int q = 0; q < SD / 4; ++q) rv.q[q] = *reinterpret_cast<const f4 *>(src + 4 * q);
+    const float v = dist_exact<SD, METRIC_L2>(rv, p.tr_cb + ((int64_t)mg * 256 + c) * SD);
+    p.tr_ids[(int64_t)mg * p.tr_stride + row0 + r] = c;
+    p.tr_dists[(int64_t)mg * p.tr_stride + row0 + r] = v;
+  }
+}
+
+// ASSIGN = true: phases 1-3 only (rows -> sweep -> exact re-check), with the k-means bias and the problem's `active` flag: the E-step
+// of the IVF training and every other f32 assign call of d <= 128 (launch_xform_assign).  One kernel instead of round 5's
+// ma_top3_kernel + ma_finalize_kernel (the rows read twice, the candidates through HBM).
+template <int KS, int SD, int METRIC, typename TX, bool PROF = false, bool ASSIGN = false>
 __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
+  if constexpr (ASSIGN) { if (p.active && !p.active[0]) return; }
   long long pa[6] = {0, 0, 0, 0, 0, 0}, pprev = 0;      // PROF: s_memtime ticks per phase, summed over this workgroup's row tiles
   uint32_t pc_und = 0;
   if constexpr (PROF) pprev = clock64();
@@ -633,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   // round 5 -- load, LDS store, next load -- paid sixteen dependent ones, 110k of a wave's 335k cycles; lanes fetching their own
   // 16-byte pieces straight from HBM measured 54k: four times the line requests).  (Persistent workgroups that request the next
   // tile's rows before the PQ phase were tried -- gpurun r06i: the 64 staging registers spill, 1.03 -> 1.36 ms.)
-  if (threadIdx.x < M) q_cnt[threadIdx.x] = 0u;
+  if constexpr (!ASSIGN) { if (threadIdx.x < M) q_cnt[threadIdx.x] = 0u; }
   const int64_t row = row0 + wave * 32 + j;
   const bool valid = row < p.n;
   constexpr int NLD = MA_ROWS * (D / 4) / 256;        // 4-element pieces per thread (16 at D = 128)
@@ -671,11 +757,12 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   }
   xn2 += __shfl_xor(xn2, 32, 64);          // (a non-finite element makes this inf / NaN: the row is then recomputed exactly, below)
   const float cmax2c = __uint_as_float(p.maxbits[0]);
-  const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2c);   // 2E, E = 2^-13 (|x|^2 + max|c|^2)
+  const float bmax = (ASSIGN && p.bias) ? __uint_as_float(p.maxbits[1]) : 0.0f;      // max |bias|: in E (the biased sum's own roundings) and in R (surrogates stay >= 0)
+  const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2c + bmax);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
   // the row's offset R (one bf16, rounded up): L2  s' = R + |c|^2 - 2 x.c = |x - c|^2 + (R - |x|^2) >= 0;  dot  s' = R - x.c >= 0
   bf16x8 bx = {0, 0, 0, 0, 0, 0, 0, 0};
   if (g == 0) {
-    const float R = METRIC == METRIC_DOT ? 0.5f * (xn2 + cmax2c) + E2 : xn2 + E2;
+    const float R = (METRIC == METRIC_DOT ? 0.5f * (xn2 + cmax2c) + E2 : xn2 + E2) + bmax;
     bx[0] = (short)0x3F80; bx[1] = (short)0x3F80; bx[2] = (short)0x3F80; bx[3] = (short)xf_bf16_up(R);
   }
   __syncthreads();   // xs is dead: the same LDS now holds centroid tiles
@@ -792,7 +879,9 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
       if (!__any(need)) continue;                                   // wave-uniform: rounds 2 and 3 are rare
       const uint32_t c = need ? cand[t] : 0u;
       const float v = xf_exact<KS, METRIC>(xf, p.cent + (int64_t)c * D, j, g);
-      if (need && (v < bestb || (v == bestb && best != LANCE_HIP_NONE && c < best))) { bestb = v; bestv = v; best = c; }
+      float vb = v;
+      if constexpr (ASSIGN) { if (p.bias) vb = v + p.bias[c]; }      // argmin_value_float over the biased values, the plain distance is what is stored
+      if (need && (vb < bestb || (vb == bestb && best != LANCE_HIP_NONE && c < best))) { bestb = vb; bestv = v; best = c; }
     }
   }
   const bool queued = valid && cl == 3;        // ma_recompute_kernel answers the row; its PQ items go to the fix lists
@@ -801,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     if (queued) {
       const uint32_t slot = atomicAdd(p.afb_cnt, 1u);
       p.afb_rows[slot] = (uint32_t)row;
-      for (int m = 0; m < M; ++m) xf_queue_item<XfLds<KS, SD>::QC>(p, q_cnt, q_rows, m, m, (uint32_t)(wave * 32 + j), row0, true);      // (rare: straight to the global lists)
+      if constexpr (!ASSIGN) for (int m = 0; m < M; ++m) xf_queue_item<XfLds<KS, SD>::QC>(p, q_cnt, q_rows, m, m, (uint32_t)(wave * 32 + j), row0, true);      // (rare: straight to the global lists)
     } else {
       p.part_ids[row] = best;
       p.dists[row] = bestv;
@@ -809,6 +898,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   }
 
   mark(2);
+  if constexpr (ASSIGN) return;
   // ---- 4. residual -> bf16 planes in LDS (the centroid tiles are dead: the sweep's last barrier is behind every wave) ----
   {
     const bool sub = p.residual && best != LANCE_HIP_NONE;
@@ -883,10 +973,10 @@ static int xf_launch_sd(lance_hip_ctx *ctx, const XfArgs &a, int d, int metric, 
   return LANCE_HIP_OK;
 }
 
-static void xf_pq_prep_launch(lance_hip_ctx *ctx, int sd, int m, const float *codebook, uint4 *pqa, float *cmax2) {
-  if (sd == 16) hipLaunchKernelGGL(xf_pq_prep_kernel<16>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
-  else if (sd == 8) hipLaunchKernelGGL(xf_pq_prep_kernel<8>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
-  else hipLaunchKernelGGL(xf_pq_prep_kernel<4>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2);
+static void xf_pq_prep_launch(lance_hip_ctx *ctx, int sd, int m, const float *codebook, uint4 *pqa, float *cmax2, uint32_t *zero_cnt = nullptr) {
+  if (sd == 16) hipLaunchKernelGGL(xf_pq_prep_kernel<16>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2, zero_cnt);
+  else if (sd == 8) hipLaunchKernelGGL(xf_pq_prep_kernel<8>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2, zero_cnt);
+  else hipLaunchKernelGGL(xf_pq_prep_kernel<4>, dim3((unsigned)m), dim3(256), 0, ctx->stream, codebook, pqa, cmax2, zero_cnt);
 }
 
 template <int SD>
@@ -1047,6 +1137,89 @@ int launch_xform_tail(lance_hip_ctx *ctx, const float *x, int64_t n, int d, cons
               (unsigned long long)tot, 100.0 * (double)tot / ((double)rows * m), (unsigned long long)mx);
     }
   }
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+// ---- PQ codebook training: the E-step of all sub-quantisers in one launch (called by launch_pq_mfma) ------------------------------------
+bool xform_pqtrain_supported(const PairwiseArgs &p, int sd, int batches) {
+  static const bool off = getenv("LANCE_HIP_NO_XFORM_FUSED") != nullptr || getenv("LANCE_HIP_NO_XF_TRAIN") != nullptr;
+  if (off || (sd != 4 && sd != 8 && sd != 16) || batches <= 0 || (batches * sd) % 128 != 0) return false;
+  if (p.k != 256 || !p.ids || !p.dists || p.codes) return false;
+  if (p.cent_batch_stride != (int64_t)256 * sd) return false;                 // codebook [b][256][sd], contiguous
+  if ((p.ldx & 3) || (p.x_batch_off & 3) || !p.x_aligned || !p.cent_aligned) return false;
+  return true;
+}
+
+// fb_cnt / fb_items: the undecided-item lists [batches], [batches][n] the caller hands to pq_mfma_fix_kernel afterwards (zeroed here)
+int launch_xform_pqtrain(lance_hip_ctx *ctx, const PairwiseArgs &p, int sd, int batches, uint32_t *fb_cnt, uint32_t *fb_items) {
+  const int na = sd == 16 ? 3 : (sd == 8 ? 2 : 1);
+  uint4 *pqa = ctx->scratch_t<uint4>("xf.pqa", (size_t)batches * 8 * na * 64);
+  float *cmax2 = ctx->scratch_t<float>("xf.cmax2", (size_t)batches);
+  if (!pqa || !cmax2) return LANCE_HIP_ENOMEM;
+  ScopedTimer t(ctx, "xf_pqtrain");
+  xf_pq_prep_launch(ctx, sd, batches, p.cent, pqa, cmax2, fb_cnt);
+  XfArgs a{};
+  a.n = p.n; a.pqa = pqa; a.pq_cmax2 = cmax2; a.m_total = batches; a.fb_cnt = fb_cnt; a.fb_items = fb_items; a.codes = nullptr;
+  a.active = p.active; a.tr_x = p.x; a.tr_cb = p.cent; a.tr_ldx = p.ldx; a.tr_boff = p.x_batch_off; a.tr_stride = p.out_batch_stride;
+  a.tr_ids = p.ids; a.tr_dists = p.dists;
+  const dim3 grid((unsigned)cdiv((uint64_t)p.n, MA_ROWS), (unsigned)(batches * sd / 128));
+  if (sd == 16) hipLaunchKernelGGL(xf_pqtrain_kernel<16>, grid, dim3(256), (xf_lds_bytes<8, 16>()), ctx->stream, a);
+  else if (sd == 8) hipLaunchKernelGGL(xf_pqtrain_kernel<8>, grid, dim3(256), (xf_lds_bytes<8, 8>()), ctx->stream, a);
+  else hipLaunchKernelGGL(xf_pqtrain_kernel<4>, grid, dim3(256), (xf_lds_bytes<8, 4>()), ctx->stream, a);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+// ---- assign (k-means E-step, lance_hip_assign, hierarchical splits) of f32 rows, d <= 128: phases 1-3 of the transform kernel ----------
+bool xform_assign_supported(const PairwiseArgs &p, int d, int metric, int batches) {
+  static const bool off = getenv("LANCE_HIP_NO_MFMA") != nullptr || getenv("LANCE_HIP_NO_XFORM_FUSED") != nullptr || getenv("LANCE_HIP_NO_XF_TRAIN") != nullptr;
+  if (off || batches != 1 || p.codes || p.matrix || p.lanes32 || !p.ids || !p.dists) return false;
+  if (metric != METRIC_L2 && metric != METRIC_DOT) return false;
+  if (d % 16 != 0 || d < 16 || d > 128 || p.k < 32 || p.n < 2048 || p.n >= (1ll << 32)) return false;
+  if (!p.x || (p.x_native && p.x_dtype != LANCE_HIP_F32) || !p.x_aligned || !p.cent_aligned) return false;
+  return true;
+}
+
+template <int KS>
+static void xf_assign_launch_ks(lance_hip_ctx *ctx, const XfArgs &a, int metric) {
+  constexpr size_t lds = xf_lds_bytes<KS, 8>();
+  const dim3 grid(xf_grid(ctx, a.n));
+  if (metric == METRIC_DOT) hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_DOT, float, false, true>), grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_L2, float, false, true>), grid, dim3(256), lds, ctx->stream, a);
+}
+
+int launch_xform_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric) {
+  const int kpad = (p.k + MA_CT - 1) / MA_CT * MA_CT;
+  uint16_t *cpl = ctx->scratch_t<uint16_t>("xf.cpl", (size_t)kpad * (2 * d + 16));
+  uint32_t *maxbits = ctx->scratch_t<uint32_t>("ma.maxbits", 4);      // [0] max |c|^2, [1] max |bias|, [2] rows left to the recompute kernel
+  uint32_t *afb_rows = ctx->scratch_t<uint32_t>("ma.fb_rows", (size_t)p.n);
+  if (!cpl || !maxbits || !afb_rows) return LANCE_HIP_ENOMEM;
+  LH_CHECK_HIP(lh::memset_async(maxbits, 0, 16, ctx->stream));
+  if (metric == METRIC_DOT) hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_DOT>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, p.cent, p.k, d, cpl, maxbits, p.bias, p.active);
+  else hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_L2>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, p.cent, p.k, d, cpl, maxbits, p.bias, p.active);
+  XfArgs a{};
+  a.x = p.x; a.n = p.n; a.ldx = p.ldx; a.k = p.k; a.cpl = cpl; a.maxbits = maxbits; a.cent = p.cent; a.check_finite = p.check_finite ? 1 : 0;
+  a.part_ids = p.ids; a.dists = p.dists; a.afb_cnt = maxbits + 2; a.afb_rows = afb_rows; a.bias = p.bias; a.active = p.active; a.d_total = d;
+  {
+    ScopedTimer t(ctx, "ma_sweep");      // (the stage names of the two-kernel route it replaces: bench.py reads them)
+    switch (d / 16) {
+      case 1: xf_assign_launch_ks<1>(ctx, a, metric); break;
+      case 2: xf_assign_launch_ks<2>(ctx, a, metric); break;
+      case 3: xf_assign_launch_ks<3>(ctx, a, metric); break;
+      case 4: xf_assign_launch_ks<4>(ctx, a, metric); break;
+      case 5: xf_assign_launch_ks<5>(ctx, a, metric); break;
+      case 6: xf_assign_launch_ks<6>(ctx, a, metric); break;
+      case 7: xf_assign_launch_ks<7>(ctx, a, metric); break;
+      default: xf_assign_launch_ks<8>(ctx, a, metric); break;
+    }
+  }
+  ScopedTimer t2(ctx, "ma_recheck");      // rows the surrogate left undecided (>= 4 candidates inside the margin, non-finite rows): exact distances to every centroid
+  ctx->count_stage("xf_assign");
+  MaArgs ma{};
+  ma.x = p.x; ma.n = p.n; ma.ldx = p.ldx; ma.d = d; ma.k = p.k; ma.cent = p.cent; ma.bias = p.bias;
+  ma.ids = p.ids; ma.dists = p.dists; ma.check_finite = p.check_finite ? 1 : 0; ma.fb_cnt = a.afb_cnt; ma.fb_rows = afb_rows; ma.active = p.active;
+  LH_TRY(ma_recompute_launch(ctx, ma, metric, LANCE_HIP_F32));
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

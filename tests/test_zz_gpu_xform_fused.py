@@ -225,3 +225,76 @@ def test_unit_rows_take_the_single_f16_product_in_the_coarse_quantiser(eng, orac
     big = cent * f32(60.0)                            # components beyond 2: outside the plane's scale -> the three-term bf16 sweep
     run_case(eng, oracle, x, big, dup_codewords(cb), "cosine", stage="xform_tail")
     assert eng.timing_query("count:ma_wide_f16")[1] == before + 1
+
+
+# ---- the codebook training's E-step on the same PQ phase (xf_pqtrain_kernel; pq/builder.rs:89-157 -> kmeans.rs:317-369) ----------------
+@pytest.mark.parametrize("d,m,n,integer", [(128, 16, 6037, False), (128, 32, 4100, False), (128, 8, 3000, False), (256, 16, 2500, False),
+                                           (1536, 96, 2177, False), (128, 16, 5000, True), (256, 64, 2300, True)])
+def test_pq_training_takes_the_pq_phase_kernel(eng, oracle, d, m, n, integer):
+    """trained codebook, iteration counts bit-equal to the oracle's; integer-valued residuals bring exact ties (the undecided lists);
+    row counts that leave the last 128-row tile ragged; problems that converge at different iterations (the `active` flags)"""
+    x = clustered(n, d, 700 + d + m, integer=integer).astype(f32)
+    if not integer:
+        x = (x * f32(0.37)).astype(f32)
+    cent = clustered(24, d, 701 + d, integer=integer).astype(f32)
+    part, _ = oracle.assign(x, cent)
+    res = oracle.residual(x, cent, part)
+    res[5] = 0
+    res[n - 3] = res[n - 9]
+    before = eng.timing_query("count:xf_pqtrain")[1]
+    cb, iters = eng.pq_train(res, m, max_iters=7, seed=31)
+    assert eng.timing_query("count:xf_pqtrain")[1] > before, "xf_pqtrain_kernel did not serve the training"
+    ocb, oit = oracle.pq_train(res, m, max_iters=7, seed=31)
+    assert (_np(iters) == oit.astype(np.uint32)).all(), (_np(iters), oit)
+    assert (_np(cb).view(np.uint32) == ocb.view(np.uint32)).all()
+
+
+def test_pq_training_kernel_long_run_converges_like_the_oracle(eng, oracle):
+    """enough iterations for some sub-quantisers to converge before others: converged problems are skipped, not recomputed"""
+    n, d, m = 4096, 128, 16
+    rng = np.random.default_rng(77)
+    res = rng.normal(0, 1, (n, d)).astype(f32)
+    res[:, :32] = np.rint(res[:, :32] * 2)          # four sub-quantisers over a tiny alphabet: they converge within a few iterations
+    before = eng.timing_query("count:xf_pqtrain")[1]
+    cb, iters = eng.pq_train(res, m, max_iters=30, seed=5)
+    assert eng.timing_query("count:xf_pqtrain")[1] > before
+    ocb, oit = oracle.pq_train(res, m, max_iters=30, seed=5)
+    assert (_np(iters) == oit.astype(np.uint32)).all(), (_np(iters), oit)
+    assert len(set(oit.tolist())) > 1, "the case is meant to have problems that stop at different iterations"
+    assert (_np(cb).view(np.uint32) == ocb.view(np.uint32)).all()
+
+
+# ---- f32 assign (k-means E-step, lance_hip_assign) through phases 1-3 of the transform kernel (xf_kernel<.., ASSIGN>) ----------------------
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+@pytest.mark.parametrize("n,d,k", [(5037, 128, 256), (3000, 64, 40), (2177, 16, 32), (2500, 112, 300), (4100, 48, 1000)])
+def test_f32_assign_takes_the_transform_kernels_first_half(eng, oracle, metric, n, d, k):
+    """ids and distances bit-equal to the oracle's argmin (kmeans.rs:317-369, argmin_value_float), with and without the k-means balance
+    bias; non-finite and zero rows; two, three and five centroids of a kind (the last forces the recompute list)"""
+    x = spoil(clustered(n, d, 900 + d + k).astype(f32))
+    cent = clustered(k, d, 901 + d + k).astype(f32)
+    if k >= 31:
+        cent = dup_centroids(cent)
+    rng = np.random.default_rng(d + k)
+    bias = (rng.random(k) * (2000.0 if metric == "l2" else 50.0)).astype(f32)
+    for b in (None, bias):
+        before = eng.timing_query("count:xf_assign")[1]
+        ids, dists = eng.assign(x, cent, metric, bias=b)
+        assert eng.timing_query("count:xf_assign")[1] == before + 1, "the transform kernel's first half did not serve this assign call"
+        oi, od = oracle.assign(x, cent, metric, bias=b)
+        ids = _np(ids).view(np.uint32)
+        bad = np.nonzero(ids != oi)[0]
+        assert bad.size == 0, (metric, b is not None, bad[:10], ids[bad[:10]], oi[bad[:10]])
+        ok = oi != oracle.NONE
+        assert (_np(dists)[ok].view(np.uint32) == od[ok].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_kmeans_training_with_a_balance_factor_runs_on_it(eng, oracle, metric):
+    n, d, k = 6000, 128, 64
+    x = clustered(n, d, 33, integer=False).astype(f32)
+    before = eng.timing_query("count:xf_assign")[1]
+    cent, loss, iters = eng.kmeans_train(x, k, max_iters=25, balance_factor=1.0, seed=7, metric=metric)
+    assert eng.timing_query("count:xf_assign")[1] >= before + 2
+    oc, ol, oit, _ = oracle.kmeans_train(x, k, max_iters=25, balance_factor=f32(1.0) / f32(n), seed=7, metric=metric)
+    assert iters == oit and loss == ol
+    assert (_np(cent).view(np.uint32) == oc.view(np.uint32)).all()
