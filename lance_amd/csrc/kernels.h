@@ -120,6 +120,9 @@ int launch_xform_pqtrain(lance_hip_ctx *ctx, const PairwiseArgs &p, int sd, int 
 // f32 rows of d <= 128: sweep + exact re-check in one kernel (phases 1-3 of the transform kernel, with the k-means bias); same outputs as launch_assign
 bool xform_assign_supported(const PairwiseArgs &p, int d, int metric, int batches);
 int launch_xform_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);
+// find_partitions over thousands of lists: the transform kernel's sweep with per-group keys (xform_fused.hip; select: coarse_select_kernel, mfma_assign.hip)
+int launch_xform_sweep_groups(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t *maxbits,
+                              float *gkey, int ng, float *e2);
 // bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);

@@ -47,6 +47,11 @@ struct MaArgs {
   float *sur = nullptr;        // [n][k] surrogate values
   float *e2 = nullptr;         // [n] 2E of the row (the select kernel's candidate margin)
   int tiles_per_block = 0;     // centroid tiles (narrow: MA_CT, wide: MW_CT centroids) per blockIdx.y slice
+  // SUR == 2 (find_partitions over thousands of lists): per (row, group of 16 centroids) the smallest surrogate, the member's slot in its
+  // four lowest mantissa bits, and the group's second smallest; ng = 4 * centroid tiles groups per row; gkey: [n][ng / 2] 16-byte records
+  // {key, key, second, second} of two groups (gsec: unused alias)
+  float *gkey = nullptr, *gsec = nullptr;
+  int ng = 0;
   // second stage of the f16 route: the kernels work on a COMPACTED subset -- planes, id1..3 / cls indexed 0..n-1, row i being row row_map[i] of
   // x / ids / dists (and of the recompute list)
   const uint32_t *row_map = nullptr;

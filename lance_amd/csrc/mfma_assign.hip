@@ -51,13 +51,19 @@ __global__ __launch_bounds__(64) void ma_prep_kernel(const float *__restrict__ c
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (threadIdx.x == 0) {
     cn[c] = s;
-    if (s == s) atomicMax(&maxbits[0], __float_as_uint(fabsf(s)));
+    atomicMax(&maxbits[0], s == s ? __float_as_uint(fabsf(s)) : 0x7F800000u);      // a NaN centroid: an infinite bound, every row takes the exact path
     if (bias) { const float b = fabsf(bias[c]); if (b == b) atomicMax(&maxbits[1], __float_as_uint(b)); }
   }
 }
 
 // KS = d / 16 MFMA k-steps (d <= 128).  DOT: surrogate = -x.c + bias.
-template <int KS, int METRIC, typename TX, bool SUR = false>
+// SUR: 0 = assign (running top-4 per row), 1 = the surrogate matrix [n][k] (find_partitions, small k), 2 = per (row, group of 16
+// centroids) the smallest surrogate with the member's slot in its four lowest mantissa bits, and the group's second smallest
+// (find_partitions over thousands of lists: see coarse_select_kernel)
+__device__ __forceinline__ float ma_min_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float ma_med3_f32(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int KS, int METRIC, typename TX, int SUR = 0>
 __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.active && !p.active[0]) return;
@@ -163,12 +169,14 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
     // D[centroid i][row j]: lane (j, g) holds centroids i = (v & 3) + 8 (v >> 2) + 4 g of each 32-block
     const int c0 = t * MA_CT;
     const float *cnb = cns + (buf * 2 + 0) * MA_CT, *bib = cns + (buf * 2 + 1) * MA_CT;
+    float gk[2] = {0.0f, 0.0f}, gs[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       // surrogates of this lane's 16 centroids of the block; the insertions only run when one of them is below the current
       // fourth-smallest (rare once a few tiles have been seen: with k = 4096 about one block in twenty)
       float sv[16];
       float bm = INFINITY;
+      float g1 = INFINITY, g2 = INFINITY;       // SUR == 2: the group's two smallest keys
 #pragma unroll
       for (int vq = 0; vq < 4; ++vq) {
         const int ib = blk * 32 + 8 * vq + 4 * g;
@@ -178,14 +186,26 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
           const float dot = blk ? acc1[vq * 4 + e] : acc0[vq * 4 + e];
           float v = METRIC == METRIC_DOT ? -dot : __builtin_fmaf(-2.0f, dot, cn4[e]);
           v += bi4[e];
+          if constexpr (SUR == 2) {
+            // a padding centroid: a huge FINITE value (+inf with slot bits would read as a NaN); a NaN surrogate drops out of both
+            // minima (v_min_f32 / v_med3_f32 return the other operands) -- such rows carry a non-finite 2E and take the exact path
+            if (c0 + ib + e >= p.k) v = 3.0e38f;
+            const float key = __uint_as_float((__float_as_uint(v) & 0xFFFFFFF0u) | (uint32_t)(vq * 4 + e));
+            g2 = ma_med3_f32(g1, g2, key);
+            g1 = ma_min_f32(g1, key);
+          } else {
           if (c0 + ib + e >= p.k) v = INFINITY;
           sv[vq * 4 + e] = v;
           bm = fminf(bm, v);
-          if constexpr (SUR) {
+          if constexpr (SUR == 1) {
             const int64_t srow = row0 + wave * 32 + j;
             if (srow < p.n && c0 + ib + e < p.k) p.sur[srow * p.k + c0 + ib + e] = v;
           }
+          }
         }
+      }
+      if constexpr (SUR == 2) {
+        gk[blk] = g1; gs[blk] = g2;
       }
       if constexpr (!SUR) {
       if (bm < tp.m4) {
@@ -195,6 +215,13 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
           for (int e = 0; e < 4; ++e) top4_insert(tp, sv[vq * 4 + e], (uint32_t)(c0 + blk * 32 + 8 * vq + 4 * g + e));
       }
       }
+    }
+    if constexpr (SUR == 2) {
+      // group (tile t, half g, block blk) -> index gi = 4 t + 2 g + blk; the lane's two groups leave as ONE 16-byte store {key, key, second,
+      // second} at [row][2 ng] floats, offset 4 (gi >> 1): the two lanes of a row fill a whole 32-byte sector per instruction (8-byte
+      // pieces into two arrays measured 1.5 ms per 10,000 x 65,536 sweep, most of it partial-sector writes)
+      const int64_t srow = row0 + wave * 32 + j;
+      if (srow < p.n) *reinterpret_cast<f4 *>(p.gkey + srow * 2 * p.ng + (int64_t)(t * 2 + g) * 4) = f4{gk[0], gk[1], gs[0], gs[1]};
     }
     if (t + 1 < ntiles) tile_store(buf ^ 1);
     __syncthreads();
@@ -900,7 +927,20 @@ int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int met
 //   remainder first, lane-ordered fold: dist_exact_rt's value), sorted by (total_cmp key, index), the first nprobes emitted.
 // A row with a NaN / overflowed bound, or with more candidates than the list holds (ties: duplicate centroids), is answered by
 // the same wave from exact distances to ALL centroids -- rare, slow, and still the reference's result.
+//
+// Thousands of lists (round 6; C4: 4096, C5: 65,536).  The matrix is [nq][nlist] floats -- 2.6 GB per 10,000-query batch at C5, written in
+// 16-byte pieces at a 256 KiB stride and read twice by the select kernel: 5.1 of the batch's 8 ms (profiles/r06w_bench_c5_*).  GROUPS = true:
+// the sweep keeps, per (query, group of 16 centroids = one lane's share of a 32-centroid block), the smallest surrogate with the member's
+// slot in its four lowest mantissa bits (key) and the group's second smallest key -- 8 bytes per group, 1 / 8 of the matrix.  Then
+//   T0   = the nprobes-th smallest of the lanes' four smallest group keys -- nprobes DISTINCT centroids have key <= T0;
+//   a centroid of the reference's answer has s <= T0 + 2E + delta, key <= T0 + 2E + 2 delta =: thr (delta = 2^-19 |s| <= 2^-5 E for the cleared
+//   bits; the margin is widened by 1/16): it is its group's key holder and that key is <= thr, or the group's SECOND key is <= thr --
+//   cand = { key holders of groups with key <= thr }  +  { all 16 members of groups whose second key is <= thr } (one query in seven has one).
+// Exact distances, sort and emission are unchanged; the exact-path fall-back writes its distances into the (otherwise untouched) matrix row.
 constexpr int CS_CAP = 128;     // candidates per query (two per lane in the final sort)
+constexpr int CS_CAP_G = 512;   // ... with per-group keys: a group with two members in reach brings all sixteen (trained centroids of structureless data:
+                                // one query in a few thousand has ~100 centroids inside the margin, and its exact-path fall-back against 65,536
+                                // centroids is one wave's work for milliseconds -- 9.5 ms per batch at C5, gpurun r06za); the final sort merges 64 at a time
 
 template <int METRIC>
 __device__ __forceinline__ float cs_group_distance(const float *wrow, const float *__restrict__ y, int d, int lane) {
@@ -944,32 +984,33 @@ __device__ __forceinline__ float cs_group_distance(const float *wrow, const floa
   return finish_metric<METRIC>(s + tot);
 }
 
-template <int METRIC>
+template <int METRIC, bool GROUPS = false>
 __global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ sur, const float *__restrict__ e2, const float *__restrict__ q,
                                                             const float *__restrict__ cent, int nq, int nlist, int d, int nprobes,
                                                             uint32_t *__restrict__ part_ids, float *__restrict__ dists,
-                                                            uint32_t *__restrict__ n_exact_rows) {
+                                                            uint32_t *__restrict__ n_exact_rows, const float *__restrict__ gkey = nullptr,
+                                                            const float *__restrict__ gsec = nullptr, int ng = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4;
   const int qi = blockIdx.x * 4 + wave;
   if (qi >= nq) return;                       // no workgroup-level barrier below: waves are independent
   const int dpad = (d + 3) & ~3;
+  constexpr int CAP = GROUPS ? CS_CAP_G : CS_CAP;
   float *wrow = reinterpret_cast<float *>(smem) + (size_t)wave * dpad;
-  unsigned long long *ck = reinterpret_cast<unsigned long long *>(smem + (size_t)4 * dpad * 4) + (size_t)wave * CS_CAP;   // (key << 32) | centroid
-  uint32_t *cl = reinterpret_cast<uint32_t *>(smem + (size_t)4 * dpad * 4 + (size_t)4 * CS_CAP * 8) + (size_t)wave * CS_CAP;
+  unsigned long long *ck = reinterpret_cast<unsigned long long *>(smem + (size_t)4 * dpad * 4) + (size_t)wave * CAP;   // (key << 32) | centroid
+  uint32_t *cl = reinterpret_cast<uint32_t *>(smem + (size_t)4 * dpad * 4 + (size_t)4 * CAP * 8) + (size_t)wave * CAP;
   const float *qv = q + (int64_t)qi * d;
   for (int e = lane; e < d; e += 64) wrow[e] = qv[e];
   float *row = sur + (int64_t)qi * nlist;
-  const float E2 = e2[qi];
+  const float E2 = GROUPS ? e2[qi] * 1.0625f : e2[qi];      // (GROUPS: + 2 delta for the keys' cleared mantissa bits)
+  const float *gk = GROUPS ? gkey + (int64_t)qi * 2 * ng : nullptr;      // per pair of groups {key, key, second, second}
   // pass 1: the four smallest values of every lane (a NaN anywhere sends the row to the exact path).  The nprobes-th smallest
   // of these 256 values bounds the nprobes-th smallest of the row from above (they are distinct elements), and unlike the
   // nprobes-th smallest of 64 lane MINIMA it stays close to it when nprobes approaches 64 (r04b: at nprobes = 50 the minima
   // gave ~90 candidates per query, most rows overflowed the list and took the exact path: 4.3 ms per 1000 queries).
   float m0 = INFINITY, m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
   bool bad = !(E2 < INFINITY) || !(E2 > 7.888609052210118e-31f);      // (2 * 2^-100 scale: products in the denormal range -> exact path)
-  for (int i = lane; i < nlist; i += 64) {
-    const float v = row[i];
-    bad |= v != v;
+  auto ins4 = [&](float v) {
     if (v < m3) {
       if (v < m2) {
         m3 = m2;
@@ -979,6 +1020,19 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ 
         } else m2 = v;
       } else m3 = v;
     }
+  };
+  if constexpr (GROUPS) {
+    for (int i = lane * 4; i < 2 * ng; i += 256) {      // (one 16-byte record per lane and round: two keys, two seconds)
+      const f4 v = *reinterpret_cast<const f4 *>(gk + i);
+      bad |= (v.x != v.x) | (v.y != v.y);
+      ins4(v.x); ins4(v.y);
+    }
+  } else {
+  for (int i = lane; i < nlist; i += 64) {
+    const float v = row[i];
+    bad |= v != v;
+    ins4(v);
+  }
   }
   bad = __any(bad);
   // bitonic network over the 256 values: element e = register e / 64 of lane e % 64 (as select_probes_wave_kernel)
@@ -1011,17 +1065,56 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ 
   const float thr = __shfl(sv4[0], nprobes - 1, 64) + E2;     // nprobes <= 64 (host); +inf when the row has fewer than nprobes values
   uint32_t cnt = 0;
   if (!bad) {
+    if constexpr (GROUPS) {
+      // group gi = 4 t + 2 g + blk holds centroids 64 t + 32 blk + 8 (slot >> 2) + 4 g + (slot & 3), slot = 0 .. 15
+      for (int base = 0; base < ng; base += 64) {
+        const int gi = base + lane;
+        const float kv = gi < ng ? gk[(gi >> 1) * 4 + (gi & 1)] : INFINITY, sv = gi < ng ? gk[(gi >> 1) * 4 + 2 + (gi & 1)] : INFINITY;
+        const bool take = kv <= thr, whole = sv <= thr;
+        const int cbase = (gi >> 2) * 64 + (gi & 1) * 32 + ((gi >> 1) & 1) * 4;
+        const unsigned long long mask = __ballot(take && !whole);
+        if (take && !whole) {
+          const uint32_t slot = __float_as_uint(kv) & 15u;
+          const int c = cbase + 8 * (int)(slot >> 2) + (int)(slot & 3u);
+          const uint32_t pos = cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+          if (pos < (uint32_t)CAP && c < nlist) cl[pos] = (uint32_t)c;
+          if (c >= nlist) bad = true;      // (a padding slot under the threshold: only with a threshold beyond every real value)
+        }
+        cnt += (uint32_t)__popcll(mask);
+        unsigned long long wm = __ballot(whole);      // groups with two members in reach: all sixteen, one group at a time (rare)
+        while (wm) {
+          const int src = __ffsll((long long)wm) - 1;
+          wm &= wm - 1ull;
+          const int cb = __shfl(cbase, src, 64);
+          if (lane < 16) {
+            const int c = cb + 8 * (lane >> 2) + (lane & 3);
+            const bool in = c < nlist;
+            const unsigned long long m16 = __ballot(in) & 0xFFFFull;
+            if (in) {
+              const uint32_t pos = cnt + (uint32_t)__popcll(m16 & ((1ull << lane) - 1ull));
+              if (pos < (uint32_t)CAP) cl[pos] = (uint32_t)c;
+            }
+          }
+          int n_in = 0;      // (the same count on every lane)
+#pragma unroll
+          for (int sl = 0; sl < 16; ++sl) n_in += (cb + 8 * (sl >> 2) + (sl & 3)) < nlist ? 1 : 0;
+          cnt += (uint32_t)n_in;
+        }
+      }
+      bad = __any(bad);
+    } else {
     for (int base = 0; base < nlist; base += 64) {
       const int i = base + lane;
       const bool take = i < nlist && row[i] <= thr;
       const unsigned long long mask = __ballot(take);
       if (take) {
         const uint32_t pos = cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < (uint32_t)CS_CAP) cl[pos] = (uint32_t)i;
+        if (pos < (uint32_t)CAP) cl[pos] = (uint32_t)i;
       }
       cnt += (uint32_t)__popcll(mask);
     }
-    if (cnt > (uint32_t)CS_CAP || cnt < (uint32_t)nprobes) bad = true;
+    }
+    if (cnt > (uint32_t)CAP || cnt < (uint32_t)nprobes) bad = true;
   }
   __builtin_amdgcn_wave_barrier();
   if (bad) {
@@ -1062,31 +1155,31 @@ __global__ __launch_bounds__(256) void coarse_select_kernel(float *__restrict__ 
     if (ci < cnt && (lane & 15) == 0) ck[ci] = ((unsigned long long)order_key(v) << 32) | c;
   }
   __builtin_amdgcn_wave_barrier();
+  // the 64 smallest (key, centroid) of the candidates, ascending, in register 0: the first 64 candidates, then 64 more at a time through a
+  // bitonic network over 128 elements (element e = register e / 64 of lane e % 64) -- one pass for up to 128 candidates
   unsigned long long v2[2];
+  v2[0] = (uint32_t)lane < cnt ? ck[lane] : ~0ull;
+  for (uint32_t base = 64;; base += 64) {
+    v2[1] = base + (uint32_t)lane < cnt ? ck[base + (uint32_t)lane] : ~0ull;
 #pragma unroll
-  for (int jr = 0; jr < 2; ++jr) {
-    const uint32_t e = (uint32_t)(jr * 64 + lane);
-    v2[jr] = e < cnt ? ck[e] : ~0ull;
-  }
-  // bitonic network over 128 elements: element e = register e / 64 of lane e % 64
+    for (int k2 = 2; k2 <= 128; k2 <<= 1) {
 #pragma unroll
-  for (int k2 = 2; k2 <= 128; k2 <<= 1) {
+      for (int dd = k2 >> 1; dd > 0; dd >>= 1) {
+        if (dd >= 64) {
+          const unsigned long long a = v2[0], b = v2[1];      // k2 = 128: one ascending sequence
+          if (a > b) { v2[0] = b; v2[1] = a; }
+        } else {
 #pragma unroll
-    for (int dd = k2 >> 1; dd > 0; dd >>= 1) {
-      if (dd >= 64) {
-        const bool up = true;       // k2 = 128: one ascending sequence
-        const unsigned long long a = v2[0], b = v2[1];
-        if ((a > b) == up) { v2[0] = b; v2[1] = a; }
-      } else {
-#pragma unroll
-        for (int jr = 0; jr < 2; ++jr) {
-          const int e = jr * 64 + lane;
-          const unsigned long long o = __shfl_xor(v2[jr], dd, 64);
-          const bool up = (e & k2) == 0, lower = (lane & dd) == 0;
-          v2[jr] = (lower == up) ? (v2[jr] < o ? v2[jr] : o) : (v2[jr] > o ? v2[jr] : o);
+          for (int jr = 0; jr < 2; ++jr) {
+            const int e = jr * 64 + lane;
+            const unsigned long long o = __shfl_xor(v2[jr], dd, 64);
+            const bool up = (e & k2) == 0, lower = (lane & dd) == 0;
+            v2[jr] = (lower == up) ? (v2[jr] < o ? v2[jr] : o) : (v2[jr] > o ? v2[jr] : o);
+          }
         }
       }
     }
+    if (base + 64 >= cnt) break;      // (wave-uniform)
   }
   if (lane < nprobes) {       // nprobes <= 64: the answer sits in register 0
     part_ids[(int64_t)qi * nprobes + lane] = (uint32_t)v2[0];
@@ -1116,8 +1209,13 @@ static void coarse_launch_narrow(lance_hip_ctx *ctx, const MaArgs &a, int metric
   const size_t lds_x = (size_t)MA_ROWS * (D + 4) * 4;
   const size_t lds_c = (size_t)2 * 2 * MA_CT * (D + 8) * 2 + (size_t)2 * 2 * MA_CT * 4;
   const size_t lds = std::max(lds_x, lds_c);
-  if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_DOT, float, true>), grid, dim3(256), lds, ctx->stream, a);
-  else hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_L2, float, true>), grid, dim3(256), lds, ctx->stream, a);
+  if (a.gkey) {
+    if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_DOT, float, 2>), grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_L2, float, 2>), grid, dim3(256), lds, ctx->stream, a);
+    return;
+  }
+  if (metric == METRIC_DOT) hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_DOT, float, 1>), grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((ma_top3_kernel<KS, METRIC_L2, float, 1>), grid, dim3(256), lds, ctx->stream, a);
 }
 
 // part_ids [nq][nprobes], dists [nq][nprobes] or NULL; matrix: [nq][nlist] scratch of the caller.  Enqueues only.
@@ -1131,18 +1229,33 @@ int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_
   uint32_t *maxbits = ctx->scratch_t<uint32_t>("cq.maxbits", 4);   // [0] max |c|^2, [1] unused (no bias), [2] rows answered by the exact path
   float *e2 = ctx->scratch_t<float>("cq.e2", (size_t)nq);
   if (!chi || !clo || !cn || !maxbits || !e2) return LANCE_HIP_ENOMEM;
+  // thousands of lists: per-group keys instead of the [nq][nlist] matrix (see coarse_select_kernel); LANCE_HIP_COARSE_GROUPS=0 / =n: off / from n lists
+  static const int groups_from = getenv("LANCE_HIP_COARSE_GROUPS") ? atoi(getenv("LANCE_HIP_COARSE_GROUPS")) : 1024;
+  const bool groups = !wide && groups_from > 0 && nlist >= (uint32_t)std::max(groups_from, 256);
+  const int ng = groups ? (int)cdiv(nlist, MA_CT) * 4 : 0;
+  float *gkey = nullptr, *gsec = nullptr;
+  if (groups) {
+    gkey = ctx->scratch_t<float>("cq.gkey", (size_t)nq * 2 * ng);      // [nq][ng / 2] records {key, key, second, second}
+    gsec = gkey;
+    if (!gkey) return LANCE_HIP_ENOMEM;
+  }
   LH_CHECK_HIP(lh::memset_async(maxbits, 0, 16, ctx->stream));
-  {
+  static const bool groups_ma = getenv("LANCE_HIP_COARSE_GROUPS_MA") != nullptr;      // A/B: the per-group keys from ma_top3_kernel<.., 2> instead of the transform kernel's sweep
+  if (groups && !groups_ma) {
+    ScopedTimer t(ctx, "dist_matrix");
+    LH_TRY(launch_xform_sweep_groups(ctx, metric, q, nq, d, cent, nlist, maxbits, gkey, ng, e2));
+  } else {
     ScopedTimer t(ctx, "dist_matrix");
     hipLaunchKernelGGL(ma_prep_kernel, dim3(nlist), dim3(64), 0, ctx->stream, cent, (int)nlist, d, dp, nullptr, chi, clo, cn, maxbits, nullptr);
     MaArgs a;
     a.x = q; a.n = nq; a.ldx = d; a.d = d; a.k = (int)nlist;
     a.chi = chi; a.clo = clo; a.cn = cn; a.bias = nullptr; a.maxbits = maxbits; a.cent = cent;
     a.sur = matrix; a.e2 = e2; a.active = nullptr;
+    a.gkey = gkey; a.gsec = gsec; a.ng = ng;
     const unsigned rblocks = (unsigned)cdiv(nq, wide ? MW_ROWS : MA_ROWS);
     const int ntiles = (int)cdiv(nlist, wide ? MW_CT : MA_CT);
     // enough slices to put about two workgroups on every CU
-    int slices = (int)std::min<uint64_t>((uint64_t)ntiles, std::max<uint64_t>(1, cdiv((uint64_t)2 * ctx->num_cus, rblocks)));
+    int slices = (int)std::min<uint64_t>((uint64_t)ntiles, std::max<uint64_t>(1, ((uint64_t)2 * ctx->num_cus) / rblocks));      // (rounded DOWN: 553 workgroups on 512 slots are two rounds, the second one almost empty -- 1.42 ms instead of 0.8 for 10,000 x 65,536, gpurun r06zf)
     a.tiles_per_block = (int)cdiv((uint64_t)ntiles, (uint64_t)slices);
     slices = (int)cdiv((uint64_t)ntiles, (uint64_t)a.tiles_per_block);
     const dim3 grid(rblocks, (unsigned)slices);
@@ -1172,13 +1285,29 @@ int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_
   {
     ScopedTimer t(ctx, "select_probes");
     const int dpad = (d + 3) & ~3;
-    const size_t lds = (size_t)4 * dpad * 4 + (size_t)4 * CS_CAP * 8 + (size_t)4 * CS_CAP * 4;
-    if (metric == METRIC_DOT)
+    const int cap = groups ? CS_CAP_G : CS_CAP;
+    const size_t lds = (size_t)4 * dpad * 4 + (size_t)4 * cap * 8 + (size_t)4 * cap * 4;
+    if (groups) {
+      ctx->count_stage("coarse_groups");
+      if (metric == METRIC_DOT)
+        hipLaunchKernelGGL((coarse_select_kernel<METRIC_DOT, true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), lds, ctx->stream, matrix, e2, q, cent, (int)nq,
+                           (int)nlist, d, (int)nprobes, part_ids, dists, maxbits + 2, gkey, gsec, ng);
+      else
+        hipLaunchKernelGGL((coarse_select_kernel<METRIC_L2, true>), dim3((unsigned)cdiv(nq, 4)), dim3(256), lds, ctx->stream, matrix, e2, q, cent, (int)nq,
+                           (int)nlist, d, (int)nprobes, part_ids, dists, maxbits + 2, gkey, gsec, ng);
+    } else if (metric == METRIC_DOT)
       hipLaunchKernelGGL((coarse_select_kernel<METRIC_DOT>), dim3((unsigned)cdiv(nq, 4)), dim3(256), lds, ctx->stream, matrix, e2, q, cent, (int)nq, (int)nlist,
                          d, (int)nprobes, part_ids, dists, maxbits + 2);
     else
       hipLaunchKernelGGL((coarse_select_kernel<METRIC_L2>), dim3((unsigned)cdiv(nq, 4)), dim3(256), lds, ctx->stream, matrix, e2, q, cent, (int)nq, (int)nlist,
                          d, (int)nprobes, part_ids, dists, maxbits + 2);
+  }
+  static const bool stats = getenv("LANCE_HIP_COARSE_STATS") != nullptr;      // diagnosis: how many queries the select kernel answered from exact distances to every centroid
+  if (stats && !ctx->capturing) {
+    uint32_t h[4];
+    LH_CHECK_HIP(hipMemcpyAsync(h, maxbits, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    fprintf(stderr, "[coarse] nq=%u nlist=%u nprobes=%u groups=%d: %u queries took the exact path\n", nq, nlist, nprobes, groups ? 1 : 0, h[2]);
   }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;

@@ -84,6 +84,12 @@ struct XfArgs {
   int col_base = 0;              // xf_tail_kernel: first column of this launch's blocks
   // xf_pqtrain_kernel (codebook training E-step): sub-quantiser b's sub-vector of row r at tr_x + b * tr_boff + r * tr_ldx; ids / dists [b][tr_stride]
   const uint8_t *active = nullptr;      // [m_total] 0: the sub-quantiser's problem has converged, nothing of it is touched (ASSIGN: [1], the one problem)
+  // MODE 2 (find_partitions over thousands of lists, see coarse_select_kernel in mfma_assign.hip): per (row, group of 16 centroids = one lane's
+  // share of a 32-centroid block) the smallest surrogate with the member's register number in its four lowest mantissa bits and the group's
+  // second smallest, as 16-byte records {key, key, second, second} of a lane's two groups at gkey[row][2 ng]; e2[row] = 2E; the centroid tiles
+  // are split over blockIdx.y
+  float *gkey = nullptr, *e2 = nullptr;
+  int ng = 0, tiles_per_block = 0;
   const float *bias = nullptr;          // ASSIGN (k-means E-step with a balance factor): argmin over dist + bias[c] (kmeans.rs:317-369); maxbits[1] = max |bias|
   const float *tr_x = nullptr, *tr_cb = nullptr;
   int64_t tr_ldx = 0, tr_boff = 0, tr_stride = 0;
@@ -690,8 +696,10 @@ __global__ __launch_bounds__(256, 2) void xf_pqtrain_kernel(XfArgs p) {
 // ASSIGN = true: phases 1-3 only (rows -> sweep -> exact re-check), with the k-means bias and the problem's `active` flag: the E-step
 // of the IVF training and every other f32 assign call of d <= 128 (launch_xform_assign).  One kernel instead of round 5's
 // ma_top3_kernel + ma_finalize_kernel (the rows read twice, the candidates through HBM).
-template <int KS, int SD, int METRIC, typename TX, bool PROF = false, bool ASSIGN = false>
+// MODE 2: phases 1-2 only, the sweep's epilogue keeps per-group keys instead of the row's four smallest (XfArgs::gkey).
+template <int KS, int SD, int METRIC, typename TX, bool PROF = false, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
+  constexpr bool ASSIGN = MODE == 1, GROUPS = MODE == 2;
   if constexpr (ASSIGN) { if (p.active && !p.active[0]) return; }
   long long pa[6] = {0, 0, 0, 0, 0, 0}, pprev = 0;      // PROF: s_memtime ticks per phase, summed over this workgroup's row tiles
   uint32_t pc_und = 0;
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   // round 5 -- load, LDS store, next load -- paid sixteen dependent ones, 110k of a wave's 335k cycles; lanes fetching their own
   // 16-byte pieces straight from HBM measured 54k: four times the line requests).  (Persistent workgroups that request the next
   // tile's rows before the PQ phase were tried -- gpurun r06i: the 64 staging registers spill, 1.03 -> 1.36 ms.)
-  if constexpr (!ASSIGN) { if (threadIdx.x < M) q_cnt[threadIdx.x] = 0u; }
+  if constexpr (MODE == 0) { if (threadIdx.x < M) q_cnt[threadIdx.x] = 0u; }
   const int64_t row = row0 + wave * 32 + j;
   const bool valid = row < p.n;
   constexpr int NLD = MA_ROWS * (D / 4) / 256;        // 4-element pieces per thread (16 at D = 128)
@@ -792,12 +800,14 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     }
   };
   Top4 tp{INFINITY, INFINITY, INFINITY, INFINITY, LANCE_HIP_NONE, LANCE_HIP_NONE, LANCE_HIP_NONE};
-  tile_fetch(0);
-  tile_store(0);
+  int t_first = 0, t_end = ntiles;
+  if constexpr (GROUPS) { t_first = (int)blockIdx.y * p.tiles_per_block; t_end = min(ntiles, t_first + p.tiles_per_block); }
+  tile_fetch(t_first);
+  tile_store(t_first & 1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_first; t < t_end; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) tile_fetch(t + 1);
+    if (t + 1 < t_end) tile_fetch(t + 1);
     const uint16_t *tl = cbuf + (size_t)buf * MA_CT * CS;
     const uint16_t *r0 = tl + j * CS + g * 8, *r1 = tl + (32 + j) * CS + g * 8;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -824,10 +834,32 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
     // running fourth-smallest (with k = 4096 about one tile in twenty) the tile's own four smallest -- value bits with the
     // register number in the five lowest mantissa bits (2^-18 relative, inside E), one v_and_or_b32 + three v_med3_u32 + one
     // v_min_u32 per centroid -- are folded into the running four.
-    uint32_t bm = min(__float_as_uint(acc0[0]), __float_as_uint(acc1[0]));
+    if constexpr (GROUPS) {
+      // surrogates are >= 0: their bit patterns order like the values.  A padding centroid's +inf (and any NaN) is clamped to a huge finite
+      // key: the select kernel compares the records as floats
+      uint32_t k1[2], k2[2];
 #pragma unroll
-    for (int v = 1; v < 16; ++v) bm = min(bm, min(__float_as_uint(acc0[v]), __float_as_uint(acc1[v])));
-    if (bm < __float_as_uint(tp.m4)) {
+      for (int blk = 0; blk < 2; ++blk) {
+        uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const uint32_t key = (__float_as_uint(blk ? acc1[v] : acc0[v]) & 0xFFFFFFF0u) | (uint32_t)v;
+          a2 = xf_med3(a1, a2, key);
+          a1 = min(a1, key);
+        }
+        k1[blk] = min(a1, 0x7F000000u); k2[blk] = min(a2, 0x7F000000u);
+      }
+      if (valid)
+        *reinterpret_cast<f4 *>(p.gkey + row * 2 * p.ng + (int64_t)(t * 2 + g) * 4) =
+            f4{__uint_as_float(k1[0]), __uint_as_float(k1[1]), __uint_as_float(k2[0]), __uint_as_float(k2[1])};
+    }
+    uint32_t bm = 0xFFFFFFFFu;
+    if constexpr (!GROUPS) {
+      bm = min(__float_as_uint(acc0[0]), __float_as_uint(acc1[0]));
+#pragma unroll
+      for (int v = 1; v < 16; ++v) bm = min(bm, min(__float_as_uint(acc0[v]), __float_as_uint(acc1[v])));
+    }
+    if (!GROUPS && bm < __float_as_uint(tp.m4)) {
       uint32_t t1 = 0xFFFFFFFFu, t2 = 0xFFFFFFFFu, t3 = 0xFFFFFFFFu, t4 = 0xFFFFFFFFu;
 #pragma unroll
       for (int li = 0; li < 32; ++li) {
@@ -844,10 +876,14 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
       };
       fold(t1); fold(t2); fold(t3); fold(t4);
     }
-    if (t + 1 < ntiles) tile_store(buf ^ 1);
+    if (t + 1 < t_end) tile_store(buf ^ 1);
     __syncthreads();
   }
   mark(1);
+  if constexpr (GROUPS) {
+    if (g == 0 && valid && blockIdx.y == 0) p.e2[row] = E2;
+    return;
+  }
   // the two lanes of a row hold disjoint centroid subsets: merge the partner's four
   {
     const float pm1 = __shfl_xor(tp.m1, 32, 64), pm2 = __shfl_xor(tp.m2, 32, 64), pm3 = __shfl_xor(tp.m3, 32, 64), pm4 = __shfl_xor(tp.m4, 32, 64);
@@ -1185,8 +1221,8 @@ template <int KS>
 static void xf_assign_launch_ks(lance_hip_ctx *ctx, const XfArgs &a, int metric) {
   constexpr size_t lds = xf_lds_bytes<KS, 8>();
   const dim3 grid(xf_grid(ctx, a.n));
-  if (metric == METRIC_DOT) hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_DOT, float, false, true>), grid, dim3(256), lds, ctx->stream, a);
-  else hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_L2, float, false, true>), grid, dim3(256), lds, ctx->stream, a);
+  if (metric == METRIC_DOT) hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_DOT, float, false, 1>), grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_L2, float, false, 1>), grid, dim3(256), lds, ctx->stream, a);
 }
 
 int launch_xform_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric) {
@@ -1220,6 +1256,46 @@ int launch_xform_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int me
   ma.x = p.x; ma.n = p.n; ma.ldx = p.ldx; ma.d = d; ma.k = p.k; ma.cent = p.cent; ma.bias = p.bias;
   ma.ids = p.ids; ma.dists = p.dists; ma.check_finite = p.check_finite ? 1 : 0; ma.fb_cnt = a.afb_cnt; ma.fb_rows = afb_rows; ma.active = p.active;
   LH_TRY(ma_recompute_launch(ctx, ma, metric, LANCE_HIP_F32));
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+// ---- find_partitions over thousands of lists: the sweep with per-group keys (the select kernel is coarse_select_kernel<.., GROUPS>) -------
+template <int KS>
+static void xf_groups_launch_ks(lance_hip_ctx *ctx, const XfArgs &a, int metric, dim3 grid) {
+  constexpr size_t lds = xf_lds_bytes<KS, 8>();
+  if (metric == METRIC_DOT) hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_DOT, float, false, 2>), grid, dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((xf_kernel<KS, 8, METRIC_L2, float, false, 2>), grid, dim3(256), lds, ctx->stream, a);
+}
+
+// q: [nq][d] f32, d a multiple of 16 and <= 128; maxbits: four zeroed words ([0] receives max |c|^2); gkey: [nq][2 ng] floats, ng = 4 * ceil(nlist / 64)
+int launch_xform_sweep_groups(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t *maxbits,
+                              float *gkey, int ng, float *e2) {
+  const int kpad = (int)((nlist + MA_CT - 1) / MA_CT * MA_CT);
+  uint16_t *cpl = ctx->scratch_t<uint16_t>("cq.cpl", (size_t)kpad * (2 * d + 16));
+  if (!cpl) return LANCE_HIP_ENOMEM;
+  if (metric == METRIC_DOT) hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_DOT>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, (int)nlist, d, cpl, maxbits, (const float *)nullptr, (const uint8_t *)nullptr);
+  else hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_L2>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, (int)nlist, d, cpl, maxbits, (const float *)nullptr, (const uint8_t *)nullptr);
+  XfArgs a{};
+  a.x = q; a.n = nq; a.ldx = d; a.k = (int)nlist; a.cpl = cpl; a.maxbits = maxbits; a.cent = cent; a.d_total = d;
+  a.gkey = gkey; a.ng = ng; a.e2 = e2;
+  const unsigned rblocks = (unsigned)cdiv(nq, MA_ROWS);
+  const int ntiles = kpad / MA_CT;
+  // enough slices of the centroid range to put about two workgroups on every CU
+  int slices = (int)std::min<uint64_t>((uint64_t)ntiles, std::max<uint64_t>(1, ((uint64_t)2 * ctx->num_cus) / rblocks));      // (rounded DOWN: 553 workgroups on 512 slots are two rounds, the second one almost empty -- 1.42 ms instead of 0.8 for 10,000 x 65,536, gpurun r06zf)
+  a.tiles_per_block = (int)cdiv((uint64_t)ntiles, (uint64_t)slices);
+  slices = (int)cdiv((uint64_t)ntiles, (uint64_t)a.tiles_per_block);
+  const dim3 grid(rblocks, (unsigned)slices);
+  switch (d / 16) {
+    case 1: xf_groups_launch_ks<1>(ctx, a, metric, grid); break;
+    case 2: xf_groups_launch_ks<2>(ctx, a, metric, grid); break;
+    case 3: xf_groups_launch_ks<3>(ctx, a, metric, grid); break;
+    case 4: xf_groups_launch_ks<4>(ctx, a, metric, grid); break;
+    case 5: xf_groups_launch_ks<5>(ctx, a, metric, grid); break;
+    case 6: xf_groups_launch_ks<6>(ctx, a, metric, grid); break;
+    case 7: xf_groups_launch_ks<7>(ctx, a, metric, grid); break;
+    default: xf_groups_launch_ks<8>(ctx, a, metric, grid); break;
+  }
   LH_CHECK_HIP(hipGetLastError());
   return LANCE_HIP_OK;
 }

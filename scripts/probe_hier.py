@@ -1,4 +1,4 @@
-"""Wall time of the hierarchical IVF trainer (k = 4096, 1M x 128 f32 sample -- the C4 shape) for the LANCE_HIP_HIER_CONTEXTS in the
+"""Wall time of the hierarchical IVF trainer (HIER_K = 4096 lists, HIER_D = 128: a 1M x 128 f32 sample -- the C4 shape; HIER_K=1024 HIER_D=1536: C3) for the LANCE_HIP_HIER_CONTEXTS in the
 environment, and that the centroids equal the library's own sequential loop bit for bit.  GPU only."""
 import os, sys, time
 import numpy as np, torch
@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lance_amd import vector as lv
 from lance_amd.vector import default_engine
 
-k = int(os.environ.get("HIER_K", "4096")); d = 128
+k = int(os.environ.get("HIER_K", "4096")); d = int(os.environ.get("HIER_D", "128"))
 rng = np.random.default_rng(7)
 cent = rng.standard_normal((512, d)).astype(np.float32) * 3
 x = (cent[rng.integers(0, 512, k * 256)] + rng.standard_normal((k * 256, d)).astype(np.float32)).astype(np.float32)

@@ -35,8 +35,9 @@ def _cases():
     eng = Engine()
     rng = np.random.default_rng(2024)
     n_cases = 0
+    # (from 1024 lists on -- or from LANCE_HIP_COARSE_GROUPS lists -- rows of <= 128 elements take the per-group keys instead of the matrix)
     for d, nlist, nq in ((16, 32, 300), (64, 100, 257), (128, 256, 1000), (96, 300, 129), (128, 5000, 200), (48, 70, 64),
-                         (1536, 1024, 130), (200, 64, 260), (132, 333, 70), (4096, 65, 5)):
+                         (1536, 1024, 130), (200, 64, 260), (132, 333, 70), (4096, 65, 5), (32, 1024, 300), (16, 65536, 40), (64, 2049, 150)):
         for metric in ("l2", "dot", "cosine"):
             cent = (rng.standard_normal((nlist, d)) * 3).astype(f32)
             q = (cent[rng.integers(0, nlist, nq)] + rng.standard_normal((nq, d)).astype(f32)).astype(f32)
@@ -69,8 +70,36 @@ def _cases():
     # (+inf, not NaN: x - NaN keeps the NaN's sign on x86 while the GPU's subtract may flip it, and total_cmp sorts -NaN first)
     cent2 = cent.copy(); cent2[11, 0] = np.inf
     _eq(eng, oracle, q, cent2, 10, "l2", "inf-centroid"); n_cases += 1
+    # the same kinds of ties over 2048 lists (per-group keys): two and five of a kind inside one group of 16 and across groups, a block
+    # of identical centroids larger than the candidate list, a NaN centroid
+    nlist = 2048
+    cent = np.rint(rng.uniform(0, 40, (nlist, d))).astype(f32)
+    cent[7] = cent[300]; cent[65] = cent[64]; cent[129] = cent[133]; cent[1000:1005] = cent[1000]
+    cent[1200:1400] = cent[1200]
+    q = np.rint(rng.uniform(0, 40, (300, d))).astype(f32)
+    q[3] = cent[1200]; q[4] = cent[64]; q[9] = cent[1000]; q[10] = cent[129]
+    q[5, 2] = np.nan; q[6] = np.inf; q[8] = 1e30
+    qd = q.copy(); qd[6] = q[7]; qd[5] = q[4]
+    for nprobes in (1, 10, 50, 64):
+        _eq(eng, oracle, q, cent, nprobes, "l2", ("ties-2048", nprobes)); n_cases += 1
+        _eq(eng, oracle, qd, cent, nprobes, "dot", ("ties-2048-dot", nprobes)); n_cases += 1
+    cent2 = cent.copy(); cent2[11, 0] = np.inf
+    _eq(eng, oracle, q[:40], cent2, 10, "l2", "inf-centroid-2048"); n_cases += 1
+    groups = eng.timing_query("count:coarse_groups")[1]
     eng.close()
-    print(f"coarse mfma cases ok: {n_cases}")
+    print(f"coarse mfma cases ok: {n_cases} (per-group keys served {groups} calls)")
+
+
+def test_find_partitions_per_group_keys_from_256_lists():
+    """every case again with the per-group keys taken from 256 lists on (the default is 1024): the tie / NaN / overflow cases of the
+    512-list set then run through it too"""
+    env = dict(os.environ, LANCE_HIP_MFMA_COARSE="1", LANCE_HIP_COARSE_GROUPS="256")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import tests.test_zz_gpu_coarse_mfma as t; t._cases()" % ROOT],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    import re
+    m = re.search(r"per-group keys served (\d+) calls", r.stdout)
+    assert m and int(m.group(1)) >= 60, r.stdout[-500:]
 
 
 def test_find_partitions_on_matrix_cores_forced_for_small_shapes():
