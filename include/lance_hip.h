@@ -24,7 +24,14 @@
  *     the device.  An index is read-only during searches and may be searched through any
  *     number of contexts at once (tests/test_zz_gpu_threads.py); building / destroying it
  *     while it is being searched is the caller's error.  lance_hip_last_error() is
- *     thread-local.
+ *     thread-local.  A context's own stream is non-blocking (no implicit ordering against the
+ *     legacy default stream).  While one thread's repeated search is being captured into a HIP
+ *     graph (its second call with the same arguments), a DEVICE-WIDE synchronise from another
+ *     thread (hipDeviceSynchronize, torch.cuda.synchronize()) is refused by the runtime and
+ *     invalidates that capture: the library then runs the batch on the plain path, but the
+ *     synchronising thread sees the runtime's error.  Hosts that search from several threads
+ *     wait on streams or events, not on the device (lance_amd/engine.py does), or set
+ *     LANCE_HIP_GRAPH=0.
  *   - "No partition" (all-NaN row; kmeans.rs:1447-1486) is id 0xFFFFFFFF.
  *   - Results are bit-identical to the reference CPU path for ids / codes / distances
  *     (see DESIGN.md for the exact statement and the two documented tie rules).

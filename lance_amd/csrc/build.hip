@@ -283,6 +283,11 @@ lance_hip_index::~lance_hip_index() {
     if (pt->beta_mean) (void)hipFree(pt->beta_mean);
     delete pt;
   }
+  if (cq) {
+    if (cq->cpl) (void)hipFree(cq->cpl);
+    if (cq->maxbits) (void)hipFree(cq->maxbits);
+    delete cq;
+  }
   if (ms) {
     if (ms->cbh) (void)hipFree(ms->cbh);
     if (ms->cbn2) (void)hipFree(ms->cbn2);

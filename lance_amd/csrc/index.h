@@ -45,7 +45,13 @@ struct lance_hip_index {
     float *row_cn2 = nullptr;     // [n] sigma^2 |reconstruction of the stored row|^2
     uint32_t sum_rs = 0, max_rs = 0;   // row slices (of 2048 rows) summed over the partitions / of the largest partition: bound the slice table
   } *ms = nullptr;
-  std::mutex lazy_mu;             // guards the creation of `pt` / `ms` (several contexts / host threads may search one index)
+  // find_partitions over thousands of lists (xform_fused.hip MODE 2): the centroids' bf16 planes [nlist ^ 64][2 d + 16] and max |c|^2, built by the
+  // first such search (they were rebuilt by every call: 65,536 x 128 centroids are 35 MB of planes, ~0.25 of the batch's 1.2 ms sweep stage)
+  struct CqConst {
+    uint16_t *cpl = nullptr;
+    uint32_t *maxbits = nullptr;  // [4] words, [0] = max |c|^2 as float bits
+  } *cq = nullptr;
+  std::mutex lazy_mu;             // guards the creation of `pt` / `ms` / `cq` (several contexts / host threads may search one index)
   uint32_t *part_offsets = nullptr;  // [nlist+1] device
   std::vector<uint32_t> part_offsets_h;
   uint8_t *codes = nullptr;       // [n][code_bytes()] row-major, rows grouped by partition

@@ -121,8 +121,12 @@ int launch_xform_pqtrain(lance_hip_ctx *ctx, const PairwiseArgs &p, int sd, int 
 bool xform_assign_supported(const PairwiseArgs &p, int d, int metric, int batches);
 int launch_xform_assign(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);
 // find_partitions over thousands of lists: the transform kernel's sweep with per-group keys (xform_fused.hip; select: coarse_select_kernel, mfma_assign.hip)
+// cpl_ready / maxbits_ready: the centroid planes and their maxima built earlier by xform_coarse_planes (an index's constants), or NULL
 int launch_xform_sweep_groups(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t *maxbits,
-                              float *gkey, int ng, float *e2);
+                              float *gkey, int ng, float *e2, const uint16_t *cpl_ready = nullptr, const uint32_t *maxbits_ready = nullptr);
+size_t xform_coarse_planes_elems(uint32_t nlist, int d);      // bf16 elements of the planes
+int xform_coarse_planes(lance_hip_ctx *ctx, int metric, const float *cent, uint32_t nlist, int d, uint16_t *cpl, uint32_t *maxbits /* zeroed */);
+bool coarse_groups_shape(int d, uint32_t nlist);             // mfma_assign.hip: find_partitions takes the per-group keys for this shape
 // bf16x3 MFMA candidates + exact re-check (mfma_assign.hip); same outputs as launch_assign
 bool mfma_assign_supported(const PairwiseArgs &p, int d, int batches);
 int launch_assign_mfma(lance_hip_ctx *ctx, const PairwiseArgs &p, int d, int metric);
@@ -161,7 +165,7 @@ int flat_topk_small(lance_hip_ctx *ctx, int metric, int dtype, const void *x, co
 // mfma_assign.hip: the coarse quantiser at query time on the matrix cores (surrogate matrix + exact re-check of the candidates)
 bool coarse_mfma_supported(int metric, int d, uint32_t nq, uint32_t nlist, uint32_t nprobes, bool lanes32, const float *q, const float *cent);
 int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t nprobes,
-                         float *matrix, uint32_t *part_ids, float *dists);
+                         float *matrix, uint32_t *part_ids, float *dists, const uint16_t *cpl_ready = nullptr, const uint32_t *maxbits_ready = nullptr);
 int launch_normalize(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16);   // f16: half-precision arithmetic on f32 containers
 // the same, and the normalised rows once more as a binary16 plane x 2^14 (stride dp = d rounded up to 32) + the squared-norm bound per row
 int launch_normalize_planes(lance_hip_ctx *ctx, const float *x, int64_t n, int d, float *out, bool f16, uint16_t *plane16, int dp, float *n2);

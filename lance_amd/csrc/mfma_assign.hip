@@ -1219,8 +1219,17 @@ static void coarse_launch_narrow(lance_hip_ctx *ctx, const MaArgs &a, int metric
 }
 
 // part_ids [nq][nprobes], dists [nq][nprobes] or NULL; matrix: [nq][nlist] scratch of the caller.  Enqueues only.
+static int coarse_groups_from() {
+  static const int v = getenv("LANCE_HIP_COARSE_GROUPS") ? atoi(getenv("LANCE_HIP_COARSE_GROUPS")) : 1024;
+  return v;
+}
+bool coarse_groups_shape(int d, uint32_t nlist) {
+  static const bool ma = getenv("LANCE_HIP_COARSE_GROUPS_MA") != nullptr;
+  return !ma && d <= 128 && d % 16 == 0 && coarse_groups_from() > 0 && nlist >= (uint32_t)std::max(coarse_groups_from(), 256);
+}
+
 int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t nprobes,
-                         float *matrix, uint32_t *part_ids, float *dists) {
+                         float *matrix, uint32_t *part_ids, float *dists, const uint16_t *cpl_ready, const uint32_t *maxbits_ready) {
   const bool wide = d > 128;
   const int dp = wide ? (d + MW_KC - 1) / MW_KC * MW_KC : d;
   const size_t kd = (size_t)nlist * dp;
@@ -1230,7 +1239,7 @@ int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_
   float *e2 = ctx->scratch_t<float>("cq.e2", (size_t)nq);
   if (!chi || !clo || !cn || !maxbits || !e2) return LANCE_HIP_ENOMEM;
   // thousands of lists: per-group keys instead of the [nq][nlist] matrix (see coarse_select_kernel); LANCE_HIP_COARSE_GROUPS=0 / =n: off / from n lists
-  static const int groups_from = getenv("LANCE_HIP_COARSE_GROUPS") ? atoi(getenv("LANCE_HIP_COARSE_GROUPS")) : 1024;
+  const int groups_from = coarse_groups_from();
   const bool groups = !wide && groups_from > 0 && nlist >= (uint32_t)std::max(groups_from, 256);
   const int ng = groups ? (int)cdiv(nlist, MA_CT) * 4 : 0;
   float *gkey = nullptr, *gsec = nullptr;
@@ -1243,7 +1252,7 @@ int find_partitions_mfma(lance_hip_ctx *ctx, int metric, const float *q, uint32_
   static const bool groups_ma = getenv("LANCE_HIP_COARSE_GROUPS_MA") != nullptr;      // A/B: the per-group keys from ma_top3_kernel<.., 2> instead of the transform kernel's sweep
   if (groups && !groups_ma) {
     ScopedTimer t(ctx, "dist_matrix");
-    LH_TRY(launch_xform_sweep_groups(ctx, metric, q, nq, d, cent, nlist, maxbits, gkey, ng, e2));
+    LH_TRY(launch_xform_sweep_groups(ctx, metric, q, nq, d, cent, nlist, maxbits, gkey, ng, e2, cpl_ready, maxbits_ready));
   } else {
     ScopedTimer t(ctx, "dist_matrix");
     hipLaunchKernelGGL(ma_prep_kernel, dim3(nlist), dim3(64), 0, ctx->stream, cent, (int)nlist, d, dp, nullptr, chi, clo, cn, maxbits, nullptr);

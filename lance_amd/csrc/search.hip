@@ -1036,6 +1036,28 @@ static bool raw_compact_enabled() {
   static const bool off = getenv("LANCE_HIP_NO_RAW_COMPACT") != nullptr;      // A/B switch: always refine from the caller's column
   return !off;
 }
+// find_partitions over thousands of lists: the centroids' bf16 planes as constants of the index (index.h CqConst).  Built by the first
+// uncaptured search of such an index or by lance_hip_index_prewarm; no memory for them, or a capture in progress: the call builds its own.
+int coarse_planes_prepare(lance_hip_ctx *ctx, const lance_hip_index *ix_c, int scan_metric) {
+  lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
+  std::lock_guard<std::mutex> lk(ix->lazy_mu);
+  if (ix->cq || ctx->capturing) return LANCE_HIP_OK;
+  auto *cq = new lance_hip_index::CqConst();
+  bool ok = hipMalloc(reinterpret_cast<void **>(&cq->cpl), xform_coarse_planes_elems(ix->nlist, (int)ix->d) * 2) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&cq->maxbits), 16) == hipSuccess;
+  auto drop = [&]() { if (cq->cpl) (void)hipFree(cq->cpl); if (cq->maxbits) (void)hipFree(cq->maxbits); delete cq; };
+  if (!ok) { (void)hipGetLastError(); drop(); return LANCE_HIP_OK; }
+  if (lh::memset_async(cq->maxbits, 0, 16, ctx->stream) != hipSuccess ||
+      xform_coarse_planes(ctx, scan_metric, ix->centroids, ix->nlist, (int)ix->d, cq->cpl, cq->maxbits) != LANCE_HIP_OK ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {      // (other contexts search the same index: published complete)
+    drop();
+    set_error("find_partitions: building the centroid planes of the index failed");
+    return LANCE_HIP_ERUNTIME;
+  }
+  ix->cq = cq;
+  return LANCE_HIP_OK;
+}
+
 const uint8_t *raw_compact_prepare(lance_hip_ctx *ctx, const lance_hip_index *ix_c) {
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);      // a cache attached to the index, like the scan constants
   if (!raw_compact_enabled() || ix->dtype != LANCE_HIP_F32 || !ix->raw || ix->n_raw == 0 || (ix->d & 15) != 0 ||
@@ -1430,8 +1452,27 @@ int ivfpq_search_enqueue(lance_hip_ctx *ctx, const lance_hip_index *ix, const fl
   // then run the batch on the plain path.  The failed capture may have left its reason in the thread's error string (a scratch slot that
   // would have had to grow): the plain run below succeeds or sets its own.
   for (const char *nm : paths) --ctx->stage_counts[nm];
+  // A capture can also be invalidated from OUTSIDE this call -- another host thread freeing device memory (an index going out of scope: hipFree
+  // synchronises the device, which a capturing stream must not be part of): make sure the stream has left capture mode and that no error of the
+  // dead capture is left for the plain run's first launch to report (tests/test_zz_gpu_threads.py after the large-index tests, gpurun r06zi)
+  {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+      hipGraph_t g2 = nullptr;
+      (void)hipStreamEndCapture(ctx->stream, &g2);
+      if (g2) (void)hipGraphDestroy(g2);
+    }
+    for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+  }
   set_error("");
-  return plain();
+  int prc = plain();
+  if (prc == LANCE_HIP_ERUNTIME) {      // once more on a drained stream
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+    set_error("");
+    prc = plain();
+  }
+  return prc;
 }
 
 static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *q, uint32_t nq, uint32_t k,
@@ -1474,7 +1515,13 @@ static int ivfpq_search_enqueue_impl(lance_hip_ctx *ctx, const lance_hip_index *
   const bool coarse_l32 = ix->dtype == LANCE_HIP_F16 && scan_metric == LANCE_HIP_DOT && d > 16;
   if (coarse_mfma_supported(scan_metric, d, nq, (uint32_t)nlist, nprobes, coarse_l32, qs, ix->centroids)) {
     // kmeans.rs:1134-1158 on the matrix cores: bf16x3 surrogate matrix, exact re-check of the nprobes + few candidates
-    LH_TRY(find_partitions_mfma(ctx, scan_metric, qs, nq, d, ix->centroids, (uint32_t)nlist, nprobes, matrix, probes, nullptr));
+    const uint16_t *cpl = nullptr;
+    const uint32_t *cmb = nullptr;
+    if (coarse_groups_shape(d, (uint32_t)nlist)) {      // thousands of lists: the centroids' bf16 planes are constants of the index
+      LH_TRY(coarse_planes_prepare(ctx, ix, scan_metric));
+      if (ix->cq) { cpl = ix->cq->cpl; cmb = ix->cq->maxbits; }
+    }
+    LH_TRY(find_partitions_mfma(ctx, scan_metric, qs, nq, d, ix->centroids, (uint32_t)nlist, nprobes, matrix, probes, nullptr, cpl, cmb));
   } else {
     PairwiseArgs pa;
     pa.x = qs; pa.n = nq; pa.ldx = d; pa.cent = ix->centroids; pa.k = nlist; pa.matrix = matrix;
@@ -1637,6 +1684,8 @@ int lance_hip_index_prewarm(lance_hip_ctx *ctx, lance_hip_index *idx) {
   LH_REQUIRE(ctx && idx, "index_prewarm: NULL argument");
   LH_CHECK_HIP(hipSetDevice(ctx->device));
   if (idx->m > 0 && idx->nbits == 8) LH_TRY(mscan_prewarm(ctx, idx));
+  if (coarse_groups_shape((int)idx->d, idx->nlist) && (reinterpret_cast<uintptr_t>(idx->centroids) & 15) == 0)
+    LH_TRY(coarse_planes_prepare(ctx, idx, idx->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : idx->metric));
   (void)raw_compact_prepare(ctx, idx);      // nullptr = the column stays f32 (not integer-valued, or not an f32 L2 / dot index): not an error
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return LANCE_HIP_OK;

@@ -1269,15 +1269,29 @@ static void xf_groups_launch_ks(lance_hip_ctx *ctx, const XfArgs &a, int metric,
 }
 
 // q: [nq][d] f32, d a multiple of 16 and <= 128; maxbits: four zeroed words ([0] receives max |c|^2); gkey: [nq][2 ng] floats, ng = 4 * ceil(nlist / 64)
-int launch_xform_sweep_groups(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t *maxbits,
-                              float *gkey, int ng, float *e2) {
+size_t xform_coarse_planes_elems(uint32_t nlist, int d) { return (size_t)((nlist + MA_CT - 1) / MA_CT * MA_CT) * (size_t)(2 * d + 16); }
+
+int xform_coarse_planes(lance_hip_ctx *ctx, int metric, const float *cent, uint32_t nlist, int d, uint16_t *cpl, uint32_t *maxbits) {
   const int kpad = (int)((nlist + MA_CT - 1) / MA_CT * MA_CT);
-  uint16_t *cpl = ctx->scratch_t<uint16_t>("cq.cpl", (size_t)kpad * (2 * d + 16));
-  if (!cpl) return LANCE_HIP_ENOMEM;
   if (metric == METRIC_DOT) hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_DOT>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, (int)nlist, d, cpl, maxbits, (const float *)nullptr, (const uint8_t *)nullptr);
   else hipLaunchKernelGGL(xf_cent_prep_kernel<METRIC_L2>, dim3((unsigned)kpad), dim3(64), 0, ctx->stream, cent, (int)nlist, d, cpl, maxbits, (const float *)nullptr, (const uint8_t *)nullptr);
+  LH_CHECK_HIP(hipGetLastError());
+  return LANCE_HIP_OK;
+}
+
+int launch_xform_sweep_groups(lance_hip_ctx *ctx, int metric, const float *q, uint32_t nq, int d, const float *cent, uint32_t nlist, uint32_t *maxbits,
+                              float *gkey, int ng, float *e2, const uint16_t *cpl_ready, const uint32_t *maxbits_ready) {
+  const int kpad = (int)((nlist + MA_CT - 1) / MA_CT * MA_CT);
+  const uint16_t *cpl = cpl_ready;
+  const uint32_t *mb = maxbits_ready;
+  if (!cpl_ready || !maxbits_ready) {
+    uint16_t *own = ctx->scratch_t<uint16_t>("cq.cpl", xform_coarse_planes_elems(nlist, d));
+    if (!own) return LANCE_HIP_ENOMEM;
+    LH_TRY(xform_coarse_planes(ctx, metric, cent, nlist, d, own, maxbits));
+    cpl = own; mb = maxbits;
+  }
   XfArgs a{};
-  a.x = q; a.n = nq; a.ldx = d; a.k = (int)nlist; a.cpl = cpl; a.maxbits = maxbits; a.cent = cent; a.d_total = d;
+  a.x = q; a.n = nq; a.ldx = d; a.k = (int)nlist; a.cpl = cpl; a.maxbits = mb; a.cent = cent; a.d_total = d;
   a.gkey = gkey; a.ng = ng; a.e2 = e2;
   const unsigned rblocks = (unsigned)cdiv(nq, MA_ROWS);
   const int ntiles = kpad / MA_CT;

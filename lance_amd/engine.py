@@ -418,6 +418,15 @@ class Engine:
 _wrap_methods(Engine, skip=("close",))
 
 
+
+def _torch_inputs_ready():
+    """What a search call needs from torch before the engine's stream reads the batch: the work torch's CURRENT stream has queued (the
+    conversion / move of the queries).  Not torch.cuda.synchronize(): a device-wide synchronise is not permitted while ANY stream of the
+    process is capturing -- another host thread's repeated search being captured into a HIP graph -- and both threads then fail (the
+    synchronising one in torch, the capturing one in the runtime; tests/test_zz_gpu_threads.py, gpurun r06zm).  The engines' streams are
+    non-blocking: torch's stream has no implicit dependency on them."""
+    torch.cuda.current_stream().synchronize()
+
 class DeviceFlatIndex:
     """Handle of a device-resident IVF_FLAT index (FlatIndex sub-index over the raw vectors of each partition)."""
 
@@ -616,13 +625,13 @@ class DeviceIndex:
             # a batch whose survivor segments would not fit the library's 2 GiB scratch limit leaves the batched kernels for the
             # query-major ones (correct, many times slower): queries are independent, so the batch goes through in slices
             step = max(1, self.MAX_PAIRS_PER_CALL // max(1, nprobes))
-            torch.cuda.synchronize()
+            _torch_inputs_ready()
             for a in range(0, nq, step):
                 b = min(nq, a + step)
                 check(fn(eng.h, self.h, _ptr(q[a:b]), b - a, k, nprobes, refine_factor, _ptr(ids[a:b]), _ptr(dists[a:b])))
             return ids, dists
         if sync:
-            torch.cuda.synchronize()
+            _torch_inputs_ready()
         elif not eng.use_torch_stream and (q.data_ptr() != t.data_ptr() or out is None):
             # the batch was converted / moved / allocated by torch kernels on torch's stream: they must finish before the
             # engine's own stream reads them.  reshape() always makes a new tensor OBJECT, so the test is on the storage: a
@@ -646,7 +655,7 @@ class DeviceIndex:
             dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         else:
             ids, dists = out
-        torch.cuda.synchronize()
+        _torch_inputs_ready()
         check(self.engine.lib.lance_hip_ivfpq_search_filtered(self.engine.h, self.h, _ptr(q), nq, k, nprobes, refine_factor, _ptr(a),
                                                               a.numel(), _ptr(ids), _ptr(dists)))
         return ids, dists
@@ -663,7 +672,7 @@ class DeviceIndex:
         ids = torch.empty((nq, keff), dtype=torch.int64, device=q.device)
         pq = torch.empty((nq, keff), dtype=torch.float32, device=q.device)
         ex = torch.empty((nq, keff), dtype=torch.float32, device=q.device) if exact else None
-        torch.cuda.synchronize()
+        _torch_inputs_ready()
         check(eng.lib.lance_hip_ivfpq_search_candidates(eng.h, self.h, _ptr(q), nq, keff, min(nprobes, self.centroids.shape[0]), _ptr(ids), _ptr(pq),
                                                         _ptr(ex) if exact else None))
         return ids, pq, ex
@@ -704,12 +713,12 @@ class DeviceIndex:
         if allow is not None:
             a = allow if isinstance(allow, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(allow, dtype=bool))
             a = a.to(torch.uint8).to(_dev()).contiguous()
-            torch.cuda.synchronize()
+            _torch_inputs_ready()
             check(self.engine.lib.lance_hip_ivfpq_search_filtered_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes,
                                                                         1 if refine_factor == -1 else 0, _ptr(a), a.numel(), lo, hi,
                                                                         _ptr(ids), _ptr(dists)))
             return ids, dists
-        torch.cuda.synchronize()
+        _torch_inputs_ready()
         check(self.engine.lib.lance_hip_ivfpq_search_range(self.engine.h, self.h, _ptr(q), nq, k, nprobes, 1 if refine_factor == -1 else 0,
                                                            lo, hi, _ptr(ids), _ptr(dists)))
         return ids, dists
