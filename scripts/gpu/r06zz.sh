@@ -14,5 +14,5 @@ f=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1); if [ -n "$f" ]; t
 (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/pmc_a -- python $R/bench.py --steps 10 --warmup 2 --streams 1 --no-pmc --no-cpu-baseline --no-grid --no-extras > $R/$O/pmc_a.log 2>&1); echo "pmc a rc=$?"
 (cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_b -- python $R/bench.py --steps 10 --warmup 2 --streams 1 --no-pmc --no-cpu-baseline --no-grid --no-extras > $R/$O/pmc_b.log 2>&1); echo "pmc b rc=$?"
 for kn in ivfpq_mscan_kernel ma_top3_kernel xf_kernel ms_bound_kernel; do timeout 100 python scripts/pmc_sq_summary.py /tmp/pmc_a $O/pmc_a_$kn.json $kn | cut -c1-500; timeout 100 python scripts/pmc_sq_summary.py /tmp/pmc_b $O/pmc_b_$kn.json $kn | cut -c1-500; done
-timeout 900 python tests/fuzz_parity.py 420 6301 --log $O/fuzz.txt --watchdog 300 > $O/fuzz_out.txt 2>&1; echo "fuzz rc=$?"; tail -3 $O/fuzz_out.txt | cut -c1-300
+timeout 900 python tests/fuzz_parity.py 420 6303 --log $O/fuzz.txt --watchdog 300 > $O/fuzz_out.txt 2>&1; echo "fuzz rc=$?"; tail -3 $O/fuzz_out.txt | cut -c1-300
 timeout 900 python scripts/measure_grid.py --c3 > $O/grid.json 2> $O/grid.err; echo "grid rc=$?"; tail -c 600 $O/grid.json
