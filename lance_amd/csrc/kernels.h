@@ -183,7 +183,7 @@ int qscan_item_tables(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nlist
 // G = queries per work item of the main pass
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
-                uint32_t max_items4, int G = 4);
+                uint32_t max_items4, int G = 4, int dot = 0);
 int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);
 int qscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *pair_idx,
@@ -204,7 +204,8 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
 constexpr int LH_NOT_TAKEN = 1;
 // search_ms.hip: the filter scan as a [rows x d] x [d x queries] product per partition on the matrix cores (8-bit PQ, d = 64 / 128, M = 16 / 32)
 bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
-bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);   // shape + batch-size part of mscan_supported
+bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
+bool mscan_dot_ready(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);   // dot metric: the batch can take the matrix-core bound pass + scan   // shape + batch-size part of mscan_supported
 int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t nprobes, const uint32_t *probes,
                  const uint32_t *pair_starts, const uint32_t *pair_idx, const uint32_t *tbound, uint32_t *seg_cnt, uint32_t *seg_pos,
                  uint32_t *qovf, const uint32_t *allow, uint32_t **qslack_out, float **seg_val_out, float **seg_scale_out);

@@ -44,6 +44,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -66,13 +67,14 @@ typedef __attribute__((address_space(1))) const void *ms_gptr;
 typedef __attribute__((address_space(3))) void *ms_lptr;
 
 // ---- index constants ---------------------------------------------------------------------------------------------------------
+// mu (dot metric): the mean codeword of every sub-quantiser ([d], lance_hip_index::cb_mean) -- the plane holds the CENTRED codewords
 __global__ __launch_bounds__(256) void ms_codebook_kernel(const float *__restrict__ cb, int64_t nwords, int sd, float scale, _Float16 *__restrict__ cbh,
-                                                          float *__restrict__ cbn2) {
+                                                          float *__restrict__ cbn2, const float *__restrict__ mu) {
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (w >= nwords) return;
   float s = 0.0f;
   for (int u = 0; u < sd; ++u) {
-    const float v = cb[w * sd + u];
+    const float v = mu ? cb[w * sd + u] - mu[(w >> 8) * sd + u] : cb[w * sd + u];
     cbh[w * sd + u] = (_Float16)(v * scale);      // scale = -2 sigma
     s += v * v;
   }
@@ -87,6 +89,14 @@ __global__ __launch_bounds__(256) void ms_row_norm_kernel(const uint8_t *__restr
   float s = 0.0f;
   for (int mm = 0; mm < m; ++mm) s += cbn2[mm * 256 + rc[mm]];
   row_cn2[r] = s * sigma2;
+}
+
+__global__ __launch_bounds__(256) void ms_max_kernel(const float *__restrict__ v, int64_t n, uint32_t *__restrict__ out) {      // v >= 0: float order = bit order
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, v[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
 // ---- per-pair pre-pass: f16 residual (scaled by sigma), limit, integer-sum scale --------------------------------------------------
@@ -104,6 +114,11 @@ struct MsPrepArgs {
   uint32_t *seg_cnt, *qovf, *ovf;
   uint32_t nan_slot;            // index into prm of the NaN-limit record (written here, loaded by the scan for padded pair slots)
   f2 *prm2;                     // [nq * nprobes] by PAIR: {s / sigma^2, (T' + E) s} -- what turns a survivor's accumulator value into its integer sum
+  int dot = 0;                  // dot metric (no residual: the operand is q / 2 for every partition; limits and sums relative to a per-query base)
+  float cmax = 0.0f;            // dot: upper bound of |CENTRED reconstruction of any stored row| (MsConst::cmax)
+  float cmax_full = 0.0f;       // dot: upper bound of |reconstruction of any stored row| (the reference's own rounding terms)
+  const float *mu = nullptr;    // dot: [d] the mean codeword of every sub-quantiser (lance_hip_index::cb_mean)
+  int m = 0;
 };
 
 constexpr int MS_PPW = 4;      // pairs per wave of the pre-pass: their loads are in flight together (one pair per wave was 100k waves of
@@ -126,51 +141,86 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
     qv[t] = p.q + (int64_t)(pair[t] / (uint32_t)p.nprobes) * p.d;
     cv[t] = p.centroids + (int64_t)p.probes[pair[t]] * p.d;
   }
-  float n2[MS_PPW], vmax[MS_PPW];
+  float n2[MS_PPW], vmax[MS_PPW], qmu[MS_PPW];
   bool bad[MS_PPW];
 #pragma unroll
-  for (int t = 0; t < MS_PPW; ++t) { n2[t] = 0.0f; vmax[t] = 0.0f; bad[t] = false; }
+  for (int t = 0; t < MS_PPW; ++t) { n2[t] = 0.0f; vmax[t] = 0.0f; qmu[t] = 0.0f; bad[t] = false; }
   for (int e = lane; e < p.d; e += 64) {
     float v[MS_PPW];
+    const float mue = p.dot ? p.mu[e] : 0.0f;
 #pragma unroll
-    for (int t = 0; t < MS_PPW; ++t) v[t] = qv[t][e] - cv[t][e];      // v2.rs:316-332, the subtraction of the exact path
+    for (int t = 0; t < MS_PPW; ++t) v[t] = p.dot ? qv[t][e] : qv[t][e] - cv[t][e];      // v2.rs:316-332, the subtraction of the exact path (dot: no residual)
+    const float hs = p.dot ? 0.5f * p.sigma : p.sigma;      // dot: the codebook plane holds -2 sigma c, the operand is sigma q / 2 (powers of two: exact)
 #pragma unroll
     for (int t = 0; t < MS_PPW; ++t) {
-      if (p.round_f16) v[t] = __half2float(__float2half_rn(v[t]));
+      if (p.round_f16 && !p.dot) v[t] = __half2float(__float2half_rn(v[t]));
       n2[t] += v[t] * v[t];
+      qmu[t] += v[t] * mue;
       vmax[t] = fmaxf(vmax[t], fabsf(v[t]));
       bad[t] |= !(fabsf(v[t]) < INFINITY);
-      if (g0 + (uint32_t)t < ng) p.rh[(int64_t)(g0 + t) * p.d + e] = (_Float16)(v[t] * p.sigma);
+      if (g0 + (uint32_t)t < ng) p.rh[(int64_t)(g0 + t) * p.d + e] = (_Float16)(v[t] * hs);
     }
   }
 #pragma unroll
   for (int t = 0; t < MS_PPW; ++t) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { n2[t] += __shfl_xor(n2[t], o, 64); vmax[t] = fmaxf(vmax[t], __shfl_xor(vmax[t], o, 64)); }
+    for (int o = 32; o > 0; o >>= 1) {
+      n2[t] += __shfl_xor(n2[t], o, 64); qmu[t] += __shfl_xor(qmu[t], o, 64); vmax[t] = fmaxf(vmax[t], __shfl_xor(vmax[t], o, 64));
+    }
     bad[t] = __any(bad[t]);
   }
   // lane t finishes pair t
-  float n2l = n2[0], vml = vmax[0]; bool badl = bad[0]; uint32_t pairl = pair[0];
+  float n2l = n2[0], vml = vmax[0], qmul = qmu[0]; bool badl = bad[0]; uint32_t pairl = pair[0];
 #pragma unroll
-  for (int t = 1; t < MS_PPW; ++t) if (lane == t) { n2l = n2[t]; vml = vmax[t]; badl = bad[t]; pairl = pair[t]; }
+  for (int t = 1; t < MS_PPW; ++t) if (lane == t) { n2l = n2[t]; vml = vmax[t]; qmul = qmu[t]; badl = bad[t]; pairl = pair[t]; }
   if (lane >= MS_PPW || g0 + (uint32_t)lane >= ng) return;
   const uint32_t q = pairl / (uint32_t)p.nprobes;
-  const float T = key_to_float(p.tbound[q]);     // class A: 0 < T < inf
-  const float s = MS_SE / T;
-  const float rn = sqrtf(n2l) * 1.000001f, st = sqrtf(T) * 1.000001f;
+  const float T = key_to_float(p.tbound[q]);     // class A: 0 < T < inf (dot: any finite T)
   const float sqd = sqrtf((float)p.d) + 1.0f;
-  const float e_abs = 6.1035156e-5f * sqd * (3.0f * rn + 2.0f * st) / p.sigma + (float)p.d * 3.7252903e-9f / (p.sigma * p.sigma);
-  const float E = 1.05f * (1.9921875e-3f * rn * (rn + st) + 1.2207031e-4f * (n2l + T)) + e_abs;     // 2^-9 * 1.02, 2^-13
-  const float eu = E * s * 1.1f + 3.0f;
-  const float lim = (T * 1.0000077f + E) - n2l;  // T (1 + 2^-17) + E - |r|^2; the cancellation's rounding sits inside the 2^-13 term
   const float sig2 = p.sigma * p.sigma;
-  const bool ok = !badl && T > 0.0f && T < INFINITY && s > 0.0f && s < INFINITY && n2l < INFINITY && vml * p.sigma < 60000.0f &&
-                  eu <= MS_SLACK_CAP && fabsf(lim * sig2) < INFINITY && n2l * s < 1e30f;
+  float s, eu, lim, zsum;
+  bool ok;
+  if (p.dot) {
+    // dist = 1 - q . c^ (pq/distance.rs:60-92, storage.rs:949-957) = (1 - q . mu) - q . c' with c' = c^ - mu the row's reconstruction from the
+    // CENTRED codebook (mu: the mean codeword of every sub-quantiser) -- what L2 gets from its residuals: for rows whose components share a
+    // sign |c'| is a third of |c^|, and with it every error term below.  The matrix product evaluates -(q . c')~; G >= |q . c'| for every
+    // stored row (Cauchy-Schwarz, cmax = the largest |c'| of the index), base = (1 - q . mu) - G is below every distance; the sums are
+    // (dist~ - base) s >= 0 with T - base + E mapped to MS_SE.  Error of dist~ against the reference's f32 table sum:
+    //   binary16 operands: |fl16(a) fl16(b) - a b| <= |a b| (2u + u^2), summed: <= 2^-10 (1 + 2^-12) |q| |c'|;
+    //   f32 accumulation of <= 128 exact products on top of the limit (<= 129 2^-24 (G + |lim|)), q . mu in f32 (<= 129 2^-24 |q| |mu|, and
+    //   |mu| <= the longest reconstruction: |q| |mu| <= Gf), the three roundings of the limit (2^-24 (1 + |T| + |q . mu|) each), the centring
+    //   c - mu in f32 (2^-24 |q| |c^|), the reference's own per-sub-vector dot products ((sd + 1) 2^-24 |q| |c^|) and the |q| |c^| part of its
+    //   sequential sum of M entries (M 2^-24 |q| |c^|): <= 2^-16 (G + 1 + |T| + |q . mu| + Gf) together for sd + M <= 48;
+    //   the rest of that sum (entries 1 - x_m, partial sums <= M + ..., the subtraction of M - 1): <= 2^-24 (M + 2)^2;
+    //   flushed binary16 subnormals: per element 2^-14 on either operand.
+    const float qn = sqrtf(n2l) * 1.000001f;
+    const float G = qn * p.cmax * 1.000001f, Gf = qn * p.cmax_full * 1.000001f;
+    const float e_abs = 6.1035156e-5f * sqd * (qn + 2.0f * p.cmax) / p.sigma + (float)p.d * 3.7252903e-9f / sig2;
+    const float E = 1.05f * (9.9609375e-4f * G + 1.5258789e-5f * (G + 1.0f + fabsf(T) + fabsf(qmul) + Gf) + 5.9604645e-8f * (float)((p.m + 2) * (p.m + 2))) + e_abs;     // 2^-10 * 1.02, 2^-16, 2^-24
+    const float Tq = (T - 1.0f) + qmul;         // the bound as a limit on -(q . c')
+    const float Tp = (Tq + G) + E;              // ... in the shifted domain (> 0: T bounds a real distance, every distance is >= base - E)
+    s = MS_SE / Tp;
+    eu = E * s * 1.1f + 3.0f;
+    lim = Tq + E;                               // a row is kept when -(q . c')~ <= T - 1 + q . mu + E
+    zsum = (lim + G) * s;                       // sum = (-(q . c')~ - lim) s + (lim + G) s = (dist~ - base) s
+    ok = !badl && fabsf(T) < INFINITY && Tp > 0.0f && Tp < INFINITY && s > 0.0f && s < INFINITY && Gf < INFINITY && vml * p.sigma < 60000.0f &&
+         eu <= MS_SLACK_CAP && fabsf(lim * sig2) < INFINITY && G * s < 1e30f && fabsf(zsum) < 1e30f;
+  } else {
+    s = MS_SE / T;
+    const float rn = sqrtf(n2l) * 1.000001f, st = sqrtf(T) * 1.000001f;
+    const float e_abs = 6.1035156e-5f * sqd * (3.0f * rn + 2.0f * st) / p.sigma + (float)p.d * 3.7252903e-9f / (p.sigma * p.sigma);
+    const float E = 1.05f * (1.9921875e-3f * rn * (rn + st) + 1.2207031e-4f * (n2l + T)) + e_abs;     // 2^-9 * 1.02, 2^-13
+    eu = E * s * 1.1f + 3.0f;
+    lim = (T * 1.0000077f + E) - n2l;  // T (1 + 2^-17) + E - |r|^2; the cancellation's rounding sits inside the 2^-13 term
+    zsum = (T * 1.0000077f + E) * s;
+    ok = !badl && T > 0.0f && T < INFINITY && s > 0.0f && s < INFINITY && n2l < INFINITY && vml * p.sigma < 60000.0f &&
+         eu <= MS_SLACK_CAP && fabsf(lim * sig2) < INFINITY && n2l * s < 1e30f;
+  }
   f4 o;
   if (ok) {
     o.x = -(lim * sig2); o.y = s / sig2; o.z = n2l * s;      // MINUS the limit: the scan's accumulator starts from it
     // by pair, for the merge kernel: sum = (accumulator value, which is relative to the limit) * y + (T (1 + 2^-17) + E) s
-    p.prm2[pairl] = f2{o.y, (T * 1.0000077f + E) * s};
+    p.prm2[pairl] = f2{o.y, zsum};
     atomicMax(&p.qslack[q], (uint32_t)ceilf(eu));
   } else {
     // this (query, partition) pair goes to the exact rescan (ivfpq_qrescan_kernel), as an overflowed segment does.  The limit is a
@@ -593,6 +643,8 @@ struct MsBoundArgs {
   float sigma;
   uint32_t *tglobal;            // [nq] bound key (atomicMin)
   const uint32_t *allow;
+  int dot = 0;                  // dot metric: operand q / 2, no residual, centred codebook plane; bins of (dist~ - base), base = (1 - q . mu) - |q| cmax (ms_prep_kernel)
+  float cmax = 0.0f, cmax_full = 0.0f;
 };
 
 template <int SD, int KS>
@@ -608,7 +660,7 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
   __shared__ __attribute__((aligned(16))) uint32_t sH[MSB_BQ * (MSB_BINS / 2)];
   __shared__ __attribute__((aligned(16))) float sPa[MSB_BQ];      // sb / sigma^2 (NaN: the query takes no bound from this pass)
   __shared__ __attribute__((aligned(16))) float sPb[MSB_BQ];      // |r|^2 sb
-  __shared__ float sN2[MSB_BQ], sSb[MSB_BQ];
+  __shared__ float sN2[MSB_BQ], sSb[MSB_BQ], sRmu[MSB_BQ];
   __shared__ uint32_t s_chunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, g = lane >> 5;
@@ -617,8 +669,11 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
   const int4 dsc = p.desc[item];
   const int part = dsc.x, i0 = dsc.y, cnt = dsc.z;
   const uint32_t off = p.part_offsets[part];
-  const int np = (int)(p.part_offsets[part + 1] - off);
-  if (np < p.keff) return;      // uniform: fewer rows than k*refine -> no bound from this partition
+  const int np_all = (int)(p.part_offsets[part + 1] - off);
+  if (np_all < p.keff) return;      // uniform: fewer rows than k*refine -> no bound from this partition
+  // u16 bins: a bin never holds more rows than were counted.  A bound only needs k*refine rows under it, so the first 65,535 rows of a larger
+  // partition give a valid (slightly looser) one -- the dot metric's lists are as uneven as the rows' norms, and it has no integer pass to fall back to
+  const int np = min(np_all, 65535);
   const int nslots = ((cnt + 31) >> 5) << 5;
 
   // the codebook: 16 bytes per lane and pass
@@ -635,9 +690,10 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
     for (int t = 0; t < SPW; ++t) { const int sl = wave + 16 * t; qi[t] = sl < cnt ? p.pair_idx0[i0 + sl] : 0u; }
     f2 qv[SPW], cv = {0.0f, 0.0f}, mu = {0.0f, 0.0f};
     if (e < D) {
-      cv = *reinterpret_cast<const f2 *>(p.centroids + (int64_t)part * D + e);
+      if (!p.dot) cv = *reinterpret_cast<const f2 *>(p.centroids + (int64_t)part * D + e);
       mu = *reinterpret_cast<const f2 *>(p.cb_mean + e);
     }
+    const float hs = p.dot ? 0.5f * p.sigma : p.sigma;
 #pragma unroll
     for (int t = 0; t < SPW; ++t) {
       qv[t] = f2{0.0f, 0.0f};
@@ -653,13 +709,13 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
       uint32_t packed = 0u;
       if (sl < cnt && e < D) {
         float v0 = qv[t].x - cv.x, v1 = qv[t].y - cv.y;      // v2.rs:316-332, the subtraction of the exact path
-        if (p.round_f16) { v0 = __half2float(__float2half_rn(v0)); v1 = __half2float(__float2half_rn(v1)); }
+        if (p.round_f16 && !p.dot) { v0 = __half2float(__float2half_rn(v0)); v1 = __half2float(__float2half_rn(v1)); }
         n2 = v0 * v0 + v1 * v1;
         vmax = fmaxf(fabsf(v0), fabsf(v1));
         rmu = v0 * mu.x + v1 * mu.y;
         bad = !(fabsf(v0) < INFINITY) || !(fabsf(v1) < INFINITY);
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 hv = {(_Float16)(v0 * p.sigma), (_Float16)(v1 * p.sigma)};
+        const h2 hv = {(_Float16)(v0 * hs), (_Float16)(v1 * hs)};
         packed = __builtin_bit_cast(uint32_t, hv);
       }
       if (e < D) *reinterpret_cast<uint32_t *>(&sB[sl * RB + ((((e >> 3) ^ key)) << 4) + ((e & 7) << 1)]) = packed;
@@ -671,14 +727,18 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
       if (lane == 0) {
         float a = __uint_as_float(0x7FC00000u), b = 0.0f, sb = 0.0f;
         if (sl < cnt) {
-          const float mean = n2 - 2.0f * rmu + p.cb_mean[D];      // sum over m of the mean table entry: the distance of a random code
+          // L2: sum over m of the mean table entry = the distance of a random code.  dot: the same minus base = (1 - q . mu) - G, G = |q| cmax >=
+          // |q . c'| (ms_prep_kernel; the centred codewords average to zero): mean - base = G; the bins count (dist~ - base) sb = (acc / sigma^2 + G) sb
+          const float G = sqrtf(n2) * 1.000001f * p.cmax * 1.000001f;
+          const float mean = p.dot ? G : n2 - 2.0f * rmu + p.cb_mean[D];
+          const float off = p.dot ? G : n2;
           sb = MSB_MEAN_BIN / mean;
           const float sig2 = p.sigma * p.sigma;
-          const bool ok = !bad && n2 < INFINITY && vmax * p.sigma < 60000.0f && mean > 0.0f && mean < INFINITY && sb > 0.0f && sb < INFINITY &&
-                          n2 * sb < 1e30f && sb / sig2 > 0.0f && sb / sig2 < INFINITY;
-          if (ok) { a = sb / sig2; b = n2 * sb; }
+          const bool ok = !bad && off < INFINITY && vmax * p.sigma < 60000.0f && mean > 0.0f && mean < INFINITY && sb > 0.0f && sb < INFINITY &&
+                          off * sb < 1e30f && sb / sig2 > 0.0f && sb / sig2 < INFINITY;
+          if (ok) { a = sb / sig2; b = off * sb; }
         }
-        sPa[sl] = a; sPb[sl] = b; sN2[sl] = n2; sSb[sl] = sb;
+        sPa[sl] = a; sPb[sl] = b; sN2[sl] = n2; sSb[sl] = sb; sRmu[sl] = rmu;
       }
     }
   }
@@ -800,10 +860,20 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
         const float Ta = (float)(bin + 1) / sb * 1.000001f;      // every counted row has dist~ < (bin + 1) / sb
         const float rn = sqrtf(n2) * 1.000001f, st = sqrtf(Ta) * 1.000001f;
         const float sqd = sqrtf((float)D) + 1.0f;
+        if (p.dot) {
+          // every counted row has dist~ - base < Ta; its reference distance is <= base + Ta + E (ms_prep_kernel's E with |T| <= |base| + Ta)
+          const float G = rn * p.cmax * 1.000001f, Gf = rn * p.cmax_full * 1.000001f, qmu = sRmu[sl];
+          const float tmag = fabsf(1.0f - qmu) + G + Ta;
+          const float e_abs = 6.1035156e-5f * sqd * (rn + 2.0f * p.cmax) / p.sigma + (float)D * 3.7252903e-9f / (p.sigma * p.sigma);
+          const float E = 1.05f * (9.9609375e-4f * G + 1.5258789e-5f * (G + 1.0f + tmag + fabsf(qmu) + Gf) + 5.9604645e-8f * (float)((M + 2) * (M + 2))) + e_abs;
+          const float T = (((1.0f - qmu) - G) + Ta) + (1.1f * E + 1.5258789e-5f * tmag);
+          if (fabsf(T) < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl]], order_key(T));
+        } else {
         const float e_abs = 6.1035156e-5f * sqd * (3.0f * rn + 2.0f * st) / p.sigma + (float)D * 3.7252903e-9f / (p.sigma * p.sigma);
         const float E = 1.05f * (1.9921875e-3f * rn * (rn + st) + 1.2207031e-4f * (n2 + Ta)) + e_abs;      // ms_prep_kernel's E at T = Ta
         const float T = (Ta + 1.1f * E) * 1.0000153f;
         if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl]], order_key(T));
+        }
       }
     }
   }
@@ -829,8 +899,23 @@ bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes)
   static const bool off = getenv("LANCE_HIP_NO_MSCAN") != nullptr;
   static const uint32_t minq = getenv("LANCE_HIP_MSCAN_MINQ") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_MSCAN_MINQ"))) : 96u;
   if (off || !ms_shape(ix, nullptr, nullptr)) return false;
-  if (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_COSINE) return false;
+  if (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_COSINE && ix->metric != LANCE_HIP_DOT) return false;
   return (uint64_t)nq * nprobes >= (uint64_t)minq * ix->nlist;
+}
+
+// dot metric: the quantised flow is the matrix-core bound pass + scan or nothing (the integer tables need entries >= 0).  What can only be
+// known inside the launchers (an all-zero codebook, unaligned query rows) makes them return LH_NOT_TAKEN and the caller keeps the exact pair scan.
+bool mscan_dot_ready(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
+  static const bool off = getenv("LANCE_HIP_NO_MSBOUND") != nullptr || getenv("LANCE_HIP_NO_DOT_FLOW") != nullptr;
+  if (off || !mscan_batch_shape(ix, nq, nprobes) || !ix->cb_mean) return false;
+  // Lists as uneven as the rows' norms (dot over unnormalised rows with components of one sign: at the C2 shape the largest of 256 lists held 82,424
+  // of the 10^6 rows and was every query's nearest): the bound of the nearest list is loose for the other probed lists, a fifth of the segments
+  // overflow into exact rescans of whole lists and the flow measured SLOWER than the exact pair scan (3.94 against 3.46 ms per 10,000-query batch,
+  // gpurun r06zu; with the same rows centred -- largest list 23,309 -- 1.16 against 1.68).  LANCE_HIP_DOT_FLOW_SKEW: the largest list / mean list
+  // ratio up to which the flow is taken (default 8).
+  static const double skew = getenv("LANCE_HIP_DOT_FLOW_SKEW") ? atof(getenv("LANCE_HIP_DOT_FLOW_SKEW")) : 8.0;
+  if ((double)ix->max_part * (double)ix->nlist > skew * (double)ix->n) return false;
+  return !ix->ms || ix->ms->usable;
 }
 
 bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
@@ -845,9 +930,29 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   std::vector<float> cb((size_t)nwords * sd);
   LH_CHECK_HIP(hipMemcpyAsync(cb.data(), ix->codebook, cb.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  float cbmax = 0.0f;
-  for (float v : cb) cbmax = std::max(cbmax, std::fabs(v));
+  const bool dot = ix->metric == LANCE_HIP_DOT;
   auto *mc = new lance_hip_index::MsConst();
+  std::vector<float> mu;      // dot: the plane holds the codewords minus their sub-quantiser's mean (ms_prep_kernel) -- the device's own cb_mean, so that
+  if (dot) {                  // the centring here and the q . mu of the pre-pass use the same numbers
+    if (!ix->cb_mean) { mc->usable = false; ix->ms = mc; return LANCE_HIP_OK; }
+    mu.resize((size_t)d);
+    LH_CHECK_HIP(hipMemcpyAsync(mu.data(), ix->cb_mean, (size_t)d * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    // |reconstruction of any row|^2 <= sum over the sub-quantisers of their longest codeword's |c|^2 (only the reference's rounding terms use it)
+    double tot = 0.0;
+    for (int mm = 0; mm < m; ++mm) {
+      double best = 0.0;
+      for (int c = 0; c < 256; ++c) {
+        double sq = 0.0;
+        for (int u = 0; u < sd; ++u) { const double v = cb[((size_t)mm * 256 + c) * sd + u]; sq += v * v; }
+        best = std::max(best, sq);
+      }
+      tot += best;
+    }
+    mc->cmax_full = (float)(std::sqrt(tot) * 1.00001);
+  }
+  float cbmax = 0.0f;
+  for (size_t i = 0; i < cb.size(); ++i) cbmax = std::max(cbmax, std::fabs(dot ? cb[i] - mu[(i / ((size_t)256 * sd)) * sd + i % sd] : cb[i]));
   if (!(cbmax > 0.0f) || !std::isfinite(cbmax) || ix->n == 0) {      // an all-zero codebook: nothing to scale by -- the integer scan serves this index
     mc->usable = false;
     ix->ms = mc;
@@ -862,9 +967,19 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   auto drop = [&]() { (void)hipFree(mc->cbh); (void)hipFree(mc->cbn2); (void)hipFree(mc->row_cn2); delete mc; };
   if (!ok) { drop(); set_error("matrix-core scan: out of device memory for the index constants"); return LANCE_HIP_ENOMEM; }
   hipLaunchKernelGGL(ms_codebook_kernel, dim3((unsigned)cdiv((uint64_t)nwords, 256)), dim3(256), 0, ctx->stream, ix->codebook, nwords, sd,
-                     -2.0f * mc->sigma, reinterpret_cast<_Float16 *>(mc->cbh), mc->cbn2);
+                     -2.0f * mc->sigma, reinterpret_cast<_Float16 *>(mc->cbh), mc->cbn2, dot ? ix->cb_mean : nullptr);
   hipLaunchKernelGGL(ms_row_norm_kernel, dim3((unsigned)cdiv(ix->n, 256)), dim3(256), 0, ctx->stream, ix->codes, (int64_t)ix->n, m, mc->cbn2,
                      mc->sigma * mc->sigma, mc->row_cn2);
+  uint32_t rowmax_bits = 0;
+  if (dot) {
+    // the largest |centred reconstruction| of any stored row (the dot metric's G), then the row term itself is ZERO: the same kernels test
+    // -(q . c')~ against the limit
+    uint32_t *mx = reinterpret_cast<uint32_t *>(mc->cbn2);      // (the per-codeword norms are not needed after the row norms: word 0 is reused)
+    (void)lh::memset_async(mx, 0, 4, ctx->stream);
+    hipLaunchKernelGGL(ms_max_kernel, dim3(256), dim3(256), 0, ctx->stream, mc->row_cn2, (int64_t)ix->n, mx);
+    (void)hipMemcpyAsync(&rowmax_bits, mx, 4, hipMemcpyDeviceToHost, ctx->stream);
+    (void)lh::memset_async(mc->row_cn2, 0, (size_t)ix->n * 4, ctx->stream);
+  }
   for (uint32_t pid = 0; pid < ix->nlist; ++pid) {
     const uint32_t rs = (uint32_t)cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), (uint64_t)ms_rows_per_slice());
     mc->sum_rs += rs; mc->max_rs = std::max(mc->max_rs, rs);
@@ -873,6 +988,11 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
     drop();
     set_error("matrix-core scan: building the index constants failed");
     return LANCE_HIP_ERUNTIME;
+  }
+  if (dot) {
+    float rm; memcpy(&rm, &rowmax_bits, 4);      // sigma^2 max |c'|^2 (the stream was synchronised above)
+    mc->cmax = (float)(std::sqrt((double)rm) / (double)mc->sigma * 1.0001);
+    if (!(mc->cmax > 0.0f) || !std::isfinite(mc->cmax)) mc->cmax = mc->cmax_full;      // (every row on the mean: any positive bound will do)
   }
   mc->usable = true;
   ix->ms = mc;      // published complete; lance_hip_index's destructor frees it
@@ -914,6 +1034,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     pa.sigma = ix->ms->sigma; pa.rh = rh; pa.prm = prm; pa.qslack = qslack; pa.seg_cnt = seg_cnt; pa.qovf = qovf; pa.ovf = ovf;
     pa.nan_slot = nan_slot; pa.prm2 = prm2;
+    pa.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; pa.cmax = ix->ms->cmax; pa.cmax_full = ix->ms->cmax_full; pa.mu = ix->cb_mean; pa.m = (int)ix->m;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
     const uint32_t rs_rows = (uint32_t)ms_rows_per_slice();
     static const bool no_order = getenv("LANCE_HIP_MS_NOORDER") != nullptr;      // A/B: one work class = slices in (roughly) index order
@@ -998,7 +1119,9 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
   static const bool off = getenv("LANCE_HIP_NO_MSBOUND") != nullptr;      // A/B switch: the integer histogram pass (search_q.hip)
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
   int sd = 0, ks = 0;
-  if (off || !ms_shape(ix, &sd, &ks) || !ix->cb_mean || ix->max_part >= 65536u) return LH_NOT_TAKEN;      // u16 bins: a bin never holds more rows than the partition has
+  const bool dot = ix->metric == LANCE_HIP_DOT;
+  // u16 bins: a bin never holds more rows than the partition has (L2: larger lists keep the integer pass; dot: the kernel counts the first 65,535 rows)
+  if (off || !ms_shape(ix, &sd, &ks) || !ix->cb_mean || (!dot && ix->max_part >= 65536u)) return LH_NOT_TAKEN;
   if (((reinterpret_cast<uintptr_t>(qs) | reinterpret_cast<uintptr_t>(ix->centroids)) & 7) != 0) return LH_NOT_TAKEN;
   LH_TRY(mscan_prepare(ctx, ix));
   if (!ix->ms->usable) return LH_NOT_TAKEN;
@@ -1011,6 +1134,7 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
   a.part_offsets = ix->part_offsets; a.codes = ix->codes; a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2;
   a.d = (int)ix->d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0; a.sigma = ix->ms->sigma;
   a.tglobal = tglobal; a.allow = allow;
+  a.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; a.cmax = ix->ms->cmax; a.cmax_full = ix->ms->cmax_full;
   const unsigned grid = (unsigned)std::min<uint64_t>(max_items, (uint64_t)nq / MSB_BQ + (uint64_t)nlist + 1);      // sum over partitions of ceil(queries / MSB_BQ)
   if (sd == 8 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<8, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
@@ -1022,7 +1146,7 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
 int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix_c) {
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
   static const bool off = getenv("LANCE_HIP_NO_MSCAN") != nullptr;
-  if (off || !ms_shape(ix, nullptr, nullptr) || (ix->metric != LANCE_HIP_L2 && ix->metric != LANCE_HIP_COSINE) || !ix->model_finite) return LANCE_HIP_OK;
+  if (off || !ms_shape(ix, nullptr, nullptr) || !ix->model_finite) return LANCE_HIP_OK;
   return mscan_prepare(ctx, ix);
 }
 

@@ -636,14 +636,15 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   a.q = qs; a.probes = probes;
   a.centroids = ix->centroids; a.codebook = ix->codebook; a.part_offsets = ix->part_offsets; a.codes = ix->codes;
   a.d = d; a.m = m; a.nprobes = (int)nprobes; a.nlist = nlist; a.keff = (int)keff;
-  a.residual = 1;
+  const bool dot = ix->metric == LANCE_HIP_DOT;      // (qscan_supported: only batches the matrix-core bound pass + scan serve)
+  a.residual = dot ? 0 : 1;
   a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
   a.prof = nullptr;
   a.tglobal = tglobal; a.pool_key = pool_key; a.pool_pos = pool_pos; a.pool_cnt = pool_cnt; a.pool_cap = pool_cap; a.flags = flags;
   a.unbounded = 0; a.loop = 0; a.allow = allow;
   const bool tiled = qscan_tiled_shape(m, sd);
   static const bool exact_bound_env = getenv("LANCE_HIP_EXACT_BOUND") != nullptr;
-  const bool exact_bound = exact_bound_env && !tiled;   // the exact pair kernel has no M > 32 instantiation
+  const bool exact_bound = exact_bound_env && !tiled && !dot;   // the exact pair kernel has no M > 32 instantiation
   {
     // bound pass: the nq (query, nearest partition) pairs grouped by partition
     ScopedTimer t(ctx, "pm_group");
@@ -662,7 +663,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     const size_t lds = pm_lds_base(d, m) + (size_t)PM_CAP_BOUND * 16;
     const bool ok = launch_pm_sd<METRIC_L2>(ctx, a, sd, (unsigned)(nq / 2 + nlist + 1), lds);
     LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
-  } else if (qscan_pt_mode(ix) == 2) {   // per-query tables built before the bound pass and shared with the main pass (search_qt.hip)
+  } else if (!dot && qscan_pt_mode(ix) == 2) {   // per-query tables built before the bound pass and shared with the main pass (search_qt.hip)
     ScopedTimer t(ctx, "ivfpq_scan_c0");
     LH_TRY(qbound_pt_launch(ctx, ix, qs, nq, nprobes, keff, probes, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal,
                             allow));
@@ -673,13 +674,14 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     if (mscan_supported(ix, nq, nprobes))
       mb_rc = msbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow);
     if (mb_rc < 0) return mb_rc;          // a real failure (every LANCE_HIP_E* code is negative): never a silent fall-back
+    if (mb_rc == LH_NOT_TAKEN && dot) return LH_NOT_TAKEN;      // no integer pass for dot: the caller runs the exact pair scan (nothing but scratch was written)
     // ... every other one from the integer histogram, four queries per gather (search_q.hip)
     if (mb_rc == LH_NOT_TAKEN) LH_TRY(qbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow));
   }
   {
     // main pass grouping: class A (bounded) pairs by partition for the filter scan, class B for the exact pair kernel
     ScopedTimer t(ctx, "pm_group");
-    LH_TRY(qscan_group(ctx, probes, nq, nprobes, nlist, tglobal, keys, tbound, pair_starts, pair_idx, item_start4, desc4, max_items4, 4));      // four queries per work item (q_common.cuh: Q_G)
+    LH_TRY(qscan_group(ctx, probes, nq, nprobes, nlist, tglobal, keys, tbound, pair_starts, pair_idx, item_start4, desc4, max_items4, 4, dot ? 1 : 0));      // four queries per work item (q_common.cuh: Q_G)
     hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, 2 * nlist, item_start);
     hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items2, 256)), dim3(256), 0, ctx->stream, item_start, pair_starts, pair_idx,
                        2 * nlist, nlist, (int)nprobes, max_items2, desc);
@@ -692,6 +694,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   if (mscan_supported(ix, nq, nprobes))
     ms_rc = mscan_launch(ctx, ix, qs, nq, nprobes, probes, pair_starts, pair_idx, tbound, seg_cnt, seg_pos, qovf, allow, &qslack, &seg_val, &seg_scale);
   if (ms_rc < 0) return ms_rc;
+  if (ms_rc == LH_NOT_TAKEN && dot) return LH_NOT_TAKEN;
   if (ms_rc == LH_NOT_TAKEN) {
     qslack = nullptr; seg_val = nullptr; seg_scale = nullptr;
     LH_TRY(qscan_launch(ctx, ix, qs, nq, nprobes, pair_idx, item_start4, desc4, max_items4, tbound, seg_cnt, seg_pos, qovf, allow, probes));
@@ -717,7 +720,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     a.cls = 1; a.bound_pass = 0; a.unbounded = 1; a.loop = 1;
     const size_t lds = pm_lds_base(d, m) + (size_t)PM_CAP * 16;
     const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)ctx->num_cus * 3, (uint64_t)max_items2);
-    const bool ok = launch_pm_sd<METRIC_L2>(ctx, a, sd, grid, lds);
+    const bool ok = dot ? launch_pm_sd<METRIC_DOT>(ctx, a, sd, grid, lds) : launch_pm_sd<METRIC_L2>(ctx, a, sd, grid, lds);
     LH_REQUIRE(ok, "partition-major scan: unsupported shape (m=%d, sd=%d)", m, sd);
   }
   {
@@ -738,8 +741,10 @@ int ivfpq_scan_merge_pm(lance_hip_ctx *ctx, const lance_hip_index *ix, const flo
                         uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
-  if (!pm_nobound() && qscan_supported(ix, nq, nprobes))
-    return ivfpq_scan_merge_q(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags, allow);
+  if (!pm_nobound() && qscan_supported(ix, nq, nprobes)) {
+    const int rc = ivfpq_scan_merge_q(ctx, ix, qs, nq, probes, nprobes, keff, k, do_refine, ids, dists, cand_rid, cand_cnt, flags, allow);
+    if (rc != LH_NOT_TAKEN) return rc;      // (dot: the matrix-core passes did not take the batch after all -- the exact pair scan below)
+  }
   const size_t npairs = (size_t)nq * nprobes;
   uint32_t *pair_starts = ctx->scratch_t<uint32_t>("pm.pair_starts", (size_t)2 * nlist + 1);
   uint32_t *pair_idx = ctx->scratch_t<uint32_t>("pm.pair_idx", npairs);

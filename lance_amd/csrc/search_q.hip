@@ -39,12 +39,13 @@ namespace lh {
 // class B (virtual partition = nlist + partition): exact pair kernel.  tbound[q] = T for class A, 0xFFFFFFFF for class B.
 __global__ __launch_bounds__(256) void q_tclass_keys_kernel(const uint32_t *__restrict__ probes, int64_t npairs, int nprobes, int nlist,
                                                             const uint32_t *__restrict__ tglobal, uint32_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ tbound) {
+                                                            uint32_t *__restrict__ tbound, int dot) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= npairs) return;
   const int64_t q = i / nprobes;
   const uint32_t T = tglobal[q];
-  const bool usable = T > 0x80000000u && T < 0xFF800000u;   // order_key(+0.0) < T < order_key(+inf)
+  // order_key(+0.0) < T < order_key(+inf); dot distances (1 - q . c^) have either sign: order_key(-inf) < T < order_key(+inf)
+  const bool usable = T > (dot ? 0x007FFFFFu : 0x80000000u) && T < 0xFF800000u;
   keys[i] = probes[i] + (usable ? 0u : (uint32_t)nlist);
   if (i % nprobes == 0) tbound[q] = usable ? T : 0xFFFFFFFFu;
 }
@@ -421,11 +422,12 @@ struct QmergeArgs {
 // 10-50 partitions one after the other (table build + scan each): 0.2-0.4 ms of single-workgroup latency in front of every
 // merge at C3, whatever the workgroup size (256 lanes: 0.25 ms, 1024 lanes: 0.22 ms).
 // BS: 256 lanes where the table is small (M = 16 / 32); 1024 for the tiled shapes (48-96 KiB of exact table per workgroup).
-template <int SD, int MU, int BS>
+template <int SD, int MU, int BS, bool DOT = false>
 __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
   constexpr int QV = SD / 4;
+  constexpr int QMET = DOT ? METRIC_DOT : METRIC_L2;
   constexpr int CAP = BS > 256 ? 2 * BS : 1024;
   __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
   const SelectOut &o = a.o;
@@ -450,8 +452,11 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
       const_cast<uint32_t *>(a.qovf)[q] = 1u;
     }
     for (int e = threadIdx.x; e < a.d; e += BS) {
-      float v = qv[e] - a.centroids[(int64_t)part * a.d + e];
-      if (a.round_f16) v = __half2float(__float2half_rn(v));
+      float v = qv[e];
+      if constexpr (!DOT) {      // (dot: no residual, pq/distance.rs:60-92)
+        v = v - a.centroids[(int64_t)part * a.d + e];
+        if (a.round_f16) v = __half2float(__float2half_rn(v));
+      }
       r[e] = v;
     }
     __syncthreads();
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
       RegVec<SD> av;
 #pragma unroll
       for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&r[mm * SD + 4 * u]);
-      lutx[idx] = finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, a.codebook + (int64_t)idx * SD));
+      lutx[idx] = finish_metric<QMET>(dist_exact<SD, QMET>(av, a.codebook + (int64_t)idx * SD));
     }
     __syncthreads();
     const uint32_t off = o.part_offsets[part];
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) dist += lutx[(w * 16 + e * 4 + bb) * 256 + ((cws[e] >> (8 * bb)) & 255u)];
         }
+        if constexpr (DOT) dist = dist - ((float)M - 1.0f);      // pq/storage.rs:949-957
         const uint32_t kk = order_key(dist);
         if (kk <= T && row_allowed(a.allow, off + (uint32_t)row)) {
           const uint32_t slot = atomicAdd(&misc[0], 1u);
@@ -532,11 +538,12 @@ __global__ __launch_bounds__(BS) void ivfpq_qrescan_kernel(QmergeArgs a) {
 #else
 #define LH_QM_BOUNDS(BS) __launch_bounds__(BS)
 #endif
-template <int SD, int MU, int BS>
+template <int SD, int MU, int BS, bool DOT = false>
 __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
   constexpr int QV = SD / 4;
+  constexpr int QMET = DOT ? METRIC_DOT : METRIC_L2;
   constexpr int CAP = BS == 128 ? 512 : 1024;   // (key, pos) entries under selection
   static_assert(BS >= SCAN_MAX_KEFF, "tighten_bs selects among one value per lane");
   __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
@@ -659,7 +666,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
         s_cnt[threadIdx.x] = c > (uint32_t)Q_CAP ? 0u : c;    // an overflowed segment comes through the pool (rescan kernel)
         if (a.seg_val) s_yz[threadIdx.x] = a.seg_scale[(int64_t)q * a.nprobes + g0 + threadIdx.x];
       }
-      if (a.vec4) {
+      if constexpr (DOT) {      // no residual (pq/distance.rs:60-92): the query itself, staged once for every probe
+        for (int t = threadIdx.x; t < a.d; t += BS) r[t] = qv[t];
+      } else if (a.vec4) {
         // long rows (C3: 5 probes x 1536 elements per group): 16-byte loads, four independent ones in flight per lane -- the
         // element-at-a-time loop below was a chain of 60 dependent L2 round trips per group at d = 1536
         const int d4 = a.d >> 2, tot4 = ng * d4;
@@ -728,7 +737,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
             const uint32_t pos = l_pos[t];
             const int rr = (int)l_rr[t];
             const uint8_t *rc = a.codes + (int64_t)pos * M;
-            const float *rres = r + rr * dpad;
+            const float *rres = r + (DOT ? 0 : rr * dpad);
             float dist = 0.0f;   // pq/distance.rs:128-141: += table[code] for m = 0..M-1 -- the table entry is recomputed here
 #pragma unroll
             for (int w = 0; w < MU; ++w) {
@@ -752,10 +761,11 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
                   RegVec<SD> av;
 #pragma unroll
                   for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&rres[mm * SD + 4 * u]);
-                  dist += finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
+                  dist += finish_metric<QMET>(dist_exact<SD, QMET>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
                 }
               }
             }
+            if constexpr (DOT) dist = dist - ((float)M - 1.0f);      // pq/storage.rs:949-957
             const uint32_t kk = order_key(dist);
             if (kk <= T) {
               const uint32_t slot = atomicAdd(&misc[0], 1u);
@@ -799,11 +809,12 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
 // residual rows -> codes -> 4 x codebook -> row ids: eight trips.  More than 512 survivors: further chunks are re-read (rare).
 // Same arithmetic, same selection machinery, same outputs as the kernel above (which keeps the batches with more probes than one
 // staging holds).
-template <int SD, int MU, int BS>
+template <int SD, int MU, int BS, bool DOT = false>
 __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int M = MU * 16;
   constexpr int QV = SD / 4;
+  constexpr int QMET = DOT ? METRIC_DOT : METRIC_L2;
   constexpr int CAP = BS == 128 ? 512 : 1024;   // (key, pos) entries under selection
   static_assert(BS >= SCAN_MAX_KEFF, "tighten_bs selects among one value per lane");
   __shared__ uint32_t ckey[CAP], cpos[CAP], sorted[BS], misc[8];
@@ -900,7 +911,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
     };
     if (nchunks > 0) load_chunk(0);
     mark(0);
-    if (a.vec4) {
+    if constexpr (DOT) {      // no residual (pq/distance.rs:60-92): the query itself, staged once for every probe
+      for (int t = threadIdx.x; t < a.d; t += BS) r[t] = qv[t];
+    } else if (a.vec4) {
       const int d4 = a.d >> 2, tot4 = np * d4;
 #pragma unroll 4
       for (int t = threadIdx.x; t < tot4; t += BS) {
@@ -1002,7 +1015,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
           const uint32_t pos = l_pos[t];
           const int rr = (int)l_rr[t];
           const uint8_t *rc = a.codes + (int64_t)pos * M;
-          const float *rres = r + rr * dpad;
+          const float *rres = r + (DOT ? 0 : rr * dpad);
           float dist = 0.0f;   // pq/distance.rs:128-141: += table[code] for m = 0..M-1 -- the table entry is recomputed here
 #pragma unroll
           for (int w = 0; w < MU; ++w) {
@@ -1026,10 +1039,11 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
                 RegVec<SD> av;
 #pragma unroll
                 for (int u = 0; u < QV; ++u) av.q[u] = *reinterpret_cast<const f4 *>(&rres[mm * SD + 4 * u]);
-                dist += finish_metric<METRIC_L2>(dist_exact<SD, METRIC_L2>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
+                dist += finish_metric<QMET>(dist_exact<SD, QMET>(av, reinterpret_cast<const float *>(&cbv[t8][0])));
               }
             }
           }
+          if constexpr (DOT) dist = dist - ((float)M - 1.0f);      // pq/storage.rs:949-957
           const uint32_t kk = order_key(dist);
           if (kk <= T) {
             const uint32_t slot = atomicAdd(&misc[0], 1u);
@@ -1094,7 +1108,10 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   static const bool off = getenv("LANCE_HIP_NO_QSCAN") != nullptr;
   if (off || !ix->model_finite) return false;      // NaN / infinite centroids or codewords: the exact kernels decide (index.h)
   const int scan_metric = ix->metric == LANCE_HIP_COSINE ? LANCE_HIP_L2 : ix->metric;
-  if (scan_metric != LANCE_HIP_L2) return false;                    // entries must be >= 0 (squared L2)
+  // the integer tables need entries >= 0 (squared L2); the dot metric has a quantised flow where the matrix-core scan and its bound pass
+  // serve the batch (search_ms.hip: limits and sums relative to a per-query base distance) -- every other dot batch keeps the exact pair scan
+  if (scan_metric == LANCE_HIP_DOT) { if (!mscan_dot_ready(ix, nq, nprobes)) return false; }
+  else if (scan_metric != LANCE_HIP_L2) return false;
   {
     const int m = (int)ix->m, sd = (int)(ix->d / ix->m);
     if (!((m == 16 || m == 32) && (sd == 4 || sd == 8 || sd == 16)) && !qscan_tiled_shape(m, sd)) return false;
@@ -1115,10 +1132,10 @@ size_t qscan_lds_bytes(int d, int m) {   // dynamic part (the quantised LUT is s
 
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
                 uint32_t *keys, uint32_t *tbound, uint32_t *pair_starts, uint32_t *pair_idx, uint32_t *item_start4, int4 *desc4,
-                uint32_t max_items4, int G) {
+                uint32_t max_items4, int G, int dot) {
   const size_t npairs = (size_t)nq * nprobes;
   hipLaunchKernelGGL(q_tclass_keys_kernel, dim3((unsigned)cdiv(npairs, 256)), dim3(256), 0, ctx->stream, probes, (int64_t)npairs, (int)nprobes,
-                     nlist, tglobal, keys, tbound);
+                     nlist, tglobal, keys, tbound, dot);
   LH_TRY(stable_group(ctx, keys, (int64_t)npairs, (int64_t)npairs, 2 * nlist, 1, pair_starts, pair_idx, (int64_t)npairs, nullptr));
   hipLaunchKernelGGL(q_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, nlist, G, item_start4);
   hipLaunchKernelGGL(q_item_desc_kernel, dim3((unsigned)cdiv(max_items4, 256)), dim3(256), 0, ctx->stream, item_start4, pair_starts, nlist, G,
@@ -1283,25 +1300,25 @@ int qbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   return LANCE_HIP_OK;
 }
 
-template <int SD, int MU>
+template <int SD, int MU, bool DOT = false>
 static void launch_qmerge_mu(lance_hip_ctx *ctx, const QmergeArgs &a, unsigned nq, int bs) {
   const int dpad = (a.d + 3) & ~3;
   const size_t lds_rescan = (size_t)dpad * 4 + (size_t)MU * 16 * 256 * 4;
   // 1024 lanes per overflowed segment for every shape (round 4; M = 16 / 32 had 256: 0.1666 -> 0.1628 ms for rescan + merge at C2 -- the few
   // segments a batch lists, ~5 per 10,000 queries there, are single-workgroup latency in front of the merge)
   const unsigned rgrid = (unsigned)std::min<uint64_t>((uint64_t)nq * a.nprobes, (uint64_t)ctx->num_cus);
-  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, 1024>), dim3(rgrid), dim3(1024), lds_rescan, ctx->stream, a);
+  hipLaunchKernelGGL((ivfpq_qrescan_kernel<SD, MU, 1024, DOT>), dim3(rgrid), dim3(1024), lds_rescan, ctx->stream, a);
   // staged residuals of min(QM_G, nprobes) probes; later the (rowid, key, position) sort buffers
   const size_t lds = std::max((size_t)std::min<int>(a.qm_g, a.nprobes) * dpad * 4, (size_t)SCAN_LCAP * 16);
   // one residual group (nprobes <= qm_g <= 16): the kernel with the short dependent chain; LANCE_HIP_QMERGE_V1=1 keeps the general one (A/B)
   static const bool v1 = getenv("LANCE_HIP_QMERGE_V1") != nullptr;
   if (!v1 && a.nprobes <= a.qm_g) {
-    if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge1g_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((ivfpq_qmerge1g_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
+    if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge1g_kernel<SD, MU, 256, DOT>), dim3(nq), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((ivfpq_qmerge1g_kernel<SD, MU, 128, DOT>), dim3(nq), dim3(128), lds, ctx->stream, a);
     return;
   }
-  if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256>), dim3(nq), dim3(256), lds, ctx->stream, a);
-  else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128>), dim3(nq), dim3(128), lds, ctx->stream, a);
+  if (bs == 256) hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 256, DOT>), dim3(nq), dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL((ivfpq_qmerge_kernel<SD, MU, 128, DOT>), dim3(nq), dim3(128), lds, ctx->stream, a);
 }
 
 int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, const uint32_t *probes, uint32_t nprobes,
@@ -1352,7 +1369,12 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
   }
   static const int bs = getenv("LANCE_HIP_QMERGE_BS") ? atoi(getenv("LANCE_HIP_QMERGE_BS")) : 128;
   bool ok = true;
-  if (m == 16) {
+  if (ix->metric == LANCE_HIP_DOT) {      // the dot flow exists for the matrix-core scan's shapes only (search_ms.hip: ms_shape)
+    if (m == 16 && sd == 4) launch_qmerge_mu<4, 1, true>(ctx, a, nq, bs);
+    else if (m == 16 && sd == 8) launch_qmerge_mu<8, 1, true>(ctx, a, nq, bs);
+    else if (m == 32 && sd == 4) launch_qmerge_mu<4, 2, true>(ctx, a, nq, bs);
+    else ok = false;
+  } else if (m == 16) {
     if (sd == 4) launch_qmerge_mu<4, 1>(ctx, a, nq, bs);
     else if (sd == 8) launch_qmerge_mu<8, 1>(ctx, a, nq, bs);
     else if (sd == 16) launch_qmerge_mu<16, 1>(ctx, a, nq, bs);

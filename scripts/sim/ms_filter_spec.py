@@ -276,6 +276,149 @@ def run_bound(name, x, q, m, nlist, keff=100, max_queries=150, seed=0, verbose=T
     return tot
 
 
+# ---- dot metric (round 6) -------------------------------------------------------------------------------------------------------------
+# dist = 1 - q . c^ (pq/distance.rs:60-92, pq/storage.rs:949-957: sum of M entries 1 - q_m . c_m, minus M - 1; no residual).  The kernels
+# evaluate (1 - q . mu) - q . c' with c' = c^ - mu the reconstruction from the CENTRED codebook (mu: mean codeword of every sub-quantiser):
+#     cbh  = binary16(-2 sigma (c - mu))     rh = binary16(sigma q / 2)     row term = 0
+#     G    = |q| cmax  (cmax >= |c'| of every stored row),   Gf = |q| cmax_full  (cmax_full >= |c^| of every stored row)
+#     E    = 1.05 [2^-10 1.02 G + 2^-16 (G + 1 + |T| + |q . mu| + Gf) + 2^-24 (M + 2)^2] + E_abs
+#     lim  = ((T - 1) + q . mu) + E        pass <=> f32(-lim sigma^2) + sum of products <= -0
+#     S    = clamp(rint(val * (s / sigma^2) + (lim + G) s), 0, 65535),   s = 30000 / (((T - 1) + q . mu + G) + E)     (sum of dist - base, base = 1 - q . mu - G)
+# bound pass: bins of (acc / sigma^2 + G) * 496 / G; T = ((1 - q . mu) - G + Ta) + 1.1 E + 2^-16 (|1 - q . mu| + G + Ta).
+
+
+def ref_lut_dot(qv, cb, m, d):
+    lut = np.empty((m, 256), f32)
+    lib.orc_build_lut_f32(C.c_int(2), P(qv), C.c_size_t(d), P(cb), C.c_size_t(m), C.c_uint32(8), P(lut))
+    return lut
+
+
+def ref_adc_dot(lut, codes):
+    acc = ref_adc(lut, codes)
+    return (acc - f32(lut.shape[0] - 1)).astype(f32)
+
+
+def _dot_E(G, Gf, tmag, qmu, qn, cmax, sigma, d, m):
+    sqd = f32(np.sqrt(f32(d), dtype=f32) + f32(1.0))
+    e_abs = f32(f32(6.1035156e-5) * sqd * (qn + f32(2.0) * cmax) / sigma + f32(d) * f32(3.7252903e-9) / (sigma * sigma))
+    return f32(f32(1.05) * (f32(9.9609375e-4) * G + f32(1.5258789e-5) * (G + f32(1.0) + tmag + abs(qmu) + Gf) + f32(5.9604645e-8) * f32((m + 2) * (m + 2))) + e_abs)
+
+
+def run_dot(name, x, q, m, nlist, keff=100, nprobes=4, max_pairs=200, seed=0, verbose=True):
+    """Filter AND bound pass of the dot flow: (i) the bound T from the nearest partition's histogram is >= its keff-th smallest reference
+    distance; (ii) with that T no row of any probed partition whose reference distance is <= T fails the test; (iii) a passing row's integer
+    sum is within the slack units of (dist_ref - base) s.  Both accumulation orders."""
+    n, d = x.shape
+    sd = d // m
+    cent, _, _, _ = oracle.kmeans_train(x[: min(n, nlist * 256)], nlist, max_iters=6, seed=1, metric="dot")
+    part, _ = oracle.assign(x, cent, "dot")
+    cb, _ = oracle.pq_train(x[: min(n, 65536)], m, max_iters=5, seed=2)
+    cb = np.ascontiguousarray(np.asarray(cb, f32).reshape(m, 256, sd))
+    codes = np.asarray(oracle.pq_encode(x, cb, "dot")).reshape(n, m)
+    mu3 = np.zeros((m, sd), f32)                    # q_codebook_mean_kernel: f32 sums of 256 codewords, times 1 / 256
+    for c in range(256):
+        mu3 = (mu3 + cb[:, c, :]).astype(f32)
+    mu3 = (mu3 * f32(1.0 / 256.0)).astype(f32)
+    mu = mu3.reshape(d)
+    cbc = (cb - mu3[:, None, :]).astype(f32)        # the centring in f32 (ms_codebook_kernel)
+    cbmax = float(np.max(np.abs(cbc)))
+    sigma = f32(np.ldexp(1.0, 13 - int(np.frexp(cbmax)[1])))
+    cbh = (cbc * f32(-2.0) * sigma).astype(f32).astype(f16)
+    rows_h = cbh[np.arange(m)[None, :], codes].reshape(n, d)
+    recc = cbc[np.arange(m)[None, :], codes].reshape(n, d).astype(f64)
+    cmax = f32(np.sqrt((recc ** 2).sum(axis=1).max()) * 1.0001)          # (the kernel: f32 row norms, max, sqrt, x 1.0001)
+    cmax_full = f32(np.sqrt(sum(float((cb[mm].astype(f64) ** 2).sum(axis=1).max()) for mm in range(m))) * 1.00001)
+    sig2 = f32(sigma * sigma)
+    probes, _ = oracle.find_partitions(q, cent, nprobes, "dot")
+    rng = np.random.default_rng(seed)
+    tot = dict(pairs=0, handed=0, must=0, violations=0, survivors=0, sum_violations=0, worst_sum_err=0.0, queries=0, no_bound=0,
+               bound_violations=0, mean_excess=0.0)
+    for qi in rng.permutation(len(q)):
+        if tot["pairs"] >= max_pairs:
+            break
+        qv = q[qi].astype(f32)
+        n2 = f32(0.0); qmu = f32(0.0)
+        for e in range(d):
+            n2 = f32(n2 + f32(qv[e] * qv[e])); qmu = f32(qmu + f32(qv[e] * mu[e]))
+        qn = f32(np.sqrt(n2, dtype=f32) * f32(1.000001))
+        G = f32(qn * cmax * f32(1.000001)); Gf = f32(qn * cmax_full * f32(1.000001))
+        rh = (qv * f32(0.5) * sigma).astype(f32).astype(f16)
+        lut = ref_lut_dot(qv, cb, m, d)
+        p0 = int(probes[qi, 0])
+        rows0 = np.nonzero(part == p0)[0]
+        if len(rows0) < keff or not G > 0:
+            continue
+        tot["queries"] += 1
+        dref0 = ref_adc_dot(lut, codes[rows0])
+        true_k = float(np.partition(dref0, keff - 1)[keff - 1])
+        Ts = []
+        for order in ("seq", "tree"):      # ---- bound pass
+            sb = f32(f32(496.0) / G)
+            a = f32(sb / sig2); b = f32(G * sb)
+            acc = mfma_acc(np.zeros(len(rows0), f32), rows_h[rows0], rh, order)
+            t = (acc.astype(f64) * f64(a) + f64(b)).astype(f32)
+            inb = t < f32(512.0)
+            hist = np.bincount(np.maximum(t[inb].astype(np.int64), 0), minlength=512)
+            hit = np.nonzero(np.cumsum(hist) >= keff)[0]
+            if hit.size == 0:
+                Ts.append(None); continue
+            Ta = f32(f32(f32(int(hit[0]) + 1) / sb) * f32(1.000001))
+            tmag = f32(abs(f32(1.0) - qmu) + G + Ta)
+            E = _dot_E(G, Gf, tmag, qmu, qn, cmax, sigma, d, m)
+            T = f32(f32(f32(f32(1.0) - qmu) - G) + Ta) + f32(f32(1.1) * E + f32(1.5258789e-5) * tmag)
+            T = f32(T)
+            tot["bound_violations"] += int(not (float(T) >= true_k))
+            Ts.append(T)
+        if Ts[0] is None:
+            tot["no_bound"] += 1
+            continue
+        T = Ts[0]
+        tot["mean_excess"] += (float(T) - true_k) / max(float(G), 1e-30)
+        # ---- filter with that T over every probed partition
+        E = _dot_E(G, Gf, abs(T), qmu, qn, cmax, sigma, d, m)
+        Tq = f32(f32(T - f32(1.0)) + qmu)
+        Tp = f32(f32(Tq + G) + E)
+        s = f32(MS_SE / Tp)
+        eu = f32(E * s * f32(1.1) + f32(3.0))
+        lim = f32(Tq + E)
+        zsum = f32(f32(lim + G) * s)
+        vmax = f32(np.max(np.abs(qv)))
+        ok = bool(np.isfinite(T) and Tp > 0 and np.isfinite(Tp) and s > 0 and np.isfinite(s) and np.isfinite(Gf) and vmax * sigma < 60000.0
+                  and eu <= MS_SLACK_CAP and np.isfinite(lim * sig2) and G * s < 1e30 and abs(zsum) < 1e30)
+        for pr in probes[qi]:
+            rows = np.nonzero(part == int(pr))[0]
+            if len(rows) == 0:
+                continue
+            tot["pairs"] += 1
+            if not ok:
+                tot["handed"] += 1
+                continue
+            dref = ref_adc_dot(lut, codes[rows])
+            must = dref <= T
+            units = int(np.ceil(eu))
+            base = f64(1.0) - f64(qmu) - f64(G)
+            for order in ("seq", "tree"):
+                acc = mfma_acc(np.full(len(rows), -f32(lim * sig2), f32), rows_h[rows], rh, order)
+                passed = acc <= f32(-0.0)
+                tot["violations"] += int(np.sum(must & ~passed))
+                if order == "seq":
+                    tot["must"] += int(must.sum()); tot["survivors"] += int(passed.sum())
+                S = np.clip(np.rint((acc[passed].astype(f64) * f64(f32(s / sig2)) + f64(zsum)).astype(f32)), 0, 65535)
+                err = np.abs(S.astype(f64) - np.maximum((dref[passed].astype(f64) - base) * f64(s), 0.0))
+                if err.size:
+                    tot["worst_sum_err"] = max(tot["worst_sum_err"], float(np.max(err / units)))
+                    tot["sum_violations"] += int(np.sum(err > units))
+    if tot["queries"] > tot["no_bound"]:
+        tot["mean_excess"] /= (tot["queries"] - tot["no_bound"])
+    if verbose:
+        print(f"{name} [dot]: d={d} M={m} sigma=2^{int(np.log2(sigma))} cmax={float(cmax):.4g} (full {float(cmax_full):.4g}) queries={tot['queries']} "
+              f"without a bound={tot['no_bound']} T below the true keff-th distance={tot['bound_violations']} mean (T - true) / G={tot['mean_excess']:.5f} | "
+              f"pairs={tot['pairs']} handed_to_rescan={tot['handed']} rows_with_dist<=T={tot['must']} violations={tot['violations']} "
+              f"survivors={tot['survivors']} ({tot['survivors'] / max(tot['must'], 1):.2f} x) largest |S - (dist - base) s| / slack units="
+              f"{tot['worst_sum_err']:.3f} sum_violations={tot['sum_violations']}")
+    return tot
+
+
 def sift_like(n, d, seed):
     rng = np.random.default_rng(seed)
     centers = rng.uniform(0, 128, (64, d))
@@ -302,6 +445,11 @@ def main():
     run_bound("unit vectors", xu.astype(f32), qu.astype(f32), 16, 16)
     run_bound("rows far from the origin", x + f32(3000.0), q + f32(3000.0), 16, 16)
     run_bound("d=64 M=16", x64, sift_like(200, 64, 6), 16, 12, keff=10)
+    run_dot("sift-like integer rows", x, q, 16, 16)
+    run_dot("sift-like, M=32", x, q, 32, 16)
+    run_dot("unit vectors", xu.astype(f32), qu.astype(f32), 16, 16)
+    run_dot("centred rows (dot products of both signs)", x - f32(64.0), q - f32(64.0), 16, 16)
+    run_dot("d=64 M=16", x64, sift_like(200, 64, 6), 16, 12, keff=10)
 
 
 if __name__ == "__main__":

@@ -23,6 +23,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("LANCE_HIP_DOT_FLOW_SKEW", "1e18")      # dot batches take the quantised flow whatever the list-size skew (tests/conftest.py)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

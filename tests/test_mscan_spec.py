@@ -70,3 +70,33 @@ def test_bound_pass_gives_no_bound_to_residuals_beyond_binary16(spec):
     with np.errstate(over="ignore"):
         t = spec.run_bound("far", xi, qf, 16, 8, keff=60, max_queries=40, seed=3, verbose=False)
     assert t["queries"] >= 30 and t["violations"] == 0 and t["no_bound"] == t["queries"]
+
+
+@pytest.mark.parametrize("d,m,keff", [(128, 16, 60), (128, 32, 60), (64, 16, 10)])
+def test_dot_flow_bound_and_filter(spec, d, m, keff):
+    """Round 6, the dot metric on the same kernels (operand q / 2 against the CENTRED codebook plane, row term zero, limits and sums relative to
+    base = 1 - q . mu - |q| cmax): the histogram bound is never below the nearest partition's keff-th reference distance
+    (pq/distance.rs:60-92 table, sequential sum, minus M - 1), no row under the bound fails the test in any probed partition, and every passing
+    row's integer sum is within the slack units of (dist - base) s -- for SIFT-like rows (all distances large and negative)."""
+    x = spec.sift_like(12000, d, 41 + d + m)
+    q = spec.sift_like(120, d, 42 + d + m)
+    t = spec.run_dot(f"d={d} M={m}", x, q, m, 8, keff=keff, nprobes=3, max_pairs=36, seed=d + m, verbose=False)
+    assert t["queries"] >= 10 and t["no_bound"] == 0 and t["must"] > 300
+    assert t["bound_violations"] == 0 and t["violations"] == 0 and t["sum_violations"] == 0
+    assert t["survivors"] <= 1.3 * t["must"] and t["worst_sum_err"] <= 1.0
+    assert t["mean_excess"] < 0.01              # T sits within 1 % of G above the true keff-th distance
+
+
+def test_dot_flow_unit_vectors_and_signed_rows(spec):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((12000, 128)).astype(f32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = rng.standard_normal((100, 128)).astype(f32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = spec.run_dot("unit", x.astype(f32), q.astype(f32), 16, 8, keff=60, nprobes=3, max_pairs=30, seed=1, verbose=False)
+    assert t["bound_violations"] == 0 and t["violations"] == 0 and t["sum_violations"] == 0 and t["must"] > 300
+    xi = spec.sift_like(12000, 128, 23) - f32(64.0)      # dot products of both signs, distances on both sides of zero
+    qi = spec.sift_like(100, 128, 24) - f32(64.0)
+    qi[0::3] *= f32(8.0)
+    t = spec.run_dot("centred", xi, qi, 16, 8, keff=60, nprobes=3, max_pairs=36, seed=2, verbose=False)
+    assert t["bound_violations"] == 0 and t["violations"] == 0 and t["sum_violations"] == 0 and t["must"] > 300
