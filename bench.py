@@ -716,6 +716,22 @@ def main():
         except Exception as e:      # the extra is informational: never fail the line over it
             result["qps_f32_refine_source"] = {"error": str(e)[:200]}
 
+    # the other metrics on the same shape (one engine context, unit-normalised rows -- what a dot index is normally built on): L2 / cosine / dot
+    # through the matrix-core flow, and dot on the exact pair scan it replaces there (LANCE_HIP_NO_DOT_FLOW=1); children of scripts/probe_dot_flow.py
+    if world == 1 and not multi and not args.no_extras and args.config == "c2" and os.environ.get("LANCE_BENCH_CHILD") != "1":
+        import subprocess
+        probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "probe_dot_flow.py")
+        om = {"what": "1M x 128 unit-normalised SIFT-like rows, IVF_PQ(256,16), 10,000-query batches, k 10, nprobes 10, refine 10, ONE engine context, "
+                      "wall clock over 20 batches (scripts/probe_dot_flow.py json)"}
+        try:
+            cp = subprocess.run([sys.executable, probe, "json", "l2", "cosine", "dot"], env=dict(os.environ, LANCE_BENCH_CHILD="1"), capture_output=True, text=True, timeout=300)
+            om.update(json.loads([l for l in cp.stdout.strip().splitlines() if l.startswith("{")][-1]))
+            cp = subprocess.run([sys.executable, probe, "json", "dot"], env=dict(os.environ, LANCE_BENCH_CHILD="1", LANCE_HIP_NO_DOT_FLOW="1"), capture_output=True, text=True, timeout=300)
+            om["dot_exact_pair_scan"] = json.loads([l for l in cp.stdout.strip().splitlines() if l.startswith("{")][-1])["dot"]
+        except Exception as e:      # informational: never fail the line over it
+            om["error"] = str(e)[:200]
+        result["other_metrics"] = om
+
     if not args.no_cpu_baseline and world == 1:
         import oracle as orc
         native = orc.use_native_build()      # time the CPU side with code generated for THIS host

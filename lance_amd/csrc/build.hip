@@ -292,6 +292,7 @@ lance_hip_index::~lance_hip_index() {
     if (ms->cbh) (void)hipFree(ms->cbh);
     if (ms->cbn2) (void)hipFree(ms->cbn2);
     if (ms->row_cn2) (void)hipFree(ms->row_cn2);
+    if (ms->cmaxp) (void)hipFree(ms->cmaxp);
     delete ms;
   }
   if (part_offsets) (void)hipFree(part_offsets);

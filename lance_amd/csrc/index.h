@@ -45,6 +45,7 @@ struct lance_hip_index {
     float *row_cn2 = nullptr;     // [n] sigma^2 |reconstruction of the stored row|^2 (dot metric: zeros)
     float cmax = 0.0f;            // dot metric: upper bound of |centred reconstruction of any stored row| (codewords minus their sub-quantiser's mean: the plane cbh holds those); search_ms.hip
     float cmax_full = 0.0f;       // dot metric: upper bound of |reconstruction of any stored row|
+    float *cmaxp = nullptr;       // dot metric: [nlist] upper bound of |centred reconstruction| over the rows of one list
     uint32_t sum_rs = 0, max_rs = 0;   // row slices (of 2048 rows) summed over the partitions / of the largest partition: bound the slice table
   } *ms = nullptr;
   // find_partitions over thousands of lists (xform_fused.hip MODE 2): the centroids' bf16 planes [nlist ^ 64][2 d + 16] and max |c|^2, built by the

@@ -99,6 +99,20 @@ __global__ __launch_bounds__(256) void ms_max_kernel(const float *__restrict__ v
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// dot metric: cmaxp[p] = upper bound of |centred reconstruction| over the rows of list p (v = sigma^2 |c'|^2 per row); one workgroup per list
+__global__ __launch_bounds__(256) void ms_part_max_kernel(const float *__restrict__ v, const uint32_t *__restrict__ part_offsets, float inv_sigma,
+                                                          float *__restrict__ cmaxp) {
+  __shared__ float wm[4];
+  const uint32_t b = part_offsets[blockIdx.x], e = part_offsets[blockIdx.x + 1];
+  float m = 0.0f;
+  for (uint32_t i = b + threadIdx.x; i < e; i += 256) m = fmaxf(m, v[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) cmaxp[blockIdx.x] = sqrtf(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))) * inv_sigma * 1.0001f;
+}
+
 // ---- per-pair pre-pass: f16 residual (scaled by sigma), limit, integer-sum scale --------------------------------------------------
 struct MsPrepArgs {
   const float *q, *centroids;
@@ -116,6 +130,8 @@ struct MsPrepArgs {
   f2 *prm2;                     // [nq * nprobes] by PAIR: {s / sigma^2, (T' + E) s} -- what turns a survivor's accumulator value into its integer sum
   int dot = 0;                  // dot metric (no residual: the operand is q / 2 for every partition; limits and sums relative to a per-query base)
   float cmax = 0.0f;            // dot: upper bound of |CENTRED reconstruction of any stored row| (MsConst::cmax)
+  const float *cmaxp = nullptr; // dot: [nlist] the same bound over the rows of one list: the pair's slack E and limit use it (the sums keep the index-wide
+                                // one: all sums of a query share one base and one scale)
   float cmax_full = 0.0f;       // dot: upper bound of |reconstruction of any stored row| (the reference's own rounding terms)
   const float *mu = nullptr;    // dot: [d] the mean codeword of every sub-quantiser (lance_hip_index::cb_mean)
   int m = 0;
@@ -196,10 +212,15 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
     const float qn = sqrtf(n2l) * 1.000001f;
     const float G = qn * p.cmax * 1.000001f, Gf = qn * p.cmax_full * 1.000001f;
     const float e_abs = 6.1035156e-5f * sqd * (qn + 2.0f * p.cmax) / p.sigma + (float)p.d * 3.7252903e-9f / sig2;
-    const float E = 1.05f * (9.9609375e-4f * G + 1.5258789e-5f * (G + 1.0f + fabsf(T) + fabsf(qmul) + Gf) + 5.9604645e-8f * (float)((p.m + 2) * (p.m + 2))) + e_abs;     // 2^-10 * 1.02, 2^-16, 2^-24
+    auto slack = [&](float g) {     // 2^-10 * 1.02, 2^-16, 2^-24
+      return 1.05f * (9.9609375e-4f * g + 1.5258789e-5f * (g + 1.0f + fabsf(T) + fabsf(qmul) + Gf) + 5.9604645e-8f * (float)((p.m + 2) * (p.m + 2))) + e_abs;
+    };
     const float Tq = (T - 1.0f) + qmul;         // the bound as a limit on -(q . c')
-    const float Tp = (Tq + G) + E;              // ... in the shifted domain (> 0: T bounds a real distance, every distance is >= base - E)
+    const float Tp = (Tq + G) + slack(G);       // ... in the shifted domain (> 0: T bounds a real distance, every distance is >= base - E): per QUERY
     s = MS_SE / Tp;
+    // the pair's own slack: the rows it meets are those of ONE list, whose longest centred reconstruction bounds |q . c'| for them
+    const float Gp = fminf(G, qn * p.cmaxp[p.probes[pairl]] * 1.000001f);
+    const float E = slack(Gp);
     eu = E * s * 1.1f + 3.0f;
     lim = Tq + E;                               // a row is kept when -(q . c')~ <= T - 1 + q . mu + E
     zsum = (lim + G) * s;                       // sum = (-(q . c')~ - lim) s + (lim + G) s = (dist~ - base) s
@@ -344,7 +365,9 @@ struct MscanArgs {
   uint32_t nan_slot;
   int nlist, nprobes;
   uint32_t *seg_cnt, *seg_pos;
-  float *seg_val = nullptr;     // [nq * nprobes][Q_CAP] the survivors' accumulator values (the merge kernel scales them into integer sums)
+  uint2 *seg_pv = nullptr;      // [nq * nprobes][Q_CAP] the survivors: {storage position, accumulator value (bits)} -- ONE 8-byte store per survivor
+                                // (two arrays were two partial cache lines per survivor: 53 bytes of HBM writes per 8-byte record, r05 PMC); the merge
+                                // kernel scales the values into integer sums
   uint32_t *ovf;
   const uint32_t *allow;
 #ifdef LH_TIMING_EXPERIMENTS
@@ -406,8 +429,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
         const uint2 ent = qw[((uint32_t)(MS_QH + 1) - cur) + (uint32_t)lane];
         const uint32_t pair = sPair[ent.x >> 8];
         if (pd_k < (uint32_t)Q_CAP) {
-          p.seg_pos[(int64_t)pair * Q_CAP + pd_k] = pd_base + (ent.x & 255u);
-          p.seg_val[(int64_t)pair * Q_CAP + pd_k] = __uint_as_float(ent.y);
+          p.seg_pv[(int64_t)pair * Q_CAP + pd_k] = make_uint2(pd_base + (ent.x & 255u), ent.y);
         } else if (pd_k == (uint32_t)Q_CAP) {      // the segment lost survivors from here on: exact rescan of this (query, probe)
           p.ovf[1u + atomicAdd(&p.ovf[0], 1u)] = pair;      // (the rescan kernel flags the query)
         }
@@ -645,6 +667,7 @@ struct MsBoundArgs {
   const uint32_t *allow;
   int dot = 0;                  // dot metric: operand q / 2, no residual, centred codebook plane; bins of (dist~ - base), base = (1 - q . mu) - |q| cmax (ms_prep_kernel)
   float cmax = 0.0f, cmax_full = 0.0f;
+  const float *cmaxp = nullptr; // dot: [nlist] per-list bound of |centred reconstruction| (the workgroup's list: bins and slack use it)
 };
 
 template <int SD, int KS>
@@ -729,7 +752,7 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
         if (sl < cnt) {
           // L2: sum over m of the mean table entry = the distance of a random code.  dot: the same minus base = (1 - q . mu) - G, G = |q| cmax >=
           // |q . c'| (ms_prep_kernel; the centred codewords average to zero): mean - base = G; the bins count (dist~ - base) sb = (acc / sigma^2 + G) sb
-          const float G = sqrtf(n2) * 1.000001f * p.cmax * 1.000001f;
+          const float G = p.dot ? sqrtf(n2) * 1.000001f * fminf(p.cmax, p.cmaxp[part]) * 1.000001f : 0.0f;      // (this list's rows only)
           const float mean = p.dot ? G : n2 - 2.0f * rmu + p.cb_mean[D];
           const float off = p.dot ? G : n2;
           sb = MSB_MEAN_BIN / mean;
@@ -862,7 +885,7 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
         const float sqd = sqrtf((float)D) + 1.0f;
         if (p.dot) {
           // every counted row has dist~ - base < Ta; its reference distance is <= base + Ta + E (ms_prep_kernel's E with |T| <= |base| + Ta)
-          const float G = rn * p.cmax * 1.000001f, Gf = rn * p.cmax_full * 1.000001f, qmu = sRmu[sl];
+          const float G = rn * fminf(p.cmax, p.cmaxp[part]) * 1.000001f, Gf = rn * p.cmax_full * 1.000001f, qmu = sRmu[sl];
           const float tmag = fabsf(1.0f - qmu) + G + Ta;
           const float e_abs = 6.1035156e-5f * sqd * (rn + 2.0f * p.cmax) / p.sigma + (float)D * 3.7252903e-9f / (p.sigma * p.sigma);
           const float E = 1.05f * (9.9609375e-4f * G + 1.5258789e-5f * (G + 1.0f + tmag + fabsf(qmu) + Gf) + 5.9604645e-8f * (float)((M + 2) * (M + 2))) + e_abs;
@@ -931,13 +954,15 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   LH_CHECK_HIP(hipMemcpyAsync(cb.data(), ix->codebook, cb.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   const bool dot = ix->metric == LANCE_HIP_DOT;
-  auto *mc = new lance_hip_index::MsConst();
   std::vector<float> mu;      // dot: the plane holds the codewords minus their sub-quantiser's mean (ms_prep_kernel) -- the device's own cb_mean, so that
-  if (dot) {                  // the centring here and the q . mu of the pre-pass use the same numbers
-    if (!ix->cb_mean) { mc->usable = false; ix->ms = mc; return LANCE_HIP_OK; }
+  if (dot && ix->cb_mean) {   // the centring here and the q . mu of the pre-pass use the same numbers
     mu.resize((size_t)d);
     LH_CHECK_HIP(hipMemcpyAsync(mu.data(), ix->cb_mean, (size_t)d * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  auto *mc = new lance_hip_index::MsConst();      // (no early return between here and its publication / drop())
+  if (dot) {
+    if (!ix->cb_mean) { mc->usable = false; ix->ms = mc; return LANCE_HIP_OK; }
     // |reconstruction of any row|^2 <= sum over the sub-quantisers of their longest codeword's |c|^2 (only the reference's rounding terms use it)
     double tot = 0.0;
     for (int mm = 0; mm < m; ++mm) {
@@ -964,7 +989,8 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
   bool ok = hipMalloc(reinterpret_cast<void **>(&mc->cbh), (size_t)nwords * sd * 2) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void **>(&mc->cbn2), (size_t)nwords * 4) == hipSuccess;
   ok = ok && hipMalloc(reinterpret_cast<void **>(&mc->row_cn2), (size_t)ix->n * 4) == hipSuccess;
-  auto drop = [&]() { (void)hipFree(mc->cbh); (void)hipFree(mc->cbn2); (void)hipFree(mc->row_cn2); delete mc; };
+  if (dot) ok = ok && hipMalloc(reinterpret_cast<void **>(&mc->cmaxp), (size_t)std::max<uint32_t>(ix->nlist, 1u) * 4) == hipSuccess;
+  auto drop = [&]() { (void)hipFree(mc->cbh); (void)hipFree(mc->cbn2); (void)hipFree(mc->row_cn2); (void)hipFree(mc->cmaxp); delete mc; };
   if (!ok) { drop(); set_error("matrix-core scan: out of device memory for the index constants"); return LANCE_HIP_ENOMEM; }
   hipLaunchKernelGGL(ms_codebook_kernel, dim3((unsigned)cdiv((uint64_t)nwords, 256)), dim3(256), 0, ctx->stream, ix->codebook, nwords, sd,
                      -2.0f * mc->sigma, reinterpret_cast<_Float16 *>(mc->cbh), mc->cbn2, dot ? ix->cb_mean : nullptr);
@@ -978,6 +1004,7 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
     (void)lh::memset_async(mx, 0, 4, ctx->stream);
     hipLaunchKernelGGL(ms_max_kernel, dim3(256), dim3(256), 0, ctx->stream, mc->row_cn2, (int64_t)ix->n, mx);
     (void)hipMemcpyAsync(&rowmax_bits, mx, 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipLaunchKernelGGL(ms_part_max_kernel, dim3(ix->nlist), dim3(256), 0, ctx->stream, mc->row_cn2, ix->part_offsets, 1.0f / mc->sigma, mc->cmaxp);
     (void)lh::memset_async(mc->row_cn2, 0, (size_t)ix->n * 4, ctx->stream);
   }
   for (uint32_t pid = 0; pid < ix->nlist; ++pid) {
@@ -1021,7 +1048,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   uint32_t *slice_start = ctx->scratch_t<uint32_t>("ms.slice_start", (size_t)nlist + 2 + 32);      // [nlist + 1], the work counter, 32 class cursors
   MsSlice *slices = reinterpret_cast<MsSlice *>(ctx->scratch("ms.slices", cap * sizeof(MsSlice)));
   uint32_t *order = ctx->scratch_t<uint32_t>("ms.order", cap);
-  float *seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP);
+  float *seg_val = ctx->scratch_t<float>("ms.seg_val", npairs * Q_CAP * 2);      // uint2 records {position, value}
   uint32_t *ovf = ctx->scratch_t<uint32_t>("q.ovf", npairs + 1);                // the merge launcher asks for the same slot
   if (!rh || !prm || !prm2 || !qslack || !slice_start || !slices || !order || !seg_val || !ovf) return LANCE_HIP_ENOMEM;
   uint32_t *slice_ctr = slice_start + nlist + 1, *cls_cursor = slice_ctr + 1;
@@ -1034,7 +1061,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.d = d; pa.nprobes = (int)nprobes; pa.nlist = nlist; pa.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0;
     pa.sigma = ix->ms->sigma; pa.rh = rh; pa.prm = prm; pa.qslack = qslack; pa.seg_cnt = seg_cnt; pa.qovf = qovf; pa.ovf = ovf;
     pa.nan_slot = nan_slot; pa.prm2 = prm2;
-    pa.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; pa.cmax = ix->ms->cmax; pa.cmax_full = ix->ms->cmax_full; pa.mu = ix->cb_mean; pa.m = (int)ix->m;
+    pa.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; pa.cmax = ix->ms->cmax; pa.cmax_full = ix->ms->cmax_full; pa.cmaxp = ix->ms->cmaxp; pa.mu = ix->cb_mean; pa.m = (int)ix->m;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
     const uint32_t rs_rows = (uint32_t)ms_rows_per_slice();
     static const bool no_order = getenv("LANCE_HIP_MS_NOORDER") != nullptr;      // A/B: one work class = slices in (roughly) index order
@@ -1050,7 +1077,7 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
   a.order = order; a.slices = slices; a.slice_start = slice_start; a.slice_ctr = slice_ctr; a.codes = ix->codes;
   a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2; a.rh = rh; a.prm = prm; a.prm2 = prm2;
   a.nan_slot = nan_slot; a.nlist = nlist; a.nprobes = (int)nprobes;
-  a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_val = seg_val; a.ovf = ovf; a.allow = allow;
+  a.seg_cnt = seg_cnt; a.seg_pos = seg_pos; a.seg_pv = reinterpret_cast<uint2 *>(seg_val); a.ovf = ovf; a.allow = allow;
 #ifdef LH_TIMING_EXPERIMENTS
   static const int dbg = [] {
     const int v = getenv("LANCE_HIP_MS_DBG") ? atoi(getenv("LANCE_HIP_MS_DBG")) : 0;
@@ -1134,7 +1161,7 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
   a.part_offsets = ix->part_offsets; a.codes = ix->codes; a.cbh = reinterpret_cast<const _Float16 *>(ix->ms->cbh); a.row_cn2 = ix->ms->row_cn2;
   a.d = (int)ix->d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0; a.sigma = ix->ms->sigma;
   a.tglobal = tglobal; a.allow = allow;
-  a.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; a.cmax = ix->ms->cmax; a.cmax_full = ix->ms->cmax_full;
+  a.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; a.cmax = ix->ms->cmax; a.cmax_full = ix->ms->cmax_full; a.cmaxp = ix->ms->cmaxp;
   const unsigned grid = (unsigned)std::min<uint64_t>(max_items, (uint64_t)nq / MSB_BQ + (uint64_t)nlist + 1);      // sum over partitions of ceil(queries / MSB_BQ)
   if (sd == 8 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<8, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);

@@ -393,7 +393,8 @@ struct QmergeArgs {
   int cut_shift;                 // histogram bin = sum >> cut_shift (512 bins cover 0 .. LIM)
   uint32_t cut_slack;            // a survivor whose sum exceeds (upper edge of the keff-th bin) + cut_slack cannot reach the top keff
   const uint32_t *qslack;        // search_ms.hip: [nq] per-query bound of |sum - dist * s| (units); the cut carries twice that on top of cut_slack
-  const float *seg_val;          // search_ms.hip (rows-on-lanes kernel): [nq * nprobes][Q_CAP] the survivors' accumulator values instead of seg_sum;
+  const float *seg_val;          // search_ms.hip (rows-on-lanes kernel): != NULL -> the survivors come as {position, accumulator value} records
+  const uint2 *seg_pv;           //   [nq * nprobes][Q_CAP] (the same pointer) instead of seg_pos / seg_sum;
   const f2 *seg_scale;           //   sum = rint(val * seg_scale[pair].x + seg_scale[pair].y), clamped to 0 .. 65535
 #ifdef LH_TIMING_EXPERIMENTS      // builds with -DLH_TIMING_EXPERIMENTS only (scripts/build_variant.sh): the product library has no such switch
   int dbg;                       // LANCE_HIP_QM_DBG (timing experiments, results WRONG): the kernel returns after 1: the cut, 2: staging the residuals,
@@ -622,7 +623,7 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
           if (t >= pi) { rr = i; st = pi; }
         }
         const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
-        const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a.seg_val[e], s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
+        const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(__uint_as_float(a.seg_pv[e].y), s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
                                       : (uint32_t)a.seg_sum[e];
         atomicAdd(&s_hist[min(511u, sv >> a.cut_shift)], 1u);
       }
@@ -717,11 +718,13 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge_kernel(QmergeArgs a) {
             if (t >= pi) { rr = i; st = pi; }   // s_pre[] is non-decreasing and t < s_pre[QM_G]: the last hit is the segment
           }
           const int64_t e = ((int64_t)q * a.nprobes + g0 + rr) * Q_CAP + (t - st);
-          const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a.seg_val[e], s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
+          uint2 pv = make_uint2(0u, 0u);
+          if (a.seg_val) pv = a.seg_pv[e];
+          const uint32_t sv = a.seg_val ? (uint32_t)__builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(__uint_as_float(pv.y), s_yz[rr].x, s_yz[rr].y)), 0.0f, 65535.0f)
                                         : (uint32_t)a.seg_sum[e];
           if (sv <= cut) {
             const uint32_t slot = atomicAdd(&l_cnt, 1u);
-            l_pos[slot] = a.seg_pos[e]; l_rr[slot] = (uint8_t)rr;
+            l_pos[slot] = a.seg_val ? pv.x : a.seg_pos[e]; l_rr[slot] = (uint8_t)rr;
           }
         }
         __syncthreads();
@@ -897,9 +900,9 @@ __global__ LH_QM_BOUNDS(BS) void ivfpq_qmerge1g_kernel(QmergeArgs a) {
             run += (int)s_cnt[i];
           }
           const int64_t e = ((int64_t)q * np + rr) * Q_CAP + (t - st);
-          sv_pos[j] = a.seg_pos[e];
           sv_rr[j] = (uint32_t)rr;
-          sv_sum[j] = a.seg_val ? __float_as_uint(a.seg_val[e]) : (uint32_t)a.seg_sum[e];      // (the value's conversion waits until it is used)
+          if (a.seg_val) { const uint2 pv = a.seg_pv[e]; sv_pos[j] = pv.x; sv_sum[j] = pv.y; }      // (the value's conversion waits until it is used)
+          else { sv_pos[j] = a.seg_pos[e]; sv_sum[j] = (uint32_t)a.seg_sum[e]; }
         }
       }
     };
@@ -1327,7 +1330,7 @@ int qmerge_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs
                   const uint32_t *qslack, const float *seg_val, const float *seg_scale) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m;
   QmergeArgs a;
-  a.qslack = qslack; a.seg_val = seg_val; a.seg_scale = reinterpret_cast<const f2 *>(seg_scale);
+  a.qslack = qslack; a.seg_val = seg_val; a.seg_pv = reinterpret_cast<const uint2 *>(seg_val); a.seg_scale = reinterpret_cast<const f2 *>(seg_scale);
 #ifdef LH_TIMING_EXPERIMENTS
   {
     static const int dbg = [] {

@@ -10,7 +10,7 @@ from lance_amd.testing import sift_like
 
 STAGES = ["find_partitions", "pm_group", "ivfpq_scan_c0", "q_residual", "ivfpq_scan_c1", "ivfpq_scan_cb", "ivfpq_merge", "refine"]
 
-def run(tag, x, qn, metric):
+def run(tag, x, qn, metric, quiet=False):
     q = torch.from_numpy(qn).cuda()
     eng = lance_amd.default_engine()
     idx = lance_amd.create_index(x, "IVF_PQ", metric=metric, num_partitions=256, num_sub_vectors=16)
@@ -28,6 +28,10 @@ def run(tag, x, qn, metric):
     line = f"{tag} {metric}: {dt * 1e3:.3f} ms per batch = {len(qn) / dt / 1e6:.2f} M q/s, matrix-core scan served {took} of {reps}"
     if sizes is not None:
         line += f"; list sizes min {sizes.min()} median {int(np.median(sizes))} max {sizes.max()}"
+    if quiet:
+        del idx
+        return {"ms_per_batch": round(dt * 1e3, 4), "qps_one_context": round(len(qn) / dt), "matrix_core_scan_batches": int(took), "batches": reps,
+                "list_sizes_min_median_max": None if sizes is None else [int(sizes.min()), int(np.median(sizes)), int(sizes.max())]}
     print(line, flush=True)
     # per-stage times (plain path, events around every stage)
     eng.timing(True)
@@ -44,7 +48,12 @@ if __name__ == "__main__":
     n, d, nq = 1_000_000, 128, 10_000
     x = sift_like(n, d, seed=1); qn = sift_like(nq, d, seed=2)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    if which == "all":
+    if which == "json":      # bench.py's child: unit-normalised rows, the metrics named on the command line -> one JSON line
+        import json
+        xu = (x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+        qu = (qn / np.maximum(np.linalg.norm(qn, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+        print(json.dumps({mt: run("unit", xu, qu, mt, quiet=True) for mt in sys.argv[2:]}), flush=True)
+    elif which == "all":
         for env in ({}, {"LANCE_HIP_NO_DOT_FLOW": "1"}):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env), capture_output=True, text=True)
             print(("quantised flow" if not env else "exact pair scan (LANCE_HIP_NO_DOT_FLOW=1)") + ":\n" + "".join(l + "\n" for l in r.stdout.splitlines() if "amdgpu.ids" not in l) + r.stderr[-1500:], flush=True)
