@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, LH_FM_WAVES) void flat_filter_mfma_kernel(FmAr
         // no threshold yet, or a NaN threshold: every row is a candidate for the exact test
         const float T = tk >= 0xFF800000u ? INFINITY : key_to_float(tk);
         pqn = qn;
-        ptq = METRIC == METRIC_DOT ? T + 0.000244140625f * qn : T - (qn - 0.000244140625f * qn);   // s' <= ptq  with  s' = xk - 2 x.q  (dot: xk + 1 - x.q)
+        ptq = METRIC == METRIC_DOT ? T + 0.000244140625f * qn + 4.7683716e-7f : T - (qn - 0.000244140625f * qn);      // (dot, + 2^-22: the reference's distance is the f32 value of 1 - x.q)   // s' <= ptq  with  s' = xk - 2 x.q  (dot: xk + 1 - x.q)
       }
     }
   };

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void flat_filter_mfma_wide_kernel(FwArgs a)
         const float qn = p.q_norm[qi];
         t = (qn > 0.0f && qn < INFINITY) ? (1.0f - FW_EWC - T) * qn : -INFINITY;      // degenerate query: everything passes to the exact evaluation
       } else if constexpr (METRIC == METRIC_DOT) {
-        t = T + FW_EW * a.qn2[qi];
+        t = T + FW_EW * a.qn2[qi] + 4.7683716e-7f;      // (+ 2^-22: the reference's distance is the f32 value of 1 - x.q -- products closer than an ulp of 1 tie there)
       } else {
         const float qn = a.qn2[qi];
         t = T - (qn - FW_EW * qn);

@@ -178,7 +178,7 @@ bool qscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes);
 // search_qt.hip: M = 48 / 64 / 96 (table tiled over the sub-quantisers); class-B queries of those shapes go to the rescan kernel
 bool qscan_tiled_shape(int m, int sd);
 int qscan_classb_to_rescan(lance_hip_ctx *ctx, const uint32_t *tbound, uint32_t nq, uint32_t nprobes, uint32_t *seg_cnt, uint32_t *qovf);
-int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys);
+int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys, uint32_t nb = 1);
 int qscan_item_tables(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nlist, int G, uint32_t *item_start, int4 *desc, uint32_t max_items);
 // G = queries per work item of the main pass
 int qscan_group(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, int nlist, const uint32_t *tglobal,
@@ -212,7 +212,8 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs,
 void mscan_cut_params(int *cut_shift, uint32_t *cut_slack);
 int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix);
 int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
-                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow);   // search_ms.hip: LH_NOT_TAKEN = the integer bound pass serves the batch
+                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow,
+                   uint32_t nb = 1);   // search_ms.hip: LH_NOT_TAKEN = the integer bound pass serves the batch
 int qscan_items(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nvp, int G, uint32_t *item_start, int4 *desc, uint32_t max_items);   // search_q.hip: work items of G grouped pairs      // builds the scan's index constants now (lance_hip_index_prewarm)
 const uint8_t *raw_compact_prepare(lance_hip_ctx *ctx, const lance_hip_index *ix);   // search.hip: lossless u8 refine copy (index.h), or nullptr
 

@@ -45,7 +45,8 @@ struct MaArgs {
   // SUR = true instantiations (coarse_mfma.hip: find_partitions at query time): the surrogates go to a matrix instead of a running
   // top-4, the centroid tiles are split over blockIdx.y (small query batches would otherwise leave most CUs idle)
   float *sur = nullptr;        // [n][k] surrogate values
-  float *e2 = nullptr;         // [n] 2E of the row (the select kernel's candidate margin)
+  float *e2 = nullptr;         // [n] 2E of the row (the select kernel's candidate margin).  Under dot every kernel adds 2^-22 to it: the reference's
+                               // distance is the f32 value of 1 - x.c, so products closer than an ulp of 1 tie there (first index wins)
   int tiles_per_block = 0;     // centroid tiles (narrow: MA_CT, wide: MW_CT centroids) per blockIdx.y slice
   // SUR == 2 (find_partitions over thousands of lists): per (row, group of 16 centroids) the smallest surrogate, the member's slot in its
   // four lowest mantissa bits, and the group's second smallest; ng = 4 * centroid tiles groups per row; gkey: [n][ng / 2] 16-byte records

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
     const int64_t srow = row0 + wave * 32 + j;
     if (g == 0 && srow < p.n && blockIdx.y == 0) {
       const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
-      p.e2[srow] = 2.0f * 0.0001220703125f * (xn2 + cmax2 + bmax);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
+      p.e2[srow] = 2.0f * 0.0001220703125f * (xn2 + cmax2 + bmax) + (METRIC == METRIC_DOT ? 4.7683716e-7f : 0.0f);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|) (+ 2^-22 under dot: see ma_common.cuh)
     }
     return;
   }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_kernel(MaArgs p) {
   const int64_t row = row0 + wave * 32 + j;
   if (g == 0 && row < p.n) {
     const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
-    const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2 + bmax);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
+    const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2 + bmax) + (METRIC == METRIC_DOT ? 4.7683716e-7f : 0.0f);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|) (+ 2^-22 under dot: see ma_common.cuh)
     uint8_t cl = 3;                       // number of exact candidates - 1; 3 = recompute against every centroid
     if (tp.m2 - tp.m1 > E2) cl = 0;
     else if (tp.m3 - tp.m1 > E2) cl = 1;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
     const int64_t srow = row0 + wave * 32 + j;
     if (g == 0 && srow < p.n && blockIdx.y == 0) {
       const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
-      p.e2[srow] = 2.0f * (F16 ? 0.001381067932f : 0.000244140625f) * (p.xn2[srow] + cmax2 + bmax);   // 2E, E = 2^-12 (F16: 2^-9.5) (|x|^2 + max|c|^2 + max|bias|)
+      p.e2[srow] = 2.0f * (F16 ? 0.001381067932f : 0.000244140625f) * (p.xn2[srow] + cmax2 + bmax) + (METRIC == METRIC_DOT ? 4.7683716e-7f : 0.0f);   // 2E, E = 2^-12 (F16: 2^-9.5) (|x|^2 + max|c|^2 + max|bias|)
     }
     return;
   }
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void ma_top3_wide_kernel(MaArgs p) {
   const int64_t row = row0 + wave * 32 + j;
   if (g == 0 && row < p.n) {
     const float cmax2 = __uint_as_float(p.maxbits[0]), bmax = __uint_as_float(p.maxbits[1]);
-    const float E2 = 2.0f * (F16 ? 0.001381067932f : 0.000244140625f) * (p.xn2[row] + cmax2 + bmax);   // 2E, E = 2^-12 (F16: 2^-9.5) (|x|^2 + max|c|^2 + max|bias|)
+    const float E2 = 2.0f * (F16 ? 0.001381067932f : 0.000244140625f) * (p.xn2[row] + cmax2 + bmax) + (METRIC == METRIC_DOT ? 4.7683716e-7f : 0.0f);   // 2E, E = 2^-12 (F16: 2^-9.5) (|x|^2 + max|c|^2 + max|bias|)
     uint8_t cl = 3;
     if (tp.m2 - tp.m1 > E2) cl = 0;
     else if (tp.m3 - tp.m1 > E2) cl = 1;

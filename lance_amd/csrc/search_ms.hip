@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
 }
 
 // ---- slices: (partition, <= MS3_PB of its pairs, <= rows-per-slice of its rows) -----------------------------------------------------------
-constexpr int MS3_PB = 512;         // pairs resident in LDS (128 KiB at d = 128)
+#ifndef LH_MS3_PB
+#define LH_MS3_PB 512
+#endif
+constexpr int MS3_PB = LH_MS3_PB;   // pairs resident in LDS (128 KiB at d = 128); -DLH_MS3_PB=256: a variant build (scripts/build_variant.sh) for A/B runs
 constexpr int MS3_RS = 2048;        // rows per slice (64 chunks of 32 for sixteen waves): the block's DMA + two barriers + the wait for the slowest wave are paid per slice
 static int ms_rows_per_slice() {    // LANCE_HIP_MS_RS: A/B of the slice height (multiple of 64)
   static const int v = [] { const char *e = getenv("LANCE_HIP_MS_RS"); const int x = e ? atoi(e) : MS3_RS; return x >= 64 ? (x / 64) * 64 : MS3_RS; }();
@@ -668,6 +671,7 @@ struct MsBoundArgs {
   int dot = 0;                  // dot metric: operand q / 2, no residual, centred codebook plane; bins of (dist~ - base), base = (1 - q . mu) - |q| cmax (ms_prep_kernel)
   float cmax = 0.0f, cmax_full = 0.0f;
   const float *cmaxp = nullptr; // dot: [nlist] per-list bound of |centred reconstruction| (the workgroup's list: bins and slack use it)
+  uint32_t nb = 1;              // entries of pair_idx0 are query * nb + b: the query's b-th nearest list (every list gives a valid bound; atomicMin keeps the best)
 };
 
 template <int SD, int KS>
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
     const int e = 2 * lane;
     uint32_t qi[SPW];
 #pragma unroll
-    for (int t = 0; t < SPW; ++t) { const int sl = wave + 16 * t; qi[t] = sl < cnt ? p.pair_idx0[i0 + sl] : 0u; }
+    for (int t = 0; t < SPW; ++t) { const int sl = wave + 16 * t; qi[t] = sl < cnt ? p.pair_idx0[i0 + sl] / p.nb : 0u; }
     f2 qv[SPW], cv = {0.0f, 0.0f}, mu = {0.0f, 0.0f};
     if (e < D) {
       if (!p.dot) cv = *reinterpret_cast<const f2 *>(p.centroids + (int64_t)part * D + e);
@@ -890,12 +894,12 @@ __global__ __launch_bounds__(1024) void ms_bound_kernel(MsBoundArgs p) {
           const float e_abs = 6.1035156e-5f * sqd * (rn + 2.0f * p.cmax) / p.sigma + (float)D * 3.7252903e-9f / (p.sigma * p.sigma);
           const float E = 1.05f * (9.9609375e-4f * G + 1.5258789e-5f * (G + 1.0f + tmag + fabsf(qmu) + Gf) + 5.9604645e-8f * (float)((M + 2) * (M + 2))) + e_abs;
           const float T = (((1.0f - qmu) - G) + Ta) + (1.1f * E + 1.5258789e-5f * tmag);
-          if (fabsf(T) < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl]], order_key(T));
+          if (fabsf(T) < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl] / p.nb], order_key(T));
         } else {
         const float e_abs = 6.1035156e-5f * sqd * (3.0f * rn + 2.0f * st) / p.sigma + (float)D * 3.7252903e-9f / (p.sigma * p.sigma);
         const float E = 1.05f * (1.9921875e-3f * rn * (rn + st) + 1.2207031e-4f * (n2 + Ta)) + e_abs;      // ms_prep_kernel's E at T = Ta
         const float T = (Ta + 1.1f * E) * 1.0000153f;
-        if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl]], order_key(T));
+        if (T > 0.0f && T < INFINITY) atomicMin(&p.tglobal[p.pair_idx0[i0 + sl] / p.nb], order_key(T));
         }
       }
     }
@@ -926,6 +930,11 @@ bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes)
   return (uint64_t)nq * nprobes >= (uint64_t)minq * ix->nlist;
 }
 
+static bool ms_dot_skew_ok(const lance_hip_index *ix) {      // (see mscan_dot_ready)
+  static const double skew = getenv("LANCE_HIP_DOT_FLOW_SKEW") ? atof(getenv("LANCE_HIP_DOT_FLOW_SKEW")) : 8.0;
+  return (double)ix->max_part * (double)ix->nlist <= skew * (double)ix->n;
+}
+
 // dot metric: the quantised flow is the matrix-core bound pass + scan or nothing (the integer tables need entries >= 0).  What can only be
 // known inside the launchers (an all-zero codebook, unaligned query rows) makes them return LH_NOT_TAKEN and the caller keeps the exact pair scan.
 bool mscan_dot_ready(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
@@ -936,8 +945,7 @@ bool mscan_dot_ready(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   // overflow into exact rescans of whole lists and the flow measured SLOWER than the exact pair scan (3.94 against 3.46 ms per 10,000-query batch,
   // gpurun r06zu; with the same rows centred -- largest list 23,309 -- 1.16 against 1.68).  LANCE_HIP_DOT_FLOW_SKEW: the largest list / mean list
   // ratio up to which the flow is taken (default 8).
-  static const double skew = getenv("LANCE_HIP_DOT_FLOW_SKEW") ? atof(getenv("LANCE_HIP_DOT_FLOW_SKEW")) : 8.0;
-  if ((double)ix->max_part * (double)ix->nlist > skew * (double)ix->n) return false;
+  if (!ms_dot_skew_ok(ix)) return false;
   return !ix->ms || ix->ms->usable;
 }
 
@@ -1142,7 +1150,8 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
 // The bound pass of a batch the matrix-core scan serves (search_pm.hip).  pair_starts0 / pair_idx0: the nq (query, nearest partition) pairs
 // grouped by partition.  -1: not taken (the caller runs the integer pass); otherwise a status code.
 int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *qs, uint32_t nq, uint32_t keff, const uint32_t *pair_starts0,
-                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow) {
+                   const uint32_t *pair_idx0, uint32_t *item_start, int4 *desc, uint32_t max_items, uint32_t *tglobal, const uint32_t *allow,
+                   uint32_t nb) {
   static const bool off = getenv("LANCE_HIP_NO_MSBOUND") != nullptr;      // A/B switch: the integer histogram pass (search_q.hip)
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
   int sd = 0, ks = 0;
@@ -1162,7 +1171,8 @@ int msbound_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float 
   a.d = (int)ix->d; a.nlist = nlist; a.keff = (int)keff; a.round_f16 = ix->dtype == LANCE_HIP_F16 ? 1 : 0; a.sigma = ix->ms->sigma;
   a.tglobal = tglobal; a.allow = allow;
   a.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; a.cmax = ix->ms->cmax; a.cmax_full = ix->ms->cmax_full; a.cmaxp = ix->ms->cmaxp;
-  const unsigned grid = (unsigned)std::min<uint64_t>(max_items, (uint64_t)nq / MSB_BQ + (uint64_t)nlist + 1);      // sum over partitions of ceil(queries / MSB_BQ)
+  a.nb = std::max<uint32_t>(nb, 1u);
+  const unsigned grid = (unsigned)std::min<uint64_t>(max_items, (uint64_t)nq * a.nb / MSB_BQ + (uint64_t)nlist + 1);      // sum over partitions of ceil(queries / MSB_BQ)
   if (sd == 8 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<8, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else if (sd == 4 && ks == 8) hipLaunchKernelGGL((ms_bound_kernel<4, 8>), dim3(grid), dim3(1024), 0, ctx->stream, a);
   else hipLaunchKernelGGL((ms_bound_kernel<4, 4>), dim3(grid), dim3(1024), 0, ctx->stream, a);
@@ -1174,6 +1184,7 @@ int mscan_prewarm(lance_hip_ctx *ctx, const lance_hip_index *ix_c) {
   lance_hip_index *ix = const_cast<lance_hip_index *>(ix_c);
   static const bool off = getenv("LANCE_HIP_NO_MSCAN") != nullptr;
   if (off || !ms_shape(ix, nullptr, nullptr) || !ix->model_finite) return LANCE_HIP_OK;
+  if (ix->metric == LANCE_HIP_DOT && (!ms_dot_skew_ok(ix) || getenv("LANCE_HIP_NO_DOT_FLOW"))) return LANCE_HIP_OK;      // the index will not take the flow: no constants
   return mscan_prepare(ctx, ix);
 }
 

@@ -601,7 +601,6 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
                               uint64_t *cand_rid, uint32_t *cand_cnt, uint32_t *flags, const uint32_t *allow) {
   const int d = (int)ix->d, m = (int)ix->m, sd = d / m, nlist = (int)ix->nlist;
   const size_t npairs = (size_t)nq * nprobes;
-  const uint32_t max_items0 = (uint32_t)(nq / 2 + nlist + 2);
   const uint32_t max_items2 = (uint32_t)(npairs / 2 + 2 * nlist + 2);
   const uint32_t max_items4 = (uint32_t)(npairs / 4 + nlist + 2);
   uint32_t *keys = ctx->scratch_t<uint32_t>("pm.keys", npairs);
@@ -610,7 +609,13 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)2 * nlist + 1);
   int4 *desc = ctx->scratch_t<int4>("pm.desc", max_items2);
   uint32_t *pair_starts0 = ctx->scratch_t<uint32_t>("q.pair_starts0", (size_t)nlist + 1);
-  uint32_t *pair_idx0 = ctx->scratch_t<uint32_t>("q.pair_idx0", nq);
+  // dot: the bound pass runs over each query's TWO nearest lists and keeps the smaller bound -- without residuals the list a query's best rows sit in is
+  // often not the one with the largest centroid score, and the nearest list's k*refine-th distance then lets hundreds of that list's rows through:
+  // at the unit-normalised C2 shape 5,311 of 100,000 segments overflowed into exact rescans of whole lists (LANCE_HIP_DOT_BOUND_LISTS: A/B)
+  static const uint32_t dot_nb_env = getenv("LANCE_HIP_DOT_BOUND_LISTS") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_DOT_BOUND_LISTS"))) : 2u;
+  const uint32_t nb0 = ix->metric == LANCE_HIP_DOT ? std::min<uint32_t>(std::min<uint32_t>(dot_nb_env, 4u), nprobes) : 1u;
+  const uint32_t max_items0 = (uint32_t)((size_t)nq * nb0 / 2 + nlist + 2);
+  uint32_t *pair_idx0 = ctx->scratch_t<uint32_t>("q.pair_idx0", (size_t)nq * nb0);
   uint32_t *item_start0 = ctx->scratch_t<uint32_t>("q.item_start0", (size_t)nlist + 1);
   int4 *desc0 = ctx->scratch_t<int4>("q.desc0", max_items0);
   uint32_t *item_start4 = ctx->scratch_t<uint32_t>("q.item_start4", (size_t)nlist + 1);
@@ -648,8 +653,8 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   {
     // bound pass: the nq (query, nearest partition) pairs grouped by partition
     ScopedTimer t(ctx, "pm_group");
-    LH_TRY(qscan_nearest_keys(ctx, probes, nq, nprobes, keys));
-    LH_TRY(stable_group(ctx, keys, (int64_t)nq, (int64_t)nq, nlist, 1, pair_starts0, pair_idx0, (int64_t)nq, nullptr));
+    LH_TRY(qscan_nearest_keys(ctx, probes, nq, nprobes, keys, nb0));
+    LH_TRY(stable_group(ctx, keys, (int64_t)nq * nb0, (int64_t)nq * nb0, nlist, 1, pair_starts0, pair_idx0, (int64_t)nq * nb0, nullptr));
     if (exact_bound) {
       hipLaunchKernelGGL(pm_item_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts0, nlist, item_start0);
       hipLaunchKernelGGL(pm_item_desc_kernel, dim3((unsigned)cdiv(max_items0, 256)), dim3(256), 0, ctx->stream, item_start0, pair_starts0, pair_idx0,
@@ -672,7 +677,7 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
     // a batch the matrix-core scan serves gets its bounds from the same matrix product (search_ms.hip: ms_bound_kernel) ...
     int mb_rc = LH_NOT_TAKEN;
     if (mscan_supported(ix, nq, nprobes))
-      mb_rc = msbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)(nq / 4 + nlist + 2), tglobal, allow);
+      mb_rc = msbound_launch(ctx, ix, qs, nq, keff, pair_starts0, pair_idx0, item_start0, desc0, (uint32_t)((size_t)nq * nb0 / 4 + nlist + 2), tglobal, allow, nb0);
     if (mb_rc < 0) return mb_rc;          // a real failure (every LANCE_HIP_E* code is negative): never a silent fall-back
     if (mb_rc == LH_NOT_TAKEN && dot) return LH_NOT_TAKEN;      // no integer pass for dot: the caller runs the exact pair scan (nothing but scratch was written)
     // ... every other one from the integer histogram, four queries per gather (search_q.hip)

@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256) void q_tclass_keys_kernel(const uint32_t *__re
   if (i % nprobes == 0) tbound[q] = usable ? T : 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(256) void q_nearest_keys_kernel(const uint32_t *__restrict__ probes, int nq, int nprobes, uint32_t *__restrict__ keys) {
+// keys[q * nb + b] = the query's b-th nearest partition, b < nb (nb = 1: the nearest; the dot metric's bound pass takes the two nearest)
+__global__ __launch_bounds__(256) void q_nearest_keys_kernel(const uint32_t *__restrict__ probes, int nq, int nprobes, int nb, uint32_t *__restrict__ keys) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nq) keys[i] = probes[(int64_t)i * nprobes];
+  if (i < nq * nb) keys[i] = probes[(int64_t)(i / nb) * nprobes + (i % nb)];
 }
 
 // item_start[vp] = exclusive scan of ceil(c_vp / G) over the first nvp virtual partitions
@@ -1153,8 +1154,8 @@ int qscan_item_tables(lance_hip_ctx *ctx, const uint32_t *pair_starts, int nlist
   return LANCE_HIP_OK;
 }
 
-int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys) {
-  hipLaunchKernelGGL(q_nearest_keys_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, ctx->stream, probes, (int)nq, (int)nprobes, keys);
+int qscan_nearest_keys(lance_hip_ctx *ctx, const uint32_t *probes, uint32_t nq, uint32_t nprobes, uint32_t *keys, uint32_t nb) {
+  hipLaunchKernelGGL(q_nearest_keys_kernel, dim3((unsigned)cdiv((uint64_t)nq * nb, 256)), dim3(256), 0, ctx->stream, probes, (int)nq, (int)nprobes, (int)nb, keys);
   return LANCE_HIP_OK;
 }
 

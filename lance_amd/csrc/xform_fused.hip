@@ -766,7 +766,10 @@ __global__ __launch_bounds__(256, 2) void xf_kernel(XfArgs p) {
   xn2 += __shfl_xor(xn2, 32, 64);          // (a non-finite element makes this inf / NaN: the row is then recomputed exactly, below)
   const float cmax2c = __uint_as_float(p.maxbits[0]);
   const float bmax = (ASSIGN && p.bias) ? __uint_as_float(p.maxbits[1]) : 0.0f;      // max |bias|: in E (the biased sum's own roundings) and in R (surrogates stay >= 0)
-  const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2c + bmax);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
+  // (dot: the reference's distance is the f32 value of 1 - x.c -- two centroids whose products differ by less than an ulp of 1 TIE there and the first
+  // wins, whatever the surrogate says about x.c itself; 2^-22 of absolute margin sends such rows to the exact re-check.  Rows and centroids of
+  // norm^2 below 2^-10 only: tests/fuzz_dot_flow.py case 25 -- 9 of 26,482 f16 rows of magnitude 1e-3 went to the other of two tied lists)
+  const float E2 = 2.0f * 0.0001220703125f * (xn2 + cmax2c + bmax) + (METRIC == METRIC_DOT ? 4.7683716e-7f : 0.0f);   // 2E, E = 2^-13 (|x|^2 + max|c|^2 + max|bias|)
   // the row's offset R (one bf16, rounded up): L2  s' = R + |c|^2 - 2 x.c = |x - c|^2 + (R - |x|^2) >= 0;  dot  s' = R - x.c >= 0
   bf16x8 bx = {0, 0, 0, 0, 0, 0, 0, 0};
   if (g == 0) {

@@ -1,0 +1,160 @@
+"""Randomised differential run of the DOT metric's quantised flow (search_ms.hip bound pass + scan, dot instantiations of the merge / rescan
+kernels) against the CPU oracle: random magnitudes (1e-3 .. 1e4), sign mixes, list counts and sizes, k / nprobes / refine, prefilters,
+f32 and f16 columns.  Not collected by pytest; GPU only.
+
+    python tests/fuzz_dot_flow.py [seconds] [seed] [--case N]
+
+Every case draws its configuration from a generator seeded with (seed, case number): `--case N` replays one case.  Every search is sized
+for the matrix-core scan (nq * nprobes >= 96 * nlist) and the harness counts how many of them actually took it.
+"""
+import os
+import sys
+import time
+
+os.environ.setdefault("LANCE_HIP_DOT_FLOW_SKEW", "1e18")      # the flow whatever the list-size skew (tests/conftest.py)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+f32 = np.float32
+
+
+def _np(t):
+    return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+
+
+def draw(rng):
+    d, m = [(128, 16), (128, 32), (64, 16)][int(rng.integers(0, 3))]
+    nlist = int(rng.choice([4, 8, 16, 24, 40, 64]))
+    n = int(rng.integers(3000, 40000))
+    kind = str(rng.choice(["positive_int", "positive", "centred", "gauss", "unit", "mixed_scale"]))
+    scale = float(10.0 ** rng.uniform(-3, 4)) if kind in ("gauss", "centred", "positive") else 1.0
+    f16 = bool(rng.random() < 0.2) and scale < 50 and kind != "positive_int"
+    nprobes = int(rng.integers(1, min(nlist, 20) + 1))
+    nq = int(max(200, -(-96 * nlist // nprobes) + rng.integers(0, 600)))
+    return dict(d=d, m=m, nlist=nlist, n=n, kind=kind, scale=scale, f16=f16, nprobes=nprobes, nq=min(nq, 4000),
+                k=int(rng.choice([1, 5, 10, 37, 100])), refine=int(rng.choice([0, 0, 1, 3, 10])), prefilter=bool(rng.random() < 0.3),
+                dup=bool(rng.random() < 0.15), zero_q=bool(rng.random() < 0.2))
+
+
+def make(rng, cfg, n, d):
+    ncl = 32
+    cen = rng.uniform(0, 128, (ncl, d))
+    x = cen[rng.integers(0, ncl, n)] + rng.normal(0, 20, (n, d))
+    k = cfg["kind"]
+    if k == "positive_int":
+        x = np.clip(np.rint(x), 0, 218)
+    elif k == "positive":
+        x = np.abs(x) * cfg["scale"] / 64.0
+    elif k == "centred":
+        x = (x - 64.0) * cfg["scale"] / 64.0
+    elif k == "gauss":
+        x = rng.standard_normal((n, d)) * cfg["scale"]
+    elif k == "unit":
+        x = x - 64.0 * (rng.random() < 0.5)
+        x = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-9)
+    else:      # rows of very different lengths
+        x = (x - 64.0) * (10.0 ** rng.uniform(-2, 2, (n, 1)))
+    return x.astype(f32)
+
+
+def run_case(eng, orc, seed, case, verbose=True):
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng([seed, case])
+    cfg = draw(rng)
+    d, m, nlist, n = cfg["d"], cfg["m"], cfg["nlist"], cfg["n"]
+    x = make(rng, cfg, n, d)
+    q = make(rng, cfg, cfg["nq"], d)
+    if cfg["dup"]:
+        x[n // 2:] = x[rng.integers(0, 200, n - n // 2)]
+    if cfg["zero_q"]:
+        q[::17] = 0.0
+        q[5::29] *= -3.0
+    if cfg["f16"]:
+        x = x.astype(np.float16); q = q.astype(np.float16)
+    cent, _, _, _ = orc.kmeans_train(x[: nlist * 64], nlist, max_iters=3, seed=case, metric="dot")
+    cb, _ = orc.pq_train(x[: 256 * 10], m, max_iters=2, seed=case + 1)
+    if not (np.isfinite(np.asarray(cent, f32)).all() and np.isfinite(np.asarray(cb, f32)).all()):
+        # f16 k-means of rows of magnitude 1e4 overflows: inf / NaN centroids and codewords.  Such a model never takes the flow (index.h: model_finite),
+        # and what its searches return depends on the SIGN of the default NaN (x86: negative, sorts first under total_cmp; gfx950: positive, sorts
+        # last) -- the oracle on this host and the device then legitimately order the lists differently; not a case for this harness
+        return cfg, -1, 0
+    oidx = orc.build_index(x, cent, cb, "dot")
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "dot")
+    pdiff = int((_np(gpart).view(np.uint32) != oidx.part_ids).sum()); cdiff = int((_np(gcodes) != oidx.codes_rowmajor).any(axis=1).sum())
+    if (pdiff or cdiff) and verbose:
+        print(f"   case {case}: cfg {cfg}: {pdiff} partition ids and {cdiff} code rows differ; max|x| {float(np.abs(x.astype(f32)).max()):.4g} "
+              f"min nonzero |x| {float(np.abs(x.astype(f32))[x != 0].min()):.4g}", flush=True)
+    assert pdiff == 0 and cdiff == 0, "encode differs"
+    g = DeviceIndex.create(eng, "dot", cent, cb, gpart, gcodes, None, raw=x)
+    raw = x.astype(f32)
+    took = 0
+    try:
+        variants = [(cfg["k"], cfg["nprobes"], cfg["refine"]), (10, cfg["nprobes"], 0)]
+        for k, nprobes, rf in variants:
+            if k * max(rf, 1) > 128:
+                rf = max(1, 128 // k) if rf else 0
+            allow = (rng.random(n) < float(rng.choice([0.05, 0.5, 0.95]))) if cfg["prefilter"] else None
+            eng.timing(True)
+            b0 = eng.timing_query("ivfpq_mscan")[1]
+            if allow is None:
+                gi, gd = g.search(q, k, nprobes, rf)
+            else:
+                gi, gd = g.search_filtered(q, k, nprobes, allow, rf)
+            eng.synchronize()
+            took += int(eng.timing_query("ivfpq_mscan")[1] > b0)
+            eng.timing(False)
+            oi, od = oidx.search(q, k, nprobes, refine=rf, raw=raw if rf else None, **({} if allow is None else {"prefilter": allow}))
+            bad = np.nonzero((_np(gi).view(np.uint64) != oi).any(axis=1))[0]
+            if bad.size and verbose:
+                b = int(bad[0])
+                print(f"   case {case}: flow taken {took} cfg {cfg}\n   query {b}: gpu ids {_np(gi)[b][:6]} dists {_np(gd)[b][:6]}\n"
+                      f"             oracle ids {oi[b][:6].astype(np.int64)} dists {od[b][:6]}; finite centroids {bool(np.isfinite(np.asarray(cent, f32)).all())} "
+                      f"codebook {bool(np.isfinite(np.asarray(cb, f32)).all())} max|x| {float(np.abs(raw).max()):.4g}", flush=True)
+            assert bad.size == 0, f"ids differ for {bad.size} queries (first {bad[:5]}) at k={k} nprobes={nprobes} refine={rf} prefilter={allow is not None}"
+            assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all(), f"distances differ at k={k} nprobes={nprobes} refine={rf}"
+    finally:
+        g.close()
+    return cfg, took, len(variants)
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    only = None
+    if "--case" in args:
+        i = args.index("--case"); only = int(args[i + 1]); del args[i:i + 2]
+    seconds = float(args[0]) if args else 120.0
+    seed = int(args[1]) if len(args) > 1 else 7001
+    import lance_amd
+    import oracle as orc
+    from lance_amd.engine import Engine
+    orc.lib()
+    eng = Engine()
+    t0 = time.time()
+    case = only if only is not None else 0
+    ok = fails = taken = searches = skipped = 0
+    while True:
+        try:
+            cfg, took, ns = run_case(eng, orc, seed, case)
+            if took < 0:
+                skipped += 1
+            else:
+                ok += 1; taken += took; searches += ns
+        except AssertionError as e:
+            fails += 1
+            print(f"FAIL case {case} (seed {seed}): {e}", flush=True)
+            if fails >= 10:
+                break
+        if only is not None or time.time() - t0 > seconds:
+            break
+        case += 1
+    print(f"dot fuzz {'ok' if fails == 0 else 'FAILED'}: {ok} configurations passed, {fails} failed, {skipped} skipped (non-finite f16 model), seed {seed}, cases 0..{case}, "
+          f"{taken} of {searches} searches took the matrix-core flow, {time.time() - t0:.0f} s", flush=True)
+    eng.close()
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

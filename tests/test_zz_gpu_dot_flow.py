@@ -167,3 +167,43 @@ def test_exact_pair_scan_keeps_its_dot_coverage():
                         "-k", "dot", "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_skew_child_uneven_lists_keep_the_exact_pair_scan(eng, oracle):
+    """Runs in the child below (LANCE_HIP_DOT_FLOW_SKEW at its default of 8): an index whose largest list holds more than 8 x the mean
+    keeps the exact pair scan for dot batches (search_ms.hip: mscan_dot_ready), an even one takes the flow; both equal the oracle."""
+    if os.environ.get("LANCE_TEST_SKEW_CHILD") != "1":
+        pytest.skip("child of test_default_skew_guard")
+    from lance_amd.engine import DeviceIndex
+    rng = np.random.default_rng(12)
+    d, m, nlist, nq = 128, 16, 16, 600
+    for uneven in (True, False):
+        if uneven:                                      # rows with components >= 0 and one long centroid: every row's largest dot product
+            x = clustered(16000, d, 91)
+            q = clustered(nq, d, 92)
+            cent = x[rng.choice(len(x), nlist, replace=False)].copy()
+            cent[0] *= 3.0
+            cb, _ = oracle.pq_train(x[:4096], m, max_iters=3, seed=1)
+        else:                                           # centred rows, dot k-means: even lists
+            x = clustered(16000, d, 91) - f32(64.0)
+            q = clustered(nq, d, 92) - f32(64.0)
+            cent, cb = _models(oracle, x, nlist, m, "dot", seed=3)
+        oidx = oracle.build_index(x, cent, cb, "dot")
+        sizes = np.diff(oidx.part_offsets)
+        assert (sizes.max() * nlist > 8 * len(x)) == uneven, sizes
+        gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "dot")
+        gidx = DeviceIndex.create(eng, "dot", cent, cb, gpart, gcodes, None, raw=x)
+        with _dot_flow_used(eng, expect=not uneven):
+            gi, gd = gidx.search(q, 10, 8, 4)
+        oi, od = oidx.search(q, 10, 8, refine=4, raw=x)
+        assert (_np(gi).view(np.uint64) == oi).all() and (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+        gidx.close()
+
+
+def test_default_skew_guard():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LANCE_HIP_DOT_FLOW_SKEW="8", LANCE_TEST_SKEW_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "skew_child", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout
