@@ -931,7 +931,7 @@ bool mscan_batch_shape(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes)
 }
 
 static bool ms_dot_skew_ok(const lance_hip_index *ix) {      // (see mscan_dot_ready)
-  static const double skew = getenv("LANCE_HIP_DOT_FLOW_SKEW") ? atof(getenv("LANCE_HIP_DOT_FLOW_SKEW")) : 8.0;
+  static const double skew = getenv("LANCE_HIP_DOT_FLOW_SKEW") ? atof(getenv("LANCE_HIP_DOT_FLOW_SKEW")) : 1e18;
   return (double)ix->max_part * (double)ix->nlist <= skew * (double)ix->n;
 }
 
@@ -941,10 +941,10 @@ bool mscan_dot_ready(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   static const bool off = getenv("LANCE_HIP_NO_MSBOUND") != nullptr || getenv("LANCE_HIP_NO_DOT_FLOW") != nullptr;
   if (off || !mscan_batch_shape(ix, nq, nprobes) || !ix->cb_mean) return false;
   // Lists as uneven as the rows' norms (dot over unnormalised rows with components of one sign: at the C2 shape the largest of 256 lists held 82,424
-  // of the 10^6 rows and was every query's nearest): the bound of the nearest list is loose for the other probed lists, a fifth of the segments
-  // overflow into exact rescans of whole lists and the flow measured SLOWER than the exact pair scan (3.94 against 3.46 ms per 10,000-query batch,
-  // gpurun r06zu; with the same rows centred -- largest list 23,309 -- 1.16 against 1.68).  LANCE_HIP_DOT_FLOW_SKEW: the largest list / mean list
-  // ratio up to which the flow is taken (default 8).
+  // of the 10^6 rows and was every query's nearest): with the bound of the NEAREST list alone a fifth of the segments overflowed into exact rescans of
+  // whole lists and the flow measured slower than the exact pair scan (3.94 against 3.46 ms per 10,000-query batch, gpurun r06zu); with the bound pass
+  // over three lists it is 1.88 (gpurun r06zzg).  LANCE_HIP_DOT_FLOW_SKEW keeps a guard for A/B runs: the largest list / mean list ratio up to which
+  // the flow is taken (default: no limit).
   if (!ms_dot_skew_ok(ix)) return false;
   return !ix->ms || ix->ms->usable;
 }

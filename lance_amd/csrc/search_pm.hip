@@ -609,10 +609,12 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   uint32_t *item_start = ctx->scratch_t<uint32_t>("pm.item_start", (size_t)2 * nlist + 1);
   int4 *desc = ctx->scratch_t<int4>("pm.desc", max_items2);
   uint32_t *pair_starts0 = ctx->scratch_t<uint32_t>("q.pair_starts0", (size_t)nlist + 1);
-  // dot: the bound pass runs over each query's TWO nearest lists and keeps the smaller bound -- without residuals the list a query's best rows sit in is
-  // often not the one with the largest centroid score, and the nearest list's k*refine-th distance then lets hundreds of that list's rows through:
-  // at the unit-normalised C2 shape 5,311 of 100,000 segments overflowed into exact rescans of whole lists (LANCE_HIP_DOT_BOUND_LISTS: A/B)
-  static const uint32_t dot_nb_env = getenv("LANCE_HIP_DOT_BOUND_LISTS") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_DOT_BOUND_LISTS"))) : 2u;
+  // dot: the bound pass runs over each query's THREE nearest lists and keeps the smallest bound -- without residuals the list a query's best rows sit in
+  // is often not the one with the largest centroid score, and the nearest list's k*refine-th distance then lets hundreds of that list's rows through.
+  // C2 shape, ms per 10,000-query batch with 1 / 2 / 3 / 4 lists (gpurun r06zzf, r06zzg): unit-normalised rows 0.951 / 0.854 / 0.860 / 0.867 (overflowed
+  // segments 5,311 -> 2,852 with two), centred rows 1.150 / 0.911 / 0.900 / 0.910, SIFT-like rows as they are (largest list 82,424 of 10^6 rows) 3.94 / 2.29 /
+  // 1.88 against 3.46 on the exact pair scan.  LANCE_HIP_DOT_BOUND_LISTS: A/B
+  static const uint32_t dot_nb_env = getenv("LANCE_HIP_DOT_BOUND_LISTS") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_DOT_BOUND_LISTS"))) : 3u;
   const uint32_t nb0 = ix->metric == LANCE_HIP_DOT ? std::min<uint32_t>(std::min<uint32_t>(dot_nb_env, 4u), nprobes) : 1u;
   const uint32_t max_items0 = (uint32_t)((size_t)nq * nb0 / 2 + nlist + 2);
   uint32_t *pair_idx0 = ctx->scratch_t<uint32_t>("q.pair_idx0", (size_t)nq * nb0);

@@ -2,8 +2,8 @@ import os
 import sys
 
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # before anything loads libgomp: the oracle's workers must not spin
-# the dot metric's quantised flow is taken whatever the list-size skew (search_ms.hip: mscan_dot_ready keeps very uneven indices on the exact
-# pair scan for speed; the tests want the flow itself -- the exact pair scan keeps its coverage through LANCE_HIP_NO_DOT_FLOW=1 children)
+# the dot metric's quantised flow is taken whatever the list-size skew (the library's default too; search_ms.hip: mscan_dot_ready has a guard for
+# A/B runs -- the exact pair scan keeps its coverage through LANCE_HIP_NO_DOT_FLOW=1 children)
 os.environ.setdefault("LANCE_HIP_DOT_FLOW_SKEW", "1e18")
 
 import pytest

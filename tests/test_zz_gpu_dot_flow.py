@@ -170,10 +170,10 @@ def test_exact_pair_scan_keeps_its_dot_coverage():
 
 
 def test_skew_child_uneven_lists_keep_the_exact_pair_scan(eng, oracle):
-    """Runs in the child below (LANCE_HIP_DOT_FLOW_SKEW at its default of 8): an index whose largest list holds more than 8 x the mean
-    keeps the exact pair scan for dot batches (search_ms.hip: mscan_dot_ready), an even one takes the flow; both equal the oracle."""
+    """Runs in the child below with LANCE_HIP_DOT_FLOW_SKEW=8 (an A/B guard, off by default): an index whose largest list holds more than 8 x the
+    mean keeps the exact pair scan for dot batches (search_ms.hip: mscan_dot_ready), an even one takes the flow; both equal the oracle."""
     if os.environ.get("LANCE_TEST_SKEW_CHILD") != "1":
-        pytest.skip("child of test_default_skew_guard")
+        pytest.skip("child of test_skew_guard_switch")
     from lance_amd.engine import DeviceIndex
     rng = np.random.default_rng(12)
     d, m, nlist, nq = 128, 16, 16, 600
@@ -200,7 +200,7 @@ def test_skew_child_uneven_lists_keep_the_exact_pair_scan(eng, oracle):
         gidx.close()
 
 
-def test_default_skew_guard():
+def test_skew_guard_switch():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LANCE_HIP_DOT_FLOW_SKEW="8", LANCE_TEST_SKEW_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "skew_child", "-p", "no:cacheprovider"],
