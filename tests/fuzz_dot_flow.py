@@ -2,7 +2,7 @@
 kernels) against the CPU oracle: random magnitudes (1e-3 .. 1e4), sign mixes, list counts and sizes, k / nprobes / refine, prefilters,
 f32 and f16 columns.  Not collected by pytest; GPU only.
 
-    python tests/fuzz_dot_flow.py [seconds] [seed] [--case N]
+    python tests/fuzz_dot_flow.py [seconds] [seed] [--case N] [--metric dot|l2|cosine|all]
 
 Every case draws its configuration from a generator seeded with (seed, case number): `--case N` replays one case.  Every search is sized
 for the matrix-core scan (nq * nprobes >= 96 * nlist) and the harness counts how many of them actually took it.
@@ -60,10 +60,15 @@ def make(rng, cfg, n, d):
     return x.astype(f32)
 
 
-def run_case(eng, orc, seed, case, verbose=True):
+def run_case(eng, orc, seed, case, verbose=True, metric="dot"):
     from lance_amd.engine import DeviceIndex
     rng = np.random.default_rng([seed, case])
     cfg = draw(rng)
+    if metric == "all":
+        metric = ("dot", "l2", "cosine")[case % 3]
+    cfg["metric"] = metric
+    if metric == "cosine":
+        cfg["zero_q"] = False
     d, m, nlist, n = cfg["d"], cfg["m"], cfg["nlist"], cfg["n"]
     x = make(rng, cfg, n, d)
     q = make(rng, cfg, cfg["nq"], d)
@@ -74,21 +79,28 @@ def run_case(eng, orc, seed, case, verbose=True):
         q[5::29] *= -3.0
     if cfg["f16"]:
         x = x.astype(np.float16); q = q.astype(np.float16)
-    cent, _, _, _ = orc.kmeans_train(x[: nlist * 64], nlist, max_iters=3, seed=case, metric="dot")
-    cb, _ = orc.pq_train(x[: 256 * 10], m, max_iters=2, seed=case + 1)
+    if metric == "dot":
+        cent, _, _, _ = orc.kmeans_train(x[: nlist * 64], nlist, max_iters=3, seed=case, metric="dot")
+        cb, _ = orc.pq_train(x[: 256 * 10], m, max_iters=2, seed=case + 1)
+    else:      # (--metric l2 / cosine / all: the same magnitudes through the residual flows)
+        xs = orc.normalize(x) if metric == "cosine" else x
+        cent, _, _, _ = orc.kmeans_train(xs[: nlist * 64], nlist, max_iters=3, seed=case, metric="l2")
+        part, _ = orc.assign(xs[: 256 * 10], cent, "l2")
+        res = orc.residual(xs[: 256 * 10], cent, np.where(part == orc.NONE, 0, part))
+        cb, _ = orc.pq_train(res, m, max_iters=2, seed=case + 1)
     if not (np.isfinite(np.asarray(cent, f32)).all() and np.isfinite(np.asarray(cb, f32)).all()):
         # f16 k-means of rows of magnitude 1e4 overflows: inf / NaN centroids and codewords.  Such a model never takes the flow (index.h: model_finite),
         # and what its searches return depends on the SIGN of the default NaN (x86: negative, sorts first under total_cmp; gfx950: positive, sorts
         # last) -- the oracle on this host and the device then legitimately order the lists differently; not a case for this harness
         return cfg, -1, 0
-    oidx = orc.build_index(x, cent, cb, "dot")
-    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, "dot")
+    oidx = orc.build_index(x, cent, cb, metric)
+    gpart, gcodes, _ = eng.ivfpq_encode(x, cent, cb, metric)
     pdiff = int((_np(gpart).view(np.uint32) != oidx.part_ids).sum()); cdiff = int((_np(gcodes) != oidx.codes_rowmajor).any(axis=1).sum())
     if (pdiff or cdiff) and verbose:
         print(f"   case {case}: cfg {cfg}: {pdiff} partition ids and {cdiff} code rows differ; max|x| {float(np.abs(x.astype(f32)).max()):.4g} "
               f"min nonzero |x| {float(np.abs(x.astype(f32))[x != 0].min()):.4g}", flush=True)
     assert pdiff == 0 and cdiff == 0, "encode differs"
-    g = DeviceIndex.create(eng, "dot", cent, cb, gpart, gcodes, None, raw=x)
+    g = DeviceIndex.create(eng, metric, cent, cb, gpart, gcodes, None, raw=x)
     raw = x.astype(f32)
     took = 0
     try:
@@ -123,8 +135,11 @@ def run_case(eng, orc, seed, case, verbose=True):
 def main():
     args = [a for a in sys.argv[1:]]
     only = None
+    metric = "dot"
     if "--case" in args:
         i = args.index("--case"); only = int(args[i + 1]); del args[i:i + 2]
+    if "--metric" in args:
+        i = args.index("--metric"); metric = args[i + 1]; del args[i:i + 2]
     seconds = float(args[0]) if args else 120.0
     seed = int(args[1]) if len(args) > 1 else 7001
     import lance_amd
@@ -137,7 +152,7 @@ def main():
     ok = fails = taken = searches = skipped = 0
     while True:
         try:
-            cfg, took, ns = run_case(eng, orc, seed, case)
+            cfg, took, ns = run_case(eng, orc, seed, case, metric=metric)
             if took < 0:
                 skipped += 1
             else:
@@ -150,7 +165,7 @@ def main():
         if only is not None or time.time() - t0 > seconds:
             break
         case += 1
-    print(f"dot fuzz {'ok' if fails == 0 else 'FAILED'}: {ok} configurations passed, {fails} failed, {skipped} skipped (non-finite f16 model), seed {seed}, cases 0..{case}, "
+    print(f"{metric} fuzz {'ok' if fails == 0 else 'FAILED'}: {ok} configurations passed, {fails} failed, {skipped} skipped (non-finite f16 model), seed {seed}, cases 0..{case}, "
           f"{taken} of {searches} searches took the matrix-core flow, {time.time() - t0:.0f} s", flush=True)
     eng.close()
     sys.exit(1 if fails else 0)
