@@ -946,7 +946,9 @@ bool mscan_dot_ready(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {
   // over three lists it is 1.88 (gpurun r06zzg).  LANCE_HIP_DOT_FLOW_SKEW keeps a guard for A/B runs: the largest list / mean list ratio up to which
   // the flow is taken (default: no limit).
   if (!ms_dot_skew_ok(ix)) return false;
-  return !ix->ms || ix->ms->usable;
+  lance_hip_index *mix = const_cast<lance_hip_index *>(ix);      // (the constants are published under this lock by the first search of any context)
+  std::lock_guard<std::mutex> lk(mix->lazy_mu);
+  return !mix->ms || mix->ms->usable;
 }
 
 bool mscan_supported(const lance_hip_index *ix, uint32_t nq, uint32_t nprobes) {

@@ -207,3 +207,32 @@ def test_skew_guard_switch():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "1 passed" in r.stdout
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_dot_tiny_magnitudes_tie_at_one(eng, oracle, dtype):
+    """Rows and centroids of magnitude 1e-3: every dot product is ~1e-5, the reference's distances 1 - x.c are a handful of f32 values just
+    under / over 1 and centroids (rows) whose products differ by less than an ulp of 1 TIE there -- the first index (the smaller row id) wins.
+    The matrix-core surrogates rank by the product itself; their margins carry 2^-22 of absolute slack under dot so that such rows reach the
+    exact evaluation (found by tests/fuzz_dot_flow.py: 9 of 26,482 rows went to the other of two tied lists).  assign, find_partitions, the
+    batched flat filters (d = 128: flat_mfma.hip; d = 256: flat_mfma_wide.hip) against the oracle."""
+    rng = np.random.default_rng(25)
+    for d, nq in ((128, 700), (256, 700)):
+        x = (rng.standard_normal((30000, d)) * 1.1e-3).astype(dtype)
+        q = (rng.standard_normal((nq, d)) * 1.1e-3).astype(dtype)
+        cent = x[rng.choice(len(x), 64, replace=False)].copy()
+        gi, gd = eng.assign(x, cent, "dot")
+        oi, od = oracle.assign(x, cent, "dot")
+        assert (_np(gi).view(np.uint32) == oi).all(), f"assign: {int((_np(gi).view(np.uint32) != oi).sum())} rows differ (d={d} {dtype})"
+        assert (_np(gd).view(np.uint32) == od.view(np.uint32)).all()
+        gp, gpd = eng.find_partitions(q, cent, 10, "dot")
+        op, opd = oracle.find_partitions(q, cent, 10, "dot")
+        assert (_np(gpd).view(np.uint32) == opd.view(np.uint32)).all(), f"find_partitions distances (d={d} {dtype})"
+        # equal distances may come in any order of partitions (the reference's partial sort is unstable): compare the SETS per distance value
+        same = np.sort(_np(gp).astype(np.int64) + (_np(gpd).view(np.uint32).astype(np.int64) << 20), axis=1) == \
+               np.sort(op.astype(np.int64) + (opd.view(np.uint32).astype(np.int64) << 20), axis=1)
+        assert same.all(), f"find_partitions ids (d={d} {dtype})"
+        fi, fd = eng.flat_topk(x, q, 10, "dot")
+        ofi, ofd = oracle.flat_knn(x, q, 10, "dot")
+        assert (_np(fi).view(np.uint64) == ofi).all(), f"flat ids: {int((_np(fi).view(np.uint64) != ofi).any(axis=1).sum())} queries differ (d={d} {dtype})"
+        assert (_np(fd).view(np.uint32) == ofd.view(np.uint32)).all()
