@@ -101,6 +101,8 @@ struct lance_hip_ctx {
   void *scratch_exact(const char *name, size_t bytes);   // no headroom; nullptr (no error set) when the device cannot give it
   void scratch_release(const char *name);      // gives a slot back (large one-call buffers); the caller has synchronised the stream
   void *host_staging(size_t bytes);
+  uint32_t *host_flags = nullptr;      // 64 pinned bytes: status words kernels leave for the host (read after a stream wait: no copy kernel)
+  uint32_t *host_flag_word();          // nullptr on failure (error set)
   template <typename T>
   T *scratch_t(const char *name, size_t count) {
     return reinterpret_cast<T *>(scratch(name, count * sizeof(T)));

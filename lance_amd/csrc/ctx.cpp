@@ -93,6 +93,18 @@ void *lance_hip_ctx::host_staging(size_t bytes) {
   return pinned;
 }
 
+uint32_t *lance_hip_ctx::host_flag_word() {
+  if (host_flags) return host_flags;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) {
+    lh::set_error("hipHostMalloc(64) for the host status words failed");
+    return nullptr;
+  }
+  host_flags = static_cast<uint32_t *>(p);
+  host_flags[0] = 0;
+  return host_flags;
+}
+
 void lance_hip_ctx::time_begin(const char *kernel) {
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -146,6 +158,7 @@ void lance_hip_ctx_destroy(lance_hip_ctx *ctx) {
   ctx->drop_graphs();
   for (auto &kv : ctx->slots) (void)hipFree(kv.second.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
   for (auto &kv : ctx->timers)
     for (auto &ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

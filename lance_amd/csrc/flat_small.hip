@@ -35,6 +35,9 @@ namespace lh {
 constexpr int FS_BS = 256;       // 16 row groups of 16 lanes
 constexpr int FS_CAP = 1024;     // list entries per query and workgroup
 constexpr int FS_RPI = 8;        // rows per group between two capacity checks
+#ifndef FS_UNROLL_R
+#define FS_UNROLL_R 2         // rows of a group in flight (x 16-lane chunk loads each)
+#endif
 constexpr int FS_MAXQ = 4;       // instantiated; flat_small_supported() decides how many queries take this path
 
 struct FsArgs {
@@ -46,6 +49,7 @@ struct FsArgs {
   uint32_t *lkeys;               // [nq][G][k]
   uint64_t *lrids;
   uint32_t *overflow;
+  uint32_t *host_flag = nullptr; // one query: pinned host word the merge kernel leaves the overflow flag in (it also clears `overflow` for the next call)
 };
 
 template <int METRIC, typename TX, int NQ>
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(FS_BS) void flat_small_scan_kernel(FsArgs a) {
     uint32_t T[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) T[qi] = misc[qi * 4 + 1];
-#pragma unroll 2
+#pragma unroll FS_UNROLL_R
     for (int r = 0; r < FS_RPI; ++r) {
       const int64_t row = base + r * 16 + g16;
       const bool valid = row < r_end;
@@ -181,7 +185,45 @@ __global__ __launch_bounds__(FS_BS) void flat_small_merge_kernel(FsArgs a, uint6
   if (threadIdx.x == 0) { misc[0] = 0; misc[1] = 0xFFFFFFFFu; misc[3] = 0; }
   __syncthreads();
   CandBuf b{ckey, cpos, &misc[0], &misc[1]};
-  for (int64_t base = 0; base < total; base += FS_BS) {
+  // Two parallel passes instead of total / 256 barrier-separated steps (round 6: the step loop below was 31 us of C1's 0.169 ms per
+  // query at k = 10 -- G x k = 10,240 pairs -- and 192 us at k = 100): every lane takes the minimum key of its strided share of the
+  // pairs, T = the k-th smallest lane minimum (k different pairs lie at or under it, so the k-th pair's key is <= T; an empty slot's
+  // key ~0 is the minimum's identity), and the pairs at or under T -- little more than k of them unless keys tie in masses -- go to
+  // the list.  A list that does not hold them is started again by the step loop, which tightens as it goes.
+  {
+    // (16-byte loads, sixteen in flight per lane: the pairs were written by workgroups of every XCD, so each first touch is a trip
+    // to memory, and a single workgroup hides those only by having all of them on the way at once)
+    const bool vec = (reinterpret_cast<uintptr_t>(lk) & 15) == 0;
+    const int64_t nch = vec ? total >> 2 : 0;
+    const uint4 *lk4 = reinterpret_cast<const uint4 *>(lk);
+    uint32_t mymin = 0xFFFFFFFFu;
+#pragma unroll 16
+    for (int64_t c = threadIdx.x; c < nch; c += FS_BS) {
+      const uint4 v = lk4[c];
+      mymin = min(mymin, min(min(v.x, v.y), min(v.z, v.w)));
+    }
+    for (int64_t i = nch * 4 + threadIdx.x; i < total; i += FS_BS) mymin = min(mymin, lk[i]);
+    kth_smallest_bs<FS_BS>(mymin, a.k - 1, sorted, &misc[2]);
+    const uint32_t T = misc[2];
+    auto take = [&](uint32_t key, int64_t i) {
+      if (key <= T && (key != 0xFFFFFFFFu || lr[i] != ~0ull)) {      // empty slots never enter
+        const uint32_t slot = atomicAdd(&misc[0], 1u);
+        if (slot < (uint32_t)FS_CAP) { ckey[slot] = key; cpos[slot] = (uint32_t)i; }
+      }
+    };
+#pragma unroll 4
+    for (int64_t c = threadIdx.x; c < nch; c += FS_BS) {
+      const uint4 v = lk4[c];
+      if (min(min(v.x, v.y), min(v.z, v.w)) <= T) { take(v.x, 4 * c); take(v.y, 4 * c + 1); take(v.z, 4 * c + 2); take(v.w, 4 * c + 3); }
+    }
+    for (int64_t i = nch * 4 + threadIdx.x; i < total; i += FS_BS) take(lk[i], i);
+    __syncthreads();
+  }
+  const bool refill = misc[0] > (uint32_t)FS_CAP;      // (uniform)
+  __syncthreads();
+  if (refill && threadIdx.x == 0) misc[0] = 0;
+  __syncthreads();
+  for (int64_t base = 0; refill && base < total; base += FS_BS) {
     const bool need = misc[0] > (uint32_t)(FS_CAP - FS_BS);
     __syncthreads();
     if (need) tighten_bs<FS_BS, FS_CAP>(b, a.k, sorted, &misc[2]);
@@ -219,6 +261,11 @@ __global__ __launch_bounds__(FS_BS) void flat_small_merge_kernel(FsArgs a, uint6
     out_ids[(int64_t)qi * a.k + i] = ok ? srid[i] : ~0ull;
     out_dists[(int64_t)qi * a.k + i] = ok ? key_to_float(ckey[i]) : INFINITY;
   }
+  if (a.host_flag && threadIdx.x == 0) {      // one query = one workgroup: nobody else touches the flag any more (its own atomicOr above was this thread's)
+    const uint32_t o = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.host_flag, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 bool flat_small_supported(int metric, int dtype, uint32_t d, uint32_t nq, uint32_t k, uint64_t n) {
@@ -250,15 +297,29 @@ int flat_topk_small(lance_hip_ctx *ctx, int metric, int dtype, const void *x, co
   FsArgs a;
   a.x = x; a.row_ids = row_ids; a.n = (int64_t)n; a.d = (int)d; a.nq = (int)nq; a.k = (int)k; a.q = q;
   const uint64_t step = 16 * FS_RPI;
-  uint64_t G = std::min<uint64_t>((uint64_t)ctx->num_cus * 4, std::max<uint64_t>(1, cdiv(n, 4 * step)));
+  static const int wgs_per_cu = getenv("LANCE_HIP_FS_WGS_PER_CU") ? std::max(1, atoi(getenv("LANCE_HIP_FS_WGS_PER_CU"))) : 4;      // A/B
+  uint64_t G = std::min<uint64_t>((uint64_t)ctx->num_cus * wgs_per_cu, std::max<uint64_t>(1, cdiv(n, 4 * step)));
   a.rows_per_wg = (int64_t)(cdiv(cdiv(n, G), step) * step);
   G = cdiv(n, (uint64_t)a.rows_per_wg);
   a.G = (int)G;
   a.lkeys = ctx->scratch_t<uint32_t>("fs.lkeys", (size_t)nq * G * k);
   a.lrids = ctx->scratch_t<uint64_t>("fs.lrids", (size_t)nq * G * k);
-  a.overflow = ctx->scratch_t<uint32_t>("fs.ovf", 1);
+  // One query (the latency case): the merge kernel leaves the flag in a pinned host word and clears the device word behind itself, so
+  // the call is two launches and a stream wait -- no fill kernel in front, no copy kernel behind (2 + 4 us of kernels and their
+  // launch gaps, r06zzm).  The device word of that protocol has a slot of its own, zeroed when it is made.
+  static const bool no_host_flag = getenv("LANCE_HIP_NO_FLAT_HOST_FLAG") != nullptr;
+  const bool host_flag = nq == 1 && !no_host_flag;
+  if (host_flag) {
+    const bool fresh = ctx->slots.find("fs.ovf1") == ctx->slots.end();
+    a.overflow = ctx->scratch_t<uint32_t>("fs.ovf1", 1);
+    a.host_flag = ctx->host_flag_word();
+    if (!a.host_flag) return LANCE_HIP_ENOMEM;
+    if (a.overflow && fresh) LH_CHECK_HIP(lh::memset_async(a.overflow, 0, 4, ctx->stream));
+  } else {
+    a.overflow = ctx->scratch_t<uint32_t>("fs.ovf", 1);
+  }
   if (!a.lkeys || !a.lrids || !a.overflow) return LANCE_HIP_ENOMEM;
-  LH_CHECK_HIP(lh::memset_async(a.overflow, 0, 4, ctx->stream));
+  if (!host_flag) LH_CHECK_HIP(lh::memset_async(a.overflow, 0, 4, ctx->stream));
   const size_t lds_fixed = (size_t)FS_CAP * 8 + (size_t)FS_BS * 4 + (size_t)FS_MAXQ * 16;
   {
     ScopedTimer t(ctx, "flat_scan");
@@ -274,8 +335,13 @@ int flat_topk_small(lance_hip_ctx *ctx, int metric, int dtype, const void *x, co
   }
   LH_CHECK_HIP(hipGetLastError());
   uint32_t ovf = 0;
-  LH_CHECK_HIP(hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-  LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (host_flag) {
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ovf = *static_cast<volatile uint32_t *>(a.host_flag);
+  } else {
+    LH_CHECK_HIP(hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
   *done = ovf == 0;
   return LANCE_HIP_OK;
 }
