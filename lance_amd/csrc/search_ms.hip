@@ -410,7 +410,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   __shared__ __attribute__((aligned(16))) uint32_t sPair[MS3_PB];
   __shared__ __attribute__((aligned(8))) uint2 sQ[16][2][MS_QH + 1];      // per wave: two halves (fill one while the other's atomics are in flight)
   __shared__ uint32_t s_slice, s_chunk;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (scalar: the queue's base address stays out of the VGPRs)
   const int j = lane & 31, g = lane >> 5;
   const uint32_t nslices = p.slice_start[p.nlist];
 
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   uint32_t qn = 0;      // wave-uniform: entries in the half being filled
   uint32_t pd_n = 0, pd_base = 0;      // wave-uniform: entries of the other half in flight (this lane's slot in pd_k), their chunk's first position
   uint32_t pd_k = 0;
+  float ncn2v = 0.0f;   // minus |c^|^2 of the lane's row in the current chunk (flush_begin finishes the survivors' values with it)
   long long pc_t0 = 0, pc_stage = 0, pc_gather = 0, pc_tiles = 0, pc_flush = 0, pct = 0, pc_nchunk = 0;      // PROF: s_memtime stamps
   if constexpr (PROF) { pc_t0 = clock64(); pct = pc_t0; }
   // Flush in two steps, one queue half apart: flush_begin requests a segment slot per entry of the full half (atomicAdd, nothing waits)
@@ -442,9 +443,19 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
   };
   auto flush_begin = [&](uint32_t pos_base) {      // (after flush_end)
     pd_k = 0xFFFFFFFFu;
-    if ((uint32_t)lane < qn && !(MS_DBG(p) & 1)) {
-      const uint2 ent = qw[cur + (uint32_t)lane];
-      if (row_allowed(p.allow, pos_base + (ent.x & 255u))) pd_k = atomicAdd(&p.seg_cnt[sPair[ent.x >> 8]], 1u);
+    // The tile loop leaves RAW entries: x = (tile << 10) | (accumulator register << 6) | lane, y = the accumulator itself.  Here, with all
+    // lanes busy and once per 64 survivors, they become {(pair slot << 8) | row, acc + |c^|^2}: the survivor branch -- executed with one
+    // or two lanes active, ~6 times per tile -- no longer assembles slot and row from the lane number nor forms the value (round 6,
+    // second half: 14 -> 9 VALU instructions per nonzero compare mask).  Row j's |c^|^2 sits in lane j of this chunk.
+    {
+      const uint2 raw = qw[cur + (uint32_t)lane];
+      const uint32_t ln_e = raw.x & 63u, vv = (raw.x >> 6) & 15u, jbb = raw.x >> 10;
+      const float nv = __shfl(ncn2v, (int)(ln_e & 31u), 64);
+      const uint2 ent = make_uint2(((jbb * 32u + 4u * (ln_e >> 5) + (vv & 3u) + 8u * (vv >> 2)) << 8) | (ln_e & 31u), __float_as_uint(__uint_as_float(raw.y) - nv));
+      if ((uint32_t)lane < qn && !(MS_DBG(p) & 1)) {
+        qw[cur + (uint32_t)lane] = ent;
+        if (row_allowed(p.allow, pos_base + (ent.x & 255u))) pd_k = atomicAdd(&p.seg_cnt[sPair[ent.x >> 8]], 1u);
+      }
     }
     pd_n = qn; pd_base = pos_base; qn = 0;
     cur = (uint32_t)(MS_QH + 1) - cur;
@@ -495,7 +506,6 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
 
       // the f16 reconstruction of the wave's 32 rows as the MFMA's B operand (lane (j, g): row j, k-slice g), |c^|^2 of row j
       ms_h8 rw[KS];
-      float ncn2v;
       {
         const int rowc = min(row0 + j, row_end - 1);
         uint32_t cw[M / 4];
@@ -590,10 +600,13 @@ __global__ __launch_bounds__(1024, 4) void ivfpq_mscan_kernel(MscanArgs p) {
             const uint32_t idx = min(qraw + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk[v] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk[v], 0u)),
                                      (uint32_t)MS_QH);      // entry MS_QH: the bin of a burst
             if (acc[v] <= ncn2v) {     // (the same compare: the compiler reuses its lane mask as the exec mask)
+#ifdef MS_LN_RECOMPUTE
               uint32_t ln;            // lane number, recomputed here (two VALU operations, no register held across the loop)
               asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-              const uint32_t ebase = ((uint32_t)jb << 13) + (((ln >> 5) << 10) | (ln & 31u));      // ((jb * 32 + 4 g) << 8) | j
-              qw[cur + idx] = make_uint2(ebase + ((uint32_t)((v & 3) + 8 * (v >> 2)) << 8), __float_as_uint(acc[v] - ncn2v));
+#else
+              const uint32_t ln = (uint32_t)lane;
+#endif
+              qw[cur + idx] = make_uint2((((uint32_t)jb << 10) | (uint32_t)(v << 6)) | ln, __float_as_uint(acc[v]));      // raw: flush_begin decodes
             }
             qraw += (uint32_t)__popcll(mk[v]);
           }
