@@ -615,7 +615,11 @@ static int ivfpq_scan_merge_q(lance_hip_ctx *ctx, const lance_hip_index *ix, con
   // segments 5,311 -> 2,852 with two), centred rows 1.150 / 0.911 / 0.900 / 0.910, SIFT-like rows as they are (largest list 82,424 of 10^6 rows) 3.94 / 2.29 /
   // 1.88 against 3.46 on the exact pair scan.  LANCE_HIP_DOT_BOUND_LISTS: A/B
   static const uint32_t dot_nb_env = getenv("LANCE_HIP_DOT_BOUND_LISTS") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_DOT_BOUND_LISTS"))) : 3u;
-  const uint32_t nb0 = ix->metric == LANCE_HIP_DOT ? std::min<uint32_t>(std::min<uint32_t>(dot_nb_env, 4u), nprobes) : 1u;
+  // L2 / cosine: LANCE_HIP_BOUND_LISTS = 2 .. 4 is an A/B switch (one list by default); only batches whose bound pass runs on the matrix cores take it
+  static const uint32_t l2_nb_env = getenv("LANCE_HIP_BOUND_LISTS") ? (uint32_t)std::max(1, atoi(getenv("LANCE_HIP_BOUND_LISTS"))) : 1u;
+  static const bool no_msbound_env = getenv("LANCE_HIP_NO_MSBOUND") != nullptr || getenv("LANCE_HIP_EXACT_BOUND") != nullptr;
+  const uint32_t l2_nb = (!no_msbound_env && l2_nb_env > 1 && mscan_supported(ix, nq, nprobes) && qscan_pt_mode(ix) != 2) ? l2_nb_env : 1u;
+  const uint32_t nb0 = std::min<uint32_t>(std::min<uint32_t>(ix->metric == LANCE_HIP_DOT ? dot_nb_env : l2_nb, 4u), nprobes);
   const uint32_t max_items0 = (uint32_t)((size_t)nq * nb0 / 2 + nlist + 2);
   uint32_t *pair_idx0 = ctx->scratch_t<uint32_t>("q.pair_idx0", (size_t)nq * nb0);
   uint32_t *item_start0 = ctx->scratch_t<uint32_t>("q.item_start0", (size_t)nlist + 1);

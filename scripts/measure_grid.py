@@ -66,9 +66,9 @@ def main():
         # roofline objects in bench.py's schema (flat scan = N*d*s bytes per batch, 2*N*d flops per query)
         t1, t10k = flat["1"]["ms"] * 1e-3, flat["10000"]["ms"] * 1e-3
         out["c1_roofline_single_query"] = {
-            "kernel": "flat_filter_kernel<128,L2> + flat_select_kernel (one query: every row read once)", "bound": "hbm",
+            "kernel": "flat_small_scan_kernel<L2,f32,1> + flat_small_merge_kernel (one query: every row read once; flat_small.hip)", "bound": "hbm",
             "achieved": x.numel() * 4 / t1 / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": x.numel() * 4 / t1 / 1e9 / 8000.0, "traffic": None,
-            "note": "latency-bound at one query: 3 epochs + select kernels; algorithmic bytes = N*d*4"}
+            "note": "wall time of one synchronous call through the Python binding (two launches + a stream wait); the scan kernel alone streams the rows at ~5.3 TB/s (profiles/r06zzo_flat_one_kernel_stats.csv); algorithmic bytes = N*d*4"}
         out["c1_roofline_batch_10k"] = {
             "kernel": "flat_filter_mfma_kernel<KS=8,L2,f32> (+ flat_mfma_eval_kernel, flat_select_kernel)", "bound": "mfma",
             "achieved": 2.0 * x.shape[0] * d * 10_000 / t10k / 1e12, "peak": 2500.0, "unit": "TFLOP/s (algorithmic 2*N*d per query; dense bf16 peak)",
