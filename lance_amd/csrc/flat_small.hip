@@ -16,9 +16,13 @@
 //     smallest of the lane minima (pm_common.cuh) -- it is always the k-th key of a SUBSET of the slice, never below the slice's
 //     true k-th key, so no row of the answer is filtered;
 //   * every workgroup leaves its k best (key, rowid) pairs; a second small kernel merges the G x k pairs per query in the
-//     SortExec order (a total order: ties by row id, as the reference's final sort).
+//     SortExec order (a total order: ties by row id, as the reference's final sort) -- two parallel passes since round 6
+//     (lane minima -> their k-th smallest -> the pairs at or under it), the barrier-separated step loop only as the refill.
 // More rows tied at a threshold than the list holds (thousands of duplicate vectors) raise a flag and the caller takes the
-// batch path, which repairs such cases.
+// batch path, which repairs such cases.  For one query the flag reaches the host through a pinned word the merge kernel
+// writes (and it clears the device word behind itself): a call is two launches and a stream wait.
+// C1 (1M x 128 f32, k = 10): 0.140 ms per call, of which the scan kernel 96 us (5.3 TB/s) and the merge 16 us
+// (profiles/r06zzo_flat_one_*).
 #include <algorithm>
 #include <cstdlib>
 
