@@ -72,6 +72,24 @@ def test_row_ids_nan_rows_and_mass_duplicates(eng, oracle):
     _check(eng, oracle, x[:4100], q, 128, "l2", tag="short table")
 
 
+def test_merge_refill_and_flag_word_reset(eng, oracle):
+    """Round 6: the merge kernel's two parallel passes hand over to its step loop when more pairs lie at or under the k-th smallest lane
+    minimum than the list holds (here: tens of thousands of identical rows spread over every workgroup's slice, k = 128, so nearly all
+    G x k pairs tie), the step loop raises the flag, the call takes the batch path -- and the NEXT single-query call must find the
+    device flag word cleared (the merge kernel clears it behind itself: there is no fill kernel in front of the scan any more)."""
+    rng = np.random.default_rng(23)
+    n, d = 60_000, 16
+    x = np.rint(rng.uniform(0, 40, (n, d))).astype(f32)
+    dup = rng.permutation(n)[:40_000]
+    x[dup] = x[3]
+    q = x[[3]].copy()
+    _check(eng, oracle, x, q, 128, "l2", tag="ties in every slice, k = 128")
+    _check(eng, oracle, x, q + 0.5, 10, "l2", tag="after an overflowed call")
+    y = np.rint(rng.uniform(0, 40, (n, d))).astype(f32)
+    for k in (1, 10, 100):
+        _check(eng, oracle, y, y[[17]] + 0.25, k, "dot", tag=("clean table after an overflowed call", k))
+
+
 def test_two_to_four_queries_on_the_single_pass_kernel():
     """By default only single queries take flat_small.hip (the batch path is faster from two queries on); LANCE_HIP_FLAT_SMALL_MAXQ=4
     (read once per process) sends two to four there as well: the cases above again in a child process with the switch set."""
@@ -82,7 +100,7 @@ def test_two_to_four_queries_on_the_single_pass_kernel():
         pytest.skip("already inside the child run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "small_batches or native or row_ids"], cwd=root, env=dict(os.environ, LANCE_HIP_FLAT_SMALL_MAXQ="4"),
+                        "-k", "small_batches or native or row_ids or refill"], cwd=root, env=dict(os.environ, LANCE_HIP_FLAT_SMALL_MAXQ="4"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
