@@ -260,7 +260,11 @@ __global__ __launch_bounds__(256) void ms_prep_kernel(MsPrepArgs p) {
 #define LH_MS3_PB 512
 #endif
 constexpr int MS3_PB = LH_MS3_PB;   // pairs resident in LDS (128 KiB at d = 128); -DLH_MS3_PB=256: a variant build (scripts/build_variant.sh) for A/B runs
-constexpr int MS3_RS = 2048;        // rows per slice (64 chunks of 32 for sixteen waves): the block's DMA + two barriers + the wait for the slowest wave are paid per slice
+constexpr int MS3_RS = 3072;        // rows per slice (96 chunks of 32 for sixteen waves): the block's DMA + two barriers + the wait for the slowest wave are paid per slice.
+                                    // 2048 until the end of round 6; on the kernel with the halved survivor branch 3072 is ahead on every batch shape tried (C2 bench:
+                                    // scan 0.166 -> 0.155 ms, 24.7 -> 25.1 M q/s; nprobes 25, 4,000-query batches, 2M rows: +0.7 .. +2.3 %; 1024 / 1536 / 2560 / 2816 /
+                                    // 3328 / 3584 / 4096 / 6144 / 8192 measured beside it: gpurun r06zzx, r06zzy).  Lists of ~3,900 rows become a 3,072-row slice and a
+                                    // small one, and the small ones fill the largest-first schedule's tail.
 static int ms_rows_per_slice() {    // LANCE_HIP_MS_RS: A/B of the slice height (multiple of 64)
   static const int v = [] { const char *e = getenv("LANCE_HIP_MS_RS"); const int x = e ? atoi(e) : MS3_RS; return x >= 64 ? (x / 64) * 64 : MS3_RS; }();
   return v;
