@@ -269,7 +269,19 @@ static int ms_rows_per_slice() {    // LANCE_HIP_MS_RS: A/B of the slice height 
   static const int v = [] { const char *e = getenv("LANCE_HIP_MS_RS"); const int x = e ? atoi(e) : MS3_RS; return x >= 64 ? (x / 64) * 64 : MS3_RS; }();
   return v;
 }
+// LANCE_HIP_MS_RS2: height of a partition's slices AFTER its first one (multiple of 64; default: the same height).  Smaller later slices
+// give the largest-first schedule more small jobs for its tail.
+static int ms_rows_per_slice2() {
+  static const int v = [] { const char *e = getenv("LANCE_HIP_MS_RS2"); const int x = e ? atoi(e) : 0; return x >= 64 ? (x / 64) * 64 : ms_rows_per_slice(); }();
+  return v;
+}
 struct MsSlice { uint32_t off, np, row_begin, row_count, gs, qp, pad0, pad1; };
+// row slice `rs` of a partition of np rows: the first one of rs1 rows, the following ones of rs2
+__host__ __device__ __forceinline__ uint32_t ms_nrs(uint32_t np, uint32_t rs1, uint32_t rs2) { return np <= rs1 ? (np ? 1u : 0u) : 1u + (np - rs1 + rs2 - 1u) / rs2; }
+__device__ __forceinline__ uint32_t ms_row_begin(uint32_t rs, uint32_t rs1, uint32_t rs2) { return rs ? rs1 + (rs - 1u) * rs2 : 0u; }
+__device__ __forceinline__ uint32_t ms_row_count(uint32_t rs, uint32_t np, uint32_t rs1, uint32_t rs2) {
+  return rs ? min(rs2, np - ms_row_begin(rs, rs1, rs2)) : min(rs1, np);
+}
 
 // slice_start[p] = exclusive scan of (pair blocks of partition p) x (row slices of partition p); cls_cursor[c] = first position, in the
 // largest-first order, of work class c (rows x pairs in 32 classes, class 0 the largest).  The persistent workgroups take slices from a
@@ -280,16 +292,16 @@ __device__ __forceinline__ uint32_t ms_work_class(uint32_t rows, uint32_t pairs,
   return 31u - (uint32_t)min<uint64_t>(31u, w * 32u / ((uint64_t)rs_rows * MS3_PB));
 }
 struct MsSplit { uint32_t npb, blk, nrs; };
-__device__ __forceinline__ MsSplit ms_split(uint32_t qp, uint32_t np, uint32_t rs_rows) {
+__device__ __forceinline__ MsSplit ms_split(uint32_t qp, uint32_t np, uint32_t rs_rows, uint32_t rs2_rows) {
   MsSplit r;
   r.npb = (qp + MS3_PB - 1) / MS3_PB;
   r.blk = r.npb ? ((((qp + r.npb - 1) / r.npb) + 31u) & ~31u) : 0u;      // equal pair blocks, whole tiles of 32 (<= MS3_PB)
-  r.nrs = (np + rs_rows - 1) / rs_rows;
+  r.nrs = ms_nrs(np, rs_rows, rs2_rows);
   return r;
 }
 
 __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__restrict__ pair_starts, const uint32_t *__restrict__ part_offsets, int nlist,
-                                                             uint32_t rs_rows, uint32_t cls_rows, uint32_t *__restrict__ slice_start,
+                                                             uint32_t rs_rows, uint32_t rs2_rows, uint32_t cls_rows, uint32_t *__restrict__ slice_start,
                                                              uint32_t *__restrict__ slice_ctr, uint32_t *__restrict__ cls_cursor) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry_s;
@@ -303,13 +315,14 @@ __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__r
     uint32_t v = 0;
     if (i < nlist) {
       const uint32_t qp = pair_starts[i + 1] - pair_starts[i], np = part_offsets[i + 1] - part_offsets[i];
-      const MsSplit sp = ms_split(qp, np, rs_rows);
+      const MsSplit sp = ms_split(qp, np, rs_rows, rs2_rows);
       v = sp.npb * sp.nrs;
-      // at most four distinct (rows, pairs) shapes per partition: full / last row slice x full / last pair block
+      // at most six distinct (rows, pairs) shapes per partition: first / middle / last row slice x full / last pair block
       for (uint32_t pb = 0; pb < sp.npb; pb += max(1u, sp.npb - 1u)) {
         const uint32_t pairs = min(sp.blk, qp - pb * sp.blk), npb_same = (pb + 1 == sp.npb) ? 1u : sp.npb - 1u;
-        if (sp.nrs > 1) atomicAdd(&hist[ms_work_class(rs_rows, pairs, cls_rows)], npb_same * (sp.nrs - 1u));
-        if (sp.nrs > 0) atomicAdd(&hist[ms_work_class(np - (sp.nrs - 1u) * rs_rows, pairs, cls_rows)], npb_same);
+        if (sp.nrs > 0) atomicAdd(&hist[ms_work_class(ms_row_count(0u, np, rs_rows, rs2_rows), pairs, cls_rows)], npb_same);
+        if (sp.nrs > 2) atomicAdd(&hist[ms_work_class(rs2_rows, pairs, cls_rows)], npb_same * (sp.nrs - 2u));
+        if (sp.nrs > 1) atomicAdd(&hist[ms_work_class(ms_row_count(sp.nrs - 1u, np, rs_rows, rs2_rows), pairs, cls_rows)], npb_same);
         if (sp.npb == 1) break;
       }
     }
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256) void ms_slice_table_kernel(const uint32_t *__r
 }
 
 __global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__restrict__ slice_start, const uint32_t *__restrict__ pair_starts,
-                                                            const uint32_t *__restrict__ part_offsets, int nlist, uint32_t rs_rows, uint32_t cls_rows,
+                                                            const uint32_t *__restrict__ part_offsets, int nlist, uint32_t rs_rows, uint32_t rs2_rows, uint32_t cls_rows,
                                                             MsSlice *__restrict__ slices, uint32_t *__restrict__ cls_cursor, uint32_t *__restrict__ order) {
   const int part = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (part >= nlist) return;
@@ -345,12 +358,12 @@ __global__ __launch_bounds__(256) void ms_slice_desc_kernel(const uint32_t *__re
   if (s1 == s0) return;
   const uint32_t off = part_offsets[part], np = part_offsets[part + 1] - off;
   const uint32_t gs = pair_starts[part], qp = pair_starts[part + 1] - gs;
-  const MsSplit sp = ms_split(qp, np, rs_rows);
+  const MsSplit sp = ms_split(qp, np, rs_rows, rs2_rows);
   // row slices vary fastest: the slices of one pair block are taken by different CUs at about the same time (its residuals come from L2)
   for (uint32_t t = (uint32_t)lane; t < s1 - s0; t += 64u) {
     const uint32_t pb = t / sp.nrs, rs = t - pb * sp.nrs;
     MsSlice u;
-    u.off = off; u.np = np; u.row_begin = rs * rs_rows; u.row_count = min(rs_rows, np - u.row_begin);
+    u.off = off; u.np = np; u.row_begin = ms_row_begin(rs, rs_rows, rs2_rows); u.row_count = ms_row_count(rs, np, rs_rows, rs2_rows);
     u.gs = gs + pb * sp.blk; u.qp = min(sp.blk, qp - pb * sp.blk); u.pad0 = u.pad1 = 0u;
     slices[s0 + t] = u;
     // the slice's place in the largest-first order (inside a class: whatever the atomics give -- only the schedule depends on it)
@@ -1035,7 +1048,7 @@ static int mscan_prepare(lance_hip_ctx *ctx, lance_hip_index *ix) {
     (void)lh::memset_async(mc->row_cn2, 0, (size_t)ix->n * 4, ctx->stream);
   }
   for (uint32_t pid = 0; pid < ix->nlist; ++pid) {
-    const uint32_t rs = (uint32_t)cdiv((uint64_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), (uint64_t)ms_rows_per_slice());
+    const uint32_t rs = ms_nrs((uint32_t)(ix->part_offsets_h[pid + 1] - ix->part_offsets_h[pid]), (uint32_t)ms_rows_per_slice(), (uint32_t)ms_rows_per_slice2());
     mc->sum_rs += rs; mc->max_rs = std::max(mc->max_rs, rs);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {   // other contexts (streams) search the same index
@@ -1090,13 +1103,13 @@ int mscan_launch(lance_hip_ctx *ctx, const lance_hip_index *ix_c, const float *q
     pa.nan_slot = nan_slot; pa.prm2 = prm2;
     pa.dot = ix->metric == LANCE_HIP_DOT ? 1 : 0; pa.cmax = ix->ms->cmax; pa.cmax_full = ix->ms->cmax_full; pa.cmaxp = ix->ms->cmaxp; pa.mu = ix->cb_mean; pa.m = (int)ix->m;
     hipLaunchKernelGGL(ms_prep_kernel, dim3((unsigned)cdiv(npairs, 4 * MS_PPW)), dim3(256), 0, ctx->stream, pa);
-    const uint32_t rs_rows = (uint32_t)ms_rows_per_slice();
+    const uint32_t rs_rows = (uint32_t)ms_rows_per_slice(), rs2_rows = (uint32_t)ms_rows_per_slice2();
     static const bool no_order = getenv("LANCE_HIP_MS_NOORDER") != nullptr;      // A/B: one work class = slices in (roughly) index order
     const uint32_t cls_rows = no_order ? 0x40000000u : rs_rows;
-    hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, rs_rows, cls_rows, slice_start,
+    hipLaunchKernelGGL(ms_slice_table_kernel, dim3(1), dim3(256), 0, ctx->stream, pair_starts, ix->part_offsets, nlist, rs_rows, rs2_rows, cls_rows, slice_start,
                        slice_ctr, cls_cursor);
     hipLaunchKernelGGL(ms_slice_desc_kernel, dim3((unsigned)cdiv((uint64_t)nlist, 4)), dim3(256), 0, ctx->stream, slice_start, pair_starts, ix->part_offsets,
-                       nlist, rs_rows, cls_rows, slices, cls_cursor, order);
+                       nlist, rs_rows, rs2_rows, cls_rows, slices, cls_cursor, order);
   }
   ScopedTimer t(ctx, "ivfpq_scan_c1");
   ScopedTimer tm(ctx, "ivfpq_mscan");      // the same launch under its own name: tests assert the matrix-core scan was the one taken
