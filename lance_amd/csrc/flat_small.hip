@@ -110,13 +110,31 @@ __global__ __launch_bounds__(FS_BS) void flat_small_scan_kernel(FsArgs a) {
           }
         }
       }
+      if constexpr (NQ == 1) {
 #pragma unroll 8
-      for (int ch = 0; ch < full; ch += 16) {
-        const float xv = ld_elem(xr, ch + gi);
+        for (int ch = 0; ch < full; ch += 16) {
+          const float xv = ld_elem(xr, ch + gi);
+          if constexpr (METRIC == METRIC_DOT) acc[0] = acc[0] + xv * qs[ch + gi];
+          else { const float diff = xv - qs[ch + gi]; acc[0] = acc[0] + diff * diff; }
+        }
+      } else {
+        // two to four queries: the row's chunk loads are issued eight at a time BEFORE anything consumes them -- left to itself the compiler
+        // put an `s_waitcnt vmcnt(0)` behind every load of this loop (the queries' LDS reads in between), i.e. one chunk in flight per group
+        for (int ch0 = 0; ch0 < full; ch0 += 128) {
+          float xv[8];
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-          if constexpr (METRIC == METRIC_DOT) acc[qi] = acc[qi] + xv * qs[qi * dpad + ch + gi];
-          else { const float diff = xv - qs[qi * dpad + ch + gi]; acc[qi] = acc[qi] + diff * diff; }
+          for (int u = 0; u < 8; ++u) xv[u] = ch0 + 16 * u < full ? ld_elem(xr, ch0 + 16 * u + gi) : 0.0f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int ch = ch0 + 16 * u;
+            if (ch < full) {
+#pragma unroll
+              for (int qi = 0; qi < NQ; ++qi) {
+                if constexpr (METRIC == METRIC_DOT) acc[qi] = acc[qi] + xv[u] * qs[qi * dpad + ch + gi];
+                else { const float diff = xv[u] - qs[qi * dpad + ch + gi]; acc[qi] = acc[qi] + diff * diff; }
+              }
+            }
+          }
         }
       }
 #pragma unroll
@@ -274,9 +292,10 @@ __global__ __launch_bounds__(FS_BS) void flat_small_merge_kernel(FsArgs a, uint6
 
 bool flat_small_supported(int metric, int dtype, uint32_t d, uint32_t nq, uint32_t k, uint64_t n) {
   static const bool off = getenv("LANCE_HIP_NO_FLAT_SMALL") != nullptr;
-  // r04c, C1 (1M x 128 f32): one query 0.135 ms here against 0.25 ms on the batch path (wall 0.177 / 0.247); with two or more
-  // queries the batch path's lanes-own-rows kernel wins (0.13-0.15 ms of kernels for 2-4 queries) -- LANCE_HIP_FLAT_SMALL_MAXQ overrides
-  static const uint32_t maxq = getenv("LANCE_HIP_FLAT_SMALL_MAXQ") ? (uint32_t)atoi(getenv("LANCE_HIP_FLAT_SMALL_MAXQ")) : 1u;
+  // r04c, C1 (1M x 128 f32): one query 0.135 ms here against 0.25 ms on the batch path (wall 0.177 / 0.247).  Round 6 (r06zzzv), wall per
+  // call at k = 10, this kernel / the batch path: two queries 0.193 / 0.256 ms (0.328 before the scan's chunk loads were issued eight at a
+  // time), four queries 0.399 / 0.271 -- so ONE OR TWO queries come here; LANCE_HIP_FLAT_SMALL_MAXQ overrides
+  static const uint32_t maxq = getenv("LANCE_HIP_FLAT_SMALL_MAXQ") ? (uint32_t)atoi(getenv("LANCE_HIP_FLAT_SMALL_MAXQ")) : 2u;
   if (off || nq == 0 || nq > std::min<uint32_t>(maxq, (uint32_t)FS_MAXQ) || k > 128 || d == 0 || d > 2048) return false;
   if (metric != LANCE_HIP_L2 && metric != LANCE_HIP_DOT) return false;      // cosine_fast has its own arithmetic (flat.hip)
   if (dtype == LANCE_HIP_F16 && metric == LANCE_HIP_DOT && d > 16) return false;   // 32 lane accumulators (dot.rs:91-102): batch path

@@ -91,7 +91,7 @@ def test_merge_refill_and_flag_word_reset(eng, oracle):
 
 
 def test_two_to_four_queries_on_the_single_pass_kernel():
-    """By default only single queries take flat_small.hip (the batch path is faster from two queries on); LANCE_HIP_FLAT_SMALL_MAXQ=4
+    """By default one or two queries take flat_small.hip (the batch path is faster from three queries on); LANCE_HIP_FLAT_SMALL_MAXQ=4
     (read once per process) sends two to four there as well: the cases above again in a child process with the switch set."""
     import os
     import subprocess
